@@ -1,0 +1,50 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Golden:
+    """npz fixture with '/'-separated nested keys -> nested access returning torch tensors."""
+
+    def __init__(self, name):
+        self._z = np.load(os.path.join(GOLDEN, name))
+        self.keys = list(self._z.keys())
+
+    def sub(self, prefix):
+        import torch
+
+        prefix = prefix.rstrip("/") + "/"
+        out = {}
+        for k in self.keys:
+            if k.startswith(prefix):
+                rest = k[len(prefix):]
+                node = out
+                parts = rest.split("/")
+                for p in parts[:-1]:
+                    node = node.setdefault(p, {})
+                node[parts[-1]] = torch.from_numpy(self._z[k])
+        return out
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = Golden(name)
+        return cache[name]
+
+    return get

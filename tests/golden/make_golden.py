@@ -1,0 +1,399 @@
+"""Generate golden fixtures by RUNNING THE REFERENCE in this container (read-only /root/reference,
+stub-imported per SURVEY.md Appendix A).  Commit the produced *.npz / *.json; this script cannot
+run on the GPU box (the reference does not travel) and nothing in tests/, smoke() or bench.py
+imports it.
+
+    python tests/golden/make_golden.py
+
+Weights are the deterministic name-keyed tensors of oracle/detweights.py loaded into the
+reference modules with load_state_dict(strict=True); fixtures hold only inputs and the
+reference's outputs.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import _ref_import  # noqa: E402
+
+DictConfig = _ref_import.install()
+
+import datasets as ds  # noqa: E402
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+import image2layout.train.models.autoreg as ar  # noqa: E402
+import image2layout.train.models.retrieval_augmented_autoreg as raa  # noqa: E402
+from image2layout.train.fid.model import FIDNetV3  # noqa: E402
+from image2layout.train.helpers.layout_tokenizer import LayoutSequenceTokenizer  # noqa: E402
+from image2layout.train.helpers.task import get_condition  # noqa: E402
+from image2layout.train.models.common.attention import Attention, FeedForward  # noqa: E402
+from image2layout.train.models.common.positional_encoding import (  # noqa: E402
+    PositionalEncoding1d,
+    PositionEmbeddingSine,
+)
+from oracle.detweights import det_state_dict  # noqa: E402
+
+torch.set_num_threads(8)
+META = {"torch": torch.__version__, "reference": "CyberAgentAILab/RALF @ 2024_08_07"}
+
+
+THIN = 37  # big weight-gradient tensors are stored as flatten()[::THIN] to keep fixtures small
+
+
+def thin(v):
+    return v.flatten()[::THIN] if v.numel() > 20000 else v
+
+
+def npify(d, prefix=""):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.update(npify(v, prefix + k + "/"))
+        elif torch.is_tensor(v):
+            if k.startswith("g_") or prefix.endswith("grads/"):
+                v = thin(v)
+            out[prefix + k] = v.detach().cpu().numpy()
+        elif isinstance(v, np.ndarray):
+            out[prefix + k] = v
+    return out
+
+
+def save(name, d):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **npify(d))
+    print("wrote", name, os.path.getsize(path) // 1024, "KiB")
+
+
+# ----------------------------------------------------------------------------------------
+class StandInBackbone(nn.Module):
+    """Parameter-free stand-in for ResnetFeatureExtractor (timm/torchvision absent): returns a
+    tensor injected by the fixture so the fixtures are backbone-independent."""
+
+    feat = None
+
+    def __init__(self, **kw):
+        super().__init__()
+
+    def forward(self, img):
+        return StandInBackbone.feat
+
+
+def fidnet_no_ckpt(dataset_name="", num_classes=3, d_model=256, nhead=4, num_layers=4, max_seq_length=10, ckpt_dir=""):
+    m = FIDNetV3(num_label=num_classes, d_model=d_model, nhead=nhead, num_layers=num_layers, max_bbox=max_seq_length)
+    m.eval()
+    for n in ("pos_token", "dec_transformer", "fc_out_disc", "fc_out_cls", "fc_out_bbox"):
+        delattr(m, n)
+    return m
+
+
+raa.ResnetFeatureExtractor = StandInBackbone
+ar.ResnetFeatureExtractor = StandInBackbone
+raa.load_fidnet_feature_extractor = fidnet_no_ckpt
+
+LABELS = {"pku": ["text", "logo", "underlay"], "cgl": ["logo", "text", "underlay", "embellishment"]}
+
+
+def make_tokenizer(dataset="pku", N=10, num_bin=128, var_order=None, shared=False):
+    return LayoutSequenceTokenizer(
+        label_feature=ds.ClassLabel(names=LABELS[dataset]),
+        max_seq_length=N,
+        num_bin=num_bin,
+        var_order=var_order or ["label", "width", "height", "center_x", "center_y"],
+        pad_until_max=False,
+        special_tokens=["pad", "bos", "eos"],
+        is_loc_vocab_shared=shared,
+        geo_quantization="linear",
+    )
+
+
+def synth_layouts(g, lead, N, C, full_first=False):
+    """random layouts: n~U{1..N} (first sample full, second single-element)."""
+    shape = tuple(lead) + (N,)
+    n = torch.randint(1, N + 1, tuple(lead), generator=g)
+    flat_n = n.view(-1)
+    if full_first:
+        flat_n[0] = N
+        if flat_n.numel() > 1:
+            flat_n[1] = 1
+    mask = torch.arange(N).expand(shape) < n.unsqueeze(-1)
+    out = {"mask": mask, "label": torch.randint(0, C, shape, generator=g) * mask}
+    for k in ("center_x", "center_y", "width", "height"):
+        out[k] = torch.rand(shape, generator=g) * mask
+    return out
+
+
+def synth_batch(seed, B, N, K, C, hw=8):
+    g = torch.Generator().manual_seed(seed)
+    b = synth_layouts(g, (B,), N, C, full_first=True)
+    b["image"] = torch.rand(B, 3, hw, hw, generator=g)
+    b["saliency"] = torch.rand(B, 1, hw, hw, generator=g)
+    b["id"] = [str(1000 + i) for i in range(B)]
+    r = synth_layouts(g, (B, K), N, C)
+    r["image"] = torch.rand(B, K, 3, hw, hw, generator=g)
+    r["saliency"] = torch.rand(B, K, 1, hw, hw, generator=g)
+    b["retrieved"] = [r]
+    return b
+
+
+def clone_batch(b):
+    out = {}
+    for k, v in b.items():
+        if torch.is_tensor(v):
+            out[k] = v.clone()
+        elif isinstance(v, list) and v and isinstance(v[0], dict):
+            out[k] = [{kk: vv.clone() for kk, vv in v[0].items()}]
+        else:
+            out[k] = list(v)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+def golden_tokenizer():
+    out = {}
+    cfgs = [
+        ("pku_n10_b128", dict(dataset="pku", N=10, num_bin=128)),
+        ("cgl_n10_b128", dict(dataset="cgl", N=10, num_bin=128)),
+        ("pku_n5_b32_xywh_shared", dict(dataset="pku", N=5, num_bin=32, var_order=["label", "center_x", "center_y", "width", "height"], shared=True)),
+        ("cgl_n11_b16", dict(dataset="cgl", N=11, num_bin=16)),
+    ]
+    for name, kw in cfgs:
+        tok = make_tokenizer(**kw)
+        N, nb = kw["N"], kw["num_bin"]
+        C = len(LABELS[kw["dataset"]])
+        g = torch.Generator().manual_seed(7)
+        lay = synth_layouts(g, (12,), N, C, full_first=True)
+        # edge cases: values exactly on bin boundaries, out of [0,1], an empty layout
+        lay["center_x"][0, :N] = (torch.arange(N) % (nb + 1)).float() / nb
+        lay["width"][0, :N] = torch.tensor([-0.5, 1.5, 0.0, 1.0, 0.999999] * 3)[:N]
+        lay["height"][2] = lay["height"][2] * 0 + 1.0 / nb * torch.arange(N) * lay["mask"][2]
+        lay["mask"][3] = False
+        for k in ("label", "center_x", "center_y", "width", "height"):
+            lay[k][3] = 0
+        enc = tok.encode({k: v.clone() for k, v in lay.items()})
+        dec = tok.decode(enc["seq"][:, 1:].clone())
+        # decode of garbage (oov / eos in the middle)
+        gseq = torch.randint(0, tok.N_total, (6, 5 * N), generator=g)
+        gdec = tok.decode(gseq.clone())
+        out[name] = {
+            "in": lay, "enc": enc, "dec": dec, "garbage_seq": gseq, "garbage_dec": gdec,
+            # (token_mask raises for is_loc_vocab_shared=True in the reference: mismatched stack sizes)
+            "token_mask": tok.token_mask if not kw.get("shared") else torch.zeros(0),
+            "meta": {"N_total": torch.tensor(tok.N_total), "pad": torch.tensor(tok.name_to_id("pad")),
+                     "bos": torch.tensor(tok.name_to_id("bos")), "eos": torch.tensor(tok.name_to_id("eos"))},
+        }
+    save("tokenizer.npz", out)
+
+
+def golden_host_path():
+    """get_condition + task preprocessor + model.preprocess (a12) for every task without external tables."""
+    tok = make_tokenizer("pku", 10)
+    out = {}
+    for task in ["uncond", "c", "cwh", "partial", "refinement"]:
+        model = build_ralf(tok, task)
+        batch = synth_batch(11, 6, 10, 16, 3)
+        out[task] = {"batch": {k: v for k, v in batch.items() if torch.is_tensor(v)},
+                     "retrieved": {k: v for k, v in batch["retrieved"][0].items() if k not in ("image", "saliency")}}
+        torch.manual_seed(1234)
+        inputs, targets = model.preprocess(clone_batch(batch))
+        out[task]["inputs"] = {k: v for k, v in inputs.items() if torch.is_tensor(v) and k != "image"}
+        out[task]["targets"] = targets
+        # test-time condition (inference.py:389) + constraint sequence
+        torch.manual_seed(4321)
+        cond, _ = get_condition(clone_batch(batch), task, tok)
+        seqc = model.preprocessor(cond)
+        out[task]["cond"] = {"seq": cond.seq if cond.seq is not None else torch.zeros(0), "mask": cond.mask if cond.mask is not None else torch.zeros(0)}
+        out[task]["cond_const"] = seqc
+    out["meta"] = {"preproc_N_total": torch.tensor(model.preprocessor.N_total)}
+    save("host_path.npz", out)
+
+
+# ----------------------------------------------------------------------------------------
+def load_det(module, prefix=""):
+    sd = module.state_dict()
+    det = det_state_dict({prefix + k: tuple(v.shape) for k, v in sd.items()})
+    module.load_state_dict({k: det[prefix + k] for k in sd}, strict=True)
+    return {prefix + k: tuple(v.shape) for k, v in sd.items()}
+
+
+def golden_modules():
+    out = {}
+    g = torch.Generator().manual_seed(3)
+    # a6 cross-attention fuse
+    attn = Attention(256, 256, heads=8, dim_head=64, dropout=0.0).eval()
+    load_det(attn, "attn.")
+    x = torch.randn(2, 15, 256, generator=g, requires_grad=True)
+    ctx = torch.randn(2, 16, 256, generator=g, requires_grad=True)
+    y = attn(x, ctx)
+    go = torch.randn(y.shape, generator=g)
+    y.backward(go)
+    out["xattn"] = {"x": x, "ctx": ctx, "y": y, "go": go, "gx": x.grad, "gctx": ctx.grad,
+                    "g_to_q": attn.to_q.weight.grad, "g_to_kv": attn.to_kv.weight.grad, "g_norm_w": attn.norm.weight.grad}
+    # FeedForward
+    ff = FeedForward(256, 1024, dropout=0.0).eval()
+    load_det(ff, "head.")
+    x = torch.randn(2, 7, 256, generator=g, requires_grad=True)
+    y = ff(x)
+    go = torch.randn(y.shape, generator=g)
+    y.backward(go)
+    out["ff"] = {"x": x, "y": y, "go": go, "gx": x.grad, "g_w1": ff.net[1].weight.grad, "g_b2": ff.net[4].bias.grad}
+    # pre-norm encoder layer with key padding
+    enc = nn.TransformerEncoderLayer(256, 8, 1024, 0.1, batch_first=True, norm_first=True).eval()
+    load_det(enc, "transformer_encoder.layers.0.")
+    x = torch.randn(3, 9, 256, generator=g, requires_grad=True)
+    kpm = torch.tensor([[False] * 9, [False] * 5 + [True] * 4, [False] * 8 + [True]])
+    y = enc(x, src_key_padding_mask=kpm)
+    go = torch.randn(y.shape, generator=g)
+    y.backward(go)
+    out["enc_layer"] = {"x": x, "kpm": kpm, "y": y, "go": go, "gx": x.grad,
+                        "g_in_proj_w": enc.self_attn.in_proj_weight.grad, "g_in_proj_b": enc.self_attn.in_proj_bias.grad,
+                        "g_lin2_w": enc.linear2.weight.grad, "g_norm1_b": enc.norm1.bias.grad}
+    # pre-norm decoder layer, causal + padding
+    dec = nn.TransformerDecoderLayer(256, 8, 1024, batch_first=True, norm_first=True).eval()
+    load_det(dec, "decoder.transformer.layers.0.")
+    x = torch.randn(3, 10, 256, generator=g, requires_grad=True)
+    mem = torch.randn(3, 21, 256, generator=g, requires_grad=True)
+    kpm = torch.tensor([[False] * 10, [False] * 6 + [True] * 4, [False] * 1 + [True] * 9])
+    cm = nn.Transformer.generate_square_subsequent_mask(10)
+    y = dec(x, mem, tgt_mask=cm, tgt_key_padding_mask=kpm)
+    go = torch.randn(y.shape, generator=g)
+    y.backward(go)
+    out["dec_layer"] = {"x": x, "mem": mem, "kpm": kpm, "y": y, "go": go, "gx": x.grad, "gmem": mem.grad,
+                        "g_cross_in_w": dec.multihead_attn.in_proj_weight.grad, "g_self_out_w": dec.self_attn.out_proj.weight.grad}
+    # frozen layout encoder
+    fid = fidnet_no_ckpt(num_classes=3, max_seq_length=10)
+    load_det(fid, "layout_encoer.")
+    lay = synth_layouts(g, (5,), 10, 3, full_first=True)
+    with torch.no_grad():
+        f = fid.extract_features({k: v for k, v in lay.items()})
+    out["fidnet"] = {"in": lay, "feat": f}
+    # positional encodings
+    pe2 = PositionEmbeddingSine(d_model=256, normalize=True)
+    z = torch.zeros(1, 256, 3, 5)
+    out["pos2d_3x5"] = {"table": pe2(z)[0]}
+    out["pos2d_16x16"] = {"table": pe2(torch.zeros(1, 256, 16, 16))[0]}
+    pe1 = PositionalEncoding1d(d_model=256).eval()
+    xx = torch.randn(2, 6, 256, generator=g)
+    out["pe1d"] = {"x": xx, "y": pe1(xx), "pe_head": pe1.pe[0, :64]}
+    save("modules.npz", out)
+
+
+# ----------------------------------------------------------------------------------------
+def build_ralf(tok, task, top_k=16):
+    feats = ds.Features({"label": ds.Sequence(ds.ClassLabel(names=tok._label_feature.names))})
+    m = raa.ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg(
+        features=feats, tokenizer=tok, dataset_name="pku", max_seq_length=tok.max_seq_length, db_dataset=None,
+        top_k=top_k, retrieval_backbone="dreamsim", random_retrieval=False, saliency_k="None", auxilary_task=task)
+    return m
+
+
+def build_autoreg(tok, task):
+    feats = ds.Features({"label": ds.Sequence(ds.ClassLabel(names=tok._label_feature.names))})
+    return ar.ConcateAuxilaryTaskAutoreg(features=feats, tokenizer=tok, auxilary_task=task)
+
+
+GRAD_KEYS_RALF = [
+    "decoder.head.1.weight", "decoder.emb.weight", "decoder.transformer.layers.5.multihead_attn.in_proj_weight",
+    "decoder.transformer.layers.0.self_attn.in_proj_bias", "transformer_encoder.layers.0.linear1.weight",
+    "transformer_encoder.layers.5.norm2.weight", "attn.to_kv.weight", "attn.to_out.0.bias", "head.net.1.weight",
+    "layout_adapter.net.4.weight", "layout_adapter.net.0.bias", "user_const_encoder.emb.weight",
+    "user_const_encoder.encoder.layers.3.self_attn.out_proj.weight", "task_emb.weight",
+]
+
+
+def golden_e2e():
+    tok = make_tokenizer("pku", 10)
+    out = {}
+    shapes_written = False
+    for task, hw in [("uncond", (3, 5)), ("refinement", (4, 4)), ("c", (2, 3))]:
+        model = build_ralf(tok, task).eval()  # eval: dropout off (parity mode)
+        shapes = load_det(model)
+        if not shapes_written:
+            with open(os.path.join(HERE, "ralf_state_shapes.json"), "w") as f:
+                json.dump({"meta": META, "shapes": {k: list(v) for k, v in shapes.items()}}, f, indent=0)
+            shapes_written = True
+        B = 3
+        batch = synth_batch(21, B, 10, 16, 3)
+        torch.manual_seed(99)
+        inputs, targets = model.preprocess(clone_batch(batch))
+        g = torch.Generator().manual_seed(5)
+        feat = torch.randn(B, 256, *hw, generator=g).requires_grad_(True)
+        StandInBackbone.feat = feat
+        model.zero_grad()
+        outputs, losses = model.train_loss(inputs, targets)
+        losses["nll_loss"].backward()
+        named = dict(model.named_parameters())
+        rec = {
+            "feat": feat, "gfeat": feat.grad, "logits": outputs["logits"], "loss": losses["nll_loss"],
+            "inputs": {k: v for k, v in inputs.items() if torch.is_tensor(v) and k != "image"},
+            "retrieved": {k: v for k, v in inputs["retrieved"].items() if k not in ("image", "saliency")},
+            "targets": targets,
+            "grads": {k: named[k].grad for k in GRAD_KEYS_RALF},
+            "gradnorm": torch.sqrt(sum((p.grad ** 2).sum() for p in model.parameters() if p.grad is not None)),
+        }
+        out["ralf_" + task] = rec
+    # Autoreg baseline (BASELINE config 1)
+    model = build_autoreg(tok, "uncond").eval()
+    shapes = load_det(model)
+    with open(os.path.join(HERE, "autoreg_state_shapes.json"), "w") as f:
+        json.dump({"meta": META, "shapes": {k: list(v) for k, v in shapes.items()}}, f, indent=0)
+    batch = synth_batch(22, 4, 10, 16, 3)
+    batch.pop("retrieved")
+    inputs, targets = model.preprocess(clone_batch(batch))
+    g = torch.Generator().manual_seed(6)
+    feat = torch.randn(4, 256, 3, 4, generator=g).requires_grad_(True)
+    StandInBackbone.feat = feat
+    outputs, losses = model.train_loss(inputs, targets)
+    losses["nll_loss"].backward()
+    named = dict(model.named_parameters())
+    out["autoreg_uncond"] = {
+        "feat": feat, "gfeat": feat.grad, "logits": outputs["logits"], "loss": losses["nll_loss"],
+        "inputs": {k: v for k, v in inputs.items() if torch.is_tensor(v) and k != "image"}, "targets": targets,
+        "grads": {k: named[k].grad for k in ["decoder.head.1.weight", "transformer_encoder.layers.2.self_attn.in_proj_weight", "task_emb.weight"]},
+    }
+    save("e2e.npz", out)
+
+
+def golden_sample():
+    """deterministic (argmax) sample() tokens -> decoded layouts, tasks without external tables."""
+    tok = make_tokenizer("pku", 10)
+    out = {}
+    cfg = DictConfig(name="deterministic")
+    for task in ["uncond", "c", "cwh", "refinement", "partial"]:
+        model = build_ralf(tok, task).eval()
+        load_det(model)
+        B = 3
+        batch = synth_batch(31, B, 10, 16, 3)
+        torch.manual_seed(77)
+        cond, _ = get_condition(clone_batch(batch), task, tok)
+        g = torch.Generator().manual_seed(8)
+        feat = torch.randn(B, 256, 2, 3, generator=g)
+        StandInBackbone.feat = feat
+        torch.manual_seed(78)
+        with torch.no_grad():
+            enc_in, seq_constraints = model._create_encoder_inputs(cond)
+            # re-run via public API (it rebuilds encoder inputs itself; reseed for `partial` shuffling)
+            torch.manual_seed(78)
+            res, vio = model.sample(cond=cond, sampling_cfg=cfg, cond_type=task, return_violation=True, use_backtrack=False)
+        out[task] = {
+            "feat": feat,
+            "cond_seq": cond.seq if cond.seq is not None else torch.zeros(0),
+            "seq_layout_const": enc_in["seq_layout_const"], "seq_layout_const_pad_mask": enc_in["seq_layout_const_pad_mask"],
+            "retrieved": {k: v for k, v in cond.retrieved.items() if k not in ("image", "saliency")},
+            "result": res,
+            "violation": {"total": torch.tensor(float(vio["total"])), "viorated": torch.tensor(float(vio["viorated"]))},
+        }
+    save("sample.npz", out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["tokenizer", "host", "modules", "e2e", "sample"]
+    fns = {"tokenizer": golden_tokenizer, "host": golden_host_path, "modules": golden_modules, "e2e": golden_e2e, "sample": golden_sample}
+    for w in which:
+        fns[w]()

@@ -1,0 +1,133 @@
+"""Pin the oracle (oracle/ralf_oracle.py) against outputs recorded from the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import ralf_oracle as O
+from oracle.detweights import det_state_dict
+
+from conftest import GOLDEN
+
+THIN = 37
+
+
+def thin(v):
+    return v.flatten()[::THIN] if v.numel() > 20000 else v
+
+
+def shapes(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return {k: tuple(v) for k, v in json.load(f)["shapes"].items()}
+
+
+def sd_for(prefixes, all_shapes):
+    return det_state_dict({k: v for k, v in all_shapes.items() if any(k.startswith(p) for p in prefixes)})
+
+
+def close(a, b, atol=2e-5, rtol=1e-4):
+    torch.testing.assert_close(a.float(), b.float(), atol=atol, rtol=rtol)
+
+
+@pytest.fixture(scope="module")
+def ralf_sd():
+    sd = det_state_dict(shapes("ralf_state_shapes.json"))
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    return sd
+
+
+def test_positional_tables(golden):
+    g = golden("modules.npz")
+    close(O.pos2d_sine_table(3, 5, 256), g.sub("pos2d_3x5")["table"])
+    close(O.pos2d_sine_table(16, 16, 256), g.sub("pos2d_16x16")["table"])
+    p = g.sub("pe1d")
+    close(O.pe1d_table(64, 256), p["pe_head"])
+    close(O.pos_enc_1d(p["x"], O.pe1d_table(5000, 256)), p["y"])
+
+
+def test_xattn_and_ff(golden, ralf_sd):
+    g = golden("modules.npz")
+    r = g.sub("xattn")
+    x, ctx = r["x"].requires_grad_(True), r["ctx"].requires_grad_(True)
+    y = O.xattn_fuse(x, ctx, ralf_sd, "attn")
+    close(y, r["y"])
+    gx, gc, gq, gkv, gn = torch.autograd.grad(y, [x, ctx, ralf_sd["attn.to_q.weight"], ralf_sd["attn.to_kv.weight"], ralf_sd["attn.norm.weight"]], r["go"])
+    close(gx, r["gx"]); close(gc, r["gctx"]); close(thin(gq), r["g_to_q"]); close(thin(gkv), r["g_to_kv"]); close(gn, r["g_norm_w"], atol=1e-4)
+    r = g.sub("ff")
+    x = r["x"].requires_grad_(True)
+    y = O.feed_forward(x, ralf_sd, "head")
+    close(y, r["y"])
+    gx, gw1, gb2 = torch.autograd.grad(y, [x, ralf_sd["head.net.1.weight"], ralf_sd["head.net.4.bias"]], r["go"])
+    close(gx, r["gx"]); close(thin(gw1), r["g_w1"]); close(gb2, r["g_b2"], atol=1e-4)
+
+
+def test_encoder_decoder_layers(golden, ralf_sd):
+    g = golden("modules.npz")
+    r = g.sub("enc_layer")
+    x = r["x"].requires_grad_(True)
+    p = "transformer_encoder.layers.0"
+    y = O.encoder_layer_prenorm(x, ralf_sd, p, 8, O.key_padding_to_additive(r["kpm"]))
+    close(y, r["y"])
+    ws = [ralf_sd[p + ".self_attn.in_proj_weight"], ralf_sd[p + ".self_attn.in_proj_bias"], ralf_sd[p + ".linear2.weight"], ralf_sd[p + ".norm1.bias"]]
+    gs = torch.autograd.grad(y, [x] + ws, r["go"])
+    close(gs[0], r["gx"]); close(thin(gs[1]), r["g_in_proj_w"]); close(gs[2], r["g_in_proj_b"], atol=1e-4)
+    close(thin(gs[3]), r["g_lin2_w"]); close(gs[4], r["g_norm1_b"], atol=1e-4)
+    r = g.sub("dec_layer")
+    x, mem = r["x"].requires_grad_(True), r["mem"].requires_grad_(True)
+    p = "decoder.transformer.layers.0"
+    mask = O.causal_additive(10) + O.key_padding_to_additive(r["kpm"])
+    y = O.decoder_layer_prenorm(x, mem, ralf_sd, p, 8, mask)
+    close(y, r["y"])
+    gs = torch.autograd.grad(y, [x, mem, ralf_sd[p + ".multihead_attn.in_proj_weight"], ralf_sd[p + ".self_attn.out_proj.weight"]], r["go"])
+    close(gs[0], r["gx"]); close(gs[1], r["gmem"]); close(thin(gs[2]), r["g_cross_in_w"]); close(thin(gs[3]), r["g_self_out_w"])
+
+
+def test_fidnet(golden, ralf_sd):
+    r = golden("modules.npz").sub("fidnet")
+    with torch.no_grad():
+        f = O.fidnet_extract(ralf_sd, "layout_encoer", r["in"])
+    close(f, r["feat"])
+
+
+@pytest.mark.parametrize("task", ["uncond", "refinement", "c"])
+def test_ralf_e2e(golden, ralf_sd, task):
+    r = golden("e2e.npz").sub("ralf_" + task)
+    feat = r["feat"].requires_grad_(True)
+    inputs = dict(r["inputs"])
+    inputs["retrieved"] = r["retrieved"]
+    logits = O.ralf_forward(ralf_sd, inputs, feat=feat)
+    close(logits, r["logits"], atol=1e-4)
+    loss = O.xent_label_smoothing(logits, r["targets"]["seq"], ignore_index=515)
+    close(loss, r["loss"], atol=1e-5)
+    keys = list(r["grads"].keys())
+    params = [v for v in ralf_sd.values() if v.requires_grad]
+    allg = torch.autograd.grad(loss, [feat] + params, allow_unused=True)
+    close(allg[0], r["gfeat"], atol=1e-6)
+    byname = {k: g for (k, v), g in zip([(k, v) for k, v in ralf_sd.items() if v.requires_grad], allg[1:])}
+    for k in keys:
+        close(thin(byname[k]), r["grads"][k], atol=2e-6, rtol=2e-3)
+    trainable = [g for k, g in byname.items() if g is not None and not k.startswith("layout_encoer.")]
+    gn = torch.sqrt(sum((g ** 2).sum() for g in trainable))
+    close(gn, r["gradnorm"], atol=1e-6, rtol=1e-3)
+
+
+def test_autoreg_e2e(golden):
+    r = golden("e2e.npz").sub("autoreg_uncond")
+    sd = det_state_dict(shapes("autoreg_state_shapes.json"))
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    feat = r["feat"].requires_grad_(True)
+    logits = O.autoreg_forward(sd, r["inputs"], feat=feat)
+    close(logits, r["logits"], atol=1e-4)
+    loss = O.xent_label_smoothing(logits, r["targets"]["seq"], ignore_index=515)
+    close(loss, r["loss"], atol=1e-5)
+    ks = list(r["grads"].keys())
+    gs = torch.autograd.grad(loss, [feat] + [sd[k] for k in ks])
+    close(gs[0], r["gfeat"], atol=1e-6)
+    for k, g in zip(ks, gs[1:]):
+        close(thin(g), r["grads"][k], atol=2e-6, rtol=2e-3)
