@@ -1,0 +1,371 @@
+// Exact inner-product top-k scan for gfx950 (MI355X).
+//
+// Replaces faiss.IndexFlat(d, METRIC_INNER_PRODUCT).search as reached from
+// image2layout/train/models/retrieval/retriever.py:200-202 (one query per call in the reference;
+// batched here).  Two phases:
+//   1. knn_scores_kernel : S[q][n] = <Q[q], X[n]> on the fp32 matrix cores
+//      (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32).  A chain of K-steps on one accumulator is
+//      bit-for-bit the ascending-d fmaf chain of oracle/knn_oracle.c, so scores are bit-exact.
+//      The index is streamed from HBM exactly once per query tile; X/Q k-tiles are staged
+//      global -> registers -> LDS (rotated rows: conflict-free ds_read_b32 fragment reads).
+//   2. knn_select_kernel : exact k-th-largest by bisection over the 32 order-preserving key bits
+//      (+13 position bits for ties), winners ranked by counting -> (score desc, index asc).
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int MF> struct Frag;
+template <> struct Frag<32> {
+    using acc_t = f32x16;
+    static constexpr int NREG = 16, KS = 2;
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+    // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    static __device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+};
+template <> struct Frag<16> {
+    using acc_t = f32x4;
+    static constexpr int NREG = 4, KS = 4;
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    // C/D layout: col = lane&15, row = (lane>>4)*4 + r
+    static __device__ __forceinline__ int crow(int r, int lane) { return (lane >> 4) * 4 + r; }
+};
+
+// Workgroups that share a row chunk (different query tiles) get consecutive virtual ids on ONE XCD
+// (block b runs on XCD b%8) so the chunk is fetched from HBM once and re-read from that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// A operand = query tile (M dim), B operand = index-row tile (N dim): for a fixed accumulator
+// register the 32 (16) lanes of a half-wave hold CONSECUTIVE index rows of one query, so the
+// score stores are contiguous 128 B (64 B) segments of S[q][*].
+template <int MF, int TQ, int TR>
+__global__ __launch_bounds__(256) void knn_scores_kernel(const float* __restrict__ X, int64_t N, int D,
+                                                          const float* __restrict__ Q, int nq, float* __restrict__ S,
+                                                          int n_qtiles, int nwg) {
+    using F = Frag<MF>;
+    constexpr int RW = 4 * TR * MF, QW = TQ * MF, BK = 32, KS = F::KS, ROT = 32 / MF;
+    constexpr int XV = RW * BK / 4 / 256;              // float4 per thread per k-tile (index rows)
+    constexpr int QV = (QW * BK / 4 + 255) / 256;      // float4 per thread per k-tile (queries)
+    __shared__ float lds[(RW + QW) * BK];
+    float* lx = lds;
+    float* lq = lds + RW * BK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int vid = xcd_remap(blockIdx.x, nwg);
+    const int qt = vid % n_qtiles, rc = vid / n_qtiles;
+    const int64_t row0 = (int64_t)rc * RW;
+    const int q0 = qt * QW;
+
+    float4 xr[XV], qr[QV];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int f = tid + 256 * i, r = f >> 3, kq = f & 7;
+            const int64_t n = row0 + r;
+            const int k = k0 + kq * 4;
+            xr[i] = (n < N && k < D) ? *reinterpret_cast<const float4*>(X + n * D + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < QV; ++i) {
+            const int f = tid + 256 * i, r = f >> 3, kq = f & 7;
+            const int qi = q0 + r, k = k0 + kq * 4;
+            qr[i] = (f < QW * 8 && qi < nq && k < D) ? *reinterpret_cast<const float4*>(Q + (int64_t)qi * D + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // element (row, k) lives at row*32 + ((k + ROT*row) & 31): both the 4 scalar writes of a float4
+    // and the per-lane fragment reads (32 or 16 rows x same k) hit distinct banks.
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int f = tid + 256 * i, r = f >> 3, kq = f & 7;
+            float* base = lx + r * BK;
+            const int rot = kq * 4 + ROT * r;
+            base[(rot + 0) & 31] = xr[i].x; base[(rot + 1) & 31] = xr[i].y;
+            base[(rot + 2) & 31] = xr[i].z; base[(rot + 3) & 31] = xr[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < QV; ++i) {
+            const int f = tid + 256 * i, r = f >> 3, kq = f & 7;
+            if (f < QW * 8) {
+                float* base = lq + r * BK;
+                const int rot = kq * 4 + ROT * r;
+                base[(rot + 0) & 31] = qr[i].x; base[(rot + 1) & 31] = qr[i].y;
+                base[(rot + 2) & 31] = qr[i].z; base[(rot + 3) & 31] = qr[i].w;
+            }
+        }
+    };
+
+    typename F::acc_t acc[TQ][TR];
+#pragma unroll
+    for (int a = 0; a < TQ; ++a)
+#pragma unroll
+        for (int b = 0; b < TR; ++b)
+#pragma unroll
+            for (int r = 0; r < F::NREG; ++r) acc[a][b][r] = 0.f;
+
+    const int lr = lane & (MF - 1), lk = lane / MF;  // row within fragment, k within K-step
+    int qoff[TQ], qrot[TQ], xoff[TR], xrot[TR];
+#pragma unroll
+    for (int a = 0; a < TQ; ++a) { const int r = a * MF + lr; qoff[a] = r * BK; qrot[a] = ROT * r + lk; }
+#pragma unroll
+    for (int b = 0; b < TR; ++b) { const int r = (wave * TR + b) * MF + lr; xoff[b] = r * BK; xrot[b] = ROT * r + lk; }
+
+    const int nkt = (D + BK - 1) / BK;
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) gload((kt + 1) * BK);  // next tile's HBM loads fly under this tile's MFMAs
+#pragma unroll
+        for (int s = 0; s < BK / KS; ++s) {
+            float a[TQ], b[TR];
+#pragma unroll
+            for (int i = 0; i < TQ; ++i) a[i] = lq[qoff[i] + ((qrot[i] + s * KS) & 31)];
+#pragma unroll
+            for (int j = 0; j < TR; ++j) b[j] = lx[xoff[j] + ((xrot[j] + s * KS) & 31)];
+#pragma unroll
+            for (int i = 0; i < TQ; ++i)
+#pragma unroll
+                for (int j = 0; j < TR; ++j) acc[i][j] = F::mfma(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            lstore();
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < TQ; ++i)
+#pragma unroll
+        for (int j = 0; j < TR; ++j) {
+            const int64_t n = row0 + (wave * TR + j) * MF + lr;
+#pragma unroll
+            for (int r = 0; r < F::NREG; ++r) {
+                const int qi = q0 + i * MF + F::crow(r, lane);
+                if (qi < nq && n < N) S[(int64_t)qi * N + n] = acc[i][j][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// selection
+// ------------------------------------------------------------------------------------------
+constexpr int SEG = 8192;       // scores handled by one workgroup
+constexpr int EPT = SEG / 256;  // keys per thread (registers)
+constexpr int KMAX = 1024;
+
+// order-preserving float -> uint (larger float = larger key); key 0 is reserved for "no entry"
+__device__ __forceinline__ uint32_t f2key(float v) {
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+    return (k == 0u) ? -__builtin_inff() : __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// sum over the 256-thread block; `slot` alternates so one barrier per call suffices
+__device__ __forceinline__ int block_sum(int v, int* red, int& slot) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[slot * 4 + (threadIdx.x >> 6)] = v;
+    __syncthreads();
+    const int s = red[slot * 4] + red[slot * 4 + 1] + red[slot * 4 + 2] + red[slot * 4 + 3];
+    slot ^= 1;
+    return s;
+}
+
+// One workgroup selects the top-k of `cnt` (<= SEG) entries of query blockIdx.y, list blockIdx.x.
+//   FROM_SCORES: entries are S[q][base + p], index = base + p
+//   else       : entries are (cs, ci)[q][base + p] candidate lists; equal scores appear in ascending
+//                index order, so "lower position wins" == "lower index wins" in both modes.
+// Output list (sorted by score desc, index asc; padded with (-inf,-1)): os/oi[q][blockIdx.x][k].
+template <bool FROM_SCORES>
+__global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict__ S, const float* __restrict__ cs,
+                                                          const int64_t* __restrict__ ci, int64_t in_stride, int64_t in_count,
+                                                          int64_t per_wg, int k, float* __restrict__ os, int64_t* __restrict__ oi) {
+    __shared__ int red[8];
+    __shared__ uint32_t wkey[KMAX];
+    __shared__ int wpos[KMAX];
+    __shared__ int wcnt;
+    const int tid = threadIdx.x;
+    const int q = blockIdx.y, lst = blockIdx.x, nlst = gridDim.x;
+    const int64_t base = (int64_t)lst * per_wg;
+    int64_t rem = in_count - base;
+    const int cnt = (int)(rem < per_wg ? rem : per_wg);
+    const float* src = (FROM_SCORES ? S : cs) + (int64_t)q * in_stride + base;
+
+    uint32_t key[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int p = tid + 256 * i;  // position (coalesced loads)
+        key[i] = (p < cnt) ? f2key(src[p]) : 0u;
+    }
+    if (tid == 0) wcnt = 0;
+    int slot = 0;
+
+    // k-th largest key by bisection: largest T with |{key >= T}| >= k
+    uint32_t T = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t t = T | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) c += (key[i] >= t);
+        if (block_sum(c, red, slot) >= k) T = t;
+    }
+    int cgt = 0, ceq = 0;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) { cgt += (key[i] > T); ceq += (key[i] == T); }
+    cgt = block_sum(cgt, red, slot);
+    ceq = block_sum(ceq, red, slot);
+    const int need = k - cgt;  // entries equal to T to keep (lowest positions first); >= 1 unless T == 0
+    int P = SEG;               // keep key == T entries with position <= P
+    if (need < ceq) {
+        // smallest P with |{key == T, pos <= P}| >= need  (bisection on 13 position bits)
+        int lo = -1;  // invariant: count(pos <= lo) < need
+        for (int bit = 12; bit >= 0; --bit) {
+            const int t = lo + (1 << bit);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) c += (key[i] == T && (tid + 256 * i) <= t);
+            if (block_sum(c, red, slot) < need) lo = t;
+        }
+        P = lo + 1;
+    }
+    // gather winners (unordered), then rank by counting
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int p = tid + 256 * i;
+        if (key[i] > T || (key[i] == T && p <= P && T != 0u)) {
+            const int s = atomicAdd(&wcnt, 1);
+            wkey[s] = key[i];
+            wpos[s] = p;
+        }
+    }
+    __syncthreads();
+    const int nw = wcnt;  // == min(k, #valid)
+    float* so = os + ((int64_t)q * nlst + lst) * k;
+    int64_t* io = oi + ((int64_t)q * nlst + lst) * k;
+    for (int i = tid; i < k; i += 256) {
+        if (i < nw) {
+            const uint32_t ki = wkey[i];
+            const int pi = wpos[i];
+            int rank = 0;
+            for (int j = 0; j < nw; ++j) rank += (wkey[j] > ki) || (wkey[j] == ki && wpos[j] < pi);
+            so[rank] = key2f(ki);
+            io[rank] = FROM_SCORES ? (base + pi) : ci[(int64_t)q * in_stride + base + pi];
+        } else {
+            so[i] = -__builtin_inff();  // ranks [nw, k) are never written by winners
+            io[i] = -1;
+        }
+    }
+}
+
+template <int MF, int TQ, int TR>
+int launch_scores(const float* X, int64_t N, int D, const float* Q, int nq, float* S, hipStream_t st) {
+    constexpr int RW = 4 * TR * MF, QW = TQ * MF;
+    const int nrc = ceil_div(N, RW), nqt = ceil_div(nq, QW);
+    const int nwg = nrc * nqt;
+    hipLaunchKernelGGL((knn_scores_kernel<MF, TQ, TR>), dim3(nwg), dim3(256), 0, st, X, N, D, Q, nq, S, nqt, nwg);
+    return ralf::check_launch("knn_scores");
+}
+
+struct SelectPlan {
+    int64_t nseg;      // lists after the score pass
+    size_t cand_bytes; // one candidate buffer (scores + indices), sized for the first level
+};
+SelectPlan plan_select(int64_t N, int nq, int k) {
+    SelectPlan p;
+    p.nseg = (N + SEG - 1) / SEG;
+    p.cand_bytes = (size_t)nq * p.nseg * k * (sizeof(float) + sizeof(int64_t));
+    return p;
+}
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" int ralf_knn_scores(const float* X, int64_t N, int D, const float* Q, int nq, float* S, void* stream) {
+    RALF_REQUIRE(X && Q && S, "knn_scores: null pointer");
+    RALF_REQUIRE(N > 0 && nq > 0 && D > 0, "knn_scores: empty problem (n_db=%lld nq=%d dim=%d)", (long long)N, nq, D);
+    RALF_REQUIRE(D % 4 == 0, "knn_scores: dim %d must be a multiple of 4 (16-byte row alignment)", D);
+    RALF_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)Q & 15) == 0, "knn_scores: index/queries must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    // HBM-bound regime (few queries): small row chunks -> >= 2 workgroups per CU in flight.
+    if (nq <= 16) return launch_scores<16, 1, 2>(X, N, D, Q, nq, S, st);
+    if (nq <= 32) return launch_scores<32, 1, 1>(X, N, D, Q, nq, S, st);
+    if (nq <= 64) return launch_scores<32, 2, 2>(X, N, D, Q, nq, S, st);
+    // FLOP-bound regime: 256 rows x 128 queries per workgroup, 8 accumulator tiles per wave.
+    return launch_scores<32, 4, 2>(X, N, D, Q, nq, S, st);
+}
+
+extern "C" size_t ralf_knn_topk_ip_workspace_bytes(int64_t N, int D, int nq, int k) {
+    (void)D;
+    if (N <= 0 || nq <= 0 || k <= 0) return 0;
+    SelectPlan p = plan_select(N, nq, k);
+    return align256((size_t)nq * N * sizeof(float)) + 2 * align256(p.cand_bytes) + 256;
+}
+
+// workspace for select alone = 2 candidate buffers
+extern "C" int ralf_knn_select(const float* S, int64_t N, int nq, int k, int64_t* out_idx, float* out_score, void* ws,
+                               size_t ws_bytes, void* stream) {
+    RALF_REQUIRE(S && out_idx && out_score, "knn_select: null pointer");
+    RALF_REQUIRE(N > 0 && nq > 0, "knn_select: empty problem");
+    RALF_REQUIRE(k >= 1 && k <= KMAX, "knn_select: k=%d outside [1,%d]", k, KMAX);
+    hipStream_t st = (hipStream_t)stream;
+    SelectPlan p = plan_select(N, nq, k);
+    if (p.nseg == 1) {
+        hipLaunchKernelGGL((knn_select_kernel<true>), dim3(1, nq), dim3(256), 0, st, S, nullptr, nullptr, N, N, (int64_t)SEG, k, out_score, out_idx);
+        return ralf::check_launch("knn_select");
+    }
+    if (!ws || ws_bytes < 2 * align256(p.cand_bytes)) {
+        ralf::set_error("knn_select: workspace %zu < required %zu bytes", ws_bytes, 2 * align256(p.cand_bytes));
+        return RALF_ERR_WORKSPACE;
+    }
+    char* w = (char*)ws;
+    float* cs[2];
+    int64_t* ci[2];
+    for (int i = 0; i < 2; ++i) {
+        ci[i] = (int64_t*)(w + i * align256(p.cand_bytes));
+        cs[i] = (float*)(ci[i] + (size_t)nq * p.nseg * k);
+    }
+    hipLaunchKernelGGL((knn_select_kernel<true>), dim3((unsigned)p.nseg, nq), dim3(256), 0, st, S, nullptr, nullptr, N, N, (int64_t)SEG, k, cs[0], ci[0]);
+    int cur = 0;
+    int64_t nl = p.nseg;
+    const int64_t group = SEG / k;  // lists merged per workgroup (>= 8 since k <= 1024)
+    while (nl > 1) {
+        const int64_t nout = (nl + group - 1) / group;
+        float* so = nout == 1 ? out_score : cs[cur ^ 1];
+        int64_t* io = nout == 1 ? out_idx : ci[cur ^ 1];
+        hipLaunchKernelGGL((knn_select_kernel<false>), dim3((unsigned)nout, nq), dim3(256), 0, st, nullptr, cs[cur], ci[cur], nl * k, nl * k, group * k, k, so, io);
+        nl = nout;
+        cur ^= 1;
+    }
+    return ralf::check_launch("knn_select");
+}
+
+extern "C" int ralf_knn_topk_ip(const float* X, int64_t N, int D, const float* Q, int nq, int k, int64_t* out_idx,
+                                float* out_score, void* ws, size_t ws_bytes, void* stream) {
+    RALF_REQUIRE(k >= 1 && k <= KMAX, "knn_topk_ip: k=%d outside [1,%d]", k, KMAX);
+    RALF_REQUIRE(N > 0 && nq > 0, "knn_topk_ip: empty problem (n_db=%lld nq=%d)", (long long)N, nq);
+    const size_t need = ralf_knn_topk_ip_workspace_bytes(N, D, nq, k);
+    if (!ws || ws_bytes < need) {
+        ralf::set_error("knn_topk_ip: workspace %zu < required %zu bytes", ws_bytes, need);
+        return RALF_ERR_WORKSPACE;
+    }
+    RALF_REQUIRE(((uintptr_t)ws & 255) == 0, "knn_topk_ip: workspace must be 256-byte aligned");
+    float* S = (float*)ws;
+    const size_t soff = align256((size_t)nq * N * sizeof(float));
+    int rc = ralf_knn_scores(X, N, D, Q, nq, S, stream);
+    if (rc) return rc;
+    return ralf_knn_select(S, N, nq, k, out_idx, out_score, (char*)ws + soff, ws_bytes - soff, stream);
+}

@@ -1,0 +1,97 @@
+"""GPU parity: HIP exact inner-product top-k (through the C ABI) vs the C oracle, bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def unit_rows(n, d, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x
+
+
+def run_hip(X, Q, k):
+    from ralf_amd.retrieval import knn_topk_ip
+
+    val, idx = knn_topk_ip(torch.from_numpy(X).cuda(), torch.from_numpy(Q).cuda(), k)
+    torch.cuda.synchronize()
+    return idx.cpu().numpy(), val.cpu().numpy()
+
+
+def assert_exact(X, Q, k):
+    from oracle import knn_oracle as K
+
+    i_ref, v_ref = K.topk_ip(X, Q, k)
+    i_hip, v_hip = run_hip(X, Q, k)
+    np.testing.assert_array_equal(i_hip, i_ref)
+    np.testing.assert_array_equal(v_hip, v_ref)  # bit-exact fp32 scores (fmaf chain == fp32 MFMA chain)
+
+
+@pytest.mark.parametrize("nq", [1, 5, 16, 17, 32, 40, 64, 100, 200])
+@pytest.mark.parametrize("k", [1, 16, 17, 33])
+def test_toy_index_ties_and_self_queries(nq, k):
+    X = unit_rows(2048, 64, 0)
+    X[100] = X[7]; X[200] = X[7]; X[5] = X[1900]; X[2047] = X[0]   # planted exact ties
+    Q = np.concatenate([X[: (nq + 1) // 2], unit_rows(nq // 2, 64, 1)])[:nq]  # self + fresh queries
+    assert_exact(X, Q, k)
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(10, 4, 3, 17), (1, 8, 1, 1), (257, 100, 9, 16), (8193, 36, 33, 33), (20000, 256, 130, 256), (300, 512, 70, 300)])
+def test_ragged_shapes(n, d, nq, k):
+    assert_exact(unit_rows(n, d, 2), unit_rows(nq, d, 3), k)
+
+
+@pytest.mark.parametrize("d,nq", [(256, 64), (1792, 32), (512, 1), (1792, 16)])
+def test_cgl_sized_index(d, nq):
+    assert_exact(unit_rows(61548, d, 4), unit_rows(nq, d, 5), 17)
+
+
+def test_select_degenerate_scores():
+    from oracle import knn_oracle as K
+    from ralf_amd.retrieval.knn import knn_select
+
+    rng = np.random.default_rng(6)
+    s = np.zeros((6, 20000), np.float32)
+    s[1] = 1.5                                  # all equal -> indices 0..k-1
+    s[2] = rng.integers(0, 3, 20000)            # massive ties straddling the threshold
+    s[3] = rng.standard_normal(20000); s[3, 17] = np.inf; s[3, 9000] = -np.inf
+    s[4] = -rng.random(20000); s[4, ::2] = -0.0
+    s[5] = rng.standard_normal(20000).astype(np.float32) * 1e-30
+    for k in (1, 17, 64, 1000):
+        i_ref, v_ref = K.select(s, k)
+        v, i = knn_select(torch.from_numpy(s).cuda(), k)
+        np.testing.assert_array_equal(i.cpu().numpy(), i_ref)
+        np.testing.assert_array_equal(v.cpu().numpy(), v_ref)
+
+
+def test_full_size_properties():
+    """BASELINE config 4: 61 548 x 1792 index, nq = 1024, k = 16 -- size-independent properties."""
+    from oracle import knn_oracle as K
+
+    X = unit_rows(61548, 1792, 7)
+    Q = np.concatenate([X[:512], unit_rows(512, 1792, 8)])
+    idx, val = run_hip(X, Q, 16)
+    assert (idx[:512, 0] == np.arange(512)).all()             # self-match is rank 0 (retriever.py:211-213)
+    assert (np.diff(val, axis=1) <= 0).all()                  # sorted
+    assert all(len(set(r)) == 16 for r in idx)                # no duplicates
+    sub = np.arange(0, 1024, 37)                              # oracle on a bounded sample of the queries
+    i_ref, v_ref = K.topk_ip(X, Q[sub], 16)
+    np.testing.assert_array_equal(idx[sub], i_ref)
+    np.testing.assert_array_equal(val[sub], v_ref)
+    # batch-size independence: the same query gives the same answer alone and inside the batch
+    i1, v1 = run_hip(X, Q[700:701], 16)
+    np.testing.assert_array_equal(i1[0], idx[700]); np.testing.assert_array_equal(v1[0], val[700])
+
+
+def test_errors_are_loud():
+    from ralf_amd._lib import RalfHipError
+    from ralf_amd.retrieval import knn_topk_ip
+
+    X = torch.zeros(16, 6, device="cuda"); Q = torch.zeros(2, 6, device="cuda")
+    with pytest.raises(RalfHipError, match="multiple of 4"):
+        knn_topk_ip(X, Q, 3)
+    with pytest.raises(RalfHipError, match="k=0"):
+        knn_topk_ip(torch.zeros(16, 8, device="cuda"), torch.zeros(2, 8, device="cuda"), 0)
