@@ -185,11 +185,18 @@ __device__ __forceinline__ int block_sum(int v, int* red, int& slot) {
     return s;
 }
 
+__device__ __forceinline__ bool better(uint32_t ka, int pa, uint32_t kb, int pb) { return ka > kb || (ka == kb && pa < pb); }
+
 // One workgroup selects the top-k of `cnt` (<= SEG) entries of query blockIdx.y, list blockIdx.x.
 //   FROM_SCORES: entries are S[q][base + p], index = base + p
 //   else       : entries are (cs, ci)[q][base + p] candidate lists; equal scores appear in ascending
 //                index order, so "lower position wins" == "lower index wins" in both modes.
 // Output list (sorted by score desc, index asc; padded with (-inf,-1)): os/oi[q][blockIdx.x][k].
+//
+// Fast path: the k-th largest of the 256 per-thread maxima is a lower bound L of the k-th largest
+// key, so only keys >= L (a few more than k on non-degenerate data) are candidates; they are ranked
+// exactly by counting.  Degenerate inputs (more than KMAX candidates: massive ties) or k > 256 take
+// the exact bisection over all SEG keys instead.  Both paths give identical results.
 template <bool FROM_SCORES>
 __global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict__ S, const float* __restrict__ cs,
                                                           const int64_t* __restrict__ ci, int64_t in_stride, int64_t in_count,
@@ -197,77 +204,109 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict
     __shared__ int red[8];
     __shared__ uint32_t wkey[KMAX];
     __shared__ int wpos[KMAX];
+    __shared__ uint32_t tmax[256];
     __shared__ int wcnt;
-    const int tid = threadIdx.x;
+    __shared__ uint32_t bound;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int q = blockIdx.y, lst = blockIdx.x, nlst = gridDim.x;
     const int64_t base = (int64_t)lst * per_wg;
     int64_t rem = in_count - base;
     const int cnt = (int)(rem < per_wg ? rem : per_wg);
     const float* src = (FROM_SCORES ? S : cs) + (int64_t)q * in_stride + base;
+    float* so = os + ((int64_t)q * nlst + lst) * k;
+    int64_t* io = oi + ((int64_t)q * nlst + lst) * k;
 
     uint32_t key[EPT];
+    uint32_t mx = 0;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         const int p = tid + 256 * i;  // position (coalesced loads)
         key[i] = (p < cnt) ? f2key(src[p]) : 0u;
+        mx = key[i] > mx ? key[i] : mx;
     }
+    tmax[tid] = mx;
     if (tid == 0) wcnt = 0;
-    int slot = 0;
-
-    // k-th largest key by bisection: largest T with |{key >= T}| >= k
-    uint32_t T = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t t = T | (1u << bit);
-        int c = 0;
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) c += (key[i] >= t);
-        if (block_sum(c, red, slot) >= k) T = t;
-    }
-    int cgt = 0, ceq = 0;
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) { cgt += (key[i] > T); ceq += (key[i] == T); }
-    cgt = block_sum(cgt, red, slot);
-    ceq = block_sum(ceq, red, slot);
-    const int need = k - cgt;  // entries equal to T to keep (lowest positions first); >= 1 unless T == 0
-    int P = SEG;               // keep key == T entries with position <= P
-    if (need < ceq) {
-        // smallest P with |{key == T, pos <= P}| >= need  (bisection on 13 position bits)
-        int lo = -1;  // invariant: count(pos <= lo) < need
-        for (int bit = 12; bit >= 0; --bit) {
-            const int t = lo + (1 << bit);
-            int c = 0;
-#pragma unroll
-            for (int i = 0; i < EPT; ++i) c += (key[i] == T && (tid + 256 * i) <= t);
-            if (block_sum(c, red, slot) < need) lo = t;
+    __syncthreads();
+    if (tid < 64) {  // wave 0: L = k-th largest thread maximum (0 if fewer than k non-empty threads)
+        uint32_t L = 0;
+        if (k <= 256) {
+            const uint32_t m0 = tmax[lane], m1 = tmax[lane + 64], m2 = tmax[lane + 128], m3 = tmax[lane + 192];
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t t = L | (1u << bit);
+                const int c = __popcll(__ballot(m0 >= t)) + __popcll(__ballot(m1 >= t)) + __popcll(__ballot(m2 >= t)) + __popcll(__ballot(m3 >= t));
+                if (c >= k) L = t;
+            }
         }
-        P = lo + 1;
+        if (lane == 0) bound = L;
     }
-    // gather winners (unordered), then rank by counting
+    __syncthreads();
+    const uint32_t L = bound;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
-        const int p = tid + 256 * i;
-        if (key[i] > T || (key[i] == T && p <= P && T != 0u)) {
+        if (key[i] >= L && key[i] != 0u) {
             const int s = atomicAdd(&wcnt, 1);
-            wkey[s] = key[i];
-            wpos[s] = p;
+            if (s < KMAX) { wkey[s] = key[i]; wpos[s] = tid + 256 * i; }
         }
     }
     __syncthreads();
-    const int nw = wcnt;  // == min(k, #valid)
-    float* so = os + ((int64_t)q * nlst + lst) * k;
-    int64_t* io = oi + ((int64_t)q * nlst + lst) * k;
-    for (int i = tid; i < k; i += 256) {
-        if (i < nw) {
-            const uint32_t ki = wkey[i];
-            const int pi = wpos[i];
-            int rank = 0;
-            for (int j = 0; j < nw; ++j) rank += (wkey[j] > ki) || (wkey[j] == ki && wpos[j] < pi);
+    int nw = wcnt;
+    if (nw > KMAX) {
+        // ---- exact bisection over all keys: largest T with |{key >= T}| >= k ----
+        __syncthreads();
+        if (tid == 0) wcnt = 0;
+        int slot = 0;
+        uint32_t T = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t t = T | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) c += (key[i] >= t);
+            if (block_sum(c, red, slot) >= k) T = t;
+        }
+        int cgt = 0, ceq = 0;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) { cgt += (key[i] > T); ceq += (key[i] == T); }
+        cgt = block_sum(cgt, red, slot);
+        ceq = block_sum(ceq, red, slot);
+        const int need = k - cgt;  // entries equal to T to keep, lowest positions first
+        int P = SEG;               // keep key == T entries with position <= P
+        if (need < ceq) {          // smallest P with |{key == T, pos <= P}| >= need (13 position bits)
+            int lo = -1;
+            for (int bit = 12; bit >= 0; --bit) {
+                const int t = lo + (1 << bit);
+                int c = 0;
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) c += (key[i] == T && (tid + 256 * i) <= t);
+                if (block_sum(c, red, slot) < need) lo = t;
+            }
+            P = lo + 1;
+        }
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int p = tid + 256 * i;
+            if (key[i] != 0u && (key[i] > T || (key[i] == T && p <= P))) {
+                const int s = atomicAdd(&wcnt, 1);
+                wkey[s] = key[i];
+                wpos[s] = p;
+            }
+        }
+        __syncthreads();
+        nw = wcnt;  // == min(k, #valid) <= KMAX
+    }
+    // rank the nw candidates exactly; the best min(nw,k) are the output
+    for (int i = tid; i < nw; i += 256) {
+        const uint32_t ki = wkey[i];
+        const int pi = wpos[i];
+        int rank = 0;
+        for (int j = 0; j < nw; ++j) rank += better(wkey[j], wpos[j], ki, pi);
+        if (rank < k) {
             so[rank] = key2f(ki);
             io[rank] = FROM_SCORES ? (base + pi) : ci[(int64_t)q * in_stride + base + pi];
-        } else {
-            so[i] = -__builtin_inff();  // ranks [nw, k) are never written by winners
-            io[i] = -1;
         }
+    }
+    for (int i = (nw < k ? nw : k) + tid; i < k; i += 256) {
+        so[i] = -__builtin_inff();
+        io[i] = -1;
     }
 }
 
