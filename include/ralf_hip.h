@@ -49,6 +49,52 @@ int ralf_knn_scores(const float* index, int64_t n_db, int dim, const float* quer
 int ralf_knn_select(const float* scores, int64_t n_db, int nq, int k, int64_t* out_idx, float* out_score,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * element types of activation / weight buffers (accumulation is always fp32)
+ * ------------------------------------------------------------------------------------------- */
+#define RALF_F32 0  /* parity mode: exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32)            */
+#define RALF_BF16 1 /* throughput mode: bf16 operands (v_mfma_f32_32x32x16_bf16), fp32 accum    */
+
+#define RALF_ACT_NONE 0
+#define RALF_ACT_RELU 1
+#define RALF_ACT_GELU 2          /* exact erf GELU (nn.GELU default, common/attention.py:23)      */
+#define RALF_AUX_NONE 0
+#define RALF_AUX_RELU_MASK 1     /* v = aux > 0 ? v * aux_scale : 0   (ReLU gradient from output) */
+#define RALF_AUX_GELU_GRAD 2     /* v *= gelu'(aux)                   (aux = pre-activation)      */
+
+/* implicit-im2col geometry: matrix rows = pixels of an (RH x RW) grid per image, columns =
+ * (kh, kw, c) with c fastest, gathered from an NHWC source [*, SH, SW, SC].
+ *   mode 0 (forward / weight-gradient): rows = output pixels, source = input x:
+ *           sy = ry*stride - pad + kh
+ *   mode 1 (data-gradient):            rows = input pixels,  source = dY:
+ *           sy = (ry + pad - kh) / stride when divisible                                         */
+typedef struct RalfConvGeom {
+    int RH, RW, SH, SW, SC, KH, KW, stride, pad, mode;
+} RalfConvGeom;
+
+/* C[z][m][n] = epi(alpha * sum_k A[z][m][k] * B[z][k][n]),  z = z1*nb0 + z0  (two batch levels).
+ * Replaces F.linear / F.conv2d / torch.bmm and their backward products, see ralf_amd/csrc/gemm.hip.
+ *   a_kcontig: A stored [M][lda] (k contiguous) else [K][lda] (m contiguous)
+ *   b_kcontig: B stored [N][ldb] (k contiguous, e.g. nn.Linear.weight) else [K][ldb]
+ *   gather:    0 none; 1 = A is the im2col matrix of g (needs a_kcontig=b_kcontig=1);
+ *              2 = B is the im2col matrix of g (weight gradient, needs a_kcontig=b_kcontig=0)
+ *   epilogue order: *alpha, +bias[n] (fp32), C2 = v (optional pre-activation copy), act,
+ *              aux mask/gradient, +res, (+C if accumulate), store as dtype or fp32 (out_f32).
+ *   splitk > 1: deterministic split of the K range through `workspace` (fp32 partial slabs).   */
+typedef struct RalfGemmDesc {
+    const void* A; const void* B; void* C; void* C2;
+    const float* bias; const void* res; const void* aux;
+    int64_t lda, ldb, ldc, ldr;
+    int64_t sA0, sA1, sB0, sB1, sC0, sC1, sR0, sR1;
+    int M, N, K, nb0, nb1;
+    int dtype, a_kcontig, b_kcontig, gather;
+    int act, aux_mode, out_f32, accumulate, splitk;
+    float alpha, aux_scale;
+    RalfConvGeom g;
+} RalfGemmDesc;
+size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d);
+int ralf_gemm(const RalfGemmDesc* d, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,401 @@
+// MFMA GEMM for gfx950 with fused epilogues; the one contraction kernel behind every Linear,
+// attention projection, FFN, vocab head and (through the implicit-im2col gather) every Conv2d
+// of the RALF train step.
+//
+//   C[z][m][n] = epi( alpha * sum_k A[z][m][k] * B[z][k][n] )
+//
+// Replaces torch.nn.functional.linear / conv2d and their autograd backward as called from
+//   nn.TransformerEncoderLayer / DecoderLayer / MultiheadAttention
+//       (image2layout/train/models/retrieval_augmented_autoreg.py:116-126, common/common.py:25-34)
+//   FeedForward / Attention (common/attention.py:15-71), BaseDecoder.head (common/common.py:38-40)
+//   ResnetBackbone convolutions (common/image.py:80-111)
+//
+// Design:
+//   * 128x128 output tile per 256-thread workgroup, 2x2 waves, each wave 2x2 fragments of 32x32
+//     (v_mfma_f32_32x32x16_bf16 or the exact-fp32 v_mfma_f32_32x32x2_f32); fp32 accumulate always.
+//   * each operand is either "k-contiguous" (row-major [rows][K]) or "row-contiguous" ([K][rows]);
+//     tiles are staged global -> registers -> LDS in their MEMORY order (coalesced 16-B loads) and
+//     the row-contiguous case is fed to the matrix core with ds_read_b64_tr_b16 (bf16) / plain
+//     ds_read_b32 (fp32), so NN / NT / TN products need no transposed copies in HBM.
+//   * the "pixel x (kh,kw,c)" operand of a convolution is gathered on the fly from NHWC (implicit
+//     im2col; forward / data-gradient / weight-gradient all use the same gather).
+//   * split-K for the weight-gradient shapes (tiny output, huge reduction), deterministic:
+//     partial slabs + a reduce kernel that also runs the epilogue.
+//   * epilogue: alpha, bias, ReLU/GELU(erf), activation-gradient masks, residual add, second
+//     (pre-activation) output, fp32 or bf16 stores.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+constexpr int BM = 128, BN = 128;
+
+struct KParams {
+    RalfGemmDesc d;
+    int tiles_m, tiles_n, nwg;
+    int kchunk;       // K range handled by one split (multiple of BK)
+    float* partial;   // [split][batch][M][N] fp32 (splitk > 1)
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <typename T> struct TT;
+template <> struct TT<float> {
+    static constexpr int VEC = 4, BK = 32, KSTEP = 2;
+    static constexpr int LDK = 32;    // k-contiguous tile: [128][32], rotated
+    static constexpr int LDR = 128;   // row-contiguous tile: [32][128]
+};
+template <> struct TT<bf16> {
+    static constexpr int VEC = 8, BK = 64, KSTEP = 16;
+    static constexpr int LDK = 72;    // [128][64 + 8 pad]
+    static constexpr int LDR = 136;   // [64][128 + 8 pad]
+};
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+template <typename T> __device__ __forceinline__ float ldf(const void* p, int64_t i);
+template <> __device__ __forceinline__ float ldf<float>(const void* p, int64_t i) { return ((const float*)p)[i]; }
+template <> __device__ __forceinline__ float ldf<bf16>(const void* p, int64_t i) { return (float)((const bf16*)p)[i]; }
+template <typename T> __device__ __forceinline__ void stf(void* p, int64_t i, float v);
+template <> __device__ __forceinline__ void stf<float>(void* p, int64_t i, float v) { ((float*)p)[i] = v; }
+template <> __device__ __forceinline__ void stf<bf16>(void* p, int64_t i, float v) { ((bf16*)p)[i] = (bf16)v; }
+
+// epilogue on one element (shared by the GEMM kernel and the split-K reducer)
+template <typename T>
+__device__ __forceinline__ void epilogue_store(const RalfGemmDesc& d, int z0, int z1, int m, int n, float v) {
+    v *= d.alpha;
+    if (d.bias) v += d.bias[n];
+    const int64_t coff = z0 * d.sC0 + z1 * d.sC1 + (int64_t)m * d.ldc + n;
+    if (d.C2) {  // pre-activation copy (needed by the activation gradient)
+        if (d.out_f32) stf<float>(d.C2, coff, v); else stf<T>(d.C2, coff, v);
+    }
+    if (d.act == RALF_ACT_RELU) v = v > 0.f ? v : 0.f;
+    else if (d.act == RALF_ACT_GELU) v = gelu_f(v);
+    if (d.aux) {
+        const float a = ldf<T>(d.aux, coff);
+        if (d.aux_mode == RALF_AUX_RELU_MASK) v = a > 0.f ? v * d.aux_scale : 0.f;
+        else if (d.aux_mode == RALF_AUX_GELU_GRAD) v *= gelu_grad(a);
+    }
+    if (d.res) v += ldf<T>(d.res, z0 * d.sR0 + z1 * d.sR1 + (int64_t)m * d.ldr + n);
+    if (d.accumulate) v += d.out_f32 ? ldf<float>(d.C, coff) : ldf<T>(d.C, coff);
+    if (d.out_f32) stf<float>(d.C, coff, v); else stf<T>(d.C, coff, v);
+}
+
+// ---- operand loaders -------------------------------------------------------------------------
+// A "source matrix" is row-major with contiguous columns: plain (ptr + row*ld + col) or the
+// implicit im2col matrix rows = pixels of a (RH x RW) grid per image, cols = (kh, kw, c).
+struct RowInfo { int64_t base; int y0, x0; bool ok; };
+
+template <bool GATHER>
+__device__ __forceinline__ RowInfo row_info(const RalfConvGeom& g, int64_t row, int64_t nrows, int64_t ld) {
+    RowInfo r;
+    r.ok = row < nrows;
+    if (!GATHER) { r.base = row * ld; r.y0 = r.x0 = 0; return r; }
+    const int hw = g.RH * g.RW;
+    const int b = (int)(row / hw), rem = (int)(row - (int64_t)b * hw);
+    const int ry = rem / g.RW, rx = rem - ry * g.RW;
+    r.base = (int64_t)b * g.SH * g.SW * g.SC;
+    if (g.mode == 0) { r.y0 = ry * g.stride - g.pad; r.x0 = rx * g.stride - g.pad; }
+    else             { r.y0 = ry + g.pad;            r.x0 = rx + g.pad; }
+    return r;
+}
+
+// 16-byte vector of VEC elements at (row, col..col+VEC-1); zero outside the matrix / the padding
+template <typename T, bool GATHER>
+__device__ __forceinline__ uint4 load_vec(const T* __restrict__ p, const RalfConvGeom& g, const RowInfo& r, int col, int ncols, bool aligned) {
+    constexpr int VEC = TT<T>::VEC;
+    uint4 z = make_uint4(0, 0, 0, 0);
+    if (!r.ok || col >= ncols) return z;
+    if (GATHER) {
+        const int c = col % g.SC, t = col / g.SC;  // SC % VEC == 0: a vector never straddles a tap
+        const int kw = t % g.KW, kh = t / g.KW;
+        int sy, sx;
+        if (g.mode == 0) { sy = r.y0 + kh; sx = r.x0 + kw; }
+        else {
+            const int ty = r.y0 - kh, tx = r.x0 - kw;
+            if (ty < 0 || tx < 0 || (ty % g.stride) || (tx % g.stride)) return z;
+            sy = ty / g.stride; sx = tx / g.stride;
+        }
+        if (sy < 0 || sy >= g.SH || sx < 0 || sx >= g.SW) return z;
+        return *reinterpret_cast<const uint4*>(p + r.base + ((int64_t)sy * g.SW + sx) * g.SC + c);
+    }
+    const T* q = p + r.base + col;
+    if (aligned && col + VEC <= ncols) return *reinterpret_cast<const uint4*>(q);
+    T tmp[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) tmp[i] = (col + i < ncols) ? q[i] : (T)0.f;
+    return *reinterpret_cast<uint4*>(tmp);
+}
+
+// AK: A is k-contiguous ([M][K]); else stored [K][M].   BKC: B is k-contiguous ([N][K]); else [K][N].
+// GATHER: 0 none, 1 = A (k-contiguous) is an im2col matrix, 2 = B (row-contiguous) is an im2col matrix.
+template <typename T, bool AK, bool BKC, int GATHER>
+__global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
+    using X = TT<T>;
+    constexpr int VEC = X::VEC, BK = X::BK;
+    constexpr int A_ELEMS = AK ? BM * X::LDK : BK * X::LDR;
+    constexpr int B_ELEMS = BKC ? BN * X::LDK : BK * X::LDR;
+    __shared__ __attribute__((aligned(16))) T lds[A_ELEMS + B_ELEMS];
+    T* la = lds;
+    T* lb = lds + A_ELEMS;
+    const RalfGemmDesc& d = P.d;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int vid = xcd_remap(blockIdx.x, P.nwg);
+    const int tn = vid % P.tiles_n, tm = vid / P.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int split = blockIdx.y, z = blockIdx.z, z0 = z % d.nb0, z1 = z / d.nb0;
+    const int kbeg = split * P.kchunk;
+    const int kend = min(d.K, kbeg + P.kchunk);
+
+    const T* Ap = (const T*)d.A + z0 * d.sA0 + z1 * d.sA1;
+    const T* Bp = (const T*)d.B + z0 * d.sB0 + z1 * d.sB1;
+    const bool a_al = (d.lda % VEC == 0) && (((uintptr_t)Ap & 15) == 0);
+    const bool b_al = (d.ldb % VEC == 0) && (((uintptr_t)Bp & 15) == 0);
+
+    // ---- per-thread staging geometry (4 vectors per operand per k-tile) ----
+    constexpr int KV = BK / VEC;        // vectors along k   (k-contiguous tile: 128 rows x KV)
+    constexpr int RV = 128 / VEC;       // vectors along rows (row-contiguous tile: BK k-rows x RV)
+    uint4 ra[4], rb[4];
+    RowInfo ia[4], ib[4];
+    if (AK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ia[i] = row_info<GATHER == 1>(d.g, m0 + (tid + 256 * i) / KV, d.M, d.lda);
+    }
+    if (BKC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ib[i] = row_info<false>(d.g, n0 + (tid + 256 * i) / KV, d.N, d.ldb);
+    }
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = tid + 256 * i;
+            if (AK) ra[i] = load_vec<T, GATHER == 1>(Ap, d.g, ia[i], k0 + (v % KV) * VEC, kend, a_al);
+            else {
+                const RowInfo r = row_info<false>(d.g, k0 + v / RV, kend, d.lda);
+                ra[i] = load_vec<T, false>(Ap, d.g, r, m0 + (v % RV) * VEC, d.M, a_al);
+            }
+            if (BKC) rb[i] = load_vec<T, false>(Bp, d.g, ib[i], k0 + (v % KV) * VEC, kend, b_al);
+            else {
+                const RowInfo r = row_info<GATHER == 2>(d.g, k0 + v / RV, kend, d.ldb);
+                rb[i] = load_vec<T, GATHER == 2>(Bp, d.g, r, n0 + (v % RV) * VEC, d.N, b_al);
+            }
+        }
+    };
+    auto lstore_one = [&](T* l, bool kc, const uint4* regs) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = tid + 256 * i;
+            if (kc) {
+                const int r = v / KV, kv = v % KV;
+                if constexpr (sizeof(T) == 4) {  // fp32: rotate each row so 32 rows x same k hit 32 banks
+                    float* base = (float*)l + r * 32;
+                    const float* s = reinterpret_cast<const float*>(&regs[i]);
+                    const int rot = kv * 4 + r;
+                    base[(rot + 0) & 31] = s[0]; base[(rot + 1) & 31] = s[1];
+                    base[(rot + 2) & 31] = s[2]; base[(rot + 3) & 31] = s[3];
+                } else {
+                    *reinterpret_cast<uint4*>(l + r * X::LDK + kv * VEC) = regs[i];
+                }
+            } else {
+                const int kr = v / RV, rv = v % RV;
+                *reinterpret_cast<uint4*>(l + kr * X::LDR + rv * VEC) = regs[i];
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    // transpose-read geometry (bf16 row-contiguous tiles): 16-lane group gi reads a [4 k][16 rows] block
+    const int trL = lane & 15, tr_rowblk = ((lane >> 4) & 1) * 16, tr_k = lh * 8 + (trL >> 2), tr_c = (trL & 3) * 4;
+
+    gload(kbeg);
+    lstore_one(la, AK, ra);
+    lstore_one(lb, BKC, rb);
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = k0 + BK < kend;
+        if (more) gload(k0 + BK);
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                const int kk = ks * 2 + lh;
+                float a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int r = wm * 64 + i * 32 + l31;
+                    a[i] = AK ? ((float*)la)[r * 32 + ((kk + r) & 31)] : ((float*)la)[kk * X::LDR + r];
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r = wn * 64 + j * 32 + l31;
+                    b[j] = BKC ? ((float*)lb)[r * 32 + ((kk + r) & 31)] : ((float*)lb)[kk * X::LDR + r];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (AK) {
+                        a[i] = *reinterpret_cast<const bf16x8*>(la + (wm * 64 + i * 32 + l31) * X::LDK + ks * 16 + lh * 8);
+                    } else {
+                        const bf16* q = (const bf16*)la + (ks * 16 + tr_k) * X::LDR + wm * 64 + i * 32 + tr_rowblk + tr_c;
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 4 * X::LDR));
+                        a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (BKC) {
+                        b[j] = *reinterpret_cast<const bf16x8*>(lb + (wn * 64 + j * 32 + l31) * X::LDK + ks * 16 + lh * 8);
+                    } else {
+                        const bf16* q = (const bf16*)lb + (ks * 16 + tr_k) * X::LDR + wn * 64 + j * 32 + tr_rowblk + tr_c;
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 4 * X::LDR));
+                        b[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (more) {
+            lstore_one(la, AK, ra);
+            lstore_one(lb, BKC, rb);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    const int nbatch = gridDim.z;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < d.M && n < d.N) {
+                    if (d.splitk > 1) P.partial[(((int64_t)split * nbatch + z) * d.M + m) * d.N + n] = acc[i][j][r];
+                    else epilogue_store<T>(d, z0, z1, m, n, acc[i][j][r]);
+                }
+            }
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams P, int nbatch) {
+    const RalfGemmDesc& d = P.d;
+    const int64_t per = (int64_t)d.M * d.N, total = per * nbatch;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int s = 0; s < d.splitk; ++s) v += P.partial[(int64_t)s * total + e];
+        const int z = (int)(e / per);
+        const int64_t r = e - (int64_t)z * per;
+        epilogue_store<T>(d, z % d.nb0, z / d.nb0, (int)(r / d.N), (int)(r % d.N), v);
+    }
+}
+
+template <typename T, bool AK, bool BKC, int GATHER>
+int launch(const KParams& P, int nbatch, hipStream_t st) {
+    hipLaunchKernelGGL((gemm_kernel<T, AK, BKC, GATHER>), dim3(P.nwg, P.d.splitk, nbatch), dim3(256), 0, st, P);
+    return ralf::check_launch("gemm");
+}
+
+template <typename T>
+int dispatch(const KParams& P, int nbatch, hipStream_t st) {
+    const RalfGemmDesc& d = P.d;
+    const int key = (d.a_kcontig ? 4 : 0) | (d.b_kcontig ? 2 : 0);
+    if (d.gather == 1) {
+        if (key != 6) { ralf::set_error("gemm: gather=1 needs A and B k-contiguous"); return RALF_ERR_INVALID; }
+        return launch<T, true, true, 1>(P, nbatch, st);
+    }
+    if (d.gather == 2) {
+        if (key != 0) { ralf::set_error("gemm: gather=2 needs A and B row-contiguous"); return RALF_ERR_INVALID; }
+        return launch<T, false, false, 2>(P, nbatch, st);
+    }
+    switch (key) {
+        case 6: return launch<T, true, true, 0>(P, nbatch, st);
+        case 4: return launch<T, true, false, 0>(P, nbatch, st);
+        case 0: return launch<T, false, false, 0>(P, nbatch, st);
+        default: return launch<T, false, true, 0>(P, nbatch, st);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d) {
+    if (!d || d->splitk <= 1) return 0;
+    const int nb = d->nb0 * (d->nb1 > 0 ? d->nb1 : 1);
+    return (size_t)d->splitk * nb * d->M * d->N * sizeof(float);
+}
+
+extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspace_bytes, void* stream) {
+    RALF_REQUIRE(dp, "gemm: null descriptor");
+    KParams P;
+    P.d = *dp;
+    RalfGemmDesc& d = P.d;
+    RALF_REQUIRE(d.A && d.B && d.C, "gemm: null operand");
+    RALF_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "gemm: empty problem M=%d N=%d K=%d", d.M, d.N, d.K);
+    RALF_REQUIRE(d.dtype == RALF_F32 || d.dtype == RALF_BF16, "gemm: dtype %d", d.dtype);
+    if (d.nb0 <= 0) d.nb0 = 1;
+    if (d.nb1 <= 0) d.nb1 = 1;
+    if (d.splitk <= 0) d.splitk = 1;
+    const int nbatch = d.nb0 * d.nb1;
+    const int BK = d.dtype == RALF_F32 ? 32 : 64, VEC = d.dtype == RALF_F32 ? 4 : 8;
+    if (d.gather) RALF_REQUIRE(d.g.SC % VEC == 0 && d.g.KH > 0 && d.g.KW > 0 && d.g.stride > 0, "gemm: gather needs channels %% %d == 0", VEC);
+    P.tiles_m = ceil_div(d.M, BM);
+    P.tiles_n = ceil_div(d.N, BN);
+    P.nwg = P.tiles_m * P.tiles_n;
+    const int ktiles = ceil_div(d.K, BK);
+    if (d.splitk > ktiles) d.splitk = ktiles;
+    P.kchunk = ceil_div(ktiles, d.splitk) * BK;
+    d.splitk = ceil_div(d.K, P.kchunk);
+    P.partial = nullptr;
+    if (d.splitk > 1) {
+        const size_t need = (size_t)d.splitk * nbatch * d.M * d.N * sizeof(float);
+        if (!workspace || workspace_bytes < need) {
+            ralf::set_error("gemm: split-K workspace %zu < required %zu bytes", workspace_bytes, need);
+            return RALF_ERR_WORKSPACE;
+        }
+        P.partial = (float*)workspace;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int rc = d.dtype == RALF_F32 ? dispatch<float>(P, nbatch, st) : dispatch<bf16>(P, nbatch, st);
+    if (rc || d.splitk <= 1) return rc;
+    const int64_t total = (int64_t)d.M * d.N * nbatch;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
+    if (d.dtype == RALF_F32) hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, P, nbatch);
+    else hipLaunchKernelGGL((splitk_reduce_kernel<bf16>), dim3(blocks), dim3(256), 0, st, P, nbatch);
+    return ralf::check_launch("gemm splitk reduce");
+}

@@ -1,0 +1,108 @@
+"""GPU numerics: ralf_gemm (through the C ABI) vs a plain torch fp32 reference of the same product."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: dict(atol=2e-5, rtol=1e-5), torch.bfloat16: dict(atol=3e-2, rtol=2e-2)}
+
+
+def rnd(*shape, seed=0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g).to(dtype)
+
+
+def ref_mm(a, b):
+    return a.float() @ b.float()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, False), (False, True)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 77, 100), (33, 518, 256), (1000, 256, 1024), (5, 3, 8)])
+def test_layouts(dtype, ak, bk, M, N, K):
+    from ralf_amd import ops
+
+    A = rnd(M, K, seed=1, dtype=dtype)   # asymmetric operands catch transposed fragments
+    B = rnd(K, N, seed=2, dtype=dtype)
+    ref = ref_mm(A, B)
+    Ad = (A if ak else A.t().contiguous()).cuda()
+    Bd = (B.t().contiguous() if bk else B).cuda()
+    C = ops.gemm(Ad, Bd, M, N, K, a_kcontig=ak, b_kcontig=bk)
+    scale = K ** 0.5
+    torch.testing.assert_close(C.float().cpu() / scale, ref / scale, **TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_epilogues_and_splitk(dtype):
+    from ralf_amd import ops
+
+    M, N, K = 300, 200, 512
+    A, W = rnd(M, K, seed=3, dtype=dtype), rnd(N, K, seed=4, dtype=dtype) * 0.05
+    bias, res = rnd(N, seed=5), rnd(M, N, seed=6, dtype=dtype)
+    z = A.float() @ W.float().t() * 0.5 + bias
+    for act, fn in [("relu", torch.relu), ("gelu", F.gelu), (None, lambda v: v)]:
+        pre = torch.empty(M, N, dtype=dtype, device="cuda")
+        C = ops.gemm(A.cuda(), W.cuda(), M, N, K, bias=bias.cuda(), act=act, res=res.cuda(), alpha=0.5, out2=pre)
+        torch.testing.assert_close(C.float().cpu(), fn(z) + res.float(), **TOL[dtype])
+        torch.testing.assert_close(pre.float().cpu(), z, **TOL[dtype])
+    # activation-gradient masks
+    y = torch.relu(z).to(dtype)
+    C = ops.gemm(A.cuda(), W.cuda(), M, N, K, aux=y.cuda(), aux_mode="relu_mask", aux_scale=2.0)
+    torch.testing.assert_close(C.float().cpu(), (A.float() @ W.float().t()) * (y.float() > 0) * 2.0, **TOL[dtype])
+    C = ops.gemm(A.cuda(), W.cuda(), M, N, K, aux=z.to(dtype).cuda(), aux_mode="gelu_grad")
+    zz = z.to(dtype).float().requires_grad_(True)
+    F.gelu(zz).sum().backward()
+    torch.testing.assert_close(C.float().cpu(), (A.float() @ W.float().t()) * zz.grad, **TOL[dtype])
+    # split-K (weight-gradient shape): dW[N,K'] = dY^T X, fp32 output, accumulate
+    Mr = 4096
+    dY, X = rnd(Mr, 96, seed=7, dtype=dtype), rnd(Mr, 160, seed=8, dtype=dtype)
+    out = torch.ones(96, 160, device="cuda")
+    ops.gemm(dY.cuda(), X.cuda(), 96, 160, Mr, a_kcontig=False, b_kcontig=False, out=out, splitk=8, accumulate=True)
+    torch.testing.assert_close(out.cpu() / 64, (dY.float().t() @ X.float() + 1) / 64, **TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_strided(dtype):
+    """two-level batch (b, h) with strided heads, as attention-style products use it."""
+    from ralf_amd import ops
+
+    Bn, H, S, dh = 3, 4, 50, 32
+    q, k = rnd(Bn, S, H * dh, seed=9, dtype=dtype), rnd(Bn, S, H * dh, seed=10, dtype=dtype)
+    ref = torch.einsum("bshd,bthd->bhst", q.float().view(Bn, S, H, dh), k.float().view(Bn, S, H, dh))
+    out = ops.gemm(q.cuda(), k.cuda(), S, S, dh, lda=H * dh, ldb=H * dh, batch=(H, Bn), sA=(dh, S * H * dh), sB=(dh, S * H * dh))
+    torch.testing.assert_close(out.float().cpu(), ref, **TOL[dtype])
+
+
+CONVS = [  # (B, H, W, Cin, Cout, k, stride, pad)
+    (2, 16, 12, 8, 64, 7, 2, 3), (2, 9, 7, 16, 24, 3, 1, 1), (2, 10, 8, 16, 32, 3, 2, 1), (3, 6, 5, 32, 16, 1, 1, 0), (2, 8, 8, 16, 40, 1, 2, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_gather(dtype, cfg):
+    """implicit-im2col forward / data-gradient / weight-gradient vs torch conv2d autograd (NCHW fp32)."""
+    from ralf_amd import ops
+
+    Bn, H, W, Ci, Co, k, s, p = cfg
+    x = rnd(Bn, Ci, H, W, seed=11, dtype=dtype).float().requires_grad_(True)
+    w = (rnd(Co, Ci, k, k, seed=12, dtype=dtype) * 0.1).float().requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    OH, OW = y.shape[2:]
+    gy = rnd(*y.shape, seed=13, dtype=dtype).float()
+    y.backward(gy)
+    xn = x.detach().permute(0, 2, 3, 1).contiguous().to(dtype).cuda()           # NHWC
+    w_ohwi = w.detach().permute(0, 2, 3, 1).contiguous().to(dtype).cuda()        # [Co][kh][kw][ci]
+    w_dgrad = w.detach().permute(1, 2, 3, 0).contiguous().to(dtype).cuda()       # [Ci][kh][kw][co]
+    gyn = gy.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    Mo, Mi, Kf = Bn * OH * OW, Bn * H * W, k * k * Ci
+    geom_f = dict(RH=OH, RW=OW, SH=H, SW=W, SC=Ci, KH=k, KW=k, stride=s, pad=p, mode=0)
+    yo = ops.gemm(xn, w_ohwi, Mo, Co, Kf, conv=geom_f, gather=1)
+    torch.testing.assert_close(yo.float().cpu().view(Bn, OH, OW, Co).permute(0, 3, 1, 2), y.detach(), **TOL[dtype])
+    geom_d = dict(RH=H, RW=W, SH=OH, SW=OW, SC=Co, KH=k, KW=k, stride=s, pad=p, mode=1)
+    gx = ops.gemm(gyn, w_dgrad, Mi, Ci, k * k * Co, conv=geom_d, gather=1)
+    torch.testing.assert_close(gx.float().cpu().view(Bn, H, W, Ci).permute(0, 3, 1, 2), x.grad, **TOL[dtype])
+    gw = ops.gemm(gyn, xn, Co, Kf, Mo, a_kcontig=False, b_kcontig=False, conv=geom_f, gather=2, splitk=3, out_dtype=torch.float32)
+    tol = dict(atol=0.15, rtol=3e-2) if dtype == torch.bfloat16 else dict(atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(gw.cpu().view(Co, k, k, Ci).permute(0, 3, 1, 2), w.grad, **tol)
