@@ -95,6 +95,81 @@ typedef struct RalfGemmDesc {
 size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d);
 int ralf_gemm(const RalfGemmDesc* d, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm (nn.LayerNorm, eps 1e-5) -- x,y [rows, cols] dtype; gamma/beta/statistics fp32.
+ * bwd ACCUMULATES into dgamma/dbeta (fp32 [cols], may be NULL).   ralf_amd/csrc/norm.hip
+ * ------------------------------------------------------------------------------------------- */
+int ralf_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                       int rows, int cols, float eps, void* stream);
+int ralf_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                       void* dx, float* dgamma, float* dbeta, int rows, int cols, void* stream);
+/* out[c] += sum_r x[r*ld + c]   (bias gradients) */
+int ralf_colsum(int dtype, const void* x, int64_t ld, float* out, int rows, int cols, void* stream);
+
+/* BatchNorm2d on NHWC viewed as [M = B*H*W, C] (timm ResNet-50 BN, momentum 0.1, eps 1e-5).
+ * train: bn_stats (s1 = sum x, s2 = sum x^2; zero on entry) -> bn_finalize(training=1) -> bn_apply
+ * eval : bn_finalize(training=0) uses the running statistics.
+ * apply: y = relu?(x*scale + shift (+ res)).   backward: bn_bwd_reduce (s1 = sum g, s2 = sum g*xhat,
+ * g = dy*(y>0) when relu) then bn_bwd_apply -> dx (and dres = g).  dgamma = s2, dbeta = s1. */
+int ralf_bn_stats(int dtype, const void* x, float* s1, float* s2, int64_t M, int C, void* stream);
+int ralf_bn_finalize(const float* s1, const float* s2, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     float* mean, float* rstd, float* scale, float* shift, int64_t M, int C, float eps, float momentum, int training, void* stream);
+int ralf_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, int64_t M, int C, int relu, void* stream);
+int ralf_bn_bwd_reduce(int dtype, const void* x, const void* dy, const void* y, const float* mean, const float* rstd, float* s1, float* s2,
+                       int64_t M, int C, int relu, void* stream);
+int ralf_bn_bwd_apply(int dtype, const void* x, const void* dy, const void* y, const float* mean, const float* rstd, const float* gamma,
+                      const float* s1, const float* s2, void* dx, void* dres, int64_t M, int C, int relu, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gather / pointwise kernels (ralf_amd/csrc/pointwise.hip)
+ * ------------------------------------------------------------------------------------------- */
+/* out[r,:] = W[idx[r],:]*scale + pe[r % S,:]   (nn.Embedding -> PositionalEncoding1d, common/common.py:97-98) */
+int ralf_embed_fwd(int dtype, const int64_t* idx, const float* W, const float* pe, void* out, int64_t rows, int S, int d, float scale, void* stream);
+int ralf_embed_bwd(int dtype, const int64_t* idx, const void* dy, float* dW, int64_t rows, int d, float scale, void* stream);
+/* y = x*keep/(1-p), mask = f(seed[0], call_id, element index): the same call on dy is the backward */
+int ralf_dropout(int dtype, const void* x, void* y, int64_t n, float p, const int64_t* seed, uint64_t call_id, void* stream);
+/* nn.CrossEntropyLoss(label_smoothing, ignore_index) on fp32 logits [rows,V]: cnt_loss = {#valid, mean loss};
+ * dlogits (dtype, may be NULL) = d loss / d logits */
+int ralf_xent_fwd_bwd(int dtype, const float* logits, const int64_t* target, void* dlogits, float* cnt_loss, int64_t rows, int V,
+                      int ignore_index, float label_smoothing, void* stream);
+int ralf_add_scalar(int dtype, const void* x, const float* s, void* y, int64_t rows, int cols, int64_t ldx, int64_t ldy, void* stream);
+int ralf_sum_all(int dtype, const void* x, float* out, int64_t rows, int cols, int64_t ldx, void* stream);
+int ralf_copy2d(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t rows, int cols, int64_t lds, int64_t ldd, int accumulate, void* stream);
+int ralf_permute4(int src_dtype, int dst_dtype, const void* in, void* out, int d0, int d1, int d2, int d3, int64_t s0, int64_t s1, int64_t s2, int64_t s3,
+                  int valid3, void* stream);
+/* ResNet stem max-pool 3x3/s2/p1 (NHWC) with saved arg-max; FPN nearest up-sampling fused with the lateral add */
+int ralf_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int8_t* arg, int B, int H, int W, int C, void* stream);
+int ralf_maxpool3x3s2_bwd(int dtype, const void* dy, const int8_t* arg, void* dx, int B, int H, int W, int C, void* stream);
+int ralf_upsample_nearest_add(int dtype, const void* src, const void* lateral, void* up, int64_t ld_up, void* sum, int B, int IH, int IW, int OH, int OW, int C, void* stream);
+int ralf_upsample_nearest_bwd(int dtype, const void* g_up, int64_t ld_up, const void* g_sum, void* dsrc, int B, int IH, int IW, int OH, int OW, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused attention (ralf_amd/csrc/attention.hip): O = dropout(softmax(scale*Q K^T + mask)) V.
+ * Operands are [B, S, H*dh]-style views: element (b, s, h, c) at base + b*bs + s*rs + h*dh + c.
+ * kpm: uint8 [B, Sk], 1 = padded key (masked).  lse/delta: fp32 [B, H, Sq] (saved for backward).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct RalfAttnDesc {
+    const void* q; const void* k; const void* v; void* o;
+    const void* dout; void* dq; void* dk; void* dv;
+    float* lse; float* delta;
+    const uint8_t* kpm; const int64_t* seed;
+    int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
+    int64_t do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+    uint64_t call_id;
+    int B, H, Sq, Sk, dh, dtype, causal;
+    float scale, p_drop;
+} RalfAttnDesc;
+int ralf_attention_fwd(const RalfAttnDesc* d, void* stream);
+int ralf_attention_bwd(const RalfAttnDesc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer (ralf_amd/csrc/optim.hip): clip_grad_norm_ + AdamW on flat fp32 buffers
+ * ------------------------------------------------------------------------------------------- */
+int ralf_sumsq(const float* g, int64_t n, float* out, void* stream);
+int ralf_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream);
+int ralf_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1, float beta2, float eps,
+               float weight_decay, int step, const float* coef, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,3 +33,45 @@ SIGNATURES.update({
     "ralf_gemm_workspace_bytes": (sz, [ctypes.POINTER(RalfGemmDesc)]),
     "ralf_gemm": (i32, [ctypes.POINTER(RalfGemmDesc), vp, sz, vp]),
 })
+
+u64, u8p = ctypes.c_uint64, vp
+
+
+class RalfAttnDesc(ctypes.Structure):
+    _fields_ = (
+        [(n, vp) for n in ("q", "k", "v", "o", "dout", "dq", "dk", "dv", "lse", "delta", "kpm", "seed")]
+        + [(n, i64) for n in ("q_bs", "q_rs", "k_bs", "k_rs", "v_bs", "v_rs", "o_bs", "o_rs",
+                              "do_bs", "do_rs", "dq_bs", "dq_rs", "dk_bs", "dk_rs", "dv_bs", "dv_rs")]
+        + [("call_id", u64)]
+        + [(n, i32) for n in ("B", "H", "Sq", "Sk", "dh", "dtype", "causal")]
+        + [("scale", f32), ("p_drop", f32)]
+    )
+
+
+SIGNATURES.update({
+    "ralf_layernorm_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
+    "ralf_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "ralf_colsum": (i32, [i32, vp, i64, vp, i32, i32, vp]),
+    "ralf_bn_stats": (i32, [i32, vp, vp, vp, i64, i32, vp]),
+    "ralf_bn_finalize": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp]),
+    "ralf_bn_apply": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "ralf_bn_bwd_reduce": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "ralf_bn_bwd_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "ralf_embed_fwd": (i32, [i32, vp, vp, vp, vp, i64, i32, i32, f32, vp]),
+    "ralf_embed_bwd": (i32, [i32, vp, vp, vp, i64, i32, f32, vp]),
+    "ralf_dropout": (i32, [i32, vp, vp, i64, f32, vp, u64, vp]),
+    "ralf_xent_fwd_bwd": (i32, [i32, vp, vp, vp, vp, i64, i32, i32, f32, vp]),
+    "ralf_add_scalar": (i32, [i32, vp, vp, vp, i64, i32, i64, i64, vp]),
+    "ralf_sum_all": (i32, [i32, vp, vp, i64, i32, i64, vp]),
+    "ralf_copy2d": (i32, [i32, i32, vp, vp, i64, i32, i64, i64, i32, vp]),
+    "ralf_permute4": (i32, [i32, i32, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, i32, vp]),
+    "ralf_maxpool3x3s2_fwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "ralf_maxpool3x3s2_bwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "ralf_upsample_nearest_add": (i32, [i32, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ralf_upsample_nearest_bwd": (i32, [i32, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ralf_attention_fwd": (i32, [ctypes.POINTER(RalfAttnDesc), vp]),
+    "ralf_attention_bwd": (i32, [ctypes.POINTER(RalfAttnDesc), vp]),
+    "ralf_sumsq": (i32, [vp, i64, vp, vp]),
+    "ralf_clip_coef": (i32, [vp, f32, vp, vp, vp]),
+    "ralf_adamw": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, vp]),
+})

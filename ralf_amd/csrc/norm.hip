@@ -1,0 +1,374 @@
+// LayerNorm and BatchNorm2d (NHWC) forward / backward for gfx950 -- HBM-bound wave64 reduction
+// kernels (no MFMA: these are byte-moving ops, sized to the memory roofline).
+//
+// Replaces nn.LayerNorm inside nn.TransformerEncoderLayer/DecoderLayer, FeedForward, Attention and
+// BaseDecoder.head (image2layout/train/models/common/attention.py:19,41; common/common.py:38-40) and
+// the nn.BatchNorm2d layers of the timm ResNet-50 body (common/image.py:39-67), train mode = batch
+// statistics, momentum 0.1, eps 1e-5, unbiased running_var.
+#include "common.h"
+
+namespace {
+typedef __bf16 bf16;
+
+template <typename T> struct V4;  // 4 consecutive elements
+template <> struct V4<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct V4<bf16> {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ void load(const bf16* p, float (&v)[4]) { bf16x4 t = *reinterpret_cast<const bf16x4*>(p); for (int i = 0; i < 4; ++i) v[i] = (float)t[i]; }
+    static __device__ __forceinline__ void store(bf16* p, const float (&v)[4]) { bf16x4 t; for (int i = 0; i < 4; ++i) t[i] = (bf16)v[i]; *reinterpret_cast<bf16x4*>(p) = t; }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, lane l owns columns {c*256 + 4l .. +3}; cols % 256 == 0, <= 1024
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int rows, float eps) {
+    constexpr int cols = NCH * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        float v[NCH][4];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            V4<T>::load(x + (int64_t)row * cols + c * 256 + lane * 4, v[c]);
+            s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+        }
+        const float mu = wave_sum(s) * (1.f / cols);
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float d = v[c][i] - mu; q += d * d; }
+        const float rs = rsqrtf(wave_sum(q) * (1.f / cols) + eps);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            float g[4], b[4], o[4];
+            V4<float>::load(gamma + c * 256 + lane * 4, g);
+            V4<float>::load(beta + c * 256 + lane * 4, b);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (v[c][i] - mu) * rs * g[i] + b[i];
+            V4<T>::store(y + (int64_t)row * cols + c * 256 + lane * 4, o);
+        }
+        if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+// dx per row + per-workgroup partial dgamma/dbeta (registers -> LDS -> one fp32 atomic per column)
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows) {
+    constexpr int cols = NCH * 256;
+    __shared__ float red[2][4][cols];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float ag[NCH][4], ab[NCH][4], g[NCH][4];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        V4<float>::load(gamma + c * 256 + lane * 4, g[c]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ag[c][i] = ab[c][i] = 0.f;
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float d[NCH][4], xh[NCH][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            float xv[4];
+            V4<T>::load(dy + (int64_t)row * cols + c * 256 + lane * 4, d[c]);
+            V4<T>::load(x + (int64_t)row * cols + c * 256 + lane * 4, xv);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xh[c][i] = (xv[i] - mu) * rs;
+                ag[c][i] += d[c][i] * xh[c][i];
+                ab[c][i] += d[c][i];
+                const float dg = d[c][i] * g[c][i];
+                s1 += dg; s2 += dg * xh[c][i];
+            }
+        }
+        s1 = wave_sum(s1) * (1.f / cols);
+        s2 = wave_sum(s2) * (1.f / cols);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = rs * (d[c][i] * g[c][i] - s1 - xh[c][i] * s2);
+            V4<T>::store(dx + (int64_t)row * cols + c * 256 + lane * 4, o);
+        }
+    }
+    if (dgamma) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { red[0][wave][c * 256 + lane * 4 + i] = ag[c][i]; red[1][wave][c * 256 + lane * 4 + i] = ab[c][i]; }
+        __syncthreads();
+        for (int c = threadIdx.x; c < cols; c += 256) {
+            atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+            atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sums over rows of a [rows, cols] matrix (bias gradients): out[c] += sum_r x[r][c]
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t ld, float* __restrict__ out, int rows, int cols, int rows_per_wg) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const int r0 = blockIdx.y * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
+    float s = 0.f;
+    if (c < cols)
+        for (int r = r0 + ty; r < r1; r += 4) s += (float)x[(int64_t)r * ld + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < cols) atomicAdd(out + c, red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm2d on NHWC viewed as [M = B*H*W, C]; a thread owns 4 consecutive channels
+// ---------------------------------------------------------------------------------------------
+// mode 0: s1 = sum x, s2 = sum x^2          (forward statistics)
+// mode 1: s1 = sum g, s2 = sum g * xhat     (backward), g = dy masked by (y > 0) when relu
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         float* __restrict__ s1, float* __restrict__ s2, int64_t M, int C, int relu) {
+    __shared__ float red[2][256][4];
+    const int cv = C >> 2;                       // channel vectors per row
+    const int tpr = cv < 256 ? cv : 256;         // threads per row (power of two or 256)
+    const int rpi = 256 / tpr;                   // rows per iteration
+    const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr;
+    const int c0 = (blockIdx.y * 256 + tx) * 4;
+    float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    if (c0 < C) {
+        float mu[4] = {0, 0, 0, 0}, rs[4] = {1, 1, 1, 1};
+        if (MODE == 1) { V4<float>::load(mean + c0, mu); V4<float>::load(rstd + c0, rs); }
+        for (int64_t r = (int64_t)blockIdx.x * rpi + ty; r < M; r += (int64_t)gridDim.x * rpi) {
+            float xv[4];
+            V4<T>::load(x + r * C + c0, xv);
+            if (MODE == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { a1[i] += xv[i]; a2[i] += xv[i] * xv[i]; }
+            } else {
+                float g[4];
+                V4<T>::load(dy + r * C + c0, g);
+                if (relu) {
+                    float yv[4];
+                    V4<T>::load(y + r * C + c0, yv);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { a1[i] += g[i]; a2[i] += g[i] * (xv[i] - mu[i]) * rs[i]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[0][threadIdx.x][i] = a1[i]; red[1][threadIdx.x][i] = a2[i]; }
+    __syncthreads();
+    if (ty == 0 && c0 < C) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int j = 0; j < rpi; ++j) { t1 += red[0][j * tpr + tx][i]; t2 += red[1][j * tpr + tx][i]; }
+            atomicAdd(s1 + c0 + i, t1);
+            atomicAdd(s2 + c0 + i, t2);
+        }
+    }
+}
+
+// training: batch mean / biased var -> (mean, rstd, scale, shift) and running-stat update (unbiased var)
+// eval: scale/shift from the running statistics
+__global__ void bn_finalize_kernel(const float* __restrict__ s1, const float* __restrict__ s2, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift,
+                                   int64_t M, int C, float eps, float momentum, int training) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float mu, var;
+    if (training) {
+        mu = s1[c] / (float)M;
+        var = fmaxf(s2[c] / (float)M - mu * mu, 0.f);
+        if (running_mean) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * ((float)M / (float)(M > 1 ? M - 1 : 1));
+        }
+    } else {
+        mu = running_mean[c];
+        var = running_var[c];
+    }
+    const float rs = rsqrtf(var + eps);
+    mean[c] = mu; rstd[c] = rs;
+    scale[c] = gamma[c] * rs;
+    shift[c] = beta[c] - mu * gamma[c] * rs;
+}
+
+// y = relu?( x*scale + shift (+ res) )
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        const T* __restrict__ res, T* __restrict__ y, int64_t total4, int C, int relu) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)((e * 4) % C);
+        float xv[4], sc[4], sh[4], o[4];
+        V4<T>::load(x + e * 4, xv);
+        V4<float>::load(scale + c0, sc);
+        V4<float>::load(shift + c0, sh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = xv[i] * sc[i] + sh[i];
+        if (res) {
+            float rv[4];
+            V4<T>::load(res + e * 4, rv);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] += rv[i];
+        }
+        if (relu) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = fmaxf(o[i], 0.f);
+        }
+        V4<T>::store(y + e * 4, o);
+    }
+}
+
+// dx = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M);  dres = g (gradient of the fused residual add)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ s1, const float* __restrict__ s2, T* __restrict__ dx, T* __restrict__ dres,
+                                                            int64_t total4, int C, float invM, int relu) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)((e * 4) % C);
+        float xv[4], g[4], mu[4], rs[4], gm[4], a1[4], a2[4], o[4];
+        V4<T>::load(x + e * 4, xv);
+        V4<T>::load(dy + e * 4, g);
+        if (relu) {
+            float yv[4];
+            V4<T>::load(y + e * 4, yv);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
+        }
+        V4<float>::load(mean + c0, mu); V4<float>::load(rstd + c0, rs); V4<float>::load(gamma + c0, gm);
+        V4<float>::load(s1 + c0, a1); V4<float>::load(s2 + c0, a2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float xh = (xv[i] - mu[i]) * rs[i];
+            o[i] = gm[i] * rs[i] * (g[i] - a1[i] * invM - xh * a2[i] * invM);
+        }
+        V4<T>::store(dx + e * 4, o);
+        if (dres) V4<T>::store(dres + e * 4, g);
+    }
+}
+
+inline int grid_for(int64_t work_items, int per_block, int cap = 2048) {
+    int64_t b = (work_items + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                                            \
+    do {                                                                  \
+        if ((dtype) == RALF_F32) { typedef float T; __VA_ARGS__; }        \
+        else if ((dtype) == RALF_BF16) { typedef bf16 T; __VA_ARGS__; }   \
+        else { ralf::set_error("bad dtype %d", (dtype)); return RALF_ERR_INVALID; } \
+    } while (0)
+
+extern "C" int ralf_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                  int rows, int cols, float eps, void* stream) {
+    RALF_REQUIRE(x && gamma && beta && y, "layernorm_fwd: null pointer");
+    RALF_REQUIRE(rows > 0 && cols % 256 == 0 && cols <= 1024, "layernorm_fwd: cols=%d must be a multiple of 256, <= 1024", cols);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(rows, 4);
+    DISPATCH_T(dtype, switch (cols / 256) {
+        case 1: hipLaunchKernelGGL((ln_fwd_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, eps); break;
+        case 2: hipLaunchKernelGGL((ln_fwd_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, eps); break;
+        case 3: hipLaunchKernelGGL((ln_fwd_kernel<T, 3>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, eps); break;
+        default: hipLaunchKernelGGL((ln_fwd_kernel<T, 4>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, eps); break;
+    });
+    return ralf::check_launch("layernorm_fwd");
+}
+
+/* dgamma/dbeta (fp32 [cols]) are ACCUMULATED into (caller zeroes or carries gradients); may be NULL */
+extern "C" int ralf_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                  void* dx, float* dgamma, float* dbeta, int rows, int cols, void* stream) {
+    RALF_REQUIRE(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
+    RALF_REQUIRE(rows > 0 && cols % 256 == 0 && cols <= 512, "layernorm_bwd: cols=%d must be 256 or 512", cols);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(rows, 64, 1024);
+    DISPATCH_T(dtype, if (cols == 256)
+                   hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows);
+               else
+                   hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows););
+    return ralf::check_launch("layernorm_bwd");
+}
+
+/* out[c] += sum_r x[r*ld + c]   (fp32 accumulate into out) */
+extern "C" int ralf_colsum(int dtype, const void* x, int64_t ld, float* out, int rows, int cols, void* stream) {
+    RALF_REQUIRE(x && out && rows > 0 && cols > 0, "colsum: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int cb = ceil_div(cols, 64);
+    int rchunks = 1024 / cb;
+    if (rchunks < 1) rchunks = 1;
+    int rpw = ceil_div(rows, rchunks);
+    if (rpw < 64) rpw = 64;
+    rchunks = ceil_div(rows, rpw);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3(cb, rchunks), dim3(256), 0, st, (const T*)x, ld, out, rows, cols, rpw));
+    return ralf::check_launch("colsum");
+}
+
+/* sums s1,s2 (fp32 [C]) must be zero on entry. */
+extern "C" int ralf_bn_stats(int dtype, const void* x, float* s1, float* s2, int64_t M, int C, void* stream) {
+    RALF_REQUIRE(x && s1 && s2 && M > 0, "bn_stats: bad arguments");
+    RALF_REQUIRE(C % 4 == 0 && (((C / 4) & (C / 4 - 1)) == 0 || (C / 4) % 256 == 0), "bn_stats: C=%d unsupported", C);
+    hipStream_t st = (hipStream_t)stream;
+    const int cv = C / 4, tpr = cv < 256 ? cv : 256, rpi = 256 / tpr, gy = ceil_div(cv, 256);
+    const int gx = grid_for(M, rpi * 32, 2048 / gy);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, nullptr, nullptr, nullptr, nullptr, s1, s2, M, C, 0));
+    return ralf::check_launch("bn_stats");
+}
+
+extern "C" int ralf_bn_finalize(const float* s1, const float* s2, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                float* mean, float* rstd, float* scale, float* shift, int64_t M, int C, float eps, float momentum, int training, void* stream) {
+    RALF_REQUIRE(gamma && beta && mean && rstd && scale && shift, "bn_finalize: null pointer");
+    RALF_REQUIRE(training ? (s1 && s2) : (running_mean && running_var), "bn_finalize: missing statistics");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, s1, s2, gamma, beta, running_mean, running_var, mean, rstd, scale, shift, M, C, eps, momentum, training);
+    return ralf::check_launch("bn_finalize");
+}
+
+extern "C" int ralf_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, int64_t M, int C, int relu, void* stream) {
+    RALF_REQUIRE(x && scale && shift && y && C % 4 == 0, "bn_apply: bad arguments");
+    const int64_t total4 = M * C / 4;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(total4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale, shift, (const T*)res, (T*)y, total4, C, relu));
+    return ralf::check_launch("bn_apply");
+}
+
+/* backward reductions: s1 = sum g, s2 = sum g*xhat (zero on entry); g = dy * (y>0) when relu */
+extern "C" int ralf_bn_bwd_reduce(int dtype, const void* x, const void* dy, const void* y, const float* mean, const float* rstd, float* s1, float* s2,
+                                  int64_t M, int C, int relu, void* stream) {
+    RALF_REQUIRE(x && dy && mean && rstd && s1 && s2 && (!relu || y), "bn_bwd_reduce: bad arguments");
+    RALF_REQUIRE(C % 4 == 0 && (((C / 4) & (C / 4 - 1)) == 0 || (C / 4) % 256 == 0), "bn_bwd_reduce: C=%d unsupported", C);
+    hipStream_t st = (hipStream_t)stream;
+    const int cv = C / 4, tpr = cv < 256 ? cv : 256, rpi = 256 / tpr, gy = ceil_div(cv, 256);
+    const int gx = grid_for(M, rpi * 32, 2048 / gy);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 1>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, s1, s2, M, C, relu));
+    return ralf::check_launch("bn_bwd_reduce");
+}
+
+extern "C" int ralf_bn_bwd_apply(int dtype, const void* x, const void* dy, const void* y, const float* mean, const float* rstd, const float* gamma,
+                                 const float* s1, const float* s2, void* dx, void* dres, int64_t M, int C, int relu, void* stream) {
+    RALF_REQUIRE(x && dy && mean && rstd && gamma && s1 && s2 && dx && (!relu || y), "bn_bwd_apply: bad arguments");
+    const int64_t total4 = M * C / 4;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(total4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, s1, s2, (T*)dx, (T*)dres, total4, C, 1.f / (float)M, relu));
+    return ralf::check_launch("bn_bwd_apply");
+}

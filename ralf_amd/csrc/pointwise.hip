@@ -1,0 +1,352 @@
+// HBM-bound byte/gather kernels of the RALF train step for gfx950: token-embedding gather (+ x sqrt(d)
+// + positional table), counter-based dropout, label-smoothed cross-entropy, scalar-flag add, dtype
+// casts / weight re-layouts, NCHW->NHWC image packing, 3x3/s2 max-pool and nearest up-sampling.
+//
+// Reference call sites (paths relative to the reference root):
+//   BaseDecoder.forward / UserConstraintTransformerEncoder.forward: emb -> PositionalEncoding1d
+//       image2layout/train/models/common/common.py:97-98,245-246; common/positional_encoding.py:92-107
+//   nn.Dropout sites of nn.Transformer*Layer, PositionalEncoding1d
+//   nn.CrossEntropyLoss(label_smoothing=0.1, ignore_index=pad)  retrieval_augmented_autoreg.py:140-142,213-214
+//   task_emb flag add                                            retrieval_augmented_autoreg.py:1022-1028
+//   ResnetBackbone max-pool / F.interpolate(nearest)            common/image.py:66-67,103-105
+#include "common.h"
+
+namespace {
+typedef __bf16 bf16;
+
+template <typename T> __device__ __forceinline__ float ld(const T* p, int64_t i) { return (float)p[i]; }
+template <typename T> __device__ __forceinline__ void st(T* p, int64_t i, float v) { p[i] = (T)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// stateless counter-based RNG: 24 uniform bits from (seed, stream id, element index)
+__device__ __forceinline__ uint32_t rng24(uint64_t seed, uint64_t call, uint64_t idx) {
+    uint64_t z = seed + call * 0x9E3779B97F4A7C15ull + idx * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 40);
+}
+
+inline int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
+    int64_t b = (n + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// out[r][:] = W[idx[r]][:] * scale + pe[r % S][:]
+template <typename T>
+__global__ void embed_fwd_kernel(const int64_t* __restrict__ idx, const float* __restrict__ W, const float* __restrict__ pe, T* __restrict__ out,
+                                 int64_t rows, int S, int d, float scale) {
+    const int64_t total = rows * d;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / d;
+        const int c = (int)(e - r * d);
+        float v = W[idx[r] * d + c] * scale;
+        if (pe) v += pe[(int64_t)(r % S) * d + c];
+        st(out, e, v);
+    }
+}
+template <typename T>
+__global__ void embed_bwd_kernel(const int64_t* __restrict__ idx, const T* __restrict__ dy, float* __restrict__ dW, int64_t rows, int d, float scale) {
+    const int64_t total = rows * d;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / d;
+        atomicAdd(dW + idx[r] * d + (e - r * d), ld(dy, e) * scale);
+    }
+}
+
+// y = x * keep/(1-p); the same call regenerates the same mask (used for the gradient)
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p, const int64_t* __restrict__ seed, uint64_t call) {
+    const uint64_t s = (uint64_t)seed[0];
+    const uint32_t thr = (uint32_t)(p * 16777216.f);
+    const float inv = 1.f / (1.f - p);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
+        st(y, e, rng24(s, call, (uint64_t)e) >= thr ? ld(x, e) * inv : 0.f);
+}
+
+// label-smoothed cross entropy, one wave per row of fp32 logits [rows, V]
+__global__ void xent_count_kernel(const int64_t* __restrict__ target, int64_t rows, int ignore_index, float* __restrict__ cnt_loss) {
+    __shared__ float red[4];
+    float c = 0.f;
+    for (int64_t r = threadIdx.x; r < rows; r += 256) c += (target[r] != ignore_index);
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { cnt_loss[0] = red[0] + red[1] + red[2] + red[3]; cnt_loss[1] = 0.f; }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, T* __restrict__ dlogits,
+                                                    float* __restrict__ cnt_loss, int64_t rows, int V, int ignore_index, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_cnt = 1.f / cnt_loss[0];
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+        const float* x = logits + r * V;
+        const int64_t t = target[r];
+        if (t == ignore_index) {
+            if (dlogits) for (int c = lane; c < V; c += 64) st(dlogits, r * V + c, 0.f);
+            continue;
+        }
+        float mx = -__builtin_inff(), sx = 0.f;
+        for (int c = lane; c < V; c += 64) { mx = fmaxf(mx, x[c]); sx += x[c]; }
+        mx = wave_max(mx);
+        sx = wave_sum(sx);
+        float se = 0.f;
+        for (int c = lane; c < V; c += 64) se += __expf(x[c] - mx);
+        se = wave_sum(se);
+        const float lse = mx + __logf(se);
+        if (lane == 0) atomicAdd(cnt_loss + 1, ((1.f - eps) * (lse - x[t]) + eps * (lse - sx / V)) * inv_cnt);
+        if (dlogits)
+            for (int c = lane; c < V; c += 64)
+                st(dlogits, r * V + c, (__expf(x[c] - lse) - (c == t ? 1.f - eps : 0.f) - eps / V) * inv_cnt);
+    }
+}
+
+// y = x + s[0]  (learned scalar flag broadcast over all channels);  sum_all: out[0] += sum x
+template <typename T>
+__global__ void add_scalar_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ y, int64_t rows, int cols, int64_t ldx, int64_t ldy) {
+    const float sv = s[0];
+    const int64_t total = rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / cols;
+        const int c = (int)(e - r * cols);
+        st(y, r * ldy + c, ld(x, r * ldx + c) + sv);
+    }
+}
+template <typename T>
+__global__ void sum_all_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t rows, int cols, int64_t ldx) {
+    __shared__ float red[4];
+    float a = 0.f;
+    const int64_t total = rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / cols;
+        a += ld(x, r * ldx + (e - r * cols));
+    }
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// strided 2-D copy with dtype conversion (concat / slice / cast): dst[r*ldd + c] = src[r*lds + c]
+template <typename TS, typename TD>
+__global__ void copy2d_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t rows, int cols, int64_t lds, int64_t ldd, int accumulate) {
+    const int64_t total = rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / cols;
+        const int c = (int)(e - r * cols);
+        float v = ld(src, r * lds + c);
+        if (accumulate) v += ld(dst, r * ldd + c);
+        st(dst, r * ldd + c, v);
+    }
+}
+
+// 4-D permute with conversion and zero padding of the (new) innermost dim:
+// out[i0][i1][i2][i3] (dims od[], innermost padded to od[3] >= source extent) = in[...] with in-stride per out-dim
+template <typename TS, typename TD>
+__global__ void permute4_kernel(const TS* __restrict__ in, TD* __restrict__ out, int d0, int d1, int d2, int d3, int64_t s0, int64_t s1, int64_t s2, int64_t s3, int valid3) {
+    const int64_t total = (int64_t)d0 * d1 * d2 * d3;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        int64_t t = e;
+        const int i3 = (int)(t % d3); t /= d3;
+        const int i2 = (int)(t % d2); t /= d2;
+        const int i1 = (int)(t % d1); t /= d1;
+        const int i0 = (int)t;
+        st(out, e, i3 < valid3 ? ld(in, i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3) : 0.f);
+    }
+}
+
+// 3x3 stride-2 pad-1 max pooling, NHWC; arg = window position (kh*3+kw) of the FIRST maximum
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int8_t* __restrict__ arg, int B, int H, int W, int C, int OH, int OW) {
+    const int64_t total = (int64_t)B * OH * OW * C;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        int64_t t = e;
+        const int c = (int)(t % C); t /= C;
+        const int ow = (int)(t % OW); t /= OW;
+        const int oh = (int)(t % OH);
+        const int b = (int)(t / OH);
+        float best = -__builtin_inff();
+        int bi = -1;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * 2 - 1 + kh;
+            if (ih < 0 || ih >= H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * 2 - 1 + kw;
+                if (iw < 0 || iw >= W) continue;
+                const float v = ld(x, (((int64_t)b * H + ih) * W + iw) * C + c);
+                if (bi < 0 || v > best) { best = v; bi = kh * 3 + kw; }
+            }
+        }
+        st(y, e, best);
+        arg[e] = (int8_t)bi;
+    }
+}
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const int8_t* __restrict__ arg, T* __restrict__ dx, int B, int H, int W, int C, int OH, int OW) {
+    const int64_t total = (int64_t)B * H * W * C;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        int64_t t = e;
+        const int c = (int)(t % C); t /= C;
+        const int iw = (int)(t % W); t /= W;
+        const int ih = (int)(t % H);
+        const int b = (int)(t / H);
+        float g = 0.f;
+        for (int oh = (ih - 1 + 1) / 2; oh <= (ih + 1) / 2; ++oh) {   // oh*2-1+kh == ih, kh in [0,2]
+            if (oh < 0 || oh >= OH) continue;
+            const int kh = ih - (oh * 2 - 1);
+            if (kh < 0 || kh > 2) continue;
+            for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow) {
+                if (ow < 0 || ow >= OW) continue;
+                const int kw = iw - (ow * 2 - 1);
+                if (kw < 0 || kw > 2) continue;
+                const int64_t o = (((int64_t)b * OH + oh) * OW + ow) * C + c;
+                if (arg[o] == kh * 3 + kw) g += ld(dy, o);
+            }
+        }
+        st(dx, e, g);
+    }
+}
+
+// nearest up-sampling (torch semantics: src = min(floor(dst * in/out), in-1)) fused with the FPN add:
+//   up[b,y,x,:]  = src[b,sy,sx,:]  -> written with row stride ld_up (into the concat buffer)
+//   sum[b,y,x,:] = up + lateral
+template <typename T>
+__global__ void upsample_add_kernel(const T* __restrict__ src, const T* __restrict__ lateral, T* __restrict__ up, int64_t ld_up, T* __restrict__ sum,
+                                    int B, int IH, int IW, int OH, int OW, int C) {
+    const float sy_scale = (float)IH / OH, sx_scale = (float)IW / OW;
+    const int64_t total = (int64_t)B * OH * OW * C;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        int64_t t = e;
+        const int c = (int)(t % C); t /= C;
+        const int x = (int)(t % OW); t /= OW;
+        const int y = (int)(t % OH);
+        const int b = (int)(t / OH);
+        const int sy = min((int)floorf(y * sy_scale), IH - 1), sx = min((int)floorf(x * sx_scale), IW - 1);
+        const float v = ld(src, (((int64_t)b * IH + sy) * IW + sx) * C + c);
+        st(up, (e / C) * ld_up + c, v);
+        st(sum, e, v + ld(lateral, e));
+    }
+}
+// dsrc[b,sy,sx,:] = sum over destination pixels mapping to (sy,sx) of (g1[dst] (row stride ld1) + g2[dst])
+template <typename T>
+__global__ void upsample_bwd_kernel(const T* __restrict__ g1, int64_t ld1, const T* __restrict__ g2, T* __restrict__ dsrc,
+                                    int B, int IH, int IW, int OH, int OW, int C) {
+    const float sy_scale = (float)IH / OH, sx_scale = (float)IW / OW;
+    const int64_t total = (int64_t)B * IH * IW * C;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        int64_t t = e;
+        const int c = (int)(t % C); t /= C;
+        const int sx = (int)(t % IW); t /= IW;
+        const int sy = (int)(t % IH);
+        const int b = (int)(t / IH);
+        float g = 0.f;
+        for (int y = 0; y < OH; ++y) {
+            if (min((int)floorf(y * sy_scale), IH - 1) != sy) continue;
+            for (int x = 0; x < OW; ++x) {
+                if (min((int)floorf(x * sx_scale), IW - 1) != sx) continue;
+                const int64_t p = ((int64_t)b * OH + y) * OW + x;
+                g += ld(g1, p * ld1 + c) + ld(g2, p * C + c);
+            }
+        }
+        st(dsrc, e, g);
+    }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                                            \
+    do {                                                                  \
+        if ((dtype) == RALF_F32) { typedef float T; __VA_ARGS__; }        \
+        else if ((dtype) == RALF_BF16) { typedef bf16 T; __VA_ARGS__; }   \
+        else { ralf::set_error("bad dtype %d", (dtype)); return RALF_ERR_INVALID; } \
+    } while (0)
+#define ST ((hipStream_t)stream)
+
+extern "C" int ralf_embed_fwd(int dtype, const int64_t* idx, const float* W, const float* pe, void* out, int64_t rows, int S, int d, float scale, void* stream) {
+    RALF_REQUIRE(idx && W && out && rows > 0 && d > 0 && S > 0, "embed_fwd: bad arguments");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((embed_fwd_kernel<T>), dim3(grid_for(rows * d)), dim3(256), 0, ST, idx, W, pe, (T*)out, rows, S, d, scale));
+    return ralf::check_launch("embed_fwd");
+}
+/* dW (fp32 [vocab, d]) is accumulated into */
+extern "C" int ralf_embed_bwd(int dtype, const int64_t* idx, const void* dy, float* dW, int64_t rows, int d, float scale, void* stream) {
+    RALF_REQUIRE(idx && dy && dW && rows > 0 && d > 0, "embed_bwd: bad arguments");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((embed_bwd_kernel<T>), dim3(grid_for(rows * d)), dim3(256), 0, ST, idx, (const T*)dy, dW, rows, d, scale));
+    return ralf::check_launch("embed_bwd");
+}
+extern "C" int ralf_dropout(int dtype, const void* x, void* y, int64_t n, float p, const int64_t* seed, uint64_t call_id, void* stream) {
+    RALF_REQUIRE(x && y && seed && n > 0 && p >= 0.f && p < 1.f, "dropout: bad arguments");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T>), dim3(grid_for(n)), dim3(256), 0, ST, (const T*)x, (T*)y, n, p, seed, call_id));
+    return ralf::check_launch("dropout");
+}
+/* cnt_loss: fp32[2] = {number of non-ignored targets, mean loss}; dlogits (dtype) = d loss / d logits, may be NULL */
+extern "C" int ralf_xent_fwd_bwd(int dtype, const float* logits, const int64_t* target, void* dlogits, float* cnt_loss, int64_t rows, int V,
+                                 int ignore_index, float label_smoothing, void* stream) {
+    RALF_REQUIRE(logits && target && cnt_loss && rows > 0 && V > 0, "xent: bad arguments");
+    hipLaunchKernelGGL(xent_count_kernel, dim3(1), dim3(256), 0, ST, target, rows, ignore_index, cnt_loss);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((xent_kernel<T>), dim3(grid_for(rows, 4, 2048)), dim3(256), 0, ST, logits, target, (T*)dlogits, cnt_loss, rows, V, ignore_index, label_smoothing));
+    return ralf::check_launch("xent");
+}
+extern "C" int ralf_add_scalar(int dtype, const void* x, const float* s, void* y, int64_t rows, int cols, int64_t ldx, int64_t ldy, void* stream) {
+    RALF_REQUIRE(x && s && y && rows > 0 && cols > 0, "add_scalar: bad arguments");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((add_scalar_kernel<T>), dim3(grid_for(rows * cols)), dim3(256), 0, ST, (const T*)x, s, (T*)y, rows, cols, ldx, ldy));
+    return ralf::check_launch("add_scalar");
+}
+/* out[0] += sum of the [rows, cols] view */
+extern "C" int ralf_sum_all(int dtype, const void* x, float* out, int64_t rows, int cols, int64_t ldx, void* stream) {
+    RALF_REQUIRE(x && out && rows > 0 && cols > 0, "sum_all: bad arguments");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((sum_all_kernel<T>), dim3(grid_for(rows * cols, 256, 256)), dim3(256), 0, ST, (const T*)x, out, rows, cols, ldx));
+    return ralf::check_launch("sum_all");
+}
+/* dst[r*ldd+c] (+)= src[r*lds+c] with conversion between RALF_F32 / RALF_BF16 */
+extern "C" int ralf_copy2d(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t rows, int cols, int64_t lds, int64_t ldd, int accumulate, void* stream) {
+    RALF_REQUIRE(src && dst && rows > 0 && cols > 0, "copy2d: bad arguments");
+    const dim3 g(grid_for(rows * cols));
+    if (src_dtype == RALF_F32 && dst_dtype == RALF_F32) hipLaunchKernelGGL((copy2d_kernel<float, float>), g, dim3(256), 0, ST, (const float*)src, (float*)dst, rows, cols, lds, ldd, accumulate);
+    else if (src_dtype == RALF_F32) hipLaunchKernelGGL((copy2d_kernel<float, bf16>), g, dim3(256), 0, ST, (const float*)src, (bf16*)dst, rows, cols, lds, ldd, accumulate);
+    else if (dst_dtype == RALF_F32) hipLaunchKernelGGL((copy2d_kernel<bf16, float>), g, dim3(256), 0, ST, (const bf16*)src, (float*)dst, rows, cols, lds, ldd, accumulate);
+    else hipLaunchKernelGGL((copy2d_kernel<bf16, bf16>), g, dim3(256), 0, ST, (const bf16*)src, (bf16*)dst, rows, cols, lds, ldd, accumulate);
+    return ralf::check_launch("copy2d");
+}
+/* out (dims d0..d3 contiguous, dtype dst) [i0,i1,i2,i3] = in[i0*s0+i1*s1+i2*s2+i3*s3] for i3 < valid3 else 0 */
+extern "C" int ralf_permute4(int src_dtype, int dst_dtype, const void* in, void* out, int d0, int d1, int d2, int d3, int64_t s0, int64_t s1, int64_t s2, int64_t s3,
+                             int valid3, void* stream) {
+    RALF_REQUIRE(in && out && d0 > 0 && d1 > 0 && d2 > 0 && d3 > 0, "permute4: bad arguments");
+    const dim3 g(grid_for((int64_t)d0 * d1 * d2 * d3));
+    if (src_dtype == RALF_F32 && dst_dtype == RALF_F32) hipLaunchKernelGGL((permute4_kernel<float, float>), g, dim3(256), 0, ST, (const float*)in, (float*)out, d0, d1, d2, d3, s0, s1, s2, s3, valid3);
+    else if (src_dtype == RALF_F32) hipLaunchKernelGGL((permute4_kernel<float, bf16>), g, dim3(256), 0, ST, (const float*)in, (bf16*)out, d0, d1, d2, d3, s0, s1, s2, s3, valid3);
+    else if (dst_dtype == RALF_F32) hipLaunchKernelGGL((permute4_kernel<bf16, float>), g, dim3(256), 0, ST, (const bf16*)in, (float*)out, d0, d1, d2, d3, s0, s1, s2, s3, valid3);
+    else hipLaunchKernelGGL((permute4_kernel<bf16, bf16>), g, dim3(256), 0, ST, (const bf16*)in, (bf16*)out, d0, d1, d2, d3, s0, s1, s2, s3, valid3);
+    return ralf::check_launch("permute4");
+}
+extern "C" int ralf_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int8_t* arg, int B, int H, int W, int C, void* stream) {
+    RALF_REQUIRE(x && y && arg && B > 0 && H > 0 && W > 0 && C > 0, "maxpool_fwd: bad arguments");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for((int64_t)B * OH * OW * C)), dim3(256), 0, ST, (const T*)x, (T*)y, arg, B, H, W, C, OH, OW));
+    return ralf::check_launch("maxpool_fwd");
+}
+extern "C" int ralf_maxpool3x3s2_bwd(int dtype, const void* dy, const int8_t* arg, void* dx, int B, int H, int W, int C, void* stream) {
+    RALF_REQUIRE(dy && dx && arg && B > 0 && H > 0 && W > 0 && C > 0, "maxpool_bwd: bad arguments");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for((int64_t)B * H * W * C)), dim3(256), 0, ST, (const T*)dy, arg, (T*)dx, B, H, W, C, OH, OW));
+    return ralf::check_launch("maxpool_bwd");
+}
+extern "C" int ralf_upsample_nearest_add(int dtype, const void* src, const void* lateral, void* up, int64_t ld_up, void* sum, int B, int IH, int IW, int OH, int OW, int C, void* stream) {
+    RALF_REQUIRE(src && lateral && up && sum, "upsample_add: null pointer");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((upsample_add_kernel<T>), dim3(grid_for((int64_t)B * OH * OW * C)), dim3(256), 0, ST, (const T*)src, (const T*)lateral, (T*)up, ld_up, (T*)sum, B, IH, IW, OH, OW, C));
+    return ralf::check_launch("upsample_add");
+}
+extern "C" int ralf_upsample_nearest_bwd(int dtype, const void* g_up, int64_t ld_up, const void* g_sum, void* dsrc, int B, int IH, int IW, int OH, int OW, int C, void* stream) {
+    RALF_REQUIRE(g_up && g_sum && dsrc, "upsample_bwd: null pointer");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3(grid_for((int64_t)B * IH * IW * C)), dim3(256), 0, ST, (const T*)g_up, ld_up, (const T*)g_sum, (T*)dsrc, B, IH, IW, OH, OW, C));
+    return ralf::check_launch("upsample_bwd");
+}

@@ -40,7 +40,7 @@ def _p(t):
 def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=True, b_kcontig=True,
          lda=None, ldb=None, out: Optional[torch.Tensor] = None, ldc=None, out_dtype=None,
          bias=None, act=None, res=None, ldr=None, aux=None, aux_mode=None, aux_scale=1.0, out2=None,
-         alpha=1.0, accumulate=False, splitk=1, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0),
+         alpha=1.0, accumulate=False, splitk=1, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=None,
          conv: Optional[dict] = None, gather=0) -> torch.Tensor:
     """C = epi(alpha * A @ B) through ralf_gemm (see include/ralf_hip.h: RalfGemmDesc)."""
     assert A.is_cuda and B.is_cuda and A.dtype == B.dtype
@@ -68,7 +68,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
     d.sA0, d.sA1 = sA
     d.sB0, d.sB1 = sB
     d.sC0, d.sC1 = sC
-    d.sR0, d.sR1 = sR if res is not None and sR != (0, 0) else sC
+    d.sR0, d.sR1 = sR if sR is not None else sC
     d.a_kcontig, d.b_kcontig, d.gather = int(a_kcontig), int(b_kcontig), gather
     d.act, d.aux_mode, d.aux_scale = ACT[act], AUX[aux_mode], aux_scale
     d.accumulate, d.splitk, d.alpha = int(accumulate), splitk, alpha
@@ -83,3 +83,212 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
     rc = L.ralf_gemm(ctypes.byref(d), _p(ws), wsn, _lib.stream_ptr())
     _lib.check(rc, "ralf_gemm")
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# normalisation / pointwise / attention / optimizer bindings (see include/ralf_hip.h)
+# ----------------------------------------------------------------------------------------------
+from ._abi import RalfAttnDesc  # noqa: E402
+
+
+def _call(name, *args):
+    rc = getattr(_lib.lib(), name)(*args, _lib.stream_ptr())
+    _lib.check(rc, name)
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5, save_stats=True):
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    _call("ralf_layernorm_fwd", dtype_code(x), _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, cols, eps)
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, need_wgrad=True):
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    dx = torch.empty_like(x)
+    dg = torch.zeros(cols, dtype=torch.float32, device=x.device) if need_wgrad else None
+    db = torch.zeros(cols, dtype=torch.float32, device=x.device) if need_wgrad else None
+    _call("ralf_layernorm_bwd", dtype_code(x), _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), rows, cols)
+    return dx, dg, db
+
+
+def colsum(x2d, rows, cols, ld=None):
+    out = torch.zeros(cols, dtype=torch.float32, device=x2d.device)
+    _call("ralf_colsum", dtype_code(x2d), _p(x2d), ld if ld is not None else cols, _p(out), rows, cols)
+    return out
+
+
+def embed_fwd(idx, W, pe, S, scale, dtype):
+    rows, d = idx.numel(), W.shape[1]
+    out = torch.empty(*idx.shape, d, dtype=dtype, device=W.device)
+    _call("ralf_embed_fwd", _TORCH2CODE[dtype], _p(idx), _p(W), _p(pe), _p(out), rows, S, d, scale)
+    return out
+
+
+def embed_bwd(idx, dy, vocab, scale):
+    d = dy.shape[-1]
+    dW = torch.zeros(vocab, d, dtype=torch.float32, device=dy.device)
+    _call("ralf_embed_bwd", dtype_code(dy), _p(idx), _p(dy), _p(dW), idx.numel(), d, scale)
+    return dW
+
+
+def dropout(x, p, seed, call_id):
+    y = torch.empty_like(x)
+    _call("ralf_dropout", dtype_code(x), _p(x), _p(y), x.numel(), p, _p(seed), call_id)
+    return y
+
+
+def xent(logits_f32, target, ignore_index, eps, grad_dtype):
+    rows, V = logits_f32.numel() // logits_f32.shape[-1], logits_f32.shape[-1]
+    cl = torch.empty(2, dtype=torch.float32, device=logits_f32.device)
+    dl = torch.empty(logits_f32.shape, dtype=grad_dtype, device=logits_f32.device) if grad_dtype is not None else None
+    _call("ralf_xent_fwd_bwd", _TORCH2CODE[grad_dtype or torch.float32], _p(logits_f32), _p(target), _p(dl), _p(cl), rows, V, ignore_index, eps)
+    return cl, dl
+
+
+def add_scalar(x, s):
+    y = torch.empty_like(x)
+    cols = x.shape[-1]
+    _call("ralf_add_scalar", dtype_code(x), _p(x), _p(s), _p(y), x.numel() // cols, cols, cols, cols)
+    return y
+
+
+def sum_all(x):
+    out = torch.zeros(1, dtype=torch.float32, device=x.device)
+    cols = x.shape[-1]
+    _call("ralf_sum_all", dtype_code(x), _p(x), _p(out), x.numel() // cols, cols, cols)
+    return out
+
+
+def cast(x, dtype):
+    """dtype conversion through ralf_copy2d (fp32 <-> bf16)."""
+    if x.dtype == dtype:
+        return x
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    n = x.numel()
+    _call("ralf_copy2d", dtype_code(x), _TORCH2CODE[dtype], _p(x), _p(y), 1, n, n, n, 0)
+    return y
+
+
+def permute4(x, out_dims, strides, valid3, dtype):
+    out = torch.empty(out_dims, dtype=dtype, device=x.device)
+    _call("ralf_permute4", dtype_code(x), _TORCH2CODE[dtype], _p(x), _p(out), *out_dims, *strides, valid3)
+    return out
+
+
+def maxpool_fwd(x):
+    B, H, W, C = x.shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B, OH, OW, C, dtype=x.dtype, device=x.device)
+    arg = torch.empty(B, OH, OW, C, dtype=torch.int8, device=x.device)
+    _call("ralf_maxpool3x3s2_fwd", dtype_code(x), _p(x), _p(y), _p(arg), B, H, W, C)
+    return y, arg
+
+
+def maxpool_bwd(dy, arg, in_shape):
+    B, H, W, C = in_shape
+    dx = torch.empty(in_shape, dtype=dy.dtype, device=dy.device)
+    _call("ralf_maxpool3x3s2_bwd", dtype_code(dy), _p(dy), _p(arg), _p(dx), B, H, W, C)
+    return dx
+
+
+def upsample_add(src, lateral):
+    B, IH, IW, C = src.shape
+    _, OH, OW, _ = lateral.shape
+    up = torch.empty_like(lateral)
+    s = torch.empty_like(lateral)
+    _call("ralf_upsample_nearest_add", dtype_code(src), _p(src), _p(lateral), _p(up), C, _p(s), B, IH, IW, OH, OW, C)
+    return up, s
+
+
+def upsample_bwd(g_up, g_sum, src_shape):
+    B, IH, IW, C = src_shape
+    _, OH, OW, _ = g_sum.shape
+    d = torch.empty(src_shape, dtype=g_sum.dtype, device=g_sum.device)
+    _call("ralf_upsample_nearest_bwd", dtype_code(g_sum), _p(g_up), C, _p(g_sum), _p(d), B, IH, IW, OH, OW, C)
+    return d
+
+
+def bn_forward(x2d, gamma, beta, running_mean, running_var, training, relu, res, eps=1e-5, momentum=0.1):
+    M, C = x2d.shape
+    dev = x2d.device
+    stats = torch.zeros(2, C, dtype=torch.float32, device=dev)
+    out = torch.empty(4, C, dtype=torch.float32, device=dev)  # mean, rstd, scale, shift
+    dt = dtype_code(x2d)
+    if training:
+        _call("ralf_bn_stats", dt, _p(x2d), _p(stats[0]), _p(stats[1]), M, C)
+    _call("ralf_bn_finalize", _p(stats[0]), _p(stats[1]), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+          _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), M, C, eps, momentum, int(training))
+    y = torch.empty_like(x2d)
+    _call("ralf_bn_apply", dt, _p(x2d), _p(out[2]), _p(out[3]), _p(res), _p(y), M, C, int(relu))
+    return y, out[0], out[1]
+
+
+def bn_backward(x2d, dy, y, gamma, mean, rstd, relu, want_dres):
+    M, C = x2d.shape
+    s = torch.zeros(2, C, dtype=torch.float32, device=x2d.device)
+    dt = dtype_code(x2d)
+    _call("ralf_bn_bwd_reduce", dt, _p(x2d), _p(dy), _p(y), _p(mean), _p(rstd), _p(s[0]), _p(s[1]), M, C, int(relu))
+    dx = torch.empty_like(x2d)
+    dres = torch.empty_like(x2d) if want_dres else None
+    _call("ralf_bn_bwd_apply", dt, _p(x2d), _p(dy), _p(y), _p(mean), _p(rstd), _p(gamma), _p(s[0]), _p(s[1]), _p(dx), _p(dres), M, C, int(relu))
+    return dx, s[1], s[0], dres  # dx, dgamma, dbeta, dres
+
+
+def _attn_desc(q, k, v, o, B, H, Sq, Sk, dh, q_off, k_off, v_off, causal, kpm, scale, p_drop, seed, call_id):
+    d = RalfAttnDesc()
+    es = q.element_size()
+
+    def base(t, off):
+        return ctypes.c_void_p(t.data_ptr() + off * es)
+
+    d.q, d.k, d.v, d.o = base(q, q_off), base(k, k_off), base(v, v_off), _p(o)
+    d.q_rs, d.q_bs = q.shape[-1], q.shape[-1] * Sq
+    d.k_rs, d.k_bs = k.shape[-1], k.shape[-1] * Sk
+    d.v_rs, d.v_bs = v.shape[-1], v.shape[-1] * Sk
+    d.o_rs, d.o_bs = o.shape[-1], o.shape[-1] * Sq
+    d.B, d.H, d.Sq, d.Sk, d.dh, d.dtype, d.causal = B, H, Sq, Sk, dh, dtype_code(q), int(causal)
+    d.kpm, d.seed, d.call_id = _p(kpm), _p(seed), call_id
+    d.scale, d.p_drop = scale, p_drop
+    return d
+
+
+def attention_fwd(q, k, v, B, H, Sq, Sk, dh, q_off=0, k_off=0, v_off=0, causal=False, kpm=None, scale=None, p_drop=0.0, seed=None, call_id=0, need_lse=True):
+    """q/k/v: contiguous [B,S,width] tensors (possibly the same packed buffer); head h of q lives at
+    column q_off + h*dh.  Returns O [B,Sq,H*dh] and lse [B,H,Sq]."""
+    o = torch.empty(B, Sq, H * dh, dtype=q.dtype, device=q.device)
+    lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device) if need_lse else None
+    d = _attn_desc(q, k, v, o, B, H, Sq, Sk, dh, q_off, k_off, v_off, causal, kpm, scale if scale is not None else dh ** -0.5, p_drop, seed, call_id)
+    d.lse = _p(lse)
+    _call("ralf_attention_fwd", ctypes.byref(d))
+    return o, lse
+
+
+def attention_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, dh, q_off=0, k_off=0, v_off=0, dq_off=0, dk_off=0, dv_off=0,
+                  causal=False, kpm=None, scale=None, p_drop=0.0, seed=None, call_id=0):
+    d = _attn_desc(q, k, v, o, B, H, Sq, Sk, dh, q_off, k_off, v_off, causal, kpm, scale if scale is not None else dh ** -0.5, p_drop, seed, call_id)
+    delta = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device)
+    es = q.element_size()
+    d.lse, d.delta, d.dout = _p(lse), _p(delta), _p(dout)
+    d.do_rs, d.do_bs = dout.shape[-1], dout.shape[-1] * Sq
+    d.dq = ctypes.c_void_p(dq.data_ptr() + dq_off * es)
+    d.dk = ctypes.c_void_p(dk.data_ptr() + dk_off * es)
+    d.dv = ctypes.c_void_p(dv.data_ptr() + dv_off * es)
+    d.dq_rs, d.dq_bs = dq.shape[-1], dq.shape[-1] * Sq
+    d.dk_rs, d.dk_bs = dk.shape[-1], dk.shape[-1] * Sk
+    d.dv_rs, d.dv_bs = dv.shape[-1], dv.shape[-1] * Sk
+    _call("ralf_attention_bwd", ctypes.byref(d))
+
+
+def sumsq(flat, out):
+    _call("ralf_sumsq", _p(flat), flat.numel(), _p(out))
+
+
+def clip_coef(sumsq_t, max_norm, coef, norm_out=None):
+    _call("ralf_clip_coef", _p(sumsq_t), max_norm, _p(coef), _p(norm_out))
+
+
+def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, coef=None, shadow=None):
+    _call("ralf_adamw", _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr, beta1, beta2, eps, wd, step, _p(coef))

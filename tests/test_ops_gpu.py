@@ -1,0 +1,235 @@
+"""GPU numerics of the non-GEMM kernels (through the C ABI) vs plain torch fp32 references on CPU."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: dict(atol=2e-5, rtol=2e-5), torch.bfloat16: dict(atol=3e-2, rtol=3e-2)}
+
+
+def rnd(*shape, seed=0, dtype=torch.float32, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def close(a, b, dtype, frac=1.0, **kw):
+    tol = dict(TOL[dtype]); tol.update(kw)
+    a, b = a.float().cpu(), b.float().cpu()
+    if frac < 1.0:  # bf16 ReLU masks may flip where the fp32 reference output is ~0: allow a few outliers
+        ok = (a - b).abs() <= tol["atol"] + tol["rtol"] * b.abs()
+        assert ok.float().mean().item() >= frac, f"only {ok.float().mean().item():.5f} within tolerance"
+        return
+    torch.testing.assert_close(a, b, **tol)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_layernorm(dtype):
+    from ralf_amd import ops
+
+    x = rnd(37, 5, 256, seed=1, dtype=dtype).float().requires_grad_(True)
+    g, b = (1 + 0.1 * rnd(256, seed=2)).requires_grad_(True), rnd(256, seed=3).requires_grad_(True)
+    y = F.layer_norm(x, (256,), g, b)
+    go = rnd(37, 5, 256, seed=4, dtype=dtype).float()
+    y.backward(go)
+    yd, mean, rstd = ops.layernorm_fwd(x.detach().to(dtype).cuda(), g.detach().cuda(), b.detach().cuda())
+    close(yd, y.detach(), dtype)
+    dx, dg, db = ops.layernorm_bwd(go.to(dtype).cuda(), x.detach().to(dtype).cuda(), g.detach().cuda(), mean, rstd)
+    close(dx, x.grad, dtype)
+    close(dg, g.grad, dtype, atol=5e-2 if dtype == torch.bfloat16 else 1e-4)
+    close(db, b.grad, dtype, atol=5e-2 if dtype == torch.bfloat16 else 1e-4)
+    close(ops.colsum(go.to(dtype).view(-1, 256).cuda(), 185, 256), go.view(-1, 256).sum(0), dtype, atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_embedding_scalar_xent(dtype):
+    from ralf_amd import ops
+
+    W, pe = rnd(50, 256, seed=5), rnd(20, 256, seed=6)
+    idx = torch.randint(0, 50, (7, 12), generator=torch.Generator().manual_seed(7))
+    out = ops.embed_fwd(idx.cuda(), W.cuda(), pe.cuda(), 12, 16.0, dtype)
+    close(out, W[idx] * 16.0 + pe[:12], dtype, atol=0.15 if dtype == torch.bfloat16 else 1e-5)
+    dy = rnd(7, 12, 256, seed=8, dtype=dtype)
+    ref = torch.zeros(50, 256).index_add_(0, idx.view(-1), dy.float().view(-1, 256) * 16.0)
+    close(ops.embed_bwd(idx.cuda(), dy.cuda(), 50, 16.0), ref, torch.float32, atol=1e-3, rtol=1e-4)
+    x, s = rnd(9, 256, seed=9, dtype=dtype), torch.tensor([0.37, -1.0])
+    close(ops.add_scalar(x.cuda(), s.cuda()[1:]), x.float() - 1.0, dtype)
+    close(ops.sum_all(x.cuda()), x.float().sum().view(1), dtype, atol=1e-2, rtol=1e-3)
+    # cross entropy with label smoothing and ignore_index
+    logits = rnd(64, 518, seed=10, scale=2.0).requires_grad_(True)
+    tgt = torch.randint(0, 518, (64,), generator=torch.Generator().manual_seed(11))
+    tgt[::5] = 515
+    loss = F.cross_entropy(logits, tgt, ignore_index=515, label_smoothing=0.1)
+    loss.backward()
+    cl, dl = ops.xent(logits.detach().cuda(), tgt.cuda(), 515, 0.1, dtype)
+    assert cl[0].item() == (tgt != 515).sum().item()
+    close(cl[1], loss.detach(), torch.float32, atol=1e-5, rtol=1e-5)
+    close(dl, logits.grad, dtype, atol=1e-6 if dtype == torch.float32 else 2e-4)
+
+
+def test_dropout_is_counter_based():
+    from ralf_amd import ops
+
+    x = torch.ones(1 << 20, device="cuda")
+    seed = torch.tensor([1234], dtype=torch.int64, device="cuda")
+    y1, y2, y3 = ops.dropout(x, 0.1, seed, 7), ops.dropout(x, 0.1, seed, 7), ops.dropout(x, 0.1, seed, 8)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    keep = (y1 != 0).float().mean().item()
+    assert abs(keep - 0.9) < 2e-3 and abs(y1.mean().item() - 1.0) < 5e-3
+    u = sorted(y1.unique().tolist())
+    assert len(u) == 2 and u[0] == 0.0 and abs(u[1] - 1 / 0.9) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_pool_upsample_permute(dtype):
+    from ralf_amd import ops
+
+    x = torch.relu(rnd(2, 16, 9, 11, seed=12, dtype=dtype).float()).requires_grad_(True)  # many exact-zero ties
+    y = F.max_pool2d(x, 3, 2, 1)
+    go = rnd(*y.shape, seed=13, dtype=dtype).float()
+    y.backward(go)
+    xn = x.detach().permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    yd, arg = ops.maxpool_fwd(xn)
+    close(yd.permute(0, 3, 1, 2), y.detach(), dtype, atol=0, rtol=0)
+    dx = ops.maxpool_bwd(go.permute(0, 2, 3, 1).contiguous().to(dtype).cuda(), arg, tuple(xn.shape))
+    close(dx.permute(0, 3, 1, 2), x.grad, dtype)
+    for (ih, iw, oh, ow) in [(4, 4, 8, 8), (11, 8, 22, 15)]:
+        src = rnd(2, 8, ih, iw, seed=14, dtype=dtype).float().requires_grad_(True)
+        lat = rnd(2, 8, oh, ow, seed=15, dtype=dtype).float()
+        up = F.interpolate(src, size=(oh, ow), mode="nearest")
+        g1, g2 = rnd(*up.shape, seed=16, dtype=dtype).float(), rnd(*up.shape, seed=17, dtype=dtype).float()
+        (up * g1 + (up + lat) * g2).sum().backward()
+        nh = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+        upd, sd = ops.upsample_add(nh(src), nh(lat))
+        close(upd.permute(0, 3, 1, 2), up.detach(), dtype, atol=0, rtol=0)
+        close(sd.permute(0, 3, 1, 2), (up + lat).detach(), dtype)
+        dsrc = ops.upsample_bwd(nh(g1), nh(g2), (2, ih, iw, 8))
+        close(dsrc.permute(0, 3, 1, 2), src.grad, dtype, atol=6e-2 if dtype == torch.bfloat16 else 1e-5)
+    w = rnd(6, 4, 7, 7, seed=18)
+    ohwi = ops.permute4(w.cuda(), (6, 7, 7, 8), (4 * 49, 7, 1, 49), 4, dtype)
+    ref = torch.zeros(6, 7, 7, 8); ref[..., :4] = w.permute(0, 2, 3, 1)
+    close(ohwi, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("C,M", [(64, 1000), (256, 333), (2048, 70)])
+def test_batchnorm(dtype, C, M):
+    from ralf_amd import ops
+
+    x = (rnd(M, C, seed=19, dtype=dtype).float() * 2 + 0.5).requires_grad_(True)
+    res = rnd(M, C, seed=20, dtype=dtype).float().requires_grad_(True)
+    g, b = (1 + 0.1 * rnd(C, seed=21)).requires_grad_(True), (0.1 * rnd(C, seed=22)).requires_grad_(True)
+    rm, rv = 0.1 * rnd(C, seed=23), 1 + 0.1 * rnd(C, seed=24).abs()
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = torch.relu(F.batch_norm(x, rm_ref, rv_ref, g, b, True, 0.1, 1e-5) + res)
+    go = rnd(M, C, seed=25, dtype=dtype).float()
+    y.backward(go)
+    rmd, rvd = rm.cuda(), rv.cuda()
+    xd, resd = x.detach().to(dtype).cuda(), res.detach().to(dtype).cuda()
+    yd, mean, rstd = ops.bn_forward(xd, g.detach().cuda(), b.detach().cuda(), rmd, rvd, True, True, resd)
+    close(yd, y.detach(), dtype)
+    close(rmd, rm_ref, torch.float32, atol=1e-3); close(rvd, rv_ref, torch.float32, atol=2e-3, rtol=2e-3)
+    dx, dg, db, dres = ops.bn_backward(xd, go.to(dtype).cuda(), yd, g.detach().cuda(), mean, rstd, True, True)
+    btol = dict(atol=6e-2, rtol=6e-2) if dtype == torch.bfloat16 else dict(atol=2e-4, rtol=1e-3)
+    fr = 0.999 if dtype == torch.bfloat16 else 1.0
+    close(dx, x.grad, dtype, frac=fr, **btol); close(dres, res.grad, dtype, frac=fr)
+    close(dg, g.grad, dtype, atol=0.5 if dtype == torch.bfloat16 else 2e-3, rtol=5e-2); close(db, b.grad, dtype, atol=0.5 if dtype == torch.bfloat16 else 2e-3, rtol=5e-2)
+    # eval mode uses the running statistics
+    ye = F.batch_norm(x.detach(), rm_ref, rv_ref, g.detach(), b.detach(), False, 0.1, 1e-5)
+    yed, _, _ = ops.bn_forward(xd, g.detach().cuda(), b.detach().cuda(), rm_ref.cuda(), rv_ref.cuda(), False, False, None)
+    close(yed, ye, dtype)
+
+
+def ref_attention(q, k, v, H, causal, kpm, scale):
+    B, Sq, _ = q.shape
+    Sk = k.shape[1]
+    dh = q.shape[-1] // H
+    qh, kh, vh = (t.view(B, -1, H, dh).transpose(1, 2) for t in (q, k, v))
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    if causal:
+        s = s + torch.triu(torch.full((Sq, Sk), float("-inf")), 1)
+    if kpm is not None:
+        s = s.masked_fill(kpm[:, None, None, :], float("-inf"))
+    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Sq, H * dh)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,Sq,Sk,dh,causal,pad", [(2, 8, 50, 50, 32, True, True), (2, 8, 70, 300, 32, False, False), (3, 4, 11, 11, 64, False, True),
+                                                      (2, 8, 256, 16, 64, False, False), (1, 8, 130, 130, 32, True, False)])
+def test_attention(dtype, B, H, Sq, Sk, dh, causal, pad):
+    from ralf_amd import ops
+
+    d = H * dh
+    q, k, v = (rnd(B, S, d, seed=s, dtype=dtype).float().requires_grad_(True) for S, s in ((Sq, 30), (Sk, 31), (Sk, 32)))
+    kpm = None
+    if pad:
+        kpm = torch.zeros(B, Sk, dtype=torch.bool); kpm[0, Sk // 2:] = True; kpm[-1, -1] = True
+    scale = dh ** -0.5
+    o = ref_attention(q, k, v, H, causal, kpm, scale)
+    go = rnd(B, Sq, d, seed=33, dtype=dtype).float()
+    o.backward(go)
+    dev = lambda t: t.detach().to(dtype).cuda()
+    kp = kpm.to(torch.uint8).cuda() if pad else None
+    qd, kd, vd = dev(q), dev(k), dev(v)
+    od, lse = ops.attention_fwd(qd, kd, vd, B, H, Sq, Sk, dh, causal=causal, kpm=kp)
+    close(od, o.detach(), dtype)
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    ops.attention_bwd(dev(go), qd, kd, vd, od, lse, dq, dk, dv, B, H, Sq, Sk, dh, causal=causal, kpm=kp)
+    tol = dict(atol=5e-2, rtol=5e-2) if dtype == torch.bfloat16 else dict(atol=5e-5, rtol=1e-4)
+    close(dq, q.grad, dtype, **tol); close(dk, k.grad, dtype, **tol); close(dv, v.grad, dtype, **tol)
+
+
+def test_attention_packed_qkv_and_dropout():
+    """self-attention on a packed [B,S,3d] buffer; dropout backward consistent with forward (finite differences)."""
+    from ralf_amd import ops
+
+    B, H, S, dh = 2, 8, 40, 32
+    d = H * dh
+    qkv = rnd(B, S, 3 * d, seed=40).cuda()
+    o1, _ = ops.attention_fwd(qkv, qkv, qkv, B, H, S, S, dh, q_off=0, k_off=d, v_off=2 * d)
+    q, k, v = qkv[..., :d].contiguous(), qkv[..., d:2 * d].contiguous(), qkv[..., 2 * d:].contiguous()
+    o2, _ = ops.attention_fwd(q, k, v, B, H, S, S, dh)
+    assert torch.equal(o1, o2)
+    seed = torch.tensor([99], dtype=torch.int64, device="cuda")
+    od, lse = ops.attention_fwd(q, k, v, B, H, S, S, dh, p_drop=0.3, seed=seed, call_id=5)
+    assert not torch.equal(od, o2)
+    go = rnd(B, S, d, seed=41).cuda()
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ops.attention_bwd(go, q, k, v, od, lse, dq, dk, dv, B, H, S, S, dh, p_drop=0.3, seed=seed, call_id=5)
+    # directional derivative check of L = <go, O(v + t*dv_dir)> (O is linear in V for a fixed mask)
+    dirv = rnd(B, S, d, seed=42).cuda()
+    o_plus, _ = ops.attention_fwd(q, k, v + dirv, B, H, S, S, dh, p_drop=0.3, seed=seed, call_id=5)
+    lhs = ((o_plus - od) * go).sum().item()
+    rhs = (dv * dirv).sum().item()
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+    eps = 1e-2
+    dirq = rnd(B, S, d, seed=43).cuda()
+    op, _ = ops.attention_fwd(q + eps * dirq, k, v, B, H, S, S, dh, p_drop=0.3, seed=seed, call_id=5)
+    om, _ = ops.attention_fwd(q - eps * dirq, k, v, B, H, S, S, dh, p_drop=0.3, seed=seed, call_id=5)
+    lhs = (((op - om) * go).sum() / (2 * eps)).item()
+    rhs = (dq * dirq).sum().item()
+    assert abs(lhs - rhs) < 2e-2 * max(1.0, abs(lhs))
+
+
+def test_adamw_and_clip():
+    from ralf_amd import ops
+
+    n = 10007
+    p0, g = rnd(n, seed=50), rnd(n, seed=51)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([p_ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    pd, m, v = p0.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    shadow = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    for step in range(1, 4):
+        gs = g * step
+        p_ref.grad = gs.clone()
+        total = torch.nn.utils.clip_grad_norm_([p_ref], 0.1)
+        opt.step()
+        ss, coef, nrm = torch.zeros(1, device="cuda"), torch.empty(1, device="cuda"), torch.empty(1, device="cuda")
+        ops.sumsq(gs.cuda(), ss); ops.clip_coef(ss, 0.1, coef, nrm)
+        torch.testing.assert_close(nrm.cpu()[0], total, rtol=1e-5, atol=1e-6)
+        ops.adamw(pd, gs.cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step, coef, shadow)
+        torch.testing.assert_close(pd.cpu(), p_ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(shadow.float().cpu(), pd.cpu(), rtol=1e-2, atol=1e-2)
