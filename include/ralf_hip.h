@@ -126,8 +126,9 @@ int ralf_bn_bwd_apply(int dtype, const void* x, const void* dy, const void* y, c
 /* out[r,:] = W[idx[r],:]*scale + pe[r % S,:]   (nn.Embedding -> PositionalEncoding1d, common/common.py:97-98) */
 int ralf_embed_fwd(int dtype, const int64_t* idx, const float* W, const float* pe, void* out, int64_t rows, int S, int d, float scale, void* stream);
 int ralf_embed_bwd(int dtype, const int64_t* idx, const void* dy, float* dW, int64_t rows, int d, float scale, void* stream);
-/* y = x*keep/(1-p), mask = f(seed[0], call_id, element index): the same call on dy is the backward */
-int ralf_dropout(int dtype, const void* x, void* y, int64_t n, float p, const int64_t* seed, uint64_t call_id, void* stream);
+/* y = x*keep/(1-p) (+ res), mask = f(seed[0], call_id, element index): the same call on dy (res = NULL) is the
+ * backward; with p == 0 it is a plain residual add */
+int ralf_dropout(int dtype, const void* x, const void* res, void* y, int64_t n, float p, const int64_t* seed, uint64_t call_id, void* stream);
 /* nn.CrossEntropyLoss(label_smoothing, ignore_index) on fp32 logits [rows,V]: cnt_loss = {#valid, mean loss};
  * dlogits (dtype, may be NULL) = d loss / d logits */
 int ralf_xent_fwd_bwd(int dtype, const float* logits, const int64_t* target, void* dlogits, float* cnt_loss, int64_t rows, int V,

@@ -59,7 +59,7 @@ SIGNATURES.update({
     "ralf_bn_bwd_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "ralf_embed_fwd": (i32, [i32, vp, vp, vp, vp, i64, i32, i32, f32, vp]),
     "ralf_embed_bwd": (i32, [i32, vp, vp, vp, i64, i32, f32, vp]),
-    "ralf_dropout": (i32, [i32, vp, vp, i64, f32, vp, u64, vp]),
+    "ralf_dropout": (i32, [i32, vp, vp, vp, i64, f32, vp, u64, vp]),
     "ralf_xent_fwd_bwd": (i32, [i32, vp, vp, vp, vp, i64, i32, i32, f32, vp]),
     "ralf_add_scalar": (i32, [i32, vp, vp, vp, i64, i32, i64, i64, vp]),
     "ralf_sum_all": (i32, [i32, vp, vp, i64, i32, i64, vp]),

@@ -66,12 +66,15 @@ __global__ void embed_bwd_kernel(const int64_t* __restrict__ idx, const T* __res
 
 // y = x * keep/(1-p); the same call regenerates the same mask (used for the gradient)
 template <typename T>
-__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p, const int64_t* __restrict__ seed, uint64_t call) {
-    const uint64_t s = (uint64_t)seed[0];
+__global__ void dropout_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, int64_t n, float p, const int64_t* __restrict__ seed, uint64_t call) {
+    const uint64_t s = p > 0.f ? (uint64_t)seed[0] : 0;
     const uint32_t thr = (uint32_t)(p * 16777216.f);
     const float inv = 1.f / (1.f - p);
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
-        st(y, e, rng24(s, call, (uint64_t)e) >= thr ? ld(x, e) * inv : 0.f);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        float v = (p <= 0.f || rng24(s, call, (uint64_t)e) >= thr) ? ld(x, e) * inv : 0.f;
+        if (res) v += ld(res, e);
+        st(y, e, v);
+    }
 }
 
 // label-smoothed cross entropy, one wave per row of fp32 logits [rows, V]
@@ -283,9 +286,9 @@ extern "C" int ralf_embed_bwd(int dtype, const int64_t* idx, const void* dy, flo
     DISPATCH_T(dtype, hipLaunchKernelGGL((embed_bwd_kernel<T>), dim3(grid_for(rows * d)), dim3(256), 0, ST, idx, (const T*)dy, dW, rows, d, scale));
     return ralf::check_launch("embed_bwd");
 }
-extern "C" int ralf_dropout(int dtype, const void* x, void* y, int64_t n, float p, const int64_t* seed, uint64_t call_id, void* stream) {
-    RALF_REQUIRE(x && y && seed && n > 0 && p >= 0.f && p < 1.f, "dropout: bad arguments");
-    DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T>), dim3(grid_for(n)), dim3(256), 0, ST, (const T*)x, (T*)y, n, p, seed, call_id));
+extern "C" int ralf_dropout(int dtype, const void* x, const void* res, void* y, int64_t n, float p, const int64_t* seed, uint64_t call_id, void* stream) {
+    RALF_REQUIRE(x && y && (seed || p == 0.f) && n > 0 && p >= 0.f && p < 1.f, "dropout: bad arguments");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T>), dim3(grid_for(n)), dim3(256), 0, ST, (const T*)x, (const T*)res, (T*)y, n, p, seed, call_id));
     return ralf::check_launch("dropout");
 }
 /* cnt_loss: fp32[2] = {number of non-ignored targets, mean loss}; dlogits (dtype) = d loss / d logits, may be NULL */

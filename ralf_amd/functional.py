@@ -1,0 +1,410 @@
+"""Autograd wiring of the HIP ops: every forward/backward below is a sequence of C-ABI calls
+(ralf_amd/ops.py); torch only owns the tensors, the tape and gradient accumulation.
+
+`Runtime` carries what the reference keeps implicitly in torch global state: compute dtype
+(fp32 parity mode / bf16 throughput mode), train/eval flag for dropout + BatchNorm, the
+device-resident dropout seed and a per-forward stream id counter for the counter-based RNG.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+
+class Runtime:
+    def __init__(self, dtype=torch.float32, seed: int = 0):
+        self.dtype = dtype
+        self.training = False
+        self._seed_host = seed
+        self.seed: Optional[torch.Tensor] = None  # int64[1] on device, advanced once per step
+        self._call = 0
+        self._lp: dict = {}
+
+    def to(self, device):
+        if self.seed is None or self.seed.device != device:
+            self.seed = torch.tensor([self._seed_host], dtype=torch.int64, device=device)
+        return self
+
+    def begin_step(self):
+        """start of a forward: restart the stream-id counter (the device seed distinguishes steps)."""
+        self._call = 0
+
+    def advance_seed(self):
+        self.seed.add_(0x9E3779B1)  # on-device: safe inside a captured graph
+
+    def next_call(self) -> int:
+        self._call += 1
+        return self._call
+
+    def drop_p(self, p: float) -> float:
+        return p if (self.training and p > 0.0) else 0.0
+
+    # low-precision / re-laid-out shadows of fp32 master weights, refreshed when the master changes
+    def lp(self, w: torch.Tensor, kind: str = "cast") -> torch.Tensor:
+        if kind == "cast" and w.dtype == self.dtype:
+            return w.detach()
+        key = (id(w), kind, self.dtype)
+        hit = self._lp.get(key)
+        if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
+            return hit[2]
+        wd = w.detach()
+        if kind == "cast":
+            t = ops.cast(wd, self.dtype)
+        else:
+            Co, Ci, kh, kw = wd.shape
+            if kind == "ohwi":      # [Co][kh][kw][Ci padded to 8]   (forward / weight-gradient layout)
+                cip = (Ci + 7) // 8 * 8
+                t = ops.permute4(wd, (Co, kh, kw, cip), (Ci * kh * kw, kw, 1, kh * kw), Ci, self.dtype)
+            elif kind == "ikwo":    # [Ci][kh][kw][Co]               (data-gradient layout)
+                t = ops.permute4(wd, (Ci, kh, kw, Co), (kh * kw, kw, 1, Ci * kh * kw), Co, self.dtype)
+            else:
+                raise ValueError(kind)
+        self._lp[key] = (w._version, w.data_ptr(), t)
+        return t
+
+
+def _2d(x):
+    return x.reshape(-1, x.shape[-1])
+
+
+def _splitk_for(out_rows: int, out_cols: int, red: int) -> int:
+    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
+    want = max(1, 512 // tiles)
+    return max(1, min(want, red // 512))
+
+
+def wgrad(dy2d, x2d, N, K, rows):
+    """dW[N,K] (fp32) = dy^T @ x, reduction over `rows` split across workgroups."""
+    return ops.gemm(dy2d, x2d, N, K, rows, a_kcontig=False, b_kcontig=False, out_dtype=torch.float32,
+                    splitk=_splitk_for(N, K, rows))
+
+
+# ----------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    """y = x W[r0:r1]^T (+ b[r0:r1]) (+ res); `rows` selects a block of a packed weight (nn.MultiheadAttention
+    in_proj for cross-attention) without materialising a sliced parameter; out_f32 -> fp32 logits."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, res, rt, out_f32, rows):
+        r0, r1 = rows if rows is not None else (0, W.shape[0])
+        N, K = r1 - r0, W.shape[1]
+        x2 = _2d(x)
+        nrow = x2.shape[0]
+        y = ops.gemm(x2, rt.lp(W)[r0:r1], nrow, N, K, bias=b.detach()[r0:r1] if b is not None else None,
+                     res=_2d(res) if res is not None else None,
+                     out_dtype=torch.float32 if out_f32 else None)
+        ctx.save_for_backward(x2, W)
+        ctx.rt, ctx.has_b, ctx.has_res, ctx.xshape, ctx.rows = rt, b is not None, res is not None, x.shape, (r0, r1)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W = ctx.saved_tensors
+        rt = ctx.rt
+        r0, r1 = ctx.rows
+        N, K = r1 - r0, W.shape[1]
+        full = N == W.shape[0]
+        dy2 = _2d(dy.contiguous())
+        if dy2.dtype != rt.dtype:
+            dy2 = ops.cast(dy2, rt.dtype)
+        nrow = dy2.shape[0]
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dy2, rt.lp(W)[r0:r1], nrow, K, N, b_kcontig=False).view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dW = wgrad(dy2, x2, N, K, nrow)
+            if not full:  # place the block into a full-size gradient (plumbing copy)
+                g = torch.zeros(W.shape, dtype=torch.float32, device=dW.device)
+                g[r0:r1] = dW
+                dW = g
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy2, nrow, N)
+            if not full:
+                g = torch.zeros(W.shape[0], dtype=torch.float32, device=db.device)
+                g[r0:r1] = db
+                db = g
+        dres = dy if ctx.has_res else None
+        return dx, dW, db, dres, None, None, None
+
+
+def linear(x, W, b=None, res=None, rt=None, out_f32=False, rows=None):
+    return LinearFn.apply(x, W, b, res, rt, out_f32, rows)
+
+
+class FFNFn(Function):
+    """y = W2 drop(act(W1 x + b1)) + b2 (+ res) with a hand-written backward (activation gradient
+    fused into the data-gradient GEMM epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, res, act, p, rt):
+        x2 = _2d(x)
+        rows, K = x2.shape
+        Hd, N = W1.shape[0], W2.shape[0]
+        z = torch.empty(rows, Hd, dtype=rt.dtype, device=x.device) if act == "gelu" else None
+        h = ops.gemm(x2, rt.lp(W1), rows, Hd, K, bias=b1.detach(), act=act, out2=z)
+        call = 0
+        if p > 0.0:
+            call = rt.next_call()
+            h = ops.dropout(h, p, rt.seed, call)
+        y = ops.gemm(h, rt.lp(W2), rows, N, Hd, bias=b2.detach(), res=_2d(res) if res is not None else None)
+        ctx.save_for_backward(x2, W1, W2, h, z)
+        ctx.rt, ctx.act, ctx.p, ctx.has_res, ctx.xshape = rt, act, p, res is not None, x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W1, W2, h, z = ctx.saved_tensors
+        rt = ctx.rt
+        dy2 = _2d(dy.contiguous())
+        rows, K = x2.shape
+        Hd, N = W1.shape[0], W2.shape[0]
+        if ctx.act == "gelu":
+            dz = ops.gemm(dy2, rt.lp(W2), rows, Hd, N, b_kcontig=False, aux=z, aux_mode="gelu_grad")
+        else:  # relu (+ dropout): h > 0 <=> pre-activation > 0 and kept
+            dz = ops.gemm(dy2, rt.lp(W2), rows, Hd, N, b_kcontig=False, aux=h, aux_mode="relu_mask", aux_scale=1.0 / (1.0 - ctx.p))
+        dW2 = wgrad(dy2, h, N, Hd, rows)
+        db2 = ops.colsum(dy2, rows, N)
+        dW1 = wgrad(dz, x2, Hd, K, rows)
+        db1 = ops.colsum(dz, rows, Hd)
+        dx = ops.gemm(dz, rt.lp(W1), rows, K, Hd, b_kcontig=False).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        return dx, dW1, db1, dW2, db2, (dy if ctx.has_res else None), None, None, None
+
+
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, g, b, rt):
+        xc = x.contiguous()
+        y, mean, rstd = ops.layernorm_fwd(xc, g.detach(), b.detach())
+        ctx.save_for_backward(xc, g, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, mean, rstd = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(dy.contiguous(), x, g.detach(), mean, rstd, need_wgrad=ctx.needs_input_grad[1])
+        return dx, dg, db, None
+
+
+def layer_norm(x, g, b, rt):
+    return LayerNormFn.apply(x, g, b, rt)
+
+
+class DropAddFn(Function):
+    """y = res + dropout(x) (plain add when p == 0)."""
+
+    @staticmethod
+    def forward(ctx, x, res, p, rt):
+        call = rt.next_call() if p > 0.0 else 0
+        ctx.rt, ctx.p, ctx.call, ctx.has_res = rt, p, call, res is not None
+        return ops.dropout(x.contiguous(), p, rt.seed, call, res.contiguous() if res is not None else None)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = ops.dropout(dy, ctx.p, ctx.rt.seed, ctx.call) if ctx.p > 0.0 else dy
+        return dx, (dy if ctx.has_res else None), None, None
+
+
+def drop_add(x, res, p, rt):
+    if p == 0.0 and res is None:
+        return x
+    return DropAddFn.apply(x, res, p, rt)
+
+
+class EmbedFn(Function):
+    """emb(idx) * sqrt(d) + pe[:S]  (nn.Embedding -> PositionalEncoding1d)."""
+
+    @staticmethod
+    def forward(ctx, idx, W, pe, rt):
+        S, d = idx.shape[-1], W.shape[1]
+        ctx.save_for_backward(idx)
+        ctx.vocab, ctx.scale = W.shape[0], math.sqrt(d)
+        return ops.embed_fwd(idx.contiguous(), W.detach(), pe, S, ctx.scale, rt.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return None, ops.embed_bwd(idx.contiguous(), dy.contiguous(), ctx.vocab, ctx.scale), None, None
+
+
+class AddScalarFn(Function):
+    """x + s[i] with s a learned scalar table (task_emb = nn.Embedding(2, 1))."""
+
+    @staticmethod
+    def forward(ctx, x, table, i):
+        ctx.i, ctx.n = i, table.shape[0]
+        return ops.add_scalar(x.contiguous(), table.detach().view(-1)[i:i + 1].contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = torch.zeros(ctx.n, 1, dtype=torch.float32, device=dy.device)
+        g[ctx.i] = ops.sum_all(dy.contiguous())  # slice assignment: plumbing
+        return dy, g, None
+
+
+class AttnFn(Function):
+    """softmax(scale Q K^T + mask) V on packed projections.
+    mode 'self':  a = qkv [B,S,3*H*dh];            mode 'cross': a = q [B,Sq,H*dh], b = kv [B,Sk,2*H*dh]"""
+
+    @staticmethod
+    def forward(ctx, a, b, H, dh, causal, kpm, p, rt):
+        a = a.contiguous()
+        inner = H * dh
+        if b is None:
+            B, Sq, _ = a.shape
+            Sk, q, k, v, offs = Sq, a, a, a, (0, inner, 2 * inner)
+        else:
+            b = b.contiguous()
+            B, Sq, _ = a.shape
+            Sk, q, k, v, offs = b.shape[1], a, b, b, (0, 0, inner)
+        call = rt.next_call() if p > 0.0 else 0
+        o, lse = ops.attention_fwd(q, k, v, B, H, Sq, Sk, dh, *offs, causal=causal, kpm=kpm, p_drop=p, seed=rt.seed, call_id=call)
+        ctx.save_for_backward(a, b, o, lse, kpm)
+        ctx.cfg = (B, H, Sq, Sk, dh, offs, causal, p, call, rt)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        a, b, o, lse, kpm = ctx.saved_tensors
+        B, H, Sq, Sk, dh, offs, causal, p, call, rt = ctx.cfg
+        do = do.contiguous()
+        da = torch.empty_like(a)
+        if b is None:
+            ops.attention_bwd(do, a, a, a, o, lse, da, da, da, B, H, Sq, Sk, dh, *offs, *offs, causal=causal, kpm=kpm, p_drop=p, seed=rt.seed, call_id=call)
+            return da, None, None, None, None, None, None, None
+        db = torch.empty_like(b)
+        ops.attention_bwd(do, a, b, b, o, lse, da, db, db, B, H, Sq, Sk, dh, *offs, *offs, causal=causal, kpm=kpm, p_drop=p, seed=rt.seed, call_id=call)
+        return da, db, None, None, None, None, None, None
+
+
+class XentFn(Function):
+    """nn.CrossEntropyLoss(label_smoothing, ignore_index) on fp32 logits; dlogits produced by the same pass."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index, eps, rt):
+        cl, dl = ops.xent(logits.contiguous(), target.contiguous(), ignore_index, eps, rt.dtype)
+        ctx.save_for_backward(dl)
+        return cl[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return (dl * g.to(dl.dtype)).float(), None, None, None, None  # scalar chain rule: plumbing
+
+
+# ----------------------------------------------------------------------------------------------
+# convolutional backbone (NHWC)
+# ----------------------------------------------------------------------------------------------
+class ConvFn(Function):
+    """NHWC conv2d through the implicit-im2col GEMM.  W is the fp32 OIHW master weight.
+    `pos` (optional, constant [OH*OW, Co]) is added to every image (fused positional table)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, stride, pad, pos, rt):
+        B, H, Wd, C = x.shape
+        Co, Ci, kh, kw = W.shape
+        OH, OW = (H + 2 * pad - kh) // stride + 1, (Wd + 2 * pad - kw) // stride + 1
+        M = B * OH * OW
+        x = x.contiguous()
+        bias = b.detach() if b is not None else None
+        if kh == 1 and stride == 1:
+            if pos is not None:  # batched over images so the [hw, Co] table is shared (batch stride 0)
+                hw = OH * OW
+                y = ops.gemm(x.view(-1, C), rt.lp(W).view(Co, Ci), hw, Co, Ci, bias=bias, res=pos, batch=(B, 1),
+                             sA=(hw * Ci, 0), sC=(hw * Co, 0), sR=(0, 0), out=torch.empty(M, Co, dtype=x.dtype, device=x.device))
+            else:
+                y = ops.gemm(x.view(-1, C), rt.lp(W).view(Co, Ci), M, Co, Ci, bias=bias)
+        else:
+            assert pos is None
+            geom = dict(RH=OH, RW=OW, SH=H, SW=Wd, SC=C, KH=kh, KW=kw, stride=stride, pad=pad, mode=0)
+            y = ops.gemm(x, rt.lp(W, "ohwi"), M, Co, kh * kw * C, conv=geom, gather=1, bias=bias)
+        ctx.save_for_backward(x, W)
+        ctx.cfg = (stride, pad, OH, OW, b is not None, rt)
+        return y.view(B, OH, OW, Co)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        stride, pad, OH, OW, has_b, rt = ctx.cfg
+        B, H, Wd, C = x.shape
+        Co, Ci, kh, kw = W.shape
+        M = B * OH * OW
+        dy = dy.contiguous()
+        dy2 = dy.view(M, Co)
+        dx = dW = db = None
+        one = kh == 1 and stride == 1
+        if ctx.needs_input_grad[0]:
+            if one:
+                dx = ops.gemm(dy2, rt.lp(W).view(Co, Ci), M, Ci, Co, b_kcontig=False).view(B, H, Wd, C)
+            else:
+                geom = dict(RH=H, RW=Wd, SH=OH, SW=OW, SC=Co, KH=kh, KW=kw, stride=stride, pad=pad, mode=1)
+                dx = ops.gemm(dy, rt.lp(W, "ikwo"), B * H * Wd, C, kh * kw * Co, conv=geom, gather=1).view(B, H, Wd, C)
+        if ctx.needs_input_grad[1]:
+            if one:
+                dW = wgrad(dy2, x.view(-1, C), Co, Ci, M).view(Co, Ci, 1, 1)
+            else:
+                geom = dict(RH=OH, RW=OW, SH=H, SW=Wd, SC=C, KH=kh, KW=kw, stride=stride, pad=pad, mode=0)
+                g = ops.gemm(dy2, x, Co, kh * kw * C, M, a_kcontig=False, b_kcontig=False, conv=geom, gather=2,
+                             out_dtype=torch.float32, splitk=_splitk_for(Co, kh * kw * C, M))
+                # fp32 [Co][kh][kw][Cpad] -> OIHW master layout (drops the stem's channel padding)
+                dW = ops.permute4(g, (Co, Ci, kh, kw), (kh * kw * C, 1, kw * C, C), kw, torch.float32)
+        if has_b and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy2, M, Co)
+        return dx, dW, db, None, None, None, None
+
+
+def conv2d(x, W, b, stride, pad, rt, pos=None):
+    return ConvFn.apply(x, W, b, stride, pad, pos, rt)
+
+
+class BatchNormFn(Function):
+    """y = relu?(BN(x) (+ res)) on NHWC; batch statistics + running-stat update in training."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, rm, rv, res, relu, training, rt):
+        shp = x.shape
+        x2 = x.contiguous().view(-1, shp[-1])
+        y, mean, rstd = ops.bn_forward(x2, g.detach(), b.detach(), rm, rv, training, relu, res.contiguous().view(-1, shp[-1]) if res is not None else None)
+        ctx.save_for_backward(x2, y, g, mean, rstd)
+        ctx.cfg = (relu, res is not None, training, shp)
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, y, g, mean, rstd = ctx.saved_tensors
+        relu, has_res, training, shp = ctx.cfg
+        assert training, "BatchNorm backward is implemented for batch statistics (train mode)"
+        dx, dg, db, dres = ops.bn_backward(x2, dy.contiguous().view(-1, shp[-1]), y, g.detach(), mean, rstd, relu, has_res)
+        return dx.view(shp), dg, db, None, None, (dres.view(shp) if has_res else None), None, None, None
+
+
+class MaxPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y, arg = ops.maxpool_fwd(x.contiguous())
+        ctx.save_for_backward(arg)
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.maxpool_bwd(dy.contiguous(), ctx.saved_tensors[0], ctx.shape)
+
+
+class UpsampleAddFn(Function):
+    """(up, s) = (nearest_upsample(src), nearest_upsample(src) + lateral)  -- FPN top-down step."""
+
+    @staticmethod
+    def forward(ctx, src, lateral):
+        ctx.shape = tuple(src.shape)
+        return ops.upsample_add(src.contiguous(), lateral.contiguous())
+
+    @staticmethod
+    def backward(ctx, g_up, g_sum):
+        g_up, g_sum = g_up.contiguous(), g_sum.contiguous()
+        return ops.upsample_bwd(g_up, g_sum, ctx.shape), g_sum

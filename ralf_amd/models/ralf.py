@@ -1,0 +1,365 @@
+"""RALF generator and the Autoreg baseline on the MI355X HIP path.
+
+Drop-in for the classes exported by image2layout/train/models/generator.py:
+  ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg
+      image2layout/train/models/retrieval_augmented_autoreg.py:60-216,635-785,944-1033
+  ConcateAuxilaryTaskAutoreg
+      image2layout/train/models/autoreg.py:29-118,590-622
+Same constructor keywords, method set (preprocess / train_loss / sample / optim_groups /
+update_per_epoch / compute_stats / aggregate_sampling_config), attributes and state_dict layout
+(SURVEY.md section 8b).  Device arithmetic runs only through libralf_hip.so; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import logging
+import random
+from typing import Iterable, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import functional as RF
+from .. import nn as RN
+from ..functional import Runtime
+from ..helpers.sampling import DECODE_SPACE_RESTRICTION, sample as sample_tokens
+from ..helpers.task import COND_TYPES, get_condition
+from ..helpers.task_preprocessor import PREPROCESSOR
+
+logger = logging.getLogger(__name__)
+_DTYPES = {"float32": torch.float32, "fp32": torch.float32, "bfloat16": torch.bfloat16, "bf16": torch.bfloat16}
+NEG_INF = -float("inf")
+
+
+def _num_classes(features) -> int:
+    f = features["label"] if not hasattr(features, "num_classes") else features
+    f = getattr(f, "feature", f)
+    return int(f.num_classes)
+
+
+class _GeneratorBase(nn.Module):
+    """Host-side API shared by both generators (BaseModel, common/base_model.py:118-389)."""
+
+    def _init_runtime(self, compute_dtype):
+        dt = _DTYPES[compute_dtype] if isinstance(compute_dtype, str) else compute_dtype
+        self.rt = Runtime(dt)
+
+    # ---- torch.nn.Module plumbing -------------------------------------------------------------
+    def train(self, mode: bool = True):
+        super().train(mode)
+        self.rt.training = mode
+        return self
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    @property
+    def compute_dtype(self):
+        return self.rt.dtype
+
+    @property
+    def special_token_ids(self):
+        ids = {k: self.tokenizer.name_to_id(k) for k in self.tokenizer.special_tokens}
+        ids.setdefault("mask", -1)
+        return ids
+
+    def compute_stats(self) -> None:
+        logger.info("number of parameters: %.2fM", sum(p.numel() for p in self.parameters()) / 1e6)
+
+    def update_per_epoch(self, epoch: int, freeze_dis_epoch: int, max_epoch: int) -> None:
+        pass
+
+    def aggregate_sampling_config(self, sampling_cfg, test_cfg=None):
+        if test_cfg is not None and getattr(test_cfg, "cond_type", None) == "refinement":
+            for name in ("mode", "offset_ratio", "lambda"):
+                key = f"refine_{name}"
+                if hasattr(test_cfg, key) or (isinstance(test_cfg, dict) and key in test_cfg):
+                    sampling_cfg[key] = test_cfg[key]
+        return sampling_cfg
+
+    def optim_groups(self, base_lr: Optional[float] = None, weight_decay: float = 0.0, forced_no_weight_decay=None,
+                     custom_lr: Optional[dict] = None) -> Iterable[dict]:
+        """AdamW groups with the reference's rule (common/base_model.py:207-347): matrix weights of
+        Linear / attention / Conv decay; biases, LayerNorm / BatchNorm / Embedding weights do not;
+        frozen parameters are skipped; `custom_lr` maps a name prefix to its own learning rate."""
+        named = {n: p for n, p in self.named_parameters() if p.requires_grad}
+        emb_like = ("emb.weight", "task_emb.weight", "emb_label.weight", "emb_hybrid_ret.weight")
+        decay, no_decay = set(), set()
+        for n, p in named.items():
+            if n.endswith("bias") or p.ndim <= 1 or n.endswith(emb_like) or (forced_no_weight_decay and n in forced_no_weight_decay):
+                no_decay.add(n)
+            else:
+                decay.add(n)
+        groups, taken = [], set()
+        for prefix, lr in (custom_lr or {}).items():
+            for names, wd in ((decay, weight_decay), (no_decay, 0.0)):
+                sel = sorted(n for n in names if n.startswith(prefix))
+                if sel:
+                    groups.append({"params": [named[n] for n in sel], "weight_decay": wd, "lr": lr})
+                    taken.update(sel)
+        for names, wd in ((decay, weight_decay), (no_decay, 0.0)):
+            sel = sorted(n for n in names if n not in taken)
+            if sel:
+                groups.append({"params": [named[n] for n in sel], "weight_decay": wd, "lr": base_lr})
+        return groups
+
+    def postprocess(self, outputs: dict) -> dict:
+        if "seq" in outputs:
+            seq = outputs["seq"]
+        else:
+            logits = outputs["logits"].clone()
+            logits[:, ~self.tokenizer.token_mask.to(logits.device)] = NEG_INF
+            seq = torch.argmax(logits, dim=-1)
+        return self.tokenizer.decode(seq)
+
+    # ---- shared model pieces --------------------------------------------------------------------
+    def _build_common(self, tokenizer, d_model, auxilary_task, use_flag_embedding, use_multitask, global_task_embedding, decoder_d_model=256):
+        assert auxilary_task in COND_TYPES, f"{auxilary_task=} must be one of {COND_TYPES}"
+        assert d_model == 256 and decoder_d_model == 256, "the reference configs use d_model = 256"
+        self.tokenizer = tokenizer
+        self.d_model = d_model
+        self.num_layers, self.nhead, self.dropout = 6, 8, 0.1
+        self.dim_feedforward = 4 * d_model
+        self.auxilary_task, self.use_multitask, self.global_task_embedding = auxilary_task, use_multitask, global_task_embedding
+        assert not global_task_embedding, "global_task_embedding=True is not used by any shipped config"
+        self.preprocessor = PREPROCESSOR[auxilary_task](tokenizer=tokenizer, global_task_embedding=global_task_embedding)
+        self.encoder = RN.ResnetFeatureExtractor(d_model)
+        self.transformer_encoder = RN.LayerStack([RN.TransformerEncoderLayer(d_model, self.nhead, self.dim_feedforward, self.dropout, True)
+                                                  for _ in range(self.num_layers)])
+        self.decoder = RN.BaseDecoder(tokenizer.N_total, decoder_d_model, self.num_layers, self.nhead, self.dim_feedforward)
+        self.user_const_encoder = RN.UserConstraintTransformerEncoder(d_model, self.nhead, self.num_layers, self.preprocessor.N_total, self.dim_feedforward)
+        self.use_flag_embedding = use_flag_embedding
+        if use_flag_embedding:
+            self.task_emb = RN.Affine(2, 1)
+            self.register_buffer("flag_img", torch.zeros(1).long())
+            self.register_buffer("flag_user_const", torch.ones(1).long())
+
+    def set_task_preprocessor(self, task: str) -> None:
+        assert task in COND_TYPES
+        if not self.use_multitask:
+            return
+        self.auxilary_task = task
+        self.preprocessor = PREPROCESSOR[task](tokenizer=self.tokenizer, global_task_embedding=self.global_task_embedding)
+
+    def get_random_task(self) -> str:
+        tasks = ["uncond", "c", "cwh", "partial", "refinement", "relation"]
+        return random.choices(tasks, weights=[1 / 12, 1 / 3, 1 / 3, 1 / 12, 1 / 3, 1 / 12])[0]
+
+    def init_weights(self) -> None:
+        """reference initialisation (retrieval_augmented_autoreg.py:171-175, common/common.py:69-82,228-236)
+        on top of torch-default-like fills for the rest."""
+        g = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
+        for name, p in self.named_parameters():
+            with torch.no_grad():
+                if name.endswith("bias"):
+                    p.zero_()
+                elif p.ndim == 1:
+                    p.fill_(1.0)
+                elif name.endswith(("emb.weight", "task_emb.weight", "decoder.head.1.weight")):
+                    p.normal_(0.0, 0.02, generator=g)
+                elif name.endswith("emb_label.weight") or name.endswith("token"):
+                    p.normal_(0.0, 1.0, generator=g)
+                elif p.ndim == 4:  # conv: He (fan_out) like timm's resnet init
+                    fan_out = p.shape[0] * p.shape[2] * p.shape[3]
+                    p.normal_(0.0, (2.0 / fan_out) ** 0.5, generator=g)
+                else:              # xavier-uniform matrices
+                    a = (6.0 / (p.shape[0] + p.shape[1])) ** 0.5
+                    p.uniform_(-a, a, generator=g)
+
+    def _constraint_memory(self, img_mem, inputs):
+        rt = self.rt
+        cf = self.user_const_encoder(inputs["seq_layout_const"], inputs["seq_layout_const_pad_mask"], rt)
+        if self.use_flag_embedding:  # learned scalars broadcast over all channels (retrieval_augmented_autoreg.py:1022-1028)
+            img_mem = RF.AddScalarFn.apply(img_mem, self.task_emb.weight, 0)
+            cf = RF.AddScalarFn.apply(cf, self.task_emb.weight, 1)
+        return torch.cat([img_mem, cf], dim=1)  # sequence concat: plumbing copy
+
+    def _image_memory(self, image):
+        rt = self.rt.to(image.device)
+        x = self.encoder(image, rt)  # [B, hw, d] with the 2-D sine table already added
+        for layer in self.transformer_encoder.layers:
+            x = layer(x, rt)
+        return x
+
+    def forward(self, inputs: dict) -> dict:
+        self.rt.to(inputs["seq"].device).begin_step()
+        memory = self._encode_into_memory(inputs)["memory"]
+        logits = self.decoder(inputs["seq"], memory, self.rt, inputs["tgt_key_padding_mask"])
+        return {"logits": logits}
+
+    def train_loss(self, inputs: dict, targets: dict, test: bool = False):
+        outputs = self(inputs)
+        loss = RF.XentFn.apply(outputs["logits"], targets["seq"], self.tokenizer.name_to_id("pad"), 0.1, self.rt)
+        return outputs, {"nll_loss": loss}
+
+    # ---- autoregressive sampling (full-prefix recompute like the reference; KV cache = next round) ----
+    @torch.no_grad()
+    def sample(self, cond, batch_size: Optional[int] = None, sampling_cfg=None, cond_type: Optional[str] = "uncond",
+               return_violation: bool = False, use_backtrack: bool = True, return_decoded_cond: bool = False, **kwargs):
+        if self.use_multitask:
+            self.set_task_preprocessor(cond.task)
+        if cond_type == "relation":
+            raise NotImplementedError("relation decoding needs the authors' relationship table")
+        dev = self.device
+        B = cond.image.size(0)
+        if B == 1 and batch_size and batch_size > 1:
+            B = batch_size
+            cond.image = cond.image.expand(B, -1, -1, -1).contiguous()
+        ids = self.special_token_ids
+        token_mask = self.tokenizer.token_mask.to(dev)
+        enc_in, _ = self._create_encoder_inputs(cond)
+        enc_in = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in enc_in.items()}
+        self.rt.to(dev).begin_step()
+        memory = self._encode_into_memory(enc_in)["memory"]
+        seq = torch.full((B, 1), ids["bos"], dtype=torch.long, device=dev)
+        start = 0
+        if cond_type == "partial":
+            seq = torch.cat([seq, cond.seq[:, 1:6].to(dev)], dim=1)
+            start = 5
+        cond_seq = cond.seq.to(dev) if cond.seq is not None else None
+        restrict = DECODE_SPACE_RESTRICTION[cond_type]
+        for i in range(start, self.tokenizer.max_token_length):
+            logits = self.decoder(seq, memory, self.rt, seq == ids["pad"])[:, i].clone()
+            logits[:, ~token_mask[i]] = NEG_INF
+            logits = restrict(i + 1, cond_seq, logits, pad_id=ids["pad"], eos_id=ids["eos"], max_length=self.tokenizer.max_token_length)
+            seq = torch.cat([seq, sample_tokens(logits, sampling_cfg)], dim=1)
+        out_tokens = seq[:, 1:].cpu()
+        result = self.postprocess({"seq": out_tokens})
+        if not return_violation:
+            return result
+        return result, self._violation(cond_type, cond, out_tokens)
+
+    def _violation(self, cond_type, cond, out_tokens) -> dict:
+        """layoutformerpp/violate.py:24-141 for the table-free tasks."""
+        if cond_type in ("uncond", "none", None, "partial"):
+            return {"total": 1, "viorated": 0}
+        pad, eos = self.tokenizer.name_to_id("pad"), self.tokenizer.name_to_id("eos")
+        total = bad = 0
+        cs, cm = cond.seq[:, 1:].cpu(), cond.mask[:, 1:].cpu()
+        for b in range(cs.size(0)):
+            given = cs[b][cm[b]]
+            given = given[(given != pad) & (given != eos)]
+            if cond_type == "refinement":
+                got, given = out_tokens[b][: given.size(0)][::5], given[::5]
+            else:
+                got = out_tokens[b][cm[b]]
+                got = got[(got != pad) & (got != eos)]
+            assert given.size(0) == got.size(0)
+            bad += int((given != got).sum())
+            total += given.size(0)
+        return {"total": total, "viorated": bad}
+
+    def _create_encoder_inputs(self, cond):
+        seqc = self.preprocessor(cond)
+        enc = {"image": cond.image, "seq_layout_const": seqc["seq"], "seq_layout_const_pad_mask": seqc["pad_mask"]}
+        if getattr(cond, "retrieved", None):
+            enc["retrieved"] = cond.retrieved
+        return enc, seqc
+
+
+class ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg(_GeneratorBase):
+    """Final RALF architecture ("# Final architecture", retrieval_augmented_autoreg.py:997-1033)."""
+
+    def __init__(self, features, tokenizer, dataset_name: str, max_seq_length: int, db_dataset=None, d_model: int = 256,
+                 encoder_pos_emb: str = "sine", decoder_pos_emb: str = "layout", weight_init: bool = True, top_k: int = 16,
+                 layout_backbone: str = "feature_extractor", use_reference_image: bool = False, freeze_layout_encoder: bool = True,
+                 retrieval_backbone: str = "saliency", random_retrieval: bool = False, saliency_k=8, decoder_d_model: int = 256,
+                 auxilary_task: Optional[str] = None, use_flag_embedding: bool = True, use_multitask: bool = False, RELATION_SIZE: int = 10,
+                 shared_embedding: bool = False, global_task_embedding: bool = False, compute_dtype="float32", **_ignored):
+        super().__init__()
+        assert encoder_pos_emb == "sine" and decoder_pos_emb == "layout" and not use_reference_image and not shared_embedding
+        assert freeze_layout_encoder is True and saliency_k != "dynamic"
+        self._init_runtime(compute_dtype)
+        self.features = features
+        self.dataset_name, self.max_seq_length, self.top_k = dataset_name, max_seq_length, top_k
+        self.retrieval_backbone, self.random_retrieval, self.saliency_k = retrieval_backbone, random_retrieval, saliency_k
+        self.use_reference_image, self.layout_backbone, self.weight_init = use_reference_image, layout_backbone, weight_init
+        self._build_common(tokenizer, d_model, auxilary_task, use_flag_embedding, use_multitask, global_task_embedding, decoder_d_model)
+        self.layout_encoer = RN.LayoutEncoder(_num_classes(features))  # [sic] checkpoint key of the reference
+        self.pos_emb_1d = RN.PosEnc1d(d_model, 5000)
+        self.layout_adapter = RN.FeedForward(256, 4 * d_model, d_model)
+        self.head = RN.FeedForward(d_model, 4 * d_model)
+        self.attn = RN.FuseAttention(d_model, d_model, heads=8, dim_head=64)
+        self.init_weights()
+        for p in self.layout_encoer.parameters():
+            p.requires_grad = False
+
+    def preprocess(self, inputs: dict):
+        """host path a12 (retrieval_augmented_autoreg.py:764-785,509-523)."""
+        if self.use_multitask:
+            self.set_task_preprocessor(self.get_random_task())
+        cond, inputs = get_condition(inputs, self.auxilary_task, self.tokenizer)
+        seqc = self.preprocessor(cond)
+        data = self.tokenizer.encode(inputs)
+        image = torch.cat([inputs["image"], inputs["saliency"]], dim=1)
+        assert inputs["retrieved"]["image"].size(2) == 4
+        _inputs = {"seq": data["seq"][:, :-1], "tgt_key_padding_mask": ~data["mask"][:, :-1], "image": image,
+                   "retrieved": inputs["retrieved"], "seq_layout_const": seqc["seq"], "seq_layout_const_pad_mask": seqc["pad_mask"]}
+        return _inputs, {"seq": data["seq"][:, 1:]}
+
+    def _retrieved_features(self, retrieved: dict, device) -> torch.Tensor:
+        """extract_retrieved_features (retrieval_augmented_autoreg.py:526-584): frozen layout encoder over
+        all B*K exemplars in one batch -> layout_adapter -> x*sqrt(d) + PE[0:K] (+dropout)."""
+        rt = self.rt
+        K = self.top_k
+        B = retrieved["label"].shape[0]
+        flat = {k: retrieved[k][:, :K].reshape(B * K, -1).to(device) for k in ("label", "mask", "center_x", "center_y", "width", "height")}
+        f = self.layout_encoer.extract_features(flat, rt)                    # [B*K, 256], no grad
+        f = self.layout_adapter(f, rt).view(B, K, -1)
+        pe = RN.ops.cast(self.pos_emb_1d.pe[0, :K].contiguous(), rt.dtype)
+        f = _ScaleAddPE.apply(f, pe, self.d_model ** 0.5)
+        return RF.drop_add(f, None, rt.drop_p(self.pos_emb_1d.p), rt)
+
+    def _encode_into_memory(self, inputs: dict) -> dict:
+        rt = self.rt
+        assert inputs["image"].size(1) == 4
+        mem = self._image_memory(inputs["image"])
+        ref = self._retrieved_features(inputs["retrieved"], mem.device)
+        ca = self.attn(mem, ref, rt)
+        fused = self.head(torch.cat([mem, ca, ref], dim=1), rt)  # sequence concat: plumbing copy
+        return {"memory": self._constraint_memory(fused, inputs)}
+
+
+class _ScaleAddPE(torch.autograd.Function):
+    """x * s + pe (PositionalEncoding1d on the K retrieved features); tiny [B,K,d] tensor."""
+
+    @staticmethod
+    def forward(ctx, x, pe, s):
+        ctx.s = s
+        B, K, d = x.shape
+        # ralf_gemm-free: reuse the embedding kernel contract through copy2d would need a scale; the
+        # residual epilogue of a 1x1 identity is overkill -> torch elementwise on a B*K*d tensor (plumbing-sized)
+        return x * s + pe
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy * ctx.s, None, None
+
+
+class ConcateAuxilaryTaskAutoreg(_GeneratorBase):
+    """Autoreg baseline without retrieval (autoreg.py:29-118, 466-622): BASELINE config 1."""
+
+    def __init__(self, features, tokenizer, d_model: int = 256, encoder_pos_emb: str = "sine", decoder_pos_emb: str = "layout",
+                 weight_init: bool = False, shared_embedding: bool = False, decoder_num_layers: int = 6, decoder_d_model: int = 256,
+                 auxilary_task: Optional[str] = None, use_flag_embedding: bool = True, use_multitask: bool = False, RELATION_SIZE: int = 10,
+                 global_task_embedding: bool = False, compute_dtype="float32", **_ignored):
+        super().__init__()
+        assert encoder_pos_emb == "sine" and decoder_pos_emb == "layout" and not shared_embedding and decoder_num_layers == 6
+        self._init_runtime(compute_dtype)
+        self.features = features
+        self._build_common(tokenizer, d_model, auxilary_task, use_flag_embedding, use_multitask, global_task_embedding, decoder_d_model)
+        self.init_weights()
+
+    def preprocess(self, inputs: dict):
+        if self.use_multitask:
+            self.set_task_preprocessor(self.get_random_task())
+        cond, inputs = get_condition(inputs, self.auxilary_task, self.tokenizer)
+        seqc = self.preprocessor(cond)
+        data = self.tokenizer.encode(inputs)
+        image = torch.cat([inputs["image"], inputs["saliency"]], dim=1)
+        _inputs = {"seq": data["seq"][:, :-1], "tgt_key_padding_mask": ~data["mask"][:, :-1], "image": image,
+                   "seq_layout_const": seqc["seq"], "seq_layout_const_pad_mask": seqc["pad_mask"]}
+        return _inputs, {"seq": data["seq"][:, 1:]}
+
+    def _encode_into_memory(self, inputs: dict) -> dict:
+        return {"memory": self._constraint_memory(self._image_memory(inputs["image"]), inputs)}

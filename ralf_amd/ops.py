@@ -134,9 +134,10 @@ def embed_bwd(idx, dy, vocab, scale):
     return dW
 
 
-def dropout(x, p, seed, call_id):
+def dropout(x, p, seed, call_id, res=None):
+    """y = dropout(x) (+ res); p == 0 -> plain add."""
     y = torch.empty_like(x)
-    _call("ralf_dropout", dtype_code(x), _p(x), _p(y), x.numel(), p, _p(seed), call_id)
+    _call("ralf_dropout", dtype_code(x), _p(x), _p(res), _p(y), x.numel(), p, _p(seed), call_id)
     return y
 
 
