@@ -168,8 +168,9 @@ int ralf_attention_bwd(const RalfAttnDesc* d, void* stream);
  * ------------------------------------------------------------------------------------------- */
 int ralf_sumsq(const float* g, int64_t n, float* out, void* stream);
 int ralf_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream);
+/* step_dev (int32[1] on the device, may be NULL) overrides `step` for the bias corrections (graph replay) */
 int ralf_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1, float beta2, float eps,
-               float weight_decay, int step, const float* coef, void* stream);
+               float weight_decay, int step, const float* coef, const int* step_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -40,8 +40,13 @@ __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                      bf16* __restrict__ shadow, int64_t n, float lr, float b1, float b2, float eps, float wd,
-                                                     float bc1, float bc2_sqrt, const float* __restrict__ coef) {
+                                                     float bc1, float bc2_sqrt, const float* __restrict__ coef, const int* __restrict__ step_dev) {
     const float c = coef ? coef[0] : 1.f;
+    if (step_dev) {  // step counter lives on the device (captured graphs): bias corrections follow it
+        const float t = (float)step_dev[0];
+        bc1 = 1.f - powf(b1, t);
+        bc2_sqrt = sqrtf(1.f - powf(b2, t));
+    }
     const float step = lr / bc1;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
         const float gr = g[e] * c;
@@ -68,12 +73,13 @@ extern "C" int ralf_clip_coef(const float* sumsq, float max_norm, float* coef, f
     hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, coef, norm_out);
     return ralf::check_launch("clip_coef");
 }
-/* torch.optim.AdamW semantics (decoupled decay, bias correction with step count `step` >= 1);
- * gradients are multiplied by coef[0] (device scalar, may be NULL); shadow = optional bf16 copy of p */
+/* torch.optim.AdamW semantics (decoupled decay, bias correction with step count `step` >= 1, or the
+ * device-resident counter step_dev[0] when given); gradients are multiplied by coef[0] (device scalar,
+ * may be NULL); shadow = optional bf16 copy of p */
 extern "C" int ralf_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1, float beta2, float eps,
-                          float weight_decay, int step, const float* coef, void* stream) {
-    RALF_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw: bad arguments");
+                          float weight_decay, int step, const float* coef, const int* step_dev, void* stream) {
+    RALF_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || step_dev), "adamw: bad arguments");
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), coef);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), coef, step_dev);
     return ralf::check_launch("adamw");
 }

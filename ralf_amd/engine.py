@@ -1,0 +1,171 @@
+"""Training-step engine: flat parameter / gradient buffers, fused clip + AdamW (HIP), whole-step
+hipGraph capture, data-parallel gradient all-reduce over RCCL.
+
+Replaces the inner loop of image2layout/train/train.py:409-489 (`train`): forward, loss.backward(),
+clip_grad_norm_(0.1), optimizer.step() -- with the same arithmetic (AdamW groups from
+`optim_groups`, global-norm clip) but
+  * gradients of all trainable tensors live in ONE fp32 buffer (one collective, one norm pass),
+  * the update is one kernel per (lr, weight-decay) group and also refreshes the bf16 weight shadow,
+  * the whole step is captured once into a hipGraph and replayed (launch-bound otherwise: ~1.5k
+    kernels per step), with the dropout seed advanced on the device.
+The reference's DDP wiring never all-reduces (SURVEY.md section 5 "DDP quirk"); this engine does.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+def _align(n, a=64):
+    return (n + a - 1) // a * a
+
+
+class FlatAdamW:
+    """AdamW + global-norm clipping over flat buffers; `groups` as returned by model.optim_groups()."""
+
+    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8, max_norm: float = 0.0, shadow_dtype=None, runtime=None):
+        self.betas, self.eps, self.max_norm = betas, eps, max_norm
+        params = [p for g in groups for p in g["params"]]
+        dev = params[0].device
+        sizes = [_align(p.numel()) for p in params]
+        total = sum(sizes)
+        self.P = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.G = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.M = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.V = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.P16 = torch.zeros(total, dtype=torch.bfloat16, device=dev) if shadow_dtype == torch.bfloat16 else None
+        self.groups = []
+        off = 0
+        for g in groups:
+            start = off
+            for p in g["params"]:
+                n = p.numel()
+                self.P[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.P[off:off + n].view(p.shape)
+                p.grad = self.G[off:off + n].view(p.shape)
+                if self.P16 is not None and runtime is not None:
+                    runtime.register_shadow(p, self.P16[off:off + n].view(p.shape))
+                off += _align(n)
+            self.groups.append({"range": (start, off), "lr": g["lr"], "weight_decay": g["weight_decay"]})
+        if self.P16 is not None:
+            self.P16.copy_(self.P)
+        self.step_count = 0
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)  # device-resident step counter (graph replay)
+        self.runtime = runtime
+        self._ss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.coef = torch.ones(1, dtype=torch.float32, device=dev)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def zero_grad(self):
+        self.G.zero_()
+
+    def clip(self):
+        self._ss.zero_()
+        ops.sumsq(self.G, self._ss)
+        ops.clip_coef(self._ss, self.max_norm, self.coef, self.grad_norm)
+
+    def step(self):
+        """the step counter for the bias corrections is advanced ON THE DEVICE, so a captured graph
+        replays with the right corrections."""
+        self.step_count += 1
+        self.step_dev.add_(1)
+        if self.max_norm > 0:
+            self.clip()
+        for g in self.groups:
+            a, b = g["range"]
+            ops.adamw(self.P[a:b], self.G[a:b], self.M[a:b], self.V[a:b], g["lr"], self.betas[0], self.betas[1], self.eps,
+                      g["weight_decay"], 1, self.coef if self.max_norm > 0 else None,
+                      self.P16[a:b] if self.P16 is not None else None, self.step_dev)
+        if self.runtime is not None:
+            self.runtime.weights_changed()
+
+
+def _clone_tree(x):
+    if torch.is_tensor(x):
+        return x.clone()
+    if isinstance(x, dict):
+        return {k: _clone_tree(v) for k, v in x.items()}
+    return x
+
+
+def _copy_tree(dst, src):
+    if torch.is_tensor(dst):
+        dst.copy_(src, non_blocking=True)
+    elif isinstance(dst, dict):
+        for k in dst:
+            _copy_tree(dst[k], src[k])
+
+
+class TrainStep:
+    """One optimisation step of `model` (a ralf_amd generator) = forward + backward + (all-reduce) + clip + AdamW."""
+
+    def __init__(self, model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, backbone_lr_scale=0.1, betas=(0.9, 0.999), eps=1e-8,
+                 use_graph=True, process_group=None):
+        self.model = model
+        rt = model.rt.to(model.device)
+        groups = model.optim_groups(base_lr=lr, weight_decay=weight_decay, custom_lr={"encoder.extractor.body": lr * backbone_lr_scale})
+        self.opt = FlatAdamW(groups, betas, eps, max_norm, shadow_dtype=rt.dtype if rt.dtype == torch.bfloat16 else None, runtime=rt)
+        self.use_graph = use_graph
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if (process_group is not None or torch.distributed.is_initialized()) else 1
+        self._static = None
+        self._graphs = None
+        self.loss = None
+        self.steps_done = 0
+
+    # ---- the step body, split at the collective so multi-GPU runs can keep RCCL outside the graphs ----
+    def _fwd_bwd(self, inputs, targets):
+        self.opt.zero_grad()
+        _, losses = self.model.train_loss(inputs, targets)
+        losses["nll_loss"].backward()
+        return losses["nll_loss"].detach()
+
+    def _allreduce(self):
+        if self.world > 1:
+            torch.distributed.all_reduce(self.opt.G, op=torch.distributed.ReduceOp.AVG, group=self.pg)
+
+    def _update(self):
+        self.opt.step()
+        self.model.rt.advance_seed()
+
+    def _eager(self, inputs, targets):
+        loss = self._fwd_bwd(inputs, targets)
+        self._allreduce()
+        self._update()
+        return loss
+
+    def __call__(self, inputs, targets):
+        if not self.use_graph:
+            self.loss = self._eager(inputs, targets)
+        else:
+            if self._graphs is None:
+                self._capture(inputs, targets)
+            else:
+                _copy_tree(self._static, {"inputs": inputs, "targets": targets})
+            ga, gb = self._graphs
+            ga.replay()
+            self._allreduce()
+            gb.replay()
+        self.steps_done += 1
+        return self.loss
+
+    def _capture(self, inputs, targets):
+        self._static = _clone_tree({"inputs": inputs, "targets": targets})
+        si, st = self._static["inputs"], self._static["targets"]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up on a side stream (allocator, lazy inits, LDS attributes)
+            for _ in range(2):
+                self._eager(si, st)
+                self.steps_done += 1
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            self.loss = self._fwd_bwd(si, st)
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            self._update()
+        self._graphs = (ga, gb)

@@ -8,6 +8,7 @@ device-resident dropout seed and a per-forward stream id counter for the counter
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Optional
 
 import torch
@@ -24,6 +25,8 @@ class Runtime:
         self.seed: Optional[torch.Tensor] = None  # int64[1] on device, advanced once per step
         self._call = 0
         self._lp: dict = {}
+        self._shadow: dict = {}   # id(param) -> persistent low-precision view kept current by the fused optimizer
+        self._wtoken = 0          # bumped when weights are rewritten behind torch's version counters
 
     def to(self, device):
         if self.seed is None or self.seed.device != device:
@@ -44,13 +47,23 @@ class Runtime:
     def drop_p(self, p: float) -> float:
         return p if (self.training and p > 0.0) else 0.0
 
+    def register_shadow(self, w: torch.Tensor, view: torch.Tensor):
+        self._shadow[id(w)] = view
+
+    def weights_changed(self):
+        self._wtoken += 1
+
     # low-precision / re-laid-out shadows of fp32 master weights, refreshed when the master changes
     def lp(self, w: torch.Tensor, kind: str = "cast") -> torch.Tensor:
-        if kind == "cast" and w.dtype == self.dtype:
-            return w.detach()
+        if kind == "cast":
+            if w.dtype == self.dtype:
+                return w.detach()
+            sh = self._shadow.get(id(w))
+            if sh is not None and sh.dtype == self.dtype:
+                return sh
         key = (id(w), kind, self.dtype)
         hit = self._lp.get(key)
-        if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
+        if hit is not None and hit[3]() is w and hit[0] == (w._version, self._wtoken) and hit[1] == w.data_ptr():
             return hit[2]
         wd = w.detach()
         if kind == "cast":
@@ -64,7 +77,7 @@ class Runtime:
                 t = ops.permute4(wd, (Ci, kh, kw, Co), (kh * kw, kw, 1, Ci * kh * kw), Co, self.dtype)
             else:
                 raise ValueError(kind)
-        self._lp[key] = (w._version, w.data_ptr(), t)
+        self._lp[key] = ((w._version, self._wtoken), w.data_ptr(), t, weakref.ref(w))  # id() can be recycled: keep a weakref
         return t
 
 

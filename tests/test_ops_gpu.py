@@ -135,7 +135,8 @@ def test_batchnorm(dtype, C, M):
     btol = dict(atol=6e-2, rtol=6e-2) if dtype == torch.bfloat16 else dict(atol=2e-4, rtol=1e-3)
     fr = 0.999 if dtype == torch.bfloat16 else 1.0
     close(dx, x.grad, dtype, frac=fr, **btol); close(dres, res.grad, dtype, frac=fr)
-    close(dg, g.grad, dtype, atol=0.5 if dtype == torch.bfloat16 else 2e-3, rtol=5e-2); close(db, b.grad, dtype, atol=0.5 if dtype == torch.bfloat16 else 2e-3, rtol=5e-2)
+    close(dg, g.grad, dtype, frac=0.99 if dtype == torch.bfloat16 else 1.0, atol=0.5 if dtype == torch.bfloat16 else 2e-3, rtol=5e-2)
+    close(db, b.grad, dtype, frac=0.99 if dtype == torch.bfloat16 else 1.0, atol=0.5 if dtype == torch.bfloat16 else 2e-3, rtol=5e-2)
     # eval mode uses the running statistics
     ye = F.batch_norm(x.detach(), rm_ref, rv_ref, g.detach(), b.detach(), False, 0.1, 1e-5)
     yed, _, _ = ops.bn_forward(xd, g.detach().cuda(), b.detach().cuda(), rm_ref.cuda(), rv_ref.cuda(), False, False, None)
@@ -230,6 +231,10 @@ def test_adamw_and_clip():
         ss, coef, nrm = torch.zeros(1, device="cuda"), torch.empty(1, device="cuda"), torch.empty(1, device="cuda")
         ops.sumsq(gs.cuda(), ss); ops.clip_coef(ss, 0.1, coef, nrm)
         torch.testing.assert_close(nrm.cpu()[0], total, rtol=1e-5, atol=1e-6)
-        ops.adamw(pd, gs.cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step, coef, shadow)
+        if step % 2:   # bias corrections from the device-resident step counter (graph-replay path)
+            sd = torch.tensor([step], dtype=torch.int32, device="cuda")
+            ops.adamw(pd, gs.cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 1, coef, shadow, sd)
+        else:          # ... or from the host step argument
+            ops.adamw(pd, gs.cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step, coef, shadow)
         torch.testing.assert_close(pd.cpu(), p_ref.detach(), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(shadow.float().cpu(), pd.cpu(), rtol=1e-2, atol=1e-2)
