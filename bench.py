@@ -1,0 +1,209 @@
+"""Benchmark of the RALF hot path on MI355X (driver contract: one JSON line on rank 0).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one RALF train step (ResNet-50/FPN + encoder + retrieval fusion + constraint encoder + causal
+decoder; forward + backward + gradient all-reduce + clip + AdamW, dropout on) on one synthetic batch of
+64 PKU-like samples per GPU (BASELINE.json configs[1]), inputs resident in HBM, bf16 operands / fp32
+accumulation.  Also reported (rank 0, N = 1): the exact top-16 k-NN scan (configs[3]) and the CPU
+baselines (oracle restatement timed on the host cores, bounded samples).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic FLOPs per sample of one train step (2 x MAC; 3 x trainable forward + frozen forward)
+STEP_GFLOP_PER_SAMPLE = {10: 50.1, 32: 56.4}
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def build_model(device, N=10, dtype="bfloat16", task="uncond"):
+    from ralf_amd.helpers.layout_tokenizer import LabelFeature, LayoutSequenceTokenizer
+    from ralf_amd.models.generator import ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg as RALF
+
+    labels = ["text", "logo", "underlay"]
+    tok = LayoutSequenceTokenizer(labels, N)
+    torch.manual_seed(0)
+    model = RALF(features={"label": LabelFeature(labels)}, tokenizer=tok, dataset_name="pku", max_seq_length=N, db_dataset=None, top_k=16,
+                 retrieval_backbone="dreamsim", random_retrieval=False, saliency_k="None", auxilary_task=task, compute_dtype=dtype)
+    return model.to(device).train()
+
+
+def bench_knn(device):
+    from ralf_amd import _lib
+    from ralf_amd.retrieval.knn import knn_topk_ip
+
+    N, D, k = 61548, 1792, 16
+    g = torch.Generator(device=device).manual_seed(0)
+    X = torch.randn(N, D, device=device, generator=g)
+    X /= X.norm(dim=1, keepdim=True)
+    out = {}
+    for nq in (1024, 16):
+        Q = torch.randn(nq, D, device=device, generator=g)
+        Q /= Q.norm(dim=1, keepdim=True)
+        ws = torch.empty(_lib.lib().ralf_knn_topk_ip_workspace_bytes(N, D, nq, k), dtype=torch.uint8, device=device)
+        for _ in range(3):
+            knn_topk_ip(X, Q, k, ws)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters = 20
+        e0.record()
+        for _ in range(iters):
+            knn_topk_ip(X, Q, k, ws)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / iters * 1e-3
+        by = N * D * 4 + nq * D * 4 + nq * k * 12
+        out[f"nq{nq}"] = {"qps": nq / t, "us_per_call": t * 1e6, "algorithmic_GBps": by / t / 1e9, "hbm_frac": by / t / 1e9 / PEAK_HBM_GBS,
+                          "fp32_TFLOPs": 2.0 * nq * N * D / t / 1e12}
+    return {"index": f"{N}x{D} fp32", "k": k, **out}
+
+
+def cpu_baseline_train(N=10, B=4, steps=2):
+    """oracle (CPU restatement, fp32) RALF train step on the host cores: bounded sample of B=4, 256x256."""
+    from oracle import ralf_oracle as O
+    from oracle.detweights import det_state_dict, resnet50_fpn_shapes
+    from ralf_amd.helpers.layout_tokenizer import LayoutSequenceTokenizer
+    from ralf_amd.helpers.task import get_condition
+    from ralf_amd.helpers.task_preprocessor import PREPROCESSOR
+    from ralf_amd.synthetic import make_batch
+
+    with open(os.path.join(ROOT, "tests", "golden", "ralf_state_shapes.json")) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f)["shapes"].items()}
+    shapes.update(resnet50_fpn_shapes())
+    sd = det_state_dict(shapes)
+    params = [v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not k.startswith("layout_encoer.") and "running_" not in k and not k.endswith(".pe")]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4)
+    tok = LayoutSequenceTokenizer(["text", "logo", "underlay"], N)
+    batch = make_batch(B, N, seed=3)
+    cond, b2 = get_condition(batch, "uncond", tok)
+    seqc = PREPROCESSOR["uncond"](tokenizer=tok)(cond)
+    data = tok.encode(b2)
+    inputs = {"seq": data["seq"][:, :-1], "tgt_key_padding_mask": ~data["mask"][:, :-1], "image": torch.cat([b2["image"], b2["saliency"]], 1),
+              "retrieved": b2["retrieved"], "seq_layout_const": seqc["seq"], "seq_layout_const_pad_mask": seqc["pad_mask"]}
+    tgt = data["seq"][:, 1:]
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        logits = O.ralf_forward(sd, inputs, training_bn=True, p_drop=0.1)
+        loss = O.xent_label_smoothing(logits, tgt, tok.name_to_id("pad"))
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 0.1)
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t = sum(times[1:]) / steps
+    return {"value": B * (5 * N + 1) / t, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/ralf_oracle.py RALF train step (fp32, dropout 0.1, batch-stat BN, clip 0.1, AdamW), B={B}, 256x256, N={N}, {steps} steps after 1 warm-up; {t:.2f} s/step"}
+
+
+def cpu_baseline_knn():
+    import numpy as np
+
+    from oracle import knn_oracle
+
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((61548, 1792)).astype(np.float32)
+    Q = rng.standard_normal((32, 1792)).astype(np.float32)
+    t0 = time.perf_counter()
+    knn_oracle.topk_ip(X, Q, 16)
+    t = time.perf_counter() - t0
+    return {"qps": 32 / t, "cores": knn_oracle.threads(), "kind": "port", "sample": f"oracle/knn_oracle.c, 61548x1792 index, 32 queries in one call, {t:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE config: 64)")
+    ap.add_argument("--elements", type=int, default=10, help="max elements per layout N (reference-compatible: 10)")
+    ap.add_argument("--dtype", default="bfloat16")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-knn", action="store_true")
+    a = ap.parse_args()
+
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from ralf_amd.engine import TrainStep
+    from ralf_amd.synthetic import make_batch, to_device
+
+    N, B = a.elements, a.batch
+    model = build_model(device, N, a.dtype)
+    if world > 1:  # identical initial weights on every rank (DDP constructor broadcast in the reference, train.py:208)
+        for t in list(model.parameters()) + list(model.buffers()):
+            torch.distributed.broadcast(t.data, 0)
+    batch = make_batch(B, N, seed=1 + rank)
+    inputs, targets = model.preprocess(batch)            # host path (tokenizer / constraint serialisation)
+    inputs, targets = to_device(inputs, device), to_device(targets, device)
+    inputs["retrieved"] = {k: v for k, v in inputs["retrieved"].items() if k != "image"}
+    step = TrainStep(model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, use_graph=not a.no_graph)
+
+    for _ in range(max(a.warmup, 1)):
+        loss = step(inputs, targets)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(a.steps):
+        loss = step(inputs, targets)
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    gpu_ms = e0.elapsed_time(e1) / a.steps
+    ms = elapsed / a.steps * 1e3
+    tokens = B * (5 * N + 1)
+    final_loss = float(loss)
+
+    if rank == 0:
+        flops = STEP_GFLOP_PER_SAMPLE.get(N, 50.1) * 1e9 * B
+        out = {
+            "metric": "layout tokens/sec (RALF train step: fwd+bwd+clip+AdamW) + top-16 retrieval QPS, PKU batch=64",
+            "value": world * tokens / (ms * 1e-3), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.dtype.startswith("b") else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"RALF PKU (configs/ralf_pku), k=16 retrieval, task uncond, 256x256 canvases, N={N} elements (S={5 * N}), batch {B} per GPU, dropout 0.1, AdamW+clip 0.1",
+                       "tokens_per_step_per_gpu": tokens, "samples_per_s": world * B / (ms * 1e-3), "parallelism": f"dp{world}", "hip_graph": not a.no_graph, "final_loss": final_loss},
+            "roofline": {"bound": "mfma", "achieved": flops / (gpu_ms * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / (gpu_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
+                         "note": f"whole train step: {flops / 1e12:.3f} algorithmic TFLOP per launch (SURVEY 8d: {STEP_GFLOP_PER_SAMPLE.get(N, 50.1)} GFLOP/sample x {B}) / {gpu_ms:.2f} ms (HIP events); per-kernel split in profiles/"},
+        }
+        if world == 1 and not a.skip_knn:
+            out["knn"] = bench_knn(device)
+            k16 = out["knn"]["nq16"]
+            out["roofline_knn"] = {"bound": "hbm", "achieved": k16["algorithmic_GBps"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": k16["hbm_frac"], "traffic": None,
+                                   "note": "exact top-16 scan, 61548x1792 fp32 index streamed once, nq=16 (HBM-bound regime); nq=1024 is fp32-FLOP-bound, see knn.nq1024"}
+        if world == 1 and not a.skip_cpu:
+            out["cpu_baseline"] = cpu_baseline_train(N)
+            out["cpu_baseline_knn"] = cpu_baseline_knn()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
