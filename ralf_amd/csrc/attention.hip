@@ -44,10 +44,13 @@ constexpr int SL = 32;     // slice of the tile owned by one wave
 template <typename T, int DH>
 __device__ __forceinline__ void stage_rows(float* dst, const T* base, int64_t row_stride, int t0, int S, float mul) {
     constexpr int VPR = DH / 4;
-    for (int e = threadIdx.x; e < TILE * VPR; e += 256) {
+    // only the 32-row slices of waves that have work are touched: zero-fill up to the next slice boundary
+    // (masked entries multiply these rows by p = 0, so they must be finite), skip the rest of the tile
+    const int nrows = min(TILE, S - t0), nfill = min(TILE, (nrows + SL - 1) / SL * SL);  // (bwd kernels walk whole slices)
+    for (int e = threadIdx.x; e < nfill * VPR; e += 256) {
         const int r = e / VPR, c = e % VPR;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t0 + r < S) v = V4<T>::load(base + (int64_t)(t0 + r) * row_stride + c * 4);
+        if (r < nrows) v = V4<T>::load(base + (int64_t)(t0 + r) * row_stride + c * 4);
         v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
         *reinterpret_cast<float4*>(dst + r * DH + c * 4) = v;
     }
@@ -84,45 +87,52 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const RalfAttnDesc d) {
         __syncthreads();
         const int kbase = t0 + wave * SL;
         if (kbase < d.Sk && !(d.causal && kbase > blockIdx.x * 64 + 63)) {
-            float s[SL];
-            float mt = -__builtin_inff();
+            // online softmax in sub-slices of SUB keys: small static register arrays (no spills), one
+            // rescale of the running output per sub-slice
+            constexpr int SUB = DH == 64 ? 4 : 8;
+#pragma unroll 1
+            for (int j0 = 0; j0 < SL; j0 += SUB) {
+                if (kbase + j0 >= d.Sk) break;
+                float s[SUB];
+                float mt = -__builtin_inff();
 #pragma unroll
-            for (int j = 0; j < SL; ++j) {
-                const int key = kbase + j;
-                const float* kr = Ks + (wave * SL + j) * DH;
-                float acc = 0.f;
-#pragma unroll
-                for (int c = 0; c < DH / 4; ++c) {
-                    const float4 kv = *reinterpret_cast<const float4*>(kr + c * 4);
-                    acc += q[4 * c] * kv.x + q[4 * c + 1] * kv.y + q[4 * c + 2] * kv.z + q[4 * c + 3] * kv.w;
-                }
-                const bool masked = key >= d.Sk || (d.causal && key > qi) || (kpm && kpm[key]);
-                s[j] = masked ? -__builtin_inff() : acc;
-                mt = fmaxf(mt, s[j]);
-            }
-            const float mn = fmaxf(m, mt);
-            if (mn > -__builtin_inff()) {
-                const float corr = __expf(m - mn);
-                l *= corr;
-#pragma unroll
-                for (int c = 0; c < DH; ++c) o[c] *= corr;
-#pragma unroll
-                for (int j = 0; j < SL; ++j) {
-                    const float p = __expf(s[j] - mn);
-                    l += p;
-                    float pd = p;
-                    if (d.p_drop > 0.f) {
-                        const uint64_t idx = (((uint64_t)b * d.H + h) * d.Sq + qi) * d.Sk + (kbase + j);
-                        pd = rng24(seed, d.call_id, idx) >= thr ? p * inv_keep : 0.f;
-                    }
-                    const float* vr = Vs + (wave * SL + j) * DH;
+                for (int j = 0; j < SUB; ++j) {
+                    const int key = kbase + j0 + j;
+                    const float* kr = Ks + (wave * SL + j0 + j) * DH;
+                    float acc = 0.f;
 #pragma unroll
                     for (int c = 0; c < DH / 4; ++c) {
-                        const float4 vv = *reinterpret_cast<const float4*>(vr + c * 4);
-                        o[4 * c] += pd * vv.x; o[4 * c + 1] += pd * vv.y; o[4 * c + 2] += pd * vv.z; o[4 * c + 3] += pd * vv.w;
+                        const float4 kv = *reinterpret_cast<const float4*>(kr + c * 4);
+                        acc += q[4 * c] * kv.x + q[4 * c + 1] * kv.y + q[4 * c + 2] * kv.z + q[4 * c + 3] * kv.w;
                     }
+                    const bool masked = key >= d.Sk || (d.causal && key > qi) || (kpm && kpm[key]);
+                    s[j] = masked ? -__builtin_inff() : acc;
+                    mt = fmaxf(mt, s[j]);
                 }
-                m = mn;
+                const float mn = fmaxf(m, mt);
+                if (mn > -__builtin_inff()) {
+                    const float corr = __expf(m - mn);
+                    l *= corr;
+#pragma unroll
+                    for (int c = 0; c < DH; ++c) o[c] *= corr;
+#pragma unroll
+                    for (int j = 0; j < SUB; ++j) {
+                        const float p = __expf(s[j] - mn);
+                        l += p;
+                        float pd = p;
+                        if (d.p_drop > 0.f) {
+                            const uint64_t idx = (((uint64_t)b * d.H + h) * d.Sq + qi) * d.Sk + (kbase + j0 + j);
+                            pd = rng24(seed, d.call_id, idx) >= thr ? p * inv_keep : 0.f;
+                        }
+                        const float* vr = Vs + (wave * SL + j0 + j) * DH;
+#pragma unroll
+                        for (int c = 0; c < DH / 4; ++c) {
+                            const float4 vv = *reinterpret_cast<const float4*>(vr + c * 4);
+                            o[4 * c] += pd * vv.x; o[4 * c + 1] += pd * vv.y; o[4 * c + 2] += pd * vv.z; o[4 * c + 3] += pd * vv.w;
+                        }
+                    }
+                    m = mn;
+                }
             }
         }
         __syncthreads();
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const RalfAttnDesc d) 
         __syncthreads();
         const int kbase = t0 + wave * SL;
         if (kbase < d.Sk && !(d.causal && kbase > blockIdx.x * 64 + 63)) {
-#pragma unroll 4
+#pragma unroll 2
             for (int j = 0; j < SL; ++j) {
                 const int key = kbase + j;
                 const float* kr = Ks + (wave * SL + j) * DH;
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const RalfAttnDesc d)
         const int qbase = t0 + wave * SL;
         // causal: queries before the first key of this block see none of its keys
         if (qbase < d.Sq && !(d.causal && qbase + SL - 1 < blockIdx.x * 64)) {
-#pragma unroll 4
+#pragma unroll 2
             for (int j = 0; j < SL; ++j) {
                 const int qi = qbase + j;
                 const float* qr = Qs + (wave * SL + j) * DH;

@@ -333,7 +333,7 @@ extern "C" int ralf_bn_stats(int dtype, const void* x, float* s1, float* s2, int
     RALF_REQUIRE(C % 4 == 0 && (((C / 4) & (C / 4 - 1)) == 0 || (C / 4) % 256 == 0), "bn_stats: C=%d unsupported", C);
     hipStream_t st = (hipStream_t)stream;
     const int cv = C / 4, tpr = cv < 256 ? cv : 256, rpi = 256 / tpr, gy = ceil_div(cv, 256);
-    const int gx = grid_for(M, rpi * 32, 2048 / gy);
+    const int gx = grid_for(M, rpi * 32, 512 / gy);
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, nullptr, nullptr, nullptr, nullptr, s1, s2, M, C, 0));
     return ralf::check_launch("bn_stats");
 }
@@ -360,7 +360,7 @@ extern "C" int ralf_bn_bwd_reduce(int dtype, const void* x, const void* dy, cons
     RALF_REQUIRE(C % 4 == 0 && (((C / 4) & (C / 4 - 1)) == 0 || (C / 4) % 256 == 0), "bn_bwd_reduce: C=%d unsupported", C);
     hipStream_t st = (hipStream_t)stream;
     const int cv = C / 4, tpr = cv < 256 ? cv : 256, rpi = 256 / tpr, gy = ceil_div(cv, 256);
-    const int gx = grid_for(M, rpi * 32, 2048 / gy);
+    const int gx = grid_for(M, rpi * 32, 512 / gy);
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 1>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, s1, s2, M, C, relu));
     return ralf::check_launch("bn_bwd_reduce");
 }
