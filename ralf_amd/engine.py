@@ -83,6 +83,14 @@ class FlatAdamW:
             self.runtime.weights_changed()
 
 
+def average_gradients(flat: torch.Tensor, world: int, group=None) -> None:
+    """data-parallel gradient exchange: ONE sum all-reduce over the flat gradient buffer.  The backward
+    pass is seeded with 1/world, so the sum IS the average (no extra scaling pass).  backend "nccl" is RCCL
+    over xGMI on ROCm; "gloo" is used by the CPU tests."""
+    if world > 1:
+        torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=group)
+
+
 def _clone_tree(x):
     if torch.is_tensor(x):
         return x.clone()
@@ -120,12 +128,12 @@ class TrainStep:
     def _fwd_bwd(self, inputs, targets):
         self.opt.zero_grad()
         _, losses = self.model.train_loss(inputs, targets)
-        losses["nll_loss"].backward()
-        return losses["nll_loss"].detach()
+        loss = losses["nll_loss"]
+        loss.backward(torch.full_like(loss, 1.0 / self.world) if self.world > 1 else None)
+        return loss.detach()
 
     def _allreduce(self):
-        if self.world > 1:
-            torch.distributed.all_reduce(self.opt.G, op=torch.distributed.ReduceOp.AVG, group=self.pg)
+        average_gradients(self.opt.G, self.world, self.pg)
 
     def _update(self):
         self.opt.step()
