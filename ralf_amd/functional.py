@@ -391,8 +391,7 @@ class BatchNormFn(Function):
     def backward(ctx, dy):
         x2, y, g, mean, rstd = ctx.saved_tensors
         relu, has_res, training, shp = ctx.cfg
-        assert training, "BatchNorm backward is implemented for batch statistics (train mode)"
-        dx, dg, db, dres = ops.bn_backward(x2, dy.contiguous().view(-1, shp[-1]), y, g.detach(), mean, rstd, relu, has_res)
+        dx, dg, db, dres = ops.bn_backward(x2, dy.contiguous().view(-1, shp[-1]), y, g.detach(), mean, rstd, relu, has_res, training)
         return dx.view(shp), dg, db, None, None, (dres.view(shp) if has_res else None), None, None, None
 
 

@@ -227,14 +227,17 @@ def bn_forward(x2d, gamma, beta, running_mean, running_var, training, relu, res,
     return y, out[0], out[1]
 
 
-def bn_backward(x2d, dy, y, gamma, mean, rstd, relu, want_dres):
+def bn_backward(x2d, dy, y, gamma, mean, rstd, relu, want_dres, training=True):
+    """training: batch-statistics backward.  eval: statistics are constants -> dx = gamma*rstd*g
+    (the same apply kernel with zero reduction terms); dgamma/dbeta are the same sums either way."""
     M, C = x2d.shape
     s = torch.zeros(2, C, dtype=torch.float32, device=x2d.device)
     dt = dtype_code(x2d)
     _call("ralf_bn_bwd_reduce", dt, _p(x2d), _p(dy), _p(y), _p(mean), _p(rstd), _p(s[0]), _p(s[1]), M, C, int(relu))
     dx = torch.empty_like(x2d)
     dres = torch.empty_like(x2d) if want_dres else None
-    _call("ralf_bn_bwd_apply", dt, _p(x2d), _p(dy), _p(y), _p(mean), _p(rstd), _p(gamma), _p(s[0]), _p(s[1]), _p(dx), _p(dres), M, C, int(relu))
+    t = s if training else torch.zeros_like(s)
+    _call("ralf_bn_bwd_apply", dt, _p(x2d), _p(dy), _p(y), _p(mean), _p(rstd), _p(gamma), _p(t[0]), _p(t[1]), _p(dx), _p(dres), M, C, int(relu))
     return dx, s[1], s[0], dres  # dx, dgamma, dbeta, dres
 
 
