@@ -11,8 +11,12 @@
 //   ResnetBackbone convolutions (common/image.py:80-111)
 //
 // Design:
-//   * 128x128 output tile per 256-thread workgroup, 2x2 waves, each wave 2x2 fragments of 32x32
-//     (v_mfma_f32_32x32x16_bf16 or the exact-fp32 v_mfma_f32_32x32x2_f32); fp32 accumulate always.
+//   * (64*FM)x(64*FN) output tile per 256-thread workgroup (FM,FN in {1,2}: 128x128 for the big products,
+//     64-wide variants for N = 64 convolutions and for small grids that need more workgroups in flight),
+//     2x2 waves, each wave FMxFN fragments of 32x32 (v_mfma_f32_32x32x16_bf16 or the exact-fp32
+//     v_mfma_f32_32x32x2_f32); fp32 accumulate always.  The matrix core computes the TRANSPOSED tile
+//     (weights as the row operand) so every lane ends up with 4 consecutive output columns: 8/16-byte
+//     epilogue loads and stores instead of 2-byte ones.
 //   * each operand is either "k-contiguous" (row-major [rows][K]) or "row-contiguous" ([K][rows]);
 //     tiles are staged global -> registers -> LDS in their MEMORY order (coalesced 16-B loads) and
 //     the row-contiguous case is fed to the matrix core with ds_read_b64_tr_b16 (bf16) / plain
@@ -35,13 +39,13 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
-constexpr int BM = 128, BN = 128;
 
 struct KParams {
     RalfGemmDesc d;
     int tiles_m, tiles_n, nwg;
     int kchunk;       // K range handled by one split (multiple of BK)
     float* partial;   // [split][batch][M][N] fp32 (splitk > 1)
+    int vec_epi;      // leading dims / bases allow 4-wide epilogue accesses
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -52,13 +56,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 template <typename T> struct TT;
 template <> struct TT<float> {
     static constexpr int VEC = 4, BK = 32, KSTEP = 2;
-    static constexpr int LDK = 32;    // k-contiguous tile: [128][32], rotated
-    static constexpr int LDR = 128;   // row-contiguous tile: [32][128]
+    static constexpr int LDK = 32;    // k-contiguous tile: [rows][32], rotated
+    static constexpr int RPAD = 0;    // row-contiguous tile: [32][rows]
 };
 template <> struct TT<bf16> {
     static constexpr int VEC = 8, BK = 64, KSTEP = 16;
-    static constexpr int LDK = 72;    // [128][64 + 8 pad]
-    static constexpr int LDR = 136;   // [64][128 + 8 pad]
+    static constexpr int LDK = 72;    // [rows][64 + 8 pad]
+    static constexpr int RPAD = 8;    // [64][rows + 8 pad]
 };
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
@@ -91,6 +95,72 @@ __device__ __forceinline__ void epilogue_store(const RalfGemmDesc& d, int z0, in
     if (d.res) v += ldf<T>(d.res, z0 * d.sR0 + z1 * d.sR1 + (int64_t)m * d.ldr + n);
     if (d.accumulate) v += d.out_f32 ? ldf<float>(d.C, coff) : ldf<T>(d.C, coff);
     if (d.out_f32) stf<float>(d.C, coff, v); else stf<T>(d.C, coff, v);
+}
+
+template <typename T> __device__ __forceinline__ void ld4(const void* p, int64_t i, float (&v)[4]);
+template <> __device__ __forceinline__ void ld4<float>(const void* p, int64_t i, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>((const float*)p + i); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void ld4<bf16>(const void* p, int64_t i, float (&v)[4]) {
+    const bf16x4 t = *reinterpret_cast<const bf16x4*>((const bf16*)p + i);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (float)t[q];
+}
+template <typename T> __device__ __forceinline__ void st4(void* p, int64_t i, const float (&v)[4]);
+template <> __device__ __forceinline__ void st4<float>(void* p, int64_t i, const float (&v)[4]) {
+    *reinterpret_cast<float4*>((float*)p + i) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void st4<bf16>(void* p, int64_t i, const float (&v)[4]) {
+    bf16x4 t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = (bf16)v[q];
+    *reinterpret_cast<bf16x4*>((bf16*)p + i) = t;
+}
+
+// epilogue on 4 consecutive columns n..n+3 of row m (same semantics as epilogue_store)
+template <typename T>
+__device__ __forceinline__ void epilogue_store4(const RalfGemmDesc& d, int z0, int z1, int m, int n, float (&v)[4]) {
+    const int64_t coff = z0 * d.sC0 + z1 * d.sC1 + (int64_t)m * d.ldc + n;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] *= d.alpha;
+    if (d.bias) {
+        float b[4];
+        ld4<float>(d.bias, n, b);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += b[q];
+    }
+    if (d.C2) { if (d.out_f32) st4<float>(d.C2, coff, v); else st4<T>(d.C2, coff, v); }
+    if (d.act == RALF_ACT_RELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+    } else if (d.act == RALF_ACT_GELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = gelu_f(v[q]);
+    }
+    if (d.aux) {
+        float a[4];
+        ld4<T>(d.aux, coff, a);
+        if (d.aux_mode == RALF_AUX_RELU_MASK) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = a[q] > 0.f ? v[q] * d.aux_scale : 0.f;
+        } else if (d.aux_mode == RALF_AUX_GELU_GRAD) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] *= gelu_grad(a[q]);
+        }
+    }
+    if (d.res) {
+        float r[4];
+        ld4<T>(d.res, z0 * d.sR0 + z1 * d.sR1 + (int64_t)m * d.ldr + n, r);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += r[q];
+    }
+    if (d.accumulate) {
+        float c[4];
+        if (d.out_f32) ld4<float>(d.C, coff, c); else ld4<T>(d.C, coff, c);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += c[q];
+    }
+    if (d.out_f32) st4<float>(d.C, coff, v); else st4<T>(d.C, coff, v);
 }
 
 // ---- operand loaders -------------------------------------------------------------------------
@@ -141,12 +211,18 @@ __device__ __forceinline__ uint4 load_vec(const T* __restrict__ p, const RalfCon
 
 // AK: A is k-contiguous ([M][K]); else stored [K][M].   BKC: B is k-contiguous ([N][K]); else [K][N].
 // GATHER: 0 none, 1 = A (k-contiguous) is an im2col matrix, 2 = B (row-contiguous) is an im2col matrix.
-template <typename T, bool AK, bool BKC, int GATHER>
+// FM, FN: 32x32 fragments per wave along m / n  ->  workgroup tile (64*FM) x (64*FN).
+template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN>
 __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
     using X = TT<T>;
     constexpr int VEC = X::VEC, BK = X::BK;
-    constexpr int A_ELEMS = AK ? BM * X::LDK : BK * X::LDR;
-    constexpr int B_ELEMS = BKC ? BN * X::LDK : BK * X::LDR;
+    constexpr int BM = 64 * FM, BN = 64 * FN;
+    constexpr int LDRA = BM + X::RPAD, LDRB = BN + X::RPAD;
+    constexpr int A_ELEMS = AK ? BM * X::LDK : BK * LDRA;
+    constexpr int B_ELEMS = BKC ? BN * X::LDK : BK * LDRB;
+    constexpr int KV = BK / VEC;                                   // vectors along k (k-contiguous tile)
+    constexpr int RVA = BM / VEC, RVB = BN / VEC;                  // vectors along rows (row-contiguous tile)
+    constexpr int NVA = BM * BK / VEC / 256, NVB = BN * BK / VEC / 256;  // 16-byte vectors per thread per k-tile
     __shared__ __attribute__((aligned(16))) T lds[A_ELEMS + B_ELEMS];
     T* la = lds;
     T* lb = lds + A_ELEMS;
@@ -165,38 +241,40 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
     const bool a_al = (d.lda % VEC == 0) && (((uintptr_t)Ap & 15) == 0);
     const bool b_al = (d.ldb % VEC == 0) && (((uintptr_t)Bp & 15) == 0);
 
-    // ---- per-thread staging geometry (4 vectors per operand per k-tile) ----
-    constexpr int KV = BK / VEC;        // vectors along k   (k-contiguous tile: 128 rows x KV)
-    constexpr int RV = 128 / VEC;       // vectors along rows (row-contiguous tile: BK k-rows x RV)
-    uint4 ra[4], rb[4];
-    RowInfo ia[4], ib[4];
+    uint4 ra[NVA], rb[NVB];
+    RowInfo ia[NVA], ib[NVB];
     if (AK) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ia[i] = row_info<GATHER == 1>(d.g, m0 + (tid + 256 * i) / KV, d.M, d.lda);
+        for (int i = 0; i < NVA; ++i) ia[i] = row_info<GATHER == 1>(d.g, m0 + (tid + 256 * i) / KV, d.M, d.lda);
     }
     if (BKC) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ib[i] = row_info<false>(d.g, n0 + (tid + 256 * i) / KV, d.N, d.ldb);
+        for (int i = 0; i < NVB; ++i) ib[i] = row_info<false>(d.g, n0 + (tid + 256 * i) / KV, d.N, d.ldb);
     }
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NVA; ++i) {
             const int v = tid + 256 * i;
             if (AK) ra[i] = load_vec<T, GATHER == 1>(Ap, d.g, ia[i], k0 + (v % KV) * VEC, kend, a_al);
             else {
-                const RowInfo r = row_info<false>(d.g, k0 + v / RV, kend, d.lda);
-                ra[i] = load_vec<T, false>(Ap, d.g, r, m0 + (v % RV) * VEC, d.M, a_al);
+                const RowInfo r = row_info<false>(d.g, k0 + v / RVA, kend, d.lda);
+                ra[i] = load_vec<T, false>(Ap, d.g, r, m0 + (v % RVA) * VEC, d.M, a_al);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int v = tid + 256 * i;
             if (BKC) rb[i] = load_vec<T, false>(Bp, d.g, ib[i], k0 + (v % KV) * VEC, kend, b_al);
             else {
-                const RowInfo r = row_info<GATHER == 2>(d.g, k0 + v / RV, kend, d.ldb);
-                rb[i] = load_vec<T, GATHER == 2>(Bp, d.g, r, n0 + (v % RV) * VEC, d.N, b_al);
+                const RowInfo r = row_info<GATHER == 2>(d.g, k0 + v / RVB, kend, d.ldb);
+                rb[i] = load_vec<T, GATHER == 2>(Bp, d.g, r, n0 + (v % RVB) * VEC, d.N, b_al);
             }
         }
     };
-    auto lstore_one = [&](T* l, bool kc, const uint4* regs) {
+    auto lstore_one = [&](T* l, bool kc, const uint4* regs, int nv, int rv, int ldr) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            if (i < nv) {
             const int v = tid + 256 * i;
             if (kc) {
                 const int r = v / KV, kv = v % KV;
@@ -210,17 +288,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
                     *reinterpret_cast<uint4*>(l + r * X::LDK + kv * VEC) = regs[i];
                 }
             } else {
-                const int kr = v / RV, rv = v % RV;
-                *reinterpret_cast<uint4*>(l + kr * X::LDR + rv * VEC) = regs[i];
+                const int kr = v / rv, c = v % rv;
+                *reinterpret_cast<uint4*>(l + kr * ldr + c * VEC) = regs[i];
+            }
             }
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[FM][FN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -229,94 +308,127 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
     const int trL = lane & 15, tr_rowblk = ((lane >> 4) & 1) * 16, tr_k = lh * 8 + (trL >> 2), tr_c = (trL & 3) * 4;
 
     gload(kbeg);
-    lstore_one(la, AK, ra);
-    lstore_one(lb, BKC, rb);
+    lstore_one(la, AK, ra, NVA, RVA, LDRA);
+    lstore_one(lb, BKC, rb, NVB, RVB, LDRB);
     __syncthreads();
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
         if (more) gload(k0 + BK);
+        // the matrix core computes the TRANSPOSED tile: row operand = n-fragment (weights), column operand =
+        // m-fragment, so accumulator register r of a lane holds (n = (r&3) + 8*(r>>2) + 4*(lane>>5), m = lane&31)
         if constexpr (sizeof(T) == 4) {
 #pragma unroll
             for (int ks = 0; ks < BK / 2; ++ks) {
                 const int kk = ks * 2 + lh;
-                float a[2], b[2];
+                float a[FM], b[FN];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int r = wm * 64 + i * 32 + l31;
-                    a[i] = AK ? ((float*)la)[r * 32 + ((kk + r) & 31)] : ((float*)la)[kk * X::LDR + r];
+                for (int i = 0; i < FM; ++i) {
+                    const int r = wm * 32 * FM + i * 32 + l31;
+                    a[i] = AK ? ((float*)la)[r * 32 + ((kk + r) & 31)] : ((float*)la)[kk * LDRA + r];
                 }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int r = wn * 64 + j * 32 + l31;
-                    b[j] = BKC ? ((float*)lb)[r * 32 + ((kk + r) & 31)] : ((float*)lb)[kk * X::LDR + r];
+                for (int j = 0; j < FN; ++j) {
+                    const int r = wn * 32 * FN + j * 32 + l31;
+                    b[j] = BKC ? ((float*)lb)[r * 32 + ((kk + r) & 31)] : ((float*)lb)[kk * LDRB + r];
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
             }
         } else {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
-                bf16x8 a[2], b[2];
+                bf16x8 a[FM], b[FN];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < FM; ++i) {
                     if (AK) {
-                        a[i] = *reinterpret_cast<const bf16x8*>(la + (wm * 64 + i * 32 + l31) * X::LDK + ks * 16 + lh * 8);
+                        a[i] = *reinterpret_cast<const bf16x8*>(la + (wm * 32 * FM + i * 32 + l31) * X::LDK + ks * 16 + lh * 8);
                     } else {
-                        const bf16* q = (const bf16*)la + (ks * 16 + tr_k) * X::LDR + wm * 64 + i * 32 + tr_rowblk + tr_c;
+                        const bf16* q = (const bf16*)la + (ks * 16 + tr_k) * LDRA + wm * 32 * FM + i * 32 + tr_rowblk + tr_c;
                         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q));
-                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 4 * X::LDR));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 4 * LDRA));
                         a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < FN; ++j) {
                     if (BKC) {
-                        b[j] = *reinterpret_cast<const bf16x8*>(lb + (wn * 64 + j * 32 + l31) * X::LDK + ks * 16 + lh * 8);
+                        b[j] = *reinterpret_cast<const bf16x8*>(lb + (wn * 32 * FN + j * 32 + l31) * X::LDK + ks * 16 + lh * 8);
                     } else {
-                        const bf16* q = (const bf16*)lb + (ks * 16 + tr_k) * X::LDR + wn * 64 + j * 32 + tr_rowblk + tr_c;
+                        const bf16* q = (const bf16*)lb + (ks * 16 + tr_k) * LDRB + wn * 32 * FN + j * 32 + tr_rowblk + tr_c;
                         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q));
-                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 4 * X::LDR));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 4 * LDRB));
                         b[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
             }
         }
         __syncthreads();
         if (more) {
-            lstore_one(la, AK, ra);
-            lstore_one(lb, BKC, rb);
+            lstore_one(la, AK, ra, NVA, RVA, LDRA);
+            lstore_one(lb, BKC, rb, NVB, RVB, LDRB);
             __syncthreads();
         }
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    // ---- epilogue: lane holds 4 consecutive columns n per register group g = r>>2 ----
+    // (no `continue`/`break` in these loops: they must unroll completely or the accumulators spill to scratch)
     const int nbatch = gridDim.z;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * 32 * FM + i * 32 + l31;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + l31;
+        for (int j = 0; j < FN; ++j) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * 32 * FN + j * 32 + 8 * g + 4 * lh;
+                float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 if (m < d.M && n < d.N) {
-                    if (d.splitk > 1) P.partial[(((int64_t)split * nbatch + z) * d.M + m) * d.N + n] = acc[i][j][r];
-                    else epilogue_store<T>(d, z0, z1, m, n, acc[i][j][r]);
+                    if (d.splitk > 1) {
+                        float* pp = P.partial + (((int64_t)split * nbatch + z) * d.M + m) * d.N + n;
+                        if (P.vec_epi && n + 3 < d.N) *reinterpret_cast<float4*>(pp) = make_float4(v[0], v[1], v[2], v[3]);
+                        else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (n + q < d.N) pp[q] = v[q];
+                        }
+                    } else if (P.vec_epi && n + 3 < d.N) {
+                        epilogue_store4<T>(d, z0, z1, m, n, v);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (n + q < d.N) epilogue_store<T>(d, z0, z1, m, n + q, v[q]);
+                    }
                 }
             }
         }
+    }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams P, int nbatch) {
     const RalfGemmDesc& d = P.d;
     const int64_t per = (int64_t)d.M * d.N, total = per * nbatch;
+    if (P.vec_epi && d.N % 4 == 0) {
+        for (int64_t e4 = (int64_t)blockIdx.x * 256 + threadIdx.x; e4 < total / 4; e4 += (int64_t)gridDim.x * 256) {
+            const int64_t e = e4 * 4;
+            float4 a = *reinterpret_cast<const float4*>(P.partial + e);
+            for (int s = 1; s < d.splitk; ++s) {
+                const float4 t = *reinterpret_cast<const float4*>(P.partial + (int64_t)s * total + e);
+                a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+            }
+            const int z = (int)(e / per);
+            const int64_t r = e - (int64_t)z * per;
+            float v[4] = {a.x, a.y, a.z, a.w};
+            epilogue_store4<T>(d, z % d.nb0, z / d.nb0, (int)(r / d.N), (int)(r % d.N), v);
+        }
+        return;
+    }
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         float v = 0.f;
         for (int s = 0; s < d.splitk; ++s) v += P.partial[(int64_t)s * total + e];
@@ -326,29 +438,43 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams P, int
     }
 }
 
-template <typename T, bool AK, bool BKC, int GATHER>
-int launch(const KParams& P, int nbatch, hipStream_t st) {
-    hipLaunchKernelGGL((gemm_kernel<T, AK, BKC, GATHER>), dim3(P.nwg, P.d.splitk, nbatch), dim3(256), 0, st, P);
+template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN>
+int launch(KParams& P, int nbatch, hipStream_t st) {
+    P.tiles_m = ceil_div(P.d.M, 64 * FM);
+    P.tiles_n = ceil_div(P.d.N, 64 * FN);
+    P.nwg = P.tiles_m * P.tiles_n;
+    hipLaunchKernelGGL((gemm_kernel<T, AK, BKC, GATHER, FM, FN>), dim3(P.nwg, P.d.splitk, nbatch), dim3(256), 0, st, P);
     return ralf::check_launch("gemm");
 }
 
+// tile choice: 128-wide only where it is filled (N > 64 / M > 64) and the grid still covers the chip
+template <typename T, bool AK, bool BKC, int GATHER>
+int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
+    const RalfGemmDesc& d = P.d;
+    const int64_t big = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) * d.splitk * nbatch;
+    const bool n128 = d.N > 64, m128 = d.M > 64;
+    if (n128 && m128 && big >= 512) return launch<T, AK, BKC, GATHER, 2, 2>(P, nbatch, st);
+    if (m128 && (!n128 || (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 64) * d.splitk * nbatch >= 512)) return launch<T, AK, BKC, GATHER, 2, 1>(P, nbatch, st);
+    return launch<T, AK, BKC, GATHER, 1, 1>(P, nbatch, st);
+}
+
 template <typename T>
-int dispatch(const KParams& P, int nbatch, hipStream_t st) {
+int dispatch(KParams& P, int nbatch, hipStream_t st) {
     const RalfGemmDesc& d = P.d;
     const int key = (d.a_kcontig ? 4 : 0) | (d.b_kcontig ? 2 : 0);
     if (d.gather == 1) {
         if (key != 6) { ralf::set_error("gemm: gather=1 needs A and B k-contiguous"); return RALF_ERR_INVALID; }
-        return launch<T, true, true, 1>(P, nbatch, st);
+        return launch_cfg<T, true, true, 1>(P, nbatch, st);
     }
     if (d.gather == 2) {
         if (key != 0) { ralf::set_error("gemm: gather=2 needs A and B row-contiguous"); return RALF_ERR_INVALID; }
-        return launch<T, false, false, 2>(P, nbatch, st);
+        return launch_cfg<T, false, false, 2>(P, nbatch, st);
     }
     switch (key) {
-        case 6: return launch<T, true, true, 0>(P, nbatch, st);
-        case 4: return launch<T, true, false, 0>(P, nbatch, st);
-        case 0: return launch<T, false, false, 0>(P, nbatch, st);
-        default: return launch<T, false, true, 0>(P, nbatch, st);
+        case 6: return launch_cfg<T, true, true, 0>(P, nbatch, st);
+        case 4: return launch_cfg<T, true, false, 0>(P, nbatch, st);
+        case 0: return launch_cfg<T, false, false, 0>(P, nbatch, st);
+        default: return launch_cfg<T, false, true, 0>(P, nbatch, st);
     }
 }
 
@@ -374,14 +500,21 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
     const int nbatch = d.nb0 * d.nb1;
     const int BK = d.dtype == RALF_F32 ? 32 : 64, VEC = d.dtype == RALF_F32 ? 4 : 8;
     if (d.gather) RALF_REQUIRE(d.g.SC % VEC == 0 && d.g.KH > 0 && d.g.KW > 0 && d.g.stride > 0, "gemm: gather needs channels %% %d == 0", VEC);
-    P.tiles_m = ceil_div(d.M, BM);
-    P.tiles_n = ceil_div(d.N, BN);
-    P.nwg = P.tiles_m * P.tiles_n;
     const int ktiles = ceil_div(d.K, BK);
     if (d.splitk > ktiles) d.splitk = ktiles;
     P.kchunk = ceil_div(ktiles, d.splitk) * BK;
     d.splitk = ceil_div(d.K, P.kchunk);
     P.partial = nullptr;
+    {   // 4-wide epilogue accesses need 4-element-aligned leading dims / batch strides and 16-byte aligned bases
+        const int es = (d.dtype == RALF_F32 || d.out_f32) ? 4 : 2;   // element size of C / C2
+        const int et = d.dtype == RALF_F32 ? 4 : 2;                   // element size of res / aux
+        auto al = [](const void* p, int bytes) { return (((uintptr_t)p) % (uintptr_t)(4 * bytes)) == 0; };
+        bool ok = d.ldc % 4 == 0 && d.sC0 % 4 == 0 && d.sC1 % 4 == 0 && al(d.C, es) && (!d.C2 || al(d.C2, es));
+        ok = ok && (!d.bias || al(d.bias, 4));
+        ok = ok && (!d.aux || al(d.aux, et));
+        ok = ok && (!d.res || (d.ldr % 4 == 0 && d.sR0 % 4 == 0 && d.sR1 % 4 == 0 && al(d.res, et)));
+        P.vec_epi = ok ? 1 : 0;
+    }
     if (d.splitk > 1) {
         const size_t need = (size_t)d.splitk * nbatch * d.M * d.N * sizeof(float);
         if (!workspace || workspace_bytes < need) {
