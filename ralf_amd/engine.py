@@ -116,6 +116,7 @@ class TrainStep:
         rt = model.rt.to(model.device)
         groups = model.optim_groups(base_lr=lr, weight_decay=weight_decay, custom_lr={"encoder.extractor.body": lr * backbone_lr_scale})
         self.opt = FlatAdamW(groups, betas, eps, max_norm, shadow_dtype=rt.dtype if rt.dtype == torch.bfloat16 else None, runtime=rt)
+        rt.direct_grads = True   # kernels accumulate parameter gradients straight into the flat buffer
         self.use_graph = use_graph
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if (process_group is not None or torch.distributed.is_initialized()) else 1

@@ -26,6 +26,7 @@ class Runtime:
         self._call = 0
         self._lp: dict = {}
         self._shadow: dict = {}   # id(param) -> persistent low-precision view kept current by the fused optimizer
+        self.direct_grads = False  # engine mode: parameter gradients are accumulated by the kernels straight into p.grad
         self._wtoken = 0          # bumped when weights are rewritten behind torch's version counters
 
     def to(self, device):
@@ -52,6 +53,13 @@ class Runtime:
 
     def weights_changed(self):
         self._wtoken += 1
+
+    def gview(self, p: torch.Tensor):
+        """flat-buffer gradient view of a parameter when the engine owns the gradients (kernels accumulate into it
+        and the autograd function returns None), else None (gradients are returned to autograd as tensors)."""
+        if self.direct_grads and p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous():
+            return p.grad
+        return None
 
     # low-precision / re-laid-out shadows of fp32 master weights, refreshed when the master changes
     def lp(self, w: torch.Tensor, kind: str = "cast") -> torch.Tensor:
@@ -91,10 +99,21 @@ def _splitk_for(out_rows: int, out_cols: int, red: int) -> int:
     return max(1, min(want, red // 512))
 
 
-def wgrad(dy2d, x2d, N, K, rows):
-    """dW[N,K] (fp32) = dy^T @ x, reduction over `rows` split across workgroups."""
+def wgrad(dy2d, x2d, N, K, rows, into=None):
+    """dW[N,K] (fp32) = dy^T @ x, reduction over `rows` split across workgroups.  `into`: accumulate into this
+    fp32 [N,K] view (flat gradient buffer) and return None."""
+    if into is not None:
+        ops.gemm(dy2d, x2d, N, K, rows, a_kcontig=False, b_kcontig=False, out=into.view(N, K), accumulate=True, splitk=_splitk_for(N, K, rows))
+        return None
     return ops.gemm(dy2d, x2d, N, K, rows, a_kcontig=False, b_kcontig=False, out_dtype=torch.float32,
                     splitk=_splitk_for(N, K, rows))
+
+
+def bgrad(dy2d, rows, N, into=None):
+    if into is not None:
+        ops.colsum(dy2d, rows, N, out=into)
+        return None
+    return ops.colsum(dy2d, rows, N)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -112,6 +131,7 @@ class LinearFn(Function):
                      res=_2d(res) if res is not None else None,
                      out_dtype=torch.float32 if out_f32 else None)
         ctx.save_for_backward(x2, W)
+        ctx.bias = b
         ctx.rt, ctx.has_b, ctx.has_res, ctx.xshape, ctx.rows = rt, b is not None, res is not None, x.shape, (r0, r1)
         return y.view(*x.shape[:-1], N)
 
@@ -130,14 +150,16 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dy2, rt.lp(W)[r0:r1], nrow, K, N, b_kcontig=False).view(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            dW = wgrad(dy2, x2, N, K, nrow)
-            if not full:  # place the block into a full-size gradient (plumbing copy)
+            gv = rt.gview(W)
+            dW = wgrad(dy2, x2, N, K, nrow, gv[r0:r1] if gv is not None else None)
+            if dW is not None and not full:  # place the block into a full-size gradient (plumbing copy)
                 g = torch.zeros(W.shape, dtype=torch.float32, device=dW.device)
                 g[r0:r1] = dW
                 dW = g
         if ctx.has_b and ctx.needs_input_grad[2]:
-            db = ops.colsum(dy2, nrow, N)
-            if not full:
+            gv = rt.gview(ctx.bias)
+            db = bgrad(dy2, nrow, N, gv[r0:r1] if gv is not None else None)
+            if db is not None and not full:
                 g = torch.zeros(W.shape[0], dtype=torch.float32, device=db.device)
                 g[r0:r1] = db
                 db = g
@@ -166,6 +188,7 @@ class FFNFn(Function):
             h = ops.dropout(h, p, rt.seed, call)
         y = ops.gemm(h, rt.lp(W2), rows, N, Hd, bias=b2.detach(), res=_2d(res) if res is not None else None)
         ctx.save_for_backward(x2, W1, W2, h, z)
+        ctx.b1, ctx.b2 = b1, b2
         ctx.rt, ctx.act, ctx.p, ctx.has_res, ctx.xshape = rt, act, p, res is not None, x.shape
         return y.view(*x.shape[:-1], N)
 
@@ -180,10 +203,10 @@ class FFNFn(Function):
             dz = ops.gemm(dy2, rt.lp(W2), rows, Hd, N, b_kcontig=False, aux=z, aux_mode="gelu_grad")
         else:  # relu (+ dropout): h > 0 <=> pre-activation > 0 and kept
             dz = ops.gemm(dy2, rt.lp(W2), rows, Hd, N, b_kcontig=False, aux=h, aux_mode="relu_mask", aux_scale=1.0 / (1.0 - ctx.p))
-        dW2 = wgrad(dy2, h, N, Hd, rows)
-        db2 = ops.colsum(dy2, rows, N)
-        dW1 = wgrad(dz, x2, Hd, K, rows)
-        db1 = ops.colsum(dz, rows, Hd)
+        dW2 = wgrad(dy2, h, N, Hd, rows, rt.gview(W2))
+        db2 = bgrad(dy2, rows, N, rt.gview(ctx.b2))
+        dW1 = wgrad(dz, x2, Hd, K, rows, rt.gview(W1))
+        db1 = bgrad(dz, rows, Hd, rt.gview(ctx.b1))
         dx = ops.gemm(dz, rt.lp(W1), rows, K, Hd, b_kcontig=False).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         return dx, dW1, db1, dW2, db2, (dy if ctx.has_res else None), None, None, None
 
@@ -194,11 +217,16 @@ class LayerNormFn(Function):
         xc = x.contiguous()
         y, mean, rstd = ops.layernorm_fwd(xc, g.detach(), b.detach())
         ctx.save_for_backward(xc, g, mean, rstd)
+        ctx.rt, ctx.beta = rt, b
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, g, mean, rstd = ctx.saved_tensors
+        gg, gb = ctx.rt.gview(g), ctx.rt.gview(ctx.beta)
+        if gg is not None and gb is not None:
+            dx, _, _ = ops.layernorm_bwd(dy.contiguous(), x, g.detach(), mean, rstd, need_wgrad=True, into=(gg, gb))
+            return dx, None, None, None
         dx, dg, db = ops.layernorm_bwd(dy.contiguous(), x, g.detach(), mean, rstd, need_wgrad=ctx.needs_input_grad[1])
         return dx, dg, db, None
 
@@ -236,28 +264,33 @@ class EmbedFn(Function):
     def forward(ctx, idx, W, pe, rt):
         S, d = idx.shape[-1], W.shape[1]
         ctx.save_for_backward(idx)
-        ctx.vocab, ctx.scale = W.shape[0], math.sqrt(d)
+        ctx.vocab, ctx.scale, ctx.rt, ctx.W = W.shape[0], math.sqrt(d), rt, W
         return ops.embed_fwd(idx.contiguous(), W.detach(), pe, S, ctx.scale, rt.dtype)
 
     @staticmethod
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
-        return None, ops.embed_bwd(idx.contiguous(), dy.contiguous(), ctx.vocab, ctx.scale), None, None
+        gv = ctx.rt.gview(ctx.W)
+        return None, ops.embed_bwd(idx.contiguous(), dy.contiguous(), ctx.vocab, ctx.scale, into=gv), None, None
 
 
 class AddScalarFn(Function):
     """x + s[i] with s a learned scalar table (task_emb = nn.Embedding(2, 1))."""
 
     @staticmethod
-    def forward(ctx, x, table, i):
-        ctx.i, ctx.n = i, table.shape[0]
+    def forward(ctx, x, table, i, rt=None):
+        ctx.i, ctx.n, ctx.rt, ctx.table = i, table.shape[0], rt, table
         return ops.add_scalar(x.contiguous(), table.detach().view(-1)[i:i + 1].contiguous())
 
     @staticmethod
     def backward(ctx, dy):
+        gv = ctx.rt.gview(ctx.table) if ctx.rt is not None else None
+        if gv is not None:
+            ops.sum_all(dy.contiguous(), out=gv.view(-1)[ctx.i:ctx.i + 1])
+            return dy, None, None, None
         g = torch.zeros(ctx.n, 1, dtype=torch.float32, device=dy.device)
         g[ctx.i] = ops.sum_all(dy.contiguous())  # slice assignment: plumbing
-        return dy, g, None
+        return dy, g, None, None
 
 
 class AttnFn(Function):
@@ -337,6 +370,7 @@ class ConvFn(Function):
             geom = dict(RH=OH, RW=OW, SH=H, SW=Wd, SC=C, KH=kh, KW=kw, stride=stride, pad=pad, mode=0)
             y = ops.gemm(x, rt.lp(W, "ohwi"), M, Co, kh * kw * C, conv=geom, gather=1, bias=bias)
         ctx.save_for_backward(x, W)
+        ctx.bias = b
         ctx.cfg = (stride, pad, OH, OW, b is not None, rt)
         return y.view(B, OH, OW, Co)
 
@@ -358,16 +392,21 @@ class ConvFn(Function):
                 geom = dict(RH=H, RW=Wd, SH=OH, SW=OW, SC=Co, KH=kh, KW=kw, stride=stride, pad=pad, mode=1)
                 dx = ops.gemm(dy, rt.lp(W, "ikwo"), B * H * Wd, C, kh * kw * Co, conv=geom, gather=1).view(B, H, Wd, C)
         if ctx.needs_input_grad[1]:
+            gv = rt.gview(W)
             if one:
-                dW = wgrad(dy2, x.view(-1, C), Co, Ci, M).view(Co, Ci, 1, 1)
+                dW = wgrad(dy2, x.view(-1, C), Co, Ci, M, gv)
+                dW = dW.view(Co, Ci, 1, 1) if dW is not None else None
             else:
                 geom = dict(RH=OH, RW=OW, SH=H, SW=Wd, SC=C, KH=kh, KW=kw, stride=stride, pad=pad, mode=0)
                 g = ops.gemm(dy2, x, Co, kh * kw * C, M, a_kcontig=False, b_kcontig=False, conv=geom, gather=2,
                              out_dtype=torch.float32, splitk=_splitk_for(Co, kh * kw * C, M))
                 # fp32 [Co][kh][kw][Cpad] -> OIHW master layout (drops the stem's channel padding)
                 dW = ops.permute4(g, (Co, Ci, kh, kw), (kh * kw * C, 1, kw * C, C), kw, torch.float32)
+                if gv is not None:   # used once per step: place it (flat buffer was zeroed at step start)
+                    gv.copy_(dW)
+                    dW = None
         if has_b and ctx.needs_input_grad[2]:
-            db = ops.colsum(dy2, M, Co)
+            db = bgrad(dy2, M, Co, rt.gview(ctx.bias))
         return dx, dW, db, None, None, None, None
 
 
@@ -384,6 +423,7 @@ class BatchNormFn(Function):
         x2 = x.contiguous().view(-1, shp[-1])
         y, mean, rstd = ops.bn_forward(x2, g.detach(), b.detach(), rm, rv, training, relu, res.contiguous().view(-1, shp[-1]) if res is not None else None)
         ctx.save_for_backward(x2, y, g, mean, rstd)
+        ctx.beta, ctx.rt = b, rt
         ctx.cfg = (relu, res is not None, training, shp)
         return y.view(shp)
 
@@ -391,7 +431,11 @@ class BatchNormFn(Function):
     def backward(ctx, dy):
         x2, y, g, mean, rstd = ctx.saved_tensors
         relu, has_res, training, shp = ctx.cfg
-        dx, dg, db, dres = ops.bn_backward(x2, dy.contiguous().view(-1, shp[-1]), y, g.detach(), mean, rstd, relu, has_res, training)
+        gg, gb = ctx.rt.gview(g), ctx.rt.gview(ctx.beta)
+        into = (gg, gb) if (gg is not None and gb is not None and training) else None
+        dx, dg, db, dres = ops.bn_backward(x2, dy.contiguous().view(-1, shp[-1]), y, g.detach(), mean, rstd, relu, has_res, training, into=into)
+        if into is not None:
+            dg = db = None
         return dx.view(shp), dg, db, None, None, (dres.view(shp) if has_res else None), None, None, None
 
 

@@ -170,8 +170,8 @@ class _GeneratorBase(nn.Module):
         rt = self.rt
         cf = self.user_const_encoder(inputs["seq_layout_const"], inputs["seq_layout_const_pad_mask"], rt)
         if self.use_flag_embedding:  # learned scalars broadcast over all channels (retrieval_augmented_autoreg.py:1022-1028)
-            img_mem = RF.AddScalarFn.apply(img_mem, self.task_emb.weight, 0)
-            cf = RF.AddScalarFn.apply(cf, self.task_emb.weight, 1)
+            img_mem = RF.AddScalarFn.apply(img_mem, self.task_emb.weight, 0, rt)
+            cf = RF.AddScalarFn.apply(cf, self.task_emb.weight, 1, rt)
         return torch.cat([img_mem, cf], dim=1)  # sequence concat: plumbing copy
 
     def _image_memory(self, image):

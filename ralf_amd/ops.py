@@ -105,17 +105,23 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, save_stats=True):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, need_wgrad=True):
+def layernorm_bwd(dy, x, gamma, mean, rstd, need_wgrad=True, into=None):
+    """into = (dgamma, dbeta) fp32 views to ACCUMULATE into (flat gradient buffer)."""
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
     dx = torch.empty_like(x)
-    dg = torch.zeros(cols, dtype=torch.float32, device=x.device) if need_wgrad else None
-    db = torch.zeros(cols, dtype=torch.float32, device=x.device) if need_wgrad else None
+    if into is not None:
+        dg, db = into
+    else:
+        dg = torch.zeros(cols, dtype=torch.float32, device=x.device) if need_wgrad else None
+        db = torch.zeros(cols, dtype=torch.float32, device=x.device) if need_wgrad else None
     _call("ralf_layernorm_bwd", dtype_code(x), _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), rows, cols)
     return dx, dg, db
 
 
-def colsum(x2d, rows, cols, ld=None):
-    out = torch.zeros(cols, dtype=torch.float32, device=x2d.device)
+def colsum(x2d, rows, cols, ld=None, out=None):
+    """out (fp32 [cols]) is accumulated into when given."""
+    if out is None:
+        out = torch.zeros(cols, dtype=torch.float32, device=x2d.device)
     _call("ralf_colsum", dtype_code(x2d), _p(x2d), ld if ld is not None else cols, _p(out), rows, cols)
     return out
 
@@ -127,11 +133,11 @@ def embed_fwd(idx, W, pe, S, scale, dtype):
     return out
 
 
-def embed_bwd(idx, dy, vocab, scale):
+def embed_bwd(idx, dy, vocab, scale, into=None):
     d = dy.shape[-1]
-    dW = torch.zeros(vocab, d, dtype=torch.float32, device=dy.device)
+    dW = into if into is not None else torch.zeros(vocab, d, dtype=torch.float32, device=dy.device)
     _call("ralf_embed_bwd", dtype_code(dy), _p(idx), _p(dy), _p(dW), idx.numel(), d, scale)
-    return dW
+    return None if into is not None else dW
 
 
 def dropout(x, p, seed, call_id, res=None):
@@ -156,8 +162,9 @@ def add_scalar(x, s):
     return y
 
 
-def sum_all(x):
-    out = torch.zeros(1, dtype=torch.float32, device=x.device)
+def sum_all(x, out=None):
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float32, device=x.device)
     cols = x.shape[-1]
     _call("ralf_sum_all", dtype_code(x), _p(x), _p(out), x.numel() // cols, cols, cols)
     return out
@@ -227,16 +234,20 @@ def bn_forward(x2d, gamma, beta, running_mean, running_var, training, relu, res,
     return y, out[0], out[1]
 
 
-def bn_backward(x2d, dy, y, gamma, mean, rstd, relu, want_dres, training=True):
+def bn_backward(x2d, dy, y, gamma, mean, rstd, relu, want_dres, training=True, into=None):
     """training: batch-statistics backward.  eval: statistics are constants -> dx = gamma*rstd*g
     (the same apply kernel with zero reduction terms); dgamma/dbeta are the same sums either way."""
     M, C = x2d.shape
-    s = torch.zeros(2, C, dtype=torch.float32, device=x2d.device)
     dt = dtype_code(x2d)
+    if into is not None:   # (dgamma, dbeta) flat-gradient views, zero at this point: reduce straight into them
+        s = (into[1], into[0])
+    else:
+        st = torch.zeros(2, C, dtype=torch.float32, device=x2d.device)
+        s = (st[0], st[1])
     _call("ralf_bn_bwd_reduce", dt, _p(x2d), _p(dy), _p(y), _p(mean), _p(rstd), _p(s[0]), _p(s[1]), M, C, int(relu))
     dx = torch.empty_like(x2d)
     dres = torch.empty_like(x2d) if want_dres else None
-    t = s if training else torch.zeros_like(s)
+    t = s if training else (torch.zeros_like(s[0]), torch.zeros_like(s[1]))
     _call("ralf_bn_bwd_apply", dt, _p(x2d), _p(dy), _p(y), _p(mean), _p(rstd), _p(gamma), _p(t[0]), _p(t[1]), _p(dx), _p(dres), M, C, int(relu))
     return dx, s[1], s[0], dres  # dx, dgamma, dbeta, dres
 
