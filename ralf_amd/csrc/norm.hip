@@ -139,53 +139,105 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
 // ---------------------------------------------------------------------------------------------
 // BatchNorm2d on NHWC viewed as [M = B*H*W, C]; a thread owns 4 consecutive channels
 // ---------------------------------------------------------------------------------------------
+// 16-byte vector of a row: 8 bf16 or 4 fp32 channels
+template <typename T> struct VW;
+template <> struct VW<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { V4<float>::load(p, v); }
+};
+template <> struct VW<bf16> {
+    static constexpr int N = 8;
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ void load(const bf16* p, float (&v)[8]) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+    }
+};
+
 // mode 0: s1 = sum x, s2 = sum x^2          (forward statistics)
 // mode 1: s1 = sum g, s2 = sum g * xhat     (backward), g = dy masked by (y > 0) when relu
+// A thread owns one 16-byte channel vector and walks rows with a 4-deep unrolled stride loop (4 x 16 B of
+// every operand in flight per thread: enough outstanding loads to approach the HBM rate).
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         float* __restrict__ s1, float* __restrict__ s2, int64_t M, int C, int relu) {
-    __shared__ float red[2][256][4];
-    const int cv = C >> 2;                       // channel vectors per row
+                                                         float* __restrict__ part, int64_t M, int C, int relu) {
+    constexpr int NV = VW<T>::N, UN = 4;
+    __shared__ float red[2][256][NV];
+    const int cv = C / NV;                       // channel vectors per row
     const int tpr = cv < 256 ? cv : 256;         // threads per row (power of two or 256)
     const int rpi = 256 / tpr;                   // rows per iteration
     const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr;
-    const int c0 = (blockIdx.y * 256 + tx) * 4;
-    float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    const int c0 = (blockIdx.y * 256 + tx) * NV;
+    float a1[NV], a2[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) a1[i] = a2[i] = 0.f;
     if (c0 < C) {
-        float mu[4] = {0, 0, 0, 0}, rs[4] = {1, 1, 1, 1};
-        if (MODE == 1) { V4<float>::load(mean + c0, mu); V4<float>::load(rstd + c0, rs); }
-        for (int64_t r = (int64_t)blockIdx.x * rpi + ty; r < M; r += (int64_t)gridDim.x * rpi) {
-            float xv[4];
-            V4<T>::load(x + r * C + c0, xv);
-            if (MODE == 0) {
+        float mu[NV], rs[NV];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { a1[i] += xv[i]; a2[i] += xv[i] * xv[i]; }
-            } else {
-                float g[4];
-                V4<T>::load(dy + r * C + c0, g);
-                if (relu) {
-                    float yv[4];
-                    V4<T>::load(y + r * C + c0, yv);
+        for (int i = 0; i < NV; ++i) { mu[i] = MODE == 1 ? mean[c0 + i] : 0.f; rs[i] = MODE == 1 ? rstd[c0 + i] : 1.f; }
+        const int64_t stride = (int64_t)gridDim.x * rpi;
+        for (int64_t r0 = (int64_t)blockIdx.x * rpi + ty; r0 < M; r0 += stride * UN) {
+            float xv[UN][NV], gv[UN][NV], yv[UN][NV];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
+            for (int u = 0; u < UN; ++u) {
+                const int64_t r = r0 + u * stride;
+                if (r < M) {
+                    VW<T>::load(x + r * C + c0, xv[u]);
+                    if (MODE == 1) {
+                        VW<T>::load(dy + r * C + c0, gv[u]);
+                        if (relu) VW<T>::load(y + r * C + c0, yv[u]);
+                    }
                 }
+            }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { a1[i] += g[i]; a2[i] += g[i] * (xv[i] - mu[i]) * rs[i]; }
+            for (int u = 0; u < UN; ++u) {
+                if (r0 + u * stride < M) {
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        if (MODE == 0) { a1[i] += xv[u][i]; a2[i] += xv[u][i] * xv[u][i]; }
+                        else {
+                            const float g = (relu && !(yv[u][i] > 0.f)) ? 0.f : gv[u][i];
+                            a1[i] += g; a2[i] += g * (xv[u][i] - mu[i]) * rs[i];
+                        }
+                    }
+                }
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { red[0][threadIdx.x][i] = a1[i]; red[1][threadIdx.x][i] = a2[i]; }
+    for (int i = 0; i < NV; ++i) { red[0][threadIdx.x][i] = a1[i]; red[1][threadIdx.x][i] = a2[i]; }
     __syncthreads();
     if (ty == 0 && c0 < C) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NV; ++i) {
             float t1 = 0.f, t2 = 0.f;
             for (int j = 0; j < rpi; ++j) { t1 += red[0][j * tpr + tx][i]; t2 += red[1][j * tpr + tx][i]; }
-            atomicAdd(s1 + c0 + i, t1);
-            atomicAdd(s2 + c0 + i, t2);
+            // per-workgroup partials (plain stores): same-address fp32 atomics from hundreds of workgroups
+            // serialise in L2 and dominated this kernel (0.3 TB/s); a tiny second kernel sums the partials
+            part[((int64_t)blockIdx.x * 2 + 0) * C + c0 + i] = t1;
+            part[((int64_t)blockIdx.x * 2 + 1) * C + c0 + i] = t2;
         }
+    }
+}
+
+// s1[c] += sum_b part[b][0][c], s2[c] += sum_b part[b][1][c]   (deterministic order)
+// 64 channels per workgroup, the 4 waves split the partial blocks (8 independent loads in flight per thread)
+__global__ __launch_bounds__(256) void bn_partial_sum_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ s1, float* __restrict__ s2) {
+    __shared__ float red[2][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float a = 0.f, b = 0.f;
+    if (c < C) {
+#pragma unroll 8
+        for (int i = ty; i < nblk; i += 4) { a += part[((int64_t)i * 2) * C + c]; b += part[((int64_t)i * 2 + 1) * C + c]; }
+    }
+    red[0][ty][tx] = a; red[1][ty][tx] = b;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        s1[c] += red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
+        s2[c] += red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
     }
 }
 
@@ -328,13 +380,25 @@ extern "C" int ralf_colsum(int dtype, const void* x, int64_t ld, float* out, int
 }
 
 /* sums s1,s2 (fp32 [C]) must be zero on entry. */
-extern "C" int ralf_bn_stats(int dtype, const void* x, float* s1, float* s2, int64_t M, int C, void* stream) {
-    RALF_REQUIRE(x && s1 && s2 && M > 0, "bn_stats: bad arguments");
-    RALF_REQUIRE(C % 4 == 0 && (((C / 4) & (C / 4 - 1)) == 0 || (C / 4) % 256 == 0), "bn_stats: C=%d unsupported", C);
+static int bn_reduce_geom(int dtype, int64_t M, int C, int* gx, int* gy) {
+    const int nv = dtype == RALF_F32 ? 4 : 8;
+    if (C % nv) return -1;
+    const int cv = C / nv;
+    if (!(((cv & (cv - 1)) == 0 && cv <= 256) || cv % 256 == 0)) return -1;
+    const int tpr = cv < 256 ? cv : 256, rpi = 256 / tpr;
+    *gy = ceil_div(cv, 256);
+    *gx = grid_for(M, rpi * 16, RALF_BN_MAX_PARTIALS);   // <= 256 workgroups along rows: one per CU, 4 x 16 B per thread in flight
+    return 0;
+}
+
+/* s1 += sum x, s2 += sum x^2 (fp32 [C]); workspace: RALF_BN_MAX_PARTIALS * 2 * C floats */
+extern "C" int ralf_bn_stats(int dtype, const void* x, float* s1, float* s2, int64_t M, int C, float* workspace, void* stream) {
+    RALF_REQUIRE(x && s1 && s2 && workspace && M > 0, "bn_stats: bad arguments");
+    int gx, gy;
+    RALF_REQUIRE(bn_reduce_geom(dtype, M, C, &gx, &gy) == 0, "bn_stats: C=%d unsupported (needs C/vec a power of two <= 256 or a multiple of 256)", C);
     hipStream_t st = (hipStream_t)stream;
-    const int cv = C / 4, tpr = cv < 256 ? cv : 256, rpi = 256 / tpr, gy = ceil_div(cv, 256);
-    const int gx = grid_for(M, rpi * 32, 512 / gy);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, nullptr, nullptr, nullptr, nullptr, s1, s2, M, C, 0));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, nullptr, nullptr, nullptr, nullptr, workspace, M, C, 0));
+    hipLaunchKernelGGL(bn_partial_sum_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, workspace, gx, C, s1, s2);
     return ralf::check_launch("bn_stats");
 }
 
@@ -353,15 +417,15 @@ extern "C" int ralf_bn_apply(int dtype, const void* x, const float* scale, const
     return ralf::check_launch("bn_apply");
 }
 
-/* backward reductions: s1 = sum g, s2 = sum g*xhat (zero on entry); g = dy * (y>0) when relu */
+/* backward reductions: s1 += sum g, s2 += sum g*xhat; g = dy * (y>0) when relu; workspace as ralf_bn_stats */
 extern "C" int ralf_bn_bwd_reduce(int dtype, const void* x, const void* dy, const void* y, const float* mean, const float* rstd, float* s1, float* s2,
-                                  int64_t M, int C, int relu, void* stream) {
-    RALF_REQUIRE(x && dy && mean && rstd && s1 && s2 && (!relu || y), "bn_bwd_reduce: bad arguments");
-    RALF_REQUIRE(C % 4 == 0 && (((C / 4) & (C / 4 - 1)) == 0 || (C / 4) % 256 == 0), "bn_bwd_reduce: C=%d unsupported", C);
+                                  int64_t M, int C, int relu, float* workspace, void* stream) {
+    RALF_REQUIRE(x && dy && mean && rstd && s1 && s2 && workspace && (!relu || y), "bn_bwd_reduce: bad arguments");
+    int gx, gy;
+    RALF_REQUIRE(bn_reduce_geom(dtype, M, C, &gx, &gy) == 0, "bn_bwd_reduce: C=%d unsupported", C);
     hipStream_t st = (hipStream_t)stream;
-    const int cv = C / 4, tpr = cv < 256 ? cv : 256, rpi = 256 / tpr, gy = ceil_div(cv, 256);
-    const int gx = grid_for(M, rpi * 32, 512 / gy);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 1>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, s1, s2, M, C, relu));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 1>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, workspace, M, C, relu));
+    hipLaunchKernelGGL(bn_partial_sum_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, workspace, gx, C, s1, s2);
     return ralf::check_launch("bn_bwd_reduce");
 }
 
