@@ -396,16 +396,20 @@ int run_bwd(const RalfAttnDesc& d, hipStream_t st) {
 }
 }  // namespace
 
+// bf16 throughput mode: matrix-core kernels (attention_mfma.hip)
+int ralf_attention_fwd_mfma(const RalfAttnDesc& d, hipStream_t st);
+int ralf_attention_bwd_mfma(const RalfAttnDesc& d, hipStream_t st);
+
 extern "C" int ralf_attention_fwd(const RalfAttnDesc* d, void* stream) {
     if (int rc = validate(d, false)) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == RALF_F32) return d->dh == 32 ? run_fwd<float, 32>(*d, st) : run_fwd<float, 64>(*d, st);
-    return d->dh == 32 ? run_fwd<bf16, 32>(*d, st) : run_fwd<bf16, 64>(*d, st);
+    return ralf_attention_fwd_mfma(*d, st);
 }
 
 extern "C" int ralf_attention_bwd(const RalfAttnDesc* d, void* stream) {
     if (int rc = validate(d, true)) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == RALF_F32) return d->dh == 32 ? run_bwd<float, 32>(*d, st) : run_bwd<float, 64>(*d, st);
-    return d->dh == 32 ? run_bwd<bf16, 32>(*d, st) : run_bwd<bf16, 64>(*d, st);
+    return ralf_attention_bwd_mfma(*d, st);
 }

@@ -1,0 +1,377 @@
+// bf16 matrix-core attention (forward, dQ, dK/dV) for gfx950 -- the throughput-mode path behind
+// ralf_attention_fwd / ralf_attention_bwd (the fp32 parity mode keeps the VALU kernels of attention.hip).
+//
+// Everything is computed TRANSPOSED so the softmax index stays lane-local:
+//   S^T[key][query] = K Q^T      v_mfma_f32_16x16x32_bf16, row operand = 16 key rows (LDS, ds_read_b128),
+//                                column operand = 16 query rows (registers)
+//   -> a lane holds ONE query (lane & 15) and 4 consecutive keys per 16-key block; row max / sum need
+//      two xor-shuffles (lanes 16/32 apart), the running (m, l) and every rescale are lane-local.
+//   O^T[d][query]  = V^T P^T     row operand = V^T via ds_read_b64_tr_b16 on the row-major V tile,
+//                                column operand = P^T straight from the S^T accumulators: the MFMA k-slot
+//                                8g+j is DEFINED as key {4g+j (j<4), 16+4g+j-4 (j>=4)} of a 32-key step, so
+//                                no data movement is needed between the two products.
+// Backward reuses the same layout: dQ^T = K^T dS^T (per-query kernel), dK^T = Q^T dS, dV^T = dO^T P
+// (per-key kernel, lane = one key).  P is recomputed from (Q, K, lse); dropout masks come from the same
+// counter-based generator as the VALU kernels, so forward/backward of either implementation agree.
+#include "common.h"
+
+namespace {
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+__device__ __forceinline__ uint32_t rng24(uint64_t seed, uint64_t call, uint64_t idx) {  // same generator as pointwise.hip
+    uint64_t z = seed + call * 0x9E3779B97F4A7C15ull + idx * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 40);
+}
+
+constexpr int KT = 64;  // rows of the streamed operand staged per iteration (keys in fwd/dQ, queries in dK/dV)
+
+template <int DH> struct L {
+    static constexpr int LD = DH + 8;  // LDS row stride in elements (16-byte pad: conflict-light b128 / tr reads)
+};
+
+// stage rows [t0, t0+KT) of a [S, *]-strided bf16 operand (head offset applied) into LDS [KT][LD]; rows >= S zero
+template <int DH>
+__device__ __forceinline__ void stage(bf16* dst, const bf16* base, int64_t rs, int t0, int S) {
+    constexpr int VPR = DH / 8;
+    for (int e = threadIdx.x; e < KT * VPR; e += 256) {
+        const int r = e / VPR, c = e % VPR;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (t0 + r < S) v = *reinterpret_cast<const uint4*>(base + (int64_t)(t0 + r) * rs + c * 8);
+        *reinterpret_cast<uint4*>(dst + r * L<DH>::LD + c * 8) = v;
+    }
+}
+
+// row-operand fragment: 16 rows x 32 k (row r = lane&15, k = 8*(lane>>4)..+7) from a k-contiguous LDS tile
+template <int DH>
+__device__ __forceinline__ bf16x8 frag_rows(const bf16* tile, int row0, int k0, int lane) {
+    return *reinterpret_cast<const bf16x8*>(tile + (row0 + (lane & 15)) * L<DH>::LD + k0 + (lane >> 4) * 8);
+}
+// the same fragment read straight from global memory (operand kept in registers for the whole kernel)
+__device__ __forceinline__ bf16x8 frag_global(const bf16* base, int64_t rs, int row, int nrows, int k0, int lane) {
+    const int r = row + (lane & 15);
+    if (r >= nrows) { bf16x8 z; for (int i = 0; i < 8; ++i) z[i] = (bf16)0.f; return z; }
+    return *reinterpret_cast<const bf16x8*>(base + (int64_t)r * rs + k0 + (lane >> 4) * 8);
+}
+// TRANSPOSED fragment of a row-major LDS tile: matrix rows = 16 columns c0..c0+15 of the tile, k-slots
+// 8g+j = tile rows {r0+4g+j (j<4), r0+16+4g+(j-4) (j>=4)}  (g = lane>>4): two transpose reads
+template <int DH>
+__device__ __forceinline__ bf16x8 frag_cols_T(const bf16* tile, int r0, int c0, int lane) {
+    const int Ls = lane & 15, g = lane >> 4;
+    const bf16* q = tile + (r0 + 4 * g + (Ls >> 2)) * L<DH>::LD + c0 + (Ls & 3) * 4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 16 * L<DH>::LD));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float xor_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ __forceinline__ float xor_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+
+// ------------------------------------------------------------------------------------------------
+// forward: grid (ceil(Sq/64), H, B), 4 waves x 16 queries
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
+    __shared__ __attribute__((aligned(16))) bf16 Ks[KT * L<DH>::LD];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[KT * L<DH>::LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 64 + wave * 16, qi = q0 + (lane & 15);
+    const bf16* Qp = (const bf16*)d.q + b * d.q_bs + (int64_t)h * DH;
+    const bf16* Kp = (const bf16*)d.k + b * d.k_bs + (int64_t)h * DH;
+    const bf16* Vp = (const bf16*)d.v + b * d.v_bs + (int64_t)h * DH;
+    const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * d.Sk : nullptr;
+    const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
+    const uint32_t thr = (uint32_t)(d.p_drop * 16777216.f);
+    const float inv_keep = 1.f / (1.f - d.p_drop);
+    const bool active = q0 < d.Sq;  // wave-uniform
+
+    bf16x8 qf[DH / 32];
+#pragma unroll
+    for (int c = 0; c < DH / 32; ++c) qf[c] = frag_global(Qp, d.q_rs, q0, d.Sq, c * 32, lane);
+    f32x4 o[DH / 16];
+#pragma unroll
+    for (int c = 0; c < DH / 16; ++c) o[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m = -__builtin_inff(), l = 0.f;
+
+    for (int t0 = 0; t0 < d.Sk; t0 += KT) {
+        stage<DH>(Ks, Kp, d.k_rs, t0, d.Sk);
+        stage<DH>(Vs, Vp, d.v_rs, t0, d.Sk);
+        __syncthreads();
+        if (active && !(d.causal && t0 > q0 + 15)) {
+#pragma unroll
+            for (int s0 = 0; s0 < KT; s0 += 32) {
+                if (t0 + s0 >= d.Sk) break;
+                // S^T for 32 keys: two 16-key blocks
+                f32x4 s[2];
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    s[blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < DH / 32; ++c) s[blk] = mfma16(frag_rows<DH>(Ks, s0 + blk * 16, c * 32, lane), qf[c], s[blk]);
+                }
+                float p[8];
+                float mt = -__builtin_inff();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int key = t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3);
+                    const bool masked = key >= d.Sk || (d.causal && key > qi) || (kpm && kpm[key]);
+                    p[j] = masked ? -__builtin_inff() : s[j >> 2][j & 3] * d.scale;
+                    mt = fmaxf(mt, p[j]);
+                }
+                mt = xor_max(mt);
+                const float mn = fmaxf(m, mt);
+                // branch-free online softmax (matrix-core ops must not sit under divergent control flow): while a
+                // query has seen only masked keys mn = -inf -> use 0 as the reference so every exp() is exp(-inf) = 0
+                const float mref = mn > -__builtin_inff() ? mn : 0.f;
+                const float corr = __expf(m - mref);
+                float ls = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { p[j] = __expf(p[j] - mref); ls += p[j]; }
+                l = l * corr + xor_sum(ls);
+                m = mn;
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float pd = p[j];
+                    if (d.p_drop > 0.f) {
+                        const int key = t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3);
+                        const uint64_t idx = (((uint64_t)b * d.H + h) * d.Sq + qi) * d.Sk + key;
+                        pd = rng24(seed, d.call_id, idx) >= thr ? pd * inv_keep : 0.f;
+                    }
+                    pf[j] = (bf16)pd;
+                }
+#pragma unroll
+                for (int c = 0; c < DH / 16; ++c) {
+                    o[c] *= corr;
+                    o[c] = mfma16(frag_cols_T<DH>(Vs, s0, c * 16, lane), pf, o[c]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (active && qi < d.Sq) {
+        const float inv = 1.f / l;
+        bf16* Op = (bf16*)d.o + b * d.o_bs + (int64_t)qi * d.o_rs + (int64_t)h * DH;
+#pragma unroll
+        for (int c = 0; c < DH / 16; ++c) {
+            bf16x4 t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = (bf16)(o[c][r] * inv);
+            *reinterpret_cast<bf16x4*>(Op + c * 16 + 4 * g) = t;
+        }
+        if (d.lse && g == 0) d.lse[((int64_t)b * d.H + h) * d.Sq + qi] = m + __logf(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dQ (+ delta): same geometry as the forward kernel
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const RalfAttnDesc d) {
+    __shared__ __attribute__((aligned(16))) bf16 Ks[KT * L<DH>::LD];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[KT * L<DH>::LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 64 + wave * 16, qi = q0 + (lane & 15);
+    const bool qok = qi < d.Sq;
+    const bf16* Qp = (const bf16*)d.q + b * d.q_bs + (int64_t)h * DH;
+    const bf16* Kp = (const bf16*)d.k + b * d.k_bs + (int64_t)h * DH;
+    const bf16* Vp = (const bf16*)d.v + b * d.v_bs + (int64_t)h * DH;
+    const bf16* Op = (const bf16*)d.o + b * d.o_bs + (int64_t)h * DH;
+    const bf16* Gp = (const bf16*)d.dout + b * d.do_bs + (int64_t)h * DH;
+    const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * d.Sk : nullptr;
+    const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
+    const uint32_t thr = (uint32_t)(d.p_drop * 16777216.f);
+    const float inv_keep = 1.f / (1.f - d.p_drop);
+    const bool active = q0 < d.Sq;
+    const int64_t stat = ((int64_t)b * d.H + h) * d.Sq + qi;
+
+    bf16x8 qf[DH / 32], gf[DH / 32];
+    float delta = 0.f;
+#pragma unroll
+    for (int c = 0; c < DH / 32; ++c) {
+        qf[c] = frag_global(Qp, d.q_rs, q0, d.Sq, c * 32, lane);
+        gf[c] = frag_global(Gp, d.do_rs, q0, d.Sq, c * 32, lane);
+        const bf16x8 of = frag_global(Op, d.o_rs, q0, d.Sq, c * 32, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) delta += (float)gf[c][i] * (float)of[i];
+    }
+    delta = xor_sum(delta);   // the 4 lane groups hold disjoint d slices of the same query
+    const float lse = qok ? d.lse[stat] : 0.f;
+    if (qok && g == 0) d.delta[stat] = delta;
+    f32x4 dq[DH / 16];
+#pragma unroll
+    for (int c = 0; c < DH / 16; ++c) dq[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int t0 = 0; t0 < d.Sk; t0 += KT) {
+        stage<DH>(Ks, Kp, d.k_rs, t0, d.Sk);
+        stage<DH>(Vs, Vp, d.v_rs, t0, d.Sk);
+        __syncthreads();
+        if (active && !(d.causal && t0 > q0 + 15)) {
+#pragma unroll
+            for (int s0 = 0; s0 < KT; s0 += 32) {
+                if (t0 + s0 >= d.Sk) break;
+                f32x4 s[2], dp[2];
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    s[blk] = dp[blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < DH / 32; ++c) {
+                        s[blk] = mfma16(frag_rows<DH>(Ks, s0 + blk * 16, c * 32, lane), qf[c], s[blk]);
+                        dp[blk] = mfma16(frag_rows<DH>(Vs, s0 + blk * 16, c * 32, lane), gf[c], dp[blk]);
+                    }
+                }
+                bf16x8 dsf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int key = t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3);
+                    const bool masked = key >= d.Sk || (d.causal && key > qi) || (kpm && kpm[key]) || !qok;
+                    const float p = masked ? 0.f : __expf(s[j >> 2][j & 3] * d.scale - lse);
+                    float dpv = dp[j >> 2][j & 3];
+                    if (d.p_drop > 0.f) {
+                        const uint64_t idx = (((uint64_t)b * d.H + h) * d.Sq + qi) * d.Sk + key;
+                        dpv = rng24(seed, d.call_id, idx) >= thr ? dpv * inv_keep : 0.f;
+                    }
+                    dsf[j] = (bf16)(p * (dpv - delta));
+                }
+#pragma unroll
+                for (int c = 0; c < DH / 16; ++c) dq[c] = mfma16(frag_cols_T<DH>(Ks, s0, c * 16, lane), dsf, dq[c]);
+            }
+        }
+        __syncthreads();
+    }
+    if (qok) {
+        bf16* dQp = (bf16*)d.dq + b * d.dq_bs + (int64_t)qi * d.dq_rs + (int64_t)h * DH;
+#pragma unroll
+        for (int c = 0; c < DH / 16; ++c) {
+            bf16x4 t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = (bf16)(dq[c][r] * d.scale);
+            *reinterpret_cast<bf16x4*>(dQp + c * 16 + 4 * g) = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dK, dV: grid (ceil(Sk/64), H, B), 4 waves x 16 keys; queries streamed in tiles of 64
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
+    __shared__ __attribute__((aligned(16))) bf16 Qs[KT * L<DH>::LD];
+    __shared__ __attribute__((aligned(16))) bf16 Gs[KT * L<DH>::LD];
+    __shared__ float Ls[KT], Ds[KT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int k0 = blockIdx.x * 64 + wave * 16, kj = k0 + (lane & 15);
+    const bool kok = kj < d.Sk;
+    const bf16* Qp = (const bf16*)d.q + b * d.q_bs + (int64_t)h * DH;
+    const bf16* Kp = (const bf16*)d.k + b * d.k_bs + (int64_t)h * DH;
+    const bf16* Vp = (const bf16*)d.v + b * d.v_bs + (int64_t)h * DH;
+    const bf16* Gp = (const bf16*)d.dout + b * d.do_bs + (int64_t)h * DH;
+    const bool kmasked = !kok || (d.kpm && d.kpm[(int64_t)b * d.Sk + kj]);
+    const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
+    const uint32_t thr = (uint32_t)(d.p_drop * 16777216.f);
+    const float inv_keep = 1.f / (1.f - d.p_drop);
+    const bool active = k0 < d.Sk;
+    const int64_t stat0 = ((int64_t)b * d.H + h) * d.Sq;
+
+    bf16x8 kf[DH / 32], vf[DH / 32];
+#pragma unroll
+    for (int c = 0; c < DH / 32; ++c) {
+        kf[c] = frag_global(Kp, d.k_rs, k0, d.Sk, c * 32, lane);
+        vf[c] = frag_global(Vp, d.v_rs, k0, d.Sk, c * 32, lane);
+    }
+    f32x4 dk[DH / 16], dv[DH / 16];
+#pragma unroll
+    for (int c = 0; c < DH / 16; ++c) dk[c] = dv[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int t0 = 0; t0 < d.Sq; t0 += KT) {
+        stage<DH>(Qs, Qp, d.q_rs, t0, d.Sq);
+        stage<DH>(Gs, Gp, d.do_rs, t0, d.Sq);
+        if (threadIdx.x < KT) {
+            const int qi = t0 + threadIdx.x;
+            Ls[threadIdx.x] = qi < d.Sq ? d.lse[stat0 + qi] : 0.f;
+            Ds[threadIdx.x] = qi < d.Sq ? d.delta[stat0 + qi] : 0.f;
+        }
+        __syncthreads();
+        // causal: a query tile entirely before this wave's first key sees none of its keys
+        if (active && !(d.causal && t0 + KT - 1 < k0)) {
+#pragma unroll
+            for (int s0 = 0; s0 < KT; s0 += 32) {
+                if (t0 + s0 >= d.Sq) break;
+                // S[query][key] and dP[query][key]: rows = 16 queries (LDS), columns = this wave's 16 keys
+                f32x4 s[2], dp[2];
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    s[blk] = dp[blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < DH / 32; ++c) {
+                        s[blk] = mfma16(frag_rows<DH>(Qs, s0 + blk * 16, c * 32, lane), kf[c], s[blk]);
+                        dp[blk] = mfma16(frag_rows<DH>(Gs, s0 + blk * 16, c * 32, lane), vf[c], dp[blk]);
+                    }
+                }
+                bf16x8 pf, dsf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ql = s0 + (j >> 2) * 16 + 4 * g + (j & 3), qi = t0 + ql;
+                    const bool masked = kmasked || qi >= d.Sq || (d.causal && kj > qi);
+                    const float p = masked ? 0.f : __expf(s[j >> 2][j & 3] * d.scale - Ls[ql]);
+                    float pd = p, dpv = dp[j >> 2][j & 3];
+                    if (d.p_drop > 0.f) {
+                        const uint64_t idx = (((uint64_t)b * d.H + h) * d.Sq + qi) * d.Sk + kj;
+                        const bool keep = rng24(seed, d.call_id, idx) >= thr;
+                        pd = keep ? p * inv_keep : 0.f;
+                        dpv = keep ? dpv * inv_keep : 0.f;
+                    }
+                    pf[j] = (bf16)pd;
+                    dsf[j] = (bf16)(p * (dpv - Ds[ql]));
+                }
+#pragma unroll
+                for (int c = 0; c < DH / 16; ++c) {
+                    dv[c] = mfma16(frag_cols_T<DH>(Gs, s0, c * 16, lane), pf, dv[c]);
+                    dk[c] = mfma16(frag_cols_T<DH>(Qs, s0, c * 16, lane), dsf, dk[c]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (kok) {
+        bf16* dKp = (bf16*)d.dk + b * d.dk_bs + (int64_t)kj * d.dk_rs + (int64_t)h * DH;
+        bf16* dVp = (bf16*)d.dv + b * d.dv_bs + (int64_t)kj * d.dv_rs + (int64_t)h * DH;
+#pragma unroll
+        for (int c = 0; c < DH / 16; ++c) {
+            bf16x4 tk, tv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { tk[r] = (bf16)(dk[c][r] * d.scale); tv[r] = (bf16)dv[c][r]; }
+            *reinterpret_cast<bf16x4*>(dKp + c * 16 + 4 * g) = tk;
+            *reinterpret_cast<bf16x4*>(dVp + c * 16 + 4 * g) = tv;
+        }
+    }
+}
+}  // namespace
+
+// called from attention.hip for dtype == RALF_BF16 (descriptor already validated)
+int ralf_attention_fwd_mfma(const RalfAttnDesc& d, hipStream_t st) {
+    const dim3 grid(ceil_div(d.Sq, 64), d.H, d.B);
+    if (d.dh == 32) hipLaunchKernelGGL((attn_fwd_mfma<32>), grid, dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((attn_fwd_mfma<64>), grid, dim3(256), 0, st, d);
+    return ralf::check_launch("attention_fwd_mfma");
+}
+int ralf_attention_bwd_mfma(const RalfAttnDesc& d, hipStream_t st) {
+    const dim3 gq(ceil_div(d.Sq, 64), d.H, d.B), gk(ceil_div(d.Sk, 64), d.H, d.B);
+    if (d.dh == 32) {
+        hipLaunchKernelGGL((attn_bwd_dq_mfma<32>), gq, dim3(256), 0, st, d);
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma<32>), gk, dim3(256), 0, st, d);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dq_mfma<64>), gq, dim3(256), 0, st, d);
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma<64>), gk, dim3(256), 0, st, d);
+    }
+    return ralf::check_launch("attention_bwd_mfma");
+}
