@@ -28,6 +28,7 @@
 //   * epilogue: alpha, bias, ReLU/GELU(erf), activation-gradient masks, residual add, second
 //     (pre-activation) output, fp32 or bf16 stores.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -451,10 +452,16 @@ int launch(KParams& P, int nbatch, hipStream_t st) {
 template <typename T, bool AK, bool BKC, int GATHER>
 int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
     const RalfGemmDesc& d = P.d;
+    static const int forced = [] { const char* e = getenv("RALF_GEMM_TILE"); return e ? atoi(e) : 0; }();  // tuning aid: 22 / 21 / 11
+    if (forced == 22) return launch<T, AK, BKC, GATHER, 2, 2>(P, nbatch, st);
+    if (forced == 21) return launch<T, AK, BKC, GATHER, 2, 1>(P, nbatch, st);
+    if (forced == 11) return launch<T, AK, BKC, GATHER, 1, 1>(P, nbatch, st);
+    // measured on MI355X (tools/gemm_bench.py, RALF_GEMM_TILE sweep): with this 1-deep pipeline the short-K
+    // products of the model (K <= 1024) run fastest on 64x64 tiles (5-7 workgroups per CU hide the global->LDS
+    // latency); 128x128 pays off only for long reductions that still fill the chip.
     const int64_t big = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) * d.splitk * nbatch;
-    const bool n128 = d.N > 64, m128 = d.M > 64;
-    if (n128 && m128 && big >= 512) return launch<T, AK, BKC, GATHER, 2, 2>(P, nbatch, st);
-    if (m128 && (!n128 || (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 64) * d.splitk * nbatch >= 512)) return launch<T, AK, BKC, GATHER, 2, 1>(P, nbatch, st);
+    const int kspan = ceil_div(d.K, d.splitk);
+    if (d.N > 64 && d.M > 64 && kspan >= 1024 && big >= 512) return launch<T, AK, BKC, GATHER, 2, 2>(P, nbatch, st);
     return launch<T, AK, BKC, GATHER, 1, 1>(P, nbatch, st);
 }
 

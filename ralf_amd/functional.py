@@ -95,8 +95,8 @@ def _2d(x):
 
 def _splitk_for(out_rows: int, out_cols: int, red: int) -> int:
     tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
-    want = max(1, 512 // tiles)
-    return max(1, min(want, red // 512))
+    want = max(1, 256 // tiles)            # ~one workgroup per CU; more splits only add slab traffic
+    return max(1, min(want, red // 1024))  # each split reduces >= 1024 rows
 
 
 def wgrad(dy2d, x2d, N, K, rows, into=None):
