@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 STEP_GFLOP_PER_SAMPLE = {10: 50.1, 32: 56.4}
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+KNN_TRAFFIC_BYTES = 446.2e6  # HBM bytes per knn_scores launch at nq=16: rocprofv3 FETCH_SIZE x2 (gfx950) + WRITE_SIZE, profiles/r01_knn_pmc.txt
 
 
 def build_model(device, N=10, dtype="bfloat16", task="uncond"):
@@ -38,31 +39,39 @@ def build_model(device, N=10, dtype="bfloat16", task="uncond"):
     return model.to(device).train()
 
 
+def _time_gpu(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
 def bench_knn(device):
+    """exact top-16 scan over the CGL-sized index (BASELINE configs[3]).  `scan_*` = the dominant kernel
+    (knn_scores_kernel: the only pass over the index) timed alone with HIP events; `us_per_call`/`qps` = the
+    whole ralf_knn_topk_ip call (scan + select + merge)."""
     from ralf_amd import _lib
-    from ralf_amd.retrieval.knn import knn_topk_ip
+    from ralf_amd.retrieval.knn import knn_scores, knn_topk_ip
 
     N, D, k = 61548, 1792, 16
     g = torch.Generator(device=device).manual_seed(0)
     X = torch.randn(N, D, device=device, generator=g)
     X /= X.norm(dim=1, keepdim=True)
     out = {}
-    for nq in (1024, 16):
+    for nq in (1024, 16, 1):
         Q = torch.randn(nq, D, device=device, generator=g)
         Q /= Q.norm(dim=1, keepdim=True)
         ws = torch.empty(_lib.lib().ralf_knn_topk_ip_workspace_bytes(N, D, nq, k), dtype=torch.uint8, device=device)
-        for _ in range(3):
-            knn_topk_ip(X, Q, k, ws)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        iters = 20
-        e0.record()
-        for _ in range(iters):
-            knn_topk_ip(X, Q, k, ws)
-        e1.record()
-        torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) / iters * 1e-3
+        t = _time_gpu(lambda: knn_topk_ip(X, Q, k, ws))
+        t_scan = _time_gpu(lambda: knn_scores(X, Q))
         by = N * D * 4 + nq * D * 4 + nq * k * 12
         out[f"nq{nq}"] = {"qps": nq / t, "us_per_call": t * 1e6, "algorithmic_GBps": by / t / 1e9, "hbm_frac": by / t / 1e9 / PEAK_HBM_GBS,
+                          "scan_us": t_scan * 1e6, "scan_GBps": by / t_scan / 1e9, "scan_hbm_frac": by / t_scan / 1e9 / PEAK_HBM_GBS,
                           "fp32_TFLOPs": 2.0 * nq * N * D / t / 1e12}
     return {"index": f"{N}x{D} fp32", "k": k, **out}
 
@@ -195,8 +204,10 @@ def main():
         if world == 1 and not a.skip_knn:
             out["knn"] = bench_knn(device)
             k16 = out["knn"]["nq16"]
-            out["roofline_knn"] = {"bound": "hbm", "achieved": k16["algorithmic_GBps"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": k16["hbm_frac"], "traffic": None,
-                                   "note": "exact top-16 scan, 61548x1792 fp32 index streamed once, nq=16 (HBM-bound regime); nq=1024 is fp32-FLOP-bound, see knn.nq1024"}
+            out["roofline_knn"] = {"bound": "hbm", "achieved": k16["scan_GBps"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": k16["scan_hbm_frac"], "traffic": KNN_TRAFFIC_BYTES,
+                                   "note": "dominant kernel knn_scores_kernel<16,1,2> at nq=16 (HBM-bound regime): 441.2 MB algorithmic bytes per launch (index 61548x1792 fp32 streamed once) / "
+                                           f"{k16['scan_us']:.1f} us (HIP events); whole call incl. select+merge {k16['us_per_call']:.1f} us = {k16['hbm_frac']:.3f} of peak; "
+                                           "nq=1024 is fp32-FLOP-bound (see knn.nq1024); traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction), profiles/"}
         if world == 1 and not a.skip_cpu:
             out["cpu_baseline"] = cpu_baseline_train(N)
             out["cpu_baseline_knn"] = cpu_baseline_knn()
