@@ -78,7 +78,7 @@ typedef struct RalfConvGeom {
  *   b_kcontig: B stored [N][ldb] (k contiguous, e.g. nn.Linear.weight) else [K][ldb]
  *   gather:    0 none; 1 = A is the im2col matrix of g (needs a_kcontig=b_kcontig=1);
  *              2 = B is the im2col matrix of g (weight gradient, needs a_kcontig=b_kcontig=0)
- *   epilogue order: *alpha, +bias[n] (fp32), C2 = v (optional pre-activation copy), act,
+ *   epilogue order: *alpha, +bias[n] (fp32), C2 = v (optional pre-activation copy), act, dropout,
  *              aux mask/gradient, +res, (+C if accumulate), store as dtype or fp32 (out_f32).
  *   splitk > 1: deterministic split of the K range through `workspace` (fp32 partial slabs).   */
 typedef struct RalfGemmDesc {
@@ -91,6 +91,12 @@ typedef struct RalfGemmDesc {
     int act, aux_mode, out_f32, accumulate, splitk;
     float alpha, aux_scale;
     RalfConvGeom g;
+    /* fused dropout after the activation: v = keep ? v/(1-p) : 0 with keep = f(seed[0], call_id, m*N+n) -- the
+     * same mask ralf_dropout produces on the contiguous [M,N] tensor (so the backward can regenerate it) */
+    const int64_t* seed; uint64_t call_id; float drop_p;
+    /* atomic_out: C (fp32) += alpha*A@B with fp32 atomics, split-K without partial slabs / reduce kernel
+     * (weight gradients accumulated straight into the flat gradient buffer; summation order not fixed) */
+    int atomic_out;
 } RalfGemmDesc;
 size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d);
 int ralf_gemm(const RalfGemmDesc* d, void* workspace, size_t workspace_bytes, void* stream);
@@ -101,8 +107,9 @@ int ralf_gemm(const RalfGemmDesc* d, void* workspace, size_t workspace_bytes, vo
  * ------------------------------------------------------------------------------------------- */
 int ralf_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                        int rows, int cols, float eps, void* stream);
+/* skip (may be NULL): gradient of the residual branch of a pre-norm block, added into dx */
 int ralf_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                       void* dx, float* dgamma, float* dbeta, int rows, int cols, void* stream);
+                       void* dx, float* dgamma, float* dbeta, const void* skip, int rows, int cols, void* stream);
 /* out[c] += sum_r x[r*ld + c]   (bias gradients) */
 int ralf_colsum(int dtype, const void* x, int64_t ld, float* out, int rows, int cols, void* stream);
 

@@ -26,6 +26,7 @@ class RalfGemmDesc(ctypes.Structure):
         + [(n, i32) for n in ("M", "N", "K", "nb0", "nb1", "dtype", "a_kcontig", "b_kcontig", "gather",
                               "act", "aux_mode", "out_f32", "accumulate", "splitk")]
         + [("alpha", f32), ("aux_scale", f32), ("g", RalfConvGeom)]
+        + [("seed", vp), ("call_id", ctypes.c_uint64), ("drop_p", f32), ("atomic_out", i32)]
     )
 
 
@@ -50,7 +51,7 @@ class RalfAttnDesc(ctypes.Structure):
 
 SIGNATURES.update({
     "ralf_layernorm_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
-    "ralf_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "ralf_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "ralf_colsum": (i32, [i32, vp, i64, vp, i32, i32, vp]),
     "ralf_bn_stats": (i32, [i32, vp, vp, vp, i64, i32, vp, vp]),
     "ralf_bn_finalize": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp]),

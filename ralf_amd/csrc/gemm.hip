@@ -66,6 +66,15 @@ template <> struct TT<bf16> {
     static constexpr int RPAD = 8;    // [64][rows + 8 pad]
 };
 
+// same counter-based generator as pointwise.hip / attention*.hip (masks must agree with ralf_dropout)
+__device__ __forceinline__ uint32_t rng24(uint64_t seed, uint64_t call, uint64_t idx) {
+    uint64_t z = seed + call * 0x9E3779B97F4A7C15ull + idx * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 40);
+}
+
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad(float x) {
     return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
@@ -88,14 +97,22 @@ __device__ __forceinline__ void epilogue_store(const RalfGemmDesc& d, int z0, in
     }
     if (d.act == RALF_ACT_RELU) v = v > 0.f ? v : 0.f;
     else if (d.act == RALF_ACT_GELU) v = gelu_f(v);
+    if (d.drop_p > 0.f) {  // element index = m*N + n of the contiguous [M,N] output (single batch)
+        const uint32_t thr = (uint32_t)(d.drop_p * 16777216.f);
+        v = rng24((uint64_t)d.seed[0], d.call_id, (uint64_t)m * d.N + n) >= thr ? v * (1.f / (1.f - d.drop_p)) : 0.f;
+    }
     if (d.aux) {
         const float a = ldf<T>(d.aux, coff);
         if (d.aux_mode == RALF_AUX_RELU_MASK) v = a > 0.f ? v * d.aux_scale : 0.f;
         else if (d.aux_mode == RALF_AUX_GELU_GRAD) v *= gelu_grad(a);
     }
     if (d.res) v += ldf<T>(d.res, z0 * d.sR0 + z1 * d.sR1 + (int64_t)m * d.ldr + n);
-    if (d.accumulate) v += d.out_f32 ? ldf<float>(d.C, coff) : ldf<T>(d.C, coff);
-    if (d.out_f32) stf<float>(d.C, coff, v); else stf<T>(d.C, coff, v);
+    if (d.atomic_out) {   // (no early `return` in these helpers: it defeats unrolling of the caller's accumulator loops)
+        atomicAdd((float*)d.C + coff, v);
+    } else {
+        if (d.accumulate) v += d.out_f32 ? ldf<float>(d.C, coff) : ldf<T>(d.C, coff);
+        if (d.out_f32) stf<float>(d.C, coff, v); else stf<T>(d.C, coff, v);
+    }
 }
 
 template <typename T> __device__ __forceinline__ void ld4(const void* p, int64_t i, float (&v)[4]);
@@ -138,6 +155,13 @@ __device__ __forceinline__ void epilogue_store4(const RalfGemmDesc& d, int z0, i
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = gelu_f(v[q]);
     }
+    if (d.drop_p > 0.f) {
+        const uint32_t thr = (uint32_t)(d.drop_p * 16777216.f);
+        const float inv = 1.f / (1.f - d.drop_p);
+        const uint64_t sd = (uint64_t)d.seed[0], e0 = (uint64_t)m * d.N + n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = rng24(sd, d.call_id, e0 + q) >= thr ? v[q] * inv : 0.f;
+    }
     if (d.aux) {
         float a[4];
         ld4<T>(d.aux, coff, a);
@@ -155,13 +179,18 @@ __device__ __forceinline__ void epilogue_store4(const RalfGemmDesc& d, int z0, i
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] += r[q];
     }
-    if (d.accumulate) {
-        float c[4];
-        if (d.out_f32) ld4<float>(d.C, coff, c); else ld4<T>(d.C, coff, c);
+    if (d.atomic_out) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += c[q];
+        for (int q = 0; q < 4; ++q) atomicAdd((float*)d.C + coff + q, v[q]);
+    } else {
+        if (d.accumulate) {
+            float c[4];
+            if (d.out_f32) ld4<float>(d.C, coff, c); else ld4<T>(d.C, coff, c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += c[q];
+        }
+        if (d.out_f32) st4<float>(d.C, coff, v); else st4<T>(d.C, coff, v);
     }
-    if (d.out_f32) st4<float>(d.C, coff, v); else st4<T>(d.C, coff, v);
 }
 
 // ---- operand loaders -------------------------------------------------------------------------
@@ -380,17 +409,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
     // ---- epilogue: lane holds 4 consecutive columns n per register group g = r>>2 ----
     // (no `continue`/`break` in these loops: they must unroll completely or the accumulators spill to scratch)
     const int nbatch = gridDim.z;
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * 32 * FM + i * 32 + l31;
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int j = 0; j < FN; ++j) {
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int g = 0; g < 4; ++g) {
                 const int n = n0 + wn * 32 * FN + j * 32 + 8 * g + 4 * lh;
                 float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 if (m < d.M && n < d.N) {
-                    if (d.splitk > 1) {
+                    if (d.splitk > 1 && !d.atomic_out) {
                         float* pp = P.partial + (((int64_t)split * nbatch + z) * d.M + m) * d.N + n;
                         if (P.vec_epi && n + 3 < d.N) *reinterpret_cast<float4*>(pp) = make_float4(v[0], v[1], v[2], v[3]);
                         else {
@@ -488,7 +517,7 @@ int dispatch(KParams& P, int nbatch, hipStream_t st) {
 }  // namespace
 
 extern "C" size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d) {
-    if (!d || d->splitk <= 1) return 0;
+    if (!d || d->splitk <= 1 || d->atomic_out) return 0;
     const int nb = d->nb0 * (d->nb1 > 0 ? d->nb1 : 1);
     return (size_t)d->splitk * nb * d->M * d->N * sizeof(float);
 }
@@ -511,6 +540,12 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
     if (d.splitk > ktiles) d.splitk = ktiles;
     P.kchunk = ceil_div(ktiles, d.splitk) * BK;
     d.splitk = ceil_div(d.K, P.kchunk);
+    if (d.atomic_out) {
+        RALF_REQUIRE((d.dtype == RALF_F32 || d.out_f32) && !d.bias && !d.act && !d.aux && !d.res && !d.C2 && d.drop_p == 0.f,
+                     "gemm: atomic_out needs a plain fp32 output (it adds alpha*A@B into C)");
+    }
+    RALF_REQUIRE(d.drop_p >= 0.f && d.drop_p < 1.f && (d.drop_p == 0.f || (d.seed && nbatch == 1 && d.ldc == d.N)),
+                 "gemm: fused dropout needs 0 <= p < 1, a seed, a single batch and a contiguous [M,N] output");
     P.partial = nullptr;
     {   // 4-wide epilogue accesses need 4-element-aligned leading dims / batch strides and 16-byte aligned bases
         const int es = (d.dtype == RALF_F32 || d.out_f32) ? 4 : 2;   // element size of C / C2
@@ -522,7 +557,7 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
         ok = ok && (!d.res || (d.ldr % 4 == 0 && d.sR0 % 4 == 0 && d.sR1 % 4 == 0 && al(d.res, et)));
         P.vec_epi = ok ? 1 : 0;
     }
-    if (d.splitk > 1) {
+    if (d.splitk > 1 && !d.atomic_out) {
         const size_t need = (size_t)d.splitk * nbatch * d.M * d.N * sizeof(float);
         if (!workspace || workspace_bytes < need) {
             ralf::set_error("gemm: split-K workspace %zu < required %zu bytes", workspace_bytes, need);
@@ -532,7 +567,7 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
     }
     hipStream_t st = (hipStream_t)stream;
     int rc = d.dtype == RALF_F32 ? dispatch<float>(P, nbatch, st) : dispatch<bf16>(P, nbatch, st);
-    if (rc || d.splitk <= 1) return rc;
+    if (rc || d.splitk <= 1 || d.atomic_out) return rc;
     const int64_t total = (int64_t)d.M * d.N * nbatch;
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
     if (d.dtype == RALF_F32) hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, P, nbatch);

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
-                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows) {
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, const T* __restrict__ skip, int rows) {
     constexpr int cols = NCH * 256;
     __shared__ float red[2][4][cols];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -103,6 +103,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             float o[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = rs * (d[c][i] * g[c][i] - s1 - xh[c][i] * s2);
+            if (skip) {  // pre-norm residual: the skip branch's gradient joins here (no separate add kernel)
+                float sk[4];
+                V4<T>::load(skip + (int64_t)row * cols + c * 256 + lane * 4, sk);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] += sk[i];
+            }
             V4<T>::store(dx + (int64_t)row * cols + c * 256 + lane * 4, o);
         }
     }
@@ -351,17 +357,18 @@ extern "C" int ralf_layernorm_fwd(int dtype, const void* x, const float* gamma, 
     return ralf::check_launch("layernorm_fwd");
 }
 
-/* dgamma/dbeta (fp32 [cols]) are ACCUMULATED into (caller zeroes or carries gradients); may be NULL */
+/* dgamma/dbeta (fp32 [cols]) are ACCUMULATED into (caller zeroes or carries gradients); may be NULL.
+ * skip (dtype [rows, cols], may be NULL) is added to dx: gradient of the residual branch x -> (LN(x), x) */
 extern "C" int ralf_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                                  void* dx, float* dgamma, float* dbeta, int rows, int cols, void* stream) {
+                                  void* dx, float* dgamma, float* dbeta, const void* skip, int rows, int cols, void* stream) {
     RALF_REQUIRE(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
     RALF_REQUIRE(rows > 0 && cols % 256 == 0 && cols <= 512, "layernorm_bwd: cols=%d must be 256 or 512", cols);
     hipStream_t st = (hipStream_t)stream;
     const int grid = grid_for(rows, 64, 1024);
     DISPATCH_T(dtype, if (cols == 256)
-                   hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows);
+                   hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, (const T*)skip, rows);
                else
-                   hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows););
+                   hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, (const T*)skip, rows););
     return ralf::check_launch("layernorm_bwd");
 }
 

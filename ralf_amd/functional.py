@@ -103,6 +103,8 @@ def wgrad(dy2d, x2d, N, K, rows, into=None):
     """dW[N,K] (fp32) = dy^T @ x, reduction over `rows` split across workgroups.  `into`: accumulate into this
     fp32 [N,K] view (flat gradient buffer) and return None."""
     if into is not None:
+        # (fp32 atomics straight into the buffer -- atomic=True -- were measured SLOWER than slabs + reduce:
+        #  ~19 G atomics/s in L2 vs millions of adds per weight gradient: 29.6 -> 36.9 ms/step)
         ops.gemm(dy2d, x2d, N, K, rows, a_kcontig=False, b_kcontig=False, out=into.view(N, K), accumulate=True, splitk=_splitk_for(N, K, rows))
         return None
     return ops.gemm(dy2d, x2d, N, K, rows, a_kcontig=False, b_kcontig=False, out_dtype=torch.float32,
@@ -122,16 +124,17 @@ class LinearFn(Function):
     in_proj for cross-attention) without materialising a sliced parameter; out_f32 -> fp32 logits."""
 
     @staticmethod
-    def forward(ctx, x, W, b, res, rt, out_f32, rows):
+    def forward(ctx, x, W, b, res, rt, out_f32, rows, p=0.0):
         r0, r1 = rows if rows is not None else (0, W.shape[0])
         N, K = r1 - r0, W.shape[1]
         x2 = _2d(x)
         nrow = x2.shape[0]
+        call = rt.next_call() if p > 0.0 else 0
         y = ops.gemm(x2, rt.lp(W)[r0:r1], nrow, N, K, bias=b.detach()[r0:r1] if b is not None else None,
                      res=_2d(res) if res is not None else None,
-                     out_dtype=torch.float32 if out_f32 else None)
+                     out_dtype=torch.float32 if out_f32 else None, drop_p=p, seed=rt.seed if p > 0.0 else None, call_id=call)
         ctx.save_for_backward(x2, W)
-        ctx.bias = b
+        ctx.bias, ctx.p, ctx.call = b, p, call
         ctx.rt, ctx.has_b, ctx.has_res, ctx.xshape, ctx.rows = rt, b is not None, res is not None, x.shape, (r0, r1)
         return y.view(*x.shape[:-1], N)
 
@@ -145,6 +148,8 @@ class LinearFn(Function):
         dy2 = _2d(dy.contiguous())
         if dy2.dtype != rt.dtype:
             dy2 = ops.cast(dy2, rt.dtype)
+        if ctx.p > 0.0:  # y = res + drop(xW^T + b): regenerate the mask on the incoming gradient
+            dy2 = ops.dropout(dy2, ctx.p, rt.seed, ctx.call)
         nrow = dy2.shape[0]
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
@@ -164,16 +169,17 @@ class LinearFn(Function):
                 g[r0:r1] = db
                 db = g
         dres = dy if ctx.has_res else None
-        return dx, dW, db, dres, None, None, None
+        return dx, dW, db, dres, None, None, None, None
 
 
-def linear(x, W, b=None, res=None, rt=None, out_f32=False, rows=None):
-    return LinearFn.apply(x, W, b, res, rt, out_f32, rows)
+def linear(x, W, b=None, res=None, rt=None, out_f32=False, rows=None, p=0.0):
+    """y = res + dropout_p(x W^T + b): bias, dropout and residual all live in the GEMM epilogue."""
+    return LinearFn.apply(x, W, b, res, rt, out_f32, rows, p)
 
 
 class FFNFn(Function):
-    """y = W2 drop(act(W1 x + b1)) + b2 (+ res) with a hand-written backward (activation gradient
-    fused into the data-gradient GEMM epilogue)."""
+    """y = res + drop_p(W2 drop_p(act(W1 x + b1)) + b2): two GEMMs whose epilogues carry bias, activation, both
+    dropouts and the residual; hand-written backward (activation gradient fused into the data-gradient GEMM)."""
 
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2, res, act, p, rt):
@@ -181,22 +187,24 @@ class FFNFn(Function):
         rows, K = x2.shape
         Hd, N = W1.shape[0], W2.shape[0]
         z = torch.empty(rows, Hd, dtype=rt.dtype, device=x.device) if act == "gelu" else None
-        h = ops.gemm(x2, rt.lp(W1), rows, Hd, K, bias=b1.detach(), act=act, out2=z)
-        call = 0
-        if p > 0.0:
-            call = rt.next_call()
-            h = ops.dropout(h, p, rt.seed, call)
-        y = ops.gemm(h, rt.lp(W2), rows, N, Hd, bias=b2.detach(), res=_2d(res) if res is not None else None)
+        c1 = rt.next_call() if p > 0.0 else 0
+        c2 = rt.next_call() if p > 0.0 else 0
+        sd = rt.seed if p > 0.0 else None
+        h = ops.gemm(x2, rt.lp(W1), rows, Hd, K, bias=b1.detach(), act=act, out2=z, drop_p=p, seed=sd, call_id=c1)
+        y = ops.gemm(h, rt.lp(W2), rows, N, Hd, bias=b2.detach(), res=_2d(res) if res is not None else None, drop_p=p, seed=sd, call_id=c2)
         ctx.save_for_backward(x2, W1, W2, h, z)
         ctx.b1, ctx.b2 = b1, b2
-        ctx.rt, ctx.act, ctx.p, ctx.has_res, ctx.xshape = rt, act, p, res is not None, x.shape
+        ctx.rt, ctx.act, ctx.p, ctx.has_res, ctx.xshape, ctx.c2 = rt, act, p, res is not None, x.shape, c2
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
         x2, W1, W2, h, z = ctx.saved_tensors
         rt = ctx.rt
-        dy2 = _2d(dy.contiguous())
+        dy = dy.contiguous()
+        dy2 = _2d(dy)
+        if ctx.p > 0.0:
+            dy2 = ops.dropout(dy2, ctx.p, rt.seed, ctx.c2)   # mask of the output dropout
         rows, K = x2.shape
         Hd, N = W1.shape[0], W2.shape[0]
         if ctx.act == "gelu":
@@ -233,6 +241,34 @@ class LayerNormFn(Function):
 
 def layer_norm(x, g, b, rt):
     return LayerNormFn.apply(x, g, b, rt)
+
+
+class LayerNormSkipFn(Function):
+    """(LN(x), x): the pre-norm residual pattern.  The gradient of the skip output is added inside the
+    LayerNorm backward kernel instead of by a separate accumulate pass."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, rt):
+        xc = x.contiguous()
+        y, mean, rstd = ops.layernorm_fwd(xc, g.detach(), b.detach())
+        ctx.save_for_backward(xc, g, mean, rstd)
+        ctx.rt, ctx.beta = rt, b
+        return y, xc.view_as(xc)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, g, mean, rstd = ctx.saved_tensors
+        gg, gb = ctx.rt.gview(g), ctx.rt.gview(ctx.beta)
+        skip = dskip.contiguous() if dskip is not None else None
+        if gg is not None and gb is not None:
+            dx, _, _ = ops.layernorm_bwd(dy.contiguous(), x, g.detach(), mean, rstd, need_wgrad=True, into=(gg, gb), skip=skip)
+            return dx, None, None, None
+        dx, dg, db = ops.layernorm_bwd(dy.contiguous(), x, g.detach(), mean, rstd, need_wgrad=True, skip=skip)
+        return dx, dg, db, None
+
+
+def layer_norm_skip(x, g, b, rt):
+    return LayerNormSkipFn.apply(x, g, b, rt)
 
 
 class DropAddFn(Function):

@@ -91,19 +91,12 @@ class MHAParams(nn.Module):
         return self._out(o, res, rt, p_out)
 
     def _out(self, o, res, rt, p_out):
-        p = rt.drop_p(p_out)
-        if p == 0.0:
-            return RF.linear(o, self.out_proj.weight, self.out_proj.bias, res=res, rt=rt)
-        return RF.drop_add(RF.linear(o, self.out_proj.weight, self.out_proj.bias, rt=rt), res, p, rt)
+        return RF.linear(o, self.out_proj.weight, self.out_proj.bias, res=res, rt=rt, p=rt.drop_p(p_out))
 
 
 class _FFNMixin:
     def _ffn(self, h, res, rt, p):
-        p = rt.drop_p(p)
-        if p == 0.0:
-            return RF.FFNFn.apply(h, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, res, "relu", 0.0, rt)
-        t = RF.FFNFn.apply(h, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, None, "relu", p, rt)
-        return RF.drop_add(t, res, p, rt)
+        return RF.FFNFn.apply(h, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, res, "relu", rt.drop_p(p), rt)
 
 
 class TransformerEncoderLayer(nn.Module, _FFNMixin):
@@ -116,9 +109,9 @@ class TransformerEncoderLayer(nn.Module, _FFNMixin):
 
     def forward(self, x, rt: Runtime, kpm=None):
         if self.norm_first:
-            h = RF.layer_norm(x, self.norm1.weight, self.norm1.bias, rt)
+            h, x = RF.layer_norm_skip(x, self.norm1.weight, self.norm1.bias, rt)
             x = self.self_attn.self_attn(h, x, rt, kpm=kpm, p_attn=self.p, p_out=self.p)
-            h = RF.layer_norm(x, self.norm2.weight, self.norm2.bias, rt)
+            h, x = RF.layer_norm_skip(x, self.norm2.weight, self.norm2.bias, rt)
             return self._ffn(h, x, rt, self.p)
         x = RF.layer_norm(self.self_attn.self_attn(x, x, rt, kpm=kpm, p_attn=self.p, p_out=self.p), self.norm1.weight, self.norm1.bias, rt)
         return RF.layer_norm(self._ffn(x, x, rt, self.p), self.norm2.weight, self.norm2.bias, rt)
@@ -133,11 +126,11 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
         self.p = dropout
 
     def forward(self, x, mem, rt: Runtime, tgt_kpm=None):
-        h = RF.layer_norm(x, self.norm1.weight, self.norm1.bias, rt)
+        h, x = RF.layer_norm_skip(x, self.norm1.weight, self.norm1.bias, rt)
         x = self.self_attn.self_attn(h, x, rt, causal=True, kpm=tgt_kpm, p_attn=self.p, p_out=self.p)
-        h = RF.layer_norm(x, self.norm2.weight, self.norm2.bias, rt)
+        h, x = RF.layer_norm_skip(x, self.norm2.weight, self.norm2.bias, rt)
         x = self.multihead_attn.cross_attn(h, mem, x, rt, p_attn=self.p, p_out=self.p)  # memory is NOT masked (common.py:116-123)
-        h = RF.layer_norm(x, self.norm3.weight, self.norm3.bias, rt)
+        h, x = RF.layer_norm_skip(x, self.norm3.weight, self.norm3.bias, rt)
         return self._ffn(h, x, rt, self.p)
 
 

@@ -41,7 +41,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
          lda=None, ldb=None, out: Optional[torch.Tensor] = None, ldc=None, out_dtype=None,
          bias=None, act=None, res=None, ldr=None, aux=None, aux_mode=None, aux_scale=1.0, out2=None,
          alpha=1.0, accumulate=False, splitk=1, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=None,
-         conv: Optional[dict] = None, gather=0) -> torch.Tensor:
+         conv: Optional[dict] = None, gather=0, drop_p=0.0, seed=None, call_id=0, atomic=False) -> torch.Tensor:
     """C = epi(alpha * A @ B) through ralf_gemm (see include/ralf_hip.h: RalfGemmDesc)."""
     assert A.is_cuda and B.is_cuda and A.dtype == B.dtype
     d = RalfGemmDesc()
@@ -72,12 +72,13 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
     d.a_kcontig, d.b_kcontig, d.gather = int(a_kcontig), int(b_kcontig), gather
     d.act, d.aux_mode, d.aux_scale = ACT[act], AUX[aux_mode], aux_scale
     d.accumulate, d.splitk, d.alpha = int(accumulate), splitk, alpha
+    d.drop_p, d.seed, d.call_id, d.atomic_out = drop_p, _p(seed), call_id, int(atomic)
     if conv is not None:
         g = RalfConvGeom(**conv)
         d.g = g
     L = _lib.lib()
     ws, wsn = None, 0
-    if splitk > 1:
+    if splitk > 1 and not atomic:
         wsn = splitk * nb0 * nb1 * M * N * 4
         ws = workspace(wsn, A.device)
     rc = L.ralf_gemm(ctypes.byref(d), _p(ws), wsn, _lib.stream_ptr())
@@ -105,7 +106,7 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, save_stats=True):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, need_wgrad=True, into=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, need_wgrad=True, into=None, skip=None):
     """into = (dgamma, dbeta) fp32 views to ACCUMULATE into (flat gradient buffer)."""
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
     dx = torch.empty_like(x)
@@ -114,7 +115,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, need_wgrad=True, into=None):
     else:
         dg = torch.zeros(cols, dtype=torch.float32, device=x.device) if need_wgrad else None
         db = torch.zeros(cols, dtype=torch.float32, device=x.device) if need_wgrad else None
-    _call("ralf_layernorm_bwd", dtype_code(x), _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), rows, cols)
+    _call("ralf_layernorm_bwd", dtype_code(x), _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), _p(skip), rows, cols)
     return dx, dg, db
 
 
