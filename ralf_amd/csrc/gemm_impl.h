@@ -1,0 +1,562 @@
+// MFMA GEMM for gfx950 with fused epilogues; the one contraction kernel behind every Linear,
+// attention projection, FFN, vocab head and (through the implicit-im2col gather) every Conv2d
+// of the RALF train step.
+//
+//   C[z][m][n] = epi( alpha * sum_k A[z][m][k] * B[z][k][n] )
+//
+// Replaces torch.nn.functional.linear / conv2d and their autograd backward as called from
+//   nn.TransformerEncoderLayer / DecoderLayer / MultiheadAttention
+//       (image2layout/train/models/retrieval_augmented_autoreg.py:116-126, common/common.py:25-34)
+//   FeedForward / Attention (common/attention.py:15-71), BaseDecoder.head (common/common.py:38-40)
+//   ResnetBackbone convolutions (common/image.py:80-111)
+//
+// Design:
+//   * (64*FM)x(64*FN) output tile per 256-thread workgroup (FM,FN in {1,2}: 128x128 for the big products,
+//     64-wide variants for N = 64 convolutions and for small grids that need more workgroups in flight),
+//     2x2 waves, each wave FMxFN fragments of 32x32 (v_mfma_f32_32x32x16_bf16 or the exact-fp32
+//     v_mfma_f32_32x32x2_f32); fp32 accumulate always.  The matrix core computes the TRANSPOSED tile
+//     (weights as the row operand) so every lane ends up with 4 consecutive output columns: 8/16-byte
+//     epilogue loads and stores instead of 2-byte ones.
+//   * each operand is either "k-contiguous" (row-major [rows][K]) or "row-contiguous" ([K][rows]);
+//     tiles are staged global -> registers -> LDS in their MEMORY order (coalesced 16-B loads) and
+//     the row-contiguous case is fed to the matrix core with ds_read_b64_tr_b16 (bf16) / plain
+//     ds_read_b32 (fp32), so NN / NT / TN products need no transposed copies in HBM.
+//   * the "pixel x (kh,kw,c)" operand of a convolution is gathered on the fly from NHWC (implicit
+//     im2col; forward / data-gradient / weight-gradient all use the same gather).
+//   * split-K for the weight-gradient shapes (tiny output, huge reduction), deterministic:
+//     partial slabs + a reduce kernel that also runs the epilogue.
+//   * epilogue: alpha, bias, ReLU/GELU(erf), activation-gradient masks, residual add, second
+//     (pre-activation) output, fp32 or bf16 stores.
+#pragma once
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+
+struct KParams {
+    RalfGemmDesc d;
+    int tiles_m, tiles_n, nwg;
+    int kchunk;       // K range handled by one split (multiple of BK)
+    float* partial;   // [split][batch][M][N] fp32 (splitk > 1)
+    int vec_epi;      // leading dims / bases allow 4-wide epilogue accesses
+    int fast;         // interior fast path: aligned operands, K range a multiple of BK (no per-tile bounds math)
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <typename T> struct TT;
+template <> struct TT<float> {
+    static constexpr int VEC = 4, BK = 32, KSTEP = 2;
+    static constexpr int LDK = 32;    // k-contiguous tile: [rows][32], rotated
+    static constexpr int RPAD = 0;    // row-contiguous tile: [32][rows]
+};
+template <> struct TT<bf16> {
+    static constexpr int VEC = 8, BK = 64, KSTEP = 16;
+    static constexpr int LDK = 72;    // [rows][64 + 8 pad]
+    static constexpr int RPAD = 8;    // [64][rows + 8 pad]
+};
+
+// same counter-based generator as pointwise.hip / attention*.hip (masks must agree with ralf_dropout)
+__device__ __forceinline__ uint32_t rng24(uint64_t seed, uint64_t call, uint64_t idx) {
+    uint64_t z = seed + call * 0x9E3779B97F4A7C15ull + idx * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 40);
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+template <typename T> __device__ __forceinline__ float ldf(const void* p, int64_t i);
+template <> __device__ __forceinline__ float ldf<float>(const void* p, int64_t i) { return ((const float*)p)[i]; }
+template <> __device__ __forceinline__ float ldf<bf16>(const void* p, int64_t i) { return (float)((const bf16*)p)[i]; }
+template <typename T> __device__ __forceinline__ void stf(void* p, int64_t i, float v);
+template <> __device__ __forceinline__ void stf<float>(void* p, int64_t i, float v) { ((float*)p)[i] = v; }
+template <> __device__ __forceinline__ void stf<bf16>(void* p, int64_t i, float v) { ((bf16*)p)[i] = (bf16)v; }
+
+// epilogue on one element (tails / unaligned outputs and the scalar split-K reducer); EPI as in epilogue_store4.
+// (A non-inlined version was tried to shrink the code: device function calls cost far more -- 3x slower kernels.)
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue_store(const RalfGemmDesc& d, int z0, int z1, int m, int n, float v) {
+    v *= d.alpha;
+    if (d.bias) v += d.bias[n];
+    const int64_t coff = z0 * d.sC0 + z1 * d.sC1 + (int64_t)m * d.ldc + n;
+    if (EPI >= 2 && d.C2) {  // pre-activation copy (needed by the activation gradient)
+        if (d.out_f32) stf<float>(d.C2, coff, v); else stf<T>(d.C2, coff, v);
+    }
+    if (d.act == RALF_ACT_RELU) v = v > 0.f ? v : 0.f;
+    else if (EPI >= 2 && d.act == RALF_ACT_GELU) v = gelu_f(v);
+    if (EPI >= 1 && d.drop_p > 0.f) {  // element index = m*N + n of the contiguous [M,N] output (single batch)
+        const uint32_t thr = (uint32_t)(d.drop_p * 16777216.f);
+        v = rng24((uint64_t)d.seed[0], d.call_id, (uint64_t)m * d.N + n) >= thr ? v * (1.f / (1.f - d.drop_p)) : 0.f;
+    }
+    if (EPI >= 1 && d.aux) {
+        const float a = ldf<T>(d.aux, coff);
+        if (d.aux_mode == RALF_AUX_RELU_MASK) v = a > 0.f ? v * d.aux_scale : 0.f;
+        else if (EPI >= 2 && d.aux_mode == RALF_AUX_GELU_GRAD) v *= gelu_grad(a);
+    }
+    if (d.res) v += ldf<T>(d.res, z0 * d.sR0 + z1 * d.sR1 + (int64_t)m * d.ldr + n);
+    if (EPI >= 2 && d.atomic_out) {   // (no early `return` in these helpers: it defeats unrolling of the caller's accumulator loops)
+        atomicAdd((float*)d.C + coff, v);
+    } else {
+        if (d.accumulate) v += d.out_f32 ? ldf<float>(d.C, coff) : ldf<T>(d.C, coff);
+        if (d.out_f32) stf<float>(d.C, coff, v); else stf<T>(d.C, coff, v);
+    }
+}
+
+template <typename T> __device__ __forceinline__ void ld4(const void* p, int64_t i, float (&v)[4]);
+template <> __device__ __forceinline__ void ld4<float>(const void* p, int64_t i, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>((const float*)p + i); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void ld4<bf16>(const void* p, int64_t i, float (&v)[4]) {
+    const bf16x4 t = *reinterpret_cast<const bf16x4*>((const bf16*)p + i);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (float)t[q];
+}
+template <typename T> __device__ __forceinline__ void st4(void* p, int64_t i, const float (&v)[4]);
+template <> __device__ __forceinline__ void st4<float>(void* p, int64_t i, const float (&v)[4]) {
+    *reinterpret_cast<float4*>((float*)p + i) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void st4<bf16>(void* p, int64_t i, const float (&v)[4]) {
+    bf16x4 t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = (bf16)v[q];
+    *reinterpret_cast<bf16x4*>((bf16*)p + i) = t;
+}
+
+// epilogue on 4 consecutive columns n..n+3 of row m (same semantics as epilogue_store).
+// EPI selects how much of the epilogue is compiled in (code size = issue slots and I-cache):
+//   0: alpha, bias, ReLU, residual, accumulate      1: + fused dropout, ReLU-gradient mask
+//   2: everything (GELU, GELU gradient, pre-activation copy, atomics)
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue_store4(const RalfGemmDesc& d, int z0, int z1, int m, int n, float (&v)[4]) {
+    const int64_t coff = z0 * d.sC0 + z1 * d.sC1 + (int64_t)m * d.ldc + n;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] *= d.alpha;
+    if (d.bias) {
+        float b[4];
+        ld4<float>(d.bias, n, b);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += b[q];
+    }
+    if (EPI >= 2 && d.C2) { if (d.out_f32) st4<float>(d.C2, coff, v); else st4<T>(d.C2, coff, v); }
+    if (d.act == RALF_ACT_RELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+    } else if (EPI >= 2 && d.act == RALF_ACT_GELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = gelu_f(v[q]);
+    }
+    if (EPI >= 1 && d.drop_p > 0.f) {
+        const uint32_t thr = (uint32_t)(d.drop_p * 16777216.f);
+        const float inv = 1.f / (1.f - d.drop_p);
+        const uint64_t sd = (uint64_t)d.seed[0], e0 = (uint64_t)m * d.N + n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = rng24(sd, d.call_id, e0 + q) >= thr ? v[q] * inv : 0.f;
+    }
+    if (EPI >= 1 && d.aux) {
+        float a[4];
+        ld4<T>(d.aux, coff, a);
+        if (d.aux_mode == RALF_AUX_RELU_MASK) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = a[q] > 0.f ? v[q] * d.aux_scale : 0.f;
+        } else if (EPI >= 2 && d.aux_mode == RALF_AUX_GELU_GRAD) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] *= gelu_grad(a[q]);
+        }
+    }
+    if (d.res) {
+        float r[4];
+        ld4<T>(d.res, z0 * d.sR0 + z1 * d.sR1 + (int64_t)m * d.ldr + n, r);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += r[q];
+    }
+    if (EPI >= 2 && d.atomic_out) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomicAdd((float*)d.C + coff + q, v[q]);
+    } else {
+        if (d.accumulate) {
+            float c[4];
+            if (d.out_f32) ld4<float>(d.C, coff, c); else ld4<T>(d.C, coff, c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += c[q];
+        }
+        if (d.out_f32) st4<float>(d.C, coff, v); else st4<T>(d.C, coff, v);
+    }
+}
+
+// ---- operand loaders -------------------------------------------------------------------------
+// A "source matrix" is row-major with contiguous columns: plain (ptr + row*ld + col) or the
+// implicit im2col matrix rows = pixels of a (RH x RW) grid per image, cols = (kh, kw, c).
+struct RowInfo { int64_t base; int y0, x0; bool ok; };
+
+template <bool GATHER>
+__device__ __forceinline__ RowInfo row_info(const RalfConvGeom& g, int64_t row, int64_t nrows, int64_t ld) {
+    RowInfo r;
+    r.ok = row < nrows;
+    if (!GATHER) { r.base = row * ld; r.y0 = r.x0 = 0; return r; }
+    const int hw = g.RH * g.RW;
+    const int b = (int)(row / hw), rem = (int)(row - (int64_t)b * hw);
+    const int ry = rem / g.RW, rx = rem - ry * g.RW;
+    r.base = (int64_t)b * g.SH * g.SW * g.SC;
+    if (g.mode == 0) { r.y0 = ry * g.stride - g.pad; r.x0 = rx * g.stride - g.pad; }
+    else             { r.y0 = ry + g.pad;            r.x0 = rx + g.pad; }
+    return r;
+}
+
+// 16-byte vector of VEC elements at (row, col..col+VEC-1); zero outside the matrix / the padding
+template <typename T, bool GATHER>
+__device__ __forceinline__ uint4 load_vec(const T* __restrict__ p, const RalfConvGeom& g, const RowInfo& r, int col, int ncols, bool aligned) {
+    constexpr int VEC = TT<T>::VEC;
+    uint4 z = make_uint4(0, 0, 0, 0);
+    if (!r.ok || col >= ncols) return z;
+    if (GATHER) {
+        const int c = col % g.SC, t = col / g.SC;  // SC % VEC == 0: a vector never straddles a tap
+        const int kw = t % g.KW, kh = t / g.KW;
+        int sy, sx;
+        if (g.mode == 0) { sy = r.y0 + kh; sx = r.x0 + kw; }
+        else {
+            const int ty = r.y0 - kh, tx = r.x0 - kw;
+            if (ty < 0 || tx < 0 || (ty % g.stride) || (tx % g.stride)) return z;
+            sy = ty / g.stride; sx = tx / g.stride;
+        }
+        if (sy < 0 || sy >= g.SH || sx < 0 || sx >= g.SW) return z;
+        return *reinterpret_cast<const uint4*>(p + r.base + ((int64_t)sy * g.SW + sx) * g.SC + c);
+    }
+    const T* q = p + r.base + col;
+    if (aligned && col + VEC <= ncols) return *reinterpret_cast<const uint4*>(q);
+    T tmp[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) tmp[i] = (col + i < ncols) ? q[i] : (T)0.f;
+    return *reinterpret_cast<uint4*>(tmp);
+}
+
+// AK: A is k-contiguous ([M][K]); else stored [K][M].   BKC: B is k-contiguous ([N][K]); else [K][N].
+// GATHER: 0 none, 1 = A (k-contiguous) is an im2col matrix, 2 = B (row-contiguous) is an im2col matrix.
+// FM, FN: 32x32 fragments per wave along m / n  ->  workgroup tile (64*FM) x (64*FN).
+template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
+    using X = TT<T>;
+    constexpr int VEC = X::VEC, BK = X::BK;
+    constexpr int BM = 64 * FM, BN = 64 * FN;
+    constexpr int LDRA = BM + X::RPAD, LDRB = BN + X::RPAD;
+    constexpr int A_ELEMS = AK ? BM * X::LDK : BK * LDRA;
+    constexpr int B_ELEMS = BKC ? BN * X::LDK : BK * LDRB;
+    constexpr int KV = BK / VEC;                                   // vectors along k (k-contiguous tile)
+    constexpr int RVA = BM / VEC, RVB = BN / VEC;                  // vectors along rows (row-contiguous tile)
+    constexpr int NVA = BM * BK / VEC / 256, NVB = BN * BK / VEC / 256;  // 16-byte vectors per thread per k-tile
+    __shared__ __attribute__((aligned(16))) T lds[A_ELEMS + B_ELEMS];
+    T* la = lds;
+    T* lb = lds + A_ELEMS;
+    const RalfGemmDesc& d = P.d;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int vid = xcd_remap(blockIdx.x, P.nwg);
+    const int tn = vid % P.tiles_n, tm = vid / P.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int split = blockIdx.y, z = blockIdx.z, z0 = z % d.nb0, z1 = z / d.nb0;
+    const int kbeg = split * P.kchunk;
+    const int kend = min(d.K, kbeg + P.kchunk);
+
+    const T* Ap = (const T*)d.A + z0 * d.sA0 + z1 * d.sA1;
+    const T* Bp = (const T*)d.B + z0 * d.sB0 + z1 * d.sB1;
+    const bool a_al = (d.lda % VEC == 0) && (((uintptr_t)Ap & 15) == 0);
+    const bool b_al = (d.ldb % VEC == 0) && (((uintptr_t)Bp & 15) == 0);
+
+    uint4 ra[NVA], rb[NVB];
+    RowInfo ia[NVA], ib[NVB];
+    // PMC (SQ_ACTIVE_INST_ANY ~ 84 % of the kernel, MFMA busy 10 %) showed this kernel is instruction-issue bound:
+    // the interior fast path keeps one pointer per staging vector and advances it by a constant per k-tile.
+    // Rows beyond M/N are clamped to the last valid row (their results are never stored).
+    const bool fast = GATHER == 0 && P.fast;
+    const T* pa[NVA];
+    const T* pb[NVB];
+    const int64_t stepA = AK ? BK : (int64_t)BK * d.lda, stepB = BKC ? BK : (int64_t)BK * d.ldb;
+    if (fast) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            const int v = tid + 256 * i;
+            if (AK) pa[i] = Ap + (int64_t)min(m0 + v / KV, d.M - 1) * d.lda + kbeg + (v % KV) * VEC;
+            else pa[i] = Ap + (int64_t)(kbeg + v / RVA) * d.lda + min(m0 + (v % RVA) * VEC, d.M - VEC);
+        }
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int v = tid + 256 * i;
+            if (BKC) pb[i] = Bp + (int64_t)min(n0 + v / KV, d.N - 1) * d.ldb + kbeg + (v % KV) * VEC;
+            else pb[i] = Bp + (int64_t)(kbeg + v / RVB) * d.ldb + min(n0 + (v % RVB) * VEC, d.N - VEC);
+        }
+    }
+    if (AK) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) ia[i] = row_info<GATHER == 1>(d.g, m0 + (tid + 256 * i) / KV, d.M, d.lda);
+    }
+    if (BKC) {
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) ib[i] = row_info<false>(d.g, n0 + (tid + 256 * i) / KV, d.N, d.ldb);
+    }
+    auto gload = [&](int k0) {
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) { ra[i] = *reinterpret_cast<const uint4*>(pa[i]); pa[i] += stepA; }
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) { rb[i] = *reinterpret_cast<const uint4*>(pb[i]); pb[i] += stepB; }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            const int v = tid + 256 * i;
+            if (AK) ra[i] = load_vec<T, GATHER == 1>(Ap, d.g, ia[i], k0 + (v % KV) * VEC, kend, a_al);
+            else {
+                const RowInfo r = row_info<false>(d.g, k0 + v / RVA, kend, d.lda);
+                ra[i] = load_vec<T, false>(Ap, d.g, r, m0 + (v % RVA) * VEC, d.M, a_al);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int v = tid + 256 * i;
+            if (BKC) rb[i] = load_vec<T, false>(Bp, d.g, ib[i], k0 + (v % KV) * VEC, kend, b_al);
+            else {
+                const RowInfo r = row_info<GATHER == 2>(d.g, k0 + v / RVB, kend, d.ldb);
+                rb[i] = load_vec<T, GATHER == 2>(Bp, d.g, r, n0 + (v % RVB) * VEC, d.N, b_al);
+            }
+        }
+    };
+    auto lstore_one = [&](T* l, bool kc, const uint4* regs, int nv, int rv, int ldr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < nv) {
+            const int v = tid + 256 * i;
+            if (kc) {
+                const int r = v / KV, kv = v % KV;
+                if constexpr (sizeof(T) == 4) {  // fp32: rotate each row so 32 rows x same k hit 32 banks
+                    float* base = (float*)l + r * 32;
+                    const float* s = reinterpret_cast<const float*>(&regs[i]);
+                    const int rot = kv * 4 + r;
+                    base[(rot + 0) & 31] = s[0]; base[(rot + 1) & 31] = s[1];
+                    base[(rot + 2) & 31] = s[2]; base[(rot + 3) & 31] = s[3];
+                } else {
+                    *reinterpret_cast<uint4*>(l + r * X::LDK + kv * VEC) = regs[i];
+                }
+            } else {
+                const int kr = v / rv, c = v % rv;
+                *reinterpret_cast<uint4*>(l + kr * ldr + c * VEC) = regs[i];
+            }
+            }
+        }
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    // transpose-read geometry (bf16 row-contiguous tiles): 16-lane group gi reads a [4 k][16 rows] block
+    const int trL = lane & 15, tr_rowblk = ((lane >> 4) & 1) * 16, tr_k = lh * 8 + (trL >> 2), tr_c = (trL & 3) * 4;
+
+    gload(kbeg);
+    lstore_one(la, AK, ra, NVA, RVA, LDRA);
+    lstore_one(lb, BKC, rb, NVB, RVB, LDRB);
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = k0 + BK < kend;
+        if (more) gload(k0 + BK);
+        // the matrix core computes the TRANSPOSED tile: row operand = n-fragment (weights), column operand =
+        // m-fragment, so accumulator register r of a lane holds (n = (r&3) + 8*(r>>2) + 4*(lane>>5), m = lane&31)
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                const int kk = ks * 2 + lh;
+                float a[FM], b[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int r = wm * 32 * FM + i * 32 + l31;
+                    a[i] = AK ? ((float*)la)[r * 32 + ((kk + r) & 31)] : ((float*)la)[kk * LDRA + r];
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int r = wn * 32 * FN + j * 32 + l31;
+                    b[j] = BKC ? ((float*)lb)[r * 32 + ((kk + r) & 31)] : ((float*)lb)[kk * LDRB + r];
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 a[FM], b[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    if (AK) {
+                        a[i] = *reinterpret_cast<const bf16x8*>(la + (wm * 32 * FM + i * 32 + l31) * X::LDK + ks * 16 + lh * 8);
+                    } else {
+                        const bf16* q = (const bf16*)la + (ks * 16 + tr_k) * LDRA + wm * 32 * FM + i * 32 + tr_rowblk + tr_c;
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 4 * LDRA));
+                        a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    if (BKC) {
+                        b[j] = *reinterpret_cast<const bf16x8*>(lb + (wn * 32 * FN + j * 32 + l31) * X::LDK + ks * 16 + lh * 8);
+                    } else {
+                        const bf16* q = (const bf16*)lb + (ks * 16 + tr_k) * LDRB + wn * 32 * FN + j * 32 + tr_rowblk + tr_c;
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 4 * LDRB));
+                        b[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (more) {
+            lstore_one(la, AK, ra, NVA, RVA, LDRA);
+            lstore_one(lb, BKC, rb, NVB, RVB, LDRB);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lane holds 4 consecutive columns n per register group g = r>>2 ----
+    // (no `continue`/`break` in these loops: they must unroll completely or the accumulators spill to scratch)
+    const int nbatch = gridDim.z;
+#pragma clang loop unroll(full)
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * 32 * FM + i * 32 + l31;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < FN; ++j) {
+#pragma clang loop unroll(full)
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * 32 * FN + j * 32 + 8 * g + 4 * lh;
+                float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                if (m < d.M && n < d.N) {
+                    if (d.splitk > 1 && !d.atomic_out) {
+                        float* pp = P.partial + (((int64_t)split * nbatch + z) * d.M + m) * d.N + n;
+                        if (P.vec_epi && n + 3 < d.N) *reinterpret_cast<float4*>(pp) = make_float4(v[0], v[1], v[2], v[3]);
+                        else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (n + q < d.N) pp[q] = v[q];
+                        }
+                    } else if (P.vec_epi && n + 3 < d.N) {
+                        epilogue_store4<T, EPI>(d, z0, z1, m, n, v);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (n + q < d.N) epilogue_store<T, EPI>(d, z0, z1, m, n + q, v[q]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams P, int nbatch) {
+    const RalfGemmDesc& d = P.d;
+    const int64_t per = (int64_t)d.M * d.N, total = per * nbatch;
+    if (P.vec_epi && d.N % 4 == 0) {
+        for (int64_t e4 = (int64_t)blockIdx.x * 256 + threadIdx.x; e4 < total / 4; e4 += (int64_t)gridDim.x * 256) {
+            const int64_t e = e4 * 4;
+            float4 a = *reinterpret_cast<const float4*>(P.partial + e);
+            for (int s = 1; s < d.splitk; ++s) {
+                const float4 t = *reinterpret_cast<const float4*>(P.partial + (int64_t)s * total + e);
+                a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+            }
+            const int z = (int)(e / per);
+            const int64_t r = e - (int64_t)z * per;
+            float v[4] = {a.x, a.y, a.z, a.w};
+            epilogue_store4<T, 2>(d, z % d.nb0, z / d.nb0, (int)(r / d.N), (int)(r % d.N), v);
+        }
+        return;
+    }
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int s = 0; s < d.splitk; ++s) v += P.partial[(int64_t)s * total + e];
+        const int z = (int)(e / per);
+        const int64_t r = e - (int64_t)z * per;
+        epilogue_store<T, 2>(d, z % d.nb0, z / d.nb0, (int)(r / d.N), (int)(r % d.N), v);
+    }
+}
+
+template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI>
+int launch(KParams& P, int nbatch, hipStream_t st) {
+    P.tiles_m = ceil_div(P.d.M, 64 * FM);
+    P.tiles_n = ceil_div(P.d.N, 64 * FN);
+    P.nwg = P.tiles_m * P.tiles_n;
+    hipLaunchKernelGGL((gemm_kernel<T, AK, BKC, GATHER, FM, FN, EPI>), dim3(P.nwg, P.d.splitk, nbatch), dim3(256), 0, st, P);
+    return ralf::check_launch("gemm");
+}
+
+template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN>
+int launch_epi(KParams& P, int nbatch, hipStream_t st) {
+    const RalfGemmDesc& d = P.d;
+    const bool lvl2 = d.C2 || d.act == RALF_ACT_GELU || d.aux_mode == RALF_AUX_GELU_GRAD || d.atomic_out;
+    const bool lvl1 = d.drop_p > 0.f || d.aux;
+    if (lvl2) return launch<T, AK, BKC, GATHER, FM, FN, 2>(P, nbatch, st);
+    if (lvl1) return launch<T, AK, BKC, GATHER, FM, FN, 1>(P, nbatch, st);
+    return launch<T, AK, BKC, GATHER, FM, FN, 0>(P, nbatch, st);
+}
+
+// tile choice, measured on MI355X (tools/gemm_bench.py): the short-K products of the model (K <= 1024) run
+// fastest on 64x64 tiles (5-7 workgroups per CU); 128x128 pays off only for long reductions that fill the chip.
+template <typename T, bool AK, bool BKC, int GATHER>
+int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
+    const RalfGemmDesc& d = P.d;
+    const int64_t big = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) * d.splitk * nbatch;
+    const int kspan = ceil_div(d.K, d.splitk);
+    if (d.N > 64 && d.M > 64 && kspan >= 1024 && big >= 512) return launch_epi<T, AK, BKC, GATHER, 2, 2>(P, nbatch, st);
+    return launch_epi<T, AK, BKC, GATHER, 1, 1>(P, nbatch, st);
+}
+
+template <typename T>
+int dispatch(KParams& P, int nbatch, hipStream_t st) {
+    const RalfGemmDesc& d = P.d;
+    const int key = (d.a_kcontig ? 4 : 0) | (d.b_kcontig ? 2 : 0);
+    if (d.gather == 1) {
+        if (key != 6) { ralf::set_error("gemm: gather=1 needs A and B k-contiguous"); return RALF_ERR_INVALID; }
+        return launch_cfg<T, true, true, 1>(P, nbatch, st);
+    }
+    if (d.gather == 2) {
+        if (key != 0) { ralf::set_error("gemm: gather=2 needs A and B row-contiguous"); return RALF_ERR_INVALID; }
+        return launch_cfg<T, false, false, 2>(P, nbatch, st);
+    }
+    switch (key) {
+        case 6: return launch_cfg<T, true, true, 0>(P, nbatch, st);
+        case 4: return launch_cfg<T, true, false, 0>(P, nbatch, st);
+        case 0: return launch_cfg<T, false, false, 0>(P, nbatch, st);
+        default: return launch_cfg<T, false, true, 0>(P, nbatch, st);
+    }
+}
+
+
+}  // namespace
+
+// one translation unit per element type (parallel builds): gemm_f32.hip / gemm_bf16.hip define these
+int ralf_gemm_dispatch_f32(void* kparams, int nbatch, hipStream_t st);
+int ralf_gemm_dispatch_bf16(void* kparams, int nbatch, hipStream_t st);
+int ralf_gemm_reduce_f32(void* kparams, int nbatch, int blocks, hipStream_t st);
+int ralf_gemm_reduce_bf16(void* kparams, int nbatch, int blocks, hipStream_t st);
