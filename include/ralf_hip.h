@@ -152,6 +152,12 @@ int ralf_maxpool3x3s2_bwd(int dtype, const void* dy, const int8_t* arg, void* dx
 int ralf_upsample_nearest_add(int dtype, const void* src, const void* lateral, void* up, int64_t ld_up, void* sum, int B, int IH, int IW, int OH, int OW, int C, void* stream);
 int ralf_upsample_nearest_bwd(int dtype, const void* g_up, int64_t ld_up, const void* g_sum, void* dsrc, int B, int IH, int IW, int OH, int OW, int C, void* stream);
 
+/* decode step tail (retrieval_augmented_autoreg.py:282-296; helpers/sampling.py:18-71): vocabulary mask of the
+ * position (tokenizer.token_mask[i]), forced token from DECODE_SPACE_RESTRICTION (-1 = free), then argmax
+ * (mode 0) or top-k multinomial with temperature (mode 1, counter-based RNG).  logits fp32 [B,V], V <= 1024. */
+int ralf_mask_sample(const float* logits, const uint8_t* allowed, const int64_t* forced, int mode, int top_k, float temperature,
+                     const int64_t* seed, uint64_t call_id, int64_t* out, int B, int V, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused attention (ralf_amd/csrc/attention.hip): O = dropout(softmax(scale*Q K^T + mask)) V.
  * Operands are [B, S, H*dh]-style views: element (b, s, h, c) at base + b*bs + s*rs + h*dh + c.

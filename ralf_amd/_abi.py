@@ -70,6 +70,7 @@ SIGNATURES.update({
     "ralf_maxpool3x3s2_bwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ralf_upsample_nearest_add": (i32, [i32, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ralf_upsample_nearest_bwd": (i32, [i32, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ralf_mask_sample": (i32, [vp, vp, vp, i32, i32, f32, vp, u64, vp, i32, i32, vp]),
     "ralf_attention_fwd": (i32, [ctypes.POINTER(RalfAttnDesc), vp]),
     "ralf_attention_bwd": (i32, [ctypes.POINTER(RalfAttnDesc), vp]),
     "ralf_sumsq": (i32, [vp, i64, vp, vp]),

@@ -265,6 +265,82 @@ __global__ void upsample_bwd_kernel(const T* __restrict__ g1, int64_t ld1, const
     }
 }
 
+// per-row decode-space mask + token choice (one wave per row of fp32 logits [B,V]):
+//   allowed[c] == 0 -> -inf (tokenizer.token_mask row);  forced[b] >= 0 -> that token is the only candidate
+//   mode 0: argmax (first maximum);  mode 1: keep logits >= k-th largest, softmax(x/T), one multinomial draw
+//   with the counter-based generator (inverse CDF in lane-major order).
+__global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ allowed,
+                                                           const int64_t* __restrict__ forced, int mode, int top_k, float temperature,
+                                                           const int64_t* __restrict__ seed, uint64_t call, int64_t* __restrict__ out, int B, int V) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float NEG = -__builtin_inff();
+    const int64_t f = forced ? forced[row] : -1;
+    if (f >= 0) { if (lane == 0) out[row] = f; return; }
+    const float* x = logits + (int64_t)row * V;
+    constexpr int MAXPER = 16;  // V <= 1024
+    float v[MAXPER];
+    float best = NEG;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < MAXPER; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = (c < V && (!allowed || allowed[c])) ? x[c] : NEG;
+        if (v[i] > best) { best = v[i]; bi = c; }
+    }
+    // wave arg-max with lowest-index tie break
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (mode == 0 || top_k <= 1) { if (lane == 0) out[row] = bi; return; }
+    // k-th largest value: peel the maximum k-1 times (ties are removed one at a time)
+    float kth = best;
+    {
+        float w[MAXPER];
+#pragma unroll
+        for (int i = 0; i < MAXPER; ++i) w[i] = v[i];
+        int wi = bi;
+        for (int r = 1; r < top_k; ++r) {
+#pragma unroll
+            for (int i = 0; i < MAXPER; ++i) if (lane + 64 * i == wi) w[i] = NEG;
+            float b2 = NEG; int i2 = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < MAXPER; ++i) if (w[i] > b2) { b2 = w[i]; i2 = lane + 64 * i; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(b2, o);
+                const int oi = __shfl_xor(i2, o);
+                if (ob > b2 || (ob == b2 && oi < i2)) { b2 = ob; i2 = oi; }
+            }
+            if (b2 == NEG) break;
+            kth = b2; wi = i2;
+        }
+    }
+    const float invT = 1.f / temperature;
+    float p[MAXPER], ls = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXPER; ++i) { p[i] = v[i] >= kth && v[i] > NEG ? __expf((v[i] - best) * invT) : 0.f; ls += p[i]; }
+    // exclusive scan of the lane sums (lane-major CDF)
+    float inc = ls;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    const float total = __shfl(inc, 63);
+    const float u = (rng24((uint64_t)seed[0], call, (uint64_t)row) + 0.5f) * (1.f / 16777216.f) * total;
+    float acc = inc - ls;
+    int pick = -1;
+#pragma unroll
+    for (int i = 0; i < MAXPER; ++i) { if (pick < 0 && p[i] > 0.f && acc + p[i] >= u) pick = lane + 64 * i; acc += p[i]; }
+    // the first lane whose range contains u owns the draw
+    const bool mine = (u > inc - ls) && (u <= inc) && pick >= 0;
+    const unsigned long long ball = __ballot(mine);
+    const int owner = ball ? __ffsll((long long)ball) - 1 : -1;
+    const int res = owner >= 0 ? __shfl(pick, owner) : bi;
+    if (lane == 0) out[row] = res;
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, ...)                                            \
@@ -352,4 +428,15 @@ extern "C" int ralf_upsample_nearest_bwd(int dtype, const void* g_up, int64_t ld
     RALF_REQUIRE(g_up && g_sum && dsrc, "upsample_bwd: null pointer");
     DISPATCH_T(dtype, hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3(grid_for((int64_t)B * IH * IW * C)), dim3(256), 0, ST, (const T*)g_up, ld_up, (const T*)g_sum, (T*)dsrc, B, IH, IW, OH, OW, C));
     return ralf::check_launch("upsample_bwd");
+}
+
+/* decode-space restriction + sampling on the device (helpers/sampling.py:18-71, decoding_space_restriction.py):
+ * logits fp32 [B,V] (V <= 1024), allowed uint8 [V] or NULL, forced int64 [B] or NULL (-1 = free),
+ * mode 0 deterministic (argmax), 1 top-k multinomial with temperature; out int64 [B] */
+extern "C" int ralf_mask_sample(const float* logits, const uint8_t* allowed, const int64_t* forced, int mode, int top_k, float temperature,
+                                const int64_t* seed, uint64_t call_id, int64_t* out, int B, int V, void* stream) {
+    RALF_REQUIRE(logits && out && B > 0 && V > 0 && V <= 1024, "mask_sample: bad arguments (V <= 1024)");
+    RALF_REQUIRE(mode == 0 || (mode == 1 && seed && top_k >= 1 && temperature > 0.f), "mask_sample: top-k sampling needs a seed, k >= 1, T > 0");
+    hipLaunchKernelGGL(mask_sample_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, logits, allowed, forced, mode, top_k, temperature, seed, call_id, out, B, V);
+    return ralf::check_launch("mask_sample");
 }

@@ -104,7 +104,8 @@ def _copy_tree(dst, src):
         dst.copy_(src, non_blocking=True)
     elif isinstance(dst, dict):
         for k in dst:
-            _copy_tree(dst[k], src[k])
+            if dst[k] is not None:
+                _copy_tree(dst[k], src[k])
 
 
 class TrainStep:
@@ -178,3 +179,32 @@ class TrainStep:
         with torch.cuda.graph(gb, pool=ga.pool()):
             self._update()
         self._graphs = (ga, gb)
+
+
+class GraphedDecode:
+    """hipGraph replay of model.decode_tokens (encoder + the whole KV-cached autoregressive loop + fused
+    mask/sample kernels): the eager loop is host-launch bound (~5k launches per batch)."""
+
+    def __init__(self, model, cond_type: str, sampling_cfg, use_kv_cache: bool = True):
+        self.model, self.cond_type, self.cfg, self.kv = model, cond_type, sampling_cfg, use_kv_cache
+        self._graph = None
+        self._static = None
+        self._out = None
+
+    def __call__(self, enc_in: dict, cond_seq):
+        if self._graph is None:
+            self._static = _clone_tree({"enc": enc_in, "seq": cond_seq})
+            s = self._static
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.model.decode_tokens(s["enc"], s["seq"], self.cond_type, self.cfg, self.kv)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._out = self.model.decode_tokens(s["enc"], s["seq"], self.cond_type, self.cfg, self.kv)
+        else:
+            _copy_tree(self._static, {"enc": enc_in, "seq": cond_seq})
+        self._graph.replay()
+        return self._out

@@ -91,3 +91,18 @@ DECODE_SPACE_RESTRICTION = {
     "c": restrict_reliable_label_or_size, "cwh": restrict_reliable_label_or_size,
     "refinement": restrict_only_category, "relation": restrict_only_category,
 }
+
+
+def forced_tokens(step: int, cond: torch.Tensor, cond_type: str, pad_id: int, eos_id: int, max_length: int):
+    """DECODE_SPACE_RESTRICTION expressed as one forced token per sample (-1 = unconstrained) for the fused
+    on-device mask+sample kernel; equivalent to restrict_* above (which mask every other logit)."""
+    if cond_type in ("none", "uncond", "partial", None) or cond is None:
+        return None
+    if cond_type in ("refinement", "relation") and (step - 1) % 5 != 0:
+        return None
+    assert cond.size(1) == max_length + 1
+    given = cond[:, step]
+    before = step < _first_pad(cond, pad_id)
+    free = before & ((given == pad_id) | (given == -1))
+    forced = torch.where(before, given, torch.full_like(given, eos_id))
+    return torch.where(free, torch.full_like(given, -1), forced).contiguous()

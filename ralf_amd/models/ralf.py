@@ -21,7 +21,7 @@ import torch.nn as nn
 from .. import functional as RF
 from .. import nn as RN
 from ..functional import Runtime
-from ..helpers.sampling import DECODE_SPACE_RESTRICTION, sample as sample_tokens
+from ..helpers.sampling import DECODE_SPACE_RESTRICTION, _get, forced_tokens, sample as sample_tokens
 from ..helpers.task import COND_TYPES, get_condition
 from ..helpers.task_preprocessor import PREPROCESSOR
 
@@ -192,10 +192,60 @@ class _GeneratorBase(nn.Module):
         loss = RF.XentFn.apply(outputs["logits"], targets["seq"], self.tokenizer.name_to_id("pad"), 0.1, self.rt)
         return outputs, {"nll_loss": loss}
 
-    # ---- autoregressive sampling (full-prefix recompute like the reference; KV cache = next round) ----
+    # ---- autoregressive sampling: KV-cached decode (default) or the reference's full-prefix recompute ----
+    @torch.no_grad()
+    def decode_tokens(self, enc_in: dict, cond_seq, cond_type: str, sampling_cfg, use_kv_cache: bool = True) -> torch.Tensor:
+        """device part of sample(): encoder inputs (device tensors) -> generated token ids [B, 5N] (device).
+        No host synchronisation inside, so the whole loop can be captured into a hipGraph (engine.GraphedDecode)."""
+        dev = enc_in["image"].device
+        B = enc_in["image"].size(0)
+        ids = self.special_token_ids
+        token_mask = self._token_mask_dev(dev)
+        token_mask_u8 = self._token_mask_u8
+        self.rt.to(dev).begin_step()
+        memory = self._encode_into_memory(enc_in)["memory"]
+        seq = torch.full((B, 1), ids["bos"], dtype=torch.long, device=dev)
+        start = 0
+        if cond_type == "partial":
+            seq = torch.cat([seq, cond_seq[:, 1:6]], dim=1)
+            start = 5
+        restrict = DECODE_SPACE_RESTRICTION[cond_type]
+        T = self.tokenizer.max_token_length
+        name = _get(sampling_cfg, "name")
+        cache = None
+        if use_kv_cache:  # O(S) decoder work per sample instead of the reference's O(S^2) prefix recompute
+            cache = RN.decoder_init_cache(self.decoder, memory, self.rt, T)
+            for j in range(start):  # prefix given by the condition (partial): fill the cache
+                RN.decoder_step(self.decoder, seq[:, j].contiguous(), j, cache, self.rt, (seq[:, :j + 1] == ids["pad"]).to(torch.uint8).contiguous())
+        for i in range(start, T):
+            if cache is not None:
+                logits = RN.decoder_step(self.decoder, seq[:, i].contiguous(), i, cache, self.rt, (seq == ids["pad"]).to(torch.uint8).contiguous())
+            else:
+                logits = self.decoder(seq, memory, self.rt, seq == ids["pad"])[:, i].clone()
+            if name in ("deterministic", "top_k"):   # vocabulary mask + restriction + choice fused in one kernel
+                forced = forced_tokens(i + 1, cond_seq, cond_type, ids["pad"], ids["eos"], T)
+                nxt = RN.ops.mask_sample(logits.float(), token_mask_u8[i], forced, 0 if name == "deterministic" else 1,
+                                         int(_get(sampling_cfg, "top_k", 1) or 1), float(_get(sampling_cfg, "temperature", 1.0) or 1.0),
+                                         self.rt.seed, 1000 + i)
+                seq = torch.cat([seq, nxt.view(B, 1)], dim=1)
+                continue
+            logits[:, ~token_mask[i]] = NEG_INF
+            logits = restrict(i + 1, cond_seq, logits, pad_id=ids["pad"], eos_id=ids["eos"], max_length=T)
+            seq = torch.cat([seq, sample_tokens(logits, sampling_cfg)], dim=1)
+        self.rt.advance_seed()   # on-device: the next call (or graph replay) draws different samples
+        return seq[:, 1:]
+
+    def _token_mask_dev(self, dev):
+        if getattr(self, "_token_mask_cache", None) is None or self._token_mask_cache.device != dev:
+            self._token_mask_cache = self.tokenizer.token_mask.to(dev)
+            self._token_mask_u8 = self._token_mask_cache.to(torch.uint8).contiguous()
+        return self._token_mask_cache
+
     @torch.no_grad()
     def sample(self, cond, batch_size: Optional[int] = None, sampling_cfg=None, cond_type: Optional[str] = "uncond",
-               return_violation: bool = False, use_backtrack: bool = True, return_decoded_cond: bool = False, **kwargs):
+               return_violation: bool = False, use_backtrack: bool = True, return_decoded_cond: bool = False,
+               use_kv_cache: bool = True, decoder=None, **kwargs):
+        """`decoder`: optional engine.GraphedDecode that replays the captured device loop."""
         if self.use_multitask:
             self.set_task_preprocessor(cond.task)
         if cond_type == "relation":
@@ -205,25 +255,15 @@ class _GeneratorBase(nn.Module):
         if B == 1 and batch_size and batch_size > 1:
             B = batch_size
             cond.image = cond.image.expand(B, -1, -1, -1).contiguous()
-        ids = self.special_token_ids
-        token_mask = self.tokenizer.token_mask.to(dev)
         enc_in, _ = self._create_encoder_inputs(cond)
-        enc_in = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in enc_in.items()}
-        self.rt.to(dev).begin_step()
-        memory = self._encode_into_memory(enc_in)["memory"]
-        seq = torch.full((B, 1), ids["bos"], dtype=torch.long, device=dev)
-        start = 0
-        if cond_type == "partial":
-            seq = torch.cat([seq, cond.seq[:, 1:6].to(dev)], dim=1)
-            start = 5
+        enc_in = {k: ({kk: vv.to(dev) for kk, vv in v.items() if torch.is_tensor(vv)} if isinstance(v, dict) else (v.to(dev) if torch.is_tensor(v) else v))
+                  for k, v in enc_in.items()}
         cond_seq = cond.seq.to(dev) if cond.seq is not None else None
-        restrict = DECODE_SPACE_RESTRICTION[cond_type]
-        for i in range(start, self.tokenizer.max_token_length):
-            logits = self.decoder(seq, memory, self.rt, seq == ids["pad"])[:, i].clone()
-            logits[:, ~token_mask[i]] = NEG_INF
-            logits = restrict(i + 1, cond_seq, logits, pad_id=ids["pad"], eos_id=ids["eos"], max_length=self.tokenizer.max_token_length)
-            seq = torch.cat([seq, sample_tokens(logits, sampling_cfg)], dim=1)
-        out_tokens = seq[:, 1:].cpu()
+        if decoder is not None:
+            tokens = decoder(enc_in, cond_seq)
+        else:
+            tokens = self.decode_tokens(enc_in, cond_seq, cond_type, sampling_cfg, use_kv_cache)
+        out_tokens = tokens.cpu()
         result = self.postprocess({"seq": out_tokens})
         if not return_violation:
             return result

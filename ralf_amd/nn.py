@@ -196,6 +196,59 @@ class BaseDecoder(nn.Module):
         return RF.linear(h, self.head[1].weight, rt=rt, out_f32=True)
 
 
+class DecodeCache:
+    """per-layer state of the KV-cached decoder: cross-attention K/V of the fixed memory (computed once) and the
+    growing self-attention K/V of the generated prefix."""
+
+    def __init__(self, cross_kv, self_kv, max_len):
+        self.cross_kv, self.self_kv, self.max_len = cross_kv, self_kv, max_len
+
+
+@torch.no_grad()
+def decoder_init_cache(dec: "BaseDecoder", memory: torch.Tensor, rt: Runtime, max_len: int) -> DecodeCache:
+    B, M, d = memory.shape
+    cross, selfkv = [], []
+    mem2 = memory.reshape(B * M, d).contiguous()
+    for layer in dec.transformer.layers:
+        a = layer.multihead_attn
+        kv = ops.gemm(mem2, rt.lp(a.in_proj_weight)[d:], B * M, 2 * d, d, bias=a.in_proj_bias.detach()[d:])
+        cross.append(kv.view(B, M, 2 * d))
+        selfkv.append(torch.zeros(B, max_len, 2 * d, dtype=rt.dtype, device=memory.device))
+    return DecodeCache(cross, selfkv, max_len)
+
+
+@torch.no_grad()
+def decoder_step(dec: "BaseDecoder", tok: torch.Tensor, pos: int, cache: DecodeCache, rt: Runtime, kpm_prefix: torch.Tensor) -> torch.Tensor:
+    """one KV-cached decode step: token ids [B] at position `pos` -> fp32 logits [B, V].  kpm_prefix uint8
+    [B, pos+1] marks padded prefix tokens (tgt_key_padding_mask of the reference's full-prefix call,
+    retrieval_augmented_autoreg.py:274-279).  Same arithmetic as BaseDecoder.forward restricted to the last row."""
+    B = tok.shape[0]
+    d, H = dec.d_model, dec.transformer.layers[0].self_attn.nhead
+    dh = d // H
+    x = ops.embed_fwd(tok.view(B, 1).contiguous(), dec.emb.weight.detach(), dec.pos_emb.pe[0, pos:pos + 1].contiguous(), 1, math.sqrt(d), rt.dtype).view(B, d)
+    L = cache.max_len
+    for li, layer in enumerate(dec.transformer.layers):
+        sa, ca = layer.self_attn, layer.multihead_attn
+        h, _, _ = ops.layernorm_fwd(x, layer.norm1.weight.detach(), layer.norm1.bias.detach(), save_stats=False)
+        W, bvec = rt.lp(sa.in_proj_weight), sa.in_proj_bias.detach()
+        q = ops.gemm(h, W[:d], B, d, d, bias=bvec[:d])
+        skv = cache.self_kv[li]
+        # k,v of the new token go straight into row `pos` of the cache (row stride = L*2d)
+        ops.gemm(h, W[d:], B, 2 * d, d, bias=bvec[d:], out=skv.view(B, L * 2 * d)[:, pos * 2 * d:], ldc=L * 2 * d)
+        o, _ = ops.attention_fwd(q.view(B, 1, d), skv, skv, B, H, 1, pos + 1, dh, 0, 0, d, causal=False, kpm=kpm_prefix, need_lse=False, kv_rows=L)
+        x = ops.gemm(o.view(B, d), rt.lp(sa.out_proj.weight), B, d, d, bias=sa.out_proj.bias.detach(), res=x)
+        h, _, _ = ops.layernorm_fwd(x, layer.norm2.weight.detach(), layer.norm2.bias.detach(), save_stats=False)
+        q = ops.gemm(h, rt.lp(ca.in_proj_weight)[:d], B, d, d, bias=ca.in_proj_bias.detach()[:d])
+        ckv = cache.cross_kv[li]
+        o, _ = ops.attention_fwd(q.view(B, 1, d), ckv, ckv, B, H, 1, ckv.shape[1], dh, 0, 0, d, need_lse=False)
+        x = ops.gemm(o.view(B, d), rt.lp(ca.out_proj.weight), B, d, d, bias=ca.out_proj.bias.detach(), res=x)
+        h, _, _ = ops.layernorm_fwd(x, layer.norm3.weight.detach(), layer.norm3.bias.detach(), save_stats=False)
+        f = ops.gemm(h, rt.lp(layer.linear1.weight), B, layer.linear1.weight.shape[0], d, bias=layer.linear1.bias.detach(), act="relu")
+        x = ops.gemm(f, rt.lp(layer.linear2.weight), B, d, f.shape[1], bias=layer.linear2.bias.detach(), res=x)
+    h, _, _ = ops.layernorm_fwd(x, dec.head[0].weight.detach(), dec.head[0].bias.detach(), save_stats=False)
+    return ops.gemm(h, rt.lp(dec.head[1].weight), B, dec.head[1].weight.shape[0], d, out_dtype=torch.float32)
+
+
 class UserConstraintTransformerEncoder(nn.Module):
     def __init__(self, d_model: int, nhead: int, num_layers: int, d_label: int, dim_feedforward: int):
         super().__init__()

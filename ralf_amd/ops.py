@@ -253,7 +253,7 @@ def bn_backward(x2d, dy, y, gamma, mean, rstd, relu, want_dres, training=True, i
     return dx, s[1], s[0], dres  # dx, dgamma, dbeta, dres
 
 
-def _attn_desc(q, k, v, o, B, H, Sq, Sk, dh, q_off, k_off, v_off, causal, kpm, scale, p_drop, seed, call_id):
+def _attn_desc(q, k, v, o, B, H, Sq, Sk, dh, q_off, k_off, v_off, causal, kpm, scale, p_drop, seed, call_id, kv_rows=None):
     d = RalfAttnDesc()
     es = q.element_size()
 
@@ -262,8 +262,9 @@ def _attn_desc(q, k, v, o, B, H, Sq, Sk, dh, q_off, k_off, v_off, causal, kpm, s
 
     d.q, d.k, d.v, d.o = base(q, q_off), base(k, k_off), base(v, v_off), _p(o)
     d.q_rs, d.q_bs = q.shape[-1], q.shape[-1] * Sq
-    d.k_rs, d.k_bs = k.shape[-1], k.shape[-1] * Sk
-    d.v_rs, d.v_bs = v.shape[-1], v.shape[-1] * Sk
+    kvr = kv_rows if kv_rows is not None else Sk   # rows allocated per batch entry (a KV cache is longer than Sk)
+    d.k_rs, d.k_bs = k.shape[-1], k.shape[-1] * kvr
+    d.v_rs, d.v_bs = v.shape[-1], v.shape[-1] * kvr
     d.o_rs, d.o_bs = o.shape[-1], o.shape[-1] * Sq
     d.B, d.H, d.Sq, d.Sk, d.dh, d.dtype, d.causal = B, H, Sq, Sk, dh, dtype_code(q), int(causal)
     d.kpm, d.seed, d.call_id = _p(kpm), _p(seed), call_id
@@ -271,13 +272,15 @@ def _attn_desc(q, k, v, o, B, H, Sq, Sk, dh, q_off, k_off, v_off, causal, kpm, s
     return d
 
 
-def attention_fwd(q, k, v, B, H, Sq, Sk, dh, q_off=0, k_off=0, v_off=0, causal=False, kpm=None, scale=None, p_drop=0.0, seed=None, call_id=0, need_lse=True):
+def attention_fwd(q, k, v, B, H, Sq, Sk, dh, q_off=0, k_off=0, v_off=0, causal=False, kpm=None, scale=None, p_drop=0.0, seed=None, call_id=0, need_lse=True,
+                  kv_rows=None, kpm_stride=None):
     """q/k/v: contiguous [B,S,width] tensors (possibly the same packed buffer); head h of q lives at
     column q_off + h*dh.  Returns O [B,Sq,H*dh] and lse [B,H,Sq]."""
     o = torch.empty(B, Sq, H * dh, dtype=q.dtype, device=q.device)
     lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device) if need_lse else None
-    d = _attn_desc(q, k, v, o, B, H, Sq, Sk, dh, q_off, k_off, v_off, causal, kpm, scale if scale is not None else dh ** -0.5, p_drop, seed, call_id)
+    d = _attn_desc(q, k, v, o, B, H, Sq, Sk, dh, q_off, k_off, v_off, causal, kpm, scale if scale is not None else dh ** -0.5, p_drop, seed, call_id, kv_rows)
     d.lse = _p(lse)
+    assert kpm_stride is None or kpm_stride == Sk, "key-padding mask rows must be Sk long"
     _call("ralf_attention_fwd", ctypes.byref(d))
     return o, lse
 
@@ -308,3 +311,11 @@ def clip_coef(sumsq_t, max_norm, coef, norm_out=None):
 
 def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, coef=None, shadow=None, step_dev=None):
     _call("ralf_adamw", _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr, beta1, beta2, eps, wd, step, _p(coef), _p(step_dev))
+
+
+def mask_sample(logits, allowed=None, forced=None, mode=0, top_k=1, temperature=1.0, seed=None, call_id=0):
+    """decode-space mask + token choice on the device -> int64 [B]."""
+    B, V = logits.shape
+    out = torch.empty(B, dtype=torch.int64, device=logits.device)
+    _call("ralf_mask_sample", _p(logits.contiguous()), _p(allowed), _p(forced), mode, top_k, temperature, _p(seed), call_id, _p(out), B, V)
+    return out

@@ -212,11 +212,15 @@ def test_deterministic_sample_matches_reference(golden, task):
     # feed the exact constraint sequence the reference produced (element shuffling is RNG-dependent)
     model._create_encoder_inputs = lambda c: ({"image": c.image, "retrieved": c.retrieved, "seq_layout_const": r["seq_layout_const"],
                                                "seq_layout_const_pad_mask": r["seq_layout_const_pad_mask"]}, None)
-    out = model.sample(cond=cond, sampling_cfg={"name": "deterministic"}, cond_type=task, return_violation=False)
-    for k in ("label", "mask"):
-        assert torch.equal(out[k], r["result"][k]), k
-    for k in ("center_x", "center_y", "width", "height"):
-        assert torch.equal(out[k], r["result"][k]), k  # identical tokens -> identical bin centres
+    from ralf_amd.engine import GraphedDecode
+
+    graphed = GraphedDecode(model, task, {"name": "deterministic"})
+    for kv, dec in ((True, None), (False, None), (True, graphed), (True, graphed)):   # KV cache, full-prefix recompute, graph capture + replay
+        out = model.sample(cond=cond, sampling_cfg={"name": "deterministic"}, cond_type=task, return_violation=False, use_kv_cache=kv, decoder=dec)
+        for k in ("label", "mask"):
+            assert torch.equal(out[k], r["result"][k]), (k, kv)
+        for k in ("center_x", "center_y", "width", "height"):
+            assert torch.equal(out[k], r["result"][k]), (k, kv)  # identical tokens -> identical bin centres
 
 
 def test_train_mode_dropout_step_is_finite_and_seeded(golden):

@@ -238,3 +238,33 @@ def test_adamw_and_clip():
             ops.adamw(pd, gs.cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step, coef, shadow)
         torch.testing.assert_close(pd.cpu(), p_ref.detach(), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(shadow.float().cpu(), pd.cpu(), rtol=1e-2, atol=1e-2)
+
+
+def test_mask_sample():
+    from ralf_amd import ops
+
+    g = torch.Generator().manual_seed(60)
+    B, V = 300, 518
+    logits = torch.randn(B, V, generator=g) * 3
+    allowed = torch.rand(V, generator=g) > 0.3
+    forced = torch.full((B,), -1, dtype=torch.int64); forced[::7] = 517; forced[3] = 5
+    ref = logits.masked_fill(~allowed, float("-inf")).argmax(1)
+    ref = torch.where(forced >= 0, forced, ref)
+    out = ops.mask_sample(logits.cuda(), allowed.to(torch.uint8).cuda(), forced.cuda(), mode=0)
+    assert torch.equal(out.cpu(), ref)
+    # ties -> first maximum, like torch.argmax
+    t = torch.zeros(4, V); t[:, 100] = 1.0; t[:, 300] = 1.0
+    assert ops.mask_sample(t.cuda()).tolist() == [100] * 4
+    # top-k multinomial: draws stay inside the top-k set and follow softmax(x/T) of it
+    seed = torch.tensor([7], dtype=torch.int64, device="cuda")
+    row = torch.randn(V, generator=g)
+    x = row.repeat(20000, 1).cuda()
+    draws = ops.mask_sample(x, allowed.to(torch.uint8).cuda(), None, mode=1, top_k=5, temperature=0.7, seed=seed, call_id=3).cpu()
+    masked = row.masked_fill(~allowed, float("-inf"))
+    top = masked.topk(5)
+    assert set(draws.tolist()) <= set(top.indices.tolist())
+    want = torch.softmax(top.values / 0.7, 0)
+    got = torch.stack([(draws == i).float().mean() for i in top.indices])
+    assert (got - want).abs().max() < 0.015, (got, want)
+    d2 = ops.mask_sample(x, allowed.to(torch.uint8).cuda(), None, mode=1, top_k=5, temperature=0.7, seed=seed, call_id=3).cpu()
+    assert torch.equal(draws, d2)   # counter-based: same seed/call -> same draws

@@ -1,0 +1,39 @@
+"""Constrained decode benchmark (BASELINE config 5): B = 256, tasks c / cwh, deterministic and top-k sampling."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import bench  # noqa: E402
+from ralf_amd.helpers.task import get_condition  # noqa: E402
+from ralf_amd.synthetic import make_batch  # noqa: E402
+
+
+def main(B=256, N=10):
+    dev = torch.device("cuda")
+    for dtype in ("bfloat16",):
+        for task in ("c", "cwh"):
+            model = bench.build_model(dev, N, dtype, task).eval()
+            batch = make_batch(B, N, seed=9)
+            cond, _ = get_condition(batch, task, model.tokenizer)
+            cond.retrieved = {k: v for k, v in cond.retrieved.items() if k != "image"}
+            for name, cfg in (("deterministic", {"name": "deterministic"}), ("top_k5", {"name": "top_k", "top_k": 5, "temperature": 1.0})):
+                from ralf_amd.engine import GraphedDecode
+                for kv, graph in ((True, True), (True, False), (False, False)):
+                    torch.manual_seed(0)
+                    dec = GraphedDecode(model, task, cfg, kv) if graph else None
+                    for _ in range(2):
+                        model.sample(cond=cond, sampling_cfg=cfg, cond_type=task, use_kv_cache=kv, decoder=dec)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    reps = 3
+                    for _ in range(reps):
+                        out = model.sample(cond=cond, sampling_cfg=cfg, cond_type=task, use_kv_cache=kv, decoder=dec)
+                    torch.cuda.synchronize()
+                    t = (time.perf_counter() - t0) / reps
+                    print(f"{dtype} task={task:3s} sampling={name:13s} kv_cache={kv!s:5s} graph={graph!s:5s}: {t*1e3:8.1f} ms/batch  {t/B*1e3:6.3f} ms/sample  {B*5*N/t:9.0f} tokens/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
