@@ -1,1 +1,3 @@
 from .knn import FlatIPIndex, knn_topk_ip  # noqa: F401
+from .reranker import maximal_marginal_relevance, reranker_random, reranker_top_k  # noqa: F401
+from .retriever import RetrievalDatasetWrapper, Retriever, coarse_saliency, load_cache_table, table_path  # noqa: F401

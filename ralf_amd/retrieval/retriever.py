@@ -1,0 +1,126 @@
+"""Retrieval-table pipeline on the HBM-resident exact index.
+
+Mirrors image2layout/train/models/retrieval/retriever.py:33-229 (`Retriever`, `preprocess_retrieval_cache`),
+image2layout/train/helpers/retrieval_dataset_wrapper.py:17-148 (`load_cache_table`, `RetrievalDatasetWrapper`)
+and retrieval/image.py:35-44 (`coarse_saliency`): same constructor arguments, same cache file names and the
+same on-disk format (`torch.save` of a plain dict data_id -> list[db index]), so tables written here are read by
+the reference's wrapper and vice versa.  Differences, all on purpose:
+  * the scan is ONE batched ralf_knn_topk_ip call per split instead of one faiss call per query;
+  * the image embedders (DreamSim / CLIP / VGG) are third-party models and stay outside: embeddings come from a
+    `feature_fn(example) -> vector` callback or a precomputed array; only the 16x16 saliency feature is built in;
+  * the dataset wrapper does not materialise the K retrieved IMAGES unless asked (they are unused when
+    use_reference_image=False, yet the reference decodes and ships ~1 GB of them per step).
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .knn import FlatIPIndex
+
+LAYOUT_KEYS = ["center_x", "center_y", "width", "height", "label", "mask"]
+
+
+def coarse_saliency(saliency: torch.Tensor, size=(16, 16)) -> np.ndarray:
+    """[1,H,W] saliency in [0,1] -> 256-d vector in [-1,1] (nearest down-sampling, retrieval/image.py:35-44)."""
+    h = F.interpolate(saliency.reshape(1, 1, *saliency.shape[-2:]).float(), size=size).flatten()
+    return (2 * torch.clamp(h, 0.0, 1.0) - 1.0).numpy()
+
+
+def _pad(values: Sequence, n: int):
+    fill = False if isinstance(values[0], bool) else (0 if isinstance(values[0], int) else 0.0)
+    return list(values) + [fill] * (n - len(values))
+
+
+def table_path(dataset_name: str, split: str, backbone: str, top_k: int, cache_dir: str = "cache") -> str:
+    return os.path.join(cache_dir, f"{dataset_name}_{split}_{backbone}_wo_head_table_between_dataset_indexes_top_k{top_k}.pt")
+
+
+def load_cache_table(cache_path: str, top_k: int) -> dict:
+    table = torch.load(cache_path)
+    return {k: v[:top_k] for k, v in table.items()}
+
+
+class Retriever:
+    def __init__(self, features=None, db_dataset=None, max_seq_length: int = 10, top_k: int = 1, dataset_name: str = "pku",
+                 retrieval_backbone: str = "saliency", saliency_k=None, feature_fn: Optional[Callable] = None,
+                 db_vectors: Optional[np.ndarray] = None, cache_dir: str = "cache", device: str = "cuda", **kwargs):
+        self.features, self.db_dataset = features, db_dataset
+        self.max_seq_length, self.top_k = max_seq_length, top_k
+        self.dataset_name, self.retrieval_backbone = dataset_name, retrieval_backbone
+        self.cache_dir, self.device = cache_dir, device
+        self.index_name = "search_feat"
+        if retrieval_backbone == "saliency" and feature_fn is None:
+            feature_fn = lambda ex: coarse_saliency(torch.as_tensor(ex["saliency"]))  # noqa: E731
+        self.feature_fn = feature_fn
+        if db_vectors is None:
+            assert feature_fn is not None, "pass feature_fn (image -> embedding) or db_vectors for non-saliency backbones"
+            db_vectors = np.stack([np.asarray(feature_fn(db_dataset[i]), np.float32) for i in range(len(db_dataset))])
+        self.index = FlatIPIndex(np.ascontiguousarray(db_vectors, np.float32), device=device)
+        self.table_paired_id_idx = {self._id(db_dataset[i]["id"]): i for i in range(len(db_dataset))}
+
+    def _id(self, data_id):
+        return int(data_id) if "pku" in self.dataset_name else data_id
+
+    def search(self, queries: np.ndarray, k: int):
+        scores, idx = self.index.search(np.ascontiguousarray(queries, np.float32), k)
+        return scores.cpu().numpy(), idx.cpu().numpy()
+
+    def preprocess_retrieval_cache(self, split: str, dataset, top_k: int, run_on_local: bool = True, save_scores: bool = False,
+                                   queries: Optional[np.ndarray] = None) -> dict:
+        """top-(k+1) search of every sample of `dataset` against the train-split index; on the train split the
+        rank-0 hit (the sample itself) is dropped (retriever.py:211-213).  Writes the reference's table file."""
+        if queries is None:
+            queries = np.stack([np.asarray(self.feature_fn(dataset[i]), np.float32) for i in range(len(dataset))])
+        scores, idx = self.search(queries, top_k + 1)
+        lo = 1 if split == "train" else 0
+        table, score_table = {}, {}
+        for i in range(len(dataset)):
+            data_id = self._id(dataset[i]["id"])
+            table[data_id] = [int(j) for j in idx[i, lo:]]
+            score_table[data_id] = scores[i, lo:]
+        os.makedirs(self.cache_dir, exist_ok=True)
+        path = table_path(self.dataset_name, split, self.retrieval_backbone, top_k, self.cache_dir)
+        torch.save(table, path)
+        if save_scores:
+            torch.save(score_table, path.replace("indexes", "scores"))
+        return table
+
+
+class RetrievalDatasetWrapper(torch.utils.data.Dataset):
+    """table lookup -> K exemplar layouts per sample, padded to max_seq_length ([K, N] fields)."""
+
+    def __init__(self, dataset_name: str, dataset, db_dataset, split: str, top_k: int, max_seq_length: int, retrieval_backbone: str,
+                 random_retrieval: bool = False, saliency_k=None, num_cache_indexes_per_sample: int = 32, cache_dir: str = "cache",
+                 with_images: bool = False, **_):
+        self.dataset_name, self.dataset, self.db_dataset = dataset_name, dataset, db_dataset
+        self.top_k, self.max_seq_length, self.with_images = top_k, max_seq_length, with_images
+        self.table_idx = load_cache_table(table_path(dataset_name, split, retrieval_backbone, num_cache_indexes_per_sample, cache_dir), top_k)
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __getitem__(self, index: int) -> dict:
+        data = dict(self.dataset[index])
+        data_id = int(data["id"]) if "pku" in self.dataset_name else data["id"]
+        hits = self.table_idx[data_id]
+        assert len(hits) == self.top_k, f"{len(hits)=} != {self.top_k=}"
+        rows = [self.db_dataset[j] for j in hits]
+        N = self.max_seq_length
+        retrieved = {"index": hits}
+        for key in LAYOUT_KEYS:
+            if key == "mask":
+                retrieved[key] = torch.tensor([_pad([True] * len(r["label"]), N) for r in rows])
+            else:
+                retrieved[key] = torch.tensor([_pad(list(r[key]), N) for r in rows])
+        if self.with_images:
+            for key in ("image", "saliency"):
+                retrieved[key] = torch.stack([torch.as_tensor(r[key]) for r in rows])
+        else:  # 1x1 placeholder keeps the 4-channel assertion of preprocess(); pixels are unused (use_reference_image=False)
+            retrieved["image"] = torch.zeros(self.top_k, 4, 1, 1)
+        data["retrieved"] = [retrieved]
+        return data

@@ -392,8 +392,26 @@ def golden_sample():
     save("sample.npz", out)
 
 
+def golden_reranker():
+    """MMR / top-k re-ranking known answers from the reference implementation (pure NumPy)."""
+    from image2layout.train.models.retrieval import reranker as RR
+
+    rng = np.random.default_rng(5)
+    out = {}
+    for i, (n, k, lam, st) in enumerate([(64, 16, 0.5, "similarity"), (128, 16, 0.9, "similarity"), (40, 8, 0.3, "distance"), (20, 20, 1.0, "similarity"), (33, 5, 0.0, "distance")]):
+        q = rng.standard_normal(n)
+        f = rng.standard_normal((n, 12))
+        f /= np.linalg.norm(f, axis=1, keepdims=True)
+        pair = f @ f.T if st == "similarity" else np.linalg.norm(f[:, None] - f[None], axis=-1)
+        out[f"case{i}"] = {"q": q, "pair": pair, "mmr": RR.maximal_marginal_relevance(q, pair, lam, k, st), "topk": RR.reranker_top_k(q, k, st),
+                           "cfg": np.array([n, k, lam, 1.0 if st == "similarity" else 0.0])}
+    save("reranker.npz", out)
+
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tokenizer", "host", "modules", "e2e", "sample"]
-    fns = {"tokenizer": golden_tokenizer, "host": golden_host_path, "modules": golden_modules, "e2e": golden_e2e, "sample": golden_sample}
+    which = sys.argv[1:] or ["tokenizer", "host", "modules", "e2e", "sample", "reranker"]
+    fns = {"tokenizer": golden_tokenizer, "host": golden_host_path, "modules": golden_modules, "e2e": golden_e2e, "sample": golden_sample,
+           "reranker": golden_reranker}
     for w in which:
         fns[w]()
