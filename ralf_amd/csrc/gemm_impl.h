@@ -526,6 +526,9 @@ int launch_epi(KParams& P, int nbatch, hipStream_t st) {
 template <typename T, bool AK, bool BKC, int GATHER>
 int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
     const RalfGemmDesc& d = P.d;
+    static const int forced = [] { const char* e = getenv("RALF_GEMM_TILE"); return e ? atoi(e) : 0; }();  // tuning aid: 22 / 11
+    if (forced == 22) return launch_epi<T, AK, BKC, GATHER, 2, 2>(P, nbatch, st);
+    if (forced == 11) return launch_epi<T, AK, BKC, GATHER, 1, 1>(P, nbatch, st);
     const int64_t big = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) * d.splitk * nbatch;
     const int kspan = ceil_div(d.K, d.splitk);
     if (d.N > 64 && d.M > 64 && kspan >= 1024 && big >= 512) return launch_epi<T, AK, BKC, GATHER, 2, 2>(P, nbatch, st);
