@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 # algorithmic FLOPs per sample of one train step (2 x MAC; 3 x trainable forward + frozen forward)
 STEP_GFLOP_PER_SAMPLE = {10: 50.1, 32: 56.4}
+ENCDEC_GFLOP_PER_SAMPLE = {10: 15.98, 32: 22.29}   # everything except ResNet-50 + FPN
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 KNN_TRAFFIC_BYTES = 446.2e6  # HBM bytes per knn_scores launch at nq=16: rocprofv3 FETCH_SIZE x2 (gfx950) + WRITE_SIZE, profiles/r01_knn_pmc.txt
@@ -37,6 +38,34 @@ def build_model(device, N=10, dtype="bfloat16", task="uncond"):
     model = RALF(features={"label": LabelFeature(labels)}, tokenizer=tok, dataset_name="pku", max_seq_length=N, db_dataset=None, top_k=16,
                  retrieval_backbone="dreamsim", random_retrieval=False, saliency_k="None", auxilary_task=task, compute_dtype=dtype)
     return model.to(device).train()
+
+
+class _BackboneStandIn(torch.nn.Module):
+    """fixed [B, hw, d] feature sequence in place of ResNet-50/FPN: times the encoder-decoder part of the
+    step alone (the 40 % MFMA target is quoted on encoder-decoder FLOPs / encoder-decoder time)."""
+
+    def __init__(self, B, hw, d, device, dtype):
+        super().__init__()
+        g = torch.Generator(device=device).manual_seed(5)
+        self.seq = torch.randn(B, hw, d, device=device, generator=g).to(dtype)
+
+    def forward(self, img, rt):
+        return self.seq
+
+
+def bench_encdec(device, N, B, dtype, steps, use_graph=True):
+    from ralf_amd.engine import TrainStep
+    from ralf_amd.synthetic import make_batch, to_device
+
+    model = build_model(device, N, dtype)
+    model.encoder = _BackboneStandIn(B, 256, 256, device, model.rt.dtype)
+    inputs, targets = model.preprocess(make_batch(B, N, seed=1))
+    inputs, targets = to_device(inputs, device), to_device(targets, device)
+    inputs["retrieved"] = {k: v for k, v in inputs["retrieved"].items() if k != "image"}
+    step = TrainStep(model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, use_graph=use_graph)
+    t = _time_gpu(lambda: step(inputs, targets), iters=steps, warm=3)
+    del step, model
+    return t
 
 
 def _time_gpu(fn, iters=20, warm=3):
@@ -145,6 +174,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-knn", action="store_true")
+    ap.add_argument("--skip-split", action="store_true", help="skip the encoder-decoder-only timing")
     a = ap.parse_args()
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
@@ -207,6 +237,16 @@ def main():
                          "frac": flops / (gpu_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
                          "note": f"whole train step: {flops / 1e12:.3f} algorithmic TFLOP per launch (SURVEY 8d: {STEP_GFLOP_PER_SAMPLE.get(N, 50.1)} GFLOP/sample x {B}) / {gpu_ms:.2f} ms (HIP events); per-kernel split in profiles/"},
         }
+        if world == 1 and not a.skip_split:
+            t_ed = bench_encdec(device, N, B, a.dtype, a.steps, not a.no_graph)
+            f_ed = ENCDEC_GFLOP_PER_SAMPLE.get(N, 15.98) * 1e9 * B
+            f_bb = flops - f_ed
+            t_bb = max(gpu_ms * 1e-3 - t_ed, 1e-9)
+            out["roofline_split"] = {
+                "encoder_decoder": {"ms": t_ed * 1e3, "TFLOP": f_ed / 1e12, "achieved": f_ed / t_ed / 1e12, "frac": f_ed / t_ed / 1e12 / PEAK_BF16_TFLOPS},
+                "resnet50_fpn": {"ms": t_bb * 1e3, "TFLOP": f_bb / 1e12, "achieved": f_bb / t_bb / 1e12, "frac": f_bb / t_bb / 1e12 / PEAK_BF16_TFLOPS},
+                "unit": "TFLOP/s", "peak": PEAK_BF16_TFLOPS,
+                "note": "encoder_decoder = the same train step with the backbone replaced by a fixed feature sequence (its own graph, clip and AdamW included); resnet50_fpn = whole step minus that"}
         if world == 1 and not a.skip_knn:
             out["knn"] = bench_knn(device)
             k16 = out["knn"]["nq16"]

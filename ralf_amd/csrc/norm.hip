@@ -63,13 +63,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     }
 }
 
-// dx per row + per-workgroup partial dgamma/dbeta (registers -> LDS -> one fp32 atomic per column)
-template <typename T, int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
+// dx per row + per-workgroup partial dgamma/dbeta (registers -> LDS -> one fp32 atomic per column).
+// 16 waves per workgroup, two rows in flight per wave: the kernel is latency-bound otherwise (a wave
+// walking 16 rows one after the other reached 1.2 TB/s), and fat workgroups keep the atomic count at
+// 2*cols per CU.
+template <typename T, int NCH, int LNB_WAVES>
+__global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, const T* __restrict__ skip, int rows) {
     constexpr int cols = NCH * 256;
-    __shared__ float red[2][4][cols];
+    __shared__ float red[2][LNB_WAVES][cols];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ag[NCH][4], ab[NCH][4], g[NCH][4];
 #pragma unroll
@@ -78,38 +81,54 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
         for (int i = 0; i < 4; ++i) ag[c][i] = ab[c][i] = 0.f;
     }
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
-        float d[NCH][4], xh[NCH][4];
-        float s1 = 0.f, s2 = 0.f;
+    for (int row0 = (blockIdx.x * LNB_WAVES + wave) * 2; row0 < rows; row0 += gridDim.x * LNB_WAVES * 2) {
+        const int nr = min(2, rows - row0);
+        float d[2][NCH][4], xh[2][NCH][4], sk[2][NCH][4], mu[2], rs[2];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            float xv[4];
-            V4<T>::load(dy + (int64_t)row * cols + c * 256 + lane * 4, d[c]);
-            V4<T>::load(x + (int64_t)row * cols + c * 256 + lane * 4, xv);
+        for (int r = 0; r < 2; ++r) {
+            const int row = row0 + (r < nr ? r : 0);   // an odd tail re-reads row0 (weight 0 below)
+            mu[r] = mean[row]; rs[r] = rstd[row];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xh[c][i] = (xv[i] - mu) * rs;
-                ag[c][i] += d[c][i] * xh[c][i];
-                ab[c][i] += d[c][i];
-                const float dg = d[c][i] * g[c][i];
-                s1 += dg; s2 += dg * xh[c][i];
+            for (int c = 0; c < NCH; ++c) {
+                V4<T>::load(dy + (int64_t)row * cols + c * 256 + lane * 4, d[r][c]);
+                V4<T>::load(x + (int64_t)row * cols + c * 256 + lane * 4, xh[r][c]);
+                if (skip) V4<T>::load(skip + (int64_t)row * cols + c * 256 + lane * 4, sk[r][c]);
             }
         }
-        s1 = wave_sum(s1) * (1.f / cols);
-        s2 = wave_sum(s2) * (1.f / cols);
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            float o[4];
+        for (int r = 0; r < 2; ++r) {
+            const float w = r < nr ? 1.f : 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = rs * (d[c][i] * g[c][i] - s1 - xh[c][i] * s2);
-            if (skip) {  // pre-norm residual: the skip branch's gradient joins here (no separate add kernel)
-                float sk[4];
-                V4<T>::load(skip + (int64_t)row * cols + c * 256 + lane * 4, sk);
+            for (int c = 0; c < NCH; ++c)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] += sk[i];
+                for (int i = 0; i < 4; ++i) {
+                    xh[r][c][i] = (xh[r][c][i] - mu[r]) * rs[r];
+                    ag[c][i] += w * d[r][c][i] * xh[r][c][i];
+                    ab[c][i] += w * d[r][c][i];
+                    const float dg = d[r][c][i] * g[c][i];
+                    s1[r] += dg; s2[r] += dg * xh[r][c][i];
+                }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s1[0] += __shfl_xor(s1[0], o); s2[0] += __shfl_xor(s2[0], o);
+            s1[1] += __shfl_xor(s1[1], o); s2[1] += __shfl_xor(s2[1], o);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (r >= nr) break;
+            const float m1 = s1[r] * (1.f / cols), m2 = s2[r] * (1.f / cols);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    o[i] = rs[r] * (d[r][c][i] * g[c][i] - m1 - xh[r][c][i] * m2);
+                    if (skip) o[i] += sk[r][c][i];   // pre-norm residual: the skip branch's gradient joins here (no separate add kernel)
+                }
+                V4<T>::store(dx + (int64_t)(row0 + r) * cols + c * 256 + lane * 4, o);
             }
-            V4<T>::store(dx + (int64_t)row * cols + c * 256 + lane * 4, o);
         }
     }
     if (dgamma) {
@@ -118,9 +137,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
             for (int i = 0; i < 4; ++i) { red[0][wave][c * 256 + lane * 4 + i] = ag[c][i]; red[1][wave][c * 256 + lane * 4 + i] = ab[c][i]; }
         __syncthreads();
-        for (int c = threadIdx.x; c < cols; c += 256) {
-            atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-            atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        for (int c = threadIdx.x; c < 2 * cols; c += LNB_WAVES * 64) {
+            const int which = c / cols, cc = c - which * cols;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < LNB_WAVES; ++w) t += red[which][w][cc];
+            atomicAdd((which ? dbeta : dgamma) + cc, t);
         }
     }
 }
@@ -128,6 +150,47 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 // ---------------------------------------------------------------------------------------------
 // column sums over rows of a [rows, cols] matrix (bias gradients): out[c] += sum_r x[r][c]
 // ---------------------------------------------------------------------------------------------
+// thread (tx, ty): 4 consecutive columns (8 / 16 B loads), rows ty, ty+RPI, ... of its row chunk; TPR = threads per row
+template <typename T, int TPR>
+__global__ __launch_bounds__(256) void colsum4_kernel(const T* __restrict__ x, int64_t ld, float* __restrict__ out, int rows, int cols, int rows_per_wg) {
+    constexpr int RPI = 256 / TPR;
+    __shared__ float red[RPI][TPR * 4];
+    const int tx = threadIdx.x % TPR, ty = threadIdx.x / TPR;
+    const int c = (blockIdx.x * TPR + tx) * 4;
+    const int r0 = blockIdx.y * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < cols) {
+        int r = r0 + ty;
+        for (; r + 3 * RPI < r1; r += 4 * RPI) {   // four independent loads in flight
+            float v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) V4<T>::load(x + (int64_t)(r + u * RPI) * ld + c, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i] += v[u][i];
+        }
+        for (; r < r1; r += RPI) {
+            float v[4];
+            V4<T>::load(x + (int64_t)r * ld + c, v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i] += v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[ty][tx * 4 + i] = s[i];
+    __syncthreads();
+    for (int j = threadIdx.x; j < TPR * 4; j += 256) {
+        const int cc = blockIdx.x * TPR * 4 + j;
+        if (cc < cols) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < RPI; ++w) t += red[w][j];
+            atomicAdd(out + cc, t);
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t ld, float* __restrict__ out, int rows, int cols, int rows_per_wg) {
     __shared__ float red[4][64];
@@ -364,11 +427,10 @@ extern "C" int ralf_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     RALF_REQUIRE(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
     RALF_REQUIRE(rows > 0 && cols % 256 == 0 && cols <= 512, "layernorm_bwd: cols=%d must be 256 or 512", cols);
     hipStream_t st = (hipStream_t)stream;
-    const int grid = grid_for(rows, 64, 1024);
     DISPATCH_T(dtype, if (cols == 256)
-                   hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, (const T*)skip, rows);
+                   hipLaunchKernelGGL((ln_bwd_kernel<T, 1, 16>), dim3(grid_for(rows, 32, 256)), dim3(1024), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, (const T*)skip, rows);
                else
-                   hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, (const T*)skip, rows););
+                   hipLaunchKernelGGL((ln_bwd_kernel<T, 2, 8>), dim3(grid_for(rows, 16, 512)), dim3(512), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, (const T*)skip, rows););
     return ralf::check_launch("layernorm_bwd");
 }
 
@@ -376,6 +438,23 @@ extern "C" int ralf_layernorm_bwd(int dtype, const void* dy, const void* x, cons
 extern "C" int ralf_colsum(int dtype, const void* x, int64_t ld, float* out, int rows, int cols, void* stream) {
     RALF_REQUIRE(x && out && rows > 0 && cols > 0, "colsum: bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    const int esz = dtype == RALF_F32 ? 4 : 2;
+    if (cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % (4 * esz)) == 0) {   // vector path: 4 columns per thread
+        const int c4 = cols / 4;
+        const int tpr = c4 >= 64 ? 64 : c4 >= 32 ? 32 : 16;
+        const int cb = ceil_div(c4, tpr), rpi = 256 / tpr;
+        int rchunks = 1024 / cb;
+        if (rchunks < 1) rchunks = 1;
+        int rpw = ceil_div(rows, rchunks);
+        if (rpw < rpi * 4) rpw = rpi * 4;
+        rchunks = ceil_div(rows, rpw);
+        DISPATCH_T(dtype, switch (tpr) {
+            case 64: hipLaunchKernelGGL((colsum4_kernel<T, 64>), dim3(cb, rchunks), dim3(256), 0, st, (const T*)x, ld, out, rows, cols, rpw); break;
+            case 32: hipLaunchKernelGGL((colsum4_kernel<T, 32>), dim3(cb, rchunks), dim3(256), 0, st, (const T*)x, ld, out, rows, cols, rpw); break;
+            default: hipLaunchKernelGGL((colsum4_kernel<T, 16>), dim3(cb, rchunks), dim3(256), 0, st, (const T*)x, ld, out, rows, cols, rpw); break;
+        });
+        return ralf::check_launch("colsum");
+    }
     const int cb = ceil_div(cols, 64);
     int rchunks = 1024 / cb;
     if (rchunks < 1) rchunks = 1;

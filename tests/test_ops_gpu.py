@@ -44,6 +44,36 @@ def test_layernorm(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,cols", [(1, 256), (33, 512), (2051, 256), (16384 + 3, 256)])
+def test_layernorm_bwd_shapes(dtype, rows, cols):
+    """odd row counts (two-rows-in-flight tail), the 512-wide variant, residual-skip addend, accumulation into dgamma/dbeta"""
+    from ralf_amd import ops
+
+    x = rnd(rows, cols, seed=11, dtype=dtype).float().requires_grad_(True)
+    g, b = (1 + 0.1 * rnd(cols, seed=12)).requires_grad_(True), rnd(cols, seed=13).requires_grad_(True)
+    go, sk = rnd(rows, cols, seed=14, dtype=dtype).float(), rnd(rows, cols, seed=15, dtype=dtype).float()
+    F.layer_norm(x, (cols,), g, b).backward(go)
+    _, mean, rstd = ops.layernorm_fwd(x.detach().to(dtype).cuda(), g.detach().cuda(), b.detach().cuda())
+    gg, gb = torch.ones(cols, device="cuda"), torch.full((cols,), 2.0, device="cuda")
+    dx, _, _ = ops.layernorm_bwd(go.to(dtype).cuda(), x.detach().to(dtype).cuda(), g.detach().cuda(), mean, rstd, need_wgrad=True, into=(gg, gb), skip=sk.to(dtype).cuda())
+    close(dx, x.grad + sk, dtype)
+    tol = dict(atol=0.5, rtol=2e-2) if dtype == torch.bfloat16 else dict(atol=2e-3, rtol=1e-4)
+    close(gg, g.grad + 1.0, torch.float32, **tol)
+    close(gb, b.grad + 2.0, torch.float32, **tol)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,cols,ld", [(1, 4, 4), (185, 256, 256), (3200, 518, 518), (16384, 768, 768), (5000, 256, 768), (777, 1024, 1024), (100, 30, 30)])
+def test_colsum_shapes(dtype, rows, cols, ld):
+    from ralf_amd import ops
+
+    x = rnd(rows, ld, seed=21, dtype=dtype)
+    out = torch.full((cols,), 3.0, device="cuda")
+    ops.colsum(x.cuda(), rows, cols, ld=ld, out=out)
+    close(out, x.float()[:, :cols].sum(0) + 3.0, torch.float32, atol=2e-2 if dtype == torch.bfloat16 else 2e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_embedding_scalar_xent(dtype):
     from ralf_amd import ops
 
