@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-knn", action="store_true")
     ap.add_argument("--skip-split", action="store_true", help="skip the encoder-decoder-only timing")
+    ap.add_argument("--no-overlap", action="store_true", help="parameter-gradient kernels on the main stream (no parallel graph branch)")
     a = ap.parse_args()
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
@@ -197,7 +198,7 @@ def main():
     inputs, targets = model.preprocess(batch)            # host path (tokenizer / constraint serialisation)
     inputs, targets = to_device(inputs, device), to_device(targets, device)
     inputs["retrieved"] = {k: v for k, v in inputs["retrieved"].items() if k != "image"}
-    step = TrainStep(model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, use_graph=not a.no_graph)
+    step = TrainStep(model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, use_graph=not a.no_graph, overlap_wgrad=not a.no_overlap)
 
     for _ in range(max(a.warmup, 1)):
         loss = step(inputs, targets)

@@ -112,12 +112,13 @@ class TrainStep:
     """One optimisation step of `model` (a ralf_amd generator) = forward + backward + (all-reduce) + clip + AdamW."""
 
     def __init__(self, model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, backbone_lr_scale=0.1, betas=(0.9, 0.999), eps=1e-8,
-                 use_graph=True, process_group=None):
+                 use_graph=True, process_group=None, overlap_wgrad=True):
         self.model = model
         rt = model.rt.to(model.device)
         groups = model.optim_groups(base_lr=lr, weight_decay=weight_decay, custom_lr={"encoder.extractor.body": lr * backbone_lr_scale})
         self.opt = FlatAdamW(groups, betas, eps, max_norm, shadow_dtype=rt.dtype if rt.dtype == torch.bfloat16 else None, runtime=rt)
         rt.direct_grads = True   # kernels accumulate parameter gradients straight into the flat buffer
+        rt.overlap = overlap_wgrad  # ... on a side stream: a parallel branch of the captured graph
         self.use_graph = use_graph
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if (process_group is not None or torch.distributed.is_initialized()) else 1
@@ -132,6 +133,7 @@ class TrainStep:
         _, losses = self.model.train_loss(inputs, targets)
         loss = losses["nll_loss"]
         loss.backward(torch.full_like(loss, 1.0 / self.world) if self.world > 1 else None)
+        self.model.rt.join_side()
         return loss.detach()
 
     def _allreduce(self):

@@ -8,6 +8,7 @@ device-resident dropout seed and a per-forward stream id counter for the counter
 from __future__ import annotations
 
 import math
+import os
 import weakref
 from typing import Optional
 
@@ -28,6 +29,10 @@ class Runtime:
         self._shadow: dict = {}   # id(param) -> persistent low-precision view kept current by the fused optimizer
         self.direct_grads = False  # engine mode: parameter gradients are accumulated by the kernels straight into p.grad
         self._wtoken = 0          # bumped when weights are rewritten behind torch's version counters
+        self.overlap = False      # engine mode: weight / bias gradient kernels run on a side stream, off the data-gradient chain
+        self._side: list = []
+        self.n_side = int(os.environ.get("RALF_SIDE_STREAMS", "1"))
+        self._keep: list = []     # operands of side-stream work in flight (kept alive until join_side)
 
     def to(self, device):
         if self.seed is None or self.seed.device != device:
@@ -53,6 +58,27 @@ class Runtime:
 
     def weights_changed(self):
         self._wtoken += 1
+
+    # parameter-gradient kernels (dW, db) feed nothing but the optimizer: with `overlap` they are issued on a second
+    # HIP stream (a parallel branch of the captured graph) so the many sub-256-workgroup launches of the
+    # data-gradient chain share the CUs with them.  All side work is serialised on ONE stream, so accumulations
+    # into the same gradient view keep their order.
+    def side(self, fn, target, *operands):
+        if not (self.overlap and self.direct_grads):
+            return fn()
+        if not self._side:
+            self._side = [torch.cuda.Stream() for _ in range(self.n_side)]
+        st = self._side[(target.data_ptr() >> 8) % len(self._side)]   # one gradient region -> always the same stream
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            fn()
+        self._keep.append(operands)
+
+    def join_side(self):
+        if self._side and self._keep:
+            for st in self._side:
+                torch.cuda.current_stream().wait_stream(st)
+            self._keep.clear()
 
     def gview(self, p: torch.Tensor):
         """flat-buffer gradient view of a parameter when the engine owns the gradients (kernels accumulate into it
@@ -99,21 +125,29 @@ def _splitk_for(out_rows: int, out_cols: int, red: int) -> int:
     return max(1, min(want, red // 1024))  # each split reduces >= 1024 rows
 
 
-def wgrad(dy2d, x2d, N, K, rows, into=None):
+def wgrad(dy2d, x2d, N, K, rows, into=None, rt=None):
     """dW[N,K] (fp32) = dy^T @ x, reduction over `rows` split across workgroups.  `into`: accumulate into this
     fp32 [N,K] view (flat gradient buffer) and return None."""
     if into is not None:
         # (fp32 atomics straight into the buffer -- atomic=True -- were measured SLOWER than slabs + reduce:
         #  ~19 G atomics/s in L2 vs millions of adds per weight gradient: 29.6 -> 36.9 ms/step)
-        ops.gemm(dy2d, x2d, N, K, rows, a_kcontig=False, b_kcontig=False, out=into.view(N, K), accumulate=True, splitk=_splitk_for(N, K, rows))
+        def run():
+            ops.gemm(dy2d, x2d, N, K, rows, a_kcontig=False, b_kcontig=False, out=into.view(N, K), accumulate=True, splitk=_splitk_for(N, K, rows))
+        if rt is not None:
+            rt.side(run, into, dy2d, x2d)
+        else:
+            run()
         return None
     return ops.gemm(dy2d, x2d, N, K, rows, a_kcontig=False, b_kcontig=False, out_dtype=torch.float32,
                     splitk=_splitk_for(N, K, rows))
 
 
-def bgrad(dy2d, rows, N, into=None):
+def bgrad(dy2d, rows, N, into=None, rt=None):
     if into is not None:
-        ops.colsum(dy2d, rows, N, out=into)
+        if rt is not None:
+            rt.side(lambda: ops.colsum(dy2d, rows, N, out=into), into, dy2d)
+        else:
+            ops.colsum(dy2d, rows, N, out=into)
         return None
     return ops.colsum(dy2d, rows, N)
 
@@ -156,14 +190,14 @@ class LinearFn(Function):
             dx = ops.gemm(dy2, rt.lp(W)[r0:r1], nrow, K, N, b_kcontig=False).view(ctx.xshape)
         if ctx.needs_input_grad[1]:
             gv = rt.gview(W)
-            dW = wgrad(dy2, x2, N, K, nrow, gv[r0:r1] if gv is not None else None)
+            dW = wgrad(dy2, x2, N, K, nrow, gv[r0:r1] if gv is not None else None, rt)
             if dW is not None and not full:  # place the block into a full-size gradient (plumbing copy)
                 g = torch.zeros(W.shape, dtype=torch.float32, device=dW.device)
                 g[r0:r1] = dW
                 dW = g
         if ctx.has_b and ctx.needs_input_grad[2]:
             gv = rt.gview(ctx.bias)
-            db = bgrad(dy2, nrow, N, gv[r0:r1] if gv is not None else None)
+            db = bgrad(dy2, nrow, N, gv[r0:r1] if gv is not None else None, rt)
             if db is not None and not full:
                 g = torch.zeros(W.shape[0], dtype=torch.float32, device=db.device)
                 g[r0:r1] = db
@@ -211,10 +245,10 @@ class FFNFn(Function):
             dz = ops.gemm(dy2, rt.lp(W2), rows, Hd, N, b_kcontig=False, aux=z, aux_mode="gelu_grad")
         else:  # relu (+ dropout): h > 0 <=> pre-activation > 0 and kept
             dz = ops.gemm(dy2, rt.lp(W2), rows, Hd, N, b_kcontig=False, aux=h, aux_mode="relu_mask", aux_scale=1.0 / (1.0 - ctx.p))
-        dW2 = wgrad(dy2, h, N, Hd, rows, rt.gview(W2))
-        db2 = bgrad(dy2, rows, N, rt.gview(ctx.b2))
-        dW1 = wgrad(dz, x2, Hd, K, rows, rt.gview(W1))
-        db1 = bgrad(dz, rows, Hd, rt.gview(ctx.b1))
+        dW2 = wgrad(dy2, h, N, Hd, rows, rt.gview(W2), rt)
+        db2 = bgrad(dy2, rows, N, rt.gview(ctx.b2), rt)
+        dW1 = wgrad(dz, x2, Hd, K, rows, rt.gview(W1), rt)
+        db1 = bgrad(dz, rows, Hd, rt.gview(ctx.b1), rt)
         dx = ops.gemm(dz, rt.lp(W1), rows, K, Hd, b_kcontig=False).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         return dx, dW1, db1, dW2, db2, (dy if ctx.has_res else None), None, None, None
 
@@ -430,19 +464,21 @@ class ConvFn(Function):
         if ctx.needs_input_grad[1]:
             gv = rt.gview(W)
             if one:
-                dW = wgrad(dy2, x.view(-1, C), Co, Ci, M, gv)
+                dW = wgrad(dy2, x.view(-1, C), Co, Ci, M, gv, rt)
                 dW = dW.view(Co, Ci, 1, 1) if dW is not None else None
             else:
                 geom = dict(RH=OH, RW=OW, SH=H, SW=Wd, SC=C, KH=kh, KW=kw, stride=stride, pad=pad, mode=0)
-                g = ops.gemm(dy2, x, Co, kh * kw * C, M, a_kcontig=False, b_kcontig=False, conv=geom, gather=2,
-                             out_dtype=torch.float32, splitk=_splitk_for(Co, kh * kw * C, M))
-                # fp32 [Co][kh][kw][Cpad] -> OIHW master layout (drops the stem's channel padding)
-                dW = ops.permute4(g, (Co, Ci, kh, kw), (kh * kw * C, 1, kw * C, C), kw, torch.float32)
-                if gv is not None:   # used once per step: place it (flat buffer was zeroed at step start)
-                    gv.copy_(dW)
-                    dW = None
+                def run(out=None):
+                    g = ops.gemm(dy2, x, Co, kh * kw * C, M, a_kcontig=False, b_kcontig=False, conv=geom, gather=2,
+                                 out_dtype=torch.float32, splitk=_splitk_for(Co, kh * kw * C, M))
+                    # fp32 [Co][kh][kw][Cpad] -> OIHW master layout (drops the stem's channel padding)
+                    return ops.permute4(g, (Co, Ci, kh, kw), (kh * kw * C, 1, kw * C, C), kw, torch.float32, out=out)
+                if gv is not None:   # used once per step: placed straight into the flat buffer (zeroed at step start)
+                    rt.side(lambda: run(gv), gv, dy2, x)
+                else:
+                    dW = run()
         if has_b and ctx.needs_input_grad[2]:
-            db = bgrad(dy2, M, Co, rt.gview(ctx.bias))
+            db = bgrad(dy2, M, Co, rt.gview(ctx.bias), rt)
         return dx, dW, db, None, None, None, None
 
 

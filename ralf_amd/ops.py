@@ -24,8 +24,8 @@ def dtype_code(t: torch.Tensor) -> int:
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """grow-only scratch buffer per device (stream-ordered reuse: all ops run on one stream)."""
-    key = (device.type, device.index)
+    """grow-only scratch buffer per (device, stream): reuse is ordered by the stream the kernels run on."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     w = _ws_cache.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -181,8 +181,10 @@ def cast(x, dtype):
     return y
 
 
-def permute4(x, out_dims, strides, valid3, dtype):
-    out = torch.empty(out_dims, dtype=dtype, device=x.device)
+def permute4(x, out_dims, strides, valid3, dtype, out=None):
+    if out is None:
+        out = torch.empty(out_dims, dtype=dtype, device=x.device)
+    assert out.is_contiguous() and tuple(out.shape) == tuple(out_dims) and out.dtype == dtype
     _call("ralf_permute4", dtype_code(x), _TORCH2CODE[dtype], _p(x), _p(out), *out_dims, *strides, valid3)
     return out
 
