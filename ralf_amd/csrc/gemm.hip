@@ -49,6 +49,13 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
     const int nbatch = d.nb0 * d.nb1;
     const int BK = d.dtype == RALF_F32 ? 32 : 64, VEC = d.dtype == RALF_F32 ? 4 : 8;
     if (d.gather) RALF_REQUIRE(d.g.SC % VEC == 0 && d.g.KH > 0 && d.g.KW > 0 && d.g.stride > 0, "gemm: gather needs channels %% %d == 0", VEC);
+    if (d.gather) {
+        RALF_REQUIRE((int64_t)(d.gather == 1 ? d.M : d.K) < (1ll << 31) && (int64_t)(d.gather == 1 ? d.K : d.N) < (1ll << 31), "gemm: gather index range");
+        P.fd_hw.set((uint32_t)(d.g.RH * d.g.RW)); P.fd_rw.set((uint32_t)d.g.RW); P.fd_sc.set((uint32_t)d.g.SC);
+        P.fd_kw.set((uint32_t)d.g.KW); P.fd_st.set((uint32_t)d.g.stride);
+    } else {
+        P.fd_hw.set(1); P.fd_rw.set(1); P.fd_sc.set(1); P.fd_kw.set(1); P.fd_st.set(1);
+    }
     const int ktiles = ceil_div(d.K, BK);
     if (d.splitk > ktiles) d.splitk = ktiles;
     P.kchunk = ceil_div(ktiles, d.splitk) * BK;

@@ -42,8 +42,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
 
+// division by a launch-time constant as multiply-high + shift (n < 2^31): the im2col gather decomposes a row
+// into (image, y, x) and a column into (kh, kw, c) for every staged vector of every k-tile -- with hardware-less
+// integer division that was ~190 VALU instructions per k-tile per wave (PMC: 48 VALU per MFMA on the 3x3 kernels).
+struct FastDiv {
+    uint32_t mul, shr, den;
+    __host__ void set(uint32_t d) {
+        den = d ? d : 1;
+        if (den == 1) { mul = 0; shr = 0; return; }
+        uint32_t lg = 0;
+        while ((1u << lg) < den) ++lg;
+        const uint32_t p = 31 + lg;
+        mul = (uint32_t)((((uint64_t)1 << p) + den - 1) / den);
+        shr = p - 32;
+    }
+    __device__ __forceinline__ uint32_t div(uint32_t n) const { return den == 1 ? n : (__umulhi(n, mul) >> shr); }
+    __device__ __forceinline__ void divmod(uint32_t n, int& q, int& r) const { const uint32_t t = div(n); q = (int)t; r = (int)(n - t * den); }
+};
+
 struct KParams {
     RalfGemmDesc d;
+    FastDiv fd_hw, fd_rw, fd_sc, fd_kw, fd_st;   // RH*RW, RW, SC, KW, stride of d.g
     int tiles_m, tiles_n, nwg;
     int kchunk;       // K range handled by one split (multiple of BK)
     float* partial;   // [split][batch][M][N] fp32 (splitk > 1)
@@ -205,13 +224,14 @@ __device__ __forceinline__ void epilogue_store4(const RalfGemmDesc& d, int z0, i
 struct RowInfo { int64_t base; int y0, x0; bool ok; };
 
 template <bool GATHER>
-__device__ __forceinline__ RowInfo row_info(const RalfConvGeom& g, int64_t row, int64_t nrows, int64_t ld) {
+__device__ __forceinline__ RowInfo row_info(const KParams& P, int64_t row, int64_t nrows, int64_t ld) {
+    const RalfConvGeom& g = P.d.g;
     RowInfo r;
     r.ok = row < nrows;
     if (!GATHER) { r.base = row * ld; r.y0 = r.x0 = 0; return r; }
-    const int hw = g.RH * g.RW;
-    const int b = (int)(row / hw), rem = (int)(row - (int64_t)b * hw);
-    const int ry = rem / g.RW, rx = rem - ry * g.RW;
+    int b, rem, ry, rx;
+    P.fd_hw.divmod((uint32_t)row, b, rem);
+    P.fd_rw.divmod((uint32_t)rem, ry, rx);
     r.base = (int64_t)b * g.SH * g.SW * g.SC;
     if (g.mode == 0) { r.y0 = ry * g.stride - g.pad; r.x0 = rx * g.stride - g.pad; }
     else             { r.y0 = ry + g.pad;            r.x0 = rx + g.pad; }
@@ -220,21 +240,26 @@ __device__ __forceinline__ RowInfo row_info(const RalfConvGeom& g, int64_t row, 
 
 // 16-byte vector of VEC elements at (row, col..col+VEC-1); zero outside the matrix / the padding
 template <typename T, bool GATHER>
-__device__ __forceinline__ uint4 load_vec(const T* __restrict__ p, const RalfConvGeom& g, const RowInfo& r, int col, int ncols, bool aligned) {
+__device__ __forceinline__ uint4 load_vec(const T* __restrict__ p, const KParams& P, const RowInfo& r, int col, int ncols, bool aligned) {
     constexpr int VEC = TT<T>::VEC;
+    const RalfConvGeom& g = P.d.g;
     uint4 z = make_uint4(0, 0, 0, 0);
     if (!r.ok || col >= ncols) return z;
     if (GATHER) {
-        const int c = col % g.SC, t = col / g.SC;  // SC % VEC == 0: a vector never straddles a tap
-        const int kw = t % g.KW, kh = t / g.KW;
+        int c, t, kw, kh;
+        P.fd_sc.divmod((uint32_t)col, t, c);  // SC % VEC == 0: a vector never straddles a tap
+        P.fd_kw.divmod((uint32_t)t, kh, kw);
         int sy, sx;
         if (g.mode == 0) { sy = r.y0 + kh; sx = r.x0 + kw; }
         else {
             const int ty = r.y0 - kh, tx = r.x0 - kw;
-            if (ty < 0 || tx < 0 || (ty % g.stride) || (tx % g.stride)) return z;
-            sy = ty / g.stride; sx = tx / g.stride;
+            if (ty < 0 || tx < 0) return z;
+            int ry, rx;
+            P.fd_st.divmod((uint32_t)ty, sy, ry);
+            P.fd_st.divmod((uint32_t)tx, sx, rx);
+            if (ry | rx) return z;
         }
-        if (sy < 0 || sy >= g.SH || sx < 0 || sx >= g.SW) return z;
+        if ((unsigned)sy >= (unsigned)g.SH || (unsigned)sx >= (unsigned)g.SW) return z;
         return *reinterpret_cast<const uint4*>(p + r.base + ((int64_t)sy * g.SW + sx) * g.SC + c);
     }
     const T* q = p + r.base + col;
@@ -302,11 +327,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
     }
     if (AK) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) ia[i] = row_info<GATHER == 1>(d.g, m0 + (tid + 256 * i) / KV, d.M, d.lda);
+        for (int i = 0; i < NVA; ++i) ia[i] = row_info<GATHER == 1>(P, m0 + (tid + 256 * i) / KV, d.M, d.lda);
     }
     if (BKC) {
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) ib[i] = row_info<false>(d.g, n0 + (tid + 256 * i) / KV, d.N, d.ldb);
+        for (int i = 0; i < NVB; ++i) ib[i] = row_info<false>(P, n0 + (tid + 256 * i) / KV, d.N, d.ldb);
     }
     auto gload = [&](int k0) {
         if (fast) {
@@ -319,19 +344,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             const int v = tid + 256 * i;
-            if (AK) ra[i] = load_vec<T, GATHER == 1>(Ap, d.g, ia[i], k0 + (v % KV) * VEC, kend, a_al);
+            if (AK) ra[i] = load_vec<T, GATHER == 1>(Ap, P, ia[i], k0 + (v % KV) * VEC, kend, a_al);
             else {
-                const RowInfo r = row_info<false>(d.g, k0 + v / RVA, kend, d.lda);
-                ra[i] = load_vec<T, false>(Ap, d.g, r, m0 + (v % RVA) * VEC, d.M, a_al);
+                const RowInfo r = row_info<false>(P, k0 + v / RVA, kend, d.lda);
+                ra[i] = load_vec<T, false>(Ap, P, r, m0 + (v % RVA) * VEC, d.M, a_al);
             }
         }
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
             const int v = tid + 256 * i;
-            if (BKC) rb[i] = load_vec<T, false>(Bp, d.g, ib[i], k0 + (v % KV) * VEC, kend, b_al);
+            if (BKC) rb[i] = load_vec<T, false>(Bp, P, ib[i], k0 + (v % KV) * VEC, kend, b_al);
             else {
-                const RowInfo r = row_info<GATHER == 2>(d.g, k0 + v / RVB, kend, d.ldb);
-                rb[i] = load_vec<T, GATHER == 2>(Bp, d.g, r, n0 + (v % RVB) * VEC, d.N, b_al);
+                const RowInfo r = row_info<GATHER == 2>(P, k0 + v / RVB, kend, d.ldb);
+                rb[i] = load_vec<T, GATHER == 2>(Bp, P, r, n0 + (v % RVB) * VEC, d.N, b_al);
             }
         }
     };
