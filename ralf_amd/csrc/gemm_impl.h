@@ -39,6 +39,7 @@ typedef __bf16 bf16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // 16-byte staging vector (a native vector: HIP's uint4 struct is copied with memcpy and can pin the staging arrays in scratch)
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
 
@@ -240,10 +241,10 @@ __device__ __forceinline__ RowInfo row_info(const KParams& P, int64_t row, int64
 
 // 16-byte vector of VEC elements at (row, col..col+VEC-1); zero outside the matrix / the padding
 template <typename T, bool GATHER>
-__device__ __forceinline__ uint4 load_vec(const T* __restrict__ p, const KParams& P, const RowInfo& r, int col, int ncols, bool aligned) {
+__device__ __forceinline__ u32x4 load_vec(const T* __restrict__ p, const KParams& P, const RowInfo& r, int col, int ncols, bool aligned) {
     constexpr int VEC = TT<T>::VEC;
     const RalfConvGeom& g = P.d.g;
-    uint4 z = make_uint4(0, 0, 0, 0);
+    const u32x4 z = {0u, 0u, 0u, 0u};
     if (!r.ok || col >= ncols) return z;
     if (GATHER) {
         int c, t, kw, kh;
@@ -260,14 +261,40 @@ __device__ __forceinline__ uint4 load_vec(const T* __restrict__ p, const KParams
             if (ry | rx) return z;
         }
         if ((unsigned)sy >= (unsigned)g.SH || (unsigned)sx >= (unsigned)g.SW) return z;
-        return *reinterpret_cast<const uint4*>(p + r.base + ((int64_t)sy * g.SW + sx) * g.SC + c);
+        return *reinterpret_cast<const u32x4*>(p + r.base + ((int64_t)sy * g.SW + sx) * g.SC + c);
     }
     const T* q = p + r.base + col;
-    if (aligned && col + VEC <= ncols) return *reinterpret_cast<const uint4*>(q);
+    if (aligned && col + VEC <= ncols) return *reinterpret_cast<const u32x4*>(q);
     T tmp[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) tmp[i] = (col + i < ncols) ? q[i] : (T)0.f;
-    return *reinterpret_cast<uint4*>(tmp);
+    return *reinterpret_cast<u32x4*>(tmp);
+}
+
+// staging registers -> LDS tile.  KC: [rows][LDK] (k-contiguous source), else [BK][LDR] (row-contiguous source)
+template <typename T, bool KC, int NV, int RV, int LDR>
+__device__ __forceinline__ void lds_stage(T* l, const u32x4 (&regs)[NV], int tid) {
+    using X = TT<T>;
+    constexpr int KV = X::BK / X::VEC;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + 256 * i;
+        if constexpr (KC) {
+            const int r = v / KV, kv = v % KV;
+            if constexpr (sizeof(T) == 4) {  // fp32: rotate each row so 32 rows x same k hit 32 banks
+                float* base = (float*)l + r * 32;
+                const float* s = reinterpret_cast<const float*>(&regs[i]);
+                const int rot = kv * 4 + r;
+                base[(rot + 0) & 31] = s[0]; base[(rot + 1) & 31] = s[1];
+                base[(rot + 2) & 31] = s[2]; base[(rot + 3) & 31] = s[3];
+            } else {
+                *reinterpret_cast<u32x4*>(l + r * X::LDK + kv * X::VEC) = regs[i];
+            }
+        } else {
+            const int kr = v / RV, c = v % RV;
+            *reinterpret_cast<u32x4*>(l + kr * LDR + c * X::VEC) = regs[i];
+        }
+    }
 }
 
 // AK: A is k-contiguous ([M][K]); else stored [K][M].   BKC: B is k-contiguous ([N][K]); else [K][N].
@@ -302,12 +329,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
     const bool a_al = (d.lda % VEC == 0) && (((uintptr_t)Ap & 15) == 0);
     const bool b_al = (d.ldb % VEC == 0) && (((uintptr_t)Bp & 15) == 0);
 
-    uint4 ra[NVA], rb[NVB];
+    u32x4 ra[NVA], rb[NVB];
     RowInfo ia[NVA], ib[NVB];
     // PMC (SQ_ACTIVE_INST_ANY ~ 84 % of the kernel, MFMA busy 10 %) showed this kernel is instruction-issue bound:
     // the interior fast path keeps one pointer per staging vector and advances it by a constant per k-tile.
     // Rows beyond M/N are clamped to the last valid row (their results are never stored).
-    const bool fast = GATHER == 0 && P.fast;
+    constexpr bool fast = GATHER == 3;   // compile-time: the general loaders (and their RowInfo registers) are not even compiled in
     const T* pa[NVA];
     const T* pb[NVB];
     const int64_t stepA = AK ? BK : (int64_t)BK * d.lda, stepB = BKC ? BK : (int64_t)BK * d.ldb;
@@ -325,22 +352,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
             else pb[i] = Bp + (int64_t)(kbeg + v / RVB) * d.ldb + min(n0 + (v % RVB) * VEC, d.N - VEC);
         }
     }
-    if (AK) {
+    if (AK && !fast) {
 #pragma unroll
         for (int i = 0; i < NVA; ++i) ia[i] = row_info<GATHER == 1>(P, m0 + (tid + 256 * i) / KV, d.M, d.lda);
     }
-    if (BKC) {
+    if (BKC && !fast) {
 #pragma unroll
         for (int i = 0; i < NVB; ++i) ib[i] = row_info<false>(P, n0 + (tid + 256 * i) / KV, d.N, d.ldb);
     }
     auto gload = [&](int k0) {
-        if (fast) {
+        if constexpr (fast) {
 #pragma unroll
-            for (int i = 0; i < NVA; ++i) { ra[i] = *reinterpret_cast<const uint4*>(pa[i]); pa[i] += stepA; }
+            for (int i = 0; i < NVA; ++i) { ra[i] = *reinterpret_cast<const u32x4*>(pa[i]); pa[i] += stepA; }
 #pragma unroll
-            for (int i = 0; i < NVB; ++i) { rb[i] = *reinterpret_cast<const uint4*>(pb[i]); pb[i] += stepB; }
-            return;
-        }
+            for (int i = 0; i < NVB; ++i) { rb[i] = *reinterpret_cast<const u32x4*>(pb[i]); pb[i] += stepB; }
+        } else {
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             const int v = tid + 256 * i;
@@ -359,31 +385,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
                 rb[i] = load_vec<T, GATHER == 2>(Bp, P, r, n0 + (v % RVB) * VEC, d.N, b_al);
             }
         }
-    };
-    auto lstore_one = [&](T* l, bool kc, const uint4* regs, int nv, int rv, int ldr) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i < nv) {
-            const int v = tid + 256 * i;
-            if (kc) {
-                const int r = v / KV, kv = v % KV;
-                if constexpr (sizeof(T) == 4) {  // fp32: rotate each row so 32 rows x same k hit 32 banks
-                    float* base = (float*)l + r * 32;
-                    const float* s = reinterpret_cast<const float*>(&regs[i]);
-                    const int rot = kv * 4 + r;
-                    base[(rot + 0) & 31] = s[0]; base[(rot + 1) & 31] = s[1];
-                    base[(rot + 2) & 31] = s[2]; base[(rot + 3) & 31] = s[3];
-                } else {
-                    *reinterpret_cast<uint4*>(l + r * X::LDK + kv * VEC) = regs[i];
-                }
-            } else {
-                const int kr = v / rv, c = v % rv;
-                *reinterpret_cast<uint4*>(l + kr * ldr + c * VEC) = regs[i];
-            }
-            }
         }
     };
-
     f32x16 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -397,12 +400,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
     const int trL = lane & 15, tr_rowblk = ((lane >> 4) & 1) * 16, tr_k = lh * 8 + (trL >> 2), tr_c = (trL & 3) * 4;
 
     gload(kbeg);
-    lstore_one(la, AK, ra, NVA, RVA, LDRA);
-    lstore_one(lb, BKC, rb, NVB, RVB, LDRB);
+    lds_stage<T, AK, NVA, RVA, LDRA>(la, ra, tid);
+    lds_stage<T, BKC, NVB, RVB, LDRB>(lb, rb, tid);
     __syncthreads();
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        const bool more = k0 + BK < kend;
-        if (more) gload(k0 + BK);
+    // one k-tile of MFMAs from the staged LDS tile
+    auto compute = [&]() {
         // the matrix core computes the TRANSPOSED tile: row operand = n-fragment (weights), column operand =
         // m-fragment, so accumulator register r of a lane holds (n = (r&3) + 8*(r>>2) + 4*(lane>>5), m = lane&31)
         if constexpr (sizeof(T) == 4) {
@@ -457,17 +459,40 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
                     for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
             }
         }
+    };
+    // branch-free steady state (the last k-tile is peeled): with an `if (more)` around the prefetch the compiler
+    // shuttled all accumulators AGPR -> VGPR -> AGPR every iteration (32 of the loop's 36 VALU instructions at 64x64)
+    for (int k0 = kbeg; k0 + BK < kend; k0 += BK) {
+        gload(k0 + BK);
+        compute();
         __syncthreads();
-        if (more) {
-            lstore_one(la, AK, ra, NVA, RVA, LDRA);
-            lstore_one(lb, BKC, rb, NVB, RVB, LDRB);
-            __syncthreads();
-        }
+        lds_stage<T, AK, NVA, RVA, LDRA>(la, ra, tid);
+        lds_stage<T, BKC, NVB, RVB, LDRB>(lb, rb, tid);
+        __syncthreads();
     }
+    compute();
 
     // ---- epilogue: lane holds 4 consecutive columns n per register group g = r>>2 ----
     // (no `continue`/`break` in these loops: they must unroll completely or the accumulators spill to scratch)
     const int nbatch = gridDim.z;
+    const bool slab = d.splitk > 1 && !d.atomic_out;
+    if (P.vec_epi && m0 + BM <= d.M && n0 + BN <= d.N) {   // interior tile (workgroup-uniform): no per-element bounds logic
+        float* pbase = slab ? P.partial + ((int64_t)split * nbatch + z) * d.M * d.N : nullptr;
+#pragma clang loop unroll(full)
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * 32 * FM + i * 32 + l31;
+#pragma clang loop unroll(full)
+            for (int j = 0; j < FN; ++j) {
+#pragma clang loop unroll(full)
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn * 32 * FN + j * 32 + 8 * g + 4 * lh;
+                    float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    if (slab) *reinterpret_cast<float4*>(pbase + (int64_t)m * d.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    else epilogue_store4<T, EPI>(d, z0, z1, m, n, v);
+                }
+            }
+        }
+    } else {
 #pragma clang loop unroll(full)
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * 32 * FM + i * 32 + l31;
@@ -478,7 +503,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
                 const int n = n0 + wn * 32 * FN + j * 32 + 8 * g + 4 * lh;
                 float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 if (m < d.M && n < d.N) {
-                    if (d.splitk > 1 && !d.atomic_out) {
+                    if (slab) {
                         float* pp = P.partial + (((int64_t)split * nbatch + z) * d.M + m) * d.N + n;
                         if (P.vec_epi && n + 3 < d.N) *reinterpret_cast<float4*>(pp) = make_float4(v[0], v[1], v[2], v[3]);
                         else {
@@ -496,6 +521,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
                 }
             }
         }
+    }
     }
 }
 
@@ -571,6 +597,16 @@ int dispatch(KParams& P, int nbatch, hipStream_t st) {
     if (d.gather == 2) {
         if (key != 0) { ralf::set_error("gemm: gather=2 needs A and B row-contiguous"); return RALF_ERR_INVALID; }
         return launch_cfg<T, false, false, 2>(P, nbatch, st);
+    }
+    if constexpr (sizeof(T) == 2) {   // bf16: the interior fast path is its own (leaner) set of kernels; fp32 is the parity mode
+        if (P.fast) {
+            switch (key) {
+                case 6: return launch_cfg<T, true, true, 3>(P, nbatch, st);
+                case 4: return launch_cfg<T, true, false, 3>(P, nbatch, st);
+                case 0: return launch_cfg<T, false, false, 3>(P, nbatch, st);
+                default: return launch_cfg<T, false, true, 3>(P, nbatch, st);
+            }
+        }
     }
     switch (key) {
         case 6: return launch_cfg<T, true, true, 0>(P, nbatch, st);
