@@ -168,55 +168,93 @@ __global__ void permute4_kernel(const TS* __restrict__ in, TD* __restrict__ out,
     }
 }
 
-// 3x3 stride-2 pad-1 max pooling, NHWC; arg = window position (kh*3+kw) of the FIRST maximum
+// 3x3 stride-2 pad-1 max pooling, NHWC; arg = window position (kh*3+kw) of the FIRST maximum.
+// One thread owns VEC consecutive channels of one pixel (16-byte accesses, 32-bit index math):
+// the scalar one-element-per-thread version ran at 1/8 of the HBM rate.
+template <typename T> struct PV;   // pooling vector: 16 bytes of channels
+template <> struct PV<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct PV<bf16> {
+    static constexpr int N = 8;
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ void load(const bf16* p, float (&v)[8]) { const bf16x8 t = *reinterpret_cast<const bf16x8*>(p); for (int i = 0; i < 8; ++i) v[i] = (float)t[i]; }
+    static __device__ __forceinline__ void store(bf16* p, const float (&v)[8]) { bf16x8 t; for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i]; *reinterpret_cast<bf16x8*>(p) = t; }
+};
+
 template <typename T>
-__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int8_t* __restrict__ arg, int B, int H, int W, int C, int OH, int OW) {
-    const int64_t total = (int64_t)B * OH * OW * C;
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int8_t* __restrict__ arg, int B, int H, int W, int C, int OH, int OW) {
+    constexpr int N = PV<T>::N;
+    const int cv = C / N;
+    const int64_t total = (int64_t)B * OH * OW * cv;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        int64_t t = e;
-        const int c = (int)(t % C); t /= C;
-        const int ow = (int)(t % OW); t /= OW;
-        const int oh = (int)(t % OH);
-        const int b = (int)(t / OH);
-        float best = -__builtin_inff();
-        int bi = -1;
+        const int c = (int)(e % cv) * N;
+        const int pix = (int)(e / cv);
+        const int ow = pix % OW, t = pix / OW, oh = t % OH, b = t / OH;
+        float best[N];
+        int8_t bi[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { best[i] = -__builtin_inff(); bi[i] = -1; }
+#pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int ih = oh * 2 - 1 + kh;
-            if (ih < 0 || ih >= H) continue;
+#pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int iw = ow * 2 - 1 + kw;
-                if (iw < 0 || iw >= W) continue;
-                const float v = ld(x, (((int64_t)b * H + ih) * W + iw) * C + c);
-                if (bi < 0 || v > best) { best = v; bi = kh * 3 + kw; }
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+                    float v[N];
+                    PV<T>::load(x + (((int64_t)b * H + ih) * W + iw) * C + c, v);
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+                        if (bi[i] < 0 || v[i] > best[i]) { best[i] = v[i]; bi[i] = (int8_t)(kh * 3 + kw); }
+                }
             }
         }
-        st(y, e, best);
-        arg[e] = (int8_t)bi;
+        const int64_t o = (int64_t)pix * C + c;
+        PV<T>::store(y + o, best);
+#pragma unroll
+        for (int i = 0; i < N; ++i) arg[o + i] = bi[i];
     }
 }
 template <typename T>
-__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const int8_t* __restrict__ arg, T* __restrict__ dx, int B, int H, int W, int C, int OH, int OW) {
-    const int64_t total = (int64_t)B * H * W * C;
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const int8_t* __restrict__ arg, T* __restrict__ dx, int B, int H, int W, int C, int OH, int OW) {
+    constexpr int N = PV<T>::N;
+    const int cv = C / N;
+    const int64_t total = (int64_t)B * H * W * cv;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        int64_t t = e;
-        const int c = (int)(t % C); t /= C;
-        const int iw = (int)(t % W); t /= W;
-        const int ih = (int)(t % H);
-        const int b = (int)(t / H);
-        float g = 0.f;
-        for (int oh = (ih - 1 + 1) / 2; oh <= (ih + 1) / 2; ++oh) {   // oh*2-1+kh == ih, kh in [0,2]
-            if (oh < 0 || oh >= OH) continue;
+        const int c = (int)(e % cv) * N;
+        const int pix = (int)(e / cv);
+        const int iw = pix % W, t = pix / W, ih = t % H, b = t / H;
+        float g[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) g[i] = 0.f;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) {          // windows with oh*2-1+kh == ih, kh in [0,2]: oh in {ih/2, (ih+1)/2}
+            const int oh = (ih + dh) / 2;
+            if (dh == 1 && oh == ih / 2) continue;
             const int kh = ih - (oh * 2 - 1);
-            if (kh < 0 || kh > 2) continue;
-            for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow) {
-                if (ow < 0 || ow >= OW) continue;
+            if (oh >= OH || kh < 0 || kh > 2) continue;
+#pragma unroll
+            for (int dw = 0; dw < 2; ++dw) {
+                const int ow = (iw + dw) / 2;
+                if (dw == 1 && ow == iw / 2) continue;
                 const int kw = iw - (ow * 2 - 1);
-                if (kw < 0 || kw > 2) continue;
+                if (ow >= OW || kw < 0 || kw > 2) continue;
                 const int64_t o = (((int64_t)b * OH + oh) * OW + ow) * C + c;
-                if (arg[o] == kh * 3 + kw) g += ld(dy, o);
+                float v[N];
+                PV<T>::load(dy + o, v);
+                int8_t a[N];
+                if constexpr (N == 8) *reinterpret_cast<uint2*>(a) = *reinterpret_cast<const uint2*>(arg + o);
+                else *reinterpret_cast<uint32_t*>(a) = *reinterpret_cast<const uint32_t*>(arg + o);
+                const int8_t want = (int8_t)(kh * 3 + kw);
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    if (a[i] == want) g[i] += v[i];
             }
         }
-        st(dx, e, g);
+        PV<T>::store(dx + (int64_t)pix * C + c, g);
     }
 }
 
@@ -408,15 +446,15 @@ extern "C" int ralf_permute4(int src_dtype, int dst_dtype, const void* in, void*
     return ralf::check_launch("permute4");
 }
 extern "C" int ralf_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int8_t* arg, int B, int H, int W, int C, void* stream) {
-    RALF_REQUIRE(x && y && arg && B > 0 && H > 0 && W > 0 && C > 0, "maxpool_fwd: bad arguments");
+    RALF_REQUIRE(x && y && arg && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "maxpool_fwd: bad arguments (C %% 8 == 0)");
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for((int64_t)B * OH * OW * C)), dim3(256), 0, ST, (const T*)x, (T*)y, arg, B, H, W, C, OH, OW));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for((int64_t)B * OH * OW * C / 4, 256, 1 << 20)), dim3(256), 0, ST, (const T*)x, (T*)y, arg, B, H, W, C, OH, OW));
     return ralf::check_launch("maxpool_fwd");
 }
 extern "C" int ralf_maxpool3x3s2_bwd(int dtype, const void* dy, const int8_t* arg, void* dx, int B, int H, int W, int C, void* stream) {
-    RALF_REQUIRE(dy && dx && arg && B > 0 && H > 0 && W > 0 && C > 0, "maxpool_bwd: bad arguments");
+    RALF_REQUIRE(dy && dx && arg && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "maxpool_bwd: bad arguments (C %% 8 == 0)");
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for((int64_t)B * H * W * C)), dim3(256), 0, ST, (const T*)dy, arg, (T*)dx, B, H, W, C, OH, OW));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for((int64_t)B * H * W * C / 4, 256, 1 << 20)), dim3(256), 0, ST, (const T*)dy, arg, (T*)dx, B, H, W, C, OH, OW));
     return ralf::check_launch("maxpool_bwd");
 }
 extern "C" int ralf_upsample_nearest_add(int dtype, const void* src, const void* lateral, void* up, int64_t ld_up, void* sum, int B, int IH, int IW, int OH, int OW, int C, void* stream) {

@@ -421,7 +421,10 @@ class ConvFn(Function):
     `pos` (optional, constant [OH*OW, Co]) is added to every image (fused positional table)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, stride, pad, pos, rt):
+    def forward(ctx, x, W, b, stride, pad, pos, rt, fork=False):
+        """fork: also return x itself as a second output (the residual / downsample branch consumes THAT alias);
+        its gradient comes back into this backward and is added in the data-gradient GEMM's epilogue instead of a
+        separate autograd accumulation pass over the block input."""
         B, H, Wd, C = x.shape
         Co, Ci, kh, kw = W.shape
         OH, OW = (H + 2 * pad - kh) // stride + 1, (Wd + 2 * pad - kw) // stride + 1
@@ -442,10 +445,13 @@ class ConvFn(Function):
         ctx.save_for_backward(x, W)
         ctx.bias = b
         ctx.cfg = (stride, pad, OH, OW, b is not None, rt)
+        ctx.fork = fork
+        if fork:
+            return y.view(B, OH, OW, Co), x
         return y.view(B, OH, OW, Co)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, W = ctx.saved_tensors
         stride, pad, OH, OW, has_b, rt = ctx.cfg
         B, H, Wd, C = x.shape
@@ -456,11 +462,12 @@ class ConvFn(Function):
         dx = dW = db = None
         one = kh == 1 and stride == 1
         if ctx.needs_input_grad[0]:
+            sk = dskip.contiguous().view(-1, C) if dskip is not None else None
             if one:
-                dx = ops.gemm(dy2, rt.lp(W).view(Co, Ci), M, Ci, Co, b_kcontig=False).view(B, H, Wd, C)
+                dx = ops.gemm(dy2, rt.lp(W).view(Co, Ci), M, Ci, Co, b_kcontig=False, res=sk).view(B, H, Wd, C)
             else:
                 geom = dict(RH=H, RW=Wd, SH=OH, SW=OW, SC=Co, KH=kh, KW=kw, stride=stride, pad=pad, mode=1)
-                dx = ops.gemm(dy, rt.lp(W, "ikwo"), B * H * Wd, C, kh * kw * Co, conv=geom, gather=1).view(B, H, Wd, C)
+                dx = ops.gemm(dy, rt.lp(W, "ikwo"), B * H * Wd, C, kh * kw * Co, conv=geom, gather=1, res=sk).view(B, H, Wd, C)
         if ctx.needs_input_grad[1]:
             gv = rt.gview(W)
             if one:
@@ -479,11 +486,11 @@ class ConvFn(Function):
                     dW = run()
         if has_b and ctx.needs_input_grad[2]:
             db = bgrad(dy2, M, Co, rt.gview(ctx.bias), rt)
-        return dx, dW, db, None, None, None, None
+        return dx, dW, db, None, None, None, None, None
 
 
-def conv2d(x, W, b, stride, pad, rt, pos=None):
-    return ConvFn.apply(x, W, b, stride, pad, pos, rt)
+def conv2d(x, W, b, stride, pad, rt, pos=None, fork=False):
+    return ConvFn.apply(x, W, b, stride, pad, pos, rt, fork)
 
 
 class BatchNormFn(Function):

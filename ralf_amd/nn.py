@@ -342,8 +342,8 @@ class Conv(nn.Module):
             self.register_parameter("bias", None)
         self.stride, self.pad = stride, pad
 
-    def forward(self, x, rt: Runtime, pos=None):
-        return RF.conv2d(x, self.weight, self.bias, self.stride, self.pad, rt, pos)
+    def forward(self, x, rt: Runtime, pos=None, fork=False):
+        return RF.conv2d(x, self.weight, self.bias, self.stride, self.pad, rt, pos, fork)
 
 
 class Bottleneck(nn.Module):
@@ -360,12 +360,12 @@ class Bottleneck(nn.Module):
             self.downsample = None
 
     def forward(self, x, rt: Runtime):
-        idn = x
-        y = self.bn1(self.conv1(x, rt), rt, True)
+        y, idn = self.conv1(x, rt, fork=True)   # idn aliases x: its gradient is summed inside conv1's data-gradient GEMM
+        y = self.bn1(y, rt, True)
         y = self.bn2(self.conv2(y, rt), rt, True)
         y = self.conv3(y, rt)
         if self.downsample is not None:
-            idn = self.downsample[1](self.downsample[0](x, rt), rt, False)
+            idn = self.downsample[1](self.downsample[0](idn, rt), rt, False)
         return self.bn3(y, rt, True, res=idn)
 
 
