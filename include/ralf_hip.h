@@ -122,6 +122,12 @@ int ralf_colsum(int dtype, const void* x, int64_t ld, float* out, int rows, int 
 int ralf_bn_stats(int dtype, const void* x, float* s1, float* s2, int64_t M, int C, float* workspace, void* stream);
 int ralf_bn_finalize(const float* s1, const float* s2, const float* gamma, const float* beta, float* running_mean, float* running_var,
                      float* mean, float* rstd, float* scale, float* shift, int64_t M, int C, float eps, float momentum, int training, void* stream);
+/* training-mode statistics in two launches (partial sums; reduce + finalize): replaces nn.BatchNorm2d's batch-stat path
+ * incl. the running_mean / running_var / num_batches_tracked updates (torch/nn/modules/batchnorm.py semantics, momentum 0.1);
+ * workspace as ralf_bn_stats; running_* and num_batches_tracked may be NULL */
+int ralf_bn_batch_stats(int dtype, const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, float* mean, float* rstd, float* scale, float* shift, int64_t M, int C,
+                        float eps, float momentum, float* workspace, void* stream);
 int ralf_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, int64_t M, int C, int relu, void* stream);
 int ralf_bn_bwd_reduce(int dtype, const void* x, const void* dy, const void* y, const float* mean, const float* rstd, float* s1, float* s2,
                        int64_t M, int C, int relu, float* workspace, void* stream);

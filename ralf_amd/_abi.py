@@ -55,6 +55,7 @@ SIGNATURES.update({
     "ralf_colsum": (i32, [i32, vp, i64, vp, i32, i32, vp]),
     "ralf_bn_stats": (i32, [i32, vp, vp, vp, i64, i32, vp, vp]),
     "ralf_bn_finalize": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp]),
+    "ralf_bn_batch_stats": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, vp, vp]),
     "ralf_bn_apply": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "ralf_bn_bwd_reduce": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]),
     "ralf_bn_bwd_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),

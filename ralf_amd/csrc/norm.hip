@@ -336,6 +336,41 @@ __global__ void bn_finalize_kernel(const float* __restrict__ s1, const float* __
     shift[c] = beta[c] - mu * gamma[c] * rs;
 }
 
+// training-mode statistics in one step after the partial sums: per-channel sum of the per-workgroup partials,
+// mean / rstd / scale / shift, running-stat update and the num_batches_tracked counter (one launch instead of
+// partial-sum + finalize + a host-issued counter increment, and no zero-fill of the sums)
+__global__ __launch_bounds__(256) void bn_partial_finalize_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                                   float* __restrict__ running_var, int64_t* __restrict__ counter,
+                                                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
+                                                                   float* __restrict__ shift, int64_t M, int C, float eps, float momentum) {
+    __shared__ float red[2][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float a = 0.f, b = 0.f;
+    if (c < C) {
+#pragma unroll 8
+        for (int i = ty; i < nblk; i += 4) { a += part[((int64_t)i * 2) * C + c]; b += part[((int64_t)i * 2 + 1) * C + c]; }
+    }
+    red[0][ty][tx] = a; red[1][ty][tx] = b;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        const float s1 = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
+        const float s2 = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+        const float mu = s1 / (float)M;
+        const float var = fmaxf(s2 / (float)M - mu * mu, 0.f);
+        if (running_mean) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * ((float)M / (float)(M > 1 ? M - 1 : 1));
+        }
+        const float rs = rsqrtf(var + eps);
+        mean[c] = mu; rstd[c] = rs;
+        scale[c] = gamma[c] * rs;
+        shift[c] = beta[c] - mu * gamma[c] * rs;
+    }
+    if (counter && blockIdx.x == 0 && threadIdx.x == 0) *counter += 1;
+}
+
 // y = relu?( x*scale + shift (+ res) )
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
@@ -494,6 +529,20 @@ extern "C" int ralf_bn_finalize(const float* s1, const float* s2, const float* g
     RALF_REQUIRE(training ? (s1 && s2) : (running_mean && running_var), "bn_finalize: missing statistics");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, s1, s2, gamma, beta, running_mean, running_var, mean, rstd, scale, shift, M, C, eps, momentum, training);
     return ralf::check_launch("bn_finalize");
+}
+
+/* training-mode forward statistics of x [M, C]: (mean, rstd, scale, shift) + running-stat update (+ counter += 1) */
+extern "C" int ralf_bn_batch_stats(int dtype, const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   int64_t* num_batches_tracked, float* mean, float* rstd, float* scale, float* shift, int64_t M, int C,
+                                   float eps, float momentum, float* workspace, void* stream) {
+    RALF_REQUIRE(x && gamma && beta && mean && rstd && scale && shift && workspace && M > 0, "bn_batch_stats: bad arguments");
+    int gx, gy;
+    RALF_REQUIRE(bn_reduce_geom(dtype, M, C, &gx, &gy) == 0, "bn_batch_stats: C=%d unsupported (needs C/vec a power of two <= 256 or a multiple of 256)", C);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, nullptr, nullptr, nullptr, nullptr, workspace, M, C, 0));
+    hipLaunchKernelGGL(bn_partial_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, workspace, gx, gamma, beta, running_mean, running_var,
+                       num_batches_tracked, mean, rstd, scale, shift, M, C, eps, momentum);
+    return ralf::check_launch("bn_batch_stats");
 }
 
 extern "C" int ralf_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, int64_t M, int C, int relu, void* stream) {

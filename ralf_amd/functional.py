@@ -497,10 +497,11 @@ class BatchNormFn(Function):
     """y = relu?(BN(x) (+ res)) on NHWC; batch statistics + running-stat update in training."""
 
     @staticmethod
-    def forward(ctx, x, g, b, rm, rv, res, relu, training, rt):
+    def forward(ctx, x, g, b, rm, rv, res, relu, training, rt, counter=None):
         shp = x.shape
         x2 = x.contiguous().view(-1, shp[-1])
-        y, mean, rstd = ops.bn_forward(x2, g.detach(), b.detach(), rm, rv, training, relu, res.contiguous().view(-1, shp[-1]) if res is not None else None)
+        y, mean, rstd = ops.bn_forward(x2, g.detach(), b.detach(), rm, rv, training, relu, res.contiguous().view(-1, shp[-1]) if res is not None else None,
+                                       counter=counter)
         ctx.save_for_backward(x2, y, g, mean, rstd)
         ctx.beta, ctx.rt = b, rt
         ctx.cfg = (relu, res is not None, training, shp)
@@ -515,7 +516,7 @@ class BatchNormFn(Function):
         dx, dg, db, dres = ops.bn_backward(x2, dy.contiguous().view(-1, shp[-1]), y, g.detach(), mean, rstd, relu, has_res, training, into=into)
         if into is not None:
             dg = db = None
-        return dx.view(shp), dg, db, None, None, (dres.view(shp) if has_res else None), None, None, None
+        return dx.view(shp), dg, db, None, None, (dres.view(shp) if has_res else None), None, None, None, None
 
 
 class MaxPoolFn(Function):

@@ -327,9 +327,9 @@ class BN(nn.Module):
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
     def forward(self, x, rt: Runtime, relu: bool, res=None):
-        if rt.training:
-            self.num_batches_tracked += 1
-        return RF.BatchNormFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, res, relu, rt.training, rt)
+        # num_batches_tracked is bumped by the statistics kernel (no separate launch per layer)
+        return RF.BatchNormFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, res, relu, rt.training, rt,
+                                    self.num_batches_tracked)
 
 
 class Conv(nn.Module):

@@ -222,16 +222,18 @@ def upsample_bwd(g_up, g_sum, src_shape):
     return d
 
 
-def bn_forward(x2d, gamma, beta, running_mean, running_var, training, relu, res, eps=1e-5, momentum=0.1):
+def bn_forward(x2d, gamma, beta, running_mean, running_var, training, relu, res, eps=1e-5, momentum=0.1, counter=None):
+    """counter: the module's num_batches_tracked (int64 scalar tensor), bumped on the device in training mode."""
     M, C = x2d.shape
     dev = x2d.device
-    stats = torch.zeros(2, C, dtype=torch.float32, device=dev)
     out = torch.empty(4, C, dtype=torch.float32, device=dev)  # mean, rstd, scale, shift
     dt = dtype_code(x2d)
     if training:
-        _call("ralf_bn_stats", dt, _p(x2d), _p(stats[0]), _p(stats[1]), M, C, _p(workspace(256 * 2 * C * 4, dev)))
-    _call("ralf_bn_finalize", _p(stats[0]), _p(stats[1]), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-          _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), M, C, eps, momentum, int(training))
+        _call("ralf_bn_batch_stats", dt, _p(x2d), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(counter),
+              _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), M, C, eps, momentum, _p(workspace(256 * 2 * C * 4, dev)))
+    else:
+        _call("ralf_bn_finalize", None, None, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+              _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), M, C, eps, momentum, 0)
     y = torch.empty_like(x2d)
     _call("ralf_bn_apply", dt, _p(x2d), _p(out[2]), _p(out[3]), _p(res), _p(y), M, C, int(relu))
     return y, out[0], out[1]

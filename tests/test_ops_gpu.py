@@ -158,7 +158,9 @@ def test_batchnorm(dtype, C, M):
     y.backward(go)
     rmd, rvd = rm.cuda(), rv.cuda()
     xd, resd = x.detach().to(dtype).cuda(), res.detach().to(dtype).cuda()
-    yd, mean, rstd = ops.bn_forward(xd, g.detach().cuda(), b.detach().cuda(), rmd, rvd, True, True, resd)
+    nbt = torch.tensor(3, dtype=torch.long, device="cuda")
+    yd, mean, rstd = ops.bn_forward(xd, g.detach().cuda(), b.detach().cuda(), rmd, rvd, True, True, resd, counter=nbt)
+    assert int(nbt) == 4  # num_batches_tracked is advanced by the statistics kernel
     close(yd, y.detach(), dtype)
     close(rmd, rm_ref, torch.float32, atol=1e-3); close(rvd, rv_ref, torch.float32, atol=2e-3, rtol=2e-3)
     dx, dg, db, dres = ops.bn_backward(xd, go.to(dtype).cuda(), yd, g.detach().cuda(), mean, rstd, True, True)
