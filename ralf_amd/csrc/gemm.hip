@@ -82,7 +82,11 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
         ok = ok && (!d.bias || al(d.bias, 4));
         ok = ok && (!d.aux || al(d.aux, et));
         ok = ok && (!d.res || (d.ldr % 4 == 0 && d.sR0 % 4 == 0 && d.sR1 % 4 == 0 && al(d.res, et)));
-        P.vec_epi = ok ? 1 : 0;
+        auto al16 = [](const void* p) { return (((uintptr_t)p) % 16) == 0; };
+        bool ok8 = ok && d.ldc % 8 == 0 && d.sC0 % 8 == 0 && d.sC1 % 8 == 0 && al16(d.C) && (!d.C2 || al16(d.C2)) && (!d.bias || al16(d.bias)) &&
+                   (!d.aux || al16(d.aux)) && (!d.res || (d.ldr % 8 == 0 && d.sR0 % 8 == 0 && d.sR1 % 8 == 0 && al16(d.res)));
+        if (d.splitk > 1 && !d.atomic_out) ok8 = ok && d.N % 8 == 0;   // slab output: [M][N] fp32 in the workspace
+        P.vec_epi = ok8 ? 2 : ok ? 1 : 0;   // 2: 8-wide (LDS-staged) epilogue, 1: 4-wide direct, 0: scalar
     }
     if (d.splitk > 1 && !d.atomic_out) {
         const size_t need = (size_t)d.splitk * nbatch * d.M * d.N * sizeof(float);

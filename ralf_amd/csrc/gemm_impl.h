@@ -138,85 +138,112 @@ __device__ __forceinline__ void epilogue_store(const RalfGemmDesc& d, int z0, in
     }
 }
 
-template <typename T> __device__ __forceinline__ void ld4(const void* p, int64_t i, float (&v)[4]);
-template <> __device__ __forceinline__ void ld4<float>(const void* p, int64_t i, float (&v)[4]) {
-    const float4 t = *reinterpret_cast<const float4*>((const float*)p + i); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-}
-template <> __device__ __forceinline__ void ld4<bf16>(const void* p, int64_t i, float (&v)[4]) {
-    const bf16x4 t = *reinterpret_cast<const bf16x4*>((const bf16*)p + i);
+// W (4 or 8) consecutive elements <-> fp32 registers; 8 x bf16 is one 16-byte access, 8 x fp32 two
+template <typename T, int W> struct VIO;
+template <int W> struct VIO<float, W> {
+    static __device__ __forceinline__ void ld(const void* p, int64_t i, float (&v)[W]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = (float)t[q];
-}
-template <typename T> __device__ __forceinline__ void st4(void* p, int64_t i, const float (&v)[4]);
-template <> __device__ __forceinline__ void st4<float>(void* p, int64_t i, const float (&v)[4]) {
-    *reinterpret_cast<float4*>((float*)p + i) = make_float4(v[0], v[1], v[2], v[3]);
-}
-template <> __device__ __forceinline__ void st4<bf16>(void* p, int64_t i, const float (&v)[4]) {
-    bf16x4 t;
+        for (int h = 0; h < W / 4; ++h) {
+            const float4 t = *reinterpret_cast<const float4*>((const float*)p + i + 4 * h);
+            v[4 * h] = t.x; v[4 * h + 1] = t.y; v[4 * h + 2] = t.z; v[4 * h + 3] = t.w;
+        }
+    }
+    static __device__ __forceinline__ void st(void* p, int64_t i, const float (&v)[W]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) t[q] = (bf16)v[q];
-    *reinterpret_cast<bf16x4*>((bf16*)p + i) = t;
-}
+        for (int h = 0; h < W / 4; ++h)
+            *reinterpret_cast<float4*>((float*)p + i + 4 * h) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+    }
+};
+template <> struct VIO<bf16, 4> {
+    static __device__ __forceinline__ void ld(const void* p, int64_t i, float (&v)[4]) {
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>((const bf16*)p + i);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (float)t[q];
+    }
+    static __device__ __forceinline__ void st(void* p, int64_t i, const float (&v)[4]) {
+        bf16x4 t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = (bf16)v[q];
+        *reinterpret_cast<bf16x4*>((bf16*)p + i) = t;
+    }
+};
+template <> struct VIO<bf16, 8> {
+    static __device__ __forceinline__ void ld(const void* p, int64_t i, float (&v)[8]) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>((const bf16*)p + i);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (float)t[q];
+    }
+    static __device__ __forceinline__ void st(void* p, int64_t i, const float (&v)[8]) {
+        bf16x8 t;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = (bf16)v[q];
+        *reinterpret_cast<bf16x8*>((bf16*)p + i) = t;
+    }
+};
 
-// epilogue on 4 consecutive columns n..n+3 of row m (same semantics as epilogue_store).
+// epilogue on W consecutive columns n..n+W-1 of row m (same semantics as epilogue_store).
 // EPI selects how much of the epilogue is compiled in (code size = issue slots and I-cache):
 //   0: alpha, bias, ReLU, residual, accumulate      1: + fused dropout, ReLU-gradient mask
 //   2: everything (GELU, GELU gradient, pre-activation copy, atomics)
-template <typename T, int EPI>
-__device__ __forceinline__ void epilogue_store4(const RalfGemmDesc& d, int z0, int z1, int m, int n, float (&v)[4]) {
+template <typename T, int EPI, int W>
+__device__ __forceinline__ void epilogue_storev(const RalfGemmDesc& d, int z0, int z1, int m, int n, float (&v)[W]) {
     const int64_t coff = z0 * d.sC0 + z1 * d.sC1 + (int64_t)m * d.ldc + n;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] *= d.alpha;
+    for (int q = 0; q < W; ++q) v[q] *= d.alpha;
     if (d.bias) {
-        float b[4];
-        ld4<float>(d.bias, n, b);
+        float b[W];
+        VIO<float, W>::ld(d.bias, n, b);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += b[q];
+        for (int q = 0; q < W; ++q) v[q] += b[q];
     }
-    if (EPI >= 2 && d.C2) { if (d.out_f32) st4<float>(d.C2, coff, v); else st4<T>(d.C2, coff, v); }
+    if (EPI >= 2 && d.C2) { if (d.out_f32) VIO<float, W>::st(d.C2, coff, v); else VIO<T, W>::st(d.C2, coff, v); }
     if (d.act == RALF_ACT_RELU) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        for (int q = 0; q < W; ++q) v[q] = fmaxf(v[q], 0.f);
     } else if (EPI >= 2 && d.act == RALF_ACT_GELU) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = gelu_f(v[q]);
+        for (int q = 0; q < W; ++q) v[q] = gelu_f(v[q]);
     }
     if (EPI >= 1 && d.drop_p > 0.f) {
         const uint32_t thr = (uint32_t)(d.drop_p * 16777216.f);
         const float inv = 1.f / (1.f - d.drop_p);
         const uint64_t sd = (uint64_t)d.seed[0], e0 = (uint64_t)m * d.N + n;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = rng24(sd, d.call_id, e0 + q) >= thr ? v[q] * inv : 0.f;
+        for (int q = 0; q < W; ++q) v[q] = rng24(sd, d.call_id, e0 + q) >= thr ? v[q] * inv : 0.f;
     }
     if (EPI >= 1 && d.aux) {
-        float a[4];
-        ld4<T>(d.aux, coff, a);
+        float a[W];
+        VIO<T, W>::ld(d.aux, coff, a);
         if (d.aux_mode == RALF_AUX_RELU_MASK) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = a[q] > 0.f ? v[q] * d.aux_scale : 0.f;
+            for (int q = 0; q < W; ++q) v[q] = a[q] > 0.f ? v[q] * d.aux_scale : 0.f;
         } else if (EPI >= 2 && d.aux_mode == RALF_AUX_GELU_GRAD) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] *= gelu_grad(a[q]);
+            for (int q = 0; q < W; ++q) v[q] *= gelu_grad(a[q]);
         }
     }
     if (d.res) {
-        float r[4];
-        ld4<T>(d.res, z0 * d.sR0 + z1 * d.sR1 + (int64_t)m * d.ldr + n, r);
+        float r[W];
+        VIO<T, W>::ld(d.res, z0 * d.sR0 + z1 * d.sR1 + (int64_t)m * d.ldr + n, r);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += r[q];
+        for (int q = 0; q < W; ++q) v[q] += r[q];
     }
     if (EPI >= 2 && d.atomic_out) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) atomicAdd((float*)d.C + coff + q, v[q]);
+        for (int q = 0; q < W; ++q) atomicAdd((float*)d.C + coff + q, v[q]);
     } else {
         if (d.accumulate) {
-            float c[4];
-            if (d.out_f32) ld4<float>(d.C, coff, c); else ld4<T>(d.C, coff, c);
+            float c[W];
+            if (d.out_f32) VIO<float, W>::ld(d.C, coff, c); else VIO<T, W>::ld(d.C, coff, c);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] += c[q];
+            for (int q = 0; q < W; ++q) v[q] += c[q];
         }
-        if (d.out_f32) st4<float>(d.C, coff, v); else st4<T>(d.C, coff, v);
+        if (d.out_f32) VIO<float, W>::st(d.C, coff, v); else VIO<T, W>::st(d.C, coff, v);
     }
+}
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue_store4(const RalfGemmDesc& d, int z0, int z1, int m, int n, float (&v)[4]) {
+    epilogue_storev<T, EPI, 4>(d, z0, z1, m, n, v);
 }
 
 // ---- operand loaders -------------------------------------------------------------------------
@@ -311,9 +338,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
     constexpr int KV = BK / VEC;                                   // vectors along k (k-contiguous tile)
     constexpr int RVA = BM / VEC, RVB = BN / VEC;                  // vectors along rows (row-contiguous tile)
     constexpr int NVA = BM * BK / VEC / 256, NVB = BN * BK / VEC / 256;  // 16-byte vectors per thread per k-tile
-    __shared__ __attribute__((aligned(16))) T lds[A_ELEMS + B_ELEMS];
-    T* la = lds;
-    T* lb = lds + A_ELEMS;
+    constexpr int CP = BN + 4;                                     // fp32 C staging tile [64][CP] (epilogue)
+    constexpr int LDS_BYTES = (A_ELEMS + B_ELEMS) * (int)sizeof(T) > 64 * CP * 4 ? (A_ELEMS + B_ELEMS) * (int)sizeof(T) : 64 * CP * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];   // ONE LDS object (operand tiles, then the C staging tile)
+    T* la = reinterpret_cast<T*>(lds_raw);
+    T* lb = la + A_ELEMS;
     const RalfGemmDesc& d = P.d;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
@@ -476,19 +505,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
     // (no `continue`/`break` in these loops: they must unroll completely or the accumulators spill to scratch)
     const int nbatch = gridDim.z;
     const bool slab = d.splitk > 1 && !d.atomic_out;
-    if (P.vec_epi && m0 + BM <= d.M && n0 + BN <= d.N) {   // interior tile (workgroup-uniform): no per-element bounds logic
+    if (P.vec_epi >= 2 && n0 + BN <= d.N) {
+        // tile interior in n: the accumulators go through LDS so every lane stores 8 consecutive columns of one row
+        // (8 lanes = one 128-byte line of bf16) instead of 32 rows x 8 bytes per store instruction; residual / mask /
+        // accumulate reads get the same shape.  64 tile rows per round.
+        float* cs = reinterpret_cast<float*>(lds_raw);
         float* pbase = slab ? P.partial + ((int64_t)split * nbatch + z) * d.M * d.N : nullptr;
+        constexpr int CG = BN / 8, RPP = 256 / CG;
 #pragma clang loop unroll(full)
-        for (int i = 0; i < FM; ++i) {
-            const int m = m0 + wm * 32 * FM + i * 32 + l31;
+        for (int h = 0; h < FM; ++h) {
+            __syncthreads();
+            if (FM == 1 || wm == h) {
 #pragma clang loop unroll(full)
-            for (int j = 0; j < FN; ++j) {
+                for (int i = 0; i < FM; ++i) {
+                    const int lr = (FM == 1 ? wm * 32 : i * 32) + l31;
 #pragma clang loop unroll(full)
-                for (int g = 0; g < 4; ++g) {
-                    const int n = n0 + wn * 32 * FN + j * 32 + 8 * g + 4 * lh;
-                    float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    if (slab) *reinterpret_cast<float4*>(pbase + (int64_t)m * d.N + n) = make_float4(v[0], v[1], v[2], v[3]);
-                    else epilogue_store4<T, EPI>(d, z0, z1, m, n, v);
+                    for (int j = 0; j < FN; ++j) {
+#pragma clang loop unroll(full)
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<float4*>(cs + lr * CP + wn * 32 * FN + j * 32 + 8 * g + 4 * lh) =
+                                make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < 64 / RPP; ++p) {
+                const int lr = p * RPP + tid / CG, c = (tid % CG) * 8;
+                const int m = m0 + h * 64 + lr;
+                if (m < d.M) {
+                    const float4 lo = *reinterpret_cast<const float4*>(cs + lr * CP + c), hi = *reinterpret_cast<const float4*>(cs + lr * CP + c + 4);
+                    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    if (slab) VIO<float, 8>::st(pbase, (int64_t)m * d.N + n0 + c, v);
+                    else epilogue_storev<T, EPI, 8>(d, z0, z1, m, n0 + c, v);
                 }
             }
         }
