@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 1
+#define RALF_ABI_VERSION 2
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -97,6 +97,11 @@ typedef struct RalfGemmDesc {
     /* atomic_out: C (fp32) += alpha*A@B with fp32 atomics, split-K without partial slabs / reduce kernel
      * (weight gradients accumulated straight into the flat gradient buffer; summation order not fixed) */
     int atomic_out;
+    /* colstats (fp32 [ceil(M/64)][2][N], may be NULL): per 64-row block of C, the column sums and sums of squares of
+     * the STORED output (after rounding to its dtype) -- the BatchNorm batch statistics of a convolution output
+     * come out of the convolution's own epilogue (ralf_bn_stats_from_partials) instead of a pass over the tensor.
+     * Needs a plain epilogue (alpha 1, no bias/act/res/aux/dropout/accumulate), splitk 1, one batch, N % 64 == 0. */
+    float* colstats;
 } RalfGemmDesc;
 size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d);
 int ralf_gemm(const RalfGemmDesc* d, void* workspace, size_t workspace_bytes, void* stream);
@@ -128,6 +133,11 @@ int ralf_bn_finalize(const float* s1, const float* s2, const float* gamma, const
 int ralf_bn_batch_stats(int dtype, const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                         int64_t* num_batches_tracked, float* mean, float* rstd, float* scale, float* shift, int64_t M, int C,
                         float eps, float momentum, float* workspace, void* stream);
+/* the same from per-64-row partial column sums written by ralf_gemm (RalfGemmDesc.colstats): partials fp32 [nrows][2][C];
+ * workspace: RALF_BN_MAX_PARTIALS * 2 * C floats */
+int ralf_bn_stats_from_partials(const float* partials, int nrows, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                int64_t* num_batches_tracked, float* mean, float* rstd, float* scale, float* shift, int64_t M, int C,
+                                float eps, float momentum, float* workspace, void* stream);
 int ralf_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, int64_t M, int C, int relu, void* stream);
 int ralf_bn_bwd_reduce(int dtype, const void* x, const void* dy, const void* y, const float* mean, const float* rstd, float* s1, float* s2,
                        int64_t M, int C, int relu, float* workspace, void* stream);

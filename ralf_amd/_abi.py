@@ -26,7 +26,7 @@ class RalfGemmDesc(ctypes.Structure):
         + [(n, i32) for n in ("M", "N", "K", "nb0", "nb1", "dtype", "a_kcontig", "b_kcontig", "gather",
                               "act", "aux_mode", "out_f32", "accumulate", "splitk")]
         + [("alpha", f32), ("aux_scale", f32), ("g", RalfConvGeom)]
-        + [("seed", vp), ("call_id", ctypes.c_uint64), ("drop_p", f32), ("atomic_out", i32)]
+        + [("seed", vp), ("call_id", ctypes.c_uint64), ("drop_p", f32), ("atomic_out", i32), ("colstats", vp)]
     )
 
 
@@ -56,6 +56,7 @@ SIGNATURES.update({
     "ralf_bn_stats": (i32, [i32, vp, vp, vp, i64, i32, vp, vp]),
     "ralf_bn_finalize": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp]),
     "ralf_bn_batch_stats": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, vp, vp]),
+    "ralf_bn_stats_from_partials": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, vp, vp]),
     "ralf_bn_apply": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "ralf_bn_bwd_reduce": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]),
     "ralf_bn_bwd_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),

@@ -88,6 +88,11 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
         if (d.splitk > 1 && !d.atomic_out) ok8 = ok && d.N % 8 == 0;   // slab output: [M][N] fp32 in the workspace
         P.vec_epi = ok8 ? 2 : ok ? 1 : 0;   // 2: 8-wide (LDS-staged) epilogue, 1: 4-wide direct, 0: scalar
     }
+    if (d.colstats) {
+        RALF_REQUIRE(P.vec_epi == 2 && d.N % 64 == 0 && d.splitk == 1 && nbatch == 1 && d.alpha == 1.f && !d.bias && !d.act && !d.res && !d.aux &&
+                     !d.C2 && !d.accumulate && !d.atomic_out && d.drop_p == 0.f && (d.dtype == RALF_F32 || !d.out_f32),
+                     "gemm: colstats needs a plain epilogue, one batch, no split-K, N %% 64 == 0 and 8-wide aligned output");
+    }
     if (d.splitk > 1 && !d.atomic_out) {
         const size_t need = (size_t)d.splitk * nbatch * d.M * d.N * sizeof(float);
         if (!workspace || workspace_bytes < need) {

@@ -529,6 +529,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
                 }
             }
             __syncthreads();
+            if (d.colstats) {   // BatchNorm batch statistics of this 64-row block, on the values as stored (rounded to T)
+                constexpr int CPW = BN / 4, RG = 64 / CPW;           // columns per wave, row groups per column
+                const int col = wave * CPW + (lane % CPW), rg = lane / CPW;
+                const int nvalid = min(64, d.M - (m0 + h * 64));   // <= 0: this 64-row block lies beyond M (no partial row exists)
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+                for (int r = rg; r < nvalid; r += RG) {
+                    const float v = (float)(T)cs[r * CP + col];
+                    s1 += v; s2 += v * v;
+                }
+#pragma unroll
+                for (int o = CPW; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+                if (rg == 0 && nvalid > 0) {
+                    float* pr = d.colstats + ((int64_t)(m0 / 64 + h) * 2) * d.N + n0 + col;
+                    pr[0] = s1; pr[d.N] = s2;
+                }
+            }
 #pragma unroll
             for (int p = 0; p < 64 / RPP; ++p) {
                 const int lr = p * RPP + tid / CG, c = (tid % CG) * 8;
@@ -627,11 +644,12 @@ template <typename T, bool AK, bool BKC, int GATHER>
 int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
     const RalfGemmDesc& d = P.d;
     static const int forced = [] { const char* e = getenv("RALF_GEMM_TILE"); return e ? atoi(e) : 0; }();  // tuning aid: 22 / 11
-    if (forced == 22) return launch_epi<T, AK, BKC, GATHER, 2, 2>(P, nbatch, st);
+    const bool ok22 = !d.colstats || d.N % 128 == 0;   // column statistics come from the staged epilogue: every tile interior in n
+    if (forced == 22 && ok22) return launch_epi<T, AK, BKC, GATHER, 2, 2>(P, nbatch, st);
     if (forced == 11) return launch_epi<T, AK, BKC, GATHER, 1, 1>(P, nbatch, st);
     const int64_t big = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) * d.splitk * nbatch;
     const int kspan = ceil_div(d.K, d.splitk);
-    if (d.N > 64 && d.M > 64 && kspan >= 1024 && big >= 512) return launch_epi<T, AK, BKC, GATHER, 2, 2>(P, nbatch, st);
+    if (ok22 && d.N > 64 && d.M > 64 && kspan >= 1024 && big >= 512) return launch_epi<T, AK, BKC, GATHER, 2, 2>(P, nbatch, st);
     return launch_epi<T, AK, BKC, GATHER, 1, 1>(P, nbatch, st);
 }
 

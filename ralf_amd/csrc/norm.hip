@@ -371,6 +371,24 @@ __global__ __launch_bounds__(256) void bn_partial_finalize_kernel(const float* _
     if (counter && blockIdx.x == 0 && threadIdx.x == 0) *counter += 1;
 }
 
+// [nrows][2][C] partial sums -> [G][2][C] (row r goes to group r % G): first stage when the GEMM wrote thousands of partial rows
+__global__ __launch_bounds__(256) void bn_partial_fold_kernel(const float* __restrict__ part, int nrows, int C, int G, float* __restrict__ out) {
+    __shared__ float red[2][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx, g = blockIdx.y;
+    float a = 0.f, b = 0.f;
+    if (c < C) {
+#pragma unroll 4
+        for (int i = g + ty * G; i < nrows; i += 4 * G) { a += part[((int64_t)i * 2) * C + c]; b += part[((int64_t)i * 2 + 1) * C + c]; }
+    }
+    red[0][ty][tx] = a; red[1][ty][tx] = b;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        out[((int64_t)g * 2) * C + c] = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
+        out[((int64_t)g * 2 + 1) * C + c] = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+    }
+}
+
 // y = relu?( x*scale + shift (+ res) )
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
@@ -543,6 +561,23 @@ extern "C" int ralf_bn_batch_stats(int dtype, const void* x, const float* gamma,
     hipLaunchKernelGGL(bn_partial_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, workspace, gx, gamma, beta, running_mean, running_var,
                        num_batches_tracked, mean, rstd, scale, shift, M, C, eps, momentum);
     return ralf::check_launch("bn_batch_stats");
+}
+
+extern "C" int ralf_bn_stats_from_partials(const float* partials, int nrows, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                           int64_t* num_batches_tracked, float* mean, float* rstd, float* scale, float* shift, int64_t M, int C,
+                                           float eps, float momentum, float* workspace, void* stream) {
+    RALF_REQUIRE(partials && nrows > 0 && gamma && beta && mean && rstd && scale && shift && workspace && M > 0 && C > 0, "bn_stats_from_partials: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const float* src = partials;
+    int n = nrows;
+    if (nrows > 64) {   // fold to <= RALF_BN_MAX_PARTIALS/2 rows with a wide grid first (the finalize kernel walks its rows serially)
+        const int G = nrows >= 1024 ? 128 : 32;
+        hipLaunchKernelGGL(bn_partial_fold_kernel, dim3(ceil_div(C, 64), G), dim3(256), 0, st, partials, nrows, C, G, workspace);
+        src = workspace; n = G;
+    }
+    hipLaunchKernelGGL(bn_partial_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, src, n, gamma, beta, running_mean, running_var,
+                       num_batches_tracked, mean, rstd, scale, shift, M, C, eps, momentum);
+    return ralf::check_launch("bn_stats_from_partials");
 }
 
 extern "C" int ralf_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, int64_t M, int C, int relu, void* stream) {

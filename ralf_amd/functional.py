@@ -421,7 +421,7 @@ class ConvFn(Function):
     `pos` (optional, constant [OH*OW, Co]) is added to every image (fused positional table)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, stride, pad, pos, rt, fork=False):
+    def forward(ctx, x, W, b, stride, pad, pos, rt, fork=False, stats=False):
         """fork: also return x itself as a second output (the residual / downsample branch consumes THAT alias);
         its gradient comes back into this backward and is added in the data-gradient GEMM's epilogue instead of a
         separate autograd accumulation pass over the block input."""
@@ -431,27 +431,34 @@ class ConvFn(Function):
         M = B * OH * OW
         x = x.contiguous()
         bias = b.detach() if b is not None else None
+        # stats: the following BatchNorm's batch statistics come out of this GEMM's epilogue (per-64-row partial sums)
+        cst = ops.colstats_buffer(M, Co, x.device) if (stats and Co % 64 == 0 and b is None and pos is None) else None
         if kh == 1 and stride == 1:
             if pos is not None:  # batched over images so the [hw, Co] table is shared (batch stride 0)
                 hw = OH * OW
                 y = ops.gemm(x.view(-1, C), rt.lp(W).view(Co, Ci), hw, Co, Ci, bias=bias, res=pos, batch=(B, 1),
                              sA=(hw * Ci, 0), sC=(hw * Co, 0), sR=(0, 0), out=torch.empty(M, Co, dtype=x.dtype, device=x.device))
             else:
-                y = ops.gemm(x.view(-1, C), rt.lp(W).view(Co, Ci), M, Co, Ci, bias=bias)
+                y = ops.gemm(x.view(-1, C), rt.lp(W).view(Co, Ci), M, Co, Ci, bias=bias, colstats=cst)
         else:
             assert pos is None
             geom = dict(RH=OH, RW=OW, SH=H, SW=Wd, SC=C, KH=kh, KW=kw, stride=stride, pad=pad, mode=0)
-            y = ops.gemm(x, rt.lp(W, "ohwi"), M, Co, kh * kw * C, conv=geom, gather=1, bias=bias)
+            y = ops.gemm(x, rt.lp(W, "ohwi"), M, Co, kh * kw * C, conv=geom, gather=1, bias=bias, colstats=cst)
         ctx.save_for_backward(x, W)
         ctx.bias = b
         ctx.cfg = (stride, pad, OH, OW, b is not None, rt)
         ctx.fork = fork
-        if fork:
-            return y.view(B, OH, OW, Co), x
-        return y.view(B, OH, OW, Co)
+        out = (y.view(B, OH, OW, Co),) + ((x,) if fork else ())
+        if stats:
+            if cst is None:   # shape not covered by the fused statistics: BatchNorm computes them itself
+                cst = torch.empty(0, dtype=torch.float32, device=x.device)
+            ctx.mark_non_differentiable(cst)
+            out = out + (cst,)
+        return out if len(out) > 1 else out[0]
 
     @staticmethod
-    def backward(ctx, dy, dskip=None):
+    def backward(ctx, dy, *rest):
+        dskip = rest[0] if ctx.fork else None
         x, W = ctx.saved_tensors
         stride, pad, OH, OW, has_b, rt = ctx.cfg
         B, H, Wd, C = x.shape
@@ -486,22 +493,25 @@ class ConvFn(Function):
                     dW = run()
         if has_b and ctx.needs_input_grad[2]:
             db = bgrad(dy2, M, Co, rt.gview(ctx.bias), rt)
-        return dx, dW, db, None, None, None, None, None
+        return dx, dW, db, None, None, None, None, None, None
 
 
-def conv2d(x, W, b, stride, pad, rt, pos=None, fork=False):
-    return ConvFn.apply(x, W, b, stride, pad, pos, rt, fork)
+def conv2d(x, W, b, stride, pad, rt, pos=None, fork=False, stats=False):
+    """returns y, then x itself when fork, then the [M/64, 2, Co] column-statistics partials when stats."""
+    return ConvFn.apply(x, W, b, stride, pad, pos, rt, fork, stats)
 
 
 class BatchNormFn(Function):
     """y = relu?(BN(x) (+ res)) on NHWC; batch statistics + running-stat update in training."""
 
     @staticmethod
-    def forward(ctx, x, g, b, rm, rv, res, relu, training, rt, counter=None):
+    def forward(ctx, x, g, b, rm, rv, res, relu, training, rt, counter=None, partials=None):
         shp = x.shape
         x2 = x.contiguous().view(-1, shp[-1])
+        if partials is not None and partials.numel() == 0:
+            partials = None
         y, mean, rstd = ops.bn_forward(x2, g.detach(), b.detach(), rm, rv, training, relu, res.contiguous().view(-1, shp[-1]) if res is not None else None,
-                                       counter=counter)
+                                       counter=counter, partials=partials)
         ctx.save_for_backward(x2, y, g, mean, rstd)
         ctx.beta, ctx.rt = b, rt
         ctx.cfg = (relu, res is not None, training, shp)
@@ -516,7 +526,7 @@ class BatchNormFn(Function):
         dx, dg, db, dres = ops.bn_backward(x2, dy.contiguous().view(-1, shp[-1]), y, g.detach(), mean, rstd, relu, has_res, training, into=into)
         if into is not None:
             dg = db = None
-        return dx.view(shp), dg, db, None, None, (dres.view(shp) if has_res else None), None, None, None, None
+        return dx.view(shp), dg, db, None, None, (dres.view(shp) if has_res else None), None, None, None, None, None
 
 
 class MaxPoolFn(Function):

@@ -326,10 +326,11 @@ class BN(nn.Module):
         self.register_buffer("running_var", torch.ones(c))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x, rt: Runtime, relu: bool, res=None):
+    def forward(self, x, rt: Runtime, relu: bool, res=None, stats=None):
+        """stats: column-statistics partials from the producing convolution (Conv.forward(..., stats=True))."""
         # num_batches_tracked is bumped by the statistics kernel (no separate launch per layer)
         return RF.BatchNormFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, res, relu, rt.training, rt,
-                                    self.num_batches_tracked)
+                                    self.num_batches_tracked, stats if rt.training else None)
 
 
 class Conv(nn.Module):
@@ -342,8 +343,8 @@ class Conv(nn.Module):
             self.register_parameter("bias", None)
         self.stride, self.pad = stride, pad
 
-    def forward(self, x, rt: Runtime, pos=None, fork=False):
-        return RF.conv2d(x, self.weight, self.bias, self.stride, self.pad, rt, pos, fork)
+    def forward(self, x, rt: Runtime, pos=None, fork=False, stats=False):
+        return RF.conv2d(x, self.weight, self.bias, self.stride, self.pad, rt, pos, fork, stats)
 
 
 class Bottleneck(nn.Module):
@@ -360,13 +361,16 @@ class Bottleneck(nn.Module):
             self.downsample = None
 
     def forward(self, x, rt: Runtime):
-        y, idn = self.conv1(x, rt, fork=True)   # idn aliases x: its gradient is summed inside conv1's data-gradient GEMM
-        y = self.bn1(y, rt, True)
-        y = self.bn2(self.conv2(y, rt), rt, True)
-        y = self.conv3(y, rt)
+        # training: every BatchNorm's batch statistics are produced by the preceding convolution's epilogue
+        y, idn, st = self.conv1(x, rt, fork=True, stats=True)   # idn aliases x: its gradient is summed inside conv1's data-gradient GEMM
+        y = self.bn1(y, rt, True, stats=st)
+        y, st = self.conv2(y, rt, stats=True)
+        y = self.bn2(y, rt, True, stats=st)
+        y, st3 = self.conv3(y, rt, stats=True)
         if self.downsample is not None:
-            idn = self.downsample[1](self.downsample[0](idn, rt), rt, False)
-        return self.bn3(y, rt, True, res=idn)
+            idn, st = self.downsample[0](idn, rt, stats=True)
+            idn = self.downsample[1](idn, rt, False, stats=st)
+        return self.bn3(y, rt, True, res=idn, stats=st3)
 
 
 RESNET50_STAGES = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))
@@ -407,7 +411,8 @@ class ResnetBackbone(nn.Module):
         # NCHW fp32 [B,4,H,W] -> NHWC compute dtype, channels zero-padded to 8 (16-byte pixel vectors)
         x = ops.permute4(img.contiguous().float(), (B, H, W, 8), (4 * H * W, W, 1, H * W), 4, rt.dtype)
         b = self.body
-        x = b.bn1(b.conv1(x, rt), rt, True)
+        x, st = b.conv1(x, rt, stats=True)
+        x = b.bn1(x, rt, True, stats=st)
         x = RF.MaxPoolFn.apply(x)
         feats = {}
         for li in (1, 2, 3, 4):

@@ -41,7 +41,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
          lda=None, ldb=None, out: Optional[torch.Tensor] = None, ldc=None, out_dtype=None,
          bias=None, act=None, res=None, ldr=None, aux=None, aux_mode=None, aux_scale=1.0, out2=None,
          alpha=1.0, accumulate=False, splitk=1, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=None,
-         conv: Optional[dict] = None, gather=0, drop_p=0.0, seed=None, call_id=0, atomic=False) -> torch.Tensor:
+         conv: Optional[dict] = None, gather=0, drop_p=0.0, seed=None, call_id=0, atomic=False, colstats=None) -> torch.Tensor:
     """C = epi(alpha * A @ B) through ralf_gemm (see include/ralf_hip.h: RalfGemmDesc)."""
     assert A.is_cuda and B.is_cuda and A.dtype == B.dtype
     d = RalfGemmDesc()
@@ -73,6 +73,9 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
     d.act, d.aux_mode, d.aux_scale = ACT[act], AUX[aux_mode], aux_scale
     d.accumulate, d.splitk, d.alpha = int(accumulate), splitk, alpha
     d.drop_p, d.seed, d.call_id, d.atomic_out = drop_p, _p(seed), call_id, int(atomic)
+    if colstats is not None:   # fp32 [ceil(M/64), 2, N]: per-64-row column sums / sums of squares of the stored output
+        assert colstats.dtype == torch.float32 and colstats.numel() >= ((M + 63) // 64) * 2 * N
+        d.colstats = _p(colstats)
     if conv is not None:
         g = RalfConvGeom(**conv)
         d.g = g
@@ -222,13 +225,21 @@ def upsample_bwd(g_up, g_sum, src_shape):
     return d
 
 
-def bn_forward(x2d, gamma, beta, running_mean, running_var, training, relu, res, eps=1e-5, momentum=0.1, counter=None):
-    """counter: the module's num_batches_tracked (int64 scalar tensor), bumped on the device in training mode."""
+def colstats_buffer(M, N, device):
+    return torch.empty((M + 63) // 64, 2, N, dtype=torch.float32, device=device)
+
+
+def bn_forward(x2d, gamma, beta, running_mean, running_var, training, relu, res, eps=1e-5, momentum=0.1, counter=None, partials=None):
+    """counter: the module's num_batches_tracked (int64 scalar tensor), bumped on the device in training mode.
+    partials: column statistics the producing GEMM already wrote (ops.gemm(colstats=...)): no pass over x for the statistics."""
     M, C = x2d.shape
     dev = x2d.device
     out = torch.empty(4, C, dtype=torch.float32, device=dev)  # mean, rstd, scale, shift
     dt = dtype_code(x2d)
-    if training:
+    if training and partials is not None:
+        _call("ralf_bn_stats_from_partials", _p(partials), partials.shape[0], _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(counter),
+              _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), M, C, eps, momentum, _p(workspace(256 * 2 * C * 4, dev)))
+    elif training:
         _call("ralf_bn_batch_stats", dt, _p(x2d), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(counter),
               _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), M, C, eps, momentum, _p(workspace(256 * 2 * C * 4, dev)))
     else:

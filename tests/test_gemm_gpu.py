@@ -106,3 +106,32 @@ def test_conv_gather(dtype, cfg):
     gw = ops.gemm(gyn, xn, Co, Kf, Mo, a_kcontig=False, b_kcontig=False, conv=geom_f, gather=2, splitk=3, out_dtype=torch.float32)
     tol = dict(atol=0.15, rtol=3e-2) if dtype == torch.bfloat16 else dict(atol=1e-4, rtol=1e-4)
     torch.testing.assert_close(gw.cpu().view(Co, k, k, Ci).permute(0, 3, 1, 2), w.grad, **tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (1000, 64, 128), (4101, 128, 2048), (70000, 256, 64), (130, 192, 64)])
+def test_column_statistics_epilogue(dtype, M, N, K):
+    """RalfGemmDesc.colstats: per-64-row column sums / sums of squares of the output AS STORED (BatchNorm batch statistics
+    out of the convolution epilogue); ragged last block, both tile shapes, thousands of partial rows -> bn_stats_from_partials."""
+    from ralf_amd import ops
+
+    A, B = rnd(M, K, seed=31, dtype=dtype).cuda(), rnd(N, K, seed=32, dtype=dtype).cuda()
+    st = torch.full(((M + 63) // 64, 2, N), float("nan"), device="cuda")
+    out = ops.gemm(A, B, M, N, K, colstats=st)
+    tol = dict(atol=1e-5 * K ** 0.5 * 2, rtol=1e-4) if dtype == torch.float32 else TOL[dtype]   # fp32: summation order over long K
+    torch.testing.assert_close(out.float().cpu(), ref_mm(A.cpu(), B.cpu().t()), **tol)
+    o = out.float()
+    pad = (-M) % 64
+    o64 = torch.cat([o, torch.zeros(pad, N, device="cuda")]).view(-1, 64, N)
+    torch.testing.assert_close(st[:, 0], o64.sum(1), atol=1e-3 * K ** 0.5, rtol=1e-4)
+    torch.testing.assert_close(st[:, 1], (o64 * o64).sum(1), atol=1e-2 * K, rtol=1e-4)
+    # the BatchNorm entry that consumes them == statistics computed from the tensor itself
+    g, b = torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
+    res = torch.empty(4, N, device="cuda")
+    ws = torch.empty(256 * 2 * N, device="cuda")
+    cnt = torch.zeros((), dtype=torch.long, device="cuda")
+    ops._call("ralf_bn_stats_from_partials", ops._p(st), st.shape[0], ops._p(g), ops._p(b), None, None, ops._p(cnt),
+              ops._p(res[0]), ops._p(res[1]), ops._p(res[2]), ops._p(res[3]), M, N, 1e-5, 0.1, ops._p(ws))
+    torch.testing.assert_close(res[0], o.mean(0), atol=1e-3, rtol=1e-3)
+    torch.testing.assert_close(res[1], (o.var(0, unbiased=False) + 1e-5).rsqrt(), atol=1e-3, rtol=2e-3)
+    assert int(cnt) == 1
