@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
     const bool a_al = (d.lda % VEC == 0) && (((uintptr_t)Ap & 15) == 0);
     const bool b_al = (d.ldb % VEC == 0) && (((uintptr_t)Bp & 15) == 0);
 
-    u32x4 ra[NVA], rb[NVB];
+    u32x4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];   // two staging register sets: prefetch distance 2 k-tiles
     RowInfo ia[NVA], ib[NVB];
     // PMC (SQ_ACTIVE_INST_ANY ~ 84 % of the kernel, MFMA busy 10 %) showed this kernel is instruction-issue bound:
     // the interior fast path keeps one pointer per staging vector and advances it by a constant per k-tile.
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
 #pragma unroll
         for (int i = 0; i < NVB; ++i) ib[i] = row_info<false>(P, n0 + (tid + 256 * i) / KV, d.N, d.ldb);
     }
-    auto gload = [&](int k0) {
+    auto gload = [&](u32x4 (&ra)[NVA], u32x4 (&rb)[NVB], int k0) {
         if constexpr (fast) {
 #pragma unroll
             for (int i = 0; i < NVA; ++i) { ra[i] = *reinterpret_cast<const u32x4*>(pa[i]); pa[i] += stepA; }
@@ -428,10 +428,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
     // transpose-read geometry (bf16 row-contiguous tiles): 16-lane group gi reads a [4 k][16 rows] block
     const int trL = lane & 15, tr_rowblk = ((lane >> 4) & 1) * 16, tr_k = lh * 8 + (trL >> 2), tr_c = (trL & 3) * 4;
 
-    gload(kbeg);
-    lds_stage<T, AK, NVA, RVA, LDRA>(la, ra, tid);
-    lds_stage<T, BKC, NVB, RVB, LDRB>(lb, rb, tid);
-    __syncthreads();
     // one k-tile of MFMAs from the staged LDS tile
     auto compute = [&]() {
         // the matrix core computes the TRANSPOSED tile: row operand = n-fragment (weights), column operand =
@@ -489,17 +485,51 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
             }
         }
     };
-    // branch-free steady state (the last k-tile is peeled): with an `if (more)` around the prefetch the compiler
-    // shuttled all accumulators AGPR -> VGPR -> AGPR every iteration (32 of the loop's 36 VALU instructions at 64x64)
-    for (int k0 = kbeg; k0 + BK < kend; k0 += BK) {
-        gload(k0 + BK);
+    // Software pipeline with prefetch distance TWO k-tiles through two staging register sets: a tile's global loads
+    // get two compute phases to land (the k-loop is bound by load latency x tiles in flight per CU, not by MFMA rate).
+    // Steady state is branch-free (an `if` around a prefetch made the compiler shuttle every accumulator
+    // AGPR -> VGPR -> AGPR per iteration); the last 1-3 tiles are peeled.
+    auto stage0 = [&]() { lds_stage<T, AK, NVA, RVA, LDRA>(la, ra0, tid); lds_stage<T, BKC, NVB, RVB, LDRB>(lb, rb0, tid); };
+    auto stage1 = [&]() { lds_stage<T, AK, NVA, RVA, LDRA>(la, ra1, tid); lds_stage<T, BKC, NVB, RVB, LDRB>(lb, rb1, tid); };
+    // (the 64x64 im2col-gather kernels keep distance 1: their index registers + a second staging set cost a wave of occupancy
+    //  and the layer1 3x3 convolutions got 20 % slower with distance 2)
+    constexpr int PF = (GATHER == 1 && FM == 1) ? 1 : 2;
+    const int nt = (kend - kbeg + BK - 1) / BK;
+    gload(ra0, rb0, kbeg);
+    if constexpr (PF == 1) {
+        stage0();
+        __syncthreads();
+        for (int t = 0; t + 1 < nt; ++t) {
+            gload(ra0, rb0, kbeg + (t + 1) * BK);
+            compute();
+            __syncthreads();
+            stage0();
+            __syncthreads();
+        }
         compute();
+    } else {
+        if (nt > 1) gload(ra1, rb1, kbeg + BK);
+        stage0();
         __syncthreads();
-        lds_stage<T, AK, NVA, RVA, LDRA>(la, ra, tid);
-        lds_stage<T, BKC, NVB, RVB, LDRB>(lb, rb, tid);
-        __syncthreads();
+        int t = 0;
+        for (; t + 3 < nt; t += 2) {        // tile t in LDS, tile t+1 in set 1
+            gload(ra0, rb0, kbeg + (t + 2) * BK);
+            compute();
+            __syncthreads();
+            stage1();
+            __syncthreads();
+            gload(ra1, rb1, kbeg + (t + 3) * BK);
+            compute();
+            __syncthreads();
+            stage0();
+            __syncthreads();
+        }
+        const int rem = nt - t;             // 1..3 tiles left: t in LDS, t+1 in set 1 (rem >= 2), t+2 not loaded yet (rem == 3)
+        if (rem == 3) gload(ra0, rb0, kbeg + (t + 2) * BK);
+        compute();
+        if (rem >= 2) { __syncthreads(); stage1(); __syncthreads(); compute(); }
+        if (rem == 3) { __syncthreads(); stage0(); __syncthreads(); compute(); }
     }
-    compute();
 
     // ---- epilogue: lane holds 4 consecutive columns n per register group g = r>>2 ----
     // (no `continue`/`break` in these loops: they must unroll completely or the accumulators spill to scratch)

@@ -119,9 +119,12 @@ def _2d(x):
     return x.reshape(-1, x.shape[-1])
 
 
+_WGRAD_WG = int(os.environ.get("RALF_WGRAD_WG", "256"))   # tuning knob (measured: 256 best on MI355X)
+
+
 def _splitk_for(out_rows: int, out_cols: int, red: int) -> int:
     tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
-    want = max(1, 256 // tiles)            # ~one workgroup per CU; more splits only add slab traffic
+    want = max(1, _WGRAD_WG // tiles)      # workgroups in flight; more splits only add slab traffic
     return max(1, min(want, red // 1024))  # each split reduces >= 1024 rows
 
 
