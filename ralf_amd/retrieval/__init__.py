@@ -1,3 +1,4 @@
 from .knn import FlatIPIndex, knn_topk_ip  # noqa: F401
 from .reranker import maximal_marginal_relevance, reranker_random, reranker_top_k  # noqa: F401
 from .retriever import RetrievalDatasetWrapper, Retriever, coarse_saliency, load_cache_table, table_path  # noqa: F401
+from .embed import coarse_saliency_batch, layout_features, pool_cosine, rerank_tables  # noqa: F401

@@ -28,3 +28,13 @@ def test_coarse_saliency_and_table_format(tmp_path):
     assert path.endswith("pku_train_dreamsim_wo_head_table_between_dataset_indexes_top_k32.pt")   # retriever.py:149
     torch.save(table, path)
     assert load_cache_table(path, 16) == {7: list(range(16)), 9: list(range(32, 48))}           # retrieval_dataset_wrapper.py:32
+
+
+def test_coarse_saliency_batch_equals_per_image():
+    from ralf_amd.retrieval import coarse_saliency_batch
+
+    s = torch.rand(5, 1, 350, 240) * 1.2 - 0.1   # values outside [0,1] exercise the clamp
+    f = coarse_saliency_batch(s)
+    assert f.shape == (5, 256)
+    for b in range(5):
+        assert np.array_equal(f[b].numpy(), coarse_saliency(s[b]))

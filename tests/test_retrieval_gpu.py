@@ -43,3 +43,45 @@ def test_table_build_and_wrapper(tmp_path):
     n = len(db[j]["label"])
     assert ret["mask"][5].sum().item() == n and ret["label"][5, :n].tolist() == db[j]["label"]
     assert torch.allclose(ret["center_x"][5, :n], torch.tensor(db[j]["center_x"]))
+
+
+def test_layout_features_and_mmr_rerank(golden):
+    """8f rank 1-2: batched layout-encoder embeddings of a whole split == the oracle's FIDNet restatement per row, and the
+    MMR re-rank driver == a straightforward per-sample computation on those embeddings."""
+    from oracle import ralf_oracle as O
+    from oracle.detweights import det_state_dict
+    from ralf_amd.functional import Runtime
+    from ralf_amd.nn import LayoutEncoder
+    from ralf_amd.retrieval import layout_features, maximal_marginal_relevance, rerank_tables
+    from test_model_cpu import ref_shapes
+
+    shapes = {k[len("layout_encoer."):]: v for k, v in dict(ref_shapes("ralf_state_shapes.json")).items() if k.startswith("layout_encoer.")}
+    sd = det_state_dict({"layout_encoer." + k: v for k, v in shapes.items()})
+    enc = LayoutEncoder(num_label=3)
+    enc.load_state_dict({k[len("layout_encoer."):]: v for k, v in sd.items()}, strict=True)
+    enc = enc.cuda()
+    rng = np.random.default_rng(5)
+    M, N = 700, 10
+    n_el = rng.integers(1, N + 1, M)
+    mask = torch.from_numpy(np.arange(N)[None, :] < n_el[:, None])
+    fields = {"label": torch.from_numpy(rng.integers(0, 3, (M, N))) * mask, "mask": mask}
+    for k in ("center_x", "center_y", "width", "height"):
+        fields[k] = torch.from_numpy(rng.random((M, N)).astype(np.float32)) * mask
+    feats = layout_features(enc, fields, Runtime(torch.float32), batch_rows=256)
+    ref = O.fidnet_extract(sd, "layout_encoer", {k: v for k, v in fields.items()})
+    torch.testing.assert_close(feats.cpu(), ref, atol=2e-4, rtol=1e-4)
+
+    K, top_k = 32, 16
+    ids = list(range(50))
+    table = {i: rng.choice(M, K, replace=False).tolist() for i in ids}
+    scores = {i: np.sort(rng.random(K).astype(np.float32))[::-1].copy() for i in ids}
+    out = rerank_tables(table, scores, feats, top_k, "mmr", lam=0.5, chunk=16)
+    f = ref.numpy().astype(np.float64)
+    for i in ids:
+        p = f[table[i]]
+        nrm = np.linalg.norm(p, axis=1)
+        cos = (p @ p.T) / np.maximum(nrm[:, None] * nrm[None, :], 1e-8)
+        local = maximal_marginal_relevance(scores[i], cos, 0.5, top_k, "similarity")
+        assert out[i] == np.asarray(table[i])[local].tolist()
+    rnd = rerank_tables(table, None, feats, top_k, "random")
+    assert all(len(set(v)) == top_k and set(v) <= set(table[i]) for i, v in rnd.items())
