@@ -21,6 +21,17 @@ template <> struct V4<bf16> {
     static __device__ __forceinline__ void store(bf16* p, const float (&v)[4]) { bf16x4 t; for (int i = 0; i < 4; ++i) t[i] = (bf16)v[i]; *reinterpret_cast<bf16x4*>(p) = t; }
 };
 
+template <typename T> struct VL;  // 16 bytes of consecutive elements
+template <> struct VL<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { V4<float>::load(p, v); }
+};
+template <> struct VL<bf16> {
+    static constexpr int N = 8;
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ void load(const bf16* p, float (&v)[8]) { const bf16x8 t = *reinterpret_cast<const bf16x8*>(p); for (int i = 0; i < 8; ++i) v[i] = (float)t[i]; }
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -150,38 +161,40 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const T* __restr
 // ---------------------------------------------------------------------------------------------
 // column sums over rows of a [rows, cols] matrix (bias gradients): out[c] += sum_r x[r][c]
 // ---------------------------------------------------------------------------------------------
-// thread (tx, ty): 4 consecutive columns (8 / 16 B loads), rows ty, ty+RPI, ... of its row chunk; TPR = threads per row
+// thread (tx, ty): one 16-byte vector of consecutive columns, rows ty, ty+RPI, ... of its row chunk; TPR = threads per row
 template <typename T, int TPR>
 __global__ __launch_bounds__(256) void colsum4_kernel(const T* __restrict__ x, int64_t ld, float* __restrict__ out, int rows, int cols, int rows_per_wg) {
-    constexpr int RPI = 256 / TPR;
-    __shared__ float red[RPI][TPR * 4];
+    constexpr int RPI = 256 / TPR, N = VL<T>::N;
+    __shared__ float red[RPI][TPR * N];
     const int tx = threadIdx.x % TPR, ty = threadIdx.x / TPR;
-    const int c = (blockIdx.x * TPR + tx) * 4;
+    const int c = (blockIdx.x * TPR + tx) * N;
     const int r0 = blockIdx.y * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    float s[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) s[i] = 0.f;
     if (c < cols) {
         int r = r0 + ty;
-        for (; r + 3 * RPI < r1; r += 4 * RPI) {   // four independent loads in flight
-            float v[4][4];
+        for (; r + 3 * RPI < r1; r += 4 * RPI) {   // four independent 16-byte loads in flight
+            float v[4][N];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) V4<T>::load(x + (int64_t)(r + u * RPI) * ld + c, v[u]);
+            for (int u = 0; u < 4; ++u) VL<T>::load(x + (int64_t)(r + u * RPI) * ld + c, v[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s[i] += v[u][i];
+                for (int i = 0; i < N; ++i) s[i] += v[u][i];
         }
         for (; r < r1; r += RPI) {
-            float v[4];
-            V4<T>::load(x + (int64_t)r * ld + c, v);
+            float v[N];
+            VL<T>::load(x + (int64_t)r * ld + c, v);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s[i] += v[i];
+            for (int i = 0; i < N; ++i) s[i] += v[i];
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) red[ty][tx * 4 + i] = s[i];
+    for (int i = 0; i < N; ++i) red[ty][tx * N + i] = s[i];
     __syncthreads();
-    for (int j = threadIdx.x; j < TPR * 4; j += 256) {
-        const int cc = blockIdx.x * TPR * 4 + j;
+    for (int j = threadIdx.x; j < TPR * N; j += 256) {
+        const int cc = blockIdx.x * TPR * N + j;
         if (cc < cols) {
             float t = 0.f;
 #pragma unroll
@@ -492,12 +505,15 @@ extern "C" int ralf_colsum(int dtype, const void* x, int64_t ld, float* out, int
     RALF_REQUIRE(x && out && rows > 0 && cols > 0, "colsum: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int esz = dtype == RALF_F32 ? 4 : 2;
-    if (cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % (4 * esz)) == 0) {   // vector path: 4 columns per thread
-        const int c4 = cols / 4;
-        const int tpr = c4 >= 64 ? 64 : c4 >= 32 ? 32 : 16;
-        const int cb = ceil_div(c4, tpr), rpi = 256 / tpr;
-        int rchunks = 1024 / cb;
-        if (rchunks < 1) rchunks = 1;
+    const int vw = 16 / esz;
+    if (cols % vw == 0 && ld % vw == 0 && ((uintptr_t)x % 16) == 0) {   // vector path: 16 bytes of columns per thread
+        const int cv = cols / vw;
+        const int tpr = cv >= 64 ? 64 : cv >= 32 ? 32 : 16;
+        const int cb = ceil_div(cv, tpr), rpi = 256 / tpr;
+        // one fp32 atomic per column per workgroup: same-address atomics run at ~19 G/s, so the row chunks are sized for
+        // <= ~32 k atomics in total (1024 chunks on a [16384, 1024] input spent 14 us in atomics alone)
+        int rchunks = 32768 / (cols > 0 ? cols : 1);
+        rchunks = rchunks < 16 ? 16 : (rchunks > 256 ? 256 : rchunks);
         int rpw = ceil_div(rows, rchunks);
         if (rpw < rpi * 4) rpw = rpi * 4;
         rchunks = ceil_div(rows, rpw);
