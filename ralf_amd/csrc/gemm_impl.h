@@ -298,6 +298,36 @@ __device__ __forceinline__ u32x4 load_vec(const T* __restrict__ p, const KParams
     return *reinterpret_cast<u32x4*>(tmp);
 }
 
+// im2col column (kh, kw, c) of a staged vector: loop-invariant for the weight-gradient gather (GATHER == 2), where
+// the gathered operand's COLUMNS are fixed per thread and its rows (pixels) advance with k
+struct ColInfo { int c, kh, kw; bool ok; };
+__device__ __forceinline__ ColInfo col_info(const KParams& P, int col, int ncols) {
+    ColInfo ci;
+    int t;
+    P.fd_sc.divmod((uint32_t)col, t, ci.c);
+    P.fd_kw.divmod((uint32_t)t, ci.kh, ci.kw);
+    ci.ok = col < ncols;
+    return ci;
+}
+template <typename T>
+__device__ __forceinline__ u32x4 load_vec_cols(const T* __restrict__ p, const KParams& P, const RowInfo& r, const ColInfo& ci) {
+    const RalfConvGeom& g = P.d.g;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    if (!r.ok || !ci.ok) return z;
+    int sy, sx;
+    if (g.mode == 0) { sy = r.y0 + ci.kh; sx = r.x0 + ci.kw; }
+    else {
+        const int ty = r.y0 - ci.kh, tx = r.x0 - ci.kw;
+        if (ty < 0 || tx < 0) return z;
+        int ry, rx;
+        P.fd_st.divmod((uint32_t)ty, sy, ry);
+        P.fd_st.divmod((uint32_t)tx, sx, rx);
+        if (ry | rx) return z;
+    }
+    if ((unsigned)sy >= (unsigned)g.SH || (unsigned)sx >= (unsigned)g.SW) return z;
+    return *reinterpret_cast<const u32x4*>(p + r.base + ((int64_t)sy * g.SW + sx) * g.SC + ci.c);
+}
+
 // staging registers -> LDS tile.  KC: [rows][LDK] (k-contiguous source), else [BK][LDR] (row-contiguous source)
 template <typename T, bool KC, int NV, int RV, int LDR>
 __device__ __forceinline__ void lds_stage(T* l, const u32x4 (&regs)[NV], int tid) {
@@ -360,6 +390,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
 
     u32x4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];   // two staging register sets: prefetch distance 2 k-tiles
     RowInfo ia[NVA], ib[NVB];
+    ColInfo cb[NVB];
+    if constexpr (GATHER == 2) {
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) cb[i] = col_info(P, n0 + ((tid + 256 * i) % RVB) * VEC, d.N);
+    }
     // PMC (SQ_ACTIVE_INST_ANY ~ 84 % of the kernel, MFMA busy 10 %) showed this kernel is instruction-issue bound:
     // the interior fast path keeps one pointer per staging vector and advances it by a constant per k-tile.
     // Rows beyond M/N are clamped to the last valid row (their results are never stored).
@@ -411,7 +446,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
             if (BKC) rb[i] = load_vec<T, false>(Bp, P, ib[i], k0 + (v % KV) * VEC, kend, b_al);
             else {
                 const RowInfo r = row_info<GATHER == 2>(P, k0 + v / RVB, kend, d.ldb);
-                rb[i] = load_vec<T, GATHER == 2>(Bp, P, r, n0 + (v % RVB) * VEC, d.N, b_al);
+                if constexpr (GATHER == 2) rb[i] = load_vec_cols<T>(Bp, P, r, cb[i]);
+                else rb[i] = load_vec<T, false>(Bp, P, r, n0 + (v % RVB) * VEC, d.N, b_al);
             }
         }
         }
