@@ -29,13 +29,6 @@ template <> struct V4<bf16> {
     static __device__ __forceinline__ void store(bf16* p, float4 v) { bf16x4 t; t[0] = (bf16)v.x; t[1] = (bf16)v.y; t[2] = (bf16)v.z; t[3] = (bf16)v.w; *reinterpret_cast<bf16x4*>(p) = t; }
 };
 
-__device__ __forceinline__ uint32_t rng24(uint64_t seed, uint64_t call, uint64_t idx) {  // same generator as pointwise.hip
-    uint64_t z = seed + call * 0x9E3779B97F4A7C15ull + idx * 0xD1B54A32D192ED03ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (uint32_t)(z >> 40);
-}
 
 constexpr int TILE = 128;  // keys (or queries) staged per block iteration
 constexpr int SL = 32;     // slice of the tile owned by one wave
@@ -121,8 +114,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const RalfAttnDesc d) {
                         l += p;
                         float pd = p;
                         if (d.p_drop > 0.f) {
-                            const uint64_t idx = (((uint64_t)b * d.H + h) * d.Sq + qi) * d.Sk + (kbase + j0 + j);
-                            pd = rng24(seed, d.call_id, idx) >= thr ? p * inv_keep : 0.f;
+                            const uint32_t rk = attn_rowkey(seed, d.call_id, ((uint64_t)b * d.H + h) * d.Sq + qi);
+                            pd = attn_rng24(rk, (uint32_t)(kbase + j0 + j)) >= thr ? p * inv_keep : 0.f;
                         }
                         const float* vr = Vs + (wave * SL + j0 + j) * DH;
 #pragma unroll
@@ -231,8 +224,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const RalfAttnDesc d) 
                 const bool masked = key >= d.Sk || (d.causal && key > qi) || (kpm && kpm[key]);
                 const float p = masked ? 0.f : __expf(s - lse);
                 if (d.p_drop > 0.f) {
-                    const uint64_t idx = (((uint64_t)b * d.H + h) * d.Sq + qi) * d.Sk + key;
-                    dp = rng24(seed, d.call_id, idx) >= thr ? dp * inv_keep : 0.f;
+                    const uint32_t rk = attn_rowkey(seed, d.call_id, ((uint64_t)b * d.H + h) * d.Sq + qi);
+                    dp = attn_rng24(rk, (uint32_t)key) >= thr ? dp * inv_keep : 0.f;
                 }
                 const float ds = p * (dp - delta);
 #pragma unroll
@@ -322,8 +315,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const RalfAttnDesc d)
                 const float p = masked ? 0.f : __expf(s - Ls[wave * SL + j]);
                 float pd = p;
                 if (d.p_drop > 0.f) {
-                    const uint64_t idx = (((uint64_t)b * d.H + h) * d.Sq + qi) * d.Sk + kj;
-                    const bool keep = rng24(seed, d.call_id, idx) >= thr;
+                    const uint32_t rk = attn_rowkey(seed, d.call_id, ((uint64_t)b * d.H + h) * d.Sq + qi);
+                    const bool keep = attn_rng24(rk, (uint32_t)kj) >= thr;
                     pd = keep ? p * inv_keep : 0.f;
                     dp = keep ? dp * inv_keep : 0.f;
                 }

@@ -22,13 +22,6 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
-__device__ __forceinline__ uint32_t rng24(uint64_t seed, uint64_t call, uint64_t idx) {  // same generator as pointwise.hip
-    uint64_t z = seed + call * 0x9E3779B97F4A7C15ull + idx * 0xD1B54A32D192ED03ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (uint32_t)(z >> 40);
-}
 
 constexpr int KT = 64;  // rows of the streamed operand staged per iteration (keys in fwd/dQ, queries in dK/dV)
 
@@ -90,6 +83,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
     const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
     const uint32_t thr = (uint32_t)(d.p_drop * 16777216.f);
     const float inv_keep = 1.f / (1.f - d.p_drop);
+    const uint32_t rowkey = d.p_drop > 0.f ? attn_rowkey(seed, d.call_id, ((uint64_t)b * d.H + h) * d.Sq + qi) : 0u;   // once per query row
     const bool active = q0 < d.Sq;  // wave-uniform
 
     bf16x8 qf[DH / 32];
@@ -142,8 +136,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
                     float pd = p[j];
                     if (d.p_drop > 0.f) {
                         const int key = t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3);
-                        const uint64_t idx = (((uint64_t)b * d.H + h) * d.Sq + qi) * d.Sk + key;
-                        pd = rng24(seed, d.call_id, idx) >= thr ? pd * inv_keep : 0.f;
+                        pd = attn_rng24(rowkey, (uint32_t)key) >= thr ? pd * inv_keep : 0.f;
                     }
                     pf[j] = (bf16)pd;
                 }
@@ -190,6 +183,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const RalfAttnDesc d) {
     const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
     const uint32_t thr = (uint32_t)(d.p_drop * 16777216.f);
     const float inv_keep = 1.f / (1.f - d.p_drop);
+    const uint32_t rowkey = d.p_drop > 0.f ? attn_rowkey(seed, d.call_id, ((uint64_t)b * d.H + h) * d.Sq + qi) : 0u;   // once per query row
     const bool active = q0 < d.Sq;
     const int64_t stat = ((int64_t)b * d.H + h) * d.Sq + qi;
 
@@ -236,8 +230,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const RalfAttnDesc d) {
                     const float p = masked ? 0.f : __expf(s[j >> 2][j & 3] * d.scale - lse);
                     float dpv = dp[j >> 2][j & 3];
                     if (d.p_drop > 0.f) {
-                        const uint64_t idx = (((uint64_t)b * d.H + h) * d.Sq + qi) * d.Sk + key;
-                        dpv = rng24(seed, d.call_id, idx) >= thr ? dpv * inv_keep : 0.f;
+                        dpv = attn_rng24(rowkey, (uint32_t)key) >= thr ? dpv * inv_keep : 0.f;
                     }
                     dsf[j] = (bf16)(p * (dpv - delta));
                 }
@@ -267,6 +260,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
     __shared__ __attribute__((aligned(16))) bf16 Qs[KT * L<DH>::LD];
     __shared__ __attribute__((aligned(16))) bf16 Gs[KT * L<DH>::LD];
     __shared__ float Ls[KT], Ds[KT];
+    __shared__ uint32_t Rk[KT];   // per-query dropout row keys of the staged query tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y;
     const int k0 = blockIdx.x * 64 + wave * 16, kj = k0 + (lane & 15);
@@ -299,6 +293,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
             const int qi = t0 + threadIdx.x;
             Ls[threadIdx.x] = qi < d.Sq ? d.lse[stat0 + qi] : 0.f;
             Ds[threadIdx.x] = qi < d.Sq ? d.delta[stat0 + qi] : 0.f;
+            if (d.p_drop > 0.f) Rk[threadIdx.x] = attn_rowkey(seed, d.call_id, ((uint64_t)b * d.H + h) * d.Sq + qi);
         }
         __syncthreads();
         // causal: a query tile entirely before this wave's first key sees none of its keys
@@ -325,8 +320,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
                     const float p = masked ? 0.f : __expf(s[j >> 2][j & 3] * d.scale - Ls[ql]);
                     float pd = p, dpv = dp[j >> 2][j & 3];
                     if (d.p_drop > 0.f) {
-                        const uint64_t idx = (((uint64_t)b * d.H + h) * d.Sq + qi) * d.Sk + kj;
-                        const bool keep = rng24(seed, d.call_id, idx) >= thr;
+                        const bool keep = attn_rng24(Rk[ql], (uint32_t)kj) >= thr;
                         pd = keep ? p * inv_keep : 0.f;
                         dpv = keep ? dpv * inv_keep : 0.f;
                     }

@@ -28,3 +28,23 @@ inline int check_launch(const char* what) {
     } while (0)
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Attention-probability dropout mask (all attention kernels, forward and backward, VALU and MFMA variants):
+// keep(b, h, q, key) = attn_rng24(attn_rowkey(seed, call, (b*H + h)*Sq + q), key) >= p * 2^24.
+// The 64-bit mix runs once per query ROW (lane-invariant in the per-query kernels, staged through LDS in the per-key
+// kernels); each element then costs one 32-bit integer mix.  The single-level 64-bit hash per element (three 64-bit
+// multiplies = ~10 quarter-rate v_mul instructions) was most of the attention kernels' time at S = 256.
+__device__ __forceinline__ uint32_t attn_rowkey(uint64_t seed, uint64_t call, uint64_t row) {
+    uint64_t z = seed + call * 0x9E3779B97F4A7C15ull + row * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 32) ^ (uint32_t)z;
+}
+__device__ __forceinline__ uint32_t attn_rng24(uint32_t rowkey, uint32_t key) {
+    uint32_t x = rowkey ^ (key * 0x9E3779B1u);
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x >> 8;
+}
