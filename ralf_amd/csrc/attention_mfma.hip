@@ -23,6 +23,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
 
+// Workgroup -> (tile, head, batch): one linear grid, remapped so the row tiles of ONE (batch, head) get consecutive
+// virtual ids on ONE XCD (hardware deals workgroups round-robin over the 8 XCDs): they stream the same K/V (or Q/dO)
+// rows, which then come from that XCD's L2 instead of being fetched from HBM once per tile.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+struct WgId { int tile, h, b; };
+__device__ __forceinline__ WgId wg_id(int ntiles, int H) {
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    WgId w;
+    w.tile = vid % ntiles;
+    const int t = vid / ntiles;
+    w.h = t % H; w.b = t / H;
+    return w;
+}
+
 constexpr int KT = 64;  // rows of the streamed operand staged per iteration (keys in fwd/dQ, queries in dK/dV)
 
 template <int DH> struct L {
@@ -74,8 +91,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
     __shared__ __attribute__((aligned(16))) bf16 Ks[KT * L<DH>::LD];
     __shared__ __attribute__((aligned(16))) bf16 Vs[KT * L<DH>::LD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 64 + wave * 16, qi = q0 + (lane & 15);
+    const WgId wg = wg_id((d.Sq + 63) / 64, d.H);
+    const int b = wg.b, h = wg.h;
+    const int q0 = wg.tile * 64 + wave * 16, qi = q0 + (lane & 15);
     const bf16* Qp = (const bf16*)d.q + b * d.q_bs + (int64_t)h * DH;
     const bf16* Kp = (const bf16*)d.k + b * d.k_bs + (int64_t)h * DH;
     const bf16* Vp = (const bf16*)d.v + b * d.v_bs + (int64_t)h * DH;
@@ -171,8 +189,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const RalfAttnDesc d) {
     __shared__ __attribute__((aligned(16))) bf16 Ks[KT * L<DH>::LD];
     __shared__ __attribute__((aligned(16))) bf16 Vs[KT * L<DH>::LD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 64 + wave * 16, qi = q0 + (lane & 15);
+    const WgId wg = wg_id((d.Sq + 63) / 64, d.H);
+    const int b = wg.b, h = wg.h;
+    const int q0 = wg.tile * 64 + wave * 16, qi = q0 + (lane & 15);
     const bool qok = qi < d.Sq;
     const bf16* Qp = (const bf16*)d.q + b * d.q_bs + (int64_t)h * DH;
     const bf16* Kp = (const bf16*)d.k + b * d.k_bs + (int64_t)h * DH;
@@ -262,8 +281,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
     __shared__ float Ls[KT], Ds[KT];
     __shared__ uint32_t Rk[KT];   // per-query dropout row keys of the staged query tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int k0 = blockIdx.x * 64 + wave * 16, kj = k0 + (lane & 15);
+    const WgId wg = wg_id((d.Sk + 63) / 64, d.H);
+    const int b = wg.b, h = wg.h;
+    const int k0 = wg.tile * 64 + wave * 16, kj = k0 + (lane & 15);
     const bool kok = kj < d.Sk;
     const bf16* Qp = (const bf16*)d.q + b * d.q_bs + (int64_t)h * DH;
     const bf16* Kp = (const bf16*)d.k + b * d.k_bs + (int64_t)h * DH;
@@ -353,13 +373,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
 
 // called from attention.hip for dtype == RALF_BF16 (descriptor already validated)
 int ralf_attention_fwd_mfma(const RalfAttnDesc& d, hipStream_t st) {
-    const dim3 grid(ceil_div(d.Sq, 64), d.H, d.B);
+    const dim3 grid(ceil_div(d.Sq, 64) * d.H * d.B);
     if (d.dh == 32) hipLaunchKernelGGL((attn_fwd_mfma<32>), grid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL((attn_fwd_mfma<64>), grid, dim3(256), 0, st, d);
     return ralf::check_launch("attention_fwd_mfma");
 }
 int ralf_attention_bwd_mfma(const RalfAttnDesc& d, hipStream_t st) {
-    const dim3 gq(ceil_div(d.Sq, 64), d.H, d.B), gk(ceil_div(d.Sk, 64), d.H, d.B);
+    const dim3 gq(ceil_div(d.Sq, 64) * d.H * d.B), gk(ceil_div(d.Sk, 64) * d.H * d.B);
     if (d.dh == 32) {
         hipLaunchKernelGGL((attn_bwd_dq_mfma<32>), gq, dim3(256), 0, st, d);
         hipLaunchKernelGGL((attn_bwd_dkv_mfma<32>), gk, dim3(256), 0, st, d);
