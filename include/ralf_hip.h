@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 2
+#define RALF_ABI_VERSION 3
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -138,11 +138,14 @@ int ralf_bn_batch_stats(int dtype, const void* x, const float* gamma, const floa
 int ralf_bn_stats_from_partials(const float* partials, int nrows, const float* gamma, const float* beta, float* running_mean, float* running_var,
                                 int64_t* num_batches_tracked, float* mean, float* rstd, float* scale, float* shift, int64_t M, int C,
                                 float eps, float momentum, float* workspace, void* stream);
-int ralf_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, int64_t M, int C, int relu, void* stream);
-int ralf_bn_bwd_reduce(int dtype, const void* x, const void* dy, const void* y, const float* mean, const float* rstd, float* s1, float* s2,
-                       int64_t M, int C, int relu, float* workspace, void* stream);
-int ralf_bn_bwd_apply(int dtype, const void* x, const void* dy, const void* y, const float* mean, const float* rstd, const float* gamma,
-                      const float* s1, const float* s2, void* dx, void* dres, int64_t M, int C, int relu, void* stream);
+/* relu_mask (optional, M*C/8 bytes; bit i of byte j <-> element 8j+i of the [M,C] tensor) is written by bn_apply when relu and read by
+ * the backward kernels INSTEAD of y (1/16 of the bytes); without it they test y > 0 (y required then). */
+int ralf_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, uint8_t* relu_mask,
+                  int64_t M, int C, int relu, void* stream);
+int ralf_bn_bwd_reduce(int dtype, const void* x, const void* dy, const void* y, const uint8_t* relu_mask, const float* mean, const float* rstd,
+                       float* s1, float* s2, int64_t M, int C, int relu, float* workspace, void* stream);
+int ralf_bn_bwd_apply(int dtype, const void* x, const void* dy, const void* y, const uint8_t* relu_mask, const float* mean, const float* rstd,
+                      const float* gamma, const float* s1, const float* s2, void* dx, void* dres, int64_t M, int C, int relu, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Gather / pointwise kernels (ralf_amd/csrc/pointwise.hip)

@@ -57,9 +57,9 @@ SIGNATURES.update({
     "ralf_bn_finalize": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp]),
     "ralf_bn_batch_stats": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, vp, vp]),
     "ralf_bn_stats_from_partials": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, vp, vp]),
-    "ralf_bn_apply": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
-    "ralf_bn_bwd_reduce": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]),
-    "ralf_bn_bwd_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "ralf_bn_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "ralf_bn_bwd_reduce": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]),
+    "ralf_bn_bwd_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "ralf_embed_fwd": (i32, [i32, vp, vp, vp, vp, i64, i32, i32, f32, vp]),
     "ralf_embed_bwd": (i32, [i32, vp, vp, vp, i64, i32, f32, vp]),
     "ralf_dropout": (i32, [i32, vp, vp, vp, i64, f32, vp, u64, vp]),

@@ -226,10 +226,17 @@ template <typename T> struct VW;
 template <> struct VW<float> {
     static constexpr int N = 4;
     static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { V4<float>::load(p, v); }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { V4<float>::store(p, v); }
 };
 template <> struct VW<bf16> {
     static constexpr int N = 8;
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ void store(bf16* p, const float (&v)[8]) {
+        bf16x8 t;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
+        *reinterpret_cast<bf16x8*>(p) = t;
+    }
     static __device__ __forceinline__ void load(const bf16* p, float (&v)[8]) {
         const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
@@ -244,7 +251,7 @@ template <> struct VW<bf16> {
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         float* __restrict__ part, int64_t M, int C, int relu) {
+                                                         float* __restrict__ part, int64_t M, int C, int relu, const uint8_t* __restrict__ mask) {
     constexpr int NV = VW<T>::N, UN = 4;
     __shared__ float red[2][256][NV];
     const int cv = C / NV;                       // channel vectors per row
@@ -261,15 +268,27 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
         for (int i = 0; i < NV; ++i) { mu[i] = MODE == 1 ? mean[c0 + i] : 0.f; rs[i] = MODE == 1 ? rstd[c0 + i] : 1.f; }
         const int64_t stride = (int64_t)gridDim.x * rpi;
         for (int64_t r0 = (int64_t)blockIdx.x * rpi + ty; r0 < M; r0 += stride * UN) {
-            float xv[UN][NV], gv[UN][NV], yv[UN][NV];
+            float xv[UN][NV], gv[UN][NV];
+            uint32_t mb[UN];   // ReLU mask bits of this vector (bit i = element i kept)
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 const int64_t r = r0 + u * stride;
+                mb[u] = 0xFFu;
                 if (r < M) {
                     VW<T>::load(x + r * C + c0, xv[u]);
                     if (MODE == 1) {
                         VW<T>::load(dy + r * C + c0, gv[u]);
-                        if (relu) VW<T>::load(y + r * C + c0, yv[u]);
+                        if (relu) {
+                            const int64_t L = r * C + c0;
+                            if (mask) mb[u] = (uint32_t)mask[L >> 3] >> (NV == 8 ? 0 : (int)(L & 4));
+                            else {
+                                float yv[NV];
+                                VW<T>::load(y + L, yv);
+                                mb[u] = 0u;
+#pragma unroll
+                                for (int i = 0; i < NV; ++i) mb[u] |= (yv[i] > 0.f ? 1u : 0u) << i;
+                            }
+                        }
                     }
                 }
             }
@@ -280,7 +299,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
                     for (int i = 0; i < NV; ++i) {
                         if (MODE == 0) { a1[i] += xv[u][i]; a2[i] += xv[u][i] * xv[u][i]; }
                         else {
-                            const float g = (relu && !(yv[u][i] > 0.f)) ? 0.f : gv[u][i];
+                            const float g = ((mb[u] >> i) & 1u) ? gv[u][i] : 0.f;
                             a1[i] += g; a2[i] += g * (xv[u][i] - mu[i]) * rs[i];
                         }
                     }
@@ -402,29 +421,41 @@ __global__ __launch_bounds__(256) void bn_partial_fold_kernel(const float* __res
     }
 }
 
-// y = relu?( x*scale + shift (+ res) )
+// y = relu?( x*scale + shift (+ res) ); 8 consecutive elements per thread.  relu_mask (optional, 1 bit per element, bit i of
+// byte j <-> element 8j+i): the backward kernels read it instead of y (1/16 of the bytes).
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                        const T* __restrict__ res, T* __restrict__ y, int64_t total4, int C, int relu) {
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (int64_t)gridDim.x * 256) {
-        const int c0 = (int)((e * 4) % C);
-        float xv[4], sc[4], sh[4], o[4];
-        V4<T>::load(x + e * 4, xv);
-        V4<float>::load(scale + c0, sc);
-        V4<float>::load(shift + c0, sh);
+                                                        const T* __restrict__ res, T* __restrict__ y, uint8_t* __restrict__ relu_mask,
+                                                        int64_t total8, int C, int relu) {
+    constexpr int NV = VW<T>::N, H = 8 / NV;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total8; e += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)((e * 8) % C);
+        uint32_t bits = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = xv[i] * sc[i] + sh[i];
-        if (res) {
-            float rv[4];
-            V4<T>::load(res + e * 4, rv);
+        for (int h = 0; h < H; ++h) {
+            float xv[NV], o[NV], sc[NV], sh[NV];
+            VW<T>::load(x + e * 8 + h * NV, xv);
+            VW<float>::load(scale + c0 + h * NV, *reinterpret_cast<float (*)[4]>(&sc[0]));
+            VW<float>::load(shift + c0 + h * NV, *reinterpret_cast<float (*)[4]>(&sh[0]));
+            if constexpr (NV == 8) {
+                VW<float>::load(scale + c0 + 4, *reinterpret_cast<float (*)[4]>(&sc[4]));
+                VW<float>::load(shift + c0 + 4, *reinterpret_cast<float (*)[4]>(&sh[4]));
+            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] += rv[i];
+            for (int i = 0; i < NV; ++i) o[i] = xv[i] * sc[i] + sh[i];
+            if (res) {
+                float rv[NV];
+                VW<T>::load(res + e * 8 + h * NV, rv);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) o[i] += rv[i];
+            }
+            if (relu) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) { bits |= (o[i] > 0.f ? 1u : 0u) << (h * NV + i); o[i] = fmaxf(o[i], 0.f); }
+            }
+            VW<T>::store(y + e * 8 + h * NV, o);
         }
-        if (relu) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = fmaxf(o[i], 0.f);
-        }
-        V4<T>::store(y + e * 4, o);
+        if (relu && relu_mask) relu_mask[e] = (uint8_t)bits;
     }
 }
 
@@ -433,13 +464,17 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ s1, const float* __restrict__ s2, T* __restrict__ dx, T* __restrict__ dres,
-                                                            int64_t total4, int C, float invM, int relu) {
+                                                            int64_t total4, int C, float invM, int relu, const uint8_t* __restrict__ mask) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (int64_t)gridDim.x * 256) {
         const int c0 = (int)((e * 4) % C);
         float xv[4], g[4], mu[4], rs[4], gm[4], a1[4], a2[4], o[4];
         V4<T>::load(x + e * 4, xv);
         V4<T>::load(dy + e * 4, g);
-        if (relu) {
+        if (relu && mask) {
+            const uint32_t mb = (uint32_t)mask[e >> 1] >> (int)((e & 1) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] = ((mb >> i) & 1u) ? g[i] : 0.f;
+        } else if (relu) {
             float yv[4];
             V4<T>::load(y + e * 4, yv);
 #pragma unroll
@@ -552,7 +587,7 @@ extern "C" int ralf_bn_stats(int dtype, const void* x, float* s1, float* s2, int
     int gx, gy;
     RALF_REQUIRE(bn_reduce_geom(dtype, M, C, &gx, &gy) == 0, "bn_stats: C=%d unsupported (needs C/vec a power of two <= 256 or a multiple of 256)", C);
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, nullptr, nullptr, nullptr, nullptr, workspace, M, C, 0));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, nullptr, nullptr, nullptr, nullptr, workspace, M, C, 0, nullptr));
     hipLaunchKernelGGL(bn_partial_sum_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, workspace, gx, C, s1, s2);
     return ralf::check_launch("bn_stats");
 }
@@ -573,7 +608,7 @@ extern "C" int ralf_bn_batch_stats(int dtype, const void* x, const float* gamma,
     int gx, gy;
     RALF_REQUIRE(bn_reduce_geom(dtype, M, C, &gx, &gy) == 0, "bn_batch_stats: C=%d unsupported (needs C/vec a power of two <= 256 or a multiple of 256)", C);
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, nullptr, nullptr, nullptr, nullptr, workspace, M, C, 0));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, nullptr, nullptr, nullptr, nullptr, workspace, M, C, 0, nullptr));
     hipLaunchKernelGGL(bn_partial_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, workspace, gx, gamma, beta, running_mean, running_var,
                        num_batches_tracked, mean, rstd, scale, shift, M, C, eps, momentum);
     return ralf::check_launch("bn_batch_stats");
@@ -596,29 +631,30 @@ extern "C" int ralf_bn_stats_from_partials(const float* partials, int nrows, con
     return ralf::check_launch("bn_stats_from_partials");
 }
 
-extern "C" int ralf_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, int64_t M, int C, int relu, void* stream) {
-    RALF_REQUIRE(x && scale && shift && y && C % 4 == 0, "bn_apply: bad arguments");
-    const int64_t total4 = M * C / 4;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(total4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale, shift, (const T*)res, (T*)y, total4, C, relu));
+extern "C" int ralf_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, uint8_t* relu_mask,
+                             int64_t M, int C, int relu, void* stream) {
+    RALF_REQUIRE(x && scale && shift && y && C % 8 == 0, "bn_apply: bad arguments (C %% 8 == 0)");
+    const int64_t total8 = M * C / 8;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(total8, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale, shift, (const T*)res, (T*)y, relu_mask, total8, C, relu));
     return ralf::check_launch("bn_apply");
 }
 
 /* backward reductions: s1 += sum g, s2 += sum g*xhat; g = dy * (y>0) when relu; workspace as ralf_bn_stats */
-extern "C" int ralf_bn_bwd_reduce(int dtype, const void* x, const void* dy, const void* y, const float* mean, const float* rstd, float* s1, float* s2,
-                                  int64_t M, int C, int relu, float* workspace, void* stream) {
-    RALF_REQUIRE(x && dy && mean && rstd && s1 && s2 && workspace && (!relu || y), "bn_bwd_reduce: bad arguments");
+extern "C" int ralf_bn_bwd_reduce(int dtype, const void* x, const void* dy, const void* y, const uint8_t* relu_mask, const float* mean, const float* rstd,
+                                  float* s1, float* s2, int64_t M, int C, int relu, float* workspace, void* stream) {
+    RALF_REQUIRE(x && dy && mean && rstd && s1 && s2 && workspace && (!relu || y || relu_mask), "bn_bwd_reduce: bad arguments");
     int gx, gy;
     RALF_REQUIRE(bn_reduce_geom(dtype, M, C, &gx, &gy) == 0, "bn_bwd_reduce: C=%d unsupported", C);
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 1>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, workspace, M, C, relu));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 1>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, workspace, M, C, relu, relu_mask));
     hipLaunchKernelGGL(bn_partial_sum_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, workspace, gx, C, s1, s2);
     return ralf::check_launch("bn_bwd_reduce");
 }
 
-extern "C" int ralf_bn_bwd_apply(int dtype, const void* x, const void* dy, const void* y, const float* mean, const float* rstd, const float* gamma,
-                                 const float* s1, const float* s2, void* dx, void* dres, int64_t M, int C, int relu, void* stream) {
-    RALF_REQUIRE(x && dy && mean && rstd && gamma && s1 && s2 && dx && (!relu || y), "bn_bwd_apply: bad arguments");
+extern "C" int ralf_bn_bwd_apply(int dtype, const void* x, const void* dy, const void* y, const uint8_t* relu_mask, const float* mean, const float* rstd,
+                                 const float* gamma, const float* s1, const float* s2, void* dx, void* dres, int64_t M, int C, int relu, void* stream) {
+    RALF_REQUIRE(x && dy && mean && rstd && gamma && s1 && s2 && dx && (!relu || y || relu_mask), "bn_bwd_apply: bad arguments");
     const int64_t total4 = M * C / 4;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(total4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, s1, s2, (T*)dx, (T*)dres, total4, C, 1.f / (float)M, relu));
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(total4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, s1, s2, (T*)dx, (T*)dres, total4, C, 1.f / (float)M, relu, relu_mask));
     return ralf::check_launch("bn_bwd_apply");
 }

@@ -513,20 +513,21 @@ class BatchNormFn(Function):
         x2 = x.contiguous().view(-1, shp[-1])
         if partials is not None and partials.numel() == 0:
             partials = None
-        y, mean, rstd = ops.bn_forward(x2, g.detach(), b.detach(), rm, rv, training, relu, res.contiguous().view(-1, shp[-1]) if res is not None else None,
-                                       counter=counter, partials=partials)
-        ctx.save_for_backward(x2, y, g, mean, rstd)
+        y, mean, rstd, mask = ops.bn_forward(x2, g.detach(), b.detach(), rm, rv, training, relu, res.contiguous().view(-1, shp[-1]) if res is not None else None,
+                                             counter=counter, partials=partials, want_mask=True)
+        # backward reads x, dy and the 1-bit ReLU mask (not y: 1/16 of the bytes, twice per backward)
+        ctx.save_for_backward(x2, mask if relu else None, g, mean, rstd)
         ctx.beta, ctx.rt = b, rt
         ctx.cfg = (relu, res is not None, training, shp)
         return y.view(shp)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, y, g, mean, rstd = ctx.saved_tensors
+        x2, mask, g, mean, rstd = ctx.saved_tensors
         relu, has_res, training, shp = ctx.cfg
         gg, gb = ctx.rt.gview(g), ctx.rt.gview(ctx.beta)
         into = (gg, gb) if (gg is not None and gb is not None and training) else None
-        dx, dg, db, dres = ops.bn_backward(x2, dy.contiguous().view(-1, shp[-1]), y, g.detach(), mean, rstd, relu, has_res, training, into=into)
+        dx, dg, db, dres = ops.bn_backward(x2, dy.contiguous().view(-1, shp[-1]), None, g.detach(), mean, rstd, relu, has_res, training, into=into, mask=mask)
         if into is not None:
             dg = db = None
         return dx.view(shp), dg, db, None, None, (dres.view(shp) if has_res else None), None, None, None, None, None

@@ -229,7 +229,7 @@ def colstats_buffer(M, N, device):
     return torch.empty((M + 63) // 64, 2, N, dtype=torch.float32, device=device)
 
 
-def bn_forward(x2d, gamma, beta, running_mean, running_var, training, relu, res, eps=1e-5, momentum=0.1, counter=None, partials=None):
+def bn_forward(x2d, gamma, beta, running_mean, running_var, training, relu, res, eps=1e-5, momentum=0.1, counter=None, partials=None, want_mask=False):
     """counter: the module's num_batches_tracked (int64 scalar tensor), bumped on the device in training mode.
     partials: column statistics the producing GEMM already wrote (ops.gemm(colstats=...)): no pass over x for the statistics."""
     M, C = x2d.shape
@@ -246,11 +246,15 @@ def bn_forward(x2d, gamma, beta, running_mean, running_var, training, relu, res,
         _call("ralf_bn_finalize", None, None, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
               _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), M, C, eps, momentum, 0)
     y = torch.empty_like(x2d)
-    _call("ralf_bn_apply", dt, _p(x2d), _p(out[2]), _p(out[3]), _p(res), _p(y), M, C, int(relu))
+    # ReLU mask bits (1/16 of y's bytes): what the backward kernels read instead of y
+    mask = torch.empty(M * C // 8, dtype=torch.uint8, device=dev) if (relu and want_mask) else None
+    _call("ralf_bn_apply", dt, _p(x2d), _p(out[2]), _p(out[3]), _p(res), _p(y), _p(mask), M, C, int(relu))
+    if want_mask:
+        return y, out[0], out[1], mask
     return y, out[0], out[1]
 
 
-def bn_backward(x2d, dy, y, gamma, mean, rstd, relu, want_dres, training=True, into=None):
+def bn_backward(x2d, dy, y, gamma, mean, rstd, relu, want_dres, training=True, into=None, mask=None):
     """training: batch-statistics backward.  eval: statistics are constants -> dx = gamma*rstd*g
     (the same apply kernel with zero reduction terms); dgamma/dbeta are the same sums either way."""
     M, C = x2d.shape
@@ -260,11 +264,11 @@ def bn_backward(x2d, dy, y, gamma, mean, rstd, relu, want_dres, training=True, i
     else:
         st = torch.zeros(2, C, dtype=torch.float32, device=x2d.device)
         s = (st[0], st[1])
-    _call("ralf_bn_bwd_reduce", dt, _p(x2d), _p(dy), _p(y), _p(mean), _p(rstd), _p(s[0]), _p(s[1]), M, C, int(relu), _p(workspace(256 * 2 * C * 4, x2d.device)))
+    _call("ralf_bn_bwd_reduce", dt, _p(x2d), _p(dy), _p(y), _p(mask), _p(mean), _p(rstd), _p(s[0]), _p(s[1]), M, C, int(relu), _p(workspace(256 * 2 * C * 4, x2d.device)))
     dx = torch.empty_like(x2d)
     dres = torch.empty_like(x2d) if want_dres else None
     t = s if training else (torch.zeros_like(s[0]), torch.zeros_like(s[1]))
-    _call("ralf_bn_bwd_apply", dt, _p(x2d), _p(dy), _p(y), _p(mean), _p(rstd), _p(gamma), _p(t[0]), _p(t[1]), _p(dx), _p(dres), M, C, int(relu))
+    _call("ralf_bn_bwd_apply", dt, _p(x2d), _p(dy), _p(y), _p(mask), _p(mean), _p(rstd), _p(gamma), _p(t[0]), _p(t[1]), _p(dx), _p(dres), M, C, int(relu))
     return dx, s[1], s[0], dres  # dx, dgamma, dbeta, dres
 
 

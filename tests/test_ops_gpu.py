@@ -169,6 +169,14 @@ def test_batchnorm(dtype, C, M):
     close(dx, x.grad, dtype, frac=fr, **btol); close(dres, res.grad, dtype, frac=fr)
     close(dg, g.grad, dtype, frac=0.99 if dtype == torch.bfloat16 else 1.0, atol=0.5 if dtype == torch.bfloat16 else 2e-3, rtol=5e-2)
     close(db, b.grad, dtype, frac=0.99 if dtype == torch.bfloat16 else 1.0, atol=0.5 if dtype == torch.bfloat16 else 2e-3, rtol=5e-2)
+    # the 1-bit ReLU mask written by the forward replaces y in the backward: identical gradients, bit for bit
+    y2, _, _, mask = ops.bn_forward(xd, g.detach().cuda(), b.detach().cuda(), rm.cuda(), rv.cuda(), True, True, resd, want_mask=True)
+    assert torch.equal(y2, yd) and mask.numel() == M * C // 8
+    bits = ((mask.view(-1, 1) >> torch.arange(8, device="cuda", dtype=torch.uint8)) & 1).view(M, C).bool()
+    assert torch.equal(bits, yd > 0)
+    dx2, dg2, db2, dres2 = ops.bn_backward(xd, go.to(dtype).cuda(), None, g.detach().cuda(), mean, rstd, True, True, mask=mask)
+    assert torch.equal(dx2, dx) and torch.equal(dres2, dres)
+    close(dg2, dg, torch.float32, atol=1e-4, rtol=1e-5); close(db2, db, torch.float32, atol=1e-4, rtol=1e-5)
     # eval mode uses the running statistics
     ye = F.batch_norm(x.detach(), rm_ref, rv_ref, g.detach(), b.detach(), False, 0.1, 1e-5)
     yed, _, _ = ops.bn_forward(xd, g.detach().cuda(), b.detach().cuda(), rm_ref.cuda(), rv_ref.cuda(), False, False, None)
