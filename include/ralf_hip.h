@@ -123,7 +123,7 @@ int ralf_colsum(int dtype, const void* x, int64_t ld, float* out, int rows, int 
  * eval : bn_finalize(training=0) uses the running statistics.
  * apply: y = relu?(x*scale + shift (+ res)).   backward: bn_bwd_reduce (s1 = sum g, s2 = sum g*xhat,
  * g = dy*(y>0) when relu) then bn_bwd_apply -> dx (and dres = g).  dgamma = s2, dbeta = s1. */
-#define RALF_BN_MAX_PARTIALS 256 /* reduction workspace = RALF_BN_MAX_PARTIALS * 2 * C floats */
+#define RALF_BN_MAX_PARTIALS 1024 /* reduction workspace = RALF_BN_MAX_PARTIALS * 2 * C floats */
 int ralf_bn_stats(int dtype, const void* x, float* s1, float* s2, int64_t M, int C, float* workspace, void* stream);
 int ralf_bn_finalize(const float* s1, const float* s2, const float* gamma, const float* beta, float* running_mean, float* running_var,
                      float* mean, float* rstd, float* scale, float* shift, int64_t M, int C, float eps, float momentum, int training, void* stream);

@@ -570,6 +570,7 @@ extern "C" int ralf_colsum(int dtype, const void* x, int64_t ld, float* out, int
 }
 
 /* sums s1,s2 (fp32 [C]) must be zero on entry. */
+static const int BN_ROW_GROUPS = [] { const char* e = getenv("RALF_BN_GROUPS"); int v = e ? atoi(e) : 512; return v < 1 ? 1 : (v > RALF_BN_MAX_PARTIALS ? RALF_BN_MAX_PARTIALS : v); }();   // tuning knob
 static int bn_reduce_geom(int dtype, int64_t M, int C, int* gx, int* gy) {
     const int nv = dtype == RALF_F32 ? 4 : 8;
     if (C % nv) return -1;
@@ -577,7 +578,7 @@ static int bn_reduce_geom(int dtype, int64_t M, int C, int* gx, int* gy) {
     if (!(((cv & (cv - 1)) == 0 && cv <= 256) || cv % 256 == 0)) return -1;
     const int tpr = cv < 256 ? cv : 256, rpi = 256 / tpr;
     *gy = ceil_div(cv, 256);
-    *gx = grid_for(M, rpi * 16, RALF_BN_MAX_PARTIALS);   // <= 256 workgroups along rows: one per CU, 4 x 16 B per thread in flight
+    *gx = grid_for(M, rpi * 16, BN_ROW_GROUPS);   // workgroups along rows (2 per CU), 4 x 16 B of every operand per thread in flight
     return 0;
 }
 

@@ -238,10 +238,10 @@ def bn_forward(x2d, gamma, beta, running_mean, running_var, training, relu, res,
     dt = dtype_code(x2d)
     if training and partials is not None:
         _call("ralf_bn_stats_from_partials", _p(partials), partials.shape[0], _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(counter),
-              _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), M, C, eps, momentum, _p(workspace(256 * 2 * C * 4, dev)))
+              _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), M, C, eps, momentum, _p(workspace(1024 * 2 * C * 4, dev)))
     elif training:
         _call("ralf_bn_batch_stats", dt, _p(x2d), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(counter),
-              _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), M, C, eps, momentum, _p(workspace(256 * 2 * C * 4, dev)))
+              _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), M, C, eps, momentum, _p(workspace(1024 * 2 * C * 4, dev)))
     else:
         _call("ralf_bn_finalize", None, None, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
               _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), M, C, eps, momentum, 0)
@@ -264,7 +264,7 @@ def bn_backward(x2d, dy, y, gamma, mean, rstd, relu, want_dres, training=True, i
     else:
         st = torch.zeros(2, C, dtype=torch.float32, device=x2d.device)
         s = (st[0], st[1])
-    _call("ralf_bn_bwd_reduce", dt, _p(x2d), _p(dy), _p(y), _p(mask), _p(mean), _p(rstd), _p(s[0]), _p(s[1]), M, C, int(relu), _p(workspace(256 * 2 * C * 4, x2d.device)))
+    _call("ralf_bn_bwd_reduce", dt, _p(x2d), _p(dy), _p(y), _p(mask), _p(mean), _p(rstd), _p(s[0]), _p(s[1]), M, C, int(relu), _p(workspace(1024 * 2 * C * 4, x2d.device)))
     dx = torch.empty_like(x2d)
     dres = torch.empty_like(x2d) if want_dres else None
     t = s if training else (torch.zeros_like(s[0]), torch.zeros_like(s[1]))

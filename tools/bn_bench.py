@@ -13,8 +13,8 @@ for (M, C) in [(1048576, 64), (262144, 64), (262144, 256), (65536, 128), (65536,
     x = torch.randn(M, C, device="cuda").bfloat16(); dy = torch.randn_like(x); y = torch.relu(x)
     s = torch.zeros(2, C, device="cuda"); mean = torch.zeros(C, device="cuda"); rstd = torch.ones(C, device="cuda"); g = torch.ones(C, device="cuda")
     L = ops._lib.lib(); P = ops._p
-    t0 = timeit(lambda: ops._call("ralf_bn_stats", 1, P(x), P(s[0]), P(s[1]), M, C, P(ops.workspace(256*2*C*4, x.device))))
-    t1 = timeit(lambda: ops._call("ralf_bn_bwd_reduce", 1, P(x), P(dy), P(y), None, P(mean), P(rstd), P(s[0]), P(s[1]), M, C, 1, P(ops.workspace(256*2*C*4, x.device))))
+    t0 = timeit(lambda: ops._call("ralf_bn_stats", 1, P(x), P(s[0]), P(s[1]), M, C, P(ops.workspace(1024*2*C*4, x.device))))
+    t1 = timeit(lambda: ops._call("ralf_bn_bwd_reduce", 1, P(x), P(dy), P(y), None, P(mean), P(rstd), P(s[0]), P(s[1]), M, C, 1, P(ops.workspace(1024*2*C*4, x.device))))
     out = torch.empty_like(x)
     t2 = timeit(lambda: ops._call("ralf_bn_apply", 1, P(x), P(g), P(mean), None, P(out), None, M, C, 1))
     t3 = timeit(lambda: ops._call("ralf_bn_bwd_apply", 1, P(x), P(dy), P(y), None, P(mean), P(rstd), P(g), P(s[0]), P(s[1]), P(out), None, M, C, 1))
