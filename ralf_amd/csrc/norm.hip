@@ -459,36 +459,46 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
-// dx = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M);  dres = g (gradient of the fused residual add)
+// dx = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M);  dres = g (gradient of the fused residual add); 8 elements per thread
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ s1, const float* __restrict__ s2, T* __restrict__ dx, T* __restrict__ dres,
-                                                            int64_t total4, int C, float invM, int relu, const uint8_t* __restrict__ mask) {
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (int64_t)gridDim.x * 256) {
-        const int c0 = (int)((e * 4) % C);
-        float xv[4], g[4], mu[4], rs[4], gm[4], a1[4], a2[4], o[4];
-        V4<T>::load(x + e * 4, xv);
-        V4<T>::load(dy + e * 4, g);
-        if (relu && mask) {
-            const uint32_t mb = (uint32_t)mask[e >> 1] >> (int)((e & 1) * 4);
+                                                            int64_t total8, int C, float invM, int relu, const uint8_t* __restrict__ mask) {
+    constexpr int NV = VW<T>::N, H = 8 / NV;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total8; e += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)((e * 8) % C);
+        const uint32_t mbyte = (relu && mask) ? (uint32_t)mask[e] : 0xFFu;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) g[i] = ((mb >> i) & 1u) ? g[i] : 0.f;
-        } else if (relu) {
-            float yv[4];
-            V4<T>::load(y + e * 4, yv);
+        for (int h = 0; h < H; ++h) {
+            const int64_t off = e * 8 + h * NV;
+            float xv[NV], g[NV], o[NV];
+            VW<T>::load(x + off, xv);
+            VW<T>::load(dy + off, g);
+            if (relu && mask) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
+                for (int i = 0; i < NV; ++i) g[i] = ((mbyte >> (h * NV + i)) & 1u) ? g[i] : 0.f;
+            } else if (relu) {
+                float yv[NV];
+                VW<T>::load(y + off, yv);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < NV / 4; ++q) {
+                const int c = c0 + h * NV + q * 4;
+                float mu[4], rs[4], gm[4], a1[4], a2[4];
+                V4<float>::load(mean + c, mu); V4<float>::load(rstd + c, rs); V4<float>::load(gamma + c, gm);
+                V4<float>::load(s1 + c, a1); V4<float>::load(s2 + c, a2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float xh = (xv[q * 4 + i] - mu[i]) * rs[i];
+                    o[q * 4 + i] = gm[i] * rs[i] * (g[q * 4 + i] - a1[i] * invM - xh * a2[i] * invM);
+                }
+            }
+            VW<T>::store(dx + off, o);
+            if (dres) VW<T>::store(dres + off, g);
         }
-        V4<float>::load(mean + c0, mu); V4<float>::load(rstd + c0, rs); V4<float>::load(gamma + c0, gm);
-        V4<float>::load(s1 + c0, a1); V4<float>::load(s2 + c0, a2);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float xh = (xv[i] - mu[i]) * rs[i];
-            o[i] = gm[i] * rs[i] * (g[i] - a1[i] * invM - xh * a2[i] * invM);
-        }
-        V4<T>::store(dx + e * 4, o);
-        if (dres) V4<T>::store(dres + e * 4, g);
     }
 }
 
@@ -655,7 +665,8 @@ extern "C" int ralf_bn_bwd_reduce(int dtype, const void* x, const void* dy, cons
 extern "C" int ralf_bn_bwd_apply(int dtype, const void* x, const void* dy, const void* y, const uint8_t* relu_mask, const float* mean, const float* rstd,
                                  const float* gamma, const float* s1, const float* s2, void* dx, void* dres, int64_t M, int C, int relu, void* stream) {
     RALF_REQUIRE(x && dy && mean && rstd && gamma && s1 && s2 && dx && (!relu || y || relu_mask), "bn_bwd_apply: bad arguments");
-    const int64_t total4 = M * C / 4;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(total4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, s1, s2, (T*)dx, (T*)dres, total4, C, 1.f / (float)M, relu, relu_mask));
+    RALF_REQUIRE(C % 8 == 0, "bn_bwd_apply: C %% 8 == 0");
+    const int64_t total8 = M * C / 8;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(total8, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, s1, s2, (T*)dx, (T*)dres, total8, C, 1.f / (float)M, relu, relu_mask));
     return ralf::check_launch("bn_bwd_apply");
 }
