@@ -718,6 +718,8 @@ int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
     const bool ok22 = !d.colstats || d.N % 128 == 0;   // column statistics come from the staged epilogue: every tile interior in n
     if (forced == 22 && ok22) return launch_epi<T, AK, BKC, GATHER, 2, 2>(P, nbatch, st);
     if (forced == 11) return launch_epi<T, AK, BKC, GATHER, 1, 1>(P, nbatch, st);
+    // (128x64 / 64x128 tiles were measured too -- tools/gemm_bench.py on a graph replay: within +-5 % of 64x64 on every
+    //  short-K shape of the model, which are bound by their output / operand streams and a ~5 us launch + tail, not by tile shape)
     const int64_t big = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) * d.splitk * nbatch;
     const int kspan = ceil_div(d.K, d.splitk);
     if (ok22 && d.N > 64 && d.M > 64 && kspan >= 1024 && big >= 512) return launch_epi<T, AK, BKC, GATHER, 2, 2>(P, nbatch, st);

@@ -8,13 +8,25 @@ from ralf_amd import ops  # noqa: E402
 
 
 def timeit(fn, iters=30):
+    """seconds per call, measured on a hipGraph replay of `iters` back-to-back launches (eager launches of kernels
+    shorter than ~18 us measure the Python/ctypes call rate, not the kernel)."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        fn()
+    g.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e-3
