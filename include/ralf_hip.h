@@ -165,6 +165,16 @@ int ralf_sum_all(int dtype, const void* x, float* out, int64_t rows, int cols, i
 int ralf_copy2d(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t rows, int cols, int64_t lds, int64_t ldd, int accumulate, void* stream);
 int ralf_permute4(int src_dtype, int dst_dtype, const void* in, void* out, int d0, int d1, int d2, int d3, int64_t s0, int64_t s1, int64_t s2, int64_t s3,
                   int valid3, void* stream);
+/* the same for a table of jobs in ONE launch (per-step re-layout of all 3x3 convolution weights: Runtime.lp shadows).
+ * jobs_device: njobs RalfPermuteJob records in DEVICE memory; job j runs on workgroups [first_block[j], first_block[j+1])
+ * (ascending, first_block[0] = 0), total_blocks = grid size. */
+typedef struct RalfPermuteJob {
+    const void* in; void* out;
+    int64_t s0, s1, s2, s3;
+    int d0, d1, d2, d3;
+    int valid3, src_dtype, dst_dtype, first_block;
+} RalfPermuteJob;
+int ralf_permute4_batched(const RalfPermuteJob* jobs_device, int njobs, int total_blocks, void* stream);
 /* ResNet stem max-pool 3x3/s2/p1 (NHWC) with saved arg-max; FPN nearest up-sampling fused with the lateral add */
 int ralf_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int8_t* arg, int B, int H, int W, int C, void* stream);
 int ralf_maxpool3x3s2_bwd(int dtype, const void* dy, const int8_t* arg, void* dx, int B, int H, int W, int C, void* stream);

@@ -19,6 +19,11 @@ class RalfConvGeom(ctypes.Structure):
     _fields_ = [(n, i32) for n in ("RH", "RW", "SH", "SW", "SC", "KH", "KW", "stride", "pad", "mode")]
 
 
+class RalfPermuteJob(ctypes.Structure):
+    _fields_ = ([("in_", vp), ("out", vp)] + [(n, i64) for n in ("s0", "s1", "s2", "s3")]
+                + [(n, i32) for n in ("d0", "d1", "d2", "d3", "valid3", "src_dtype", "dst_dtype", "first_block")])
+
+
 class RalfGemmDesc(ctypes.Structure):
     _fields_ = (
         [(n, vp) for n in ("A", "B", "C", "C2", "bias", "res", "aux")]
@@ -31,6 +36,7 @@ class RalfGemmDesc(ctypes.Structure):
 
 
 SIGNATURES.update({
+    "ralf_permute4_batched": (i32, [vp, i32, i32, vp]),
     "ralf_gemm_workspace_bytes": (sz, [ctypes.POINTER(RalfGemmDesc)]),
     "ralf_gemm": (i32, [ctypes.POINTER(RalfGemmDesc), vp, sz, vp]),
 })

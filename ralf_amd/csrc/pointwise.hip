@@ -168,6 +168,34 @@ __global__ void permute4_kernel(const TS* __restrict__ in, TD* __restrict__ out,
     }
 }
 
+// many permute4 jobs in ONE launch (the per-step re-layout of every 3x3 convolution weight: ~40 launches of a few
+// microseconds each otherwise); jobs[] lives in device memory, job j owns workgroups [first_block[j], first_block[j+1])
+template <typename TS, typename TD>
+__device__ __forceinline__ void permute4_job(const RalfPermuteJob& J, int blk, int nblk) {
+    const TS* in = (const TS*)J.in;
+    TD* out = (TD*)J.out;
+    const int64_t total = (int64_t)J.d0 * J.d1 * J.d2 * J.d3;
+    for (int64_t e = (int64_t)blk * 256 + threadIdx.x; e < total; e += (int64_t)nblk * 256) {
+        int64_t t = e;
+        const int i3 = (int)(t % J.d3); t /= J.d3;
+        const int i2 = (int)(t % J.d2); t /= J.d2;
+        const int i1 = (int)(t % J.d1); t /= J.d1;
+        const int i0 = (int)t;
+        st(out, e, i3 < J.valid3 ? ld(in, i0 * J.s0 + i1 * J.s1 + i2 * J.s2 + i3 * J.s3) : 0.f);
+    }
+}
+__global__ __launch_bounds__(256) void permute4_batched_kernel(const RalfPermuteJob* __restrict__ jobs, int njobs) {
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;   // njobs is small (tens): linear scan
+    const RalfPermuteJob J = jobs[j];
+    const int nblk = (j + 1 < njobs ? jobs[j + 1].first_block : (int)gridDim.x) - J.first_block;
+    const int blk = (int)blockIdx.x - J.first_block;
+    if (J.src_dtype == RALF_F32 && J.dst_dtype == RALF_F32) permute4_job<float, float>(J, blk, nblk);
+    else if (J.src_dtype == RALF_F32) permute4_job<float, bf16>(J, blk, nblk);
+    else if (J.dst_dtype == RALF_F32) permute4_job<bf16, float>(J, blk, nblk);
+    else permute4_job<bf16, bf16>(J, blk, nblk);
+}
+
 // 3x3 stride-2 pad-1 max pooling, NHWC; arg = window position (kh*3+kw) of the FIRST maximum.
 // One thread owns VEC consecutive channels of one pixel (16-byte accesses, 32-bit index math):
 // the scalar one-element-per-thread version ran at 1/8 of the HBM rate.
@@ -444,6 +472,11 @@ extern "C" int ralf_permute4(int src_dtype, int dst_dtype, const void* in, void*
     else if (dst_dtype == RALF_F32) hipLaunchKernelGGL((permute4_kernel<bf16, float>), g, dim3(256), 0, ST, (const bf16*)in, (float*)out, d0, d1, d2, d3, s0, s1, s2, s3, valid3);
     else hipLaunchKernelGGL((permute4_kernel<bf16, bf16>), g, dim3(256), 0, ST, (const bf16*)in, (bf16*)out, d0, d1, d2, d3, s0, s1, s2, s3, valid3);
     return ralf::check_launch("permute4");
+}
+extern "C" int ralf_permute4_batched(const RalfPermuteJob* jobs_device, int njobs, int total_blocks, void* stream) {
+    RALF_REQUIRE(jobs_device && njobs > 0 && total_blocks >= njobs, "permute4_batched: bad arguments");
+    hipLaunchKernelGGL(permute4_batched_kernel, dim3(total_blocks), dim3(256), 0, ST, jobs_device, njobs);
+    return ralf::check_launch("permute4_batched");
 }
 extern "C" int ralf_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int8_t* arg, int B, int H, int W, int C, void* stream) {
     RALF_REQUIRE(x && y && arg && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "maxpool_fwd: bad arguments (C %% 8 == 0)");

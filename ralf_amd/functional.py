@@ -29,6 +29,7 @@ class Runtime:
         self._shadow: dict = {}   # id(param) -> persistent low-precision view kept current by the fused optimizer
         self.direct_grads = False  # engine mode: parameter gradients are accumulated by the kernels straight into p.grad
         self._wtoken = 0          # bumped when weights are rewritten behind torch's version counters
+        self._conv_table = None   # batched re-layout job table of the convolution weights (refresh_conv_shadows)
         self.overlap = False      # engine mode: weight / bias gradient kernels run on a side stream, off the data-gradient chain
         self._side: list = []
         self.n_side = int(os.environ.get("RALF_SIDE_STREAMS", "1"))
@@ -86,6 +87,37 @@ class Runtime:
         if self.direct_grads and p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous():
             return p.grad
         return None
+
+    def refresh_conv_shadows(self, weights):
+        """re-layout shadows ([Co][kh][kw][Ci] and [Ci][kh][kw][Co]) of all k>1 convolution weights in ONE launch when the
+        masters changed (every optimizer step): ~40 separate few-microsecond launches otherwise.  `weights`: the conv
+        weight Parameters (OIHW fp32).  lp(w, "ohwi"/"ikwo") then hits the cache."""
+        ws = [w for w in weights if w.dim() == 4 and w.shape[2] > 1]
+        if not ws:
+            return
+        sig = tuple((w.data_ptr(), w._version) for w in ws)
+        st = self._conv_table
+        if st is None or st["ptrs"] != tuple(w.data_ptr() for w in ws) or st["dtype"] != self.dtype:
+            jobs, outs = [], []
+            for w in ws:
+                Co, Ci, kh, kw = w.shape
+                cip = (Ci + 7) // 8 * 8
+                o1 = torch.empty(Co, kh, kw, cip, dtype=self.dtype, device=w.device)
+                o2 = torch.empty(Ci, kh, kw, Co, dtype=self.dtype, device=w.device)
+                jobs.append((w.detach(), o1, (Co, kh, kw, cip), (Ci * kh * kw, kw, 1, kh * kw), Ci))
+                jobs.append((w.detach(), o2, (Ci, kh, kw, Co), (kh * kw, kw, 1, Ci * kh * kw), Co))
+                outs.append((o1, o2))
+            table, n, blocks = ops.permute4_table(jobs, ws[0].device)
+            st = self._conv_table = {"ptrs": tuple(w.data_ptr() for w in ws), "dtype": self.dtype, "table": table, "n": n, "blocks": blocks,
+                                     "outs": outs, "sig": None, "token": None}
+        if st["sig"] == sig and st["token"] == self._wtoken:
+            return
+        ops.permute4_batched(st["table"], st["n"], st["blocks"])
+        for w, (o1, o2) in zip(ws, st["outs"]):
+            stamp = ((w._version, self._wtoken), w.data_ptr())
+            self._lp[(id(w), "ohwi", self.dtype)] = (stamp[0], stamp[1], o1, weakref.ref(w))
+            self._lp[(id(w), "ikwo", self.dtype)] = (stamp[0], stamp[1], o2, weakref.ref(w))
+        st["sig"], st["token"] = sig, self._wtoken
 
     # low-precision / re-laid-out shadows of fp32 master weights, refreshed when the master changes
     def lp(self, w: torch.Tensor, kind: str = "cast") -> torch.Tensor:

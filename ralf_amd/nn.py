@@ -398,6 +398,7 @@ class ResnetBackbone(nn.Module):
         self.fpn_conv33 = Conv(256, 256, 3, 1, 1, bias=True)
         self.proj = Conv(512, d_model, 1, bias=True)
         self._pos_cache: dict = {}
+        self._conv_weights = None
 
     def pos_table(self, h, w, d, rt, device):
         key = (h, w, d, rt.dtype, str(device))
@@ -411,6 +412,9 @@ class ResnetBackbone(nn.Module):
         # NCHW fp32 [B,4,H,W] -> NHWC compute dtype, channels zero-padded to 8 (16-byte pixel vectors)
         x = ops.permute4(img.contiguous().float(), (B, H, W, 8), (4 * H * W, W, 1, H * W), 4, rt.dtype)
         b = self.body
+        if self._conv_weights is None:
+            self._conv_weights = [m.weight for m in self.modules() if isinstance(m, Conv)]
+        rt.refresh_conv_shadows(self._conv_weights)   # all 3x3 / 7x7 weight re-layouts of this step in one launch
         x, st = b.conv1(x, rt, stats=True)
         x = b.bn1(x, rt, True, stats=st)
         x = RF.MaxPoolFn.apply(x)

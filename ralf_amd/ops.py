@@ -192,6 +192,28 @@ def permute4(x, out_dims, strides, valid3, dtype, out=None):
     return out
 
 
+def permute4_table(jobs, device):
+    """jobs: list of (src, dst, out_dims, strides, valid3) -> (device table, njobs, total_blocks) for permute4_batched."""
+    from ._abi import RalfPermuteJob
+
+    arr = (RalfPermuteJob * len(jobs))()
+    blk = 0
+    for j, (src, dst, dims, strides, valid3) in enumerate(jobs):
+        assert dst.is_contiguous() and tuple(dst.shape) == tuple(dims)
+        r = arr[j]
+        r.in_, r.out = src.data_ptr(), dst.data_ptr()
+        r.s0, r.s1, r.s2, r.s3 = strides
+        r.d0, r.d1, r.d2, r.d3 = dims
+        r.valid3, r.src_dtype, r.dst_dtype, r.first_block = valid3, dtype_code(src), dtype_code(dst), blk
+        blk += max(1, min(256, (dst.numel() + 2047) // 2048))
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    return raw, len(jobs), blk
+
+
+def permute4_batched(table, njobs, total_blocks):
+    _call("ralf_permute4_batched", _p(table), njobs, total_blocks)
+
+
 def maxpool_fwd(x):
     B, H, W, C = x.shape
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
