@@ -25,6 +25,7 @@ STEP_GFLOP_PER_SAMPLE = {10: 50.1, 32: 56.4}
 ENCDEC_GFLOP_PER_SAMPLE = {10: 15.98, 32: 22.29}   # everything except ResNet-50 + FPN
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+TRAIN_TRAFFIC_BYTES = 45.6e9  # HBM bytes per train step (B=64): rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, profiles/r01l_train_step_hbm_traffic_pmc.txt
 KNN_TRAFFIC_BYTES = 446.2e6  # HBM bytes per knn_scores launch at nq=16: rocprofv3 FETCH_SIZE x2 (gfx950) + WRITE_SIZE, profiles/r01_knn_pmc.txt
 
 
@@ -235,9 +236,14 @@ def main():
             "config": {"workload": f"RALF PKU (configs/ralf_pku), k=16 retrieval, task uncond, 256x256 canvases, N={N} elements (S={5 * N}), batch {B} per GPU, dropout 0.1, AdamW+clip 0.1",
                        "tokens_per_step_per_gpu": tokens, "samples_per_s": world * B / (ms * 1e-3), "parallelism": f"dp{world}", "hip_graph": not a.no_graph, "final_loss": final_loss},
             "roofline": {"bound": "mfma", "achieved": flops / (gpu_ms * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flops / (gpu_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
-                         "note": f"whole train step: {flops / 1e12:.3f} algorithmic TFLOP per launch (SURVEY 8d: {STEP_GFLOP_PER_SAMPLE.get(N, 50.1)} GFLOP/sample x {B}) / {gpu_ms:.2f} ms (HIP events); per-kernel split in profiles/"},
+                         "frac": flops / (gpu_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                         "traffic": TRAIN_TRAFFIC_BYTES if (B == 64 and N == 10 and a.dtype.startswith("b")) else None,
+                         "note": f"whole train step: {flops / 1e12:.3f} algorithmic TFLOP per launch (SURVEY 8d: {STEP_GFLOP_PER_SAMPLE.get(N, 50.1)} GFLOP/sample x {B}) / {gpu_ms:.2f} ms (HIP events); per-kernel split in profiles/; traffic = PMC HBM bytes per step (31.1 GB fetched + 14.5 GB written = " + f"{TRAIN_TRAFFIC_BYTES / (gpu_ms * 1e-3) / 1e12:.2f} TB/s): the step is as much HBM- as MFMA-shaped"},
         }
+        if out["roofline"]["traffic"]:   # the same step seen from the memory side (measured PMC bytes / measured time)
+            gbs = TRAIN_TRAFFIC_BYTES / (gpu_ms * 1e-3) / 1e9
+            out["roofline_hbm_view"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": TRAIN_TRAFFIC_BYTES,
+                                        "note": "whole train step: measured HBM-side bytes per step (not algorithmic bytes) / step time; BatchNorm passes and the 1x1 convolutions of layer1/2 dominate"}
         if world == 1 and not a.skip_split:
             t_ed = bench_encdec(device, N, B, a.dtype, a.steps, not a.no_graph)
             f_ed = ENCDEC_GFLOP_PER_SAMPLE.get(N, 15.98) * 1e9 * B
