@@ -1,0 +1,231 @@
+"""Decoding-space restriction for the `relation` task (host integer / set logic).
+
+Behavioural mirror of `TransformerSortByDictRelationConstraint`
+(image2layout/train/models/layoutformerpp/relation_restriction.py:354-825; originally LayoutFormer++'s
+constrained decoding): for one sample decoded token by token it returns, per step, the vocabulary mask
+(True = forbidden) implied by the label order and by the size / location relations to already generated
+elements (or to the canvas), plus the position to back-track to when the step turns out infeasible.
+
+Written from the reference's observable behaviour (its interval arithmetic, rounding directions, the quirks
+noted inline) as a small table-driven interpreter: every (attribute slot, relation) pair maps to an integer
+interval [lo, hi) of admissible bins; intervals of all constraints on the current element are intersected.
+"""
+from __future__ import annotations
+
+import copy
+from math import ceil, floor
+from typing import List, Optional, Tuple
+
+import torch
+
+from .relationships import REL_SIZE_ALPHA, RELATIVE_RELATION, RelElement, RelLoc, RelSize
+
+TYPE, WIDTH, HEIGHT, CX, CY = range(5)   # attribute slot of a sequence position (position % 5), var_order of the tokenizer
+CANVAS = "canvas"
+
+
+class _State:
+    """progress after a given number of decoded tokens"""
+
+    def __init__(self, num_elements: int):
+        self.num_elements = num_elements
+        self.curr_element = 0
+        self.num_bbox = 0
+        self.pred_labels: list = []
+        self.pred_bbox: list = []   # per element: [w, h, cx, cy] bins decoded so far
+
+    @property
+    def finished(self) -> bool:
+        return self.curr_element == self.num_elements and self.num_bbox >= 4
+
+
+def _nth_occurrence(types: torch.Tensor, label: torch.Tensor, ordinal: int) -> int:
+    return int(torch.nonzero(types == label)[ordinal])
+
+
+class RelationConstraint:
+    def __init__(self, preprocessor):
+        self.pre = preprocessor
+        tok = preprocessor.tokenizer
+        self.nbin = int(tok._num_bin)
+        self.canvas = self.nbin - 1            # bins span [0, nbin-1]
+        self._token_mask = tok.token_mask
+        self.V = self._token_mask.size(-1)
+        # first bin token of every geometric slot; the slot's admissible set ends with the two special tokens
+        self.start = {}
+        for slot in (WIDTH, HEIGHT, CX, CY):
+            nz = self._token_mask[slot].nonzero()
+            lo, hi = int(nz[0]), int(nz[-3]) + 1
+            assert hi - lo == self.nbin
+            self.start[slot] = lo
+        self.ordinal = {e: i for i, e in enumerate(RelElement)}
+        self.history: List[_State] = []
+        self.types: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------------------------------
+    def prepare(self, seq: torch.Tensor) -> list:
+        """constraint-encoder sequence of ONE sample -> per element the list of its constraints:
+        ("canvas", RelLoc) or (relation, index of the EARLIER element it refers to).  Resets the decode history."""
+        pre = self.pre
+        eos = int(torch.argmax((seq == pre.name_to_id("eos")).float()))
+        rsep = int(torch.argmax((seq == pre.name_to_id("relation_sep")).float()))
+        seq = seq[:eos]
+        types = seq[3:rsep][::2]               # labels, `sep` between them; [bos, task, end_of_task] in front
+        self.types = types
+        rel = seq[rsep + 1:]
+        rel = rel[rel != pre.name_to_id("sep")].reshape(-1, 5)
+        n = types.size(0)
+        self.history = [_State(n)]
+        out: list = [[] for _ in range(n)]
+        for label_i, elem_i, rel_id, label_j, elem_j in rel:
+            kind = pre.id_to_name(int(rel_id))
+            pi = _nth_occurrence(types, label_i, self.ordinal[pre.id_to_name(int(elem_i))])
+            if pre.id_to_name(int(label_j)) == CANVAS:
+                out[pi].append((CANVAS, kind))
+                continue
+            pj = _nth_occurrence(types, label_j, self.ordinal[pre.id_to_name(int(elem_j))])
+            if pj > pi:                        # always constrain the LATER element by the earlier one
+                pi, pj, kind = pj, pi, RELATIVE_RELATION[kind]
+            assert pi > pj, f"{pi=} {pj=} {kind=}"
+            out[pi].append((kind, pj))
+        self.label_tokens = [pre.name_to_id(name) for name in pre.tokenizer._label_feature.names]
+        return out
+
+    # ---- admissible bin interval [lo, hi) of one constraint on one attribute slot (None = unconstrained) --------------
+    def _canvas_cy(self, kind, h) -> Tuple[int, int]:
+        cs, half = self.canvas, h / 2
+        if kind == RelLoc.TOP:
+            return ceil(half), floor(cs / 3 - half)
+        if kind == RelLoc.CENTER:
+            return ceil(cs / 3 + half), floor(2 * cs / 3 - half)
+        if kind == RelLoc.BOTTOM:
+            return ceil(2 * cs / 3 + half), floor(cs - half)
+        raise ValueError(f"Unknown rel_type: {kind}")
+
+    def _interval(self, slot, kind, tgt, cur) -> Optional[Tuple[int, int]]:
+        cs, nb = self.canvas, self.nbin
+        if slot == CX:
+            w = cur[0]
+            tw, tcx = tgt[0], tgt[2]
+            if kind == RelLoc.LEFT:
+                return floor(tcx + tw / 2 + w / 2), ceil(cs - w / 2)
+            if kind == RelLoc.RIGHT:
+                return floor(w / 2), ceil(tcx - tw / 2 - w / 2)
+            if kind == RelLoc.CENTER:
+                return ceil(tcx - tw / 2 + w / 2), floor(tcx + tw / 2 - w / 2)
+            return floor(w / 2), ceil(cs - w / 2)
+        if slot == CY:
+            h = cur[1]
+            th, tcy = tgt[1], tgt[3]
+            if kind == RelLoc.TOP:
+                return floor(tcy + th / 2 + h / 2), ceil(cs - h / 2)
+            if kind == RelLoc.BOTTOM:
+                return floor(h / 2), ceil(tcy - th / 2 - h / 2)
+            if kind == RelLoc.CENTER:   # (sic) the reference widens the band by the current height here
+                return ceil(tcy - th / 2 - h / 2), floor(tcy + th / 2 + h / 2)
+            return floor(h / 2), ceil(cs - h / 2)
+        if slot == WIDTH:
+            tw, th, tcx = tgt[0], tgt[1], tgt[2]
+            area = tw * th
+            if kind == RelLoc.LEFT:
+                return 0, ceil(cs - tcx - tw / 2)
+            if kind == RelLoc.RIGHT:
+                return 0, ceil(tcx - tw / 2)
+            if kind == RelLoc.CENTER:
+                return 0, (floor(cs - tcx + tw / 2) if tcx < nb // 2 else floor(tcx + tw / 2))
+            if kind == RelSize.SMALLER:
+                area /= 1 - REL_SIZE_ALPHA
+                return min(ceil(area / cs), cs), ceil(area)
+            if kind == RelSize.LARGER:
+                area /= 1 + REL_SIZE_ALPHA
+                return 0, floor(area / cs)
+            if kind == RelSize.EQUAL:
+                return floor(area / (1 + REL_SIZE_ALPHA) / cs), ceil(area / (1 - REL_SIZE_ALPHA) / cs)
+            return None
+        # HEIGHT
+        w = cur[0]
+        th, tcy = tgt[1], tgt[3]
+        area = tgt[0] * th
+        if kind == RelLoc.TOP:
+            return 0, ceil(tcy - th / 2)
+        if kind == RelLoc.BOTTOM:
+            return 0, floor(tcy - th / 2)
+        if kind == RelLoc.CENTER:
+            return 0, (floor(cs - tcy + th / 2) if tcy < nb // 2 else floor(tcy + th / 2))
+        if kind == RelSize.SMALLER:
+            area /= 1 - REL_SIZE_ALPHA
+            return (cs if w == 0 else min(ceil(area / w), cs)), nb
+        if kind == RelSize.LARGER:
+            area /= 1 + REL_SIZE_ALPHA
+            return 0, (nb if w == 0 else min(floor(area / w), nb))
+        if kind == RelSize.EQUAL:
+            w = 1 if w == 0 else w
+            return floor(area / (1 + REL_SIZE_ALPHA) / w), ceil(area / (1 - REL_SIZE_ALPHA) / w)
+        return None
+
+    @staticmethod
+    def _meet(allowed: set, interval) -> set:
+        """intersection with [lo, hi); an EMPTY interval leaves the set unchanged (the reference's `_intersect`)"""
+        if interval is None:
+            return allowed
+        lo, hi = interval
+        if hi <= lo:
+            return allowed
+        return {b for b in allowed if lo <= b < hi}
+
+    def _mask_from(self, allowed: set, slot: int) -> torch.Tensor:
+        mask = torch.ones(self.V, dtype=torch.bool)
+        if allowed:
+            mask[torch.tensor(sorted(allowed), dtype=torch.long) + self.start[slot]] = False
+        return mask
+
+    # ------------------------------------------------------------------------------------------
+    def __call__(self, token_ids: torch.Tensor, rel_constraints: list):
+        """token_ids [1, L] (bos + L-1 decoded tokens) -> (mask [V] True = forbidden, back-track position or None)"""
+        n_decoded = token_ids.size(1) - 1
+        self.history = self.history[: n_decoded + 1]
+        st = copy.deepcopy(self.history[-1])
+        slot = n_decoded % 5
+        if n_decoded > 0:
+            last = int(token_ids[0, -1])
+            if last in self.label_tokens:
+                st.pred_labels.append(last)
+                st.pred_bbox.append([])
+            else:   # the token of the previous slot, as a bin index (KeyError for a non-label at a type slot, like the reference)
+                st.pred_bbox[-1].append(int(last - self.start[{HEIGHT: WIDTH, CX: HEIGHT, CY: CX, TYPE: CY}[slot]]))
+        back = None
+        if st.finished:
+            mask = torch.ones(self.V, dtype=torch.bool)
+            mask[self.pre.tokenizer.name_to_id("eos")] = False
+            return mask, back            # (a finished state is not recorded)
+        if slot == TYPE:
+            st.curr_element += 1
+            st.num_bbox = 0
+            mask = torch.ones(self.V, dtype=torch.bool)
+            mask[self.types[n_decoded // 5]] = False
+        else:
+            cons = rel_constraints[st.curr_element - 1]
+            cur = st.pred_bbox[-1]
+            if st.curr_element == 1:     # first element: only canvas constraints, and only on cy
+                allowed = set(range(self.nbin))
+                for kind, arg in cons:
+                    if slot == CY and kind == CANVAS:
+                        allowed = self._meet(allowed, self._canvas_cy(arg, cur[1]))
+                mask = self._mask_from(allowed, slot)
+            elif len(cons) == 0:
+                mask = ~self._token_mask[n_decoded].clone()
+            else:
+                allowed = set(range(self.nbin))
+                for kind, arg in cons:
+                    if kind == CANVAS:
+                        back = None      # (the reference overwrites the back-track target with every constraint it visits)
+                        if slot != CY:
+                            continue
+                        allowed = self._meet(allowed, self._canvas_cy(arg, cur[1]))
+                        continue
+                    back = arg * 5 + st.num_bbox + 1
+                    allowed = self._meet(allowed, self._interval(slot, kind, st.pred_bbox[arg], cur))
+                mask = self._mask_from(allowed, slot)
+            st.num_bbox += 1
+        self.history.append(st)
+        return mask, back

@@ -2,8 +2,8 @@
 
 get_condition mirrors image2layout/train/helpers/task.py:45-183; the containers mirror
 image2layout/train/models/common/base_model.py:17-115 (same attribute names, `.to`, `.duplicate`).
-The `relation` task needs the authors' pre-computed relationship table
-(cache/pku_cgl_relationships_dic_using_canvas_sort_label_lexico.pt) and is not available here.
+The `relation` task adds the randomly thinned pairwise relations of helpers/relationships.compute_relation
+(consumes Python's global `random` like the reference).
 """
 from __future__ import annotations
 
@@ -15,6 +15,7 @@ import torch
 from .layout_tokenizer import GEO_KEYS
 
 REFINEMENT_NOISE_STD = 0.01
+EDGE_RATIO = 0.1          # fraction of relations kept by compute_relation (helpers/task.py:18)
 COND_TYPES = ["c", "cwh", "partial", "gt", "refinement", "relation", None, "none", "uncond"]
 VARS = {
     "c": ["label"],
@@ -104,7 +105,8 @@ def get_condition(batch: dict, cond_type: Optional[str] = None, tokenizer=None):
             cond["mask"] = keep
     elif cond_type in ("c", "cwh", "relation"):
         if cond_type == "relation":
-            raise NotImplementedError("relation conditioning needs the authors' relationship table (not shipped)")
+            from .relationships import compute_relation
+            cond.update(compute_relation(batch, edge_ratio=EDGE_RATIO))
         if has_bos:
             attr = (torch.arange(S).view(1, S) - 1) % C
             attr[:, 0] = -1

@@ -10,9 +10,11 @@ seeded run reproduces the reference's sequences.
 from __future__ import annotations
 
 import copy
+import random
 
 import torch
 
+from .relationships import RelElement, RelLoc, RelSize
 from .task import VARS
 
 TASK_TOKENS = ["end_of_task", "label", "label_size", "relationship", "refinement", "completion", "uncondition"]
@@ -36,12 +38,21 @@ class BasePreprocessor:
         self._ids = dict(tokenizer._special_token_name_to_id)
         for i, name in enumerate(TASK_TOKENS + SEP_TOKENS):
             self._ids[name] = tokenizer.N_total + i
+        # relationship vocabulary: element markers A.. (one per element slot), then RelLoc, then RelSize members; the enum
+        # MEMBERS are the keys, like the reference's table entries (task_preprocessor.py:65-87,119-124)
+        rel_tokens = list(RelElement)[: tokenizer.max_seq_length] + list(RelLoc) + list(RelSize)
+        for i, member in enumerate(rel_tokens):
+            self._ids[member] = tokenizer.N_total + len(TASK_TOKENS) + len(SEP_TOKENS) + i
         for i, name in enumerate(tokenizer._label_feature.names):
             self._ids[name] = i
+        self._names = {v: k for k, v in self._ids.items()}
         self.device = torch.device("cpu")
 
     def name_to_id(self, name):
         return self._ids[name]
+
+    def id_to_name(self, idx: int):
+        return self._names[idx]
 
     def tok(self, name, batch):
         return torch.full((batch, 1), self._ids[name], dtype=torch.long, device=self.device)
@@ -129,11 +140,79 @@ class PartialPreprocessor(BasePreprocessor):
         return self.serialise(cond, True)
 
 
-class RelationshipPreprocessor(BasePreprocessor):
-    TASK, VAR = "relationship", VARS["relation"]
+class _RefEnumUnpickler:
+    """pickle module shim for torch.load: the authors' table pickles the reference's enum classes
+    (image2layout.train.helpers.relationships.*); map them onto ralf_amd.helpers.relationships."""
+    import pickle as _pk
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError("relation task needs the authors' relationship table (cache/pku_cgl_relationships_dic_...pt)")
+    class Unpickler(_pk.Unpickler):
+        def find_class(self, module, name):
+            if module.endswith("helpers.relationships"):
+                from . import relationships
+                return getattr(relationships, name)
+            return super().find_class(module, name)
+
+    load = staticmethod(lambda f, **kw: _RefEnumUnpickler.Unpickler(f, **kw).load())
+    __name__ = "pickle"
+
+
+def _load_relationship_table(path: str) -> dict:
+    return torch.load(path, pickle_module=_RefEnumUnpickler, weights_only=False)
+
+
+class RelationshipPreprocessor(BasePreprocessor):
+    """Gen-R (task_preprocessor.py:488-606): [bos, relationship, end_of_task, l1 | l2 | ..., relation_sep,
+    (label_i, elem_i, relation, label_j, elem_j) sep ... eos] with RELATION_SIZE % of the sample's relations drawn by
+    `random.sample`.
+
+    `table`: dict str(data id) -> list of [label name, RelElement, RelLoc | RelSize, label name | "canvas", RelElement | "pad"]
+    (helpers.relationships.relationship_table builds one from layouts), or a path to the authors' torch-saved table.  Like
+    the reference, every list is shuffled once at construction with Python's global `random`."""
+    TASK, VAR = "relationship", VARS["relation"]
+    TABLE_PATH = "cache/pku_cgl_relationships_dic_using_canvas_sort_label_lexico.pt"
+
+    def __init__(self, tokenizer, global_task_embedding: bool = False, RELATION_SIZE: int = 10, table=None):
+        super().__init__(tokenizer, global_task_embedding)
+        self.RELATION_SIZE = RELATION_SIZE
+        if table is None or isinstance(table, str):
+            table = _load_relationship_table(table or self.TABLE_PATH)
+        self.table = {k: random.sample(v, len(v)) for k, v in table.items()}
+        self.label_preprocessor = LabelPreprocessor(tokenizer, global_task_embedding)
+
+    def set_relation_size(self, RELATION_SIZE: int) -> None:
+        self.RELATION_SIZE = RELATION_SIZE
+
+    def __call__(self, cond):
+        ids = cond.id.cpu().tolist() if torch.is_tensor(cond.id) else cond.id
+        relations = [self.table[str(i)] for i in ids]
+        self.split_vars(cond.seq, True)          # consumes the element-shuffle randomness the reference spends here (result unused)
+        lab = self.label_preprocessor(cond)      # ... and shuffles again for the sequence that is kept
+        seq_label, pad_mask = lab["seq"], lab["pad_mask"]
+        self.device = seq_label.device
+        B = seq_label.size(0)
+        if not self.global_task_embedding:
+            seq_label[:, 1] = self._ids[self.TASK]
+        seq_label[seq_label == self._ids["eos"]] = self._ids["relation_sep"]
+        rows = []
+        for b in range(B):
+            head = seq_label[b][~pad_mask[b]]
+            if len(relations[b]) == 0:
+                rows.append(torch.cat([head, self.tok("eos", 1)[0]]))
+                continue
+            k = max(len(relations[b]) * self.RELATION_SIZE // 100, 1)
+            picked = random.sample(relations[b], k)
+            rel = torch.tensor([[self._ids[e] for e in r] for r in picked], device=self.device)
+            rel = torch.cat([rel, self.tok("sep", rel.size(0))], dim=1).view(-1)
+            rel[-1] = self._ids["eos"]
+            rows.append(torch.cat([head, rel]))
+        # the output width is the longest row AMONG SAMPLES THAT HAVE RELATIONS (task_preprocessor.py:559-585)
+        longest = max((r.size(0) for r, rl in zip(rows, relations) if len(rl) > 0), default=-1)
+        if longest < 0:
+            raise ValueError("relation task: no sample of the batch has relations (the reference fails here as well)")
+        seq = torch.full((B, longest), self._ids["pad"], dtype=torch.long, device=self.device)
+        for b, r in enumerate(rows):
+            seq[b, : r.size(0)] = r
+        return {"seq": seq, "pad_mask": seq == self._ids["pad"]}
 
 
 PREPROCESSOR = {

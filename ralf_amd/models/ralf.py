@@ -122,7 +122,7 @@ class _GeneratorBase(nn.Module):
         self.dim_feedforward = 4 * d_model
         self.auxilary_task, self.use_multitask, self.global_task_embedding = auxilary_task, use_multitask, global_task_embedding
         assert not global_task_embedding, "global_task_embedding=True is not used by any shipped config"
-        self.preprocessor = PREPROCESSOR[auxilary_task](tokenizer=tokenizer, global_task_embedding=global_task_embedding)
+        self.preprocessor = self._make_preprocessor(auxilary_task)
         self.encoder = RN.ResnetFeatureExtractor(d_model)
         self.transformer_encoder = RN.LayerStack([RN.TransformerEncoderLayer(d_model, self.nhead, self.dim_feedforward, self.dropout, True)
                                                   for _ in range(self.num_layers)])
@@ -134,12 +134,18 @@ class _GeneratorBase(nn.Module):
             self.register_buffer("flag_img", torch.zeros(1).long())
             self.register_buffer("flag_user_const", torch.ones(1).long())
 
+    def _make_preprocessor(self, task):
+        kw = dict(tokenizer=self.tokenizer, global_task_embedding=self.global_task_embedding)
+        if task == "relation":   # `relation_table` (ctor keyword, extension): in-memory table instead of the cache file
+            kw["table"] = getattr(self, "relation_table", None)
+        return PREPROCESSOR[task](**kw)
+
     def set_task_preprocessor(self, task: str) -> None:
         assert task in COND_TYPES
         if not self.use_multitask:
             return
         self.auxilary_task = task
-        self.preprocessor = PREPROCESSOR[task](tokenizer=self.tokenizer, global_task_embedding=self.global_task_embedding)
+        self.preprocessor = self._make_preprocessor(task)
 
     def get_random_task(self) -> str:
         tasks = ["uncond", "c", "cwh", "partial", "refinement", "relation"]
@@ -248,14 +254,14 @@ class _GeneratorBase(nn.Module):
         """`decoder`: optional engine.GraphedDecode that replays the captured device loop."""
         if self.use_multitask:
             self.set_task_preprocessor(cond.task)
-        if cond_type == "relation":
-            raise NotImplementedError("relation decoding needs the authors' relationship table")
+        if cond_type == "relation" and use_backtrack:
+            return self.sample_relation(cond, batch_size=batch_size, sampling_cfg=sampling_cfg, return_violation=return_violation, **kwargs)
         dev = self.device
         B = cond.image.size(0)
         if B == 1 and batch_size and batch_size > 1:
             B = batch_size
             cond.image = cond.image.expand(B, -1, -1, -1).contiguous()
-        enc_in, _ = self._create_encoder_inputs(cond)
+        enc_in, seqc = self._create_encoder_inputs(cond)
         enc_in = {k: ({kk: vv.to(dev) for kk, vv in v.items() if torch.is_tensor(vv)} if isinstance(v, dict) else (v.to(dev) if torch.is_tensor(v) else v))
                   for k, v in enc_in.items()}
         cond_seq = cond.seq.to(dev) if cond.seq is not None else None
@@ -267,7 +273,111 @@ class _GeneratorBase(nn.Module):
         result = self.postprocess({"seq": out_tokens})
         if not return_violation:
             return result
+        if cond_type == "relation":   # restriction without back-tracking: relations are only scored afterwards
+            from ..helpers.relation_restriction import RelationConstraint
+            rc = RelationConstraint(self.preprocessor)
+            return result, self._violation_relation(result, [rc.prepare(seqc["seq"][b].cpu()) for b in range(seqc["seq"].size(0))])
         return result, self._violation(cond_type, cond, out_tokens)
+
+    @torch.no_grad()
+    def sample_relation(self, cond, batch_size: Optional[int] = None, sampling_cfg=None, return_violation: bool = False,
+                        prob_gate: float = 0.3, RELATION_SIZE: int = 10, **kwargs):
+        """Relation-constrained decoding with back-tracking (retrieval_augmented_autoreg.py:336-507): per sample, every step
+        masks the vocabulary by (token mask, forced label, relation constraints); when nothing admissible is left (or only
+        logits below `prob_gate`), the prefix is cut back to the element the violated constraint refers to (random position
+        after three failures at one step), the next draw uses temperature 1.5; > 30 back-tracks restart the sample and after
+        the 4th restart the relation mask is dropped.  Same control flow and `random` consumption as the reference; the
+        decoder runs KV-cached on the device (a cut prefix just rewinds the cache position)."""
+        from ..helpers.relation_restriction import RelationConstraint
+
+        self.preprocessor.set_relation_size(RELATION_SIZE)
+        dev = self.device
+        B = cond.image.size(0)
+        if B == 1 and batch_size and batch_size > 1:
+            B = batch_size
+            cond.image = cond.image.expand(B, -1, -1, -1).contiguous()
+        ids = self.special_token_ids
+        T = self.tokenizer.max_token_length
+        token_mask = self._token_mask_dev(dev)
+        enc_in, seqc = self._create_encoder_inputs(cond)
+        enc_dev = {k: ({kk: vv.to(dev) for kk, vv in v.items() if torch.is_tensor(vv)} if isinstance(v, dict) else (v.to(dev) if torch.is_tensor(v) else v))
+                   for k, v in enc_in.items()}
+        self.rt.to(dev).begin_step()
+        memory = self._encode_into_memory(enc_dev)["memory"]
+        constraint = RelationConstraint(self.preprocessor)
+        restrict = DECODE_SPACE_RESTRICTION["relation"]
+        cond_seq = cond.seq.to(dev)
+        rows, prepared = [], []
+        for b in range(B):
+            cache = RN.decoder_init_cache(self.decoder, memory[b:b + 1].contiguous(), self.rt, T)
+            rel = constraint.prepare(seqc["seq"][b].cpu())
+            seq = torch.full((1, 1), ids["bos"], dtype=torch.long, device=dev)
+            flagged, back_flag, n_back, resets, idx = [], False, 0, 0, 0
+            while True:
+                L = seq.size(1)
+                logits = RN.decoder_step(self.decoder, seq[:, L - 1].contiguous(), L - 1, cache, self.rt,
+                                         (seq == ids["pad"]).to(torch.uint8).contiguous()).float()
+                n_dec = L - 1
+                logits[:, ~token_mask[n_dec]] = NEG_INF
+                logits = restrict(n_dec + 1, cond_seq[b:b + 1], logits, pad_id=ids["pad"], eos_id=ids["eos"], max_length=T)
+                raw = logits.clone()
+                mask, back_idx = constraint(seq.cpu(), rel)
+                logits[:, mask.to(dev)] = NEG_INF
+                pruned_max = torch.where(logits < prob_gate, torch.full_like(logits, NEG_INF), logits).max()
+                if resets > 3:
+                    logits, back_flag = raw, False
+                elif (not back_flag and bool(pruned_max == NEG_INF)) or bool(logits.max() == NEG_INF):
+                    flagged.append(idx)
+                    back_flag = True
+                    idx = back_idx if (back_idx is not None and flagged.count(idx) < 3) else random.randint(2, max(2, idx - 1))
+                    seq = seq[:, :idx]
+                    n_back += 1
+                    if n_back > 30:
+                        flagged, back_flag, n_back = [], False, 0
+                        resets += 1
+                        seq = torch.full((1, 1), ids["bos"], dtype=torch.long, device=dev)
+                        idx = 0
+                    continue
+                temperature = None
+                if back_flag:
+                    back_flag, temperature = False, 1.5
+                nxt = sample_tokens(logits, sampling_cfg, temperature=temperature)
+                seq = torch.cat([seq, nxt], dim=1)
+                if int(nxt) == ids["eos"] or seq.size(1) == T + 1:
+                    break
+                idx += 1
+            # (sic) finished sequences are padded with the literal True (= token 1), retrieval_augmented_autoreg.py:475-483
+            seq = torch.cat([seq, torch.full((1, T + 2 - seq.size(1)), 1, dtype=torch.long, device=dev)], dim=1)
+            rows.append(seq)
+            prepared.append(rel)
+        tokens = torch.cat(rows, dim=0)[:, 1:-1].cpu()
+        result = self.postprocess({"seq": tokens})
+        if not return_violation:
+            return result
+        return result, self._violation_relation(result, prepared)
+
+    @staticmethod
+    def _violation_relation(result: dict, prepared: list) -> dict:
+        """layoutformerpp/violate.py:143-236: re-detect every prepared relation on the decoded boxes."""
+        from ..helpers.relationships import (RelLoc, RelSize, detect_loc_relation_between_element_and_canvas, detect_loc_relation_between_elements,
+                                             detect_size_relation)
+
+        total = bad = 0
+        for b, cons in enumerate(prepared):
+            box = lambda i: [result[k][b, i].item() for k in ("center_x", "center_y", "width", "height")]  # noqa: E731
+            bad_b = 0
+            for i, lst in enumerate(cons):
+                for kind, arg in lst:
+                    total += 1
+                    if kind == "canvas":
+                        if detect_loc_relation_between_element_and_canvas(box(i)) != arg:
+                            bad += 1
+                    else:
+                        found = detect_size_relation(box(i), box(arg)) if isinstance(kind, RelSize) else detect_loc_relation_between_elements(box(i), box(arg))
+                        if found != kind:
+                            bad_b += 1
+            bad += bad_b
+        return {"total": total, "viorated": bad}
 
     def _violation(self, cond_type, cond, out_tokens) -> dict:
         """layoutformerpp/violate.py:24-141 for the table-free tasks."""
@@ -305,8 +415,9 @@ class ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg(_GeneratorBas
                  layout_backbone: str = "feature_extractor", use_reference_image: bool = False, freeze_layout_encoder: bool = True,
                  retrieval_backbone: str = "saliency", random_retrieval: bool = False, saliency_k=8, decoder_d_model: int = 256,
                  auxilary_task: Optional[str] = None, use_flag_embedding: bool = True, use_multitask: bool = False, RELATION_SIZE: int = 10,
-                 shared_embedding: bool = False, global_task_embedding: bool = False, compute_dtype="float32", **_ignored):
+                 shared_embedding: bool = False, global_task_embedding: bool = False, compute_dtype="float32", relation_table=None, **_ignored):
         super().__init__()
+        self.relation_table = relation_table   # extension: in-memory relationship table (default: the reference's cache file)
         assert encoder_pos_emb == "sine" and decoder_pos_emb == "layout" and not use_reference_image and not shared_embedding
         assert freeze_layout_encoder is True and saliency_k != "dynamic"
         self._init_runtime(compute_dtype)
@@ -382,8 +493,9 @@ class ConcateAuxilaryTaskAutoreg(_GeneratorBase):
     def __init__(self, features, tokenizer, d_model: int = 256, encoder_pos_emb: str = "sine", decoder_pos_emb: str = "layout",
                  weight_init: bool = False, shared_embedding: bool = False, decoder_num_layers: int = 6, decoder_d_model: int = 256,
                  auxilary_task: Optional[str] = None, use_flag_embedding: bool = True, use_multitask: bool = False, RELATION_SIZE: int = 10,
-                 global_task_embedding: bool = False, compute_dtype="float32", **_ignored):
+                 global_task_embedding: bool = False, compute_dtype="float32", relation_table=None, **_ignored):
         super().__init__()
+        self.relation_table = relation_table
         assert encoder_pos_emb == "sine" and decoder_pos_emb == "layout" and not shared_embedding and decoder_num_layers == 6
         self._init_runtime(compute_dtype)
         self.features = features

@@ -409,9 +409,167 @@ def golden_reranker():
 
 
 
+def _enc_entry(e):
+    """relationship-table entry -> JSON-able [label, elem value, relation value, label | "canvas", elem value | "pad"]"""
+    return [e[0], int(e[1]), int(e[2]), e[3], (e[4] if isinstance(e[4], str) else int(e[4]))]
+
+
+def _enc_constraints(rel):
+    out = []
+    for lst in rel:
+        out.append([[("canvas", int(b)) if a == "canvas" else (int(a), int(b)) for a, b in lst]])
+    return [[list(x) for x in l[0]] for l in out]
+
+
+def golden_relation():
+    """`relation` task (needs a relationship table: synthesised with the reference's own rules and written where the
+    reference looks for it, in a scratch cwd): compute_relation, RelationshipPreprocessor, the per-step constraint
+    masks of TransformerSortByDictRelationConstraint, and end-to-end sample_relation tokens (deterministic sampling)."""
+    import random
+    import tempfile
+
+    from image2layout.train.helpers import relationships as RS
+    from image2layout.train.models.layoutformerpp.relation_restriction import TransformerSortByDictRelationConstraint
+
+    tok = make_tokenizer("pku", 10)
+    names = LABELS["pku"]
+    out, js = {}, {}
+    B = 4
+    batch = synth_batch(41, B, 10, 16, 3)
+    batch["mask"][2, 1:] = False   # a single-element layout: only a canvas relation
+    for k in ("label", "center_x", "center_y", "width", "height"):
+        batch[k][2, 1:] = 0
+    # --- compute_relation (helpers/relationships.py:112-166) ---
+    random.seed(5)
+    cr = RS.compute_relation({k: v for k, v in batch.items() if torch.is_tensor(v)}, edge_ratio=0.5)
+    out["compute_relation"] = {"batch": {k: batch[k] for k in ("label", "mask", "center_x", "center_y", "width", "height")}, **cr}
+    # --- table with the rules of preprocess/precompute_relationship.py:57-126 (restated here with the reference's detectors/enums) ---
+    def build_table(batch):
+        table = {}
+        for b in range(batch["label"].size(0)):
+            seen, uniq = {}, []
+            for lab, m in zip(batch["label"][b].tolist(), batch["mask"][b].tolist()):
+                if not m:
+                    uniq.append(None)
+                    continue
+                seen[lab] = seen.get(lab, 0) + 1
+                uniq.append([names[lab], list(RS.RelElement)[seen[lab] - 1]])
+            valid = [i for i, m in enumerate(batch["mask"][b].tolist()) if m][::-1]
+            box = lambda i: [batch[k][b, i].item() for k in ("center_x", "center_y", "width", "height")]  # noqa: E731
+            loc, size, canvas = [], [], []
+            for pos, i in enumerate(valid):
+                for j in valid[pos + 1:]:
+                    loc.append([*uniq[i], RS.detect_loc_relation_between_elements(box(i), box(j)), *uniq[j]])
+                    size.append([*uniq[i], RS.detect_size_relation(box(i), box(j)), *uniq[j]])
+                canvas.append([*uniq[i], RS.detect_loc_relation_between_element_and_canvas(box(i)), "canvas", "pad"])
+            table[batch["id"][b]] = loc + size + canvas
+        return table
+
+    def drive(fn, seqs, n_iter, seed):
+        """walk the constraint function with random admissible tokens, cuts on infeasible steps and spontaneous cuts"""
+        rng = np.random.default_rng(seed)
+        tm = tok.token_mask
+        steps, cons = {}, {}
+        for b in range(seqs.size(0)):
+            rel = fn.prepare(seqs[b])
+            cons[str(b)] = _enc_constraints(rel)
+            seq = torch.full((1, 1), tok.name_to_id("bos"))
+            rec_mask, rec_back, rec_tok, rec_len = [], [], [], []
+            for it in range(n_iter):
+                mask, back = fn(seq, rel)
+                n_dec = seq.size(1) - 1
+                rec_len.append(n_dec)
+                rec_mask.append(mask.clone())
+                rec_back.append(-1 if back is None else int(back))
+                ok = (~mask) & tm[n_dec]
+                if int(ok.sum()) == 0:             # infeasible: back-track like sample_relation (or cut two tokens)
+                    cut = back if (back is not None and rng.random() < 0.7) else max(2, seq.size(1) - 2)
+                    seq = seq[:, :cut]
+                    rec_tok.append(-1)
+                    continue
+                cand = ok.nonzero().flatten()
+                t = int(cand[int(rng.integers(0, len(cand)))])
+                rec_tok.append(t)
+                seq = torch.cat([seq, torch.tensor([[t]])], dim=1)
+                if t == tok.name_to_id("eos") or seq.size(1) == tok.max_token_length + 1:
+                    break
+                if rng.random() < 0.04 and seq.size(1) > 4:   # spontaneous cut: exercises the history slicing
+                    seq = seq[:, : int(rng.integers(2, seq.size(1)))]
+            steps[f"s{b}"] = {"mask": torch.stack(rec_mask), "back": torch.tensor(rec_back), "token": torch.tensor(rec_tok), "n_decoded": torch.tensor(rec_len)}
+        return steps, cons
+
+    table = build_table(batch)
+    js["table"] = {k: [_enc_entry(e) for e in v] for k, v in table.items()}
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "cache"))
+    torch.save(table, os.path.join(tmp, "cache", "pku_cgl_relationships_dic_using_canvas_sort_label_lexico.pt"))
+    os.chdir(tmp)
+    torch.serialization.add_safe_globals([RS.RelElement, RS.RelLoc, RS.RelSize])   # torch >= 2.6 loads with weights_only=True
+    try:
+        # --- preprocessor + constraint masks ---
+        random.seed(6)
+        torch.manual_seed(6)
+        model = build_ralf(tok, "relation").eval()      # its ctor builds the RelationshipPreprocessor (shuffles the table: random)
+        load_det(model)
+        random.seed(7)
+        torch.manual_seed(7)
+        cond, _ = get_condition(clone_batch(batch), "relation", tok)
+        model.preprocessor.set_relation_size(30)
+        seqc = model.preprocessor(cond)
+        out["preprocessor"] = {"cond_seq": cond.seq, "cond_mask": cond.mask, "edge_indexes": cond.edge_indexes, "edge_attributes": cond.edge_attributes,
+                               "seq": seqc["seq"], "pad_mask": seqc["pad_mask"]}
+        fn = TransformerSortByDictRelationConstraint(model.preprocessor)
+        out["steps"], js["constraints"] = drive(fn, seqc["seq"], 140, 9)
+        # --- scenario 2: dense layouts, 60 % of the relations (every relation kind on every slot) ---
+        from image2layout.train.models.layoutformerpp.task_preprocessor import RelationshipPreprocessor
+        batch2 = synth_batch(43, 6, 10, 16, 3)
+        for b2 in range(6):                         # at least 6 elements everywhere
+            n = max(int(batch2["mask"][b2].sum()), 6 + b2 % 4)
+            g2 = torch.Generator().manual_seed(100 + b2)
+            batch2["mask"][b2] = torch.arange(10) < n
+            batch2["label"][b2] = torch.randint(0, 3, (10,), generator=g2) * batch2["mask"][b2]
+            for k in ("center_x", "center_y"):
+                batch2[k][b2] = (0.1 + 0.8 * torch.rand(10, generator=g2)) * batch2["mask"][b2]
+            for k in ("width", "height"):
+                batch2[k][b2] = (0.05 + 0.3 * torch.rand(10, generator=g2)) * batch2["mask"][b2]
+        table2 = build_table(batch2)
+        js["table2"] = {k: [_enc_entry(e) for e in v] for k, v in table2.items()}
+        torch.save(table2, os.path.join(tmp, "cache", "pku_cgl_relationships_dic_using_canvas_sort_label_lexico.pt"))
+        random.seed(16)
+        pre2 = RelationshipPreprocessor(tokenizer=tok, global_task_embedding=False)
+        random.seed(17)
+        torch.manual_seed(17)
+        condb, _ = get_condition(clone_batch(batch2), "relation", tok)
+        pre2.set_relation_size(60)
+        seqc2 = pre2(condb)
+        out["preprocessor2"] = {"batch": {k: batch2[k] for k in ("label", "mask", "center_x", "center_y", "width", "height")},
+                                "cond_seq": condb.seq, "seq": seqc2["seq"], "pad_mask": seqc2["pad_mask"]}
+        out["steps2"], js["constraints2"] = drive(TransformerSortByDictRelationConstraint(pre2), seqc2["seq"], 220, 19)
+        # --- end-to-end sample_relation (deterministic = argmax; back-tracking uses Python's random) ---
+        g = torch.Generator().manual_seed(12)
+        feat = torch.randn(B, 256, 2, 3, generator=g)
+        StandInBackbone.feat = feat
+        random.seed(8)
+        torch.manual_seed(8)
+        cond2, _ = get_condition(clone_batch(batch), "relation", tok)
+        random.seed(10)
+        torch.manual_seed(10)
+        res, vio = model.sample(cond=cond2, sampling_cfg=DictConfig(name="deterministic", temperature=1.0), cond_type="relation",
+                                return_violation=True, use_backtrack=True, RELATION_SIZE=30)
+        out["sample"] = {"feat": feat, "cond_seq": cond2.seq, "cond_mask": cond2.mask,
+                         "retrieved": {k: v for k, v in cond2.retrieved.items() if k not in ("image", "saliency")},
+                         "result": res, "violation": {"total": torch.tensor(float(vio["total"])), "viorated": torch.tensor(float(vio["viorated"]))}}
+    finally:
+        os.chdir(cwd)
+    with open(os.path.join(HERE, "relation.json"), "w") as f:
+        json.dump(js, f)
+    save("relation.npz", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tokenizer", "host", "modules", "e2e", "sample", "reranker"]
+    which = sys.argv[1:] or ["tokenizer", "host", "modules", "e2e", "sample", "reranker", "relation"]
     fns = {"tokenizer": golden_tokenizer, "host": golden_host_path, "modules": golden_modules, "e2e": golden_e2e, "sample": golden_sample,
-           "reranker": golden_reranker}
+           "reranker": golden_reranker, "relation": golden_relation}
     for w in which:
         fns[w]()

@@ -1,0 +1,144 @@
+"""Host path of the `relation` task against vectors recorded from the reference (tests/golden/relation.{npz,json},
+make_golden.py golden_relation): compute_relation, RelationshipPreprocessor, and every per-step vocabulary mask /
+back-track target of the relation-constrained decoder, including history rewinds."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from ralf_amd.helpers.layout_tokenizer import LayoutSequenceTokenizer
+from ralf_amd.helpers.relation_restriction import RelationConstraint
+from ralf_amd.helpers.relationships import (RelElement, RelLoc, RelSize, compute_relation, detect_loc_relation_between_elements,
+                                            detect_size_relation, relationship_table)
+from ralf_amd.helpers.task import get_condition
+from ralf_amd.helpers.task_preprocessor import PREPROCESSOR
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LABELS = ["text", "logo", "underlay"]
+
+
+def _rel(v: int):
+    return RelSize(v) if v <= 3 else RelLoc(v)
+
+
+def load_table(suffix=""):
+    with open(os.path.join(HERE, "golden", "relation.json")) as f:
+        js = json.load(f)
+    table = {k: [[e[0], RelElement(e[1]), _rel(e[2]), e[3], (e[4] if isinstance(e[4], str) else RelElement(e[4]))] for e in v] for k, v in js["table" + suffix].items()}
+    return table, js["constraints" + suffix]
+
+
+def make_batch(r):
+    b = {k: r["batch"][k].clone() for k in ("label", "mask", "center_x", "center_y", "width", "height")}
+    B = b["label"].size(0)
+    b["image"], b["saliency"] = torch.zeros(B, 3, 8, 8), torch.zeros(B, 1, 8, 8)
+    b["id"] = [str(1000 + i) for i in range(B)]
+    return b
+
+
+def test_compute_relation_matches_reference(golden):
+    r = golden("relation.npz").sub("compute_relation")
+    random.seed(5)
+    out = compute_relation(make_batch(r), edge_ratio=0.5)
+    assert torch.equal(out["edge_indexes"], r["edge_indexes"]) and torch.equal(out["edge_attributes"], r["edge_attributes"])
+
+
+def test_relationship_table_rules(golden):
+    """the synthesiser of the (unshipped) table reproduces the table the fixtures were made from"""
+    r = golden("relation.npz").sub("compute_relation")
+    table, _ = load_table()
+    assert relationship_table(make_batch(r), LABELS) == table
+    # detectors: known answers
+    assert detect_size_relation([0, 0, 1.0, 1.0], [0, 0, 1.0, 1.05]) == RelSize.EQUAL
+    assert detect_size_relation([0, 0, 1.0, 1.0], [0, 0, 2.0, 1.0]) == RelSize.LARGER
+    assert detect_loc_relation_between_elements([0.5, 0.8, 0.2, 0.2], [0.5, 0.2, 0.2, 0.2]) == RelLoc.TOP
+    assert detect_loc_relation_between_elements([0.2, 0.5, 0.2, 0.6], [0.8, 0.5, 0.2, 0.6]) == RelLoc.RIGHT
+    assert detect_loc_relation_between_elements([0.5, 0.5, 0.4, 0.4], [0.6, 0.6, 0.4, 0.4]) == RelLoc.CENTER
+
+
+@pytest.fixture()
+def prepared(golden):
+    """same seeding protocol as the generator: table shuffle at construction, then condition + serialisation"""
+    g = golden("relation.npz")
+    table, cons = load_table()
+    tok = LayoutSequenceTokenizer(LABELS, 10)
+    random.seed(6)
+    pre = PREPROCESSOR["relation"](tokenizer=tok, table=table)
+    random.seed(7)
+    torch.manual_seed(7)
+    cond, _ = get_condition(make_batch(g.sub("compute_relation")), "relation", tok)
+    pre.set_relation_size(30)
+    seqc = pre(cond)
+    return g, tok, pre, cond, seqc, cons
+
+
+def test_relationship_preprocessor_matches_reference(prepared):
+    g, tok, pre, cond, seqc, _ = prepared
+    r = g.sub("preprocessor")
+    assert torch.equal(cond.seq, r["cond_seq"]) and torch.equal(cond.mask, r["cond_mask"])
+    assert torch.equal(cond.edge_indexes, r["edge_indexes"]) and torch.equal(cond.edge_attributes, r["edge_attributes"])
+    assert torch.equal(seqc["seq"], r["seq"]) and torch.equal(seqc["pad_mask"], r["pad_mask"])
+    assert pre.N_total == tok.N_total + 7 + 3 + 10 + 6 + 4
+    assert pre.id_to_name(pre.name_to_id(RelLoc.TOP)) == RelLoc.TOP and pre.id_to_name(pre.name_to_id("canvas")) == "canvas"
+
+
+def _replay(g, tok, pre, cons, key_pre, key_steps):
+    r = g.sub(key_pre)
+    rc = RelationConstraint(pre)
+    steps = g.sub(key_steps)
+    kinds = set()
+    for b in range(r["seq"].size(0)):
+        rel = rc.prepare(r["seq"][b])
+        enc = [[["canvas", int(a)] if k == "canvas" else [int(k), int(a)] for k, a in lst] for lst in rel]
+        assert enc == cons[str(b)], f"sample {b}: prepared constraints differ"
+        s = steps[f"s{b}"]
+        seq = torch.full((1, 1), tok.name_to_id("bos"))
+        n_checked = 0
+        for it in range(s["mask"].size(0)):
+            # rebuild the prefix the generator had at this step (it may have been cut back)
+            n_dec = int(s["n_decoded"][it])
+            assert seq.size(1) - 1 >= n_dec
+            seq = seq[:, : n_dec + 1]
+            mask, back = rc(seq, rel)
+            assert torch.equal(mask, s["mask"][it]), f"sample {b} step {it} (decoded {n_dec}): mask differs"
+            assert (-1 if back is None else back) == int(s["back"][it]), f"sample {b} step {it}: back-track target differs"
+            t = int(s["token"][it])
+            if t >= 0:
+                seq = torch.cat([seq, torch.tensor([[t]])], dim=1)
+            n_checked += 1
+        assert n_checked >= 5
+        kinds |= {k for lst in rel for k, _ in lst}
+    return kinds
+
+
+def test_constraint_masks_match_reference(prepared):
+    g, tok, pre, cond, seqc, cons = prepared
+    _replay(g, tok, pre, cons, "preprocessor", "steps")
+
+
+def test_constraint_masks_dense_layouts(golden):
+    """6 layouts with 6-9 elements, 60 % of all relations: every relation kind, hundreds of steps with infeasible cuts"""
+    g = golden("relation.npz")
+    table, cons = load_table("2")
+    tok = LayoutSequenceTokenizer(LABELS, 10)
+    random.seed(16)
+    pre = PREPROCESSOR["relation"](tokenizer=tok, table=table)
+    r = g.sub("preprocessor2")
+    assert relationship_table(make_batch(r), LABELS) == table
+    random.seed(17)
+    torch.manual_seed(17)
+    cond, _ = get_condition(make_batch(r), "relation", tok)
+    pre.set_relation_size(60)
+    seqc = pre(cond)
+    assert torch.equal(cond.seq, r["cond_seq"]) and torch.equal(seqc["seq"], r["seq"]) and torch.equal(seqc["pad_mask"], r["pad_mask"])
+    kinds = _replay(g, tok, pre, cons, "preprocessor2", "steps2")
+    assert {"canvas", RelSize.SMALLER, RelSize.LARGER, RelLoc.TOP, RelLoc.BOTTOM, RelLoc.LEFT, RelLoc.RIGHT, RelLoc.CENTER} <= kinds
+
+
+def test_relation_task_without_table_fails_loudly():
+    tok = LayoutSequenceTokenizer(LABELS, 10)
+    with pytest.raises(Exception):
+        PREPROCESSOR["relation"](tokenizer=tok)   # no cache/pku_cgl_relationships_dic_...pt here
