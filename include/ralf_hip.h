@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 3
+#define RALF_ABI_VERSION 4
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -211,9 +211,10 @@ int ralf_attention_bwd(const RalfAttnDesc* d, void* stream);
  * ------------------------------------------------------------------------------------------- */
 int ralf_sumsq(const float* g, int64_t n, float* out, void* stream);
 int ralf_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream);
-/* step_dev (int32[1] on the device, may be NULL) overrides `step` for the bias corrections (graph replay) */
+/* step_dev (int32[1] on the device, may be NULL) overrides `step` for the bias corrections (graph replay);
+ * lr_scale (fp32[1] on the device, may be NULL) multiplies lr: the scheduler's factor (train/schedulers/multi_step_lr.py) without re-capturing */
 int ralf_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1, float beta2, float eps,
-               float weight_decay, int step, const float* coef, const int* step_dev, void* stream);
+               float weight_decay, int step, const float* coef, const int* step_dev, const float* lr_scale, void* stream);
 
 #ifdef __cplusplus
 }

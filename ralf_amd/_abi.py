@@ -83,5 +83,5 @@ SIGNATURES.update({
     "ralf_attention_bwd": (i32, [ctypes.POINTER(RalfAttnDesc), vp]),
     "ralf_sumsq": (i32, [vp, i64, vp, vp]),
     "ralf_clip_coef": (i32, [vp, f32, vp, vp, vp]),
-    "ralf_adamw": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, vp, vp]),
+    "ralf_adamw": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, vp, vp, vp]),
 })

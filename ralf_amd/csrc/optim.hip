@@ -40,8 +40,10 @@ __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                      bf16* __restrict__ shadow, int64_t n, float lr, float b1, float b2, float eps, float wd,
-                                                     float bc1, float bc2_sqrt, const float* __restrict__ coef, const int* __restrict__ step_dev) {
+                                                     float bc1, float bc2_sqrt, const float* __restrict__ coef, const int* __restrict__ step_dev,
+                                                     const float* __restrict__ lr_scale) {
     const float c = coef ? coef[0] : 1.f;
+    if (lr_scale) lr *= lr_scale[0];   // learning-rate schedule factor on the device: a captured graph follows the scheduler
     if (step_dev) {  // step counter lives on the device (captured graphs): bias corrections follow it
         const float t = (float)step_dev[0];
         bc1 = 1.f - powf(b1, t);
@@ -77,9 +79,9 @@ extern "C" int ralf_clip_coef(const float* sumsq, float max_norm, float* coef, f
  * device-resident counter step_dev[0] when given); gradients are multiplied by coef[0] (device scalar,
  * may be NULL); shadow = optional bf16 copy of p */
 extern "C" int ralf_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1, float beta2, float eps,
-                          float weight_decay, int step, const float* coef, const int* step_dev, void* stream) {
+                          float weight_decay, int step, const float* coef, const int* step_dev, const float* lr_scale, void* stream) {
     RALF_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || step_dev), "adamw: bad arguments");
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), coef, step_dev);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), coef, step_dev, lr_scale);
     return ralf::check_launch("adamw");
 }

@@ -58,6 +58,7 @@ class FlatAdamW:
         self._ss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.coef = torch.ones(1, dtype=torch.float32, device=dev)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.lr_scale = torch.ones(1, dtype=torch.float32, device=dev)   # scheduler factor, read by the kernel (graph-replay safe)
 
     def zero_grad(self):
         self.G.zero_()
@@ -78,9 +79,32 @@ class FlatAdamW:
             a, b = g["range"]
             ops.adamw(self.P[a:b], self.G[a:b], self.M[a:b], self.V[a:b], g["lr"], self.betas[0], self.betas[1], self.eps,
                       g["weight_decay"], 1, self.coef if self.max_norm > 0 else None,
-                      self.P16[a:b] if self.P16 is not None else None, self.step_dev)
+                      self.P16[a:b] if self.P16 is not None else None, self.step_dev, self.lr_scale)
         if self.runtime is not None:
             self.runtime.weights_changed()
+
+
+class MultiStepLR:
+    """train/schedulers/multi_step_lr.py:10-46 for the fused optimizer: at the given fractions of `epochs` (or absolute
+    epochs) the learning rate of every group is multiplied by gamma.  step() once per epoch, like train/train.py:283-287."""
+
+    def __init__(self, optimizer: FlatAdamW, epochs: int, milestones=(0.7,), gamma: float = 0.1, **_ignored):
+        ms = list(milestones)
+        if isinstance(ms[0], float):
+            assert all(0.0 <= m <= 1.0 for m in ms)
+            ms = [int(m * epochs) for m in ms]
+        self.opt, self.milestones, self.gamma, self.epoch = optimizer, sorted(int(m) for m in ms), gamma, 0
+        self.base_lrs = [g["lr"] for g in optimizer.groups]
+
+    def _factor(self) -> float:
+        return self.gamma ** sum(1 for m in self.milestones if m <= self.epoch)
+
+    def step(self) -> None:
+        self.epoch += 1
+        self.opt.lr_scale.fill_(self._factor())
+
+    def get_last_lr(self):
+        return [lr * self._factor() for lr in self.base_lrs]
 
 
 def average_gradients(flat: torch.Tensor, world: int, group=None) -> None:

@@ -350,8 +350,8 @@ def clip_coef(sumsq_t, max_norm, coef, norm_out=None):
     _call("ralf_clip_coef", _p(sumsq_t), max_norm, _p(coef), _p(norm_out))
 
 
-def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, coef=None, shadow=None, step_dev=None):
-    _call("ralf_adamw", _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr, beta1, beta2, eps, wd, step, _p(coef), _p(step_dev))
+def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, coef=None, shadow=None, step_dev=None, lr_scale=None):
+    _call("ralf_adamw", _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr, beta1, beta2, eps, wd, step, _p(coef), _p(step_dev), _p(lr_scale))
 
 
 def mask_sample(logits, allowed=None, forced=None, mode=0, top_k=1, temperature=1.0, seed=None, call_id=0):

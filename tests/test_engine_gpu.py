@@ -59,3 +59,58 @@ def test_graph_replay_matches_eager(golden, dtype):
     tol = 2e-2 if dtype == "bfloat16" else 2e-4
     for a, b in zip(le[2:], lg):
         assert abs(a - b) < tol, (le, lg)
+
+
+def test_multistep_lr_follows_torch_scheduler_through_graph_replay(golden):
+    """the scheduler factor lives on the device: a captured graph keeps replaying while the learning rate steps down
+    (train/schedulers/multi_step_lr.py semantics: milestones as fractions of the epochs, gamma 0.1)."""
+    from ralf_amd.engine import MultiStepLR, TrainStep
+
+    ref, inputs, tgt = make(golden)
+    opt = torch.optim.AdamW(ref.optim_groups(1e-3, 1e-4, custom_lr={"encoder.extractor.body": 1e-4}), betas=(0.9, 0.999), eps=1e-8)
+    sched_ref = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[int(0.5 * 4)], gamma=0.1)
+    fused, _, _ = make(golden)
+    step = TrainStep(fused, lr=1e-3, weight_decay=1e-4, max_norm=0.1, use_graph=True)
+    sched = MultiStepLR(step.opt, epochs=4, milestones=[0.5], gamma=0.1)
+    losses_ref, losses = [], []
+    for epoch in range(4):
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            loss = ref.train_loss(inputs, tgt)[1]["nll_loss"]
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.1)
+            opt.step()
+            losses_ref.append(loss.item())
+        sched_ref.step()
+        n_before = step.steps_done
+        while step.steps_done < n_before + 2:     # the first call runs warm-up + capture (3 optimizer steps)
+            step(inputs, tgt)
+        sched.step()
+        assert sched.get_last_lr()[-1] == pytest.approx(sched_ref.get_last_lr()[-1])
+    assert sched.get_last_lr()[-1] == pytest.approx(1e-4)
+    assert float(step.opt.lr_scale) == pytest.approx(0.1)
+
+
+def test_lr_scale_changes_the_update_like_torch(golden):
+    from ralf_amd.engine import MultiStepLR, TrainStep
+
+    ref, inputs, tgt = make(golden)
+    opt = torch.optim.AdamW(ref.optim_groups(1e-3, 1e-2, custom_lr={"encoder.extractor.body": 1e-4}), betas=(0.9, 0.999), eps=1e-8)
+    sched_ref = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[1], gamma=0.1)
+    fused, _, _ = make(golden)
+    step = TrainStep(fused, lr=1e-3, weight_decay=1e-2, max_norm=0.1, use_graph=False)
+    sched = MultiStepLR(step.opt, epochs=2, milestones=[1], gamma=0.1)
+    for epoch in range(2):
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            ref.train_loss(inputs, tgt)[1]["nll_loss"].backward()
+            torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.1)
+            opt.step()
+            step(inputs, tgt)
+        sched_ref.step()
+        sched.step()
+    a, b = dict(ref.named_parameters()), dict(fused.named_parameters())
+    for k in ("decoder.head.1.weight", "attn.to_kv.weight", "head.net.0.bias"):
+        diff = (b[k] - a[k]).abs()
+        # 2 steps at 1e-3 then 2 at 1e-4: an unscaled second epoch would be off by ~1.8e-3 on most elements
+        assert (diff <= 3e-5 + 1e-4 * a[k].abs()).float().mean().item() >= 0.99, (k, diff.max().item())
