@@ -1,4 +1,5 @@
 from .knn import FlatIPIndex, knn_topk_ip  # noqa: F401
 from .reranker import maximal_marginal_relevance, reranker_random, reranker_top_k  # noqa: F401
-from .retriever import RetrievalDatasetWrapper, Retriever, coarse_saliency, load_cache_table, table_path  # noqa: F401
+from .retriever import (RetrievalDatasetWrapper, Retriever, coarse_saliency, cross_dataset_table, load_cache_table, merge_retrieval_cache,  # noqa: F401
+                        merged_vectors, table_path)
 from .embed import coarse_saliency_batch, layout_features, pool_cosine, rerank_tables  # noqa: F401

@@ -91,6 +91,54 @@ class Retriever:
         return table
 
 
+def merged_vectors(vector_sets: Sequence[np.ndarray], where_norm: str) -> np.ndarray:
+    """concatenation of several backbones' embeddings (retriever.py:255-270 / :304-315): `where_norm` in
+    {"before_concat", "after_concat"} divides by numpy's `LA.norm(x, ord=2)` of each part / of the concatenation --
+    for a 2-D database block that is its SPECTRAL norm (a single scalar), for a 1-D query its length; kept as is."""
+    assert where_norm in ("before_concat", "after_concat")
+    parts = [np.asarray(v, np.float32) for v in vector_sets]
+    if where_norm == "before_concat":
+        parts = [v / np.linalg.norm(v, ord=2) for v in parts]
+    out = np.concatenate(parts, axis=-1)
+    if where_norm == "after_concat":
+        out = out / np.linalg.norm(out, ord=2)
+    return np.ascontiguousarray(out, np.float32)
+
+
+def merge_retrieval_cache(dataset_name: str, split: str, backbones: Sequence[str], db_vector_sets, query_sets, data_ids, top_k: int,
+                          where_norm: str, cache_dir: str = "cache", device: str = "cuda") -> dict:
+    """`Retriever.preprocess_to_merge_retrieval_cache` (retriever.py:231-343): one index over the concatenated embeddings
+    of several backbones; queries are normalised one by one (the reference's per-query 2-norm), searched in ONE batched
+    scan, rank 0 dropped on the train split; written to the reference's file name."""
+    name = "merge_" + "_".join(backbones)
+    index = FlatIPIndex(merged_vectors(db_vector_sets, where_norm), device=device)
+    n = len(data_ids)
+    queries = np.stack([merged_vectors([qs[i] for qs in query_sets], where_norm) for i in range(n)])
+    _, idx = index.search(queries, top_k + 1)
+    idx = idx.cpu().numpy()
+    lo = 1 if split == "train" else 0
+    table = {(int(i) if "pku" in dataset_name else i): [int(j) for j in idx[r, lo:]] for r, i in enumerate(data_ids)}
+    os.makedirs(cache_dir, exist_ok=True)
+    torch.save(table, os.path.join(cache_dir, f"{dataset_name}_{split}_{name}_{where_norm}__topk{top_k}.pt"))
+    return table
+
+
+def cross_dataset_table(source: str, reference: str, split: str, backbone: str, reference_vectors: np.ndarray, queries: np.ndarray, source_ids,
+                        top_k: int, save_scores: bool = False, cache_dir: str = "cache", device: str = "cuda") -> dict:
+    """`CrossRetriever.preprocess_retrieval_cache` (cross_retriever.py:133-207): queries of one dataset against the other's
+    index; keeps all top_k + 1 hits (nothing is dropped: a sample is never in the other dataset)."""
+    index = FlatIPIndex(np.ascontiguousarray(reference_vectors, np.float32), device=device)
+    scores, idx = index.search(np.ascontiguousarray(queries, np.float32), top_k + 1)
+    scores, idx = scores.cpu().numpy(), idx.cpu().numpy()
+    table = {(int(i) if source == "pku" else i): [int(j) for j in idx[r]] for r, i in enumerate(source_ids)}
+    os.makedirs(cache_dir, exist_ok=True)
+    path = os.path.join(cache_dir, f"source_{source}_reference_{reference}_{split}_{backbone}_cross_dataset_indexes_top_k{top_k}.pt")
+    torch.save(table, path)
+    if save_scores:
+        torch.save({k: scores[r] for r, k in enumerate(table)}, path.replace("indexes", "scores"))
+    return table
+
+
 class RetrievalDatasetWrapper(torch.utils.data.Dataset):
     """table lookup -> K exemplar layouts per sample, padded to max_seq_length ([K, N] fields)."""
 

@@ -85,3 +85,26 @@ def test_layout_features_and_mmr_rerank(golden):
         assert out[i] == np.asarray(table[i])[local].tolist()
     rnd = rerank_tables(table, None, feats, top_k, "random")
     assert all(len(set(v)) == top_k and set(v) <= set(table[i]) for i, v in rnd.items())
+
+
+def test_merged_and_cross_dataset_tables(tmp_path):
+    """retriever.py:231-343 (merged backbones) and cross_retriever.py:133-207 on the HIP scan vs the CPU oracle."""
+    from oracle import knn_oracle
+    from ralf_amd.retrieval import cross_dataset_table, merge_retrieval_cache, merged_vectors
+
+    rng = np.random.default_rng(3)
+    a, b = rng.standard_normal((500, 64)).astype(np.float32), rng.standard_normal((500, 32)).astype(np.float32)
+    for where in ("before_concat", "after_concat"):
+        db = merged_vectors([a, b], where)
+        assert db.shape == (500, 96)
+        qs = np.stack([merged_vectors([a[i], b[i]], where) for i in range(40)])
+        t = merge_retrieval_cache("pku", "train", ["clip", "saliency"], [a, b], [a[:40], b[:40]], [str(7000 + i) for i in range(40)], 8, where, cache_dir=str(tmp_path))
+        ref, _ = knn_oracle.topk_ip(db, qs, 9)
+        assert all(t[7000 + i] == ref[i, 1:].tolist() for i in range(40))
+        assert (tmp_path / f"pku_train_merge_clip_saliency_{where}__topk8.pt").exists()
+    refv, q = rng.standard_normal((300, 256)).astype(np.float32), rng.standard_normal((25, 256)).astype(np.float32)
+    t = cross_dataset_table("cgl", "pku", "test", "saliency", refv, q, [f"id{i}" for i in range(25)], 16, save_scores=True, cache_dir=str(tmp_path))
+    ref, _ = knn_oracle.topk_ip(refv, q, 17)
+    assert all(t[f"id{i}"] == ref[i].tolist() for i in range(25))
+    assert (tmp_path / "source_cgl_reference_pku_test_saliency_cross_dataset_indexes_top_k16.pt").exists()
+    assert (tmp_path / "source_cgl_reference_pku_test_saliency_cross_dataset_scores_top_k16.pt").exists()
