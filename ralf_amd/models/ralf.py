@@ -279,9 +279,44 @@ class _GeneratorBase(nn.Module):
             return result, self._violation_relation(result, [rc.prepare(seqc["seq"][b].cpu()) for b in range(seqc["seq"].size(0))])
         return result, self._violation(cond_type, cond, out_tokens)
 
+    class _StepGraphs:
+        """one captured hipGraph per decode position for the batch-1 KV-cached decoder step (static token / padding-mask /
+        cache buffers): the relation loop replays them instead of issuing ~60 eager launches per step."""
+
+        def __init__(self, model, T, dev):
+            self.model, self.T = model, T
+            self.tok = torch.zeros(1, dtype=torch.long, device=dev)
+            self.kpm = torch.zeros(1, T, dtype=torch.uint8, device=dev)
+            self.cache, self.graphs, self.out = None, {}, {}
+
+        def bind(self, cache):
+            if self.cache is None:
+                self.cache = cache
+            else:
+                for dst, src in zip(self.cache.cross_kv, cache.cross_kv):
+                    dst.copy_(src)
+
+        def __call__(self, token, pos, kpm_prefix):
+            m = self.model
+            self.tok.copy_(token)
+            self.kpm[:, : pos + 1].copy_(kpm_prefix)
+            if pos not in self.graphs:
+                run = lambda: RN.decoder_step(m.decoder, self.tok, pos, self.cache, m.rt, self.kpm[:, : pos + 1])  # noqa: E731
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    run()
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.out[pos] = run()
+                self.graphs[pos] = g
+            self.graphs[pos].replay()
+            return self.out[pos]
+
     @torch.no_grad()
     def sample_relation(self, cond, batch_size: Optional[int] = None, sampling_cfg=None, return_violation: bool = False,
-                        prob_gate: float = 0.3, RELATION_SIZE: int = 10, **kwargs):
+                        prob_gate: float = 0.3, RELATION_SIZE: int = 10, use_graph: bool = True, **kwargs):
         """Relation-constrained decoding with back-tracking (retrieval_augmented_autoreg.py:336-507): per sample, every step
         masks the vocabulary by (token mask, forced label, relation constraints); when nothing admissible is left (or only
         logits below `prob_gate`), the prefix is cut back to the element the violated constraint refers to (random position
@@ -298,7 +333,6 @@ class _GeneratorBase(nn.Module):
             cond.image = cond.image.expand(B, -1, -1, -1).contiguous()
         ids = self.special_token_ids
         T = self.tokenizer.max_token_length
-        token_mask = self._token_mask_dev(dev)
         enc_in, seqc = self._create_encoder_inputs(cond)
         enc_dev = {k: ({kk: vv.to(dev) for kk, vv in v.items() if torch.is_tensor(vv)} if isinstance(v, dict) else (v.to(dev) if torch.is_tensor(v) else v))
                    for k, v in enc_in.items()}
@@ -306,23 +340,36 @@ class _GeneratorBase(nn.Module):
         memory = self._encode_into_memory(enc_dev)["memory"]
         constraint = RelationConstraint(self.preprocessor)
         restrict = DECODE_SPACE_RESTRICTION["relation"]
-        cond_seq = cond.seq.to(dev)
+        cond_seq = cond.seq.cpu()
+        token_mask_h = self.tokenizer.token_mask.cpu()
         rows, prepared = [], []
+        stepper = None
+        if use_graph:
+            if getattr(self, "_relation_stepper", None) is None or self._relation_stepper.tok.device != dev:
+                self._relation_stepper = self._StepGraphs(self, T, dev)
+            stepper = self._relation_stepper
+        # the sequence, the masks and the draw live on the HOST (518 logits per step come back in one copy): the reference's
+        # control flow is host logic anyway, and a dozen tiny device ops + three syncs per step cost more than the decoder step
         for b in range(B):
             cache = RN.decoder_init_cache(self.decoder, memory[b:b + 1].contiguous(), self.rt, T)
+            if stepper is not None:
+                stepper.bind(cache)
             rel = constraint.prepare(seqc["seq"][b].cpu())
-            seq = torch.full((1, 1), ids["bos"], dtype=torch.long, device=dev)
+            seq = torch.full((1, 1), ids["bos"], dtype=torch.long)
             flagged, back_flag, n_back, resets, idx = [], False, 0, 0, 0
             while True:
                 L = seq.size(1)
-                logits = RN.decoder_step(self.decoder, seq[:, L - 1].contiguous(), L - 1, cache, self.rt,
-                                         (seq == ids["pad"]).to(torch.uint8).contiguous()).float()
+                kpm = (seq == ids["pad"]).to(torch.uint8)
+                if stepper is not None:
+                    logits = stepper(seq[:, L - 1].to(dev), L - 1, kpm.to(dev)).float().cpu()
+                else:
+                    logits = RN.decoder_step(self.decoder, seq[:, L - 1].to(dev).contiguous(), L - 1, cache, self.rt, kpm.to(dev).contiguous()).float().cpu()
                 n_dec = L - 1
-                logits[:, ~token_mask[n_dec]] = NEG_INF
+                logits[:, ~token_mask_h[n_dec]] = NEG_INF
                 logits = restrict(n_dec + 1, cond_seq[b:b + 1], logits, pad_id=ids["pad"], eos_id=ids["eos"], max_length=T)
                 raw = logits.clone()
-                mask, back_idx = constraint(seq.cpu(), rel)
-                logits[:, mask.to(dev)] = NEG_INF
+                mask, back_idx = constraint(seq, rel)
+                logits[:, mask] = NEG_INF
                 pruned_max = torch.where(logits < prob_gate, torch.full_like(logits, NEG_INF), logits).max()
                 if resets > 3:
                     logits, back_flag = raw, False
@@ -335,7 +382,7 @@ class _GeneratorBase(nn.Module):
                     if n_back > 30:
                         flagged, back_flag, n_back = [], False, 0
                         resets += 1
-                        seq = torch.full((1, 1), ids["bos"], dtype=torch.long, device=dev)
+                        seq = torch.full((1, 1), ids["bos"], dtype=torch.long)
                         idx = 0
                     continue
                 temperature = None
@@ -347,10 +394,10 @@ class _GeneratorBase(nn.Module):
                     break
                 idx += 1
             # (sic) finished sequences are padded with the literal True (= token 1), retrieval_augmented_autoreg.py:475-483
-            seq = torch.cat([seq, torch.full((1, T + 2 - seq.size(1)), 1, dtype=torch.long, device=dev)], dim=1)
+            seq = torch.cat([seq, torch.full((1, T + 2 - seq.size(1)), 1, dtype=torch.long)], dim=1)
             rows.append(seq)
             prepared.append(rel)
-        tokens = torch.cat(rows, dim=0)[:, 1:-1].cpu()
+        tokens = torch.cat(rows, dim=0)[:, 1:-1]
         result = self.postprocess({"seq": tokens})
         if not return_violation:
             return result
