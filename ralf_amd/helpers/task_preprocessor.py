@@ -28,9 +28,9 @@ class BasePreprocessor:
     SHUFFLE = False
 
     def __init__(self, tokenizer, global_task_embedding: bool = False):
-        if tokenizer.max_seq_length > MAX_REL_ELEMENTS:
-            raise ValueError(f"max_seq_length={tokenizer.max_seq_length} > {MAX_REL_ELEMENTS}: the reference's constraint vocabulary "
-                             "has only 11 element markers (task_preprocessor.py:65-68)")
+        # the reference's constraint vocabulary has one element marker per slot taken from the 11-member RelElement enum
+        # (task_preprocessor.py:65-68), so it cannot be built for max_seq_length > 11.  Longer layouts (the <= 32-element
+        # measurement config) get anonymous marker ids beyond K: every task except `relation` is unaffected.
         self.tokenizer = tokenizer
         self.global_task_embedding = global_task_embedding
         n_extra = len(TASK_TOKENS) + len(SEP_TOKENS) + tokenizer.max_seq_length + N_REL_LOC + N_REL_SIZE
@@ -40,7 +40,9 @@ class BasePreprocessor:
             self._ids[name] = tokenizer.N_total + i
         # relationship vocabulary: element markers A.. (one per element slot), then RelLoc, then RelSize members; the enum
         # MEMBERS are the keys, like the reference's table entries (task_preprocessor.py:65-87,119-124)
-        rel_tokens = list(RelElement)[: tokenizer.max_seq_length] + list(RelLoc) + list(RelSize)
+        n_el = tokenizer.max_seq_length
+        markers = list(RelElement)[:n_el] + [f"element_{i}" for i in range(MAX_REL_ELEMENTS, n_el)]
+        rel_tokens = markers + list(RelLoc) + list(RelSize)
         for i, member in enumerate(rel_tokens):
             self._ids[member] = tokenizer.N_total + len(TASK_TOKENS) + len(SEP_TOKENS) + i
         for i, name in enumerate(tokenizer._label_feature.names):
@@ -173,6 +175,8 @@ class RelationshipPreprocessor(BasePreprocessor):
 
     def __init__(self, tokenizer, global_task_embedding: bool = False, RELATION_SIZE: int = 10, table=None):
         super().__init__(tokenizer, global_task_embedding)
+        if tokenizer.max_seq_length > MAX_REL_ELEMENTS:
+            raise ValueError(f"relation task: max_seq_length={tokenizer.max_seq_length} > {MAX_REL_ELEMENTS} element markers (RelElement)")
         self.RELATION_SIZE = RELATION_SIZE
         if table is None or isinstance(table, str):
             table = _load_relationship_table(table or self.TABLE_PATH)

@@ -142,3 +142,14 @@ def test_relation_task_without_table_fails_loudly():
     tok = LayoutSequenceTokenizer(LABELS, 10)
     with pytest.raises(Exception):
         PREPROCESSOR["relation"](tokenizer=tok)   # no cache/pku_cgl_relationships_dic_...pt here
+
+
+def test_long_layouts_keep_every_other_task():
+    """<= 32-element layouts (BASELINE north star): the reference cannot build its constraint vocabulary beyond 11 elements
+    (11 RelElement markers); here only the `relation` task is unavailable there."""
+    tok = LayoutSequenceTokenizer(LABELS, 32)
+    pre = PREPROCESSOR["c"](tokenizer=tok)
+    assert pre.N_total == tok.N_total + 7 + 3 + 32 + 6 + 4
+    assert pre.name_to_id(RelLoc.UNKNOWN) == tok.N_total + 10 + 32
+    with pytest.raises(ValueError):
+        PREPROCESSOR["relation"](tokenizer=tok, table={})
