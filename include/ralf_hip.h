@@ -48,6 +48,10 @@ int ralf_knn_topk_ip(const float* index, int64_t n_db, int dim, const float* que
 int ralf_knn_scores(const float* index, int64_t n_db, int dim, const float* queries, int nq, float* scores, void* stream);
 int ralf_knn_select(const float* scores, int64_t n_db, int nq, int k, int64_t* out_idx, float* out_score,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* exact re-scoring for the two-stage search (bf16 coarse ranking by ralf_gemm, then this, then ralf_knn_select):
+ * out[q][j] = <Q[q], X[cand[q][j]]> for cand int64 [nq, pool] (row indices, every value in [0, N)); same accumulation chain as
+ * ralf_knn_scores, hence bit-identical scores */
+int ralf_knn_rescore(const float* X, int64_t N, int D, const float* Q, int nq, const int64_t* cand, int pool, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * element types of activation / weight buffers (accumulation is always fp32)

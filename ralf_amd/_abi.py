@@ -12,6 +12,7 @@ SIGNATURES = {
     "ralf_knn_topk_ip": (i32, [vp, i64, i32, vp, i32, i32, vp, vp, vp, sz, vp]),
     "ralf_knn_scores": (i32, [vp, i64, i32, vp, i32, vp, vp]),
     "ralf_knn_select": (i32, [vp, i64, i32, i32, vp, vp, vp, sz, vp]),
+    "ralf_knn_rescore": (i32, [vp, i64, i32, vp, i32, vp, i32, vp, vp]),
 }
 
 

@@ -43,10 +43,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // A operand = query tile (M dim), B operand = index-row tile (N dim): for a fixed accumulator
 // register the 32 (16) lanes of a half-wave hold CONSECUTIVE index rows of one query, so the
 // score stores are contiguous 128 B (64 B) segments of S[q][*].
-template <int MF, int TQ, int TR>
+// GATHER (exact re-scoring of per-query candidate lists, two-stage search): workgroup <-> (query q, chunk of its `pool`
+// candidates); the index rows come from cand[q][*], the query tile holds the single query q, S is [nq][pool].  The
+// accumulation code is the one of the exhaustive scan, so a re-scored pair is bit-identical to its exhaustive score.
+template <int MF, int TQ, int TR, bool GATHER = false>
 __global__ __launch_bounds__(256) void knn_scores_kernel(const float* __restrict__ X, int64_t N, int D,
                                                           const float* __restrict__ Q, int nq, float* __restrict__ S,
-                                                          int n_qtiles, int nwg) {
+                                                          int n_qtiles, int nwg, const int64_t* __restrict__ cand = nullptr, int pool = 0) {
     using F = Frag<MF>;
     constexpr int RW = 4 * TR * MF, QW = TQ * MF, BK = 32, KS = F::KS, ROT = 32 / MF;
     constexpr int XV = RW * BK / 4 / 256;              // float4 per thread per k-tile (index rows)
@@ -59,7 +62,9 @@ __global__ __launch_bounds__(256) void knn_scores_kernel(const float* __restrict
     const int vid = xcd_remap(blockIdx.x, nwg);
     const int qt = vid % n_qtiles, rc = vid / n_qtiles;
     const int64_t row0 = (int64_t)rc * RW;
-    const int q0 = qt * QW;
+    const int q0 = GATHER ? qt : qt * QW;                  // GATHER: qt is the query itself (n_qtiles = nq)
+    const int64_t nrows = GATHER ? pool : N;               // rows addressable by this workgroup's list
+    const int nq_hi = GATHER ? q0 + 1 : nq;                // GATHER: only row 0 of the query tile is real
 
     float4 xr[XV], qr[QV];
     auto gload = [&](int k0) {
@@ -68,13 +73,14 @@ __global__ __launch_bounds__(256) void knn_scores_kernel(const float* __restrict
             const int f = tid + 256 * i, r = f >> 3, kq = f & 7;
             const int64_t n = row0 + r;
             const int k = k0 + kq * 4;
-            xr[i] = (n < N && k < D) ? *reinterpret_cast<const float4*>(X + n * D + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int64_t src = (GATHER && n < nrows) ? cand[(int64_t)q0 * pool + n] : n;
+            xr[i] = (n < nrows && k < D) ? *reinterpret_cast<const float4*>(X + src * D + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < QV; ++i) {
             const int f = tid + 256 * i, r = f >> 3, kq = f & 7;
             const int qi = q0 + r, k = k0 + kq * 4;
-            qr[i] = (f < QW * 8 && qi < nq && k < D) ? *reinterpret_cast<const float4*>(Q + (int64_t)qi * D + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            qr[i] = (f < QW * 8 && qi < nq_hi && k < D) ? *reinterpret_cast<const float4*>(Q + (int64_t)qi * D + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     // element (row, k) lives at row*32 + ((k + ROT*row) & 31): both the 4 scalar writes of a float4
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256) void knn_scores_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < F::NREG; ++r) {
                 const int qi = q0 + i * MF + F::crow(r, lane);
-                if (qi < nq && n < N) S[(int64_t)qi * N + n] = acc[i][j][r];
+                if (qi < nq_hi && n < nrows) S[(int64_t)qi * nrows + n] = acc[i][j][r];
             }
         }
 }
@@ -319,6 +325,14 @@ int launch_scores(const float* X, int64_t N, int D, const float* Q, int nq, floa
     return ralf::check_launch("knn_scores");
 }
 
+int launch_rescore(const float* X, int64_t N, int D, const float* Q, int nq, const int64_t* cand, int pool, float* S, hipStream_t st) {
+    constexpr int MF = 16, RW = 4 * MF;                    // 64 candidates per workgroup, one query per 16-row query tile
+    const int nrc = ceil_div(pool, RW);
+    const int nwg = nrc * nq;
+    hipLaunchKernelGGL((knn_scores_kernel<MF, 1, 1, true>), dim3(nwg), dim3(256), 0, st, X, N, D, Q, nq, S, nq, nwg, cand, pool);
+    return ralf::check_launch("knn_rescore");
+}
+
 struct SelectPlan {
     int64_t nseg;      // lists after the score pass
     size_t cand_bytes; // one candidate buffer (scores + indices), sized for the first level
@@ -345,6 +359,13 @@ extern "C" int ralf_knn_scores(const float* X, int64_t N, int D, const float* Q,
     if (nq <= 64) return launch_scores<32, 2, 2>(X, N, D, Q, nq, S, st);
     // FLOP-bound regime: 256 rows x 128 queries per workgroup, 8 accumulator tiles per wave.
     return launch_scores<32, 4, 2>(X, N, D, Q, nq, S, st);
+}
+
+/* exact fp32 scores of per-query candidate rows: out[q][j] = <Q[q], X[cand[q][j]]>, bit-identical to ralf_knn_scores */
+extern "C" int ralf_knn_rescore(const float* X, int64_t N, int D, const float* Q, int nq, const int64_t* cand, int pool, float* out, void* stream) {
+    RALF_REQUIRE(X && Q && cand && out && N > 0 && nq > 0 && pool > 0 && D > 0 && D % 4 == 0, "knn_rescore: bad arguments");
+    RALF_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)Q & 15) == 0, "knn_rescore: index/queries must be 16-byte aligned");
+    return launch_rescore(X, N, D, Q, nq, cand, pool, out, (hipStream_t)stream);
 }
 
 extern "C" size_t ralf_knn_topk_ip_workspace_bytes(int64_t N, int D, int nq, int k) {

@@ -50,12 +50,60 @@ def knn_select(scores: torch.Tensor, k: int):
     return val, idx
 
 
+def knn_rescore(index: torch.Tensor, queries: torch.Tensor, cand: torch.Tensor) -> torch.Tensor:
+    """exact fp32 scores of per-query candidate rows: out[q, j] = <queries[q], index[cand[q, j]]> (bit-identical to knn_scores)."""
+    N, D = index.shape
+    nq, pool = cand.shape
+    out = torch.empty(nq, pool, dtype=torch.float32, device=index.device)
+    rc = _lib.lib().ralf_knn_rescore(_lib.ptr(index), N, D, _lib.ptr(queries.contiguous()), nq, _lib.ptr(cand.contiguous()), pool, _lib.ptr(out), _lib.stream_ptr())
+    _lib.check(rc, "ralf_knn_rescore")
+    return out
+
+
+def knn_topk_ip_two_stage(index: torch.Tensor, index_bf16: torch.Tensor, queries: torch.Tensor, k: int, pool: int = 0, index_norm_max: float | None = None):
+    """Exact top-k for LARGE query batches (nq >> 32, where the fp32 scan is bound by the 157 TFLOP/s fp32 matrix rate,
+    SURVEY section 7): a bf16-MFMA coarse pass ranks every row, the best `pool` candidates per query are re-scored exactly
+    in fp32 (same ascending-d accumulation chain as the exhaustive scan, so the scores are bit-identical), and the result is
+    CERTIFIED per query: with eps >= |coarse - exact| for every row (bf16 rounding of both operands: 2^-8 |q| |x|),
+        exact k-th score  >=  coarse (pool+1)-th score + eps
+    proves that no row outside the pool can enter the top-k.  Queries that fail the test are re-run through the exhaustive
+    fp32 path, so the returned (scores, indices) always equal knn_topk_ip's.  Returns (scores, idx, n_fallback)."""
+    from .. import ops
+
+    assert index.is_cuda and index.dtype == torch.float32 and index_bf16.dtype == torch.bfloat16 and index_bf16.shape == index.shape
+    N, D = index.shape
+    nq = queries.shape[0]
+    pool = pool or min(max(4 * k, 64), N - 1)
+    assert k <= pool < N
+    q = queries.contiguous()
+    qb = ops.cast(q, torch.bfloat16)
+    coarse = ops.gemm(qb, index_bf16, nq, N, D, out_dtype=torch.float32)             # [nq, N] = Qb Xb^T (bf16 MFMA, fp32 accumulate)
+    cval, cidx = knn_select(coarse, pool + 1)                                         # sorted by coarse score
+    bound = cval[:, pool]                                                             # upper bound of every row OUTSIDE the pool
+    cand, _ = torch.sort(cidx[:, :pool], dim=1)                                       # ascending row index: ties then resolve like the exhaustive path
+    exact = knn_rescore(index, q, cand)                                              # same fp32 MFMA chain as the exhaustive scan
+    val, pos = knn_select(exact, k)
+    idx = torch.gather(cand, 1, pos)
+    if index_norm_max is None:
+        index_norm_max = float(torch.linalg.vector_norm(index, dim=1).max())
+    eps = (2.0 ** -8) * 1.001 * torch.linalg.vector_norm(q, dim=1) * index_norm_max + 1e-6
+    bad = torch.nonzero(~(val[:, k - 1] >= bound + eps)).flatten()
+    if bad.numel():   # not certified (tiny gaps / mass ties): exhaustive fp32 scan for those queries only
+        v2, i2 = knn_topk_ip(index, q[bad].contiguous(), k)
+        val[bad], idx[bad] = v2, i2
+    return val, idx, int(bad.numel())
+
+
 class FlatIPIndex:
     """Flat inner-product index kept in HBM; `search` mirrors faiss.IndexFlat.search(x, k) -> (D, I)."""
 
-    def __init__(self, vectors: torch.Tensor, device: str = "cuda"):
+    def __init__(self, vectors: torch.Tensor, device: str = "cuda", two_stage_min_queries: int = 128):
         self.vectors = torch.as_tensor(vectors, dtype=torch.float32).to(device).contiguous()
         self._ws = None
+        self._bf16 = None                 # bf16 shadow of the index for the coarse pass of large query batches (built on first use)
+        self._norm_max = None
+        self.two_stage_min_queries = two_stage_min_queries
+        self.last_fallbacks = 0
 
     @property
     def ntotal(self) -> int:
@@ -69,6 +117,13 @@ class FlatIPIndex:
         q = torch.as_tensor(queries, dtype=torch.float32).to(self.vectors.device)
         if q.dim() == 1:
             q = q[None]
+        if self.two_stage_min_queries and q.shape[0] >= self.two_stage_min_queries and k < self.ntotal // 8 and self.d % 8 == 0:
+            from .. import ops
+            if self._bf16 is None:
+                self._bf16 = ops.cast(self.vectors, torch.bfloat16)
+                self._norm_max = float(torch.linalg.vector_norm(self.vectors, dim=1).max())
+            val, idx, self.last_fallbacks = knn_topk_ip_two_stage(self.vectors, self._bf16, q, k, index_norm_max=self._norm_max)
+            return val, idx
         need = _lib.lib().ralf_knn_topk_ip_workspace_bytes(self.ntotal, self.d, q.shape[0], k)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.vectors.device)

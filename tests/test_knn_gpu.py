@@ -95,3 +95,26 @@ def test_errors_are_loud():
         knn_topk_ip(X, Q, 3)
     with pytest.raises(RalfHipError, match="k=0"):
         knn_topk_ip(torch.zeros(16, 8, device="cuda"), torch.zeros(2, 8, device="cuda"), 0)
+
+
+@pytest.mark.parametrize("N,D,nq,k", [(5000, 256, 300, 16), (61548, 1792, 256, 16), (3000, 64, 200, 5)])
+def test_two_stage_search_equals_exhaustive(N, D, nq, k):
+    """bf16 coarse pass + exact fp32 re-score + per-query certificate == the exhaustive fp32 scan, bit for bit
+    (scores and indices), including near-duplicate rows that defeat the certificate and force the fallback."""
+    from ralf_amd import ops
+    from ralf_amd.retrieval.knn import FlatIPIndex, knn_topk_ip, knn_topk_ip_two_stage
+
+    g = torch.Generator(device="cuda").manual_seed(N + nq)
+    X = torch.randn(N, D, device="cuda", generator=g)
+    X /= X.norm(dim=1, keepdim=True)
+    X[N // 2: N // 2 + 100] = X[7] + 1e-4 * torch.randn(100, D, device="cuda", generator=g)   # near duplicates: more than the candidate pool
+    Q = torch.randn(nq, D, device="cuda", generator=g)
+    Q /= Q.norm(dim=1, keepdim=True)
+    Q[3] = X[7]                                                                               # a query inside the cluster
+    v_ref, i_ref = knn_topk_ip(X, Q, k)
+    v, i, nfb = knn_topk_ip_two_stage(X, ops.cast(X, torch.bfloat16), Q, k)
+    assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
+    assert nfb >= 1 and nfb < nq // 2          # the cluster query falls back, ordinary queries are certified
+    index = FlatIPIndex(X)                      # the index front end picks the two-stage path for large batches
+    v2, i2 = index.search(Q, k)
+    assert torch.equal(i2, i_ref) and torch.equal(v2, v_ref)
