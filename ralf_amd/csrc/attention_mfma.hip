@@ -369,10 +369,117 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
         }
     }
 }
+// ------------------------------------------------------------------------------------------------
+// Decode step (Sq = 1, head dim 32, no dropout): a streaming kernel instead of the tiled one.  The work is reading the
+// K/V cache once (B x Sk x 2 x d bytes: 140 MB per cross-attention call at B = 256, Sk = 532) -- there is one query per
+// head, so nothing for the matrix cores to do.  Workgroup = (batch element, head PAIR): per key the pair's K (or V) slice is
+// one 128-byte line; lane = (key slot = lane / 8, 16-byte chunk = lane % 8), 4 waves x 8 keys per wave-load.
+// Pass 1 streams K -> scores in LDS, block softmax, pass 2 streams V weighted by the probabilities.
+// ------------------------------------------------------------------------------------------------
+constexpr int DEC_MAXK = 2048;
+__global__ __launch_bounds__(256) void attn_decode_kernel(const RalfAttnDesc d) {
+    __shared__ float sc[DEC_MAXK][2];
+    __shared__ float red[2][4][2];
+    __shared__ float part[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hpairs = d.H / 2, hp = blockIdx.x % hpairs, b = blockIdx.x / hpairs;
+    const int chunk = lane & 7, slot = lane >> 3, head = chunk >> 2;
+    const bf16* Qp = (const bf16*)d.q + b * d.q_bs + hp * 64 + chunk * 8;
+    const bf16* Kp = (const bf16*)d.k + b * d.k_bs + hp * 64 + chunk * 8;
+    const bf16* Vp = (const bf16*)d.v + b * d.v_bs + hp * 64 + chunk * 8;
+    const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * d.Sk : nullptr;
+    float qv[8];
+    {
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(Qp);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qv[i] = (float)t[i] * d.scale;
+    }
+    // ---- pass 1: scores ----
+    for (int key0 = wave * 8; key0 < d.Sk; key0 += 32 * 4) {
+        bf16x8 kv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = key0 + u * 32 + slot;
+            if (key < d.Sk) kv[u] = *reinterpret_cast<const bf16x8*>(Kp + (int64_t)key * d.k_rs);
+            else for (int i = 0; i < 8; ++i) kv[u][i] = (bf16)0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = key0 + u * 32 + slot;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += qv[i] * (float)kv[u][i];
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            if ((chunk & 3) == 0 && key < d.Sk) sc[key][head] = (kpm && kpm[key]) ? -__builtin_inff() : s;
+        }
+    }
+    __syncthreads();
+    // ---- softmax over the keys, per head (thread parity = head) ----
+    const int h2 = tid & 1;
+    float m = -__builtin_inff();
+    for (int key = tid >> 1; key < d.Sk; key += 128) m = fmaxf(m, sc[key][h2]);
+#pragma unroll
+    for (int o = 2; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane < 2) red[0][wave][lane] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0][0][h2], red[0][1][h2]), fmaxf(red[0][2][h2], red[0][3][h2]));
+    const float mref = m > -__builtin_inff() ? m : 0.f;
+    float l = 0.f;
+    for (int key = tid >> 1; key < d.Sk; key += 128) {
+        const float p = __expf(sc[key][h2] - mref);
+        sc[key][h2] = p;
+        l += p;
+    }
+#pragma unroll
+    for (int o = 2; o < 64; o <<= 1) l += __shfl_xor(l, o);
+    if (lane < 2) red[1][wave][lane] = l;
+    __syncthreads();
+    // ---- pass 2: weighted sum of V ----
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int key0 = wave * 8; key0 < d.Sk; key0 += 32 * 4) {
+        bf16x8 vv[4];
+        float p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = key0 + u * 32 + slot;
+            if (key < d.Sk) { vv[u] = *reinterpret_cast<const bf16x8*>(Vp + (int64_t)key * d.v_rs); p[u] = sc[key][head]; }
+            else { for (int i = 0; i < 8; ++i) vv[u][i] = (bf16)0.f; p[u] = 0.f; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += p[u] * (float)vv[u][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        acc[i] += __shfl_xor(acc[i], 8);
+        acc[i] += __shfl_xor(acc[i], 16);
+        acc[i] += __shfl_xor(acc[i], 32);
+    }
+    if (slot == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) part[wave][chunk * 8 + i] = acc[i];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int hh = tid >> 5;
+        const float lsum = red[1][0][hh] + red[1][1][hh] + red[1][2][hh] + red[1][3][hh];
+        const float o = (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) / lsum;
+        ((bf16*)d.o)[b * d.o_bs + hp * 64 + tid] = (bf16)o;
+    }
+}
 }  // namespace
 
 // called from attention.hip for dtype == RALF_BF16 (descriptor already validated)
 int ralf_attention_fwd_mfma(const RalfAttnDesc& d, hipStream_t st) {
+    if (d.Sq == 1 && d.dh == 32 && d.H % 2 == 0 && !d.causal && d.p_drop == 0.f && !d.lse && d.Sk <= DEC_MAXK &&
+        d.k_rs % 8 == 0 && d.v_rs % 8 == 0 && d.k_bs % 8 == 0 && d.v_bs % 8 == 0 && d.q_bs % 8 == 0) {
+        hipLaunchKernelGGL(attn_decode_kernel, dim3(d.B * (d.H / 2)), dim3(256), 0, st, d);
+        return ralf::check_launch("attention_decode");
+    }
     const dim3 grid(ceil_div(d.Sq, 64) * d.H * d.B);
     if (d.dh == 32) hipLaunchKernelGGL((attn_fwd_mfma<32>), grid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL((attn_fwd_mfma<64>), grid, dim3(256), 0, st, d);

@@ -97,7 +97,7 @@ def knn_topk_ip_two_stage(index: torch.Tensor, index_bf16: torch.Tensor, queries
 class FlatIPIndex:
     """Flat inner-product index kept in HBM; `search` mirrors faiss.IndexFlat.search(x, k) -> (D, I)."""
 
-    def __init__(self, vectors: torch.Tensor, device: str = "cuda", two_stage_min_queries: int = 128):
+    def __init__(self, vectors: torch.Tensor, device: str = "cuda", two_stage_min_queries: int = 256):
         self.vectors = torch.as_tensor(vectors, dtype=torch.float32).to(device).contiguous()
         self._ws = None
         self._bf16 = None                 # bf16 shadow of the index for the coarse pass of large query batches (built on first use)

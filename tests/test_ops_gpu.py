@@ -308,3 +308,27 @@ def test_mask_sample():
     assert (got - want).abs().max() < 0.015, (got, want)
     d2 = ops.mask_sample(x, allowed.to(torch.uint8).cuda(), None, mode=1, top_k=5, temperature=0.7, seed=seed, call_id=3).cpu()
     assert torch.equal(draws, d2)   # counter-based: same seed/call -> same draws
+
+
+@pytest.mark.parametrize("B,Sk,pad", [(3, 1, False), (5, 51, True), (4, 532, False), (2, 700, True)])
+def test_attention_decode_step(B, Sk, pad):
+    """Sq = 1 streaming kernel (bf16, need_lse=False) on the KV-cache layout of nn.decoder_step: packed [K|V] rows,
+    cache longer than the valid prefix (kv_rows), key-padding mask."""
+    from ralf_amd import ops
+
+    H, dh = 8, 32
+    d = H * dh
+    L = Sk + 7                                       # cache rows beyond the prefix hold garbage that must not be read
+    q = rnd(B, 1, d, seed=50, dtype=torch.bfloat16)
+    kv = rnd(B, L, 2 * d, seed=51, dtype=torch.bfloat16)
+    kv[:, Sk:] = float("nan")
+    kpm = None
+    if pad:
+        kpm = torch.zeros(B, Sk, dtype=torch.bool); kpm[0, Sk // 2:] = True; kpm[-1, 0] = True
+    ref = ref_attention(q.float(), kv[:, :Sk, :d].float(), kv[:, :Sk, d:].float(), H, False, kpm, dh ** -0.5)
+    kp = kpm.to(torch.uint8).cuda() if pad else None
+    o, lse = ops.attention_fwd(q.cuda(), kv.cuda(), kv.cuda(), B, H, 1, Sk, dh, 0, 0, d, causal=False, kpm=kp, need_lse=False, kv_rows=L)
+    assert lse is None
+    close(o, ref, torch.bfloat16)
+    o2, _ = ops.attention_fwd(q.cuda(), kv.cuda(), kv.cuda(), B, H, 1, Sk, dh, 0, 0, d, causal=False, kpm=kp, need_lse=True, kv_rows=L)   # tiled kernel
+    close(o, o2.float().cpu(), torch.bfloat16)
