@@ -93,6 +93,23 @@ DECODE_SPACE_RESTRICTION = {
 }
 
 
+def forced_tokens_all(cond: torch.Tensor, cond_type: str, pad_id: int, eos_id: int, max_length: int):
+    """forced_tokens for every decode step at once: int64 [max_length, B] (row i = step i + 1), or None when the task does
+    not constrain tokens.  The decode loop indexes one row per step instead of re-deriving it with ~10 tiny launches."""
+    if cond_type in ("none", "uncond", "partial", None) or cond is None:
+        return None
+    assert cond.size(1) == max_length + 1
+    steps = torch.arange(1, max_length + 1, device=cond.device).view(1, -1)        # [1, T]
+    given = cond[:, 1:]                                                              # [B, T]
+    before = steps < _first_pad(cond, pad_id).view(-1, 1)
+    free = before & ((given == pad_id) | (given == -1))
+    forced = torch.where(before, given, torch.full_like(given, eos_id))
+    forced = torch.where(free, torch.full_like(given, -1), forced)
+    if cond_type in ("refinement", "relation"):                                      # only the label slots are constrained
+        forced = torch.where((steps - 1) % 5 == 0, forced, torch.full_like(forced, -1))
+    return forced.t().contiguous()
+
+
 def forced_tokens(step: int, cond: torch.Tensor, cond_type: str, pad_id: int, eos_id: int, max_length: int):
     """DECODE_SPACE_RESTRICTION expressed as one forced token per sample (-1 = unconstrained) for the fused
     on-device mask+sample kernel; equivalent to restrict_* above (which mask every other logit)."""

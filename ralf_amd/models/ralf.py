@@ -21,7 +21,7 @@ import torch.nn as nn
 from .. import functional as RF
 from .. import nn as RN
 from ..functional import Runtime
-from ..helpers.sampling import DECODE_SPACE_RESTRICTION, _get, forced_tokens, sample as sample_tokens
+from ..helpers.sampling import DECODE_SPACE_RESTRICTION, _get, forced_tokens_all, sample as sample_tokens
 from ..helpers.task import COND_TYPES, get_condition
 from ..helpers.task_preprocessor import PREPROCESSOR
 
@@ -223,13 +223,14 @@ class _GeneratorBase(nn.Module):
             cache = RN.decoder_init_cache(self.decoder, memory, self.rt, T)
             for j in range(start):  # prefix given by the condition (partial): fill the cache
                 RN.decoder_step(self.decoder, seq[:, j].contiguous(), j, cache, self.rt, (seq[:, :j + 1] == ids["pad"]).to(torch.uint8).contiguous())
+        forced_all = forced_tokens_all(cond_seq, cond_type, ids["pad"], ids["eos"], T) if name in ("deterministic", "top_k") else None
         for i in range(start, T):
             if cache is not None:
                 logits = RN.decoder_step(self.decoder, seq[:, i].contiguous(), i, cache, self.rt, (seq == ids["pad"]).to(torch.uint8).contiguous())
             else:
                 logits = self.decoder(seq, memory, self.rt, seq == ids["pad"])[:, i].clone()
             if name in ("deterministic", "top_k"):   # vocabulary mask + restriction + choice fused in one kernel
-                forced = forced_tokens(i + 1, cond_seq, cond_type, ids["pad"], ids["eos"], T)
+                forced = forced_all[i] if forced_all is not None else None
                 nxt = RN.ops.mask_sample(logits.float(), token_mask_u8[i], forced, 0 if name == "deterministic" else 1,
                                          int(_get(sampling_cfg, "top_k", 1) or 1), float(_get(sampling_cfg, "temperature", 1.0) or 1.0),
                                          self.rt.seed, 1000 + i)

@@ -88,3 +88,33 @@ def test_condition_and_constraint_sequence(golden, task):
     if task != "uncond":
         assert torch.equal(cond.mask, g["cond"]["mask"])
         assert torch.equal(cond.seq, g["cond"]["seq"]) or torch.equal(seq_before, g["cond"]["seq"])
+
+
+@pytest.mark.parametrize("cond_type", ["c", "cwh", "refinement", "relation", "uncond"])
+def test_forced_token_table_equals_per_step_restriction(cond_type):
+    """the [T, B] forced-token table the decode loop indexes == the per-step restriction (restrict_* keep exactly one token
+    where a token is forced and every token elsewhere)"""
+    from ralf_amd.helpers.sampling import DECODE_SPACE_RESTRICTION, NEG_INF, forced_tokens, forced_tokens_all
+
+    g = torch.Generator().manual_seed(3)
+    B, T, V, pad, eos = 7, 50, 140, 139, 138
+    cond = torch.randint(0, 137, (B, T + 1), generator=g)
+    cond[torch.rand(B, T + 1, generator=g) < 0.3] = -1      # free slots
+    for b, n in enumerate([0, 1, 6, 11, 26, 50, 51]):       # ragged lengths incl. empty and full
+        cond[b, n:] = pad
+    table = forced_tokens_all(cond, cond_type, pad, eos, T)
+    if cond_type == "uncond":
+        assert table is None
+        return
+    assert table.shape == (T, B) and table.is_contiguous()
+    for step in range(1, T + 1):
+        one = forced_tokens(step, cond, cond_type, pad, eos, T)
+        row = table[step - 1]
+        assert torch.equal(row, one if one is not None else torch.full_like(row, -1))
+        kept = DECODE_SPACE_RESTRICTION[cond_type](step, cond, torch.zeros(B, V), pad, eos, T) != NEG_INF
+        want = torch.ones(B, V, dtype=torch.bool)
+        for b in range(B):
+            if row[b] >= 0:
+                want[b] = False
+                want[b, row[b]] = True
+        assert torch.equal(kept, want)
