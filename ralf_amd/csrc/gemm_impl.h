@@ -11,9 +11,8 @@
 //   ResnetBackbone convolutions (common/image.py:80-111)
 //
 // Design:
-//   * (64*FM)x(64*FN) output tile per 256-thread workgroup (FM,FN in {1,2}: 128x128 for the big products,
-//     64-wide variants for N = 64 convolutions and for small grids that need more workgroups in flight),
-//     2x2 waves, each wave FMxFN fragments of 32x32 (v_mfma_f32_32x32x16_bf16 or the exact-fp32
+//   * 64x64 output tile per 4-wave workgroup (2x2 waves of 32x32) or 128x128 per 8-wave workgroup (2x4 waves of 64x32),
+//     see launch_cfg; fragments of 32x32 (v_mfma_f32_32x32x16_bf16 or the exact-fp32
 //     v_mfma_f32_32x32x2_f32); fp32 accumulate always.  The matrix core computes the TRANSPOSED tile
 //     (weights as the row operand) so every lane ends up with 4 consecutive output columns: 8/16-byte
 //     epilogue loads and stores instead of 2-byte ones.
@@ -60,6 +59,21 @@ struct FastDiv {
     __device__ __forceinline__ uint32_t div(uint32_t n) const { return den == 1 ? n : (__umulhi(n, mul) >> shr); }
     __device__ __forceinline__ void divmod(uint32_t n, int& q, int& r) const { const uint32_t t = div(n); q = (int)t; r = (int)(n - t * den); }
 };
+
+// tools/gemm_probe.hip builds ONE instantiation with -DRALF_GEMM_PROBE: per-workgroup phase time stamps (s_memtime) + placement
+#ifdef RALF_GEMM_PROBE
+__device__ unsigned long long ralf_probe_buf[8 * 65536];
+#define RALF_PROBE(i)                                                                                                          \
+    do {                                                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < 65536) ralf_probe_buf[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define RALF_PROBE(i)
+#endif
+
+#ifndef RALF_GEMM_PERSISTENT
+#define RALF_GEMM_PERSISTENT 0
+#endif
 
 struct KParams {
     RalfGemmDesc d;
@@ -329,13 +343,13 @@ __device__ __forceinline__ u32x4 load_vec_cols(const T* __restrict__ p, const KP
 }
 
 // staging registers -> LDS tile.  KC: [rows][LDK] (k-contiguous source), else [BK][LDR] (row-contiguous source)
-template <typename T, bool KC, int NV, int RV, int LDR>
+template <typename T, bool KC, int NV, int RV, int LDR, int NT>
 __device__ __forceinline__ void lds_stage(T* l, const u32x4 (&regs)[NV], int tid) {
     using X = TT<T>;
     constexpr int KV = X::BK / X::VEC;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int v = tid + 256 * i;
+        const int v = tid + NT * i;
         if constexpr (KC) {
             const int r = v / KV, kv = v % KV;
             if constexpr (sizeof(T) == 4) {  // fp32: rotate each row so 32 rows x same k hit 32 banks
@@ -357,8 +371,9 @@ __device__ __forceinline__ void lds_stage(T* l, const u32x4 (&regs)[NV], int tid
 // AK: A is k-contiguous ([M][K]); else stored [K][M].   BKC: B is k-contiguous ([N][K]); else [K][N].
 // GATHER: 0 none, 1 = A (k-contiguous) is an im2col matrix, 2 = B (row-contiguous) is an im2col matrix.
 // FM, FN: 32x32 fragments per wave along m / n  ->  workgroup tile (64*FM) x (64*FN).
-template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
+// NW: waves per workgroup, 4 (2 x 2 waves, FM x FN fragments each) or 8 (2 x 4 waves, FM x FN/2 fragments each; FN = 2 only)
+template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_kernel(const KParams P) {
     using X = TT<T>;
     constexpr int VEC = X::VEC, BK = X::BK;
     constexpr int BM = 64 * FM, BN = 64 * FN;
@@ -367,7 +382,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
     constexpr int B_ELEMS = BKC ? BN * X::LDK : BK * LDRB;
     constexpr int KV = BK / VEC;                                   // vectors along k (k-contiguous tile)
     constexpr int RVA = BM / VEC, RVB = BN / VEC;                  // vectors along rows (row-contiguous tile)
-    constexpr int NVA = BM * BK / VEC / 256, NVB = BN * BK / VEC / 256;  // 16-byte vectors per thread per k-tile
+    constexpr int NT = 64 * NW, WGN = NW / 2;                       // threads; waves along n (2 along m)
+    constexpr int WFM = FM, WFN = FN * 2 / WGN;                    // 32x32 fragments per wave
+    static_assert(NW == 4 || (NW == 8 && FN == 2), "8 waves: 2 x 4 over a 128-wide tile");
+    constexpr int NVA = BM * BK / VEC / NT, NVB = BN * BK / VEC / NT;  // 16-byte vectors per thread per k-tile  // 16-byte vectors per thread per k-tile
     constexpr int CP = BN + 4;                                     // fp32 C staging tile [64][CP] (epilogue)
     constexpr int LDS_BYTES = (A_ELEMS + B_ELEMS) * (int)sizeof(T) > 64 * CP * 4 ? (A_ELEMS + B_ELEMS) * (int)sizeof(T) : 64 * CP * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];   // ONE LDS object (operand tiles, then the C staging tile)
@@ -375,19 +393,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
     T* lb = la + A_ELEMS;
     const RalfGemmDesc& d = P.d;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    // one linear index over (split, tile): all output tiles of ONE k-split get consecutive virtual ids, i.e. run together on
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WGN, wn = wave % WGN;
+    RALF_PROBE(0);
+#ifdef RALF_GEMM_PROBE
+    if (tid == 0 && blockIdx.x < 65536) {
+        ralf_probe_buf[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+        ralf_probe_buf[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+#endif
+    // PERSISTENT workgroups: the grid is at most (CUs x resident workgroups per CU); each workgroup walks over output tiles
+    // bid = blockIdx.x, blockIdx.x + gridDim.x, ... and issues the first operand loads of its NEXT tile before the epilogue of
+    // the current one.  (s_memtime stamps, tools/gemm_probe.hip: of a 64x64x256 tile's 9.8 k cycles, 1.3 k were index setup and
+    // 2.4 k the wait for the first operand tile -- per tile, with nothing else of that workgroup to overlap it.)
+    //
+    // One linear index over (split, tile): all output tiles of ONE k-split get consecutive virtual ids, i.e. run together on
     // one XCD, so the operand strips they share (the same rows of dy and x in a weight gradient) are fetched from HBM once
     // and re-read from that XCD's L2.  (With the split on blockIdx.y the tiles of a split were scattered over all 8 XCDs:
-    // PMC FETCH_SIZE showed 11 GB per step fetched by the weight-gradient GEMMs for 4.5 GB of operands.)
-    const int vid = xcd_remap(blockIdx.x, P.nwg * d.splitk);
-    const int split = vid / P.nwg, tile = vid - split * P.nwg;
-    const int tn = tile % P.tiles_n, tm = tile / P.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    // PMC FETCH_SIZE showed 11 GB per step fetched by the weight-gradient GEMMs for 4.5 GB of operands.)  gridDim.x is a
+    // multiple of 8 whenever a workgroup owns more than one tile, so all tiles of a workgroup map to its own XCD's range.
+    const int total = P.nwg * d.splitk;
     const int z = blockIdx.z, z0 = z % d.nb0, z1 = z / d.nb0;
-    const int kbeg = split * P.kchunk;
-    const int kend = min(d.K, kbeg + P.kchunk);
-
     const T* Ap = (const T*)d.A + z0 * d.sA0 + z1 * d.sA1;
     const T* Bp = (const T*)d.B + z0 * d.sB0 + z1 * d.sB1;
     const bool a_al = (d.lda % VEC == 0) && (((uintptr_t)Ap & 15) == 0);
@@ -396,10 +421,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
     u32x4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];   // two staging register sets: prefetch distance 2 k-tiles
     RowInfo ia[NVA], ib[NVB];
     ColInfo cb[NVB];
-    if constexpr (GATHER == 2) {
-#pragma unroll
-        for (int i = 0; i < NVB; ++i) cb[i] = col_info(P, n0 + ((tid + 256 * i) % RVB) * VEC, d.N);
-    }
     // PMC (SQ_ACTIVE_INST_ANY ~ 84 % of the kernel, MFMA busy 10 %) showed this kernel is instruction-issue bound:
     // the interior fast path keeps one pointer per staging vector and advances it by a constant per k-tile.
     // Rows beyond M/N are clamped to the last valid row (their results are never stored).
@@ -407,28 +428,43 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
     const T* pa[NVA];
     const T* pb[NVB];
     const int64_t stepA = AK ? BK : (int64_t)BK * d.lda, stepB = BKC ? BK : (int64_t)BK * d.ldb;
-    if (fast) {
+    int split, m0, n0, kbeg, kend, nt;   // the tile whose operands are being LOADED
+    auto setup = [&](int bid) {
+        const int vid = xcd_remap(bid, total);
+        split = vid / P.nwg;
+        const int tile = vid - split * P.nwg;
+        const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
+        m0 = tm * BM; n0 = tn * BN;
+        kbeg = split * P.kchunk;
+        kend = min(d.K, kbeg + P.kchunk);
+        nt = (kend - kbeg + BK - 1) / BK;
+        if constexpr (GATHER == 2) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) {
-            const int v = tid + 256 * i;
-            if (AK) pa[i] = Ap + (int64_t)min(m0 + v / KV, d.M - 1) * d.lda + kbeg + (v % KV) * VEC;
-            else pa[i] = Ap + (int64_t)(kbeg + v / RVA) * d.lda + min(m0 + (v % RVA) * VEC, d.M - VEC);
+            for (int i = 0; i < NVB; ++i) cb[i] = col_info(P, n0 + ((tid + NT * i) % RVB) * VEC, d.N);
         }
+        if (fast) {
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) {
-            const int v = tid + 256 * i;
-            if (BKC) pb[i] = Bp + (int64_t)min(n0 + v / KV, d.N - 1) * d.ldb + kbeg + (v % KV) * VEC;
-            else pb[i] = Bp + (int64_t)(kbeg + v / RVB) * d.ldb + min(n0 + (v % RVB) * VEC, d.N - VEC);
+            for (int i = 0; i < NVA; ++i) {
+                const int v = tid + NT * i;
+                if (AK) pa[i] = Ap + (int64_t)min(m0 + v / KV, d.M - 1) * d.lda + kbeg + (v % KV) * VEC;
+                else pa[i] = Ap + (int64_t)(kbeg + v / RVA) * d.lda + min(m0 + (v % RVA) * VEC, d.M - VEC);
+            }
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                const int v = tid + NT * i;
+                if (BKC) pb[i] = Bp + (int64_t)min(n0 + v / KV, d.N - 1) * d.ldb + kbeg + (v % KV) * VEC;
+                else pb[i] = Bp + (int64_t)(kbeg + v / RVB) * d.ldb + min(n0 + (v % RVB) * VEC, d.N - VEC);
+            }
         }
-    }
-    if (AK && !fast) {
+        if (AK && !fast) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) ia[i] = row_info<GATHER == 1>(P, m0 + (tid + 256 * i) / KV, d.M, d.lda);
-    }
-    if (BKC && !fast) {
+            for (int i = 0; i < NVA; ++i) ia[i] = row_info<GATHER == 1>(P, m0 + (tid + NT * i) / KV, d.M, d.lda);
+        }
+        if (BKC && !fast) {
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) ib[i] = row_info<false>(P, n0 + (tid + 256 * i) / KV, d.N, d.ldb);
-    }
+            for (int i = 0; i < NVB; ++i) ib[i] = row_info<false>(P, n0 + (tid + NT * i) / KV, d.N, d.ldb);
+        }
+    };
     auto gload = [&](u32x4 (&ra)[NVA], u32x4 (&rb)[NVB], int k0) {
         if constexpr (fast) {
 #pragma unroll
@@ -438,7 +474,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
         } else {
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
-            const int v = tid + 256 * i;
+            const int v = tid + NT * i;
             if (AK) ra[i] = load_vec<T, GATHER == 1>(Ap, P, ia[i], k0 + (v % KV) * VEC, kend, a_al);
             else {
                 const RowInfo r = row_info<false>(P, k0 + v / RVA, kend, d.lda);
@@ -447,7 +483,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
         }
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
-            const int v = tid + 256 * i;
+            const int v = tid + NT * i;
             if (BKC) rb[i] = load_vec<T, false>(Bp, P, ib[i], k0 + (v % KV) * VEC, kend, b_al);
             else {
                 const RowInfo r = row_info<GATHER == 2>(P, k0 + v / RVB, kend, d.ldb);
@@ -457,13 +493,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
         }
         }
     };
-    f32x16 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x16 acc[WFM][WFN];
 
     const int l31 = lane & 31, lh = lane >> 5;
     // transpose-read geometry (bf16 row-contiguous tiles): 16-lane group gi reads a [4 k][16 rows] block
@@ -477,43 +507,43 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
 #pragma unroll
             for (int ks = 0; ks < BK / 2; ++ks) {
                 const int kk = ks * 2 + lh;
-                float a[FM], b[FN];
+                float a[WFM], b[WFN];
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
-                    const int r = wm * 32 * FM + i * 32 + l31;
+                    const int r = wm * 32 * WFM + i * 32 + l31;
                     a[i] = AK ? ((float*)la)[r * 32 + ((kk + r) & 31)] : ((float*)la)[kk * LDRA + r];
                 }
 #pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    const int r = wn * 32 * FN + j * 32 + l31;
+                for (int j = 0; j < WFN; ++j) {
+                    const int r = wn * 32 * WFN + j * 32 + l31;
                     b[j] = BKC ? ((float*)lb)[r * 32 + ((kk + r) & 31)] : ((float*)lb)[kk * LDRB + r];
                 }
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < WFN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
             }
         } else {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
-                bf16x8 a[FM], b[FN];
+                bf16x8 a[WFM], b[WFN];
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     if (AK) {
-                        a[i] = *reinterpret_cast<const bf16x8*>(la + (wm * 32 * FM + i * 32 + l31) * X::LDK + ks * 16 + lh * 8);
+                        a[i] = *reinterpret_cast<const bf16x8*>(la + (wm * 32 * WFM + i * 32 + l31) * X::LDK + ks * 16 + lh * 8);
                     } else {
-                        const bf16* q = (const bf16*)la + (ks * 16 + tr_k) * LDRA + wm * 32 * FM + i * 32 + tr_rowblk + tr_c;
+                        const bf16* q = (const bf16*)la + (ks * 16 + tr_k) * LDRA + wm * 32 * WFM + i * 32 + tr_rowblk + tr_c;
                         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q));
                         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 4 * LDRA));
                         a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < FN; ++j) {
+                for (int j = 0; j < WFN; ++j) {
                     if (BKC) {
-                        b[j] = *reinterpret_cast<const bf16x8*>(lb + (wn * 32 * FN + j * 32 + l31) * X::LDK + ks * 16 + lh * 8);
+                        b[j] = *reinterpret_cast<const bf16x8*>(lb + (wn * 32 * WFN + j * 32 + l31) * X::LDK + ks * 16 + lh * 8);
                     } else {
-                        const bf16* q = (const bf16*)lb + (ks * 16 + tr_k) * LDRB + wn * 32 * FN + j * 32 + tr_rowblk + tr_c;
+                        const bf16* q = (const bf16*)lb + (ks * 16 + tr_k) * LDRB + wn * 32 * WFN + j * 32 + tr_rowblk + tr_c;
                         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q));
                         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 4 * LDRB));
                         b[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -522,7 +552,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < WFN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
             }
         }
     };
@@ -530,18 +560,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
     // get two compute phases to land (the k-loop is bound by load latency x tiles in flight per CU, not by MFMA rate).
     // Steady state is branch-free (an `if` around a prefetch made the compiler shuttle every accumulator
     // AGPR -> VGPR -> AGPR per iteration); the last 1-3 tiles are peeled.
-    auto stage0 = [&]() { lds_stage<T, AK, NVA, RVA, LDRA>(la, ra0, tid); lds_stage<T, BKC, NVB, RVB, LDRB>(lb, rb0, tid); };
-    auto stage1 = [&]() { lds_stage<T, AK, NVA, RVA, LDRA>(la, ra1, tid); lds_stage<T, BKC, NVB, RVB, LDRB>(lb, rb1, tid); };
+    auto stage0 = [&]() { lds_stage<T, AK, NVA, RVA, LDRA, NT>(la, ra0, tid); lds_stage<T, BKC, NVB, RVB, LDRB, NT>(lb, rb0, tid); };
+    auto stage1 = [&]() { lds_stage<T, AK, NVA, RVA, LDRA, NT>(la, ra1, tid); lds_stage<T, BKC, NVB, RVB, LDRB, NT>(lb, rb1, tid); };
     // (the 64x64 im2col-gather kernels keep distance 1: their index registers + a second staging set cost a wave of occupancy
     //  and the layer1 3x3 convolutions got 20 % slower with distance 2)
     constexpr int PF = (GATHER == 1 && FM == 1) ? 1 : 2;
-    const int nt = (kend - kbeg + BK - 1) / BK;
+    RALF_PROBE(1);
+    setup(blockIdx.x);
     gload(ra0, rb0, kbeg);
+    if (PF == 2 && nt > 1) gload(ra1, rb1, kbeg + BK);
+    for (int bid = blockIdx.x;;) {
+    const int c_m0 = m0, c_n0 = n0, c_split = split, c_kbeg = kbeg, c_nt = nt;   // the tile being COMPUTED
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < WFN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     if constexpr (PF == 1) {
         stage0();
         __syncthreads();
-        for (int t = 0; t + 1 < nt; ++t) {
-            gload(ra0, rb0, kbeg + (t + 1) * BK);
+        for (int t = 0; t + 1 < c_nt; ++t) {
+            gload(ra0, rb0, c_kbeg + (t + 1) * BK);
             compute();
             __syncthreads();
             stage0();
@@ -549,40 +589,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
         }
         compute();
     } else {
-        if (nt > 1) gload(ra1, rb1, kbeg + BK);
         stage0();
         __syncthreads();
+        RALF_PROBE(2);
         int t = 0;
-        for (; t + 3 < nt; t += 2) {        // tile t in LDS, tile t+1 in set 1
-            gload(ra0, rb0, kbeg + (t + 2) * BK);
+        for (; t + 3 < c_nt; t += 2) {        // tile t in LDS, tile t+1 in set 1
+            gload(ra0, rb0, c_kbeg + (t + 2) * BK);
             compute();
             __syncthreads();
             stage1();
             __syncthreads();
-            gload(ra1, rb1, kbeg + (t + 3) * BK);
+            gload(ra1, rb1, c_kbeg + (t + 3) * BK);
             compute();
             __syncthreads();
             stage0();
             __syncthreads();
         }
-        const int rem = nt - t;             // 1..3 tiles left: t in LDS, t+1 in set 1 (rem >= 2), t+2 not loaded yet (rem == 3)
-        if (rem == 3) gload(ra0, rb0, kbeg + (t + 2) * BK);
+        const int rem = c_nt - t;             // 1..3 tiles left: t in LDS, t+1 in set 1 (rem >= 2), t+2 not loaded yet (rem == 3)
+        if (rem == 3) gload(ra0, rb0, c_kbeg + (t + 2) * BK);
         compute();
         if (rem >= 2) { __syncthreads(); stage1(); __syncthreads(); compute(); }
         if (rem == 3) { __syncthreads(); stage0(); __syncthreads(); compute(); }
     }
+    // the operands of this workgroup's next tile start their way while this tile's results are stored
+    const int nbid = bid + (int)gridDim.x;
+    const bool more = RALF_GEMM_PERSISTENT && nbid < total;
+    if (more) {
+        setup(nbid);
+        gload(ra0, rb0, kbeg);
+        if (PF == 2 && nt > 1) gload(ra1, rb1, kbeg + BK);
+    }
 
+    RALF_PROBE(3);
     // ---- epilogue: lane holds 4 consecutive columns n per register group g = r>>2 ----
     // (no `continue`/`break` in these loops: they must unroll completely or the accumulators spill to scratch)
     const int nbatch = gridDim.z;
     const bool slab = d.splitk > 1 && !d.atomic_out;
-    if (P.vec_epi >= 2 && n0 + BN <= d.N) {
+    if (P.vec_epi >= 2 && c_n0 + BN <= d.N) {
         // tile interior in n: the accumulators go through LDS so every lane stores 8 consecutive columns of one row
         // (8 lanes = one 128-byte line of bf16) instead of 32 rows x 8 bytes per store instruction; residual / mask /
         // accumulate reads get the same shape.  64 tile rows per round.
         float* cs = reinterpret_cast<float*>(lds_raw);
-        float* pbase = slab ? P.partial + ((int64_t)split * nbatch + z) * d.M * d.N : nullptr;
-        constexpr int CG = BN / 8, RPP = 256 / CG;
+        float* pbase = slab ? P.partial + ((int64_t)c_split * nbatch + z) * d.M * d.N : nullptr;
+        constexpr int CG = BN / 8, RPP = NT / CG;
 #pragma clang loop unroll(full)
         for (int h = 0; h < FM; ++h) {
             __syncthreads();
@@ -591,19 +640,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
                 for (int i = 0; i < FM; ++i) {
                     const int lr = (FM == 1 ? wm * 32 : i * 32) + l31;
 #pragma clang loop unroll(full)
-                    for (int j = 0; j < FN; ++j) {
+                    for (int j = 0; j < WFN; ++j) {
 #pragma clang loop unroll(full)
                         for (int g = 0; g < 4; ++g)
-                            *reinterpret_cast<float4*>(cs + lr * CP + wn * 32 * FN + j * 32 + 8 * g + 4 * lh) =
+                            *reinterpret_cast<float4*>(cs + lr * CP + wn * 32 * WFN + j * 32 + 8 * g + 4 * lh) =
                                 make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
                     }
                 }
             }
             __syncthreads();
             if (d.colstats) {   // BatchNorm batch statistics of this 64-row block, on the values as stored (rounded to T)
-                constexpr int CPW = BN / 4, RG = 64 / CPW;           // columns per wave, row groups per column
+                constexpr int CPW = BN / NW, RG = 64 / CPW;           // columns per wave, row groups per column
                 const int col = wave * CPW + (lane % CPW), rg = lane / CPW;
-                const int nvalid = min(64, d.M - (m0 + h * 64));   // <= 0: this 64-row block lies beyond M (no partial row exists)
+                const int nvalid = min(64, d.M - (c_m0 + h * 64));   // <= 0: this 64-row block lies beyond M (no partial row exists)
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll 8
                 for (int r = rg; r < nvalid; r += RG) {
@@ -613,35 +662,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
 #pragma unroll
                 for (int o = CPW; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
                 if (rg == 0 && nvalid > 0) {
-                    float* pr = d.colstats + ((int64_t)(m0 / 64 + h) * 2) * d.N + n0 + col;
+                    float* pr = d.colstats + ((int64_t)(c_m0 / 64 + h) * 2) * d.N + c_n0 + col;
                     pr[0] = s1; pr[d.N] = s2;
                 }
             }
 #pragma unroll
             for (int p = 0; p < 64 / RPP; ++p) {
                 const int lr = p * RPP + tid / CG, c = (tid % CG) * 8;
-                const int m = m0 + h * 64 + lr;
+                const int m = c_m0 + h * 64 + lr;
                 if (m < d.M) {
                     const float4 lo = *reinterpret_cast<const float4*>(cs + lr * CP + c), hi = *reinterpret_cast<const float4*>(cs + lr * CP + c + 4);
                     float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    if (slab) VIO<float, 8>::st(pbase, (int64_t)m * d.N + n0 + c, v);
-                    else epilogue_storev<T, EPI, 8>(d, z0, z1, m, n0 + c, v);
+                    if (slab) VIO<float, 8>::st(pbase, (int64_t)m * d.N + c_n0 + c, v);
+                    else epilogue_storev<T, EPI, 8>(d, z0, z1, m, c_n0 + c, v);
                 }
             }
         }
     } else {
 #pragma clang loop unroll(full)
     for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm * 32 * FM + i * 32 + l31;
+        const int m = c_m0 + wm * 32 * WFM + i * 32 + l31;
 #pragma clang loop unroll(full)
-        for (int j = 0; j < FN; ++j) {
+        for (int j = 0; j < WFN; ++j) {
 #pragma clang loop unroll(full)
             for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * 32 * FN + j * 32 + 8 * g + 4 * lh;
+                const int n = c_n0 + wn * 32 * WFN + j * 32 + 8 * g + 4 * lh;
                 float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 if (m < d.M && n < d.N) {
                     if (slab) {
-                        float* pp = P.partial + (((int64_t)split * nbatch + z) * d.M + m) * d.N + n;
+                        float* pp = P.partial + (((int64_t)c_split * nbatch + z) * d.M + m) * d.N + n;
                         if (P.vec_epi && n + 3 < d.N) *reinterpret_cast<float4*>(pp) = make_float4(v[0], v[1], v[2], v[3]);
                         else {
 #pragma unroll
@@ -659,6 +708,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KParams P) {
             }
         }
     }
+    }
+    RALF_PROBE(4);
+    if (!more) break;
+    bid = nbid;
+    __syncthreads();   // the C staging tile shares the LDS with the operand tiles
     }
 }
 
@@ -690,40 +744,62 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams P, int
     }
 }
 
-template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI>
+// resident workgroups the chip holds for one kernel instantiation (queried once): the persistent grid
+template <typename K>
+int resident_workgroups(K kernel, int threads) {
+    int dev = 0, cus = 256, per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    (void)hipGetLastError();
+    return (cus / 8 * 8) * per_cu;
+}
+
+template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW = 4>
 int launch(KParams& P, int nbatch, hipStream_t st) {
     P.tiles_m = ceil_div(P.d.M, 64 * FM);
     P.tiles_n = ceil_div(P.d.N, 64 * FN);
     P.nwg = P.tiles_m * P.tiles_n;
-    hipLaunchKernelGGL((gemm_kernel<T, AK, BKC, GATHER, FM, FN, EPI>), dim3(P.nwg * P.d.splitk, 1, nbatch), dim3(256), 0, st, P);
+    static const int cap = resident_workgroups(gemm_kernel<T, AK, BKC, GATHER, FM, FN, EPI, NW>, 64 * NW);
+    static const int persist = RALF_GEMM_PERSISTENT;
+    const int total = P.nwg * P.d.splitk;
+    int grid = total;
+    const int room = std::max(8, cap / nbatch / 8 * 8);
+    if (persist && total > room) {   // equal shares: every workgroup gets `rounds` (or rounds - 1) tiles
+        const int rounds = ceil_div(total, room);
+        grid = std::min(room, ceil_div(ceil_div(total, rounds), 8) * 8);
+    }
+    hipLaunchKernelGGL((gemm_kernel<T, AK, BKC, GATHER, FM, FN, EPI, NW>), dim3(grid, 1, nbatch), dim3(64 * NW), 0, st, P);
     return ralf::check_launch("gemm");
 }
 
-template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN>
+template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int NW>
 int launch_epi(KParams& P, int nbatch, hipStream_t st) {
     const RalfGemmDesc& d = P.d;
     const bool lvl2 = d.C2 || d.act == RALF_ACT_GELU || d.aux_mode == RALF_AUX_GELU_GRAD || d.atomic_out;
     const bool lvl1 = d.drop_p > 0.f || d.aux;
-    if (lvl2) return launch<T, AK, BKC, GATHER, FM, FN, 2>(P, nbatch, st);
-    if (lvl1) return launch<T, AK, BKC, GATHER, FM, FN, 1>(P, nbatch, st);
-    return launch<T, AK, BKC, GATHER, FM, FN, 0>(P, nbatch, st);
+    if (lvl2) return launch<T, AK, BKC, GATHER, FM, FN, 2, NW>(P, nbatch, st);
+    if (lvl1) return launch<T, AK, BKC, GATHER, FM, FN, 1, NW>(P, nbatch, st);
+    return launch<T, AK, BKC, GATHER, FM, FN, 0, NW>(P, nbatch, st);
 }
 
-// tile choice, measured on MI355X (tools/gemm_bench.py): the short-K products of the model (K <= 1024) run
-// fastest on 64x64 tiles (5-7 workgroups per CU); 128x128 pays off only for long reductions that fill the chip.
+// Tile choice, measured on MI355X (tools/gemm_probe.hip, tools/gemm_bench.py).  Two configurations:
+//   64x64, 4 waves (4-5 workgroups per CU): s_memtime stamps + LDS cycle counts show it LDS-bound on the model's mid-size
+//     products (per tile and k-step: 16 KB of ds_write_b128 + 32 ds_read_b128 for 4 MFMAs per wave);
+//   128x128, 8 waves (2 x 4, 64x32 per wave, 2 workgroups = 16 waves per CU): a third fewer LDS cycles per flop and as
+//     many waves in flight -> 10-15 % faster wherever >= ~200 such tiles exist.  (128x128 with 4 waves of 64x64 has the
+//     fewest LDS cycles but only 8 waves per CU: latency-bound, no faster than 64x64 below K ~ 4096; 128x64 / 64x128: +-5 %.)
 template <typename T, bool AK, bool BKC, int GATHER>
 int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
     const RalfGemmDesc& d = P.d;
-    static const int forced = [] { const char* e = getenv("RALF_GEMM_TILE"); return e ? atoi(e) : 0; }();  // tuning aid: 22 / 11
+    static const int forced = [] { const char* e = getenv("RALF_GEMM_TILE"); return e ? atoi(e) : 0; }();  // tuning / test aid: 22 / 11
     const bool ok22 = !d.colstats || d.N % 128 == 0;   // column statistics come from the staged epilogue: every tile interior in n
-    if (forced == 22 && ok22) return launch_epi<T, AK, BKC, GATHER, 2, 2>(P, nbatch, st);
-    if (forced == 11) return launch_epi<T, AK, BKC, GATHER, 1, 1>(P, nbatch, st);
-    // (128x64 / 64x128 tiles were measured too -- tools/gemm_bench.py on a graph replay: within +-5 % of 64x64 on every
-    //  short-K shape of the model, which are bound by their output / operand streams and a ~5 us launch + tail, not by tile shape)
+    if (forced == 22 && ok22) return launch_epi<T, AK, BKC, GATHER, 2, 2, 8>(P, nbatch, st);
+    if (forced == 11) return launch_epi<T, AK, BKC, GATHER, 1, 1, 4>(P, nbatch, st);
     const int64_t big = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) * d.splitk * nbatch;
     const int kspan = ceil_div(d.K, d.splitk);
-    if (ok22 && d.N > 64 && d.M > 64 && kspan >= 1024 && big >= 512) return launch_epi<T, AK, BKC, GATHER, 2, 2>(P, nbatch, st);
-    return launch_epi<T, AK, BKC, GATHER, 1, 1>(P, nbatch, st);
+    const bool shape_ok = ok22 && d.M >= 128 && (d.N % 128 == 0 || d.N >= 512);
+    if (shape_ok && ((d.splitk == 1 && big >= 192) || (kspan >= 1024 && big >= 512))) return launch_epi<T, AK, BKC, GATHER, 2, 2, 8>(P, nbatch, st);
+    return launch_epi<T, AK, BKC, GATHER, 1, 1, 4>(P, nbatch, st);
 }
 
 template <typename T>

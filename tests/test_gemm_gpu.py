@@ -135,3 +135,17 @@ def test_column_statistics_epilogue(dtype, M, N, K):
     torch.testing.assert_close(res[0], o.mean(0), atol=1e-3, rtol=1e-3)
     torch.testing.assert_close(res[1], (o.var(0, unbiased=False) + 1e-5).rsqrt(), atol=1e-3, rtol=2e-3)
     assert int(cnt) == 1
+
+
+@pytest.mark.parametrize("tile", ["11", "22"])
+def test_every_case_on_a_forced_tile(tile):
+    """the tile heuristic picks 64x64 (4 waves) or 128x128 (8 waves) by shape; RALF_GEMM_TILE pins one of them (read once per
+    process), so the layout / epilogue / gather / column-statistics cases above are re-run in a child process on each."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, RALF_GEMM_TILE=tile)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "not forced_tile", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -4,6 +4,10 @@ import sys
 import torch
 
 sys.path.insert(0, ".")
+import os
+import ralf_amd._lib as _L
+if os.environ.get("RALF_LIB"):
+    _L.LIB_PATH = os.path.abspath(os.environ["RALF_LIB"])   # A/B runs of two builds
 from ralf_amd import ops  # noqa: E402
 
 
