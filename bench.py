@@ -192,6 +192,7 @@ def main():
     ap.add_argument("--skip-knn", action="store_true")
     ap.add_argument("--skip-split", action="store_true", help="skip the encoder-decoder-only timing")
     ap.add_argument("--no-overlap", action="store_true", help="parameter-gradient kernels on the main stream (no parallel graph branch)")
+    ap.add_argument("--dp-selftest", action="store_true", help="single GPU: run the data-parallel code path (1-rank RCCL group, staged backward, overlapped exchange)")
     a = ap.parse_args()
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
@@ -199,7 +200,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or a.dp_selftest:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from ralf_amd.engine import TrainStep
@@ -214,7 +217,8 @@ def main():
     inputs, targets = model.preprocess(batch)            # host path (tokenizer / constraint serialisation)
     inputs, targets = to_device(inputs, device), to_device(targets, device)
     inputs["retrieved"] = {k: v for k, v in inputs["retrieved"].items() if k != "image"}
-    step = TrainStep(model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, use_graph=not a.no_graph, overlap_wgrad=not a.no_overlap)
+    step = TrainStep(model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, use_graph=not a.no_graph, overlap_wgrad=not a.no_overlap,
+                     process_group=torch.distributed.group.WORLD if a.dp_selftest else None, overlap_allreduce=True if a.dp_selftest else None)
 
     for _ in range(max(a.warmup, 1)):
         loss = step(inputs, targets)
@@ -279,9 +283,17 @@ def main():
         if world == 1 and not a.skip_cpu:
             out["cpu_baseline"] = cpu_baseline_train(N)
             out["cpu_baseline_knn"] = cpu_baseline_knn()
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    else:
+        out = None
+    if world > 1 or a.dp_selftest:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if out is not None:
+        # the ONE json line goes out last: RCCL prints a version banner through C stdio (flushed at exit when piped)
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -19,6 +19,10 @@ import torch
 from . import ops
 
 
+# other threads (RCCL's watchdog polls events) may touch the HIP runtime while this thread captures
+_CAPTURE_MODE = "thread_local"
+
+
 def _align(n, a=64):
     return (n + a - 1) // a * a
 
@@ -115,6 +119,32 @@ def average_gradients(flat: torch.Tensor, world: int, group=None) -> None:
         torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=group)
 
 
+def flat_ranges(params, flat: torch.Tensor, align: int = 1):
+    """[(begin, end)] element ranges of the flat buffer `flat` covered by the .grad views of `params` (views INTO flat),
+    adjacent views merged (gaps up to `align` - 1 padding elements are bridged)."""
+    es = flat.element_size()
+    iv = sorted(((p.grad.data_ptr() - flat.data_ptr()) // es, p.numel()) for p in params)
+    out = []
+    for a, n in iv:
+        assert 0 <= a and a + n <= flat.numel(), "parameter gradient is not a view into the flat buffer"
+        if out and a - out[-1][1] < align:
+            out[-1][1] = a + n
+        else:
+            out.append([a, a + n])
+    return [(a, b) for a, b in out]
+
+
+def complement_ranges(ranges, total: int):
+    out, pos = [], 0
+    for a, b in sorted(ranges):
+        if a > pos:
+            out.append((pos, a))
+        pos = max(pos, b)
+    if pos < total:
+        out.append((pos, total))
+    return out
+
+
 def _clone_tree(x):
     if torch.is_tensor(x):
         return x.clone()
@@ -136,7 +166,7 @@ class TrainStep:
     """One optimisation step of `model` (a ralf_amd generator) = forward + backward + (all-reduce) + clip + AdamW."""
 
     def __init__(self, model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, backbone_lr_scale=0.1, betas=(0.9, 0.999), eps=1e-8,
-                 use_graph=True, process_group=None, overlap_wgrad=True):
+                 use_graph=True, process_group=None, overlap_wgrad=True, overlap_allreduce=None):
         self.model = model
         rt = model.rt.to(model.device)
         groups = model.optim_groups(base_lr=lr, weight_decay=weight_decay, custom_lr={"encoder.extractor.body": lr * backbone_lr_scale})
@@ -150,15 +180,54 @@ class TrainStep:
         self._graphs = None
         self.loss = None
         self.steps_done = 0
+        # Data parallel: the backward runs in two stages around rt.grad_cut() (after layer2 of the ResNet).  Stage 1
+        # (decoder, encoders, FPN, layer4, layer3) completes 94 % of the gradient bytes; their all-reduce runs on RCCL's
+        # stream WHILE stage 2 (layer2, layer1, stem: most of the backbone's backward time, 6 % of the bytes) computes.
+        # Only the small stage-2 exchange is exposed.  (xGMI is point-to-point: 172 MB cost ~1-2 ms per step un-overlapped.)
+        self.staged = bool(overlap_allreduce) if overlap_allreduce is not None else self.world > 1
+        self._late = self._early = None
+        if self.staged:
+            before = self._params_before_cut()
+            if before:
+                self._late = flat_ranges(before, self.opt.G, align=64)            # exchanged after stage 2
+                self._early = complement_ranges(self._late, self.opt.G.numel())     # exchanged during stage 2
+            else:
+                self.staged = False
 
-    # ---- the step body, split at the collective so multi-GPU runs can keep RCCL outside the graphs ----
+    def _params_before_cut(self):
+        out = []
+        for m in self.model.modules():
+            if hasattr(m, "parameters_before_cut"):
+                out += m.parameters_before_cut()
+        return out
+
+    # ---- the step body, split at the collectives so multi-GPU runs keep RCCL outside the graphs ----
     def _fwd_bwd(self, inputs, targets):
+        """forward + backward (stage 1 only when staged: down to the grad_cut points)"""
+        rt = self.model.rt
         self.opt.zero_grad()
-        _, losses = self.model.train_loss(inputs, targets)
+        rt.cut_enabled, rt._cuts = self.staged, []
+        try:
+            _, losses = self.model.train_loss(inputs, targets)
+        finally:
+            rt.cut_enabled = False
         loss = losses["nll_loss"]
         loss.backward(torch.full_like(loss, 1.0 / self.world) if self.world > 1 else None)
-        self.model.rt.join_side()
+        rt.join_side()
         return loss.detach()
+
+    def _bwd_rest(self):
+        """stage 2: the backward of everything in front of the grad_cut points"""
+        rt = self.model.rt
+        cuts, rt._cuts = rt._cuts, []
+        if cuts:
+            torch.autograd.backward([o for o, _ in cuts], [leaf.grad for _, leaf in cuts])
+            rt.join_side()
+
+    def _reduce(self, ranges, async_op):
+        if self.world <= 1 and self.pg is None:
+            return []
+        return [torch.distributed.all_reduce(self.opt.G[a:b], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=async_op) for a, b in ranges]
 
     def _allreduce(self):
         average_gradients(self.opt.G, self.world, self.pg)
@@ -167,9 +236,20 @@ class TrainStep:
         self.opt.step()
         self.model.rt.advance_seed()
 
+    def _exchange_around(self, stage2):
+        """stage-1 gradients on the wire while `stage2` (the rest of the backward) is issued; then the stage-2 gradients"""
+        works = self._reduce(self._early, True)
+        stage2()
+        for w in works:
+            w.wait()
+        self._reduce(self._late, False)
+
     def _eager(self, inputs, targets):
         loss = self._fwd_bwd(inputs, targets)
-        self._allreduce()
+        if self.staged:
+            self._exchange_around(self._bwd_rest)
+        else:
+            self._allreduce()
         self._update()
         return loss
 
@@ -181,9 +261,12 @@ class TrainStep:
                 self._capture(inputs, targets)
             else:
                 _copy_tree(self._static, {"inputs": inputs, "targets": targets})
-            ga, gb = self._graphs
+            ga, gm, gb = self._graphs
             ga.replay()
-            self._allreduce()
+            if gm is not None:
+                self._exchange_around(gm.replay)
+            else:
+                self._allreduce()
             gb.replay()
         self.steps_done += 1
         return self.loss
@@ -200,11 +283,15 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
+        gm = torch.cuda.CUDAGraph() if self.staged else None
+        with torch.cuda.graph(ga, capture_error_mode=_CAPTURE_MODE):
             self.loss = self._fwd_bwd(si, st)
-        with torch.cuda.graph(gb, pool=ga.pool()):
+        if gm is not None:
+            with torch.cuda.graph(gm, pool=ga.pool(), capture_error_mode=_CAPTURE_MODE):
+                self._bwd_rest()
+        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode=_CAPTURE_MODE):
             self._update()
-        self._graphs = (ga, gb)
+        self._graphs = (ga, gm, gb)
 
 
 class GraphedDecode:
@@ -228,7 +315,7 @@ class GraphedDecode:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with torch.cuda.graph(self._graph, capture_error_mode=_CAPTURE_MODE):
                 self._out = self.model.decode_tokens(s["enc"], s["seq"], self.cond_type, self.cfg, self.kv)
         else:
             _copy_tree(self._static, {"enc": enc_in, "seq": cond_seq})

@@ -34,6 +34,8 @@ class Runtime:
         self._side: list = []
         self.n_side = int(os.environ.get("RALF_SIDE_STREAMS", "1"))
         self._keep: list = []     # operands of side-stream work in flight (kept alive until join_side)
+        self.cut_enabled = False  # engine mode (data parallel): split the backward at grad_cut() points
+        self._cuts: list = []     # (tensor of the early graph, detached leaf the late graph continued from)
 
     def to(self, device):
         if self.seed is None or self.seed.device != device:
@@ -53,6 +55,16 @@ class Runtime:
 
     def drop_p(self, p: float) -> float:
         return p if (self.training and p > 0.0) else 0.0
+
+    def grad_cut(self, x: torch.Tensor) -> torch.Tensor:
+        """identity, unless the engine asked for a staged backward: then the autograd graph is cut here, so the
+        gradients of everything computed AFTER this point are complete (and can be exchanged between ranks) before the
+        backward of what came BEFORE it runs -- engine.TrainStep overlaps the two."""
+        if not (self.cut_enabled and torch.is_grad_enabled() and x.requires_grad):
+            return x
+        leaf = x.detach().requires_grad_()
+        self._cuts.append((x, leaf))
+        return leaf
 
     def register_shadow(self, w: torch.Tensor, view: torch.Tensor):
         self._shadow[id(w)] = view

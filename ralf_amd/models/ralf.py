@@ -309,7 +309,7 @@ class _GeneratorBase(nn.Module):
                     run()
                 torch.cuda.current_stream().wait_stream(side)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self.out[pos] = run()
                 self.graphs[pos] = g
             self.graphs[pos].replay()

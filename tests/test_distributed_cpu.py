@@ -42,3 +42,59 @@ def test_single_process_is_a_noop():
     g = torch.arange(8.0)
     average_gradients(g, 1)
     assert torch.equal(g, torch.arange(8.0))
+
+
+def test_flat_ranges_and_complement():
+    """the staged exchange addresses the flat gradient buffer by ranges: parameter views -> merged ranges (alignment padding
+    bridged), complement = everything else; together they tile the buffer exactly once."""
+    from ralf_amd.engine import complement_ranges, flat_ranges
+
+    flat = torch.zeros(64 * 10)
+    sizes = [(0, 50), (64, 64), (128, 7), (320, 100), (448, 64), (512, 30)]   # 64-aligned starts, as FlatAdamW lays them out
+    params = []
+    for a, n in sizes:
+        p = torch.nn.Parameter(torch.zeros(n))
+        p.grad = flat[a:a + n]
+        params.append(p)
+    r = flat_ranges(params[::-1], flat, align=64)
+    assert r == [(0, 135), (320, 542)]
+    c = complement_ranges(r, flat.numel())
+    assert c == [(135, 320), (542, 640)]
+    cover = torch.zeros(flat.numel())
+    for a, b in r + c:
+        cover[a:b] += 1
+    assert bool((cover == 1).all())
+    assert complement_ranges([], 10) == [(0, 10)] and complement_ranges([(0, 10)], 10) == []
+
+
+def _worker_ranges(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ralf_amd.engine import complement_ranges
+
+    torch.manual_seed(7 + rank)
+    flat = torch.randn(4096)
+    whole = flat.clone()
+    dist.all_reduce(whole)
+    late = [(0, 700), (1500, 1564)]
+    early = complement_ranges(late, flat.numel())
+    works = [dist.all_reduce(flat[a:b], async_op=True) for a, b in early]      # TrainStep._exchange_around
+    for w in works:
+        w.wait()
+    for a, b in late:
+        dist.all_reduce(flat[a:b])
+    q.put((rank, torch.equal(flat, whole), 0.0))
+    dist.destroy_process_group()
+
+
+def test_ranged_exchange_equals_whole_buffer_exchange_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_ranges, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res

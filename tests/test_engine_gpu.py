@@ -114,3 +114,59 @@ def test_lr_scale_changes_the_update_like_torch(golden):
         diff = (b[k] - a[k]).abs()
         # 2 steps at 1e-3 then 2 at 1e-4: an unscaled second epoch would be off by ~1.8e-3 on most elements
         assert (diff <= 3e-5 + 1e-4 * a[k].abs()).float().mean().item() >= 0.99, (k, diff.max().item())
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_staged_backward_with_overlapped_exchange_matches_plain_step(golden, use_graph):
+    """data-parallel mode: backward cut after layer2 of the ResNet, stage-1 gradients all-reduced (RCCL, a 1-rank group here)
+    while stage 2 runs, three graphs instead of two -- same losses and the same weights as the plain step."""
+    import os
+
+    import torch.distributed as dist
+    from ralf_amd.engine import TrainStep
+
+    if not dist.is_initialized():   # one 1-rank RCCL group for the whole test process (left to process exit)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29000 + os.getpid() % 2000))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    if True:
+        import bench
+        from ralf_amd.synthetic import make_batch, to_device
+
+        dev = torch.device("cuda", 0)
+        m1, m2 = bench.build_model(dev, 10, "bfloat16"), bench.build_model(dev, 10, "bfloat16")   # the full model: ResNet-50 + FPN in front
+        m2.load_state_dict(m1.state_dict())
+        inputs, tgt = m1.preprocess(make_batch(4, 10, seed=3))
+        inputs, tgt = to_device(inputs, dev), to_device(tgt, dev)
+        inputs["retrieved"] = {k: v for k, v in inputs["retrieved"].items() if k != "image"}
+        plain = TrainStep(m1, use_graph=use_graph, overlap_allreduce=False)
+        staged = TrainStep(m2, use_graph=use_graph, process_group=dist.group.WORLD, overlap_allreduce=True)
+        assert staged.staged and staged._late and staged._early
+        n_late = sum(b - a for a, b in staged._late)
+        assert 0 < n_late < 0.1 * staged.opt.G.numel()          # stem + layer1-2: a few percent of the gradient bytes
+        # reference for run-to-run noise (fp32 atomics reorder gradient sums; Adam turns sign flips of ~0 gradients into +-lr)
+        m3 = bench.build_model(dev, 10, "bfloat16")
+        m3.load_state_dict(m1.state_dict())
+        again = TrainStep(m3, use_graph=use_graph, overlap_allreduce=False)
+        lp = [plain(inputs, tgt).item() for _ in range(4)]
+        ls = [staged(inputs, tgt).item() for _ in range(4)]
+        la = [again(inputs, tgt).item() for _ in range(4)]
+        for a, b in zip(lp, ls):
+            assert abs(a - b) < 2e-2, (lp, ls, la)
+        torch.cuda.synchronize()
+
+        def close_fraction(x, y):
+            d = (x - y).abs()
+            return d.max().item(), (d <= 2e-6 + 1e-4 * x.abs()).float().mean().item()
+
+        # the gradients of the last step, stage by stage (relative to the gradient scale of each range)
+        for a, b in staged._late + staged._early:
+            ga, gs = plain.opt.G[a:b], staged.opt.G[a:b]
+            scale = ga.abs().max().item()
+            assert (ga - gs).abs().max().item() <= max(0.05 * scale, (ga - again.opt.G[a:b]).abs().max().item() * 4), (a, b, scale)
+        mx, frac = close_fraction(plain.opt.P, staged.opt.P)
+        mx0, frac0 = close_fraction(plain.opt.P, again.opt.P)
+        assert mx <= max(8e-4, 2 * mx0) and frac >= frac0 - 0.03, (mx, frac, mx0, frac0)
+        # stage 2 really produced the early-layer gradients (not zeros)
+        a, b = staged._late[0]
+        assert staged.opt.G[a:b].abs().sum().item() > 0
