@@ -222,6 +222,8 @@ def main():
 
     for _ in range(max(a.warmup, 1)):
         loss = step(inputs, targets)
+    if not a.no_graph:   # the batch lives in the buffers the captured graphs read (a loader writes the next batch in place)
+        inputs, targets = step.static_batch()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()

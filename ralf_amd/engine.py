@@ -155,7 +155,8 @@ def _clone_tree(x):
 
 def _copy_tree(dst, src):
     if torch.is_tensor(dst):
-        dst.copy_(src, non_blocking=True)
+        if dst is not src:   # a caller that filled the step's own buffers in place (static_batch()) pays no copy
+            dst.copy_(src, non_blocking=True)
     elif isinstance(dst, dict):
         for k in dst:
             if dst[k] is not None:
@@ -270,6 +271,12 @@ class TrainStep:
             gb.replay()
         self.steps_done += 1
         return self.loss
+
+    def static_batch(self):
+        """(inputs, targets) trees the captured graphs read: a loader may write the next batch INTO these tensors and pass
+        them back to __call__, which then replays without the ~120 small device copies of a fresh batch."""
+        assert self._static is not None, "static_batch() exists after the first graphed step"
+        return self._static["inputs"], self._static["targets"]
 
     def _capture(self, inputs, targets):
         self._static = _clone_tree({"inputs": inputs, "targets": targets})

@@ -170,3 +170,21 @@ def test_staged_backward_with_overlapped_exchange_matches_plain_step(golden, use
         # stage 2 really produced the early-layer gradients (not zeros)
         a, b = staged._late[0]
         assert staged.opt.G[a:b].abs().sum().item() > 0
+
+
+def test_static_batch_replay_equals_copied_batch(golden):
+    """a loader may fill TrainStep.static_batch() in place and hand the same tensors back: no per-tensor copies, same step"""
+    from ralf_amd.engine import TrainStep
+
+    m1, inputs, tgt = make(golden, "float32")
+    m2, _, _ = make(golden, "float32")
+    a, b = TrainStep(m1, use_graph=True), TrainStep(m2, use_graph=True)
+    a(inputs, tgt), b(inputs, tgt)
+    si, st = b.static_batch()
+    assert si["seq"].data_ptr() != inputs["seq"].data_ptr()
+    for _ in range(3):
+        la = a(inputs, tgt).item()
+        for k, v in tgt.items():          # "the loader": write the batch into the step's buffers
+            st[k].copy_(v)
+        lb = b(si, st).item()
+        assert abs(la - lb) < 2e-4, (la, lb)
