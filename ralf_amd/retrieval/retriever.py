@@ -20,6 +20,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .faiss_io import METRIC_INNER_PRODUCT, index_cache_path, read_flat_index, write_flat_index
 from .knn import FlatIPIndex
 
 LAYOUT_KEYS = ["center_x", "center_y", "width", "height", "label", "mask"]
@@ -57,9 +58,21 @@ class Retriever:
         if retrieval_backbone == "saliency" and feature_fn is None:
             feature_fn = lambda ex: coarse_saliency(torch.as_tensor(ex["saliency"]))  # noqa: E731
         self.feature_fn = feature_fn
-        if db_vectors is None:
+        # the reference's embedding cache (retriever.py:65-88): read `{dataset}_{backbone}_wo_head_index.faiss` when it exists,
+        # otherwise embed the split and write it, so either implementation can consume the other's cache directory
+        cache_file = index_cache_path(dataset_name, retrieval_backbone, cache_dir)
+        if db_vectors is None and kwargs.get("use_index_cache", True) and os.path.exists(cache_file):
+            db_vectors, metric = read_flat_index(cache_file)
+            if metric != METRIC_INNER_PRODUCT:
+                raise ValueError(f"{cache_file}: metric_type {metric}, the retrieval index is inner product")
+            if db_dataset is not None and len(db_dataset) != db_vectors.shape[0]:
+                raise ValueError(f"{cache_file}: {db_vectors.shape[0]} vectors for a database of {len(db_dataset)}")
+        elif db_vectors is None:
             assert feature_fn is not None, "pass feature_fn (image -> embedding) or db_vectors for non-saliency backbones"
             db_vectors = np.stack([np.asarray(feature_fn(db_dataset[i]), np.float32) for i in range(len(db_dataset))])
+            if kwargs.get("use_index_cache", True) and kwargs.get("save_index_cache", True):
+                os.makedirs(cache_dir, exist_ok=True)
+                write_flat_index(cache_file, db_vectors)
         self.index = FlatIPIndex(np.ascontiguousarray(db_vectors, np.float32), device=device)
         self.table_paired_id_idx = {self._id(db_dataset[i]["id"]): i for i in range(len(db_dataset))}
 
@@ -103,6 +116,11 @@ def merged_vectors(vector_sets: Sequence[np.ndarray], where_norm: str) -> np.nda
     if where_norm == "after_concat":
         out = out / np.linalg.norm(out, ord=2)
     return np.ascontiguousarray(out, np.float32)
+
+
+def load_backbone_vectors(dataset_name: str, backbones: Sequence[str], cache_dir: str = "cache"):
+    """the per-backbone embedding caches the reference merges (retriever.py:255-259: faiss.read_index + reconstruct_n)"""
+    return [read_flat_index(index_cache_path(dataset_name, b, cache_dir))[0] for b in backbones]
 
 
 def merge_retrieval_cache(dataset_name: str, split: str, backbones: Sequence[str], db_vector_sets, query_sets, data_ids, top_k: int,

@@ -1,5 +1,6 @@
 """CPU: host side of the retrieval pipeline -- re-rankers vs known answers recorded from the reference,
 coarse saliency feature, table file format."""
+import pytest
 import numpy as np
 import torch
 
@@ -38,3 +39,34 @@ def test_coarse_saliency_batch_equals_per_image():
     assert f.shape == (5, 256)
     for b in range(5):
         assert np.array_equal(f[b].numpy(), coarse_saliency(s[b]))
+
+
+def test_faiss_flat_index_file_layout_and_round_trip(tmp_path):
+    """the on-disk layout of a faiss flat index (faiss 1.7 index_write.cpp), spelled out byte by byte; the reader returns the
+    matrix, the writer reproduces the same bytes; non-flat / truncated / inconsistent files fail loudly"""
+    import struct
+
+    import numpy as np
+    from ralf_amd.retrieval.faiss_io import METRIC_INNER_PRODUCT, METRIC_L2, read_flat_index, write_flat_index
+
+    x = (np.arange(5 * 3, dtype=np.float32).reshape(5, 3) - 7) / 4
+    raw = b"IxFI" + struct.pack("<i", 3) + struct.pack("<q", 5) + struct.pack("<qq", 1 << 20, 1 << 20) + b"\x01" + struct.pack("<i", 0)
+    raw += struct.pack("<Q", 15) + x.astype("<f4").tobytes()
+    p = tmp_path / "pku_saliency_wo_head_index.faiss"
+    p.write_bytes(raw)
+    got, metric = read_flat_index(str(p))
+    assert metric == METRIC_INNER_PRODUCT and got.dtype == np.float32 and np.array_equal(got, x)
+    q = tmp_path / "w.faiss"
+    write_flat_index(str(q), x)
+    assert q.read_bytes() == raw
+    write_flat_index(str(q), x, METRIC_L2)
+    assert q.read_bytes()[:4] == b"IxF2" and read_flat_index(str(q))[1] == METRIC_L2
+    big = np.random.default_rng(0).standard_normal((1000, 257)).astype(np.float32)
+    write_flat_index(str(q), big)
+    assert np.array_equal(read_flat_index(str(q))[0], big)
+    for bad in (raw[:20], raw[:-4], b"IwFl" + raw[4:], raw[:45 - 8] + struct.pack("<Q", 14) + raw[45:], b"IxF2" + raw[4:]):
+        p.write_bytes(bad)
+        with pytest.raises(ValueError):
+            read_flat_index(str(p))
+    with pytest.raises(ValueError):
+        write_flat_index(str(q), np.zeros(4, np.float32))

@@ -43,6 +43,17 @@ def test_table_build_and_wrapper(tmp_path):
     n = len(db[j]["label"])
     assert ret["mask"][5].sum().item() == n and ret["label"][5, :n].tolist() == db[j]["label"]
     assert torch.allclose(ret["center_x"][5, :n], torch.tensor(db[j]["center_x"]))
+    # the embedding cache in faiss' flat-index file format: written above, re-read here instead of embedding again
+    from ralf_amd.retrieval.faiss_io import index_cache_path, read_flat_index
+
+    vec, metric = read_flat_index(index_cache_path("pku", "saliency", str(tmp_path)))
+    assert metric == 0 and np.array_equal(vec, X.astype(np.float32))
+
+    def no_embedding(_):
+        raise AssertionError("the cached index must be used")
+
+    r2 = Retriever(db_dataset=db, max_seq_length=10, top_k=16, dataset_name="pku", retrieval_backbone="saliency", cache_dir=str(tmp_path), feature_fn=no_embedding)
+    assert r2.preprocess_retrieval_cache("val", val, top_k=32, queries=Qv) == t_val
 
 
 def test_layout_features_and_mmr_rerank(golden):
