@@ -22,6 +22,11 @@ class Golden:
         self._z = np.load(os.path.join(GOLDEN, name))
         self.keys = list(self._z.keys())
 
+    def __getitem__(self, key):
+        import torch
+
+        return torch.from_numpy(self._z[key])
+
     def sub(self, prefix):
         import torch
 

@@ -567,9 +567,34 @@ def golden_relation():
     save("relation.npz", out)
 
 
+def golden_retrieval_augment():
+    """the RetrievalAugmentation block shared by the *_ra baselines (models/common/retrieval_augment.py:18-101)"""
+    import image2layout.train.models.common.retrieval_augment as rag
+
+    rag.load_fidnet_feature_extractor = fidnet_no_ckpt
+    m = rag.RetrievalAugmentation(d_model=256, dataset_name="pku", top_k=16, num_classes=3, max_seq_length=10, use_reference_image=False).eval()
+    shapes = load_det(m)
+    with open(os.path.join(HERE, "retrieval_augment_state_shapes.json"), "w") as f:
+        json.dump({"meta": META, "shapes": {k: list(v) for k, v in shapes.items()}}, f, indent=0)
+    B = 3
+    batch = synth_batch(31, B, 10, 16, 3)
+    retrieved = m.preprocess_retrieved_samples(batch["retrieved"])
+    g = torch.Generator().manual_seed(8)
+    feat = torch.randn(B, 12, 256, generator=g).requires_grad_(True)
+    w = torch.randn(B, 12 + 12 + 16, 256, generator=g)
+    memory = m(None, feat, retrieved)
+    (memory * w).sum().backward()
+    named = dict(m.named_parameters())
+    save("retrieval_augment.npz", {
+        "feat": feat, "w": w, "memory": memory, "gfeat": feat.grad,
+        "retrieved": {k: v for k, v in retrieved.items() if k not in ("image", "saliency")},
+        "grads": {k: named[k].grad for k in ["attn.to_kv.weight", "attn.to_out.0.bias", "head.net.1.weight", "layout_adapter.net.4.weight", "layout_adapter.net.0.bias"]},
+    })
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tokenizer", "host", "modules", "e2e", "sample", "reranker", "relation"]
+    which = sys.argv[1:] or ["tokenizer", "host", "modules", "e2e", "sample", "reranker", "relation", "retrieval_augment"]
     fns = {"tokenizer": golden_tokenizer, "host": golden_host_path, "modules": golden_modules, "e2e": golden_e2e, "sample": golden_sample,
-           "reranker": golden_reranker, "relation": golden_relation}
+           "reranker": golden_reranker, "relation": golden_relation, "retrieval_augment": golden_retrieval_augment}
     for w in which:
         fns[w]()

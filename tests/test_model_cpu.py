@@ -2,6 +2,7 @@
 import json
 import os
 
+import pytest
 import torch
 
 from conftest import GOLDEN
@@ -51,3 +52,14 @@ def test_optim_groups_rule():
             assert g["weight_decay"] == (0.0 if no_decay else 1e-4), n
     assert seen == {n for n, p in m.named_parameters() if p.requires_grad}
     assert {"RetrievalAugmented", "AuxilaryTask", "Autoreg"} <= {s for s in ("RetrievalAugmented", "AuxilaryTask", "Autoreg") if s in type(m).__name__}
+
+
+def test_retrieval_augmentation_state_dict_layout_matches_reference():
+    """checkpoints of the reference's `RetrievalAugmentation` (models/common/retrieval_augment.py) load strictly"""
+    from ralf_amd.models.retrieval_augment import RetrievalAugmentation
+
+    m = RetrievalAugmentation(d_model=256, dataset_name="pku", top_k=16, num_classes=3, max_seq_length=10, use_reference_image=False)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == dict(ref_shapes("retrieval_augment_state_shapes.json"))
+    assert not any(p.requires_grad for p in m.layout_encoder.parameters())
+    with pytest.raises(NotImplementedError):
+        RetrievalAugmentation(d_model=256, dataset_name="pku", top_k=16, num_classes=3, max_seq_length=10, use_reference_image=True)
