@@ -423,26 +423,32 @@ __global__ __launch_bounds__(256) void bn_partial_fold_kernel(const float* __res
 
 // y = relu?( x*scale + shift (+ res) ); 8 consecutive elements per thread.  relu_mask (optional, 1 bit per element, bit i of
 // byte j <-> element 8j+i): the backward kernels read it instead of y (1/16 of the bytes).
-template <typename T>
+// HOIST: the grid stride (gridDim.x * 256 * 8 elements) is a multiple of C, so a thread sees the SAME 8 channels in every
+// iteration and loads their coefficients once (they were 4 of the 6 vector loads per iteration: the kernel ran at the L1 rate).
+template <typename T, bool HOIST>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const T* __restrict__ res, T* __restrict__ y, uint8_t* __restrict__ relu_mask,
                                                         int64_t total8, int C, int relu) {
     constexpr int NV = VW<T>::N, H = 8 / NV;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total8; e += (int64_t)gridDim.x * 256) {
-        const int c0 = (int)((e * 8) % C);
+    float sc[8], sh[8];
+    auto coef = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            VW<float>::load(scale + c0 + 4 * q, *reinterpret_cast<float (*)[4]>(&sc[4 * q]));
+            VW<float>::load(shift + c0 + 4 * q, *reinterpret_cast<float (*)[4]>(&sh[4 * q]));
+        }
+    };
+    const int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (HOIST && e0 < total8) coef((int)((e0 * 8) % C));
+    for (int64_t e = e0; e < total8; e += (int64_t)gridDim.x * 256) {
+        if (!HOIST) coef((int)((e * 8) % C));
         uint32_t bits = 0;
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-            float xv[NV], o[NV], sc[NV], sh[NV];
+            float xv[NV], o[NV];
             VW<T>::load(x + e * 8 + h * NV, xv);
-            VW<float>::load(scale + c0 + h * NV, *reinterpret_cast<float (*)[4]>(&sc[0]));
-            VW<float>::load(shift + c0 + h * NV, *reinterpret_cast<float (*)[4]>(&sh[0]));
-            if constexpr (NV == 8) {
-                VW<float>::load(scale + c0 + 4, *reinterpret_cast<float (*)[4]>(&sc[4]));
-                VW<float>::load(shift + c0 + 4, *reinterpret_cast<float (*)[4]>(&sh[4]));
-            }
 #pragma unroll
-            for (int i = 0; i < NV; ++i) o[i] = xv[i] * sc[i] + sh[i];
+            for (int i = 0; i < NV; ++i) o[i] = xv[i] * sc[h * NV + i] + sh[h * NV + i];
             if (res) {
                 float rv[NV];
                 VW<T>::load(res + e * 8 + h * NV, rv);
@@ -460,14 +466,26 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 }
 
 // dx = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M);  dres = g (gradient of the fused residual add); 8 elements per thread
-template <typename T>
+template <typename T, bool HOIST>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ s1, const float* __restrict__ s2, T* __restrict__ dx, T* __restrict__ dres,
                                                             int64_t total8, int C, float invM, int relu, const uint8_t* __restrict__ mask) {
     constexpr int NV = VW<T>::N, H = 8 / NV;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total8; e += (int64_t)gridDim.x * 256) {
-        const int c0 = (int)((e * 8) % C);
+    float mu[8], rs[8], gm[8], a1[8], a2[8];   // HOIST (see bn_apply_kernel): loaded once per thread instead of 10 vector loads per iteration
+    auto coef = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = c0 + 4 * q;
+            VW<float>::load(mean + c, *reinterpret_cast<float (*)[4]>(&mu[4 * q])); VW<float>::load(rstd + c, *reinterpret_cast<float (*)[4]>(&rs[4 * q]));
+            VW<float>::load(gamma + c, *reinterpret_cast<float (*)[4]>(&gm[4 * q]));
+            VW<float>::load(s1 + c, *reinterpret_cast<float (*)[4]>(&a1[4 * q])); VW<float>::load(s2 + c, *reinterpret_cast<float (*)[4]>(&a2[4 * q]));
+        }
+    };
+    const int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (HOIST && e0 < total8) coef((int)((e0 * 8) % C));
+    for (int64_t e = e0; e < total8; e += (int64_t)gridDim.x * 256) {
+        if (!HOIST) coef((int)((e * 8) % C));
         const uint32_t mbyte = (relu && mask) ? (uint32_t)mask[e] : 0xFFu;
 #pragma unroll
         for (int h = 0; h < H; ++h) {
@@ -485,21 +503,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                 for (int i = 0; i < NV; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
             }
 #pragma unroll
-            for (int q = 0; q < NV / 4; ++q) {
-                const int c = c0 + h * NV + q * 4;
-                float mu[4], rs[4], gm[4], a1[4], a2[4];
-                V4<float>::load(mean + c, mu); V4<float>::load(rstd + c, rs); V4<float>::load(gamma + c, gm);
-                V4<float>::load(s1 + c, a1); V4<float>::load(s2 + c, a2);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float xh = (xv[q * 4 + i] - mu[i]) * rs[i];
-                    o[q * 4 + i] = gm[i] * rs[i] * (g[q * 4 + i] - a1[i] * invM - xh * a2[i] * invM);
-                }
+            for (int i = 0; i < NV; ++i) {
+                const int c = h * NV + i;
+                const float xh = (xv[i] - mu[c]) * rs[c];
+                o[i] = gm[c] * rs[c] * (g[i] - a1[c] * invM - xh * a2[c] * invM);
             }
             VW<T>::store(dx + off, o);
             if (dres) VW<T>::store(dres + off, g);
         }
     }
+}
+
+// grid of a flat 8-elements-per-thread kernel: `hoist` = its stride is a multiple of C (per-thread channels loop-invariant)
+inline int flat_grid(int64_t total8, int C, bool* hoist) {
+    const int64_t need = (total8 + 255) / 256;
+    const int grid = (int)(need < 1 ? 1 : (need > 4096 ? 4096 : need));
+    *hoist = need <= 4096 || ((int64_t)grid * 2048) % C == 0;
+    return grid;
 }
 
 inline int grid_for(int64_t work_items, int per_block, int cap = 2048) {
@@ -646,7 +666,10 @@ extern "C" int ralf_bn_apply(int dtype, const void* x, const float* scale, const
                              int64_t M, int C, int relu, void* stream) {
     RALF_REQUIRE(x && scale && shift && y && C % 8 == 0, "bn_apply: bad arguments (C %% 8 == 0)");
     const int64_t total8 = M * C / 8;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(total8, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale, shift, (const T*)res, (T*)y, relu_mask, total8, C, relu));
+    bool hoist;
+    const int grid = flat_grid(total8, C, &hoist);
+    if (hoist) DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale, shift, (const T*)res, (T*)y, relu_mask, total8, C, relu));
+    else DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale, shift, (const T*)res, (T*)y, relu_mask, total8, C, relu));
     return ralf::check_launch("bn_apply");
 }
 
@@ -667,6 +690,9 @@ extern "C" int ralf_bn_bwd_apply(int dtype, const void* x, const void* dy, const
     RALF_REQUIRE(x && dy && mean && rstd && gamma && s1 && s2 && dx && (!relu || y || relu_mask), "bn_bwd_apply: bad arguments");
     RALF_REQUIRE(C % 8 == 0, "bn_bwd_apply: C %% 8 == 0");
     const int64_t total8 = M * C / 8;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(total8, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, s1, s2, (T*)dx, (T*)dres, total8, C, 1.f / (float)M, relu, relu_mask));
+    bool hoist;
+    const int grid = flat_grid(total8, C, &hoist);
+    if (hoist) DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, s1, s2, (T*)dx, (T*)dres, total8, C, 1.f / (float)M, relu, relu_mask));
+    else DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, gamma, s1, s2, (T*)dx, (T*)dres, total8, C, 1.f / (float)M, relu, relu_mask));
     return ralf::check_launch("bn_bwd_apply");
 }
