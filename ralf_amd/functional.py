@@ -495,6 +495,7 @@ class ConvFn(Function):
         ctx.bias = b
         ctx.cfg = (stride, pad, OH, OW, b is not None, rt)
         ctx.fork = fork
+        ctx.set_materialize_grads(False)   # no zero-filled "gradient" of the statistics output / an unused fork (59 fills per step)
         out = (y.view(B, OH, OW, Co),) + ((x,) if fork else ())
         if stats:
             if cst is None:   # shape not covered by the fused statistics: BatchNorm computes them itself
@@ -508,6 +509,8 @@ class ConvFn(Function):
         dskip = rest[0] if ctx.fork else None
         x, W = ctx.saved_tensors
         stride, pad, OH, OW, has_b, rt = ctx.cfg
+        if dy is None:   # only the fork alias carried a gradient
+            return (dskip,) + (None,) * 8
         B, H, Wd, C = x.shape
         Co, Ci, kh, kw = W.shape
         M = B * OH * OW

@@ -148,25 +148,23 @@ def test_staged_backward_with_overlapped_exchange_matches_plain_step(golden, use
         m3 = bench.build_model(dev, 10, "bfloat16")
         m3.load_state_dict(m1.state_dict())
         again = TrainStep(m3, use_graph=use_graph, overlap_allreduce=False)
-        lp = [plain(inputs, tgt).item() for _ in range(4)]
-        ls = [staged(inputs, tgt).item() for _ in range(4)]
-        la = [again(inputs, tgt).item() for _ in range(4)]
+        # first step: identical weights everywhere, so the gradient buffers differ only by summation-order noise
+        lp, ls, la = [plain(inputs, tgt).item()], [staged(inputs, tgt).item()], [again(inputs, tgt).item()]
+        torch.cuda.synchronize()
+        if not use_graph:   # (a graphed TrainStep's first call already ran 3 steps: warm-up x2 + the first replay)
+            for a, b in staged._late + staged._early:
+                ga, gs, gn = plain.opt.G[a:b], staged.opt.G[a:b], again.opt.G[a:b]
+                noise = (ga - gn).abs().max().item()
+                assert (ga - gs).abs().max().item() <= max(4 * noise, 1e-3 * ga.abs().max().item()), (a, b, noise)
+        lp += [plain(inputs, tgt).item() for _ in range(3)]
+        ls += [staged(inputs, tgt).item() for _ in range(3)]
+        la += [again(inputs, tgt).item() for _ in range(3)]
         for a, b in zip(lp, ls):
             assert abs(a - b) < 2e-2, (lp, ls, la)
         torch.cuda.synchronize()
-
-        def close_fraction(x, y):
-            d = (x - y).abs()
-            return d.max().item(), (d <= 2e-6 + 1e-4 * x.abs()).float().mean().item()
-
-        # the gradients of the last step, stage by stage (relative to the gradient scale of each range)
-        for a, b in staged._late + staged._early:
-            ga, gs = plain.opt.G[a:b], staged.opt.G[a:b]
-            scale = ga.abs().max().item()
-            assert (ga - gs).abs().max().item() <= max(0.05 * scale, (ga - again.opt.G[a:b]).abs().max().item() * 4), (a, b, scale)
-        mx, frac = close_fraction(plain.opt.P, staged.opt.P)
-        mx0, frac0 = close_fraction(plain.opt.P, again.opt.P)
-        assert mx <= max(8e-4, 2 * mx0) and frac >= frac0 - 0.03, (mx, frac, mx0, frac0)
+        mx = (plain.opt.P - staged.opt.P).abs().max().item()
+        mx0 = (plain.opt.P - again.opt.P).abs().max().item()
+        assert mx <= max(8e-4, 2 * mx0), (mx, mx0)       # Adam turns sign flips of ~0 gradients into +-lr per step
         # stage 2 really produced the early-layer gradients (not zeros)
         a, b = staged._late[0]
         assert staged.opt.G[a:b].abs().sum().item() > 0
