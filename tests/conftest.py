@@ -53,3 +53,16 @@ def golden():
         return cache[name]
 
     return get
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _dist_cleanup():
+    """a test may create a 1-rank RCCL group (tests/test_engine_gpu.py): shut it down once, at the end of the session"""
+    yield
+    try:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:
+        pass
