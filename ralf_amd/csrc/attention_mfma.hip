@@ -90,6 +90,7 @@ template <int DH>
 __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
     __shared__ __attribute__((aligned(16))) bf16 Ks[KT * L<DH>::LD];
     __shared__ __attribute__((aligned(16))) bf16 Vs[KT * L<DH>::LD];
+    __shared__ __attribute__((aligned(16))) uint8_t Ms[KT];   // per key of the staged tile: padded / beyond Sk (one byte load per key per TILE)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
     const WgId wg = wg_id((d.Sq + 63) / 64, d.H);
     const int b = wg.b, h = wg.h;
@@ -110,11 +111,15 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
     f32x4 o[DH / 16];
 #pragma unroll
     for (int c = 0; c < DH / 16; ++c) o[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m = -__builtin_inff(), l = 0.f;
+    // the per-score work bounds this kernel (VALU, not the matrix cores): scores live in the log2 domain (one multiply, one
+    // v_exp_f32 per score), masks come from LDS, the dropout hash uses full-rate integer ops (common.h)
+    float m = -__builtin_inff(), l = 0.f;   // running max / sum of 2^(score * scale * log2 e)
+    const float scale2 = d.scale * 1.4426950408889634f;
 
     for (int t0 = 0; t0 < d.Sk; t0 += KT) {
         stage<DH>(Ks, Kp, d.k_rs, t0, d.Sk);
         stage<DH>(Vs, Vp, d.v_rs, t0, d.Sk);
+        if (threadIdx.x < KT) Ms[threadIdx.x] = (t0 + (int)threadIdx.x >= d.Sk || (kpm && kpm[t0 + threadIdx.x])) ? 1 : 0;
         __syncthreads();
         if (active && !(d.causal && t0 > q0 + 15)) {
 #pragma unroll
@@ -130,11 +135,12 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
                 }
                 float p[8];
                 float mt = -__builtin_inff();
+                const uint32_t mw[2] = {*reinterpret_cast<const uint32_t*>(Ms + s0 + 4 * g), *reinterpret_cast<const uint32_t*>(Ms + s0 + 16 + 4 * g)};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int key = t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3);
-                    const bool masked = key >= d.Sk || (d.causal && key > qi) || (kpm && kpm[key]);
-                    p[j] = masked ? -__builtin_inff() : s[j >> 2][j & 3] * d.scale;
+                    const bool masked = ((mw[j >> 2] >> (8 * (j & 3))) & 0xffu) || (d.causal && key > qi);
+                    p[j] = masked ? -__builtin_inff() : s[j >> 2][j & 3] * scale2;
                     mt = fmaxf(mt, p[j]);
                 }
                 mt = xor_max(mt);
@@ -142,10 +148,10 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
                 // branch-free online softmax (matrix-core ops must not sit under divergent control flow): while a
                 // query has seen only masked keys mn = -inf -> use 0 as the reference so every exp() is exp(-inf) = 0
                 const float mref = mn > -__builtin_inff() ? mn : 0.f;
-                const float corr = __expf(m - mref);
+                const float corr = __builtin_amdgcn_exp2f(m - mref);
                 float ls = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { p[j] = __expf(p[j] - mref); ls += p[j]; }
+                for (int j = 0; j < 8; ++j) { p[j] = __builtin_amdgcn_exp2f(p[j] - mref); ls += p[j]; }
                 l = l * corr + xor_sum(ls);
                 m = mn;
                 bf16x8 pf;
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
             for (int r = 0; r < 4; ++r) t[r] = (bf16)(o[c][r] * inv);
             *reinterpret_cast<bf16x4*>(Op + c * 16 + 4 * g) = t;
         }
-        if (d.lse && g == 0) d.lse[((int64_t)b * d.H + h) * d.Sq + qi] = m + __logf(l);
+        if (d.lse && g == 0) d.lse[((int64_t)b * d.H + h) * d.Sq + qi] = m * 0.6931471805599453f + __logf(l);
     }
 }
 
@@ -188,6 +194,7 @@ template <int DH>
 __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const RalfAttnDesc d) {
     __shared__ __attribute__((aligned(16))) bf16 Ks[KT * L<DH>::LD];
     __shared__ __attribute__((aligned(16))) bf16 Vs[KT * L<DH>::LD];
+    __shared__ __attribute__((aligned(16))) uint8_t Ms[KT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
     const WgId wg = wg_id((d.Sq + 63) / 64, d.H);
     const int b = wg.b, h = wg.h;
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const RalfAttnDesc d) {
         for (int i = 0; i < 8; ++i) delta += (float)gf[c][i] * (float)of[i];
     }
     delta = xor_sum(delta);   // the 4 lane groups hold disjoint d slices of the same query
-    const float lse = qok ? d.lse[stat] : 0.f;
+    const float lse2 = qok ? d.lse[stat] * 1.4426950408889634f : 0.f, scale2 = d.scale * 1.4426950408889634f;
     if (qok && g == 0) d.delta[stat] = delta;
     f32x4 dq[DH / 16];
 #pragma unroll
@@ -226,6 +233,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const RalfAttnDesc d) {
     for (int t0 = 0; t0 < d.Sk; t0 += KT) {
         stage<DH>(Ks, Kp, d.k_rs, t0, d.Sk);
         stage<DH>(Vs, Vp, d.v_rs, t0, d.Sk);
+        if (threadIdx.x < KT) Ms[threadIdx.x] = (t0 + (int)threadIdx.x >= d.Sk || (kpm && kpm[t0 + threadIdx.x])) ? 1 : 0;
         __syncthreads();
         if (active && !(d.causal && t0 > q0 + 15)) {
 #pragma unroll
@@ -242,11 +250,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const RalfAttnDesc d) {
                     }
                 }
                 bf16x8 dsf;
+                const uint32_t mw[2] = {*reinterpret_cast<const uint32_t*>(Ms + s0 + 4 * g), *reinterpret_cast<const uint32_t*>(Ms + s0 + 16 + 4 * g)};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int key = t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3);
-                    const bool masked = key >= d.Sk || (d.causal && key > qi) || (kpm && kpm[key]) || !qok;
-                    const float p = masked ? 0.f : __expf(s[j >> 2][j & 3] * d.scale - lse);
+                    const bool masked = ((mw[j >> 2] >> (8 * (j & 3))) & 0xffu) || (d.causal && key > qi) || !qok;
+                    const float p = masked ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -lse2));
                     float dpv = dp[j >> 2][j & 3];
                     if (d.p_drop > 0.f) {
                         dpv = attn_rng24(rowkey, (uint32_t)key) >= thr ? dpv * inv_keep : 0.f;
@@ -294,6 +303,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
     const uint32_t thr = (uint32_t)(d.p_drop * 16777216.f);
     const float inv_keep = 1.f / (1.f - d.p_drop);
     const bool active = k0 < d.Sk;
+    const float scale2 = d.scale * 1.4426950408889634f;
     const int64_t stat0 = ((int64_t)b * d.H + h) * d.Sq;
 
     bf16x8 kf[DH / 32], vf[DH / 32];
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
         stage<DH>(Gs, Gp, d.do_rs, t0, d.Sq);
         if (threadIdx.x < KT) {
             const int qi = t0 + threadIdx.x;
-            Ls[threadIdx.x] = qi < d.Sq ? d.lse[stat0 + qi] : 0.f;
+            Ls[threadIdx.x] = qi < d.Sq ? d.lse[stat0 + qi] * 1.4426950408889634f : 0.f;   // log2 domain
             Ds[threadIdx.x] = qi < d.Sq ? d.delta[stat0 + qi] : 0.f;
             if (d.p_drop > 0.f) Rk[threadIdx.x] = attn_rowkey(seed, d.call_id, ((uint64_t)b * d.H + h) * d.Sq + qi);
         }
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
                 for (int j = 0; j < 8; ++j) {
                     const int ql = s0 + (j >> 2) * 16 + 4 * g + (j & 3), qi = t0 + ql;
                     const bool masked = kmasked || qi >= d.Sq || (d.causal && kj > qi);
-                    const float p = masked ? 0.f : __expf(s[j >> 2][j & 3] * d.scale - Ls[ql]);
+                    const float p = masked ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -Ls[ql]));
                     float pd = p, dpv = dp[j >> 2][j & 3];
                     if (d.p_drop > 0.f) {
                         const bool keep = attn_rng24(Rk[ql], (uint32_t)kj) >= thr;

