@@ -759,8 +759,8 @@ int launch(KParams& P, int nbatch, hipStream_t st) {
     P.tiles_m = ceil_div(P.d.M, 64 * FM);
     P.tiles_n = ceil_div(P.d.N, 64 * FN);
     P.nwg = P.tiles_m * P.tiles_n;
-    static const int cap = resident_workgroups(gemm_kernel<T, AK, BKC, GATHER, FM, FN, EPI, NW>, 64 * NW);
-    static const int persist = RALF_GEMM_PERSISTENT;
+    constexpr bool persist = RALF_GEMM_PERSISTENT != 0;   // off: measured -4...+6 % (the prefetch across the epilogue costs a wave of occupancy)
+    static const int cap = persist ? resident_workgroups(gemm_kernel<T, AK, BKC, GATHER, FM, FN, EPI, NW>, 64 * NW) : 0;
     const int total = P.nwg * P.d.splitk;
     int grid = total;
     const int room = std::max(8, cap / nbatch / 8 * 8);
