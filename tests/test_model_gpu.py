@@ -154,6 +154,26 @@ def test_backbone_fp32_vs_oracle(training):
     assert int(bn.num_batches_tracked) == 1
 
 
+def test_backbone_real_canvas_350x240_fp32_vs_oracle():
+    """the datasets' real canvas (350 x 240, common/image.py:88: layer-3 map 22 x 15 = 330 tokens): odd intermediate sizes
+    (175, 88, 11 x 8) and a non-integer nearest up-sampling ratio (8 -> 15 columns) in the FPN"""
+    sd = det_state_dict(resnet50_fpn_shapes())
+    img = torch.rand(1, 4, 350, 240, generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        ref = O.resnet50_fpn(img, sd, training=False)
+    B, C, h, w = ref.shape
+    assert (h, w) == (22, 15)
+    bb = RN.ResnetFeatureExtractor(256)
+    bb.load_state_dict({k[len("encoder."):]: v.detach().clone() for k, v in sd.items()}, strict=True)
+    bb = bb.cuda()
+    rt = RN.Runtime(torch.float32).to(torch.device("cuda"))
+    with torch.no_grad():
+        out = bb(img.cuda(), rt)
+    assert out.shape == (1, 330, 256)
+    want = ref.flatten(2).transpose(1, 2) + RN.pos2d_sine(h, w, C)
+    torch.testing.assert_close(out.cpu(), want, atol=2e-4, rtol=2e-4)
+
+
 @pytest.mark.parametrize("inpl,planes,stride,ds,H,W", [(2048, 512, 1, False, 4, 5), (1024, 512, 2, True, 8, 10), (64, 64, 1, True, 16, 20)])
 def test_bottleneck_blocks_fp32(inpl, planes, stride, ds, H, W):
     """one ResNet bottleneck (conv/BN/ReLU/residual, train-mode statistics) forward + all gradients vs torch."""
