@@ -25,7 +25,7 @@ STEP_GFLOP_PER_SAMPLE = {10: 50.1, 32: 56.4}
 ENCDEC_GFLOP_PER_SAMPLE = {10: 15.98, 32: 22.29}   # everything except ResNet-50 + FPN
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-TRAIN_TRAFFIC_BYTES = 45.6e9  # HBM bytes per train step (B=64): rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, profiles/r01l_train_step_hbm_traffic_pmc.txt
+TRAIN_TRAFFIC_BYTES = 45.6e9  # HBM bytes per train step (B=64): rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, profiles/r01o_train_step_hbm_traffic_pmc.txt
 KNN_TRAFFIC_BYTES = 446.2e6  # HBM bytes per knn_scores launch at nq=16: rocprofv3 FETCH_SIZE x2 (gfx950) + WRITE_SIZE, profiles/r01_knn_pmc.txt
 
 
