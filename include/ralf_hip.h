@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 4
+#define RALF_ABI_VERSION 5
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -190,6 +190,12 @@ int ralf_upsample_nearest_bwd(int dtype, const void* g_up, int64_t ld_up, const 
  * (mode 0) or top-k multinomial with temperature (mode 1, counter-based RNG).  logits fp32 [B,V], V <= 1024. */
 int ralf_mask_sample(const float* logits, const uint8_t* allowed, const int64_t* forced, int mode, int top_k, float temperature,
                      const int64_t* seed, uint64_t call_id, int64_t* out, int B, int V, void* stream);
+/* the same, and the chosen token also lands where the NEXT decode step reads it (no slice / compare / concatenate kernels between
+ * steps): seq_out[b * seq_ld] = token (column of the [B, max_len+1] sequence buffer, may be NULL), pad_flag_out[b * flag_ld] =
+ * (token == pad_id) (column of the uint8 key-padding mask of the self-attention, may be NULL) */
+int ralf_mask_sample_step(const float* logits, const uint8_t* allowed, const int64_t* forced, int mode, int top_k, float temperature,
+                          const int64_t* seed, uint64_t call_id, int64_t* out, int64_t* seq_out, int64_t seq_ld, uint8_t* pad_flag_out,
+                          int64_t flag_ld, int64_t pad_id, int B, int V, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused attention (ralf_amd/csrc/attention.hip): O = dropout(softmax(scale*Q K^T + mask)) V.
@@ -206,6 +212,7 @@ typedef struct RalfAttnDesc {
     uint64_t call_id;
     int B, H, Sq, Sk, dh, dtype, causal;
     float scale, p_drop;
+    int64_t kpm_bs; /* row stride of kpm in bytes; 0 = Sk (a decode loop keeps ONE [B, max_len] mask and grows Sk) */
 } RalfAttnDesc;
 int ralf_attention_fwd(const RalfAttnDesc* d, void* stream);
 int ralf_attention_bwd(const RalfAttnDesc* d, void* stream);

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const RalfAttnDesc d) {
     const T* Qp = (const T*)d.q + b * d.q_bs + (int64_t)h * DH;
     const T* Kp = (const T*)d.k + b * d.k_bs + (int64_t)h * DH;
     const T* Vp = (const T*)d.v + b * d.v_bs + (int64_t)h * DH;
-    const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * d.Sk : nullptr;
+    const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * (d.kpm_bs ? d.kpm_bs : (int64_t)d.Sk) : nullptr;
     const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
     const uint32_t thr = (uint32_t)(d.p_drop * 16777216.f);
     const float inv_keep = 1.f / (1.f - d.p_drop);
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const RalfAttnDesc d) 
     const T* Vp = (const T*)d.v + b * d.v_bs + (int64_t)h * DH;
     const T* Op = (const T*)d.o + b * d.o_bs + (int64_t)h * DH;
     const T* dOp = (const T*)d.dout + b * d.do_bs + (int64_t)h * DH;
-    const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * d.Sk : nullptr;
+    const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * (d.kpm_bs ? d.kpm_bs : (int64_t)d.Sk) : nullptr;
     const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
     const uint32_t thr = (uint32_t)(d.p_drop * 16777216.f);
     const float inv_keep = 1.f / (1.f - d.p_drop);
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const RalfAttnDesc d)
     const T* Kp = (const T*)d.k + b * d.k_bs + (int64_t)h * DH;
     const T* Vp = (const T*)d.v + b * d.v_bs + (int64_t)h * DH;
     const T* dOp = (const T*)d.dout + b * d.do_bs + (int64_t)h * DH;
-    const bool kmasked = !kok || (d.kpm && d.kpm[(int64_t)b * d.Sk + kj]);
+    const bool kmasked = !kok || (d.kpm && d.kpm[(int64_t)b * (d.kpm_bs ? d.kpm_bs : (int64_t)d.Sk) + kj]);
     const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
     const uint32_t thr = (uint32_t)(d.p_drop * 16777216.f);
     const float inv_keep = 1.f / (1.f - d.p_drop);

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
     const bf16* Qp = (const bf16*)d.q + b * d.q_bs + (int64_t)h * DH;
     const bf16* Kp = (const bf16*)d.k + b * d.k_bs + (int64_t)h * DH;
     const bf16* Vp = (const bf16*)d.v + b * d.v_bs + (int64_t)h * DH;
-    const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * d.Sk : nullptr;
+    const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * (d.kpm_bs ? d.kpm_bs : (int64_t)d.Sk) : nullptr;
     const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
     const uint32_t thr = (uint32_t)(d.p_drop * 16777216.f);
     const float inv_keep = 1.f / (1.f - d.p_drop);
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const RalfAttnDesc d) {
     const bf16* Vp = (const bf16*)d.v + b * d.v_bs + (int64_t)h * DH;
     const bf16* Op = (const bf16*)d.o + b * d.o_bs + (int64_t)h * DH;
     const bf16* Gp = (const bf16*)d.dout + b * d.do_bs + (int64_t)h * DH;
-    const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * d.Sk : nullptr;
+    const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * (d.kpm_bs ? d.kpm_bs : (int64_t)d.Sk) : nullptr;
     const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
     const uint32_t thr = (uint32_t)(d.p_drop * 16777216.f);
     const float inv_keep = 1.f / (1.f - d.p_drop);
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
     const bf16* Kp = (const bf16*)d.k + b * d.k_bs + (int64_t)h * DH;
     const bf16* Vp = (const bf16*)d.v + b * d.v_bs + (int64_t)h * DH;
     const bf16* Gp = (const bf16*)d.dout + b * d.do_bs + (int64_t)h * DH;
-    const bool kmasked = !kok || (d.kpm && d.kpm[(int64_t)b * d.Sk + kj]);
+    const bool kmasked = !kok || (d.kpm && d.kpm[(int64_t)b * (d.kpm_bs ? d.kpm_bs : (int64_t)d.Sk) + kj]);
     const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
     const uint32_t thr = (uint32_t)(d.p_drop * 16777216.f);
     const float inv_keep = 1.f / (1.f - d.p_drop);
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const RalfAttnDesc d) 
     const bf16* Qp = (const bf16*)d.q + b * d.q_bs + hp * 64 + chunk * 8;
     const bf16* Kp = (const bf16*)d.k + b * d.k_bs + hp * 64 + chunk * 8;
     const bf16* Vp = (const bf16*)d.v + b * d.v_bs + hp * 64 + chunk * 8;
-    const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * d.Sk : nullptr;
+    const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * (d.kpm_bs ? d.kpm_bs : (int64_t)d.Sk) : nullptr;
     float qv[8];
     {
         const bf16x8 t = *reinterpret_cast<const bf16x8*>(Qp);

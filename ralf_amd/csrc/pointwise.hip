@@ -337,12 +337,18 @@ __global__ void upsample_bwd_kernel(const T* __restrict__ g1, int64_t ld1, const
 //   with the counter-based generator (inverse CDF in lane-major order).
 __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ allowed,
                                                            const int64_t* __restrict__ forced, int mode, int top_k, float temperature,
-                                                           const int64_t* __restrict__ seed, uint64_t call, int64_t* __restrict__ out, int B, int V) {
+                                                           const int64_t* __restrict__ seed, uint64_t call, int64_t* __restrict__ out, int B, int V,
+                                                           int64_t* __restrict__ seq_out, int64_t seq_ld, uint8_t* __restrict__ flag_out, int64_t flag_ld, int64_t pad_id) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
+    auto emit = [&](int64_t tok) {   // lane 0: the token, its column of the sequence buffer, its key-padding flag
+        out[row] = tok;
+        if (seq_out) seq_out[(int64_t)row * seq_ld] = tok;
+        if (flag_out) flag_out[(int64_t)row * flag_ld] = tok == pad_id ? 1 : 0;
+    };
     const float NEG = -__builtin_inff();
     const int64_t f = forced ? forced[row] : -1;
-    if (f >= 0) { if (lane == 0) out[row] = f; return; }
+    if (f >= 0) { if (lane == 0) emit(f); return; }
     const float* x = logits + (int64_t)row * V;
     constexpr int MAXPER = 16;  // V <= 1024
     float v[MAXPER];
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restric
         const int oi = __shfl_xor(bi, o);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
-    if (mode == 0 || top_k <= 1) { if (lane == 0) out[row] = bi; return; }
+    if (mode == 0 || top_k <= 1) { if (lane == 0) emit(bi); return; }
     // k-th largest value: peel the maximum k-1 times (ties are removed one at a time)
     float kth = best;
     {
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restric
     const unsigned long long ball = __ballot(mine);
     const int owner = ball ? __ffsll((long long)ball) - 1 : -1;
     const int res = owner >= 0 ? __shfl(pick, owner) : bi;
-    if (lane == 0) out[row] = res;
+    if (lane == 0) emit(res);
 }
 
 }  // namespace
@@ -504,10 +510,17 @@ extern "C" int ralf_upsample_nearest_bwd(int dtype, const void* g_up, int64_t ld
 /* decode-space restriction + sampling on the device (helpers/sampling.py:18-71, decoding_space_restriction.py):
  * logits fp32 [B,V] (V <= 1024), allowed uint8 [V] or NULL, forced int64 [B] or NULL (-1 = free),
  * mode 0 deterministic (argmax), 1 top-k multinomial with temperature; out int64 [B] */
-extern "C" int ralf_mask_sample(const float* logits, const uint8_t* allowed, const int64_t* forced, int mode, int top_k, float temperature,
-                                const int64_t* seed, uint64_t call_id, int64_t* out, int B, int V, void* stream) {
+extern "C" int ralf_mask_sample_step(const float* logits, const uint8_t* allowed, const int64_t* forced, int mode, int top_k, float temperature,
+                                     const int64_t* seed, uint64_t call_id, int64_t* out, int64_t* seq_out, int64_t seq_ld, uint8_t* pad_flag_out,
+                                     int64_t flag_ld, int64_t pad_id, int B, int V, void* stream) {
     RALF_REQUIRE(logits && out && B > 0 && V > 0 && V <= 1024, "mask_sample: bad arguments (V <= 1024)");
     RALF_REQUIRE(mode == 0 || (mode == 1 && seed && top_k >= 1 && temperature > 0.f), "mask_sample: top-k sampling needs a seed, k >= 1, T > 0");
-    hipLaunchKernelGGL(mask_sample_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, logits, allowed, forced, mode, top_k, temperature, seed, call_id, out, B, V);
+    RALF_REQUIRE((!seq_out || seq_ld > 0) && (!pad_flag_out || flag_ld > 0), "mask_sample: output strides must be positive");
+    hipLaunchKernelGGL(mask_sample_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, logits, allowed, forced, mode, top_k, temperature, seed, call_id, out, B, V,
+                       seq_out, seq_ld, pad_flag_out, flag_ld, pad_id);
     return ralf::check_launch("mask_sample");
+}
+extern "C" int ralf_mask_sample(const float* logits, const uint8_t* allowed, const int64_t* forced, int mode, int top_k, float temperature,
+                                const int64_t* seed, uint64_t call_id, int64_t* out, int B, int V, void* stream) {
+    return ralf_mask_sample_step(logits, allowed, forced, mode, top_k, temperature, seed, call_id, out, nullptr, 0, nullptr, 0, -1, B, V, stream);
 }

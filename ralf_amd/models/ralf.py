@@ -219,17 +219,37 @@ class _GeneratorBase(nn.Module):
         T = self.tokenizer.max_token_length
         name = _get(sampling_cfg, "name")
         cache = None
+        fused = name in ("deterministic", "top_k")   # vocabulary mask + restriction + choice in one kernel
+        forced_all = forced_tokens_all(cond_seq, cond_type, ids["pad"], ids["eos"], T) if fused else None
+        if use_kv_cache and fused:
+            # static buffers for the whole loop: the sampling kernel writes each token into its column of `seqbuf`, its
+            # padding flag into `padbuf` (the self-attention's key-padding mask, read with row stride T + 1) and hands the
+            # contiguous token vector to the next step -- no slice / compare / concatenate kernels between steps
+            cache = RN.decoder_init_cache(self.decoder, memory, self.rt, T)
+            seqbuf = torch.full((B, T + 1), ids["pad"], dtype=torch.long, device=dev)
+            seqbuf[:, :start + 1] = seq
+            padbuf = (seqbuf == ids["pad"]).to(torch.uint8)
+            for j in range(start):   # prefix given by the condition (partial): fill the cache
+                RN.decoder_step(self.decoder, seqbuf[:, j].contiguous(), j, cache, self.rt, padbuf, kpm_stride=T + 1)
+            tok = seqbuf[:, start].contiguous()
+            mode, k = (0 if name == "deterministic" else 1), int(_get(sampling_cfg, "top_k", 1) or 1)
+            temp = float(_get(sampling_cfg, "temperature", 1.0) or 1.0)
+            for i in range(start, T):
+                logits = RN.decoder_step(self.decoder, tok, i, cache, self.rt, padbuf, kpm_stride=T + 1)
+                tok = RN.ops.mask_sample(logits, token_mask_u8[i], forced_all[i] if forced_all is not None else None, mode, k, temp,
+                                         self.rt.seed, 1000 + i, seq_col=seqbuf[:, i + 1], pad_flag_col=padbuf[:, i + 1], pad_id=ids["pad"])
+            self.rt.advance_seed()   # on-device: the next call (or graph replay) draws different samples
+            return seqbuf[:, 1:]
         if use_kv_cache:  # O(S) decoder work per sample instead of the reference's O(S^2) prefix recompute
             cache = RN.decoder_init_cache(self.decoder, memory, self.rt, T)
             for j in range(start):  # prefix given by the condition (partial): fill the cache
                 RN.decoder_step(self.decoder, seq[:, j].contiguous(), j, cache, self.rt, (seq[:, :j + 1] == ids["pad"]).to(torch.uint8).contiguous())
-        forced_all = forced_tokens_all(cond_seq, cond_type, ids["pad"], ids["eos"], T) if name in ("deterministic", "top_k") else None
         for i in range(start, T):
             if cache is not None:
                 logits = RN.decoder_step(self.decoder, seq[:, i].contiguous(), i, cache, self.rt, (seq == ids["pad"]).to(torch.uint8).contiguous())
             else:
                 logits = self.decoder(seq, memory, self.rt, seq == ids["pad"])[:, i].clone()
-            if name in ("deterministic", "top_k"):   # vocabulary mask + restriction + choice fused in one kernel
+            if fused:
                 forced = forced_all[i] if forced_all is not None else None
                 nxt = RN.ops.mask_sample(logits.float(), token_mask_u8[i], forced, 0 if name == "deterministic" else 1,
                                          int(_get(sampling_cfg, "top_k", 1) or 1), float(_get(sampling_cfg, "temperature", 1.0) or 1.0),

@@ -218,10 +218,12 @@ def decoder_init_cache(dec: "BaseDecoder", memory: torch.Tensor, rt: Runtime, ma
 
 
 @torch.no_grad()
-def decoder_step(dec: "BaseDecoder", tok: torch.Tensor, pos: int, cache: DecodeCache, rt: Runtime, kpm_prefix: torch.Tensor) -> torch.Tensor:
+def decoder_step(dec: "BaseDecoder", tok: torch.Tensor, pos: int, cache: DecodeCache, rt: Runtime, kpm_prefix: torch.Tensor,
+                 kpm_stride: Optional[int] = None) -> torch.Tensor:
     """one KV-cached decode step: token ids [B] at position `pos` -> fp32 logits [B, V].  kpm_prefix uint8
     [B, pos+1] marks padded prefix tokens (tgt_key_padding_mask of the reference's full-prefix call,
-    retrieval_augmented_autoreg.py:274-279).  Same arithmetic as BaseDecoder.forward restricted to the last row."""
+    retrieval_augmented_autoreg.py:274-279); with `kpm_stride` it is the [B, kpm_stride] mask buffer of the whole loop, of
+    which the first pos+1 columns are read.  Same arithmetic as BaseDecoder.forward restricted to the last row."""
     B = tok.shape[0]
     d, H = dec.d_model, dec.transformer.layers[0].self_attn.nhead
     dh = d // H
@@ -235,7 +237,7 @@ def decoder_step(dec: "BaseDecoder", tok: torch.Tensor, pos: int, cache: DecodeC
         skv = cache.self_kv[li]
         # k,v of the new token go straight into row `pos` of the cache (row stride = L*2d)
         ops.gemm(h, W[d:], B, 2 * d, d, bias=bvec[d:], out=skv.view(B, L * 2 * d)[:, pos * 2 * d:], ldc=L * 2 * d)
-        o, _ = ops.attention_fwd(q.view(B, 1, d), skv, skv, B, H, 1, pos + 1, dh, 0, 0, d, causal=False, kpm=kpm_prefix, need_lse=False, kv_rows=L)
+        o, _ = ops.attention_fwd(q.view(B, 1, d), skv, skv, B, H, 1, pos + 1, dh, 0, 0, d, causal=False, kpm=kpm_prefix, need_lse=False, kv_rows=L, kpm_stride=kpm_stride)
         x = ops.gemm(o.view(B, d), rt.lp(sa.out_proj.weight), B, d, d, bias=sa.out_proj.bias.detach(), res=x)
         h, _, _ = ops.layernorm_fwd(x, layer.norm2.weight.detach(), layer.norm2.bias.detach(), save_stats=False)
         q = ops.gemm(h, rt.lp(ca.in_proj_weight)[:d], B, d, d, bias=ca.in_proj_bias.detach()[:d])

@@ -321,7 +321,7 @@ def attention_fwd(q, k, v, B, H, Sq, Sk, dh, q_off=0, k_off=0, v_off=0, causal=F
     lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device) if need_lse else None
     d = _attn_desc(q, k, v, o, B, H, Sq, Sk, dh, q_off, k_off, v_off, causal, kpm, scale if scale is not None else dh ** -0.5, p_drop, seed, call_id, kv_rows)
     d.lse = _p(lse)
-    assert kpm_stride is None or kpm_stride == Sk, "key-padding mask rows must be Sk long"
+    d.kpm_bs = int(kpm_stride) if kpm_stride else 0   # kpm rows longer than Sk: one [B, max_len] mask for a growing prefix
     _call("ralf_attention_fwd", ctypes.byref(d))
     return o, lse
 
@@ -354,9 +354,24 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, coef=None, shadow=None, s
     _call("ralf_adamw", _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr, beta1, beta2, eps, wd, step, _p(coef), _p(step_dev), _p(lr_scale))
 
 
-def mask_sample(logits, allowed=None, forced=None, mode=0, top_k=1, temperature=1.0, seed=None, call_id=0):
-    """decode-space mask + token choice on the device -> int64 [B]."""
+def mask_sample(logits, allowed=None, forced=None, mode=0, top_k=1, temperature=1.0, seed=None, call_id=0,
+                seq_col=None, pad_flag_col=None, pad_id=-1):
+    """decode-space mask + token choice on the device -> int64 [B].  seq_col / pad_flag_col: COLUMN views of the [B, L] int64
+    sequence buffer / uint8 key-padding mask that also receive the token / (token == pad_id)."""
     B, V = logits.shape
     out = torch.empty(B, dtype=torch.int64, device=logits.device)
-    _call("ralf_mask_sample", _p(logits.contiguous()), _p(allowed), _p(forced), mode, top_k, temperature, _p(seed), call_id, _p(out), B, V)
+    if seq_col is None and pad_flag_col is None:
+        _call("ralf_mask_sample", _p(logits.contiguous()), _p(allowed), _p(forced), mode, top_k, temperature, _p(seed), call_id, _p(out), B, V)
+        return out
+
+    def col(t, dtype):
+        if t is None:
+            return None, 0
+        assert t.dtype == dtype and t.dim() == 1 and t.shape[0] == B and t.stride(0) > 0
+        return ctypes.c_void_p(t.data_ptr()), t.stride(0)
+
+    sp, sl = col(seq_col, torch.int64)
+    fp, fl = col(pad_flag_col, torch.uint8)
+    _call("ralf_mask_sample_step", _p(logits.contiguous()), _p(allowed), _p(forced), mode, top_k, temperature, _p(seed), call_id, _p(out),
+          sp, sl, fp, fl, int(pad_id), B, V)
     return out

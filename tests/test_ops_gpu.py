@@ -308,6 +308,15 @@ def test_mask_sample():
     assert (got - want).abs().max() < 0.015, (got, want)
     d2 = ops.mask_sample(x, allowed.to(torch.uint8).cuda(), None, mode=1, top_k=5, temperature=0.7, seed=seed, call_id=3).cpu()
     assert torch.equal(draws, d2)   # counter-based: same seed/call -> same draws
+    # decode-loop form: the token also lands in a column of the sequence buffer, its pad flag in a column of the mask buffer
+    seqbuf = torch.full((B, 9), -7, dtype=torch.int64, device="cuda")
+    padbuf = torch.full((B, 9), 9, dtype=torch.uint8, device="cuda")
+    out2 = ops.mask_sample(logits.cuda(), allowed.to(torch.uint8).cuda(), forced.cuda(), mode=0, seq_col=seqbuf[:, 4], pad_flag_col=padbuf[:, 6], pad_id=517)
+    assert torch.equal(out2.cpu(), ref) and torch.equal(seqbuf[:, 4].cpu(), ref) and torch.equal(padbuf[:, 6].cpu(), (ref == 517).to(torch.uint8))
+    assert bool((seqbuf[:, [0, 1, 2, 3, 5, 6, 7, 8]] == -7).all()) and bool((padbuf[:, [0, 1, 2, 3, 4, 5, 7, 8]] == 9).all())
+    d3 = ops.mask_sample(x, allowed.to(torch.uint8).cuda(), None, mode=1, top_k=5, temperature=0.7, seed=seed, call_id=3,
+                         seq_col=torch.empty(20000, 2, dtype=torch.int64, device="cuda")[:, 1]).cpu()
+    assert torch.equal(draws, d3)
 
 
 @pytest.mark.parametrize("B,Sk,pad", [(3, 1, False), (5, 51, True), (4, 532, False), (2, 700, True)])
@@ -332,3 +341,9 @@ def test_attention_decode_step(B, Sk, pad):
     close(o, ref, torch.bfloat16)
     o2, _ = ops.attention_fwd(q.cuda(), kv.cuda(), kv.cuda(), B, H, 1, Sk, dh, 0, 0, d, causal=False, kpm=kp, need_lse=True, kv_rows=L)   # tiled kernel
     close(o, o2.float().cpu(), torch.bfloat16)
+    if pad:   # the decode loop's form of the mask: ONE [B, max_len] buffer, rows longer than the prefix (RalfAttnDesc.kpm_bs)
+        wide = torch.ones(B, Sk + 5, dtype=torch.uint8)
+        wide[:, :Sk] = kpm.to(torch.uint8)
+        for need_lse in (False, True):
+            o3, _ = ops.attention_fwd(q.cuda(), kv.cuda(), kv.cuda(), B, H, 1, Sk, dh, 0, 0, d, causal=False, kpm=wide.cuda(), need_lse=need_lse, kv_rows=L, kpm_stride=Sk + 5)
+            assert torch.equal(o3, o if not need_lse else o2)
