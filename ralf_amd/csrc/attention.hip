@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const RalfAttnDesc d) {
     const T* Vp = (const T*)d.v + b * d.v_bs + (int64_t)h * DH;
     const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * (d.kpm_bs ? d.kpm_bs : (int64_t)d.Sk) : nullptr;
     const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
-    const uint32_t thr = (uint32_t)(d.p_drop * 16777216.f);
+    const uint32_t thr = attn_thr16(d.p_drop);
     const float inv_keep = 1.f / (1.f - d.p_drop);
 
     float q[DH], o[DH];
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const RalfAttnDesc d) {
                         float pd = p;
                         if (d.p_drop > 0.f) {
                             const uint32_t rk = attn_rowkey(seed, d.call_id, ((uint64_t)b * d.H + h) * d.Sq + qi);
-                            pd = attn_rng24(rk, (uint32_t)(kbase + j0 + j)) >= thr ? p * inv_keep : 0.f;
+                            pd = attn_keep(rk, (uint32_t)(kbase + j0 + j), thr) ? p * inv_keep : 0.f;
                         }
                         const float* vr = Vs + (wave * SL + j0 + j) * DH;
 #pragma unroll
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const RalfAttnDesc d) 
     const T* dOp = (const T*)d.dout + b * d.do_bs + (int64_t)h * DH;
     const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * (d.kpm_bs ? d.kpm_bs : (int64_t)d.Sk) : nullptr;
     const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
-    const uint32_t thr = (uint32_t)(d.p_drop * 16777216.f);
+    const uint32_t thr = attn_thr16(d.p_drop);
     const float inv_keep = 1.f / (1.f - d.p_drop);
     const int64_t stat = ((int64_t)b * d.H + h) * d.Sq + qi;
 
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const RalfAttnDesc d) 
                 const float p = masked ? 0.f : __expf(s - lse);
                 if (d.p_drop > 0.f) {
                     const uint32_t rk = attn_rowkey(seed, d.call_id, ((uint64_t)b * d.H + h) * d.Sq + qi);
-                    dp = attn_rng24(rk, (uint32_t)key) >= thr ? dp * inv_keep : 0.f;
+                    dp = attn_keep(rk, (uint32_t)key, thr) ? dp * inv_keep : 0.f;
                 }
                 const float ds = p * (dp - delta);
 #pragma unroll
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const RalfAttnDesc d)
     const T* dOp = (const T*)d.dout + b * d.do_bs + (int64_t)h * DH;
     const bool kmasked = !kok || (d.kpm && d.kpm[(int64_t)b * (d.kpm_bs ? d.kpm_bs : (int64_t)d.Sk) + kj]);
     const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
-    const uint32_t thr = (uint32_t)(d.p_drop * 16777216.f);
+    const uint32_t thr = attn_thr16(d.p_drop);
     const float inv_keep = 1.f / (1.f - d.p_drop);
 
     float k[DH], v[DH], dk[DH], dv[DH];
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const RalfAttnDesc d)
                 float pd = p;
                 if (d.p_drop > 0.f) {
                     const uint32_t rk = attn_rowkey(seed, d.call_id, ((uint64_t)b * d.H + h) * d.Sq + qi);
-                    const bool keep = attn_rng24(rk, (uint32_t)kj) >= thr;
+                    const bool keep = attn_keep(rk, (uint32_t)kj, thr);
                     pd = keep ? p * inv_keep : 0.f;
                     dp = keep ? dp * inv_keep : 0.f;
                 }

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
     __shared__ __attribute__((aligned(16))) bf16 Ks[KT * L<DH>::LD];
     __shared__ __attribute__((aligned(16))) bf16 Vs[KT * L<DH>::LD];
     __shared__ __attribute__((aligned(16))) uint8_t Ms[KT];   // per key of the staged tile: padded / beyond Sk (one byte load per key per TILE)
+    __shared__ int tile_any;                                    // any such key in the tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
     const WgId wg = wg_id((d.Sq + 63) / 64, d.H);
     const int b = wg.b, h = wg.h;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
     const bf16* Vp = (const bf16*)d.v + b * d.v_bs + (int64_t)h * DH;
     const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * (d.kpm_bs ? d.kpm_bs : (int64_t)d.Sk) : nullptr;
     const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
-    const uint32_t thr = (uint32_t)(d.p_drop * 16777216.f);
+    const uint32_t thr = attn_thr16(d.p_drop);
     const float inv_keep = 1.f / (1.f - d.p_drop);
     const uint32_t rowkey = d.p_drop > 0.f ? attn_rowkey(seed, d.call_id, ((uint64_t)b * d.H + h) * d.Sq + qi) : 0u;   // once per query row
     const bool active = q0 < d.Sq;  // wave-uniform
@@ -119,8 +120,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
     for (int t0 = 0; t0 < d.Sk; t0 += KT) {
         stage<DH>(Ks, Kp, d.k_rs, t0, d.Sk);
         stage<DH>(Vs, Vp, d.v_rs, t0, d.Sk);
-        if (threadIdx.x < KT) Ms[threadIdx.x] = (t0 + (int)threadIdx.x >= d.Sk || (kpm && kpm[t0 + threadIdx.x])) ? 1 : 0;
+        if (threadIdx.x < KT) {   // wave 0
+            const bool mk = t0 + (int)threadIdx.x >= d.Sk || (kpm && kpm[t0 + threadIdx.x]);
+            Ms[threadIdx.x] = mk ? 1 : 0;
+            const unsigned long long any = __ballot(mk);
+            if (threadIdx.x == 0) tile_any = any != 0ull ? 1 : 0;
+        }
         __syncthreads();
+        const bool tile_masked = tile_any != 0;
         if (active && !(d.causal && t0 > q0 + 15)) {
 #pragma unroll
             for (int s0 = 0; s0 < KT; s0 += 32) {
@@ -135,13 +142,18 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
                 }
                 float p[8];
                 float mt = -__builtin_inff();
-                const uint32_t mw[2] = {*reinterpret_cast<const uint32_t*>(Ms + s0 + 4 * g), *reinterpret_cast<const uint32_t*>(Ms + s0 + 16 + 4 * g)};
+                if (tile_masked || d.causal) {   // wave-uniform: most tiles of the model (no padded key, not causal) skip the mask work
+                    const uint32_t mw[2] = {*reinterpret_cast<const uint32_t*>(Ms + s0 + 4 * g), *reinterpret_cast<const uint32_t*>(Ms + s0 + 16 + 4 * g)};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int key = t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3);
-                    const bool masked = ((mw[j >> 2] >> (8 * (j & 3))) & 0xffu) || (d.causal && key > qi);
-                    p[j] = masked ? -__builtin_inff() : s[j >> 2][j & 3] * scale2;
-                    mt = fmaxf(mt, p[j]);
+                    for (int j = 0; j < 8; ++j) {
+                        const int key = t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3);
+                        const bool masked = ((mw[j >> 2] >> (8 * (j & 3))) & 0xffu) || (d.causal && key > qi);
+                        p[j] = masked ? -__builtin_inff() : s[j >> 2][j & 3] * scale2;
+                        mt = fmaxf(mt, p[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { p[j] = s[j >> 2][j & 3] * scale2; mt = fmaxf(mt, p[j]); }
                 }
                 mt = xor_max(mt);
                 const float mn = fmaxf(m, mt);
@@ -155,14 +167,16 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
                 l = l * corr + xor_sum(ls);
                 m = mn;
                 bf16x8 pf;
+                if (d.p_drop > 0.f) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float pd = p[j];
-                    if (d.p_drop > 0.f) {
-                        const int key = t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3);
-                        pd = attn_rng24(rowkey, (uint32_t)key) >= thr ? pd * inv_keep : 0.f;
+                    for (int j = 0; j < 8; j += 2) {   // keys j, j+1 of this lane are an (even, odd) pair: one hash for both
+                        const uint32_t h = attn_rng2x16(rowkey, (uint32_t)(t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3)) >> 1);
+                        pf[j] = (bf16)((h & 0xffffu) >= thr ? p[j] * inv_keep : 0.f);
+                        pf[j + 1] = (bf16)((h >> 16) >= thr ? p[j + 1] * inv_keep : 0.f);
                     }
-                    pf[j] = (bf16)pd;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (bf16)p[j];
                 }
 #pragma unroll
                 for (int c = 0; c < DH / 16; ++c) {
@@ -195,6 +209,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const RalfAttnDesc d) {
     __shared__ __attribute__((aligned(16))) bf16 Ks[KT * L<DH>::LD];
     __shared__ __attribute__((aligned(16))) bf16 Vs[KT * L<DH>::LD];
     __shared__ __attribute__((aligned(16))) uint8_t Ms[KT];
+    __shared__ int tile_any;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
     const WgId wg = wg_id((d.Sq + 63) / 64, d.H);
     const int b = wg.b, h = wg.h;
@@ -207,7 +222,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const RalfAttnDesc d) {
     const bf16* Gp = (const bf16*)d.dout + b * d.do_bs + (int64_t)h * DH;
     const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * (d.kpm_bs ? d.kpm_bs : (int64_t)d.Sk) : nullptr;
     const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
-    const uint32_t thr = (uint32_t)(d.p_drop * 16777216.f);
+    const uint32_t thr = attn_thr16(d.p_drop);
     const float inv_keep = 1.f / (1.f - d.p_drop);
     const uint32_t rowkey = d.p_drop > 0.f ? attn_rowkey(seed, d.call_id, ((uint64_t)b * d.H + h) * d.Sq + qi) : 0u;   // once per query row
     const bool active = q0 < d.Sq;
@@ -233,8 +248,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const RalfAttnDesc d) {
     for (int t0 = 0; t0 < d.Sk; t0 += KT) {
         stage<DH>(Ks, Kp, d.k_rs, t0, d.Sk);
         stage<DH>(Vs, Vp, d.v_rs, t0, d.Sk);
-        if (threadIdx.x < KT) Ms[threadIdx.x] = (t0 + (int)threadIdx.x >= d.Sk || (kpm && kpm[t0 + threadIdx.x])) ? 1 : 0;
+        if (threadIdx.x < KT) {   // wave 0
+            const bool mk = t0 + (int)threadIdx.x >= d.Sk || (kpm && kpm[t0 + threadIdx.x]);
+            Ms[threadIdx.x] = mk ? 1 : 0;
+            const unsigned long long any = __ballot(mk);
+            if (threadIdx.x == 0) tile_any = any != 0ull ? 1 : 0;
+        }
         __syncthreads();
+        const bool tile_masked = tile_any != 0;
         if (active && !(d.causal && t0 > q0 + 15)) {
 #pragma unroll
             for (int s0 = 0; s0 < KT; s0 += 32) {
@@ -250,17 +271,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const RalfAttnDesc d) {
                     }
                 }
                 bf16x8 dsf;
-                const uint32_t mw[2] = {*reinterpret_cast<const uint32_t*>(Ms + s0 + 4 * g), *reinterpret_cast<const uint32_t*>(Ms + s0 + 16 + 4 * g)};
+                float pj[8];
+                if (tile_masked || d.causal || !qok) {
+                    const uint32_t mw[2] = {*reinterpret_cast<const uint32_t*>(Ms + s0 + 4 * g), *reinterpret_cast<const uint32_t*>(Ms + s0 + 16 + 4 * g)};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int key = t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3);
-                    const bool masked = ((mw[j >> 2] >> (8 * (j & 3))) & 0xffu) || (d.causal && key > qi) || !qok;
-                    const float p = masked ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -lse2));
-                    float dpv = dp[j >> 2][j & 3];
-                    if (d.p_drop > 0.f) {
-                        dpv = attn_rng24(rowkey, (uint32_t)key) >= thr ? dpv * inv_keep : 0.f;
+                    for (int j = 0; j < 8; ++j) {
+                        const int key = t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3);
+                        const bool masked = ((mw[j >> 2] >> (8 * (j & 3))) & 0xffu) || (d.causal && key > qi) || !qok;
+                        pj[j] = masked ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -lse2));
                     }
-                    dsf[j] = (bf16)(p * (dpv - delta));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pj[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -lse2));
+                }
+                if (d.p_drop > 0.f) {
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const uint32_t h = attn_rng2x16(rowkey, (uint32_t)(t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3)) >> 1);
+                        const float d0 = (h & 0xffffu) >= thr ? dp[j >> 2][j & 3] * inv_keep : 0.f;
+                        const float d1 = (h >> 16) >= thr ? dp[(j + 1) >> 2][(j + 1) & 3] * inv_keep : 0.f;
+                        dsf[j] = (bf16)(pj[j] * (d0 - delta));
+                        dsf[j + 1] = (bf16)(pj[j + 1] * (d1 - delta));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dsf[j] = (bf16)(pj[j] * (dp[j >> 2][j & 3] - delta));
                 }
 #pragma unroll
                 for (int c = 0; c < DH / 16; ++c) dq[c] = mfma16(frag_cols_T<DH>(Ks, s0, c * 16, lane), dsf, dq[c]);
@@ -300,7 +335,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
     const bf16* Gp = (const bf16*)d.dout + b * d.do_bs + (int64_t)h * DH;
     const bool kmasked = !kok || (d.kpm && d.kpm[(int64_t)b * (d.kpm_bs ? d.kpm_bs : (int64_t)d.Sk) + kj]);
     const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
-    const uint32_t thr = (uint32_t)(d.p_drop * 16777216.f);
+    const uint32_t thr = attn_thr16(d.p_drop);
     const float inv_keep = 1.f / (1.f - d.p_drop);
     const bool active = k0 < d.Sk;
     const float scale2 = d.scale * 1.4426950408889634f;
@@ -350,7 +385,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
                     const float p = masked ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -Ls[ql]));
                     float pd = p, dpv = dp[j >> 2][j & 3];
                     if (d.p_drop > 0.f) {
-                        const bool keep = attn_rng24(Rk[ql], (uint32_t)kj) >= thr;
+                        const bool keep = attn_keep(Rk[ql], (uint32_t)kj, thr);
                         pd = keep ? p * inv_keep : 0.f;
                         dpv = keep ? dpv * inv_keep : 0.f;
                     }

@@ -41,14 +41,20 @@ __device__ __forceinline__ uint32_t attn_rowkey(uint64_t seed, uint64_t call, ui
     z ^= z >> 31;
     return (uint32_t)(z >> 32) ^ (uint32_t)z;
 }
-__device__ __forceinline__ uint32_t attn_rng24(uint32_t rowkey, uint32_t key) {
-    // full-rate integer instructions only (24-bit multiplies, shifts, xors): the attention kernels are VALU-bound on their
-    // per-score work (~40 issue slots per score against 1/8 MFMA), and each 32-bit v_mul_lo_u32 of the former lowbias32
-    // finalizer costs four slots.  Checked on 4 M (row, key) pairs: keep rate 0.9000 at p = 0.1, adjacent-key and
-    // adjacent-row correlation < 1e-3, chi^2 / dof of the top and low byte 1.0-1.2 (also with sequential row keys).
-    uint32_t x = rowkey ^ __umul24(key, 0x9E3779u);
+// keep(row, key) = field(attn_rng2x16(rowkey(row), key >> 1), key & 1) >= p * 2^16: ONE hash decides a PAIR of adjacent keys
+// (two 16-bit fields), so the kernels whose lanes hold adjacent keys of a row (forward, dQ) hash once per two scores.
+// Full-rate integer instructions only (24-bit multiplies, shifts, xors): the attention kernels are VALU-bound on their per-score
+// work, and a 32-bit v_mul_lo_u32 costs four issue slots.  Checked on 4 M (row, key) pairs (also with sequential row keys):
+// keep rate 0.8998-0.9000 at p = 0.1; correlation within a pair, between pairs and between rows < 1.1e-3.
+__device__ __forceinline__ uint32_t attn_rng2x16(uint32_t rowkey, uint32_t pair) {
+    uint32_t x = rowkey ^ __umul24(pair, 0x9E3779u);
     x ^= x >> 16; x = __umul24(x, 0xEB352Du);
     x ^= x >> 15; x = __umul24(x, 0xA68B6Bu);
-    x ^= x >> 16;
-    return x >> 8;
+    x ^= x >> 15;
+    return x;
+}
+__device__ __forceinline__ uint32_t attn_thr16(float p_drop) { return (uint32_t)(p_drop * 65536.f); }
+__device__ __forceinline__ bool attn_keep(uint32_t rowkey, uint32_t key, uint32_t thr16) {
+    const uint32_t h = attn_rng2x16(rowkey, key >> 1);
+    return ((key & 1u) ? (h >> 16) : (h & 0xffffu)) >= thr16;
 }
