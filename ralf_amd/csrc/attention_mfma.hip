@@ -322,8 +322,8 @@ template <int DH>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
     __shared__ __attribute__((aligned(16))) bf16 Qs[KT * L<DH>::LD];
     __shared__ __attribute__((aligned(16))) bf16 Gs[KT * L<DH>::LD];
-    __shared__ float Ls[KT], Ds[KT];
-    __shared__ uint32_t Rk[KT];   // per-query dropout row keys of the staged query tile
+    __shared__ __attribute__((aligned(16))) float Ls[KT], Ds[KT];
+    __shared__ __attribute__((aligned(16))) uint32_t Rk[KT];   // per-query dropout row keys of the staged query tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
     const WgId wg = wg_id((d.Sk + 63) / 64, d.H);
     const int b = wg.b, h = wg.h;
@@ -378,19 +378,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
                     }
                 }
                 bf16x8 pf, dsf;
+                // the lane's 8 queries are two runs of 4: their statistics / row keys come as 16-byte LDS reads
+                const f32x4 L4[2] = {*reinterpret_cast<const f32x4*>(Ls + s0 + 4 * g), *reinterpret_cast<const f32x4*>(Ls + s0 + 16 + 4 * g)};
+                const f32x4 D4[2] = {*reinterpret_cast<const f32x4*>(Ds + s0 + 4 * g), *reinterpret_cast<const f32x4*>(Ds + s0 + 16 + 4 * g)};
+                float pj[8];
+                if (!d.causal && t0 + KT <= d.Sq) {   // wave-uniform: whole query tile valid, only this lane's key can be masked
+                    const float kz = kmasked ? 0.f : 1.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int ql = s0 + (j >> 2) * 16 + 4 * g + (j & 3), qi = t0 + ql;
-                    const bool masked = kmasked || qi >= d.Sq || (d.causal && kj > qi);
-                    const float p = masked ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -Ls[ql]));
-                    float pd = p, dpv = dp[j >> 2][j & 3];
-                    if (d.p_drop > 0.f) {
-                        const bool keep = attn_keep(Rk[ql], (uint32_t)kj, thr);
-                        pd = keep ? p * inv_keep : 0.f;
-                        dpv = keep ? dpv * inv_keep : 0.f;
+                    for (int j = 0; j < 8; ++j) pj[j] = kz * __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -L4[j >> 2][j & 3]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int qi = t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3);
+                        const bool masked = kmasked || qi >= d.Sq || (d.causal && kj > qi);
+                        pj[j] = masked ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -L4[j >> 2][j & 3]));
                     }
-                    pf[j] = (bf16)pd;
-                    dsf[j] = (bf16)(p * (dpv - Ds[ql]));
+                }
+                if (d.p_drop > 0.f) {
+                    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+                    const u32x4v R4[2] = {*reinterpret_cast<const u32x4v*>(Rk + s0 + 4 * g), *reinterpret_cast<const u32x4v*>(Rk + s0 + 16 + 4 * g)};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const bool keep = attn_keep(R4[j >> 2][j & 3], (uint32_t)kj, thr);
+                        pf[j] = (bf16)(keep ? pj[j] * inv_keep : 0.f);
+                        dsf[j] = (bf16)(pj[j] * ((keep ? dp[j >> 2][j & 3] * inv_keep : 0.f) - D4[j >> 2][j & 3]));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        pf[j] = (bf16)pj[j];
+                        dsf[j] = (bf16)(pj[j] * (dp[j >> 2][j & 3] - D4[j >> 2][j & 3]));
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < DH / 16; ++c) {
