@@ -723,8 +723,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams P, int
     if (P.vec_epi && d.N % 4 == 0) {
         for (int64_t e4 = (int64_t)blockIdx.x * 256 + threadIdx.x; e4 < total / 4; e4 += (int64_t)gridDim.x * 256) {
             const int64_t e = e4 * 4;
+            // slabs summed in split order (deterministic); 8 loads in flight: a tiny output with 64 splits was one dependent
+            // load after the other (33-63 us for the layer1 weight gradients)
             float4 a = *reinterpret_cast<const float4*>(P.partial + e);
-            for (int s = 1; s < d.splitk; ++s) {
+            int s = 1;
+            for (; s + 8 <= d.splitk; s += 8) {
+                float4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(P.partial + (int64_t)(s + u) * total + e);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { a.x += t[u].x; a.y += t[u].y; a.z += t[u].z; a.w += t[u].w; }
+            }
+            for (; s < d.splitk; ++s) {
                 const float4 t = *reinterpret_cast<const float4*>(P.partial + (int64_t)s * total + e);
                 a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
             }

@@ -163,7 +163,7 @@ def _2d(x):
     return x.reshape(-1, x.shape[-1])
 
 
-_WGRAD_WG = int(os.environ.get("RALF_WGRAD_WG", "256"))   # tuning knob (measured: 256 best on MI355X)
+_WGRAD_WG = int(os.environ.get("RALF_WGRAD_WG", "512"))   # tuning knob (measured on MI355X: 512 best once the slab reduce keeps 8 loads in flight)
 
 
 def _splitk_for(out_rows: int, out_cols: int, red: int) -> int:
