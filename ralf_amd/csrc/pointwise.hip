@@ -168,6 +168,34 @@ __global__ void permute4_kernel(const TS* __restrict__ in, TD* __restrict__ out,
     }
 }
 
+// the same with an innermost output dim of exactly 8 (NCHW image -> NHWC with the channels padded to 8: one pixel per thread,
+// plane-wise coalesced reads, one 16-byte (bf16) / 32-byte (fp32) store instead of 8 scalar ones with index math per element)
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void permute4_pack8_kernel(const TS* __restrict__ in, TD* __restrict__ out, int d0, int d1, int d2, int64_t s0, int64_t s1, int64_t s2,
+                                                              int64_t s3, int valid3) {
+    const int64_t total = (int64_t)d0 * d1 * d2;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        int64_t t = e;
+        const int i2 = (int)(t % d2); t /= d2;
+        const int i1 = (int)(t % d1);
+        const int i0 = (int)(t / d1);
+        const int64_t base = i0 * s0 + i1 * s1 + i2 * s2;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = c < valid3 ? ld(in, base + c * s3) : 0.f;
+        if constexpr (sizeof(TD) == 2) {
+            typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+            bf16x8v o;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o[c] = (__bf16)v[c];
+            *reinterpret_cast<bf16x8v*>(out + e * 8) = o;
+        } else {
+            *reinterpret_cast<float4*>(out + e * 8) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(out + e * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+}
+
 // many permute4 jobs in ONE launch (the per-step re-layout of every 3x3 convolution weight: ~40 launches of a few
 // microseconds each otherwise); jobs[] lives in device memory, job j owns workgroups [first_block[j], first_block[j+1])
 template <typename TS, typename TD>
@@ -472,6 +500,12 @@ extern "C" int ralf_copy2d(int src_dtype, int dst_dtype, const void* src, void* 
 extern "C" int ralf_permute4(int src_dtype, int dst_dtype, const void* in, void* out, int d0, int d1, int d2, int d3, int64_t s0, int64_t s1, int64_t s2, int64_t s3,
                              int valid3, void* stream) {
     RALF_REQUIRE(in && out && d0 > 0 && d1 > 0 && d2 > 0 && d3 > 0, "permute4: bad arguments");
+    if (d3 == 8 && src_dtype == RALF_F32 && s2 == 1 && (((uintptr_t)out) & 31) == 0) {   // pixel packing (see permute4_pack8_kernel)
+        const dim3 gp(grid_for((int64_t)d0 * d1 * d2));
+        if (dst_dtype == RALF_F32) hipLaunchKernelGGL((permute4_pack8_kernel<float, float>), gp, dim3(256), 0, ST, (const float*)in, (float*)out, d0, d1, d2, s0, s1, s2, s3, valid3);
+        else hipLaunchKernelGGL((permute4_pack8_kernel<float, bf16>), gp, dim3(256), 0, ST, (const float*)in, (bf16*)out, d0, d1, d2, s0, s1, s2, s3, valid3);
+        return ralf::check_launch("permute4");
+    }
     const dim3 g(grid_for((int64_t)d0 * d1 * d2 * d3));
     if (src_dtype == RALF_F32 && dst_dtype == RALF_F32) hipLaunchKernelGGL((permute4_kernel<float, float>), g, dim3(256), 0, ST, (const float*)in, (float*)out, d0, d1, d2, d3, s0, s1, s2, s3, valid3);
     else if (src_dtype == RALF_F32) hipLaunchKernelGGL((permute4_kernel<float, bf16>), g, dim3(256), 0, ST, (const float*)in, (bf16*)out, d0, d1, d2, d3, s0, s1, s2, s3, valid3);

@@ -141,6 +141,13 @@ def test_pool_upsample_permute(dtype):
     ohwi = ops.permute4(w.cuda(), (6, 7, 7, 8), (4 * 49, 7, 1, 49), 4, dtype)
     ref = torch.zeros(6, 7, 7, 8); ref[..., :4] = w.permute(0, 2, 3, 1)
     close(ohwi, ref, dtype)
+    # image packing NCHW fp32 -> NHWC with channels padded to 8 (the pixel-per-thread path), odd sizes; and a general permute (d3 != 8)
+    img = rnd(3, 4, 35, 24, seed=19)
+    nhwc = ops.permute4(img.cuda(), (3, 35, 24, 8), (4 * 35 * 24, 24, 1, 35 * 24), 4, dtype)
+    ref = torch.zeros(3, 35, 24, 8); ref[..., :4] = img.permute(0, 2, 3, 1)
+    close(nhwc, ref, dtype)
+    gen = ops.permute4(img.cuda(), (3, 24, 35, 4), (4 * 35 * 24, 1, 24, 35 * 24), 4, dtype)
+    close(gen, img.permute(0, 3, 2, 1), dtype)
 
 
 @pytest.mark.parametrize("dtype", DT)
