@@ -371,24 +371,28 @@ __global__ void bn_finalize_kernel(const float* __restrict__ s1, const float* __
 // training-mode statistics in one step after the partial sums: per-channel sum of the per-workgroup partials,
 // mean / rstd / scale / shift, running-stat update and the num_batches_tracked counter (one launch instead of
 // partial-sum + finalize + a host-issued counter increment, and no zero-fill of the sums)
-__global__ __launch_bounds__(256) void bn_partial_finalize_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ gamma,
+// WAVES = 4, or 16 for a few hundred partial rows: one launch instead of fold + finalize (two dependent launches of ~5 us of work
+// each, on the forward critical path of every BatchNorm of layer2 / layer3)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void bn_partial_finalize_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float* __restrict__ running_mean,
                                                                    float* __restrict__ running_var, int64_t* __restrict__ counter,
                                                                    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
                                                                    float* __restrict__ shift, int64_t M, int C, float eps, float momentum) {
-    __shared__ float red[2][4][64];
+    __shared__ float red[2][WAVES][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
     float a = 0.f, b = 0.f;
     if (c < C) {
 #pragma unroll 8
-        for (int i = ty; i < nblk; i += 4) { a += part[((int64_t)i * 2) * C + c]; b += part[((int64_t)i * 2 + 1) * C + c]; }
+        for (int i = ty; i < nblk; i += WAVES) { a += part[((int64_t)i * 2) * C + c]; b += part[((int64_t)i * 2 + 1) * C + c]; }
     }
     red[0][ty][tx] = a; red[1][ty][tx] = b;
     __syncthreads();
     if (ty == 0 && c < C) {
-        const float s1 = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
-        const float s2 = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) { s1 += red[0][w][tx]; s2 += red[1][w][tx]; }
         const float mu = s1 / (float)M;
         const float var = fmaxf(s2 / (float)M - mu * mu, 0.f);
         if (running_mean) {
@@ -640,7 +644,7 @@ extern "C" int ralf_bn_batch_stats(int dtype, const void* x, const float* gamma,
     RALF_REQUIRE(bn_reduce_geom(dtype, M, C, &gx, &gy) == 0, "bn_batch_stats: C=%d unsupported (needs C/vec a power of two <= 256 or a multiple of 256)", C);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, nullptr, nullptr, nullptr, nullptr, workspace, M, C, 0, nullptr));
-    hipLaunchKernelGGL(bn_partial_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, workspace, gx, gamma, beta, running_mean, running_var,
+    hipLaunchKernelGGL(bn_partial_finalize_kernel<4>, dim3(ceil_div(C, 64)), dim3(256), 0, st, workspace, gx, gamma, beta, running_mean, running_var,
                        num_batches_tracked, mean, rstd, scale, shift, M, C, eps, momentum);
     return ralf::check_launch("bn_batch_stats");
 }
@@ -652,12 +656,17 @@ extern "C" int ralf_bn_stats_from_partials(const float* partials, int nrows, con
     hipStream_t st = (hipStream_t)stream;
     const float* src = partials;
     int n = nrows;
-    if (nrows > 64) {   // fold to <= RALF_BN_MAX_PARTIALS/2 rows with a wide grid first (the finalize kernel walks its rows serially)
-        const int G = nrows >= 1024 ? 128 : 32;
+    if (nrows > 64 && nrows <= 1024) {   // a few hundred rows: 16 waves walk them in one launch
+        hipLaunchKernelGGL(bn_partial_finalize_kernel<16>, dim3(ceil_div(C, 64)), dim3(1024), 0, st, src, n, gamma, beta, running_mean, running_var,
+                           num_batches_tracked, mean, rstd, scale, shift, M, C, eps, momentum);
+        return ralf::check_launch("bn_stats_from_partials");
+    }
+    if (nrows > 1024) {   // thousands of rows: fold to 128 rows with a wide grid first (the finalize kernel walks its rows serially)
+        const int G = 128;
         hipLaunchKernelGGL(bn_partial_fold_kernel, dim3(ceil_div(C, 64), G), dim3(256), 0, st, partials, nrows, C, G, workspace);
         src = workspace; n = G;
     }
-    hipLaunchKernelGGL(bn_partial_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, src, n, gamma, beta, running_mean, running_var,
+    hipLaunchKernelGGL(bn_partial_finalize_kernel<4>, dim3(ceil_div(C, 64)), dim3(256), 0, st, src, n, gamma, beta, running_mean, running_var,
                        num_batches_tracked, mean, rstd, scale, shift, M, C, eps, momentum);
     return ralf::check_launch("bn_stats_from_partials");
 }
