@@ -463,6 +463,12 @@ class XentFn(Function):
 # ----------------------------------------------------------------------------------------------
 # convolutional backbone (NHWC)
 # ----------------------------------------------------------------------------------------------
+def _conv_splitk(M: int, K: int) -> int:
+    """3x3 convolutions of layer4 (M = 4096 output pixels, K = 4608): 32 x 4 tiles of 128 x 128 leave half the chip idle and
+    512 tiles of 64 x 64 run at the LDS rate; 4 k-splits on the 128 x 128 tiles: 65 -> 45 us (tools/conv_sweep.py)"""
+    return 4 if (M <= 4096 and K >= 4096) else 1
+
+
 class ConvFn(Function):
     """NHWC conv2d through the implicit-im2col GEMM.  W is the fp32 OIHW master weight.
     `pos` (optional, constant [OH*OW, Co]) is added to every image (fused positional table)."""
@@ -479,7 +485,8 @@ class ConvFn(Function):
         x = x.contiguous()
         bias = b.detach() if b is not None else None
         # stats: the following BatchNorm's batch statistics come out of this GEMM's epilogue (per-64-row partial sums)
-        cst = ops.colstats_buffer(M, Co, x.device) if (stats and Co % 64 == 0 and b is None and pos is None) else None
+        sk = _conv_splitk(M, kh * kw * C) if kh > 1 else 1
+        cst = ops.colstats_buffer(M, Co, x.device) if (stats and Co % 64 == 0 and b is None and pos is None and sk == 1) else None
         if kh == 1 and stride == 1:
             if pos is not None:  # batched over images so the [hw, Co] table is shared (batch stride 0)
                 hw = OH * OW
@@ -490,7 +497,7 @@ class ConvFn(Function):
         else:
             assert pos is None
             geom = dict(RH=OH, RW=OW, SH=H, SW=Wd, SC=C, KH=kh, KW=kw, stride=stride, pad=pad, mode=0)
-            y = ops.gemm(x, rt.lp(W, "ohwi"), M, Co, kh * kw * C, conv=geom, gather=1, bias=bias, colstats=cst)
+            y = ops.gemm(x, rt.lp(W, "ohwi"), M, Co, kh * kw * C, conv=geom, gather=1, bias=bias, colstats=cst, splitk=sk)
         ctx.save_for_backward(x, W)
         ctx.bias = b
         ctx.cfg = (stride, pad, OH, OW, b is not None, rt)
@@ -524,7 +531,8 @@ class ConvFn(Function):
                 dx = ops.gemm(dy2, rt.lp(W).view(Co, Ci), M, Ci, Co, b_kcontig=False, res=sk).view(B, H, Wd, C)
             else:
                 geom = dict(RH=H, RW=Wd, SH=OH, SW=OW, SC=Co, KH=kh, KW=kw, stride=stride, pad=pad, mode=1)
-                dx = ops.gemm(dy, rt.lp(W, "ikwo"), B * H * Wd, C, kh * kw * Co, conv=geom, gather=1, res=sk).view(B, H, Wd, C)
+                dx = ops.gemm(dy, rt.lp(W, "ikwo"), B * H * Wd, C, kh * kw * Co, conv=geom, gather=1, res=sk,
+                              splitk=_conv_splitk(B * H * Wd, kh * kw * Co)).view(B, H, Wd, C)
         if ctx.needs_input_grad[1]:
             gv = rt.gview(W)
             if one:
