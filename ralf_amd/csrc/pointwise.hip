@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         const int pix = (int)(e / cv);
         const int ow = pix % OW, t = pix / OW, oh = t % OH, b = t / OH;
         float best[N];
-        int8_t bi[N];
+        __attribute__((aligned(8))) int8_t bi[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) { best[i] = -__builtin_inff(); bi[i] = -1; }
 #pragma unroll
@@ -270,8 +270,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         }
         const int64_t o = (int64_t)pix * C + c;
         PV<T>::store(y + o, best);
-#pragma unroll
-        for (int i = 0; i < N; ++i) arg[o + i] = bi[i];
+        if constexpr (N == 8) *reinterpret_cast<uint2*>(arg + o) = *reinterpret_cast<const uint2*>(bi);   // one 8-byte store, not 8 byte stores
+        else *reinterpret_cast<uint32_t*>(arg + o) = *reinterpret_cast<const uint32_t*>(bi);
     }
 }
 template <typename T>
