@@ -72,6 +72,7 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
                         (d.sA0 * es) % 16 == 0 && (d.sA1 * es) % 16 == 0 && (d.sB0 * es) % 16 == 0 && (d.sB1 * es) % 16 == 0;
         const bool rows_ok = (d.a_kcontig || (d.M % VEC == 0 && d.M >= VEC)) && (d.b_kcontig || (d.N % VEC == 0 && d.N >= VEC));
         P.fast = (!d.gather && al && rows_ok && d.K % BK == 0) ? 1 : 0;
+        P.tapuni = (d.gather == 1 && d.g.SC % BK == 0 && P.kchunk % BK == 0) ? 1 : 0;
     }
     P.partial = nullptr;
     {   // 4-wide epilogue accesses need 4-element-aligned leading dims / batch strides and 16-byte aligned bases

@@ -83,6 +83,7 @@ struct KParams {
     float* partial;   // [split][batch][M][N] fp32 (splitk > 1)
     int vec_epi;      // leading dims / bases allow 4-wide epilogue accesses
     int fast;         // interior fast path: aligned operands, K range a multiple of BK (no per-tile bounds math)
+    int tapuni;       // gather = 1 and channels % BK == 0: every k-tile lies inside one (kh, kw) tap
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -312,6 +313,27 @@ __device__ __forceinline__ u32x4 load_vec(const T* __restrict__ p, const KParams
     return *reinterpret_cast<u32x4*>(tmp);
 }
 
+// the same gather with the tap (kh, kw) given: when the channel count is a multiple of the k-tile, a whole k-tile lies inside
+// ONE tap, so the column -> (kh, kw, c) decomposition is done once per k-tile on the scalar unit instead of per staged vector
+template <typename T>
+__device__ __forceinline__ u32x4 load_vec_tap(const T* __restrict__ p, const KParams& P, const RowInfo& r, int kh, int kw, int c) {
+    const RalfConvGeom& g = P.d.g;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    if (!r.ok) return z;
+    int sy, sx;
+    if (g.mode == 0) { sy = r.y0 + kh; sx = r.x0 + kw; }
+    else {
+        const int ty = r.y0 - kh, tx = r.x0 - kw;
+        if (ty < 0 || tx < 0) return z;
+        int ry, rx;
+        P.fd_st.divmod((uint32_t)ty, sy, ry);
+        P.fd_st.divmod((uint32_t)tx, sx, rx);
+        if (ry | rx) return z;
+    }
+    if ((unsigned)sy >= (unsigned)g.SH || (unsigned)sx >= (unsigned)g.SW) return z;
+    return *reinterpret_cast<const u32x4*>(p + r.base + ((int64_t)sy * g.SW + sx) * g.SC + c);
+}
+
 // im2col column (kh, kw, c) of a staged vector: loop-invariant for the weight-gradient gather (GATHER == 2), where
 // the gathered operand's COLUMNS are fixed per thread and its rows (pixels) advance with k
 struct ColInfo { int c, kh, kw; bool ok; };
@@ -472,11 +494,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_kernel(const KP
 #pragma unroll
             for (int i = 0; i < NVB; ++i) { rb[i] = *reinterpret_cast<const u32x4*>(pb[i]); pb[i] += stepB; }
         } else {
+        int tap_kh = 0, tap_kw = 0, tap_c0 = 0;
+        if (GATHER == 1 && P.tapuni) {   // k0 is wave-uniform: scalar arithmetic
+            int t;
+            P.fd_sc.divmod((uint32_t)k0, t, tap_c0);
+            P.fd_kw.divmod((uint32_t)t, tap_kh, tap_kw);
+        }
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             const int v = tid + NT * i;
-            if (AK) ra[i] = load_vec<T, GATHER == 1>(Ap, P, ia[i], k0 + (v % KV) * VEC, kend, a_al);
-            else {
+            if (AK) {
+                if (GATHER == 1 && P.tapuni) ra[i] = load_vec_tap<T>(Ap, P, ia[i], tap_kh, tap_kw, tap_c0 + (v % KV) * VEC);
+                else ra[i] = load_vec<T, GATHER == 1>(Ap, P, ia[i], k0 + (v % KV) * VEC, kend, a_al);
+            } else {
                 const RowInfo r = row_info<false>(P, k0 + v / RVA, kend, d.lda);
                 ra[i] = load_vec<T, false>(Ap, P, r, m0 + (v % RVA) * VEC, d.M, a_al);
             }
