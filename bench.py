@@ -245,6 +245,7 @@ def main():
     gpu_ms = e0.elapsed_time(e1) / a.steps
     ms = elapsed / a.steps * 1e3
     tokens = B * (5 * N + 1)
+    nonpad = int((targets["seq"] != model.tokenizer.name_to_id("pad")).sum().item()) + B   # target tokens that are not padding, + BOS
     final_loss = float(loss)
 
     if rank == 0:
@@ -255,7 +256,8 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.dtype.startswith("b") else "f32",
             "data": "synthetic",
             "config": {"workload": f"RALF PKU (configs/ralf_pku), k=16 retrieval, task uncond, 256x256 canvases, N={N} elements (S={5 * N}), batch {B} per GPU, dropout 0.1, AdamW+clip 0.1",
-                       "tokens_per_step_per_gpu": tokens, "samples_per_s": world * B / (ms * 1e-3), "parallelism": f"dp{world}", "hip_graph": not a.no_graph, "final_loss": final_loss},
+                       "tokens_per_step_per_gpu": tokens, "samples_per_s": world * B / (ms * 1e-3),
+                       "nonpad_tokens_per_s": world * nonpad / (ms * 1e-3), "parallelism": f"dp{world}", "hip_graph": not a.no_graph, "final_loss": final_loss},
             "roofline": {"bound": "mfma", "achieved": flops / (gpu_ms * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / (gpu_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                          "traffic": TRAIN_TRAFFIC_BYTES if (B == 64 and N == 10 and a.dtype.startswith("b")) else None,

@@ -4,3 +4,4 @@ from .retriever import (RetrievalDatasetWrapper, Retriever, coarse_saliency, cro
                         merged_vectors, table_path)
 from .embed import coarse_saliency_batch, layout_features, pool_cosine, rerank_tables  # noqa: F401
 from .faiss_io import read_flat_index, write_flat_index  # noqa: F401
+from .sharded import merge_topk, query_block, search_index_sharded, search_query_sharded  # noqa: F401

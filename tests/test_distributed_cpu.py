@@ -98,3 +98,62 @@ def test_ranged_exchange_equals_whole_buffer_exchange_world2():
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
+
+
+def _numpy_scan(X):
+    """exact flat-IP top-k with the scan's tie order (score desc, index asc); pads with (-inf, -1) when k > rows"""
+    import numpy as np
+
+    def search(Q, k):
+        S = (np.asarray(Q, np.float64) @ X.T.astype(np.float64)).astype(np.float32)
+        order = np.lexsort((np.broadcast_to(np.arange(S.shape[1]), S.shape), -S), axis=1)[:, :k]
+        s, i = np.take_along_axis(S, order, 1), order.astype(np.int64)
+        if s.shape[1] < k:
+            pad = k - s.shape[1]
+            s = np.concatenate([s, np.full((s.shape[0], pad), -np.inf, np.float32)], 1)
+            i = np.concatenate([i, np.full((i.shape[0], pad), -1, np.int64)], 1)
+        return torch.from_numpy(s), torch.from_numpy(i)
+    return search
+
+
+def _worker_knn(rank, world, port, q):
+    import numpy as np
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ralf_amd.retrieval.sharded import query_block, search_index_sharded, search_query_sharded
+
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((301, 16)).astype(np.float32)
+    X[40] = X[7]; X[200] = X[7]                                   # exact ties across shards
+    Q = torch.from_numpy(np.concatenate([X[[7, 40]], rng.standard_normal((9, 16)).astype(np.float32)]))
+    want_s, want_i = _numpy_scan(X)(Q, 17)
+    ok = True
+    s, i = search_query_sharded(_numpy_scan(X), Q, 17)            # replicas: rank r scans its block of the queries
+    ok &= torch.equal(i, want_i) and torch.equal(s, want_s)
+    blk = query_block(X.shape[0], rank, world)                    # index shards: rank r owns a block of the rows
+    s, i = search_index_sharded(_numpy_scan(X[blk]), blk.start, Q, 17)
+    ok &= torch.equal(i, want_i) and torch.equal(s, want_s)
+    tiny = query_block(5, rank, world)                            # shards smaller than k: padded lists still merge
+    s, i = search_index_sharded(_numpy_scan(X[:5][tiny]), tiny.start, Q, 4)
+    ws, wi = _numpy_scan(X[:5])(Q, 4)
+    ok &= torch.equal(i, wi) and torch.equal(s, ws)
+    q.put((rank, bool(ok), 0.0))
+    dist.destroy_process_group()
+
+
+def test_sharded_knn_world2():
+    """query-sharded replicas and index shards (all_gather of the local top-k + merge by score desc, index asc)"""
+    from ralf_amd.retrieval.sharded import query_block
+
+    assert [query_block(11, r, 4) for r in range(4)] == [slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 11)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_knn, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res

@@ -118,3 +118,26 @@ def test_two_stage_search_equals_exhaustive(N, D, nq, k):
     index = FlatIPIndex(X)                      # the index front end picks the two-stage path for large batches
     v2, i2 = index.search(Q, k)
     assert torch.equal(i2, i_ref) and torch.equal(v2, v_ref)
+
+
+def test_sharded_search_forms_on_the_hip_scan():
+    """SURVEY 8e on the real scan (1-rank RCCL group; the 2-rank exchange is covered on CPU with gloo): query-sharded replicas and
+    an index shard with a row offset return the table of the plain search"""
+    import os
+
+    import torch.distributed as dist
+    from ralf_amd.retrieval import FlatIPIndex, search_index_sharded, search_query_sharded
+
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29000 + os.getpid() % 2000))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    g = torch.Generator().manual_seed(4)
+    X = torch.randn(5000, 64, generator=g)
+    Q = torch.randn(37, 64, generator=g).cuda()
+    index = FlatIPIndex(X)
+    s0, i0 = index.search(Q, 16)
+    s1, i1 = search_query_sharded(index.search, Q, 16)
+    assert torch.equal(i1, i0) and torch.equal(s1, s0)
+    s2, i2 = search_index_sharded(index.search, 1000, Q, 16)
+    assert torch.equal(i2, i0 + 1000) and torch.equal(s2, s0)
