@@ -32,7 +32,9 @@ class LinearBucketizer:
         self.centers = ((edges[:-1] + edges[1:]) / 2.0).unsqueeze(1)
 
     def encode(self, x: torch.Tensor) -> torch.Tensor:
-        return torch.bucketize(torch.clamp(x, min=0.0, max=1.0), self.boundaries)
+        # == torch.bucketize(x, boundaries) (same kernel, same right=False rule); bucketize itself spends milliseconds per call in
+        # this torch build's dispatch on tiny tensors, searchsorted microseconds: 8 calls per batch were 10-40 ms of host time
+        return torch.searchsorted(self.boundaries, torch.clamp(x, min=0.0, max=1.0).contiguous())
 
     def decode(self, idx: torch.Tensor) -> torch.Tensor:
         idx = torch.clamp(idx, min=0, max=len(self.centers) - 1)

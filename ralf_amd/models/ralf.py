@@ -510,7 +510,7 @@ class ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg(_GeneratorBas
         cond, inputs = get_condition(inputs, self.auxilary_task, self.tokenizer)
         seqc = self.preprocessor(cond)
         data = self.tokenizer.encode(inputs)
-        image = torch.cat([inputs["image"], inputs["saliency"]], dim=1)
+        image = cond.image if torch.is_tensor(getattr(cond, "image", None)) and cond.image.size(1) == 4 else torch.cat([inputs["image"], inputs["saliency"]], dim=1)   # (get_condition already built the 4-channel image: 67 MB per batch)
         assert inputs["retrieved"]["image"].size(2) == 4
         _inputs = {"seq": data["seq"][:, :-1], "tgt_key_padding_mask": ~data["mask"][:, :-1], "image": image,
                    "retrieved": inputs["retrieved"], "seq_layout_const": seqc["seq"], "seq_layout_const_pad_mask": seqc["pad_mask"]}
@@ -576,7 +576,7 @@ class ConcateAuxilaryTaskAutoreg(_GeneratorBase):
         cond, inputs = get_condition(inputs, self.auxilary_task, self.tokenizer)
         seqc = self.preprocessor(cond)
         data = self.tokenizer.encode(inputs)
-        image = torch.cat([inputs["image"], inputs["saliency"]], dim=1)
+        image = cond.image if torch.is_tensor(getattr(cond, "image", None)) and cond.image.size(1) == 4 else torch.cat([inputs["image"], inputs["saliency"]], dim=1)   # (get_condition already built the 4-channel image: 67 MB per batch)
         _inputs = {"seq": data["seq"][:, :-1], "tgt_key_padding_mask": ~data["mask"][:, :-1], "image": image,
                    "seq_layout_const": seqc["seq"], "seq_layout_const_pad_mask": seqc["pad_mask"]}
         return _inputs, {"seq": data["seq"][:, 1:]}
