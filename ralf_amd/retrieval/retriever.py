@@ -166,6 +166,25 @@ class RetrievalDatasetWrapper(torch.utils.data.Dataset):
         self.dataset_name, self.dataset, self.db_dataset = dataset_name, dataset, db_dataset
         self.top_k, self.max_seq_length, self.with_images = top_k, max_seq_length, with_images
         self.table_idx = load_cache_table(table_path(dataset_name, split, retrieval_backbone, num_cache_indexes_per_sample, cache_dir), top_k)
+        self._layouts = self._layout_table(db_dataset, max_seq_length)
+
+    @staticmethod
+    def _layout_table(db_dataset, N: int) -> dict:
+        """padded [n_db, N] arrays of the database layouts, built ONCE from the layout columns only: an item then costs one fancy
+        index per field instead of K row fetches (which, on an image dataset, decode K images that are never used)"""
+        cols = ["label", "center_x", "center_y", "width", "height"]
+        src = db_dataset.select_columns(cols) if hasattr(db_dataset, "select_columns") else db_dataset
+        n = len(src)
+        out = {k: np.zeros((n, N), np.int64 if k == "label" else np.float32) for k in cols}
+        out["mask"] = np.zeros((n, N), bool)
+        for i in range(n):
+            r = src[i]
+            m = len(r["label"])
+            assert m <= N, f"database layout {i} has {m} elements > max_seq_length {N}"
+            for k in cols:
+                out[k][i, :m] = np.asarray(r[k])
+            out["mask"][i, :m] = True
+        return out
 
     def __len__(self):
         return len(self.dataset)
@@ -175,15 +194,12 @@ class RetrievalDatasetWrapper(torch.utils.data.Dataset):
         data_id = int(data["id"]) if "pku" in self.dataset_name else data["id"]
         hits = self.table_idx[data_id]
         assert len(hits) == self.top_k, f"{len(hits)=} != {self.top_k=}"
-        rows = [self.db_dataset[j] for j in hits]
-        N = self.max_seq_length
+        sel = np.asarray(hits, np.int64)
         retrieved = {"index": hits}
         for key in LAYOUT_KEYS:
-            if key == "mask":
-                retrieved[key] = torch.tensor([_pad([True] * len(r["label"]), N) for r in rows])
-            else:
-                retrieved[key] = torch.tensor([_pad(list(r[key]), N) for r in rows])
+            retrieved[key] = torch.from_numpy(self._layouts[key][sel])
         if self.with_images:
+            rows = [self.db_dataset[j] for j in hits]
             for key in ("image", "saliency"):
                 retrieved[key] = torch.stack([torch.as_tensor(r[key]) for r in rows])
         else:  # 1x1 placeholder keeps the 4-channel assertion of preprocess(); pixels are unused (use_reference_image=False)
