@@ -41,6 +41,13 @@ def table_path(dataset_name: str, split: str, backbone: str, top_k: int, cache_d
     return os.path.join(cache_dir, f"{dataset_name}_{split}_{backbone}_wo_head_table_between_dataset_indexes_top_k{top_k}.pt")
 
 
+def _ids_of(dataset) -> list:
+    """the `id` column without touching the other columns (an HF image dataset decodes every image on row access)"""
+    if hasattr(dataset, "column_names") and "id" in dataset.column_names:
+        return list(dataset["id"])
+    return [dataset[i]["id"] for i in range(len(dataset))]
+
+
 def load_cache_table(cache_path: str, top_k: int) -> dict:
     table = torch.load(cache_path)
     return {k: v[:top_k] for k, v in table.items()}
@@ -74,7 +81,7 @@ class Retriever:
                 os.makedirs(cache_dir, exist_ok=True)
                 write_flat_index(cache_file, db_vectors)
         self.index = FlatIPIndex(np.ascontiguousarray(db_vectors, np.float32), device=device)
-        self.table_paired_id_idx = {self._id(db_dataset[i]["id"]): i for i in range(len(db_dataset))}
+        self.table_paired_id_idx = {self._id(v): i for i, v in enumerate(_ids_of(db_dataset))}
 
     def _id(self, data_id):
         return int(data_id) if "pku" in self.dataset_name else data_id
@@ -92,8 +99,8 @@ class Retriever:
         scores, idx = self.search(queries, top_k + 1)
         lo = 1 if split == "train" else 0
         table, score_table = {}, {}
-        for i in range(len(dataset)):
-            data_id = self._id(dataset[i]["id"])
+        for i, raw_id in enumerate(_ids_of(dataset)):
+            data_id = self._id(raw_id)
             table[data_id] = [int(j) for j in idx[i, lo:]]
             score_table[data_id] = scores[i, lo:]
         os.makedirs(self.cache_dir, exist_ok=True)
