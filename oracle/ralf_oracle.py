@@ -13,8 +13,9 @@ Pinning status:
     checked by tests/test_oracle_golden.py).
   * ResNet-50 body: the arithmetic lives in timm 0.9.x + torchvision 0.14 FX (absent from
     /root/reference and from this image) -> restated from the published ResNet-v1.5 bottleneck
-    definition; wrapper/FPN follows image2layout/train/models/common/image.py:27-120.
-    PARITY UNPINNED for the body (no reference run possible here).
+    definition.  PARITY UNPINNED for the body (no reference run possible here).
+  * backbone WRAPPER (4-channel stem construction, FPN fuse, projection; common/image.py:70-111): PINNED against the
+    reference's own ResnetBackbone run around a stand-in body (tests/golden/backbone_wrapper.npz).
 """
 from __future__ import annotations
 
@@ -233,8 +234,21 @@ def resnet50_fpn(img: Tensor, sd: SD, p: str = "encoder.extractor", training: bo
                 idn = _bn(F.conv2d(x, sd[q + ".downsample.0.weight"], None, s), sd, q + ".downsample.1", training)
             x = torch.relu(y + idn)
         feats[li] = x
-    f4 = F.conv2d(feats[3], sd[p + ".fpn_conv11_4.weight"], sd[p + ".fpn_conv11_4.bias"])
-    f5 = F.conv2d(feats[4], sd[p + ".fpn_conv11_5.weight"], sd[p + ".fpn_conv11_5.bias"])
+    return fpn_fuse(feats[3], feats[4], sd, p)
+
+
+def stem_weight_4ch(w3: Tensor) -> Tensor:
+    """the 4-channel stem the wrapper builds from the pretrained 3-channel 7x7 filters: 4th input channel (saliency) =
+    mean of the RGB filters (common/image.py:70-77).  PINNED: tests/golden/backbone_wrapper.npz."""
+    return torch.cat([w3, w3.mean(dim=1, keepdim=True)], dim=1)
+
+
+def fpn_fuse(layer3: Tensor, layer4: Tensor, sd: SD, p: str = "encoder.extractor") -> Tensor:
+    """FPN fuse + projection of ResnetBackbone.forward (common/image.py:99-111): 1x1 laterals, nearest up-sampling of the
+    layer-4 map to the layer-3 size (F.interpolate(size=...): src = floor(dst * in / out), non-integer ratio at 350x240),
+    3x3 on the sum, channel concat [up, conv33], 1x1 proj.  PINNED: tests/golden/backbone_wrapper.npz."""
+    f4 = F.conv2d(layer3, sd[p + ".fpn_conv11_4.weight"], sd[p + ".fpn_conv11_4.bias"])
+    f5 = F.conv2d(layer4, sd[p + ".fpn_conv11_5.weight"], sd[p + ".fpn_conv11_5.bias"])
     f5u = F.interpolate(f5, size=f4.shape[2:], mode="nearest")
     fused = torch.cat([f5u, F.conv2d(f5u + f4, sd[p + ".fpn_conv33.weight"], sd[p + ".fpn_conv33.bias"], 1, 1)], dim=1)
     return F.conv2d(fused, sd[p + ".proj.weight"], sd[p + ".proj.bias"])

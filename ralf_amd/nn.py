@@ -432,14 +432,30 @@ class ResnetBackbone(nn.Module):
             if li == 2:   # data parallel: stem + layer1-2 hold 6 % of the parameters and most of the backbone's backward time
                 x = rt.grad_cut(x)
             feats[li] = x
-        f4 = self.fpn_conv11_4(feats[3], rt)
-        f5 = self.fpn_conv11_5(feats[4], rt)
+        return self.fpn(feats[3], feats[4], rt)
+
+    def fpn(self, layer3: torch.Tensor, layer4: torch.Tensor, rt: Runtime) -> torch.Tensor:
+        """FPN fuse + projection (common/image.py:99-111) on NHWC maps -> [B, h*w, d] with the 2-D sine table added."""
+        B = layer3.shape[0]
+        f4 = self.fpn_conv11_4(layer3, rt)
+        f5 = self.fpn_conv11_5(layer4, rt)
         f5u, s = RF.UpsampleAddFn.apply(f5, f4)
         c33 = self.fpn_conv33(s, rt)
         fused = torch.cat([f5u, c33], dim=-1)  # channel concat: plumbing copy
         h, w = fused.shape[1:3]
-        out = self.proj(fused, rt, pos=self.pos_table(h, w, self.proj.weight.shape[0], rt, img.device))
+        out = self.proj(fused, rt, pos=self.pos_table(h, w, self.proj.weight.shape[0], rt, layer3.device))
         return out.view(B, h * w, -1)
+
+    @torch.no_grad()
+    def load_pretrained_body(self, state_dict: dict) -> None:
+        """timm ResNet-50 checkpoint (3-channel stem, e.g. resnet50_a1_0-14fe96d1.pth) -> this body, the way the reference's
+        constructor does it (common/image.py:39-48, 70-77): `fc.*` is not part of the extracted body and the 4th stem channel
+        (saliency) is the mean of the RGB filters."""
+        sd = {k: v for k, v in state_dict.items() if not k.startswith("fc.")}
+        w3 = sd["conv1.weight"]
+        assert w3.shape[1] == 3, "expected the pretrained 3-channel stem"
+        sd["conv1.weight"] = torch.cat([w3, w3.mean(dim=1, keepdim=True)], dim=1)
+        self.body.load_state_dict(sd, strict=True)
 
 
 class ResnetFeatureExtractor(nn.Module):

@@ -592,9 +592,132 @@ def golden_retrieval_augment():
     })
 
 
+def golden_backbone_wrapper():
+    """a1 wrapper: the reference's OWN ResnetBackbone constructor and forward (common/image.py:27-120) around a stand-in
+    body -- timm / torchvision are absent here, so `timm.create_model` hands the constructor a module with a 3-channel 7x7
+    `conv1` (the only attribute the wrapper touches) whose forward returns injected {"layer3", "layer4"} maps.  Recorded:
+    the 4-channel stem weight the constructor builds from the 3-channel one (image.py:70-77), its output on an image, and the
+    FPN fuse + projection (image.py:99-111) with gradients, at 16x16 / 8x8 (256x256 canvas) and 22x15 / 11x8 (350x240)."""
+    import io
+
+    import image2layout.train.models.common.image as im
+
+    class Body(nn.Module):
+        feats = None
+
+        def __init__(self):
+            super().__init__()
+            self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+
+        def forward(self, img):
+            return Body.feats
+
+    class FakeFS:
+        def exists(self, p):
+            return True
+
+        def open(self, p, mode="rb"):
+            return io.BytesIO(b"")
+
+    body = Body()
+    w3 = det_state_dict({"encoder.extractor.body.conv1.weight3": (64, 3, 7, 7)})["encoder.extractor.body.conv1.weight3"]
+    body.conv1.weight.data = w3.clone()
+    saved = (im.timm.create_model, im.fsspec.core.url_to_fs, im.torch.load, im.create_feature_extractor)
+    im.timm.create_model = lambda name: body
+    im.fsspec.core.url_to_fs = lambda path: (FakeFS(), path)
+    im.torch.load = lambda f: body.state_dict()
+    im.create_feature_extractor = lambda model, return_nodes: model
+    try:
+        bb = im.ResnetBackbone(backbone="resnet50", d_model=256, head="transformer")
+    finally:
+        im.timm.create_model, im.fsspec.core.url_to_fs, im.torch.load, im.create_feature_extractor = saved
+    out = {"stem": {"w3": w3, "w4": bb.body.conv1.weight.data.clone()}}
+    g = torch.Generator().manual_seed(17)
+    img = torch.rand(2, 4, 32, 40, generator=g)
+    out["stem"]["img"] = img
+    out["stem"]["y"] = bb.body.conv1(img)
+    fpn = {k: v for k, v in bb.state_dict().items() if k.startswith(("fpn_", "proj."))}
+    det = det_state_dict({"encoder.extractor." + k: tuple(v.shape) for k, v in fpn.items()})
+    bb.load_state_dict({**bb.state_dict(), **{k: det["encoder.extractor." + k] for k in fpn}}, strict=True)
+    # the injected maps are regenerated from seeds by the tests (torch's CPU generator is deterministic for a fixed build,
+    # the same convention as oracle/detweights.py), so the fixture holds only the reference's outputs
+    for name, (h3, w3_, h4, w4_, seed) in {"c256": (16, 16, 8, 8, 171), "c350x240": (22, 15, 11, 8, 172)}.items():
+        gg = torch.Generator().manual_seed(seed)
+        f3 = torch.randn(1, 1024, h3, w3_, generator=gg).requires_grad_(True)
+        f4 = torch.randn(1, 2048, h4, w4_, generator=gg).requires_grad_(True)
+        go = torch.randn(1, 256, h3, w3_, generator=gg)
+        Body.feats = {"layer3": f3, "layer4": f4}
+        bb.zero_grad()
+        y = bb(torch.zeros(1, 4, 8, 8))
+        y.backward(go)
+        named = dict(bb.named_parameters())
+        out[name] = {"seed": torch.tensor(seed), "y": y, "g_layer3": thin(f3.grad), "g_layer4": thin(f4.grad),
+                     "grads": {k: named[k].grad for k in ["fpn_conv11_4.weight", "fpn_conv11_5.bias", "fpn_conv33.weight", "proj.weight", "proj.bias"]}}
+    save("backbone_wrapper.npz", out)
+
+
+def golden_e2e_cgl():
+    """BASELINE config 3's model: the CGL label set (4 labels -> V = 519, Vc = 549, 4-row layout-encoder label table;
+    helpers/layout_tokenizer.py:253-274).  train_loss + gradients (task c) and deterministic sample() tokens (task cwh)."""
+    tok = make_tokenizer("cgl", 10)
+    feats = ds.Features({"label": ds.Sequence(ds.ClassLabel(names=LABELS["cgl"]))})
+
+    def build(task):
+        return raa.ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg(
+            features=feats, tokenizer=tok, dataset_name="cgl", max_seq_length=10, db_dataset=None, top_k=16,
+            retrieval_backbone="dreamsim", random_retrieval=False, saliency_k="None", auxilary_task=task)
+
+    out = {}
+    model = build("c").eval()
+    shapes = load_det(model)
+    with open(os.path.join(HERE, "ralf_cgl_state_shapes.json"), "w") as f:
+        json.dump({"meta": META, "shapes": {k: list(v) for k, v in shapes.items()}}, f, indent=0)
+    B = 3
+    batch = synth_batch(51, B, 10, 16, 4)
+    torch.manual_seed(199)
+    inputs, targets = model.preprocess(clone_batch(batch))
+    g = torch.Generator().manual_seed(15)
+    feat = torch.randn(B, 256, 3, 4, generator=g).requires_grad_(True)
+    StandInBackbone.feat = feat
+    model.zero_grad()
+    outputs, losses = model.train_loss(inputs, targets)
+    losses["nll_loss"].backward()
+    named = dict(model.named_parameters())
+    out["ralf_c"] = {
+        "feat": feat, "gfeat": feat.grad, "logits": outputs["logits"], "loss": losses["nll_loss"],
+        "inputs": {k: v for k, v in inputs.items() if torch.is_tensor(v) and k != "image"},
+        "retrieved": {k: v for k, v in inputs["retrieved"].items() if k not in ("image", "saliency")},
+        "targets": targets,
+        "grads": {k: named[k].grad for k in GRAD_KEYS_RALF},
+        "gradnorm": torch.sqrt(sum((p.grad ** 2).sum() for p in model.parameters() if p.grad is not None)),
+        "meta": {"N_total": torch.tensor(tok.N_total), "preproc_N_total": torch.tensor(model.preprocessor.N_total)},
+    }
+    model = build("cwh").eval()
+    load_det(model)
+    batch = synth_batch(52, B, 10, 16, 4)
+    torch.manual_seed(177)
+    cond, _ = get_condition(clone_batch(batch), "cwh", tok)
+    feat = torch.randn(B, 256, 2, 3, generator=torch.Generator().manual_seed(18))
+    StandInBackbone.feat = feat
+    torch.manual_seed(178)
+    with torch.no_grad():
+        enc_in, _ = model._create_encoder_inputs(cond)
+        torch.manual_seed(178)
+        res, vio = model.sample(cond=cond, sampling_cfg=DictConfig(name="deterministic"), cond_type="cwh", return_violation=True, use_backtrack=False)
+    out["sample_cwh"] = {
+        "feat": feat, "cond_seq": cond.seq,
+        "seq_layout_const": enc_in["seq_layout_const"], "seq_layout_const_pad_mask": enc_in["seq_layout_const_pad_mask"],
+        "retrieved": {k: v for k, v in cond.retrieved.items() if k not in ("image", "saliency")},
+        "result": res,
+        "violation": {"total": torch.tensor(float(vio["total"])), "viorated": torch.tensor(float(vio["viorated"]))},
+    }
+    save("e2e_cgl.npz", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tokenizer", "host", "modules", "e2e", "sample", "reranker", "relation", "retrieval_augment"]
+    which = sys.argv[1:] or ["tokenizer", "host", "modules", "e2e", "sample", "reranker", "relation", "retrieval_augment", "backbone_wrapper", "e2e_cgl"]
     fns = {"tokenizer": golden_tokenizer, "host": golden_host_path, "modules": golden_modules, "e2e": golden_e2e, "sample": golden_sample,
-           "reranker": golden_reranker, "relation": golden_relation, "retrieval_augment": golden_retrieval_augment}
+           "reranker": golden_reranker, "relation": golden_relation, "retrieval_augment": golden_retrieval_augment,
+           "backbone_wrapper": golden_backbone_wrapper, "e2e_cgl": golden_e2e_cgl}
     for w in which:
         fns[w]()

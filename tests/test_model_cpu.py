@@ -11,14 +11,16 @@ from ralf_amd.helpers.layout_tokenizer import LabelFeature, LayoutSequenceTokeni
 from ralf_amd.models.generator import ConcateAuxilaryTaskAutoreg, ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg
 
 LABELS = ["text", "logo", "underlay"]
+CGL_LABELS = ["logo", "text", "underlay", "embellishment"]   # BASELINE config 3 (helpers/layout_tokenizer.py:253-274: V = 519)
 
 
-def build(cls=ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg, task="uncond", **kw):
-    tok = LayoutSequenceTokenizer(LABELS, 10)
-    feats = {"label": LabelFeature(LABELS)}
+def build(cls=ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg, task="uncond", dataset="pku", N=10, **kw):
+    labels = CGL_LABELS if dataset == "cgl" else LABELS
+    tok = LayoutSequenceTokenizer(labels, N)
+    feats = {"label": LabelFeature(labels)}
     if cls is ConcateAuxilaryTaskAutoreg:
         return cls(features=feats, tokenizer=tok, auxilary_task=task, **kw)
-    return cls(features=feats, tokenizer=tok, dataset_name="pku", max_seq_length=10, db_dataset=None, top_k=16,
+    return cls(features=feats, tokenizer=tok, dataset_name=dataset, max_seq_length=N, db_dataset=None, top_k=16,
                retrieval_backbone="dreamsim", random_retrieval=False, saliency_k="None", auxilary_task=task, **kw)
 
 
@@ -34,6 +36,28 @@ def test_state_dict_layout_matches_reference():
         got = {k: tuple(v.shape) for k, v in build(cls).state_dict().items()}
         assert got == want
         build(cls).load_state_dict(det_state_dict(want), strict=True)
+
+
+def test_cgl_state_dict_layout_matches_reference():
+    want = dict(ref_shapes("ralf_cgl_state_shapes.json"))
+    want.update(resnet50_fpn_shapes())
+    m = build(dataset="cgl", task="c")
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == want
+    assert m.tokenizer.N_total == 519 and m.preprocessor.N_total == 549
+
+
+def test_pretrained_stem_construction_matches_reference(golden):
+    """ResnetBackbone.load_pretrained_body: 3-channel timm checkpoint -> 4-channel stem exactly as the reference's
+    constructor builds it (common/image.py:70-77; vectors recorded from that constructor)"""
+    from ralf_amd.nn import ResnetBackbone
+
+    r = golden("backbone_wrapper.npz").sub("stem")
+    bb = ResnetBackbone(256)
+    sd = {k: v.clone() for k, v in bb.body.state_dict().items()}
+    sd["conv1.weight"] = r["w3"]
+    sd["fc.weight"], sd["fc.bias"] = torch.zeros(1000, 2048), torch.zeros(1000)   # timm checkpoints carry the classifier
+    bb.load_pretrained_body(sd)
+    assert torch.equal(bb.body.conv1.weight.data, r["w4"])
 
 
 def test_optim_groups_rule():

@@ -87,6 +87,78 @@ def test_autoreg_e2e_fp32_vs_reference(golden):
         torch.testing.assert_close(thin(named[k].grad).cpu(), g, atol=3e-6, rtol=3e-3)
 
 
+def test_ralf_cgl_e2e_fp32_vs_reference(golden):
+    """BASELINE config 3's model (CGL: 4 labels, V = 519, Vc = 549) on the HIP path vs the reference's recorded vectors"""
+    r = golden("e2e_cgl.npz").sub("ralf_c")
+    model = load_det(build(task="c", dataset="cgl"), "ralf_cgl_state_shapes.json").eval()
+    assert model.tokenizer.N_total == 519
+    feat = r["feat"].cuda().requires_grad_(True)
+    model.encoder = FeatStandIn(feat)
+    inputs = to_dev(dict(r["inputs"]))
+    inputs["retrieved"] = to_dev(r["retrieved"])
+    inputs["image"] = torch.zeros(feat.shape[0], 4, 8, 8, device="cuda")
+    outputs, losses = model.train_loss(inputs, {"seq": r["targets"]["seq"].cuda()})
+    assert outputs["logits"].shape[-1] == 519
+    torch.testing.assert_close(outputs["logits"].cpu(), r["logits"], atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(losses["nll_loss"].cpu(), r["loss"], atol=1e-5, rtol=1e-5)
+    losses["nll_loss"].backward()
+    torch.testing.assert_close(feat.grad.cpu(), r["gfeat"], atol=2e-6, rtol=2e-3)
+    named = dict(model.named_parameters())
+    for k, g in r["grads"].items():
+        torch.testing.assert_close(thin(named[k].grad).cpu(), g, atol=3e-6, rtol=3e-3, msg=lambda m, k=k: f"{k}: {m}")
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)).float().cpu()
+    torch.testing.assert_close(gn, r["gradnorm"], atol=1e-6, rtol=2e-3)
+
+
+def test_cgl_deterministic_sample_matches_reference(golden):
+    from ralf_amd.engine import GraphedDecode
+    from ralf_amd.helpers.task import RetrievalAugmentedConditionalInputsForDiscreteLayout as Cond
+
+    r = golden("e2e_cgl.npz").sub("sample_cwh")
+    model = load_det(build(task="cwh", dataset="cgl"), "ralf_cgl_state_shapes.json").eval()
+    model.encoder = FeatStandIn(r["feat"].cuda())
+    B = r["feat"].shape[0]
+    cond = Cond(image=torch.zeros(B, 4, 8, 8), task="cwh", seq=r["cond_seq"], mask=None, retrieved=dict(r["retrieved"]))
+    model._create_encoder_inputs = lambda c: ({"image": c.image, "retrieved": c.retrieved, "seq_layout_const": r["seq_layout_const"],
+                                               "seq_layout_const_pad_mask": r["seq_layout_const_pad_mask"]}, None)
+    graphed = GraphedDecode(model, "cwh", {"name": "deterministic"})
+    for kv, dec in ((True, None), (False, None), (True, graphed)):
+        out = model.sample(cond=cond, sampling_cfg={"name": "deterministic"}, cond_type="cwh", return_violation=False, use_kv_cache=kv, decoder=dec)
+        for k in ("label", "mask", "center_x", "center_y", "width", "height"):
+            assert torch.equal(out[k], r["result"][k]), (k, kv)
+
+
+WRAPPER_CASES = {"c256": (16, 16, 8, 8), "c350x240": (22, 15, 11, 8)}
+
+
+@pytest.mark.parametrize("case", list(WRAPPER_CASES))
+def test_backbone_wrapper_fp32_vs_reference(golden, case):
+    """a1 wrapper on the HIP path (1x1 laterals, nearest up-sampling + add, 3x3, concat, projection + 2-D sine table) against
+    the output and gradients of the REFERENCE's ResnetBackbone.forward around injected layer3 / layer4 maps
+    (common/image.py:99-111; tests/golden/make_golden.py: golden_backbone_wrapper)"""
+    from test_oracle_golden import _wrapper_inputs
+
+    r = golden("backbone_wrapper.npz").sub(case)
+    h3, w3, h4, w4 = WRAPPER_CASES[case]
+    f3, f4, go = _wrapper_inputs(int(r["seed"]), h3, w3, h4, w4)
+    bb = RN.ResnetBackbone(256)
+    sd = det_state_dict(resnet50_fpn_shapes())
+    bb.load_state_dict({k[len("encoder.extractor."):]: v for k, v in sd.items()}, strict=True)
+    bb = bb.cuda()
+    rt = RN.Runtime(torch.float32).to(torch.device("cuda"))
+    x3 = f3.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+    x4 = f4.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+    out = bb.fpn(x3, x4, rt)                                   # [1, h*w, 256] with the sine table added
+    want = r["y"].flatten(2).transpose(1, 2) + RN.pos2d_sine(h3, w3, 256)
+    torch.testing.assert_close(out.detach().cpu(), want, atol=1e-4, rtol=1e-4)
+    out.backward(go.flatten(2).transpose(1, 2).contiguous().cuda())
+    torch.testing.assert_close(thin(x3.grad.permute(0, 3, 1, 2).contiguous()).cpu(), r["g_layer3"], atol=1e-4, rtol=1e-3)
+    torch.testing.assert_close(thin(x4.grad.permute(0, 3, 1, 2).contiguous()).cpu(), r["g_layer4"], atol=1e-4, rtol=1e-3)
+    named = dict(bb.named_parameters())
+    for k, g in r["grads"].items():
+        torch.testing.assert_close(thin(named[k].grad).cpu(), g, atol=2e-4, rtol=2e-3, msg=lambda m, k=k: f"{k}: {m}")
+
+
 def test_ralf_e2e_bf16_close_to_reference(golden):
     r = golden("e2e.npz").sub("ralf_refinement")
     model = load_det(build(task="refinement", compute_dtype="bfloat16"), "ralf_state_shapes.json").eval()

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import ralf_oracle as O
-from oracle.detweights import det_state_dict
+from oracle.detweights import det_state_dict, resnet50_fpn_shapes
 
 from conftest import GOLDEN
 
@@ -125,6 +125,67 @@ def test_autoreg_e2e(golden):
     logits = O.autoreg_forward(sd, r["inputs"], feat=feat)
     close(logits, r["logits"], atol=1e-4)
     loss = O.xent_label_smoothing(logits, r["targets"]["seq"], ignore_index=515)
+    close(loss, r["loss"], atol=1e-5)
+    ks = list(r["grads"].keys())
+    gs = torch.autograd.grad(loss, [feat] + [sd[k] for k in ks])
+    close(gs[0], r["gfeat"], atol=1e-6)
+    for k, g in zip(ks, gs[1:]):
+        close(thin(g), r["grads"][k], atol=2e-6, rtol=2e-3)
+
+
+def _wrapper_inputs(seed, h3, w3, h4, w4):
+    """the injected layer3 / layer4 maps and output gradient of tests/golden/make_golden.py: golden_backbone_wrapper"""
+    gg = torch.Generator().manual_seed(seed)
+    f3 = torch.randn(1, 1024, h3, w3, generator=gg)
+    f4 = torch.randn(1, 2048, h4, w4, generator=gg)
+    go = torch.randn(1, 256, h3, w3, generator=gg)
+    return f3, f4, go
+
+
+WRAPPER_CASES = {"c256": (16, 16, 8, 8), "c350x240": (22, 15, 11, 8)}
+
+
+def test_backbone_wrapper_stem_channel(golden):
+    """a1 wrapper, stem: the 4th input channel the reference's constructor builds (common/image.py:70-77)"""
+    r = golden("backbone_wrapper.npz").sub("stem")
+    w4 = O.stem_weight_4ch(r["w3"])
+    assert torch.equal(w4, r["w4"])
+    close(torch.nn.functional.conv2d(r["img"], w4, None, 2, 3), r["y"], atol=1e-6)
+
+
+@pytest.mark.parametrize("case", list(WRAPPER_CASES))
+def test_backbone_wrapper_fpn(golden, case):
+    """a1 wrapper, FPN fuse + projection (common/image.py:99-111) incl. the non-integer nearest up-sampling at 350x240"""
+    r = golden("backbone_wrapper.npz").sub(case)
+    f3, f4, go = _wrapper_inputs(int(r["seed"]), *WRAPPER_CASES[case])
+    f3.requires_grad_(True), f4.requires_grad_(True)
+    sd = det_state_dict({k: v for k, v in resnet50_fpn_shapes().items() if ".body." not in k})
+    for v in sd.values():
+        v.requires_grad_(True)
+    y = O.fpn_fuse(f3, f4, sd)
+    close(y, r["y"], atol=1e-5)
+    ks = list(r["grads"].keys())
+    gs = torch.autograd.grad(y, [f3, f4] + [sd["encoder.extractor." + k] for k in ks], go)
+    close(thin(gs[0]), r["g_layer3"], atol=1e-5); close(thin(gs[1]), r["g_layer4"], atol=1e-5)
+    for k, g in zip(ks, gs[2:]):
+        close(thin(g), r["grads"][k], atol=1e-4, rtol=1e-3)
+
+
+def test_ralf_cgl_e2e(golden):
+    """BASELINE config 3's label set (CGL: 4 labels, V = 519, Vc = 549) against the reference's recorded logits / gradients"""
+    r = golden("e2e_cgl.npz").sub("ralf_c")
+    assert int(r["meta"]["N_total"]) == 519 and int(r["meta"]["preproc_N_total"]) == 549
+    sd = det_state_dict(shapes("ralf_cgl_state_shapes.json"))
+    assert sd["decoder.emb.weight"].shape[0] == 519 and sd["user_const_encoder.emb.weight"].shape[0] == 549 and sd["layout_encoer.emb_label.weight"].shape[0] == 4
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    feat = r["feat"].requires_grad_(True)
+    inputs = dict(r["inputs"])
+    inputs["retrieved"] = r["retrieved"]
+    logits = O.ralf_forward(sd, inputs, feat=feat)
+    close(logits, r["logits"], atol=1e-4)
+    loss = O.xent_label_smoothing(logits, r["targets"]["seq"], ignore_index=516)
     close(loss, r["loss"], atol=1e-5)
     ks = list(r["grads"].keys())
     gs = torch.autograd.grad(loss, [feat] + [sd[k] for k in ks])
