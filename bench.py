@@ -106,16 +106,17 @@ def bench_knn(device):
     # large query batches: bf16 coarse ranking + exact fp32 re-scoring of 64 candidates per query + per-query certificate
     # (ralf_amd/retrieval/knn.py: knn_topk_ip_two_stage) -- same indices and scores, bit for bit
     from ralf_amd import ops
-    from ralf_amd.retrieval.knn import knn_topk_ip_two_stage
+    from ralf_amd.retrieval.knn import knn_rownorms, knn_topk_ip_two_stage
 
-    Xb, nmax = ops.cast(X, torch.bfloat16), float(X.norm(dim=1).max())   # built once per index
+    Xb = ops.cast(X, torch.bfloat16)                                         # built once per index
+    _, xn = knn_rownorms(X, Xb, want_rows=False, want_max=True)              # the certificate's index constants
     nq = 1024
     Q = torch.randn(nq, D, device=device, generator=g)
     Q /= Q.norm(dim=1, keepdim=True)
     v0, i0 = knn_topk_ip(X, Q, k)
-    v1, i1, nfb = knn_topk_ip_two_stage(X, Xb, Q, k, index_norm_max=nmax)
+    v1, i1, nfb = knn_topk_ip_two_stage(X, Xb, Q, k, index_norms=xn)
     assert torch.equal(i0, i1) and torch.equal(v0, v1), "two-stage search must equal the exhaustive scan"
-    t2 = _time_gpu(lambda: knn_topk_ip_two_stage(X, Xb, Q, k, index_norm_max=nmax), iters=10)
+    t2 = _time_gpu(lambda: knn_topk_ip_two_stage(X, Xb, Q, k, index_norms=xn), iters=10)
     out["nq1024_two_stage"] = {"qps": nq / t2, "us_per_call": t2 * 1e6, "fallback_queries": nfb, "bf16_coarse_TFLOPs": 2.0 * nq * N * D / t2 / 1e12,
                                "note": "identical results to nq1024 (checked in this run); coarse pass on the bf16 matrix cores"}
     return {"index": f"{N}x{D} fp32", "k": k, **out}
@@ -179,6 +180,27 @@ def cpu_baseline_knn(budget_s=12.0):
             "sample": f"oracle/knn_oracle.c (OpenMP), 61548x1792 fp32 index, k=16, {done} queries in batches of 256, {t:.1f} s"}
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: N ranks through torch.distributed.run (one process per GPU, RCCL over xGMI),
+    rendezvous on 127.0.0.1.  Returns the exit code; fails with a message (not a traceback) when the node has fewer GPUs."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()   # does not initialise the GPU on this image
+    if have < n:
+        print(f"bench.py: --gpus {n} needs {n} GPUs on this node, found {have}", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's intra-node transport on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,8 +218,14 @@ def main():
     a = ap.parse_args()
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # not under a launcher: spawn one rank per GPU ourselves, like the reference does (image2layout/train/train.py:52-61,
+        # mp.spawn over torch.cuda.device_count()).  This parent never initialises the GPU; rank 0's JSON line is its stdout.
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run --nproc-per-node {a.gpus}, or run bench.py --gpus {a.gpus} directly: it spawns its own ranks)")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1 or a.dp_selftest:

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 5
+#define RALF_ABI_VERSION 6
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -52,6 +52,16 @@ int ralf_knn_select(const float* scores, int64_t n_db, int nq, int k, int64_t* o
  * out[q][j] = <Q[q], X[cand[q][j]]> for cand int64 [nq, pool] (row indices, every value in [0, N)); same accumulation chain as
  * ralf_knn_scores, hence bit-identical scores */
 int ralf_knn_rescore(const float* X, int64_t N, int D, const float* Q, int nq, const int64_t* cand, int pool, float* out, void* stream);
+/* last step of the two-stage search (replaces the sort / gather / norm arithmetic around faiss-style re-ranking): the k best of
+ * `pool` re-scored candidates per query by (score desc, row index asc) -> out_idx / out_score [nq, k]; when `bad` (int32 [nq]) is
+ * given it also receives the per-query certificate  bad[q] = !(k-th exact score >= bound[q * bound_ld] + eps[q])  with
+ * eps = |q - qb| max|x| + |qb| max|x - xb| + 2 D 2^-24 |q| max|x| (bf16 rounding of both operands + fp32 accumulation of both
+ * passes): qnorms fp32 [nq, 3] and xnorms fp32 [3] from ralf_knn_rownorms.  pool <= 1024. */
+int ralf_knn_select_cand(const float* exact, const int64_t* cand, int nq, int pool, int k, int64_t* out_idx, float* out_score,
+                         const float* bound, int64_t bound_ld, const float* qnorms, const float* xnorms, int D, int32_t* bad, void* stream);
+/* per row of X fp32 [R, D] and its bf16 copy Xb: norms[r] = {|x|, |xb|, |x - xb|} (fp32 [R, 3], may be NULL); maxes fp32 [3]
+ * (may be NULL, zero on entry) = column maxima over the rows.  Values are rounded UP (they feed an upper bound). */
+int ralf_knn_rownorms(const float* X, const void* Xb_bf16, int64_t R, int D, float* norms, float* maxes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * element types of activation / weight buffers (accumulation is always fp32)

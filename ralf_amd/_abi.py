@@ -13,6 +13,8 @@ SIGNATURES = {
     "ralf_knn_scores": (i32, [vp, i64, i32, vp, i32, vp, vp]),
     "ralf_knn_select": (i32, [vp, i64, i32, i32, vp, vp, vp, sz, vp]),
     "ralf_knn_rescore": (i32, [vp, i64, i32, vp, i32, vp, i32, vp, vp]),
+    "ralf_knn_select_cand": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, i64, vp, vp, i32, vp, vp]),
+    "ralf_knn_rownorms": (i32, [vp, vp, i64, i32, vp, vp, vp]),
 }
 
 

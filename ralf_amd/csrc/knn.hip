@@ -2,7 +2,9 @@
 //
 // Replaces faiss.IndexFlat(d, METRIC_INNER_PRODUCT).search as reached from
 // image2layout/train/models/retrieval/retriever.py:200-202 (one query per call in the reference;
-// batched here).  Two phases:
+// batched here).  ralf_knn_topk_ip (k <= 64) runs the scan with a FUSED per-workgroup selection: every workgroup reduces
+// its [queries x 128..256 rows] score tile to k (score, index) pairs per query in LDS, so the [nq, N] score matrix never
+// reaches HBM and one merge launch finishes the call.  The two phases separately (larger k, tests, profiling):
 //   1. knn_scores_kernel : S[q][n] = <Q[q], X[n]> on the fp32 matrix cores
 //      (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32).  A chain of K-steps on one accumulator is
 //      bit-for-bit the ascending-d fmaf chain of oracle/knn_oracle.c, so scores are bit-exact.
@@ -40,16 +42,30 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// order-preserving float -> uint (larger float = larger key); key 0 is reserved for "no entry"
+__device__ __forceinline__ uint32_t f2key(float v) {
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+    return (k == 0u) ? -__builtin_inff() : __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__device__ __forceinline__ bool better(uint32_t ka, int pa, uint32_t kb, int pb) { return ka > kb || (ka == kb && pa < pb); }
+constexpr int KFUSED = 64;      // largest k of the fused scan + selection
+
 // A operand = query tile (M dim), B operand = index-row tile (N dim): for a fixed accumulator
 // register the 32 (16) lanes of a half-wave hold CONSECUTIVE index rows of one query, so the
 // score stores are contiguous 128 B (64 B) segments of S[q][*].
 // GATHER (exact re-scoring of per-query candidate lists, two-stage search): workgroup <-> (query q, chunk of its `pool`
 // candidates); the index rows come from cand[q][*], the query tile holds the single query q, S is [nq][pool].  The
 // accumulation code is the one of the exhaustive scan, so a re-scored pair is bit-identical to its exhaustive score.
-template <int MF, int TQ, int TR, bool GATHER = false>
+// TOPK (fused selection, k <= KFUSED): instead of the score tile the workgroup writes, per query, the k best (score, index)
+// pairs of its RW rows, sorted by (score desc, index asc) and padded with (-inf, -1):  ts / ti [q][row chunk][k].
+template <int MF, int TQ, int TR, bool GATHER = false, bool TOPK = false>
 __global__ __launch_bounds__(256) void knn_scores_kernel(const float* __restrict__ X, int64_t N, int D,
                                                           const float* __restrict__ Q, int nq, float* __restrict__ S,
-                                                          int n_qtiles, int nwg, const int64_t* __restrict__ cand = nullptr, int pool = 0) {
+                                                          int n_qtiles, int nwg, const int64_t* __restrict__ cand = nullptr, int pool = 0,
+                                                          int k = 0, float* __restrict__ ts = nullptr, int64_t* __restrict__ ti = nullptr) {
     using F = Frag<MF>;
     constexpr int RW = 4 * TR * MF, QW = TQ * MF, BK = 32, KS = F::KS, ROT = 32 / MF;
     constexpr int XV = RW * BK / 4 / 256;              // float4 per thread per k-tile (index rows)
@@ -146,6 +162,70 @@ __global__ __launch_bounds__(256) void knn_scores_kernel(const float* __restrict
         }
     }
 
+    if constexpr (TOPK) {
+        // ---- fused selection: MF queries x RW rows at a time through LDS (the operand tiles are dead: the k-loop ended with a barrier) ----
+        constexpr int E = RW / 64;                      // scores per lane: position p = e*64 + lane <-> index row0 + p
+        float* sl = lds;                                // [MF][RW]
+        uint32_t* wk = reinterpret_cast<uint32_t*>(lds + MF * RW) + wave * 128;   // this wave's winners: keys [64], positions [64]
+        int* wp = reinterpret_cast<int*>(wk) + 64;
+        const int nrc = nwg / n_qtiles;                 // row chunks = candidate lists per query
+        static_assert(MF * RW + 4 * 128 <= (RW + QW) * BK, "selection staging exceeds the operand tiles");
+#pragma unroll
+        for (int i = 0; i < TQ; ++i) {
+            if (i) __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TR; ++j) {
+                const int p = (wave * TR + j) * MF + lr;
+#pragma unroll
+                for (int r = 0; r < F::NREG; ++r) sl[F::crow(r, lane) * RW + p] = acc[i][j][r];
+            }
+            __syncthreads();
+            for (int ql = wave; ql < MF; ql += 4) {     // one wave per query
+                const int qi = q0 + i * MF + ql;
+                if (qi >= nq) break;                    // (wave-uniform)
+                uint32_t key[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) key[e] = (row0 + e * 64 + lane < N) ? f2key(sl[ql * RW + e * 64 + lane]) : 0u;
+                uint32_t T = 0;                         // largest T with |{key >= T}| >= k (0: fewer than k rows)
+                for (int bit = 31; bit >= 0; --bit) {
+                    const uint32_t t = T | (1u << bit);
+                    int c = 0;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) c += __popcll(__ballot(key[e] >= t));
+                    if (c >= k) T = t;
+                }
+                int cgt = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) cgt += __popcll(__ballot(key[e] > T));
+                const int need = k - cgt;               // entries equal to T to keep, lowest positions first
+                const unsigned long long below = (1ull << lane) - 1ull;
+                int nwin = 0, eqseen = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const unsigned long long eqm = __ballot(key[e] == T && T != 0u);
+                    const bool win = key[e] > T || (key[e] == T && T != 0u && eqseen + __popcll(eqm & below) < need);
+                    const unsigned long long wm = __ballot(win);
+                    if (win) { const int s = nwin + __popcll(wm & below); wk[s] = key[e]; wp[s] = e * 64 + lane; }
+                    nwin += __popcll(wm);
+                    eqseen += __popcll(eqm);
+                }
+                float* so = ts + ((int64_t)qi * nrc + rc) * k;
+                int64_t* io = ti + ((int64_t)qi * nrc + rc) * k;
+                __builtin_amdgcn_wave_barrier();        // the winners were written by other lanes of THIS wave (LDS ops of a wave complete in order)
+                if (lane < nwin) {
+                    const uint32_t mk = wk[lane];
+                    const int mp = wp[lane];
+                    int rank = 0;
+                    for (int j = 0; j < nwin; ++j) rank += better(wk[j], wp[j], mk, mp);
+                    so[rank] = key2f(mk);
+                    io[rank] = row0 + mp;
+                } else if (lane < k) {
+                    so[lane] = -__builtin_inff();
+                    io[lane] = -1;
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < TQ; ++i)
 #pragma unroll
@@ -157,6 +237,7 @@ __global__ __launch_bounds__(256) void knn_scores_kernel(const float* __restrict
                 if (qi < nq_hi && n < nrows) S[(int64_t)qi * nrows + n] = acc[i][j][r];
             }
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -166,14 +247,6 @@ constexpr int SEG = 8192;       // scores handled by one workgroup
 constexpr int EPT = SEG / 256;  // keys per thread (registers)
 constexpr int KMAX = 1024;
 
-// order-preserving float -> uint (larger float = larger key); key 0 is reserved for "no entry"
-__device__ __forceinline__ uint32_t f2key(float v) {
-    const uint32_t u = __float_as_uint(v);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key2f(uint32_t k) {
-    return (k == 0u) ? -__builtin_inff() : __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
 
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
@@ -190,8 +263,6 @@ __device__ __forceinline__ int block_sum(int v, int* red, int& slot) {
     slot ^= 1;
     return s;
 }
-
-__device__ __forceinline__ bool better(uint32_t ka, int pa, uint32_t kb, int pb) { return ka > kb || (ka == kb && pa < pb); }
 
 // One workgroup selects the top-k of `cnt` (<= SEG) entries of query blockIdx.y, list blockIdx.x.
 //   FROM_SCORES: entries are S[q][base + p], index = base + p
@@ -316,6 +387,72 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict
     }
 }
 
+
+// ---- two-stage search helpers ------------------------------------------------------------------------------------
+// final selection among per-query candidates: exact[q][j] is the score of index row cand[q][j]; the k best by
+// (score desc, row index asc) -- the order of the exhaustive scan -- plus the per-query certificate of the two-stage search:
+//   bad[q] = !(k-th exact score >= bound[q] + eps[q]),  eps = |q - qb| xmax + |qb| dxmax + 2 D 2^-24 |q| xmax + 1e-6
+// (qn = per-query norms {|q|, |qb|, |q - qb|}, xn = index constants {max|x|, max|xb|, max|x - xb|}; see retrieval/knn.py).
+// One wave per query; pool <= 1024.
+__global__ __launch_bounds__(64) void knn_select_cand_kernel(const float* __restrict__ exact, const int64_t* __restrict__ cand, int pool, int k,
+                                                             float* __restrict__ os, int64_t* __restrict__ oi, const float* __restrict__ bound,
+                                                             int64_t bound_ld, const float* __restrict__ qn, const float* __restrict__ xn, int D,
+                                                             int32_t* __restrict__ bad) {
+    __shared__ uint32_t key[KMAX];
+    __shared__ int64_t row[KMAX];
+    const int q = blockIdx.x, lane = threadIdx.x;
+    for (int j = lane; j < pool; j += 64) {
+        key[j] = f2key(exact[(int64_t)q * pool + j]);
+        row[j] = cand[(int64_t)q * pool + j];
+    }
+    __syncthreads();
+    float kth = -__builtin_inff();
+    for (int j = lane; j < pool; j += 64) {
+        const uint32_t kj = key[j];
+        const int64_t rj = row[j];
+        int rank = 0;
+        for (int i = 0; i < pool; ++i) rank += (key[i] > kj) || (key[i] == kj && row[i] < rj);
+        if (rank < k) {
+            os[(int64_t)q * k + rank] = key2f(kj);
+            oi[(int64_t)q * k + rank] = rj;
+            if (rank == k - 1) kth = key2f(kj);
+        }
+    }
+    if (bad) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kth = fmaxf(kth, __shfl_xor(kth, o));
+        if (lane == 0) {
+            const float eps = qn[q * 3 + 2] * xn[0] + qn[q * 3 + 1] * xn[2] + 2.f * (float)D * 5.9604645e-8f * qn[q * 3] * xn[0] + 1e-6f;
+            bad[q] = !(kth >= bound[(int64_t)q * bound_ld] + eps * 1.001f);
+        }
+    }
+}
+
+// per row r of X [R, D] (fp32) and its bf16 rounding Xb: norms[r] = {|x_r|, |xb_r|, |x_r - xb_r|} (may be NULL) and
+// maxes[0..2] = max over rows (may be NULL; non-negative floats compare like their bit patterns; caller zeroes it).
+__global__ __launch_bounds__(256) void knn_rownorms_kernel(const float* __restrict__ X, const __bf16* __restrict__ Xb, int64_t R, int D,
+                                                          float* __restrict__ norms, float* __restrict__ maxes) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float x = X[r * D + d], xb = (float)Xb[r * D + d], e = x - xb;
+        a += x * x; b += xb * xb; c += e * e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+    if (lane == 0) {
+        a = sqrtf(a) * 1.000001f; b = sqrtf(b) * 1.000001f; c = sqrtf(c) * 1.000001f;   // rounded up: these feed an upper bound
+        if (norms) { norms[r * 3] = a; norms[r * 3 + 1] = b; norms[r * 3 + 2] = c; }
+        if (maxes) {
+            atomicMax(reinterpret_cast<unsigned int*>(maxes), __float_as_uint(a));
+            atomicMax(reinterpret_cast<unsigned int*>(maxes) + 1, __float_as_uint(b));
+            atomicMax(reinterpret_cast<unsigned int*>(maxes) + 2, __float_as_uint(c));
+        }
+    }
+}
+
 template <int MF, int TQ, int TR>
 int launch_scores(const float* X, int64_t N, int D, const float* Q, int nq, float* S, hipStream_t st) {
     constexpr int RW = 4 * TR * MF, QW = TQ * MF;
@@ -324,6 +461,19 @@ int launch_scores(const float* X, int64_t N, int D, const float* Q, int nq, floa
     hipLaunchKernelGGL((knn_scores_kernel<MF, TQ, TR>), dim3(nwg), dim3(256), 0, st, X, N, D, Q, nq, S, nqt, nwg);
     return ralf::check_launch("knn_scores");
 }
+
+template <int MF, int TQ, int TR>
+int launch_scan_topk(const float* X, int64_t N, int D, const float* Q, int nq, int k, float* ts, int64_t* ti, hipStream_t st) {
+    constexpr int RW = 4 * TR * MF, QW = TQ * MF;
+    const int nrc = ceil_div(N, RW), nqt = ceil_div(nq, QW);
+    const int nwg = nrc * nqt;
+    hipLaunchKernelGGL((knn_scores_kernel<MF, TQ, TR, false, true>), dim3(nwg), dim3(256), 0, st, X, N, D, Q, nq, (float*)nullptr, nqt, nwg,
+                       (const int64_t*)nullptr, 0, k, ts, ti);
+    return ralf::check_launch("knn_scan_topk");
+}
+
+// rows scanned per workgroup of the fused scan (= rows per candidate list), by query count: the tile shapes of ralf_knn_scores
+inline int fused_rows_per_wg(int nq) { return nq <= 32 ? 128 : 256; }
 
 int launch_rescore(const float* X, int64_t N, int D, const float* Q, int nq, const int64_t* cand, int pool, float* S, hipStream_t st) {
     constexpr int MF = 16, RW = 4 * MF;                    // 64 candidates per workgroup, one query per 16-row query tile
@@ -368,9 +518,32 @@ extern "C" int ralf_knn_rescore(const float* X, int64_t N, int D, const float* Q
     return launch_rescore(X, N, D, Q, nq, cand, pool, out, (hipStream_t)stream);
 }
 
+extern "C" int ralf_knn_select_cand(const float* exact, const int64_t* cand, int nq, int pool, int k, int64_t* out_idx, float* out_score,
+                                    const float* bound, int64_t bound_ld, const float* qnorms, const float* xnorms, int D, int32_t* bad, void* stream) {
+    RALF_REQUIRE(exact && cand && out_idx && out_score && nq > 0, "knn_select_cand: bad arguments");
+    RALF_REQUIRE(pool >= 1 && pool <= KMAX && k >= 1 && k <= pool, "knn_select_cand: pool=%d k=%d outside [1,%d]", pool, k, KMAX);
+    RALF_REQUIRE(!bad || (bound && qnorms && xnorms), "knn_select_cand: the certificate needs bound, qnorms and xnorms");
+    hipLaunchKernelGGL(knn_select_cand_kernel, dim3(nq), dim3(64), 0, (hipStream_t)stream, exact, cand, pool, k, out_score, out_idx, bound, bound_ld,
+                       qnorms, xnorms, D, bad);
+    return ralf::check_launch("knn_select_cand");
+}
+
+extern "C" int ralf_knn_rownorms(const float* X, const void* Xb, int64_t R, int D, float* norms, float* maxes, void* stream) {
+    RALF_REQUIRE(X && Xb && R > 0 && D > 0 && (norms || maxes), "knn_rownorms: bad arguments");
+    hipLaunchKernelGGL(knn_rownorms_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X, (const __bf16*)Xb, R, D, norms, maxes);
+    return ralf::check_launch("knn_rownorms");
+}
+
+// lists of k candidates per query after the fused scan
+static inline int64_t fused_lists(int64_t N, int nq) { return (N + fused_rows_per_wg(nq) - 1) / fused_rows_per_wg(nq); }
+
 extern "C" size_t ralf_knn_topk_ip_workspace_bytes(int64_t N, int D, int nq, int k) {
     (void)D;
     if (N <= 0 || nq <= 0 || k <= 0) return 0;
+    if (k <= KFUSED) {   // fused scan + selection: two candidate buffers, no score matrix
+        const size_t cand = (size_t)nq * fused_lists(N, nq) * k * (sizeof(float) + sizeof(int64_t));
+        return 2 * align256(cand) + 256;
+    }
     SelectPlan p = plan_select(N, nq, k);
     return align256((size_t)nq * N * sizeof(float)) + 2 * align256(p.cand_bytes) + 256;
 }
@@ -413,6 +586,21 @@ extern "C" int ralf_knn_select(const float* S, int64_t N, int nq, int k, int64_t
     return ralf::check_launch("knn_select");
 }
 
+// candidate lists [nq][nl][k] (equal scores in ascending index order) -> out, by rounds of knn_select_kernel<false>
+static int merge_lists(float* cs[2], int64_t* ci[2], int64_t nl, int nq, int k, int64_t* out_idx, float* out_score, hipStream_t st) {
+    int cur = 0;
+    const int64_t group = SEG / k;  // lists merged per workgroup (>= 8 since k <= 1024)
+    do {
+        const int64_t nout = (nl + group - 1) / group;
+        float* so = nout == 1 ? out_score : cs[cur ^ 1];
+        int64_t* io = nout == 1 ? out_idx : ci[cur ^ 1];
+        hipLaunchKernelGGL((knn_select_kernel<false>), dim3((unsigned)nout, nq), dim3(256), 0, st, nullptr, cs[cur], ci[cur], nl * k, nl * k, group * k, k, so, io);
+        nl = nout;
+        cur ^= 1;
+    } while (nl > 1);
+    return ralf::check_launch("knn_merge");
+}
+
 extern "C" int ralf_knn_topk_ip(const float* X, int64_t N, int D, const float* Q, int nq, int k, int64_t* out_idx,
                                 float* out_score, void* ws, size_t ws_bytes, void* stream) {
     RALF_REQUIRE(k >= 1 && k <= KMAX, "knn_topk_ip: k=%d outside [1,%d]", k, KMAX);
@@ -423,6 +611,30 @@ extern "C" int ralf_knn_topk_ip(const float* X, int64_t N, int D, const float* Q
         return RALF_ERR_WORKSPACE;
     }
     RALF_REQUIRE(((uintptr_t)ws & 255) == 0, "knn_topk_ip: workspace must be 256-byte aligned");
+    if (k <= KFUSED) {
+        RALF_REQUIRE(X && Q && out_idx && out_score, "knn_topk_ip: null pointer");
+        RALF_REQUIRE(D > 0 && D % 4 == 0, "knn_topk_ip: dim %d must be a multiple of 4 (16-byte row alignment)", D);
+        RALF_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)Q & 15) == 0, "knn_topk_ip: index/queries must be 16-byte aligned");
+        hipStream_t st = (hipStream_t)stream;
+        const int64_t nl = fused_lists(N, nq);
+        const size_t cand = (size_t)nq * nl * k * (sizeof(float) + sizeof(int64_t));
+        float* cs[2];
+        int64_t* ci[2];
+        for (int i = 0; i < 2; ++i) {
+            ci[i] = (int64_t*)((char*)ws + i * align256(cand));
+            cs[i] = (float*)(ci[i] + (size_t)nq * nl * k);
+        }
+        // one list and it is the answer: the scan writes the output itself
+        float* ts = nl == 1 ? out_score : cs[0];
+        int64_t* ti = nl == 1 ? out_idx : ci[0];
+        int rc;
+        if (nq <= 16) rc = launch_scan_topk<16, 1, 2>(X, N, D, Q, nq, k, ts, ti, st);        // same tiles as ralf_knn_scores
+        else if (nq <= 32) rc = launch_scan_topk<32, 1, 1>(X, N, D, Q, nq, k, ts, ti, st);
+        else if (nq <= 64) rc = launch_scan_topk<32, 2, 2>(X, N, D, Q, nq, k, ts, ti, st);
+        else rc = launch_scan_topk<32, 4, 2>(X, N, D, Q, nq, k, ts, ti, st);
+        if (rc || nl == 1) return rc;
+        return merge_lists(cs, ci, nl, nq, k, out_idx, out_score, st);
+    }
     float* S = (float*)ws;
     const size_t soff = align256((size_t)nq * N * sizeof(float));
     int rc = ralf_knn_scores(X, N, D, Q, nq, S, stream);

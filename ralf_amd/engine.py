@@ -67,6 +67,18 @@ class FlatAdamW:
     def zero_grad(self):
         self.G.zero_()
 
+    def sync_shadow(self):
+        """the fp32 masters were rewritten behind the optimizer's back (load_state_dict, broadcast, re-init, EMA copy): refresh
+        the bf16 shadow the forward reads and invalidate the runtime's derived weight layouts"""
+        if self.P16 is not None:
+            ops.cast_into(self.P, self.P16)
+        if self.runtime is not None:
+            for e in self.runtime._shadow.values():   # the views are current again: re-stamp them
+                w = e[3]()
+                if w is not None:
+                    e[1], e[2] = w._version, w.data_ptr()
+            self.runtime.weights_changed()
+
     def clip(self):
         self._ss.zero_()
         ops.sumsq(self.G, self._ss)
@@ -119,6 +131,60 @@ def average_gradients(flat: torch.Tensor, world: int, group=None) -> None:
         torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=group)
 
 
+class GradExchange:
+    """Sum of the flat fp32 gradient buffer over the ranks, by element ranges (the staged backward exchanges the buffer in
+    two parts, TrainStep._exchange_around).
+
+    wire = "fp32": all_reduce of the fp32 ranges in place (172 MB per step for RALF).
+    wire = "bf16": each range is packed to a bf16 staging buffer (ralf_copy2d), all-reduced there and unpacked back into the
+        fp32 buffer: HALF the bytes per xGMI link (the ring is per-link bound, SURVEY 8e: 86 MB instead of 172 MB); the
+        backward was seeded with 1/world, so the wire carries averages-in-the-making of bf16-computed gradients (their own
+        rounding is 2^-9 relative) and clip / AdamW still run on fp32.
+    `pack(src_fp32, dst_bf16)` / `unpack(src_bf16, dst_fp32)` default to the HIP cast kernel; the gloo CPU test passes
+    torch copies."""
+
+    def __init__(self, flat: torch.Tensor, world: int, group=None, wire: str = "fp32", pack=None, unpack=None):
+        assert wire in ("fp32", "bf16")
+        self.flat, self.world, self.group, self.wire = flat, world, group, wire
+        self.stage = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device) if (wire == "bf16" and self.active) else None
+        self._pack = pack or ops.cast_into
+        self._unpack = unpack or ops.cast_into
+
+    @property
+    def active(self) -> bool:
+        return self.world > 1 or self.group is not None
+
+    def bytes_on_wire(self, ranges) -> int:
+        return sum(b - a for a, b in ranges) * (2 if self.wire == "bf16" else 4)
+
+    def start(self, ranges, async_op: bool):
+        """launch the exchange of `ranges`; returns a token for finish()"""
+        if not self.active:
+            return None
+        ar = torch.distributed.all_reduce
+        if self.wire == "fp32":
+            return [ar(self.flat[a:b], op=torch.distributed.ReduceOp.SUM, group=self.group, async_op=async_op) for a, b in ranges], ranges
+        works = []
+        for a, b in ranges:
+            self._pack(self.flat[a:b], self.stage[a:b])
+            works.append(ar(self.stage[a:b], op=torch.distributed.ReduceOp.SUM, group=self.group, async_op=async_op))
+        return works, ranges
+
+    def finish(self, token) -> None:
+        if token is None:
+            return
+        works, ranges = token
+        for w in works:
+            if w is not None:
+                w.wait()
+        if self.wire == "bf16":
+            for a, b in ranges:
+                self._unpack(self.stage[a:b], self.flat[a:b])
+
+    def run(self, ranges) -> None:
+        self.finish(self.start(ranges, False))
+
+
 def flat_ranges(params, flat: torch.Tensor, align: int = 1):
     """[(begin, end)] element ranges of the flat buffer `flat` covered by the .grad views of `params` (views INTO flat),
     adjacent views merged (gaps up to `align` - 1 padding elements are bridged)."""
@@ -167,7 +233,7 @@ class TrainStep:
     """One optimisation step of `model` (a ralf_amd generator) = forward + backward + (all-reduce) + clip + AdamW."""
 
     def __init__(self, model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, backbone_lr_scale=0.1, betas=(0.9, 0.999), eps=1e-8,
-                 use_graph=True, process_group=None, overlap_wgrad=True, overlap_allreduce=None):
+                 use_graph=True, process_group=None, overlap_wgrad=True, overlap_allreduce=None, grad_wire=None):
         self.model = model
         rt = model.rt.to(model.device)
         groups = model.optim_groups(base_lr=lr, weight_decay=weight_decay, custom_lr={"encoder.extractor.body": lr * backbone_lr_scale})
@@ -177,6 +243,11 @@ class TrainStep:
         self.use_graph = use_graph
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if (process_group is not None or torch.distributed.is_initialized()) else 1
+        # gradient exchange: bf16 on the wire when the step computes in bf16 (half the bytes per xGMI link), fp32 in parity mode
+        wire = grad_wire or ("bf16" if rt.dtype == torch.bfloat16 else "fp32")
+        self.exchange = GradExchange(self.opt.G, self.world, process_group, wire)
+        if self.world > 1:
+            self._sync_replicas(rt)
         self._static = None
         self._graphs = None
         self.loss = None
@@ -225,13 +296,22 @@ class TrainStep:
             torch.autograd.backward([o for o, _ in cuts], [leaf.grad for _, leaf in cuts])
             rt.join_side()
 
-    def _reduce(self, ranges, async_op):
-        if self.world <= 1 and self.pg is None:
-            return []
-        return [torch.distributed.all_reduce(self.opt.G[a:b], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=async_op) for a, b in ranges]
+    def _sync_replicas(self, rt):
+        """what the reference's DDP constructor does (train/train.py:208): every rank starts from rank 0's parameters and
+        buffers; the dropout generator is decorrelated across ranks (seed offset by rank)."""
+        rank = torch.distributed.get_rank(self.pg)
+        src = torch.distributed.get_global_rank(self.pg, 0) if self.pg is not None else 0
+        torch.distributed.broadcast(self.opt.P, src, group=self.pg)
+        for b in self.model.buffers():
+            if b.is_floating_point() or b.dtype in (torch.int64, torch.int32, torch.bool, torch.uint8):
+                torch.distributed.broadcast(b.data, src, group=self.pg)
+        self.opt.sync_shadow()
+        rt._seed_host = rt._seed_host + 0x51ED27 * rank
+        rt.seed = None
+        rt.to(self.model.device)
 
     def _allreduce(self):
-        average_gradients(self.opt.G, self.world, self.pg)
+        self.exchange.run([(0, self.opt.G.numel())])
 
     def _update(self):
         self.opt.step()
@@ -239,11 +319,10 @@ class TrainStep:
 
     def _exchange_around(self, stage2):
         """stage-1 gradients on the wire while `stage2` (the rest of the backward) is issued; then the stage-2 gradients"""
-        works = self._reduce(self._early, True)
+        token = self.exchange.start(self._early, True)
         stage2()
-        for w in works:
-            w.wait()
-        self._reduce(self._late, False)
+        self.exchange.finish(token)
+        self.exchange.run(self._late)
 
     def _eager(self, inputs, targets):
         loss = self._fwd_bwd(inputs, targets)

@@ -67,7 +67,10 @@ class Runtime:
         return leaf
 
     def register_shadow(self, w: torch.Tensor, view: torch.Tensor):
-        self._shadow[id(w)] = view
+        """low-precision view kept current by the fused optimizer (which rewrites the master through its raw pointer, i.e.
+        WITHOUT bumping w._version): any other in-place write to the master (load_state_dict, broadcast, re-init, EMA copy)
+        does bump it, and lp() then re-casts the view."""
+        self._shadow[id(w)] = [view, w._version, w.data_ptr(), weakref.ref(w)]
 
     def weights_changed(self):
         self._wtoken += 1
@@ -137,8 +140,12 @@ class Runtime:
             if w.dtype == self.dtype:
                 return w.detach()
             sh = self._shadow.get(id(w))
-            if sh is not None and sh.dtype == self.dtype:
-                return sh
+            if sh is not None and sh[3]() is w and sh[0].dtype == self.dtype:
+                if sh[1] != w._version or sh[2] != w.data_ptr():   # master rewritten behind the optimizer: refresh the view
+                    ops.cast_into(w.detach().contiguous().view(-1), sh[0].view(-1))
+                    sh[1], sh[2] = w._version, w.data_ptr()
+                    self._wtoken += 1
+                return sh[0]
         key = (id(w), kind, self.dtype)
         hit = self._lp.get(key)
         if hit is not None and hit[3]() is w and hit[0] == (w._version, self._wtoken) and hit[1] == w.data_ptr():

@@ -184,6 +184,14 @@ def cast(x, dtype):
     return y
 
 
+def cast_into(x, out):
+    """out[:] = x with dtype conversion (fp32 <-> bf16) through ralf_copy2d; both contiguous, same element count."""
+    n = x.numel()
+    assert out.numel() == n and x.is_contiguous() and out.is_contiguous()
+    _call("ralf_copy2d", dtype_code(x), dtype_code(out), _p(x), _p(out), 1, n, n, n, 0)
+    return out
+
+
 def permute4(x, out_dims, strides, valid3, dtype, out=None):
     if out is None:
         out = torch.empty(out_dims, dtype=dtype, device=x.device)

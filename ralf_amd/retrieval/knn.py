@@ -60,34 +60,60 @@ def knn_rescore(index: torch.Tensor, queries: torch.Tensor, cand: torch.Tensor) 
     return out
 
 
-def knn_topk_ip_two_stage(index: torch.Tensor, index_bf16: torch.Tensor, queries: torch.Tensor, k: int, pool: int = 0, index_norm_max: float | None = None):
+def knn_rownorms(x: torch.Tensor, xb: torch.Tensor, want_rows: bool = True, want_max: bool = False):
+    """per row {|x|, |xb|, |x - xb|} of an fp32 matrix and its bf16 copy (ralf_knn_rownorms) -> ([R,3] or None, [3] maxima or None)"""
+    R, D = x.shape
+    norms = torch.empty(R, 3, dtype=torch.float32, device=x.device) if want_rows else None
+    mx = torch.zeros(3, dtype=torch.float32, device=x.device) if want_max else None
+    rc = _lib.lib().ralf_knn_rownorms(_lib.ptr(x), _lib.ptr(xb), R, D, _lib.ptr(norms), _lib.ptr(mx), _lib.stream_ptr())
+    _lib.check(rc, "ralf_knn_rownorms")
+    return norms, mx
+
+
+def knn_select_cand(exact: torch.Tensor, cand: torch.Tensor, k: int, bound=None, qnorms=None, xnorms=None, D: int = 0):
+    """k best of the re-scored candidates per query by (score desc, row index asc); with bound/qnorms/xnorms also the
+    per-query certificate flags (int32 [nq], 1 = not certified)."""
+    nq, pool = exact.shape
+    idx = torch.empty(nq, k, dtype=torch.int64, device=exact.device)
+    val = torch.empty(nq, k, dtype=torch.float32, device=exact.device)
+    bad = torch.empty(nq, dtype=torch.int32, device=exact.device) if bound is not None else None
+    import ctypes
+    bptr = ctypes.c_void_p(bound.data_ptr()) if bound is not None else None
+    rc = _lib.lib().ralf_knn_select_cand(_lib.ptr(exact), _lib.ptr(cand), nq, pool, k, _lib.ptr(idx), _lib.ptr(val), bptr,
+                                         bound.stride(0) if bound is not None else 0, _lib.ptr(qnorms), _lib.ptr(xnorms), D, _lib.ptr(bad), _lib.stream_ptr())
+    _lib.check(rc, "ralf_knn_select_cand")
+    return val, idx, bad
+
+
+def knn_topk_ip_two_stage(index: torch.Tensor, index_bf16: torch.Tensor, queries: torch.Tensor, k: int, pool: int = 0, index_norms: torch.Tensor | None = None):
     """Exact top-k for LARGE query batches (nq >> 32, where the fp32 scan is bound by the 157 TFLOP/s fp32 matrix rate,
     SURVEY section 7): a bf16-MFMA coarse pass ranks every row, the best `pool` candidates per query are re-scored exactly
     in fp32 (same ascending-d accumulation chain as the exhaustive scan, so the scores are bit-identical), and the result is
-    CERTIFIED per query: with eps >= |coarse - exact| for every row (bf16 rounding of both operands: 2^-8 |q| |x|),
-        exact k-th score  >=  coarse (pool+1)-th score + eps
-    proves that no row outside the pool can enter the top-k.  Queries that fail the test are re-run through the exhaustive
-    fp32 path, so the returned (scores, indices) always equal knn_topk_ip's.  Returns (scores, idx, n_fallback)."""
+    CERTIFIED per query.  With qb / xb the bf16 roundings,
+        |coarse(q, x) - exact(q, x)|  <=  |q - qb| |x| + |qb| |x - xb|  (operand rounding)  +  2 D 2^-24 |q| |x|  (fp32 accumulation of
+        both passes)  =: eps,   evaluated with the index-wide maxima of |x| and |x - xb| (index_norms, built once per index),
+    so   exact k-th score  >=  coarse (pool+1)-th score + eps   proves that no row outside the pool can enter the top-k.
+    Queries that fail the test are re-run through the exhaustive fp32 path, so the returned (scores, indices) always equal
+    knn_topk_ip's.  Every step is a HIP kernel (cast, GEMM, select, gathered re-score, candidate select + certificate).
+    Returns (scores, idx, n_fallback)."""
     from .. import ops
 
     assert index.is_cuda and index.dtype == torch.float32 and index_bf16.dtype == torch.bfloat16 and index_bf16.shape == index.shape
     N, D = index.shape
     nq = queries.shape[0]
-    pool = pool or min(max(4 * k, 64), N - 1)
+    pool = pool or min(max(4 * k, 64), N - 1, 1023)
     assert k <= pool < N
     q = queries.contiguous()
     qb = ops.cast(q, torch.bfloat16)
+    if index_norms is None:
+        _, index_norms = knn_rownorms(index, index_bf16, want_rows=False, want_max=True)
+    qn, _ = knn_rownorms(q, qb)
     coarse = ops.gemm(qb, index_bf16, nq, N, D, out_dtype=torch.float32)             # [nq, N] = Qb Xb^T (bf16 MFMA, fp32 accumulate)
     cval, cidx = knn_select(coarse, pool + 1)                                         # sorted by coarse score
-    bound = cval[:, pool]                                                             # upper bound of every row OUTSIDE the pool
-    cand, _ = torch.sort(cidx[:, :pool], dim=1)                                       # ascending row index: ties then resolve like the exhaustive path
-    exact = knn_rescore(index, q, cand)                                              # same fp32 MFMA chain as the exhaustive scan
-    val, pos = knn_select(exact, k)
-    idx = torch.gather(cand, 1, pos)
-    if index_norm_max is None:
-        index_norm_max = float(torch.linalg.vector_norm(index, dim=1).max())
-    eps = (2.0 ** -8) * 1.001 * torch.linalg.vector_norm(q, dim=1) * index_norm_max + 1e-6
-    bad = torch.nonzero(~(val[:, k - 1] >= bound + eps)).flatten()
+    # candidates = the pool+1 best coarse rows; every row outside them has a coarse score <= cval[:, pool]
+    exact = knn_rescore(index, q, cidx)                                              # same fp32 MFMA chain as the exhaustive scan
+    val, idx, bad = knn_select_cand(exact, cidx, k, bound=cval[:, pool], qnorms=qn, xnorms=index_norms, D=D)
+    bad = torch.nonzero(bad).flatten()                                               # (index plumbing; syncs with the host)
     if bad.numel():   # not certified (tiny gaps / mass ties): exhaustive fp32 scan for those queries only
         v2, i2 = knn_topk_ip(index, q[bad].contiguous(), k)
         val[bad], idx[bad] = v2, i2
@@ -101,7 +127,7 @@ class FlatIPIndex:
         self.vectors = torch.as_tensor(vectors, dtype=torch.float32).to(device).contiguous()
         self._ws = None
         self._bf16 = None                 # bf16 shadow of the index for the coarse pass of large query batches (built on first use)
-        self._norm_max = None
+        self._norms = None                # {max|x|, max|xb|, max|x - xb|} of the index rows: the certificate's constants
         self.two_stage_min_queries = two_stage_min_queries
         self.last_fallbacks = 0
 
@@ -121,8 +147,8 @@ class FlatIPIndex:
             from .. import ops
             if self._bf16 is None:
                 self._bf16 = ops.cast(self.vectors, torch.bfloat16)
-                self._norm_max = float(torch.linalg.vector_norm(self.vectors, dim=1).max())
-            val, idx, self.last_fallbacks = knn_topk_ip_two_stage(self.vectors, self._bf16, q, k, index_norm_max=self._norm_max)
+                _, self._norms = knn_rownorms(self.vectors, self._bf16, want_rows=False, want_max=True)
+            val, idx, self.last_fallbacks = knn_topk_ip_two_stage(self.vectors, self._bf16, q, k, index_norms=self._norms)
             return val, idx
         need = _lib.lib().ralf_knn_topk_ip_workspace_bytes(self.ntotal, self.d, q.shape[0], k)
         if self._ws is None or self._ws.numel() < need:

@@ -48,9 +48,40 @@ def _ids_of(dataset) -> list:
     return [dataset[i]["id"] for i in range(len(dataset))]
 
 
+PRECOMPUTED_WEIGHT_DIR = "./cache/PRECOMPUTED_WEIGHT_DIR"   # image2layout/train/global_variables.py:21
+
+
+class _TablePickle:
+    """pickle-module shim for torch.load of retrieval tables: only the container classes such a table holds resolve
+    (collections.defaultdict / OrderedDict and builtins); everything else is refused.  (torch's weights_only unpickler cannot
+    rebuild a defaultdict at all: "Can only SETITEM for dict ...".)"""
+    import pickle as _pk
+
+    _ALLOWED = {("collections", "defaultdict"), ("collections", "OrderedDict"), ("builtins", "list"), ("builtins", "dict"),
+                ("builtins", "int"), ("builtins", "str"), ("builtins", "float"), ("builtins", "tuple"), ("builtins", "set")}
+
+    class Unpickler(_pk.Unpickler):
+        def find_class(self, module, name):
+            if ("builtins" if module == "__builtin__" else module, name) in _TablePickle._ALLOWED:   # protocol-2 pickles spell it __builtin__
+                return super().find_class(module, name)
+            raise _TablePickle._pk.UnpicklingError(f"retrieval table: refusing to load {module}.{name}")
+
+    load = staticmethod(lambda f, **kw: _TablePickle.Unpickler(f, **kw).load())
+    __name__ = "pickle"
+
+
 def load_cache_table(cache_path: str, top_k: int) -> dict:
-    table = torch.load(cache_path)
-    return {k: v[:top_k] for k, v in table.items()}
+    """helpers/retrieval_dataset_wrapper.py:17-33: the table at `cache_path`, else the precomputed one of the same file name under
+    PRECOMPUTED_WEIGHT_DIR/retrieval_indexes.  The reference writes its tables as collections.defaultdict(list)
+    (models/retrieval/retriever.py:188-221), which torch >= 2.6's default weights_only=True unpickler rejects; they are read
+    through an allow-listing unpickler and returned as a plain dict."""
+    if not os.path.exists(cache_path):
+        alt = os.path.join(PRECOMPUTED_WEIGHT_DIR, "retrieval_indexes", os.path.basename(cache_path))
+        if not os.path.exists(alt):
+            raise ValueError(f"Cache not found in {alt}")
+        cache_path = alt
+    table = torch.load(cache_path, pickle_module=_TablePickle, weights_only=False)
+    return {k: v[:top_k] for k, v in dict(table).items()}
 
 
 class Retriever:

@@ -21,7 +21,7 @@ def test_header_matches_abi_table_and_library():
     L = _lib.lib()
     for s in syms:
         assert hasattr(L, s), f"libralf_hip.so does not export {s}"
-    assert L.ralf_abi_version() == 5
+    assert L.ralf_abi_version() == 6
     assert isinstance(L.ralf_last_error(), bytes)
 
 
@@ -30,5 +30,8 @@ def test_workspace_query_is_pure_host():
 
     L = _lib.lib()
     assert L.ralf_knn_topk_ip_workspace_bytes(0, 64, 1, 16) == 0
+    # k <= 64: fused scan + selection, two candidate buffers of nq x ceil(N / 256) lists x k (score, index) pairs -- no score matrix
     w = L.ralf_knn_topk_ip_workspace_bytes(61548, 1792, 1024, 17)
-    assert w >= 61548 * 1024 * 4
+    assert 2 * 1024 * 241 * 17 * 12 <= w < 61548 * 1024 * 4
+    # larger k: score matrix + candidate buffers
+    assert L.ralf_knn_topk_ip_workspace_bytes(61548, 1792, 1024, 100) >= 61548 * 1024 * 4

@@ -49,6 +49,59 @@ def test_cgl_sized_index(d, nq):
     assert_exact(unit_rows(61548, d, 4), unit_rows(nq, d, 5), 17)
 
 
+@pytest.mark.parametrize("nq", [1, 20, 50, 100])
+@pytest.mark.parametrize("k", [1, 16, 64])
+def test_fused_scan_selection_degenerate_rows(nq, k):
+    """the fused scan + per-workgroup selection (k <= 64) on inputs that stress the in-LDS selection: whole row chunks of identical
+    rows (ties fill a chunk's list), all-zero rows (score -0.0 / +0.0), chunks shorter than k, negative-only scores"""
+    rng = np.random.default_rng(nq * 100 + k)
+    X = unit_rows(1000, 32, 11)
+    X[128:384] = X[130]                      # two full 128-row chunks (one 256-row chunk) of identical rows
+    X[500:520] = 0.0                         # zero rows
+    X[900:] = -np.abs(X[900:])               # last (short) chunk
+    Q = np.concatenate([X[[130, 0, 505]], np.abs(unit_rows(max(nq - 3, 1), 32, 12))])[:nq]
+    assert_exact(X, Q, k)
+    assert_exact(X[:37], Q, k)               # fewer rows than k = 64: padded with (-inf, -1)
+
+
+def test_two_stage_certificate_is_a_bound():
+    """the certificate's eps (ralf_knn_rownorms + ralf_knn_select_cand) really bounds |coarse - exact| for every (query, row)
+    pair: operand rounding to bf16 plus the fp32 accumulation of both passes"""
+    from ralf_amd import ops
+    from ralf_amd.retrieval.knn import knn_rownorms, knn_scores
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for scale in (1.0, 37.0):                 # un-normalised rows too
+        X = torch.randn(3000, 1792, device="cuda", generator=g) * scale
+        Q = torch.randn(64, 1792, device="cuda", generator=g)
+        Xb, Qb = ops.cast(X, torch.bfloat16), ops.cast(Q, torch.bfloat16)
+        qn, _ = knn_rownorms(Q, Qb)
+        xr, xn = knn_rownorms(X, Xb, want_rows=True, want_max=True)
+        torch.testing.assert_close(qn[:, 0], Q.norm(dim=1), rtol=1e-5, atol=0)
+        torch.testing.assert_close(xr[:, 2], (X - Xb.float()).norm(dim=1), rtol=1e-4, atol=0)
+        assert torch.equal(xn, xr.max(dim=0).values)
+        coarse = ops.gemm(Qb, Xb, 64, 3000, 1792, out_dtype=torch.float32)
+        exact = knn_scores(X, Q)
+        eps = qn[:, 2] * xn[0] + qn[:, 1] * xn[2] + 2 * 1792 * 2.0 ** -24 * qn[:, 0] * xn[0]
+        assert bool(((coarse - exact).abs() <= eps[:, None]).all())
+        assert float(((coarse - exact).abs() / eps[:, None]).max()) > 0.02      # ... and is not vacuous
+
+
+def test_select_cand_orders_by_score_then_row():
+    from ralf_amd.retrieval.knn import knn_select_cand
+
+    rng = np.random.default_rng(2)
+    for pool, k in ((65, 16), (200, 33), (1024, 64), (5, 5)):
+        cand = np.stack([rng.permutation(5000)[:pool] for _ in range(7)]).astype(np.int64)
+        sc = rng.integers(0, 6, (7, pool)).astype(np.float32)       # massive ties
+        v, i, bad = knn_select_cand(torch.from_numpy(sc).cuda(), torch.from_numpy(cand).cuda(), k)
+        assert bad is None
+        for q in range(7):
+            order = np.lexsort((cand[q], -sc[q]))[:k]
+            np.testing.assert_array_equal(i[q].cpu().numpy(), cand[q][order])
+            np.testing.assert_array_equal(v[q].cpu().numpy(), sc[q][order])
+
+
 def test_select_degenerate_scores():
     from oracle import knn_oracle as K
     from ralf_amd.retrieval.knn import knn_select

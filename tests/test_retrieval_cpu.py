@@ -1,6 +1,8 @@
 """CPU: host side of the retrieval pipeline -- re-rankers vs known answers recorded from the reference,
 coarse saliency feature, table file format."""
 import pytest
+import os
+
 import numpy as np
 import torch
 
@@ -29,6 +31,31 @@ def test_coarse_saliency_and_table_format(tmp_path):
     assert path.endswith("pku_train_dreamsim_wo_head_table_between_dataset_indexes_top_k32.pt")   # retriever.py:149
     torch.save(table, path)
     assert load_cache_table(path, 16) == {7: list(range(16)), 9: list(range(32, 48))}           # retrieval_dataset_wrapper.py:32
+
+
+def test_load_cache_table_reads_reference_written_tables(tmp_path, monkeypatch):
+    """the reference saves collections.defaultdict(list) tables with string or int ids (models/retrieval/retriever.py:188-221);
+    a missing file falls back to PRECOMPUTED_WEIGHT_DIR/retrieval_indexes/<name> (helpers/retrieval_dataset_wrapper.py:21-27)"""
+    import collections
+
+    from ralf_amd.retrieval import retriever as R
+
+    table = collections.defaultdict(list)
+    for i in range(3):
+        table[f"id{i}"] = [int(j) for j in range(i, i + 32)]
+    path = table_path("cgl", "val", "dreamsim", 32, str(tmp_path))
+    torch.save(table, path)
+    got = load_cache_table(path, 16)
+    assert type(got) is dict and got == {f"id{i}": list(range(i, i + 16)) for i in range(3)}
+    # fallback directory
+    pre = tmp_path / "pre"
+    (pre / "retrieval_indexes").mkdir(parents=True)
+    name = os.path.basename(path)
+    torch.save(table, str(pre / "retrieval_indexes" / name))
+    monkeypatch.setattr(R, "PRECOMPUTED_WEIGHT_DIR", str(pre))
+    assert load_cache_table(str(tmp_path / "nowhere" / name), 2) == {f"id{i}": [i, i + 1] for i in range(3)}
+    with pytest.raises(ValueError, match="Cache not found"):
+        load_cache_table(str(tmp_path / "nowhere" / "other.pt"), 2)
 
 
 def test_coarse_saliency_batch_equals_per_image():
