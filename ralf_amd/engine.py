@@ -357,16 +357,40 @@ class TrainStep:
         assert self._static is not None, "static_batch() exists after the first graphed step"
         return self._static["inputs"], self._static["targets"]
 
+    def _snapshot(self):
+        """everything a step mutates besides the gradients: optimizer state, step counters, dropout seed, model buffers
+        (BatchNorm running statistics / num_batches_tracked)"""
+        o, rt = self.opt, self.model.rt
+        return {"P": o.P.clone(), "M": o.M.clone(), "V": o.V.clone(), "P16": None if o.P16 is None else o.P16.clone(),
+                "step_dev": o.step_dev.clone(), "step_count": o.step_count, "seed": rt.seed.clone(),
+                "buffers": [b.clone() for b in self.model.buffers()], "steps_done": self.steps_done}
+
+    def _restore(self, snap):
+        o, rt = self.opt, self.model.rt
+        o.P.copy_(snap["P"]); o.M.copy_(snap["M"]); o.V.copy_(snap["V"])
+        if o.P16 is not None:
+            o.P16.copy_(snap["P16"])
+        o.step_dev.copy_(snap["step_dev"])
+        o.step_count = snap["step_count"]
+        rt.seed.copy_(snap["seed"])
+        for b, v in zip(self.model.buffers(), snap["buffers"]):
+            b.copy_(v)
+        self.steps_done = snap["steps_done"]
+        rt.weights_changed()
+
     def _capture(self, inputs, targets):
         self._static = _clone_tree({"inputs": inputs, "targets": targets})
         si, st = self._static["inputs"], self._static["targets"]
+        # the warm-up steps (allocator, lazy inits, LDS attributes) must not train: the state they touch is put back, so the
+        # first graphed call is exactly ONE optimisation step, like use_graph=False and like the reference's loop
+        snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # warm-up on a side stream (allocator, lazy inits, LDS attributes)
+        with torch.cuda.stream(side):
             for _ in range(2):
                 self._eager(si, st)
-                self.steps_done += 1
         torch.cuda.current_stream().wait_stream(side)
+        self._restore(snap)
         torch.cuda.synchronize()
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         gm = torch.cuda.CUDAGraph() if self.staged else None
@@ -378,6 +402,9 @@ class TrainStep:
         with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode=_CAPTURE_MODE):
             self._update()
         self._graphs = (ga, gm, gb)
+        # (capturing ran the host side of the step once more without executing kernels: put the host counters back too)
+        self.opt.step_count = snap["step_count"]
+        self.model.rt._wtoken += 1
 
 
 class GraphedDecode:

@@ -100,6 +100,53 @@ def test_ranged_exchange_equals_whole_buffer_exchange_world2():
     assert all(ok for _, ok, _ in res), res
 
 
+def _worker_exchange(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ralf_amd.engine import GradExchange, complement_ranges
+
+    def cp(src, dst):      # stands in for the HIP cast kernel (ralf_copy2d) on this CPU-only box
+        dst.copy_(src)
+
+    torch.manual_seed(11 + rank)
+    local = torch.randn(5000)
+    gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    late = [(0, 640), (1920, 2048)]
+    early = complement_ranges(late, local.numel())
+    ok = True
+    for wire in ("fp32", "bf16"):
+        flat = local / world                                   # the backward was seeded with 1/world
+        ex = GradExchange(flat, world, None, wire, pack=cp, unpack=cp)
+        token = ex.start(early, True)                          # TrainStep._exchange_around: early ranges overlap stage 2 ...
+        ex.finish(token)
+        ex.run(late)                                           # ... the rest afterwards
+        if wire == "fp32":
+            want = torch.stack(gathered).mean(0)
+            ok &= torch.allclose(flat, want, atol=1e-6)
+        else:   # each rank's contribution is rounded to bf16, the sum is carried in bf16
+            want = sum((g / world).bfloat16() for g in gathered).float()
+            ok &= torch.allclose(flat, want, atol=0, rtol=2 ** -7)
+            ok &= (flat - torch.stack(gathered).mean(0)).abs().max().item() < 2e-2
+            ok &= ex.bytes_on_wire(early + late) == 2 * local.numel()
+    q.put((rank, bool(ok), 0.0))
+    dist.destroy_process_group()
+
+
+def test_grad_exchange_fp32_and_bf16_wire_world2():
+    """engine.GradExchange over two gloo ranks: ranged start/finish + run tile the buffer; the bf16 wire halves the bytes"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_exchange, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+
+
 def _numpy_scan(X):
     """exact flat-IP top-k with the scan's tie order (score desc, index asc); pads with (-inf, -1) when k > rows"""
     import numpy as np

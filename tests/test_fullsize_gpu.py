@@ -1,0 +1,146 @@
+"""GPU: the configurations of BASELINE.json at their FULL sizes, through size-independent properties (no oracle can run
+B = 64 at 256x256 in seconds): bf16 against fp32 on the whole model incl. the ResNet, graph replay against eager execution,
+B = 256 decode against the rows recorded from the reference at B = 3, and the 32-element layouts of the north star."""
+import pytest
+import torch
+
+import bench
+from test_model_cpu import build
+from test_model_gpu import FeatStandIn, load_det, to_dev
+from ralf_amd.synthetic import make_batch, to_device
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def batch_on_device(model, B, N, seed=1):
+    inputs, targets = model.preprocess(make_batch(B, N, seed=seed))
+    inputs, targets = to_device(inputs, DEV), to_device(targets, DEV)
+    inputs["retrieved"] = {k: v for k, v in inputs["retrieved"].items() if k != "image"}
+    return inputs, targets
+
+
+def cos(a, b):
+    return torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
+
+
+def test_b64_train_step_bf16_against_fp32_whole_model():
+    """BASELINE config 2 at its real size (B = 64, 256x256, ResNet-50/FPN in front): the bf16 throughput mode against the fp32
+    parity mode on identical weights and inputs -- loss, logits and gradients of every part of the model, BatchNorm on batch
+    statistics, dropout off (the two modes draw different masks per element type only through rounding, but a comparison
+    needs none)."""
+    m32 = bench.build_model(torch.device(DEV), 10, "float32")
+    m16 = bench.build_model(torch.device(DEV), 10, "bfloat16")
+    m16.load_state_dict(m32.state_dict())
+    for m in (m32, m16):
+        m.rt.drop_p = lambda p: 0.0          # train mode (BatchNorm batch statistics) without dropout
+    inputs, targets = batch_on_device(m32, 64, 10)
+    out = {}
+    for name, m in (("f32", m32), ("bf16", m16)):
+        o, l = m.train_loss(inputs, targets)
+        l["nll_loss"].backward()
+        out[name] = (o["logits"].float(), l["nll_loss"].item(), {k: p.grad.float() for k, p in m.named_parameters() if p.grad is not None})
+    (lg32, l32, g32), (lg16, l16, g16) = out["f32"], out["bf16"]
+    assert abs(l32 - l16) < 3e-2 * abs(l32), (l32, l16)
+    assert cos(lg32, lg16) > 0.999
+    keys = ["decoder.head.1.weight", "decoder.transformer.layers.0.multihead_attn.in_proj_weight", "transformer_encoder.layers.0.linear1.weight",
+            "transformer_encoder.layers.5.self_attn.in_proj_weight", "head.net.1.weight", "attn.to_kv.weight",
+            "encoder.extractor.proj.weight", "encoder.extractor.fpn_conv33.weight", "encoder.extractor.body.layer4.2.conv2.weight",
+            "encoder.extractor.body.layer3.0.conv1.weight", "encoder.extractor.body.layer2.0.conv2.weight", "encoder.extractor.body.conv1.weight"]
+    report = {k: (cos(g32[k], g16[k]), (g16[k].norm() / g32[k].norm()).item()) for k in keys}
+    for k, (c, r) in report.items():
+        body = ".body." in k
+        assert c > (0.90 if body else 0.98) and abs(r - 1) < (0.15 if body else 0.05), report
+    assert set(g16) == set(g32)
+
+
+def test_b64_graph_replay_equals_eager_bf16_with_dropout():
+    """B = 64 bf16 train step, dropout ON: the captured graphs and the eager step draw the same counter-based masks (same
+    device seed sequence), so losses agree step by step and the weights stay together"""
+    from ralf_amd.engine import TrainStep
+
+    m1 = bench.build_model(torch.device(DEV), 10, "bfloat16")
+    m2 = bench.build_model(torch.device(DEV), 10, "bfloat16")
+    m2.load_state_dict(m1.state_dict())
+    inputs, targets = batch_on_device(m1, 64, 10)
+    eager, graphed = TrainStep(m1, use_graph=False), TrainStep(m2, use_graph=True)
+    le = [eager(inputs, targets).item() for _ in range(4)]
+    lg = [graphed(inputs, targets).item() for _ in range(4)]
+    assert all(abs(a - b) < 2e-2 for a, b in zip(le, lg)), (le, lg)
+    assert le[-1] < le[0]
+    torch.cuda.synchronize()
+    assert (eager.opt.P - graphed.opt.P).abs().max().item() <= 9e-4      # 4 steps of at most lr each where a ~0 gradient flips sign
+    bn = "encoder.extractor.body.layer3.0.bn1"
+    a, b = dict(m1.named_buffers()), dict(m2.named_buffers())
+    torch.testing.assert_close(a[bn + ".running_var"], b[bn + ".running_var"], rtol=2e-2, atol=1e-4)
+    assert int(a[bn + ".num_batches_tracked"]) == int(b[bn + ".num_batches_tracked"]) == 4
+
+
+@pytest.mark.parametrize("task", ["c", "cwh"])
+def test_b256_decode_rows_equal_reference_rows(golden, task):
+    """BASELINE config 5 at its real batch (B = 256): the 3 samples recorded from the reference, tiled to 256 rows, decode to the
+    reference's tokens in every row (KV-cached, graph-captured loop) -- batch-size independence of the whole decode path"""
+    from ralf_amd.engine import GraphedDecode
+    from ralf_amd.helpers.task import RetrievalAugmentedConditionalInputsForDiscreteLayout as Cond
+
+    r = golden("sample.npz").sub(task)
+    model = load_det(build(task=task), "ralf_state_shapes.json").eval()
+    B, reps = 256, 86
+    tile = lambda t: t.repeat((reps,) + (1,) * (t.dim() - 1))[:B]   # noqa: E731
+    model.encoder = FeatStandIn(tile(r["feat"]).cuda())
+    cond = Cond(image=torch.zeros(B, 4, 8, 8), task=task, seq=tile(r["cond_seq"]), mask=None, retrieved={k: tile(v) for k, v in r["retrieved"].items()})
+    model._create_encoder_inputs = lambda c: ({"image": c.image, "retrieved": c.retrieved, "seq_layout_const": tile(r["seq_layout_const"]),
+                                               "seq_layout_const_pad_mask": tile(r["seq_layout_const_pad_mask"])}, None)
+    graphed = GraphedDecode(model, task, {"name": "deterministic"})
+    for dec in (None, graphed, graphed):
+        out = model.sample(cond=cond, sampling_cfg={"name": "deterministic"}, cond_type=task, return_violation=False, use_kv_cache=True, decoder=dec)
+        for k in ("label", "mask", "center_x", "center_y", "width", "height"):
+            assert torch.equal(out[k], tile(r["result"][k])), k
+    # throughput sampling mode at this batch: every row is a valid layout token sequence (vocabulary mask + restriction hold)
+    out = model.sample(cond=cond, sampling_cfg={"name": "top_k", "top_k": 5, "temperature": 1.0}, cond_type=task, return_violation=False)
+    assert out["label"].shape == (B, 10) and torch.equal(out["label"] * out["mask"], tile(r["result"]["label"]) * tile(r["result"]["mask"]))
+
+
+def test_n32_layouts_against_the_oracle_and_full_batch():
+    """the north star's 32-element layouts (S = 160): fp32 logits against the (pinned) oracle at B = 2, then a B = 64 bf16 train
+    step and a KV-cached decode equal to the full-prefix recompute"""
+    import json
+    import os
+
+    from conftest import GOLDEN
+    from oracle import ralf_oracle as O
+    from oracle.detweights import det_state_dict, resnet50_fpn_shapes
+    from ralf_amd.engine import TrainStep
+    from ralf_amd.helpers.task import get_condition
+
+    N = 32
+    with open(os.path.join(GOLDEN, "ralf_state_shapes.json")) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f)["shapes"].items()}
+    shapes.update(resnet50_fpn_shapes())
+    sd = det_state_dict(shapes)
+    model = build(task="uncond", N=N)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    inputs, targets = model.preprocess(make_batch(2, N, H=64, W=64, seed=4))
+    assert inputs["seq"].shape == (2, 5 * N)
+    with torch.no_grad():
+        ref = O.ralf_forward(sd, inputs)
+        got = model(to_device(inputs, DEV))["logits"]
+    torch.testing.assert_close(got.cpu(), ref, atol=5e-4, rtol=1e-4)
+    # B = 64 train step at S = 160
+    m = bench.build_model(torch.device(DEV), N, "bfloat16")
+    bi, bt = batch_on_device(m, 64, N)
+    step = TrainStep(m, use_graph=True)
+    losses = [step(bi, bt).item() for _ in range(3)]
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
+    # decode: KV cache == full-prefix recompute (the reference's loop) at 160 tokens, fp32 (argmax ties aside, bit-equal tokens)
+    mc = build(task="c", N=N)
+    mc.load_state_dict(sd, strict=True)
+    mc = mc.cuda().eval()
+    cond, _ = get_condition(make_batch(8, N, H=64, W=64, seed=5), "c", mc.tokenizer)
+    cond.retrieved = {k: v for k, v in cond.retrieved.items() if k != "image"}
+    a = mc.sample(cond=cond, sampling_cfg={"name": "deterministic"}, cond_type="c", return_violation=False, use_kv_cache=True)
+    b = mc.sample(cond=cond, sampling_cfg={"name": "deterministic"}, cond_type="c", return_violation=False, use_kv_cache=False)
+    assert a["label"].shape == (8, N)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
