@@ -72,78 +72,108 @@ class RetrievalAugmentedConditionalInputsForDiscreteLayout(ConditionalInputsForD
         return self
 
 
+# ---- conditions -------------------------------------------------------------------------------------------------
+# A condition is the tokenised ground truth with the tokens the model must generate blanked out.  Every task below is a
+# COLUMN rule on the [B, S] token grid (column 0 = BOS when the tokenizer has one, then C tokens per element in
+# tokenizer.var_order), so the whole batch is handled with one boolean column vector -- no per-sample loop.
+
+def _column_roles(tokenizer, S: int) -> torch.Tensor:
+    """role of every sequence column: index into tokenizer.var_order, -1 for the BOS column"""
+    lead = 1 if "bos" in tokenizer.special_tokens else 0
+    roles = (torch.arange(S) - lead) % tokenizer.N_var_per_element
+    roles[:lead] = -1
+    return roles
+
+
+def _given_columns(tokenizer, S: int, names) -> torch.Tensor:
+    """bool [S]: BOS plus the columns carrying one of the attributes `names`"""
+    roles = _column_roles(tokenizer, S)
+    wanted = torch.tensor([tokenizer.var_order.index(n) for n in names])
+    return (roles == -1) | torch.isin(roles, wanted)
+
+
+def _blank_id(tokenizer) -> int:
+    return tokenizer.name_to_id("mask") if "mask" in tokenizer.special_tokens else -1
+
+
+def _cond_unconditional(enc, batch, tokenizer):
+    return {"seq": None, "mask": None}
+
+
+def _cond_ground_truth(enc, batch, tokenizer):
+    return enc
+
+
+def _cond_first_element(enc, batch, tokenizer):
+    """`partial`: only the first element is known.  Its tokens already sit at the head of the sequence (right behind BOS), so
+    "move the known tokens to the front" is the identity on the first `lead + C` columns, for every row alike."""
+    S = enc["seq"].shape[1]
+    lead = 1 if "bos" in tokenizer.special_tokens else 0
+    known = torch.arange(S) < lead + tokenizer.N_var_per_element
+    seq = torch.where(known, enc["seq"], torch.full_like(enc["seq"], _blank_id(tokenizer)))
+    return {"seq": seq, "mask": known.expand_as(enc["mask"]).clone()}
+
+
+def _cond_attributes(names, with_relations=False):
+    def build(enc, batch, tokenizer):
+        out = dict(enc)
+        if with_relations:   # consumes Python's `random` exactly once per call, before anything else (like the reference)
+            from .relationships import compute_relation
+            out.update(compute_relation(batch, edge_ratio=EDGE_RATIO))
+        given = _given_columns(tokenizer, enc["seq"].shape[1], names)
+        real = enc["mask"]                                   # tokens of existing elements (and BOS / EOS)
+        seq = torch.where(given, enc["seq"], torch.full_like(enc["seq"], _blank_id(tokenizer)))
+        out["seq"] = torch.where(real, seq, torch.full_like(seq, tokenizer.name_to_id("pad")))   # the element count is known
+        out["mask"] = (real & given) | ~real
+        return out
+    return build
+
+
+def _cond_noisy_geometry(enc, batch, tokenizer):
+    """`refinement`: the geometry is observed through N(0, 0.01) noise (one torch.normal per geometry key, in GEO_KEYS order:
+    the reference's random stream); the perturbed layout also REPLACES the batch's geometry, as in the reference"""
+    observed = {"label": batch["label"], "mask": batch["mask"]}
+    present = batch["mask"]
+    for key in GEO_KEYS:
+        jitter = torch.normal(0, REFINEMENT_NOISE_STD, size=batch[key].size())
+        observed[key] = torch.clamp(batch[key] + jitter, min=0.0, max=1.0) * present
+        batch[key] = observed[key].clone()
+    return {"seq": tokenizer.encode(observed)["seq"], "mask": enc["mask"], "seq_observed": observed}
+
+
+_CONDITION_BUILDERS = {
+    None: _cond_unconditional, "none": _cond_unconditional, "uncond": _cond_unconditional,
+    "gt": _cond_ground_truth,
+    "partial": _cond_first_element,
+    "c": _cond_attributes(VARS["c"]),
+    "cwh": _cond_attributes(VARS["cwh"]),
+    "relation": _cond_attributes(VARS["relation"], with_relations=True),
+    "refinement": _cond_noisy_geometry,
+}
+
+
+def _sample_ids(batch):
+    ids = batch.get("id")
+    try:
+        return torch.tensor([int(i) for i in ids], dtype=torch.long)
+    except (TypeError, ValueError):
+        return ids
+
+
 def get_condition(batch: dict, cond_type: Optional[str] = None, tokenizer=None):
+    """(condition container, batch) for `cond_type` -- same contract as image2layout/train/helpers/task.py:45-183: `seq` holds
+    the known tokens with the blank id (-1 / [MASK]) where the model must generate, `mask` is True on known and special
+    tokens.  Without a tokenizer the batch passes through untouched (GAN-style generators)."""
     assert cond_type in COND_TYPES
     if tokenizer is None:
         return batch, batch
     image = batch["image"] if batch["image"].size(1) == 4 else torch.cat([batch["image"], batch["saliency"]], dim=1)
-    specials = tokenizer.special_tokens
-    pad_id = tokenizer.name_to_id("pad")
-    mask_id = tokenizer.name_to_id("mask") if "mask" in specials else -1
-    cond = tokenizer.encode(batch)
-    B, S = cond["seq"].shape
-    C = tokenizer.N_var_per_element
-    has_bos = "bos" in specials
-
-    if cond_type in (None, "none", "uncond"):
-        cond = {"seq": None, "mask": None}
-    elif cond_type == "partial":
-        keep = torch.zeros_like(batch["mask"])
-        keep[:, 0] = True  # only the first element is given
-        keep = keep.unsqueeze(-1).expand(-1, -1, C).reshape(B, -1)
-        if has_bos:
-            keep = torch.cat([torch.ones(B, 1, dtype=torch.bool), keep], dim=-1)
-            new_seq = torch.full_like(cond["seq"], mask_id)
-            new_mask = torch.zeros_like(cond["mask"])
-            for i in range(B):
-                n = int(keep[i].sum())
-                new_seq[i, :n] = cond["seq"][i][keep[i]]
-                new_mask[i, :n] = True
-            cond["seq"], cond["mask"] = new_seq, new_mask
-        else:
-            cond["seq"][~keep] = mask_id
-            cond["mask"] = keep
-    elif cond_type in ("c", "cwh", "relation"):
-        if cond_type == "relation":
-            from .relationships import compute_relation
-            cond.update(compute_relation(batch, edge_ratio=EDGE_RATIO))
-        if has_bos:
-            attr = (torch.arange(S).view(1, S) - 1) % C
-            attr[:, 0] = -1
-        else:
-            attr = torch.arange(S).view(1, S) % C
-        keep = torch.zeros(B, S, dtype=torch.bool)
-        if has_bos:
-            keep[:, 0] = True
-        for name in VARS[cond_type]:
-            keep |= attr == tokenizer.var_order.index(name)
-        cond["seq"][~keep] = mask_id
-        cond["seq"][~cond["mask"]] = pad_id
-        cond["mask"] = (cond["mask"] & keep) | ~cond["mask"]
-    elif cond_type == "gt":
-        pass
-    elif cond_type == "refinement":
-        noisy = {"label": batch["label"], "mask": batch["mask"]}
-        for key in GEO_KEYS:
-            noise = torch.normal(0, REFINEMENT_NOISE_STD, size=batch[key].size())
-            noisy[key] = torch.clamp(batch[key] + noise, min=0.0, max=1.0)
-            noisy[key][~batch["mask"]] = 0.0
-            batch[key] = noisy[key].clone()
-        cond = {"seq": tokenizer.encode(noisy)["seq"], "mask": cond["mask"], "seq_observed": noisy}
-    else:
-        raise NotImplementedError(cond_type)
-
-    try:
-        cond["id"] = torch.tensor([int(i) for i in batch["id"]], dtype=torch.long)
-    except Exception:
-        cond["id"] = batch.get("id")
-
+    fields = _CONDITION_BUILDERS[cond_type](tokenizer.encode(batch), batch, tokenizer)
+    fields = dict(fields, id=_sample_ids(batch))
+    container = ConditionalInputsForDiscreteLayout
     if "retrieved" in batch:
-        if isinstance(batch["retrieved"], list):
-            assert len(batch["retrieved"]) == 1
-            batch["retrieved"] = batch["retrieved"][0]
-        cond["retrieved"] = batch["retrieved"]
-        cls = RetrievalAugmentedConditionalInputsForDiscreteLayout
-    else:
-        cls = ConditionalInputsForDiscreteLayout
-    return cls(image=image, task=cond_type, **cond), batch
+        if isinstance(batch["retrieved"], list):   # collate_fn wraps the exemplars in a one-element list
+            (batch["retrieved"],) = batch["retrieved"]
+        fields["retrieved"] = batch["retrieved"]
+        container = RetrievalAugmentedConditionalInputsForDiscreteLayout
+    return container(image=image, task=cond_type, **fields), batch
