@@ -116,6 +116,15 @@ typedef struct RalfGemmDesc {
      * come out of the convolution's own epilogue (ralf_bn_stats_from_partials) instead of a pass over the tensor.
      * Needs a plain epilogue (alpha 1, no bias/act/res/aux/dropout/accumulate), splitk 1, one batch, N % 64 == 0. */
     float* colstats;
+    /* sBias0: element stride of `bias` per z0 batch entry (0 = one bias vector shared by the batch).
+     * kseg / sBk (0 = off): the K range of B is a chain of segments of kseg rows (a multiple of the k-tile: 64 bf16 / 32 fp32),
+     * segment s starting sBk elements beyond where a contiguous B would put it -- several weight matrices that live apart in
+     * one flat parameter buffer act as ONE stacked operand (cross-attention K/V projections of all decoder layers over the
+     * same memory: one data-gradient product instead of a product + accumulate per layer).  Needs the aligned interior path
+     * (K a multiple of the k-tile, 16-byte aligned operands) and splitk == 1. */
+    int64_t sBias0;
+    int64_t sBk;
+    int kseg;
 } RalfGemmDesc;
 size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d);
 int ralf_gemm(const RalfGemmDesc* d, void* workspace, size_t workspace_bytes, void* stream);

@@ -35,6 +35,7 @@ class RalfGemmDesc(ctypes.Structure):
                               "act", "aux_mode", "out_f32", "accumulate", "splitk")]
         + [("alpha", f32), ("aux_scale", f32), ("g", RalfConvGeom)]
         + [("seed", vp), ("call_id", ctypes.c_uint64), ("drop_p", f32), ("atomic_out", i32), ("colstats", vp)]
+        + [("sBias0", i64), ("sBk", i64), ("kseg", i32)]
     )
 
 

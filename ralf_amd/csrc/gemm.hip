@@ -74,6 +74,11 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
         P.fast = (!d.gather && al && rows_ok && d.K % BK == 0) ? 1 : 0;
         P.tapuni = (d.gather == 1 && d.g.SC % BK == 0 && P.kchunk % BK == 0) ? 1 : 0;
     }
+    if (d.kseg) {
+        RALF_REQUIRE(P.fast && d.dtype == RALF_BF16 && d.splitk == 1 && d.kseg % BK == 0 && d.K % d.kseg == 0 && (d.sBk * 2) % 16 == 0,
+                     "gemm: a segmented B (kseg=%d) needs the bf16 interior path, no split-K, kseg %% %d == 0 and K %% kseg == 0", d.kseg, BK);
+    }
+    RALF_REQUIRE(d.sBias0 == 0 || (d.bias && d.sBias0 % 4 == 0), "gemm: sBias0 needs a bias and a multiple of 4");
     P.partial = nullptr;
     {   // 4-wide epilogue accesses need 4-element-aligned leading dims / batch strides and 16-byte aligned bases
         const int es = (d.dtype == RALF_F32 || d.out_f32) ? 4 : 2;   // element size of C / C2

@@ -128,7 +128,7 @@ template <> __device__ __forceinline__ void stf<bf16>(void* p, int64_t i, float 
 template <typename T, int EPI>
 __device__ __forceinline__ void epilogue_store(const RalfGemmDesc& d, int z0, int z1, int m, int n, float v) {
     v *= d.alpha;
-    if (d.bias) v += d.bias[n];
+    if (d.bias) v += d.bias[z0 * d.sBias0 + n];
     const int64_t coff = z0 * d.sC0 + z1 * d.sC1 + (int64_t)m * d.ldc + n;
     if (EPI >= 2 && d.C2) {  // pre-activation copy (needed by the activation gradient)
         if (d.out_f32) stf<float>(d.C2, coff, v); else stf<T>(d.C2, coff, v);
@@ -207,7 +207,7 @@ __device__ __forceinline__ void epilogue_storev(const RalfGemmDesc& d, int z0, i
     for (int q = 0; q < W; ++q) v[q] *= d.alpha;
     if (d.bias) {
         float b[W];
-        VIO<float, W>::ld(d.bias, n, b);
+        VIO<float, W>::ld(d.bias, z0 * d.sBias0 + n, b);
 #pragma unroll
         for (int q = 0; q < W; ++q) v[q] += b[q];
     }
@@ -476,6 +476,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_kernel(const KP
                 const int v = tid + NT * i;
                 if (BKC) pb[i] = Bp + (int64_t)min(n0 + v / KV, d.N - 1) * d.ldb + kbeg + (v % KV) * VEC;
                 else pb[i] = Bp + (int64_t)(kbeg + v / RVB) * d.ldb + min(n0 + (v % RVB) * VEC, d.N - VEC);
+                if (d.kseg) pb[i] += (int64_t)(kbeg / d.kseg) * d.sBk;   // segmented K range of B (kbeg is a multiple of the k-tile)
             }
         }
         if (AK && !fast) {
@@ -493,6 +494,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_kernel(const KP
             for (int i = 0; i < NVA; ++i) { ra[i] = *reinterpret_cast<const u32x4*>(pa[i]); pa[i] += stepA; }
 #pragma unroll
             for (int i = 0; i < NVB; ++i) { rb[i] = *reinterpret_cast<const u32x4*>(pb[i]); pb[i] += stepB; }
+            if (d.kseg && (k0 + BK) % d.kseg == 0) {   // (wave-uniform) the next k-tile opens a new segment of B
+#pragma unroll
+                for (int i = 0; i < NVB; ++i) pb[i] += d.sBk;
+            }
         } else {
         int tap_kh = 0, tap_kw = 0, tap_c0 = 0;
         if (GATHER == 1 && P.tapuni) {   // k0 is wave-uniform: scalar arithmetic

@@ -2,16 +2,20 @@
 //
 // Replaces faiss.IndexFlat(d, METRIC_INNER_PRODUCT).search as reached from
 // image2layout/train/models/retrieval/retriever.py:200-202 (one query per call in the reference;
-// batched here).  ralf_knn_topk_ip (k <= 64) runs the scan with a FUSED per-workgroup selection: every workgroup reduces
-// its [queries x 128..256 rows] score tile to k (score, index) pairs per query in LDS, so the [nq, N] score matrix never
-// reaches HBM and one merge launch finishes the call.  The two phases separately (larger k, tests, profiling):
+// batched here).  Two phases:
 //   1. knn_scores_kernel : S[q][n] = <Q[q], X[n]> on the fp32 matrix cores
 //      (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32).  A chain of K-steps on one accumulator is
 //      bit-for-bit the ascending-d fmaf chain of oracle/knn_oracle.c, so scores are bit-exact.
 //      The index is streamed from HBM exactly once per query tile; X/Q k-tiles are staged
 //      global -> registers -> LDS (rotated rows: conflict-free ds_read_b32 fragment reads).
-//   2. knn_select_kernel : exact k-th-largest by bisection over the 32 order-preserving key bits
-//      (+13 position bits for ties), winners ranked by counting -> (score desc, index asc).
+//   2. selection.  k <= 64 and N <= 65536 (every shipped index): knn_select_wide_kernel, ONE launch of one 1024-thread
+//      workgroup per query over the whole score row -- a lower bound of the k-th best from two reductions (minimum over >= k
+//      disjoint thread groups of the group maxima), the few dozen survivors ranked exactly by counting.  Otherwise
+//      knn_select_kernel per 8192-score segment (exact k-th-largest by bisection over the 32 order-preserving key bits,
+//      +13 position bits for ties) and merge rounds.  Both give (score desc, index asc), bit-identical.
+//    (Measured and dropped: the selection fused into the scan's epilogue -- per-workgroup top-k of the [queries x 128..256 rows]
+//     tile in LDS, no score matrix.  A wave-level exact top-16 of 128 costs thousands of dependent scalar/vector round trips
+//     per query: the scan got 14-23 us slower at nq = 16-32 and 39 % slower at nq = 1024, more than the selection launches cost.)
 #include "common.h"
 
 namespace {
@@ -51,7 +55,6 @@ __device__ __forceinline__ float key2f(uint32_t k) {
     return (k == 0u) ? -__builtin_inff() : __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 __device__ __forceinline__ bool better(uint32_t ka, int pa, uint32_t kb, int pb) { return ka > kb || (ka == kb && pa < pb); }
-constexpr int KFUSED = 64;      // largest k of the fused scan + selection
 
 // A operand = query tile (M dim), B operand = index-row tile (N dim): for a fixed accumulator
 // register the 32 (16) lanes of a half-wave hold CONSECUTIVE index rows of one query, so the
@@ -59,13 +62,10 @@ constexpr int KFUSED = 64;      // largest k of the fused scan + selection
 // GATHER (exact re-scoring of per-query candidate lists, two-stage search): workgroup <-> (query q, chunk of its `pool`
 // candidates); the index rows come from cand[q][*], the query tile holds the single query q, S is [nq][pool].  The
 // accumulation code is the one of the exhaustive scan, so a re-scored pair is bit-identical to its exhaustive score.
-// TOPK (fused selection, k <= KFUSED): instead of the score tile the workgroup writes, per query, the k best (score, index)
-// pairs of its RW rows, sorted by (score desc, index asc) and padded with (-inf, -1):  ts / ti [q][row chunk][k].
-template <int MF, int TQ, int TR, bool GATHER = false, bool TOPK = false>
+template <int MF, int TQ, int TR, bool GATHER = false>
 __global__ __launch_bounds__(256) void knn_scores_kernel(const float* __restrict__ X, int64_t N, int D,
                                                           const float* __restrict__ Q, int nq, float* __restrict__ S,
-                                                          int n_qtiles, int nwg, const int64_t* __restrict__ cand = nullptr, int pool = 0,
-                                                          int k = 0, float* __restrict__ ts = nullptr, int64_t* __restrict__ ti = nullptr) {
+                                                          int n_qtiles, int nwg, const int64_t* __restrict__ cand = nullptr, int pool = 0) {
     using F = Frag<MF>;
     constexpr int RW = 4 * TR * MF, QW = TQ * MF, BK = 32, KS = F::KS, ROT = 32 / MF;
     constexpr int XV = RW * BK / 4 / 256;              // float4 per thread per k-tile (index rows)
@@ -162,70 +162,6 @@ __global__ __launch_bounds__(256) void knn_scores_kernel(const float* __restrict
         }
     }
 
-    if constexpr (TOPK) {
-        // ---- fused selection: MF queries x RW rows at a time through LDS (the operand tiles are dead: the k-loop ended with a barrier) ----
-        constexpr int E = RW / 64;                      // scores per lane: position p = e*64 + lane <-> index row0 + p
-        float* sl = lds;                                // [MF][RW]
-        uint32_t* wk = reinterpret_cast<uint32_t*>(lds + MF * RW) + wave * 128;   // this wave's winners: keys [64], positions [64]
-        int* wp = reinterpret_cast<int*>(wk) + 64;
-        const int nrc = nwg / n_qtiles;                 // row chunks = candidate lists per query
-        static_assert(MF * RW + 4 * 128 <= (RW + QW) * BK, "selection staging exceeds the operand tiles");
-#pragma unroll
-        for (int i = 0; i < TQ; ++i) {
-            if (i) __syncthreads();
-#pragma unroll
-            for (int j = 0; j < TR; ++j) {
-                const int p = (wave * TR + j) * MF + lr;
-#pragma unroll
-                for (int r = 0; r < F::NREG; ++r) sl[F::crow(r, lane) * RW + p] = acc[i][j][r];
-            }
-            __syncthreads();
-            for (int ql = wave; ql < MF; ql += 4) {     // one wave per query
-                const int qi = q0 + i * MF + ql;
-                if (qi >= nq) break;                    // (wave-uniform)
-                uint32_t key[E];
-#pragma unroll
-                for (int e = 0; e < E; ++e) key[e] = (row0 + e * 64 + lane < N) ? f2key(sl[ql * RW + e * 64 + lane]) : 0u;
-                uint32_t T = 0;                         // largest T with |{key >= T}| >= k (0: fewer than k rows)
-                for (int bit = 31; bit >= 0; --bit) {
-                    const uint32_t t = T | (1u << bit);
-                    int c = 0;
-#pragma unroll
-                    for (int e = 0; e < E; ++e) c += __popcll(__ballot(key[e] >= t));
-                    if (c >= k) T = t;
-                }
-                int cgt = 0;
-#pragma unroll
-                for (int e = 0; e < E; ++e) cgt += __popcll(__ballot(key[e] > T));
-                const int need = k - cgt;               // entries equal to T to keep, lowest positions first
-                const unsigned long long below = (1ull << lane) - 1ull;
-                int nwin = 0, eqseen = 0;
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const unsigned long long eqm = __ballot(key[e] == T && T != 0u);
-                    const bool win = key[e] > T || (key[e] == T && T != 0u && eqseen + __popcll(eqm & below) < need);
-                    const unsigned long long wm = __ballot(win);
-                    if (win) { const int s = nwin + __popcll(wm & below); wk[s] = key[e]; wp[s] = e * 64 + lane; }
-                    nwin += __popcll(wm);
-                    eqseen += __popcll(eqm);
-                }
-                float* so = ts + ((int64_t)qi * nrc + rc) * k;
-                int64_t* io = ti + ((int64_t)qi * nrc + rc) * k;
-                __builtin_amdgcn_wave_barrier();        // the winners were written by other lanes of THIS wave (LDS ops of a wave complete in order)
-                if (lane < nwin) {
-                    const uint32_t mk = wk[lane];
-                    const int mp = wp[lane];
-                    int rank = 0;
-                    for (int j = 0; j < nwin; ++j) rank += better(wk[j], wp[j], mk, mp);
-                    so[rank] = key2f(mk);
-                    io[rank] = row0 + mp;
-                } else if (lane < k) {
-                    so[lane] = -__builtin_inff();
-                    io[lane] = -1;
-                }
-            }
-        }
-    } else {
 #pragma unroll
     for (int i = 0; i < TQ; ++i)
 #pragma unroll
@@ -237,7 +173,6 @@ __global__ __launch_bounds__(256) void knn_scores_kernel(const float* __restrict
                 if (qi < nq_hi && n < nrows) S[(int64_t)qi * nrows + n] = acc[i][j][r];
             }
         }
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -453,6 +388,135 @@ __global__ __launch_bounds__(256) void knn_rownorms_kernel(const float* __restri
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// single-launch selection: one 1024-thread workgroup per query over a whole score row (cnt <= 1024 * EPT)
+// ------------------------------------------------------------------------------------------
+constexpr int WIDE_T = 1024;
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+}
+
+// Bound: threads are dealt into G >= k disjoint groups (tid & (G-1), G a power of two <= 64); every non-empty group's maximum
+// is a distinct entry, so the minimum L over the groups is <= the k-th largest entry: only entries >= L can be in the top-k.
+// (An empty group makes L = 0 = "keep everything valid".)  On non-degenerate data a few dozen entries survive; more than KMAX
+// survivors (mass ties) take the exact bisection over all keys, like knn_select_kernel.
+__device__ __forceinline__ int block_sum_wide(int v, int* red, int& slot) {   // 16 waves; `slot` alternates: one barrier per call
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[slot * 16 + (threadIdx.x >> 6)] = v;
+    __syncthreads();
+    int s = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[slot * 16 + w];
+    slot ^= 1;
+    return s;
+}
+
+template <int EPT>
+__global__ __launch_bounds__(WIDE_T) void knn_select_wide_kernel(const float* __restrict__ S, int64_t stride, int cnt, int k, int G,
+                                                                 float* __restrict__ os, int64_t* __restrict__ oi) {
+    __shared__ uint32_t gmax[64];
+    __shared__ uint32_t wkey[KMAX];
+    __shared__ int wpos[KMAX];
+    __shared__ int wcnt;
+    __shared__ int red[32];
+    const int tid = threadIdx.x, lane = tid & 63, q = blockIdx.x;
+    const float* src = S + (int64_t)q * stride;
+    uint32_t key[EPT];
+    uint32_t mx = 0;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int p = tid + WIDE_T * i;
+        key[i] = (p < cnt) ? f2key(src[p]) : 0u;
+        mx = key[i] > mx ? key[i] : mx;
+    }
+    if (tid < 64) gmax[tid] = 0u;
+    if (tid == 0) wcnt = 0;
+    __syncthreads();
+    atomicMax(&gmax[tid & (G - 1)], mx);
+    __syncthreads();
+    const uint32_t L = wave_min_u32(lane < G ? gmax[lane] : 0xffffffffu);   // (every wave computes it: no second barrier)
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        if (key[i] >= L && key[i] != 0u) {
+            const int s = atomicAdd(&wcnt, 1);
+            if (s < KMAX) { wkey[s] = key[i]; wpos[s] = tid + WIDE_T * i; }
+        }
+    }
+    __syncthreads();
+    int nw = wcnt;
+    if (nw > KMAX) {
+        // ---- exact bisection over all keys: largest T with |{key >= T}| >= k; ties at T resolved by position ----
+        __syncthreads();
+        if (tid == 0) wcnt = 0;
+        int slot = 0;
+        uint32_t T = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t t = T | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) c += (key[i] >= t);
+            if (block_sum_wide(c, red, slot) >= k) T = t;
+        }
+        int cgt = 0, ceq = 0;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) { cgt += (key[i] > T); ceq += (key[i] == T); }
+        cgt = block_sum_wide(cgt, red, slot);
+        ceq = block_sum_wide(ceq, red, slot);
+        const int need = k - cgt;      // entries equal to T to keep, lowest positions first
+        int P = WIDE_T * EPT;          // keep key == T entries with position <= P
+        if (need < ceq) {              // smallest P with |{key == T, pos <= P}| >= need (17 position bits)
+            int lo = -1;
+            for (int bit = 16; bit >= 0; --bit) {
+                const int t = lo + (1 << bit);
+                int c = 0;
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) c += (key[i] == T && (tid + WIDE_T * i) <= t);
+                if (block_sum_wide(c, red, slot) < need) lo = t;
+            }
+            P = lo + 1;
+        }
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int p = tid + WIDE_T * i;
+            if (key[i] != 0u && (key[i] > T || (key[i] == T && p <= P))) {
+                const int s = atomicAdd(&wcnt, 1);
+                wkey[s] = key[i];
+                wpos[s] = p;
+            }
+        }
+        __syncthreads();
+        nw = wcnt;  // == min(k, #valid) <= KMAX
+    }
+    float* so = os + (int64_t)q * k;
+    int64_t* io = oi + (int64_t)q * k;
+    for (int i = tid; i < nw; i += WIDE_T) {
+        const uint32_t ki = wkey[i];
+        const int pi = wpos[i];
+        int rank = 0;
+        for (int j = 0; j < nw; ++j) rank += better(wkey[j], wpos[j], ki, pi);
+        if (rank < k) { so[rank] = key2f(ki); io[rank] = pi; }
+    }
+    for (int i = (nw < k ? nw : k) + tid; i < k; i += WIDE_T) { so[i] = -__builtin_inff(); io[i] = -1; }
+}
+
+// one launch for the whole selection when a score row fits one wide workgroup and k <= 64; false = use the segment path
+static bool launch_select_wide(const float* S, int64_t N, int nq, int k, int64_t* out_idx, float* out_score, hipStream_t st) {
+    if (k > 64 || N > (int64_t)WIDE_T * 64) return false;
+    int G = 1;
+    while (G < k) G <<= 1;   // >= k groups, power of two, <= 64
+    const int ept = (int)((N + WIDE_T - 1) / WIDE_T);
+#define RALF_WIDE(E) hipLaunchKernelGGL((knn_select_wide_kernel<E>), dim3(nq), dim3(WIDE_T), 0, st, S, N, (int)N, k, G, out_score, out_idx)
+    if (ept <= 8) RALF_WIDE(8);
+    else if (ept <= 16) RALF_WIDE(16);
+    else if (ept <= 32) RALF_WIDE(32);
+    else RALF_WIDE(64);
+#undef RALF_WIDE
+    return true;
+}
+
 template <int MF, int TQ, int TR>
 int launch_scores(const float* X, int64_t N, int D, const float* Q, int nq, float* S, hipStream_t st) {
     constexpr int RW = 4 * TR * MF, QW = TQ * MF;
@@ -461,19 +525,6 @@ int launch_scores(const float* X, int64_t N, int D, const float* Q, int nq, floa
     hipLaunchKernelGGL((knn_scores_kernel<MF, TQ, TR>), dim3(nwg), dim3(256), 0, st, X, N, D, Q, nq, S, nqt, nwg);
     return ralf::check_launch("knn_scores");
 }
-
-template <int MF, int TQ, int TR>
-int launch_scan_topk(const float* X, int64_t N, int D, const float* Q, int nq, int k, float* ts, int64_t* ti, hipStream_t st) {
-    constexpr int RW = 4 * TR * MF, QW = TQ * MF;
-    const int nrc = ceil_div(N, RW), nqt = ceil_div(nq, QW);
-    const int nwg = nrc * nqt;
-    hipLaunchKernelGGL((knn_scores_kernel<MF, TQ, TR, false, true>), dim3(nwg), dim3(256), 0, st, X, N, D, Q, nq, (float*)nullptr, nqt, nwg,
-                       (const int64_t*)nullptr, 0, k, ts, ti);
-    return ralf::check_launch("knn_scan_topk");
-}
-
-// rows scanned per workgroup of the fused scan (= rows per candidate list), by query count: the tile shapes of ralf_knn_scores
-inline int fused_rows_per_wg(int nq) { return nq <= 32 ? 128 : 256; }
 
 int launch_rescore(const float* X, int64_t N, int D, const float* Q, int nq, const int64_t* cand, int pool, float* S, hipStream_t st) {
     constexpr int MF = 16, RW = 4 * MF;                    // 64 candidates per workgroup, one query per 16-row query tile
@@ -534,16 +585,9 @@ extern "C" int ralf_knn_rownorms(const float* X, const void* Xb, int64_t R, int 
     return ralf::check_launch("knn_rownorms");
 }
 
-// lists of k candidates per query after the fused scan
-static inline int64_t fused_lists(int64_t N, int nq) { return (N + fused_rows_per_wg(nq) - 1) / fused_rows_per_wg(nq); }
-
 extern "C" size_t ralf_knn_topk_ip_workspace_bytes(int64_t N, int D, int nq, int k) {
     (void)D;
     if (N <= 0 || nq <= 0 || k <= 0) return 0;
-    if (k <= KFUSED) {   // fused scan + selection: two candidate buffers, no score matrix
-        const size_t cand = (size_t)nq * fused_lists(N, nq) * k * (sizeof(float) + sizeof(int64_t));
-        return 2 * align256(cand) + 256;
-    }
     SelectPlan p = plan_select(N, nq, k);
     return align256((size_t)nq * N * sizeof(float)) + 2 * align256(p.cand_bytes) + 256;
 }
@@ -555,6 +599,7 @@ extern "C" int ralf_knn_select(const float* S, int64_t N, int nq, int k, int64_t
     RALF_REQUIRE(N > 0 && nq > 0, "knn_select: empty problem");
     RALF_REQUIRE(k >= 1 && k <= KMAX, "knn_select: k=%d outside [1,%d]", k, KMAX);
     hipStream_t st = (hipStream_t)stream;
+    if (launch_select_wide(S, N, nq, k, out_idx, out_score, st)) return ralf::check_launch("knn_select");
     SelectPlan p = plan_select(N, nq, k);
     if (p.nseg == 1) {
         hipLaunchKernelGGL((knn_select_kernel<true>), dim3(1, nq), dim3(256), 0, st, S, nullptr, nullptr, N, N, (int64_t)SEG, k, out_score, out_idx);
@@ -586,21 +631,6 @@ extern "C" int ralf_knn_select(const float* S, int64_t N, int nq, int k, int64_t
     return ralf::check_launch("knn_select");
 }
 
-// candidate lists [nq][nl][k] (equal scores in ascending index order) -> out, by rounds of knn_select_kernel<false>
-static int merge_lists(float* cs[2], int64_t* ci[2], int64_t nl, int nq, int k, int64_t* out_idx, float* out_score, hipStream_t st) {
-    int cur = 0;
-    const int64_t group = SEG / k;  // lists merged per workgroup (>= 8 since k <= 1024)
-    do {
-        const int64_t nout = (nl + group - 1) / group;
-        float* so = nout == 1 ? out_score : cs[cur ^ 1];
-        int64_t* io = nout == 1 ? out_idx : ci[cur ^ 1];
-        hipLaunchKernelGGL((knn_select_kernel<false>), dim3((unsigned)nout, nq), dim3(256), 0, st, nullptr, cs[cur], ci[cur], nl * k, nl * k, group * k, k, so, io);
-        nl = nout;
-        cur ^= 1;
-    } while (nl > 1);
-    return ralf::check_launch("knn_merge");
-}
-
 extern "C" int ralf_knn_topk_ip(const float* X, int64_t N, int D, const float* Q, int nq, int k, int64_t* out_idx,
                                 float* out_score, void* ws, size_t ws_bytes, void* stream) {
     RALF_REQUIRE(k >= 1 && k <= KMAX, "knn_topk_ip: k=%d outside [1,%d]", k, KMAX);
@@ -611,30 +641,6 @@ extern "C" int ralf_knn_topk_ip(const float* X, int64_t N, int D, const float* Q
         return RALF_ERR_WORKSPACE;
     }
     RALF_REQUIRE(((uintptr_t)ws & 255) == 0, "knn_topk_ip: workspace must be 256-byte aligned");
-    if (k <= KFUSED) {
-        RALF_REQUIRE(X && Q && out_idx && out_score, "knn_topk_ip: null pointer");
-        RALF_REQUIRE(D > 0 && D % 4 == 0, "knn_topk_ip: dim %d must be a multiple of 4 (16-byte row alignment)", D);
-        RALF_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)Q & 15) == 0, "knn_topk_ip: index/queries must be 16-byte aligned");
-        hipStream_t st = (hipStream_t)stream;
-        const int64_t nl = fused_lists(N, nq);
-        const size_t cand = (size_t)nq * nl * k * (sizeof(float) + sizeof(int64_t));
-        float* cs[2];
-        int64_t* ci[2];
-        for (int i = 0; i < 2; ++i) {
-            ci[i] = (int64_t*)((char*)ws + i * align256(cand));
-            cs[i] = (float*)(ci[i] + (size_t)nq * nl * k);
-        }
-        // one list and it is the answer: the scan writes the output itself
-        float* ts = nl == 1 ? out_score : cs[0];
-        int64_t* ti = nl == 1 ? out_idx : ci[0];
-        int rc;
-        if (nq <= 16) rc = launch_scan_topk<16, 1, 2>(X, N, D, Q, nq, k, ts, ti, st);        // same tiles as ralf_knn_scores
-        else if (nq <= 32) rc = launch_scan_topk<32, 1, 1>(X, N, D, Q, nq, k, ts, ti, st);
-        else if (nq <= 64) rc = launch_scan_topk<32, 2, 2>(X, N, D, Q, nq, k, ts, ti, st);
-        else rc = launch_scan_topk<32, 4, 2>(X, N, D, Q, nq, k, ts, ti, st);
-        if (rc || nl == 1) return rc;
-        return merge_lists(cs, ci, nl, nq, k, out_idx, out_score, st);
-    }
     float* S = (float*)ws;
     const size_t soff = align256((size_t)nq * N * sizeof(float));
     int rc = ralf_knn_scores(X, N, D, Q, nq, S, stream);

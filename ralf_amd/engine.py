@@ -12,6 +12,7 @@ The reference's DDP wiring never all-reduces (SURVEY.md section 5 "DDP quirk"); 
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -240,6 +241,7 @@ class TrainStep:
         self.opt = FlatAdamW(groups, betas, eps, max_norm, shadow_dtype=rt.dtype if rt.dtype == torch.bfloat16 else None, runtime=rt)
         rt.direct_grads = True   # kernels accumulate parameter gradients straight into the flat buffer
         rt.overlap = overlap_wgrad  # ... on a side stream: a parallel branch of the captured graph
+        rt.branches = os.environ.get("RALF_BRANCHES", "1") != "0"   # independent sub-networks on their own graph branches
         self.use_graph = use_graph
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if (process_group is not None or torch.distributed.is_initialized()) else 1
@@ -286,6 +288,7 @@ class TrainStep:
         loss = losses["nll_loss"]
         loss.backward(torch.full_like(loss, 1.0 / self.world) if self.world > 1 else None)
         rt.join_side()
+        rt.join_all_branches()
         return loss.detach()
 
     def _bwd_rest(self):
@@ -295,6 +298,7 @@ class TrainStep:
         if cuts:
             torch.autograd.backward([o for o, _ in cuts], [leaf.grad for _, leaf in cuts])
             rt.join_side()
+            rt.join_all_branches()
 
     def _sync_replicas(self, rt):
         """what the reference's DDP constructor does (train/train.py:208): every rank starts from rank 0's parameters and

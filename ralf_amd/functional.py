@@ -36,6 +36,12 @@ class Runtime:
         self._keep: list = []     # operands of side-stream work in flight (kept alive until join_side)
         self.cut_enabled = False  # engine mode (data parallel): split the backward at grad_cut() points
         self._cuts: list = []     # (tensor of the early graph, detached leaf the late graph continued from)
+        # engine mode: independent sub-networks (constraint encoder, retrieved-layout branch) are issued on their own HIP
+        # streams = parallel branches of the captured graph; autograd replays every backward node on its forward stream, so
+        # the branches' backward chains of tiny launch-latency-bound kernels overlap the big kernels of the image branch too
+        self.branches = False
+        self._branch_streams: dict = {}
+        self._branch_keep: list = []
 
     def to(self, device):
         if self.seed is None or self.seed.device != device:
@@ -45,6 +51,7 @@ class Runtime:
     def begin_step(self):
         """start of a forward: restart the stream-id counter (the device seed distinguishes steps)."""
         self._call = 0
+        self._branch_keep.clear()   # (every branch entry first waits for all work issued so far: the previous step's consumers are ordered)
 
     def advance_seed(self):
         self.seed.add_(0x9E3779B1)  # on-device: safe inside a captured graph
@@ -95,6 +102,26 @@ class Runtime:
             for st in self._side:
                 torch.cuda.current_stream().wait_stream(st)
             self._keep.clear()
+
+    def branch(self, name: str):
+        """context manager: the enclosed forward work runs on the branch stream `name` (after everything issued so far);
+        call join_branch(name, outputs...) before consuming its outputs on the current stream."""
+        return _Branch(self, name)
+
+    def join_branch(self, name: str, *outputs):
+        st = self._branch_streams.get(name)
+        if st is None:
+            return
+        torch.cuda.current_stream().wait_stream(st)
+        # tensors that cross streams stay allocated until the end of the step: the caching allocator only orders reuse per stream
+        self._branch_keep.extend(o for o in outputs if torch.is_tensor(o))
+
+    def join_all_branches(self):
+        """end of the backward: the branches' parameter-gradient kernels wrote into the flat buffer on their own streams"""
+        cur = torch.cuda.current_stream()
+        for st in self._branch_streams.values():
+            cur.wait_stream(st)
+        self._branch_keep.clear()
 
     def gview(self, p: torch.Tensor):
         """flat-buffer gradient view of a parameter when the engine owns the gradients (kernels accumulate into it
@@ -164,6 +191,28 @@ class Runtime:
                 raise ValueError(kind)
         self._lp[key] = ((w._version, self._wtoken), w.data_ptr(), t, weakref.ref(w))  # id() can be recycled: keep a weakref
         return t
+
+
+class _Branch:
+    def __init__(self, rt, name):
+        self.rt, self.name, self.ctx = rt, name, None
+
+    def __enter__(self):
+        rt = self.rt
+        if not (rt.branches and torch.cuda.is_available()):
+            return self
+        st = rt._branch_streams.get(self.name)
+        if st is None:
+            st = rt._branch_streams[self.name] = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        self.ctx = torch.cuda.stream(st)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
 
 
 def _2d(x):
@@ -465,6 +514,123 @@ class XentFn(Function):
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
         return (dl * g.to(dl.dtype)).float(), None, None, None, None  # scalar chain rule: plumbing
+
+
+# ----------------------------------------------------------------------------------------------
+# cross-attention K/V projections of ALL decoder layers over the same memory in one product
+# ----------------------------------------------------------------------------------------------
+class CrossKVPlan:
+    """The 6 decoder layers of BaseDecoder project the SAME memory with their own packed in_proj rows [d:3d]
+    (common/common.py:25-34: nn.TransformerDecoderLayer.multihead_attn).  When the engine keeps all parameters in one flat
+    buffer, consecutive layers sit a constant stride apart, so the 6 products are ONE batched GEMM launch (forward, weight
+    gradient) and -- through a K range chained over the 6 weight blocks -- ONE data-gradient GEMM instead of 6 products and 5
+    full-size accumulations of d(memory).  `make` returns None when the layout does not allow it (plain torch parameters:
+    the per-layer path of MHAParams.cross_attn is used)."""
+
+    def __init__(self, L, d, sW, sWg, sB, sBg):
+        self.L, self.d, self.sW, self.sWg, self.sB, self.sBg = L, d, sW, sWg, sB, sBg
+        self.dkv = None   # gradient of the stacked K/V projections, filled slice by slice by the layers' attention backward
+
+    # OFF by default -- measured on MI355X (B = 64, same run): encoder-decoder step 6.92 ms per-layer vs 7.52 ms stacked.  The
+    # stacked K/V tensor (209 MB) and its gradient are produced by one launch and consumed layer by layer much later, i.e. from
+    # HBM instead of the 256 MB Infinity Cache the per-layer products (35 MB each, consumed at once) live in.  Kept for tests
+    # and for re-measuring (RALF_STACKED_KV=1).
+    enabled = os.environ.get("RALF_STACKED_KV", "0") == "1"
+
+    @staticmethod
+    def make(attns, rt):
+        if not (CrossKVPlan.enabled and rt.direct_grads) or len(attns) < 2:
+            return None
+        Ws, bs = [a.in_proj_weight for a in attns], [a.in_proj_bias for a in attns]
+        if any(rt.gview(w) is None for w in Ws) or any(rt.gview(b) is None for b in bs):
+            return None
+
+        def stride(ts):
+            e = ts[0].element_size()
+            ds = {(ts[i + 1].data_ptr() - ts[i].data_ptr()) for i in range(len(ts) - 1)}
+            return (ds.pop() // e) if len(ds) == 1 and next(iter(ds)) % (16) == 0 and next(iter(ds)) > 0 else None
+
+        lw = [rt.lp(w) for w in Ws]
+        st = [stride(lw), stride([rt.gview(w) for w in Ws]), stride([b.detach() for b in bs]), stride([rt.gview(b) for b in bs])]
+        if any(x is None for x in st) or len({tuple(w.shape) for w in Ws}) != 1:
+            return None
+        return CrossKVPlan(len(attns), Ws[0].shape[1], *st)
+
+
+class CrossKVFn(Function):
+    """kv_all [B*M, L*2d] = memory @ [W_0[d:3d]; ...; W_{L-1}[d:3d]]^T + biases  (layer l owns columns [l*2d, (l+1)*2d))"""
+
+    @staticmethod
+    def forward(ctx, mem, plan, rt, W0, b0, *rest):
+        L, d = plan.L, plan.d
+        mem2 = _2d(mem.contiguous())
+        rows = mem2.shape[0]
+        out = torch.empty(rows, L * 2 * d, dtype=rt.dtype, device=mem.device)
+        ops.gemm(mem2, rt.lp(W0)[d:], rows, 2 * d, d, bias=b0.detach()[d:], batch=(L, 1), sA=(0, 0), sB=(plan.sW, 0), sC=(2 * d, 0),
+                 ldc=L * 2 * d, out=out, sBias0=plan.sB)
+        ctx.save_for_backward(mem2, W0)
+        ctx.plan, ctx.rt, ctx.b0, ctx.mshape = plan, rt, b0, mem.shape
+        plan.dkv = None
+        return out.view(*mem.shape[:-1], L * 2 * d)
+
+    @staticmethod
+    def backward(ctx, dkv):
+        mem2, W0 = ctx.saved_tensors
+        plan, rt = ctx.plan, ctx.rt
+        L, d = plan.L, plan.d
+        rows = mem2.shape[0]
+        dkv2 = _2d(dkv.contiguous())
+        K = L * 2 * d
+        if rt.dtype == torch.bfloat16:   # one product over the chained K range
+            dmem = ops.gemm(dkv2, rt.lp(W0)[d:], rows, d, K, b_kcontig=False, kseg=2 * d, sBk=plan.sW - 2 * d * d)
+        else:                            # parity mode: per layer, accumulated in the GEMM epilogue
+            dmem = torch.empty(rows, d, dtype=rt.dtype, device=dkv2.device)
+            w0 = rt.lp(W0)
+            for l in range(L):
+                wl = torch.as_strided(w0, (3 * d, d), (d, 1), w0.storage_offset() + l * plan.sW)[d:]
+                ops.gemm(dkv2[:, l * 2 * d:], wl, rows, d, 2 * d, lda=K, b_kcontig=False, out=dmem, accumulate=l > 0)
+        gW, gb = rt.gview(W0), rt.gview(ctx.b0)
+
+        def wg():   # dW_l[d:3d] += dkv_l^T mem for all layers at once (batched over l, split over the rows)
+            ops.gemm(dkv2, mem2, 2 * d, d, rows, a_kcontig=False, b_kcontig=False, lda=K, batch=(L, 1), sA=(2 * d, 0), sB=(0, 0), sC=(plan.sWg, 0),
+                     out=gW[d:], accumulate=True, splitk=_splitk_for(2 * d * L, d, rows))
+            tmp = ops.colsum(dkv2, rows, K)
+            ops.copy2d_acc(tmp, gb[d:], L, 2 * d, 2 * d, plan.sBg)
+        rt.side(wg, gW, dkv2, mem2)
+        return (dmem.view(ctx.mshape), None, None, None, None) + (None,) * (2 * L - 2)
+
+
+class AttnCrossSliceFn(Function):
+    """cross-attention of decoder layer `li` reading its K/V from the stacked projection kv_all; the backward writes dK/dV into
+    the shared gradient buffer of kv_all (plan.dkv) and only layer 0 -- whose backward runs last -- hands that buffer to
+    autograd, so no per-layer zero-filled full-size gradients are summed."""
+
+    @staticmethod
+    def forward(ctx, q, kv_all, li, plan, H, dh, p, rt):
+        q = q.contiguous()
+        B, Sq, _ = q.shape
+        Sk = kv_all.shape[1]
+        d = plan.d
+        call = rt.next_call() if p > 0.0 else 0
+        o, lse = ops.attention_fwd(q, kv_all, kv_all, B, H, Sq, Sk, dh, 0, li * 2 * d, li * 2 * d + d, p_drop=p, seed=rt.seed, call_id=call)
+        ctx.save_for_backward(q, kv_all, o, lse)
+        ctx.cfg = (B, H, Sq, Sk, dh, li, plan, p, call, rt)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv_all, o, lse = ctx.saved_tensors
+        B, H, Sq, Sk, dh, li, plan, p, call, rt = ctx.cfg
+        d = plan.d
+        if plan.dkv is None:
+            plan.dkv = torch.empty_like(kv_all)
+        dq = torch.empty_like(q)
+        ops.attention_bwd(do.contiguous(), q, kv_all, kv_all, o, lse, dq, plan.dkv, plan.dkv, B, H, Sq, Sk, dh, 0, li * 2 * d, li * 2 * d + d,
+                          0, li * 2 * d, li * 2 * d + d, p_drop=p, seed=rt.seed, call_id=call)
+        out = plan.dkv if li == 0 else None
+        if li == 0:
+            plan.dkv = None
+        return dq, out, None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------

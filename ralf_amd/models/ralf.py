@@ -172,9 +172,19 @@ class _GeneratorBase(nn.Module):
                     a = (6.0 / (p.shape[0] + p.shape[1])) ** 0.5
                     p.uniform_(-a, a, generator=g)
 
-    def _constraint_memory(self, img_mem, inputs):
+    def _constraint_features(self, inputs):
+        """constraint encoder (a8) on its own graph branch: 6 layers of launch-latency-bound kernels (Lc = 4 ... 63 tokens per
+        sample) that depend on nothing but the token ids"""
         rt = self.rt
-        cf = self.user_const_encoder(inputs["seq_layout_const"], inputs["seq_layout_const_pad_mask"], rt)
+        with rt.branch("constraint"):
+            cf = self.user_const_encoder(inputs["seq_layout_const"], inputs["seq_layout_const_pad_mask"], rt)
+        return cf
+
+    def _constraint_memory(self, img_mem, inputs, cf=None):
+        rt = self.rt
+        if cf is None:
+            cf = self._constraint_features(inputs)
+        rt.join_branch("constraint", cf)
         if self.use_flag_embedding:  # learned scalars broadcast over all channels (retrieval_augmented_autoreg.py:1022-1028)
             img_mem = RF.AddScalarFn.apply(img_mem, self.task_emb.weight, 0, rt)
             cf = RF.AddScalarFn.apply(cf, self.task_emb.weight, 1, rt)
@@ -530,13 +540,17 @@ class ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg(_GeneratorBas
         return RF.drop_add(f, None, rt.drop_p(self.pos_emb_1d.p), rt)
 
     def _encode_into_memory(self, inputs: dict) -> dict:
-        rt = self.rt
+        rt = self.rt.to(inputs["image"].device)
         assert inputs["image"].size(1) == 4
+        # three independent sub-networks start here; the two small ones are issued first, each on its own branch
+        cf = self._constraint_features(inputs)
+        with rt.branch("retrieved"):
+            ref = self._retrieved_features(inputs["retrieved"], inputs["image"].device)
         mem = self._image_memory(inputs["image"])
-        ref = self._retrieved_features(inputs["retrieved"], mem.device)
+        rt.join_branch("retrieved", ref)
         ca = self.attn(mem, ref, rt)
         fused = self.head(torch.cat([mem, ca, ref], dim=1), rt)  # sequence concat: plumbing copy
-        return {"memory": self._constraint_memory(fused, inputs)}
+        return {"memory": self._constraint_memory(fused, inputs, cf)}
 
 
 class _ScaleAddPE(torch.autograd.Function):
@@ -582,4 +596,6 @@ class ConcateAuxilaryTaskAutoreg(_GeneratorBase):
         return _inputs, {"seq": data["seq"][:, 1:]}
 
     def _encode_into_memory(self, inputs: dict) -> dict:
-        return {"memory": self._constraint_memory(self._image_memory(inputs["image"]), inputs)}
+        self.rt.to(inputs["image"].device)
+        cf = self._constraint_features(inputs)
+        return {"memory": self._constraint_memory(self._image_memory(inputs["image"]), inputs, cf)}

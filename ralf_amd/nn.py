@@ -90,6 +90,13 @@ class MHAParams(nn.Module):
         o = RF.AttnFn.apply(q, kv, self.nhead, d // self.nhead, False, None, rt.drop_p(p_attn), rt)
         return self._out(o, res, rt, p_out)
 
+    def cross_attn_stacked(self, x, kv_all, li, plan, res, rt: Runtime, p_attn=0.0, p_out=0.0):
+        """cross_attn with K/V taken from the projection of all layers at once (functional.CrossKVFn)"""
+        d = self.d
+        q = RF.linear(x, self.in_proj_weight, self.in_proj_bias, rt=rt, rows=(0, d))
+        o = RF.AttnCrossSliceFn.apply(q, kv_all, li, plan, self.nhead, d // self.nhead, rt.drop_p(p_attn), rt)
+        return self._out(o, res, rt, p_out)
+
     def _out(self, o, res, rt, p_out):
         return RF.linear(o, self.out_proj.weight, self.out_proj.bias, res=res, rt=rt, p=rt.drop_p(p_out))
 
@@ -125,11 +132,15 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
         self.norm1, self.norm2, self.norm3 = Affine(d, bias_dim=d), Affine(d, bias_dim=d), Affine(d, bias_dim=d)
         self.p = dropout
 
-    def forward(self, x, mem, rt: Runtime, tgt_kpm=None):
+    def forward(self, x, mem, rt: Runtime, tgt_kpm=None, stacked=None):
+        """stacked = (kv_all, layer index, plan): this layer's cross-attention K/V were projected with all other layers' (BaseDecoder)"""
         h, x = RF.layer_norm_skip(x, self.norm1.weight, self.norm1.bias, rt)
         x = self.self_attn.self_attn(h, x, rt, causal=True, kpm=tgt_kpm, p_attn=self.p, p_out=self.p)
         h, x = RF.layer_norm_skip(x, self.norm2.weight, self.norm2.bias, rt)
-        x = self.multihead_attn.cross_attn(h, mem, x, rt, p_attn=self.p, p_out=self.p)  # memory is NOT masked (common.py:116-123)
+        if stacked is not None:
+            x = self.multihead_attn.cross_attn_stacked(h, stacked[0], stacked[1], stacked[2], x, rt, p_attn=self.p, p_out=self.p)
+        else:
+            x = self.multihead_attn.cross_attn(h, mem, x, rt, p_attn=self.p, p_out=self.p)  # memory is NOT masked (common.py:116-123)
         h, x = RF.layer_norm_skip(x, self.norm3.weight, self.norm3.bias, rt)
         return self._ffn(h, x, rt, self.p)
 
@@ -190,8 +201,15 @@ class BaseDecoder(nn.Module):
         h = RF.EmbedFn.apply(tgt, self.emb.weight, self.pos_emb.pe[0], rt)
         h = RF.drop_add(h, None, rt.drop_p(self.pos_emb.p), rt)
         kpm = _kpm_u8(tgt_key_padding_mask)
-        for layer in self.transformer.layers:
-            h = layer(h, memory, rt, kpm)
+        layers = list(self.transformer.layers)
+        attns = [l.multihead_attn for l in layers]
+        plan = RF.CrossKVPlan.make(attns, rt) if torch.is_grad_enabled() else None
+        kv_all = None
+        if plan is not None:   # all layers' cross-attention K/V projections of the memory in one launch
+            wb = [t for a in attns for t in (a.in_proj_weight, a.in_proj_bias)]
+            kv_all = RF.CrossKVFn.apply(memory, plan, rt, *wb)
+        for li, layer in enumerate(layers):
+            h = layer(h, memory, rt, kpm, stacked=(kv_all, li, plan) if plan is not None else None)
         h = RF.layer_norm(h, self.head[0].weight, self.head[0].bias, rt)
         return RF.linear(h, self.head[1].weight, rt=rt, out_f32=True)
 

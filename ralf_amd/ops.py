@@ -41,7 +41,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
          lda=None, ldb=None, out: Optional[torch.Tensor] = None, ldc=None, out_dtype=None,
          bias=None, act=None, res=None, ldr=None, aux=None, aux_mode=None, aux_scale=1.0, out2=None,
          alpha=1.0, accumulate=False, splitk=1, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=None,
-         conv: Optional[dict] = None, gather=0, drop_p=0.0, seed=None, call_id=0, atomic=False, colstats=None) -> torch.Tensor:
+         conv: Optional[dict] = None, gather=0, drop_p=0.0, seed=None, call_id=0, atomic=False, colstats=None,
+         sBias0=0, kseg=0, sBk=0) -> torch.Tensor:
     """C = epi(alpha * A @ B) through ralf_gemm (see include/ralf_hip.h: RalfGemmDesc)."""
     assert A.is_cuda and B.is_cuda and A.dtype == B.dtype
     d = RalfGemmDesc()
@@ -73,6 +74,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
     d.act, d.aux_mode, d.aux_scale = ACT[act], AUX[aux_mode], aux_scale
     d.accumulate, d.splitk, d.alpha = int(accumulate), splitk, alpha
     d.drop_p, d.seed, d.call_id, d.atomic_out = drop_p, _p(seed), call_id, int(atomic)
+    d.sBias0, d.kseg, d.sBk = sBias0, kseg, sBk
     if colstats is not None:   # fp32 [ceil(M/64), 2, N]: per-64-row column sums / sums of squares of the stored output
         assert colstats.dtype == torch.float32 and colstats.numel() >= ((M + 63) // 64) * 2 * N
         d.colstats = _p(colstats)
@@ -190,6 +192,12 @@ def cast_into(x, out):
     assert out.numel() == n and x.is_contiguous() and out.is_contiguous()
     _call("ralf_copy2d", dtype_code(x), dtype_code(out), _p(x), _p(out), 1, n, n, n, 0)
     return out
+
+
+def copy2d_acc(src, dst, rows, cols, lds, ldd):
+    """dst[r*ldd + c] += src[r*lds + c] (fp32): a stacked result scattered into equally spaced views of a flat buffer"""
+    assert src.dtype == torch.float32 and dst.dtype == torch.float32
+    _call("ralf_copy2d", F32, F32, _p(src), _p(dst), rows, cols, lds, ldd, 1)
 
 
 def permute4(x, out_dims, strides, valid3, dtype, out=None):

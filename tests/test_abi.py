@@ -30,8 +30,5 @@ def test_workspace_query_is_pure_host():
 
     L = _lib.lib()
     assert L.ralf_knn_topk_ip_workspace_bytes(0, 64, 1, 16) == 0
-    # k <= 64: fused scan + selection, two candidate buffers of nq x ceil(N / 256) lists x k (score, index) pairs -- no score matrix
     w = L.ralf_knn_topk_ip_workspace_bytes(61548, 1792, 1024, 17)
-    assert 2 * 1024 * 241 * 17 * 12 <= w < 61548 * 1024 * 4
-    # larger k: score matrix + candidate buffers
-    assert L.ralf_knn_topk_ip_workspace_bytes(61548, 1792, 1024, 100) >= 61548 * 1024 * 4
+    assert w >= 61548 * 1024 * 4

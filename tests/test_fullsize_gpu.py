@@ -31,6 +31,13 @@ def test_b64_train_step_bf16_against_fp32_whole_model():
     needs none)."""
     m32 = bench.build_model(torch.device(DEV), 10, "float32")
     m16 = bench.build_model(torch.device(DEV), 10, "bfloat16")
+    # gradients of a deep randomly initialised ReLU network decorrelate under ANY perturbation of the forward pass (mask flips
+    # multiply over 50 layers: with plain He init the stem gradient of the bf16 run has cosine 0.1 with the fp32 one although
+    # loss and logits agree): damp the residual branches (bn3 gamma 0.25), the regime a trained network is in
+    with torch.no_grad():
+        for n, p in m32.named_parameters():
+            if n.endswith("bn3.weight"):
+                p.fill_(0.25)
     m16.load_state_dict(m32.state_dict())
     for m in (m32, m16):
         m.rt.drop_p = lambda p: 0.0          # train mode (BatchNorm batch statistics) without dropout
@@ -47,7 +54,8 @@ def test_b64_train_step_bf16_against_fp32_whole_model():
             "transformer_encoder.layers.5.self_attn.in_proj_weight", "head.net.1.weight", "attn.to_kv.weight",
             "encoder.extractor.proj.weight", "encoder.extractor.fpn_conv33.weight", "encoder.extractor.body.layer4.2.conv2.weight",
             "encoder.extractor.body.layer3.0.conv1.weight", "encoder.extractor.body.layer2.0.conv2.weight", "encoder.extractor.body.conv1.weight"]
-    report = {k: (cos(g32[k], g16[k]), (g16[k].norm() / g32[k].norm()).item()) for k in keys}
+    report = {k: (round(cos(g32[k], g16[k]), 4), round((g16[k].norm() / g32[k].norm()).item(), 4)) for k in keys}
+    print("bf16 vs fp32 gradient (cosine, norm ratio):", report)
     for k, (c, r) in report.items():
         body = ".body." in k
         assert c > (0.90 if body else 0.98) and abs(r - 1) < (0.15 if body else 0.05), report
