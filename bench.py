@@ -122,8 +122,43 @@ def bench_knn(device):
     return {"index": f"{N}x{D} fp32", "k": k, **out}
 
 
+def bench_decode(device, N=10, B=256, dtype="bfloat16", reps=3):
+    """constrained inference (BASELINE configs[4]): B = 256 autoregressive decode, tasks c -> s+p and cwh -> p, deterministic
+    (argmax) and top-k 5 sampling; ms per sample as image2layout/train/inference.py:494-495 reports it (whole sample() call from
+    host tensors: encoder + 5N KV-cached decoder steps captured in one hipGraph + token decode on the host)."""
+    from ralf_amd.engine import GraphedDecode
+    from ralf_amd.helpers.task import get_condition
+    from ralf_amd.synthetic import make_batch
+
+    out = {"batch": B, "tokens_per_sample": 5 * N, "note": "sample() incl. H2D of the image batch and host-side token decoding; graph_ms = the captured device loop alone"}
+    for task in ("c", "cwh"):
+        model = build_model(device, N, dtype, task).eval()
+        cond, _ = get_condition(make_batch(B, N, seed=9), task, model.tokenizer)
+        cond.retrieved = {k: v for k, v in cond.retrieved.items() if k != "image"}
+        for name, cfg in (("deterministic", {"name": "deterministic"}), ("top_k5", {"name": "top_k", "top_k": 5, "temperature": 1.0})):
+            dec = GraphedDecode(model, task, cfg, True)
+            for _ in range(2):
+                res = model.sample(cond=cond, sampling_cfg=cfg, cond_type=task, decoder=dec)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                res = model.sample(cond=cond, sampling_cfg=cfg, cond_type=task, decoder=dec)
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / reps
+            tg = _time_gpu(lambda: dec._graph.replay(), iters=reps, warm=1)
+            assert res["label"].shape == (B, N)
+            # the cross-attention K/V cache of the 2*hw + K + Lc memory rows is read once per decoder step and layer
+            M = dec._static["enc"]["seq_layout_const"].shape[1] + 2 * 256 + 16
+            kv_bytes = 6 * B * M * 512 * 2 * 5 * N
+            out[f"{task}_{name}"] = {"ms_per_batch": t * 1e3, "ms_per_sample": t * 1e3 / B, "tokens_per_s": B * 5 * N / t, "graph_ms": tg * 1e3,
+                                     "cross_kv_cache_TBps": kv_bytes / tg / 1e12}
+        del model
+    return out
+
+
 def cpu_baseline_train(N=10, B=4, steps=2):
-    """oracle (CPU restatement, fp32) RALF train step on the host cores: bounded sample of B=4, 256x256."""
+    """oracle (CPU restatement, fp32) train steps on the host cores, bounded samples of B = 4 at 256x256: the RALF model (the
+    `value` workload at 1/16 of its batch) and the Autoreg baseline without retrieval (BASELINE configs[0], its own batch)."""
     from oracle import ralf_oracle as O
     from oracle.detweights import det_state_dict, resnet50_fpn_shapes
     from ralf_amd.helpers.layout_tokenizer import LayoutSequenceTokenizer
@@ -131,12 +166,8 @@ def cpu_baseline_train(N=10, B=4, steps=2):
     from ralf_amd.helpers.task_preprocessor import PREPROCESSOR
     from ralf_amd.synthetic import make_batch
 
-    with open(os.path.join(ROOT, "tests", "golden", "ralf_state_shapes.json")) as f:
-        shapes = {k: tuple(v) for k, v in json.load(f)["shapes"].items()}
-    shapes.update(resnet50_fpn_shapes())
-    sd = det_state_dict(shapes)
-    params = [v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not k.startswith("layout_encoer.") and "running_" not in k and not k.endswith(".pe")]
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4)
+    # B = 4 at 256x256 does not scale past a few dozen threads (128 threads: 5.3 s/step, 8 threads: 1.5 s/step on the same code)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
     tok = LayoutSequenceTokenizer(["text", "logo", "underlay"], N)
     batch = make_batch(B, N, seed=3)
     cond, b2 = get_condition(batch, "uncond", tok)
@@ -145,19 +176,33 @@ def cpu_baseline_train(N=10, B=4, steps=2):
     inputs = {"seq": data["seq"][:, :-1], "tgt_key_padding_mask": ~data["mask"][:, :-1], "image": torch.cat([b2["image"], b2["saliency"]], 1),
               "retrieved": b2["retrieved"], "seq_layout_const": seqc["seq"], "seq_layout_const_pad_mask": seqc["pad_mask"]}
     tgt = data["seq"][:, 1:]
-    times = []
-    for i in range(steps + 1):
-        t0 = time.perf_counter()
-        opt.zero_grad(set_to_none=True)
-        logits = O.ralf_forward(sd, inputs, training_bn=True, p_drop=0.1)
-        loss = O.xent_label_smoothing(logits, tgt, tok.name_to_id("pad"))
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, 0.1)
-        opt.step()
-        times.append(time.perf_counter() - t0)
-    t = sum(times[1:]) / steps
+
+    def run(fixture, forward, nsteps):
+        with open(os.path.join(ROOT, "tests", "golden", fixture)) as f:
+            shapes = {k: tuple(v) for k, v in json.load(f)["shapes"].items()}
+        shapes.update(resnet50_fpn_shapes())
+        sd = det_state_dict(shapes)
+        params = [v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not k.startswith("layout_encoer.") and "running_" not in k and not k.endswith(".pe")]
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4)
+        times = []
+        for i in range(nsteps + 1):
+            t0 = time.perf_counter()
+            opt.zero_grad(set_to_none=True)
+            logits = forward(sd, inputs, training_bn=True, p_drop=0.1)
+            loss = O.xent_label_smoothing(logits, tgt, tok.name_to_id("pad"))
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(params, 0.1)
+            opt.step()
+            times.append(time.perf_counter() - t0)
+        return sum(times[1:]) / nsteps
+
+    t = run("ralf_state_shapes.json", O.ralf_forward, steps)
+    ta = run("autoreg_state_shapes.json", O.autoreg_forward, 1)
     return {"value": B * (5 * N + 1) / t, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/ralf_oracle.py RALF train step (fp32, dropout 0.1, batch-stat BN, clip 0.1, AdamW), B={B}, 256x256, N={N}, {steps} steps after 1 warm-up; {t:.2f} s/step"}
+            "sample": f"oracle/ralf_oracle.py RALF train step (fp32, dropout 0.1, batch-stat BN, clip 0.1, AdamW), B={B} (1/16 of the GPU batch), 256x256, N={N}, "
+                      f"{steps} steps after 1 warm-up; {t:.2f} s/step",
+            "autoreg_baseline": {"value": B * (5 * N + 1) / ta, "unit": "tokens/s",
+                                 "sample": f"BASELINE configs[0]: Autoreg baseline (no retrieval), uncond, B={B}, same oracle, 1 step after 1 warm-up; {ta:.2f} s/step"}}
 
 
 def cpu_baseline_knn(budget_s=12.0):
@@ -213,6 +258,7 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-knn", action="store_true")
     ap.add_argument("--skip-split", action="store_true", help="skip the encoder-decoder-only timing")
+    ap.add_argument("--skip-decode", action="store_true", help="skip the B = 256 constrained-decode block")
     ap.add_argument("--no-overlap", action="store_true", help="parameter-gradient kernels on the main stream (no parallel graph branch)")
     ap.add_argument("--dp-selftest", action="store_true", help="single GPU: run the data-parallel code path (1-rank RCCL group, staged backward, overlapped exchange)")
     a = ap.parse_args()
@@ -312,6 +358,8 @@ def main():
                                    "note": "dominant kernel knn_scores_kernel<16,1,2> at nq=16 (HBM-bound regime): 441.2 MB algorithmic bytes per launch (index 61548x1792 fp32 streamed once) / "
                                            f"{k16['scan_us']:.1f} us (HIP events); whole call incl. select+merge {k16['us_per_call']:.1f} us = {k16['hbm_frac']:.3f} of peak; "
                                            "nq=1024 is fp32-FLOP-bound (see knn.nq1024); traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction), profiles/"}
+        if world == 1 and not a.skip_decode:
+            out["decode"] = bench_decode(device, N)
         if world == 1 and not a.skip_cpu:
             out["cpu_baseline"] = cpu_baseline_train(N)
             out["cpu_baseline_knn"] = cpu_baseline_knn()

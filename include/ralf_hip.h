@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 6
+#define RALF_ABI_VERSION 7
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -129,17 +129,41 @@ typedef struct RalfGemmDesc {
 size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d);
 int ralf_gemm(const RalfGemmDesc* d, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Weight gradients of MANY linear layers in one launch (the `dW += dy^T x` products autograd issues one by one for nn.Linear /
+ * nn.MultiheadAttention in_proj / out_proj, e.g. 24 per encoder stack): job j adds dy_j^T x_j into the fp32 matrix dw_j.
+ *   dy bf16 [rows, n_out] (leading dimension ld_dy), x bf16 [rows, n_in] (ld_x), dw fp32 [n_out, n_in] (ld_dw)
+ *   splitk <= 1: every output tile walks the whole `rows` reduction (deterministic, no workspace);
+ *   splitk  > 1: the reduction is cut into slabs in `workspace` and summed in split order by a second launch.
+ * rows % 64 == 0; n_out, n_in and the leading dimensions % 8 == 0; 16-byte aligned pointers. */
+typedef struct RalfWgradJob {
+    const void* dy; const void* x; float* dw;
+    int64_t rows, ld_dy, ld_x, ld_dw;
+    int n_out, n_in, splitk, pad;
+} RalfWgradJob;
+size_t ralf_wgrad_grouped_workspace_bytes(const RalfWgradJob* jobs, int njobs);
+int ralf_wgrad_grouped(const RalfWgradJob* jobs, int njobs, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm (nn.LayerNorm, eps 1e-5) -- x,y [rows, cols] dtype; gamma/beta/statistics fp32.
  * bwd ACCUMULATES into dgamma/dbeta (fp32 [cols], may be NULL).   ralf_amd/csrc/norm.hip
  * ------------------------------------------------------------------------------------------- */
 int ralf_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                        int rows, int cols, float eps, void* stream);
-/* skip (may be NULL): gradient of the residual branch of a pre-norm block, added into dx */
+/* skip (may be NULL): gradient of the residual branch of a pre-norm block, added into dx.
+ * dx_drop (may be NULL): second output = ralf_dropout(dx, p_drop, seed, call_id) -- the block in front of this norm is
+ * `x + dropout(f(x))`, whose backward starts by masking dx: done here while dx is in registers. */
 int ralf_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                       void* dx, float* dgamma, float* dbeta, const void* skip, int rows, int cols, void* stream);
+                       void* dx, float* dgamma, float* dbeta, const void* skip, int rows, int cols,
+                       void* dx_drop, float p_drop, const int64_t* seed, uint64_t call_id, void* stream);
 /* out[c] += sum_r x[r*ld + c]   (bias gradients) */
 int ralf_colsum(int dtype, const void* x, int64_t ld, float* out, int rows, int cols, void* stream);
+/* the same for many matrices in one launch (the bias gradients that go with ralf_wgrad_grouped); bf16, cols % 256 == 0, ld % 8 == 0 */
+typedef struct RalfColsumJob {
+    const void* x; float* out;
+    int64_t ld;
+    int rows, cols;
+} RalfColsumJob;
+int ralf_colsum_grouped(const RalfColsumJob* jobs, int njobs, int dtype, void* stream);
 
 /* BatchNorm2d on NHWC viewed as [M = B*H*W, C] (timm ResNet-50 BN, momentum 0.1, eps 1e-5).
  * train: bn_stats (s1 = sum x, s2 = sum x^2; zero on entry) -> bn_finalize(training=1) -> bn_apply

@@ -39,7 +39,19 @@ class RalfGemmDesc(ctypes.Structure):
     )
 
 
+class RalfWgradJob(ctypes.Structure):
+    _fields_ = [("dy", vp), ("x", vp), ("dw", vp), ("rows", i64), ("ld_dy", i64), ("ld_x", i64), ("ld_dw", i64),
+                ("n_out", i32), ("n_in", i32), ("splitk", i32), ("pad", i32)]
+
+
+class RalfColsumJob(ctypes.Structure):
+    _fields_ = [("x", vp), ("out", vp), ("ld", i64), ("rows", i32), ("cols", i32)]
+
+
 SIGNATURES.update({
+    "ralf_wgrad_grouped_workspace_bytes": (sz, [ctypes.POINTER(RalfWgradJob), i32]),
+    "ralf_wgrad_grouped": (i32, [ctypes.POINTER(RalfWgradJob), i32, i32, vp, sz, vp]),
+    "ralf_colsum_grouped": (i32, [ctypes.POINTER(RalfColsumJob), i32, i32, vp]),
     "ralf_permute4_batched": (i32, [vp, i32, i32, vp]),
     "ralf_gemm_workspace_bytes": (sz, [ctypes.POINTER(RalfGemmDesc)]),
     "ralf_gemm": (i32, [ctypes.POINTER(RalfGemmDesc), vp, sz, vp]),
@@ -62,7 +74,7 @@ class RalfAttnDesc(ctypes.Structure):
 
 SIGNATURES.update({
     "ralf_layernorm_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
-    "ralf_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "ralf_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, f32, vp, u64, vp]),
     "ralf_colsum": (i32, [i32, vp, i64, vp, i32, i32, vp]),
     "ralf_bn_stats": (i32, [i32, vp, vp, vp, i64, i32, vp, vp]),
     "ralf_bn_finalize": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp]),

@@ -114,3 +114,23 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
     return d.dtype == RALF_F32 ? ralf_gemm_reduce_f32(&P, nbatch, blocks, st) : ralf_gemm_reduce_bf16(&P, nbatch, blocks, st);
 }
+
+extern "C" size_t ralf_wgrad_grouped_workspace_bytes(const RalfWgradJob* jobs, int njobs) {
+    size_t n = 0;
+    for (int i = 0; jobs && i < njobs; ++i)
+        if (jobs[i].splitk > 1) n += (size_t)jobs[i].splitk * jobs[i].n_out * jobs[i].n_in * sizeof(float);
+    return n;
+}
+
+extern "C" int ralf_wgrad_grouped(const RalfWgradJob* jobs, int njobs, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    RALF_REQUIRE(jobs && njobs > 0, "wgrad_grouped: no jobs");
+    RALF_REQUIRE(dtype == RALF_BF16, "wgrad_grouped: bf16 operands only (the fp32 parity mode uses ralf_gemm per layer)");
+    for (int i = 0; i < njobs; ++i) {
+        const RalfWgradJob& w = jobs[i];
+        RALF_REQUIRE(w.dy && w.x && w.dw && w.rows > 0 && w.rows % 64 == 0 && w.rows < (1ll << 31), "wgrad_grouped: job %d: rows %lld must be a positive multiple of 64", i, (long long)w.rows);
+        RALF_REQUIRE(w.n_out >= 8 && w.n_in >= 8 && w.n_out % 8 == 0 && w.n_in % 8 == 0 && w.ld_dy % 8 == 0 && w.ld_x % 8 == 0 && w.ld_dw % 8 == 0,
+                     "wgrad_grouped: job %d: dimensions and leading dimensions must be multiples of 8", i);
+        RALF_REQUIRE(((uintptr_t)w.dy % 16) == 0 && ((uintptr_t)w.x % 16) == 0 && ((uintptr_t)w.dw % 16) == 0, "wgrad_grouped: job %d: operands must be 16-byte aligned", i);
+    }
+    return ralf_gemm_grouped_bf16(jobs, njobs, workspace, workspace_bytes, (hipStream_t)stream);
+}

@@ -6,3 +6,50 @@ int ralf_gemm_reduce_bf16(void* kparams, int nbatch, int blocks, hipStream_t st)
     hipLaunchKernelGGL((splitk_reduce_kernel<bf16>), dim3(blocks), dim3(256), 0, st, *(KParams*)kparams, nbatch);
     return ralf::check_launch("gemm splitk reduce");
 }
+
+// ---- grouped weight gradients (ralf_wgrad_grouped) ----
+// jobs: RalfWgradJob records; launched in chunks of GROUP_MAX jobs: one gemm_grouped_kernel (128x128 tiles, 8 waves) and, when
+// some job splits its reduction, one gemm_grouped_reduce_kernel per chunk.
+int ralf_gemm_grouped_bf16(const void* jobs_v, int njobs, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    const RalfWgradJob* jobs = (const RalfWgradJob*)jobs_v;
+    float* ws = (float*)workspace;
+    size_t ws_used = 0;
+    for (int j0 = 0; j0 < njobs; j0 += GROUP_MAX) {
+        const int n = std::min(GROUP_MAX, njobs - j0);
+        GParams G;
+        GRedParams R;
+        G.njobs = n;
+        R.njobs = 0;
+        int first = 0, rfirst = 0;
+        for (int i = 0; i < n; ++i) {
+            const RalfWgradJob& w = jobs[j0 + i];
+            GJob& J = G.j[i];
+            J.A = w.dy; J.B = w.x; J.C = w.dw; J.partial = nullptr;
+            J.M = w.n_out; J.N = w.n_in; J.K = (int)w.rows; J.lda = (int)w.ld_dy; J.ldb = (int)w.ld_x; J.ldc = (int)w.ld_dw;
+            const int ktiles = J.K / 64;
+            int sk = w.splitk < 1 ? 1 : (w.splitk > ktiles ? ktiles : w.splitk);
+            J.kchunk = ceil_div(ktiles, sk) * 64;
+            J.splitk = sk = ceil_div(J.K, J.kchunk);
+            J.tiles_n = ceil_div(J.N, 128);
+            J.nwg = ceil_div(J.M, 128) * J.tiles_n;
+            J.first = first;
+            J.pad = 0;
+            first += J.nwg * sk;
+            if (sk > 1) {
+                const size_t need = (size_t)sk * J.M * J.N;
+                if ((ws_used + need) * sizeof(float) > workspace_bytes) {
+                    ralf::set_error("wgrad_grouped: split-K workspace too small (%zu bytes)", workspace_bytes);
+                    return RALF_ERR_WORKSPACE;
+                }
+                J.partial = ws + ws_used;
+                ws_used += need;
+                GRed& r = R.j[R.njobs++];
+                r.partial = J.partial; r.C = J.C; r.per = (int64_t)J.M * J.N; r.ldc = J.ldc; r.N = J.N; r.splitk = sk; r.first = rfirst;
+                rfirst += ceil_div(r.per, 2048);
+            }
+        }
+        hipLaunchKernelGGL((gemm_grouped_kernel<bf16, 2, 2, 8>), dim3(first), dim3(512), 0, st, G);
+        if (R.njobs) hipLaunchKernelGGL(gemm_grouped_reduce_kernel, dim3(rfirst), dim3(256), 0, st, R);
+    }
+    return ralf::check_launch("wgrad_grouped");
+}

@@ -394,23 +394,33 @@ __device__ __forceinline__ void lds_stage(T* l, const u32x4 (&regs)[NV], int tid
 // GATHER: 0 none, 1 = A (k-contiguous) is an im2col matrix, 2 = B (row-contiguous) is an im2col matrix.
 // FM, FN: 32x32 fragments per wave along m / n  ->  workgroup tile (64*FM) x (64*FN).
 // NW: waves per workgroup, 4 (2 x 2 waves, FM x FN fragments each) or 8 (2 x 4 waves, FM x FN/2 fragments each; FN = 2 only)
-template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_kernel(const KParams P) {
+// LDS bytes of one workgroup: the operand tiles, re-used as the fp32 C staging tile [64][BN + 4] of the epilogue
+template <typename T, bool AK, bool BKC, int FM, int FN>
+constexpr int gemm_lds_bytes() {
+    using X = TT<T>;
+    constexpr int BM = 64 * FM, BN = 64 * FN, BK = X::BK;
+    constexpr int A_ELEMS = AK ? BM * X::LDK : BK * (BM + X::RPAD);
+    constexpr int B_ELEMS = BKC ? BN * X::LDK : BK * (BN + X::RPAD);
+    constexpr int ops = (A_ELEMS + B_ELEMS) * (int)sizeof(T), cst = 64 * (BN + 4) * 4;
+    return ops > cst ? ops : cst;
+}
+
+// the body of one workgroup: output tiles bid0, bid0 + grid_x, ... of batch entry z (grid_x matters only for persistent
+// launches).  Called by gemm_kernel (one problem per launch) and gemm_grouped_kernel (many problems per launch).
+template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW>
+__device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, const int grid_x, const int z, const int nbatch, unsigned char* lds_raw) {
     using X = TT<T>;
     constexpr int VEC = X::VEC, BK = X::BK;
     constexpr int BM = 64 * FM, BN = 64 * FN;
     constexpr int LDRA = BM + X::RPAD, LDRB = BN + X::RPAD;
     constexpr int A_ELEMS = AK ? BM * X::LDK : BK * LDRA;
-    constexpr int B_ELEMS = BKC ? BN * X::LDK : BK * LDRB;
     constexpr int KV = BK / VEC;                                   // vectors along k (k-contiguous tile)
     constexpr int RVA = BM / VEC, RVB = BN / VEC;                  // vectors along rows (row-contiguous tile)
     constexpr int NT = 64 * NW, WGN = NW / 2;                       // threads; waves along n (2 along m)
     constexpr int WFM = FM, WFN = FN * 2 / WGN;                    // 32x32 fragments per wave
     static_assert(NW == 4 || (NW == 8 && FN == 2), "8 waves: 2 x 4 over a 128-wide tile");
-    constexpr int NVA = BM * BK / VEC / NT, NVB = BN * BK / VEC / NT;  // 16-byte vectors per thread per k-tile  // 16-byte vectors per thread per k-tile
+    constexpr int NVA = BM * BK / VEC / NT, NVB = BN * BK / VEC / NT;  // 16-byte vectors per thread per k-tile
     constexpr int CP = BN + 4;                                     // fp32 C staging tile [64][CP] (epilogue)
-    constexpr int LDS_BYTES = (A_ELEMS + B_ELEMS) * (int)sizeof(T) > 64 * CP * 4 ? (A_ELEMS + B_ELEMS) * (int)sizeof(T) : 64 * CP * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];   // ONE LDS object (operand tiles, then the C staging tile)
     T* la = reinterpret_cast<T*>(lds_raw);
     T* lb = la + A_ELEMS;
     const RalfGemmDesc& d = P.d;
@@ -434,7 +444,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_kernel(const KP
     // PMC FETCH_SIZE showed 11 GB per step fetched by the weight-gradient GEMMs for 4.5 GB of operands.)  gridDim.x is a
     // multiple of 8 whenever a workgroup owns more than one tile, so all tiles of a workgroup map to its own XCD's range.
     const int total = P.nwg * d.splitk;
-    const int z = blockIdx.z, z0 = z % d.nb0, z1 = z / d.nb0;
+    const int z0 = z % d.nb0, z1 = z / d.nb0;
     const T* Ap = (const T*)d.A + z0 * d.sA0 + z1 * d.sA1;
     const T* Bp = (const T*)d.B + z0 * d.sB0 + z1 * d.sB1;
     const bool a_al = (d.lda % VEC == 0) && (((uintptr_t)Ap & 15) == 0);
@@ -601,10 +611,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_kernel(const KP
     //  and the layer1 3x3 convolutions got 20 % slower with distance 2)
     constexpr int PF = (GATHER == 1 && FM == 1) ? 1 : 2;
     RALF_PROBE(1);
-    setup(blockIdx.x);
+    setup(bid0);
     gload(ra0, rb0, kbeg);
     if (PF == 2 && nt > 1) gload(ra1, rb1, kbeg + BK);
-    for (int bid = blockIdx.x;;) {
+    for (int bid = bid0;;) {
     const int c_m0 = m0, c_n0 = n0, c_split = split, c_kbeg = kbeg, c_nt = nt;   // the tile being COMPUTED
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -647,7 +657,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_kernel(const KP
         if (rem == 3) { __syncthreads(); stage0(); __syncthreads(); compute(); }
     }
     // the operands of this workgroup's next tile start their way while this tile's results are stored
-    const int nbid = bid + (int)gridDim.x;
+    const int nbid = bid + grid_x;
     const bool more = RALF_GEMM_PERSISTENT && nbid < total;
     if (more) {
         setup(nbid);
@@ -658,7 +668,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_kernel(const KP
     RALF_PROBE(3);
     // ---- epilogue: lane holds 4 consecutive columns n per register group g = r>>2 ----
     // (no `continue`/`break` in these loops: they must unroll completely or the accumulators spill to scratch)
-    const int nbatch = gridDim.z;
     const bool slab = d.splitk > 1 && !d.atomic_out;
     if (P.vec_epi >= 2 && c_n0 + BN <= d.N) {
         // tile interior in n: the accumulators go through LDS so every lane stores 8 consecutive columns of one row
@@ -749,6 +758,71 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_kernel(const KP
     bid = nbid;
     __syncthreads();   // the C staging tile shares the LDS with the operand tiles
     }
+}
+
+template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_kernel(const KParams P) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[gemm_lds_bytes<T, AK, BKC, FM, FN>()];   // ONE LDS object
+    gemm_body<T, AK, BKC, GATHER, FM, FN, EPI, NW>(P, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z, (int)gridDim.z, lds_raw);
+}
+
+// ---- grouped weight gradients ---------------------------------------------------------------------------------------
+// Many C_j[M_j, N_j] (fp32) += A_j^T B_j products in ONE launch: the weight gradients dW = dy^T x of several linear layers
+// (A_j = dy_j [K_j rows][M_j], B_j = x_j [K_j rows][N_j], both row-major as the activations are stored).  Every output tile is
+// owned by one workgroup that walks the whole reduction (or one k-split of it, into a slab), so the result is deterministic
+// and needs no atomics; with a few dozen layers per launch there are enough tiles without splitting the reduction of the
+// transformer-sized problems.  Job records travel by value in the kernel arguments (graph-capture friendly).
+struct GJob {
+    const void* A; const void* B; float* C; float* partial;
+    int M, N, K, lda, ldb, ldc, splitk, kchunk, tiles_n, nwg, first;   // first = first workgroup of the job
+    int pad;
+};
+constexpr int GROUP_MAX = 48;
+struct GParams { int njobs; int pad[3]; GJob j[GROUP_MAX]; };
+
+template <typename T, int FM, int FN, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_grouped_kernel(const GParams G) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[gemm_lds_bytes<T, false, false, FM, FN>()];
+    const int b = (int)blockIdx.x;
+    int ji = 0;
+    while (ji + 1 < G.njobs && b >= G.j[ji + 1].first) ++ji;   // (uniform: scalar loads from the kernel arguments)
+    const GJob& J = G.j[ji];
+    KParams P;
+    RalfGemmDesc& d = P.d;
+    d.A = J.A; d.B = J.B; d.C = J.C; d.C2 = nullptr; d.bias = nullptr; d.res = nullptr; d.aux = nullptr;
+    d.lda = J.lda; d.ldb = J.ldb; d.ldc = J.ldc; d.ldr = 0;
+    d.sA0 = d.sA1 = d.sB0 = d.sB1 = d.sC0 = d.sC1 = d.sR0 = d.sR1 = 0;
+    d.M = J.M; d.N = J.N; d.K = J.K; d.nb0 = d.nb1 = 1;
+    d.dtype = RALF_BF16; d.a_kcontig = 0; d.b_kcontig = 0; d.gather = 0;
+    d.act = 0; d.aux_mode = 0; d.out_f32 = 1; d.accumulate = 1; d.splitk = J.splitk;
+    d.alpha = 1.f; d.aux_scale = 1.f; d.seed = nullptr; d.call_id = 0; d.drop_p = 0.f; d.atomic_out = 0; d.colstats = nullptr;
+    d.sBias0 = 0; d.sBk = 0; d.kseg = 0;
+    P.tiles_n = J.tiles_n; P.tiles_m = J.nwg / J.tiles_n; P.nwg = J.nwg; P.kchunk = J.kchunk; P.partial = J.partial;
+    P.vec_epi = 2; P.fast = 1; P.tapuni = 0;
+    gemm_body<T, false, false, 3, FM, FN, 0, NW>(P, b - J.first, 1, 0, 1, lds_raw);
+}
+
+// C_j += sum over the k-splits of job j's slabs (jobs with splitk > 1 only); first = first workgroup, 2048 outputs per workgroup
+struct GRed { const float* partial; float* C; int64_t per; int ldc, N, splitk, first; };
+struct GRedParams { int njobs; int pad[3]; GRed j[GROUP_MAX]; };
+__global__ __launch_bounds__(256) void gemm_grouped_reduce_kernel(const GRedParams G) {
+    const int b = (int)blockIdx.x;
+    int ji = 0;
+    while (ji + 1 < G.njobs && b >= G.j[ji + 1].first) ++ji;
+    const GRed& J = G.j[ji];
+    const int64_t e0 = ((int64_t)(b - J.first) * 256 + threadIdx.x) * 8;
+    if (e0 >= J.per) return;
+    float a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = 0.f;
+    for (int sp = 0; sp < J.splitk; ++sp) {   // slabs in split order: deterministic
+        const float4 lo = *reinterpret_cast<const float4*>(J.partial + (int64_t)sp * J.per + e0), hi = *reinterpret_cast<const float4*>(J.partial + (int64_t)sp * J.per + e0 + 4);
+        a[0] += lo.x; a[1] += lo.y; a[2] += lo.z; a[3] += lo.w; a[4] += hi.x; a[5] += hi.y; a[6] += hi.z; a[7] += hi.w;
+    }
+    float* c = J.C + (e0 / J.N) * J.ldc + (e0 % J.N);   // N % 8 == 0: the 8 outputs share a row
+    float4 lo = *reinterpret_cast<float4*>(c), hi = *reinterpret_cast<float4*>(c + 4);
+    lo.x += a[0]; lo.y += a[1]; lo.z += a[2]; lo.w += a[3]; hi.x += a[4]; hi.y += a[5]; hi.z += a[6]; hi.w += a[7];
+    *reinterpret_cast<float4*>(c) = lo; *reinterpret_cast<float4*>(c + 4) = hi;
 }
 
 template <typename T>
@@ -885,3 +959,4 @@ int ralf_gemm_dispatch_f32(void* kparams, int nbatch, hipStream_t st);
 int ralf_gemm_dispatch_bf16(void* kparams, int nbatch, hipStream_t st);
 int ralf_gemm_reduce_f32(void* kparams, int nbatch, int blocks, hipStream_t st);
 int ralf_gemm_reduce_bf16(void* kparams, int nbatch, int blocks, hipStream_t st);
+int ralf_gemm_grouped_bf16(const void* jobs, int njobs, void* workspace, size_t workspace_bytes, hipStream_t st);

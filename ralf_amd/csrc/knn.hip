@@ -8,14 +8,16 @@
 //      bit-for-bit the ascending-d fmaf chain of oracle/knn_oracle.c, so scores are bit-exact.
 //      The index is streamed from HBM exactly once per query tile; X/Q k-tiles are staged
 //      global -> registers -> LDS (rotated rows: conflict-free ds_read_b32 fragment reads).
-//   2. selection.  k <= 64 and N <= 65536 (every shipped index): knn_select_wide_kernel, ONE launch of one 1024-thread
-//      workgroup per query over the whole score row -- a lower bound of the k-th best from two reductions (minimum over >= k
-//      disjoint thread groups of the group maxima), the few dozen survivors ranked exactly by counting.  Otherwise
-//      knn_select_kernel per 8192-score segment (exact k-th-largest by bisection over the 32 order-preserving key bits,
-//      +13 position bits for ties) and merge rounds.  Both give (score desc, index asc), bit-identical.
-//    (Measured and dropped: the selection fused into the scan's epilogue -- per-workgroup top-k of the [queries x 128..256 rows]
-//     tile in LDS, no score matrix.  A wave-level exact top-16 of 128 costs thousands of dependent scalar/vector round trips
-//     per query: the scan got 14-23 us slower at nq = 16-32 and 39 % slower at nq = 1024, more than the selection launches cost.)
+//   2. selection: knn_select_kernel per 8192-score segment (lower bound of the k-th best from the per-thread maxima, the few
+//      survivors ranked exactly by counting; exact bisection over the 32 order-preserving key bits + 13 position bits for
+//      mass ties).  k <= 64 and <= 64 segments (every shipped index): the segment lists of a query are merged by the last
+//      workgroup of that query to finish (agent-scope release / ticket / acquire), i.e. ONE launch for the whole selection;
+//      otherwise merge rounds with the same kernel.  Result order (score desc, index asc), bit-identical on all paths.
+//    Measured and dropped (MI355X, 61548 x 1792, k = 16): (a) the selection fused into the scan's epilogue -- per-workgroup
+//    top-k of the [queries x 128..256 rows] tile in LDS, no score matrix: a wave-level exact top-16 of 128 is thousands of
+//    dependent scalar/vector round trips per query, the scan got 14-23 us slower at nq = 16-32 and 39 % slower at nq = 1024;
+//    (b) one 1024-thread workgroup per query over the whole score row: a single CU pulls ~25 GB/s, 17-19 us per launch vs
+//    16 us for the two launches it replaced.
 #include "common.h"
 
 namespace {
@@ -199,73 +201,58 @@ __device__ __forceinline__ int block_sum(int v, int* red, int& slot) {
     return s;
 }
 
-// One workgroup selects the top-k of `cnt` (<= SEG) entries of query blockIdx.y, list blockIdx.x.
-//   FROM_SCORES: entries are S[q][base + p], index = base + p
-//   else       : entries are (cs, ci)[q][base + p] candidate lists; equal scores appear in ascending
-//                index order, so "lower position wins" == "lower index wins" in both modes.
-// Output list (sorted by score desc, index asc; padded with (-inf,-1)): os/oi[q][blockIdx.x][k].
+// Winners of one list held in registers: key[i] of thread t is the entry at position t + 256*i (0 = no entry).
+// On return wkey/wpos[0..nw) hold every entry that can be in the top-k (exactly min(k, #valid) of them on the bisection
+// path, a few more on the fast path); the caller ranks them.  Ends with a barrier.
 //
 // Fast path: the k-th largest of the 256 per-thread maxima is a lower bound L of the k-th largest
 // key, so only keys >= L (a few more than k on non-degenerate data) are candidates; they are ranked
 // exactly by counting.  Degenerate inputs (more than KMAX candidates: massive ties) or k > 256 take
 // the exact bisection over all SEG keys instead.  Both paths give identical results.
-template <bool FROM_SCORES>
-__global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict__ S, const float* __restrict__ cs,
-                                                          const int64_t* __restrict__ ci, int64_t in_stride, int64_t in_count,
-                                                          int64_t per_wg, int k, float* __restrict__ os, int64_t* __restrict__ oi) {
-    __shared__ int red[8];
-    __shared__ uint32_t wkey[KMAX];
-    __shared__ int wpos[KMAX];
-    __shared__ uint32_t tmax[256];
-    __shared__ int wcnt;
-    __shared__ uint32_t bound;
+struct SelLds {
+    int red[8];
+    uint32_t wkey[KMAX];
+    int wpos[KMAX];
+    uint32_t tmax[256];
+    int wcnt;
+    uint32_t bound;
+    int last;
+};
+__device__ __forceinline__ int select_winners(const uint32_t (&key)[EPT], int k, SelLds& L_) {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int q = blockIdx.y, lst = blockIdx.x, nlst = gridDim.x;
-    const int64_t base = (int64_t)lst * per_wg;
-    int64_t rem = in_count - base;
-    const int cnt = (int)(rem < per_wg ? rem : per_wg);
-    const float* src = (FROM_SCORES ? S : cs) + (int64_t)q * in_stride + base;
-    float* so = os + ((int64_t)q * nlst + lst) * k;
-    int64_t* io = oi + ((int64_t)q * nlst + lst) * k;
-
-    uint32_t key[EPT];
     uint32_t mx = 0;
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-        const int p = tid + 256 * i;  // position (coalesced loads)
-        key[i] = (p < cnt) ? f2key(src[p]) : 0u;
-        mx = key[i] > mx ? key[i] : mx;
-    }
-    tmax[tid] = mx;
-    if (tid == 0) wcnt = 0;
+    for (int i = 0; i < EPT; ++i) mx = key[i] > mx ? key[i] : mx;
+    L_.tmax[tid] = mx;
+    if (tid == 0) L_.wcnt = 0;
     __syncthreads();
     if (tid < 64) {  // wave 0: L = k-th largest thread maximum (0 if fewer than k non-empty threads)
         uint32_t L = 0;
         if (k <= 256) {
-            const uint32_t m0 = tmax[lane], m1 = tmax[lane + 64], m2 = tmax[lane + 128], m3 = tmax[lane + 192];
+            const uint32_t m0 = L_.tmax[lane], m1 = L_.tmax[lane + 64], m2 = L_.tmax[lane + 128], m3 = L_.tmax[lane + 192];
             for (int bit = 31; bit >= 0; --bit) {
                 const uint32_t t = L | (1u << bit);
                 const int c = __popcll(__ballot(m0 >= t)) + __popcll(__ballot(m1 >= t)) + __popcll(__ballot(m2 >= t)) + __popcll(__ballot(m3 >= t));
                 if (c >= k) L = t;
             }
         }
-        if (lane == 0) bound = L;
+        if (lane == 0) L_.bound = L;
     }
     __syncthreads();
-    const uint32_t L = bound;
+    const uint32_t L = L_.bound;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         if (key[i] >= L && key[i] != 0u) {
-            const int s = atomicAdd(&wcnt, 1);
-            if (s < KMAX) { wkey[s] = key[i]; wpos[s] = tid + 256 * i; }
+            const int s = atomicAdd(&L_.wcnt, 1);
+            if (s < KMAX) { L_.wkey[s] = key[i]; L_.wpos[s] = tid + 256 * i; }
         }
     }
     __syncthreads();
-    int nw = wcnt;
+    int nw = L_.wcnt;
     if (nw > KMAX) {
         // ---- exact bisection over all keys: largest T with |{key >= T}| >= k ----
         __syncthreads();
-        if (tid == 0) wcnt = 0;
+        if (tid == 0) L_.wcnt = 0;
         int slot = 0;
         uint32_t T = 0;
         for (int bit = 31; bit >= 0; --bit) {
@@ -273,13 +260,13 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict
             int c = 0;
 #pragma unroll
             for (int i = 0; i < EPT; ++i) c += (key[i] >= t);
-            if (block_sum(c, red, slot) >= k) T = t;
+            if (block_sum(c, L_.red, slot) >= k) T = t;
         }
         int cgt = 0, ceq = 0;
 #pragma unroll
         for (int i = 0; i < EPT; ++i) { cgt += (key[i] > T); ceq += (key[i] == T); }
-        cgt = block_sum(cgt, red, slot);
-        ceq = block_sum(ceq, red, slot);
+        cgt = block_sum(cgt, L_.red, slot);
+        ceq = block_sum(ceq, L_.red, slot);
         const int need = k - cgt;  // entries equal to T to keep, lowest positions first
         int P = SEG;               // keep key == T entries with position <= P
         if (need < ceq) {          // smallest P with |{key == T, pos <= P}| >= need (13 position bits)
@@ -289,7 +276,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict
                 int c = 0;
 #pragma unroll
                 for (int i = 0; i < EPT; ++i) c += (key[i] == T && (tid + 256 * i) <= t);
-                if (block_sum(c, red, slot) < need) lo = t;
+                if (block_sum(c, L_.red, slot) < need) lo = t;
             }
             P = lo + 1;
         }
@@ -297,20 +284,56 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict
         for (int i = 0; i < EPT; ++i) {
             const int p = tid + 256 * i;
             if (key[i] != 0u && (key[i] > T || (key[i] == T && p <= P))) {
-                const int s = atomicAdd(&wcnt, 1);
-                wkey[s] = key[i];
-                wpos[s] = p;
+                const int s = atomicAdd(&L_.wcnt, 1);
+                L_.wkey[s] = key[i];
+                L_.wpos[s] = p;
             }
         }
         __syncthreads();
-        nw = wcnt;  // == min(k, #valid) <= KMAX
+        nw = L_.wcnt;  // == min(k, #valid) <= KMAX
     }
+    return nw;
+}
+
+// One workgroup selects the top-k of `cnt` (<= SEG) entries of query blockIdx.y, list blockIdx.x.
+//   FROM_SCORES: entries are S[q][base + p], index = base + p
+//   else       : entries are (cs, ci)[q][base + p] candidate lists; equal scores appear in ascending
+//                index order, so "lower position wins" == "lower index wins" in both modes.
+// Output list (sorted by score desc, index asc; padded with (-inf,-1)): os/oi[q][blockIdx.x][k].
+//
+// FUSED_MERGE (FROM_SCORES, k <= 64, <= 64 lists): the segment lists of a query are merged by the LAST workgroup of that
+// query to finish -- one launch for the whole selection.  Hand-off: every wave drains its list stores, the workgroup's
+// lane 0 issues an agent-scope release, then takes a ticket on the query's counter (zeroed by a memset node ahead of the
+// launch); the workgroup that draws the last ticket issues one agent-scope acquire and reads the lists with plain loads.
+template <bool FROM_SCORES, bool FUSED_MERGE = false>
+__global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict__ S, const float* __restrict__ cs,
+                                                          const int64_t* __restrict__ ci, int64_t in_stride, int64_t in_count,
+                                                          int64_t per_wg, int k, float* __restrict__ os, int64_t* __restrict__ oi,
+                                                          unsigned int* __restrict__ tickets = nullptr, float* __restrict__ fs = nullptr,
+                                                          int64_t* __restrict__ fi = nullptr) {
+    __shared__ SelLds L_;
+    const int tid = threadIdx.x;
+    const int q = blockIdx.y, lst = blockIdx.x, nlst = gridDim.x;
+    const int64_t base = (int64_t)lst * per_wg;
+    int64_t rem = in_count - base;
+    const int cnt = (int)(rem < per_wg ? rem : per_wg);
+    const float* src = (FROM_SCORES ? S : cs) + (int64_t)q * in_stride + base;
+    float* so = os + ((int64_t)q * nlst + lst) * k;
+    int64_t* io = oi + ((int64_t)q * nlst + lst) * k;
+
+    uint32_t key[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int p = tid + 256 * i;  // position (coalesced loads)
+        key[i] = (p < cnt) ? f2key(src[p]) : 0u;
+    }
+    int nw = select_winners(key, k, L_);
     // rank the nw candidates exactly; the best min(nw,k) are the output
     for (int i = tid; i < nw; i += 256) {
-        const uint32_t ki = wkey[i];
-        const int pi = wpos[i];
+        const uint32_t ki = L_.wkey[i];
+        const int pi = L_.wpos[i];
         int rank = 0;
-        for (int j = 0; j < nw; ++j) rank += better(wkey[j], wpos[j], ki, pi);
+        for (int j = 0; j < nw; ++j) rank += better(L_.wkey[j], L_.wpos[j], ki, pi);
         if (rank < k) {
             so[rank] = key2f(ki);
             io[rank] = FROM_SCORES ? (base + pi) : ci[(int64_t)q * in_stride + base + pi];
@@ -320,8 +343,45 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict
         so[i] = -__builtin_inff();
         io[i] = -1;
     }
+    if constexpr (FUSED_MERGE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its list stores have left
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned int t = __hip_atomic_fetch_add(tickets + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (t == (unsigned int)(nlst - 1));
+            if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            L_.last = last;
+        }
+        __syncthreads();
+        if (!L_.last) return;
+        // ---- merge the nlst lists of this query: nlst * k <= 4096 candidates, positions list-major ----
+        const int total = nlst * k;
+        const float* mcs = os + (int64_t)q * total;
+        const int64_t* mci = oi + (int64_t)q * total;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int p = tid + 256 * i;
+            key[i] = (p < total) ? f2key(mcs[p]) : 0u;
+        }
+        nw = select_winners(key, k, L_);
+        for (int i = tid; i < nw; i += 256) {
+            const uint32_t ki = L_.wkey[i];
+            const int pi = L_.wpos[i];
+            int rank = 0;
+            for (int j = 0; j < nw; ++j) rank += better(L_.wkey[j], L_.wpos[j], ki, pi);
+            if (rank < k) {
+                fs[(int64_t)q * k + rank] = key2f(ki);
+                fi[(int64_t)q * k + rank] = mci[pi];
+            }
+        }
+        for (int i = (nw < k ? nw : k) + tid; i < k; i += 256) {
+            fs[(int64_t)q * k + i] = -__builtin_inff();
+            fi[(int64_t)q * k + i] = -1;
+        }
+    }
 }
-
 
 // ---- two-stage search helpers ------------------------------------------------------------------------------------
 // final selection among per-query candidates: exact[q][j] is the score of index row cand[q][j]; the k best by
@@ -388,134 +448,6 @@ __global__ __launch_bounds__(256) void knn_rownorms_kernel(const float* __restri
     }
 }
 
-
-// ------------------------------------------------------------------------------------------
-// single-launch selection: one 1024-thread workgroup per query over a whole score row (cnt <= 1024 * EPT)
-// ------------------------------------------------------------------------------------------
-constexpr int WIDE_T = 1024;
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t < v ? t : v; }
-    return v;
-}
-
-// Bound: threads are dealt into G >= k disjoint groups (tid & (G-1), G a power of two <= 64); every non-empty group's maximum
-// is a distinct entry, so the minimum L over the groups is <= the k-th largest entry: only entries >= L can be in the top-k.
-// (An empty group makes L = 0 = "keep everything valid".)  On non-degenerate data a few dozen entries survive; more than KMAX
-// survivors (mass ties) take the exact bisection over all keys, like knn_select_kernel.
-__device__ __forceinline__ int block_sum_wide(int v, int* red, int& slot) {   // 16 waves; `slot` alternates: one barrier per call
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) red[slot * 16 + (threadIdx.x >> 6)] = v;
-    __syncthreads();
-    int s = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) s += red[slot * 16 + w];
-    slot ^= 1;
-    return s;
-}
-
-template <int EPT>
-__global__ __launch_bounds__(WIDE_T) void knn_select_wide_kernel(const float* __restrict__ S, int64_t stride, int cnt, int k, int G,
-                                                                 float* __restrict__ os, int64_t* __restrict__ oi) {
-    __shared__ uint32_t gmax[64];
-    __shared__ uint32_t wkey[KMAX];
-    __shared__ int wpos[KMAX];
-    __shared__ int wcnt;
-    __shared__ int red[32];
-    const int tid = threadIdx.x, lane = tid & 63, q = blockIdx.x;
-    const float* src = S + (int64_t)q * stride;
-    uint32_t key[EPT];
-    uint32_t mx = 0;
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-        const int p = tid + WIDE_T * i;
-        key[i] = (p < cnt) ? f2key(src[p]) : 0u;
-        mx = key[i] > mx ? key[i] : mx;
-    }
-    if (tid < 64) gmax[tid] = 0u;
-    if (tid == 0) wcnt = 0;
-    __syncthreads();
-    atomicMax(&gmax[tid & (G - 1)], mx);
-    __syncthreads();
-    const uint32_t L = wave_min_u32(lane < G ? gmax[lane] : 0xffffffffu);   // (every wave computes it: no second barrier)
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-        if (key[i] >= L && key[i] != 0u) {
-            const int s = atomicAdd(&wcnt, 1);
-            if (s < KMAX) { wkey[s] = key[i]; wpos[s] = tid + WIDE_T * i; }
-        }
-    }
-    __syncthreads();
-    int nw = wcnt;
-    if (nw > KMAX) {
-        // ---- exact bisection over all keys: largest T with |{key >= T}| >= k; ties at T resolved by position ----
-        __syncthreads();
-        if (tid == 0) wcnt = 0;
-        int slot = 0;
-        uint32_t T = 0;
-        for (int bit = 31; bit >= 0; --bit) {
-            const uint32_t t = T | (1u << bit);
-            int c = 0;
-#pragma unroll
-            for (int i = 0; i < EPT; ++i) c += (key[i] >= t);
-            if (block_sum_wide(c, red, slot) >= k) T = t;
-        }
-        int cgt = 0, ceq = 0;
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) { cgt += (key[i] > T); ceq += (key[i] == T); }
-        cgt = block_sum_wide(cgt, red, slot);
-        ceq = block_sum_wide(ceq, red, slot);
-        const int need = k - cgt;      // entries equal to T to keep, lowest positions first
-        int P = WIDE_T * EPT;          // keep key == T entries with position <= P
-        if (need < ceq) {              // smallest P with |{key == T, pos <= P}| >= need (17 position bits)
-            int lo = -1;
-            for (int bit = 16; bit >= 0; --bit) {
-                const int t = lo + (1 << bit);
-                int c = 0;
-#pragma unroll
-                for (int i = 0; i < EPT; ++i) c += (key[i] == T && (tid + WIDE_T * i) <= t);
-                if (block_sum_wide(c, red, slot) < need) lo = t;
-            }
-            P = lo + 1;
-        }
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            const int p = tid + WIDE_T * i;
-            if (key[i] != 0u && (key[i] > T || (key[i] == T && p <= P))) {
-                const int s = atomicAdd(&wcnt, 1);
-                wkey[s] = key[i];
-                wpos[s] = p;
-            }
-        }
-        __syncthreads();
-        nw = wcnt;  // == min(k, #valid) <= KMAX
-    }
-    float* so = os + (int64_t)q * k;
-    int64_t* io = oi + (int64_t)q * k;
-    for (int i = tid; i < nw; i += WIDE_T) {
-        const uint32_t ki = wkey[i];
-        const int pi = wpos[i];
-        int rank = 0;
-        for (int j = 0; j < nw; ++j) rank += better(wkey[j], wpos[j], ki, pi);
-        if (rank < k) { so[rank] = key2f(ki); io[rank] = pi; }
-    }
-    for (int i = (nw < k ? nw : k) + tid; i < k; i += WIDE_T) { so[i] = -__builtin_inff(); io[i] = -1; }
-}
-
-// one launch for the whole selection when a score row fits one wide workgroup and k <= 64; false = use the segment path
-static bool launch_select_wide(const float* S, int64_t N, int nq, int k, int64_t* out_idx, float* out_score, hipStream_t st) {
-    if (k > 64 || N > (int64_t)WIDE_T * 64) return false;
-    int G = 1;
-    while (G < k) G <<= 1;   // >= k groups, power of two, <= 64
-    const int ept = (int)((N + WIDE_T - 1) / WIDE_T);
-#define RALF_WIDE(E) hipLaunchKernelGGL((knn_select_wide_kernel<E>), dim3(nq), dim3(WIDE_T), 0, st, S, N, (int)N, k, G, out_score, out_idx)
-    if (ept <= 8) RALF_WIDE(8);
-    else if (ept <= 16) RALF_WIDE(16);
-    else if (ept <= 32) RALF_WIDE(32);
-    else RALF_WIDE(64);
-#undef RALF_WIDE
-    return true;
-}
 
 template <int MF, int TQ, int TR>
 int launch_scores(const float* X, int64_t N, int D, const float* Q, int nq, float* S, hipStream_t st) {
@@ -589,24 +521,21 @@ extern "C" size_t ralf_knn_topk_ip_workspace_bytes(int64_t N, int D, int nq, int
     (void)D;
     if (N <= 0 || nq <= 0 || k <= 0) return 0;
     SelectPlan p = plan_select(N, nq, k);
-    return align256((size_t)nq * N * sizeof(float)) + 2 * align256(p.cand_bytes) + 256;
+    return align256((size_t)nq * N * sizeof(float)) + 2 * align256(p.cand_bytes) + align256((size_t)nq * sizeof(unsigned int)) + 256;
 }
 
-// workspace for select alone = 2 candidate buffers
-extern "C" int ralf_knn_select(const float* S, int64_t N, int nq, int k, int64_t* out_idx, float* out_score, void* ws,
-                               size_t ws_bytes, void* stream) {
-    RALF_REQUIRE(S && out_idx && out_score, "knn_select: null pointer");
-    RALF_REQUIRE(N > 0 && nq > 0, "knn_select: empty problem");
-    RALF_REQUIRE(k >= 1 && k <= KMAX, "knn_select: k=%d outside [1,%d]", k, KMAX);
-    hipStream_t st = (hipStream_t)stream;
-    if (launch_select_wide(S, N, nq, k, out_idx, out_score, st)) return ralf::check_launch("knn_select");
+// workspace for select alone = 2 candidate buffers (+ 256 bytes of ticket counters per 64 queries at its end)
+static int select_impl(const float* S, int64_t N, int nq, int k, int64_t* out_idx, float* out_score, void* ws, size_t ws_bytes,
+                       hipStream_t st, bool tickets_zeroed) {
     SelectPlan p = plan_select(N, nq, k);
     if (p.nseg == 1) {
-        hipLaunchKernelGGL((knn_select_kernel<true>), dim3(1, nq), dim3(256), 0, st, S, nullptr, nullptr, N, N, (int64_t)SEG, k, out_score, out_idx);
+        hipLaunchKernelGGL((knn_select_kernel<true>), dim3(1, nq), dim3(256), 0, st, S, nullptr, nullptr, N, N, (int64_t)SEG, k, out_score, out_idx,
+                           (unsigned int*)nullptr, (float*)nullptr, (int64_t*)nullptr);
         return ralf::check_launch("knn_select");
     }
-    if (!ws || ws_bytes < 2 * align256(p.cand_bytes)) {
-        ralf::set_error("knn_select: workspace %zu < required %zu bytes", ws_bytes, 2 * align256(p.cand_bytes));
+    const size_t tick_bytes = align256((size_t)nq * sizeof(unsigned int));
+    if (!ws || ws_bytes < 2 * align256(p.cand_bytes) + tick_bytes) {
+        ralf::set_error("knn_select: workspace %zu < required %zu bytes", ws_bytes, 2 * align256(p.cand_bytes) + tick_bytes);
         return RALF_ERR_WORKSPACE;
     }
     char* w = (char*)ws;
@@ -616,7 +545,15 @@ extern "C" int ralf_knn_select(const float* S, int64_t N, int nq, int k, int64_t
         ci[i] = (int64_t*)(w + i * align256(p.cand_bytes));
         cs[i] = (float*)(ci[i] + (size_t)nq * p.nseg * k);
     }
-    hipLaunchKernelGGL((knn_select_kernel<true>), dim3((unsigned)p.nseg, nq), dim3(256), 0, st, S, nullptr, nullptr, N, N, (int64_t)SEG, k, cs[0], ci[0]);
+    if (k <= 64 && p.nseg <= 64) {   // one launch: the last workgroup of every query merges that query's segment lists
+        unsigned int* tickets = (unsigned int*)(w + 2 * align256(p.cand_bytes));
+        if (!tickets_zeroed && hipMemsetAsync(tickets, 0, (size_t)nq * sizeof(unsigned int), st) != hipSuccess) return ralf::check_launch("knn_select memset");
+        hipLaunchKernelGGL((knn_select_kernel<true, true>), dim3((unsigned)p.nseg, nq), dim3(256), 0, st, S, nullptr, nullptr, N, N, (int64_t)SEG, k, cs[0], ci[0],
+                           tickets, out_score, out_idx);
+        return ralf::check_launch("knn_select");
+    }
+    hipLaunchKernelGGL((knn_select_kernel<true>), dim3((unsigned)p.nseg, nq), dim3(256), 0, st, S, nullptr, nullptr, N, N, (int64_t)SEG, k, cs[0], ci[0],
+                       (unsigned int*)nullptr, (float*)nullptr, (int64_t*)nullptr);
     int cur = 0;
     int64_t nl = p.nseg;
     const int64_t group = SEG / k;  // lists merged per workgroup (>= 8 since k <= 1024)
@@ -624,11 +561,20 @@ extern "C" int ralf_knn_select(const float* S, int64_t N, int nq, int k, int64_t
         const int64_t nout = (nl + group - 1) / group;
         float* so = nout == 1 ? out_score : cs[cur ^ 1];
         int64_t* io = nout == 1 ? out_idx : ci[cur ^ 1];
-        hipLaunchKernelGGL((knn_select_kernel<false>), dim3((unsigned)nout, nq), dim3(256), 0, st, nullptr, cs[cur], ci[cur], nl * k, nl * k, group * k, k, so, io);
+        hipLaunchKernelGGL((knn_select_kernel<false>), dim3((unsigned)nout, nq), dim3(256), 0, st, nullptr, cs[cur], ci[cur], nl * k, nl * k, group * k, k, so, io,
+                           (unsigned int*)nullptr, (float*)nullptr, (int64_t*)nullptr);
         nl = nout;
         cur ^= 1;
     }
     return ralf::check_launch("knn_select");
+}
+
+extern "C" int ralf_knn_select(const float* S, int64_t N, int nq, int k, int64_t* out_idx, float* out_score, void* ws,
+                               size_t ws_bytes, void* stream) {
+    RALF_REQUIRE(S && out_idx && out_score, "knn_select: null pointer");
+    RALF_REQUIRE(N > 0 && nq > 0, "knn_select: empty problem");
+    RALF_REQUIRE(k >= 1 && k <= KMAX, "knn_select: k=%d outside [1,%d]", k, KMAX);
+    return select_impl(S, N, nq, k, out_idx, out_score, ws, ws_bytes, (hipStream_t)stream, false);
 }
 
 extern "C" int ralf_knn_topk_ip(const float* X, int64_t N, int D, const float* Q, int nq, int k, int64_t* out_idx,
@@ -643,7 +589,14 @@ extern "C" int ralf_knn_topk_ip(const float* X, int64_t N, int D, const float* Q
     RALF_REQUIRE(((uintptr_t)ws & 255) == 0, "knn_topk_ip: workspace must be 256-byte aligned");
     float* S = (float*)ws;
     const size_t soff = align256((size_t)nq * N * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    // the ticket counters of the selection's hand-off are zeroed AHEAD of the scan (a memset node between scan and selection
+    // would sit on the critical path)
+    SelectPlan p = plan_select(N, nq, k);
+    const bool fused = p.nseg > 1 && k <= 64 && p.nseg <= 64;
+    if (fused && hipMemsetAsync((char*)ws + soff + 2 * align256(p.cand_bytes), 0, (size_t)nq * sizeof(unsigned int), st) != hipSuccess)
+        return ralf::check_launch("knn_topk_ip memset");
     int rc = ralf_knn_scores(X, N, D, Q, nq, S, stream);
     if (rc) return rc;
-    return ralf_knn_select(S, N, nq, k, out_idx, out_score, (char*)ws + soff, ws_bytes - soff, stream);
+    return select_impl(S, N, nq, k, out_idx, out_score, (char*)ws + soff, ws_bytes - soff, st, fused);
 }

@@ -78,10 +78,23 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // 16 waves per workgroup, two rows in flight per wave: the kernel is latency-bound otherwise (a wave
 // walking 16 rows one after the other reached 1.2 TB/s), and fat workgroups keep the atomic count at
 // 2*cols per CU.
+// same counter-based generator as pointwise.hip / gemm_impl.h (the masks must agree with ralf_dropout)
+__device__ __forceinline__ uint32_t ln_rng24(uint64_t seed, uint64_t call, uint64_t idx) {
+    uint64_t z = seed + call * 0x9E3779B97F4A7C15ull + idx * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 40);
+}
+
+// dx_drop (optional): a second output = dropout mask (seed, call, p) applied to dx.  dx is the gradient of the residual stream in
+// front of this norm; the block that produced that stream is `x_prev + dropout(f(..))`, so its backward starts by masking dx --
+// here, while dx is in registers, instead of in a launch of its own.
 template <typename T, int NCH, int LNB_WAVES>
 __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
-                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, const T* __restrict__ skip, int rows) {
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, const T* __restrict__ skip, int rows,
+                                                      T* __restrict__ dx_drop, float p_drop, const int64_t* __restrict__ seed, uint64_t call) {
     constexpr int cols = NCH * 256;
     __shared__ float red[2][LNB_WAVES][cols];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -139,6 +152,18 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const T* __restr
                     if (skip) o[i] += sk[r][c][i];   // pre-norm residual: the skip branch's gradient joins here (no separate add kernel)
                 }
                 V4<T>::store(dx + (int64_t)(row0 + r) * cols + c * 256 + lane * 4, o);
+                if (dx_drop) {
+                    const uint64_t e0 = (uint64_t)(row0 + r) * cols + c * 256 + lane * 4, sd = (uint64_t)seed[0];
+                    const uint32_t thr = (uint32_t)(p_drop * 16777216.f);
+                    const float inv = 1.f / (1.f - p_drop);
+                    float m[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        // (mask the value as ralf_dropout would see it: rounded to T first)
+                        m[i] = ln_rng24(sd, call, e0 + i) >= thr ? (float)(T)o[i] * inv : 0.f;
+                    }
+                    V4<T>::store(dx_drop + (int64_t)(row0 + r) * cols + c * 256 + lane * 4, m);
+                }
             }
         }
     }
@@ -558,18 +583,92 @@ extern "C" int ralf_layernorm_fwd(int dtype, const void* x, const float* gamma, 
 /* dgamma/dbeta (fp32 [cols]) are ACCUMULATED into (caller zeroes or carries gradients); may be NULL.
  * skip (dtype [rows, cols], may be NULL) is added to dx: gradient of the residual branch x -> (LN(x), x) */
 extern "C" int ralf_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                                  void* dx, float* dgamma, float* dbeta, const void* skip, int rows, int cols, void* stream) {
+                                  void* dx, float* dgamma, float* dbeta, const void* skip, int rows, int cols,
+                                  void* dx_drop, float p_drop, const int64_t* seed, uint64_t call_id, void* stream) {
     RALF_REQUIRE(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
+    RALF_REQUIRE(!dx_drop || (seed && p_drop > 0.f && p_drop < 1.f), "layernorm_bwd: dx_drop needs a seed and 0 < p < 1");
     RALF_REQUIRE(rows > 0 && cols % 256 == 0 && cols <= 512, "layernorm_bwd: cols=%d must be 256 or 512", cols);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype, if (cols == 256)
-                   hipLaunchKernelGGL((ln_bwd_kernel<T, 1, 16>), dim3(grid_for(rows, 32, 256)), dim3(1024), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, (const T*)skip, rows);
+                   hipLaunchKernelGGL((ln_bwd_kernel<T, 1, 16>), dim3(grid_for(rows, 32, 256)), dim3(1024), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, (const T*)skip, rows, (T*)dx_drop, p_drop, seed, call_id);
                else
-                   hipLaunchKernelGGL((ln_bwd_kernel<T, 2, 8>), dim3(grid_for(rows, 16, 512)), dim3(512), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, (const T*)skip, rows););
+                   hipLaunchKernelGGL((ln_bwd_kernel<T, 2, 8>), dim3(grid_for(rows, 16, 512)), dim3(512), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, dgamma, dbeta, (const T*)skip, rows, (T*)dx_drop, p_drop, seed, call_id););
     return ralf::check_launch("layernorm_bwd");
 }
 
 /* out[c] += sum_r x[r*ld + c]   (fp32 accumulate into out) */
+// many column sums in one launch: job j = (matrix, rows, cols % 256 == 0); workgroup <-> (job, 256-column block, row chunk)
+struct CSJob { const bf16* x; float* out; int64_t ld; int rows, rpw, cb, first; };
+constexpr int CS_MAX = 64;
+struct CSParams { int njobs; int pad[3]; CSJob j[CS_MAX]; };
+__global__ __launch_bounds__(256) void colsum_grouped_kernel(const CSParams G) {
+    constexpr int TPR = 32, RPI = 8, N = 8;
+    __shared__ float red[RPI][TPR * N];
+    const int b = (int)blockIdx.x;
+    int ji = 0;
+    while (ji + 1 < G.njobs && b >= G.j[ji + 1].first) ++ji;
+    const CSJob& J = G.j[ji];
+    const int lb = b - J.first, cbi = lb % J.cb, rci = lb / J.cb;
+    const int tx = threadIdx.x % TPR, ty = threadIdx.x / TPR;
+    const int c = (cbi * TPR + tx) * N;
+    const int r0 = rci * J.rpw, r1 = min(J.rows, r0 + J.rpw);
+    float s[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) s[i] = 0.f;
+    int r = r0 + ty;
+    for (; r + 3 * RPI < r1; r += 4 * RPI) {
+        float v[4][N];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) VL<bf16>::load(J.x + (int64_t)(r + u * RPI) * J.ld + c, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < N; ++i) s[i] += v[u][i];
+    }
+    for (; r < r1; r += RPI) {
+        float v[N];
+        VL<bf16>::load(J.x + (int64_t)r * J.ld + c, v);
+#pragma unroll
+        for (int i = 0; i < N; ++i) s[i] += v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) red[ty][tx * N + i] = s[i];
+    __syncthreads();
+    {
+        const int j = threadIdx.x;   // 256 columns, 256 threads
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < RPI; ++w) t += red[w][j];
+        atomicAdd(J.out + cbi * TPR * N + j, t);
+    }
+}
+
+extern "C" int ralf_colsum_grouped(const RalfColsumJob* jobs, int njobs, int dtype, void* stream) {
+    RALF_REQUIRE(jobs && njobs > 0 && dtype == RALF_BF16, "colsum_grouped: bf16 jobs only");
+    for (int j0 = 0; j0 < njobs; j0 += CS_MAX) {
+        const int n = njobs - j0 < CS_MAX ? njobs - j0 : CS_MAX;
+        CSParams G;
+        G.njobs = n;
+        int first = 0;
+        for (int i = 0; i < n; ++i) {
+            const RalfColsumJob& w = jobs[j0 + i];
+            RALF_REQUIRE(w.x && w.out && w.rows > 0 && w.cols > 0 && w.cols % 256 == 0 && w.ld % 8 == 0 && ((uintptr_t)w.x % 16) == 0,
+                         "colsum_grouped: job %d: cols %% 256, ld %% 8, 16-byte alignment", j0 + i);
+            CSJob& J = G.j[i];
+            J.x = (const bf16*)w.x; J.out = w.out; J.ld = w.ld; J.rows = w.rows; J.cb = w.cols / 256;
+            int rchunks = 32768 / w.cols;   // <= ~32 k same-address atomics per job (see ralf_colsum)
+            rchunks = rchunks < 16 ? 16 : (rchunks > 256 ? 256 : rchunks);
+            int rpw = ceil_div(w.rows, rchunks);
+            if (rpw < 32) rpw = 32;
+            J.rpw = rpw;
+            J.first = first;
+            first += J.cb * ceil_div(w.rows, rpw);
+        }
+        hipLaunchKernelGGL(colsum_grouped_kernel, dim3(first), dim3(256), 0, (hipStream_t)stream, G);
+    }
+    return ralf::check_launch("colsum_grouped");
+}
+
 extern "C" int ralf_colsum(int dtype, const void* x, int64_t ld, float* out, int rows, int cols, void* stream) {
     RALF_REQUIRE(x && out && rows > 0 && cols > 0, "colsum: bad arguments");
     hipStream_t st = (hipStream_t)stream;

@@ -242,6 +242,7 @@ class TrainStep:
         rt.direct_grads = True   # kernels accumulate parameter gradients straight into the flat buffer
         rt.overlap = overlap_wgrad  # ... on a side stream: a parallel branch of the captured graph
         rt.branches = os.environ.get("RALF_BRANCHES", "1") != "0"   # independent sub-networks on their own graph branches
+        rt.group_wgrads = os.environ.get("RALF_GROUP_WGRADS", "1") != "0"   # weight / bias gradients in grouped launches
         self.use_graph = use_graph
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if (process_group is not None or torch.distributed.is_initialized()) else 1

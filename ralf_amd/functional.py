@@ -42,6 +42,22 @@ class Runtime:
         self.branches = False
         self._branch_streams: dict = {}
         self._branch_keep: list = []
+        # engine mode (bf16): weight / bias gradients of the linear layers are COLLECTED during the backward and issued as grouped
+        # launches (ops.wgrad_grouped: every output tile walks its whole reduction, no split-K slabs, no reduce kernels; one
+        # column-sum launch for all bias gradients) whenever `group_tiles` output tiles are pending
+        self.group_wgrads = False
+        self.group_tiles = int(os.environ.get("RALF_WGRAD_GROUP_TILES", "160"))
+        self.group_target_wgs = int(os.environ.get("RALF_WGRAD_GROUP_WGS", "1024"))
+        self._wjobs: list = []
+        self._bjobs: list = []
+        self._wtiles = 0
+        self._main_stream = None
+        self._step_start = None
+        # y = res + dropout(f(x)) outputs are tagged with their mask (p, call); the LayerNorm that consumes y then also emits the
+        # MASKED gradient of y from its backward kernel, which the backward of f picks up instead of launching ralf_dropout
+        self._drop_tags: dict = {}
+        self._masked: dict = {}
+        self.ln_dropout = True
 
     def to(self, device):
         if self.seed is None or self.seed.device != device:
@@ -51,7 +67,15 @@ class Runtime:
     def begin_step(self):
         """start of a forward: restart the stream-id counter (the device seed distinguishes steps)."""
         self._call = 0
-        self._branch_keep.clear()   # (every branch entry first waits for all work issued so far: the previous step's consumers are ordered)
+        self._main_stream = torch.cuda.current_stream() if torch.cuda.is_available() else None
+        if self.branches and self._main_stream is not None:
+            # branches depend on the step's inputs only: they wait for THIS point of the main stream, not for whatever the main
+            # stream has been given by the time the branch is issued
+            self._step_start = torch.cuda.Event()
+            self._step_start.record(self._main_stream)
+        self._branch_keep.clear()
+        self._drop_tags.clear()
+        self._masked.clear()   # (every branch entry first waits for all work issued so far: the previous step's consumers are ordered)
 
     def advance_seed(self):
         self.seed.add_(0x9E3779B1)  # on-device: safe inside a captured graph
@@ -97,15 +121,89 @@ class Runtime:
             fn()
         self._keep.append(operands)
 
+    def tag_dropout(self, y: torch.Tensor, p: float, call: int):
+        if p > 0.0 and self.ln_dropout and torch.is_grad_enabled():
+            self._drop_tags[y.data_ptr()] = (p, call)
+
+    def dropout_tag(self, x: torch.Tensor):
+        return self._drop_tags.get(x.data_ptr())
+
+    def offer_masked(self, dx: torch.Tensor, call: int, dx_masked: torch.Tensor):
+        self._masked[dx.data_ptr()] = (call, dx_masked, dx)   # (dx itself is kept so that its address cannot be reused meanwhile)
+
+    def masked_grad(self, dy: torch.Tensor, p: float, call: int) -> torch.Tensor:
+        """dropout(dy) with the mask (p, call): taken from the LayerNorm backward that produced dy when it offered one"""
+        hit = self._masked.pop(dy.data_ptr(), None)
+        if hit is not None and hit[0] == call and hit[1].shape == dy.shape:
+            return hit[1]
+        return ops.dropout(dy, p, self.seed, call)
+
+    def defer_wgrad(self, dy2d, x2d, into) -> bool:
+        """queue dW (`into`, fp32 [n_out, n_in] view of the flat gradient buffer) += dy^T x for the next grouped launch; False when
+        the shapes do not fit the grouped kernel (the caller then issues the product itself)"""
+        rows, n_out = dy2d.shape
+        n_in = x2d.shape[1]
+        if not (self.group_wgrads and self.dtype == torch.bfloat16 and rows % 64 == 0 and n_out % 128 == 0 and n_in % 128 == 0
+                and dy2d.stride(1) == 1 and x2d.stride(1) == 1 and dy2d.stride(0) % 8 == 0 and x2d.stride(0) % 8 == 0
+                and dy2d.data_ptr() % 16 == 0 and x2d.data_ptr() % 16 == 0 and rows <= 65536):
+            return False
+        self._wjobs.append((dy2d, x2d, into.view(n_out, n_in), 1))
+        self._wtiles += (n_out // 128) * (n_in // 128)
+        if self._wtiles >= self.group_tiles:
+            self.flush_wgrads()
+        return True
+
+    def defer_bgrad(self, dy2d, into) -> bool:
+        if not (self.group_wgrads and self.dtype == torch.bfloat16 and dy2d.shape[1] % 256 == 0 and dy2d.stride(1) == 1 and dy2d.stride(0) % 8 == 0
+                and dy2d.data_ptr() % 16 == 0):
+            return False
+        self._bjobs.append((dy2d, into))
+        return True
+
+    def flush_wgrads(self):
+        """issue the queued weight / bias gradients (on the side stream when the engine overlaps them with the data-gradient chain)"""
+        wj, bj = self._wjobs, self._bjobs
+        if not (wj or bj):
+            return
+        # reduction splits: one workgroup sustains ~1 TFLOP/s on a 128x128 tile (measured), so a launch wants ~1000 workgroups;
+        # every split walks at least 2048 rows (slab traffic), tiny reductions stay whole
+        want = max(1, self.group_target_wgs // max(self._wtiles, 1))
+        wj = [(dy, x, dw, max(1, min(want, dy.shape[0] // 2048))) for dy, x, dw, _ in wj]
+        self._wjobs, self._bjobs, self._wtiles = [], [], 0
+
+        def run():
+            if wj:
+                ops.wgrad_grouped(wj)
+            if bj:
+                ops.colsum_grouped(bj)
+        if self.overlap and self.direct_grads:
+            if not self._side:
+                self._side = [torch.cuda.Stream() for _ in range(self.n_side)]
+            st = self._side[0]
+            st.wait_stream(torch.cuda.current_stream())
+            if self._main_stream is not None:         # operands were produced on the step's main stream or on a branch stream
+                st.wait_stream(self._main_stream)
+            for b in self._branch_streams.values():
+                st.wait_stream(b)
+            with torch.cuda.stream(st):
+                run()
+            self._keep.append((wj, bj))
+        else:
+            run()
+
     def join_side(self):
+        self.flush_wgrads()
         if self._side and self._keep:
             for st in self._side:
                 torch.cuda.current_stream().wait_stream(st)
             self._keep.clear()
 
     def branch(self, name: str):
-        """context manager: the enclosed forward work runs on the branch stream `name` (after everything issued so far);
-        call join_branch(name, outputs...) before consuming its outputs on the current stream."""
+        """context manager: the enclosed forward work runs on the branch stream `name`, ordered only after the START of the step
+        (begin_step): it must depend on nothing but the step's inputs and the weights.  Issue a branch LATE in program order
+        (just before its output is consumed): on the device it still starts with the step, and autograd -- which runs the
+        most recently recorded nodes first -- then starts its backward EARLY, beside the backward of the main branch, instead
+        of as a serial tail.  Call join_branch(name, outputs...) before consuming its outputs on the current stream."""
         return _Branch(self, name)
 
     def join_branch(self, name: str, *outputs):
@@ -204,7 +302,10 @@ class _Branch:
         st = rt._branch_streams.get(self.name)
         if st is None:
             st = rt._branch_streams[self.name] = torch.cuda.Stream()
-        st.wait_stream(torch.cuda.current_stream())
+        if rt._step_start is not None:
+            st.wait_event(rt._step_start)      # inputs and weights of this step are ready there
+        else:
+            st.wait_stream(torch.cuda.current_stream())
         self.ctx = torch.cuda.stream(st)
         self.ctx.__enter__()
         return self
@@ -232,6 +333,8 @@ def wgrad(dy2d, x2d, N, K, rows, into=None, rt=None):
     """dW[N,K] (fp32) = dy^T @ x, reduction over `rows` split across workgroups.  `into`: accumulate into this
     fp32 [N,K] view (flat gradient buffer) and return None."""
     if into is not None:
+        if rt is not None and rt.defer_wgrad(dy2d, x2d, into):
+            return None
         # (fp32 atomics straight into the buffer -- atomic=True -- were measured SLOWER than slabs + reduce:
         #  ~19 G atomics/s in L2 vs millions of adds per weight gradient: 29.6 -> 36.9 ms/step)
         def run():
@@ -247,6 +350,8 @@ def wgrad(dy2d, x2d, N, K, rows, into=None, rt=None):
 
 def bgrad(dy2d, rows, N, into=None, rt=None):
     if into is not None:
+        if rt is not None and rt.defer_bgrad(dy2d, into):
+            return None
         if rt is not None:
             rt.side(lambda: ops.colsum(dy2d, rows, N, out=into), into, dy2d)
         else:
@@ -273,6 +378,7 @@ class LinearFn(Function):
         ctx.save_for_backward(x2, W)
         ctx.bias, ctx.p, ctx.call = b, p, call
         ctx.rt, ctx.has_b, ctx.has_res, ctx.xshape, ctx.rows = rt, b is not None, res is not None, x.shape, (r0, r1)
+        rt.tag_dropout(y, p, call)
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -286,7 +392,7 @@ class LinearFn(Function):
         if dy2.dtype != rt.dtype:
             dy2 = ops.cast(dy2, rt.dtype)
         if ctx.p > 0.0:  # y = res + drop(xW^T + b): regenerate the mask on the incoming gradient
-            dy2 = ops.dropout(dy2, ctx.p, rt.seed, ctx.call)
+            dy2 = rt.masked_grad(dy2, ctx.p, ctx.call)
         nrow = dy2.shape[0]
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
@@ -332,6 +438,7 @@ class FFNFn(Function):
         ctx.save_for_backward(x2, W1, W2, h, z)
         ctx.b1, ctx.b2 = b1, b2
         ctx.rt, ctx.act, ctx.p, ctx.has_res, ctx.xshape, ctx.c2 = rt, act, p, res is not None, x.shape, c2
+        rt.tag_dropout(y, p, c2)
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -341,7 +448,7 @@ class FFNFn(Function):
         dy = dy.contiguous()
         dy2 = _2d(dy)
         if ctx.p > 0.0:
-            dy2 = ops.dropout(dy2, ctx.p, rt.seed, ctx.c2)   # mask of the output dropout
+            dy2 = rt.masked_grad(dy2, ctx.p, ctx.c2)   # mask of the output dropout
         rows, K = x2.shape
         Hd, N = W1.shape[0], W2.shape[0]
         if ctx.act == "gelu":
@@ -356,23 +463,35 @@ class FFNFn(Function):
         return dx, dW1, db1, dW2, db2, (dy if ctx.has_res else None), None, None, None
 
 
+def _ln_backward(ctx, dy, skip):
+    """shared backward of LayerNormFn / LayerNormSkipFn; when the normalised tensor came out of `res + dropout(..)` (tagged), the
+    kernel also writes the masked gradient that the producer's backward will ask for"""
+    x, g, mean, rstd = ctx.saved_tensors
+    rt = ctx.rt
+    gg, gb = rt.gview(g), rt.gview(ctx.beta)
+    drop = (ctx.tag[0], rt.seed, ctx.tag[1]) if ctx.tag is not None else None
+    into = (gg, gb) if (gg is not None and gb is not None) else None
+    out = ops.layernorm_bwd(dy.contiguous(), x, g.detach(), mean, rstd, need_wgrad=True, into=into, skip=skip, drop=drop)
+    dx = out[0]
+    if drop is not None:
+        rt.offer_masked(dx, ctx.tag[1], out[3])
+    if into is not None:
+        return dx, None, None
+    return dx, out[1], out[2]
+
+
 class LayerNormFn(Function):
     @staticmethod
     def forward(ctx, x, g, b, rt):
         xc = x.contiguous()
         y, mean, rstd = ops.layernorm_fwd(xc, g.detach(), b.detach())
         ctx.save_for_backward(xc, g, mean, rstd)
-        ctx.rt, ctx.beta = rt, b
+        ctx.rt, ctx.beta, ctx.tag = rt, b, rt.dropout_tag(xc)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, g, mean, rstd = ctx.saved_tensors
-        gg, gb = ctx.rt.gview(g), ctx.rt.gview(ctx.beta)
-        if gg is not None and gb is not None:
-            dx, _, _ = ops.layernorm_bwd(dy.contiguous(), x, g.detach(), mean, rstd, need_wgrad=True, into=(gg, gb))
-            return dx, None, None, None
-        dx, dg, db = ops.layernorm_bwd(dy.contiguous(), x, g.detach(), mean, rstd, need_wgrad=ctx.needs_input_grad[1])
+        dx, dg, db = _ln_backward(ctx, dy, None)
         return dx, dg, db, None
 
 
@@ -389,18 +508,13 @@ class LayerNormSkipFn(Function):
         xc = x.contiguous()
         y, mean, rstd = ops.layernorm_fwd(xc, g.detach(), b.detach())
         ctx.save_for_backward(xc, g, mean, rstd)
-        ctx.rt, ctx.beta = rt, b
+        ctx.rt, ctx.beta, ctx.tag = rt, b, rt.dropout_tag(xc)
         return y, xc.view_as(xc)
 
     @staticmethod
     def backward(ctx, dy, dskip):
-        x, g, mean, rstd = ctx.saved_tensors
-        gg, gb = ctx.rt.gview(g), ctx.rt.gview(ctx.beta)
         skip = dskip.contiguous() if dskip is not None else None
-        if gg is not None and gb is not None:
-            dx, _, _ = ops.layernorm_bwd(dy.contiguous(), x, g.detach(), mean, rstd, need_wgrad=True, into=(gg, gb), skip=skip)
-            return dx, None, None, None
-        dx, dg, db = ops.layernorm_bwd(dy.contiguous(), x, g.detach(), mean, rstd, need_wgrad=True, skip=skip)
+        dx, dg, db = _ln_backward(ctx, dy, skip)
         return dx, dg, db, None
 
 

@@ -542,15 +542,15 @@ class ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg(_GeneratorBas
     def _encode_into_memory(self, inputs: dict) -> dict:
         rt = self.rt.to(inputs["image"].device)
         assert inputs["image"].size(1) == 4
-        # three independent sub-networks start here; the two small ones are issued first, each on its own branch
-        cf = self._constraint_features(inputs)
+        # three independent sub-networks; the two small ones run on their own graph branches (Runtime.branch: issued late,
+        # started with the step)
+        mem = self._image_memory(inputs["image"])
         with rt.branch("retrieved"):
             ref = self._retrieved_features(inputs["retrieved"], inputs["image"].device)
-        mem = self._image_memory(inputs["image"])
         rt.join_branch("retrieved", ref)
         ca = self.attn(mem, ref, rt)
         fused = self.head(torch.cat([mem, ca, ref], dim=1), rt)  # sequence concat: plumbing copy
-        return {"memory": self._constraint_memory(fused, inputs, cf)}
+        return {"memory": self._constraint_memory(fused, inputs)}
 
 
 class _ScaleAddPE(torch.autograd.Function):
@@ -597,5 +597,4 @@ class ConcateAuxilaryTaskAutoreg(_GeneratorBase):
 
     def _encode_into_memory(self, inputs: dict) -> dict:
         self.rt.to(inputs["image"].device)
-        cf = self._constraint_features(inputs)
-        return {"memory": self._constraint_memory(self._image_memory(inputs["image"]), inputs, cf)}
+        return {"memory": self._constraint_memory(self._image_memory(inputs["image"]), inputs)}

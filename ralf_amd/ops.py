@@ -111,8 +111,9 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, save_stats=True):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, need_wgrad=True, into=None, skip=None):
-    """into = (dgamma, dbeta) fp32 views to ACCUMULATE into (flat gradient buffer)."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, need_wgrad=True, into=None, skip=None, drop=None):
+    """into = (dgamma, dbeta) fp32 views to ACCUMULATE into (flat gradient buffer).
+    drop = (p, seed, call_id): also return dropout(dx) with that mask as a 4th value."""
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
     dx = torch.empty_like(x)
     if into is not None:
@@ -120,7 +121,12 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, need_wgrad=True, into=None, skip=Non
     else:
         dg = torch.zeros(cols, dtype=torch.float32, device=x.device) if need_wgrad else None
         db = torch.zeros(cols, dtype=torch.float32, device=x.device) if need_wgrad else None
-    _call("ralf_layernorm_bwd", dtype_code(x), _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), _p(skip), rows, cols)
+    dxd = torch.empty_like(x) if drop is not None else None
+    p, seed, call = drop if drop is not None else (0.0, None, 0)
+    _call("ralf_layernorm_bwd", dtype_code(x), _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), _p(skip), rows, cols,
+          _p(dxd), p, _p(seed), call)
+    if drop is not None:
+        return dx, dg, db, dxd
     return dx, dg, db
 
 
@@ -198,6 +204,39 @@ def copy2d_acc(src, dst, rows, cols, lds, ldd):
     """dst[r*ldd + c] += src[r*lds + c] (fp32): a stacked result scattered into equally spaced views of a flat buffer"""
     assert src.dtype == torch.float32 and dst.dtype == torch.float32
     _call("ralf_copy2d", F32, F32, _p(src), _p(dst), rows, cols, lds, ldd, 1)
+
+
+def wgrad_grouped(jobs):
+    """jobs: list of (dy2d bf16 [rows, n_out], x2d bf16 [rows, n_in], dw fp32 view [n_out, n_in], splitk): dw += dy^T x for all jobs
+    in one launch (ralf_wgrad_grouped)."""
+    from ._abi import RalfWgradJob
+
+    arr = (RalfWgradJob * len(jobs))()
+    for r, (dy, x, dw, sk) in zip(arr, jobs):
+        rows, n_out = dy.shape
+        n_in = x.shape[1]
+        assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32 and x.shape[0] == rows
+        assert dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(1) == 1 and tuple(dw.shape) == (n_out, n_in)
+        r.dy, r.x, r.dw = dy.data_ptr(), x.data_ptr(), dw.data_ptr()
+        r.rows, r.ld_dy, r.ld_x, r.ld_dw = rows, dy.stride(0), x.stride(0), dw.stride(0)
+        r.n_out, r.n_in, r.splitk = n_out, n_in, sk
+    L = _lib.lib()
+    need = L.ralf_wgrad_grouped_workspace_bytes(arr, len(jobs))
+    ws = workspace(need, jobs[0][0].device) if need else None
+    rc = L.ralf_wgrad_grouped(arr, len(jobs), BF16, _p(ws), need, _lib.stream_ptr())
+    _lib.check(rc, "ralf_wgrad_grouped")
+
+
+def colsum_grouped(jobs):
+    """jobs: list of (x2d bf16 [rows, cols], out fp32 [cols]): out += column sums, all in one launch"""
+    from ._abi import RalfColsumJob
+
+    arr = (RalfColsumJob * len(jobs))()
+    for r, (x, out) in zip(arr, jobs):
+        assert x.dtype == torch.bfloat16 and out.dtype == torch.float32 and x.stride(1) == 1 and out.is_contiguous()
+        r.x, r.out, r.ld, r.rows, r.cols = x.data_ptr(), out.data_ptr(), x.stride(0), x.shape[0], x.shape[1]
+    rc = _lib.lib().ralf_colsum_grouped(arr, len(jobs), BF16, _lib.stream_ptr())
+    _lib.check(rc, "ralf_colsum_grouped")
 
 
 def permute4(x, out_dims, strides, valid3, dtype, out=None):

@@ -243,3 +243,25 @@ def test_stacked_cross_kv_projection_equals_per_layer_path(golden, dtype):
         p1, p2 = dict(m1.named_parameters())[k], dict(m2.named_parameters())[k]
         r = ((p1.grad - p2.grad).norm() / p2.grad.norm().clamp_min(1e-12)).item()
         assert r < (3e-2 if dtype == "bfloat16" else 1e-4), (k, r)
+
+
+def test_grouped_wgrads_and_branches_equal_plain_step(golden):
+    """engine modes: weight / bias gradients collected into grouped launches + independent sub-networks on their own graph
+    branches, against the plain one-launch-per-product, single-stream step: same loss, same flat gradient buffer (bf16)"""
+    from ralf_amd.engine import TrainStep
+
+    m1, inputs, tgt = make(golden, "bfloat16")
+    m2, _, _ = make(golden, "bfloat16")
+    a, b = TrainStep(m1, use_graph=False), TrainStep(m2, use_graph=False)
+    assert m1.rt.group_wgrads and m1.rt.branches
+    m2.rt.group_wgrads = m2.rt.branches = False
+    la, lb = a(inputs, tgt).item(), b(inputs, tgt).item()
+    torch.cuda.synchronize()
+    assert abs(la - lb) < 1e-4, (la, lb)
+    rel = ((a.opt.G - b.opt.G).norm() / b.opt.G.norm()).item()
+    assert rel < 2e-3, rel          # identical bf16 products, fp32 sums in a different order
+    for k in ("transformer_encoder.layers.2.linear1.weight", "transformer_encoder.layers.2.linear1.bias", "decoder.transformer.layers.4.multihead_attn.in_proj_weight",
+              "user_const_encoder.encoder.layers.0.self_attn.out_proj.weight", "head.net.4.weight"):
+        p1, p2 = dict(m1.named_parameters())[k], dict(m2.named_parameters())[k]
+        r = ((p1.grad - p2.grad).norm() / p2.grad.norm().clamp_min(1e-12)).item()
+        assert r < 2e-3, (k, r)

@@ -149,3 +149,38 @@ def test_every_case_on_a_forced_tile(tile):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "not forced_tile", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_grouped_weight_gradients_match_per_layer_products():
+    """ralf_wgrad_grouped / ralf_colsum_grouped: the weight and bias gradients of several linear layers in one launch each (tiles that
+    walk their whole reduction, and the slab + grouped-reduce form for long reductions) against fp32 matmuls of the same operands"""
+    from ralf_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(7)
+    shapes = [(16384, 768, 256, 1), (16384, 256, 1024, 1), (3200, 1024, 256, 1), (34048, 512, 256, 3), (256, 256, 256, 1), (1024, 128, 384, 2)]
+    jobs, refs, bjobs, brefs = [], [], [], []
+    flat = torch.randn(sum(n * k for _, n, k, _ in shapes) + 4096, device="cuda", generator=g)   # "the flat gradient buffer": accumulate into it
+    before = flat.clone()
+    off = 0
+    for rows, n_out, n_in, sk in shapes:
+        big = torch.randn(rows, n_out + 256, device="cuda", generator=g).bfloat16()
+        dy = big[:, 128:128 + n_out]                                   # a column slice: leading dimension != width
+        x = torch.randn(rows, n_in, device="cuda", generator=g).bfloat16()
+        dw = flat[off:off + n_out * n_in].view(n_out, n_in)
+        jobs.append((dy, x, dw, sk))
+        refs.append((off, dy.float().t() @ x.float()))
+        off += n_out * n_in
+        if n_out % 256 == 0:
+            db = torch.zeros(n_out, device="cuda")
+            bjobs.append((dy, db))
+            brefs.append(dy.float().sum(0))
+    ops.wgrad_grouped(jobs)
+    ops.colsum_grouped(bjobs)
+    torch.cuda.synchronize()
+    for (o, ref), (_, _, dw, _) in zip(refs, jobs):
+        got = dw - before[o:o + dw.numel()].view_as(dw)
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-5, err                                         # fp32 accumulation of exact bf16 products: summation order only
+    assert torch.equal(flat[off:], before[off:])                       # nothing written past the last job
+    for (_, db), ref in zip(bjobs, brefs):
+        assert ((db - ref).abs().max() / ref.abs().max()).item() < 2e-5

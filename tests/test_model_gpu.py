@@ -105,7 +105,9 @@ def test_ralf_cgl_e2e_fp32_vs_reference(golden):
     torch.testing.assert_close(feat.grad.cpu(), r["gfeat"], atol=2e-6, rtol=2e-3)
     named = dict(model.named_parameters())
     for k, g in r["grads"].items():
-        torch.testing.assert_close(thin(named[k].grad).cpu(), g, atol=3e-6, rtol=3e-3, msg=lambda m, k=k: f"{k}: {m}")
+        # (embedding rows of the task-c constraint sequence collect up to B*N label tokens through fp32 atomics: summation order)
+        atol = 2e-5 if k.endswith("emb.weight") else 6e-6
+        torch.testing.assert_close(thin(named[k].grad).cpu(), g, atol=atol, rtol=3e-3, msg=lambda m, k=k: f"{k}: {m}")
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)).float().cpu()
     torch.testing.assert_close(gn, r["gradnorm"], atol=1e-6, rtol=2e-3)
 
@@ -332,6 +334,29 @@ def test_train_mode_dropout_step_is_finite_and_seeded(golden):
     l2.backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     assert abs(l2.item() - r["loss"].item()) < 0.5
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_dropout_mask_from_layernorm_backward_equals_dropout_launch(golden, dtype):
+    """train mode, dropout on: the masked gradient written by the LayerNorm backward kernel (second output) is the one a separate
+    ralf_dropout launch on the same gradient produces -- gradients of the whole model agree to summation-order noise"""
+    r = golden("e2e.npz").sub("ralf_refinement")
+    grads = []
+    for fused in (True, False):
+        model = load_det(build(task="refinement", compute_dtype=dtype), "ralf_state_shapes.json").train()
+        model.rt.ln_dropout = fused
+        model.encoder = FeatStandIn(r["feat"].cuda())
+        inputs = to_dev(dict(r["inputs"]))
+        inputs["retrieved"] = to_dev(r["retrieved"])
+        inputs["image"] = torch.zeros(3, 4, 8, 8, device="cuda")
+        loss = model.train_loss(inputs, {"seq": r["targets"]["seq"].cuda()})[1]["nll_loss"]
+        loss.backward()
+        grads.append((loss.item(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    (l1, g1), (l2, g2) = grads
+    assert l1 == l2
+    for k in g1:
+        d = (g1[k] - g2[k]).abs().max().item()
+        assert d <= 1e-6 + 2e-5 * g2[k].abs().max().item(), (k, d)
 
 
 def test_retrieval_augmentation_block_matches_reference(golden):
