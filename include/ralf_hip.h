@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 7
+#define RALF_ABI_VERSION 9
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -129,6 +129,27 @@ typedef struct RalfGemmDesc {
 size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d);
 int ralf_gemm(const RalfGemmDesc* d, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Row-strip linear layer (ralf_amd/csrc/rowstrip.hip): y = epi(LN?(x) @ W^T) for W = nn.Linear.weight [N, K] (w_kcontig = 1) or
+ * y = epi(x @ W) for W [K, N] (w_kcontig = 0: the data gradient of that layer), bf16 operands, fp32 accumulate.  One workgroup
+ * owns 64 rows for the whole product (x read once, weights streamed), see the file header.
+ *   ln_gamma / ln_beta (fp32 [K], K = 256, forward only): LayerNorm(x) (eps ln_eps) is applied to the strip first; xln (bf16 [M, K]),
+ *     ln_mean / ln_rstd (fp32 [M]) receive the normalised rows and the statistics when given (the backward pass needs them)
+ *   epilogue order: +bias[n] (fp32), y2 = v (bf16 pre-activation copy), act, dropout(drop_p, seed, call_id; mask = ralf_dropout's on
+ *     the contiguous [M, N] output), aux mask (v = aux > 0 ? v * aux_scale : 0), +res, store bf16 (or fp32 when out_f32)
+ * K % 64 == 0, N % 8 == 0, leading dimensions % 8 == 0, 16-byte aligned pointers. */
+typedef struct RalfRsDesc {
+    const void* x; const void* w; void* y; void* y2;
+    const float* bias; const void* res; const void* aux;
+    void* xln; const float* ln_gamma; const float* ln_beta; float* ln_mean; float* ln_rstd;
+    const int64_t* seed;
+    int64_t ldx, ldw, ldy, ldr;
+    uint64_t call_id;
+    int M, N, K, w_kcontig, act, out_f32;
+    float drop_p, aux_scale, ln_eps;
+    int pad;
+} RalfRsDesc;
+int ralf_rs_gemm(const RalfRsDesc* d, void* stream);
+
 /* Weight gradients of MANY linear layers in one launch (the `dW += dy^T x` products autograd issues one by one for nn.Linear /
  * nn.MultiheadAttention in_proj / out_proj, e.g. 24 per encoder stack): job j adds dy_j^T x_j into the fp32 matrix dw_j.
  *   dy bf16 [rows, n_out] (leading dimension ld_dy), x bf16 [rows, n_in] (ld_x), dw fp32 [n_out, n_in] (ld_dw)
@@ -207,6 +228,15 @@ int ralf_dropout(int dtype, const void* x, const void* res, void* y, int64_t n, 
  * dlogits (dtype, may be NULL) = d loss / d logits */
 int ralf_xent_fwd_bwd(int dtype, const float* logits, const int64_t* target, void* dlogits, float* cnt_loss, int64_t rows, int V,
                       int ignore_index, float label_smoothing, void* stream);
+/* sequence concatenation of up to 4 sources [B, rows_i, d] into out [B, sum rows_i, d], each with an optional learned scalar added
+ * (torch.cat + the nn.Embedding(2, 1) flags of retrieval_augmented_autoreg.py:963-994,1022-1028); backward = 1: `out` is the
+ * gradient of the concatenation, src_i receive its pieces (contiguous) and dscalar_i[0] += the piece's sum. */
+int ralf_concat_rows(int dtype, int backward, int nsrc, const void* const* src, const int* rows, const float* const* scalar, float* const* dscalar,
+                     void* out, int B, int d, void* stream);
+/* y = dropout_p(x * scale + pe[r % S, :]) on [rows, d]: PositionalEncoding1d (common/positional_encoding.py:92-107) of the K retrieved
+ * features; pe fp32 [S, d] or NULL (the same call on a gradient with pe = NULL is the backward) */
+int ralf_scale_pe_dropout(int dtype, const void* x, const float* pe, void* y, int64_t rows, int S, int d, float scale, float p,
+                          const int64_t* seed, uint64_t call_id, void* stream);
 int ralf_add_scalar(int dtype, const void* x, const float* s, void* y, int64_t rows, int cols, int64_t ldx, int64_t ldy, void* stream);
 int ralf_sum_all(int dtype, const void* x, float* out, int64_t rows, int cols, int64_t ldx, void* stream);
 int ralf_copy2d(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t rows, int cols, int64_t lds, int64_t ldd, int accumulate, void* stream);

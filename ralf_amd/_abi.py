@@ -39,6 +39,13 @@ class RalfGemmDesc(ctypes.Structure):
     )
 
 
+class RalfRsDesc(ctypes.Structure):
+    _fields_ = ([(n, vp) for n in ("x", "w", "y", "y2", "bias", "res", "aux", "xln", "ln_gamma", "ln_beta", "ln_mean", "ln_rstd", "seed")]
+                + [(n, i64) for n in ("ldx", "ldw", "ldy", "ldr")] + [("call_id", ctypes.c_uint64)]
+                + [(n, i32) for n in ("M", "N", "K", "w_kcontig", "act", "out_f32")]
+                + [("drop_p", f32), ("aux_scale", f32), ("ln_eps", f32), ("pad", i32)])
+
+
 class RalfWgradJob(ctypes.Structure):
     _fields_ = [("dy", vp), ("x", vp), ("dw", vp), ("rows", i64), ("ld_dy", i64), ("ld_x", i64), ("ld_dw", i64),
                 ("n_out", i32), ("n_in", i32), ("splitk", i32), ("pad", i32)]
@@ -49,6 +56,7 @@ class RalfColsumJob(ctypes.Structure):
 
 
 SIGNATURES.update({
+    "ralf_rs_gemm": (i32, [ctypes.POINTER(RalfRsDesc), vp]),
     "ralf_wgrad_grouped_workspace_bytes": (sz, [ctypes.POINTER(RalfWgradJob), i32]),
     "ralf_wgrad_grouped": (i32, [ctypes.POINTER(RalfWgradJob), i32, i32, vp, sz, vp]),
     "ralf_colsum_grouped": (i32, [ctypes.POINTER(RalfColsumJob), i32, i32, vp]),
@@ -87,6 +95,8 @@ SIGNATURES.update({
     "ralf_embed_bwd": (i32, [i32, vp, vp, vp, i64, i32, f32, vp]),
     "ralf_dropout": (i32, [i32, vp, vp, vp, i64, f32, vp, u64, vp]),
     "ralf_xent_fwd_bwd": (i32, [i32, vp, vp, vp, vp, i64, i32, i32, f32, vp]),
+    "ralf_concat_rows": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "ralf_scale_pe_dropout": (i32, [i32, vp, vp, vp, i64, i32, i32, f32, f32, vp, u64, vp]),
     "ralf_add_scalar": (i32, [i32, vp, vp, vp, i64, i32, i64, i64, vp]),
     "ralf_sum_all": (i32, [i32, vp, vp, i64, i32, i64, vp]),
     "ralf_copy2d": (i32, [i32, i32, vp, vp, i64, i32, i64, i64, i32, vp]),

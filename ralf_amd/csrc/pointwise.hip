@@ -140,6 +140,86 @@ __global__ void sum_all_kernel(const T* __restrict__ x, float* __restrict__ out,
     if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+
+// ---- sequence concatenation [B, S_0 + S_1 + ..., d] of up to 4 sources [B, S_i, d], each with an optional learned scalar added
+// (the flag embedding nn.Embedding(2, 1) of retrieval_augmented_autoreg.py:1022-1028), and its backward: the gradient split back
+// into contiguous pieces + the scalars' gradients (sums).  One 16-byte vector per thread, no per-element index division.
+struct CatSrc { const void* p; const float* scalar; float* dscalar; int rows; int off; };   // rows per batch entry, first output row
+struct CatParams { CatSrc s[4]; int nsrc; int B; int total_rows; int vec_per_row; };
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void concat_rows_kernel(const CatParams P, void* out_v) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int vpr = P.vec_per_row;
+    const int64_t nvec = (int64_t)P.B * P.total_rows * vpr;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+        const int64_t row = v / vpr;                   // (one division per 16-byte vector)
+        const int c = (int)(v - row * vpr);
+        const int b = (int)(row / P.total_rows), r = (int)(row - (int64_t)b * P.total_rows);
+        int si = 0;
+#pragma unroll
+        for (int i = 1; i < 4; ++i) si += (i < P.nsrc && r >= P.s[i].off);
+        const CatSrc& S = P.s[si];
+        const int64_t sidx = (((int64_t)b * S.rows + (r - S.off)) * vpr + c) * VEC;
+        const int64_t oidx = v * VEC;
+        T tmp[VEC];
+        if (!BWD) {
+            *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>((const T*)S.p + sidx);
+            if (S.scalar) {
+                const float sv = S.scalar[0];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) tmp[i] = (T)((float)tmp[i] + sv);
+            }
+            *reinterpret_cast<uint4*>((T*)out_v + oidx) = *reinterpret_cast<uint4*>(tmp);
+        } else {   // out_v = the gradient of the concatenation (read), S.p = the piece's gradient (written)
+            *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>((const T*)out_v + oidx);
+            *reinterpret_cast<uint4*>((T*)const_cast<void*>(S.p) + sidx) = *reinterpret_cast<uint4*>(tmp);
+            if (S.dscalar) {
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) a += (float)tmp[i];
+                acc[si] += a;
+            }
+        }
+    }
+    if (BWD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < P.nsrc && P.s[i].dscalar) {
+                const float t = wave_sum(acc[i]);
+                if ((threadIdx.x & 63) == 0) atomicAdd(P.s[i].dscalar, t);
+            }
+        }
+    }
+}
+
+// y = dropout_p(x * scale + pe[r % S])  (PositionalEncoding1d on a [rows, d] tensor; pe fp32 [S, d] or NULL)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_pe_drop_kernel(const T* __restrict__ x, const float* __restrict__ pe, T* __restrict__ y, int64_t rows, int S, int d,
+                                                           float scale, float p, const int64_t* __restrict__ seed, uint64_t call) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int vpr = d / VEC;
+    const int64_t nvec = rows * vpr;
+    const uint64_t sd = p > 0.f ? (uint64_t)seed[0] : 0;
+    const uint32_t thr = (uint32_t)(p * 16777216.f);
+    const float inv = 1.f / (1.f - p);
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+        const int64_t row = v / vpr;
+        const int c = (int)(v - row * vpr) * VEC;
+        T tmp[VEC];
+        *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(x + v * VEC);
+        const float* pr = pe ? pe + (row % S) * d + c : nullptr;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float f = (float)tmp[i] * scale + (pr ? pr[i] : 0.f);
+            if (p > 0.f) f = rng24(sd, call, (uint64_t)(v * VEC + i)) >= thr ? (float)(T)f * inv : 0.f;   // mask the value as stored (ralf_dropout semantics)
+            tmp[i] = (T)f;
+        }
+        *reinterpret_cast<uint4*>(y + v * VEC) = *reinterpret_cast<uint4*>(tmp);
+    }
+}
+
 // strided 2-D copy with dtype conversion (concat / slice / cast): dst[r*ldd + c] = src[r*lds + c]
 template <typename TS, typename TD>
 __global__ void copy2d_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t rows, int cols, int64_t lds, int64_t ldd, int accumulate) {
@@ -485,6 +565,42 @@ extern "C" int ralf_sum_all(int dtype, const void* x, float* out, int64_t rows, 
     RALF_REQUIRE(x && out && rows > 0 && cols > 0, "sum_all: bad arguments");
     DISPATCH_T(dtype, hipLaunchKernelGGL((sum_all_kernel<T>), dim3(grid_for(rows * cols, 256, 256)), dim3(256), 0, ST, (const T*)x, out, rows, cols, ldx));
     return ralf::check_launch("sum_all");
+}
+
+/* out[b, off_i + r, :] = src_i[b, r, :] (+ scalar_i[0])  for up to 4 sources [B, rows_i, d] -> out [B, sum rows_i, d]  (backward = 0), or
+ * the reverse split of a gradient `out` into the pieces dsrc_i (+ dscalar_i[0] += sum of the piece) (backward = 1).  d * sizeof % 16 == 0. */
+extern "C" int ralf_concat_rows(int dtype, int backward, int nsrc, const void* const* src, const int* rows, const float* const* scalar, float* const* dscalar,
+                                void* out, int B, int d, void* stream) {
+    RALF_REQUIRE(nsrc >= 1 && nsrc <= 4 && src && rows && out && B > 0 && d > 0, "concat_rows: bad arguments");
+    const int vec = dtype == RALF_F32 ? 4 : 8;
+    RALF_REQUIRE(d % vec == 0 && ((uintptr_t)out % 16) == 0, "concat_rows: d %% %d and 16-byte alignment", vec);
+    CatParams P;
+    int off = 0;
+    for (int i = 0; i < 4; ++i) {
+        P.s[i].p = nullptr; P.s[i].scalar = nullptr; P.s[i].dscalar = nullptr; P.s[i].rows = 0; P.s[i].off = 0;
+        if (i < nsrc) {
+            RALF_REQUIRE(src[i] && rows[i] > 0 && ((uintptr_t)src[i] % 16) == 0, "concat_rows: source %d", i);
+            P.s[i].p = src[i]; P.s[i].rows = rows[i]; P.s[i].off = off;
+            P.s[i].scalar = (!backward && scalar) ? scalar[i] : nullptr;
+            P.s[i].dscalar = (backward && dscalar) ? dscalar[i] : nullptr;
+            off += rows[i];
+        }
+    }
+    P.nsrc = nsrc; P.B = B; P.total_rows = off; P.vec_per_row = d / vec;
+    const dim3 g(grid_for((int64_t)B * off * P.vec_per_row, 256, 2048));
+    if (dtype == RALF_F32) { if (backward) hipLaunchKernelGGL((concat_rows_kernel<float, true>), g, dim3(256), 0, ST, P, out); else hipLaunchKernelGGL((concat_rows_kernel<float, false>), g, dim3(256), 0, ST, P, out); }
+    else { if (backward) hipLaunchKernelGGL((concat_rows_kernel<bf16, true>), g, dim3(256), 0, ST, P, out); else hipLaunchKernelGGL((concat_rows_kernel<bf16, false>), g, dim3(256), 0, ST, P, out); }
+    return ralf::check_launch("concat_rows");
+}
+/* y = dropout_p(x * scale + pe[r % S, :])  on [rows, d] (PositionalEncoding1d of the K retrieved features, common/positional_encoding.py:92-107);
+ * pe fp32 [S, d] or NULL; the same call on a gradient with pe = NULL is the backward */
+extern "C" int ralf_scale_pe_dropout(int dtype, const void* x, const float* pe, void* y, int64_t rows, int S, int d, float scale, float p,
+                                     const int64_t* seed, uint64_t call_id, void* stream) {
+    RALF_REQUIRE(x && y && rows > 0 && d > 0 && (seed || p == 0.f) && p >= 0.f && p < 1.f && (S > 0 || !pe), "scale_pe_dropout: bad arguments");
+    const int vec = dtype == RALF_F32 ? 4 : 8;
+    RALF_REQUIRE(d % vec == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0, "scale_pe_dropout: d %% %d and 16-byte alignment", vec);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((scale_pe_drop_kernel<T>), dim3(grid_for(rows * (d / vec), 256, 2048)), dim3(256), 0, ST, (const T*)x, pe, (T*)y, rows, S > 0 ? S : 1, d, scale, p, seed, call_id));
+    return ralf::check_launch("scale_pe_dropout");
 }
 /* dst[r*ldd+c] (+)= src[r*lds+c] with conversion between RALF_F32 / RALF_BF16 */
 extern "C" int ralf_copy2d(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t rows, int cols, int64_t lds, int64_t ldd, int accumulate, void* stream) {

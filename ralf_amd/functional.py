@@ -51,12 +51,14 @@ class Runtime:
         self._wjobs: list = []
         self._bjobs: list = []
         self._wtiles = 0
+        self._wdeps: dict = {}
         self._main_stream = None
         self._step_start = None
         # y = res + dropout(f(x)) outputs are tagged with their mask (p, call); the LayerNorm that consumes y then also emits the
         # MASKED gradient of y from its backward kernel, which the backward of f picks up instead of launching ralf_dropout
         self._drop_tags: dict = {}
         self._masked: dict = {}
+        self._fanout: dict = {}
         self.ln_dropout = True
 
     def to(self, device):
@@ -75,7 +77,8 @@ class Runtime:
             self._step_start.record(self._main_stream)
         self._branch_keep.clear()
         self._drop_tags.clear()
-        self._masked.clear()   # (every branch entry first waits for all work issued so far: the previous step's consumers are ordered)
+        self._masked.clear()
+        self._fanout.clear()   # (every branch entry first waits for all work issued so far: the previous step's consumers are ordered)
 
     def advance_seed(self):
         self.seed.add_(0x9E3779B1)  # on-device: safe inside a captured graph
@@ -121,8 +124,14 @@ class Runtime:
             fn()
         self._keep.append(operands)
 
+    def mark_fanout(self, x: torch.Tensor):
+        """x is the input of SEVERAL linear layers whose backward products are the only gradients of x: they are summed in the
+        GEMM epilogue (LinearFn.backward) instead of by autograd's add kernels.  Valid for one backward pass."""
+        if torch.is_grad_enabled() and x.requires_grad:
+            self._fanout[x.contiguous().data_ptr()] = [None]
+
     def tag_dropout(self, y: torch.Tensor, p: float, call: int):
-        if p > 0.0 and self.ln_dropout and torch.is_grad_enabled():
+        if p > 0.0 and self.ln_dropout:   # (called inside Function.forward, where grad mode is off: no grad-mode test here)
             self._drop_tags[y.data_ptr()] = (p, call)
 
     def dropout_tag(self, x: torch.Tensor):
@@ -149,6 +158,7 @@ class Runtime:
             return False
         self._wjobs.append((dy2d, x2d, into.view(n_out, n_in), 1))
         self._wtiles += (n_out // 128) * (n_in // 128)
+        self._note_producer()
         if self._wtiles >= self.group_tiles:
             self.flush_wgrads()
         return True
@@ -158,7 +168,18 @@ class Runtime:
                 and dy2d.data_ptr() % 16 == 0):
             return False
         self._bjobs.append((dy2d, into))
+        self._note_producer()
         return True
+
+    def _note_producer(self):
+        """the queued operand was produced on the CURRENT stream (main, or a branch's stream during its backward): the grouped
+        launch must wait for this point of THAT stream only -- waiting for whole streams would park the weight gradients of the
+        big layers behind the chain of tiny kernels of an unrelated branch"""
+        if self.overlap and self.direct_grads:
+            st = torch.cuda.current_stream()
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self._wdeps[st.cuda_stream] = ev   # a later event on the same stream covers the earlier ones
 
     def flush_wgrads(self):
         """issue the queued weight / bias gradients (on the side stream when the engine overlaps them with the data-gradient chain)"""
@@ -180,11 +201,9 @@ class Runtime:
             if not self._side:
                 self._side = [torch.cuda.Stream() for _ in range(self.n_side)]
             st = self._side[0]
-            st.wait_stream(torch.cuda.current_stream())
-            if self._main_stream is not None:         # operands were produced on the step's main stream or on a branch stream
-                st.wait_stream(self._main_stream)
-            for b in self._branch_streams.values():
-                st.wait_stream(b)
+            for ev in self._wdeps.values():
+                st.wait_event(ev)
+            self._wdeps = {}
             with torch.cuda.stream(st):
                 run()
             self._keep.append((wj, bj))
@@ -378,6 +397,7 @@ class LinearFn(Function):
         ctx.save_for_backward(x2, W)
         ctx.bias, ctx.p, ctx.call = b, p, call
         ctx.rt, ctx.has_b, ctx.has_res, ctx.xshape, ctx.rows = rt, b is not None, res is not None, x.shape, (r0, r1)
+        ctx.fan = x2.data_ptr() if x2.data_ptr() in rt._fanout else None
         rt.tag_dropout(y, p, call)
         return y.view(*x.shape[:-1], N)
 
@@ -396,7 +416,16 @@ class LinearFn(Function):
         nrow = dy2.shape[0]
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm(dy2, rt.lp(W)[r0:r1], nrow, K, N, b_kcontig=False).view(ctx.xshape)
+            acc = rt._fanout.get(ctx.fan) if ctx.fan is not None else None
+            if acc is not None and acc[0] is not None:
+                # x feeds several linear layers (the memory of the 6 cross-attentions): the first backward to run handed its
+                # product to autograd, the others add theirs into THAT buffer in the GEMM epilogue and return nothing
+                ops.gemm(dy2, rt.lp(W)[r0:r1], nrow, K, N, b_kcontig=False, out=acc[0], accumulate=True)
+            else:
+                dx = ops.gemm(dy2, rt.lp(W)[r0:r1], nrow, K, N, b_kcontig=False)
+                if acc is not None:
+                    acc[0] = dx
+                dx = dx.view(ctx.xshape)
         if ctx.needs_input_grad[1]:
             gv = rt.gview(W)
             dW = wgrad(dy2, x2, N, K, nrow, gv[r0:r1] if gv is not None else None, rt)
@@ -542,6 +571,55 @@ def drop_add(x, res, p, rt):
     if p == 0.0 and res is None:
         return x
     return DropAddFn.apply(x, res, p, rt)
+
+
+class ConcatRowsFn(Function):
+    """cat(dim=1) of [B, S_i, d] tensors, with a learned scalar table[idx_i] added to source i where idx_i is not None (the
+    flag embedding task_emb = nn.Embedding(2, 1), retrieval_augmented_autoreg.py:1022-1028): one launch forward, one launch
+    backward (contiguous gradient pieces + the scalars' gradients)."""
+
+    @staticmethod
+    def forward(ctx, table, idxs, rt, *srcs):
+        srcs = [t.contiguous() for t in srcs]
+        scal = None
+        if table is not None:
+            tv = table.detach().view(-1)
+            scal = [tv[i:i + 1] if i is not None else None for i in idxs]
+        ctx.shapes, ctx.idxs, ctx.rt, ctx.table = [tuple(t.shape) for t in srcs], idxs, rt, table
+        ctx.dtype = srcs[0].dtype
+        return ops.concat_rows(srcs, scal)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        pieces = [torch.empty(shp, dtype=ctx.dtype, device=dy.device) for shp in ctx.shapes]
+        dtab, dsc = None, None
+        if ctx.table is not None:
+            gv = ctx.rt.gview(ctx.table) if ctx.rt is not None else None
+            acc = gv.view(-1) if gv is not None else torch.zeros(ctx.table.numel(), dtype=torch.float32, device=dy.device)
+            dsc = [acc[i:i + 1] if i is not None else None for i in ctx.idxs]
+            dtab = None if gv is not None else acc.view_as(ctx.table)
+        ops.concat_rows(pieces, out=dy, backward=True, dscalars=dsc)
+        return (dtab, None, None) + tuple(pieces)
+
+
+def concat_rows(srcs, rt, table=None, idxs=None):
+    return ConcatRowsFn.apply(table, idxs if idxs is not None else [None] * len(srcs), rt, *srcs)
+
+
+class ScalePEDropFn(Function):
+    """dropout_p(x * s + pe[:S]) on [B, S, d]: PositionalEncoding1d (common/positional_encoding.py:92-107) of the retrieved features"""
+
+    @staticmethod
+    def forward(ctx, x, pe, scale, p, rt):
+        call = rt.next_call() if p > 0.0 else 0
+        ctx.cfg = (scale, p, call, rt)
+        return ops.scale_pe_dropout(x.contiguous(), pe, x.shape[-2], scale, p, rt.seed, call)
+
+    @staticmethod
+    def backward(ctx, dy):
+        scale, p, call, rt = ctx.cfg
+        return ops.scale_pe_dropout(dy.contiguous(), None, 1, scale, p, rt.seed, call), None, None, None, None
 
 
 class EmbedFn(Function):

@@ -185,10 +185,9 @@ class _GeneratorBase(nn.Module):
         if cf is None:
             cf = self._constraint_features(inputs)
         rt.join_branch("constraint", cf)
-        if self.use_flag_embedding:  # learned scalars broadcast over all channels (retrieval_augmented_autoreg.py:1022-1028)
-            img_mem = RF.AddScalarFn.apply(img_mem, self.task_emb.weight, 0, rt)
-            cf = RF.AddScalarFn.apply(cf, self.task_emb.weight, 1, rt)
-        return torch.cat([img_mem, cf], dim=1)  # sequence concat: plumbing copy
+        if self.use_flag_embedding:   # cat([img_mem + task_emb[0], cf + task_emb[1]]) in one launch (retrieval_augmented_autoreg.py:1022-1028)
+            return RF.concat_rows([img_mem, cf], rt, self.task_emb.weight, [0, 1])
+        return RF.concat_rows([img_mem, cf], rt)
 
     def _image_memory(self, image):
         rt = self.rt.to(image.device)
@@ -535,9 +534,7 @@ class ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg(_GeneratorBas
         flat = {k: retrieved[k][:, :K].reshape(B * K, -1).to(device) for k in ("label", "mask", "center_x", "center_y", "width", "height")}
         f = self.layout_encoer.extract_features(flat, rt)                    # [B*K, 256], no grad
         f = self.layout_adapter(f, rt).view(B, K, -1)
-        pe = RN.ops.cast(self.pos_emb_1d.pe[0, :K].contiguous(), rt.dtype)
-        f = _ScaleAddPE.apply(f, pe, self.d_model ** 0.5)
-        return RF.drop_add(f, None, rt.drop_p(self.pos_emb_1d.p), rt)
+        return RF.ScalePEDropFn.apply(f, self.pos_emb_1d.pe[0, :K].contiguous(), self.d_model ** 0.5, rt.drop_p(self.pos_emb_1d.p), rt)
 
     def _encode_into_memory(self, inputs: dict) -> dict:
         rt = self.rt.to(inputs["image"].device)
@@ -549,24 +546,8 @@ class ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg(_GeneratorBas
             ref = self._retrieved_features(inputs["retrieved"], inputs["image"].device)
         rt.join_branch("retrieved", ref)
         ca = self.attn(mem, ref, rt)
-        fused = self.head(torch.cat([mem, ca, ref], dim=1), rt)  # sequence concat: plumbing copy
+        fused = self.head(RF.concat_rows([mem, ca, ref], rt), rt)
         return {"memory": self._constraint_memory(fused, inputs)}
-
-
-class _ScaleAddPE(torch.autograd.Function):
-    """x * s + pe (PositionalEncoding1d on the K retrieved features); tiny [B,K,d] tensor."""
-
-    @staticmethod
-    def forward(ctx, x, pe, s):
-        ctx.s = s
-        B, K, d = x.shape
-        # ralf_gemm-free: reuse the embedding kernel contract through copy2d would need a scale; the
-        # residual epilogue of a 1x1 identity is overkill -> torch elementwise on a B*K*d tensor (plumbing-sized)
-        return x * s + pe
-
-    @staticmethod
-    def backward(ctx, dy):
-        return dy * ctx.s, None, None
 
 
 class ConcateAuxilaryTaskAutoreg(_GeneratorBase):

@@ -16,7 +16,7 @@ import torch.nn as nn
 from .. import functional as RF
 from .. import nn as RN
 from ..functional import Runtime
-from .ralf import _DTYPES, _ScaleAddPE
+from .ralf import _DTYPES
 
 LAYOUT_KEYS = ("label", "mask", "center_x", "center_y", "width", "height")
 
@@ -60,8 +60,6 @@ class RetrievalAugmentation(nn.Module):
         flat = {k: retrieved_layouts[k][:, :K].reshape(B * K, -1).to(img_feature.device) for k in LAYOUT_KEYS}
         f = self.layout_encoder.extract_features(flat, rt)                   # [B*K, 256], no grad
         f = self.layout_adapter(f, rt).view(B, K, -1)
-        pe = RN.ops.cast(self.pos_emb_1d.pe[0, :K].contiguous(), rt.dtype)
-        ref = _ScaleAddPE.apply(f, pe, self.d_model ** 0.5)
-        ref = RF.drop_add(ref, None, rt.drop_p(self.pos_emb_1d.p), rt)
+        ref = RF.ScalePEDropFn.apply(f, self.pos_emb_1d.pe[0, :K].contiguous(), self.d_model ** 0.5, rt.drop_p(self.pos_emb_1d.p), rt)
         ca = self.attn(img_feature, ref, rt)
-        return self.head(torch.cat([img_feature, ca, ref], dim=1), rt)      # sequence concat: plumbing copy
+        return self.head(RF.concat_rows([img_feature.contiguous(), ca, ref], rt), rt)

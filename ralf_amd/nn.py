@@ -203,6 +203,8 @@ class BaseDecoder(nn.Module):
         kpm = _kpm_u8(tgt_key_padding_mask)
         layers = list(self.transformer.layers)
         attns = [l.multihead_attn for l in layers]
+        memory = memory.contiguous()
+        rt.mark_fanout(memory)   # d(memory) = sum of the 6 cross-attention K/V projections' data gradients, summed in their epilogues
         plan = RF.CrossKVPlan.make(attns, rt) if torch.is_grad_enabled() else None
         kv_all = None
         if plan is not None:   # all layers' cross-attention K/V projections of the memory in one launch

@@ -167,6 +167,30 @@ def xent(logits_f32, target, ignore_index, eps, grad_dtype):
     return cl, dl
 
 
+def concat_rows(srcs, scalars=None, out=None, backward=False, dscalars=None):
+    """forward: out[b, off_i + r, :] = srcs[i][b, r, :] (+ scalars[i][0]); backward: `out` is the gradient, srcs[i] are written with
+    its pieces and dscalars[i][0] += sum(piece).  srcs: contiguous [B, S_i, d] tensors of one dtype."""
+    n = len(srcs)
+    B, d = srcs[0].shape[0], srcs[0].shape[-1]
+    rows = [t.shape[1] for t in srcs]
+    if out is None:
+        out = torch.empty(B, sum(rows), d, dtype=srcs[0].dtype, device=srcs[0].device)
+    P = ctypes.c_void_p * n
+    sp = P(*[t.data_ptr() for t in srcs])
+    rp = (ctypes.c_int * n)(*rows)
+    sc = P(*[(s.data_ptr() if s is not None else None) for s in (scalars or [None] * n)])
+    ds = P(*[(s.data_ptr() if s is not None else None) for s in (dscalars or [None] * n)])
+    _call("ralf_concat_rows", dtype_code(srcs[0]), int(backward), n, sp, rp, sc, ds, _p(out), B, d)
+    return out
+
+
+def scale_pe_dropout(x, pe, S, scale, p=0.0, seed=None, call_id=0):
+    y = torch.empty_like(x)
+    d = x.shape[-1]
+    _call("ralf_scale_pe_dropout", dtype_code(x), _p(x), _p(pe), _p(y), x.numel() // d, S, d, scale, p, _p(seed), call_id)
+    return y
+
+
 def add_scalar(x, s):
     y = torch.empty_like(x)
     cols = x.shape[-1]
@@ -204,6 +228,35 @@ def copy2d_acc(src, dst, rows, cols, lds, ldd):
     """dst[r*ldd + c] += src[r*lds + c] (fp32): a stacked result scattered into equally spaced views of a flat buffer"""
     assert src.dtype == torch.float32 and dst.dtype == torch.float32
     _call("ralf_copy2d", F32, F32, _p(src), _p(dst), rows, cols, lds, ldd, 1)
+
+
+def rs_gemm(x, w, M, N, K, *, w_kcontig=True, out=None, out_dtype=None, bias=None, act=None, res=None, aux=None, aux_scale=1.0, out2=None,
+            drop_p=0.0, seed=None, call_id=0, ln=None, xln=None, ln_stats=None, ldx=None, ldw=None, ldy=None, ldr=None):
+    """row-strip linear layer (ralf_rs_gemm): y = epi(LN?(x) @ w^T) (w [N, K]) or epi(x @ w) (w [K, N], w_kcontig=False); bf16 operands.
+    ln = (gamma, beta) fp32: LayerNorm prologue (K = 256); xln / ln_stats = (mean, rstd) receive the normalised rows / statistics."""
+    from ._abi import RalfRsDesc
+
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype or torch.bfloat16, device=x.device)
+    d = RalfRsDesc()
+    d.x, d.w, d.y, d.y2 = _p(x), _p(w), _p(out), _p(out2)
+    d.bias, d.res, d.aux = _p(bias), _p(res), _p(aux)
+    d.ldx = ldx if ldx is not None else K
+    d.ldw = ldw if ldw is not None else (K if w_kcontig else N)
+    d.ldy = ldy if ldy is not None else N
+    d.ldr = ldr if ldr is not None else N
+    d.M, d.N, d.K, d.w_kcontig, d.act = M, N, K, int(w_kcontig), ACT[act]
+    d.out_f32 = int(out.dtype == torch.float32)
+    d.drop_p, d.seed, d.call_id, d.aux_scale = drop_p, _p(seed), call_id, aux_scale
+    if ln is not None:
+        d.ln_gamma, d.ln_beta, d.ln_eps = _p(ln[0]), _p(ln[1]), 1e-5
+        d.xln = _p(xln)
+        if ln_stats is not None:
+            d.ln_mean, d.ln_rstd = _p(ln_stats[0]), _p(ln_stats[1])
+    rc = _lib.lib().ralf_rs_gemm(ctypes.byref(d), _lib.stream_ptr())
+    _lib.check(rc, "ralf_rs_gemm")
+    return out
 
 
 def wgrad_grouped(jobs):
