@@ -117,9 +117,12 @@ __global__ __launch_bounds__(NT) void rs_gemm_kernel(const RalfRsDesc d) {
         }
     }
 
-    // ---- streaming loaders ----
-    u32x4 rb[NVB], ra;
-    auto gload = [&](int nt, int kt) {
+    // ---- streaming loaders: a ring of 3 register stages in front of the 2 LDS buffers.  One workgroup per CU means no other
+    // workgroup hides a load's latency: with the loads of step s+1 issued at the top of step s, a step cost a full L2 round trip
+    // (~1 us measured).  The data of step s+1 is now requested two steps earlier. ----
+    constexpr int RING = 3;
+    u32x4 rb[RING][NVB], ra[RING];
+    auto gload = [&](int stage, int nt, int kt) {
         const int n0 = nt * BN, k0 = kt * BK;
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
@@ -127,29 +130,29 @@ __global__ __launch_bounds__(NT) void rs_gemm_kernel(const RalfRsDesc d) {
             if constexpr (BKC) {
                 const int r = v >> 3, c = v & 7;
                 const int n = min(n0 + r, N - 1);
-                rb[i] = *reinterpret_cast<const u32x4*>(W + (int64_t)n * d.ldw + k0 + c * 8);
+                rb[stage][i] = *reinterpret_cast<const u32x4*>(W + (int64_t)n * d.ldw + k0 + c * 8);
             } else {
                 constexpr int VR = BN / 8;
                 const int r = v / VR, c = v % VR;
                 const int n = min(n0 + c * 8, N - 8);
-                rb[i] = *reinterpret_cast<const u32x4*>(W + (int64_t)(k0 + r) * d.ldw + n);
+                rb[stage][i] = *reinterpret_cast<const u32x4*>(W + (int64_t)(k0 + r) * d.ldw + n);
             }
         }
         if constexpr (KRES == 0) {
             const int r = tid >> 3, c = tid & 7;
             const int m = min(m0 + r, M - 1);
-            ra = *reinterpret_cast<const u32x4*>(X + (int64_t)m * d.ldx + k0 + c * 8);
+            ra[stage] = *reinterpret_cast<const u32x4*>(X + (int64_t)m * d.ldx + k0 + c * 8);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int stage, int buf) {
         bf16* b = lb + buf * B_ELEMS;
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
             const int v = tid + NT * i;
-            if constexpr (BKC) *reinterpret_cast<u32x4*>(b + (v >> 3) * LDK + (v & 7) * 8) = rb[i];
-            else { constexpr int VR = BN / 8; *reinterpret_cast<u32x4*>(b + (v / VR) * LDB + (v % VR) * 8) = rb[i]; }
+            if constexpr (BKC) *reinterpret_cast<u32x4*>(b + (v >> 3) * LDK + (v & 7) * 8) = rb[stage][i];
+            else { constexpr int VR = BN / 8; *reinterpret_cast<u32x4*>(b + (v / VR) * LDB + (v % VR) * 8) = rb[stage][i]; }
         }
-        if constexpr (KRES == 0) *reinterpret_cast<u32x4*>(la + buf * BM * LDK + (tid >> 3) * LDK + (tid & 7) * 8) = ra;
+        if constexpr (KRES == 0) *reinterpret_cast<u32x4*>(la + buf * BM * LDK + (tid >> 3) * LDK + (tid & 7) * 8) = ra[stage];
     };
 
     f32x16 acc[WFN];
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(NT) void rs_gemm_kernel(const RalfRsDesc d) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    auto compute = [&](int buf, int kt) {
+    auto compute = [&](const int buf, const int kt) {
         const bf16* b = lb + buf * B_ELEMS;
         const bf16* a = KRES ? la + kt * BK : la + buf * BM * LDK;
 #pragma unroll
@@ -251,21 +254,32 @@ __global__ __launch_bounds__(NT) void rs_gemm_kernel(const RalfRsDesc d) {
         }
     };
 
-    // ---- one flat loop over (column tile, k-step): loads of step s+1 under the MFMAs of step s, one barrier per step ----
-    gload(0, 0);
-    lstore(0);
-    __syncthreads();
-    int nt = 0, kt = 0;
-    for (int s = 0; s < S; ++s) {
-        int nt1 = nt, kt1 = kt + 1;
-        if (kt1 == KT) { kt1 = 0; ++nt1; }
-        const bool more = s + 1 < S;
-        if (more) gload(nt1, kt1);
-        compute(s & 1, kt);
-        if (more) lstore((s + 1) & 1);
+    // ---- one flat loop over (column tile, k-step), one barrier per step.  At the top of step s: LDS buffer s&1 holds step s,
+    // register stage (s+1)%3 holds step s+1 (requested two steps ago), stage (s+2)%3 step s+2; step s+3 is requested now.
+    // Unrolled by 6 so that ring stage and buffer parity are compile-time constants (no runtime-indexed register arrays). ----
+    auto step_of = [&](int s, int& nt, int& kt) { nt = s / KT; kt = s - nt * KT; };
+    {
+        int nt_, kt_;
+        gload(0, 0, 0);
+        if (S > 1) { step_of(1, nt_, kt_); gload(1, nt_, kt_); }
+        if (S > 2) { step_of(2, nt_, kt_); gload(2, nt_, kt_); }
+        lstore(0, 0);
         __syncthreads();
-        if (kt == KT - 1) epilogue(nt);   // (ends with reads of cs only: the next write of cs is at least one barrier away)
-        nt = nt1; kt = kt1;
+    }
+    for (int sb = 0; sb < S; sb += 6) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int s = sb + u;
+            if (s < S) {   // (uniform)
+                int nt, kt;
+                step_of(s, nt, kt);
+                if (s + 3 < S) { int n3, k3; step_of(s + 3, n3, k3); gload(u % 3, n3, k3); }   // stage (s+3)%3 = s%3 was stored a step ago
+                compute(u & 1, kt);
+                if (s + 1 < S) lstore((u + 1) % 3, (u + 1) & 1);
+                __syncthreads();
+                if (kt == KT - 1) epilogue(nt);   // (ends with reads of cs only: the next write of cs is at least one barrier away)
+            }
+        }
     }
 }
 

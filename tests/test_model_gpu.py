@@ -353,7 +353,7 @@ def test_dropout_mask_from_layernorm_backward_equals_dropout_launch(golden, dtyp
         loss.backward()
         grads.append((loss.item(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
     (l1, g1), (l2, g2) = grads
-    assert l1 == l2
+    assert abs(l1 - l2) < 1e-5      # (the forward is the same code; fp32 atomics of the loss reduction reorder the sum)
     for k in g1:
         d = (g1[k] - g2[k]).abs().max().item()
         assert d <= 1e-6 + 2e-5 * g2[k].abs().max().item(), (k, d)
