@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 9
+#define RALF_ABI_VERSION 10
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -72,6 +72,7 @@ int ralf_knn_rownorms(const float* X, const void* Xb_bf16, int64_t R, int D, flo
 #define RALF_ACT_NONE 0
 #define RALF_ACT_RELU 1
 #define RALF_ACT_GELU 2          /* exact erf GELU (nn.GELU default, common/attention.py:23)      */
+#define RALF_ACT_RELU_POST 3     /* ReLU applied AFTER the residual: relu(colscale*acc + bias + res), the tail of a ResNet bottleneck in inference */
 #define RALF_AUX_NONE 0
 #define RALF_AUX_RELU_MASK 1     /* v = aux > 0 ? v * aux_scale : 0   (ReLU gradient from output) */
 #define RALF_AUX_GELU_GRAD 2     /* v *= gelu'(aux)                   (aux = pre-activation)      */
@@ -125,6 +126,9 @@ typedef struct RalfGemmDesc {
     int64_t sBias0;
     int64_t sBk;
     int kseg;
+    /* inference-time BatchNorm folded into the producing convolution: acc * colscale[n] (fp32 [N], may be NULL) before the bias,
+     * i.e. y = act(conv(x) * gamma/sqrt(var+eps) + (beta - mean*gamma/sqrt(var+eps)) (+ res)) with scale/shift from ralf_bn_fold_batched */
+    const float* colscale;
 } RalfGemmDesc;
 size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d);
 int ralf_gemm(const RalfGemmDesc* d, void* workspace, size_t workspace_bytes, void* stream);
@@ -208,6 +212,14 @@ int ralf_bn_stats_from_partials(const float* partials, int nrows, const float* g
                                 float eps, float momentum, float* workspace, void* stream);
 /* relu_mask (optional, M*C/8 bytes; bit i of byte j <-> element 8j+i of the [M,C] tensor) is written by bn_apply when relu and read by
  * the backward kernels INSTEAD of y (1/16 of the bytes); without it they test y > 0 (y required then). */
+/* eval-mode scale / shift of many BatchNorm layers in ONE launch (the 53 of a ResNet-50): scale = gamma * rsqrt(running_var + eps),
+ * shift = beta - running_mean * scale, for the colscale / bias of the folded convolution epilogue.  jobs_device: device array. */
+typedef struct RalfBnFoldJob {
+    const float* gamma; const float* beta; const float* mean; const float* var;
+    float* scale; float* shift;
+    int C; int pad_;
+} RalfBnFoldJob;
+int ralf_bn_fold_batched(const RalfBnFoldJob* jobs_device, int njobs, float eps, void* stream);
 int ralf_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, uint8_t* relu_mask,
                   int64_t M, int C, int relu, void* stream);
 int ralf_bn_bwd_reduce(int dtype, const void* x, const void* dy, const void* y, const uint8_t* relu_mask, const float* mean, const float* rstd,
@@ -299,6 +311,15 @@ int ralf_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_
  * lr_scale (fp32[1] on the device, may be NULL) multiplies lr: the scheduler's factor (train/schedulers/multi_step_lr.py) without re-capturing */
 int ralf_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1, float beta2, float eps,
                float weight_decay, int step, const float* coef, const int* step_dev, const float* lr_scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Streams owned by the library (ralf_amd/csrc/optim.hip).  The host runtime runs its graph branches, weight-gradient
+ * queue and captures on THESE, never on streams of the framework's shared pool: the pool also hands its streams to the
+ * collective library, and an event of an in-flight collective that sits on a stream which later starts capturing makes the
+ * collective's completion poll fail (hipErrorCapturedEvent) and takes the process down.  Non-blocking w.r.t. the null stream.
+ * ------------------------------------------------------------------------------------------- */
+int ralf_stream_create(void** out_stream);
+int ralf_stream_destroy(void* stream);
 
 #ifdef __cplusplus
 }

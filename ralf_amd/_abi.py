@@ -22,6 +22,10 @@ class RalfConvGeom(ctypes.Structure):
     _fields_ = [(n, i32) for n in ("RH", "RW", "SH", "SW", "SC", "KH", "KW", "stride", "pad", "mode")]
 
 
+class RalfBnFoldJob(ctypes.Structure):
+    _fields_ = [(n, vp) for n in ("gamma", "beta", "mean", "var", "scale", "shift")] + [("C", i32), ("pad_", i32)]
+
+
 class RalfPermuteJob(ctypes.Structure):
     _fields_ = ([("in_", vp), ("out", vp)] + [(n, i64) for n in ("s0", "s1", "s2", "s3")]
                 + [(n, i32) for n in ("d0", "d1", "d2", "d3", "valid3", "src_dtype", "dst_dtype", "first_block")])
@@ -35,7 +39,7 @@ class RalfGemmDesc(ctypes.Structure):
                               "act", "aux_mode", "out_f32", "accumulate", "splitk")]
         + [("alpha", f32), ("aux_scale", f32), ("g", RalfConvGeom)]
         + [("seed", vp), ("call_id", ctypes.c_uint64), ("drop_p", f32), ("atomic_out", i32), ("colstats", vp)]
-        + [("sBias0", i64), ("sBk", i64), ("kseg", i32)]
+        + [("sBias0", i64), ("sBk", i64), ("kseg", i32), ("colscale", vp)]
     )
 
 
@@ -88,6 +92,7 @@ SIGNATURES.update({
     "ralf_bn_finalize": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp]),
     "ralf_bn_batch_stats": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, vp, vp]),
     "ralf_bn_stats_from_partials": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, vp, vp]),
+    "ralf_bn_fold_batched": (i32, [vp, i32, f32, vp]),
     "ralf_bn_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "ralf_bn_bwd_reduce": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]),
     "ralf_bn_bwd_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
@@ -112,4 +117,6 @@ SIGNATURES.update({
     "ralf_sumsq": (i32, [vp, i64, vp, vp]),
     "ralf_clip_coef": (i32, [vp, f32, vp, vp, vp]),
     "ralf_adamw": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, vp, vp, vp]),
+    "ralf_stream_create": (i32, [ctypes.POINTER(vp)]),
+    "ralf_stream_destroy": (i32, [vp]),
 })

@@ -128,6 +128,7 @@ template <> __device__ __forceinline__ void stf<bf16>(void* p, int64_t i, float 
 template <typename T, int EPI>
 __device__ __forceinline__ void epilogue_store(const RalfGemmDesc& d, int z0, int z1, int m, int n, float v) {
     v *= d.alpha;
+    if (d.colscale) v *= d.colscale[n];
     if (d.bias) v += d.bias[z0 * d.sBias0 + n];
     const int64_t coff = z0 * d.sC0 + z1 * d.sC1 + (int64_t)m * d.ldc + n;
     if (EPI >= 2 && d.C2) {  // pre-activation copy (needed by the activation gradient)
@@ -145,6 +146,7 @@ __device__ __forceinline__ void epilogue_store(const RalfGemmDesc& d, int z0, in
         else if (EPI >= 2 && d.aux_mode == RALF_AUX_GELU_GRAD) v *= gelu_grad(a);
     }
     if (d.res) v += ldf<T>(d.res, z0 * d.sR0 + z1 * d.sR1 + (int64_t)m * d.ldr + n);
+    if (d.act == RALF_ACT_RELU_POST) v = v > 0.f ? v : 0.f;
     if (EPI >= 2 && d.atomic_out) {   // (no early `return` in these helpers: it defeats unrolling of the caller's accumulator loops)
         atomicAdd((float*)d.C + coff, v);
     } else {
@@ -205,6 +207,12 @@ __device__ __forceinline__ void epilogue_storev(const RalfGemmDesc& d, int z0, i
     const int64_t coff = z0 * d.sC0 + z1 * d.sC1 + (int64_t)m * d.ldc + n;
 #pragma unroll
     for (int q = 0; q < W; ++q) v[q] *= d.alpha;
+    if (d.colscale) {
+        float c[W];
+        VIO<float, W>::ld(d.colscale, n, c);
+#pragma unroll
+        for (int q = 0; q < W; ++q) v[q] *= c[q];
+    }
     if (d.bias) {
         float b[W];
         VIO<float, W>::ld(d.bias, z0 * d.sBias0 + n, b);
@@ -242,6 +250,10 @@ __device__ __forceinline__ void epilogue_storev(const RalfGemmDesc& d, int z0, i
         VIO<T, W>::ld(d.res, z0 * d.sR0 + z1 * d.sR1 + (int64_t)m * d.ldr + n, r);
 #pragma unroll
         for (int q = 0; q < W; ++q) v[q] += r[q];
+    }
+    if (d.act == RALF_ACT_RELU_POST) {
+#pragma unroll
+        for (int q = 0; q < W; ++q) v[q] = fmaxf(v[q], 0.f);
     }
     if (EPI >= 2 && d.atomic_out) {
 #pragma unroll
@@ -394,14 +406,16 @@ __device__ __forceinline__ void lds_stage(T* l, const u32x4 (&regs)[NV], int tid
 // GATHER: 0 none, 1 = A (k-contiguous) is an im2col matrix, 2 = B (row-contiguous) is an im2col matrix.
 // FM, FN: 32x32 fragments per wave along m / n  ->  workgroup tile (64*FM) x (64*FN).
 // NW: waves per workgroup, 4 (2 x 2 waves, FM x FN fragments each) or 8 (2 x 4 waves, FM x FN/2 fragments each; FN = 2 only)
-// LDS bytes of one workgroup: the operand tiles, re-used as the fp32 C staging tile [64][BN + 4] of the epilogue
-template <typename T, bool AK, bool BKC, int FM, int FN>
+// LDS bytes of one workgroup: two buffers of operand tiles, re-used as the fp32 C staging tile [64][BN + 4] of the epilogue
+template <int GATHER, int FM>
+constexpr int gemm_nbuf() { return (GATHER == 1 && FM == 1) ? 1 : 2; }   // the prefetch-distance-1 kernels keep one buffer
+template <typename T, bool AK, bool BKC, int FM, int FN, int NBUF = 2>
 constexpr int gemm_lds_bytes() {
     using X = TT<T>;
     constexpr int BM = 64 * FM, BN = 64 * FN, BK = X::BK;
     constexpr int A_ELEMS = AK ? BM * X::LDK : BK * (BM + X::RPAD);
     constexpr int B_ELEMS = BKC ? BN * X::LDK : BK * (BN + X::RPAD);
-    constexpr int ops = (A_ELEMS + B_ELEMS) * (int)sizeof(T), cst = 64 * (BN + 4) * 4;
+    constexpr int ops = NBUF * (A_ELEMS + B_ELEMS) * (int)sizeof(T), cst = 64 * (BN + 4) * 4;   // NBUF operand buffers (see the k-loop)
     return ops > cst ? ops : cst;
 }
 
@@ -421,8 +435,11 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     static_assert(NW == 4 || (NW == 8 && FN == 2), "8 waves: 2 x 4 over a 128-wide tile");
     constexpr int NVA = BM * BK / VEC / NT, NVB = BN * BK / VEC / NT;  // 16-byte vectors per thread per k-tile
     constexpr int CP = BN + 4;                                     // fp32 C staging tile [64][CP] (epilogue)
-    T* la = reinterpret_cast<T*>(lds_raw);
-    T* lb = la + A_ELEMS;
+    constexpr int B_ELEMS = BKC ? BN * X::LDK : BK * LDRB;
+    T* const la0 = reinterpret_cast<T*>(lds_raw);
+    T* const lb0 = la0 + A_ELEMS;
+    T* const la1 = lb0 + B_ELEMS;
+    T* const lb1 = la1 + A_ELEMS;
     const RalfGemmDesc& d = P.d;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WGN, wn = wave % WGN;
@@ -545,7 +562,7 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     const int trL = lane & 15, tr_rowblk = ((lane >> 4) & 1) * 16, tr_k = lh * 8 + (trL >> 2), tr_c = (trL & 3) * 4;
 
     // one k-tile of MFMAs from the staged LDS tile
-    auto compute = [&]() {
+    auto compute = [&](const T* la, const T* lb) {
         // the matrix core computes the TRANSPOSED tile: row operand = n-fragment (weights), column operand =
         // m-fragment, so accumulator register r of a lane holds (n = (r&3) + 8*(r>>2) + 4*(lane>>5), m = lane&31)
         if constexpr (sizeof(T) == 4) {
@@ -601,12 +618,17 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
             }
         }
     };
-    // Software pipeline with prefetch distance TWO k-tiles through two staging register sets: a tile's global loads
-    // get two compute phases to land (the k-loop is bound by load latency x tiles in flight per CU, not by MFMA rate).
+    // Software pipeline: prefetch distance TWO k-tiles through two staging register sets (a tile's global loads get two compute
+    // phases to land: the k-loop is bound by load latency x tiles in flight per CU, not by MFMA rate) and TWO LDS buffers, so a
+    // step is  [registers of tile t+1 -> the other buffer | request tile t+3 | MFMAs of tile t | ONE barrier]  -- the LDS writes of
+    // the next tile overlap the matrix work of this one.  (One buffer with compute / barrier / stage / barrier per tile ran the
+    // 256-tile launches -- one workgroup per CU, nothing to interleave with -- at 1.2 us per 128x128x64 step, 6x the MFMA time.)
     // Steady state is branch-free (an `if` around a prefetch made the compiler shuttle every accumulator
-    // AGPR -> VGPR -> AGPR per iteration); the last 1-3 tiles are peeled.
-    auto stage0 = [&]() { lds_stage<T, AK, NVA, RVA, LDRA, NT>(la, ra0, tid); lds_stage<T, BKC, NVB, RVB, LDRB, NT>(lb, rb0, tid); };
-    auto stage1 = [&]() { lds_stage<T, AK, NVA, RVA, LDRA, NT>(la, ra1, tid); lds_stage<T, BKC, NVB, RVB, LDRB, NT>(lb, rb1, tid); };
+    // AGPR -> VGPR -> AGPR per iteration); the last 1-4 tiles are peeled.
+    auto stage = [&](T* la, T* lb, const u32x4 (&ra)[NVA], const u32x4 (&rb)[NVB]) {
+        lds_stage<T, AK, NVA, RVA, LDRA, NT>(la, ra, tid);
+        lds_stage<T, BKC, NVB, RVB, LDRB, NT>(lb, rb, tid);
+    };
     // (the 64x64 im2col-gather kernels keep distance 1: their index registers + a second staging set cost a wave of occupancy
     //  and the layer1 3x3 convolutions got 20 % slower with distance 2)
     constexpr int PF = (GATHER == 1 && FM == 1) ? 1 : 2;
@@ -622,39 +644,52 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
         for (int j = 0; j < WFN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if constexpr (PF == 1) {
-        stage0();
+    if constexpr (PF == 1) {   // one LDS buffer (a second one measured 46.6 -> 54.3 us on the layer1 3x3 convolutions)
+        stage(la0, lb0, ra0, rb0);
         __syncthreads();
         for (int t = 0; t + 1 < c_nt; ++t) {
             gload(ra0, rb0, c_kbeg + (t + 1) * BK);
-            compute();
+            compute(la0, lb0);
             __syncthreads();
-            stage0();
+            stage(la0, lb0, ra0, rb0);
             __syncthreads();
         }
-        compute();
+        compute(la0, lb0);
     } else {
-        stage0();
+        stage(la0, lb0, ra0, rb0);
+        if (c_nt > 2) gload(ra0, rb0, c_kbeg + 2 * BK);
         __syncthreads();
         RALF_PROBE(2);
+        // top of an even step t: buffer 0 = tile t, set 1 = tile t+1 and set 0 = tile t+2 (both on their way)
         int t = 0;
-        for (; t + 3 < c_nt; t += 2) {        // tile t in LDS, tile t+1 in set 1
-            gload(ra0, rb0, c_kbeg + (t + 2) * BK);
-            compute();
-            __syncthreads();
-            stage1();
-            __syncthreads();
+        for (; t + 4 < c_nt; t += 2) {
+            stage(la1, lb1, ra1, rb1);
             gload(ra1, rb1, c_kbeg + (t + 3) * BK);
-            compute();
+            compute(la0, lb0);
             __syncthreads();
-            stage0();
+            stage(la0, lb0, ra0, rb0);
+            gload(ra0, rb0, c_kbeg + (t + 4) * BK);
+            compute(la1, lb1);
             __syncthreads();
         }
-        const int rem = c_nt - t;             // 1..3 tiles left: t in LDS, t+1 in set 1 (rem >= 2), t+2 not loaded yet (rem == 3)
-        if (rem == 3) gload(ra0, rb0, c_kbeg + (t + 2) * BK);
-        compute();
-        if (rem >= 2) { __syncthreads(); stage1(); __syncthreads(); compute(); }
-        if (rem == 3) { __syncthreads(); stage0(); __syncthreads(); compute(); }
+        const int rem = c_nt - t;             // 1..4 tiles left; tile t+3 (rem == 4) has not been requested yet
+        if (rem >= 2) stage(la1, lb1, ra1, rb1);
+        if (rem == 4) gload(ra1, rb1, c_kbeg + (t + 3) * BK);
+        compute(la0, lb0);
+        if (rem >= 2) {
+            __syncthreads();
+            if (rem >= 3) stage(la0, lb0, ra0, rb0);
+            compute(la1, lb1);
+        }
+        if (rem >= 3) {
+            __syncthreads();
+            if (rem == 4) stage(la1, lb1, ra1, rb1);
+            compute(la0, lb0);
+        }
+        if (rem == 4) {
+            __syncthreads();
+            compute(la1, lb1);
+        }
     }
     // the operands of this workgroup's next tile start their way while this tile's results are stored
     const int nbid = bid + grid_x;
@@ -762,7 +797,7 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
 
 template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW = 4>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_kernel(const KParams P) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[gemm_lds_bytes<T, AK, BKC, FM, FN>()];   // ONE LDS object
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[gemm_lds_bytes<T, AK, BKC, FM, FN, gemm_nbuf<GATHER, FM>()>()];   // ONE LDS object
     gemm_body<T, AK, BKC, GATHER, FM, FN, EPI, NW>(P, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z, (int)gridDim.z, lds_raw);
 }
 

@@ -726,6 +726,22 @@ extern "C" int ralf_bn_stats(int dtype, const void* x, float* s1, float* s2, int
     return ralf::check_launch("bn_stats");
 }
 
+// eval-mode scale / shift of many BatchNorm layers: one workgroup per layer
+__global__ __launch_bounds__(256) void bn_fold_batched_kernel(const RalfBnFoldJob* __restrict__ jobs, float eps) {
+    const RalfBnFoldJob j = jobs[blockIdx.x];
+    for (int c = threadIdx.x; c < j.C; c += 256) {
+        const float sc = j.gamma[c] * rsqrtf(j.var[c] + eps);
+        j.scale[c] = sc;
+        j.shift[c] = j.beta[c] - j.mean[c] * sc;
+    }
+}
+
+extern "C" int ralf_bn_fold_batched(const RalfBnFoldJob* jobs_device, int njobs, float eps, void* stream) {
+    RALF_REQUIRE(jobs_device && njobs > 0, "bn_fold_batched: bad arguments");
+    hipLaunchKernelGGL(bn_fold_batched_kernel, dim3(njobs), dim3(256), 0, (hipStream_t)stream, jobs_device, eps);
+    return ralf::check_launch("bn_fold_batched");
+}
+
 extern "C" int ralf_bn_finalize(const float* s1, const float* s2, const float* gamma, const float* beta, float* running_mean, float* running_var,
                                 float* mean, float* rstd, float* scale, float* shift, int64_t M, int C, float eps, float momentum, int training, void* stream) {
     RALF_REQUIRE(gamma && beta && mean && rstd && scale && shift, "bn_finalize: null pointer");

@@ -85,3 +85,19 @@ extern "C" int ralf_adamw(float* p, const float* g, float* m, float* v, void* sh
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), coef, step_dev, lr_scale);
     return ralf::check_launch("adamw");
 }
+
+extern "C" int ralf_stream_create(void** out_stream) {
+    if (!out_stream) { ralf::set_error("stream_create: null output"); return RALF_ERR_INVALID; }
+    hipStream_t s = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) { ralf::set_error("stream_create: %s", hipGetErrorString(e)); return RALF_ERR_LAUNCH; }
+    *out_stream = (void*)s;
+    return RALF_OK;
+}
+
+extern "C" int ralf_stream_destroy(void* stream) {
+    if (!stream) return RALF_OK;
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) { ralf::set_error("stream_destroy: %s", hipGetErrorString(e)); return RALF_ERR_LAUNCH; }
+    return RALF_OK;
+}

@@ -389,7 +389,8 @@ class TrainStep:
         # the warm-up steps (allocator, lazy inits, LDS attributes) must not train: the state they touch is put back, so the
         # first graphed call is exactly ONE optimisation step, like use_graph=False and like the reference's loop
         snap = self._snapshot()
-        side = torch.cuda.Stream()
+        # (warm-up ON the capture stream: the per-stream workspaces reach their size before the capture, outside its pool)
+        side = cap = ops.own_stream("capture")
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
@@ -399,12 +400,12 @@ class TrainStep:
         torch.cuda.synchronize()
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         gm = torch.cuda.CUDAGraph() if self.staged else None
-        with torch.cuda.graph(ga, capture_error_mode=_CAPTURE_MODE):
+        with torch.cuda.graph(ga, stream=cap, capture_error_mode=_CAPTURE_MODE):
             self.loss = self._fwd_bwd(si, st)
         if gm is not None:
-            with torch.cuda.graph(gm, pool=ga.pool(), capture_error_mode=_CAPTURE_MODE):
+            with torch.cuda.graph(gm, pool=ga.pool(), stream=cap, capture_error_mode=_CAPTURE_MODE):
                 self._bwd_rest()
-        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode=_CAPTURE_MODE):
+        with torch.cuda.graph(gb, pool=ga.pool(), stream=cap, capture_error_mode=_CAPTURE_MODE):
             self._update()
         self._graphs = (ga, gm, gb)
         # (capturing ran the host side of the step once more without executing kernels: put the host counters back too)
@@ -426,14 +427,14 @@ class GraphedDecode:
         if self._graph is None:
             self._static = _clone_tree({"enc": enc_in, "seq": cond_seq})
             s = self._static
-            side = torch.cuda.Stream()
+            side = ops.own_stream("capture")
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 self.model.decode_tokens(s["enc"], s["seq"], self.cond_type, self.cfg, self.kv)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph, capture_error_mode=_CAPTURE_MODE):
+            with torch.cuda.graph(self._graph, stream=ops.own_stream("capture"), capture_error_mode=_CAPTURE_MODE):
                 self._out = self.model.decode_tokens(s["enc"], s["seq"], self.cond_type, self.cfg, self.kv)
         else:
             _copy_tree(self._static, {"enc": enc_in, "seq": cond_seq})

@@ -60,6 +60,7 @@ class Runtime:
         self._masked: dict = {}
         self._fanout: dict = {}
         self.ln_dropout = True
+        self.fold_bn = True       # inference: eval-mode BatchNorm folded into the convolution epilogues (conv_bn_infer)
 
     def to(self, device):
         if self.seed is None or self.seed.device != device:
@@ -117,7 +118,7 @@ class Runtime:
         if not (self.overlap and self.direct_grads):
             return fn()
         if not self._side:
-            self._side = [torch.cuda.Stream() for _ in range(self.n_side)]
+            self._side = [ops.own_stream(("side", i)) for i in range(self.n_side)]
         st = self._side[(target.data_ptr() >> 8) % len(self._side)]   # one gradient region -> always the same stream
         st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):
@@ -143,8 +144,8 @@ class Runtime:
     def masked_grad(self, dy: torch.Tensor, p: float, call: int) -> torch.Tensor:
         """dropout(dy) with the mask (p, call): taken from the LayerNorm backward that produced dy when it offered one"""
         hit = self._masked.pop(dy.data_ptr(), None)
-        if hit is not None and hit[0] == call and hit[1].shape == dy.shape:
-            return hit[1]
+        if hit is not None and hit[0] == call and hit[1].numel() == dy.numel():
+            return hit[1].view(dy.shape)   # (the LayerNorm wrote it in ITS view of the rows: [B, S, d] against the GEMM's [B*S, d])
         return ops.dropout(dy, p, self.seed, call)
 
     def defer_wgrad(self, dy2d, x2d, into) -> bool:
@@ -199,7 +200,7 @@ class Runtime:
                 ops.colsum_grouped(bj)
         if self.overlap and self.direct_grads:
             if not self._side:
-                self._side = [torch.cuda.Stream() for _ in range(self.n_side)]
+                self._side = [ops.own_stream(("side", i)) for i in range(self.n_side)]
             st = self._side[0]
             for ev in self._wdeps.values():
                 st.wait_event(ev)
@@ -320,7 +321,7 @@ class _Branch:
             return self
         st = rt._branch_streams.get(self.name)
         if st is None:
-            st = rt._branch_streams[self.name] = torch.cuda.Stream()
+            st = rt._branch_streams[self.name] = ops.own_stream(("branch", self.name))
         if rt._step_start is not None:
             st.wait_event(rt._step_start)      # inputs and weights of this step are ready there
         else:
@@ -922,6 +923,26 @@ class ConvFn(Function):
 def conv2d(x, W, b, stride, pad, rt, pos=None, fork=False, stats=False):
     """returns y, then x itself when fork, then the [M/64, 2, Co] column-statistics partials when stats."""
     return ConvFn.apply(x, W, b, stride, pad, pos, rt, fork, stats)
+
+
+@torch.no_grad()
+def conv_bn_infer(x, W, scale, shift, stride, pad, relu, res, rt):
+    """inference: act(conv(x) * scale + shift (+ res)) in ONE GEMM -- the eval-mode BatchNorm (scale / shift from ops.bn_fold_batched) and
+    the ReLU live in the convolution's epilogue; no normalisation pass over the activation (at B = 256 the 53 bn_apply launches were
+    3.5 ms of a 12 ms backbone forward).  relu: False, True (no residual) or "post" (after the residual: the bottleneck's tail)."""
+    B, H, Wd, C = x.shape
+    Co, Ci, kh, kw = W.shape
+    OH, OW = (H + 2 * pad - kh) // stride + 1, (Wd + 2 * pad - kw) // stride + 1
+    M = B * OH * OW
+    x = x.contiguous()
+    act = "relu_post" if (relu and res is not None) else ("relu" if relu else None)
+    r2 = res.contiguous().view(M, Co) if res is not None else None
+    if kh == 1 and stride == 1:
+        y = ops.gemm(x.view(-1, C), rt.lp(W).view(Co, Ci), M, Co, Ci, bias=shift, colscale=scale, act=act, res=r2)
+    else:
+        geom = dict(RH=OH, RW=OW, SH=H, SW=Wd, SC=C, KH=kh, KW=kw, stride=stride, pad=pad, mode=0)
+        y = ops.gemm(x, rt.lp(W, "ohwi"), M, Co, kh * kw * C, conv=geom, gather=1, bias=shift, colscale=scale, act=act, res=r2)
+    return y.view(B, OH, OW, Co)
 
 
 class BatchNormFn(Function):

@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from .. import functional as RF
 from .. import nn as RN
+from .. import ops
 from ..functional import Runtime
 from ..helpers.sampling import DECODE_SPACE_RESTRICTION, _get, forced_tokens_all, sample as sample_tokens
 from ..helpers.task import COND_TYPES, get_condition
@@ -332,13 +333,13 @@ class _GeneratorBase(nn.Module):
             self.kpm[:, : pos + 1].copy_(kpm_prefix)
             if pos not in self.graphs:
                 run = lambda: RN.decoder_step(m.decoder, self.tok, pos, self.cache, m.rt, self.kpm[:, : pos + 1])  # noqa: E731
-                side = torch.cuda.Stream()
+                side = ops.own_stream("capture")
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     run()
                 torch.cuda.current_stream().wait_stream(side)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                with torch.cuda.graph(g, stream=ops.own_stream("capture"), capture_error_mode="thread_local"):
                     self.out[pos] = run()
                 self.graphs[pos] = g
             self.graphs[pos].replay()

@@ -347,6 +347,7 @@ class BN(nn.Module):
         self.register_buffer("running_mean", torch.zeros(c))
         self.register_buffer("running_var", torch.ones(c))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.fold = None   # (scale, shift) views of the backbone's eval-mode fold buffer (ResnetBackbone._refresh_fold)
 
     def forward(self, x, rt: Runtime, relu: bool, res=None, stats=None):
         """stats: column-statistics partials from the producing convolution (Conv.forward(..., stats=True))."""
@@ -381,6 +382,14 @@ class Bottleneck(nn.Module):
             self.downsample = nn.ModuleList([Conv(inpl, planes * 4, 1, stride, 0), BN(planes * 4)])
         else:
             self.downsample = None
+
+    def forward_infer(self, x, rt: Runtime):
+        """inference (no autograd, running statistics): each BatchNorm (+ ReLU, + the residual) is the epilogue of its convolution"""
+        cb = lambda conv, bn, inp, relu, res=None: RF.conv_bn_infer(inp, conv.weight, bn.fold[0], bn.fold[1], conv.stride, conv.pad, relu, res, rt)  # noqa: E731
+        y = cb(self.conv1, self.bn1, x, True)
+        y = cb(self.conv2, self.bn2, y, True)
+        idn = cb(self.downsample[0], self.downsample[1], x, False) if self.downsample is not None else x
+        return cb(self.conv3, self.bn3, y, True, idn)
 
     def forward(self, x, rt: Runtime):
         # training: every BatchNorm's batch statistics are produced by the preceding convolution's epilogue
@@ -421,6 +430,7 @@ class ResnetBackbone(nn.Module):
         self.proj = Conv(512, d_model, 1, bias=True)
         self._pos_cache: dict = {}
         self._conv_weights = None
+        self._fold_state = None
 
     def parameters_before_cut(self):
         """parameters whose gradients are produced AFTER the rt.grad_cut() point in the backward (stem, layer1, layer2)"""
@@ -433,6 +443,19 @@ class ResnetBackbone(nn.Module):
             self._pos_cache[key] = ops.cast(pos2d_sine(h, w, d).to(device), rt.dtype)
         return self._pos_cache[key]
 
+    def _refresh_fold(self, device):
+        """eval-mode scale / shift of all BatchNorm layers, recomputed by ONE launch per forward (so a captured graph always folds the
+        current statistics); the job table is rebuilt only when a parameter or buffer moved (optimizer flat buffers, .to())"""
+        bns = [m for m in self.body.modules() if isinstance(m, BN)]
+        key = tuple(t.data_ptr() for m in bns for t in (m.weight, m.bias, m.running_mean, m.running_var))
+        if self._fold_state is None or self._fold_state[0] != key:
+            buf = torch.empty(2 * sum(m.weight.numel() for m in bns), dtype=torch.float32, device=device)
+            table, views = ops.bn_fold_table([(m.weight.detach(), m.bias.detach(), m.running_mean, m.running_var) for m in bns], buf, device)
+            for m, v in zip(bns, views):
+                m.fold = v
+            self._fold_state = (key, table, buf, len(bns))
+        ops.bn_fold_batched(self._fold_state[1], self._fold_state[3])
+
     def forward(self, img: torch.Tensor, rt: Runtime) -> torch.Tensor:
         B, C, H, W = img.shape
         assert C == 4
@@ -442,13 +465,18 @@ class ResnetBackbone(nn.Module):
         if self._conv_weights is None:
             self._conv_weights = [m.weight for m in self.modules() if isinstance(m, Conv)]
         rt.refresh_conv_shadows(self._conv_weights)   # all 3x3 / 7x7 weight re-layouts of this step in one launch
-        x, st = b.conv1(x, rt, stats=True)
-        x = b.bn1(x, rt, True, stats=st)
+        infer = rt.fold_bn and not rt.training and not torch.is_grad_enabled()
+        if infer:
+            self._refresh_fold(img.device)
+            x = RF.conv_bn_infer(x, b.conv1.weight, b.bn1.fold[0], b.bn1.fold[1], b.conv1.stride, b.conv1.pad, True, None, rt)
+        else:
+            x, st = b.conv1(x, rt, stats=True)
+            x = b.bn1(x, rt, True, stats=st)
         x = RF.MaxPoolFn.apply(x)
         feats = {}
         for li in (1, 2, 3, 4):
             for blk in getattr(b, f"layer{li}"):
-                x = blk(x, rt)
+                x = blk.forward_infer(x, rt) if infer else blk(x, rt)
             if li == 2:   # data parallel: stem + layer1-2 hold 6 % of the parameters and most of the backbone's backward time
                 x = rt.grad_cut(x)
             feats[li] = x

@@ -12,7 +12,7 @@ from . import _lib
 from ._abi import RalfConvGeom, RalfGemmDesc
 
 F32, BF16 = 0, 1
-ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2}
+ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "relu_post": 3}   # relu_post: after the residual
 AUX = {None: 0, "relu_mask": 1, "gelu_grad": 2}
 _TORCH2CODE = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -23,12 +23,21 @@ def dtype_code(t: torch.Tensor) -> int:
     return _TORCH2CODE[t.dtype]
 
 
+_ws_retired: list = []
+
+
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """grow-only scratch buffer per (device, stream): reuse is ordered by the stream the kernels run on."""
+    """grow-only scratch buffer per (device, stream): reuse is ordered by the stream the kernels run on.
+    A buffer that is outgrown is RETIRED, never freed: a captured graph holds its raw address (a B = 4 graph followed by a B = 64
+    capture on the same stream replaced the buffer, the allocator released the old one with the first graph's pool, and the second
+    graph -- whose early kernels had still used it -- faulted on replay).  Growth is geometric, so the retired bytes stay below
+    the live buffer's size."""
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     w = _ws_cache.get(key)
     if w is None or w.numel() < nbytes:
-        w = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        if w is not None:
+            _ws_retired.append(w)
+        w = torch.empty(max(nbytes, 1 << 20, 2 * w.numel() if w is not None else 0), dtype=torch.uint8, device=device)
         _ws_cache[key] = w
     return w
 
@@ -37,12 +46,33 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_own_streams: dict = {}
+
+
+def own_stream(slot, device=None) -> "torch.cuda.Stream":
+    """the library-owned HIP stream `slot` (any hashable name) of `device`, created on first use and kept for the life of the
+    process (ralf_stream_create, include/ralf_hip.h).  Every side stream, graph branch and capture stream of the runtime is
+    one of these -- NOT torch.cuda.Stream(), which deals out the 32 streams of a shared pool round-robin: RCCL's stream comes
+    from that same pool, and when a branch landed on it the collective watchdog's event query hit a capturing stream
+    (hipErrorCapturedEvent -> process abort)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, slot)
+    st = _own_streams.get(key)
+    if st is None:
+        with torch.cuda.device(idx):
+            raw = ctypes.c_void_p()
+            _lib.check(_lib.lib().ralf_stream_create(ctypes.byref(raw)), "ralf_stream_create")
+            st = _own_streams[key] = torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", idx))
+    return st
+
+
 def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=True, b_kcontig=True,
          lda=None, ldb=None, out: Optional[torch.Tensor] = None, ldc=None, out_dtype=None,
          bias=None, act=None, res=None, ldr=None, aux=None, aux_mode=None, aux_scale=1.0, out2=None,
          alpha=1.0, accumulate=False, splitk=1, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=None,
          conv: Optional[dict] = None, gather=0, drop_p=0.0, seed=None, call_id=0, atomic=False, colstats=None,
-         sBias0=0, kseg=0, sBk=0) -> torch.Tensor:
+         sBias0=0, kseg=0, sBk=0, colscale=None) -> torch.Tensor:
     """C = epi(alpha * A @ B) through ralf_gemm (see include/ralf_hip.h: RalfGemmDesc)."""
     assert A.is_cuda and B.is_cuda and A.dtype == B.dtype
     d = RalfGemmDesc()
@@ -75,6 +105,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
     d.accumulate, d.splitk, d.alpha = int(accumulate), splitk, alpha
     d.drop_p, d.seed, d.call_id, d.atomic_out = drop_p, _p(seed), call_id, int(atomic)
     d.sBias0, d.kseg, d.sBk = sBias0, kseg, sBk
+    d.colscale = _p(colscale)
     if colstats is not None:   # fp32 [ceil(M/64), 2, N]: per-64-row column sums / sums of squares of the stored output
         assert colstats.dtype == torch.float32 and colstats.numel() >= ((M + 63) // 64) * 2 * N
         d.colstats = _p(colstats)
@@ -316,6 +347,27 @@ def permute4_table(jobs, device):
         blk += max(1, min(256, (dst.numel() + 2047) // 2048))
     raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
     return raw, len(jobs), blk
+
+
+def bn_fold_table(bns, buf, device):
+    """bns: list of (gamma, beta, running_mean, running_var) fp32 tensors; buf: fp32 [2 * sum C] receiving scale | shift of each layer in
+    turn -> (device job table, [(scale view, shift view)]) for bn_fold_batched"""
+    from ._abi import RalfBnFoldJob
+
+    arr = (RalfBnFoldJob * len(bns))()
+    views, off = [], 0
+    for j, (g, b, m, v) in enumerate(bns):
+        C = g.numel()
+        sc, sh = buf[off:off + C], buf[off + C:off + 2 * C]
+        r = arr[j]
+        r.gamma, r.beta, r.mean, r.var, r.scale, r.shift, r.C = g.data_ptr(), b.data_ptr(), m.data_ptr(), v.data_ptr(), sc.data_ptr(), sh.data_ptr(), C
+        views.append((sc, sh))
+        off += 2 * C
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device), views
+
+
+def bn_fold_batched(table, njobs, eps=1e-5):
+    _call("ralf_bn_fold_batched", _p(table), njobs, eps)
 
 
 def permute4_batched(table, njobs, total_blocks):

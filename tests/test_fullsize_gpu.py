@@ -128,11 +128,10 @@ def test_n32_layouts_against_the_oracle_and_full_batch():
     from ralf_amd.helpers.task import get_condition
 
     N = 32
-    with open(os.path.join(GOLDEN, "ralf_state_shapes.json")) as f:
-        shapes = {k: tuple(v) for k, v in json.load(f)["shapes"].items()}
+    model = build(task="uncond", N=N)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}   # (the constraint vocabulary grows with N)
     shapes.update(resnet50_fpn_shapes())
     sd = det_state_dict(shapes)
-    model = build(task="uncond", N=N)
     model.load_state_dict(sd, strict=True)
     model = model.cuda().eval()
     inputs, targets = model.preprocess(make_batch(2, N, H=64, W=64, seed=4))

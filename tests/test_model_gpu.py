@@ -248,6 +248,37 @@ def test_backbone_real_canvas_350x240_fp32_vs_oracle():
     torch.testing.assert_close(out.cpu(), want, atol=2e-4, rtol=2e-4)
 
 
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_inference_backbone_with_folded_batchnorm_equals_separate_batchnorm(dtype):
+    """inference: eval-mode BatchNorm (+ ReLU, + residual) in the convolution epilogues (Runtime.fold_bn) against the
+    convolution -> bn_apply chain, same weights, same input; non-trivial running statistics"""
+    sd = det_state_dict(resnet50_fpn_shapes())
+    g = torch.Generator().manual_seed(5)
+    for k in sd:
+        if k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(sd[k].shape, generator=g)
+        if k.endswith("running_mean"):
+            sd[k] = 0.2 * torch.randn(sd[k].shape, generator=g)
+    img = torch.rand(3, 4, 96, 128, generator=g)
+    bb = RN.ResnetFeatureExtractor(256)
+    bb.load_state_dict({k[len("encoder."):]: v.detach().clone() for k, v in sd.items()}, strict=True)
+    bb = bb.cuda()
+    rt = RN.Runtime(getattr(torch, dtype)).to(torch.device("cuda"))
+    with torch.no_grad():
+        rt.fold_bn = True
+        a = bb(img.cuda(), rt).float()
+        rt.fold_bn = False
+        b = bb(img.cuda(), rt).float()
+    if dtype == "float32":
+        torch.testing.assert_close(a, b, atol=1e-4, rtol=1e-4)
+        ref = O.resnet50_fpn(img, sd, training=False)
+        want = ref.flatten(2).transpose(1, 2) + RN.pos2d_sine(ref.shape[2], ref.shape[3], ref.shape[1])
+        torch.testing.assert_close(a.cpu(), want, atol=2e-4, rtol=2e-4)
+    else:   # the folded path rounds to bf16 once per convolution (after BN+ReLU) instead of twice
+        cos = torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
+        assert cos > 0.9995 and (a - b).abs().max().item() < 0.15 * b.abs().max().item(), (cos, (a - b).abs().max().item())
+
+
 @pytest.mark.parametrize("inpl,planes,stride,ds,H,W", [(2048, 512, 1, False, 4, 5), (1024, 512, 2, True, 8, 10), (64, 64, 1, True, 16, 20)])
 def test_bottleneck_blocks_fp32(inpl, planes, stride, ds, H, W):
     """one ResNet bottleneck (conv/BN/ReLU/residual, train-mode statistics) forward + all gradients vs torch."""

@@ -1,16 +1,29 @@
-"""graph-replayed KV-cached decode (B = 256, cwh, top-k 5) for rocprofv3"""
-import sys, torch
-sys.path.insert(0, "."); sys.path.insert(0, "tools")
-import bench
-from ralf_amd.engine import GraphedDecode
-from ralf_amd.helpers.task import get_condition
-from ralf_amd.synthetic import make_batch
-dev = torch.device("cuda"); B, N, task = 256, 10, "cwh"
-model = bench.build_model(dev, N, "bfloat16", task).eval()
-cond, _ = get_condition(make_batch(B, N, seed=9), task, model.tokenizer)
+"""B = 256 constrained decode (task c, argmax) a few times -- for rocprofv3 timelines: python3 tools/decode_once.py [reps]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from ralf_amd.engine import GraphedDecode  # noqa: E402
+from ralf_amd.helpers.task import get_condition  # noqa: E402
+from ralf_amd.synthetic import make_batch  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+dev = torch.device("cuda", 0)
+model = bench.build_model(dev, 10, "bfloat16", "c").eval()
+cond, _ = get_condition(make_batch(256, 10, seed=9), "c", model.tokenizer)
 cond.retrieved = {k: v for k, v in cond.retrieved.items() if k != "image"}
-cfg = {"name": "top_k", "top_k": 5, "temperature": 1.0}
-dec = GraphedDecode(model, task, cfg, True)
-for _ in range(4):
-    model.sample(cond=cond, sampling_cfg=cfg, cond_type=task, decoder=dec)
+cfg = {"name": "deterministic"}
+dec = GraphedDecode(model, "c", cfg, True)
+for _ in range(reps):
+    res = model.sample(cond=cond, sampling_cfg=cfg, cond_type="c", decoder=dec)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+dec._graph.replay()
+e1.record()
+torch.cuda.synchronize()
+print("graph replay ms", e0.elapsed_time(e1))
