@@ -25,8 +25,25 @@ STEP_GFLOP_PER_SAMPLE = {10: 50.1, 32: 56.4}
 ENCDEC_GFLOP_PER_SAMPLE = {10: 15.98, 32: 22.29}   # everything except ResNet-50 + FPN
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-TRAIN_TRAFFIC_BYTES = 45.6e9  # HBM bytes per train step (B=64): rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, profiles/r01o_train_step_hbm_traffic_pmc.txt
-KNN_TRAFFIC_BYTES = 446.2e6  # HBM bytes per knn_scores launch at nq=16: rocprofv3 FETCH_SIZE x2 (gfx950) + WRITE_SIZE, profiles/r01_knn_pmc.txt
+
+
+def measured_traffic(key):
+    """HBM bytes per launch from the NEWEST committed PMC summary profiles/r*_hbm_traffic.json (written by tools/pmc_total.py from
+    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this very workload: FETCH_SIZE x 2 (gfx950 correction for
+    wide coalesced reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE).  bench.py cannot run the profiler on itself inside the timed
+    region; None when no profile of the workload has been committed.  -> (bytes, entry dict) or (None, None)"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                e = json.load(f).get(key)
+        except (OSError, ValueError):
+            continue
+        if e:
+            e = dict(e, file=os.path.relpath(path, ROOT))
+            return 2.0 * e["fetch_size_bytes"] + e["write_size_bytes"], e
+    return None, None
+
 
 
 def build_model(device, N=10, dtype="bfloat16", task="uncond"):
@@ -337,13 +354,17 @@ def main():
                        "nonpad_tokens_per_s": world * nonpad / (ms * 1e-3), "parallelism": f"dp{world}", "hip_graph": not a.no_graph, "final_loss": final_loss},
             "roofline": {"bound": "mfma", "achieved": flops / (gpu_ms * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / (gpu_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                         "traffic": TRAIN_TRAFFIC_BYTES if (B == 64 and N == 10 and a.dtype.startswith("b")) else None,
-                         "note": f"whole train step: {flops / 1e12:.3f} algorithmic TFLOP per launch (SURVEY 8d: {STEP_GFLOP_PER_SAMPLE.get(N, 50.1)} GFLOP/sample x {B}) / {gpu_ms:.2f} ms (HIP events); per-kernel split in profiles/; traffic = PMC HBM bytes per step (31.1 GB fetched + 14.5 GB written = " + f"{TRAIN_TRAFFIC_BYTES / (gpu_ms * 1e-3) / 1e12:.2f} TB/s): the step is as much HBM- as MFMA-shaped"},
+                         "traffic": None,
+                         "note": f"whole train step: {flops / 1e12:.3f} algorithmic TFLOP per launch (SURVEY 8d: {STEP_GFLOP_PER_SAMPLE.get(N, 50.1)} GFLOP/sample x {B}) / {gpu_ms:.2f} ms (HIP events); per-kernel split in profiles/"},
         }
-        if out["roofline"]["traffic"]:   # the same step seen from the memory side (measured PMC bytes / measured time)
-            gbs = TRAIN_TRAFFIC_BYTES / (gpu_ms * 1e-3) / 1e9
-            out["roofline_hbm_view"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": TRAIN_TRAFFIC_BYTES,
-                                        "note": "whole train step: measured HBM-side bytes per step (not algorithmic bytes) / step time; BatchNorm passes and the 1x1 convolutions of layer1/2 dominate"}
+        tb, te = measured_traffic("train_step_B64_N10_bf16") if (B == 64 and N == 10 and a.dtype.startswith("b")) else (None, None)
+        if tb:   # the same step seen from the memory side (measured PMC bytes / measured time)
+            out["roofline"]["traffic"] = tb
+            out["roofline"]["note"] += (f"; traffic = PMC HBM bytes per step from {te['file']} ({2 * te['fetch_size_bytes'] / 1e9:.1f} GB fetched + "
+                                        f"{te['write_size_bytes'] / 1e9:.1f} GB written = {tb / (gpu_ms * 1e-3) / 1e12:.2f} TB/s): the step is as much HBM- as MFMA-shaped")
+            gbs = tb / (gpu_ms * 1e-3) / 1e9
+            out["roofline_hbm_view"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": tb,
+                                        "note": f"whole train step: measured HBM-side bytes per step ({te['file']}, not algorithmic bytes) / step time; BatchNorm passes and the 1x1 convolutions of layer1/2 dominate"}
         if world == 1 and not a.skip_split:
             t_ed = bench_encdec(device, N, B, a.dtype, a.steps, not a.no_graph)
             f_ed = ENCDEC_GFLOP_PER_SAMPLE.get(N, 15.98) * 1e9 * B
@@ -357,10 +378,11 @@ def main():
         if world == 1 and not a.skip_knn:
             out["knn"] = bench_knn(device)
             k16 = out["knn"]["nq16"]
-            out["roofline_knn"] = {"bound": "hbm", "achieved": k16["scan_GBps"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": k16["scan_hbm_frac"], "traffic": KNN_TRAFFIC_BYTES,
+            kb, ke = measured_traffic("knn_scores_nq16_61548x1792")
+            out["roofline_knn"] = {"bound": "hbm", "achieved": k16["scan_GBps"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": k16["scan_hbm_frac"], "traffic": kb,
                                    "note": "dominant kernel knn_scores_kernel<16,1,2> at nq=16 (HBM-bound regime): 441.2 MB algorithmic bytes per launch (index 61548x1792 fp32 streamed once) / "
                                            f"{k16['scan_us']:.1f} us (HIP events); whole call incl. select+merge {k16['us_per_call']:.1f} us = {k16['hbm_frac']:.3f} of peak; "
-                                           "nq=1024 is fp32-FLOP-bound (see knn.nq1024); traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction), profiles/"}
+                                           "nq=1024 is fp32-FLOP-bound (see knn.nq1024); traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, " + (ke["file"] if ke else "no committed profile")}
         if world == 1 and not a.skip_decode:
             out["decode"] = bench_decode(device, N)
         if world == 1 and not a.skip_cpu:

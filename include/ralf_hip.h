@@ -264,6 +264,14 @@ typedef struct RalfPermuteJob {
     int valid3, src_dtype, dst_dtype, first_block;
 } RalfPermuteJob;
 int ralf_permute4_batched(const RalfPermuteJob* jobs_device, int njobs, int total_blocks, void* stream);
+/* Both GEMM operand layouts of k x k convolution weights from one read of the fp32 OIHW masters, many weights per launch (every
+ * optimizer step re-derives them): ohwi [Co][KK][Cip] (input channels zero-padded to Cip) and ikwo [Ci][KK][Co], KK = kh*kw <= 49,
+ * dst_dtype RALF_F32 / RALF_BF16.  Job j owns workgroups [first_block[j], first_block[j+1]); jobs_device: device array. */
+typedef struct RalfConvRelayoutJob {
+    const void* w; void* ohwi; void* ikwo;
+    int Co, Ci, KK, Cip, dst_dtype, first_block;
+} RalfConvRelayoutJob;
+int ralf_conv_relayout_batched(const RalfConvRelayoutJob* jobs_device, int njobs, int total_blocks, void* stream);
 /* ResNet stem max-pool 3x3/s2/p1 (NHWC) with saved arg-max; FPN nearest up-sampling fused with the lateral add */
 int ralf_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int8_t* arg, int B, int H, int W, int C, void* stream);
 int ralf_maxpool3x3s2_bwd(int dtype, const void* dy, const int8_t* arg, void* dx, int B, int H, int W, int C, void* stream);
@@ -301,6 +309,22 @@ typedef struct RalfAttnDesc {
 } RalfAttnDesc;
 int ralf_attention_fwd(const RalfAttnDesc* d, void* stream);
 int ralf_attention_bwd(const RalfAttnDesc* d, void* stream);
+/* One attention block of a KV-cached decode step with its projections inside (ralf_amd/csrc/attention_mfma.hip): for row b
+ *   h = LayerNorm(x[b]);  q = h Wq^T + bq;  self_: (k, v) = h Wk^T + bk, h Wv^T + bv are written to cache row Sk first;
+ *   o[b] = softmax(q K^T * scale, keys masked by kpm) V   per head, over the Sk cached rows (+ the new one when self_).
+ * Replaces ralf_layernorm_fwd + 2 x ralf_gemm + ralf_attention_fwd of the reference's per-token decoder call
+ * (retrieval_augmented_autoreg.py:274-279, nn.TransformerDecoderLayer norm_first) at batch 256: bf16, d = 256, H = 8.
+ *   x [B, d] bf16 (row stride x_rs)   W: nn.MultiheadAttention.in_proj_weight as bf16 [3d, d] (rows 0..d-1 = q; self_ also k, v)
+ *   bias fp32 [3d]   kv: bf16 cache [B, rows, 2d] (k at column 0, v at column d; strides in elements)   kpm uint8 [B, kpm_bs] or NULL */
+typedef struct RalfDecodeAttnDesc {
+    const void* x; const float* ln_g; const float* ln_b;
+    const void* W; const float* bias;
+    void* kv; const uint8_t* kpm; void* o;
+    int64_t x_rs, kv_bs, kv_rs, kpm_bs, o_rs;
+    int B, H, d, Sk, self_;
+    float scale, eps;
+} RalfDecodeAttnDesc;
+int ralf_decode_attn(const RalfDecodeAttnDesc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer (ralf_amd/csrc/optim.hip): clip_grad_norm_ + AdamW on flat fp32 buffers

@@ -22,8 +22,18 @@ class RalfConvGeom(ctypes.Structure):
     _fields_ = [(n, i32) for n in ("RH", "RW", "SH", "SW", "SC", "KH", "KW", "stride", "pad", "mode")]
 
 
+class RalfDecodeAttnDesc(ctypes.Structure):
+    _fields_ = ([(n, vp) for n in ("x", "ln_g", "ln_b", "W", "bias", "kv", "kpm", "o")]
+                + [(n, i64) for n in ("x_rs", "kv_bs", "kv_rs", "kpm_bs", "o_rs")]
+                + [(n, i32) for n in ("B", "H", "d", "Sk", "self_")] + [("scale", f32), ("eps", f32)])
+
+
 class RalfBnFoldJob(ctypes.Structure):
     _fields_ = [(n, vp) for n in ("gamma", "beta", "mean", "var", "scale", "shift")] + [("C", i32), ("pad_", i32)]
+
+
+class RalfConvRelayoutJob(ctypes.Structure):
+    _fields_ = [(n, vp) for n in ("w", "ohwi", "ikwo")] + [(n, i32) for n in ("Co", "Ci", "KK", "Cip", "dst_dtype", "first_block")]
 
 
 class RalfPermuteJob(ctypes.Structure):
@@ -65,6 +75,7 @@ SIGNATURES.update({
     "ralf_wgrad_grouped": (i32, [ctypes.POINTER(RalfWgradJob), i32, i32, vp, sz, vp]),
     "ralf_colsum_grouped": (i32, [ctypes.POINTER(RalfColsumJob), i32, i32, vp]),
     "ralf_permute4_batched": (i32, [vp, i32, i32, vp]),
+    "ralf_conv_relayout_batched": (i32, [vp, i32, i32, vp]),
     "ralf_gemm_workspace_bytes": (sz, [ctypes.POINTER(RalfGemmDesc)]),
     "ralf_gemm": (i32, [ctypes.POINTER(RalfGemmDesc), vp, sz, vp]),
 })
@@ -114,6 +125,7 @@ SIGNATURES.update({
     "ralf_mask_sample_step": (i32, [vp, vp, vp, i32, i32, f32, vp, u64, vp, vp, i64, vp, i64, i64, i32, i32, vp]),
     "ralf_attention_fwd": (i32, [ctypes.POINTER(RalfAttnDesc), vp]),
     "ralf_attention_bwd": (i32, [ctypes.POINTER(RalfAttnDesc), vp]),
+    "ralf_decode_attn": (i32, [ctypes.POINTER(RalfDecodeAttnDesc), vp]),
     "ralf_sumsq": (i32, [vp, i64, vp, vp]),
     "ralf_clip_coef": (i32, [vp, f32, vp, vp, vp]),
     "ralf_adamw": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, vp, vp, vp]),

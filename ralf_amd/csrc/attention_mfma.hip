@@ -462,9 +462,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const RalfAttnDesc d) 
         bf16x8 kv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int key = key0 + u * 32 + slot;
-            if (key < d.Sk) kv[u] = *reinterpret_cast<const bf16x8*>(Kp + (int64_t)key * d.k_rs);
-            else for (int i = 0; i < 8; ++i) kv[u][i] = (bf16)0.f;
+            // (unconditional load of a clamped row: a load under `if (key < Sk)` is followed by s_waitcnt vmcnt(0), one round trip each)
+            const int key = min(key0 + u * 32 + slot, d.Sk - 1);
+            kv[u] = *reinterpret_cast<const bf16x8*>(Kp + (int64_t)key * d.k_rs);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -507,9 +507,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const RalfAttnDesc d) 
         float p[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int key = key0 + u * 32 + slot;
-            if (key < d.Sk) { vv[u] = *reinterpret_cast<const bf16x8*>(Vp + (int64_t)key * d.v_rs); p[u] = sc[key][head]; }
-            else { for (int i = 0; i < 8; ++i) vv[u][i] = (bf16)0.f; p[u] = 0.f; }
+            const int key = key0 + u * 32 + slot, kc = min(key, d.Sk - 1);
+            vv[u] = *reinterpret_cast<const bf16x8*>(Vp + (int64_t)kc * d.v_rs);
+            p[u] = key < d.Sk ? sc[kc][head] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -532,6 +532,184 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const RalfAttnDesc d) 
         const float lsum = red[1][0][hh] + red[1][1][hh] + red[1][2][hh] + red[1][3][hh];
         const float o = (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) / lsum;
         ((bf16*)d.o)[b * d.o_bs + hp * 64 + tid] = (bf16)o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decode step of one attention block with its projections inside: LayerNorm(x) -> q (and, self-attention, k / v of the new
+// token, appended to the cache) -> attention over the cache -> o.  Replaces the layer-norm, q-projection, k/v-projection and
+// attention launches of a KV-cached decoder step (4 launches of ~5-7 us of mostly launch latency each at B = 256) by one.
+// Workgroup = (batch element, head pair) like attn_decode_kernel; every workgroup normalises its row itself (256 elements) and
+// multiplies it with the 64 (x3) weight rows of its head pair: 32 (96) KB of weights per workgroup, L2 hits after the first.
+// Rounding points are those of the separate kernels (LayerNorm output, q / k / v and o in bf16; fp32 accumulation).
+// d = 256, H = 8 (head dim 32).
+// ------------------------------------------------------------------------------------------------
+template <bool SELF>
+__global__ __launch_bounds__(256) void attn_decode_fused_kernel(const RalfDecodeAttnDesc d) {
+    __shared__ float sc[DEC_MAXK + 1][2];
+    __shared__ float red[2][4][2];
+    __shared__ float part[4][64];
+    __shared__ float hrow[256];
+    __shared__ float qkv[3][64];
+    __shared__ float lnred[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hpairs = d.H / 2, hp = blockIdx.x % hpairs, b = blockIdx.x / hpairs;
+    const int chunk = lane & 7, slot = lane >> 3, head = chunk >> 2;
+    const int D = 256;
+    // ---- LayerNorm of the row ----
+    {
+        const float xv = (float)((const bf16*)d.x)[(int64_t)b * d.x_rs + tid];
+        float s = xv;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+        if (lane == 0) lnred[0][wave] = s;
+        __syncthreads();
+        const float mu = (lnred[0][0] + lnred[0][1] + lnred[0][2] + lnred[0][3]) * (1.f / D);
+        const float dv = xv - mu;
+        float q2 = dv * dv;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) q2 += __shfl_xor(q2, o);
+        if (lane == 0) lnred[1][wave] = q2;
+        __syncthreads();
+        const float rs = rsqrtf((lnred[1][0] + lnred[1][1] + lnred[1][2] + lnred[1][3]) * (1.f / D) + d.eps);
+        hrow[tid] = (float)(bf16)(dv * rs * d.ln_g[tid] + d.ln_b[tid]);
+    }
+    __syncthreads();
+    // ---- projections: 8 lanes per weight row (one 128-byte line per load instruction and row), 8 rows per wave-load ----
+    {
+        constexpr int NP = SELF ? 3 : 1;
+        const int sub = lane >> 3, ch = lane & 7;
+        bf16x8 w[NP][2][4];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int row = ps * 32 + wave * 8 + sub;
+                const bf16* wr = (const bf16*)d.W + (int64_t)(p * D + hp * 64 + row) * D + ch * 8;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[p][ps][i] = *reinterpret_cast<const bf16x8*>(wr + i * 64);
+            }
+        float hv[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[i][e] = hrow[i * 64 + ch * 8 + e];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a += hv[i][e] * (float)w[p][ps][i][e];
+                a += __shfl_xor(a, 1);
+                a += __shfl_xor(a, 2);
+                a += __shfl_xor(a, 4);
+                const int row = ps * 32 + wave * 8 + sub;
+                if (ch == 0) qkv[p][row] = (float)(bf16)(a + d.bias[p * D + hp * 64 + row]);
+            }
+    }
+    __syncthreads();
+    bf16* KV = (bf16*)d.kv + (int64_t)b * d.kv_bs + hp * 64;
+    if (SELF && tid < 128) {   // the new token's k / v: row Sk of the cache (k at column 0, v at column d)
+        const int which = tid >> 6, c = tid & 63;
+        KV[(int64_t)d.Sk * d.kv_rs + which * D + c] = (bf16)qkv[1 + which][c];
+    }
+    const bf16* Kp = KV + chunk * 8;
+    const bf16* Vp = KV + D + chunk * 8;
+    const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * d.kpm_bs : nullptr;
+    float qv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qv[i] = qkv[0][chunk * 8 + i] * d.scale;
+    const int nk = SELF ? d.Sk + 1 : d.Sk;   // keys incl. the new one (whose k / v are still in LDS)
+    // ---- pass 1: scores of the cached keys ----
+    if (d.Sk > 0) {
+        for (int key0 = wave * 8; key0 < d.Sk; key0 += 32 * 4) {
+            bf16x8 kv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int key = min(key0 + u * 32 + slot, d.Sk - 1);
+                kv[u] = *reinterpret_cast<const bf16x8*>(Kp + (int64_t)key * d.kv_rs);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int key = key0 + u * 32 + slot;
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += qv[i] * (float)kv[u][i];
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                if ((chunk & 3) == 0 && key < d.Sk) sc[key][head] = (kpm && kpm[key]) ? -__builtin_inff() : s;
+            }
+        }
+    }
+    if (SELF && tid < 8) {   // the new key (lanes 0..7 of wave 0: slot 0)
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += qv[i] * qkv[1][chunk * 8 + i];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if ((chunk & 3) == 0) sc[d.Sk][head] = (kpm && kpm[d.Sk]) ? -__builtin_inff() : s;
+    }
+    __syncthreads();
+    // ---- softmax over the keys, per head (thread parity = head) ----
+    const int h2 = tid & 1;
+    float m = -__builtin_inff();
+    for (int key = tid >> 1; key < nk; key += 128) m = fmaxf(m, sc[key][h2]);
+#pragma unroll
+    for (int o = 2; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane < 2) red[0][wave][lane] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0][0][h2], red[0][1][h2]), fmaxf(red[0][2][h2], red[0][3][h2]));
+    const float mref = m > -__builtin_inff() ? m : 0.f;
+    float l = 0.f;
+    for (int key = tid >> 1; key < nk; key += 128) {
+        const float p = __expf(sc[key][h2] - mref);
+        sc[key][h2] = p;
+        l += p;
+    }
+#pragma unroll
+    for (int o = 2; o < 64; o <<= 1) l += __shfl_xor(l, o);
+    if (lane < 2) red[1][wave][lane] = l;
+    __syncthreads();
+    // ---- pass 2: weighted sum of V ----
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    if (d.Sk > 0) {
+        for (int key0 = wave * 8; key0 < d.Sk; key0 += 32 * 4) {
+            bf16x8 vv[4];
+            float p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int key = key0 + u * 32 + slot, kc = min(key, d.Sk - 1);
+                vv[u] = *reinterpret_cast<const bf16x8*>(Vp + (int64_t)kc * d.kv_rs);
+                p[u] = key < d.Sk ? sc[kc][head] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += p[u] * (float)vv[u][i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        acc[i] += __shfl_xor(acc[i], 8);
+        acc[i] += __shfl_xor(acc[i], 16);
+        acc[i] += __shfl_xor(acc[i], 32);
+    }
+    if (slot == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) part[wave][chunk * 8 + i] = acc[i];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int hh = tid >> 5;
+        const float lsum = red[1][0][hh] + red[1][1][hh] + red[1][2][hh] + red[1][3][hh];
+        float o = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+        if (SELF) o += sc[d.Sk][hh] * qkv[2][tid];
+        ((bf16*)d.o)[(int64_t)b * d.o_rs + hp * 64 + tid] = (bf16)(o / lsum);
     }
 }
 }  // namespace
@@ -558,4 +736,18 @@ int ralf_attention_bwd_mfma(const RalfAttnDesc& d, hipStream_t st) {
         hipLaunchKernelGGL((attn_bwd_dkv_mfma<64>), gk, dim3(256), 0, st, d);
     }
     return ralf::check_launch("attention_bwd_mfma");
+}
+
+extern "C" int ralf_decode_attn(const RalfDecodeAttnDesc* dp, void* stream) {
+    RALF_REQUIRE(dp, "decode_attn: null descriptor");
+    const RalfDecodeAttnDesc& d = *dp;
+    RALF_REQUIRE(d.x && d.ln_g && d.ln_b && d.W && d.bias && d.kv && d.o, "decode_attn: null pointer");
+    RALF_REQUIRE(d.d == 256 && d.H == 8 && d.B > 0 && d.Sk >= 0 && (d.self_ || d.Sk > 0) && d.Sk + (d.self_ ? 1 : 0) <= DEC_MAXK,
+                 "decode_attn: needs d = 256, H = 8 and at most %d keys (got d=%d H=%d Sk=%d)", DEC_MAXK, d.d, d.H, d.Sk);
+    RALF_REQUIRE(d.kv_rs % 8 == 0 && d.kv_bs % 8 == 0 && ((uintptr_t)d.kv % 16) == 0 && ((uintptr_t)d.W % 16) == 0 && (!d.kpm || d.kpm_bs > 0),
+                 "decode_attn: cache rows and weights must be 16-byte aligned; kpm needs its row stride");
+    hipStream_t st = (hipStream_t)stream;
+    if (d.self_) hipLaunchKernelGGL(attn_decode_fused_kernel<true>, dim3(d.B * 4), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(attn_decode_fused_kernel<false>, dim3(d.B * 4), dim3(256), 0, st, d);
+    return ralf::check_launch("decode_attn");
 }

@@ -305,6 +305,54 @@ __global__ __launch_bounds__(256) void permute4_batched_kernel(const RalfPermute
     else permute4_job<bf16, bf16>(J, blk, nblk);
 }
 
+// ---- both GEMM layouts of a k x k convolution weight from ONE read of the fp32 OIHW master:
+//   ohwi[o][t][i] (i padded with zeros to Cip: the forward's k-contiguous B operand) and ikwo[i][t][o] (the data gradient's), t = kh*kw.
+// A workgroup owns a tile of 8 output channels x 64 input channels (all taps): the reads are runs of 64*KK contiguous floats per
+// output channel, the writes 128-byte runs of i (ohwi) and 16-byte vectors of o (ikwo).  (The generic element-wise permute read
+// with a stride and divided three times per element: 109 us per step for the 17 weights of the ResNet-50 + FPN, 45 MB.)
+constexpr int RL_O = 8, RL_LS = 577;   // 8 output channels x (i-tile * KK <= 576) floats (+1: bank spread)
+__host__ __device__ __forceinline__ int rl_itile(int KK) { return KK <= 9 ? 64 : (576 / KK > 0 ? 576 / KK : 1); }
+template <typename TD>
+__device__ __forceinline__ void relayout_tile(const RalfConvRelayoutJob& J, int tile, float* lds) {
+    const int KK = J.KK, TI = rl_itile(KK), nti = (J.Ci + TI - 1) / TI;
+    const int o0 = (tile / nti) * RL_O, i0 = (tile % nti) * TI;
+    const int ni = min(TI, J.Ci - i0), no = min(RL_O, J.Co - o0);
+    const float* in = (const float*)J.w;
+    const int run = ni * KK;                       // contiguous floats per output channel
+    for (int e = threadIdx.x; e < RL_O * run; e += 256) {
+        const int o = e / run, r = e - o * run;
+        lds[o * RL_LS + r] = o < no ? in[((int64_t)(o0 + o) * J.Ci + i0) * KK + r] : 0.f;
+    }
+    __syncthreads();
+    TD* o1 = (TD*)J.ohwi;
+    TD* o2 = (TD*)J.ikwo;
+    // ohwi: [o][t][i0 + i]; channels beyond Ci (up to Cip) are zero
+    const int nip = (i0 + TI >= J.Ci) ? (J.Cip - i0) : TI;     // the last i-tile also writes the padding
+    for (int e = threadIdx.x; e < no * KK * nip; e += 256) {
+        const int i = e % nip, t = (e / nip) % KK, o = e / (nip * KK);
+        const float v = i < ni ? lds[o * RL_LS + i * KK + t] : 0.f;
+        o1[((int64_t)(o0 + o) * KK + t) * J.Cip + i0 + i] = (TD)v;
+    }
+    // ikwo: [i0 + i][t][o0 + o]
+    for (int e = threadIdx.x; e < ni * KK * no; e += 256) {
+        const int o = e % no, t = (e / no) % KK, i = e / (no * KK);
+        o2[((int64_t)(i0 + i) * KK + t) * J.Co + o0 + o] = (TD)lds[o * RL_LS + i * KK + t];
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void conv_relayout_batched_kernel(const RalfConvRelayoutJob* __restrict__ jobs, int njobs) {
+    __shared__ float lds[RL_O * RL_LS];
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;
+    const RalfConvRelayoutJob J = jobs[j];
+    const int nblk = (j + 1 < njobs ? jobs[j + 1].first_block : (int)gridDim.x) - J.first_block;
+    const int TI = rl_itile(J.KK);
+    const int ntiles = ((J.Co + RL_O - 1) / RL_O) * ((J.Ci + TI - 1) / TI);
+    for (int tile = (int)blockIdx.x - J.first_block; tile < ntiles; tile += nblk) {
+        if (J.dst_dtype == RALF_F32) relayout_tile<float>(J, tile, lds); else relayout_tile<bf16>(J, tile, lds);
+    }
+}
+
 // 3x3 stride-2 pad-1 max pooling, NHWC; arg = window position (kh*3+kw) of the FIRST maximum.
 // One thread owns VEC consecutive channels of one pixel (16-byte accesses, 32-bit index math):
 // the scalar one-element-per-thread version ran at 1/8 of the HBM rate.
@@ -465,8 +513,10 @@ __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restric
     int bi = 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < MAXPER; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = (c < V && (!allowed || allowed[c])) ? x[c] : NEG;
+        const int c = lane + 64 * i, cc = min(c, V - 1);   // unconditional loads of a clamped column (conditional ones are serialised)
+        const float xv = x[cc];
+        const uint8_t al = allowed ? allowed[cc] : (uint8_t)1;
+        v[i] = (c < V && al) ? xv : NEG;
         if (v[i] > best) { best = v[i]; bi = c; }
     }
     // wave arg-max with lowest-index tie break
@@ -634,6 +684,11 @@ extern "C" int ralf_permute4_batched(const RalfPermuteJob* jobs_device, int njob
     RALF_REQUIRE(jobs_device && njobs > 0 && total_blocks >= njobs, "permute4_batched: bad arguments");
     hipLaunchKernelGGL(permute4_batched_kernel, dim3(total_blocks), dim3(256), 0, ST, jobs_device, njobs);
     return ralf::check_launch("permute4_batched");
+}
+extern "C" int ralf_conv_relayout_batched(const RalfConvRelayoutJob* jobs_device, int njobs, int total_blocks, void* stream) {
+    RALF_REQUIRE(jobs_device && njobs > 0 && total_blocks >= njobs, "conv_relayout_batched: bad arguments");
+    hipLaunchKernelGGL(conv_relayout_batched_kernel, dim3(total_blocks), dim3(256), 0, ST, jobs_device, njobs);
+    return ralf::check_launch("conv_relayout_batched");
 }
 extern "C" int ralf_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int8_t* arg, int B, int H, int W, int C, void* stream) {
     RALF_REQUIRE(x && y && arg && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "maxpool_fwd: bad arguments (C %% 8 == 0)");

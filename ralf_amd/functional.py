@@ -60,6 +60,7 @@ class Runtime:
         self._masked: dict = {}
         self._fanout: dict = {}
         self.ln_dropout = True
+        self.fused_decode = True  # KV-cached decode step: LayerNorm + projections + attention per block in one launch (bf16, d = 256, 8 heads)
         self.fold_bn = True       # inference: eval-mode BatchNorm folded into the convolution epilogues (conv_bn_infer)
 
     def to(self, device):
@@ -264,15 +265,14 @@ class Runtime:
                 cip = (Ci + 7) // 8 * 8
                 o1 = torch.empty(Co, kh, kw, cip, dtype=self.dtype, device=w.device)
                 o2 = torch.empty(Ci, kh, kw, Co, dtype=self.dtype, device=w.device)
-                jobs.append((w.detach(), o1, (Co, kh, kw, cip), (Ci * kh * kw, kw, 1, kh * kw), Ci))
-                jobs.append((w.detach(), o2, (Ci, kh, kw, Co), (kh * kw, kw, 1, Ci * kh * kw), Co))
+                jobs.append((w.detach(), o1, o2))
                 outs.append((o1, o2))
-            table, n, blocks = ops.permute4_table(jobs, ws[0].device)
+            table, n, blocks = ops.conv_relayout_table(jobs, ws[0].device)
             st = self._conv_table = {"ptrs": tuple(w.data_ptr() for w in ws), "dtype": self.dtype, "table": table, "n": n, "blocks": blocks,
                                      "outs": outs, "sig": None, "token": None}
         if st["sig"] == sig and st["token"] == self._wtoken:
             return
-        ops.permute4_batched(st["table"], st["n"], st["blocks"])
+        ops.conv_relayout_batched(st["table"], st["n"], st["blocks"])
         for w, (o1, o2) in zip(ws, st["outs"]):
             stamp = ((w._version, self._wtoken), w.data_ptr())
             self._lp[(id(w), "ohwi", self.dtype)] = (stamp[0], stamp[1], o1, weakref.ref(w))

@@ -249,21 +249,31 @@ def decoder_step(dec: "BaseDecoder", tok: torch.Tensor, pos: int, cache: DecodeC
     dh = d // H
     x = ops.embed_fwd(tok.view(B, 1).contiguous(), dec.emb.weight.detach(), dec.pos_emb.pe[0, pos:pos + 1].contiguous(), 1, math.sqrt(d), rt.dtype).view(B, d)
     L = cache.max_len
+    # bf16, d = 256, 8 heads: LayerNorm + q / k / v projections + attention of each block in ONE launch (ralf_decode_attn)
+    fused = rt.fused_decode and rt.dtype == torch.bfloat16 and d == 256 and H == 8 and x.stride(1) == 1
     for li, layer in enumerate(dec.transformer.layers):
         sa, ca = layer.self_attn, layer.multihead_attn
-        h, _, _ = ops.layernorm_fwd(x, layer.norm1.weight.detach(), layer.norm1.bias.detach(), save_stats=False)
-        W, bvec = rt.lp(sa.in_proj_weight), sa.in_proj_bias.detach()
-        q = ops.gemm(h, W[:d], B, d, d, bias=bvec[:d])
-        skv = cache.self_kv[li]
-        # k,v of the new token go straight into row `pos` of the cache (row stride = L*2d)
-        ops.gemm(h, W[d:], B, 2 * d, d, bias=bvec[d:], out=skv.view(B, L * 2 * d)[:, pos * 2 * d:], ldc=L * 2 * d)
-        o, _ = ops.attention_fwd(q.view(B, 1, d), skv, skv, B, H, 1, pos + 1, dh, 0, 0, d, causal=False, kpm=kpm_prefix, need_lse=False, kv_rows=L, kpm_stride=kpm_stride)
-        x = ops.gemm(o.view(B, d), rt.lp(sa.out_proj.weight), B, d, d, bias=sa.out_proj.bias.detach(), res=x)
-        h, _, _ = ops.layernorm_fwd(x, layer.norm2.weight.detach(), layer.norm2.bias.detach(), save_stats=False)
-        q = ops.gemm(h, rt.lp(ca.in_proj_weight)[:d], B, d, d, bias=ca.in_proj_bias.detach()[:d])
-        ckv = cache.cross_kv[li]
-        o, _ = ops.attention_fwd(q.view(B, 1, d), ckv, ckv, B, H, 1, ckv.shape[1], dh, 0, 0, d, need_lse=False)
-        x = ops.gemm(o.view(B, d), rt.lp(ca.out_proj.weight), B, d, d, bias=ca.out_proj.bias.detach(), res=x)
+        skv, ckv = cache.self_kv[li], cache.cross_kv[li]
+        if fused:
+            kst = kpm_stride if kpm_stride else kpm_prefix.shape[1]
+            o = ops.decode_attn(x, layer.norm1.weight.detach(), layer.norm1.bias.detach(), rt.lp(sa.in_proj_weight), sa.in_proj_bias.detach(),
+                                skv, pos, H, True, kpm=kpm_prefix, kpm_stride=kst)
+            x = ops.gemm(o, rt.lp(sa.out_proj.weight), B, d, d, bias=sa.out_proj.bias.detach(), res=x)
+            o = ops.decode_attn(x, layer.norm2.weight.detach(), layer.norm2.bias.detach(), rt.lp(ca.in_proj_weight), ca.in_proj_bias.detach(),
+                                ckv, ckv.shape[1], H, False)
+            x = ops.gemm(o, rt.lp(ca.out_proj.weight), B, d, d, bias=ca.out_proj.bias.detach(), res=x)
+        else:
+            h, _, _ = ops.layernorm_fwd(x, layer.norm1.weight.detach(), layer.norm1.bias.detach(), save_stats=False)
+            W, bvec = rt.lp(sa.in_proj_weight), sa.in_proj_bias.detach()
+            q = ops.gemm(h, W[:d], B, d, d, bias=bvec[:d])
+            # k,v of the new token go straight into row `pos` of the cache (row stride = L*2d)
+            ops.gemm(h, W[d:], B, 2 * d, d, bias=bvec[d:], out=skv.view(B, L * 2 * d)[:, pos * 2 * d:], ldc=L * 2 * d)
+            o, _ = ops.attention_fwd(q.view(B, 1, d), skv, skv, B, H, 1, pos + 1, dh, 0, 0, d, causal=False, kpm=kpm_prefix, need_lse=False, kv_rows=L, kpm_stride=kpm_stride)
+            x = ops.gemm(o.view(B, d), rt.lp(sa.out_proj.weight), B, d, d, bias=sa.out_proj.bias.detach(), res=x)
+            h, _, _ = ops.layernorm_fwd(x, layer.norm2.weight.detach(), layer.norm2.bias.detach(), save_stats=False)
+            q = ops.gemm(h, rt.lp(ca.in_proj_weight)[:d], B, d, d, bias=ca.in_proj_bias.detach()[:d])
+            o, _ = ops.attention_fwd(q.view(B, 1, d), ckv, ckv, B, H, 1, ckv.shape[1], dh, 0, 0, d, need_lse=False)
+            x = ops.gemm(o.view(B, d), rt.lp(ca.out_proj.weight), B, d, d, bias=ca.out_proj.bias.detach(), res=x)
         h, _, _ = ops.layernorm_fwd(x, layer.norm3.weight.detach(), layer.norm3.bias.detach(), save_stats=False)
         f = ops.gemm(h, rt.lp(layer.linear1.weight), B, layer.linear1.weight.shape[0], d, bias=layer.linear1.bias.detach(), act="relu")
         x = ops.gemm(f, rt.lp(layer.linear2.weight), B, d, f.shape[1], bias=layer.linear2.bias.detach(), res=x)

@@ -370,6 +370,28 @@ def bn_fold_batched(table, njobs, eps=1e-5):
     _call("ralf_bn_fold_batched", _p(table), njobs, eps)
 
 
+def conv_relayout_table(jobs, device):
+    """jobs: list of (w fp32 OIHW, ohwi [Co, kh, kw, Cip], ikwo [Ci, kh, kw, Co]) -> (device table, njobs, total_blocks)"""
+    from ._abi import RalfConvRelayoutJob
+
+    arr = (RalfConvRelayoutJob * len(jobs))()
+    blk = 0
+    for j, (w, o1, o2) in enumerate(jobs):
+        Co, Ci, kh, kw = w.shape
+        assert w.dtype == torch.float32 and w.is_contiguous() and o1.is_contiguous() and o2.is_contiguous() and kh * kw <= 49
+        assert tuple(o1.shape[:3]) == (Co, kh, kw) and tuple(o2.shape) == (Ci, kh, kw, Co) and o1.dtype == o2.dtype
+        r = arr[j]
+        r.w, r.ohwi, r.ikwo = w.data_ptr(), o1.data_ptr(), o2.data_ptr()
+        r.Co, r.Ci, r.KK, r.Cip, r.dst_dtype, r.first_block = Co, Ci, kh * kw, o1.shape[3], dtype_code(o1), blk
+        ti = 64 if kh * kw <= 9 else max(1, 576 // (kh * kw))
+        blk += max(1, min(512, ((Co + 7) // 8) * ((Ci + ti - 1) // ti)))
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device), len(jobs), blk
+
+
+def conv_relayout_batched(table, njobs, total_blocks):
+    _call("ralf_conv_relayout_batched", _p(table), njobs, total_blocks)
+
+
 def permute4_batched(table, njobs, total_blocks):
     _call("ralf_permute4_batched", _p(table), njobs, total_blocks)
 
@@ -484,6 +506,23 @@ def attention_fwd(q, k, v, B, H, Sq, Sk, dh, q_off=0, k_off=0, v_off=0, causal=F
     d.kpm_bs = int(kpm_stride) if kpm_stride else 0   # kpm rows longer than Sk: one [B, max_len] mask for a growing prefix
     _call("ralf_attention_fwd", ctypes.byref(d))
     return o, lse
+
+
+def decode_attn(x, ln_g, ln_b, W, bias, kv, Sk, H, self_attn, kpm=None, kpm_stride=0, eps=1e-5):
+    """one attention block of a KV-cached decode step with LayerNorm and the q (k, v) projections inside (ralf_decode_attn):
+    x [B, d] bf16, W bf16 [3d, d] (in_proj_weight), bias fp32 [3d], kv bf16 cache [B, rows, 2d] -> o [B, d]."""
+    from ._abi import RalfDecodeAttnDesc
+
+    B, d_model = x.shape
+    assert x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and kv.dtype == torch.bfloat16 and kv.shape[2] == 2 * d_model
+    o = torch.empty(B, d_model, dtype=x.dtype, device=x.device)
+    d = RalfDecodeAttnDesc()
+    d.x, d.ln_g, d.ln_b, d.W, d.bias, d.kv, d.kpm, d.o = _p(x), _p(ln_g), _p(ln_b), _p(W), _p(bias), _p(kv), _p(kpm), _p(o)
+    d.x_rs, d.kv_bs, d.kv_rs, d.kpm_bs, d.o_rs = x.stride(0), kv.stride(0), kv.stride(1), int(kpm_stride), d_model
+    d.B, d.H, d.d, d.Sk, d.self_ = B, H, d_model, int(Sk), int(bool(self_attn))
+    d.scale, d.eps = (d_model // H) ** -0.5, eps
+    _call("ralf_decode_attn", ctypes.byref(d))
+    return o
 
 
 def attention_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, dh, q_off=0, k_off=0, v_off=0, dq_off=0, dk_off=0, dv_off=0,

@@ -348,6 +348,47 @@ def test_deterministic_sample_matches_reference(golden, task):
             assert torch.equal(out[k], r["result"][k]), (k, kv)  # identical tokens -> identical bin centres
 
 
+@pytest.mark.parametrize("task", ["c", "uncond"])
+def test_fused_decode_attention_equals_separate_kernels_bf16(golden, task):
+    """KV-cached decode step in bf16: LayerNorm + q/k/v projections + attention per block in one launch (ralf_decode_attn) against
+    the layer-norm / GEMM / attention kernel chain -- same rounding points, so logits agree to bf16 accumulation-order noise,
+    step by step on the same tokens (teacher-forced by the separate-kernel path), keys masked by the padding flags included"""
+    r = golden("sample.npz").sub(task)
+    model = load_det(build(task=task, compute_dtype="bfloat16"), "ralf_state_shapes.json").eval()
+    model.encoder = FeatStandIn(r["feat"].cuda())
+    rt, dec = model.rt, model.decoder
+    dev = torch.device("cuda")
+    enc_in = {"image": torch.zeros(r["feat"].shape[0], 4, 8, 8, device=dev), "retrieved": to_dev(dict(r["retrieved"])),
+              "seq_layout_const": r["seq_layout_const"].cuda(), "seq_layout_const_pad_mask": r["seq_layout_const_pad_mask"].cuda()}
+    with torch.no_grad():
+        rt.to(dev).begin_step()
+        memory = model._encode_into_memory(enc_in)["memory"]
+        B, T = memory.shape[0], model.tokenizer.max_token_length
+        ids = model.special_token_ids
+        caches = {f: RN.decoder_init_cache(dec, memory, rt, T) for f in (True, False)}
+        seq = torch.full((B, 1), ids["bos"], dtype=torch.long, device=dev)
+        model._token_mask_dev(dev)
+        worst, agree = 0.0, 0
+        for i in range(T):
+            kpm = (seq == ids["pad"]).to(torch.uint8).contiguous()
+            if i == 7:
+                kpm[0, 3] = 1    # a masked key inside the prefix
+            out = {}
+            for f in (True, False):
+                rt.fused_decode = f
+                out[f] = RN.decoder_step(dec, seq[:, i].contiguous(), i, caches[f], rt, kpm).float()
+            worst = max(worst, ((out[True] - out[False]).abs().max() / (1.0 + out[False].abs().max())).item())
+            nxt = RN.ops.mask_sample(out[False], model._token_mask_u8[i], None, 0, 1, 1.0, rt.seed, 1000 + i)
+            agree += int((out[True].argmax(1) == out[False].argmax(1)).sum())
+            seq = torch.cat([seq, nxt.view(B, 1)], dim=1)
+        rt.fused_decode = True
+        # the caches hold the same keys / values (bf16-rounded the same way)
+        for a, b in zip(caches[True].self_kv, caches[False].self_kv):
+            assert (a.float() - b.float()).abs().max().item() <= 0.02 * (1 + b.float().abs().max().item())
+    assert worst < 0.03, worst
+    assert agree >= 0.97 * B * T, (agree, B * T)
+
+
 def test_train_mode_dropout_step_is_finite_and_seeded(golden):
     r = golden("e2e.npz").sub("ralf_uncond")
     model = load_det(build(task="uncond", compute_dtype="bfloat16"), "ralf_state_shapes.json").train()

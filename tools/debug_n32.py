@@ -54,3 +54,14 @@ with torch.no_grad():
             print(f"step {i:3d} max|dlogit| {d:.3e} token mismatch rows {ne} npad {int(kpm.sum())} top2 gap (min over rows) {(t2[:, 0] - t2[:, 1]).min().item():.3e}", flush=True)
         seq = torch.cat([seq, ta.view(B, 1)], dim=1)
     print("worst", worst)
+
+with torch.no_grad():
+    cfg = {"name": "deterministic"}
+    a = mc.decode_tokens(enc_in, cond_seq, "c", cfg, True)
+    b = mc.decode_tokens(enc_in, cond_seq, "c", cfg, False)
+    ne = (a != b).nonzero()
+    print("decode_tokens cached(static buffers) vs full: mismatches", ne.shape[0], ne[:10].tolist())
+    if ne.shape[0]:
+        r, c = ne[0].tolist()
+        print("row", r, "col", c, "cached", a[r, max(0, c - 3):c + 3].tolist(), "full", b[r, max(0, c - 3):c + 3].tolist(), "teacher", seq[r, 1 + max(0, c - 3):1 + c + 3].tolist())
+    print("full == teacher-forced", bool((b == seq[:, 1:]).all()), " cached == teacher-forced", bool((a == seq[:, 1:]).all()))
