@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const RalfAttnDesc d) 
 // Rounding points are those of the separate kernels (LayerNorm output, q / k / v and o in bf16; fp32 accumulation).
 // d = 256, H = 8 (head dim 32).
 // ------------------------------------------------------------------------------------------------
-template <bool SELF>
+template <bool SELF, int NS>
 __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const RalfDecodeAttnDesc d) {
     __shared__ float sc[DEC_MAXK + 1][2];
     __shared__ float red[2][4][2];
@@ -553,9 +553,30 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const RalfDecode
     __shared__ float qkv[3][64];
     __shared__ float lnred[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hpairs = d.H / 2, hp = blockIdx.x % hpairs, b = blockIdx.x / hpairs;
+    const int hpairs = d.H / 2, hp = blockIdx.x % hpairs, b0 = (blockIdx.x / hpairs) * NS;
     const int chunk = lane & 7, slot = lane >> 3, head = chunk >> 2;
-    const int D = 256;
+    constexpr int D = 256;
+    constexpr int NP = SELF ? 3 : 1;
+    // ---- the head pair's weight rows, once per workgroup: 8 lanes per row (one 128-byte line per load instruction and row),
+    //      8 rows per wave-load.  (NS batch elements share them: with one element per workgroup the 1024 workgroups pulled
+    //      100 MB of the same 384 KB through the L2 per call and the self-attention block took 21 us.)
+    const int sub = lane >> 3;
+    bf16x8 w[NP][2][4];
+    float bias_r[NP][2];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int row = ps * 32 + wave * 8 + sub;
+            const bf16* wr = (const bf16*)d.W + (int64_t)(p * D + hp * 64 + row) * D + chunk * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[p][ps][i] = *reinterpret_cast<const bf16x8*>(wr + i * 64);
+            bias_r[p][ps] = d.bias[p * D + hp * 64 + row];
+        }
+    const float ln_g = d.ln_g[tid], ln_b = d.ln_b[tid];
+    for (int si = 0; si < NS; ++si) {
+    const int b = b0 + si;
+    if (b >= d.B) break;
     // ---- LayerNorm of the row ----
     {
         const float xv = (float)((const bf16*)d.x)[(int64_t)b * d.x_rs + tid];
@@ -572,28 +593,16 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const RalfDecode
         if (lane == 0) lnred[1][wave] = q2;
         __syncthreads();
         const float rs = rsqrtf((lnred[1][0] + lnred[1][1] + lnred[1][2] + lnred[1][3]) * (1.f / D) + d.eps);
-        hrow[tid] = (float)(bf16)(dv * rs * d.ln_g[tid] + d.ln_b[tid]);
+        hrow[tid] = (float)(bf16)(dv * rs * ln_g + ln_b);
     }
     __syncthreads();
-    // ---- projections: 8 lanes per weight row (one 128-byte line per load instruction and row), 8 rows per wave-load ----
+    // ---- projections ----
     {
-        constexpr int NP = SELF ? 3 : 1;
-        const int sub = lane >> 3, ch = lane & 7;
-        bf16x8 w[NP][2][4];
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                const int row = ps * 32 + wave * 8 + sub;
-                const bf16* wr = (const bf16*)d.W + (int64_t)(p * D + hp * 64 + row) * D + ch * 8;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) w[p][ps][i] = *reinterpret_cast<const bf16x8*>(wr + i * 64);
-            }
         float hv[4][8];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hv[i][e] = hrow[i * 64 + ch * 8 + e];
+            for (int e = 0; e < 8; ++e) hv[i][e] = hrow[i * 64 + chunk * 8 + e];
 #pragma unroll
         for (int p = 0; p < NP; ++p)
 #pragma unroll
@@ -606,8 +615,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const RalfDecode
                 a += __shfl_xor(a, 1);
                 a += __shfl_xor(a, 2);
                 a += __shfl_xor(a, 4);
-                const int row = ps * 32 + wave * 8 + sub;
-                if (ch == 0) qkv[p][row] = (float)(bf16)(a + d.bias[p * D + hp * 64 + row]);
+                if (chunk == 0) qkv[p][ps * 32 + wave * 8 + sub] = (float)(bf16)(a + bias_r[p][ps]);
             }
     }
     __syncthreads();
@@ -711,6 +719,206 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const RalfDecode
         if (SELF) o += sc[d.Sk][hh] * qkv[2][tid];
         ((bf16*)d.o)[(int64_t)b * d.o_rs + hp * 64 + tid] = (bf16)(o / lsum);
     }
+    if (NS > 1) __syncthreads();   // the LDS arrays are reused by the next batch element
+    }
+}
+
+// Self-attention block of a decode step, 4 batch elements per workgroup, one WAVE per element: the head pair's q / k / v weight rows
+// (96 KB) are loaded once per workgroup, spread over the registers of its 4 waves; every wave multiplies ITS rows with the
+// normalised rows of all 4 elements (LDS), and after one barrier each wave runs the whole attention of its own element (a few dozen
+// cached keys) with wave-local reductions only.  (One element per workgroup: 1024 workgroups pulled 100 MB of the same 384 KB of
+// weights through the L2, 21 us; four elements one after the other in a workgroup: 25 us of serial latency chains.)
+__global__ __launch_bounds__(256) void attn_decode_self4_kernel(const RalfDecodeAttnDesc d) {
+    constexpr int D = 256, NS = 4;
+    __shared__ float hrow[NS][D];
+    __shared__ float qkv[NS][3][64];
+    __shared__ float sc[NS][DEC_MAXK + 1][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hpairs = d.H / 2, hp = blockIdx.x % hpairs, b0 = (blockIdx.x / hpairs) * NS;
+    const int chunk = lane & 7, slot = lane >> 3, head = chunk >> 2, sub = slot;
+    const int b = b0 + wave;                 // this wave's batch element
+    const bool live = b < d.B;
+    // ---- weight rows of this wave: rows {wave*8 + sub, 32 + wave*8 + sub} of each of q, k, v ----
+    bf16x8 w[3][2][4];
+    float bias_r[3][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int row = ps * 32 + wave * 8 + sub;
+            const bf16* wr = (const bf16*)d.W + (int64_t)(p * D + hp * 64 + row) * D + chunk * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[p][ps][i] = *reinterpret_cast<const bf16x8*>(wr + i * 64);
+            bias_r[p][ps] = d.bias[p * D + hp * 64 + row];
+        }
+    // ---- the first 64 cached keys / values of this wave's element start their way now (rows < Sk were written by earlier steps):
+    //      their latency hides behind the LayerNorm and the projections ----
+    constexpr int NPRE = 8;                 // wave-loads of 8 keys
+    bf16x8 kpre[NPRE], vpre[NPRE];
+    {
+        const int bb = live ? b : d.B - 1;
+        const bf16* KVr = (const bf16*)d.kv + (int64_t)bb * d.kv_bs + hp * 64 + chunk * 8;
+        const int last = d.Sk > 0 ? d.Sk - 1 : 0;
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int key = min(u * 8 + slot, last);
+            kpre[u] = *reinterpret_cast<const bf16x8*>(KVr + (int64_t)key * d.kv_rs);
+            vpre[u] = *reinterpret_cast<const bf16x8*>(KVr + D + (int64_t)key * d.kv_rs);
+        }
+    }
+    // ---- LayerNorm of this wave's row (lane = 4 consecutive elements) ----
+    {
+        const int bb = live ? b : d.B - 1;
+        const bf16x4 xr = *reinterpret_cast<const bf16x4*>((const bf16*)d.x + (int64_t)bb * d.x_rs + lane * 4);
+        float xv[4], s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xv[i] = (float)xr[i]; s += xv[i]; }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+        const float mu = s * (1.f / D);
+        float q2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xv[i] -= mu; q2 += xv[i] * xv[i]; }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) q2 += __shfl_xor(q2, o);
+        const float rs = rsqrtf(q2 * (1.f / D) + d.eps);
+        const float4 g = *reinterpret_cast<const float4*>(d.ln_g + lane * 4), be = *reinterpret_cast<const float4*>(d.ln_b + lane * 4);
+        const float gg[4] = {g.x, g.y, g.z, g.w}, bb4[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hrow[wave][lane * 4 + i] = (float)(bf16)(xv[i] * rs * gg[i] + bb4[i]);
+    }
+    __syncthreads();
+    // ---- projections: this wave's 6 x 8 rows against all NS normalised rows ----
+#pragma unroll 1
+    for (int si = 0; si < NS; ++si) {
+        float hv[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[i][e] = hrow[si][i * 64 + chunk * 8 + e];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a += hv[i][e] * (float)w[p][ps][i][e];
+                a += __shfl_xor(a, 1);
+                a += __shfl_xor(a, 2);
+                a += __shfl_xor(a, 4);
+                if (chunk == 0) qkv[si][p][ps * 32 + wave * 8 + sub] = (float)(bf16)(a + bias_r[p][ps]);
+            }
+    }
+    __syncthreads();
+    if (!live) return;
+    // ---- from here on: one wave = one batch element, wave-local ----
+    bf16* KV = (bf16*)d.kv + (int64_t)b * d.kv_bs + hp * 64;
+    KV[(int64_t)d.Sk * d.kv_rs + lane] = (bf16)qkv[wave][1][lane];            // the new token's k / v: row Sk of the cache
+    KV[(int64_t)d.Sk * d.kv_rs + D + lane] = (bf16)qkv[wave][2][lane];
+    const bf16* Kp = KV + chunk * 8;
+    const bf16* Vp = KV + D + chunk * 8;
+    const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * d.kpm_bs : nullptr;
+    float qv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qv[i] = qkv[wave][0][chunk * 8 + i] * d.scale;
+    float (*scw)[2] = sc[wave];
+    // scores of the cached keys: 8 keys per wave-load; the first 64 keys are already in registers
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+        const int key = u * 8 + slot;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += qv[i] * (float)kpre[u][i];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if ((chunk & 3) == 0 && key < d.Sk) scw[key][head] = (kpm && kpm[key]) ? -__builtin_inff() : s;
+    }
+    for (int key0 = NPRE * 8; key0 < d.Sk; key0 += 32) {
+        bf16x8 kv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = min(key0 + u * 8 + slot, d.Sk - 1);
+            kv[u] = *reinterpret_cast<const bf16x8*>(Kp + (int64_t)key * d.kv_rs);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = key0 + u * 8 + slot;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += qv[i] * (float)kv[u][i];
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            if ((chunk & 3) == 0 && key < d.Sk) scw[key][head] = (kpm && kpm[key]) ? -__builtin_inff() : s;
+        }
+    }
+    if (lane < 8) {   // the new key (slot 0)
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += qv[i] * qkv[wave][1][chunk * 8 + i];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if ((chunk & 3) == 0) scw[d.Sk][head] = (kpm && kpm[d.Sk]) ? -__builtin_inff() : s;
+    }
+    __builtin_amdgcn_wave_barrier();   // (scores written by other lanes of this wave: LDS accesses of a wave complete in order)
+    const int nk = d.Sk + 1;
+    // softmax per head: lane parity = head, 32 lanes per head
+    const int h2 = lane & 1;
+    float m = -__builtin_inff();
+    for (int key = lane >> 1; key < nk; key += 32) m = fmaxf(m, scw[key][h2]);
+#pragma unroll
+    for (int o = 2; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float mref = m > -__builtin_inff() ? m : 0.f;
+    float l = 0.f;
+    for (int key = lane >> 1; key < nk; key += 32) {
+        const float p = __expf(scw[key][h2] - mref);
+        scw[key][h2] = p;
+        l += p;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int o = 2; o < 64; o <<= 1) l += __shfl_xor(l, o);      // lane parity h2 holds the sum of head h2
+    // weighted sum of V
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+        const int key = u * 8 + slot;
+        const float p = key < d.Sk ? scw[key][head] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += p * (float)vpre[u][i];
+    }
+    for (int key0 = NPRE * 8; key0 < d.Sk; key0 += 32) {
+        bf16x8 vv[4];
+        float p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = key0 + u * 8 + slot, kc = min(key, d.Sk - 1);
+            vv[u] = *reinterpret_cast<const bf16x8*>(Vp + (int64_t)kc * d.kv_rs);
+            p[u] = key < d.Sk ? scw[kc][head] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += p[u] * (float)vv[u][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        acc[i] += __shfl_xor(acc[i], 8);
+        acc[i] += __shfl_xor(acc[i], 16);
+        acc[i] += __shfl_xor(acc[i], 32);
+    }
+    // lanes 0..7 (slot 0) hold the 64 sums: chunk c -> columns 8c .. 8c+7 (head = c >> 2)
+    const float l0 = __shfl(l, 0), l1 = __shfl(l, 1);
+    if (slot == 0) {
+        const float lsum = head ? l1 : l0, pn = scw[d.Sk][head];
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (bf16)((acc[i] + pn * qkv[wave][2][chunk * 8 + i]) / lsum);
+        *reinterpret_cast<bf16x8*>((bf16*)d.o + (int64_t)b * d.o_rs + hp * 64 + chunk * 8) = o;
+    }
 }
 }  // namespace
 
@@ -747,7 +955,9 @@ extern "C" int ralf_decode_attn(const RalfDecodeAttnDesc* dp, void* stream) {
     RALF_REQUIRE(d.kv_rs % 8 == 0 && d.kv_bs % 8 == 0 && ((uintptr_t)d.kv % 16) == 0 && ((uintptr_t)d.W % 16) == 0 && (!d.kpm || d.kpm_bs > 0),
                  "decode_attn: cache rows and weights must be 16-byte aligned; kpm needs its row stride");
     hipStream_t st = (hipStream_t)stream;
-    if (d.self_) hipLaunchKernelGGL(attn_decode_fused_kernel<true>, dim3(d.B * 4), dim3(256), 0, st, d);
-    else hipLaunchKernelGGL(attn_decode_fused_kernel<false>, dim3(d.B * 4), dim3(256), 0, st, d);
+    // self-attention (a few dozen keys): 4 batch elements share a workgroup's weight rows; cross-attention streams its K/V cache
+    // from HBM and wants every workgroup it can get
+    if (d.self_) hipLaunchKernelGGL(attn_decode_self4_kernel, dim3(ceil_div(d.B, 4) * 4), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((attn_decode_fused_kernel<false, 1>), dim3(d.B * 4), dim3(256), 0, st, d);
     return ralf::check_launch("decode_attn");
 }

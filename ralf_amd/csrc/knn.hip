@@ -495,7 +495,13 @@ extern "C" int ralf_knn_scores(const float* X, int64_t N, int D, const float* Q,
     hipStream_t st = (hipStream_t)stream;
     // HBM-bound regime (few queries): small row chunks -> >= 2 workgroups per CU in flight.
     if (nq <= 16) return launch_scores<16, 1, 2>(X, N, D, Q, nq, S, st);
-    if (nq <= 32) return launch_scores<32, 1, 1>(X, N, D, Q, nq, S, st);
+    if (nq <= 32) {
+        static const int v32 = [] { const char* e = getenv("RALF_KNN_V32"); return e ? atoi(e) : 0; }();   // tuning aid
+        if (v32 == 1) return launch_scores<32, 1, 2>(X, N, D, Q, nq, S, st);
+        if (v32 == 2) return launch_scores<16, 2, 2>(X, N, D, Q, nq, S, st);
+        if (v32 == 3) return launch_scores<16, 2, 1>(X, N, D, Q, nq, S, st);
+        return launch_scores<32, 1, 1>(X, N, D, Q, nq, S, st);
+    }
     if (nq <= 64) return launch_scores<32, 2, 2>(X, N, D, Q, nq, S, st);
     // FLOP-bound regime: 256 rows x 128 queries per workgroup, 8 accumulator tiles per wave.
     return launch_scores<32, 4, 2>(X, N, D, Q, nq, S, st);

@@ -1,0 +1,43 @@
+#!/bin/bash
+# final measurements of the round: bench line, rocprofv3 kernel statistics, PMC HBM traffic, kNN / decode profiles
+R=${1:-r02b}
+O=gpurun_out/$R; mkdir -p $O
+ROOT=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+prof() { # name, steps-in-trace, header, command...
+  name=$1; steps=$2; header=$3; shift 3
+  rm -rf $ROOT/$O/p_$name
+  timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$O/p_$name -o t -- "$@" > $ROOT/$O/${name}.log 2>&1
+  DB=$(find $ROOT/$O/p_$name -name "*.db" | head -1)
+  python3 $ROOT/tools/prof_summary.py $DB $ROOT/$O/${name}_kernel_stats.txt "$header" $steps
+  rm -rf $ROOT/$O/p_$name
+}
+BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --skip-cpu --skip-knn --skip-split --skip-decode"
+prof train_step 6 "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --skip-cpu --skip-knn --skip-split --skip-decode (MI355X, $R; graph replay, parameter-gradient kernels on parallel graph branches: per-kernel times include overlap)" $BENCH
+prof train_step_single_stream 6 "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --skip-cpu --skip-knn --skip-split --skip-decode --no-overlap (MI355X, $R; one stream: per-kernel times are not inflated by overlap)" $BENCH --no-overlap
+prof encoder_decoder_only 11 "# rocprofv3 --kernel-trace --stats -- python3 tools/encdec_once.py 8 (MI355X, $R; backbone replaced by a fixed feature sequence)" python3 $ROOT/tools/encdec_once.py 8
+prof decode 4 "# rocprofv3 --kernel-trace --stats -- python3 tools/decode_once.py 3 (MI355X, $R; B = 256, task c, argmax; 4 replays of the captured loop + 2 eager warm-up passes in the trace)" python3 $ROOT/tools/decode_once.py 3
+prof knn 1 "# rocprofv3 --kernel-trace --stats -- python3 tools/knn_once.py (MI355X, $R; 61548 x 1792 fp32, nq = 16 and 1024: 3 scans + 1 whole call each)" python3 $ROOT/tools/knn_once.py
+# PMC passes (one counter per run; --kernel-trace only)
+PB="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-graph --skip-cpu --skip-knn --skip-split --skip-decode"
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $ROOT/$O/pmc_$C $ROOT/$O/pmck_$C
+  timeout 900 rocprofv3 --pmc $C --kernel-trace -d $ROOT/$O/pmc_$C -o t -- $PB > $ROOT/$O/pmc_$C.log 2>&1
+  timeout 600 rocprofv3 --pmc $C --kernel-trace -d $ROOT/$O/pmck_$C -o t -- python3 $ROOT/tools/knn_once.py > $ROOT/$O/pmck_$C.log 2>&1
+done
+cd $ROOT
+F=$(find $O/pmc_FETCH_SIZE -name "*.db" | head -1); W=$(find $O/pmc_WRITE_SIZE -name "*.db" | head -1)
+python3 tools/pmc_traffic_json.py $O/${R}_hbm_traffic.json train_step_B64_N10_bf16 $F $W 3 "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-graph --skip-cpu --skip-knn --skip-split --skip-decode (separate passes; 3 eager steps in each trace, model set-up included)" > $O/pmc_summary.txt 2>&1
+python3 tools/pmc_total.py $F FETCH_SIZE 3 > $O/train_step_hbm_traffic_pmc.txt 2>&1; python3 tools/pmc_total.py $W WRITE_SIZE 3 >> $O/train_step_hbm_traffic_pmc.txt 2>&1
+F=$(find $O/pmck_FETCH_SIZE -name "*.db" | head -1); W=$(find $O/pmck_WRITE_SIZE -name "*.db" | head -1)
+python3 tools/pmc_traffic_json.py $O/${R}_hbm_traffic.json knn_scores_nq16_61548x1792 $F $W 1 "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/knn_once.py (separate passes; per dispatch of knn_scores_kernel<16,1,2>)" "knn_scores_kernel%16%1%2" >> $O/pmc_summary.txt 2>&1
+python3 tools/pmc_traffic_json.py $O/${R}_hbm_traffic.json knn_scores_nq1024_61548x1792 $F $W 1 "same passes; per dispatch of knn_scores_kernel<32,4,2>" "knn_scores_kernel%32%4%2" >> $O/pmc_summary.txt 2>&1
+python3 tools/pmc_total.py $F FETCH_SIZE 1 > $O/knn_pmc.txt 2>&1; python3 tools/pmc_total.py $W WRITE_SIZE 1 >> $O/knn_pmc.txt 2>&1
+rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmck_FETCH_SIZE $O/pmck_WRITE_SIZE
+cat $O/pmc_summary.txt
+# the new traffic file must be visible to bench.py in THIS run
+cp $O/${R}_hbm_traffic.json profiles/${R}_hbm_traffic.json
+timeout 300 python3 tools/knn_graph_bench.py 1 16 32 64 128 1024 > $O/knn_microbench.txt 2>&1
+timeout 1500 python3 bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
+timeout 600 python3 bench.py --dp-selftest --skip-cpu --skip-knn --skip-split --skip-decode > $O/bench_dp_selftest.json 2> $O/bench_dp.err; python3 -c "
+import json; d=json.load(open('$O/bench_dp_selftest.json')); print('dp-selftest ms', d['ms_per_step'])"
