@@ -294,7 +294,13 @@ def main():
         sys.exit("bench.py: no GPU visible (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    real_stdout = None
     if world > 1 or a.dp_selftest:
+        # RCCL prints a version banner through C stdio on file descriptor 1: from here on fd 1 IS stderr, and the one JSON line
+        # is written to the saved descriptor at the end -- stdout carries nothing but that line
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -338,6 +344,20 @@ def main():
         elapsed = t.item()
     gpu_ms = e0.elapsed_time(e1) / a.steps
     ms = elapsed / a.steps * 1e3
+    dp_info = None
+    if step.exchange.active:   # the gradient exchange on its own (NOT overlapped): what the staged backward hides
+        nG = step.opt.G.numel()
+        step.exchange.run([(0, nG)])
+        torch.cuda.synchronize()
+        x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        x0.record()
+        for _ in range(5):
+            step.exchange.run([(0, nG)])
+        x1.record()
+        torch.cuda.synchronize()
+        dp_info = {"rccl_ranks": world, "wire": step.exchange.wire, "bytes_on_wire_per_step": step.exchange.bytes_on_wire([(0, nG)]),
+                   "allreduce_ms_standalone": x0.elapsed_time(x1) / 5, "staged_backward": bool(step.staged),
+                   "bytes_exchanged_during_stage2": step.exchange.bytes_on_wire(step._early) if step.staged else 0}
     tokens = B * (5 * N + 1)
     nonpad = int((targets["seq"] != model.tokenizer.name_to_id("pad")).sum().item()) + B   # target tokens that are not padding, + BOS
     final_loss = float(loss)
@@ -357,6 +377,8 @@ def main():
                          "traffic": None,
                          "note": f"whole train step: {flops / 1e12:.3f} algorithmic TFLOP per launch (SURVEY 8d: {STEP_GFLOP_PER_SAMPLE.get(N, 50.1)} GFLOP/sample x {B}) / {gpu_ms:.2f} ms (HIP events); per-kernel split in profiles/"},
         }
+        if dp_info is not None:
+            out["config"]["data_parallel"] = dp_info
         tb, te = measured_traffic("train_step_B64_N10_bf16") if (B == 64 and N == 10 and a.dtype.startswith("b")) else (None, None)
         if tb:   # the same step seen from the memory side (measured PMC bytes / measured time)
             out["roofline"]["traffic"] = tb
@@ -394,11 +416,15 @@ def main():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if out is not None:
-        # the ONE json line goes out last: RCCL prints a version banner through C stdio (flushed at exit when piped)
         import ctypes
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out) + "\n"
+        if real_stdout is not None:
+            os.write(real_stdout, line.encode())
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
 
 
 if __name__ == "__main__":

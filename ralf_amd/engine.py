@@ -389,12 +389,21 @@ class TrainStep:
         # the warm-up steps (allocator, lazy inits, LDS attributes) must not train: the state they touch is put back, so the
         # first graphed call is exactly ONE optimisation step, like use_graph=False and like the reference's loop
         snap = self._snapshot()
-        # (warm-up ON the capture stream: the per-stream workspaces reach their size before the capture, outside its pool)
-        side = cap = ops.own_stream("capture")
+        # warm-up: one full step (collectives included) on a stream of its own, then the CAPTURED pieces alone on the capture
+        # stream, so its per-stream workspaces reach their size before the capture and outside its pool.  No collective may ever
+        # run on the capture stream: RCCL issues a synchronous collective on the CURRENT stream, and its completion event --
+        # polled by the watchdog thread -- must not sit on a stream that starts capturing (hipErrorCapturedEvent -> abort).
+        side, cap = ops.own_stream("warmup"), ops.own_stream("capture")
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(2):
-                self._eager(si, st)
+            self._eager(si, st)
+        cap.wait_stream(side)
+        with torch.cuda.stream(cap):
+            self._fwd_bwd(si, st)
+            if self.staged:
+                self._bwd_rest()
+            self._update()
+        side.wait_stream(cap)
         torch.cuda.current_stream().wait_stream(side)
         self._restore(snap)
         torch.cuda.synchronize()
