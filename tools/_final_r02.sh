@@ -16,8 +16,8 @@ BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --skip-cpu --skip-knn --skip-
 prof train_step 6 "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --skip-cpu --skip-knn --skip-split --skip-decode (MI355X, $R; graph replay, parameter-gradient kernels on parallel graph branches: per-kernel times include overlap)" $BENCH
 prof train_step_single_stream 6 "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --skip-cpu --skip-knn --skip-split --skip-decode --no-overlap (MI355X, $R; one stream: per-kernel times are not inflated by overlap)" $BENCH --no-overlap
 prof encoder_decoder_only 11 "# rocprofv3 --kernel-trace --stats -- python3 tools/encdec_once.py 8 (MI355X, $R; backbone replaced by a fixed feature sequence)" python3 $ROOT/tools/encdec_once.py 8
-prof decode 4 "# rocprofv3 --kernel-trace --stats -- python3 tools/decode_once.py 3 (MI355X, $R; B = 256, task c, argmax; 4 replays of the captured loop + 2 eager warm-up passes in the trace)" python3 $ROOT/tools/decode_once.py 3
-prof knn 1 "# rocprofv3 --kernel-trace --stats -- python3 tools/knn_once.py (MI355X, $R; 61548 x 1792 fp32, nq = 16 and 1024: 3 scans + 1 whole call each)" python3 $ROOT/tools/knn_once.py
+prof decode 5 "# rocprofv3 --kernel-trace --stats -- python3 tools/decode_once.py 3 (MI355X, $R; B = 256, task c, argmax; 4 replays of the captured loop + 2 eager warm-up passes in the trace)" python3 $ROOT/tools/decode_once.py 3
+prof knn 1 "# rocprofv3 --kernel-trace --stats -- python3 tools/knn_once.py (MI355X, $R; 61548 x 1792 fp32, nq = 16: 20 scans + 10 whole calls, nq = 1024: 3 scans + 1 whole call)" python3 $ROOT/tools/knn_once.py
 # PMC passes (one counter per run; --kernel-trace only)
 PB="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-graph --skip-cpu --skip-knn --skip-split --skip-decode"
 for C in FETCH_SIZE WRITE_SIZE; do

@@ -1,0 +1,5 @@
+#!/bin/bash
+O=gpurun_out/r02z; mkdir -p $O
+timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py tests/test_engine_gpu.py -x -q 2>&1 | tail -4 | cut -c1-250
+for i in 1 2; do timeout 900 python bench.py --steps 10 --warmup 3 --skip-cpu --skip-knn --skip-decode > $O/bench$i.json 2> $O/bench.err; python -c "
+import json; d=json.load(open('$O/bench$i.json')); print(d['ms_per_step'], d['roofline_split']['encoder_decoder']['ms'], d['config']['final_loss'])"; done
