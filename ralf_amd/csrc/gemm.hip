@@ -52,9 +52,9 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
     if (d.gather) {
         RALF_REQUIRE((int64_t)(d.gather == 1 ? d.M : d.K) < (1ll << 31) && (int64_t)(d.gather == 1 ? d.K : d.N) < (1ll << 31), "gemm: gather index range");
         P.fd_hw.set((uint32_t)(d.g.RH * d.g.RW)); P.fd_rw.set((uint32_t)d.g.RW); P.fd_sc.set((uint32_t)d.g.SC);
-        P.fd_kw.set((uint32_t)d.g.KW); P.fd_st.set((uint32_t)d.g.stride);
+        P.fd_kw.set((uint32_t)d.g.KW); P.fd_st.set((uint32_t)d.g.stride); P.fd_tap.set(d.g.mode ? (uint32_t)d.g.stride : 1u);
     } else {
-        P.fd_hw.set(1); P.fd_rw.set(1); P.fd_sc.set(1); P.fd_kw.set(1); P.fd_st.set(1);
+        P.fd_hw.set(1); P.fd_rw.set(1); P.fd_sc.set(1); P.fd_kw.set(1); P.fd_st.set(1); P.fd_tap.set(1);
     }
     const int ktiles = ceil_div(d.K, BK);
     if (d.splitk > ktiles) d.splitk = ktiles;
@@ -73,6 +73,10 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
         const bool rows_ok = (d.a_kcontig || (d.M % VEC == 0 && d.M >= VEC)) && (d.b_kcontig || (d.N % VEC == 0 && d.N >= VEC));
         P.fast = (!d.gather && al && rows_ok && d.K % BK == 0) ? 1 : 0;
         P.tapuni = (d.gather == 1 && d.g.SC % BK == 0 && P.kchunk % BK == 0) ? 1 : 0;
+        // convolution GEMMs load whole aligned vectors without an element-wise fallback (load_vec_al): weights [N][K] with
+        // K % VEC == 0 for the forward / data gradient, dy [K][M] with M % VEC == 0 for the weight gradient
+        if (d.gather == 1) RALF_REQUIRE(al && d.K % VEC == 0, "gemm: gather=1 needs 16-byte aligned operands and K %% %d == 0", VEC);
+        if (d.gather == 2) RALF_REQUIRE(al && d.M % VEC == 0 && d.M >= VEC, "gemm: gather=2 needs 16-byte aligned operands and M %% %d == 0", VEC);
     }
     if (d.kseg) {
         RALF_REQUIRE(P.fast && d.dtype == RALF_BF16 && d.splitk == 1 && d.kseg % BK == 0 && d.K % d.kseg == 0 && (d.sBk * 2) % 16 == 0,

@@ -56,7 +56,7 @@ struct FastDiv {
         mul = (uint32_t)((((uint64_t)1 << p) + den - 1) / den);
         shr = p - 32;
     }
-    __device__ __forceinline__ uint32_t div(uint32_t n) const { return den == 1 ? n : (__umulhi(n, mul) >> shr); }
+    __device__ __forceinline__ uint32_t div(uint32_t n) const { const uint32_t t = __umulhi(n, mul) >> shr; return den == 1 ? n : t; }   // (a select, not a branch)
     __device__ __forceinline__ void divmod(uint32_t n, int& q, int& r) const { const uint32_t t = div(n); q = (int)t; r = (int)(n - t * den); }
 };
 
@@ -78,6 +78,7 @@ __device__ unsigned long long ralf_probe_buf[8 * 65536];
 struct KParams {
     RalfGemmDesc d;
     FastDiv fd_hw, fd_rw, fd_sc, fd_kw, fd_st;   // RH*RW, RW, SC, KW, stride of d.g
+    FastDiv fd_tap;                              // stride in mode 1 (data gradient), 1 in mode 0: the divisor of tap_offset
     int tiles_m, tiles_n, nwg;
     int kchunk;       // K range handled by one split (multiple of BK)
     float* partial;   // [split][batch][M][N] fp32 (splitk > 1)
@@ -293,30 +294,45 @@ __device__ __forceinline__ RowInfo row_info(const KParams& P, int64_t row, int64
     return r;
 }
 
+// ---- loaders.  The gather (and the operands paired with a gather) load UNCONDITIONALLY from a clamped address and hand back a
+// validity flag; the zeroing of invalid vectors happens when the registers are staged to LDS (a select right behind the load
+// made the compiler wait for that load before it computed the next vector's address): a load behind `if (!ok) return zero` is compiled as a branch whose join waits with s_waitcnt vmcnt(0), i.e. the
+// 4-8 staging vectors of a k-tile went out ONE AT A TIME (ISA of the 3x3 convolution kernels: load, vmcnt(0), load, vmcnt(0), ...).
+__device__ __forceinline__ u32x4 sel_vec(bool ok, const u32x4 v) {
+    u32x4 o;
+    o.x = ok ? v.x : 0u; o.y = ok ? v.y : 0u; o.z = ok ? v.z : 0u; o.w = ok ? v.w : 0u;
+    return o;
+}
+// source pixel of (output row r, tap kh, kw): offset in elements, validity folded into ok
+__device__ __forceinline__ int64_t tap_offset(const RalfConvGeom& g, const KParams& P, const RowInfo& r, int kh, int kw, bool& ok) {
+    // mode 0 (forward / weight gradient): source = (y0 + kh, x0 + kw);  mode 1 (data gradient): source = ((y0 - kh) / stride, ..) where
+    // that division is exact.  ONE branch-free form: P.fd_tap divides by 1 in mode 0 (set at launch), sgn = +-1.
+    const int sgn = g.mode ? -1 : 1;
+    const int ty = r.y0 + sgn * kh, tx = r.x0 + sgn * kw;
+    ok = ok && ty >= 0 && tx >= 0;
+    int sy, sx, ry, rx;
+    P.fd_tap.divmod((uint32_t)(ty < 0 ? 0 : ty), sy, ry);
+    P.fd_tap.divmod((uint32_t)(tx < 0 ? 0 : tx), sx, rx);
+    ok = ok && (ry | rx) == 0 && sy < g.SH && sx < g.SW;
+    return r.base + ((int64_t)sy * g.SW + sx) * g.SC;
+}
 // 16-byte vector of VEC elements at (row, col..col+VEC-1); zero outside the matrix / the padding
 template <typename T, bool GATHER>
-__device__ __forceinline__ u32x4 load_vec(const T* __restrict__ p, const KParams& P, const RowInfo& r, int col, int ncols, bool aligned) {
+__device__ __forceinline__ u32x4 load_vec(const T* __restrict__ p, const KParams& P, const RowInfo& r, int col, int ncols, bool aligned, bool& okout) {
     constexpr int VEC = TT<T>::VEC;
     const RalfConvGeom& g = P.d.g;
     const u32x4 z = {0u, 0u, 0u, 0u};
-    if (!r.ok || col >= ncols) return z;
     if (GATHER) {
+        bool ok = r.ok && col < ncols;
         int c, t, kw, kh;
         P.fd_sc.divmod((uint32_t)col, t, c);  // SC % VEC == 0: a vector never straddles a tap
         P.fd_kw.divmod((uint32_t)t, kh, kw);
-        int sy, sx;
-        if (g.mode == 0) { sy = r.y0 + kh; sx = r.x0 + kw; }
-        else {
-            const int ty = r.y0 - kh, tx = r.x0 - kw;
-            if (ty < 0 || tx < 0) return z;
-            int ry, rx;
-            P.fd_st.divmod((uint32_t)ty, sy, ry);
-            P.fd_st.divmod((uint32_t)tx, sx, rx);
-            if (ry | rx) return z;
-        }
-        if ((unsigned)sy >= (unsigned)g.SH || (unsigned)sx >= (unsigned)g.SW) return z;
-        return *reinterpret_cast<const u32x4*>(p + r.base + ((int64_t)sy * g.SW + sx) * g.SC + c);
+        const int64_t off = tap_offset(g, P, r, kh, kw, ok) + c;
+        okout = ok;
+        return *reinterpret_cast<const u32x4*>(p + (off & -(int64_t)ok));   // (mask, not a select: no control flow)
     }
+    okout = true;
+    if (!r.ok || col >= ncols) return z;
     const T* q = p + r.base + col;
     if (aligned && col + VEC <= ncols) return *reinterpret_cast<const u32x4*>(q);
     T tmp[VEC];
@@ -324,26 +340,23 @@ __device__ __forceinline__ u32x4 load_vec(const T* __restrict__ p, const KParams
     for (int i = 0; i < VEC; ++i) tmp[i] = (col + i < ncols) ? q[i] : (T)0.f;
     return *reinterpret_cast<u32x4*>(tmp);
 }
+// plain operand of a convolution GEMM (weights / dy): whole, 16-byte aligned vectors by construction (channel counts are
+// multiples of VEC, checked at launch), so no element-wise fallback and no branch
+template <typename T>
+__device__ __forceinline__ u32x4 load_vec_al(const T* __restrict__ p, const RowInfo& r, int col, int ncols, bool& okout) {
+    const bool ok = r.ok && col < ncols;
+    okout = ok;
+    return *reinterpret_cast<const u32x4*>(p + ((r.base + col) & -(int64_t)ok));
+}
 
 // the same gather with the tap (kh, kw) given: when the channel count is a multiple of the k-tile, a whole k-tile lies inside
 // ONE tap, so the column -> (kh, kw, c) decomposition is done once per k-tile on the scalar unit instead of per staged vector
 template <typename T>
-__device__ __forceinline__ u32x4 load_vec_tap(const T* __restrict__ p, const KParams& P, const RowInfo& r, int kh, int kw, int c) {
-    const RalfConvGeom& g = P.d.g;
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    if (!r.ok) return z;
-    int sy, sx;
-    if (g.mode == 0) { sy = r.y0 + kh; sx = r.x0 + kw; }
-    else {
-        const int ty = r.y0 - kh, tx = r.x0 - kw;
-        if (ty < 0 || tx < 0) return z;
-        int ry, rx;
-        P.fd_st.divmod((uint32_t)ty, sy, ry);
-        P.fd_st.divmod((uint32_t)tx, sx, rx);
-        if (ry | rx) return z;
-    }
-    if ((unsigned)sy >= (unsigned)g.SH || (unsigned)sx >= (unsigned)g.SW) return z;
-    return *reinterpret_cast<const u32x4*>(p + r.base + ((int64_t)sy * g.SW + sx) * g.SC + c);
+__device__ __forceinline__ u32x4 load_vec_tap(const T* __restrict__ p, const KParams& P, const RowInfo& r, int kh, int kw, int c, bool& okout) {
+    bool ok = r.ok;
+    const int64_t off = tap_offset(P.d.g, P, r, kh, kw, ok) + c;
+    okout = ok;
+    return *reinterpret_cast<const u32x4*>(p + (off & -(int64_t)ok));
 }
 
 // im2col column (kh, kw, c) of a staged vector: loop-invariant for the weight-gradient gather (GATHER == 2), where
@@ -358,22 +371,11 @@ __device__ __forceinline__ ColInfo col_info(const KParams& P, int col, int ncols
     return ci;
 }
 template <typename T>
-__device__ __forceinline__ u32x4 load_vec_cols(const T* __restrict__ p, const KParams& P, const RowInfo& r, const ColInfo& ci) {
-    const RalfConvGeom& g = P.d.g;
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    if (!r.ok || !ci.ok) return z;
-    int sy, sx;
-    if (g.mode == 0) { sy = r.y0 + ci.kh; sx = r.x0 + ci.kw; }
-    else {
-        const int ty = r.y0 - ci.kh, tx = r.x0 - ci.kw;
-        if (ty < 0 || tx < 0) return z;
-        int ry, rx;
-        P.fd_st.divmod((uint32_t)ty, sy, ry);
-        P.fd_st.divmod((uint32_t)tx, sx, rx);
-        if (ry | rx) return z;
-    }
-    if ((unsigned)sy >= (unsigned)g.SH || (unsigned)sx >= (unsigned)g.SW) return z;
-    return *reinterpret_cast<const u32x4*>(p + r.base + ((int64_t)sy * g.SW + sx) * g.SC + ci.c);
+__device__ __forceinline__ u32x4 load_vec_cols(const T* __restrict__ p, const KParams& P, const RowInfo& r, const ColInfo& ci, bool& okout) {
+    bool ok = r.ok && ci.ok;
+    const int64_t off = tap_offset(P.d.g, P, r, ci.kh, ci.kw, ok) + ci.c;
+    okout = ok;
+    return *reinterpret_cast<const u32x4*>(p + (off & -(int64_t)ok));
 }
 
 // staging registers -> LDS tile.  KC: [rows][LDK] (k-contiguous source), else [BK][LDR] (row-contiguous source)
@@ -403,12 +405,13 @@ __device__ __forceinline__ void lds_stage(T* l, const u32x4 (&regs)[NV], int tid
 }
 
 // AK: A is k-contiguous ([M][K]); else stored [K][M].   BKC: B is k-contiguous ([N][K]); else [K][N].
-// GATHER: 0 none, 1 = A (k-contiguous) is an im2col matrix, 2 = B (row-contiguous) is an im2col matrix.
+// GATHER: 0 none, 1 = A (k-contiguous) is an im2col matrix whose k-tiles lie inside one tap (channels % BK == 0), 4 = the same with any
+// channel count (per-vector tap decomposition), 2 = B (row-contiguous) is an im2col matrix, 3 = no gather, interior fast path.
 // FM, FN: 32x32 fragments per wave along m / n  ->  workgroup tile (64*FM) x (64*FN).
 // NW: waves per workgroup, 4 (2 x 2 waves, FM x FN fragments each) or 8 (2 x 4 waves, FM x FN/2 fragments each; FN = 2 only)
 // LDS bytes of one workgroup: two buffers of operand tiles, re-used as the fp32 C staging tile [64][BN + 4] of the epilogue
 template <int GATHER, int FM>
-constexpr int gemm_nbuf() { return (GATHER == 1 && FM == 1) ? 1 : 2; }   // the prefetch-distance-1 kernels keep one buffer
+constexpr int gemm_nbuf() { return ((GATHER == 1 || GATHER == 4) && FM == 1) ? 1 : 2; }   // the prefetch-distance-1 kernels keep one buffer
 template <typename T, bool AK, bool BKC, int FM, int FN, int NBUF = 2>
 constexpr int gemm_lds_bytes() {
     using X = TT<T>;
@@ -508,15 +511,17 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
         }
         if (AK && !fast) {
 #pragma unroll
-            for (int i = 0; i < NVA; ++i) ia[i] = row_info<GATHER == 1>(P, m0 + (tid + NT * i) / KV, d.M, d.lda);
+            for (int i = 0; i < NVA; ++i) ia[i] = row_info<GATHER == 1 || GATHER == 4>(P, m0 + (tid + NT * i) / KV, d.M, d.lda);
         }
         if (BKC && !fast) {
 #pragma unroll
             for (int i = 0; i < NVB; ++i) ib[i] = row_info<false>(P, n0 + (tid + NT * i) / KV, d.N, d.ldb);
         }
     };
-    auto gload = [&](u32x4 (&ra)[NVA], u32x4 (&rb)[NVB], int k0) {
+    uint32_t okm0 = ~0u, okm1 = ~0u;   // validity bits of the staged vectors of set 0 / 1 (A: bits 0.., B: bits 16..): zeroed at stage time
+    auto gload = [&](u32x4 (&ra)[NVA], u32x4 (&rb)[NVB], int k0, uint32_t& okm) {
         if constexpr (fast) {
+            (void)okm;
 #pragma unroll
             for (int i = 0; i < NVA; ++i) { ra[i] = *reinterpret_cast<const u32x4*>(pa[i]); pa[i] += stepA; }
 #pragma unroll
@@ -526,33 +531,46 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                 for (int i = 0; i < NVB; ++i) pb[i] += d.sBk;
             }
         } else {
+        // GATHER 1: every k-tile lies inside ONE tap (channels % BK == 0), decomposed once per k-tile on the scalar unit; GATHER 4: the
+        // general gather (stem: 8 channels), per vector.  Two kernels, not a run-time flag: the flag's uniform branch around every
+        // vector load ended a basic block there, and each block end waited for its load (s_waitcnt vmcnt(0)).
         int tap_kh = 0, tap_kw = 0, tap_c0 = 0;
-        if (GATHER == 1 && P.tapuni) {   // k0 is wave-uniform: scalar arithmetic
+        if constexpr (GATHER == 1) {   // k0 is wave-uniform: scalar arithmetic
             int t;
             P.fd_sc.divmod((uint32_t)k0, t, tap_c0);
             P.fd_kw.divmod((uint32_t)t, tap_kh, tap_kw);
         }
+        uint32_t m = 0u;
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             const int v = tid + NT * i;
+            bool ok;
             if (AK) {
-                if (GATHER == 1 && P.tapuni) ra[i] = load_vec_tap<T>(Ap, P, ia[i], tap_kh, tap_kw, tap_c0 + (v % KV) * VEC);
-                else ra[i] = load_vec<T, GATHER == 1>(Ap, P, ia[i], k0 + (v % KV) * VEC, kend, a_al);
+                if constexpr (GATHER == 1) ra[i] = load_vec_tap<T>(Ap, P, ia[i], tap_kh, tap_kw, tap_c0 + (v % KV) * VEC, ok);
+                else ra[i] = load_vec<T, GATHER == 4>(Ap, P, ia[i], k0 + (v % KV) * VEC, kend, a_al, ok);
             } else {
                 const RowInfo r = row_info<false>(P, k0 + v / RVA, kend, d.lda);
-                ra[i] = load_vec<T, false>(Ap, P, r, m0 + (v % RVA) * VEC, d.M, a_al);
+                if constexpr (GATHER == 2) ra[i] = load_vec_al<T>(Ap, r, m0 + (v % RVA) * VEC, d.M, ok);
+                else ra[i] = load_vec<T, false>(Ap, P, r, m0 + (v % RVA) * VEC, d.M, a_al, ok);
             }
+            m |= (uint32_t)ok << i;
         }
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
             const int v = tid + NT * i;
-            if (BKC) rb[i] = load_vec<T, false>(Bp, P, ib[i], k0 + (v % KV) * VEC, kend, b_al);
+            bool ok;
+            if (BKC) {
+                if constexpr (GATHER == 1 || GATHER == 4) rb[i] = load_vec_al<T>(Bp, ib[i], k0 + (v % KV) * VEC, kend, ok);
+                else rb[i] = load_vec<T, false>(Bp, P, ib[i], k0 + (v % KV) * VEC, kend, b_al, ok);
+            }
             else {
                 const RowInfo r = row_info<GATHER == 2>(P, k0 + v / RVB, kend, d.ldb);
-                if constexpr (GATHER == 2) rb[i] = load_vec_cols<T>(Bp, P, r, cb[i]);
-                else rb[i] = load_vec<T, false>(Bp, P, r, n0 + (v % RVB) * VEC, d.N, b_al);
+                if constexpr (GATHER == 2) rb[i] = load_vec_cols<T>(Bp, P, r, cb[i], ok);
+                else rb[i] = load_vec<T, false>(Bp, P, r, n0 + (v % RVB) * VEC, d.N, b_al, ok);
             }
+            m |= (uint32_t)ok << (16 + i);
         }
+        okm = m;
         }
     };
     f32x16 acc[WFM][WFN];
@@ -625,17 +643,23 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     // 256-tile launches -- one workgroup per CU, nothing to interleave with -- at 1.2 us per 128x128x64 step, 6x the MFMA time.)
     // Steady state is branch-free (an `if` around a prefetch made the compiler shuttle every accumulator
     // AGPR -> VGPR -> AGPR per iteration); the last 1-4 tiles are peeled.
-    auto stage = [&](T* la, T* lb, const u32x4 (&ra)[NVA], const u32x4 (&rb)[NVB]) {
+    auto stage = [&](T* la, T* lb, u32x4 (&ra)[NVA], u32x4 (&rb)[NVB], uint32_t okm) {
+        if constexpr (!fast) {
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) ra[i] = sel_vec((okm >> i) & 1u, ra[i]);
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) rb[i] = sel_vec((okm >> (16 + i)) & 1u, rb[i]);
+        }
         lds_stage<T, AK, NVA, RVA, LDRA, NT>(la, ra, tid);
         lds_stage<T, BKC, NVB, RVB, LDRB, NT>(lb, rb, tid);
     };
     // (the 64x64 im2col-gather kernels keep distance 1: their index registers + a second staging set cost a wave of occupancy
     //  and the layer1 3x3 convolutions got 20 % slower with distance 2)
-    constexpr int PF = (GATHER == 1 && FM == 1) ? 1 : 2;
+    constexpr int PF = ((GATHER == 1 || GATHER == 4) && FM == 1) ? 1 : 2;
     RALF_PROBE(1);
     setup(bid0);
-    gload(ra0, rb0, kbeg);
-    if (PF == 2 && nt > 1) gload(ra1, rb1, kbeg + BK);
+    gload(ra0, rb0, kbeg, okm0);
+    if (PF == 2 && nt > 1) gload(ra1, rb1, kbeg + BK, okm1);
     for (int bid = bid0;;) {
     const int c_m0 = m0, c_n0 = n0, c_split = split, c_kbeg = kbeg, c_nt = nt;   // the tile being COMPUTED
 #pragma unroll
@@ -645,45 +669,45 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     if constexpr (PF == 1) {   // one LDS buffer (a second one measured 46.6 -> 54.3 us on the layer1 3x3 convolutions)
-        stage(la0, lb0, ra0, rb0);
+        stage(la0, lb0, ra0, rb0, okm0);
         __syncthreads();
         for (int t = 0; t + 1 < c_nt; ++t) {
-            gload(ra0, rb0, c_kbeg + (t + 1) * BK);
+            gload(ra0, rb0, c_kbeg + (t + 1) * BK, okm0);
             compute(la0, lb0);
             __syncthreads();
-            stage(la0, lb0, ra0, rb0);
+            stage(la0, lb0, ra0, rb0, okm0);
             __syncthreads();
         }
         compute(la0, lb0);
     } else {
-        stage(la0, lb0, ra0, rb0);
-        if (c_nt > 2) gload(ra0, rb0, c_kbeg + 2 * BK);
+        stage(la0, lb0, ra0, rb0, okm0);
+        if (c_nt > 2) gload(ra0, rb0, c_kbeg + 2 * BK, okm0);
         __syncthreads();
         RALF_PROBE(2);
         // top of an even step t: buffer 0 = tile t, set 1 = tile t+1 and set 0 = tile t+2 (both on their way)
         int t = 0;
         for (; t + 4 < c_nt; t += 2) {
-            stage(la1, lb1, ra1, rb1);
-            gload(ra1, rb1, c_kbeg + (t + 3) * BK);
+            stage(la1, lb1, ra1, rb1, okm1);
+            gload(ra1, rb1, c_kbeg + (t + 3) * BK, okm1);
             compute(la0, lb0);
             __syncthreads();
-            stage(la0, lb0, ra0, rb0);
-            gload(ra0, rb0, c_kbeg + (t + 4) * BK);
+            stage(la0, lb0, ra0, rb0, okm0);
+            gload(ra0, rb0, c_kbeg + (t + 4) * BK, okm0);
             compute(la1, lb1);
             __syncthreads();
         }
         const int rem = c_nt - t;             // 1..4 tiles left; tile t+3 (rem == 4) has not been requested yet
-        if (rem >= 2) stage(la1, lb1, ra1, rb1);
-        if (rem == 4) gload(ra1, rb1, c_kbeg + (t + 3) * BK);
+        if (rem >= 2) stage(la1, lb1, ra1, rb1, okm1);
+        if (rem == 4) gload(ra1, rb1, c_kbeg + (t + 3) * BK, okm1);
         compute(la0, lb0);
         if (rem >= 2) {
             __syncthreads();
-            if (rem >= 3) stage(la0, lb0, ra0, rb0);
+            if (rem >= 3) stage(la0, lb0, ra0, rb0, okm0);
             compute(la1, lb1);
         }
         if (rem >= 3) {
             __syncthreads();
-            if (rem == 4) stage(la1, lb1, ra1, rb1);
+            if (rem == 4) stage(la1, lb1, ra1, rb1, okm1);
             compute(la0, lb0);
         }
         if (rem == 4) {
@@ -696,8 +720,8 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     const bool more = RALF_GEMM_PERSISTENT && nbid < total;
     if (more) {
         setup(nbid);
-        gload(ra0, rb0, kbeg);
-        if (PF == 2 && nt > 1) gload(ra1, rb1, kbeg + BK);
+        gload(ra0, rb0, kbeg, okm0);
+        if (PF == 2 && nt > 1) gload(ra1, rb1, kbeg + BK, okm1);
     }
 
     RALF_PROBE(3);
@@ -962,7 +986,8 @@ int dispatch(KParams& P, int nbatch, hipStream_t st) {
     const int key = (d.a_kcontig ? 4 : 0) | (d.b_kcontig ? 2 : 0);
     if (d.gather == 1) {
         if (key != 6) { ralf::set_error("gemm: gather=1 needs A and B k-contiguous"); return RALF_ERR_INVALID; }
-        return launch_cfg<T, true, true, 1>(P, nbatch, st);
+        if (P.tapuni) return launch_cfg<T, true, true, 1>(P, nbatch, st);
+        return launch_cfg<T, true, true, 4>(P, nbatch, st);
     }
     if (d.gather == 2) {
         if (key != 0) { ralf::set_error("gemm: gather=2 needs A and B row-contiguous"); return RALF_ERR_INVALID; }
