@@ -58,6 +58,34 @@ __device__ __forceinline__ void stage(bf16* dst, const bf16* base, int64_t rs, i
     }
 }
 
+// the same in two halves, so that the global loads of tile t+1 fly while tile t is being computed: tile_load (unconditional loads of
+// clamped rows, zero selected afterwards) into registers, tile_store into LDS at the top of the next iteration
+template <int DH> struct TileRegs { uint4 v[KT * (DH / 8) / 256]; uint32_t ok; };
+template <int DH>
+__device__ __forceinline__ void tile_load(TileRegs<DH>& r, const bf16* base, int64_t rs, int t0, int S) {
+    constexpr int VPR = DH / 8, NV = KT * VPR / 256;
+    uint32_t ok = 0u;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = threadIdx.x + 256 * i, row = e / VPR, c = e % VPR;
+        const int rr = t0 + row;
+        r.v[i] = *reinterpret_cast<const uint4*>(base + (int64_t)(rr < S ? rr : S - 1) * rs + c * 8);
+        ok |= (rr < S ? 1u : 0u) << i;      // (the zeroing waits until tile_store: a select here would wait for the load at once)
+    }
+    r.ok = ok;
+}
+template <int DH>
+__device__ __forceinline__ void tile_store(bf16* dst, const TileRegs<DH>& r) {
+    constexpr int VPR = DH / 8, NV = KT * VPR / 256;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        const bool ok = (r.ok >> i) & 1u;
+        const uint4 v = r.v[i];
+        *reinterpret_cast<uint4*>(dst + (e / VPR) * L<DH>::LD + (e % VPR) * 8) = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+    }
+}
+
 // row-operand fragment: 16 rows x 32 k (row r = lane&15, k = 8*(lane>>4)..+7) from a k-contiguous LDS tile
 template <int DH>
 __device__ __forceinline__ bf16x8 frag_rows(const bf16* tile, int row0, int k0, int lane) {
@@ -117,9 +145,12 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
     float m = -__builtin_inff(), l = 0.f;   // running max / sum of 2^(score * scale * log2 e)
     const float scale2 = d.scale * 1.4426950408889634f;
 
+    TileRegs<DH> kreg, vreg;
+    tile_load<DH>(kreg, Kp, d.k_rs, 0, d.Sk);
+    tile_load<DH>(vreg, Vp, d.v_rs, 0, d.Sk);
     for (int t0 = 0; t0 < d.Sk; t0 += KT) {
-        stage<DH>(Ks, Kp, d.k_rs, t0, d.Sk);
-        stage<DH>(Vs, Vp, d.v_rs, t0, d.Sk);
+        tile_store<DH>(Ks, kreg);
+        tile_store<DH>(Vs, vreg);
         if (threadIdx.x < KT) {   // wave 0
             const bool mk = t0 + (int)threadIdx.x >= d.Sk || (kpm && kpm[t0 + threadIdx.x]);
             Ms[threadIdx.x] = mk ? 1 : 0;
@@ -127,6 +158,10 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
             if (threadIdx.x == 0) tile_any = any != 0ull ? 1 : 0;
         }
         __syncthreads();
+        if (t0 + KT < d.Sk) {   // the next tile's rows start their way now and land under this tile's matrix work
+            tile_load<DH>(kreg, Kp, d.k_rs, t0 + KT, d.Sk);
+            tile_load<DH>(vreg, Vp, d.v_rs, t0 + KT, d.Sk);
+        }
         const bool tile_masked = tile_any != 0;
         if (active && !(d.causal && t0 > q0 + 15)) {
 #pragma unroll
@@ -245,9 +280,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const RalfAttnDesc d) {
 #pragma unroll
     for (int c = 0; c < DH / 16; ++c) dq[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    TileRegs<DH> kreg, vreg;
+    tile_load<DH>(kreg, Kp, d.k_rs, 0, d.Sk);
+    tile_load<DH>(vreg, Vp, d.v_rs, 0, d.Sk);
     for (int t0 = 0; t0 < d.Sk; t0 += KT) {
-        stage<DH>(Ks, Kp, d.k_rs, t0, d.Sk);
-        stage<DH>(Vs, Vp, d.v_rs, t0, d.Sk);
+        tile_store<DH>(Ks, kreg);
+        tile_store<DH>(Vs, vreg);
         if (threadIdx.x < KT) {   // wave 0
             const bool mk = t0 + (int)threadIdx.x >= d.Sk || (kpm && kpm[t0 + threadIdx.x]);
             Ms[threadIdx.x] = mk ? 1 : 0;
@@ -255,6 +293,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const RalfAttnDesc d) {
             if (threadIdx.x == 0) tile_any = any != 0ull ? 1 : 0;
         }
         __syncthreads();
+        if (t0 + KT < d.Sk) {   // the next tile's rows start their way now and land under this tile's matrix work
+            tile_load<DH>(kreg, Kp, d.k_rs, t0 + KT, d.Sk);
+            tile_load<DH>(vreg, Vp, d.v_rs, t0 + KT, d.Sk);
+        }
         const bool tile_masked = tile_any != 0;
         if (active && !(d.causal && t0 > q0 + 15)) {
 #pragma unroll
@@ -351,9 +393,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
 #pragma unroll
     for (int c = 0; c < DH / 16; ++c) dk[c] = dv[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    TileRegs<DH> qreg, greg;
+    tile_load<DH>(qreg, Qp, d.q_rs, 0, d.Sq);
+    tile_load<DH>(greg, Gp, d.do_rs, 0, d.Sq);
     for (int t0 = 0; t0 < d.Sq; t0 += KT) {
-        stage<DH>(Qs, Qp, d.q_rs, t0, d.Sq);
-        stage<DH>(Gs, Gp, d.do_rs, t0, d.Sq);
+        tile_store<DH>(Qs, qreg);
+        tile_store<DH>(Gs, greg);
         if (threadIdx.x < KT) {
             const int qi = t0 + threadIdx.x;
             Ls[threadIdx.x] = qi < d.Sq ? d.lse[stat0 + qi] * 1.4426950408889634f : 0.f;   // log2 domain
@@ -361,6 +406,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
             if (d.p_drop > 0.f) Rk[threadIdx.x] = attn_rowkey(seed, d.call_id, ((uint64_t)b * d.H + h) * d.Sq + qi);
         }
         __syncthreads();
+        if (t0 + KT < d.Sq) {   // next query tile: loads fly under this tile's matrix work
+            tile_load<DH>(qreg, Qp, d.q_rs, t0 + KT, d.Sq);
+            tile_load<DH>(greg, Gp, d.do_rs, t0 + KT, d.Sq);
+        }
         // causal: a query tile entirely before this wave's first key sees none of its keys
         if (active && !(d.causal && t0 + KT - 1 < k0)) {
 #pragma unroll

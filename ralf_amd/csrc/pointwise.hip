@@ -271,7 +271,10 @@ __global__ __launch_bounds__(256) void permute4_pack8_kernel(const TS* __restric
         const int64_t base = i0 * s0 + i1 * s1 + i2 * s2;
         float v[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = c < valid3 ? ld(in, base + c * s3) : 0.f;
+        for (int c = 0; c < 8; ++c) {   // (unconditional load of a clamped channel plane, zero selected afterwards)
+            const float t = ld(in, base + (c < valid3 ? c : valid3 - 1) * s3);
+            v[c] = c < valid3 ? t : 0.f;
+        }
         if constexpr (sizeof(TD) == 2) {
             typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
             bf16x8v o;
@@ -390,19 +393,28 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         __attribute__((aligned(8))) int8_t bi[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) { best[i] = -__builtin_inff(); bi[i] = -1; }
+        // all 9 taps are loaded unconditionally from clamped coordinates (a load under `if (inside)` waits for itself before the next
+        // tap's address is even computed: 9 dependent round trips per output vector), padding taps are skipped in the comparison
+        float v[9][N];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = min(max(oh * 2 - 1 + kh, 0), H - 1);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = min(max(ow * 2 - 1 + kw, 0), W - 1);
+                PV<T>::load(x + (((int64_t)b * H + ih) * W + iw) * C + c, v[kh * 3 + kw]);
+            }
+        }
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int ih = oh * 2 - 1 + kh;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int iw = ow * 2 - 1 + kw;
-                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-                    float v[N];
-                    PV<T>::load(x + (((int64_t)b * H + ih) * W + iw) * C + c, v);
+                const bool inside = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
 #pragma unroll
-                    for (int i = 0; i < N; ++i)
-                        if (bi[i] < 0 || v[i] > best[i]) { best[i] = v[i]; bi[i] = (int8_t)(kh * 3 + kw); }
-                }
+                for (int i = 0; i < N; ++i)
+                    if (inside && (bi[i] < 0 || v[kh * 3 + kw][i] > best[i])) { best[i] = v[kh * 3 + kw][i]; bi[i] = (int8_t)(kh * 3 + kw); }
             }
         }
         const int64_t o = (int64_t)pix * C + c;
