@@ -67,8 +67,12 @@ __device__ __forceinline__ bool better(uint32_t ka, int pa, uint32_t kb, int pb)
 template <int MF, int TQ, int TR, bool GATHER = false>
 __global__ __launch_bounds__(256) void knn_scores_kernel(const float* __restrict__ X, int64_t N, int D,
                                                           const float* __restrict__ Q, int nq, float* __restrict__ S,
-                                                          int n_qtiles, int nwg, const int64_t* __restrict__ cand = nullptr, int pool = 0) {
+                                                          int n_qtiles, int nwg, const int64_t* __restrict__ cand = nullptr, int pool = 0,
+                                                          unsigned int* __restrict__ zero_me = nullptr, int nzero = 0) {
     using F = Frag<MF>;
+    // the hand-off counters of the selection that FOLLOWS this scan are cleared here (stream order makes the zeros visible to it):
+    // no memset node in front of the scan
+    if (zero_me && blockIdx.x == 0) for (int i = threadIdx.x; i < nzero; i += 256) zero_me[i] = 0u;
     constexpr int RW = 4 * TR * MF, QW = TQ * MF, BK = 32, KS = F::KS, ROT = 32 / MF;
     constexpr int XV = RW * BK / 4 / 256;              // float4 per thread per k-tile (index rows)
     constexpr int QV = (QW * BK / 4 + 255) / 256;      // float4 per thread per k-tile (queries)
@@ -457,11 +461,11 @@ __global__ __launch_bounds__(256) void knn_rownorms_kernel(const float* __restri
 
 
 template <int MF, int TQ, int TR>
-int launch_scores(const float* X, int64_t N, int D, const float* Q, int nq, float* S, hipStream_t st) {
+int launch_scores(const float* X, int64_t N, int D, const float* Q, int nq, float* S, hipStream_t st, unsigned int* zero_me = nullptr, int nzero = 0) {
     constexpr int RW = 4 * TR * MF, QW = TQ * MF;
     const int nrc = ceil_div(N, RW), nqt = ceil_div(nq, QW);
     const int nwg = nrc * nqt;
-    hipLaunchKernelGGL((knn_scores_kernel<MF, TQ, TR>), dim3(nwg), dim3(256), 0, st, X, N, D, Q, nq, S, nqt, nwg);
+    hipLaunchKernelGGL((knn_scores_kernel<MF, TQ, TR>), dim3(nwg), dim3(256), 0, st, X, N, D, Q, nq, S, nqt, nwg, nullptr, 0, zero_me, nzero);
     return ralf::check_launch("knn_scores");
 }
 
@@ -487,24 +491,27 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
 
+static int scores_impl(const float* X, int64_t N, int D, const float* Q, int nq, float* S, hipStream_t st, unsigned int* zero_me, int nzero) {
+    // HBM-bound regime (few queries): small row chunks -> >= 2 workgroups per CU in flight.
+    if (nq <= 16) return launch_scores<16, 1, 2>(X, N, D, Q, nq, S, st, zero_me, nzero);
+    if (nq <= 32) {
+        static const int v32 = [] { const char* e = getenv("RALF_KNN_V32"); return e ? atoi(e) : 0; }();   // tuning aid
+        if (v32 == 1) return launch_scores<32, 1, 2>(X, N, D, Q, nq, S, st, zero_me, nzero);
+        if (v32 == 2) return launch_scores<16, 2, 2>(X, N, D, Q, nq, S, st, zero_me, nzero);
+        if (v32 == 3) return launch_scores<16, 2, 1>(X, N, D, Q, nq, S, st, zero_me, nzero);
+        return launch_scores<32, 1, 1>(X, N, D, Q, nq, S, st, zero_me, nzero);
+    }
+    if (nq <= 64) return launch_scores<32, 2, 2>(X, N, D, Q, nq, S, st, zero_me, nzero);
+    // FLOP-bound regime: 256 rows x 128 queries per workgroup, 8 accumulator tiles per wave.
+    return launch_scores<32, 4, 2>(X, N, D, Q, nq, S, st, zero_me, nzero);
+}
+
 extern "C" int ralf_knn_scores(const float* X, int64_t N, int D, const float* Q, int nq, float* S, void* stream) {
     RALF_REQUIRE(X && Q && S, "knn_scores: null pointer");
     RALF_REQUIRE(N > 0 && nq > 0 && D > 0, "knn_scores: empty problem (n_db=%lld nq=%d dim=%d)", (long long)N, nq, D);
     RALF_REQUIRE(D % 4 == 0, "knn_scores: dim %d must be a multiple of 4 (16-byte row alignment)", D);
     RALF_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)Q & 15) == 0, "knn_scores: index/queries must be 16-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
-    // HBM-bound regime (few queries): small row chunks -> >= 2 workgroups per CU in flight.
-    if (nq <= 16) return launch_scores<16, 1, 2>(X, N, D, Q, nq, S, st);
-    if (nq <= 32) {
-        static const int v32 = [] { const char* e = getenv("RALF_KNN_V32"); return e ? atoi(e) : 0; }();   // tuning aid
-        if (v32 == 1) return launch_scores<32, 1, 2>(X, N, D, Q, nq, S, st);
-        if (v32 == 2) return launch_scores<16, 2, 2>(X, N, D, Q, nq, S, st);
-        if (v32 == 3) return launch_scores<16, 2, 1>(X, N, D, Q, nq, S, st);
-        return launch_scores<32, 1, 1>(X, N, D, Q, nq, S, st);
-    }
-    if (nq <= 64) return launch_scores<32, 2, 2>(X, N, D, Q, nq, S, st);
-    // FLOP-bound regime: 256 rows x 128 queries per workgroup, 8 accumulator tiles per wave.
-    return launch_scores<32, 4, 2>(X, N, D, Q, nq, S, st);
+    return scores_impl(X, N, D, Q, nq, S, (hipStream_t)stream, nullptr, 0);
 }
 
 /* exact fp32 scores of per-query candidate rows: out[q][j] = <Q[q], X[cand[q][j]]>, bit-identical to ralf_knn_scores */
@@ -603,13 +610,14 @@ extern "C" int ralf_knn_topk_ip(const float* X, int64_t N, int D, const float* Q
     float* S = (float*)ws;
     const size_t soff = align256((size_t)nq * N * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
-    // the ticket counters of the selection's hand-off are zeroed AHEAD of the scan (a memset node between scan and selection
-    // would sit on the critical path)
+    // the ticket counters of the selection's hand-off are zeroed BY the scan kernel (its first workgroup): neither a memset node
+    // between scan and selection (critical path) nor one in front of the scan
     SelectPlan p = plan_select(N, nq, k);
     const bool fused = p.nseg > 1 && k <= 64 && p.nseg <= 64;
-    if (fused && hipMemsetAsync((char*)ws + soff + 2 * align256(p.cand_bytes), 0, (size_t)nq * sizeof(unsigned int), st) != hipSuccess)
-        return ralf::check_launch("knn_topk_ip memset");
-    int rc = ralf_knn_scores(X, N, D, Q, nq, S, stream);
+    RALF_REQUIRE(X && Q, "knn_topk_ip: null pointer");
+    RALF_REQUIRE(D > 0 && D % 4 == 0, "knn_topk_ip: dim %d must be a multiple of 4 (16-byte row alignment)", D);
+    RALF_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)Q & 15) == 0, "knn_topk_ip: index/queries must be 16-byte aligned");
+    int rc = scores_impl(X, N, D, Q, nq, S, st, fused ? (unsigned int*)((char*)ws + soff + 2 * align256(p.cand_bytes)) : nullptr, fused ? nq : 0);
     if (rc) return rc;
     return select_impl(S, N, nq, k, out_idx, out_score, (char*)ws + soff, ws_bytes - soff, st, fused);
 }

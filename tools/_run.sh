@@ -1,6 +1,6 @@
 #!/bin/bash
-O=gpurun_out/r02ac; mkdir -p $O
-timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest_all.txt 2>&1; echo "pytest rc=$?"
-grep -n "^E \|passed\|failed" $O/pytest_all.txt | head -10 | cut -c1-250
-for i in 1 2; do timeout 900 python bench.py --steps 20 --warmup 3 --skip-cpu --skip-knn --skip-decode > $O/bench$i.json 2> $O/bench.err; python -c "
-import json; d=json.load(open('$O/bench$i.json')); print(d['ms_per_step'], d['roofline_split']['encoder_decoder']['ms'])"; done
+O=gpurun_out/r02af; mkdir -p $O
+timeout 900 python -m pytest tests/test_knn_gpu.py tests/test_retrieval_gpu.py -x -q > $O/pytest.txt 2>&1; echo "pytest rc=$?"
+grep -n "^E \|passed\|failed" $O/pytest.txt | head -10 | cut -c1-250
+timeout 300 python tools/knn_graph_bench.py 1 16 32 2>&1 | grep V32
+timeout 300 python tools/knn_graph_bench.py 1 16 32 2>&1 | grep V32
