@@ -935,9 +935,10 @@ __global__ __launch_bounds__(256) void attn_decode_self4_kernel(const RalfDecode
 #pragma unroll
     for (int u = 0; u < NPRE; ++u) {
         const int key = u * 8 + slot;
-        const float p = key < d.Sk ? scw[key][head] : 0.f;
+        const bool in = key < d.Sk;          // (rows beyond the prefix may hold anything: select, never multiply by zero)
+        const float p = in ? scw[key][head] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += p * (float)vpre[u][i];
+        for (int i = 0; i < 8; ++i) acc[i] += in ? p * (float)vpre[u][i] : 0.f;
     }
     for (int key0 = NPRE * 8; key0 < d.Sk; key0 += 32) {
         bf16x8 vv[4];

@@ -354,3 +354,108 @@ def test_attention_decode_step(B, Sk, pad):
         for need_lse in (False, True):
             o3, _ = ops.attention_fwd(q.cuda(), kv.cuda(), kv.cuda(), B, H, 1, Sk, dh, 0, 0, d, causal=False, kpm=wide.cuda(), need_lse=need_lse, kv_rows=L, kpm_stride=Sk + 5)
             assert torch.equal(o3, o if not need_lse else o2)
+
+
+@pytest.mark.parametrize("B,pos,pad", [(3, 0, False), (5, 1, False), (6, 37, True), (9, 70, True), (4, 159, False)])
+def test_decode_attn_self_block(B, pos, pad):
+    """ralf_decode_attn, self-attention form: LayerNorm + q/k/v projections + cache append + attention over pos+1 keys in one launch,
+    against the same arithmetic in torch fp32 with the kernel's rounding points (h, q/k/v, o in bf16); B not a multiple of the 4
+    elements a workgroup shares, more than 64 cached keys, masked keys"""
+    from ralf_amd import ops
+
+    d, H, L = 256, 8, 200
+    dh = d // H
+    x = rnd(B, d, seed=60, dtype=torch.bfloat16)
+    g, be = rnd(d, seed=61) * 0.2 + 1.0, rnd(d, seed=62) * 0.1
+    W = rnd(3 * d, d, seed=63, scale=d ** -0.5).bfloat16()
+    bias = rnd(3 * d, seed=64) * 0.1
+    kv = rnd(B, L, 2 * d, seed=65, dtype=torch.bfloat16)
+    kv[:, pos:] = float("nan")                      # rows the kernel must not read (row `pos` is written by it)
+    kpm = torch.zeros(B, L, dtype=torch.uint8)
+    if pad:
+        kpm[0, 1:pos:3] = 1; kpm[-1, pos // 2] = 1
+    h = F.layer_norm(x.float(), (d,), g, be, 1e-5).bfloat16().float()
+    qkv = (h @ W.float().t() + bias).bfloat16().float()
+    q, k, v = (t.contiguous() for t in (qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]))
+    K = torch.cat([kv[:, :pos, :d].float(), k[:, None]], 1)
+    V = torch.cat([kv[:, :pos, d:].float(), v[:, None]], 1)
+    ref = ref_attention(q[:, None].contiguous(), K, V, H, False, kpm[:, :pos + 1].bool() if pad else None, dh ** -0.5)[:, 0]
+    kvd = kv.cuda()
+    o = ops.decode_attn(x.cuda(), g.cuda(), be.cuda(), W.cuda(), bias.cuda(), kvd, pos, H, True, kpm=kpm.cuda(), kpm_stride=L)
+    close(o, ref, torch.bfloat16)
+    torch.testing.assert_close(kvd[:, pos, :d].float().cpu(), k.bfloat16().float(), atol=2e-2, rtol=2e-2)     # the appended row
+    torch.testing.assert_close(kvd[:, pos, d:].float().cpu(), v.bfloat16().float(), atol=2e-2, rtol=2e-2)
+    assert bool(torch.isnan(kvd[:, pos + 1:].float()).all())                                                    # nothing else was touched
+
+
+@pytest.mark.parametrize("B,M", [(3, 1), (5, 130), (2, 578)])
+def test_decode_attn_cross_block(B, M):
+    """ralf_decode_attn, cross-attention form (q projection only, K/V of the memory precomputed) against torch fp32"""
+    from ralf_amd import ops
+
+    d, H = 256, 8
+    x = rnd(B, d, seed=70, dtype=torch.bfloat16)
+    g, be = rnd(d, seed=71) * 0.2 + 1.0, rnd(d, seed=72) * 0.1
+    W = rnd(3 * d, d, seed=73, scale=d ** -0.5).bfloat16()
+    bias = rnd(3 * d, seed=74) * 0.1
+    kv = rnd(B, M, 2 * d, seed=75, dtype=torch.bfloat16)
+    h = F.layer_norm(x.float(), (d,), g, be, 1e-5).bfloat16().float()
+    q = (h @ W[:d].float().t() + bias[:d]).bfloat16().float()
+    ref = ref_attention(q[:, None].contiguous(), kv[:, :, :d].float().contiguous(), kv[:, :, d:].float().contiguous(), H, False, None, (d // H) ** -0.5)[:, 0]
+    o = ops.decode_attn(x.cuda(), g.cuda(), be.cuda(), W.cuda(), bias.cuda(), kv.cuda(), M, H, False)
+    close(o, ref, torch.bfloat16)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv_weight_relayout_and_folded_batchnorm_epilogue(dtype):
+    """ralf_conv_relayout_batched (both GEMM layouts of k x k weights from one read, incl. the zero-padded 4-channel stem and a 7x7
+    kernel) and the inference epilogue colscale / bias / ReLU-after-residual of ralf_gemm with ralf_bn_fold_batched's scale / shift"""
+    from ralf_amd import ops
+
+    ws = [rnd(16, 4, 7, 7, seed=80), rnd(24, 72, 3, 3, seed=81), rnd(128, 64, 3, 3, seed=82), rnd(8, 200, 3, 3, seed=83)]
+    jobs, outs = [], []
+    for w in ws:
+        Co, Ci, kh, kw = w.shape
+        cip = (Ci + 7) // 8 * 8
+        o1 = torch.full((Co, kh, kw, cip), float("nan"), dtype=dtype, device="cuda")
+        o2 = torch.full((Ci, kh, kw, Co), float("nan"), dtype=dtype, device="cuda")
+        jobs.append((w.cuda(), o1, o2)); outs.append((o1, o2))
+    table, n, blocks = ops.conv_relayout_table(jobs, torch.device("cuda", 0))
+    ops.conv_relayout_batched(table, n, blocks)
+    for w, (o1, o2) in zip(ws, outs):
+        Ci = w.shape[1]
+        ref1 = torch.zeros(o1.shape)
+        ref1[..., :Ci] = w.permute(0, 2, 3, 1)
+        assert torch.equal(o1.float().cpu(), ref1.to(dtype).float())
+        assert torch.equal(o2.float().cpu(), w.permute(1, 2, 3, 0).to(dtype).float())
+    # folded BatchNorm: y = relu(x W^T * scale + shift + res)
+    M, K, N = 200, 64, 128
+    bns = [(rnd(N, seed=84) * 0.2 + 1.0, rnd(N, seed=85) * 0.1, rnd(N, seed=86) * 0.3, torch.rand(N, generator=torch.Generator().manual_seed(87)) + 0.5)]
+    buf = torch.empty(2 * N, dtype=torch.float32, device="cuda")
+    tb, views = ops.bn_fold_table([tuple(t.cuda() for t in bns[0])], buf, torch.device("cuda", 0))
+    ops.bn_fold_batched(tb, 1, 1e-5)
+    gam, bet, mu, var = bns[0]
+    sc = gam / torch.sqrt(var + 1e-5)
+    torch.testing.assert_close(views[0][0].cpu(), sc, atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(views[0][1].cpu(), bet - mu * sc, atol=1e-6, rtol=1e-6)
+    x, W, res = rnd(M, K, seed=88).to(dtype), rnd(N, K, seed=89, scale=K ** -0.5).to(dtype), rnd(M, N, seed=90).to(dtype)
+    y = ops.gemm(x.cuda(), W.cuda(), M, N, K, colscale=views[0][0], bias=views[0][1], act="relu_post", res=res.cuda())
+    ref = torch.relu(x.float() @ W.float().t() * sc + (bet - mu * sc) + res.float())
+    close(y, ref, dtype)
+    y2 = ops.gemm(x.cuda(), W.cuda(), M, N, K, colscale=views[0][0], bias=views[0][1], act="relu")
+    close(y2, torch.relu(x.float() @ W.float().t() * sc + (bet - mu * sc)), dtype)
+
+
+def test_library_streams_are_not_pool_streams():
+    """ops.own_stream: created by ralf_stream_create, stable per slot, distinct from every stream of torch's pool"""
+    from ralf_amd import ops
+
+    a, b = ops.own_stream("t1"), ops.own_stream("t2")
+    assert a.cuda_stream != b.cuda_stream and ops.own_stream("t1").cuda_stream == a.cuda_stream
+    pool = {torch.cuda.Stream().cuda_stream for _ in range(40)}
+    assert a.cuda_stream not in pool and b.cuda_stream not in pool
+    x = torch.ones(1 << 20, device="cuda")
+    with torch.cuda.stream(a):
+        y = x * 2
+    a.synchronize()
+    assert float(y.sum()) == 2 * (1 << 20)
