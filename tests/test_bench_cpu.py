@@ -1,0 +1,36 @@
+"""CPU: the parts of bench.py that do not need a GPU -- the self-launcher's clean failure on a node with too few GPUs, and the
+reader of the committed PMC traffic summaries (bench.py never carries a hard-coded traffic figure)."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def test_gpus_n_without_enough_gpus_fails_with_a_message_not_a_traceback():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs 2 GPUs" in r.stderr and "Traceback" not in r.stderr
+    assert r.stdout.strip() == ""            # stdout is reserved for the one JSON line
+
+
+def test_traffic_comes_from_the_newest_committed_profile(tmp_path, monkeypatch):
+    import bench
+
+    tb, entry = bench.measured_traffic("train_step_B64_N10_bf16")
+    assert tb and entry["file"].startswith("profiles/") and entry["file"].endswith("_hbm_traffic.json")
+    assert tb == 2.0 * entry["fetch_size_bytes"] + entry["write_size_bytes"]      # gfx950: FETCH_SIZE counts half of a wide read
+    assert 20e9 < tb < 80e9
+    kb, ke = bench.measured_traffic("knn_scores_nq16_61548x1792")
+    assert 0.43e9 < kb < 0.50e9 and ke["file"] == entry["file"]                   # 441.2 MB algorithmic, read once
+    assert bench.measured_traffic("no_such_workload") == (None, None)
+    # the newest file by name wins
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    for name, fetch in (("r03a_hbm_traffic.json", 1.0e9), ("r02z_hbm_traffic.json", 9.0e9)):
+        (prof / name).write_text(json.dumps({"train_step_B64_N10_bf16": {"fetch_size_bytes": fetch, "write_size_bytes": 5.0e8}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    tb2, e2 = bench.measured_traffic("train_step_B64_N10_bf16")
+    assert tb2 == 2.5e9 and e2["file"].endswith("r03a_hbm_traffic.json")
