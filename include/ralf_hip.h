@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 10
+#define RALF_ABI_VERSION 11
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -329,8 +329,13 @@ int ralf_decode_attn(const RalfDecodeAttnDesc* d, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * Optimizer (ralf_amd/csrc/optim.hip): clip_grad_norm_ + AdamW on flat fp32 buffers
  * ------------------------------------------------------------------------------------------- */
-int ralf_sumsq(const float* g, int64_t n, float* out, void* stream);
+int ralf_sumsq(const float* g, int64_t n, float* out, void* stream);                 /* out[0] += sum g^2 (fp32 atomics: order not fixed) */
 int ralf_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream);
+/* the deterministic pair the train step uses: RALF_SUMSQ_PARTS per-workgroup partial sums (fixed element assignment), summed in a fixed
+ * order -- the same gradient buffer gives the same clip coefficient bit for bit, on every run and on every data-parallel rank */
+#define RALF_SUMSQ_PARTS 1024
+int ralf_sumsq_partials(const float* g, int64_t n, float* partials, void* stream);
+int ralf_clip_coef_partials(const float* partials, float max_norm, float* coef, float* norm_out, void* stream);
 /* step_dev (int32[1] on the device, may be NULL) overrides `step` for the bias corrections (graph replay);
  * lr_scale (fp32[1] on the device, may be NULL) multiplies lr: the scheduler's factor (train/schedulers/multi_step_lr.py) without re-capturing */
 int ralf_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1, float beta2, float eps,

@@ -128,6 +128,8 @@ SIGNATURES.update({
     "ralf_decode_attn": (i32, [ctypes.POINTER(RalfDecodeAttnDesc), vp]),
     "ralf_sumsq": (i32, [vp, i64, vp, vp]),
     "ralf_clip_coef": (i32, [vp, f32, vp, vp, vp]),
+    "ralf_sumsq_partials": (i32, [vp, i64, vp, vp]),
+    "ralf_clip_coef_partials": (i32, [vp, f32, vp, vp, vp]),
     "ralf_adamw": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, vp, vp, vp]),
     "ralf_stream_create": (i32, [ctypes.POINTER(vp)]),
     "ralf_stream_destroy": (i32, [vp]),

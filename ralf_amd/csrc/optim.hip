@@ -31,6 +31,42 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+// deterministic form: partials[b] = sum of squares of block b's elements (fixed assignment), summed in a fixed order by
+// clip_coef_partials_kernel.  With the atomic form the clip coefficient differed in its last bit from run to run -- and between
+// data-parallel RANKS holding bit-identical averaged gradients, whose weights then drifted apart at rounding level (found by the
+// two-ranks-on-one-GPU test); torch's clip_grad_norm_ gives every rank the same coefficient.
+__global__ __launch_bounds__(256) void sumsq_partials_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partials) {
+    __shared__ float red[4];
+    float a = 0.f;
+    const int64_t n4 = n >> 2;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(g)[e];
+        a += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; a += v * v; }
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void clip_coef_partials_kernel(const float* __restrict__ partials, int nparts, float max_norm,
+                                                                  float* __restrict__ coef, float* __restrict__ norm_out) {
+    __shared__ float red[256];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) a += partials[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float nrm = sqrtf(red[0]);
+        if (norm_out) norm_out[0] = nrm;
+        coef[0] = max_norm > 0.f ? fminf(1.f, max_norm / (nrm + 1e-6f)) : 1.f;
+    }
+}
+
 // coef = min(1, max_norm / (sqrt(sumsq) + 1e-6))  (torch.nn.utils.clip_grad_norm_); norm_out = sqrt(sumsq)
 __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ coef, float* __restrict__ norm_out) {
     const float nrm = sqrtf(sumsq[0]);
@@ -69,6 +105,17 @@ extern "C" int ralf_sumsq(const float* g, int64_t n, float* out, void* stream) {
     RALF_REQUIRE(((uintptr_t)g & 15) == 0, "sumsq: buffer must be 16-byte aligned");
     hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1) > 1024 ? 1024 : grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, g, n, out);
     return ralf::check_launch("sumsq");
+}
+extern "C" int ralf_sumsq_partials(const float* g, int64_t n, float* partials, void* stream) {
+    RALF_REQUIRE(g && partials && n > 0, "sumsq_partials: bad arguments");
+    RALF_REQUIRE(((uintptr_t)g & 15) == 0, "sumsq_partials: buffer must be 16-byte aligned");
+    hipLaunchKernelGGL(sumsq_partials_kernel, dim3(RALF_SUMSQ_PARTS), dim3(256), 0, (hipStream_t)stream, g, n, partials);
+    return ralf::check_launch("sumsq_partials");
+}
+extern "C" int ralf_clip_coef_partials(const float* partials, float max_norm, float* coef, float* norm_out, void* stream) {
+    RALF_REQUIRE(partials && coef, "clip_coef_partials: null pointer");
+    hipLaunchKernelGGL(clip_coef_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, RALF_SUMSQ_PARTS, max_norm, coef, norm_out);
+    return ralf::check_launch("clip_coef_partials");
 }
 extern "C" int ralf_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream) {
     RALF_REQUIRE(sumsq && coef, "clip_coef: null pointer");

@@ -60,7 +60,7 @@ class FlatAdamW:
         self.step_count = 0
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)  # device-resident step counter (graph replay)
         self.runtime = runtime
-        self._ss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._ss = torch.zeros(ops.SUMSQ_PARTS, dtype=torch.float32, device=dev)   # per-workgroup partial sums of |G|^2 (deterministic clip)
         self.coef = torch.ones(1, dtype=torch.float32, device=dev)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.lr_scale = torch.ones(1, dtype=torch.float32, device=dev)   # scheduler factor, read by the kernel (graph-replay safe)
@@ -81,9 +81,9 @@ class FlatAdamW:
             self.runtime.weights_changed()
 
     def clip(self):
-        self._ss.zero_()
-        ops.sumsq(self.G, self._ss)
-        ops.clip_coef(self._ss, self.max_norm, self.coef, self.grad_norm)
+        # fixed-order reduction: the same G gives the same coefficient bit for bit on every rank (replicas stay identical)
+        ops.sumsq_partials(self.G, self._ss)
+        ops.clip_coef_partials(self._ss, self.max_norm, self.coef, self.grad_norm)
 
     def step(self):
         """the step counter for the bias corrections is advanced ON THE DEVICE, so a captured graph

@@ -549,6 +549,19 @@ def clip_coef(sumsq_t, max_norm, coef, norm_out=None):
     _call("ralf_clip_coef", _p(sumsq_t), max_norm, _p(coef), _p(norm_out))
 
 
+SUMSQ_PARTS = 1024   # RALF_SUMSQ_PARTS
+
+
+def sumsq_partials(flat, partials):
+    """deterministic: partials (fp32 [SUMSQ_PARTS]) <- per-workgroup sums of squares (no atomics)"""
+    assert partials.numel() >= SUMSQ_PARTS and partials.dtype == torch.float32
+    _call("ralf_sumsq_partials", _p(flat), flat.numel(), _p(partials))
+
+
+def clip_coef_partials(partials, max_norm, coef, norm_out=None):
+    _call("ralf_clip_coef_partials", _p(partials), max_norm, _p(coef), _p(norm_out))
+
+
 def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, coef=None, shadow=None, step_dev=None, lr_scale=None):
     _call("ralf_adamw", _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr, beta1, beta2, eps, wd, step, _p(coef), _p(step_dev), _p(lr_scale))
 

@@ -278,6 +278,17 @@ def test_adamw_and_clip():
         ss, coef, nrm = torch.zeros(1, device="cuda"), torch.empty(1, device="cuda"), torch.empty(1, device="cuda")
         ops.sumsq(gs.cuda(), ss); ops.clip_coef(ss, 0.1, coef, nrm)
         torch.testing.assert_close(nrm.cpu()[0], total, rtol=1e-5, atol=1e-6)
+        # the deterministic pair the train step uses: same norm, and bit-identical from call to call
+        parts, c2, n2 = torch.empty(ops.SUMSQ_PARTS, device="cuda"), torch.empty(1, device="cuda"), torch.empty(1, device="cuda")
+        ops.sumsq_partials(gs.cuda(), parts); ops.clip_coef_partials(parts, 0.1, c2, n2)
+        torch.testing.assert_close(n2.cpu()[0], total, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(c2, coef, rtol=1e-5, atol=0)
+        big = rnd(3_000_001, seed=52).cuda()
+        outs = []
+        for _ in range(3):
+            ops.sumsq_partials(big, parts); ops.clip_coef_partials(parts, 0.1, c2, n2)
+            outs.append((float(c2), float(n2)))
+        assert outs[0] == outs[1] == outs[2]
         if step % 2:   # bias corrections from the device-resident step counter (graph-replay path)
             sd = torch.tensor([step], dtype=torch.int32, device="cuda")
             ops.adamw(pd, gs.cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 1, coef, shadow, sd)
