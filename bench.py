@@ -292,6 +292,12 @@ def main():
         sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run --nproc-per-node {a.gpus}, or run bench.py --gpus {a.gpus} directly: it spawns its own ranks)")
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible (the HIP path has no CPU fallback)")
+    # test hook (tests/test_two_ranks_gpu.py): all ranks on device 0 with gloo carrying the device tensors, so the N > 1 flow of this
+    # file (rendezvous, replica sync, barriers, max-over-ranks timing, rank 0's JSON line) runs on a one-GPU box; RCCL itself
+    # refuses two ranks on one device
+    one_device = os.environ.get("RALF_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     real_stdout = None
@@ -303,7 +309,10 @@ def main():
         os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if one_device:
+            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from ralf_amd.engine import TrainStep
     from ralf_amd.synthetic import make_batch, to_device
@@ -318,7 +327,8 @@ def main():
     inputs, targets = to_device(inputs, device), to_device(targets, device)
     inputs["retrieved"] = {k: v for k, v in inputs["retrieved"].items() if k != "image"}
     step = TrainStep(model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, use_graph=not a.no_graph, overlap_wgrad=not a.no_overlap,
-                     process_group=torch.distributed.group.WORLD if a.dp_selftest else None, overlap_allreduce=True if a.dp_selftest else None)
+                     process_group=torch.distributed.group.WORLD if a.dp_selftest else None, overlap_allreduce=True if a.dp_selftest else None,
+                     grad_wire="fp32" if one_device else None)   # (gloo does not reduce bf16 device tensors)
 
     for _ in range(max(a.warmup, 1)):
         loss = step(inputs, targets)

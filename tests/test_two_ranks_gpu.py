@@ -65,3 +65,28 @@ def test_two_ranks_on_one_gpu_keep_identical_weights(tmp_path):
     assert r[0]["seed"] != r[1]["seed"], "ranks drew the same dropout masks"
     assert all(x == x for x in r[0]["losses"] + r[1]["losses"])
     assert abs(r[0]["pnorm"] - r[1]["pnorm"]) == 0.0
+
+
+def test_bench_two_ranks_on_one_gpu_prints_one_json_line(tmp_path):
+    """the N > 1 flow of bench.py itself (launcher environment, replica sync, barriers, max-over-ranks timing, rank 0's line, the
+    data_parallel block) with two ranks on this one GPU (RALF_BENCH_ONE_DEVICE: gloo instead of RCCL, both ranks on device 0)"""
+    import json
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RALF_BENCH_ONE_DEVICE="1", OMP_NUM_THREADS="4")
+    port = 29900 + os.getpid() % 90
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]                 # stdout carries exactly the one JSON line of rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["warmup"] == 1
+    dp = d["config"]["data_parallel"]
+    assert dp["rccl_ranks"] == 2 and dp["staged_backward"] and dp["bytes_on_wire_per_step"] > 0 and dp["allreduce_ms_standalone"] > 0
+    assert d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    # whole-job throughput: both ranks' tokens over the slowest rank's time
+    assert abs(d["value"] - 2 * d["config"]["tokens_per_step_per_gpu"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert "knn" not in d and "cpu_baseline" not in d        # single-GPU legs only run at N = 1
