@@ -90,3 +90,43 @@ def test_bench_two_ranks_on_one_gpu_prints_one_json_line(tmp_path):
     # whole-job throughput: both ranks' tokens over the slowest rank's time
     assert abs(d["value"] - 2 * d["config"]["tokens_per_step_per_gpu"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "knn" not in d and "cpu_baseline" not in d        # single-GPU legs only run at N = 1
+
+
+def _rank_knn(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from ralf_amd.retrieval import FlatIPIndex, knn_topk_ip, query_block, search_index_sharded, search_query_sharded
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    g = torch.Generator().manual_seed(21)
+    X = torch.randn(5003, 64, generator=g)
+    X[4000] = X[17]; X[2501] = X[17]                      # exact ties across the two shards
+    Q = torch.cat([X[[17, 4000]], torch.randn(21, 64, generator=g)])
+    want_s, want_i = knn_topk_ip(X.to(dev), Q.to(dev), 16)
+    ok = {}
+    s, i = search_query_sharded(FlatIPIndex(X, device="cuda").search, Q.to(dev), 16)      # replicas: rank r scans its block of the queries
+    ok["query_sharded"] = bool(torch.equal(i, want_i) and torch.equal(s, want_s))
+    blk = query_block(X.shape[0], rank, world)                                            # index shards: rank r owns a block of the rows
+    s, i = search_index_sharded(FlatIPIndex(X[blk], device="cuda").search, blk.start, Q.to(dev), 16)
+    ok["index_sharded"] = bool(torch.equal(i, want_i) and torch.equal(s, want_s))
+    torch.save(ok, os.path.join(out_dir, f"k{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_knn_two_ranks_on_the_hip_scan(tmp_path):
+    """SURVEY 8e with TWO ranks on the real scan: query-sharded replicas and index shards (local top-k with global indices
+    all-gathered, merged by score descending / index ascending) reproduce the single-GPU result bit for bit, ties across shards
+    included"""
+    import torch.multiprocessing as mp
+
+    port = 29800 + os.getpid() % 90
+    mp.spawn(_rank_knn, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        ok = torch.load(os.path.join(str(tmp_path), f"k{r}.pt"))
+        assert ok == {"query_sharded": True, "index_sharded": True}, (r, ok)
