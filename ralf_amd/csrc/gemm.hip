@@ -56,6 +56,29 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
     } else {
         P.fd_hw.set(1); P.fd_rw.set(1); P.fd_sc.set(1); P.fd_kw.set(1); P.fd_st.set(1); P.fd_tap.set(1);
     }
+    P.ln_sgn = 1; P.ln_sh = 0; P.ln_pm = 0; P.img = P.swsc = 0; P.inc_b = P.inc_y = P.inc_x = 0;
+    bool lean_ok = false;   // the gathered tensor can be addressed with 32-bit element offsets (and 24-bit row multiplies)
+    if (d.gather) {
+        const RalfConvGeom& g = d.g;
+        RALF_REQUIRE(g.RH > 0 && g.RW > 0 && g.SH > 0 && g.SW > 0 && g.pad >= 0 && (g.mode == 0 || g.mode == 1), "gemm: gather geometry");
+        const int64_t rows = d.gather == 1 ? d.M : d.K, hw = (int64_t)g.RH * g.RW;
+        const int64_t img = (int64_t)g.SH * g.SW * g.SC, src = ceil_div(rows, hw) * img + img;
+        const int tap = g.mode ? g.stride : 1;
+        lean_ok = src < (1ll << 30) && (int64_t)g.SW * g.SC < (1 << 22) && g.SH < (1 << 20) && g.RH < (1 << 20) && g.KH < 1024 && g.KW < 1024 && g.stride < 1024;
+        if (lean_ok) { P.img = (int)img; P.swsc = g.SW * g.SC; }
+        if (d.gather == 1 && (tap & (tap - 1)) == 0) {
+            P.ln_sgn = g.mode ? -1 : 1; P.ln_pm = tap - 1;
+            while ((1 << P.ln_sh) < tap) ++P.ln_sh;
+        } else if (d.gather == 1) {
+            lean_ok = false;
+        }
+        if (d.gather == 2) {
+            RALF_REQUIRE(g.mode == 0, "gemm: gather=2 (weight gradient) takes the forward geometry (mode 0)");
+            RALF_REQUIRE(lean_ok, "gemm: gather=2 source too large for 32-bit offsets (%lld elements)", (long long)src);
+            RALF_REQUIRE((BK / hw) * img < (1ll << 30), "gemm: gather=2 image step");
+            P.inc_b = (int)((BK / hw) * img); P.inc_y = (int)((BK % hw) / g.RW); P.inc_x = (int)((BK % hw) % g.RW);
+        }
+    }
     const int ktiles = ceil_div(d.K, BK);
     if (d.splitk > ktiles) d.splitk = ktiles;
     P.kchunk = ceil_div(ktiles, d.splitk) * BK;
@@ -72,7 +95,7 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
                         (d.sA0 * es) % 16 == 0 && (d.sA1 * es) % 16 == 0 && (d.sB0 * es) % 16 == 0 && (d.sB1 * es) % 16 == 0;
         const bool rows_ok = (d.a_kcontig || (d.M % VEC == 0 && d.M >= VEC)) && (d.b_kcontig || (d.N % VEC == 0 && d.N >= VEC));
         P.fast = (!d.gather && al && rows_ok && d.K % BK == 0) ? 1 : 0;
-        P.tapuni = (d.gather == 1 && d.g.SC % BK == 0 && P.kchunk % BK == 0) ? 1 : 0;
+        P.tapuni = (d.gather == 1 && lean_ok && d.g.SC % BK == 0 && P.kchunk % BK == 0 && d.K % BK == 0) ? 1 : 0;
         // convolution GEMMs load whole aligned vectors without an element-wise fallback (load_vec_al): weights [N][K] with
         // K % VEC == 0 for the forward / data gradient, dy [K][M] with M % VEC == 0 for the weight gradient
         if (d.gather == 1) RALF_REQUIRE(al && d.K % VEC == 0, "gemm: gather=1 needs 16-byte aligned operands and K %% %d == 0", VEC);

@@ -85,6 +85,10 @@ struct KParams {
     int vec_epi;      // leading dims / bases allow 4-wide epilogue accesses
     int fast;         // interior fast path: aligned operands, K range a multiple of BK (no per-tile bounds math)
     int tapuni;       // gather = 1 and channels % BK == 0: every k-tile lies inside one (kh, kw) tap
+    // lean gather loaders (32-bit element offsets, no per-vector division, see gemm_body):
+    int ln_sgn, ln_sh, ln_pm;       // gather 1: tap sign (+1 forward, -1 data gradient), log2 / mask of the tap stride (data gradient: the conv stride)
+    int img, swsc;                  // elements of one source image, of one source row
+    int inc_b, inc_y, inc_x;        // gather 2: BK rows of the pixel grid = inc_b ELEMENTS of whole images + inc_y rows + inc_x pixels
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -349,16 +353,6 @@ __device__ __forceinline__ u32x4 load_vec_al(const T* __restrict__ p, const RowI
     return *reinterpret_cast<const u32x4*>(p + ((r.base + col) & -(int64_t)ok));
 }
 
-// the same gather with the tap (kh, kw) given: when the channel count is a multiple of the k-tile, a whole k-tile lies inside
-// ONE tap, so the column -> (kh, kw, c) decomposition is done once per k-tile on the scalar unit instead of per staged vector
-template <typename T>
-__device__ __forceinline__ u32x4 load_vec_tap(const T* __restrict__ p, const KParams& P, const RowInfo& r, int kh, int kw, int c, bool& okout) {
-    bool ok = r.ok;
-    const int64_t off = tap_offset(P.d.g, P, r, kh, kw, ok) + c;
-    okout = ok;
-    return *reinterpret_cast<const u32x4*>(p + (off & -(int64_t)ok));
-}
-
 // im2col column (kh, kw, c) of a staged vector: loop-invariant for the weight-gradient gather (GATHER == 2), where
 // the gathered operand's COLUMNS are fixed per thread and its rows (pixels) advance with k
 struct ColInfo { int c, kh, kw; bool ok; };
@@ -370,14 +364,6 @@ __device__ __forceinline__ ColInfo col_info(const KParams& P, int col, int ncols
     ci.ok = col < ncols;
     return ci;
 }
-template <typename T>
-__device__ __forceinline__ u32x4 load_vec_cols(const T* __restrict__ p, const KParams& P, const RowInfo& r, const ColInfo& ci, bool& okout) {
-    bool ok = r.ok && ci.ok;
-    const int64_t off = tap_offset(P.d.g, P, r, ci.kh, ci.kw, ok) + ci.c;
-    okout = ok;
-    return *reinterpret_cast<const u32x4*>(p + (off & -(int64_t)ok));
-}
-
 // staging registers -> LDS tile.  KC: [rows][LDK] (k-contiguous source), else [BK][LDR] (row-contiguous source)
 template <typename T, bool KC, int NV, int RV, int LDR, int NT>
 __device__ __forceinline__ void lds_stage(T* l, const u32x4 (&regs)[NV], int tid) {
@@ -472,13 +458,21 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
 
     u32x4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];   // two staging register sets: prefetch distance 2 k-tiles
     RowInfo ia[NVA], ib[NVB];
-    ColInfo cb[NVB];
     // PMC (SQ_ACTIVE_INST_ANY ~ 84 % of the kernel, MFMA busy 10 %) showed this kernel is instruction-issue bound:
     // the interior fast path keeps one pointer per staging vector and advances it by a constant per k-tile.
     // Rows beyond M/N are clamped to the last valid row (their results are never stored).
     constexpr bool fast = GATHER == 3;   // compile-time: the general loaders (and their RowInfo registers) are not even compiled in
     const T* pa[NVA];
     const T* pb[NVB];
+    // LEAN GATHERS.  ISA of the first version (one RowInfo per vector, 64-bit offsets, a division per tap): 90-300 VALU instructions per
+    // k-tile and wave against 4-8 MFMAs -- the 64x64 gather kernels were bound by their address arithmetic (the weight gradient of a
+    // 3x3 convolution: 1.6 us per k-step).  Now all offsets are 32-bit elements (checked at launch) and
+    //   gather 1: per vector (image base + channel, pixel offset, y0, x0) are fixed per tile; a k-tile's tap adds ONE scalar delta;
+    //   gather 2: the column (tap, channel) is fixed per thread, the pixel (oy, ox, image offset) advances by BK rows per k-tile with
+    //             carries instead of divisions.
+    int g_bc[NVA], g_p0[NVA], g_y0[NVA], g_x0[NVA];            // gather 1
+    int h_oy[NVB], h_ox[NVB], h_bo[NVB], h_tyo = 0, h_txo = 0, h_c = 0;   // gather 2
+    bool h_cok = false;
     const int64_t stepA = AK ? BK : (int64_t)BK * d.lda, stepB = BKC ? BK : (int64_t)BK * d.ldb;
     int split, m0, n0, kbeg, kend, nt;   // the tile whose operands are being LOADED
     auto setup = [&](int bid) {
@@ -490,9 +484,39 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
         kbeg = split * P.kchunk;
         kend = min(d.K, kbeg + P.kchunk);
         nt = (kend - kbeg + BK - 1) / BK;
-        if constexpr (GATHER == 2) {
+        if constexpr (GATHER == 1) {
+            const RalfConvGeom& g = d.g;
 #pragma unroll
-            for (int i = 0; i < NVB; ++i) cb[i] = col_info(P, n0 + ((tid + NT * i) % RVB) * VEC, d.N);
+            for (int i = 0; i < NVA; ++i) {
+                const int v = tid + NT * i;
+                const RowInfo r = row_info<true>(P, m0 + v / KV, d.M, d.lda);
+                g_bc[i] = (int)r.base + (v % KV) * VEC;
+                g_p0[i] = (r.y0 * g.SW + r.x0) * g.SC;
+                g_y0[i] = r.ok ? r.y0 : -(1 << 30);     // a row beyond M fails every bounds test
+                g_x0[i] = r.x0;
+            }
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {   // weights [N][K], K a multiple of the k-tile: a pointer per vector, rows clamped (never stored)
+                const int v = tid + NT * i;
+                pb[i] = Bp + (int64_t)min(n0 + v / KV, d.N - 1) * d.ldb + kbeg + (v % KV) * VEC;
+            }
+        }
+        if constexpr (GATHER == 2) {
+            const RalfConvGeom& g = d.g;
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {   // dy [K][M]: a pointer per vector (rows beyond the k range are not dereferenced)
+                const int v = tid + NT * i;
+                pa[i] = Ap + (int64_t)(kbeg + v / RVA) * d.lda + min(m0 + (v % RVA) * VEC, d.M - VEC);
+            }
+            const ColInfo ci = col_info(P, n0 + (tid % RVB) * VEC, d.N);   // NT % RVB == 0: one column for all vectors of a thread
+            h_tyo = ci.kh - g.pad; h_txo = ci.kw - g.pad; h_c = ci.c; h_cok = ci.ok;
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                int b, rem;
+                P.fd_hw.divmod((uint32_t)(kbeg + (tid + NT * i) / RVB), b, rem);
+                P.fd_rw.divmod((uint32_t)rem, h_oy[i], h_ox[i]);
+                h_bo[i] = b * P.img;
+            }
         }
         if (fast) {
 #pragma unroll
@@ -509,11 +533,12 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                 if (d.kseg) pb[i] += (int64_t)(kbeg / d.kseg) * d.sBk;   // segmented K range of B (kbeg is a multiple of the k-tile)
             }
         }
-        if (AK && !fast) {
+        constexpr bool generic = GATHER == 0 || GATHER == 4;
+        if (AK && generic) {
 #pragma unroll
-            for (int i = 0; i < NVA; ++i) ia[i] = row_info<GATHER == 1 || GATHER == 4>(P, m0 + (tid + NT * i) / KV, d.M, d.lda);
+            for (int i = 0; i < NVA; ++i) ia[i] = row_info<GATHER == 4>(P, m0 + (tid + NT * i) / KV, d.M, d.lda);
         }
-        if (BKC && !fast) {
+        if (BKC && generic) {
 #pragma unroll
             for (int i = 0; i < NVB; ++i) ib[i] = row_info<false>(P, n0 + (tid + NT * i) / KV, d.N, d.ldb);
         }
@@ -530,28 +555,68 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
 #pragma unroll
                 for (int i = 0; i < NVB; ++i) pb[i] += d.sBk;
             }
+        } else if constexpr (GATHER == 1) {
+            // every k-tile lies inside ONE tap (channels % BK == 0): its (kh, kw, c0) come from the scalar unit
+            const RalfConvGeom& g = d.g;
+            int t, c0, kh, kw;
+            P.fd_sc.divmod((uint32_t)k0, t, c0);
+            P.fd_kw.divmod((uint32_t)t, kh, kw);
+            const int skh = P.ln_sgn * kh, skw = P.ln_sgn * kw;
+            const int delta = (skh * g.SW + skw) * g.SC;
+            uint32_t m = 0xffff0000u;
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                // source pixel = ((y0 + skh) >> sh, (x0 + skw) >> sh), valid when both shifts are exact (data gradient of a strided
+                // convolution) and inside the image; its offset (y*SW + x)*SC = (p0 + delta) >> sh for exactly those
+                const int ty = g_y0[i] + skh, tx = g_x0[i] + skw;
+                const bool ok = (((ty | tx) & P.ln_pm) == 0) & ((uint32_t)(ty >> P.ln_sh) < (uint32_t)g.SH) & ((uint32_t)(tx >> P.ln_sh) < (uint32_t)g.SW);
+                const int off = g_bc[i] + ((g_p0[i] + delta) >> P.ln_sh) + c0;
+                ra[i] = *reinterpret_cast<const u32x4*>(Ap + (ok ? off : 0));
+                m |= (uint32_t)ok << i;
+            }
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) { rb[i] = *reinterpret_cast<const u32x4*>(pb[i]); pb[i] += BK; }
+            okm = m;
+        } else if constexpr (GATHER == 2) {
+            const RalfConvGeom& g = d.g;
+            const int kleft = kend - k0;   // (uniform) rows of the k range still ahead
+            uint32_t m = 0u;
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                const bool ok = (tid + NT * i) / RVA < kleft;
+                ra[i] = *reinterpret_cast<const u32x4*>(ok ? pa[i] : Ap);
+                pa[i] += stepA;
+                m |= (uint32_t)ok << i;
+            }
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                const int ty = __mul24(h_oy[i], g.stride) + h_tyo, tx = __mul24(h_ox[i], g.stride) + h_txo;
+                const bool ok = ((tid + NT * i) / RVB < kleft) & h_cok & ((uint32_t)ty < (uint32_t)g.SH) & ((uint32_t)tx < (uint32_t)g.SW);
+                const int off = h_bo[i] + __mul24(ty, P.swsc) + __mul24(tx, g.SC) + h_c;
+                rb[i] = *reinterpret_cast<const u32x4*>(Bp + (ok ? off : 0));
+                m |= (uint32_t)ok << (16 + i);
+                // the pixel BK rows further on (one carry each: inc_x < RW, inc_y < RH)
+                int ox = h_ox[i] + P.inc_x;
+                const int wx = ox >= g.RW;
+                h_ox[i] = ox - (wx ? g.RW : 0);
+                int oy = h_oy[i] + P.inc_y + wx;
+                const int wy = oy >= g.RH;
+                h_oy[i] = oy - (wy ? g.RH : 0);
+                h_bo[i] += P.inc_b + (wy ? P.img : 0);
+            }
+            okm = m;
         } else {
-        // GATHER 1: every k-tile lies inside ONE tap (channels % BK == 0), decomposed once per k-tile on the scalar unit; GATHER 4: the
-        // general gather (stem: 8 channels), per vector.  Two kernels, not a run-time flag: the flag's uniform branch around every
-        // vector load ended a basic block there, and each block end waited for its load (s_waitcnt vmcnt(0)).
-        int tap_kh = 0, tap_kw = 0, tap_c0 = 0;
-        if constexpr (GATHER == 1) {   // k0 is wave-uniform: scalar arithmetic
-            int t;
-            P.fd_sc.divmod((uint32_t)k0, t, tap_c0);
-            P.fd_kw.divmod((uint32_t)t, tap_kh, tap_kw);
-        }
+        // GATHER 4: the general gather (stem: 8 channels), per vector; GATHER 0: plain operands with edges
         uint32_t m = 0u;
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             const int v = tid + NT * i;
             bool ok;
             if (AK) {
-                if constexpr (GATHER == 1) ra[i] = load_vec_tap<T>(Ap, P, ia[i], tap_kh, tap_kw, tap_c0 + (v % KV) * VEC, ok);
-                else ra[i] = load_vec<T, GATHER == 4>(Ap, P, ia[i], k0 + (v % KV) * VEC, kend, a_al, ok);
+                ra[i] = load_vec<T, GATHER == 4>(Ap, P, ia[i], k0 + (v % KV) * VEC, kend, a_al, ok);
             } else {
                 const RowInfo r = row_info<false>(P, k0 + v / RVA, kend, d.lda);
-                if constexpr (GATHER == 2) ra[i] = load_vec_al<T>(Ap, r, m0 + (v % RVA) * VEC, d.M, ok);
-                else ra[i] = load_vec<T, false>(Ap, P, r, m0 + (v % RVA) * VEC, d.M, a_al, ok);
+                ra[i] = load_vec<T, false>(Ap, P, r, m0 + (v % RVA) * VEC, d.M, a_al, ok);
             }
             m |= (uint32_t)ok << i;
         }
@@ -560,13 +625,12 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
             const int v = tid + NT * i;
             bool ok;
             if (BKC) {
-                if constexpr (GATHER == 1 || GATHER == 4) rb[i] = load_vec_al<T>(Bp, ib[i], k0 + (v % KV) * VEC, kend, ok);
+                if constexpr (GATHER == 4) rb[i] = load_vec_al<T>(Bp, ib[i], k0 + (v % KV) * VEC, kend, ok);
                 else rb[i] = load_vec<T, false>(Bp, P, ib[i], k0 + (v % KV) * VEC, kend, b_al, ok);
             }
             else {
-                const RowInfo r = row_info<GATHER == 2>(P, k0 + v / RVB, kend, d.ldb);
-                if constexpr (GATHER == 2) rb[i] = load_vec_cols<T>(Bp, P, r, cb[i], ok);
-                else rb[i] = load_vec<T, false>(Bp, P, r, n0 + (v % RVB) * VEC, d.N, b_al, ok);
+                const RowInfo r = row_info<false>(P, k0 + v / RVB, kend, d.ldb);
+                rb[i] = load_vec<T, false>(Bp, P, r, n0 + (v % RVB) * VEC, d.N, b_al, ok);
             }
             m |= (uint32_t)ok << (16 + i);
         }
