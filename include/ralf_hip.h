@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 11
+#define RALF_ABI_VERSION 12
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -129,6 +129,14 @@ typedef struct RalfGemmDesc {
     /* inference-time BatchNorm folded into the producing convolution: acc * colscale[n] (fp32 [N], may be NULL) before the bias,
      * i.e. y = act(conv(x) * gamma/sqrt(var+eps) + (beta - mean*gamma/sqrt(var+eps)) (+ res)) with scale/shift from ralf_bn_fold_batched */
     const float* colscale;
+    /* BatchNorm-backward statistics out of a data-gradient GEMM (all four NULL = off).  C is the gradient dz of a tensor
+     * z = relu(BN(x) (+ res)): the epilogue zeroes dz where the ReLU was inactive (bnb_mask: the 1-bit mask ralf_bn_apply wrote,
+     * bit (m*N + n) & 7 of byte (m*N + n) >> 3; NULL = no ReLU) and writes, per 64-row block of C, the column sums of the STORED dz
+     * and of dz * (x - mean[n]) to bnb_part (fp32 [ceil(M/64)][2][N]) -- the reductions of the BatchNorm backward
+     * (ralf_bn_bwd_stats_from_partials) without a pass over dz and x (replaces the first half of torch's native_batch_norm_backward).
+     * bnb_x: the BatchNorm INPUT x, contiguous [M][N] in the GEMM's dtype.  Needs splitk 1, one batch, N % 64 == 0, a contiguous
+     * 16-byte aligned [M][N] output in the GEMM's dtype, epilogue limited to alpha / bias / res / accumulate. */
+    const void* bnb_x; const unsigned char* bnb_mask; const float* bnb_mean; float* bnb_part;
 } RalfGemmDesc;
 size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d);
 int ralf_gemm(const RalfGemmDesc* d, void* workspace, size_t workspace_bytes, void* stream);
@@ -224,6 +232,10 @@ int ralf_bn_apply(int dtype, const void* x, const float* scale, const float* shi
                   int64_t M, int C, int relu, void* stream);
 int ralf_bn_bwd_reduce(int dtype, const void* x, const void* dy, const void* y, const uint8_t* relu_mask, const float* mean, const float* rstd,
                        float* s1, float* s2, int64_t M, int C, int relu, float* workspace, void* stream);
+/* the reductions from the partial rows a data-gradient GEMM wrote (RalfGemmDesc.bnb_part, nrows = ceil(M/64)):
+ * s1[c] += sum dz, s2[c] += rstd[c] * sum dz*(x - mean) = sum dz*xhat; workspace: 128*2*C floats.  Then ralf_bn_bwd_apply with relu = 0
+ * (dz is already masked; the gradient of the residual branch is dz itself). */
+int ralf_bn_bwd_stats_from_partials(const float* partials, int nrows, const float* rstd, float* s1, float* s2, int C, float* workspace, void* stream);
 int ralf_bn_bwd_apply(int dtype, const void* x, const void* dy, const void* y, const uint8_t* relu_mask, const float* mean, const float* rstd,
                       const float* gamma, const float* s1, const float* s2, void* dx, void* dres, int64_t M, int C, int relu, void* stream);
 

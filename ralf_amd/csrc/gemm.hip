@@ -126,6 +126,13 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
                      !d.C2 && !d.accumulate && !d.atomic_out && d.drop_p == 0.f && (d.dtype == RALF_F32 || !d.out_f32),
                      "gemm: colstats needs a plain epilogue, one batch, no split-K, N %% 64 == 0 and 8-wide aligned output");
     }
+    if (d.bnb_part || d.bnb_x || d.bnb_mean || d.bnb_mask) {
+        const bool same = d.dtype == RALF_F32 || !d.out_f32;
+        RALF_REQUIRE(d.bnb_part && d.bnb_x && d.bnb_mean && P.vec_epi == 2 && d.N % 64 == 0 && d.splitk == 1 && nbatch == 1 && same && d.ldc == d.N &&
+                     (!d.res || d.ldr % 8 == 0) && !d.act && !d.aux && !d.C2 && !d.accumulate && !d.atomic_out && !d.colstats && !d.colscale && d.drop_p == 0.f &&
+                     ((uintptr_t)d.bnb_x % 16) == 0 && ((uintptr_t)d.bnb_mean % 16) == 0 && ((uintptr_t)d.bnb_part % 4) == 0,
+                     "gemm: bnb_* needs x, mean and the partial buffer, a contiguous aligned [M,N] output in the operand dtype, N %% 64 == 0, no split-K and an alpha / bias / res epilogue");
+    }
     if (d.splitk > 1 && !d.atomic_out) {
         const size_t need = (size_t)d.splitk * nbatch * d.M * d.N * sizeof(float);
         if (!workspace || workspace_bytes < need) {

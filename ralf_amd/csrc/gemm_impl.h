@@ -273,6 +273,37 @@ __device__ __forceinline__ void epilogue_storev(const RalfGemmDesc& d, int z0, i
         if (d.out_f32) VIO<float, W>::st(d.C, coff, v); else VIO<T, W>::st(d.C, coff, v);
     }
 }
+// EPI 3 (RalfGemmDesc.bnb_*): the output is the gradient dz of z = relu(BN(x) (+ res)); 8 consecutive columns of row m.  After alpha / bias / res
+// the ReLU mask bits zero the inactive elements, the value is rounded to T (what the BatchNorm backward will read) and the thread's
+// running column sums s1 += dz, s2 += dz * (x - mean) are updated; the caller reduces them over the 64-row block.
+template <typename T>
+__device__ __forceinline__ void epilogue_storev_bnb(const RalfGemmDesc& d, int m, int n, float (&v)[8], const float (&mu)[8], float (&s1)[8], float (&s2)[8]) {
+    const int64_t e = (int64_t)m * d.N + n;   // contiguous [M][N]: output, x and the mask bits share the element index
+    float xv[8];
+    VIO<T, 8>::ld(d.bnb_x, e, xv);
+    const uint32_t mb = d.bnb_mask ? (uint32_t)d.bnb_mask[e >> 3] : 0xffu;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] *= d.alpha;
+    if (d.bias) {
+        float b[8];
+        VIO<float, 8>::ld(d.bias, n, b);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += b[q];
+    }
+    if (d.res) {
+        float r[8];
+        VIO<T, 8>::ld(d.res, (int64_t)m * d.ldr + n, r);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += r[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        v[q] = (float)(T)(((mb >> q) & 1u) ? v[q] : 0.f);
+        s1[q] += v[q];
+        s2[q] += v[q] * (xv[q] - mu[q]);
+    }
+    VIO<T, 8>::st(d.C, e, v);
+}
 template <typename T, int EPI>
 __device__ __forceinline__ void epilogue_store4(const RalfGemmDesc& d, int z0, int z1, int m, int n, float (&v)[4]) {
     epilogue_storev<T, EPI, 4>(d, z0, z1, m, n, v);
@@ -833,6 +864,12 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                     pr[0] = s1; pr[d.N] = s2;
                 }
             }
+            float bs1[8], bs2[8], bmu[8];   // EPI 3: this thread's column sums over its rows of the block, the columns' BatchNorm means
+            if constexpr (EPI == 3) {
+                VIO<float, 8>::ld(d.bnb_mean, c_n0 + (tid % CG) * 8, bmu);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) bs1[q] = bs2[q] = 0.f;
+            }
 #pragma unroll
             for (int p = 0; p < 64 / RPP; ++p) {
                 const int lr = p * RPP + tid / CG, c = (tid % CG) * 8;
@@ -840,8 +877,26 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                 if (m < d.M) {
                     const float4 lo = *reinterpret_cast<const float4*>(cs + lr * CP + c), hi = *reinterpret_cast<const float4*>(cs + lr * CP + c + 4);
                     float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    if (slab) VIO<float, 8>::st(pbase, (int64_t)m * d.N + c_n0 + c, v);
+                    if constexpr (EPI == 3) epilogue_storev_bnb<T>(d, m, c_n0 + c, v, bmu, bs1, bs2);
+                    else if (slab) VIO<float, 8>::st(pbase, (int64_t)m * d.N + c_n0 + c, v);
                     else epilogue_storev<T, EPI, 8>(d, z0, z1, m, c_n0 + c, v);
+                }
+            }
+            if constexpr (EPI == 3) {
+                // the RPP threads that share a column group hand their sums over through the (now idle) staging tile, fixed order
+                static_assert(RPP * 2 * BN <= 64 * CP, "the partial sums reuse the C staging tile");
+                __syncthreads();
+                float* ps = cs + (tid / CG) * 2 * BN + (tid % CG) * 8;
+                *reinterpret_cast<float4*>(ps) = make_float4(bs1[0], bs1[1], bs1[2], bs1[3]);
+                *reinterpret_cast<float4*>(ps + 4) = make_float4(bs1[4], bs1[5], bs1[6], bs1[7]);
+                *reinterpret_cast<float4*>(ps + BN) = make_float4(bs2[0], bs2[1], bs2[2], bs2[3]);
+                *reinterpret_cast<float4*>(ps + BN + 4) = make_float4(bs2[4], bs2[5], bs2[6], bs2[7]);
+                __syncthreads();
+                if (tid < 2 * BN && c_m0 + h * 64 < d.M) {
+                    float t = 0.f;
+#pragma unroll 8
+                    for (int r = 0; r < RPP; ++r) t += cs[r * 2 * BN + tid];
+                    d.bnb_part[((int64_t)(c_m0 / 64 + h) * 2 + tid / BN) * d.N + c_n0 + tid % BN] = t;
                 }
             }
         }
@@ -865,11 +920,11 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                                 if (n + q < d.N) pp[q] = v[q];
                         }
                     } else if (P.vec_epi && n + 3 < d.N) {
-                        epilogue_store4<T, EPI>(d, z0, z1, m, n, v);
+                        epilogue_store4<T, (EPI == 3 ? 0 : EPI)>(d, z0, z1, m, n, v);
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (n + q < d.N) epilogue_store<T, EPI>(d, z0, z1, m, n + q, v[q]);
+                            if (n + q < d.N) epilogue_store<T, (EPI == 3 ? 0 : EPI)>(d, z0, z1, m, n + q, v[q]);
                     }
                 }
             }
@@ -1017,6 +1072,10 @@ int launch(KParams& P, int nbatch, hipStream_t st) {
 template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int NW>
 int launch_epi(KParams& P, int nbatch, hipStream_t st) {
     const RalfGemmDesc& d = P.d;
+    if (d.bnb_part) {   // BatchNorm-backward statistics: data-gradient products only (A k-contiguous: 1x1 on the interior path, k x k through the tap gather)
+        if constexpr (AK && (GATHER == 0 || GATHER == 1 || GATHER == 3)) return launch<T, AK, BKC, GATHER, FM, FN, 3, NW>(P, nbatch, st);
+        else { ralf::set_error("gemm: bnb_* needs a k-contiguous A (no general per-vector gather, no weight-gradient layout)"); return RALF_ERR_INVALID; }
+    }
     const bool lvl2 = d.C2 || d.act == RALF_ACT_GELU || d.aux_mode == RALF_AUX_GELU_GRAD || d.atomic_out;
     const bool lvl1 = d.drop_p > 0.f || d.aux;
     if (lvl2) return launch<T, AK, BKC, GATHER, FM, FN, 2, NW>(P, nbatch, st);
@@ -1034,7 +1093,7 @@ template <typename T, bool AK, bool BKC, int GATHER>
 int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
     const RalfGemmDesc& d = P.d;
     static const int forced = [] { const char* e = getenv("RALF_GEMM_TILE"); return e ? atoi(e) : 0; }();  // tuning / test aid: 22 / 11
-    const bool ok22 = !d.colstats || d.N % 128 == 0;   // column statistics come from the staged epilogue: every tile interior in n
+    const bool ok22 = (!d.colstats && !d.bnb_part) || d.N % 128 == 0;   // column statistics come from the staged epilogue: every tile interior in n
     if (forced == 22 && ok22) return launch_epi<T, AK, BKC, GATHER, 2, 2, 8>(P, nbatch, st);
     if (forced == 11) return launch_epi<T, AK, BKC, GATHER, 1, 1, 4>(P, nbatch, st);
     const int64_t big = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) * d.splitk * nbatch;

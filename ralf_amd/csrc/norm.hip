@@ -429,6 +429,30 @@ __global__ __launch_bounds__(64 * WAVES) void bn_partial_finalize_kernel(const f
     if (counter && blockIdx.x == 0 && threadIdx.x == 0) *counter += 1;
 }
 
+// backward statistics from the partial rows a data-gradient GEMM wrote (RalfGemmDesc.bnb_part: [nblk][2][C], sums of dz and of dz * (x - mean)):
+// s1[c] += sum_b part[b][0][c],  s2[c] += rstd[c] * sum_b part[b][1][c]   (= sum dz * xhat); deterministic order
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void bn_bwd_partial_sum_kernel(const float* __restrict__ part, int nblk, int C, const float* __restrict__ rstd,
+                                                                  float* __restrict__ s1, float* __restrict__ s2) {
+    __shared__ float red[2][WAVES][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float a = 0.f, b = 0.f;
+    if (c < C) {
+#pragma unroll 8
+        for (int i = ty; i < nblk; i += WAVES) { a += part[((int64_t)i * 2) * C + c]; b += part[((int64_t)i * 2 + 1) * C + c]; }
+    }
+    red[0][ty][tx] = a; red[1][ty][tx] = b;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) { t1 += red[0][w][tx]; t2 += red[1][w][tx]; }
+        s1[c] += t1;
+        s2[c] += rstd[c] * t2;
+    }
+}
+
 // [nrows][2][C] partial sums -> [G][2][C] (row r goes to group r % G): first stage when the GEMM wrote thousands of partial rows
 __global__ __launch_bounds__(256) void bn_partial_fold_kernel(const float* __restrict__ part, int nrows, int C, int G, float* __restrict__ out) {
     __shared__ float red[2][4][64];
@@ -781,6 +805,21 @@ extern "C" int ralf_bn_stats_from_partials(const float* partials, int nrows, con
     hipLaunchKernelGGL(bn_partial_finalize_kernel<4>, dim3(ceil_div(C, 64)), dim3(256), 0, st, src, n, gamma, beta, running_mean, running_var,
                        num_batches_tracked, mean, rstd, scale, shift, M, C, eps, momentum);
     return ralf::check_launch("bn_stats_from_partials");
+}
+
+extern "C" int ralf_bn_bwd_stats_from_partials(const float* partials, int nrows, const float* rstd, float* s1, float* s2, int C, float* workspace, void* stream) {
+    RALF_REQUIRE(partials && nrows > 0 && rstd && s1 && s2 && workspace && C > 0, "bn_bwd_stats_from_partials: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const float* src = partials;
+    int n = nrows;
+    if (nrows > 1024) {   // thousands of rows: fold to 128 rows with a wide grid first
+        const int G = 128;
+        hipLaunchKernelGGL(bn_partial_fold_kernel, dim3(ceil_div(C, 64), G), dim3(256), 0, st, partials, nrows, C, G, workspace);
+        src = workspace; n = G;
+    }
+    if (n > 64) hipLaunchKernelGGL(bn_bwd_partial_sum_kernel<16>, dim3(ceil_div(C, 64)), dim3(1024), 0, st, src, n, C, rstd, s1, s2);
+    else hipLaunchKernelGGL(bn_bwd_partial_sum_kernel<4>, dim3(ceil_div(C, 64)), dim3(256), 0, st, src, n, C, rstd, s1, s2);
+    return ralf::check_launch("bn_bwd_stats_from_partials");
 }
 
 extern "C" int ralf_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, uint8_t* relu_mask,

@@ -60,6 +60,13 @@ class Runtime:
         self._masked: dict = {}
         self._fanout: dict = {}
         self.ln_dropout = True
+        # z = relu(BN(x) (+ res)) outputs are tagged with what the BatchNorm backward reduces over (x, ReLU mask bits, mean); the convolution
+        # that consumes z then masks dz and emits the reductions from its data-gradient epilogue (RalfGemmDesc.bnb_*), and the BatchNorm
+        # backward that receives exactly that dz skips its own pass over dz and x
+        self.bn_bwd_fused = os.environ.get("RALF_BN_BWD_FUSED", "1") != "0"
+        self._bn_tags: dict = {}
+        self._bn_stats: dict = {}
+        self.bn_fused_hits = 0    # BatchNorm backwards that took their reductions from a data-gradient epilogue (tests / diagnostics)
         self.fused_decode = True  # KV-cached decode step: LayerNorm + projections + attention per block in one launch (bf16, d = 256, 8 heads)
         self.fold_bn = True       # inference: eval-mode BatchNorm folded into the convolution epilogues (conv_bn_infer)
 
@@ -80,6 +87,8 @@ class Runtime:
         self._branch_keep.clear()
         self._drop_tags.clear()
         self._masked.clear()
+        self._bn_tags.clear()
+        self._bn_stats.clear()
         self._fanout.clear()   # (every branch entry first waits for all work issued so far: the previous step's consumers are ordered)
 
     def advance_seed(self):
@@ -138,6 +147,26 @@ class Runtime:
 
     def dropout_tag(self, x: torch.Tensor):
         return self._drop_tags.get(x.data_ptr())
+
+    def tag_bn_output(self, z: torch.Tensor, x2: torch.Tensor, mask, mean: torch.Tensor):
+        if self.bn_bwd_fused and x2.shape[1] % 64 == 0:   # (called inside Function.forward: no grad-mode test here)
+            self._bn_tags[z.data_ptr()] = (x2, mask, mean)
+
+    def take_bn_tag(self, z: torch.Tensor):
+        """the tag goes to the FIRST convolution that consumes z (a bottleneck's conv1 with fork=True, which sums the gradients of all
+        other consumers in its own epilogue; conv2 / conv3 are sole consumers)"""
+        return self._bn_tags.pop(z.data_ptr(), None)
+
+    def offer_bn_stats(self, dz: torch.Tensor, partials: torch.Tensor):
+        self._bn_stats[dz.data_ptr()] = (partials, dz)   # (dz itself is kept so that its address cannot be reused meanwhile)
+
+    def bn_stats(self, dy: torch.Tensor, M: int, C: int):
+        """the partial reductions a data-gradient GEMM wrote next to dy (already ReLU-masked), when dy IS that GEMM's output"""
+        hit = self._bn_stats.pop(dy.data_ptr(), None)
+        if hit is not None and hit[1].numel() == M * C and hit[0].shape[2] == C and dy.is_contiguous():
+            self.bn_fused_hits += 1
+            return hit[0]
+        return None
 
     def offer_masked(self, dx: torch.Tensor, call: int, dx_masked: torch.Tensor):
         self._masked[dx.data_ptr()] = (call, dx_masked, dx)   # (dx itself is kept so that its address cannot be reused meanwhile)
@@ -867,6 +896,7 @@ class ConvFn(Function):
         ctx.save_for_backward(x, W)
         ctx.bias = b
         ctx.cfg = (stride, pad, OH, OW, b is not None, rt)
+        ctx.bn = rt.take_bn_tag(x)   # x is a relu(BatchNorm) output: this convolution's data gradient also feeds that BatchNorm's backward
         ctx.fork = fork
         ctx.set_materialize_grads(False)   # no zero-filled "gradient" of the statistics output / an unused fork (59 fills per step)
         out = (y.view(B, OH, OW, Co),) + ((x,) if fork else ())
@@ -893,12 +923,19 @@ class ConvFn(Function):
         one = kh == 1 and stride == 1
         if ctx.needs_input_grad[0]:
             sk = dskip.contiguous().view(-1, C) if dskip is not None else None
+            Mi = B * H * Wd
+            dsk = 1 if one else _conv_splitk(Mi, kh * kw * Co)
+            bnb = None
+            if ctx.bn is not None and dsk == 1 and ctx.bn[0].shape == (Mi, C) and (one or (Co % (64 if dy.dtype == torch.bfloat16 else 32) == 0 and stride in (1, 2))):
+                bnb = ctx.bn + (torch.empty((Mi + 63) // 64, 2, C, dtype=torch.float32, device=dy.device),)
             if one:
-                dx = ops.gemm(dy2, rt.lp(W).view(Co, Ci), M, Ci, Co, b_kcontig=False, res=sk).view(B, H, Wd, C)
+                dx = ops.gemm(dy2, rt.lp(W).view(Co, Ci), M, Ci, Co, b_kcontig=False, res=sk, bnb=bnb)
             else:
                 geom = dict(RH=H, RW=Wd, SH=OH, SW=OW, SC=Co, KH=kh, KW=kw, stride=stride, pad=pad, mode=1)
-                dx = ops.gemm(dy, rt.lp(W, "ikwo"), B * H * Wd, C, kh * kw * Co, conv=geom, gather=1, res=sk,
-                              splitk=_conv_splitk(B * H * Wd, kh * kw * Co)).view(B, H, Wd, C)
+                dx = ops.gemm(dy, rt.lp(W, "ikwo"), Mi, C, kh * kw * Co, conv=geom, gather=1, res=sk, splitk=dsk, bnb=bnb)
+            if bnb is not None:
+                rt.offer_bn_stats(dx, bnb[3])
+            dx = dx.view(B, H, Wd, C)
         if ctx.needs_input_grad[1]:
             gv = rt.gview(W)
             if one:
@@ -958,6 +995,8 @@ class BatchNormFn(Function):
                                              counter=counter, partials=partials, want_mask=True)
         # backward reads x, dy and the 1-bit ReLU mask (not y: 1/16 of the bytes, twice per backward)
         ctx.save_for_backward(x2, mask if relu else None, g, mean, rstd)
+        if training and relu:
+            rt.tag_bn_output(y, x2, mask, mean)
         ctx.beta, ctx.rt = b, rt
         ctx.cfg = (relu, res is not None, training, shp)
         return y.view(shp)
@@ -968,7 +1007,9 @@ class BatchNormFn(Function):
         relu, has_res, training, shp = ctx.cfg
         gg, gb = ctx.rt.gview(g), ctx.rt.gview(ctx.beta)
         into = (gg, gb) if (gg is not None and gb is not None and training) else None
-        dx, dg, db, dres = ops.bn_backward(x2, dy.contiguous().view(-1, shp[-1]), None, g.detach(), mean, rstd, relu, has_res, training, into=into, mask=mask)
+        dy2 = dy.contiguous().view(-1, shp[-1])
+        part = ctx.rt.bn_stats(dy, x2.shape[0], x2.shape[1]) if (training and relu) else None
+        dx, dg, db, dres = ops.bn_backward(x2, dy2, None, g.detach(), mean, rstd, relu, has_res, training, into=into, mask=mask, partials=part)
         if into is not None:
             dg = db = None
         return dx.view(shp), dg, db, None, None, (dres.view(shp) if has_res else None), None, None, None, None, None

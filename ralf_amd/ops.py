@@ -72,7 +72,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
          bias=None, act=None, res=None, ldr=None, aux=None, aux_mode=None, aux_scale=1.0, out2=None,
          alpha=1.0, accumulate=False, splitk=1, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=None,
          conv: Optional[dict] = None, gather=0, drop_p=0.0, seed=None, call_id=0, atomic=False, colstats=None,
-         sBias0=0, kseg=0, sBk=0, colscale=None) -> torch.Tensor:
+         sBias0=0, kseg=0, sBk=0, colscale=None, bnb=None) -> torch.Tensor:
     """C = epi(alpha * A @ B) through ralf_gemm (see include/ralf_hip.h: RalfGemmDesc)."""
     assert A.is_cuda and B.is_cuda and A.dtype == B.dtype
     d = RalfGemmDesc()
@@ -106,6 +106,10 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
     d.drop_p, d.seed, d.call_id, d.atomic_out = drop_p, _p(seed), call_id, int(atomic)
     d.sBias0, d.kseg, d.sBk = sBias0, kseg, sBk
     d.colscale = _p(colscale)
+    if bnb is not None:   # (x, relu mask bits or None, mean, partials [ceil(M/64), 2, N]): BatchNorm-backward reductions from this epilogue
+        bx, bm, bmean, bpart = bnb
+        assert bx.dtype == A.dtype and bx.is_contiguous() and bx.numel() == M * N and bpart.dtype == torch.float32 and bpart.numel() >= ((M + 63) // 64) * 2 * N
+        d.bnb_x, d.bnb_mask, d.bnb_mean, d.bnb_part = _p(bx), _p(bm), _p(bmean), _p(bpart)
     if colstats is not None:   # fp32 [ceil(M/64), 2, N]: per-64-row column sums / sums of squares of the stored output
         assert colstats.dtype == torch.float32 and colstats.numel() >= ((M + 63) // 64) * 2 * N
         d.colstats = _p(colstats)
@@ -458,9 +462,11 @@ def bn_forward(x2d, gamma, beta, running_mean, running_var, training, relu, res,
     return y, out[0], out[1]
 
 
-def bn_backward(x2d, dy, y, gamma, mean, rstd, relu, want_dres, training=True, into=None, mask=None):
+def bn_backward(x2d, dy, y, gamma, mean, rstd, relu, want_dres, training=True, into=None, mask=None, partials=None):
     """training: batch-statistics backward.  eval: statistics are constants -> dx = gamma*rstd*g
-    (the same apply kernel with zero reduction terms); dgamma/dbeta are the same sums either way."""
+    (the same apply kernel with zero reduction terms); dgamma/dbeta are the same sums either way.
+    partials: dy is the output of a data-gradient GEMM that already masked it and wrote the reductions per 64-row block
+    (ops.gemm(bnb=...)): no pass over dy and x for the sums, and the residual branch's gradient is dy itself."""
     M, C = x2d.shape
     dt = dtype_code(x2d)
     if into is not None:   # (dgamma, dbeta) flat-gradient views, zero at this point: reduce straight into them
@@ -468,6 +474,11 @@ def bn_backward(x2d, dy, y, gamma, mean, rstd, relu, want_dres, training=True, i
     else:
         st = torch.zeros(2, C, dtype=torch.float32, device=x2d.device)
         s = (st[0], st[1])
+    if partials is not None:
+        _call("ralf_bn_bwd_stats_from_partials", _p(partials), partials.shape[0], _p(rstd), _p(s[0]), _p(s[1]), C, _p(workspace(128 * 2 * C * 4, x2d.device)))
+        dx = torch.empty_like(x2d)
+        _call("ralf_bn_bwd_apply", dt, _p(x2d), _p(dy), None, None, _p(mean), _p(rstd), _p(gamma), _p(s[0]), _p(s[1]), _p(dx), None, M, C, 0)
+        return dx, s[1], s[0], (dy if want_dres else None)
     _call("ralf_bn_bwd_reduce", dt, _p(x2d), _p(dy), _p(y), _p(mask), _p(mean), _p(rstd), _p(s[0]), _p(s[1]), M, C, int(relu), _p(workspace(1024 * 2 * C * 4, x2d.device)))
     dx = torch.empty_like(x2d)
     dres = torch.empty_like(x2d) if want_dres else None

@@ -76,6 +76,8 @@ def test_batched_strided(dtype):
 
 CONVS = [  # (B, H, W, Cin, Cout, k, stride, pad)
     (2, 16, 12, 8, 64, 7, 2, 3), (2, 9, 7, 16, 24, 3, 1, 1), (2, 10, 8, 16, 32, 3, 2, 1), (3, 6, 5, 32, 16, 1, 1, 0), (2, 8, 8, 16, 40, 1, 2, 0),
+    # channel counts that are multiples of the k-tile (one tap per k-tile: the scalar-tap loaders) on odd, non-square grids
+    (2, 11, 9, 64, 128, 3, 1, 1), (2, 13, 10, 64, 64, 3, 2, 1), (1, 15, 15, 128, 64, 1, 2, 0), (3, 5, 23, 64, 72, 3, 1, 1),
 ]
 
 
@@ -135,6 +137,37 @@ def test_column_statistics_epilogue(dtype, M, N, K):
     torch.testing.assert_close(res[0], o.mean(0), atol=1e-3, rtol=1e-3)
     torch.testing.assert_close(res[1], (o.var(0, unbiased=False) + 1e-5).rsqrt(), atol=1e-3, rtol=2e-3)
     assert int(cnt) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,relu", [(1000, 128, 192, True), (4101, 64, 64, True), (300, 256, 512, False)])
+def test_batchnorm_backward_statistics_epilogue(dtype, M, N, K, relu):
+    """RalfGemmDesc.bnb_*: dz = mask * (dy @ W + skip) stored in the operand dtype, and per 64-row block the column sums of dz and of
+    dz * (x - mean); then ralf_bn_bwd_stats_from_partials == the sums ralf_bn_bwd_reduce computes from the tensors (ragged last block,
+    both tile shapes via N)."""
+    from ralf_amd import ops
+
+    A, W = rnd(M, K, seed=41, dtype=dtype).cuda(), (rnd(K, N, seed=42, dtype=dtype) * 0.1).to(dtype).cuda()
+    skip, x = rnd(M, N, seed=43, dtype=dtype).cuda(), rnd(M, N, seed=44, dtype=dtype).cuda()
+    mean, rstd = rnd(N, seed=45).cuda() * 0.3, rnd(N, seed=46).abs().cuda() + 0.5
+    keep = torch.rand(M, N, generator=torch.Generator().manual_seed(47)) > 0.4
+    bits = (keep.view(-1, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(1).to(torch.uint8).cuda() if relu else None
+    part = torch.full(((M + 63) // 64, 2, N), float("nan"), device="cuda")
+    dz = ops.gemm(A, W, M, N, K, b_kcontig=False, res=skip, bnb=(x, bits, mean, part))
+    want = A.float() @ W.float() + skip.float()
+    if relu:
+        want = want * keep.cuda()
+    torch.testing.assert_close(dz.float().cpu(), want.to(dtype).float().cpu(), **TOL[dtype])
+    assert not relu or bool((dz[~keep.cuda()] == 0).all())
+    d = dz.float()
+    pad = (-M) % 64
+    z64 = lambda t: torch.cat([t, torch.zeros(pad, N, device="cuda")]).view(-1, 64, N)   # noqa: E731
+    torch.testing.assert_close(part[:, 0], z64(d).sum(1), atol=1e-3, rtol=1e-4)
+    torch.testing.assert_close(part[:, 1], z64(d * (x.float() - mean)).sum(1), atol=2e-3, rtol=1e-4)
+    s = torch.ones(2, N, device="cuda")
+    ops._call("ralf_bn_bwd_stats_from_partials", ops._p(part), part.shape[0], ops._p(rstd), ops._p(s[0]), ops._p(s[1]), N, ops._p(torch.empty(128 * 2 * N, device="cuda")))
+    torch.testing.assert_close(s[0] - 1, d.sum(0), atol=2e-3, rtol=1e-4)
+    torch.testing.assert_close(s[1] - 1, (d * (x.float() - mean) * rstd).sum(0), atol=5e-3, rtol=2e-4)
 
 
 @pytest.mark.parametrize("tile", ["11", "22"])

@@ -321,6 +321,38 @@ def test_bottleneck_blocks_fp32(inpl, planes, stride, ds, H, W):
     assert rel(xd.grad.cpu().permute(0, 3, 1, 2), x.grad) < 1e-4
     for n, p in blk.named_parameters():
         assert rel(p.grad.cpu(), P[n].grad) < 1e-4, n
+    # bn1 / bn2 took their reductions from the epilogues of the conv2 / conv3 data gradients (layer4's 3x3 splits K: bn1 does not)
+    assert rt.bn_fused_hits == (1 if planes == 512 else 2), rt.bn_fused_hits
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_batchnorm_backward_reductions_from_the_data_gradient_epilogue_equal_the_separate_pass(dtype):
+    """RalfGemmDesc.bnb_*: the consuming convolution masks dz and writes the BatchNorm-backward sums from its data-gradient epilogue
+    (53 BatchNorms of the ResNet: conv2 / conv3 inputs, and the block outputs through conv1's fork).  Same forward, so the two
+    backward paths differ by summation order only."""
+    sd = det_state_dict(resnet50_fpn_shapes())
+    g = torch.Generator().manual_seed(4)
+    img = torch.rand(3, 4, 128, 96, generator=g).cuda()
+    go = (torch.randn(3, 8 * 6, 256, generator=g) * 0.1).cuda()
+    grads, hits = [], []
+    for fused in (True, False):
+        bb = RN.ResnetFeatureExtractor(256)
+        bb.load_state_dict({k[len("encoder."):]: v.detach().clone() for k, v in sd.items()}, strict=True)
+        bb = bb.cuda()
+        rt = RN.Runtime(getattr(torch, dtype)).to(torch.device("cuda"))
+        rt.training, rt.bn_bwd_fused = True, fused
+        out = bb(img, rt)
+        out.backward(go.to(out.dtype))
+        grads.append({k: p.grad.float().clone() for k, p in bb.named_parameters()})
+        hits.append(rt.bn_fused_hits)
+    assert hits[1] == 0 and hits[0] >= 40, hits
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        if dtype == "float32":
+            assert ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item() < 2e-5, (k, (a - b).abs().max().item(), b.abs().max().item())
+        else:   # one-ulp differences of the bf16 dx grow through 53 batch-statistic BatchNorm backwards (like the fp32 oracle comparison above)
+            cos = torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
+            assert cos > 0.99 and abs((a.norm() / b.norm()).item() - 1) < 0.05, (k, cos, a.norm().item(), b.norm().item())
 
 
 @pytest.mark.parametrize("task", ["uncond", "c", "cwh", "refinement", "partial"])
