@@ -975,6 +975,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_grouped_kernel(
     d.act = 0; d.aux_mode = 0; d.out_f32 = 1; d.accumulate = 1; d.splitk = J.splitk;
     d.alpha = 1.f; d.aux_scale = 1.f; d.seed = nullptr; d.call_id = 0; d.drop_p = 0.f; d.atomic_out = 0; d.colstats = nullptr;
     d.sBias0 = 0; d.sBk = 0; d.kseg = 0; d.colscale = nullptr;
+    d.bnb_x = nullptr; d.bnb_mask = nullptr; d.bnb_mean = nullptr; d.bnb_part = nullptr;
     P.tiles_n = J.tiles_n; P.tiles_m = J.nwg / J.tiles_n; P.nwg = J.nwg; P.kchunk = J.kchunk; P.partial = J.partial;
     P.vec_epi = 2; P.fast = 1; P.tapuni = 0;
     gemm_body<T, false, false, 3, FM, FN, 0, NW>(P, b - J.first, 1, 0, 1, lds_raw);
