@@ -1004,6 +1004,83 @@ __global__ __launch_bounds__(256) void gemm_grouped_reduce_kernel(const GRedPara
     *reinterpret_cast<float4*>(c) = lo; *reinterpret_cast<float4*>(c + 4) = hi;
 }
 
+// ---- few-row products (KV-cached decode: M = batch rows) ---------------------------------------------------------------------
+// One WAVE per 32x32 output tile, no LDS, no barrier: lane (r = lane & 31, h = lane >> 5) loads the 16-byte k-slices of ITS fragment
+// row of A and of B straight from global memory (both k-contiguous) and the wave runs the K/16 MFMAs of its tile -- the same MFMA
+// chain in the same order as the tiled kernel (bit-identical results).  A decode-step linear layer (256 x 256..1024 x 256..1024) is
+// pure latency: the tiled kernel's index set-up, two staging hops and barriers cost 7.2 us per launch (1 266 launches per batch);
+// here a tile is one load round trip + K/16 MFMAs.
+template <typename T, int EPI, int CH>
+__global__ __launch_bounds__(64) void gemm_skinny_kernel(const KParams P) {
+    static_assert(sizeof(T) == 2, "bf16 only");
+    const RalfGemmDesc& d = P.d;
+    const int lane = threadIdx.x, l31 = lane & 31, lh = lane >> 5;
+    const int tm = (int)blockIdx.x / P.tiles_n, tn = (int)blockIdx.x - tm * P.tiles_n;
+    const int m0 = tm * 32, n0 = tn * 32;
+    const bf16* a = (const bf16*)d.A + (int64_t)min(m0 + l31, d.M - 1) * d.lda + lh * 8;   // (rows beyond M / N are clamped: never stored)
+    const bf16* b = (const bf16*)d.B + (int64_t)min(n0 + l31, d.N - 1) * d.ldb + lh * 8;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // chunks of CH 16-wide k-slices, two register sets: 2 x CH x 2 loads in flight (K = 256 with CH = 8: everything at once)
+    bf16x8 a0[CH], b0[CH], a1[CH], b1[CH];
+    auto load = [&](bf16x8 (&ar)[CH], bf16x8 (&br)[CH], int c) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            ar[i] = *reinterpret_cast<const bf16x8*>(a + (c * CH + i) * 16);
+            br[i] = *reinterpret_cast<const bf16x8*>(b + (c * CH + i) * 16);
+        }
+    };
+    auto comp = [&](const bf16x8 (&ar)[CH], const bf16x8 (&br)[CH]) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[i], ar[i], acc, 0, 0, 0);
+    };
+    const int nch = d.K / (16 * CH);
+    load(a0, b0, 0);
+    int c = 0;
+    for (; c + 2 < nch; c += 2) {
+        load(a1, b1, c + 1);
+        comp(a0, b0);
+        load(a0, b0, c + 2);
+        comp(a1, b1);
+    }
+    if (c + 1 < nch) {
+        load(a1, b1, c + 1);
+        comp(a0, b0);
+        comp(a1, b1);
+    } else {
+        comp(a0, b0);
+    }
+    const int m = m0 + l31;
+    // (written out per register group: a loop the compiler leaves rolled indexes the accumulator dynamically = scratch memory)
+#define RALF_SKINNY_STORE(g)                                                                              \
+    {                                                                                                     \
+        const int n = n0 + 8 * (g) + 4 * lh;                                                              \
+        float v[4] = {acc[4 * (g)], acc[4 * (g) + 1], acc[4 * (g) + 2], acc[4 * (g) + 3]};                \
+        if (m < d.M && n < d.N) {                                                                         \
+            if (P.vec_epi && n + 3 < d.N) {                                                               \
+                epilogue_store4<T, EPI>(d, 0, 0, m, n, v);                                                \
+            } else {                                                                                      \
+                if (n + 0 < d.N) epilogue_store<T, EPI>(d, 0, 0, m, n + 0, v[0]);                         \
+                if (n + 1 < d.N) epilogue_store<T, EPI>(d, 0, 0, m, n + 1, v[1]);                         \
+                if (n + 2 < d.N) epilogue_store<T, EPI>(d, 0, 0, m, n + 2, v[2]);                         \
+                if (n + 3 < d.N) epilogue_store<T, EPI>(d, 0, 0, m, n + 3, v[3]);                         \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+    RALF_SKINNY_STORE(0) RALF_SKINNY_STORE(1) RALF_SKINNY_STORE(2) RALF_SKINNY_STORE(3)
+#undef RALF_SKINNY_STORE
+}
+
+template <typename T, int EPI>
+int launch_skinny(KParams& P, hipStream_t st) {
+    P.tiles_m = ceil_div(P.d.M, 32);
+    P.tiles_n = ceil_div(P.d.N, 32);
+    if (P.d.K % 128 == 0) hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 8>), dim3(P.tiles_m * P.tiles_n), dim3(64), 0, st, P);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 4>), dim3(P.tiles_m * P.tiles_n), dim3(64), 0, st, P);
+    return ralf::check_launch("gemm (few rows)");
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams P, int nbatch) {
     const RalfGemmDesc& d = P.d;
@@ -1118,6 +1195,12 @@ int dispatch(KParams& P, int nbatch, hipStream_t st) {
         return launch_cfg<T, false, false, 2>(P, nbatch, st);
     }
     if constexpr (sizeof(T) == 2) {   // bf16: the interior fast path is its own (leaner) set of kernels; fp32 is the parity mode
+        static const int skinny_rows = [] { const char* e = getenv("RALF_GEMM_SKINNY_ROWS"); return e ? atoi(e) : 512; }();   // 0 = off (A/B runs)
+        if (P.fast && key == 6 && d.M <= skinny_rows && nbatch == 1 && d.splitk == 1 && !d.colstats && !d.bnb_part && !d.kseg && !d.atomic_out) {
+            const bool lvl2 = d.C2 || d.act == RALF_ACT_GELU || d.aux_mode == RALF_AUX_GELU_GRAD;
+            const bool lvl1 = d.drop_p > 0.f || d.aux;
+            return lvl2 ? launch_skinny<T, 2>(P, st) : lvl1 ? launch_skinny<T, 1>(P, st) : launch_skinny<T, 0>(P, st);
+        }
         if (P.fast) {
             switch (key) {
                 case 6: return launch_cfg<T, true, true, 3>(P, nbatch, st);
