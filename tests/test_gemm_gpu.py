@@ -217,3 +217,37 @@ def test_grouped_weight_gradients_match_per_layer_products():
     assert torch.equal(flat[off:], before[off:])                       # nothing written past the last job
     for (_, db), ref in zip(bjobs, brefs):
         assert ((db - ref).abs().max() / ref.abs().max()).item() < 2e-5
+
+
+_FEW_ROW_SNIPPET = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from ralf_amd import ops
+g = torch.Generator().manual_seed(7)
+out = {}
+for (M, N, K, act, res) in [(256, 256, 256, None, True), (256, 1024, 256, "gelu", False), (256, 256, 1024, None, True), (33, 518, 256, None, False), (500, 192, 64, "relu", False)]:
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    r = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda() if res else None
+    out[f"{M}x{N}x{K}"] = ops.gemm(A, W, M, N, K, bias=b, act=act, res=r).cpu()
+torch.save(out, sys.argv[2])
+"""
+
+
+def test_few_row_kernel_is_bit_identical_to_the_tiled_kernel(tmp_path):
+    """gemm_skinny_kernel (bf16 NT products with M <= 512: the decode step's linear layers) runs the tiled kernel's MFMA chain in the same
+    order: the two builds of the same product agree bit for bit (RALF_GEMM_SKINNY_ROWS=0 switches the few-row path off in a child process)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for rows in ("512", "0"):
+        f = str(tmp_path / f"o{rows}.pt")
+        env = dict(os.environ, RALF_GEMM_SKINNY_ROWS=rows)
+        subprocess.run([sys.executable, "-c", _FEW_ROW_SNIPPET, root, f], check=True, env=env, timeout=600)
+        outs.append(torch.load(f))
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
