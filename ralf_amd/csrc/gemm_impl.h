@@ -71,6 +71,8 @@ __device__ unsigned long long ralf_probe_buf[8 * 65536];
 #define RALF_PROBE(i)
 #endif
 
+// (experiment switch, off: persistent workgroups measured -4...+6 % in round 1; NOT maintained since the gather loaders keep per-tile state in
+//  registers -- a build with it on runs the train step at 89 ms)
 #ifndef RALF_GEMM_PERSISTENT
 #define RALF_GEMM_PERSISTENT 0
 #endif
