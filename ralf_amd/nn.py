@@ -401,17 +401,25 @@ class Bottleneck(nn.Module):
         idn = cb(self.downsample[0], self.downsample[1], x, False) if self.downsample is not None else x
         return cb(self.conv3, self.bn3, y, True, idn)
 
-    def forward(self, x, rt: Runtime):
+    def forward(self, x, rt: Runtime, want_alias: bool = False):
+        """want_alias (blocks with a downsample branch): also return an alias of x for ONE more consumer outside the block (the FPN lateral
+        of layer3's output): its gradient is summed in the downsample convolution's data-gradient epilogue, that sum in conv1's -- the block
+        input's gradient leaves conv1 complete (no autograd add kernel, and its BatchNorm backward takes the fused reductions)"""
         # training: every BatchNorm's batch statistics are produced by the preceding convolution's epilogue
         y, idn, st = self.conv1(x, rt, fork=True, stats=True)   # idn aliases x: its gradient is summed inside conv1's data-gradient GEMM
         y = self.bn1(y, rt, True, stats=st)
         y, st = self.conv2(y, rt, stats=True)
         y = self.bn2(y, rt, True, stats=st)
         y, st3 = self.conv3(y, rt, stats=True)
+        alias = None
         if self.downsample is not None:
-            idn, st = self.downsample[0](idn, rt, stats=True)
+            if want_alias:
+                idn, alias, st = self.downsample[0](idn, rt, fork=True, stats=True)
+            else:
+                idn, st = self.downsample[0](idn, rt, stats=True)
             idn = self.downsample[1](idn, rt, False, stats=st)
-        return self.bn3(y, rt, True, res=idn, stats=st3)
+        out = self.bn3(y, rt, True, res=idn, stats=st3)
+        return (out, alias) if want_alias else out
 
 
 RESNET50_STAGES = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))
@@ -483,14 +491,21 @@ class ResnetBackbone(nn.Module):
             x, st = b.conv1(x, rt, stats=True)
             x = b.bn1(x, rt, True, stats=st)
         x = RF.MaxPoolFn.apply(x)
-        feats = {}
+        feats, lat3 = {}, None
         for li in (1, 2, 3, 4):
-            for blk in getattr(b, f"layer{li}"):
-                x = blk.forward_infer(x, rt) if infer else blk(x, rt)
+            for bi, blk in enumerate(getattr(b, f"layer{li}")):
+                if infer:
+                    x = blk.forward_infer(x, rt)
+                elif li == 4 and bi == 0 and torch.is_grad_enabled():
+                    # layer3's output has two consumers (layer4 and the FPN lateral): the lateral reads an alias handed out by layer4's first
+                    # block, so both gradients meet inside that block's data-gradient epilogues instead of in an autograd add kernel
+                    x, lat3 = blk(x, rt, want_alias=True)
+                else:
+                    x = blk(x, rt)
             if li == 2:   # data parallel: stem + layer1-2 hold 6 % of the parameters and most of the backbone's backward time
                 x = rt.grad_cut(x)
             feats[li] = x
-        return self.fpn(feats[3], feats[4], rt)
+        return self.fpn(lat3 if lat3 is not None else feats[3], feats[4], rt)
 
     def fpn(self, layer3: torch.Tensor, layer4: torch.Tensor, rt: Runtime) -> torch.Tensor:
         """FPN fuse + projection (common/image.py:99-111) on NHWC maps -> [B, h*w, d] with the 2-D sine table added."""
