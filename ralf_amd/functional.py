@@ -46,8 +46,8 @@ class Runtime:
         # launches (ops.wgrad_grouped: every output tile walks its whole reduction, no split-K slabs, no reduce kernels; one
         # column-sum launch for all bias gradients) whenever `group_tiles` output tiles are pending
         self.group_wgrads = False
-        self.group_tiles = int(os.environ.get("RALF_WGRAD_GROUP_TILES", "160"))
-        self.group_target_wgs = int(os.environ.get("RALF_WGRAD_GROUP_WGS", "1024"))
+        self.group_tiles = int(os.environ.get("RALF_WGRAD_GROUP_TILES", "100"))
+        self.group_target_wgs = int(os.environ.get("RALF_WGRAD_GROUP_WGS", "2048"))
         self._wjobs: list = []
         self._bjobs: list = []
         self._wtiles = 0
@@ -369,7 +369,7 @@ def _2d(x):
     return x.reshape(-1, x.shape[-1])
 
 
-_WGRAD_WG = int(os.environ.get("RALF_WGRAD_WG", "512"))   # tuning knob (measured on MI355X: 512 best once the slab reduce keeps 8 loads in flight)
+_WGRAD_WG = int(os.environ.get("RALF_WGRAD_WG", "256"))   # tuning knob (re-measured after the lean gather loaders: 256 | 512 | 1024 = 15.89 | 15.97 | 16.07 ms per step)
 
 
 def _splitk_for(out_rows: int, out_cols: int, red: int) -> int:
