@@ -1179,7 +1179,8 @@ int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
     const int64_t big = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) * d.splitk * nbatch;
     const int kspan = ceil_div(d.K, d.splitk);
     const bool shape_ok = ok22 && d.M >= 128 && (d.N % 128 == 0 || d.N >= 512);
-    if (shape_ok && ((d.splitk == 1 && big >= 192) || (kspan >= 1024 && big >= 512))) return launch_epi<T, AK, BKC, GATHER, 2, 2, 8>(P, nbatch, st);
+    static const int big1 = [] { const char* e = getenv("RALF_GEMM_BIG"); return e ? atoi(e) : 192; }();   // tuning aid (tools/knob_sweep.sh)
+    if (shape_ok && ((d.splitk == 1 && big >= big1) || (kspan >= 1024 && big >= 512))) return launch_epi<T, AK, BKC, GATHER, 2, 2, 8>(P, nbatch, st);
     return launch_epi<T, AK, BKC, GATHER, 1, 1, 4>(P, nbatch, st);
 }
 
