@@ -33,6 +33,8 @@ class Runtime:
         self.overlap = False      # engine mode: weight / bias gradient kernels run on a side stream, off the data-gradient chain
         self._side: list = []
         self.n_side = int(os.environ.get("RALF_SIDE_STREAMS", "1"))
+        self.side_policy = os.environ.get("RALF_SIDE_POLICY", "rr")
+        self._side_rr = 0
         self._keep: list = []     # operands of side-stream work in flight (kept alive until join_side)
         self.cut_enabled = False  # engine mode (data parallel): split the backward at grad_cut() points
         self._cuts: list = []     # (tensor of the early graph, detached leaf the late graph continued from)
@@ -78,6 +80,7 @@ class Runtime:
     def begin_step(self):
         """start of a forward: restart the stream-id counter (the device seed distinguishes steps)."""
         self._call = 0
+        self._side_rr = 0
         self._main_stream = torch.cuda.current_stream() if torch.cuda.is_available() else None
         if self.branches and self._main_stream is not None:
             # branches depend on the step's inputs only: they wait for THIS point of the main stream, not for whatever the main
@@ -129,7 +132,11 @@ class Runtime:
             return fn()
         if not self._side:
             self._side = [ops.own_stream(("side", i)) for i in range(self.n_side)]
-        st = self._side[(target.data_ptr() >> 8) % len(self._side)]   # one gradient region -> always the same stream
+        if self.side_policy == "rr":   # call order: the same assignment in every run (each gradient region is written once per step)
+            st = self._side[self._side_rr % len(self._side)]
+            self._side_rr += 1
+        else:
+            st = self._side[(target.data_ptr() >> 8) % len(self._side)]   # one gradient region -> always the same stream
         st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):
             fn()
