@@ -225,9 +225,9 @@ class Runtime:
         if not (wj or bj):
             return
         # reduction splits: one workgroup sustains ~1 TFLOP/s on a 128x128 tile (measured), so a launch wants ~1000 workgroups;
-        # every split walks at least 2048 rows (slab traffic), tiny reductions stay whole
+        # every split walks at least 4096 rows (slab traffic; 2048: +0.05 ms per step), tiny reductions stay whole
         want = max(1, self.group_target_wgs // max(self._wtiles, 1))
-        wj = [(dy, x, dw, max(1, min(want, dy.shape[0] // 2048))) for dy, x, dw, _ in wj]
+        wj = [(dy, x, dw, max(1, min(want, dy.shape[0] // _GROUP_MIN_ROWS))) for dy, x, dw, _ in wj]
         self._wjobs, self._bjobs, self._wtiles = [], [], 0
 
         def run():
@@ -376,13 +376,15 @@ def _2d(x):
     return x.reshape(-1, x.shape[-1])
 
 
+_WGRAD_MIN_ROWS = int(os.environ.get("RALF_WGRAD_MIN_ROWS", "1024"))
+_GROUP_MIN_ROWS = int(os.environ.get("RALF_GROUP_MIN_ROWS", "4096"))
 _WGRAD_WG = int(os.environ.get("RALF_WGRAD_WG", "256"))   # tuning knob (re-measured after the lean gather loaders: 256 | 512 | 1024 = 15.89 | 15.97 | 16.07 ms per step)
 
 
 def _splitk_for(out_rows: int, out_cols: int, red: int) -> int:
     tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
     want = max(1, _WGRAD_WG // tiles)      # workgroups in flight; more splits only add slab traffic
-    return max(1, min(want, red // 1024))  # each split reduces >= 1024 rows
+    return max(1, min(want, red // _WGRAD_MIN_ROWS))  # each split reduces >= 1024 rows
 
 
 def wgrad(dy2d, x2d, N, K, rows, into=None, rt=None):
