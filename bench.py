@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 # algorithmic FLOPs per sample of one train step (2 x MAC; 3 x trainable forward + frozen forward)
 STEP_GFLOP_PER_SAMPLE = {10: 50.1, 32: 56.4}
 ENCDEC_GFLOP_PER_SAMPLE = {10: 15.98, 32: 22.29}   # everything except ResNet-50 + FPN
+REAL_CANVAS_STEP_GFLOP_PER_SAMPLE = 64.0            # 350x240 canvases: hw = 22 x 15 = 330, M = 680 (common/image.py:88)
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
@@ -44,6 +45,21 @@ def measured_traffic(key):
             return 2.0 * e["fetch_size_bytes"] + e["write_size_bytes"], e
     return None, None
 
+
+
+def measured_mfma_busy(key):
+    """MFMA-busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles) of a workload from the NEWEST committed profiles/r*_mfma_busy.json
+    (tools/pmc_mfma.py on a `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE` pass) -> (fraction, file) or (None, None)"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_busy.json")), reverse=True):
+        try:
+            with open(path) as f:
+                e = json.load(f).get(key)
+        except (OSError, ValueError):
+            continue
+        if e:
+            return e["mfma_busy"], os.path.relpath(path, ROOT)
+    return None, None
 
 
 def build_model(device, N=10, dtype="bfloat16", task="uncond"):
@@ -71,7 +87,8 @@ class _BackboneStandIn(torch.nn.Module):
         return self.seq
 
 
-def bench_encdec(device, N, B, dtype, steps, use_graph=True):
+def bench_encdec(device, N, B, dtype, steps, use_graph=True, overlap=True, pause_s=0.0):
+    """pause_s: idle gap between set-up (eager warm-up, capture) and the timed replays -- tools/prof_summary.py cuts a trace there"""
     from ralf_amd.engine import TrainStep
     from ralf_amd.synthetic import make_batch, to_device
 
@@ -80,11 +97,16 @@ def bench_encdec(device, N, B, dtype, steps, use_graph=True):
     inputs, targets = model.preprocess(make_batch(B, N, seed=1))
     inputs, targets = to_device(inputs, device), to_device(targets, device)
     inputs["retrieved"] = {k: v for k, v in inputs["retrieved"].items() if k != "image"}
-    step = TrainStep(model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, use_graph=use_graph)
+    step = TrainStep(model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, use_graph=use_graph, overlap_wgrad=overlap)
+    if not overlap:
+        model.rt.branches = False     # one stream: no parallel graph branches either
     step(inputs, targets)
     if use_graph:   # like the main timing: the batch lives in the buffers the captured graphs read
         inputs, targets = step.static_batch()
-    t = _time_gpu(lambda: step(inputs, targets), iters=steps, warm=3)
+    if pause_s:
+        torch.cuda.synchronize()
+        time.sleep(pause_s)
+    t = _time_gpu(lambda: step(inputs, targets), iters=steps, warm=0 if pause_s else 3)
     del step, model
     return t
 
@@ -113,7 +135,7 @@ def bench_knn(device):
     X = torch.randn(N, D, device=device, generator=g)
     X /= X.norm(dim=1, keepdim=True)
     out = {}
-    for nq in (1024, 16, 1):
+    for nq in (1024, 32, 16, 1):
         Q = torch.randn(nq, D, device=device, generator=g)
         Q /= Q.norm(dim=1, keepdim=True)
         ws = torch.empty(_lib.lib().ralf_knn_topk_ip_workspace_bytes(N, D, nq, k), dtype=torch.uint8, device=device)
@@ -176,7 +198,87 @@ def bench_decode(device, N=10, B=256, dtype="bfloat16", reps=3):
     return out
 
 
-def cpu_baseline_train(N=10, B=4, steps=2):
+def bench_step_variant(device, N, B, dtype, steps, H=256, W=256):
+    """the same train step (whole model, graph replay, clip + AdamW) at another size of BASELINE / SURVEY 8d: N = 32 elements
+    (S = 160, the north star's "<= 32-element layouts") or the real 350x240 canvases (hw = 330)"""
+    from ralf_amd.engine import TrainStep
+    from ralf_amd.synthetic import make_batch, to_device
+
+    model = build_model(device, N, dtype)
+    inputs, targets = model.preprocess(make_batch(B, N, H=H, W=W, seed=1))
+    inputs, targets = to_device(inputs, device), to_device(targets, device)
+    inputs["retrieved"] = {k: v for k, v in inputs["retrieved"].items() if k != "image"}
+    step = TrainStep(model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, use_graph=True)
+    step(inputs, targets)
+    inputs, targets = step.static_batch()
+    t = _time_gpu(lambda: step(inputs, targets), iters=steps, warm=3)
+    del step, model
+    return t
+
+
+def bench_relation(device, N=10, B=256, dtype="bfloat16"):
+    """BASELINE configs[4], relationship task at batch 256: sample(cond_type="relation") with back-tracking
+    (retrieval_augmented_autoreg.py:336-507: a per-sample loop by construction -- a violated constraint rewinds THAT sample's
+    prefix, and the draws come from one global `random` stream in sample order), the decoder step KV-cached on the device and
+    replayed from per-position hipGraphs.  Synthetic relation table built with the reference's own rules from the batch."""
+    import random
+
+    from ralf_amd.helpers.layout_tokenizer import LabelFeature, LayoutSequenceTokenizer
+    from ralf_amd.helpers.relationships import relationship_table
+    from ralf_amd.helpers.task import get_condition
+    from ralf_amd.models.generator import ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg as RALF
+    from ralf_amd.synthetic import make_batch
+
+    labels = ["text", "logo", "underlay"]
+    batch = make_batch(B, N, seed=13)
+    random.seed(3)
+    table = relationship_table({k: v for k, v in batch.items() if k != "retrieved"}, labels)
+    tok = LayoutSequenceTokenizer(labels, N)
+    torch.manual_seed(0)
+    model = RALF(features={"label": LabelFeature(labels)}, tokenizer=tok, dataset_name="pku", max_seq_length=N, db_dataset=None, top_k=16,
+                 retrieval_backbone="dreamsim", random_retrieval=False, saliency_k="None", auxilary_task="relation", compute_dtype=dtype,
+                 relation_table=table).to(device).eval()
+    cond, _ = get_condition(batch, "relation", tok)
+    cond.retrieved = {k: v for k, v in cond.retrieved.items() if k != "image"}
+    cfg = {"name": "deterministic", "temperature": 1.0}
+
+    def sub(c, n):
+        import copy
+        c2 = copy.copy(c)
+        c2.image, c2.seq = c.image[:n], c.seq[:n].clone()
+        c2.mask = c.mask[:n] if torch.is_tensor(getattr(c, "mask", None)) else getattr(c, "mask", None)
+        c2.retrieved = {k: v[:n] for k, v in c.retrieved.items()}
+        if hasattr(c, "id"):
+            c2.id = c.id[:n]
+        return c2
+    model.sample(cond=sub(cond, 4), sampling_cfg=cfg, cond_type="relation", return_violation=True, use_backtrack=True)   # warm-up (graphs per position)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res, vio = model.sample(cond=cond, sampling_cfg=cfg, cond_type="relation", return_violation=True, use_backtrack=True)
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    assert res["label"].shape == (B, N)
+    return {"batch": B, "ms_per_batch": t * 1e3, "ms_per_sample": t * 1e3 / B, "relations_checked": int(vio["total"]), "relations_violated": int(vio["viorated"]),
+            "note": "sample_relation with back-tracking, deterministic draw, RELATION_SIZE 10; one decoder step per generated / re-generated token and sample "
+                    "(device, graph replay) + the constraint masks of layoutformerpp/relation_restriction.py on the host"}
+
+
+def committed_kernel_avg_us(pattern, suffix="_knn_kernel_stats.txt"):
+    """(avg_us, min_us, file) of the first kernel row matching `pattern` in the NEWEST committed rocprofv3 summary profiles/r*<suffix>"""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*" + suffix)), reverse=True):
+        try:
+            for line in open(path):
+                if re.search(pattern, line):
+                    f = line.split()
+                    return float(f[-4]), float(f[-3]), os.path.relpath(path, ROOT)
+        except (OSError, ValueError, IndexError):
+            continue
+    return None, None, None
+
+
+def cpu_baseline_train(N=10, B=4, steps=5, warm=2):
     """oracle (CPU restatement, fp32) train steps on the host cores, bounded samples of B = 4 at 256x256: the RALF model (the
     `value` workload at 1/16 of its batch) and the Autoreg baseline without retrieval (BASELINE configs[0], its own batch)."""
     from oracle import ralf_oracle as O
@@ -205,7 +307,7 @@ def cpu_baseline_train(N=10, B=4, steps=2):
         params = [v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not k.startswith("layout_encoer.") and "running_" not in k and not k.endswith(".pe")]
         opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4)
         times = []
-        for i in range(nsteps + 1):
+        for i in range(nsteps + warm):
             t0 = time.perf_counter()
             opt.zero_grad(set_to_none=True)
             logits = forward(sd, inputs, training_bn=True, p_drop=0.1)
@@ -214,15 +316,16 @@ def cpu_baseline_train(N=10, B=4, steps=2):
             torch.nn.utils.clip_grad_norm_(params, 0.1)
             opt.step()
             times.append(time.perf_counter() - t0)
-        return sum(times[1:]) / nsteps
+        return sorted(times[warm:])[nsteps // 2]     # median of the timed steps
 
     t = run("ralf_state_shapes.json", O.ralf_forward, steps)
-    ta = run("autoreg_state_shapes.json", O.autoreg_forward, 1)
+    ta = run("autoreg_state_shapes.json", O.autoreg_forward, steps)
     return {"value": B * (5 * N + 1) / t, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/ralf_oracle.py RALF train step (fp32, dropout 0.1, batch-stat BN, clip 0.1, AdamW), B={B} (1/16 of the GPU batch), 256x256, N={N}, "
-                      f"{steps} steps after 1 warm-up; {t:.2f} s/step",
+            "sample": f"oracle/ralf_oracle.py RALF train step (fp32, dropout 0.1, batch-stat BN, clip 0.1, AdamW, anomaly detection off), "
+                      f"BOUND: B={B} = 1/16 of the GPU batch (a B=64 step on these cores takes ~16x as long: bench.py --cpu-batch 64 times it), 256x256, N={N}, "
+                      f"median of {steps} steps after {warm} warm-ups; {t:.2f} s/step",
             "autoreg_baseline": {"value": B * (5 * N + 1) / ta, "unit": "tokens/s",
-                                 "sample": f"BASELINE configs[0]: Autoreg baseline (no retrieval), uncond, B={B}, same oracle, 1 step after 1 warm-up; {ta:.2f} s/step"}}
+                                 "sample": f"BASELINE configs[0]: Autoreg baseline (no retrieval), uncond, B={B} (its own batch), same oracle, median of {steps} steps after {warm} warm-ups; {ta:.2f} s/step"}}
 
 
 def cpu_baseline_knn(budget_s=12.0):
@@ -241,8 +344,16 @@ def cpu_baseline_knn(budget_s=12.0):
         knn_oracle.topk_ip(X, Q, 16)
         done += 256
     t = time.perf_counter() - t0
+    # the reference's own regime: ONE query per call (models/retrieval/retriever.py:193-202 loops over the items of a split)
+    n1, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < budget_s / 3:
+        knn_oracle.topk_ip(X, Q[n1 % 256:n1 % 256 + 1], 17)
+        n1 += 1
+    t1 = time.perf_counter() - t1
     return {"qps": done / t, "cores": knn_oracle.threads(), "kind": "port",
-            "sample": f"oracle/knn_oracle.c (OpenMP), 61548x1792 fp32 index, k=16, {done} queries in batches of 256, {t:.1f} s"}
+            "sample": f"oracle/knn_oracle.c (OpenMP), 61548x1792 fp32 index, k=16, {done} queries in batches of 256, {t:.1f} s",
+            "nq1_per_call": {"qps": n1 / t1, "ms_per_call": t1 * 1e3 / n1,
+                             "sample": f"one query per call (the reference's regime, retriever.py:193-202), k=17, {n1} calls, {t1:.1f} s"}}
 
 
 def self_launch(n, argv):
@@ -261,6 +372,10 @@ def self_launch(n, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's intra-node transport on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    # ROCclr's default, pinned: the graph branches of the step alias onto this many hardware queues, and which branch shares a queue with
+    # which decides whether a graph edge is an in-queue order or a cross-queue signal (8 queues ran the three-graph data-parallel
+    # step at 35.6 ms instead of 16.2) -- a box with another default must not change the measurement
+    env.setdefault("GPU_MAX_HW_QUEUES", "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     return subprocess.call(cmd, env=env)
@@ -281,8 +396,11 @@ def main():
     ap.add_argument("--skip-decode", action="store_true", help="skip the B = 256 constrained-decode block")
     ap.add_argument("--no-overlap", action="store_true", help="parameter-gradient kernels on the main stream (no parallel graph branch)")
     ap.add_argument("--dp-selftest", action="store_true", help="single GPU: run the data-parallel code path (1-rank RCCL group, staged backward, overlapped exchange)")
+    ap.add_argument("--skip-variants", action="store_true", help="skip the N = 32 / 350x240 train-step blocks and the relation-decode block")
+    ap.add_argument("--cpu-batch", type=int, default=4, help="batch of the CPU baseline's RALF leg (64 = the GPU batch: minutes)")
     a = ap.parse_args()
 
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")   # (see self_launch; read by the HIP runtime when the device is first touched)
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if a.gpus > 1 and "RANK" not in os.environ:
         # not under a launcher: spawn one rank per GPU ourselves, like the reference does (image2layout/train/train.py:52-61,
@@ -365,7 +483,10 @@ def main():
             step.exchange.run([(0, nG)])
         x1.record()
         torch.cuda.synchronize()
-        dp_info = {"rccl_ranks": world, "wire": step.exchange.wire, "bytes_on_wire_per_step": step.exchange.bytes_on_wire([(0, nG)]),
+        group_ranks = torch.distributed.get_world_size()
+        assert group_ranks == a.gpus and (one_device or torch.distributed.get_backend() == "nccl"), "the exchange must run on an RCCL group of --gpus ranks"
+        dp_info = {"rccl_ranks": group_ranks, "backend": torch.distributed.get_backend(), "wire": step.exchange.wire, "exchange": step.exchange.mode,
+                   "bytes_on_wire_per_step": step.exchange.bytes_on_wire([(0, nG)]),
                    "allreduce_ms_standalone": x0.elapsed_time(x1) / 5, "staged_backward": bool(step.staged),
                    "bytes_exchanged_during_stage2": step.exchange.bytes_on_wire(step._early) if step.staged else 0}
     tokens = B * (5 * N + 1)
@@ -389,6 +510,10 @@ def main():
         }
         if dp_info is not None:
             out["config"]["data_parallel"] = dp_info
+        mb, mf = measured_mfma_busy("train_step_B64_N10_bf16") if (B == 64 and N == 10 and a.dtype.startswith("b")) else (None, None)
+        if mb is not None:
+            out["roofline"]["mfma_busy"] = mb
+            out["roofline"]["note"] += f"; mfma_busy = {mb:.3f} of the SIMD-cycles (PMC SQ_VALU_MFMA_BUSY_CYCLES, {mf})"
         tb, te = measured_traffic("train_step_B64_N10_bf16") if (B == 64 and N == 10 and a.dtype.startswith("b")) else (None, None)
         if tb:   # the same step seen from the memory side (measured PMC bytes / measured time)
             out["roofline"]["traffic"] = tb
@@ -402,8 +527,9 @@ def main():
             f_ed = ENCDEC_GFLOP_PER_SAMPLE.get(N, 15.98) * 1e9 * B
             f_bb = flops - f_ed
             t_bb = max(gpu_ms * 1e-3 - t_ed, 1e-9)
+            mbe, _ = measured_mfma_busy("encoder_decoder_B64_N10_bf16")
             out["roofline_split"] = {
-                "encoder_decoder": {"ms": t_ed * 1e3, "TFLOP": f_ed / 1e12, "achieved": f_ed / t_ed / 1e12, "frac": f_ed / t_ed / 1e12 / PEAK_BF16_TFLOPS},
+                "encoder_decoder": {"ms": t_ed * 1e3, "TFLOP": f_ed / 1e12, "achieved": f_ed / t_ed / 1e12, "frac": f_ed / t_ed / 1e12 / PEAK_BF16_TFLOPS, "mfma_busy": mbe},
                 "resnet50_fpn": {"ms": t_bb * 1e3, "TFLOP": f_bb / 1e12, "achieved": f_bb / t_bb / 1e12, "frac": f_bb / t_bb / 1e12 / PEAK_BF16_TFLOPS},
                 "unit": "TFLOP/s", "peak": PEAK_BF16_TFLOPS,
                 "note": "encoder_decoder = the same train step with the backbone replaced by a fixed feature sequence (its own graph, clip and AdamW included); resnet50_fpn = whole step minus that"}
@@ -411,14 +537,30 @@ def main():
             out["knn"] = bench_knn(device)
             k16 = out["knn"]["nq16"]
             kb, ke = measured_traffic("knn_scores_nq16_61548x1792")
+            pa, pm, pf = committed_kernel_avg_us(r"knn_scores_kernel<16, *1, *2")
+            by16 = 61548 * 1792 * 4 + 16 * 1792 * 4 + 16 * 16 * 12
             out["roofline_knn"] = {"bound": "hbm", "achieved": k16["scan_GBps"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": k16["scan_hbm_frac"], "traffic": kb,
+                                   "hip_event_us": k16["scan_us"], "rocprof_avg_us": pa, "rocprof_min_us": pm, "rocprof_file": pf,
+                                   "frac_at_rocprof_avg": (by16 / (pa * 1e-6) / 1e9 / PEAK_HBM_GBS) if pa else None,
+                                   "whole_call_frac": {f"nq{q}": out["knn"][f"nq{q}"]["hbm_frac"] for q in (1, 16, 32)},
                                    "note": "dominant kernel knn_scores_kernel<16,1,2> at nq=16 (HBM-bound regime): 441.2 MB algorithmic bytes per launch (index 61548x1792 fp32 streamed once) / "
                                            f"{k16['scan_us']:.1f} us (HIP events); whole call incl. select+merge {k16['us_per_call']:.1f} us = {k16['hbm_frac']:.3f} of peak; "
                                            "nq=1024 is fp32-FLOP-bound (see knn.nq1024); traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, " + (ke["file"] if ke else "no committed profile")}
         if world == 1 and not a.skip_decode:
             out["decode"] = bench_decode(device, N)
+        if world == 1 and not a.skip_variants and B == 64 and N == 10:
+            # the other sizes SURVEY 8d names: the north star's 32-element layouts and the real 350x240 canvases, same step, same B
+            t32 = bench_step_variant(device, 32, B, a.dtype, min(a.steps, 10))
+            f32 = STEP_GFLOP_PER_SAMPLE[32] * 1e9 * B
+            out["n32"] = {"workload": f"N=32 elements (S=160, M=2*256+16+Lc), batch {B}, 256x256", "ms_per_step": t32 * 1e3, "tokens_per_s": B * 161 / t32,
+                          "TFLOP": f32 / 1e12, "achieved": f32 / t32 / 1e12, "frac": f32 / t32 / 1e12 / PEAK_BF16_TFLOPS, "unit": "TFLOP/s"}
+            trc = bench_step_variant(device, N, B, a.dtype, min(a.steps, 10), H=350, W=240)
+            frc = REAL_CANVAS_STEP_GFLOP_PER_SAMPLE * 1e9 * B
+            out["real_canvas_350x240"] = {"workload": f"350x240 canvases (hw = 22x15 = 330, M = 680), N={N}, batch {B}", "ms_per_step": trc * 1e3, "tokens_per_s": tokens / trc,
+                                          "TFLOP": frc / 1e12, "achieved": frc / trc / 1e12, "frac": frc / trc / 1e12 / PEAK_BF16_TFLOPS, "unit": "TFLOP/s"}
+            out["relation"] = bench_relation(device, N)
         if world == 1 and not a.skip_cpu:
-            out["cpu_baseline"] = cpu_baseline_train(N)
+            out["cpu_baseline"] = cpu_baseline_train(N, B=a.cpu_batch)
             out["cpu_baseline_knn"] = cpu_baseline_knn()
     else:
         out = None

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 12
+#define RALF_ABI_VERSION 13
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -140,27 +140,6 @@ typedef struct RalfGemmDesc {
 } RalfGemmDesc;
 size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d);
 int ralf_gemm(const RalfGemmDesc* d, void* workspace, size_t workspace_bytes, void* stream);
-
-/* Row-strip linear layer (ralf_amd/csrc/rowstrip.hip): y = epi(LN?(x) @ W^T) for W = nn.Linear.weight [N, K] (w_kcontig = 1) or
- * y = epi(x @ W) for W [K, N] (w_kcontig = 0: the data gradient of that layer), bf16 operands, fp32 accumulate.  One workgroup
- * owns 64 rows for the whole product (x read once, weights streamed), see the file header.
- *   ln_gamma / ln_beta (fp32 [K], K = 256, forward only): LayerNorm(x) (eps ln_eps) is applied to the strip first; xln (bf16 [M, K]),
- *     ln_mean / ln_rstd (fp32 [M]) receive the normalised rows and the statistics when given (the backward pass needs them)
- *   epilogue order: +bias[n] (fp32), y2 = v (bf16 pre-activation copy), act, dropout(drop_p, seed, call_id; mask = ralf_dropout's on
- *     the contiguous [M, N] output), aux mask (v = aux > 0 ? v * aux_scale : 0), +res, store bf16 (or fp32 when out_f32)
- * K % 64 == 0, N % 8 == 0, leading dimensions % 8 == 0, 16-byte aligned pointers. */
-typedef struct RalfRsDesc {
-    const void* x; const void* w; void* y; void* y2;
-    const float* bias; const void* res; const void* aux;
-    void* xln; const float* ln_gamma; const float* ln_beta; float* ln_mean; float* ln_rstd;
-    const int64_t* seed;
-    int64_t ldx, ldw, ldy, ldr;
-    uint64_t call_id;
-    int M, N, K, w_kcontig, act, out_f32;
-    float drop_p, aux_scale, ln_eps;
-    int pad;
-} RalfRsDesc;
-int ralf_rs_gemm(const RalfRsDesc* d, void* stream);
 
 /* Weight gradients of MANY linear layers in one launch (the `dW += dy^T x` products autograd issues one by one for nn.Linear /
  * nn.MultiheadAttention in_proj / out_proj, e.g. 24 per encoder stack): job j adds dy_j^T x_j into the fp32 matrix dw_j.
@@ -337,6 +316,9 @@ typedef struct RalfDecodeAttnDesc {
     float scale, eps;
 } RalfDecodeAttnDesc;
 int ralf_decode_attn(const RalfDecodeAttnDesc* d, void* stream);
+/* most keys (cached rows, + the new one when self_) ralf_decode_attn accepts: its scores live in LDS.  Callers with longer memories
+ * (2*h*w + K + Lc rows: e.g. 512x512 canvases) use ralf_layernorm_fwd + ralf_gemm + ralf_attention_fwd instead. */
+int ralf_decode_attn_max_keys(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer (ralf_amd/csrc/optim.hip): clip_grad_norm_ + AdamW on flat fp32 buffers

@@ -54,13 +54,6 @@ class RalfGemmDesc(ctypes.Structure):
     )
 
 
-class RalfRsDesc(ctypes.Structure):
-    _fields_ = ([(n, vp) for n in ("x", "w", "y", "y2", "bias", "res", "aux", "xln", "ln_gamma", "ln_beta", "ln_mean", "ln_rstd", "seed")]
-                + [(n, i64) for n in ("ldx", "ldw", "ldy", "ldr")] + [("call_id", ctypes.c_uint64)]
-                + [(n, i32) for n in ("M", "N", "K", "w_kcontig", "act", "out_f32")]
-                + [("drop_p", f32), ("aux_scale", f32), ("ln_eps", f32), ("pad", i32)])
-
-
 class RalfWgradJob(ctypes.Structure):
     _fields_ = [("dy", vp), ("x", vp), ("dw", vp), ("rows", i64), ("ld_dy", i64), ("ld_x", i64), ("ld_dw", i64),
                 ("n_out", i32), ("n_in", i32), ("splitk", i32), ("pad", i32)]
@@ -71,7 +64,6 @@ class RalfColsumJob(ctypes.Structure):
 
 
 SIGNATURES.update({
-    "ralf_rs_gemm": (i32, [ctypes.POINTER(RalfRsDesc), vp]),
     "ralf_wgrad_grouped_workspace_bytes": (sz, [ctypes.POINTER(RalfWgradJob), i32]),
     "ralf_wgrad_grouped": (i32, [ctypes.POINTER(RalfWgradJob), i32, i32, vp, sz, vp]),
     "ralf_colsum_grouped": (i32, [ctypes.POINTER(RalfColsumJob), i32, i32, vp]),
@@ -128,6 +120,7 @@ SIGNATURES.update({
     "ralf_attention_fwd": (i32, [ctypes.POINTER(RalfAttnDesc), vp]),
     "ralf_attention_bwd": (i32, [ctypes.POINTER(RalfAttnDesc), vp]),
     "ralf_decode_attn": (i32, [ctypes.POINTER(RalfDecodeAttnDesc), vp]),
+    "ralf_decode_attn_max_keys": (i32, []),
     "ralf_sumsq": (i32, [vp, i64, vp, vp]),
     "ralf_clip_coef": (i32, [vp, f32, vp, vp, vp]),
     "ralf_sumsq_partials": (i32, [vp, i64, vp, vp]),

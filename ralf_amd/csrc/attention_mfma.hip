@@ -996,6 +996,8 @@ int ralf_attention_bwd_mfma(const RalfAttnDesc& d, hipStream_t st) {
     return ralf::check_launch("attention_bwd_mfma");
 }
 
+extern "C" int ralf_decode_attn_max_keys(void) { return DEC_MAXK; }
+
 extern "C" int ralf_decode_attn(const RalfDecodeAttnDesc* dp, void* stream) {
     RALF_REQUIRE(dp, "decode_attn: null descriptor");
     const RalfDecodeAttnDesc& d = *dp;

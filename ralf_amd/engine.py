@@ -134,22 +134,28 @@ def average_gradients(flat: torch.Tensor, world: int, group=None) -> None:
 
 class GradExchange:
     """Sum of the flat fp32 gradient buffer over the ranks, by element ranges (the staged backward exchanges the buffer in
-    two parts, TrainStep._exchange_around).
+    two parts, TrainStep._exchange_around).  Replaces what DDP's reducer would do behind train/train.py:207-210.
 
-    wire = "fp32": all_reduce of the fp32 ranges in place (172 MB per step for RALF).
-    wire = "bf16": each range is packed to a bf16 staging buffer (ralf_copy2d), all-reduced there and unpacked back into the
-        fp32 buffer: HALF the bytes per xGMI link (the ring is per-link bound, SURVEY 8e: 86 MB instead of 172 MB); the
-        backward was seeded with 1/world, so the wire carries averages-in-the-making of bf16-computed gradients (their own
-        rounding is 2^-9 relative) and clip / AdamW still run on fp32.
-    `pack(src_fp32, dst_bf16)` / `unpack(src_bf16, dst_fp32)` default to the HIP cast kernel; the gloo CPU test passes
+    wire = "fp32" (default): the fp32 ranges themselves are reduced in place (172 MB per step for RALF), like DDP.
+    wire = "bf16" (opt-in): each range is packed to a bf16 staging buffer (ralf_copy2d), reduced there and unpacked back into the
+        fp32 buffer: HALF the bytes per xGMI link (86 MB); the backward was seeded with 1/world, so the wire carries
+        averages-in-the-making of bf16-computed gradients (their own rounding is 2^-9 relative, no error feedback) and clip /
+        AdamW still run on fp32.
+    mode = "allreduce": one all_reduce per range.
+    mode = "rs_ag": reduce_scatter_tensor into this rank's 1/world shard of the range, then all_gather_into_tensor of the shards,
+        both in place -- the two halves of a ring all-reduce as separate collectives, each of which RCCL can spread over the 7
+        point-to-point xGMI links of a rank instead of one ring.  Ranges whose length is not a multiple of the
+        world size fall back to all_reduce.
+    `pack(src_fp32, dst_bf16)` / `unpack(src_bf16, dst_fp32)` default to the HIP cast kernel; the gloo CPU tests pass
     torch copies."""
 
-    def __init__(self, flat: torch.Tensor, world: int, group=None, wire: str = "fp32", pack=None, unpack=None):
-        assert wire in ("fp32", "bf16")
-        self.flat, self.world, self.group, self.wire = flat, world, group, wire
+    def __init__(self, flat: torch.Tensor, world: int, group=None, wire: str = "fp32", pack=None, unpack=None, mode: str = "allreduce"):
+        assert wire in ("fp32", "bf16") and mode in ("allreduce", "rs_ag")
+        self.flat, self.world, self.group, self.wire, self.mode = flat, world, group, wire, mode
         self.stage = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device) if (wire == "bf16" and self.active) else None
         self._pack = pack or ops.cast_into
         self._unpack = unpack or ops.cast_into
+        self.rank = torch.distributed.get_rank(group) if self.active and torch.distributed.is_initialized() else 0
 
     @property
     def active(self) -> bool:
@@ -158,26 +164,39 @@ class GradExchange:
     def bytes_on_wire(self, ranges) -> int:
         return sum(b - a for a, b in ranges) * (2 if self.wire == "bf16" else 4)
 
+    def _shard(self, buf, a, b):
+        n = (b - a) // self.world
+        return buf[a + self.rank * n:a + (self.rank + 1) * n]
+
     def start(self, ranges, async_op: bool):
         """launch the exchange of `ranges`; returns a token for finish()"""
         if not self.active:
             return None
-        ar = torch.distributed.all_reduce
-        if self.wire == "fp32":
-            return [ar(self.flat[a:b], op=torch.distributed.ReduceOp.SUM, group=self.group, async_op=async_op) for a, b in ranges], ranges
+        dist = torch.distributed
+        buf = self.flat if self.wire == "fp32" else self.stage
         works = []
         for a, b in ranges:
-            self._pack(self.flat[a:b], self.stage[a:b])
-            works.append(ar(self.stage[a:b], op=torch.distributed.ReduceOp.SUM, group=self.group, async_op=async_op))
+            if self.wire == "bf16":
+                self._pack(self.flat[a:b], self.stage[a:b])
+            if self.mode == "rs_ag" and (b - a) % self.world == 0 and b > a:
+                works.append((dist.reduce_scatter_tensor(self._shard(buf, a, b), buf[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), a, b))
+            else:
+                works.append((dist.all_reduce(buf[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), None, None))
         return works, ranges
 
     def finish(self, token) -> None:
         if token is None:
             return
         works, ranges = token
-        for w in works:
+        buf = self.flat if self.wire == "fp32" else self.stage
+        gathers = []
+        for w, a, b in works:
             if w is not None:
                 w.wait()
+            if a is not None:   # second half: every rank's reduced shard to everyone (issued once the shard is complete)
+                gathers.append(torch.distributed.all_gather_into_tensor(buf[a:b], self._shard(buf, a, b), group=self.group, async_op=True))
+        for g in gathers:
+            g.wait()
         if self.wire == "bf16":
             for a, b in ranges:
                 self._unpack(self.stage[a:b], self.flat[a:b])
@@ -234,7 +253,7 @@ class TrainStep:
     """One optimisation step of `model` (a ralf_amd generator) = forward + backward + (all-reduce) + clip + AdamW."""
 
     def __init__(self, model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, backbone_lr_scale=0.1, betas=(0.9, 0.999), eps=1e-8,
-                 use_graph=True, process_group=None, overlap_wgrad=True, overlap_allreduce=None, grad_wire=None):
+                 use_graph=True, process_group=None, overlap_wgrad=True, overlap_allreduce=None, grad_wire=None, grad_exchange=None):
         self.model = model
         rt = model.rt.to(model.device)
         groups = model.optim_groups(base_lr=lr, weight_decay=weight_decay, custom_lr={"encoder.extractor.body": lr * backbone_lr_scale})
@@ -246,9 +265,11 @@ class TrainStep:
         self.use_graph = use_graph
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if (process_group is not None or torch.distributed.is_initialized()) else 1
-        # gradient exchange: bf16 on the wire when the step computes in bf16 (half the bytes per xGMI link), fp32 in parity mode
-        wire = grad_wire or ("bf16" if rt.dtype == torch.bfloat16 else "fp32")
-        self.exchange = GradExchange(self.opt.G, self.world, process_group, wire)
+        # gradient exchange: fp32 on the wire, like the reference's DDP averages (train/train.py:207-210).  "bf16" (half the bytes per
+        # xGMI link, no error feedback) changes the training numerics and is OPT-IN: grad_wire="bf16" or RALF_GRAD_WIRE=bf16
+        wire = grad_wire or os.environ.get("RALF_GRAD_WIRE", "fp32")
+        assert wire == "fp32" or rt.dtype == torch.bfloat16, "the bf16 wire belongs to the bf16 throughput mode"
+        self.exchange = GradExchange(self.opt.G, self.world, process_group, wire, mode=grad_exchange or os.environ.get("RALF_GRAD_EXCHANGE", "allreduce"))
         if self.world > 1:
             self._sync_replicas(rt)
         self._static = None

@@ -60,7 +60,6 @@ class Runtime:
         # MASKED gradient of y from its backward kernel, which the backward of f picks up instead of launching ralf_dropout
         self._drop_tags: dict = {}
         self._masked: dict = {}
-        self._fanout: dict = {}
         self.ln_dropout = True
         # z = relu(BN(x) (+ res)) outputs are tagged with what the BatchNorm backward reduces over (x, ReLU mask bits, mean); the convolution
         # that consumes z then masks dz and emits the reductions from its data-gradient epilogue (RalfGemmDesc.bnb_*), and the BatchNorm
@@ -92,7 +91,6 @@ class Runtime:
         self._masked.clear()
         self._bn_tags.clear()
         self._bn_stats.clear()
-        self._fanout.clear()   # (every branch entry first waits for all work issued so far: the previous step's consumers are ordered)
 
     def advance_seed(self):
         self.seed.add_(0x9E3779B1)  # on-device: safe inside a captured graph
@@ -132,21 +130,28 @@ class Runtime:
             return fn()
         if not self._side:
             self._side = [ops.own_stream(("side", i)) for i in range(self.n_side)]
-        if self.side_policy == "rr":   # call order: the same assignment in every run (each gradient region is written once per step)
-            st = self._side[self._side_rr % len(self._side)]
-            self._side_rr += 1
+        if self.side_policy == "rr" and len(self._side) == 1:   # call order: the same assignment in every run
+            st = self._side[0]
         else:
-            st = self._side[(target.data_ptr() >> 8) % len(self._side)]   # one gradient region -> always the same stream
+            # several side streams: one gradient region -> always the same stream, so two non-atomic `accumulate` writes into the
+            # same region (a weight used twice in a step, a deferred and a direct gradient of one W) stay ordered
+            st = self._side[(target.data_ptr() >> 8) % len(self._side)]
         st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):
             fn()
         self._keep.append(operands)
 
-    def mark_fanout(self, x: torch.Tensor):
-        """x is the input of SEVERAL linear layers whose backward products are the only gradients of x: they are summed in the
-        GEMM epilogue (LinearFn.backward) instead of by autograd's add kernels.  Valid for one backward pass."""
-        if torch.is_grad_enabled() and x.requires_grad:
-            self._fanout[x.contiguous().data_ptr()] = [None]
+    def fanout_alias(self, x: torch.Tensor) -> torch.Tensor:
+        """an alias of x to hand to SEVERAL linear layers: their backward products are summed in the GEMM epilogue
+        (LinearFn.backward: the first one's output is the buffer, the others accumulate into it) instead of by autograd's add
+        kernels.  The alias is a node of its own in the autograd graph, so that sum is complete when it reaches x however many
+        OTHER consumers x itself has (their gradients meet the sum in autograd's ordinary accumulation).  Only the linear layers
+        that receive the returned tensor object take part (the mark travels as an attribute of that object)."""
+        if not (torch.is_grad_enabled() and x.requires_grad):
+            return x
+        a = _AliasFn.apply(x)
+        a._ralf_fan = [None]
+        return a
 
     def tag_dropout(self, y: torch.Tensor, p: float, call: int):
         if p > 0.0 and self.ln_dropout:   # (called inside Function.forward, where grad mode is off: no grad-mode test here)
@@ -376,6 +381,18 @@ def _2d(x):
     return x.reshape(-1, x.shape[-1])
 
 
+class _AliasFn(Function):
+    """identity on a view of x (no kernel): Runtime.fanout_alias"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 _WGRAD_MIN_ROWS = int(os.environ.get("RALF_WGRAD_MIN_ROWS", "1024"))
 _GROUP_MIN_ROWS = int(os.environ.get("RALF_GROUP_MIN_ROWS", "4096"))
 _WGRAD_WG = int(os.environ.get("RALF_WGRAD_WG", "256"))   # tuning knob (re-measured after the lean gather loaders: 256 | 512 | 1024 = 15.89 | 15.97 | 16.07 ms per step)
@@ -436,7 +453,7 @@ class LinearFn(Function):
         ctx.save_for_backward(x2, W)
         ctx.bias, ctx.p, ctx.call = b, p, call
         ctx.rt, ctx.has_b, ctx.has_res, ctx.xshape, ctx.rows = rt, b is not None, res is not None, x.shape, (r0, r1)
-        ctx.fan = x2.data_ptr() if x2.data_ptr() in rt._fanout else None
+        ctx.fan = getattr(x, "_ralf_fan", None)   # (Runtime.fanout_alias)
         rt.tag_dropout(y, p, call)
         return y.view(*x.shape[:-1], N)
 
@@ -455,7 +472,7 @@ class LinearFn(Function):
         nrow = dy2.shape[0]
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
-            acc = rt._fanout.get(ctx.fan) if ctx.fan is not None else None
+            acc = ctx.fan
             if acc is not None and acc[0] is not None:
                 # x feeds several linear layers (the memory of the 6 cross-attentions): the first backward to run handed its
                 # product to autograd, the others add theirs into THAT buffer in the GEMM epilogue and return nothing

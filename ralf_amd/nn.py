@@ -203,8 +203,9 @@ class BaseDecoder(nn.Module):
         kpm = _kpm_u8(tgt_key_padding_mask)
         layers = list(self.transformer.layers)
         attns = [l.multihead_attn for l in layers]
-        memory = memory.contiguous()
-        rt.mark_fanout(memory)   # d(memory) = sum of the 6 cross-attention K/V projections' data gradients, summed in their epilogues
+        # d(memory) = sum of the 6 cross-attention K/V projections' data gradients, summed in their epilogues: the projections read an
+        # alias that only they hold, so any other consumer of `memory` is summed by autograd as usual
+        memory = rt.fanout_alias(memory.contiguous())
         plan = RF.CrossKVPlan.make(attns, rt) if torch.is_grad_enabled() else None
         kv_all = None
         if plan is not None:   # all layers' cross-attention K/V projections of the memory in one launch
@@ -250,7 +251,10 @@ def decoder_step(dec: "BaseDecoder", tok: torch.Tensor, pos: int, cache: DecodeC
     x = ops.embed_fwd(tok.view(B, 1).contiguous(), dec.emb.weight.detach(), dec.pos_emb.pe[0, pos:pos + 1].contiguous(), 1, math.sqrt(d), rt.dtype).view(B, d)
     L = cache.max_len
     # bf16, d = 256, 8 heads: LayerNorm + q / k / v projections + attention of each block in ONE launch (ralf_decode_attn)
-    fused = rt.fused_decode and rt.dtype == torch.bfloat16 and d == 256 and H == 8 and x.stride(1) == 1
+    # (the fused kernel keeps the scores of at most ops.decode_attn_max_keys() keys in LDS; longer memories, e.g. 512x512 canvases, take
+    #  the per-kernel path below)
+    fused = (rt.fused_decode and rt.dtype == torch.bfloat16 and d == 256 and H == 8 and x.stride(1) == 1
+             and cache.cross_kv[0].shape[1] <= ops.decode_attn_max_keys() and pos + 1 <= ops.decode_attn_max_keys())
     for li, layer in enumerate(dec.transformer.layers):
         sa, ca = layer.self_attn, layer.multihead_attn
         skv, ckv = cache.self_kv[li], cache.cross_kv[li]

@@ -265,35 +265,6 @@ def copy2d_acc(src, dst, rows, cols, lds, ldd):
     _call("ralf_copy2d", F32, F32, _p(src), _p(dst), rows, cols, lds, ldd, 1)
 
 
-def rs_gemm(x, w, M, N, K, *, w_kcontig=True, out=None, out_dtype=None, bias=None, act=None, res=None, aux=None, aux_scale=1.0, out2=None,
-            drop_p=0.0, seed=None, call_id=0, ln=None, xln=None, ln_stats=None, ldx=None, ldw=None, ldy=None, ldr=None):
-    """row-strip linear layer (ralf_rs_gemm): y = epi(LN?(x) @ w^T) (w [N, K]) or epi(x @ w) (w [K, N], w_kcontig=False); bf16 operands.
-    ln = (gamma, beta) fp32: LayerNorm prologue (K = 256); xln / ln_stats = (mean, rstd) receive the normalised rows / statistics."""
-    from ._abi import RalfRsDesc
-
-    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
-    if out is None:
-        out = torch.empty(M, N, dtype=out_dtype or torch.bfloat16, device=x.device)
-    d = RalfRsDesc()
-    d.x, d.w, d.y, d.y2 = _p(x), _p(w), _p(out), _p(out2)
-    d.bias, d.res, d.aux = _p(bias), _p(res), _p(aux)
-    d.ldx = ldx if ldx is not None else K
-    d.ldw = ldw if ldw is not None else (K if w_kcontig else N)
-    d.ldy = ldy if ldy is not None else N
-    d.ldr = ldr if ldr is not None else N
-    d.M, d.N, d.K, d.w_kcontig, d.act = M, N, K, int(w_kcontig), ACT[act]
-    d.out_f32 = int(out.dtype == torch.float32)
-    d.drop_p, d.seed, d.call_id, d.aux_scale = drop_p, _p(seed), call_id, aux_scale
-    if ln is not None:
-        d.ln_gamma, d.ln_beta, d.ln_eps = _p(ln[0]), _p(ln[1]), 1e-5
-        d.xln = _p(xln)
-        if ln_stats is not None:
-            d.ln_mean, d.ln_rstd = _p(ln_stats[0]), _p(ln_stats[1])
-    rc = _lib.lib().ralf_rs_gemm(ctypes.byref(d), _lib.stream_ptr())
-    _lib.check(rc, "ralf_rs_gemm")
-    return out
-
-
 def wgrad_grouped(jobs):
     """jobs: list of (dy2d bf16 [rows, n_out], x2d bf16 [rows, n_in], dw fp32 view [n_out, n_in], splitk): dw += dy^T x for all jobs
     in one launch (ralf_wgrad_grouped)."""
@@ -517,6 +488,17 @@ def attention_fwd(q, k, v, B, H, Sq, Sk, dh, q_off=0, k_off=0, v_off=0, causal=F
     d.kpm_bs = int(kpm_stride) if kpm_stride else 0   # kpm rows longer than Sk: one [B, max_len] mask for a growing prefix
     _call("ralf_attention_fwd", ctypes.byref(d))
     return o, lse
+
+
+_DEC_MAXK = None
+
+
+def decode_attn_max_keys() -> int:
+    """most keys ralf_decode_attn takes (its scores live in LDS)"""
+    global _DEC_MAXK
+    if _DEC_MAXK is None:
+        _DEC_MAXK = int(_lib.lib().ralf_decode_attn_max_keys())
+    return _DEC_MAXK
 
 
 def decode_attn(x, ln_g, ln_b, W, bias, kv, Sk, H, self_attn, kpm=None, kpm_stride=0, eps=1e-5):

@@ -19,8 +19,15 @@ def _load_fidnet(num_label: int, max_bbox: int, weight_dir: str, device):
     path = os.path.join(weight_dir, "model_best.pth.tar")
     state = torch.load(path, map_location="cpu", weights_only=True)
     state = state.get("state_dict", state)
+    state = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state.items()}   # a DDP-wrapped checkpoint
     own = enc.state_dict()
-    enc.load_state_dict({k: v for k, v in state.items() if k in own}, strict=False)
+    res = enc.load_state_dict({k: v for k, v in state.items() if k in own}, strict=False)
+    # the features ARE the encoder: a checkpoint that fills none / part of it would silently re-rank with random features
+    need = ("emb_label.", "fc_bbox.", "enc_fc_in.", "enc_transformer.")
+    missing = [k for k in res.missing_keys if k.startswith(need)]
+    if missing:
+        raise RuntimeError(f"{path}: FIDNetV3 encoder keys missing from the checkpoint (first: {missing[:4]}, {len(missing)} in all); "
+                           f"checkpoint keys look like {list(state)[:3]}")
     return enc.to(device).eval()
 
 

@@ -34,3 +34,13 @@ def test_traffic_comes_from_the_newest_committed_profile(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     tb2, e2 = bench.measured_traffic("train_step_B64_N10_bf16")
     assert tb2 == 2.5e9 and e2["file"].endswith("r03a_hbm_traffic.json")
+
+
+def test_committed_rocprof_average_reader():
+    """roofline_knn quotes the HIP-event time AND the rocprofv3 average of the same kernel from the newest committed summary"""
+    import bench
+
+    avg, mn, f = bench.committed_kernel_avg_us(r"knn_scores_kernel<16, *1, *2")
+    assert f and f.startswith("profiles/") and f.endswith("_knn_kernel_stats.txt")
+    assert 60.0 < mn <= avg < 120.0          # 441 MB at 3.7 ... 7.3 TB/s
+    assert bench.committed_kernel_avg_us(r"no_such_kernel") == (None, None, None)

@@ -112,12 +112,14 @@ def _worker_exchange(rank, world, port, q):
     local = torch.randn(5000)
     gathered = [torch.empty_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
-    late = [(0, 640), (1920, 2048)]
-    early = complement_ranges(late, local.numel())
     ok = True
-    for wire in ("fp32", "bf16"):
+    # (the second set of ranges has odd lengths: rs_ag falls back to all_reduce for those)
+    for wire, mode, late in (("fp32", "allreduce", [(0, 640), (1920, 2048)]), ("bf16", "allreduce", [(0, 640), (1920, 2048)]),
+                             ("fp32", "rs_ag", [(0, 640), (1920, 2048)]), ("bf16", "rs_ag", [(0, 640), (1920, 2048)]),
+                             ("fp32", "rs_ag", [(0, 641), (1920, 2048)])):
+        early = complement_ranges(late, local.numel())
         flat = local / world                                   # the backward was seeded with 1/world
-        ex = GradExchange(flat, world, None, wire, pack=cp, unpack=cp)
+        ex = GradExchange(flat, world, None, wire, pack=cp, unpack=cp, mode=mode)
         token = ex.start(early, True)                          # TrainStep._exchange_around: early ranges overlap stage 2 ...
         ex.finish(token)
         ex.run(late)                                           # ... the rest afterwards
@@ -129,12 +131,19 @@ def _worker_exchange(rank, world, port, q):
             ok &= torch.allclose(flat, want, atol=0, rtol=2 ** -7)
             ok &= (flat - torch.stack(gathered).mean(0)).abs().max().item() < 2e-2
             ok &= ex.bytes_on_wire(early + late) == 2 * local.numel()
+            # replica identity: both ranks hold the same bits; the clip norm moves by rounding only
+            both = [torch.empty_like(flat) for _ in range(world)]
+            dist.all_gather(both, flat)
+            ok &= torch.equal(both[0], both[1])
+            n_bf16, n_fp32 = flat.double().norm().item(), torch.stack(gathered).mean(0).double().norm().item()
+            ok &= abs(n_bf16 - n_fp32) < 2.0 ** -8 * n_fp32
     q.put((rank, bool(ok), 0.0))
     dist.destroy_process_group()
 
 
 def test_grad_exchange_fp32_and_bf16_wire_world2():
-    """engine.GradExchange over two gloo ranks: ranged start/finish + run tile the buffer; the bf16 wire halves the bytes"""
+    """engine.GradExchange over two gloo ranks: ranged start/finish + run tile the buffer, as all_reduce and as reduce-scatter +
+    all-gather; the (opt-in) bf16 wire halves the bytes"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 35500 + os.getpid() % 2000

@@ -194,3 +194,49 @@ def test_sharded_search_forms_on_the_hip_scan():
     assert torch.equal(i1, i0) and torch.equal(s1, s0)
     s2, i2 = search_index_sharded(index.search, 1000, Q, 16)
     assert torch.equal(i2, i0 + 1000) and torch.equal(s2, s0)
+
+
+def test_summation_order_risk_at_full_size():
+    """faiss-cpu (absent here) sums the D products of a score in an order of its own; the oracle and the HIP scan use the
+    ascending-d fmaf chain.  Any two legal fp32 summation orders of one score differ by at most 2*D*2^-24*|q||x| (each is within
+    D*u*sum|q_i x_i| <= D*u*|q||x| of the exact value, u = 2^-24).  On the BASELINE config-4 workload (61 548 x 1792, nq = 1024,
+    k = 16) this test COUNTS the queries a different order could change -- as a SET (gap between rank k and rank k+1 below the bound)
+    and as an ordered LIST (any adjacent gap inside the top k+1 below the bound) -- and asserts that every other query equals the
+    float64 NumPy ranking exactly (reference call site: models/retrieval/retriever.py:193-213)."""
+    import json
+    import os
+
+    N, D, nq, k = 61548, 1792, 1024, 16
+    X, Q = unit_rows(N, D, 7), unit_rows(nq, D, 8)
+    idx, val = run_hip(X, Q, k + 1)
+    X64 = X.astype(np.float64)
+    bound = 2.0 * D * 2.0 ** -24          # unit rows and queries: |q||x| = 1
+    typical = 2.0 * np.sqrt(D) * 2.0 ** -24   # random-walk size of the same difference (for the report only)
+    set_risk = order_risk = set_typ = order_typ = 0
+    checked_set = checked_order = 0
+    for q0 in range(0, nq, 128):
+        S = Q[q0:q0 + 128].astype(np.float64) @ X64.T                      # exact scores to ~1e-16
+        order = np.lexsort((np.broadcast_to(np.arange(N), S.shape), -S), axis=1)[:, :k + 1]
+        top = np.take_along_axis(S, order, 1)
+        gaps = top[:, :-1] - top[:, 1:]                                    # [128, k] exact adjacent gaps, the last one = rank k vs k+1
+        for r in range(gaps.shape[0]):
+            q = q0 + r
+            s_risky, o_risky = gaps[r, -1] < bound, bool((gaps[r] < bound).any())
+            set_risk += s_risky; order_risk += o_risky
+            set_typ += gaps[r, -1] < typical; order_typ += bool((gaps[r] < typical).any())
+            if not s_risky:     # the top-k SET is determined whatever the summation order
+                assert set(idx[q, :k].tolist()) == set(order[r, :k].tolist()), q
+                checked_set += 1
+            if not o_risky:     # ... and so is the ordered list
+                np.testing.assert_array_equal(idx[q, :k], order[r, :k])
+                checked_order += 1
+    report = {"index": f"{N}x{D} fp32 unit rows", "nq": nq, "k": k, "bound_2_D_u": bound, "queries_set_at_risk": int(set_risk),
+              "queries_order_at_risk": int(order_risk), "queries_set_at_risk_typical_error": int(set_typ),
+              "queries_order_at_risk_typical_error": int(order_typ), "verified_equal_to_float64_set": checked_set,
+              "verified_equal_to_float64_ordered": checked_order}
+    print("summation-order risk:", json.dumps(report))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "knn_summation_order_risk.json"), "w") as f:
+            json.dump(report, f, indent=1)
+    assert checked_set + set_risk == nq and checked_set > nq // 2

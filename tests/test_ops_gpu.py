@@ -470,3 +470,38 @@ def test_library_streams_are_not_pool_streams():
         y = x * 2
     a.synchronize()
     assert float(y.sum()) == 2 * (1 << 20)
+
+
+def test_fanout_alias_with_an_extra_consumer_of_the_shared_input():
+    """Runtime.fanout_alias: the linear layers that read the alias sum their data gradients in the GEMM epilogue (one buffer, in place);
+    another consumer of the ORIGINAL tensor whose backward runs between them must still be summed in (the alias is an autograd node
+    of its own).  Reference: the same graph on plain torch ops."""
+    from ralf_amd import functional as RF
+    from ralf_amd.functional import Runtime
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rt = Runtime(torch.float32).to(torch.device("cuda"))
+    x = torch.randn(192, 64, device="cuda", generator=g, requires_grad=True)
+    Ws = [torch.randn(128, 64, device="cuda", generator=g, requires_grad=True) for _ in range(3)]
+    c = torch.randn(192, 64, device="cuda", generator=g)
+    up = [torch.randn(192, 128, device="cuda", generator=g) for _ in range(3)]
+
+    def graph(lin, shared):
+        y0 = (lin(shared, Ws[0]) * up[0]).sum()
+        extra = (x * c).sum()                       # a consumer of x itself, recorded between the projections
+        y1 = (lin(shared, Ws[1]) * up[1]).sum()
+        extra2 = (x.sin() * c).sum()
+        y2 = (lin(shared, Ws[2]) * up[2]).sum()
+        return y0 + extra + y1 + extra2 + y2
+    rt.begin_step()
+    a = rt.fanout_alias(x)
+    assert a.data_ptr() == x.data_ptr() and a is not x
+    graph(lambda t, W: RF.linear(t, W, rt=rt), a).backward()
+    got = [x.grad.clone()] + [W.grad.clone() for W in Ws]
+    x.grad = None
+    for W in Ws:
+        W.grad = None
+    graph(lambda t, W: t @ W.t(), x).backward()
+    want = [x.grad] + [W.grad for W in Ws]
+    for u, v in zip(got, want):
+        torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-4)

@@ -119,3 +119,79 @@ def test_merged_and_cross_dataset_tables(tmp_path):
     assert all(t[f"id{i}"] == ref[i].tolist() for i in range(25))
     assert (tmp_path / "source_cgl_reference_pku_test_saliency_cross_dataset_indexes_top_k16.pt").exists()
     assert (tmp_path / "source_cgl_reference_pku_test_saliency_cross_dataset_scores_top_k16.pt").exists()
+
+
+def test_preprocess_drivers_end_to_end_on_a_saved_dataset(tmp_path):
+    """the command-line drivers themselves (image2layout/preprocess/build_retrieval_indexes.py:42-121, rerank_indexes.py:86-148):
+    build_retrieval_indexes.main() and rerank_indexes.main() run end to end on a tiny `datasets.DatasetDict.save_to_disk` directory
+    (saliency backbone, FIDNetV3 checkpoint in the reference's model_best.pth.tar layout, DDP-prefixed keys) and write the reference's
+    table files; the tables equal the CPU oracle's search / a per-sample MMR."""
+    import datasets as ds
+
+    from oracle import knn_oracle
+    from ralf_amd.nn import LayoutEncoder
+    from ralf_amd.preprocess import build_retrieval_indexes, rerank_indexes
+    from ralf_amd.retrieval import coarse_saliency, load_cache_table, maximal_marginal_relevance, table_path
+
+    rng = np.random.default_rng(9)
+    feats = ds.Features({"id": ds.Value("string"), "saliency": ds.Array3D((1, 32, 24), "float32"),
+                         "label": ds.Sequence(ds.ClassLabel(names=["text", "logo", "underlay"])),
+                         **{k: ds.Sequence(ds.Value("float32")) for k in ("center_x", "center_y", "width", "height")}})
+
+    def split(n, base):
+        rows = {k: [] for k in feats}
+        for i in range(n):
+            m = int(rng.integers(1, 11))
+            rows["id"].append(str(base + i))
+            rows["saliency"].append(rng.random((1, 32, 24)).astype(np.float32))
+            rows["label"].append(rng.integers(0, 3, m).tolist())
+            for k in ("center_x", "center_y", "width", "height"):
+                rows[k].append(rng.random(m).astype(np.float32).tolist())
+        return ds.Dataset.from_dict(rows, features=feats)
+    dd = ds.DatasetDict({"train": split(150, 1000), "val": split(20, 5000), "test": split(20, 7000)})
+    root = tmp_path / "data" / "pku10"
+    dd.save_to_disk(str(root))
+    cache = tmp_path / "cache"
+    build_retrieval_indexes.main(["--dataset_name", "pku", "--dataset_path", str(tmp_path / "data"), "--retrieval_backbone", "saliency",
+                                  "--top_k", "32", "--save_scores", "--cache_dir", str(cache)])
+    X = np.stack([coarse_saliency(torch.as_tensor(np.asarray(e["saliency"]))) for e in dd["train"]])
+    tables = {}
+    for sp in ("train", "val", "test"):
+        tables[sp] = load_cache_table(table_path("pku", sp, "saliency", 32, str(cache)), 32)
+        Q = np.stack([coarse_saliency(torch.as_tensor(np.asarray(e["saliency"]))) for e in dd[sp]])
+        ref, _ = knn_oracle.topk_ip(X, Q, 33)
+        for i, e in enumerate(dd[sp]):
+            assert tables[sp][int(e["id"])] == (ref[i, 1:] if sp == "train" else ref[i, :32]).tolist(), (sp, i)
+        assert (cache / f"pku_{sp}_saliency_wo_head_table_between_dataset_indexes_top_k32.pt").exists()
+        assert (cache / f"pku_{sp}_saliency_wo_head_table_between_dataset_scores_top_k32.pt").exists()
+    # FIDNetV3 checkpoint as a DDP run would have written it: keys prefixed with "module." (the loader strips it and refuses a
+    # checkpoint that leaves encoder keys unfilled)
+    enc = LayoutEncoder(num_label=3)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for p in enc.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    wdir = tmp_path / "fidnet"
+    wdir.mkdir()
+    torch.save({"state_dict": {"module." + k: v for k, v in enc.state_dict().items()}}, str(wdir / "model_best.pth.tar"))
+    rerank_indexes.main(rerank_indexes.parse(["--dataset", "pku", "--dataset_path", str(tmp_path / "data"), "--top_k", "16", "--retrieval_backbone", "saliency",
+                                              "--rerank_pool_size", "32", "--rerank_type", "mmr", "--rerank_mmr_lam", "0.5", "--fid_weight_dir", str(wdir),
+                                              "--cache_dir", str(cache)]))
+    from ralf_amd.functional import Runtime
+    from ralf_amd.retrieval import RetrievalDatasetWrapper, layout_features
+    fields = RetrievalDatasetWrapper._layout_table(dd["train"], 10)
+    f = layout_features(enc.cuda().eval(), fields, Runtime(torch.float32).to(torch.device("cuda")), device=torch.device("cuda")).cpu().numpy().astype(np.float64)
+    for sp in ("val", "test"):
+        out = torch.load(str(cache / f"pku_{sp}_saliency_rerank_mmr_lam_0.5_wo_head_table_between_dataset_indexes_top_k16.pt"), weights_only=False)
+        sc = load_cache_table(table_path("pku", sp, "saliency", 32, str(cache)).replace("indexes", "scores"), 32)
+        for i, pool in tables[sp].items():
+            p = f[pool]
+            nrm = np.linalg.norm(p, axis=1)
+            cosm = (p @ p.T) / np.maximum(nrm[:, None] * nrm[None, :], 1e-8)
+            local = maximal_marginal_relevance(np.asarray(sc[i]), cosm, 0.5, 16, "similarity")
+            assert out[i] == np.asarray(pool)[local].tolist(), (sp, i)
+    bad = tmp_path / "bad"
+    bad.mkdir()
+    torch.save({"state_dict": {"encoder." + k: v for k, v in enc.state_dict().items()}}, str(bad / "model_best.pth.tar"))
+    with pytest.raises(RuntimeError, match="encoder keys missing"):
+        rerank_indexes._load_fidnet(3, 10, str(bad), torch.device("cuda"))

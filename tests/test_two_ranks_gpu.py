@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _rank(rank, world, port, out_dir):
+def _rank(rank, world, port, out_dir, wire="fp32", mode="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
 
@@ -31,6 +31,15 @@ def _rank(rank, world, port, out_dir):
         torch.save({"skip": repr(e)}, os.path.join(out_dir, f"r{rank}.pt"))
         return
     assert ok
+    if wire == "bf16":
+        try:   # the (opt-in) bf16 wire reduces bf16 DEVICE tensors: not every gloo build carries them
+            t = torch.ones(8, device=dev, dtype=torch.bfloat16) * (rank + 1)
+            dist.all_reduce(t)
+            dist.reduce_scatter_tensor(t[rank * 4:(rank + 1) * 4], t)
+            assert float(t[rank * 4]) == 6.0
+        except Exception as e:
+            torch.save({"skip": repr(e)}, os.path.join(out_dir, f"r{rank}.pt"))
+            return
     torch.manual_seed(100 + rank)                                   # DIFFERENT initial weights per rank: the step must sync them
     model = bench.build_model(dev, 10, "bfloat16")
     with torch.no_grad():
@@ -39,8 +48,8 @@ def _rank(rank, world, port, out_dir):
     inputs, tgt = model.preprocess(make_batch(2, 10, seed=7 + rank))   # different data per rank
     inputs, tgt = to_device(inputs, dev), to_device(tgt, dev)
     inputs["retrieved"] = {k: v for k, v in inputs["retrieved"].items() if k != "image"}
-    step = TrainStep(model, use_graph=True, grad_wire="fp32")
-    assert step.world == 2 and step.staged and step.exchange.active
+    step = TrainStep(model, use_graph=True, grad_wire=wire, grad_exchange=mode)
+    assert step.world == 2 and step.staged and step.exchange.active and step.exchange.wire == wire and step.exchange.mode == mode
     seed0 = int(model.rt._seed_host)
     losses = [float(step(inputs, tgt)) for _ in range(3)]
     torch.cuda.synchronize()
@@ -48,23 +57,40 @@ def _rank(rank, world, port, out_dir):
     gathered = [torch.empty_like(P) for _ in range(world)]
     dist.all_gather(gathered, P)
     same = bool(torch.equal(gathered[0], gathered[1]))
-    torch.save({"losses": losses, "same": same, "seed": seed0, "pnorm": float(P.double().norm())}, os.path.join(out_dir, f"r{rank}.pt"))
+    torch.save({"losses": losses, "same": same, "seed": seed0, "pnorm": float(P.double().norm()), "gnorm": float(step.opt.grad_norm)},
+               os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_keep_identical_weights(tmp_path):
+_FP32_RUN = {}
+
+
+@pytest.mark.parametrize("wire,mode", [("fp32", "allreduce"), ("fp32", "rs_ag"), ("bf16", "rs_ag")])
+def test_two_ranks_on_one_gpu_keep_identical_weights(tmp_path, wire, mode):
+    """every form of the gradient exchange (all_reduce / reduce-scatter + all-gather, fp32 wire / the opt-in bf16 wire with its HIP
+    pack and unpack kernels over the staged ranges): replicas stay bit-identical; reduce-scatter + all-gather sums in the same
+    pairs as all_reduce on two ranks (same weights and clip norm); the bf16 wire moves the clip norm by rounding only"""
     import torch.multiprocessing as mp
 
-    port = 29600 + os.getpid() % 300
-    mp.spawn(_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    port = 29600 + os.getpid() % 300 + {"allreduce": 0, "rs_ag": 1}[mode] + (2 if wire == "bf16" else 0)
+    mp.spawn(_rank, args=(2, port, str(tmp_path), wire, mode), nprocs=2, join=True)
     r = [torch.load(os.path.join(str(tmp_path), f"r{i}.pt")) for i in range(2)]
     if "skip" in r[0]:
-        pytest.skip("gloo cannot reduce device tensors in this build: " + r[0]["skip"])
+        pytest.skip("gloo cannot reduce these device tensors in this build: " + r[0]["skip"])
     assert r[0]["same"] and r[1]["same"], "ranks diverged"
     assert r[0]["seed"] != r[1]["seed"], "ranks drew the same dropout masks"
     assert all(x == x for x in r[0]["losses"] + r[1]["losses"])
     assert abs(r[0]["pnorm"] - r[1]["pnorm"]) == 0.0
+    assert r[0]["gnorm"] == r[1]["gnorm"] and r[0]["gnorm"] > 0      # the clip coefficient is the same bit pattern on both ranks
+    if (wire, mode) == ("fp32", "allreduce"):
+        _FP32_RUN.update(r[0])
+    elif _FP32_RUN:
+        base = _FP32_RUN
+        if wire == "fp32":
+            assert r[0]["gnorm"] == base["gnorm"] and r[0]["pnorm"] == base["pnorm"]
+        else:   # bf16 on the wire: every gradient element rounded to 8 bits once per rank -> the norm moves by << 2^-8 relative
+            assert abs(r[0]["gnorm"] - base["gnorm"]) < 2.0 ** -8 * base["gnorm"], (r[0]["gnorm"], base["gnorm"])
 
 
 def test_bench_two_ranks_on_one_gpu_prints_one_json_line(tmp_path):

@@ -1,11 +1,15 @@
 #!/bin/bash
-# copy the judged summaries of a final-measurement run (tools/_final_r02.sh R) from gpurun_out/R into profiles/
+# copy the judged summaries of a final-measurement run (tools/measure_round.sh R) from gpurun_out/R into profiles/
 R=$1; O=gpurun_out/$R
 cp $O/bench.json profiles/${R}_bench.json
 cp $O/bench_dp_selftest.json profiles/${R}_bench_dp_selftest.json
 cp $O/train_step_kernel_stats.txt profiles/${R}_train_step_kernel_stats.txt
 cp $O/train_step_single_stream_kernel_stats.txt profiles/${R}_train_step_kernel_stats_single_stream.txt
 cp $O/encoder_decoder_only_kernel_stats.txt profiles/${R}_encoder_decoder_only_kernel_stats.txt
+cp $O/encoder_decoder_only_single_stream_kernel_stats.txt profiles/${R}_encoder_decoder_only_kernel_stats_single_stream.txt
+cp $O/train_step_mfma_pmc.txt profiles/${R}_train_step_mfma_pmc.txt
+cp $O/encoder_decoder_only_mfma_pmc.txt profiles/${R}_encoder_decoder_only_mfma_pmc.txt
+cp $O/${R}_mfma_busy.json profiles/${R}_mfma_busy.json
 cp $O/decode_kernel_stats.txt profiles/${R}_decode_kernel_stats.txt
 cp $O/knn_kernel_stats.txt profiles/${R}_knn_kernel_stats.txt
 cp $O/knn_microbench.txt profiles/${R}_knn_microbench.txt
