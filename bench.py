@@ -396,6 +396,7 @@ def main():
     ap.add_argument("--skip-decode", action="store_true", help="skip the B = 256 constrained-decode block")
     ap.add_argument("--no-overlap", action="store_true", help="parameter-gradient kernels on the main stream (no parallel graph branch)")
     ap.add_argument("--dp-selftest", action="store_true", help="single GPU: run the data-parallel code path (1-rank RCCL group, staged backward, overlapped exchange)")
+    ap.add_argument("--profile-pause", type=float, default=0.0, help="idle seconds between warm-up / capture and the timed steps (tools/prof_summary.py cuts a rocprofv3 trace at that gap)")
     ap.add_argument("--skip-variants", action="store_true", help="skip the N = 32 / 350x240 train-step blocks and the relation-decode block")
     ap.add_argument("--cpu-batch", type=int, default=4, help="batch of the CPU baseline's RALF leg (64 = the GPU batch: minutes)")
     a = ap.parse_args()
@@ -453,6 +454,8 @@ def main():
     if not a.no_graph:   # the batch lives in the buffers the captured graphs read (a loader writes the next batch in place)
         inputs, targets = step.static_batch()
     torch.cuda.synchronize()
+    if a.profile_pause > 0:
+        time.sleep(a.profile_pause)
     if world > 1:
         torch.distributed.barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -242,6 +242,11 @@ int ralf_scale_pe_dropout(int dtype, const void* x, const float* pe, void* y, in
                           const int64_t* seed, uint64_t call_id, void* stream);
 int ralf_add_scalar(int dtype, const void* x, const float* s, void* y, int64_t rows, int cols, int64_t ldx, int64_t ldy, void* stream);
 int ralf_sum_all(int dtype, const void* x, float* out, int64_t rows, int cols, int64_t ldx, void* stream);
+/* y[i] (fp32) = x[i] (dtype) * s[0], s on the device: the chain rule through a scalar loss (`dlogits * grad_output` in autograd's
+ * backward of nn.CrossEntropyLoss on fp32 logits, retrieval_augmented_autoreg.py:209-216) without a host read of the factor */
+int ralf_scale_dev(int dtype, const void* x, const float* s, float* y, int64_t n, void* stream);
+/* p[0 .. nbytes) = 0 (16-byte aligned, nbytes % 16 == 0): optimizer.zero_grad() on the flat gradient buffer (train/train.py:444) */
+int ralf_zero(void* p, int64_t nbytes, void* stream);
 int ralf_copy2d(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t rows, int cols, int64_t lds, int64_t ldd, int accumulate, void* stream);
 int ralf_permute4(int src_dtype, int dst_dtype, const void* in, void* out, int d0, int d1, int d2, int d3, int64_t s0, int64_t s1, int64_t s2, int64_t s3,
                   int valid3, void* stream);

@@ -430,15 +430,26 @@ __device__ __forceinline__ void lds_stage(T* l, const u32x4 (&regs)[NV], int tid
 // NW: waves per workgroup, 4 (2 x 2 waves, FM x FN fragments each) or 8 (2 x 4 waves, FM x FN/2 fragments each; FN = 2 only)
 // LDS bytes of one workgroup: two buffers of operand tiles, re-used as the fp32 C staging tile [64][BN + 4] of the epilogue
 template <int GATHER, int FM>
-constexpr int gemm_nbuf() { return ((GATHER == 1 || GATHER == 4) && FM == 1) ? 1 : 2; }   // the prefetch-distance-1 kernels keep one buffer
-template <typename T, bool AK, bool BKC, int FM, int FN, int NBUF = 2>
+constexpr int gemm_nbuf() { return GATHER == 6 ? 3 : ((GATHER == 1 || GATHER == 4) && FM == 1) ? 1 : 2; }   // the prefetch-distance-1 kernels keep one buffer
+// GLDS (GATHER 5 / 6): operand tiles go global -> LDS directly (global_load_lds_dwordx4), unpadded [rows][64] images whose 16-byte
+// slots are XOR-swizzled through the SOURCE address; a ring of 2 / 3 stages
+template <typename T, bool AK, bool BKC, int FM, int FN, int NBUF = 2, bool GLDS = false>
 constexpr int gemm_lds_bytes() {
     using X = TT<T>;
     constexpr int BM = 64 * FM, BN = 64 * FN, BK = X::BK;
-    constexpr int A_ELEMS = AK ? BM * X::LDK : BK * (BM + X::RPAD);
-    constexpr int B_ELEMS = BKC ? BN * X::LDK : BK * (BN + X::RPAD);
+    constexpr int A_ELEMS = GLDS ? BM * BK : AK ? BM * X::LDK : BK * (BM + X::RPAD);
+    constexpr int B_ELEMS = GLDS ? BN * BK : BKC ? BN * X::LDK : BK * (BN + X::RPAD);
     constexpr int ops = NBUF * (A_ELEMS + B_ELEMS) * (int)sizeof(T), cst = 64 * (BN + 4) * 4;   // NBUF operand buffers (see the k-loop)
     return ops > cst ? ops : cst;
+}
+
+// counted wait for this wave's oldest vector-memory operations (all but the N youngest) + its LDS reads; compiler memory fence
+template <int N>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+// workgroup barrier that does NOT drain the vector-memory queue (LDS-DMA loads stay in flight across it)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
 // the body of one workgroup: output tiles bid0, bid0 + grid_x, ... of batch entry z (grid_x matters only for persistent
@@ -494,6 +505,8 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     // PMC (SQ_ACTIVE_INST_ANY ~ 84 % of the kernel, MFMA busy 10 %) showed this kernel is instruction-issue bound:
     // the interior fast path keeps one pointer per staging vector and advances it by a constant per k-tile.
     // Rows beyond M/N are clamped to the last valid row (their results are never stored).
+    constexpr bool GLDS = GATHER == 5 || GATHER == 6;   // direct-to-LDS ring (bf16, both operands k-contiguous, interior fast path)
+    static_assert(!GLDS || (AK && BKC && sizeof(T) == 2), "direct-to-LDS: k-contiguous bf16 operands");
     constexpr bool fast = GATHER == 3;   // compile-time: the general loaders (and their RowInfo registers) are not even compiled in
     const T* pa[NVA];
     const T* pb[NVB];
@@ -551,6 +564,24 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                 h_bo[i] = b * P.img;
             }
         }
+        if constexpr (GLDS) {
+            // one global_load_lds_dwordx4 moves 64 lanes x 16 bytes = 8 tile rows of 128 bytes into 1 KiB of LDS, lane-linear: lane l
+            // fills 16-byte slot (l & 7) of row (l >> 3) of its chunk.  The slot holds k-vector (slot ^ ((row >> 1) & 7)) of that row:
+            // a 16-lane group of a ds_read_b128 (32 consecutive rows, one k-vector) then touches 16 distinct (row parity, slot)
+            // pairs = all 64 banks once.  The 8 lanes of a row still read one whole 128-byte line.
+            constexpr int CHA = BM / 8 / NW, CHB = BN / 8 / NW;   // 1-KiB chunks per wave and k-tile
+            static_assert(CHA == NVA && CHB == NVB, "chunk = one 16-byte vector per lane");
+#pragma unroll
+            for (int i = 0; i < CHA; ++i) {
+                const int row = (wave * CHA + i) * 8 + (lane >> 3);
+                pa[i] = Ap + (int64_t)min(m0 + row, d.M - 1) * d.lda + kbeg + (((lane & 7) ^ ((row >> 1) & 7)) * VEC);
+            }
+#pragma unroll
+            for (int i = 0; i < CHB; ++i) {
+                const int row = (wave * CHB + i) * 8 + (lane >> 3);
+                pb[i] = Bp + (int64_t)min(n0 + row, d.N - 1) * d.ldb + kbeg + (((lane & 7) ^ ((row >> 1) & 7)) * VEC);
+            }
+        }
         if (fast) {
 #pragma unroll
             for (int i = 0; i < NVA; ++i) {
@@ -566,7 +597,7 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                 if (d.kseg) pb[i] += (int64_t)(kbeg / d.kseg) * d.sBk;   // segmented K range of B (kbeg is a multiple of the k-tile)
             }
         }
-        constexpr bool generic = GATHER == 0 || GATHER == 4;
+        constexpr bool generic = GATHER == 0 || GATHER == 4;   // (GLDS: neither)
         if (AK && generic) {
 #pragma unroll
             for (int i = 0; i < NVA; ++i) ia[i] = row_info<GATHER == 4>(P, m0 + (tid + NT * i) / KV, d.M, d.lda);
@@ -578,7 +609,9 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     };
     uint32_t okm0 = ~0u, okm1 = ~0u;   // validity bits of the staged vectors of set 0 / 1 (A: bits 0.., B: bits 16..): zeroed at stage time
     auto gload = [&](u32x4 (&ra)[NVA], u32x4 (&rb)[NVB], int k0, uint32_t& okm) {
-        if constexpr (fast) {
+        if constexpr (GLDS) {
+            (void)ra; (void)rb; (void)k0; (void)okm;   // (the direct-to-LDS loop below issues its own loads)
+        } else if constexpr (fast) {
             (void)okm;
 #pragma unroll
             for (int i = 0; i < NVA; ++i) { ra[i] = *reinterpret_cast<const u32x4*>(pa[i]); pa[i] += stepA; }
@@ -676,6 +709,9 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     // transpose-read geometry (bf16 row-contiguous tiles): 16-lane group gi reads a [4 k][16 rows] block
     const int trL = lane & 15, tr_rowblk = ((lane >> 4) & 1) * 16, tr_k = lh * 8 + (trL >> 2), tr_c = (trL & 3) * 4;
 
+    // direct-to-LDS images: this lane's read offsets (bytes from the stage's A / B base) for k-slice 0
+    const unsigned gl_sw = (unsigned)((l31 >> 1) & 7) ^ (unsigned)lh;
+    const unsigned gl_offa = (unsigned)(wm * 32 * WFM + l31) * 128u + (gl_sw << 4), gl_offb = (unsigned)(wn * 32 * WFN + l31) * 128u + (gl_sw << 4);
     // one k-tile of MFMAs from the staged LDS tile
     auto compute = [&](const T* la, const T* lb) {
         // the matrix core computes the TRANSPOSED tile: row operand = n-fragment (weights), column operand =
@@ -699,6 +735,24 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < WFN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
+        } else if constexpr (GLDS) {
+            // swizzled [rows][64] images: k-vector kv of row r sits in slot kv ^ ((r >> 1) & 7); with kv = 2 ks + lh that is byte offset
+            // (r * 128 + ((lh ^ sw) << 4)) ^ (ks << 5): ONE xor per k-slice and operand, fragments 32 rows apart by immediate offsets
+            const unsigned char* pa8 = reinterpret_cast<const unsigned char*>(la);
+            const unsigned char* pb8 = reinterpret_cast<const unsigned char*>(lb);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 a[WFM], b[WFN];
+                const unsigned oa = gl_offa ^ (unsigned)(ks << 5), ob = gl_offb ^ (unsigned)(ks << 5);
+#pragma unroll
+                for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(pa8 + oa + i * 32 * 128);
+#pragma unroll
+                for (int j = 0; j < WFN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(pb8 + ob + j * 32 * 128);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WFN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
             }
         } else {
 #pragma unroll
@@ -765,7 +819,52 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
         for (int j = 0; j < WFN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if constexpr (PF == 1) {   // one LDS buffer (a second one measured 46.6 -> 54.3 us on the layer1 3x3 convolutions)
+    if constexpr (GLDS) {
+        // DIRECT-TO-LDS RING.  No staging registers and no ds_write: every wave issues NVA + NVB global_load_lds_dwordx4 per k-tile (1 KiB
+        // each) into a ring of NST stages.  Waits are COUNTED (s_waitcnt vmcnt(N) leaves the younger tiles in flight) and the barrier is
+        // the raw s_barrier: __syncthreads() would drain the queue (an LDS-DMA is a pending LDS write on the VM counter).  A tile is
+        // read only after [its issuing wave's vmcnt] + [a barrier]; a stage is re-filled only after the barrier that ends its reads.
+        static_assert(!RALF_GEMM_PERSISTENT, "the direct-to-LDS loop is one tile per workgroup");
+        constexpr int NST = gemm_nbuf<GATHER, FM>();
+        constexpr int STAGE = (BM + BN) * BK, NLD = NVA + NVB;
+        auto issue = [&](int st) {
+            T* sa = la0 + st * STAGE + wave * (NVA * 512);
+            T* sb = la0 + st * STAGE + BM * BK + wave * (NVB * 512);
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[i], LDS_PTR(void, sa + i * 512), 16, 0, 0);
+                pa[i] += BK;
+            }
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb[i], LDS_PTR(void, sb + i * 512), 16, 0, 0);
+                pb[i] += BK;
+            }
+        };
+        issue(0);
+        if (c_nt > 1) issue(1);
+        if (NST == 3 && c_nt > 2) issue(2);
+        if (c_nt >= NST) vm_wait<NLD * (NST - 1)>();
+        else if (NST == 3 && c_nt == 2) vm_wait<NLD>();
+        else vm_wait<0>();
+        lds_barrier();
+        int st = 0, t = 0;
+        for (; t + NST < c_nt; ++t) {   // steady state: tiles t+1 .. t+NST-1 in flight
+            compute(la0 + st * STAGE, la0 + st * STAGE + BM * BK);
+            vm_wait<NLD * (NST - 2)>();   // tile t+1 has landed (this wave's share; the barrier covers the others')
+            lds_barrier();
+            issue(st);                    // tile t+NST into the stage whose reads just ended
+            st = (st + 1 == NST) ? 0 : st + 1;
+        }
+        for (; t + 1 < c_nt; ++t) {       // drain: nothing left to issue
+            compute(la0 + st * STAGE, la0 + st * STAGE + BM * BK);
+            if (NST == 3 && c_nt - t - 2 == 1) vm_wait<NLD>();
+            else vm_wait<0>();
+            lds_barrier();
+            st = (st + 1 == NST) ? 0 : st + 1;
+        }
+        compute(la0 + st * STAGE, la0 + st * STAGE + BM * BK);
+    } else if constexpr (PF == 1) {   // one LDS buffer (a second one measured 46.6 -> 54.3 us on the layer1 3x3 convolutions)
         stage(la0, lb0, ra0, rb0, okm0);
         __syncthreads();
         for (int t = 0; t + 1 < c_nt; ++t) {
@@ -941,8 +1040,8 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
 }
 
 template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_kernel(const KParams P) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[gemm_lds_bytes<T, AK, BKC, FM, FN, gemm_nbuf<GATHER, FM>()>()];   // ONE LDS object
+__global__ __launch_bounds__(64 * NW, NW == 8 ? (GATHER == 6 ? 2 : 4) : 1) void gemm_kernel(const KParams P) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[gemm_lds_bytes<T, AK, BKC, FM, FN, gemm_nbuf<GATHER, FM>(), (GATHER == 5 || GATHER == 6)>()];   // ONE LDS object
     gemm_body<T, AK, BKC, GATHER, FM, FN, EPI, NW>(P, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z, (int)gridDim.z, lds_raw);
 }
 
@@ -1180,7 +1279,22 @@ int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
     const int kspan = ceil_div(d.K, d.splitk);
     const bool shape_ok = ok22 && d.M >= 128 && (d.N % 128 == 0 || d.N >= 512);
     static const int big1 = [] { const char* e = getenv("RALF_GEMM_BIG"); return e ? atoi(e) : 192; }();   // tuning aid (tools/knob_sweep.sh)
-    if (shape_ok && ((d.splitk == 1 && big >= big1) || (kspan >= 1024 && big >= 512))) return launch_epi<T, AK, BKC, GATHER, 2, 2, 8>(P, nbatch, st);
+    const bool use128 = shape_ok && ((d.splitk == 1 && big >= big1) || (kspan >= 1024 && big >= 512));
+    if constexpr (GATHER == 3 && AK && BKC && sizeof(T) == 2) {
+        // DIRECT-TO-LDS main loop for the aligned NT products (every forward linear layer / 1x1 convolution): bit-identical to the
+        // register-staged kernel, 5-10 % faster on 17 of the model's 19 NT shapes (tools/gemm_lab.hip, interleaved A/B on MI355X:
+        // 16384x1024x256 19.0 -> 17.7 us, 8192^3 1293 -> 1189 us = 925 TFLOP/s).  Three stages (one workgroup per CU) only where a
+        // launch has at most one workgroup per CU anyway and a long reduction to pipeline (16384x256x1024: 15.0 -> 13.9 us).
+        static const int glds = [] { const char* e = getenv("RALF_GEMM_GLDS"); return e ? atoi(e) : 1; }();   // 0: off (A/B runs)
+        if (glds && !d.kseg && !d.bnb_part && !forced) {
+            if (use128) {
+                if (big <= 256 && kspan >= 1024) return launch_epi<T, AK, BKC, 6, 2, 2, 8>(P, nbatch, st);
+                return launch_epi<T, AK, BKC, 5, 2, 2, 8>(P, nbatch, st);
+            }
+            return launch_epi<T, AK, BKC, 5, 1, 1, 4>(P, nbatch, st);
+        }
+    }
+    if (use128) return launch_epi<T, AK, BKC, GATHER, 2, 2, 8>(P, nbatch, st);
     return launch_epi<T, AK, BKC, GATHER, 1, 1, 4>(P, nbatch, st);
 }
 

@@ -131,6 +131,17 @@ __global__ void add_scalar_kernel(const T* __restrict__ x, const float* __restri
         st(y, r * ldy + c, ld(x, r * ldx + c) + sv);
     }
 }
+// y = x * s[0] with the factor on the device (the incoming gradient of a scalar loss: 1 or 1/world, graph-replay safe)
+template <typename T>
+__global__ void scale_dev_kernel(const T* __restrict__ x, const float* __restrict__ s, float* __restrict__ y, int64_t n) {
+    const float sv = s[0];
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) y[e] = ld(x, e) * sv;
+}
+// zero fill in 16-byte stores (the flat gradient buffer at the start of a step)
+__global__ void zero_kernel(uint4* __restrict__ p, int64_t n16) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n16; e += (int64_t)gridDim.x * 256) p[e] = z;
+}
 template <typename T>
 __global__ void sum_all_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t rows, int cols, int64_t ldx) {
     __shared__ float red[4];
@@ -630,6 +641,17 @@ extern "C" int ralf_add_scalar(int dtype, const void* x, const float* s, void* y
     RALF_REQUIRE(x && s && y && rows > 0 && cols > 0, "add_scalar: bad arguments");
     DISPATCH_T(dtype, hipLaunchKernelGGL((add_scalar_kernel<T>), dim3(grid_for(rows * cols)), dim3(256), 0, ST, (const T*)x, s, (T*)y, rows, cols, ldx, ldy));
     return ralf::check_launch("add_scalar");
+}
+extern "C" int ralf_scale_dev(int dtype, const void* x, const float* s, float* y, int64_t n, void* stream) {
+    RALF_REQUIRE(x && s && y && n > 0, "scale_dev: bad arguments");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((scale_dev_kernel<T>), dim3(grid_for(n)), dim3(256), 0, ST, (const T*)x, s, y, n));
+    return ralf::check_launch("scale_dev");
+}
+extern "C" int ralf_zero(void* p, int64_t nbytes, void* stream) {
+    RALF_REQUIRE(p && nbytes >= 0 && ((uintptr_t)p % 16) == 0 && nbytes % 16 == 0, "zero: 16-byte aligned buffer and size");
+    if (nbytes == 0) return RALF_OK;
+    hipLaunchKernelGGL(zero_kernel, dim3(grid_for(nbytes / 16, 256, 2048)), dim3(256), 0, ST, (uint4*)p, nbytes / 16);
+    return ralf::check_launch("zero");
 }
 /* out[0] += sum of the [rows, cols] view */
 extern "C" int ralf_sum_all(int dtype, const void* x, float* out, int64_t rows, int cols, int64_t ldx, void* stream) {

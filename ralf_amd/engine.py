@@ -66,7 +66,7 @@ class FlatAdamW:
         self.lr_scale = torch.ones(1, dtype=torch.float32, device=dev)   # scheduler factor, read by the kernel (graph-replay safe)
 
     def zero_grad(self):
-        self.G.zero_()
+        ops.zero_(self.G)
 
     def sync_shadow(self):
         """the fp32 masters were rewritten behind the optimizer's back (load_state_dict, broadcast, re-init, EMA copy): refresh

@@ -761,7 +761,8 @@ class XentFn(Function):
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
-        return (dl * g.to(dl.dtype)).float(), None, None, None, None  # scalar chain rule: plumbing
+        # scalar chain rule on the device by the library's own kernel (the logits are fp32, so is their gradient)
+        return ops.scale_dev(dl, g.detach().float().reshape(1).contiguous()), None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------

@@ -376,9 +376,15 @@ class _GeneratorBase(nn.Module):
         rows, prepared = [], []
         stepper = None
         if use_graph:
-            if getattr(self, "_relation_stepper", None) is None or self._relation_stepper.tok.device != dev:
-                self._relation_stepper = self._StepGraphs(self, T, dev)
-            stepper = self._relation_stepper
+            # the captured steps hold the cross-attention cache of ONE memory length (2 h w + K + Lc, and Lc is padded per batch):
+            # one set of graphs per length, the few most recent kept
+            pool = self.__dict__.setdefault("_relation_steppers", {})
+            key = (int(memory.shape[1]), str(dev))
+            if key not in pool:
+                while len(pool) >= 4:
+                    pool.pop(next(iter(pool)))
+                pool[key] = self._StepGraphs(self, T, dev)
+            stepper = pool[key]
         # the sequence, the masks and the draw live on the HOST (518 logits per step come back in one copy): the reference's
         # control flow is host logic anyway, and a dozen tiny device ops + three syncs per step cost more than the decoder step
         for b in range(B):

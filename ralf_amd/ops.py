@@ -233,6 +233,19 @@ def add_scalar(x, s):
     return y
 
 
+def scale_dev(x, s):
+    """fp32 x * s[0] with the fp32 factor on the device (ralf_scale_dev)"""
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _call("ralf_scale_dev", dtype_code(x), _p(x), _p(s), _p(y), x.numel())
+    return y
+
+
+def zero_(t):
+    """t[...] = 0 through the library's own kernel (ralf_zero); t contiguous, 16-byte aligned, a multiple of 16 bytes"""
+    _call("ralf_zero", _p(t), t.numel() * t.element_size())
+    return t
+
+
 def sum_all(x, out=None):
     if out is None:
         out = torch.zeros(1, dtype=torch.float32, device=x.device)

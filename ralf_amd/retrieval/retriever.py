@@ -57,8 +57,12 @@ class _TablePickle:
     rebuild a defaultdict at all: "Can only SETITEM for dict ...".)"""
     import pickle as _pk
 
+    # (score tables hold one numpy array per sample: retriever.py:216-221 saves `scores[i]` as returned by faiss)
     _ALLOWED = {("collections", "defaultdict"), ("collections", "OrderedDict"), ("builtins", "list"), ("builtins", "dict"),
-                ("builtins", "int"), ("builtins", "str"), ("builtins", "float"), ("builtins", "tuple"), ("builtins", "set")}
+                ("builtins", "int"), ("builtins", "str"), ("builtins", "float"), ("builtins", "tuple"), ("builtins", "set"),
+                ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"), ("numpy", "dtype"),
+                ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+                ("_codecs", "encode")}   # (protocol-2 pickles carry an array's bytes as a latin-1 string)
 
     class Unpickler(_pk.Unpickler):
         def find_class(self, module, name):

@@ -162,17 +162,25 @@ def test_relation_b256_rows_equal_reference_rows(golden):
 
 
 # ---- bf16 against fp32, block by block ---------------------------------------------------------------------------------------------
-def _block_case(name, f32, f16, x32, n_round, report, extra32=(), extra16=(), bwd=True):
+P_FLIP = 2 * 0.3989 * 4 * U     # see _block_case
+
+
+def _block_case(name, f32, f16, x32, n_round, report, extra32=(), extra16=(), bwd=True, n_relu=0):
     """one block in both precisions on the SAME input (the fp32 model's activation, rounded once for the bf16 block) and the same
-    upstream gradient: forward output, data gradient and parameter gradients within u * rounding points * 2 (a block's rounding
-    errors add at most linearly; the factor 2 covers the amplification by a normalisation that follows a small-variance channel)"""
+    upstream gradient.  Budgets (relative Frobenius error against the fp32 block):
+      forward:  2 u (n + 1)      -- n rounding points of u = 2^-9 each + the input's, adding at most linearly; the factor 2 covers the
+                                    amplification by a normalisation that follows a small-variance channel;
+      backward: 2 u (2 n + 2) + 1.5 sqrt(n_relu * p_flip)  -- the rounding points of the forward AND backward chains, plus the ReLU
+                decisions that rounding flips: a pre-activation of unit scale known to ~4 u changes sign with probability
+                p_flip = 2 phi(0) 4 u = 0.62 %, and a flipped element carries a whole gradient entry, i.e. sqrt(p_flip) = 8 % of the
+                gradient's norm per ReLU.  (The forward does not see this: a flipped pre-activation is ~0 on both sides.)
+    All rows are collected; the caller asserts at the end so that the whole table is printed."""
     x32 = x32.detach().requires_grad_(bwd)
     x16 = x32.detach().to(torch.bfloat16).requires_grad_(bwd)
     o32, o16 = f32(x32, *extra32), f16(x16, *extra16)
     e_fwd = rel(o16.float(), o32)
-    budget_f, budget_b = 2 * U * (n_round + 1), 2 * U * (2 * n_round + 2)
+    budget_f, budget_b = 2 * U * (n_round + 1), 2 * U * (2 * n_round + 2) + 1.5 * (n_relu * P_FLIP) ** 0.5
     row = {"fwd": e_fwd, "budget_fwd": budget_f}
-    assert e_fwd < budget_f, (name, row)
     if bwd:
         g = torch.Generator(device=DEV).manual_seed(17)
         dy = torch.randn(o32.shape, device=DEV, generator=g) * o32.detach().abs().mean()
@@ -185,7 +193,6 @@ def _block_case(name, f32, f16, x32, n_round, report, extra32=(), extra16=(), bw
         row["dx"] = rel(x16.grad.float(), x32.grad)
         row["dW_worst"] = max([rel(b.grad, a.grad) for a, b in zip(p32, p16) if a.grad is not None and a.grad.norm() > 0] or [0.0])
         row["budget_bwd"] = budget_b
-        assert row["dx"] < budget_b and row["dW_worst"] < budget_b, (name, row)
     report[name] = {k: round(v, 5) for k, v in row.items()}
     return o32.detach()
 
@@ -232,7 +239,7 @@ def test_bf16_block_by_block_error_budgets_plain_init():
             for bi, (k32, k16) in enumerate(zip(getattr(b32.body, f"layer{li}"), getattr(b16.body, f"layer{li}"))):
                 rt32.begin_step(); rt16.begin_step()
                 n_round = 8 if k32.downsample is not None else 6
-                x = _block_case(f"layer{li}.{bi}", k32.forward, k16.forward, x, n_round, report, extra32=(rt32,), extra16=(rt16,))
+                x = _block_case(f"layer{li}.{bi}", k32.forward, k16.forward, x, n_round, report, extra32=(rt32,), extra16=(rt16,), n_relu=3)
             feats[li] = x
 
         class Fpn:
@@ -248,7 +255,7 @@ def test_bf16_block_by_block_error_budgets_plain_init():
         x = _block_case("fpn", f32_.run, f16_.run, feats[3], 5, report)
         for i, (k32, k16) in enumerate(zip(m32.transformer_encoder.layers, m16.transformer_encoder.layers)):
             rt32.begin_step(); rt16.begin_step()
-            x = _block_case(f"encoder.{i}", k32.forward, k16.forward, x, 8, report, extra32=(rt32,), extra16=(rt16,))
+            x = _block_case(f"encoder.{i}", k32.forward, k16.forward, x, 8, report, extra32=(rt32,), extra16=(rt16,), n_relu=1)
         mem = x
         rt32.begin_step(); rt16.begin_step()
         with torch.no_grad():
@@ -262,9 +269,13 @@ def test_bf16_block_by_block_error_budgets_plain_init():
         memory = torch.cat([mem, mem[:, :20]], dim=1).contiguous()      # 276 memory rows (content is what the encoder produced)
         for i, (k32, k16) in enumerate(zip(m32.decoder.transformer.layers, m16.decoder.transformer.layers)):
             rt32.begin_step(); rt16.begin_step()
-            h = _block_case(f"decoder.{i}", k32.forward, k16.forward, h, 12, report, extra32=(memory, rt32, kpm), extra16=(memory.to(torch.bfloat16), rt16, kpm))
-    worst = {k: max(report[n].get(k, 0.0) / report[n]["budget_fwd" if k == "fwd" else "budget_bwd"] for n in report) for k in ("fwd", "dx", "dW_worst")}
+            h = _block_case(f"decoder.{i}", k32.forward, k16.forward, h, 12, report, extra32=(memory, rt32, kpm), extra16=(memory.to(torch.bfloat16), rt16, kpm), n_relu=1)
+    worst = {k: max(report[n].get(k, 0.0) / report[n].get("budget_fwd" if k == "fwd" else "budget_bwd", 1.0) for n in report) for k in ("fwd", "dx", "dW_worst")}
     print("bf16 vs fp32 per block (relative Frobenius error):")
     for n, row in report.items():
         print(f"  {n:16s} {row}")
     print("largest used fraction of the budget:", {k: round(v, 3) for k, v in worst.items()})
+    for n, row in report.items():
+        assert row["fwd"] < row["budget_fwd"], (n, row)
+        if "dx" in row:
+            assert row["dx"] < row["budget_bwd"] and row["dW_worst"] < row["budget_bwd"], (n, row)

@@ -251,3 +251,55 @@ def test_few_row_kernel_is_bit_identical_to_the_tiled_kernel(tmp_path):
         outs.append(torch.load(f))
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+_GLDS_CASES = """
+import sys, torch
+sys.path.insert(0, {root!r})
+from ralf_amd import ops
+g = torch.Generator(device="cuda").manual_seed(11)
+out = {{}}
+seed = torch.tensor([1234], dtype=torch.int64, device="cuda")
+for M, N, K in [(16384, 1024, 256), (16384, 256, 1024), (3300, 768, 256), (4096, 512, 2048), (200, 256, 128), (33792, 264, 64), (8192, 128, 4096)]:
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g)
+    r = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    out[(M, N, K, "plain")] = ops.gemm(x, w, M, N, K)
+    out[(M, N, K, "bias_relu")] = ops.gemm(x, w, M, N, K, bias=b, act="relu")
+    out[(M, N, K, "bias_res_drop")] = ops.gemm(x, w, M, N, K, bias=b, res=r, drop_p=0.1, seed=seed, call_id=3)
+    out[(M, N, K, "f32")] = ops.gemm(x, w, M, N, K, out_dtype=torch.float32)
+    if N % 128 == 0 and M % 64 == 0:
+        z = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        out[(M, N, K, "gelu_out2")] = ops.gemm(x, w, M, N, K, bias=b, act="gelu", out2=z)
+        out[(M, N, K, "gelu_pre")] = z
+        cst = ops.colstats_buffer(M, N, x.device)
+        out[(M, N, K, "stats_y")] = ops.gemm(x, w, M, N, K, colstats=cst)
+        out[(M, N, K, "stats")] = cst
+torch.cuda.synchronize()
+torch.save({{k: v.cpu() for k, v in out.items()}}, {path!r})
+"""
+
+
+def test_direct_to_lds_kernels_are_bit_identical_to_register_staged(tmp_path):
+    """the aligned NT products run on the direct-to-LDS kernels (global_load_lds ring, gemm_impl.h GATHER 5 / 6) by default and on the
+    register-staged kernels with RALF_GEMM_GLDS=0 (read once per process): same MFMA chain in the same order, so every output --
+    plain, fused epilogues, fp32 logits, the pre-activation copy, the BatchNorm column statistics -- is the same bits.  Shapes: both
+    tile sizes, the 3-stage ring (<= 256 tiles, K >= 1024), ragged M and N, a single k-tile."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for flag in ("1", "0"):
+        path = str(tmp_path / f"glds{flag}.pt")
+        r = subprocess.run([sys.executable, "-c", _GLDS_CASES.format(root=root, path=path)], env=dict(os.environ, RALF_GEMM_GLDS=flag),
+                           capture_output=True, text=True, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        res[flag] = torch.load(path)
+    assert set(res["1"]) == set(res["0"]) and len(res["1"]) >= 36
+    for k in res["1"]:
+        assert torch.equal(res["1"][k], res["0"][k]), k
+    x = res["1"][(16384, 1024, 256, "plain")]
+    assert torch.isfinite(x.float()).all() and x.float().abs().max() > 0.1

@@ -127,3 +127,32 @@ def test_preprocess_drivers_expose_the_reference_arguments():
     with pytest.raises(SystemExit):
         R.parse(["--rerank_type", "bm25"])
     assert isinstance(a, argparse.Namespace)
+
+
+def test_score_tables_with_numpy_rows_load(tmp_path):
+    """the reference saves its score tables with one numpy array per sample (retriever.py:216-224); load_cache_table reads them
+    through the allow-listing unpickler (and still refuses arbitrary classes)"""
+    import collections
+    import pickle
+
+    import numpy as np
+    import pytest
+    import torch
+
+    from ralf_amd.retrieval.retriever import load_cache_table
+
+    t = collections.defaultdict(list)
+    t[7] = np.arange(5, dtype=np.float32)
+    t["a"] = np.linspace(0, 1, 6).astype(np.float32)
+    p = tmp_path / "scores.pt"
+    torch.save(t, str(p))
+    out = load_cache_table(str(p), 3)
+    assert isinstance(out, dict) and np.array_equal(out[7], np.arange(3, dtype=np.float32)) and out["a"].shape == (3,)
+
+    class Evil:
+        def __reduce__(self):
+            return (print, ("pwned",))
+    q = tmp_path / "evil.pt"
+    torch.save({1: Evil()}, str(q))
+    with pytest.raises(pickle.UnpicklingError):
+        load_cache_table(str(q), 3)

@@ -32,11 +32,18 @@ def _rank(rank, world, port, out_dir, wire="fp32", mode="allreduce"):
         return
     assert ok
     if wire == "bf16":
-        try:   # the (opt-in) bf16 wire reduces bf16 DEVICE tensors: not every gloo build carries them
-            t = torch.ones(8, device=dev, dtype=torch.bfloat16) * (rank + 1)
-            dist.all_reduce(t)
-            dist.reduce_scatter_tensor(t[rank * 4:(rank + 1) * 4], t)
-            assert float(t[rank * 4]) == 6.0
+        try:   # the (opt-in) bf16 wire reduces bf16 DEVICE tensors: probe the transport itself at the size of a real range first
+            g = torch.Generator().manual_seed(5)
+            both = [torch.randn(1 << 20, generator=g).bfloat16() for _ in range(world)]
+            want = (both[0].float() + both[1].float()).bfloat16()
+            t = both[rank].to(dev)
+            if mode == "rs_ag":
+                n = t.numel() // world
+                dist.reduce_scatter_tensor(t[rank * n:(rank + 1) * n], t)
+                dist.all_gather_into_tensor(t, t[rank * n:(rank + 1) * n])
+            else:
+                dist.all_reduce(t)
+            assert torch.equal(t.cpu(), want), "gloo does not sum bf16 device tensors of this size correctly"
         except Exception as e:
             torch.save({"skip": repr(e)}, os.path.join(out_dir, f"r{rank}.pt"))
             return
@@ -66,7 +73,7 @@ def _rank(rank, world, port, out_dir, wire="fp32", mode="allreduce"):
 _FP32_RUN = {}
 
 
-@pytest.mark.parametrize("wire,mode", [("fp32", "allreduce"), ("fp32", "rs_ag"), ("bf16", "rs_ag")])
+@pytest.mark.parametrize("wire,mode", [("fp32", "allreduce"), ("fp32", "rs_ag"), ("bf16", "allreduce"), ("bf16", "rs_ag")])
 def test_two_ranks_on_one_gpu_keep_identical_weights(tmp_path, wire, mode):
     """every form of the gradient exchange (all_reduce / reduce-scatter + all-gather, fp32 wire / the opt-in bf16 wire with its HIP
     pack and unpack kernels over the staged ranges): replicas stay bit-identical; reduce-scatter + all-gather sums in the same
@@ -87,8 +94,8 @@ def test_two_ranks_on_one_gpu_keep_identical_weights(tmp_path, wire, mode):
         _FP32_RUN.update(r[0])
     elif _FP32_RUN:
         base = _FP32_RUN
-        if wire == "fp32":
-            assert r[0]["gnorm"] == base["gnorm"] and r[0]["pnorm"] == base["pnorm"]
+        if wire == "fp32":   # (two runs of the step agree to the order of the fp32 atomics in the embedding gradients)
+            assert abs(r[0]["gnorm"] - base["gnorm"]) < 1e-5 * base["gnorm"] and abs(r[0]["pnorm"] - base["pnorm"]) < 1e-6 * base["pnorm"]
         else:   # bf16 on the wire: every gradient element rounded to 8 bits once per rank -> the norm moves by << 2^-8 relative
             assert abs(r[0]["gnorm"] - base["gnorm"]) < 2.0 ** -8 * base["gnorm"], (r[0]["gnorm"], base["gnorm"])
 

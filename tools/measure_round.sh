@@ -12,16 +12,17 @@ prof() { # name, steps-in-trace, header, command...
   python3 $ROOT/tools/prof_summary.py $DB $ROOT/$O/${name}_kernel_stats.txt "$header" $steps $GAP
   rm -rf $ROOT/$O/p_$name
 }
-BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --skip-cpu --skip-knn --skip-split --skip-decode"
-prof train_step 6 "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --skip-cpu --skip-knn --skip-split --skip-decode (MI355X, $R; graph replay, parameter-gradient kernels on parallel graph branches: per-kernel times include overlap)" $BENCH
-prof train_step_single_stream 6 "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --skip-cpu --skip-knn --skip-split --skip-decode --no-overlap (MI355X, $R; one stream: per-kernel times are not inflated by overlap)" $BENCH --no-overlap
+BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --skip-cpu --skip-knn --skip-split --skip-decode --skip-variants --profile-pause 1"
+# (the window after the idle second = the 5 timed graph replays only: no model set-up, eager warm-up, snapshot copies or capture)
+GAP=300 prof train_step 5 "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --skip-cpu --skip-knn --skip-split --skip-decode --skip-variants --profile-pause 1 (MI355X, $R; graph replay, parameter-gradient kernels on parallel graph branches: per-kernel times include overlap)" $BENCH
+GAP=300 prof train_step_single_stream 5 "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 ... --profile-pause 1 --no-overlap (MI355X, $R; one stream: per-kernel times are not inflated by overlap)" $BENCH --no-overlap
 prof encoder_decoder_only 11 "# rocprofv3 --kernel-trace --stats -- python3 tools/encdec_once.py 8 (MI355X, $R; backbone replaced by a fixed feature sequence; whole trace incl. eager warm-up + capture)" python3 $ROOT/tools/encdec_once.py 8
 # single stream, graph replays only (the window after the idle second): kernel time per step re-derives the HIP-event figure of bench.py
 GAP=300 prof encoder_decoder_only_single_stream 8 "# rocprofv3 --kernel-trace --stats -- python3 tools/encdec_once.py 8 single (MI355X, $R; backbone replaced by a fixed feature sequence; ONE stream: no parallel graph branches, kernel durations not inflated by overlap)" python3 $ROOT/tools/encdec_once.py 8 single
 prof decode 5 "# rocprofv3 --kernel-trace --stats -- python3 tools/decode_once.py 3 (MI355X, $R; B = 256, task c, argmax; 4 replays of the captured loop + 2 eager warm-up passes in the trace)" python3 $ROOT/tools/decode_once.py 3
 prof knn 1 "# rocprofv3 --kernel-trace --stats -- python3 tools/knn_once.py (MI355X, $R; 61548 x 1792 fp32, nq = 16: 20 scans + 10 whole calls, nq = 1024: 3 scans + 1 whole call)" python3 $ROOT/tools/knn_once.py
 # PMC passes (one counter per run; --kernel-trace only)
-PB="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-graph --skip-cpu --skip-knn --skip-split --skip-decode"
+PB="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-graph --skip-cpu --skip-knn --skip-split --skip-decode --skip-variants"
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $ROOT/$O/pmc_$C $ROOT/$O/pmck_$C
   timeout 900 rocprofv3 --pmc $C --kernel-trace -d $ROOT/$O/pmc_$C -o t -- $PB > $ROOT/$O/pmc_$C.log 2>&1
