@@ -242,6 +242,13 @@ int ralf_scale_pe_dropout(int dtype, const void* x, const float* pe, void* y, in
                           const int64_t* seed, uint64_t call_id, void* stream);
 int ralf_add_scalar(int dtype, const void* x, const float* s, void* y, int64_t rows, int cols, int64_t ldx, int64_t ldy, void* stream);
 int ralf_sum_all(int dtype, const void* x, float* out, int64_t rows, int cols, int64_t ldx, void* stream);
+/* *counter += inc on the device (int32 or int64): the optimizer's step count / the dropout seed of the next step, advanced inside a
+ * captured graph (torch: `state["step"] += 1`, train/train.py:449-454; the generator state) */
+int ralf_counter_add(void* counter, int is_int64, int64_t inc, void* stream);
+/* input rows of the frozen layout encoder (fid/model.py:90-103: stack of (cx, cy, w, h)) and the key-padding mask of its sequence:
+ * bbox [R*N, 8] (dtype; columns 4..7 zero), kpm uint8 [R, N+1] = (0, !mask[r, 0], ..., !mask[r, N-1]); cx..h fp32 [R, N], mask uint8/bool [R, N] */
+int ralf_layout_pack(int dtype, const float* cx, const float* cy, const float* w, const float* h, const uint8_t* mask, void* bbox, uint8_t* kpm,
+                     int64_t R, int N, void* stream);
 /* y[i] (fp32) = x[i] (dtype) * s[0], s on the device: the chain rule through a scalar loss (`dlogits * grad_output` in autograd's
  * backward of nn.CrossEntropyLoss on fp32 logits, retrieval_augmented_autoreg.py:209-216) without a host read of the factor */
 int ralf_scale_dev(int dtype, const void* x, const float* s, float* y, int64_t n, void* stream);

@@ -110,6 +110,8 @@ SIGNATURES.update({
     "ralf_add_scalar": (i32, [i32, vp, vp, vp, i64, i32, i64, i64, vp]),
     "ralf_sum_all": (i32, [i32, vp, vp, i64, i32, i64, vp]),
     "ralf_scale_dev": (i32, [i32, vp, vp, vp, i64, vp]),
+    "ralf_counter_add": (i32, [vp, i32, i64, vp]),
+    "ralf_layout_pack": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
     "ralf_zero": (i32, [vp, i64, vp]),
     "ralf_copy2d": (i32, [i32, i32, vp, vp, i64, i32, i64, i64, i32, vp]),
     "ralf_permute4": (i32, [i32, i32, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, i32, vp]),

@@ -48,7 +48,10 @@ int ralf_gemm_grouped_bf16(const void* jobs_v, int njobs, void* workspace, size_
                 rfirst += ceil_div(r.per, 2048);
             }
         }
-        hipLaunchKernelGGL((gemm_grouped_kernel<bf16, 2, 2, 8>), dim3(first), dim3(512), 0, st, G);
+        // direct-to-LDS ring (gemm_impl.h GATHER 5, both operands row-contiguous): bit-identical, 81.9 -> 71.0 us per launch inside the step
+        static const int glds = [] { const char* e = getenv("RALF_GEMM_GLDS_GROUPED"); return e ? atoi(e) : 1; }();   // 0: off (A/B runs, tests)
+        if (glds) hipLaunchKernelGGL((gemm_grouped_kernel<bf16, 2, 2, 8, 5>), dim3(first), dim3(512), 0, st, G);
+        else hipLaunchKernelGGL((gemm_grouped_kernel<bf16, 2, 2, 8>), dim3(first), dim3(512), 0, st, G);
         if (R.njobs) hipLaunchKernelGGL(gemm_grouped_reduce_kernel, dim3(rfirst), dim3(256), 0, st, R);
     }
     return ralf::check_launch("wgrad_grouped");

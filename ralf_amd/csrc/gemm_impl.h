@@ -431,8 +431,8 @@ __device__ __forceinline__ void lds_stage(T* l, const u32x4 (&regs)[NV], int tid
 // LDS bytes of one workgroup: two buffers of operand tiles, re-used as the fp32 C staging tile [64][BN + 4] of the epilogue
 template <int GATHER, int FM>
 constexpr int gemm_nbuf() { return GATHER == 6 ? 3 : ((GATHER == 1 || GATHER == 4) && FM == 1) ? 1 : 2; }   // the prefetch-distance-1 kernels keep one buffer
-// GLDS (GATHER 5 / 6): operand tiles go global -> LDS directly (global_load_lds_dwordx4), unpadded [rows][64] images whose 16-byte
-// slots are XOR-swizzled through the SOURCE address; a ring of 2 / 3 stages
+// GLDS (GATHER 5 / 6): operand tiles go global -> LDS directly (global_load_lds_dwordx4), unpadded images whose 16-byte slots are
+// XOR-swizzled through the SOURCE address; a ring of 2 / 3 stages
 template <typename T, bool AK, bool BKC, int FM, int FN, int NBUF = 2, bool GLDS = false>
 constexpr int gemm_lds_bytes() {
     using X = TT<T>;
@@ -505,8 +505,15 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     // PMC (SQ_ACTIVE_INST_ANY ~ 84 % of the kernel, MFMA busy 10 %) showed this kernel is instruction-issue bound:
     // the interior fast path keeps one pointer per staging vector and advances it by a constant per k-tile.
     // Rows beyond M/N are clamped to the last valid row (their results are never stored).
-    constexpr bool GLDS = GATHER == 5 || GATHER == 6;   // direct-to-LDS ring (bf16, both operands k-contiguous, interior fast path)
-    static_assert(!GLDS || (AK && BKC && sizeof(T) == 2), "direct-to-LDS: k-contiguous bf16 operands");
+    constexpr bool GLDS = GATHER == 5 || GATHER == 6;   // direct-to-LDS ring (bf16, interior fast path, any of the four operand layouts)
+    static_assert(!GLDS || sizeof(T) == 2, "direct-to-LDS: bf16 operands");
+    // row-contiguous image of an operand with R = BM / BN rows: [BK k-rows][R] bf16, S = 2 R bytes per k-row (128 or 256), no padding.
+    // A 1-KiB LDS-DMA covers 1024 / S k-rows with S / 16 lanes each.  The transpose read of a 32-lane half touches 4 consecutive k-rows
+    // x 64 bytes; with S a multiple of 128 those rows would share their banks, so the 64-byte granule g of k-row k holds source
+    // granule g ^ x(k): x = k & 3 (S = 256), (k >> 1) & 1 (S = 128) -> the four rows land in four different quarters of the 64 banks.
+    constexpr int SA = BM * 2, SB = BN * 2;
+    constexpr int RPCA = 1024 / SA, RPCB = 1024 / SB, LPRA = SA / 16, LPRB = SB / 16;
+    auto xkey = [](int S, int k) { return S == 256 ? (k & 3) : ((k >> 1) & 1); };
     constexpr bool fast = GATHER == 3;   // compile-time: the general loaders (and their RowInfo registers) are not even compiled in
     const T* pa[NVA];
     const T* pb[NVB];
@@ -565,21 +572,34 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
             }
         }
         if constexpr (GLDS) {
-            // one global_load_lds_dwordx4 moves 64 lanes x 16 bytes = 8 tile rows of 128 bytes into 1 KiB of LDS, lane-linear: lane l
-            // fills 16-byte slot (l & 7) of row (l >> 3) of its chunk.  The slot holds k-vector (slot ^ ((row >> 1) & 7)) of that row:
-            // a 16-lane group of a ds_read_b128 (32 consecutive rows, one k-vector) then touches 16 distinct (row parity, slot)
-            // pairs = all 64 banks once.  The 8 lanes of a row still read one whole 128-byte line.
-            constexpr int CHA = BM / 8 / NW, CHB = BN / 8 / NW;   // 1-KiB chunks per wave and k-tile
-            static_assert(CHA == NVA && CHB == NVB, "chunk = one 16-byte vector per lane");
+            // one global_load_lds_dwordx4 moves 64 lanes x 16 bytes into 1 KiB of LDS, lane-linear.
+            // k-contiguous operand: 8 tile rows of 128 bytes; lane l fills slot (l & 7) of row (l >> 3) of its chunk with k-vector
+            // (slot ^ ((row >> 1) & 7)): a 16-lane group of a ds_read_b128 (32 consecutive rows, one k-vector) then touches 16 distinct
+            // (row parity, slot) pairs = all 64 banks once.  The 8 lanes of a row still read one whole 128-byte line.
+            // row-contiguous operand: 1024 / S k-rows of S bytes; lane l fills slot (l % (S/16)) of k-row (l / (S/16)) with the source
+            // column granule permuted as described at SA / SB above (whole 64-byte pieces of one contiguous S-byte run).
+            static_assert(BM / 8 / NW == NVA && BN / 8 / NW == NVB, "chunk = one 16-byte vector per lane");
 #pragma unroll
-            for (int i = 0; i < CHA; ++i) {
-                const int row = (wave * CHA + i) * 8 + (lane >> 3);
-                pa[i] = Ap + (int64_t)min(m0 + row, d.M - 1) * d.lda + kbeg + (((lane & 7) ^ ((row >> 1) & 7)) * VEC);
+            for (int i = 0; i < NVA; ++i) {
+                if constexpr (AK) {
+                    const int row = (wave * NVA + i) * 8 + (lane >> 3);
+                    pa[i] = Ap + (int64_t)min(m0 + row, d.M - 1) * d.lda + kbeg + (((lane & 7) ^ ((row >> 1) & 7)) * VEC);
+                } else {
+                    const int krow = (wave * NVA + i) * RPCA + lane / LPRA, slot = lane % LPRA;
+                    const int col16 = (((slot >> 2) ^ xkey(SA, krow)) << 2) | (slot & 3);
+                    pa[i] = Ap + (int64_t)(kbeg + krow) * d.lda + min(m0 + col16 * VEC, d.M - VEC);
+                }
             }
 #pragma unroll
-            for (int i = 0; i < CHB; ++i) {
-                const int row = (wave * CHB + i) * 8 + (lane >> 3);
-                pb[i] = Bp + (int64_t)min(n0 + row, d.N - 1) * d.ldb + kbeg + (((lane & 7) ^ ((row >> 1) & 7)) * VEC);
+            for (int i = 0; i < NVB; ++i) {
+                if constexpr (BKC) {
+                    const int row = (wave * NVB + i) * 8 + (lane >> 3);
+                    pb[i] = Bp + (int64_t)min(n0 + row, d.N - 1) * d.ldb + kbeg + (((lane & 7) ^ ((row >> 1) & 7)) * VEC);
+                } else {
+                    const int krow = (wave * NVB + i) * RPCB + lane / LPRB, slot = lane % LPRB;
+                    const int col16 = (((slot >> 2) ^ xkey(SB, krow)) << 2) | (slot & 3);
+                    pb[i] = Bp + (int64_t)(kbeg + krow) * d.ldb + min(n0 + col16 * VEC, d.N - VEC);
+                }
             }
         }
         if (fast) {
@@ -712,6 +732,12 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     // direct-to-LDS images: this lane's read offsets (bytes from the stage's A / B base) for k-slice 0
     const unsigned gl_sw = (unsigned)((l31 >> 1) & 7) ^ (unsigned)lh;
     const unsigned gl_offa = (unsigned)(wm * 32 * WFM + l31) * 128u + (gl_sw << 4), gl_offb = (unsigned)(wn * 32 * WFN + l31) * 128u + (gl_sw << 4);
+    // ... and, for row-contiguous images, the transpose-read offsets per fragment (k-slice 0)
+    unsigned gl_tra[WFM], gl_trb[WFN];
+#pragma unroll
+    for (int i = 0; i < WFM; ++i) gl_tra[i] = (unsigned)(tr_k * SA) + (((unsigned)(wm * WFM + i) * 64u) ^ ((unsigned)xkey(SA, tr_k) << 6)) + (unsigned)(tr_rowblk + tr_c) * 2u;
+#pragma unroll
+    for (int j = 0; j < WFN; ++j) gl_trb[j] = (unsigned)(tr_k * SB) + (((unsigned)(wn * WFN + j) * 64u) ^ ((unsigned)xkey(SB, tr_k) << 6)) + (unsigned)(tr_rowblk + tr_c) * 2u;
     // one k-tile of MFMAs from the staged LDS tile
     auto compute = [&](const T* la, const T* lb) {
         // the matrix core computes the TRANSPOSED tile: row operand = n-fragment (weights), column operand =
@@ -737,8 +763,9 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                     for (int j = 0; j < WFN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
             }
         } else if constexpr (GLDS) {
-            // swizzled [rows][64] images: k-vector kv of row r sits in slot kv ^ ((r >> 1) & 7); with kv = 2 ks + lh that is byte offset
-            // (r * 128 + ((lh ^ sw) << 4)) ^ (ks << 5): ONE xor per k-slice and operand, fragments 32 rows apart by immediate offsets
+            // k-contiguous: swizzled [rows][64] images, k-vector kv of row r in slot kv ^ ((r >> 1) & 7); with kv = 2 ks + lh that is byte
+            // offset (r * 128 + ((lh ^ sw) << 4)) ^ (ks << 5): ONE xor per k-slice and operand, fragments 32 rows apart by immediate offsets.
+            // row-contiguous: transpose reads at k-row (16 ks + tr_k [+ 4]), column bytes (fragment base ^ (x << 6)) + lane part.
             const unsigned char* pa8 = reinterpret_cast<const unsigned char*>(la);
             const unsigned char* pb8 = reinterpret_cast<const unsigned char*>(lb);
 #pragma unroll
@@ -746,9 +773,25 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                 bf16x8 a[WFM], b[WFN];
                 const unsigned oa = gl_offa ^ (unsigned)(ks << 5), ob = gl_offb ^ (unsigned)(ks << 5);
 #pragma unroll
-                for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(pa8 + oa + i * 32 * 128);
+                for (int i = 0; i < FM; ++i) {
+                    if constexpr (AK) a[i] = *reinterpret_cast<const bf16x8*>(pa8 + oa + i * 32 * 128);
+                    else {
+                        const unsigned char* q = pa8 + ks * 16 * SA + gl_tra[i];
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 4 * SA));
+                        a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
 #pragma unroll
-                for (int j = 0; j < WFN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(pb8 + ob + j * 32 * 128);
+                for (int j = 0; j < WFN; ++j) {
+                    if constexpr (BKC) b[j] = *reinterpret_cast<const bf16x8*>(pb8 + ob + j * 32 * 128);
+                    else {
+                        const unsigned char* q = pb8 + ks * 16 * SB + gl_trb[j];
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 4 * SB));
+                        b[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -833,12 +876,12 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
 #pragma unroll
             for (int i = 0; i < NVA; ++i) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[i], LDS_PTR(void, sa + i * 512), 16, 0, 0);
-                pa[i] += BK;
+                pa[i] += stepA;
             }
 #pragma unroll
             for (int i = 0; i < NVB; ++i) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb[i], LDS_PTR(void, sb + i * 512), 16, 0, 0);
-                pb[i] += BK;
+                pb[i] += stepB;
             }
         };
         issue(0);
@@ -934,10 +977,13 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
 #pragma clang loop unroll(full)
         for (int h = 0; h < FM; ++h) {
             __syncthreads();
-            if (FM == 1 || wm == h) {
+            // round h = tile rows 64 h .. 64 h + 63 = two 32-row fragments: of both wave rows (FM = 1), or fragments (2h) % WFM, + 1 of
+            // wave row (2h) / WFM (FM = 2: the wave row's two fragments; FM = 4: half of a wave row's four)
+            if (FM == 1 || wm == (2 * h) / WFM) {
 #pragma clang loop unroll(full)
-                for (int i = 0; i < FM; ++i) {
-                    const int lr = (FM == 1 ? wm * 32 : i * 32) + l31;
+                for (int ii = 0; ii < (FM == 1 ? 1 : 2); ++ii) {
+                    const int i = FM == 1 ? 0 : (2 * h) % WFM + ii;
+                    const int lr = (FM == 1 ? wm * 32 : ii * 32) + l31;
 #pragma clang loop unroll(full)
                     for (int j = 0; j < WFN; ++j) {
 #pragma clang loop unroll(full)
@@ -1040,7 +1086,7 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
 }
 
 template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? (GATHER == 6 ? 2 : 4) : 1) void gemm_kernel(const KParams P) {
+__global__ __launch_bounds__(64 * NW, NW == 8 ? ((GATHER == 6 || FM == 4) ? 2 : 4) : 1) void gemm_kernel(const KParams P) {
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[gemm_lds_bytes<T, AK, BKC, FM, FN, gemm_nbuf<GATHER, FM>(), (GATHER == 5 || GATHER == 6)>()];   // ONE LDS object
     gemm_body<T, AK, BKC, GATHER, FM, FN, EPI, NW>(P, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z, (int)gridDim.z, lds_raw);
 }
@@ -1059,9 +1105,9 @@ struct GJob {
 constexpr int GROUP_MAX = 48;
 struct GParams { int njobs; int pad[3]; GJob j[GROUP_MAX]; };
 
-template <typename T, int FM, int FN, int NW>
+template <typename T, int FM, int FN, int NW, int GATHER = 3>   // GATHER 3: register-staged, 5: direct-to-LDS ring
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_grouped_kernel(const GParams G) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[gemm_lds_bytes<T, false, false, FM, FN>()];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[gemm_lds_bytes<T, false, false, FM, FN, 2, GATHER == 5>()];
     const int b = (int)blockIdx.x;
     int ji = 0;
     while (ji + 1 < G.njobs && b >= G.j[ji + 1].first) ++ji;   // (uniform: scalar loads from the kernel arguments)
@@ -1079,7 +1125,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_grouped_kernel(
     d.bnb_x = nullptr; d.bnb_mask = nullptr; d.bnb_mean = nullptr; d.bnb_part = nullptr;
     P.tiles_n = J.tiles_n; P.tiles_m = J.nwg / J.tiles_n; P.nwg = J.nwg; P.kchunk = J.kchunk; P.partial = J.partial;
     P.vec_epi = 2; P.fast = 1; P.tapuni = 0;
-    gemm_body<T, false, false, 3, FM, FN, 0, NW>(P, b - J.first, 1, 0, 1, lds_raw);
+    gemm_body<T, false, false, GATHER, FM, FN, 0, NW>(P, b - J.first, 1, 0, 1, lds_raw);
 }
 
 // C_j += sum over the k-splits of job j's slabs (jobs with splitk > 1 only); first = first workgroup, 2048 outputs per workgroup
@@ -1252,7 +1298,7 @@ template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int NW>
 int launch_epi(KParams& P, int nbatch, hipStream_t st) {
     const RalfGemmDesc& d = P.d;
     if (d.bnb_part) {   // BatchNorm-backward statistics: data-gradient products only (A k-contiguous: 1x1 on the interior path, k x k through the tap gather)
-        if constexpr (AK && (GATHER == 0 || GATHER == 1 || GATHER == 3)) return launch<T, AK, BKC, GATHER, FM, FN, 3, NW>(P, nbatch, st);
+        if constexpr (AK && (GATHER == 0 || GATHER == 1 || GATHER == 3 || GATHER == 5 || GATHER == 6)) return launch<T, AK, BKC, GATHER, FM, FN, 3, NW>(P, nbatch, st);
         else { ralf::set_error("gemm: bnb_* needs a k-contiguous A (no general per-vector gather, no weight-gradient layout)"); return RALF_ERR_INVALID; }
     }
     const bool lvl2 = d.C2 || d.act == RALF_ACT_GELU || d.aux_mode == RALF_AUX_GELU_GRAD || d.atomic_out;
@@ -1281,17 +1327,17 @@ int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
     static const int big1 = [] { const char* e = getenv("RALF_GEMM_BIG"); return e ? atoi(e) : 192; }();   // tuning aid (tools/knob_sweep.sh)
     const bool use128 = shape_ok && ((d.splitk == 1 && big >= big1) || (kspan >= 1024 && big >= 512));
     if constexpr (GATHER == 3 && AK && BKC && sizeof(T) == 2) {
-        // DIRECT-TO-LDS main loop for the aligned NT products (every forward linear layer / 1x1 convolution): bit-identical to the
-        // register-staged kernel, 5-10 % faster on 17 of the model's 19 NT shapes (tools/gemm_lab.hip, interleaved A/B on MI355X:
-        // 16384x1024x256 19.0 -> 17.7 us, 8192^3 1293 -> 1189 us = 925 TFLOP/s).  Three stages (one workgroup per CU) only where a
-        // launch has at most one workgroup per CU anyway and a long reduction to pipeline (16384x256x1024: 15.0 -> 13.9 us).
-        static const int glds = [] { const char* e = getenv("RALF_GEMM_GLDS"); return e ? atoi(e) : 1; }();   // 0: off (A/B runs)
-        if (glds && !d.kseg && !d.bnb_part && !forced) {
-            if (use128) {
-                if (big <= 256 && kspan >= 1024) return launch_epi<T, AK, BKC, 6, 2, 2, 8>(P, nbatch, st);
-                return launch_epi<T, AK, BKC, 5, 2, 2, 8>(P, nbatch, st);
-            }
-            return launch_epi<T, AK, BKC, 5, 1, 1, 4>(P, nbatch, st);
+        // DIRECT-TO-LDS main loop for the aligned NT products on 128x128 tiles (forward linear layers / 1x1 convolutions): bit-identical to
+        // the register-staged kernel.  Measured on MI355X -- tools/gemm_lab.hip (back-to-back launches of one shape, interleaved A/B):
+        // 5-10 % faster on 17 of the model's 19 NT shapes, 8192^3 1293 -> 1189 us = 925 TFLOP/s; INSIDE the graph-replayed step (windowed
+        // rocprofv3 A/B, profiles/r03*): 128x128 NT -5 %, 64x64 tiles +4-27 % (slower), NN / the im2col gathers through the same ring
+        // neutral or slower (the padded register-staged images read with fewer conflicts than the XOR-swizzled transpose reads), the
+        // grouped weight gradients (TN, 128x128) -13 %.  So: 128x128 NT here, the grouped kernel in gemm_bf16.hip, nothing else.
+        // Three stages (one workgroup per CU) where a launch has at most one workgroup per CU anyway and a long reduction to pipeline.
+        static const int glds = [] { const char* e = getenv("RALF_GEMM_GLDS"); return e ? atoi(e) : 1; }();   // 0: off (A/B runs, tests)
+        if (glds && use128 && !d.kseg && !d.bnb_part && !forced) {
+            if (big <= 256 && kspan >= 1024) return launch_epi<T, AK, BKC, 6, 2, 2, 8>(P, nbatch, st);
+            return launch_epi<T, AK, BKC, 5, 2, 2, 8>(P, nbatch, st);
         }
     }
     if (use128) return launch_epi<T, AK, BKC, GATHER, 2, 2, 8>(P, nbatch, st);

@@ -13,7 +13,12 @@
 //      mass ties).  k <= 64 and <= 64 segments (every shipped index): the segment lists of a query are merged by the last
 //      workgroup of that query to finish (agent-scope release / ticket / acquire), i.e. ONE launch for the whole selection;
 //      otherwise merge rounds with the same kernel.  Result order (score desc, index asc), bit-identical on all paths.
-//    Measured and dropped (MI355X, 61548 x 1792, k = 16): (a) the selection fused into the scan's epilogue -- per-workgroup
+//    Measured and dropped (MI355X, 61548 x 1792, k = 16): (c, round 3) the scan on a direct-to-LDS ring (global_load_lds_dwordx4 into 2-4
+//    stages, XOR-swizzled 16-byte slots, ds_read_b128 / ds_read_b32 fragment reads, one barrier per k-tile, counted vmcnt; scores
+//    bit-identical): nq <= 16 81-83 us vs 79-82, nq = 17-32 100-104 us vs 92 -- the register-staged scan's rotated rows give it
+//    conflict-free 4-byte fragment reads, which a lane-linear LDS-DMA image cannot (16-byte granules: two rows per bank pair, or a
+//    select per operand), and at <= 16 queries the stream is already at 0.67-0.70 of peak;
+//    (a) the selection fused into the scan's epilogue -- per-workgroup
 //    top-k of the [queries x 128..256 rows] tile in LDS, no score matrix: a wave-level exact top-16 of 128 is thousands of
 //    dependent scalar/vector round trips per query, the scan got 14-23 us slower at nq = 16-32 and 39 % slower at nq = 1024;
 //    (b) one 1024-thread workgroup per query over the whole score row: a single CU pulls ~25 GB/s, 17-19 us per launch vs
@@ -177,171 +182,6 @@ __global__ __launch_bounds__(256) void knn_scores_kernel(const float* __restrict
             for (int r = 0; r < F::NREG; ++r) {
                 const int qi = q0 + i * MF + F::crow(r, lane);
                 if (qi < nq_hi && n < nrows) S[(int64_t)qi * nrows + n] = acc[i][j][r];
-            }
-        }
-}
-
-// ---- the same scan with the tiles going global -> LDS directly (global_load_lds_dwordx4) ---------------------------------------
-// The exhaustive scan above stages every k-tile through registers and writes it to LDS with four ds_write_b32 per float4 (the
-// rotated rows its ds_read_b32 fragment reads need), on ONE buffer with two barriers per k-tile: the matrix pipe idles while a
-// workgroup stores, which shows once the fp32 MFMA time comes near the stream time (17-32 queries: 0.52 of peak).  Here a wave
-// issues one LDS-DMA per 8 rows x 128 bytes into a ring of NST stages (no staging registers, no ds_write, ONE barrier per k-tile,
-// counted s_waitcnt vmcnt leaves NST - 1 tiles in flight).  An LDS-DMA is lane-linear, so the 16-byte slot s of row r holds k-quad
-// (s ^ ((r >> 1) & 7)): 32-row fragments (ds_read_b128: each lane its row's quad, two K-steps per read) touch all 64 banks once;
-// 16-row fragments read the single float they feed (ds_read_b32, two rows per bank pair).  The MFMA K-steps take the same
-// (k, k+1[, k+2, k+3]) values in the same order as above: scores are bit-identical.  Rows beyond N and k beyond D read a zero page.
-__device__ float ralf_knn_zero_page[64];   // (zero-initialised)
-
-template <int N>
-__device__ __forceinline__ void knn_vm_wait() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void knn_lds_barrier() {
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-template <int MF, int TQ, int TR, int NST>
-__global__ __launch_bounds__(256) void knn_scores_glds_kernel(const float* __restrict__ X, int64_t N, int D, const float* __restrict__ Q, int nq,
-                                                               float* __restrict__ S, int n_qtiles, int nwg, unsigned int* __restrict__ zero_me, int nzero) {
-    using F = Frag<MF>;
-    if (zero_me && blockIdx.x == 0) for (int i = threadIdx.x; i < nzero; i += 256) zero_me[i] = 0u;
-    constexpr int RW = 4 * TR * MF, QW = TQ * MF, BK = 32;
-    constexpr int XC = RW / 32, QC = (QW / 8 + 3) / 4;       // 1-KiB chunks (8 rows) per wave and k-tile: index rows, queries
-    constexpr int NLD = XC + QC;                             // LDS-DMAs per wave and k-tile (every wave issues all of them: equal counts)
-    constexpr int QROWS = QC * 32;                           // query rows a stage holds (>= QW: the waves' surplus chunks read the zero page)
-    constexpr int STAGE = (RW + QROWS) * BK;                 // floats per stage
-    __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];   // ONE LDS object
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int vid = xcd_remap(blockIdx.x, nwg);
-    const int qt = vid % n_qtiles, rc = vid / n_qtiles;
-    const int64_t row0 = (int64_t)rc * RW;
-    const int q0 = qt * QW;
-    const int lrow = lane >> 3, lslot = lane & 7;
-
-    // per-lane sources: row (clamped into the zero page when beyond the matrix) and the k-quad its slot holds
-    const float* px[XC];
-    const float* pq[QC];
-    int kx[XC], kq_[QC];
-    bool okx[XC], okq[QC];
-#pragma unroll
-    for (int i = 0; i < XC; ++i) {
-        const int r = (wave * XC + i) * 8 + lrow;
-        kx[i] = (lslot ^ ((r >> 1) & 7)) * 4;
-        okx[i] = row0 + r < N;
-        px[i] = X + (okx[i] ? (row0 + r) * D : 0) + kx[i];
-    }
-#pragma unroll
-    for (int i = 0; i < QC; ++i) {
-        const int c = wave * QC + i;                         // (chunks beyond the query tile are issued too: zeros into the stage's padding rows)
-        const int r = c * 8 + lrow;
-        kq_[i] = (lslot ^ ((r >> 1) & 7)) * 4;
-        okq[i] = r < QW && q0 + r < nq;
-        pq[i] = Q + (okq[i] ? (int64_t)(q0 + r) * D : 0) + kq_[i];
-    }
-    const int nkt = (D + BK - 1) / BK;
-    const bool ragged = (D & (BK - 1)) != 0;
-    auto issue = [&](int st, int kt) {
-        float* sx = lds + st * STAGE;
-        float* sq = sx + RW * BK;
-        const bool tail = ragged && kt == nkt - 1;
-#pragma unroll
-        for (int i = 0; i < XC; ++i) {
-            const bool ok = okx[i] && (!tail || kt * BK + kx[i] < D);
-            const float* src = ok ? px[i] : ralf_knn_zero_page;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(sx + (wave * XC + i) * 256), 16, 0, 0);
-            px[i] += BK;
-        }
-#pragma unroll
-        for (int i = 0; i < QC; ++i) {
-            const int c = wave * QC + i;
-            const bool ok = okq[i] && (!tail || kt * BK + kq_[i] < D);
-            const float* src = ok ? pq[i] : ralf_knn_zero_page;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(sq + c * 256), 16, 0, 0);
-            pq[i] += BK;
-        }
-    };
-
-    typename F::acc_t acc[TQ][TR];
-#pragma unroll
-    for (int a = 0; a < TQ; ++a)
-#pragma unroll
-        for (int b = 0; b < TR; ++b)
-#pragma unroll
-            for (int r = 0; r < F::NREG; ++r) acc[a][b][r] = 0.f;
-
-    const int lr = lane & (MF - 1), lk = lane / MF;
-    const unsigned sw = (unsigned)((lr >> 1) & 7);
-    unsigned qoff[TQ], xoff[TR];                             // byte offsets of this lane's fragment rows (k-quad 0, swizzled)
-#pragma unroll
-    for (int a = 0; a < TQ; ++a) qoff[a] = (unsigned)(a * MF + lr) * 128u + (sw << 4) + (MF == 16 ? lk * 4u : 0u);
-#pragma unroll
-    for (int b = 0; b < TR; ++b) xoff[b] = (unsigned)((wave * TR + b) * MF + lr) * 128u + (sw << 4) + (MF == 16 ? lk * 4u : 0u);
-
-    auto compute = [&](int st) {
-        const unsigned char* sx = reinterpret_cast<const unsigned char*>(lds + st * STAGE);
-        const unsigned char* sq = sx + RW * BK * 4;
-#pragma unroll
-        for (int q = 0; q < BK / 4; ++q) {                   // k-quad q of the tile sits at slot q ^ sw: byte offset (row base) ^ (q << 4)
-            if constexpr (MF == 32) {
-                // (a NATIVE vector type: a load of HIP's float4 struct carries a memory operand for which hipcc inserts s_waitcnt vmcnt(0)
-                //  in front of the first LDS read after an LDS-DMA -- the whole ring drained every k-tile; checked in the ISA)
-                f32x4 a[TQ], b[TR];
-#pragma unroll
-                for (int i = 0; i < TQ; ++i) a[i] = *reinterpret_cast<const f32x4*>(sq + (qoff[i] ^ (unsigned)(q << 4)));
-#pragma unroll
-                for (int j = 0; j < TR; ++j) b[j] = *reinterpret_cast<const f32x4*>(sx + (xoff[j] ^ (unsigned)(q << 4)));
-                // K-step 2q feeds (k, k+1) = elements (0, 1) through lanes lk = 0, 1; K-step 2q+1 elements (2, 3)
-#pragma unroll
-                for (int i = 0; i < TQ; ++i)
-#pragma unroll
-                    for (int j = 0; j < TR; ++j) acc[i][j] = F::mfma(lk ? a[i][1] : a[i][0], lk ? b[j][1] : b[j][0], acc[i][j]);
-#pragma unroll
-                for (int i = 0; i < TQ; ++i)
-#pragma unroll
-                    for (int j = 0; j < TR; ++j) acc[i][j] = F::mfma(lk ? a[i][3] : a[i][2], lk ? b[j][3] : b[j][2], acc[i][j]);
-            } else {
-                float a[TQ], b[TR];                           // one K-step per quad: lane lk holds element lk of it
-#pragma unroll
-                for (int i = 0; i < TQ; ++i) a[i] = *reinterpret_cast<const float*>(sq + (qoff[i] ^ (unsigned)(q << 4)));
-#pragma unroll
-                for (int j = 0; j < TR; ++j) b[j] = *reinterpret_cast<const float*>(sx + (xoff[j] ^ (unsigned)(q << 4)));
-#pragma unroll
-                for (int i = 0; i < TQ; ++i)
-#pragma unroll
-                    for (int j = 0; j < TR; ++j) acc[i][j] = F::mfma(a[i], b[j], acc[i][j]);
-            }
-        }
-    };
-
-    // ring: a tile is read after [its issuing waves' counted vmcnt] + [a barrier]; a stage is re-filled after the barrier that follows its
-    // last read.  While tile kt is multiplied, tiles kt+1 .. kt+NST-1 are in flight.
-#pragma unroll
-    for (int s_ = 0; s_ < NST - 1; ++s_)
-        if (s_ < nkt) issue(s_, s_);
-    int st = 0, fill = NST - 1;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int younger = min(NST - 2, nkt - 1 - kt);      // tiles issued after tile kt so far
-        if (NST > 3 && younger >= 2) knn_vm_wait<NLD * 2>();
-        else if (NST > 2 && younger == 1) knn_vm_wait<NLD>();
-        else knn_vm_wait<0>();
-        knn_lds_barrier();                                   // tile kt visible to all; all reads of tile kt-1 done
-        if (kt + NST - 1 < nkt) {
-            issue(fill, kt + NST - 1);                        // into the stage of tile kt-1
-            fill = fill + 1 == NST ? 0 : fill + 1;
-        }
-        compute(st);
-        st = st + 1 == NST ? 0 : st + 1;
-    }
-
-#pragma unroll
-    for (int i = 0; i < TQ; ++i)
-#pragma unroll
-        for (int j = 0; j < TR; ++j) {
-            const int64_t n = row0 + (wave * TR + j) * MF + lr;
-#pragma unroll
-            for (int r = 0; r < F::NREG; ++r) {
-                const int qi = q0 + i * MF + F::crow(r, lane);
-                if (qi < nq && n < N) S[(int64_t)qi * N + n] = acc[i][j][r];
             }
         }
 }
@@ -634,15 +474,6 @@ int launch_scores(const float* X, int64_t N, int D, const float* Q, int nq, floa
     return ralf::check_launch("knn_scores");
 }
 
-template <int MF, int TQ, int TR, int NST>
-int launch_scores_glds(const float* X, int64_t N, int D, const float* Q, int nq, float* S, hipStream_t st, unsigned int* zero_me = nullptr, int nzero = 0) {
-    constexpr int RW = 4 * TR * MF, QW = TQ * MF;
-    const int nrc = ceil_div(N, RW), nqt = ceil_div(nq, QW);
-    const int nwg = nrc * nqt;
-    hipLaunchKernelGGL((knn_scores_glds_kernel<MF, TQ, TR, NST>), dim3(nwg), dim3(256), 0, st, X, N, D, Q, nq, S, nqt, nwg, zero_me, nzero);
-    return ralf::check_launch("knn_scores (direct-to-LDS)");
-}
-
 int launch_rescore(const float* X, int64_t N, int D, const float* Q, int nq, const int64_t* cand, int pool, float* S, hipStream_t st) {
     constexpr int MF = 16, RW = 4 * MF;                    // 64 candidates per workgroup, one query per 16-row query tile
     const int nrc = ceil_div(pool, RW);
@@ -667,22 +498,6 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static int scores_impl(const float* X, int64_t N, int D, const float* Q, int nq, float* S, hipStream_t st, unsigned int* zero_me, int nzero) {
     // HBM-bound regime (few queries): small row chunks -> >= 2 workgroups per CU in flight.
-    // RALF_KNN_GLDS (tuning / A-B aid, read once): 0 = register-staged scan, else (variant * 10 + stages) of the direct-to-LDS scan
-    static const int glds = [] { const char* e = getenv("RALF_KNN_GLDS"); return e ? atoi(e) : 0; }();
-    if (glds && nq <= 16) {
-        if (glds == 4) return launch_scores_glds<16, 1, 2, 4>(X, N, D, Q, nq, S, st, zero_me, nzero);
-        if (glds == 2) return launch_scores_glds<16, 1, 2, 2>(X, N, D, Q, nq, S, st, zero_me, nzero);
-        if (glds == 13) return launch_scores_glds<16, 1, 1, 3>(X, N, D, Q, nq, S, st, zero_me, nzero);
-        if (glds == 14) return launch_scores_glds<16, 1, 1, 4>(X, N, D, Q, nq, S, st, zero_me, nzero);
-        return launch_scores_glds<16, 1, 2, 3>(X, N, D, Q, nq, S, st, zero_me, nzero);
-    }
-    if (glds && nq <= 32) {
-        if (glds == 4) return launch_scores_glds<32, 1, 1, 4>(X, N, D, Q, nq, S, st, zero_me, nzero);
-        if (glds == 2) return launch_scores_glds<32, 1, 1, 2>(X, N, D, Q, nq, S, st, zero_me, nzero);
-        if (glds == 13) return launch_scores_glds<32, 1, 2, 3>(X, N, D, Q, nq, S, st, zero_me, nzero);
-        if (glds == 14) return launch_scores_glds<32, 1, 2, 2>(X, N, D, Q, nq, S, st, zero_me, nzero);
-        return launch_scores_glds<32, 1, 1, 3>(X, N, D, Q, nq, S, st, zero_me, nzero);
-    }
     if (nq <= 16) return launch_scores<16, 1, 2>(X, N, D, Q, nq, S, st, zero_me, nzero);
     if (nq <= 32) {
         static const int v32 = [] { const char* e = getenv("RALF_KNN_V32"); return e ? atoi(e) : 0; }();   // tuning aid

@@ -131,6 +131,29 @@ __global__ void add_scalar_kernel(const T* __restrict__ x, const float* __restri
         st(y, r * ldy + c, ld(x, r * ldx + c) + sv);
     }
 }
+// counter += inc on the device (the AdamW step count, the dropout seed): graph-replay safe, no framework kernel
+__global__ void counter_add_kernel(void* p, int is64, long long inc) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (is64) *reinterpret_cast<long long*>(p) += inc;
+        else *reinterpret_cast<int*>(p) += (int)inc;
+    }
+}
+// frozen layout encoder input (fid/model.py:90-103): geometry columns -> [R*N, 8] rows (cx, cy, w, h, 0, 0, 0, 0) in the compute dtype
+// (8 columns: a 16-byte bf16 operand row for the fc_bbox product), and the key-padding mask of the [token; elements] sequence
+template <typename T>
+__global__ void layout_pack_kernel(const float* __restrict__ cx, const float* __restrict__ cy, const float* __restrict__ w, const float* __restrict__ h,
+                                   const unsigned char* __restrict__ mask, T* __restrict__ bbox, unsigned char* __restrict__ kpm, int64_t R, int N) {
+    const int64_t total = R * N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / N;
+        const int n = (int)(e - r * N);
+        T* o = bbox + e * 8;
+        o[0] = (T)cx[e]; o[1] = (T)cy[e]; o[2] = (T)w[e]; o[3] = (T)h[e];
+        o[4] = (T)0.f; o[5] = (T)0.f; o[6] = (T)0.f; o[7] = (T)0.f;
+        kpm[r * (N + 1) + 1 + n] = mask[e] ? 0 : 1;
+        if (n == 0) kpm[r * (N + 1)] = 0;
+    }
+}
 // y = x * s[0] with the factor on the device (the incoming gradient of a scalar loss: 1 or 1/world, graph-replay safe)
 template <typename T>
 __global__ void scale_dev_kernel(const T* __restrict__ x, const float* __restrict__ s, float* __restrict__ y, int64_t n) {
@@ -641,6 +664,17 @@ extern "C" int ralf_add_scalar(int dtype, const void* x, const float* s, void* y
     RALF_REQUIRE(x && s && y && rows > 0 && cols > 0, "add_scalar: bad arguments");
     DISPATCH_T(dtype, hipLaunchKernelGGL((add_scalar_kernel<T>), dim3(grid_for(rows * cols)), dim3(256), 0, ST, (const T*)x, s, (T*)y, rows, cols, ldx, ldy));
     return ralf::check_launch("add_scalar");
+}
+extern "C" int ralf_counter_add(void* counter, int is_int64, int64_t inc, void* stream) {
+    RALF_REQUIRE(counter, "counter_add: null pointer");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, ST, counter, is_int64, (long long)inc);
+    return ralf::check_launch("counter_add");
+}
+extern "C" int ralf_layout_pack(int dtype, const float* cx, const float* cy, const float* w, const float* h, const uint8_t* mask, void* bbox, uint8_t* kpm,
+                                int64_t R, int N, void* stream) {
+    RALF_REQUIRE(cx && cy && w && h && mask && bbox && kpm && R > 0 && N > 0, "layout_pack: bad arguments");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((layout_pack_kernel<T>), dim3(grid_for(R * N)), dim3(256), 0, ST, cx, cy, w, h, mask, (T*)bbox, kpm, R, N));
+    return ralf::check_launch("layout_pack");
 }
 extern "C" int ralf_scale_dev(int dtype, const void* x, const float* s, float* y, int64_t n, void* stream) {
     RALF_REQUIRE(x && s && y && n > 0, "scale_dev: bad arguments");

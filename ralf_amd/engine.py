@@ -89,7 +89,7 @@ class FlatAdamW:
         """the step counter for the bias corrections is advanced ON THE DEVICE, so a captured graph
         replays with the right corrections."""
         self.step_count += 1
-        self.step_dev.add_(1)
+        ops.counter_add_(self.step_dev, 1)
         if self.max_norm > 0:
             self.clip()
         for g in self.groups:
@@ -274,6 +274,7 @@ class TrainStep:
             self._sync_replicas(rt)
         self._static = None
         self._graphs = None
+        self._seed_grad = None
         self.loss = None
         self.steps_done = 0
         # Data parallel: the backward runs in two stages around rt.grad_cut() (after layer2 of the ResNet).  Stage 1
@@ -308,7 +309,9 @@ class TrainStep:
         finally:
             rt.cut_enabled = False
         loss = losses["nll_loss"]
-        loss.backward(torch.full_like(loss, 1.0 / self.world) if self.world > 1 else None)
+        if self._seed_grad is None or self._seed_grad.device != loss.device:   # d(loss) = 1 / world, a constant made once (no fill kernel per step)
+            self._seed_grad = torch.full_like(loss, 1.0 / self.world)
+        loss.backward(self._seed_grad)
         rt.join_side()
         rt.join_all_branches()
         return loss.detach()

@@ -93,7 +93,7 @@ class Runtime:
         self._bn_stats.clear()
 
     def advance_seed(self):
-        self.seed.add_(0x9E3779B1)  # on-device: safe inside a captured graph
+        ops.counter_add_(self.seed, 0x9E3779B1)  # on-device: safe inside a captured graph
 
     def next_call(self) -> int:
         self._call += 1
@@ -661,6 +661,53 @@ class ConcatRowsFn(Function):
 
 def concat_rows(srcs, rt, table=None, idxs=None):
     return ConcatRowsFn.apply(table, idxs if idxs is not None else [None] * len(srcs), rt, *srcs)
+
+
+class Fork2Fn(Function):
+    """(x, x): two aliases of a tensor with two consumers; their gradients are summed by the library's own kernel instead of autograd's
+    accumulation add"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None or g2 is None:
+            return g1 if g2 is None else g2
+        return ops.dropout(g1.contiguous(), 0.0, None, 0, g2.contiguous())
+
+
+def fork2(x):
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x, x
+    return Fork2Fn.apply(x)
+
+
+class ConcatColsFn(Function):
+    """cat(dim=-1) of two [..., Ca] / [..., Cb] tensors (the FPN's channel concat, common/image.py:108): two strided copies by the
+    library's own kernel each way"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        Ca, Cb = a.shape[-1], b.shape[-1]
+        rows = a.numel() // Ca
+        out = torch.empty(*a.shape[:-1], Ca + Cb, dtype=a.dtype, device=a.device)
+        ops.copy2d(a, out, rows, Ca, Ca, Ca + Cb)
+        ops.copy2d(b, out.view(-1)[Ca:], rows, Cb, Cb, Ca + Cb)
+        ctx.dims = (Ca, Cb, rows, tuple(a.shape), tuple(b.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Ca, Cb, rows, sa, sb = ctx.dims
+        g = g.contiguous()
+        ga = torch.empty(sa, dtype=g.dtype, device=g.device)
+        gb = torch.empty(sb, dtype=g.dtype, device=g.device)
+        ops.copy2d(g, ga, rows, Ca, Ca + Cb, Ca)
+        ops.copy2d(g.view(-1)[Ca:], gb, rows, Cb, Ca + Cb, Cb)
+        return ga, gb
 
 
 class ScalePEDropFn(Function):

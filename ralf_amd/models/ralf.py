@@ -552,8 +552,10 @@ class ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg(_GeneratorBas
         with rt.branch("retrieved"):
             ref = self._retrieved_features(inputs["retrieved"], inputs["image"].device)
         rt.join_branch("retrieved", ref)
-        ca = self.attn(mem, ref, rt)
-        fused = self.head(RF.concat_rows([mem, ca, ref], rt), rt)
+        mem_a, mem_b = RF.fork2(mem)     # two consumers each: the fusion attention and the concatenation
+        ref_a, ref_b = RF.fork2(ref)
+        ca = self.attn(mem_a, ref_a, rt)
+        fused = self.head(RF.concat_rows([mem_b, ca, ref_b], rt), rt)
         return {"memory": self._constraint_memory(fused, inputs)}
 
 

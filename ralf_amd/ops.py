@@ -233,6 +233,31 @@ def add_scalar(x, s):
     return y
 
 
+def counter_add_(t, inc: int):
+    """t[0] += inc on the device (int32 / int64 scalar tensor) through ralf_counter_add"""
+    assert t.numel() == 1 and t.dtype in (torch.int32, torch.int64)
+    _call("ralf_counter_add", _p(t), int(t.dtype == torch.int64), int(inc))
+    return t
+
+
+def layout_pack(cx, cy, w, h, mask, dtype):
+    """-> (bbox [R*N, 8] dtype, kpm uint8 [R, N+1]) for the frozen layout encoder (ralf_layout_pack)"""
+    R, N = cx.shape
+    f = lambda t: t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()   # noqa: E731
+    cx, cy, w, h = f(cx), f(cy), f(w), f(h)
+    m = mask.contiguous()
+    m = m.view(torch.uint8) if m.dtype == torch.bool else m
+    bbox = torch.empty(R * N, 8, dtype=dtype, device=cx.device)
+    kpm = torch.empty(R, N + 1, dtype=torch.uint8, device=cx.device)
+    _call("ralf_layout_pack", _TORCH2CODE[dtype], _p(cx), _p(cy), _p(w), _p(h), _p(m), _p(bbox), _p(kpm), R, N)
+    return bbox, kpm
+
+
+def copy2d(src, dst, rows, cols, lds, ldd):
+    """dst[r * ldd + c] = src[r * lds + c] with dtype conversion (ralf_copy2d); src / dst: tensors whose data_ptr is element (0, 0)"""
+    _call("ralf_copy2d", dtype_code(src), dtype_code(dst), _p(src), _p(dst), rows, cols, lds, ldd, 0)
+
+
 def scale_dev(x, s):
     """fp32 x * s[0] with the fp32 factor on the device (ralf_scale_dev)"""
     y = torch.empty(x.shape, dtype=torch.float32, device=x.device)

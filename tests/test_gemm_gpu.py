@@ -276,16 +276,66 @@ for M, N, K in [(16384, 1024, 256), (16384, 256, 1024), (3300, 768, 256), (4096,
         cst = ops.colstats_buffer(M, N, x.device)
         out[(M, N, K, "stats_y")] = ops.gemm(x, w, M, N, K, colstats=cst)
         out[(M, N, K, "stats")] = cst
+# NN (data gradient of a linear layer: B = W [K][N]) and TN (weight gradient: both operands [rows][cols], reduction over the rows)
+for M, N, K in [(16384, 256, 1024), (16384, 1024, 256), (3300, 256, 768), (4096, 2048, 512), (65536, 128, 512)]:
+    dy = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(K, N, device="cuda", generator=g) * 0.05).bfloat16()
+    r = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    out[(M, N, K, "nn")] = ops.gemm(dy, w, M, N, K, b_kcontig=False)
+    out[(M, N, K, "nn_res_mask")] = ops.gemm(dy, w, M, N, K, b_kcontig=False, res=r, aux=r, aux_mode="relu_mask", aux_scale=1.25)
+for rows, n_out, n_in, sk in [(16384, 256, 1024, 4), (16384, 768, 256, 2), (4096, 512, 2048, 1), (3200, 128, 256, 1), (1000, 64, 192, 1)]:
+    dy = torch.randn(rows, n_out, device="cuda", generator=g).bfloat16()
+    x = torch.randn(rows, n_in, device="cuda", generator=g).bfloat16()
+    out[(rows, n_out, n_in, "tn")] = ops.gemm(dy, x, n_out, n_in, rows, a_kcontig=False, b_kcontig=False, out_dtype=torch.float32, splitk=sk)
+# grouped weight gradients (ralf_wgrad_grouped)
+jobs = []
+flat = torch.zeros(256 * 1024 + 768 * 256 + 512 * 256 + 64, device="cuda")
+off = 0
+for rows, n_out, n_in, sk in [(16384, 256, 1024, 1), (16384, 768, 256, 2), (34048, 512, 256, 3)]:
+    dy = torch.randn(rows, n_out, device="cuda", generator=g).bfloat16()
+    x = torch.randn(rows, n_in, device="cuda", generator=g).bfloat16()
+    jobs.append((dy, x, flat[off:off + n_out * n_in].view(n_out, n_in), sk))
+    off += n_out * n_in
+ops.wgrad_grouped(jobs)
+out[("grouped",)] = flat
+# weight gradients of k x k convolutions through the pixel gather (TN, split reduction)
+for B, H, C, Co, k, stride in [(8, 32, 64, 128, 3, 1), (4, 30, 128, 64, 3, 2), (64, 16, 256, 256, 3, 1), (16, 16, 256, 512, 1, 2), (2, 64, 8, 64, 7, 2)]:
+    pad = k // 2
+    OH = (H + 2 * pad - k) // stride + 1
+    x = torch.randn(B, H, H, C, device="cuda", generator=g).bfloat16()
+    dy = torch.randn(B * OH * OH, Co, device="cuda", generator=g).bfloat16()
+    geom = dict(RH=OH, RW=OH, SH=H, SW=H, SC=C, KH=k, KW=k, stride=stride, pad=pad, mode=0)
+    for sk in (1, 5):
+        out[("conv_wgrad", B, H, C, Co, k, stride, sk)] = ops.gemm(dy, x, Co, k * k * C, B * OH * OH, a_kcontig=False, b_kcontig=False, conv=geom, gather=2,
+                                                                  out_dtype=torch.float32, splitk=sk)
+# k x k convolutions through the tap-uniform gather: forward (mode 0) and data gradient (mode 1, stride 1 and 2), with padding
+for B, H, C, Co, k, stride in [(8, 32, 64, 128, 3, 1), (4, 30, 128, 64, 3, 2), (64, 16, 256, 256, 3, 1), (16, 16, 256, 512, 1, 2)]:
+    pad = k // 2
+    OH = (H + 2 * pad - k) // stride + 1
+    x = torch.randn(B, H, H, C, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(Co, k, k, C, device="cuda", generator=g) * 0.05).bfloat16()
+    M = B * OH * OH
+    geom = dict(RH=OH, RW=OH, SH=H, SW=H, SC=C, KH=k, KW=k, stride=stride, pad=pad, mode=0)
+    cst = ops.colstats_buffer(M, Co, x.device) if Co % 64 == 0 and M % 64 == 0 else None
+    out[("conv_fwd", B, H, C, Co, k, stride)] = ops.gemm(x, w, M, Co, k * k * C, conv=geom, gather=1, colstats=cst)
+    if cst is not None:
+        out[("conv_fwd_stats", B, H, C, Co, k, stride)] = cst
+    dy = torch.randn(B, OH, OH, Co, device="cuda", generator=g).bfloat16()
+    wt = (torch.randn(C, k, k, Co, device="cuda", generator=g) * 0.05).bfloat16()
+    geom = dict(RH=H, RW=H, SH=OH, SW=OH, SC=Co, KH=k, KW=k, stride=stride, pad=pad, mode=1)
+    r = torch.randn(B * H * H, C, device="cuda", generator=g).bfloat16()
+    out[("conv_dgrad", B, H, C, Co, k, stride)] = ops.gemm(dy, wt, B * H * H, C, k * k * Co, conv=geom, gather=1, res=r)
 torch.cuda.synchronize()
 torch.save({{k: v.cpu() for k, v in out.items()}}, {path!r})
 """
 
 
 def test_direct_to_lds_kernels_are_bit_identical_to_register_staged(tmp_path):
-    """the aligned NT products run on the direct-to-LDS kernels (global_load_lds ring, gemm_impl.h GATHER 5 / 6) by default and on the
-    register-staged kernels with RALF_GEMM_GLDS=0 (read once per process): same MFMA chain in the same order, so every output --
-    plain, fused epilogues, fp32 logits, the pre-activation copy, the BatchNorm column statistics -- is the same bits.  Shapes: both
-    tile sizes, the 3-stage ring (<= 256 tiles, K >= 1024), ragged M and N, a single k-tile."""
+    """the aligned NT products on 128x128 tiles and the grouped weight gradients run on the direct-to-LDS kernels (global_load_lds ring,
+    gemm_impl.h GATHER 5 / 6) by default and on the register-staged kernels with RALF_GEMM_GLDS=0 RALF_GEMM_GLDS_GROUPED=0 (read once
+    per process): same MFMA chain in the same order, so every output -- plain, fused epilogues, fp32 logits, the pre-activation copy,
+    the BatchNorm column statistics, the grouped fp32 accumulations -- is the same bits (the other layouts / gathers are the same
+    kernels in both runs).  Shapes: both tile sizes, the 3-stage ring (<= 256 tiles, K >= 1024), ragged M and N, a single k-tile."""
     import os
     import subprocess
     import sys
@@ -294,11 +344,12 @@ def test_direct_to_lds_kernels_are_bit_identical_to_register_staged(tmp_path):
     res = {}
     for flag in ("1", "0"):
         path = str(tmp_path / f"glds{flag}.pt")
-        r = subprocess.run([sys.executable, "-c", _GLDS_CASES.format(root=root, path=path)], env=dict(os.environ, RALF_GEMM_GLDS=flag),
+        env = dict(os.environ, RALF_GEMM_GLDS=flag, RALF_GEMM_GLDS_GROUPED=flag)
+        r = subprocess.run([sys.executable, "-c", _GLDS_CASES.format(root=root, path=path)], env=env,
                            capture_output=True, text=True, cwd=root)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         res[flag] = torch.load(path)
-    assert set(res["1"]) == set(res["0"]) and len(res["1"]) >= 36
+    assert set(res["1"]) == set(res["0"]) and len(res["1"]) >= 70
     for k in res["1"]:
         assert torch.equal(res["1"][k], res["0"][k]), k
     x = res["1"][(16384, 1024, 256, "plain")]

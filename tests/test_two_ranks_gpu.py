@@ -58,13 +58,15 @@ def _rank(rank, world, port, out_dir, wire="fp32", mode="allreduce"):
     step = TrainStep(model, use_graph=True, grad_wire=wire, grad_exchange=mode)
     assert step.world == 2 and step.staged and step.exchange.active and step.exchange.wire == wire and step.exchange.mode == mode
     seed0 = int(model.rt._seed_host)
-    losses = [float(step(inputs, tgt)) for _ in range(3)]
+    losses = [float(step(inputs, tgt))]
+    gnorm1 = float(step.opt.grad_norm)      # clip norm of the FIRST step: same weights in every run, so the runs differ by the wire alone
+    losses += [float(step(inputs, tgt)) for _ in range(2)]
     torch.cuda.synchronize()
     P = step.opt.P.detach().clone()
     gathered = [torch.empty_like(P) for _ in range(world)]
     dist.all_gather(gathered, P)
     same = bool(torch.equal(gathered[0], gathered[1]))
-    torch.save({"losses": losses, "same": same, "seed": seed0, "pnorm": float(P.double().norm()), "gnorm": float(step.opt.grad_norm)},
+    torch.save({"losses": losses, "same": same, "seed": seed0, "pnorm": float(P.double().norm()), "gnorm": float(step.opt.grad_norm), "gnorm1": gnorm1},
                os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -96,8 +98,12 @@ def test_two_ranks_on_one_gpu_keep_identical_weights(tmp_path, wire, mode):
         base = _FP32_RUN
         if wire == "fp32":   # (two runs of the step agree to the order of the fp32 atomics in the embedding gradients)
             assert abs(r[0]["gnorm"] - base["gnorm"]) < 1e-5 * base["gnorm"] and abs(r[0]["pnorm"] - base["pnorm"]) < 1e-6 * base["pnorm"]
-        else:   # bf16 on the wire: every gradient element rounded to 8 bits once per rank -> the norm moves by << 2^-8 relative
-            assert abs(r[0]["gnorm"] - base["gnorm"]) < 2.0 ** -8 * base["gnorm"], (r[0]["gnorm"], base["gnorm"])
+        else:
+            # bf16 on the wire: every gradient element rounded to 8 bits once per rank -> the FIRST step's norm moves by << 2^-8 relative
+            # (measured 4e-5).  Later steps are not comparable: AdamW's normalised update turns the rounding of a near-zero gradient
+            # into a full-size step, so the two trajectories separate (step 2: 0.9 %, step 3: tens of percent on this tiny batch) --
+            # which is why the bf16 wire is opt-in
+            assert abs(r[0]["gnorm1"] - base["gnorm1"]) < 2.0 ** -8 * base["gnorm1"], (r[0]["gnorm1"], base["gnorm1"])
 
 
 def test_bench_two_ranks_on_one_gpu_prints_one_json_line(tmp_path):

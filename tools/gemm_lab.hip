@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
     const Variant V[] = {
         {"reg 128x128/8w", launch<bf16, true, true, 3, 2, 2, 0, 8>}, {"glds2 128x128/8w", launch<bf16, true, true, 5, 2, 2, 0, 8>},
         {"glds3 128x128/8w", launch<bf16, true, true, 6, 2, 2, 0, 8>}, {"reg 64x64/4w", launch<bf16, true, true, 3, 1, 1, 0, 4>},
-        {"glds2 64x64/4w", launch<bf16, true, true, 5, 1, 1, 0, 4>},  {"glds3 64x64/4w", launch<bf16, true, true, 6, 1, 1, 0, 4>},
+        {"glds2 256x128/8w", launch<bf16, true, true, 5, 4, 2, 0, 8>},  {"glds3 256x128/8w", launch<bf16, true, true, 6, 4, 2, 0, 8>},
     };
     const int NV = sizeof(V) / sizeof(V[0]);
     size_t maxA = 0, maxB = 0, maxC = 0;

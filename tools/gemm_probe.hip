@@ -17,14 +17,14 @@
         if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } \
     } while (0)
 
-template <bool AK, bool BKC, int FM, int FN, int NW = 4>
+template <bool AK, bool BKC, int FM, int FN, int NW = 4, int G = 3>
 int run(KParams& P, int iters) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) launch<bf16, AK, BKC, 3, FM, FN, 0, NW>(P, 1, 0);
+    for (int i = 0; i < 3; ++i) launch<bf16, AK, BKC, G, FM, FN, 0, NW>(P, 1, 0);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) launch<bf16, AK, BKC, 3, FM, FN, 0, NW>(P, 1, 0);
+    for (int i = 0; i < iters; ++i) launch<bf16, AK, BKC, G, FM, FN, 0, NW>(P, 1, 0);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms = 0;
@@ -33,7 +33,7 @@ int run(KParams& P, int iters) {
            2.0 * P.d.M * P.d.N * P.d.K / (ms * 1e-3 / iters) / 1e12);
     // one clean launch for the stamps
     CK(hipDeviceSynchronize());
-    launch<bf16, AK, BKC, 3, FM, FN, 0, NW>(P, 1, 0);
+    launch<bf16, AK, BKC, G, FM, FN, 0, NW>(P, 1, 0);
     CK(hipDeviceSynchronize());
     const int nblk = std::min(P.nwg * P.d.splitk, 65536);
     std::vector<unsigned long long> h((size_t)nblk * 8);
@@ -104,7 +104,9 @@ int main(int argc, char** argv) {
     P.kchunk = K; P.fast = 1; P.vec_epi = 2;
     printf("%s M=%d N=%d K=%d tile %d\n", lay, M, N, K, tile);
     int rc;
-    if (tile == 28) rc = (AK && BKC) ? run<true, true, 2, 2, 8>(P, 50) : AK ? run<true, false, 2, 2, 8>(P, 50) : run<false, false, 2, 2, 8>(P, 50);
+    if (tile == 58) rc = run<true, true, 2, 2, 8, 5>(P, 50);          // direct-to-LDS ring, 128x128 on 8 waves (nt)
+    else if (tile == 54) rc = run<true, true, 1, 1, 4, 5>(P, 50);     // direct-to-LDS ring, 64x64 on 4 waves (nt)
+    else if (tile == 28) rc = (AK && BKC) ? run<true, true, 2, 2, 8>(P, 50) : AK ? run<true, false, 2, 2, 8>(P, 50) : run<false, false, 2, 2, 8>(P, 50);
     else if (tile == 22) rc = (AK && BKC) ? run<true, true, 2, 2>(P, 50) : AK ? run<true, false, 2, 2>(P, 50) : run<false, false, 2, 2>(P, 50);
     else rc = (AK && BKC) ? run<true, true, 1, 1>(P, 50) : AK ? run<true, false, 1, 1>(P, 50) : run<false, false, 1, 1>(P, 50);
     if (rc) return rc;
