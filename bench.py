@@ -47,7 +47,7 @@ def measured_traffic(key):
 
 
 
-def measured_mfma_busy(key):
+def measured_mfma_busy(key, field="mfma_busy"):
     """MFMA-busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles) of a workload from the NEWEST committed profiles/r*_mfma_busy.json
     (tools/pmc_mfma.py on a `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE` pass) -> (fraction, file) or (None, None)"""
     import glob
@@ -57,8 +57,8 @@ def measured_mfma_busy(key):
                 e = json.load(f).get(key)
         except (OSError, ValueError):
             continue
-        if e:
-            return e["mfma_busy"], os.path.relpath(path, ROOT)
+        if e and field in e:
+            return e[field], os.path.relpath(path, ROOT)
     return None, None
 
 
@@ -172,7 +172,10 @@ def bench_decode(device, N=10, B=256, dtype="bfloat16", reps=3):
     from ralf_amd.helpers.task import get_condition
     from ralf_amd.synthetic import make_batch
 
-    out = {"batch": B, "tokens_per_sample": 5 * N, "note": "sample() incl. H2D of the image batch and host-side token decoding; graph_ms = the captured device loop alone"}
+    out = {"batch": B, "tokens_per_sample": 5 * N,
+           "note": "sample() incl. H2D of the image batch and host-side token decoding; graph_ms = the captured device loop alone; hbm_frac = the "
+                   "loop's unavoidable stream (the cross-attention K/V cache of 6 layers, read once per generated token) / graph_ms / 8 TB/s: the "
+                   "whole-loop lower bound on the memory side (the cross-attention kernel itself runs at 0.62 of peak, profiles/*_decode_kernel_stats.txt)"}
     for task in ("c", "cwh"):
         model = build_model(device, N, dtype, task).eval()
         cond, _ = get_condition(make_batch(B, N, seed=9), task, model.tokenizer)
@@ -193,7 +196,7 @@ def bench_decode(device, N=10, B=256, dtype="bfloat16", reps=3):
             M = dec._static["enc"]["seq_layout_const"].shape[1] + 2 * 256 + 16
             kv_bytes = 6 * B * M * 512 * 2 * 5 * N
             out[f"{task}_{name}"] = {"ms_per_batch": t * 1e3, "ms_per_sample": t * 1e3 / B, "tokens_per_s": B * 5 * N / t, "graph_ms": tg * 1e3,
-                                     "cross_kv_cache_TBps": kv_bytes / tg / 1e12}
+                                     "cross_kv_cache_TBps": kv_bytes / tg / 1e12, "hbm_frac": kv_bytes / tg / 1e9 / PEAK_HBM_GBS}
         del model
     return out
 
@@ -453,6 +456,7 @@ def main():
         loss = step(inputs, targets)
     if not a.no_graph:   # the batch lives in the buffers the captured graphs read (a loader writes the next batch in place)
         inputs, targets = step.static_batch()
+    nonpad = int((targets["seq"] != model.tokenizer.name_to_id("pad")).sum().item()) + B   # target tokens that are not padding, + BOS
     torch.cuda.synchronize()
     if a.profile_pause > 0:
         time.sleep(a.profile_pause)
@@ -493,7 +497,6 @@ def main():
                    "allreduce_ms_standalone": x0.elapsed_time(x1) / 5, "staged_backward": bool(step.staged),
                    "bytes_exchanged_during_stage2": step.exchange.bytes_on_wire(step._early) if step.staged else 0}
     tokens = B * (5 * N + 1)
-    nonpad = int((targets["seq"] != model.tokenizer.name_to_id("pad")).sum().item()) + B   # target tokens that are not padding, + BOS
     final_loss = float(loss)
 
     if rank == 0:
@@ -516,7 +519,13 @@ def main():
         mb, mf = measured_mfma_busy("train_step_B64_N10_bf16") if (B == 64 and N == 10 and a.dtype.startswith("b")) else (None, None)
         if mb is not None:
             out["roofline"]["mfma_busy"] = mb
-            out["roofline"]["note"] += f"; mfma_busy = {mb:.3f} of the SIMD-cycles (PMC SQ_VALU_MFMA_BUSY_CYCLES, {mf})"
+            out["roofline"]["note"] += (f"; mfma_busy = {mb:.3f} = SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles with a kernel resident, from an EAGER pass with "
+                                        f"per-dispatch counter collection ({mf}: a lower bound -- the collection stretches every dispatch)")
+            cyc = measured_mfma_busy("train_step_B64_N10_bf16", "mfma_busy_cycles_per_step")[0]
+            if cyc:
+                out["roofline"]["mfma_pipe_frac_at_max_clock"] = cyc / (1024 * 2.4e9 * gpu_ms * 1e-3)
+                out["roofline"]["note"] += (f"; the same pass counts {cyc:.3e} MFMA-busy cycles per step = {cyc / 32 * 32768 / 1e12:.2f} TFLOP issued (tile padding "
+                                            f"included) = {cyc / (1024 * 2.4e9 * gpu_ms * 1e-3):.3f} of the 1024 matrix pipes' cycles at 2.4 GHz over this run's step time")
         tb, te = measured_traffic("train_step_B64_N10_bf16") if (B == 64 and N == 10 and a.dtype.startswith("b")) else (None, None)
         if tb:   # the same step seen from the memory side (measured PMC bytes / measured time)
             out["roofline"]["traffic"] = tb
@@ -548,7 +557,10 @@ def main():
                                    "whole_call_frac": {f"nq{q}": out["knn"][f"nq{q}"]["hbm_frac"] for q in (1, 16, 32)},
                                    "note": "dominant kernel knn_scores_kernel<16,1,2> at nq=16 (HBM-bound regime): 441.2 MB algorithmic bytes per launch (index 61548x1792 fp32 streamed once) / "
                                            f"{k16['scan_us']:.1f} us (HIP events); whole call incl. select+merge {k16['us_per_call']:.1f} us = {k16['hbm_frac']:.3f} of peak; "
-                                           "nq=1024 is fp32-FLOP-bound (see knn.nq1024); traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, " + (ke["file"] if ke else "no committed profile")}
+                                           "nq=1024 is fp32-FLOP-bound when scanned exhaustively (knn.nq1024: 2.9x the algorithmic traffic, 0.6 of the fp32-matrix peak); "
+                                           "the index front end (retrieval.FlatIPIndex.search) therefore routes batches of >= 256 queries to the two-stage search "
+                                           "(knn.nq1024_two_stage: identical results, checked in this run); traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
+                                           + (ke["file"] if ke else "no committed profile")}
         if world == 1 and not a.skip_decode:
             out["decode"] = bench_decode(device, N)
         if world == 1 and not a.skip_variants and B == 64 and N == 10:

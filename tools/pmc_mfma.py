@@ -27,16 +27,16 @@ def main(db, out, header, steps):
             m, g = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), d.get("GRBM_GUI_ACTIVE", 0.0)
             name = re.sub(r"\(anonymous namespace\)::|void ", "", k)[:86]
             f.write(f"{name:86s} {d['n']:6d} {m:15.0f} {g:15.0f} {100 * m / max(g / 8 * 1024, 1):8.2f}% {100 * g / max(tot_g, 1):9.2f}%\n")
-    return tot_m / max(tot_g / 8 * 1024, 1)
+    return tot_m / max(tot_g / 8 * 1024, 1), tot_m / steps
 
 
 if __name__ == "__main__":
-    frac = main(sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]))
+    frac, cyc = main(sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]))
     print("mfma_busy", frac)
     if len(sys.argv) > 6:      # json file, key: the figure bench.py quotes in its roofline note
         import json
         import os
         path, key = sys.argv[5], sys.argv[6]
         d = json.load(open(path)) if os.path.exists(path) else {}
-        d[key] = {"mfma_busy": frac, "source": os.path.basename(sys.argv[2]), "command": sys.argv[3].lstrip("# ")}
+        d[key] = {"mfma_busy": frac, "mfma_busy_cycles_per_step": cyc, "source": os.path.basename(sys.argv[2]), "command": sys.argv[3].lstrip("# ")}
         json.dump(d, open(path, "w"), indent=1)
