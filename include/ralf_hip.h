@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 13
+#define RALF_ABI_VERSION 14
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -331,6 +331,42 @@ int ralf_decode_attn(const RalfDecodeAttnDesc* d, void* stream);
 /* most keys (cached rows, + the new one when self_) ralf_decode_attn accepts: its scores live in LDS.  Callers with longer memories
  * (2*h*w + K + Lc rows: e.g. 512x512 canvases) use ralf_layernorm_fwd + ralf_gemm + ralf_attention_fwd instead. */
 int ralf_decode_attn_max_keys(void);
+
+/* Pre-norm transformer layers (forward, training) of SHORT sequences (ralf_amd/csrc/tlayer.hip): a workgroup per sample keeps its
+ * S <= RALF_TLAYER_MAX_ROWS rows in LDS from a LayerNorm to the end of the block chain.  bf16, d = 256, 8 heads, ff = 1024:
+ *   x1  = x  + drop(attn(LN1(x))      Wo^T  + bo)            self-attention (causal and / or key-padding mask)        parts 0, 1
+ *   q   = LN2(x1) Wq^T + bq                                   the cross-attention's queries                            part 1
+ *   x2  = x1 + drop(o2 Wo2^T + bo2)                           o2 = ralf_attention_fwd(q, memory k | v), run by the caller between parts 1 and 2   part 2
+ *   out = r  + drop(W2 drop(relu(W1 LN3(r) + b1)) + b2)      r = x2 (part 2) or x1 (part 0)                          parts 0, 2
+ * part 0 = a whole nn.TransformerEncoderLayer in one launch; parts 1 + ralf_attention_fwd + 2 = nn.TransformerDecoderLayer in three
+ * (norm_first; image2layout/train/models/common/common.py:25-34,84-135,216-226), instead of the 7 (12) launches of ralf_layernorm_fwd /
+ * ralf_gemm / ralf_attention_fwd, with the SAME arithmetic and dropout masks (call ids = the RalfGemmDesc.call_id / RalfAttnDesc.call_id
+ * of those launches) and every tensor their backward passes read written on the way -- the backward is the unfused one.
+ *   weights: bf16 in FRAGMENT ORDER (ralf_tlayer_pack of the row-major [n_out, n_in] matrix; w_q = the first 256 rows of the cross-attention's
+ *   in_proj_weight); biases and LayerNorm parameters fp32; activations bf16 [B*S, width]; statistics fp32 [B*S]; lse fp32 [B, 8, S];
+ *   kpm uint8 [B, kpm_bs] or NULL; seed int64[1] on the device (needed when a dropout probability is > 0) */
+#define RALF_TLAYER_MAX_ROWS 64
+typedef struct RalfTLayerDesc {
+    const void* x;
+    const float* ln1_g; const float* ln1_b; const void* w_in; const float* b_in; const void* w_o; const float* b_o;
+    const uint8_t* kpm;
+    const float* ln2_g; const float* ln2_b; const void* w_q; const float* b_q; const void* o2; const void* w_o2; const float* b_o2;
+    const float* ln3_g; const float* ln3_b; const void* w1; const float* b1; const void* w2; const float* b2;
+    void* h1; float* mean1; float* rstd1; void* qkv; void* o1; float* lse1; void* x1;   /* x1: output of parts 0, 1; input of part 2 */
+    void* h2; float* mean2; float* rstd2; void* q; void* x2;
+    void* h3; float* mean3; float* rstd3; void* hid; void* out;
+    const int64_t* seed;
+    uint64_t call_attn1, call_out1, call_out2, call_ffn1, call_ffn2;
+    int64_t kpm_bs; /* row stride of kpm in bytes */
+    int B, S, causal, part;
+    float scale, p_attn, p_res, eps;
+} RalfTLayerDesc;
+int ralf_tlayer_fwd(const RalfTLayerDesc* d, void* stream);
+/* weights -> the fragment order ralf_tlayer_fwd streams: for the 32-row tile t and the 16-wide k-slice i of src [N][K] (row stride ld
+ * elements), the 64 lanes' MFMA operands (lane (r, half) = src[32 t + r][16 i + 8 half .. + 7]) become 1 KiB of consecutive memory at
+ * dst + ((t * K/16 + i) * 64 + lane) * 8 elements.  N % 32 == 0, K % 16 == 0; up to 48 matrices per launch (jobs is a HOST array). */
+typedef struct RalfPackJob { const void* src; void* dst; int64_t ld; int N, K; } RalfPackJob;
+int ralf_tlayer_pack(const RalfPackJob* jobs, int njobs, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer (ralf_amd/csrc/optim.hip): clip_grad_norm_ + AdamW on flat fp32 buffers

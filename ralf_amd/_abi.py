@@ -28,6 +28,23 @@ class RalfDecodeAttnDesc(ctypes.Structure):
                 + [(n, i32) for n in ("B", "H", "d", "Sk", "self_")] + [("scale", f32), ("eps", f32)])
 
 
+class RalfTLayerDesc(ctypes.Structure):
+    _fields_ = ([(n, vp) for n in ("x", "ln1_g", "ln1_b", "w_in", "b_in", "w_o", "b_o", "kpm",
+                                   "ln2_g", "ln2_b", "w_q", "b_q", "o2", "w_o2", "b_o2",
+                                   "ln3_g", "ln3_b", "w1", "b1", "w2", "b2",
+                                   "h1", "mean1", "rstd1", "qkv", "o1", "lse1", "x1",
+                                   "h2", "mean2", "rstd2", "q", "x2",
+                                   "h3", "mean3", "rstd3", "hid", "out", "seed")]
+                + [(n, ctypes.c_uint64) for n in ("call_attn1", "call_out1", "call_out2", "call_ffn1", "call_ffn2")]
+                + [("kpm_bs", i64)]
+                + [(n, i32) for n in ("B", "S", "causal", "part")]
+                + [(n, f32) for n in ("scale", "p_attn", "p_res", "eps")])
+
+
+class RalfPackJob(ctypes.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("ld", i64), ("N", i32), ("K", i32)]
+
+
 class RalfBnFoldJob(ctypes.Structure):
     _fields_ = [(n, vp) for n in ("gamma", "beta", "mean", "var", "scale", "shift")] + [("C", i32), ("pad_", i32)]
 
@@ -125,6 +142,8 @@ SIGNATURES.update({
     "ralf_attention_bwd": (i32, [ctypes.POINTER(RalfAttnDesc), vp]),
     "ralf_decode_attn": (i32, [ctypes.POINTER(RalfDecodeAttnDesc), vp]),
     "ralf_decode_attn_max_keys": (i32, []),
+    "ralf_tlayer_fwd": (i32, [ctypes.POINTER(RalfTLayerDesc), vp]),
+    "ralf_tlayer_pack": (i32, [ctypes.POINTER(RalfPackJob), i32, vp]),
     "ralf_sumsq": (i32, [vp, i64, vp, vp]),
     "ralf_clip_coef": (i32, [vp, f32, vp, vp, vp]),
     "ralf_sumsq_partials": (i32, [vp, i64, vp, vp]),

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
                 float ls = 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { p[j] = __builtin_amdgcn_exp2f(p[j] - mref); ls += p[j]; }
-                l = l * corr + xor_sum(ls);
+                l = __fmaf_rn(l, corr, xor_sum(ls));   // (explicit: tlayer.hip must write the same bits)
                 m = mn;
                 bf16x8 pf;
                 if (d.p_drop > 0.f) {
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
             for (int r = 0; r < 4; ++r) t[r] = (bf16)(o[c][r] * inv);
             *reinterpret_cast<bf16x4*>(Op + c * 16 + 4 * g) = t;
         }
-        if (d.lse && g == 0) d.lse[((int64_t)b * d.H + h) * d.Sq + qi] = m * 0.6931471805599453f + __logf(l);
+        if (d.lse && g == 0) d.lse[((int64_t)b * d.H + h) * d.Sq + qi] = __fmaf_rn(m, 0.6931471805599453f, __logf(l));   // (explicit fma: tlayer.hip must write the same bits)
     }
 }
 

@@ -29,6 +29,39 @@ inline int check_launch(const char* what) {
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Element dropout mask (GEMM epilogues, ralf_dropout, ralf_scale_pe_dropout, the LayerNorm backward's masked gradient, tlayer.hip):
+//   keep(e) = 16-bit field (e & 3) of drop_hash4(seed, call, e >> 2) >= p * 2^16
+// ONE 64-bit counter hash (splitmix64 finaliser) decides FOUR consecutive elements of the contiguous tensor.  The kernels hold 4 or 8
+// consecutive elements per lane, so the hash -- three 64-bit multiplies = ~25 quarter-rate 32-bit multiplies, ~120-180 cycles per call
+// measured in the transformer-layer kernel (tools/tlayer_probe.hip: a quarter of its run time with one hash per element) -- runs once per
+// four elements.  p is quantised to 1 / 65536 (0.1 -> 0.099991); the kept elements are scaled by 1 / (1 - p) with the nominal p.
+__device__ __forceinline__ uint64_t drop_hash4(uint64_t seed, uint64_t call, uint64_t group) {
+    uint64_t z = seed + call * 0x9E3779B97F4A7C15ull + group * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint32_t drop_thr16(float p) { return (uint32_t)(p * 65536.f); }
+__device__ __forceinline__ bool drop_keep(uint64_t h, int field, uint32_t thr16) { return ((uint32_t)(h >> (16 * field)) & 0xffffu) >= thr16; }
+__device__ __forceinline__ bool drop_keep1(uint64_t seed, uint64_t call, uint64_t e, uint32_t thr16) {
+    return drop_keep(drop_hash4(seed, call, e >> 2), (int)(e & 3), thr16);
+}
+// W (4 or 8) consecutive elements starting at e0: v[q] = keep ? v[q] * inv : 0
+template <int W>
+__device__ __forceinline__ void drop_apply(float (&v)[W], uint64_t seed, uint64_t call, uint64_t e0, uint32_t thr16, float inv) {
+    if ((e0 & 3) == 0 && W % 4 == 0) {
+#pragma unroll
+        for (int g = 0; g < W / 4; ++g) {
+            const uint64_t h = drop_hash4(seed, call, (e0 >> 2) + g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[4 * g + q] = drop_keep(h, q, thr16) ? v[4 * g + q] * inv : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < W; ++q) v[q] = drop_keep1(seed, call, e0 + q, thr16) ? v[q] * inv : 0.f;
+    }
+}
+
 // Attention-probability dropout mask (all attention kernels, forward and backward, VALU and MFMA variants):
 // keep(b, h, q, key) = attn_rng24(attn_rowkey(seed, call, (b*H + h)*Sq + q), key) >= p * 2^24.
 // The 64-bit mix runs once per query ROW (lane-invariant in the per-query kernels, staged through LDS in the per-key

@@ -110,14 +110,7 @@ template <> struct TT<bf16> {
     static constexpr int RPAD = 8;    // [64][rows + 8 pad]
 };
 
-// same counter-based generator as pointwise.hip / attention*.hip (masks must agree with ralf_dropout)
-__device__ __forceinline__ uint32_t rng24(uint64_t seed, uint64_t call, uint64_t idx) {
-    uint64_t z = seed + call * 0x9E3779B97F4A7C15ull + idx * 0xD1B54A32D192ED03ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (uint32_t)(z >> 40);
-}
+// (the epilogue dropout mask: drop_hash4 / drop_apply, common.h -- shared with ralf_dropout, the LayerNorm backward and tlayer.hip)
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad(float x) {
@@ -144,8 +137,7 @@ __device__ __forceinline__ void epilogue_store(const RalfGemmDesc& d, int z0, in
     if (d.act == RALF_ACT_RELU) v = v > 0.f ? v : 0.f;
     else if (EPI >= 2 && d.act == RALF_ACT_GELU) v = gelu_f(v);
     if (EPI >= 1 && d.drop_p > 0.f) {  // element index = m*N + n of the contiguous [M,N] output (single batch)
-        const uint32_t thr = (uint32_t)(d.drop_p * 16777216.f);
-        v = rng24((uint64_t)d.seed[0], d.call_id, (uint64_t)m * d.N + n) >= thr ? v * (1.f / (1.f - d.drop_p)) : 0.f;
+        v = drop_keep1((uint64_t)d.seed[0], d.call_id, (uint64_t)m * d.N + n, drop_thr16(d.drop_p)) ? v * (1.f / (1.f - d.drop_p)) : 0.f;
     }
     if (EPI >= 1 && d.aux) {
         const float a = ldf<T>(d.aux, coff);
@@ -235,11 +227,7 @@ __device__ __forceinline__ void epilogue_storev(const RalfGemmDesc& d, int z0, i
         for (int q = 0; q < W; ++q) v[q] = gelu_f(v[q]);
     }
     if (EPI >= 1 && d.drop_p > 0.f) {
-        const uint32_t thr = (uint32_t)(d.drop_p * 16777216.f);
-        const float inv = 1.f / (1.f - d.drop_p);
-        const uint64_t sd = (uint64_t)d.seed[0], e0 = (uint64_t)m * d.N + n;
-#pragma unroll
-        for (int q = 0; q < W; ++q) v[q] = rng24(sd, d.call_id, e0 + q) >= thr ? v[q] * inv : 0.f;
+        drop_apply<W>(v, (uint64_t)d.seed[0], d.call_id, (uint64_t)m * d.N + n, drop_thr16(d.drop_p), 1.f / (1.f - d.drop_p));
     }
     if (EPI >= 1 && d.aux) {
         float a[W];

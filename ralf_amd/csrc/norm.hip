@@ -59,15 +59,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const float d = v[c][i] - mu; q += d * d; }
-        const float rs = rsqrtf(wave_sum(q) * (1.f / cols) + eps);
+            for (int i = 0; i < 4; ++i) { const float d = v[c][i] - mu; q = __fmaf_rn(d, d, q); }   // (explicit fma here and below: tlayer.hip writes the same bits)
+        const float rs = rsqrtf(__fmaf_rn(wave_sum(q), 1.f / cols, eps));
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             float g[4], b[4], o[4];
             V4<float>::load(gamma + c * 256 + lane * 4, g);
             V4<float>::load(beta + c * 256 + lane * 4, b);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = (v[c][i] - mu) * rs * g[i] + b[i];
+            for (int i = 0; i < 4; ++i) o[i] = __fmaf_rn((v[c][i] - mu) * rs, g[i], b[i]);
             V4<T>::store(y + (int64_t)row * cols + c * 256 + lane * 4, o);
         }
         if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
@@ -78,15 +78,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // 16 waves per workgroup, two rows in flight per wave: the kernel is latency-bound otherwise (a wave
 // walking 16 rows one after the other reached 1.2 TB/s), and fat workgroups keep the atomic count at
 // 2*cols per CU.
-// same counter-based generator as pointwise.hip / gemm_impl.h (the masks must agree with ralf_dropout)
-__device__ __forceinline__ uint32_t ln_rng24(uint64_t seed, uint64_t call, uint64_t idx) {
-    uint64_t z = seed + call * 0x9E3779B97F4A7C15ull + idx * 0xD1B54A32D192ED03ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (uint32_t)(z >> 40);
-}
-
 // dx_drop (optional): a second output = dropout mask (seed, call, p) applied to dx.  dx is the gradient of the residual stream in
 // front of this norm; the block that produced that stream is `x_prev + dropout(f(..))`, so its backward starts by masking dx --
 // here, while dx is in registers, instead of in a launch of its own.
@@ -154,13 +145,14 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const T* __restr
                 V4<T>::store(dx + (int64_t)(row0 + r) * cols + c * 256 + lane * 4, o);
                 if (dx_drop) {
                     const uint64_t e0 = (uint64_t)(row0 + r) * cols + c * 256 + lane * 4, sd = (uint64_t)seed[0];
-                    const uint32_t thr = (uint32_t)(p_drop * 16777216.f);
+                    const uint32_t thr = drop_thr16(p_drop);
                     const float inv = 1.f / (1.f - p_drop);
+                    const uint64_t hh = drop_hash4(sd, call, e0 >> 2);   // (e0 is a multiple of 4: one hash for the lane's 4 columns, common.h)
                     float m[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         // (mask the value as ralf_dropout would see it: rounded to T first)
-                        m[i] = ln_rng24(sd, call, e0 + i) >= thr ? (float)(T)o[i] * inv : 0.f;
+                        m[i] = drop_keep(hh, i, thr) ? (float)(T)o[i] * inv : 0.f;
                     }
                     V4<T>::store(dx_drop + (int64_t)(row0 + r) * cols + c * 256 + lane * 4, m);
                 }

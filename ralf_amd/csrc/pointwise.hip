@@ -68,10 +68,10 @@ __global__ void embed_bwd_kernel(const int64_t* __restrict__ idx, const T* __res
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, int64_t n, float p, const int64_t* __restrict__ seed, uint64_t call) {
     const uint64_t s = p > 0.f ? (uint64_t)seed[0] : 0;
-    const uint32_t thr = (uint32_t)(p * 16777216.f);
+    const uint32_t thr = drop_thr16(p);
     const float inv = 1.f / (1.f - p);
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-        float v = (p <= 0.f || rng24(s, call, (uint64_t)e) >= thr) ? ld(x, e) * inv : 0.f;
+        float v = (p <= 0.f || drop_keep1(s, call, (uint64_t)e, thr)) ? ld(x, e) * inv : 0.f;
         if (res) v += ld(res, e);
         st(y, e, v);
     }
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void scale_pe_drop_kernel(const T* __restrict_
     const int vpr = d / VEC;
     const int64_t nvec = rows * vpr;
     const uint64_t sd = p > 0.f ? (uint64_t)seed[0] : 0;
-    const uint32_t thr = (uint32_t)(p * 16777216.f);
+    const uint32_t thr = drop_thr16(p);
     const float inv = 1.f / (1.f - p);
     for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
         const int64_t row = v / vpr;
@@ -253,10 +253,15 @@ __global__ __launch_bounds__(256) void scale_pe_drop_kernel(const T* __restrict_
         T tmp[VEC];
         *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(x + v * VEC);
         const float* pr = pe ? pe + (row % S) * d + c : nullptr;
+        uint64_t hh[VEC / 4];
+        if (p > 0.f) {
+#pragma unroll
+            for (int g = 0; g < VEC / 4; ++g) hh[g] = drop_hash4(sd, call, (uint64_t)(v * (VEC / 4) + g));   // (one hash per 4 elements: common.h)
+        }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float f = (float)tmp[i] * scale + (pr ? pr[i] : 0.f);
-            if (p > 0.f) f = rng24(sd, call, (uint64_t)(v * VEC + i)) >= thr ? (float)(T)f * inv : 0.f;   // mask the value as stored (ralf_dropout semantics)
+            if (p > 0.f) f = drop_keep(hh[i / 4], i & 3, thr) ? (float)(T)f * inv : 0.f;   // mask the value as stored (ralf_dropout semantics)
             tmp[i] = (T)f;
         }
         *reinterpret_cast<uint4*>(y + v * VEC) = *reinterpret_cast<uint4*>(tmp);

@@ -1,0 +1,534 @@
+// One launch per pre-norm transformer layer (forward) for SHORT sequences: the causal decoder layers (S = 5N <= 64 tokens per sample,
+// self-attention + cross-attention over the memory + FFN) and the constraint-encoder layers (self-attention + FFN) of
+//   image2layout/train/models/common/common.py:25-34,84-135,216-226 (nn.TransformerDecoderLayer / nn.TransformerEncoderLayer, norm_first).
+// At B = 64 these layers are chains of 12 (7) launch-latency-bound kernels on 3 200 (256) rows each: ~100 us per decoder layer forward
+// for 0.3 us of matrix work.  Here ONE workgroup owns a sample: its <= 64 rows stay in LDS from LayerNorm to the layer's output, the
+// weights stream from L2 straight into MFMA operands (each lane loads the 16-byte k-slices of its own weight row, as gemm_skinny
+// does), and every tensor the unfused backward needs (LayerNorm outputs and statistics, qkv, attention outputs + lse, the FFN hidden) is
+// written out on the way -- the backward pass is unchanged.
+//
+// Arithmetic is that of the unfused kernels at the same rounding points (bf16 after LayerNorm, after every GEMM epilogue, after the
+// attention; fp32 accumulation in k order; the same counter-based dropout masks), so the fused forward reproduces them bit for bit:
+//   LayerNorm            = norm.hip ln_fwd_kernel (wave per row, lane owns 4 columns)
+//   linear layers        = gemm_impl.h (32x32x16 MFMA chains in ascending k, epilogue order bias -> act -> dropout -> residual)
+//   attention            = attention_mfma.hip attn_fwd_mfma (transposed 16x16x32 formulation, 32-key steps, log2-domain softmax)
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+constexpr int TD = 256, TH = 8, TDH = 32, TFF = 1024, TS = 64;
+constexpr int LDA = TD + 8;          // [64][264] activation strip: 528-byte rows = 4 banks apart, conflict-free ds_read_b128 over 16 rows
+constexpr int LDQ = 3 * TD + 8;      // [64][776] q | k | v strip (1552-byte rows: the same 4-bank shift)
+constexpr int NW = 8, NT = 512;
+constexpr int BUFA_ELEMS = TS * LDA;                 // 33 792 B
+constexpr int BUFB_ELEMS = 3 * TS * LDA;             // 101 376 B: the qkv strip (99 328 B) | Q + K tile + V tile | one FFN hidden chunk
+constexpr int LDS_BYTES = (BUFA_ELEMS + BUFB_ELEMS) * 2 + 64 + 16;
+
+// workgroup barrier for LDS hand-overs only: waits for this wave's LDS traffic, NOT for its global loads and stores -- the weight fragments
+// requested for the next tile stay in flight across it, and the stores of the tensors kept for the backward pass drain in the background
+// (__syncthreads() = a release / acquire fence: s_waitcnt vmcnt(0) at every phase boundary, ~2 k cycles each).  No thread of this kernel
+// reads global memory another thread of it wrote.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float xor_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ __forceinline__ float xor_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+
+// tools/tlayer_probe.hip builds this file with -DRALF_TLAYER_PROBE: s_memtime stamps per workgroup at the phase boundaries
+#ifdef RALF_TLAYER_PROBE
+__device__ unsigned long long tlayer_probe_buf[16 * 4096];
+#define TL_PROBE(i)                                                                                                     \
+    do {                                                                                                                \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) tlayer_probe_buf[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define TL_PROBE(i)
+#endif
+
+// ---- row pass: one wave per row (rows wave, wave + 8, ..), lane l owns columns 4l .. 4l+3 (norm.hip ln_fwd_kernel's assignment) ----
+//   value  = STAGE ? bf16(stage[row][..] (fp32, LDS) + res[row][..]) : res[row][..]        (the GEMM epilogue's residual add and rounding)
+//   XOUT:    value -> xout (global, 512 contiguous bytes per row)
+//   LN:      LayerNorm(value) -> dst (LDS, rows >= S zero) + hout (global) + mean / rstd
+// All of a wave's global rows are requested before the first is used (a wave owns 8 rows: one latency, not eight).
+constexpr int STG_LD = TD + 4;   // fp32 staging rows of 1040 bytes
+template <bool STAGE, bool XOUT, bool LN>
+__device__ __forceinline__ void row_pass(const float* stage, const bf16* __restrict__ res, bf16* __restrict__ xout, int S, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, float eps, bf16* dst, bf16* __restrict__ hout, float* __restrict__ mean,
+                                         float* __restrict__ rstd, int wave, int lane) {
+    float g[4], bb[4];
+    if (LN) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { g[i] = gamma[lane * 4 + i]; bb[i] = beta[lane * 4 + i]; }
+    }
+    constexpr int NR = TS / NW;   // 8 rows per wave, processed TOGETHER: the two butterfly reductions per row are chains of 6 dependent cross-lane
+                                  // reads each; row after row they cost ~10 k cycles per pass (s_memtime), interleaved over the rows one chain's latency
+    bf16x4 rr[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int row = wave + k * NW;
+        rr[k] = *reinterpret_cast<const bf16x4*>(res + (int64_t)(row < S ? row : 0) * TD + lane * 4);
+    }
+    float v[NR][4];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int row = wave + k * NW;
+        if (STAGE) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(stage + row * STG_LD + lane * 4);
+            bf16x4 t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = (bf16)(a[i] + (float)rr[k][i]);
+            if (XOUT && row < S) *reinterpret_cast<bf16x4*>(xout + (int64_t)row * TD + lane * 4) = t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[k][i] = (float)t[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[k][i] = (float)rr[k][i];
+        }
+    }
+    if (!LN) return;
+    float s1[NR], s2[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) s1[k] = v[k][0] + v[k][1] + v[k][2] + v[k][3];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < NR; ++k) s1[k] += __shfl_xor(s1[k], o);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        s1[k] *= (1.f / TD);   // mean
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float dd = v[k][i] - s1[k]; q = __fmaf_rn(dd, dd, q); }   // (explicit fma here and in ln_fwd_kernel: same bits)
+        s2[k] = q;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < NR; ++k) s2[k] += __shfl_xor(s2[k], o);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int row = wave + k * NW;
+        const float mu = s1[k], rs = rsqrtf(__fmaf_rn(s2[k], 1.f / TD, eps));
+        bf16x4 ov;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ov[i] = row < S ? (bf16)__fmaf_rn((v[k][i] - mu) * rs, g[i], bb[i]) : (bf16)0.f;
+        if (row < S) {
+            *reinterpret_cast<bf16x4*>(hout + (int64_t)row * TD + lane * 4) = ov;
+            if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+        }
+        *reinterpret_cast<bf16x4*>(dst + row * LDA + lane * 4) = ov;
+    }
+}
+// LDS rows [S][WIDTH] (leading dimension ld) -> global rows (leading dimension gld): 16 bytes per lane, row-contiguous
+template <int WIDTH>
+__device__ __forceinline__ void copy_out(const bf16* src, int ld, bf16* __restrict__ dstg, int64_t gld, int S, int tid) {
+    constexpr int VPR = WIDTH / 8;
+    for (int e = tid; e < S * VPR; e += NT) {
+        const int r = e / VPR, c = e % VPR;
+        *reinterpret_cast<uint4*>(dstg + (int64_t)r * gld + c * 8) = *reinterpret_cast<const uint4*>(src + r * ld + c * 8);
+    }
+}
+// global rows [S][256] -> LDS strip [64][LDA] (rows >= S zero)
+__device__ __forceinline__ void copy_in(bf16* dst, const bf16* __restrict__ srcg, int S, int tid) {
+    constexpr int VPR = TD / 8;
+#pragma unroll
+    for (int i = 0; i < TS * VPR / NT; ++i) {
+        const int e = tid + NT * i, r = e / VPR, c = e % VPR;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (r < S) v = *reinterpret_cast<const uint4*>(srcg + (int64_t)r * TD + c * 8);
+        *reinterpret_cast<uint4*>(dst + r * LDA + c * 8) = v;
+    }
+}
+
+// ---- one 64 x 32 output tile of  A[64][256] (LDS, k-contiguous, leading dimension lda) x W[n0 .. n0+31][k0 .. k0+255]^T (global) ----
+// The matrix core computes the TRANSPOSED tile (weights as the row operand), so accumulator register r of lane (l31, lh) is
+// (row m = l31 [+32], column n0 + (r & 3) + 8 (r >> 2) + 4 lh): four consecutive columns per register group, as in gemm_impl.h.
+// Weights arrive PACKED in fragment order (ralf_tlayer_pack): for the 32-row tile t and the 16-wide k-slice i of a [N][K] matrix, the 64 lanes'
+// 16-byte operands (lane (l31, lh) = W[32 t + l31][16 i + 8 lh .. + 7]) are 1 KiB of consecutive memory, so one load instruction of a wave
+// is one contiguous KiB.  (Each lane reading its own row of the row-major matrix -- 64 different cache lines per instruction, 16 bytes used
+// of each -- ran the whole layer at the request rate of the vector memory pipeline: 12-15 k cycles per 32-column tile, s_memtime stamps.)
+// The fragments live in registers (16 k-slices = 64 VGPRs); while a tile's matrix work consumes one half, the freed half is refilled with the
+// NEXT tile's (`next`: that tile's lane pointer, or null), so the L2 latency of the weight stream hides under the previous tile's work.
+struct WFrag { bf16x8 v[16]; };
+__device__ __forceinline__ const bf16* w_ptr(const bf16* __restrict__ Wp, int kslices, int tile, int slice0, int lane) {
+    return Wp + ((int64_t)tile * kslices + slice0) * 512 + lane * 8;
+}
+__device__ __forceinline__ void load_w_half(WFrag& w, int half, const bf16* __restrict__ p) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w.v[half * 8 + i] = *reinterpret_cast<const bf16x8*>(p + (half * 8 + i) * 512);
+}
+__device__ __forceinline__ void load_w(WFrag& w, const bf16* __restrict__ p) { load_w_half(w, 0, p); load_w_half(w, 1, p); }
+__device__ __forceinline__ void tile_mma(f32x16 (&acc)[2], const bf16* A, int lda, WFrag& w, const bf16* __restrict__ next, int lane) {
+    const bf16* a0 = A + (lane & 31) * lda + (lane >> 5) * 8;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int i = half * 8; i < half * 8 + 8; ++i) {
+            const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(a0 + i * 16);
+            const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(a0 + 32 * lda + i * 16);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v[i], x0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v[i], x1, acc[1], 0, 0, 0);
+        }
+        if (next) load_w_half(w, half, next);
+    }
+}
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+}
+// epilogue walker: f(row m in 0..63, first column n of 4 consecutive ones, values v[4])
+template <typename F>
+__device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[2], int n0, int lane, F&& f) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4] = {acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+            f(i * 32 + (lane & 31), n0 + 8 * g + 4 * (lane >> 5), v);
+        }
+}
+__device__ __forceinline__ bf16x4 to_bf16x4(const float (&v)[4]) {
+    bf16x4 t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = (bf16)v[q];
+    return t;
+}
+// GEMM-epilogue dropout on 4 consecutive elements of a contiguous [rows][N] output (ralf_dropout's mask: common.h)
+__device__ __forceinline__ void drop4(float (&v)[4], float p, uint64_t seed, uint64_t call, uint64_t e0) {
+    if (p > 0.f) drop_apply<4>(v, seed, call, e0, drop_thr16(p), 1.f / (1.f - p));
+}
+
+// ---- attention of ONE head by ONE wave over keys / values staged in LDS (attn_fwd_mfma's arithmetic) ----
+// qt: query rows [64][ldq] at the head's columns; kt / vt: key / value rows [nkeys_staged][ldk] at the head's columns; Ms: per staged key
+// 1 = masked.  State (m, l, o) per 16-query group lives in the caller (the cross-attention streams several key tiles).
+struct AttnState { float m[4], l[4]; f32x4 o[4][2]; };
+__device__ __forceinline__ void attn_init(AttnState& st) {
+#pragma unroll
+    for (int qg = 0; qg < 4; ++qg) {
+        st.m[qg] = -__builtin_inff(); st.l[qg] = 0.f;
+        st.o[qg][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; st.o[qg][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+template <bool CAUSAL>
+__device__ __forceinline__ void attn_tile(AttnState& st, const bf16* qt, int ldq, const bf16* kt, const bf16* vt, int ldk, const uint8_t* Ms, bool tile_masked,
+                                          int t0, int Sk, int Sq, float scale2, float p_drop, const uint32_t (&rowkey)[4], int lane) {
+    const int g = lane >> 4, Ls = lane & 15;
+    const uint32_t thr = attn_thr16(p_drop);
+    const float inv_keep = 1.f / (1.f - p_drop);
+#pragma unroll
+    for (int qg = 0; qg < 4; ++qg) {
+        if (qg * 16 >= Sq) break;                        // (wave-uniform)
+        const int qi = qg * 16 + Ls;
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qt + (qg * 16 + Ls) * ldq + g * 8);
+        float m = st.m[qg], l = st.l[qg];
+#pragma unroll
+        for (int s0 = 0; s0 < TS; s0 += 32) {
+            if (t0 + s0 >= Sk) break;
+            if (CAUSAL && t0 + s0 > qg * 16 + 15) break;   // every key of this step lies beyond every query of the group
+            f32x4 s[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + (s0 + blk * 16 + Ls) * ldk + g * 8);
+                s[blk] = mfma16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f});
+            }
+            float p[8];
+            float mt = -__builtin_inff();
+            if (tile_masked || CAUSAL) {
+                const uint32_t mw[2] = {*reinterpret_cast<const uint32_t*>(Ms + s0 + 4 * g), *reinterpret_cast<const uint32_t*>(Ms + s0 + 16 + 4 * g)};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int key = t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3);
+                    const bool masked = ((mw[j >> 2] >> (8 * (j & 3))) & 0xffu) || (CAUSAL && key > qi);
+                    p[j] = masked ? -__builtin_inff() : s[j >> 2][j & 3] * scale2;
+                    mt = fmaxf(mt, p[j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { p[j] = s[j >> 2][j & 3] * scale2; mt = fmaxf(mt, p[j]); }
+            }
+            mt = xor_max(mt);
+            const float mn = fmaxf(m, mt);
+            const float mref = mn > -__builtin_inff() ? mn : 0.f;
+            const float corr = __builtin_amdgcn_exp2f(m - mref);
+            float ls = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { p[j] = __builtin_amdgcn_exp2f(p[j] - mref); ls += p[j]; }
+            l = __fmaf_rn(l, corr, xor_sum(ls));
+            m = mn;
+            bf16x8 pf;
+            if (p_drop > 0.f) {
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const uint32_t hh = attn_rng2x16(rowkey[qg], (uint32_t)(t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3)) >> 1);
+                    pf[j] = (bf16)((hh & 0xffffu) >= thr ? p[j] * inv_keep : 0.f);
+                    pf[j + 1] = (bf16)((hh >> 16) >= thr ? p[j + 1] * inv_keep : 0.f);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (bf16)p[j];
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                // V^T fragment: matrix rows = 16 columns (dims) of the value tile, k-slots = keys {s0+4g+j, s0+16+4g+(j-4)}
+                const bf16* q = vt + (s0 + 4 * g + (Ls >> 2)) * ldk + c * 16 + (Ls & 3) * 4;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 16 * ldk));
+                st.o[qg][c] *= corr;
+                st.o[qg][c] = mfma16(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), pf, st.o[qg][c]);
+            }
+        }
+        st.m[qg] = m; st.l[qg] = l;
+    }
+}
+// normalise a head's output into the O strip (LDS, [64][LDA]; rows >= Sq zero) + lse
+__device__ __forceinline__ void attn_finish(const AttnState& st, int Sq, int h, bf16* Os, float* __restrict__ lse, int lane) {
+    const int g = lane >> 4, Ls = lane & 15;
+#pragma unroll
+    for (int qg = 0; qg < 4; ++qg) {
+        const int qi = qg * 16 + Ls;
+        const float inv = 1.f / st.l[qg];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            bf16x4 t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = qi < Sq ? (bf16)(st.o[qg][c][r] * inv) : (bf16)0.f;
+            *reinterpret_cast<bf16x4*>(Os + qi * LDA + h * TDH + c * 16 + 4 * g) = t;
+        }
+        if (qi < Sq && g == 0) lse[qi] = __fmaf_rn(st.m[qg], 0.6931471805599453f, __logf(st.l[qg]));   // (as attn_fwd_mfma)
+    }
+}
+
+// PART 0: encoder layer (self-attention block + feed-forward block)
+// PART 1: decoder layer up to the cross-attention's queries (self-attention block, LayerNorm 2, q projection)
+// PART 2: decoder layer from the cross-attention's output (out-projection 2 + residual, LayerNorm 3, feed-forward block)
+// The cross-attention itself (S x M scores per head over a memory of hundreds of rows) is per-score VALU work that wants the whole chip, not the
+// B workgroups of this kernel: it stays ralf_attention_fwd between parts 1 and 2.
+template <int PART>
+__global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];   // ONE LDS object
+    bf16* bufA = reinterpret_cast<bf16*>(lds);              // the A operand of the running product: h1 | o1 | h2 | o2 | h3
+    bf16* bufB = bufA + BUFA_ELEMS;                         // q|k|v strip, fp32 epilogue staging, q, one hidden chunk
+    float* stage = reinterpret_cast<float*>(bufB);
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(bufB + BUFB_ELEMS);
+    int* flags = reinterpret_cast<int*>(Ms + 64);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, S = d.S;
+    const int64_t row0 = (int64_t)b * S;
+    const uint64_t seed = (d.p_attn > 0.f || d.p_res > 0.f) ? (uint64_t)d.seed[0] : 0;
+    WFrag w;
+    TL_PROBE(0);
+
+    const bf16* res_g;   // the residual stream the feed-forward block starts from
+    if constexpr (PART != 2) {
+        // ================= self-attention block: x1 = x + drop(attn(LN1(x)) Wo^T + bo) =================
+        const float scale2 = d.scale * 1.4426950408889634f;   // log2 domain
+        const bf16* xg = (const bf16*)d.x + row0 * TD;
+        load_w(w, w_ptr((const bf16*)d.w_in, 16, wave, 0, lane));
+        row_pass<false, false, true>(nullptr, xg, nullptr, S, d.ln1_g, d.ln1_b, d.eps, bufA, (bf16*)d.h1 + row0 * TD, d.mean1 + row0, d.rstd1 + row0, wave, lane);
+        if (tid < TS) {
+            const bool mk = tid >= S || (d.kpm && d.kpm[(int64_t)b * d.kpm_bs + tid]);
+            Ms[tid] = mk ? 1 : 0;
+            const unsigned long long any = __ballot(mk);
+            if (tid == 0) flags[0] = any != 0ull ? 1 : 0;
+        }
+        lds_barrier();
+        TL_PROBE(1);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {   // qkv = h1 Win^T + bin  -> LDS strip [64][LDQ]: wave h writes exactly head h's q, k and v columns
+            const int n0 = (t * NW + wave) * 32;
+            const bf16* next = t + 1 < 3 ? w_ptr((const bf16*)d.w_in, 16, (t + 1) * NW + wave, 0, lane) : w_ptr((const bf16*)d.w_o, 16, wave, 0, lane);
+            f32x16 acc[2];
+            zero_acc(acc);
+            tile_mma(acc, bufA, LDA, w, next, lane);
+            tile_epilogue(acc, n0, lane, [&](int m, int n, float (&v)[4]) {
+                const float4 bb = *reinterpret_cast<const float4*>(d.b_in + n);
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                *reinterpret_cast<bf16x4*>(bufB + m * LDQ + n) = to_bf16x4(v);
+            });
+        }
+        lds_barrier();
+        TL_PROBE(2);
+        copy_out<3 * TD>(bufB, LDQ, (bf16*)d.qkv + row0 * (3 * TD), 3 * TD, S, tid);
+        {   // wave = head: softmax(q k^T / sqrt(32) + masks) v, keys = the sample's own rows
+            const int h = wave;
+            AttnState st;
+            attn_init(st);
+            uint32_t rowkey[4];
+#pragma unroll
+            for (int qg = 0; qg < 4; ++qg)
+                rowkey[qg] = d.p_attn > 0.f ? attn_rowkey(seed, d.call_attn1, ((uint64_t)b * TH + h) * S + qg * 16 + (lane & 15)) : 0u;
+            const bool tm = flags[0] != 0;
+            if (d.causal) attn_tile<true>(st, bufB + h * TDH, LDQ, bufB + TD + h * TDH, bufB + 2 * TD + h * TDH, LDQ, Ms, tm, 0, S, S, scale2, d.p_attn, rowkey, lane);
+            else attn_tile<false>(st, bufB + h * TDH, LDQ, bufB + TD + h * TDH, bufB + 2 * TD + h * TDH, LDQ, Ms, tm, 0, S, S, scale2, d.p_attn, rowkey, lane);
+            attn_finish(st, S, h, bufA, d.lse1 + ((int64_t)b * TH + h) * S, lane);
+        }
+        lds_barrier();
+        TL_PROBE(3);
+        copy_out<TD>(bufA, LDA, (bf16*)d.o1 + row0 * TD, TD, S, tid);
+        {   // drop(o1 Wo^T + bo) -> fp32 staging (the strip is dead)
+            f32x16 acc[2];
+            zero_acc(acc);
+            tile_mma(acc, bufA, LDA, w, PART == 1 ? w_ptr((const bf16*)d.w_q, 16, wave, 0, lane) : w_ptr((const bf16*)d.w1, 16, wave, 0, lane), lane);
+            tile_epilogue(acc, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
+                const float4 bb = *reinterpret_cast<const float4*>(d.b_o + n);
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                drop4(v, d.p_res, seed, d.call_out1, (uint64_t)(row0 + m) * TD + n);
+                *reinterpret_cast<f32x4*>(stage + m * STG_LD + n) = (f32x4){v[0], v[1], v[2], v[3]};
+            });
+        }
+        lds_barrier();
+        TL_PROBE(4);
+        // x1 = x + staged rows; the next LayerNorm of the residual stream on the way
+        if constexpr (PART == 1)
+            row_pass<true, true, true>(stage, xg, (bf16*)d.x1 + row0 * TD, S, d.ln2_g, d.ln2_b, d.eps, bufA, (bf16*)d.h2 + row0 * TD, d.mean2 + row0, d.rstd2 + row0, wave, lane);
+        else
+            row_pass<true, true, true>(stage, xg, (bf16*)d.x1 + row0 * TD, S, d.ln3_g, d.ln3_b, d.eps, bufA, (bf16*)d.h3 + row0 * TD, d.mean3 + row0, d.rstd3 + row0, wave, lane);
+        lds_barrier();
+        TL_PROBE(5);
+        res_g = (const bf16*)d.x1 + row0 * TD;
+    }
+    if constexpr (PART == 1) {   // q = h2 Wq^T + bq
+        f32x16 acc[2];
+        zero_acc(acc);
+        tile_mma(acc, bufA, LDA, w, nullptr, lane);
+        tile_epilogue(acc, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
+            const float4 bb = *reinterpret_cast<const float4*>(d.b_q + n);
+            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            *reinterpret_cast<bf16x4*>(bufB + m * LDA + n) = to_bf16x4(v);
+        });
+        lds_barrier();
+        copy_out<TD>(bufB, LDA, (bf16*)d.q + row0 * TD, TD, S, tid);
+        TL_PROBE(6);
+        return;
+    }
+    if constexpr (PART == 2) {
+        // ================= cross-attention block, second half: x2 = x1 + drop(o2 Wo2^T + bo2) =================
+        const bf16* x1g = (const bf16*)d.x1 + row0 * TD;
+        load_w(w, w_ptr((const bf16*)d.w_o2, 16, wave, 0, lane));
+        copy_in(bufA, (const bf16*)d.o2 + row0 * TD, S, tid);
+        lds_barrier();
+        TL_PROBE(7);
+        {
+            f32x16 acc[2];
+            zero_acc(acc);
+            tile_mma(acc, bufA, LDA, w, w_ptr((const bf16*)d.w1, 16, wave, 0, lane), lane);
+            tile_epilogue(acc, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
+                const float4 bb = *reinterpret_cast<const float4*>(d.b_o2 + n);
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                drop4(v, d.p_res, seed, d.call_out2, (uint64_t)(row0 + m) * TD + n);
+                *reinterpret_cast<f32x4*>(stage + m * STG_LD + n) = (f32x4){v[0], v[1], v[2], v[3]};
+            });
+        }
+        lds_barrier();
+        TL_PROBE(8);
+        row_pass<true, true, true>(stage, x1g, (bf16*)d.x2 + row0 * TD, S, d.ln3_g, d.ln3_b, d.eps, bufA, (bf16*)d.h3 + row0 * TD, d.mean3 + row0, d.rstd3 + row0, wave, lane);
+        lds_barrier();
+        res_g = (const bf16*)d.x2 + row0 * TD;
+    }
+    TL_PROBE(9);
+
+    // ================= feed-forward block: out = r + drop(W2 drop(relu(W1 LN3(r) + b1)) + b2) =================
+    f32x16 yacc[2];
+    zero_acc(yacc);
+    bf16* Hc = bufB;   // one 256-wide chunk of the hidden activation, [64][LDA]
+#pragma unroll 1
+    for (int c = 0; c < TFF / TD; ++c) {
+        {   // hidden columns c*256 + wave*32 ..: tile c*8 + wave of W1; next in the weight stream: W2[wave*32 ..][c*256 ..]
+            f32x16 acc[2];
+            zero_acc(acc);
+            tile_mma(acc, bufA, LDA, w, w_ptr((const bf16*)d.w2, TFF / 16, wave, c * 16, lane), lane);
+            tile_epilogue(acc, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
+                const int col = c * TD + n;
+                const float4 bb = *reinterpret_cast<const float4*>(d.b1 + col);
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                drop4(v, d.p_res, seed, d.call_ffn1, (uint64_t)(row0 + m) * TFF + col);
+                *reinterpret_cast<bf16x4*>(Hc + m * LDA + n) = to_bf16x4(v);
+            });
+        }
+        lds_barrier();
+        copy_out<TD>(Hc, LDA, (bf16*)d.hid + row0 * TFF + c * TD, TFF, S, tid);
+        tile_mma(yacc, Hc, LDA, w, c + 1 < TFF / TD ? w_ptr((const bf16*)d.w1, 16, (c + 1) * NW + wave, 0, lane) : nullptr, lane);
+        lds_barrier();
+    }
+    TL_PROBE(10);
+    tile_epilogue(yacc, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
+        const float4 bb = *reinterpret_cast<const float4*>(d.b2 + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        drop4(v, d.p_res, seed, d.call_ffn2, (uint64_t)(row0 + m) * TD + n);
+        *reinterpret_cast<f32x4*>(stage + m * STG_LD + n) = (f32x4){v[0], v[1], v[2], v[3]};
+    });
+    lds_barrier();
+    if constexpr (PART == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // res_g = x1, stored by these same lanes earlier in this launch
+    row_pass<true, true, false>(stage, res_g, (bf16*)d.out + row0 * TD, S, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, wave, lane);
+    TL_PROBE(11);
+}
+
+// ---- weights -> fragment order (see WFrag).  One 16-byte chunk per thread: chunk c of job j = lane (c & 63) of (tile, k-slice) c >> 6 ----
+constexpr int PACK_MAX_JOBS = 48;
+struct PackJobs { RalfPackJob j[PACK_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void tlayer_pack_kernel(const PackJobs jobs) {
+    const RalfPackJob jb = jobs.j[blockIdx.y];
+    const int kslices = jb.K / 16;
+    const int64_t nchunks = (int64_t)(jb.N / 32) * kslices * 64;
+    for (int64_t c = blockIdx.x * 256 + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(c & 63);
+        const int64_t ts = c >> 6;
+        const int tile = (int)(ts / kslices), slice = (int)(ts % kslices);
+        const bf16* src = (const bf16*)jb.src + (int64_t)(tile * 32 + (lane & 31)) * jb.ld + slice * 16 + (lane >> 5) * 8;
+        *reinterpret_cast<uint4*>((bf16*)jb.dst + c * 8) = *reinterpret_cast<const uint4*>(src);
+    }
+}
+}  // namespace
+
+extern "C" int ralf_tlayer_pack(const RalfPackJob* jobs, int njobs, void* stream) {
+    RALF_REQUIRE(jobs && njobs > 0 && njobs <= PACK_MAX_JOBS, "tlayer_pack: 1 .. %d jobs per call (got %d)", PACK_MAX_JOBS, njobs);
+    PackJobs pj;
+    memset(&pj, 0, sizeof(pj));
+    int64_t most = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const RalfPackJob& j = jobs[i];
+        RALF_REQUIRE(j.src && j.dst && j.N > 0 && j.K > 0 && j.N % 32 == 0 && j.K % 16 == 0 && j.ld >= j.K && j.ld % 8 == 0, "tlayer_pack: job %d: [N %% 32 == 0][K %% 16 == 0] bf16, ld %% 8 == 0", i);
+        pj.j[i] = j;
+        most = most > (int64_t)j.N * j.K / 8 ? most : (int64_t)j.N * j.K / 8;
+    }
+    hipLaunchKernelGGL(tlayer_pack_kernel, dim3((unsigned)((most + 1023) / 1024), njobs), dim3(256), 0, (hipStream_t)stream, pj);
+    return ralf::check_launch("tlayer_pack");
+}
+
+extern "C" int ralf_tlayer_fwd(const RalfTLayerDesc* dp, void* stream) {
+    RALF_REQUIRE(dp, "tlayer_fwd: null descriptor");
+    const RalfTLayerDesc& d = *dp;
+    RALF_REQUIRE(d.part >= 0 && d.part <= 2, "tlayer_fwd: part 0 (encoder layer), 1 or 2 (decoder layer before / after its cross-attention)");
+    RALF_REQUIRE(d.B > 0 && d.S > 0 && d.S <= TS, "tlayer_fwd: needs 1 <= S <= %d rows per sample (got %d)", TS, d.S);
+    RALF_REQUIRE(d.p_attn >= 0.f && d.p_attn < 1.f && d.p_res >= 0.f && d.p_res < 1.f && ((d.p_attn == 0.f && d.p_res == 0.f) || d.seed), "tlayer_fwd: dropout needs a seed");
+    if (d.part != 2) {
+        RALF_REQUIRE(d.x && d.ln1_g && d.ln1_b && d.w_in && d.b_in && d.w_o && d.b_o, "tlayer_fwd: self-attention block: null input / weight pointer");
+        RALF_REQUIRE(d.h1 && d.mean1 && d.rstd1 && d.qkv && d.o1 && d.lse1 && d.x1, "tlayer_fwd: self-attention block: null output pointer");
+        RALF_REQUIRE(!d.kpm || d.kpm_bs >= d.S, "tlayer_fwd: kpm row stride");
+    }
+    if (d.part == 1) RALF_REQUIRE(d.ln2_g && d.ln2_b && d.w_q && d.b_q && d.h2 && d.mean2 && d.rstd2 && d.q, "tlayer_fwd: part 1 needs LayerNorm 2, the q projection and their outputs");
+    if (d.part == 2) RALF_REQUIRE(d.x1 && d.o2 && d.w_o2 && d.b_o2 && d.x2, "tlayer_fwd: part 2 needs x1, o2, the second out-projection and x2");
+    if (d.part != 1) {
+        RALF_REQUIRE(d.ln3_g && d.ln3_b && d.w1 && d.b1 && d.w2 && d.b2, "tlayer_fwd: feed-forward block: null weight pointer");
+        RALF_REQUIRE(d.h3 && d.mean3 && d.rstd3 && d.hid && d.out, "tlayer_fwd: feed-forward block: null output pointer");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (d.part == 0) hipLaunchKernelGGL((tlayer_fwd_kernel<0>), dim3(d.B), dim3(NT), 0, st, d);
+    else if (d.part == 1) hipLaunchKernelGGL((tlayer_fwd_kernel<1>), dim3(d.B), dim3(NT), 0, st, d);
+    else hipLaunchKernelGGL((tlayer_fwd_kernel<2>), dim3(d.B), dim3(NT), 0, st, d);
+    return ralf::check_launch("tlayer_fwd");
+}

@@ -68,6 +68,9 @@ class Runtime:
         self._bn_tags: dict = {}
         self._bn_stats: dict = {}
         self.bn_fused_hits = 0    # BatchNorm backwards that took their reductions from a data-gradient epilogue (tests / diagnostics)
+        # training / full-sequence forward of the SHORT-sequence transformer layers (decoder: 5N <= 64 tokens; constraint encoder): one launch per
+        # layer instead of 12 (7) (ops.tlayer_fwd; bf16, d = 256, 8 heads, ff = 1024).  The backward pass is the unfused one.
+        self.fused_layers = os.environ.get("RALF_FUSED_LAYERS", "1") != "0"
         self.fused_decode = True  # KV-cached decode step: LayerNorm + projections + attention per block in one launch (bf16, d = 256, 8 heads)
         self.fold_bn = True       # inference: eval-mode BatchNorm folded into the convolution epilogues (conv_bn_infer)
 
@@ -927,6 +930,122 @@ class AttnCrossSliceFn(Function):
         if li == 0:
             plan.dkv = None
         return dq, out, None, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# whole pre-norm transformer layer, forward in one launch (ops.tlayer_fwd)
+# ----------------------------------------------------------------------------------------------
+class _Ctx:
+    """stand-in for an autograd ctx: TLayerFn.backward runs the unfused Functions' OWN backward code on the tensors the fused forward
+    saved, so the two paths cannot drift apart"""
+
+    def __init__(self, saved, needs=None, **kw):
+        self.saved_tensors, self.needs_input_grad = saved, needs
+        self.__dict__.update(kw)
+
+
+def tlayer_supported(x, rt, d, nhead, dim_ff) -> bool:
+    return (rt.fused_layers and rt.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 3 and x.shape[1] <= ops.TLAYER_MAX_ROWS
+            and d == 256 and nhead == 8 and dim_ff == 1024 and x.shape[2] == d)
+
+
+def tlayer_matrices(params, rt):
+    """the row-major bf16 weight matrices of a layer in the order TLayerFn takes their packed forms: self in_proj, self out_proj,
+    [cross in_proj rows 0..d-1 (the q projection), cross out_proj,] linear1, linear2"""
+    cross = len(params) == 18
+    d = params[2].shape[1]
+    mats = [rt.lp(params[2]), rt.lp(params[4])]
+    if cross:
+        mats += [rt.lp(params[8])[:d], rt.lp(params[10])]
+    return mats + [rt.lp(params[-4]), rt.lp(params[-2])]
+
+
+class TLayerFn(Function):
+    """nn.TransformerDecoderLayer (kv = the memory's packed k | v projections [B, M, 2d]) or nn.TransformerEncoderLayer (kv None), norm_first:
+    the forward is ONE launch (decoder: two, around the cross-attention's own) that also writes what LayerNormSkipFn / LinearFn / AttnFn / FFNFn would have saved; the backward calls their
+    backward code in reverse order.  params = norm1 (w, b), self in_proj (w, b), self out_proj (w, b), [norm2 (w, b), cross in_proj (w, b),
+    cross out_proj (w, b),] last norm (w, b), linear1 (w, b), linear2 (w, b); packed = ops.tlayer_pack(tlayer_matrices(params, rt)) when the caller
+    packed several layers in one launch, else None.  Dropout call ids are drawn in the unfused order."""
+
+    @staticmethod
+    def forward(ctx, x, kv, kpm, causal, p, rt, packed, *params):
+        cross = kv is not None
+        assert len(params) == (18 if cross else 12)
+        x = x.contiguous()
+        n1w, n1b, siw, sib, sow, sob = params[:6]
+        n3w, n3b, w1, b1, w2, b2 = params[-6:]
+        nc = lambda: rt.next_call() if p > 0.0 else 0
+        a1, o1 = nc(), nc()
+        a2, o2 = (nc(), nc()) if cross else (0, 0)
+        calls = (a1, o1, a2, o2, nc(), nc())
+        if packed is None:
+            packed = ops.tlayer_pack(tlayer_matrices(params, rt))
+        W = {"ln1": (n1w.detach(), n1b.detach()), "sa_in": (packed[0], sib.detach()), "sa_out": (packed[1], sob.detach()),
+             "ln3": (n3w.detach(), n3b.detach()), "ffn1": (packed[-2], b1.detach()), "ffn2": (packed[-1], b2.detach())}
+        if cross:
+            n2w, n2b, ciw, cib, cow, cob = params[6:12]
+            W.update({"ln2": (n2w.detach(), n2b.detach()), "q_proj": (packed[2], cib.detach()[:x.shape[2]]), "out2": (packed[3], cob.detach())})
+            kv = kv.contiguous()
+        t = ops.tlayer_fwd(x, W, causal=causal, kpm=kpm, kv=kv, p_attn=p, p_res=p, seed=rt.seed if p > 0.0 else None, calls=calls)
+        ctx.keys = tuple(k for k in t if k != "out")
+        ctx.save_for_backward(x, kv, kpm, *params, *[t[k] for k in ctx.keys])
+        ctx.cfg = (cross, causal, p, calls, rt, rt.dropout_tag(x))
+        rt.tag_dropout(t["out"], p, calls[5])
+        return t["out"]
+
+    @staticmethod
+    def backward(ctx, dy):
+        cross, causal, p, calls, rt, tag_in = ctx.cfg
+        sv = ctx.saved_tensors
+        x, kv, kpm = sv[:3]
+        npar = 18 if cross else 12
+        params = sv[3:3 + npar]
+        t = dict(zip(ctx.keys, sv[3 + npar:]))
+        n1w, n1b, siw, sib, sow, sob = params[:6]
+        n3w, n3b, w1, b1, w2, b2 = params[-6:]
+        B, S, d = x.shape
+        H, rows = 8, B * S
+        need = ctx.needs_input_grad[7:]
+        tag = (lambda call: (p, call)) if (p > 0.0 and rt.ln_dropout) else (lambda call: None)
+        two = lambda a: a.view(rows, a.shape[-1])
+        grads = [None] * npar
+
+        def lin_bwd(g, xin, W, b, wi, prows, has_res, call):
+            c = _Ctx((two(xin), W), (True, need[wi], need[wi + 1]), rt=rt, rows=prows, p=(p if call else 0.0), call=call, fan=None, bias=b,
+                     has_b=True, has_res=has_res, xshape=x.shape)
+            dx, dW, db = LinearFn.backward(c, g)[:3]
+            grads[wi], grads[wi + 1] = _acc(grads[wi], dW), _acc(grads[wi + 1], db)
+            return dx
+
+        def ln_bwd(g, skip, xin, gw, gb, mean, rstd, wi, tg):
+            dx, dg, db = _ln_backward(_Ctx((xin, gw, mean, rstd), rt=rt, beta=gb, tag=tg), g, skip)
+            grads[wi], grads[wi + 1] = dg, db
+            return dx
+
+        # feed-forward block
+        r = t["x2"] if cross else t["x1"]
+        c = _Ctx((two(t["h3"]), w1, w2, two(t["hid"]), None), (True,), b1=b1, b2=b2, rt=rt, act="relu", p=p, has_res=True, xshape=x.shape, c2=calls[5])
+        dh, grads[npar - 4], grads[npar - 3], grads[npar - 2], grads[npar - 1], dres = FFNFn.backward(c, dy)[:6]
+        g = ln_bwd(dh, dres, r, n3w, n3b, t["mean3"], t["rstd3"], npar - 6, tag(calls[3] if cross else calls[1]))
+        dkv = None
+        if cross:   # cross-attention block
+            n2w, n2b, ciw, cib, cow, cob = params[6:12]
+            do = lin_bwd(g, t["o2"], cow, cob, 10, (0, d), True, calls[3])
+            c = _Ctx((t["q"], kv, t["o2"], t["lse2"], None), cfg=(B, H, S, kv.shape[1], d // H, (0, 0, d), False, p, calls[2], rt))
+            dq, dkv = AttnFn.backward(c, do)[:2]
+            dh = lin_bwd(dq, t["h2"], ciw, cib, 8, (0, d), False, 0)
+            g = ln_bwd(dh, g, t["x1"], n2w, n2b, t["mean2"], t["rstd2"], 6, tag(calls[1]))
+        # self-attention block
+        do = lin_bwd(g, t["o1"], sow, sob, 4, (0, d), True, calls[1])
+        c = _Ctx((t["qkv"], None, t["o1"], t["lse1"], kpm), cfg=(B, H, S, S, d // H, (0, d, 2 * d), causal, p, calls[0], rt))
+        dqkv = AttnFn.backward(c, do)[0]
+        dh = lin_bwd(dqkv, t["h1"], siw, sib, 2, (0, 3 * d), False, 0)
+        dx = ln_bwd(dh, g, x, n1w, n1b, t["mean1"], t["rstd1"], 0, tag_in)
+        return (dx, dkv, None, None, None, None, None, *grads)
+
+
+def _acc(a, b):
+    return b if a is None else (a if b is None else a + b)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -114,7 +114,17 @@ class TransformerEncoderLayer(nn.Module, _FFNMixin):
         self.norm1, self.norm2 = Affine(d, bias_dim=d), Affine(d, bias_dim=d)
         self.p, self.norm_first = dropout, norm_first
 
-    def forward(self, x, rt: Runtime, kpm=None):
+    def _params(self):
+        a = self.self_attn
+        return (self.norm1.weight, self.norm1.bias, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
+                self.norm2.weight, self.norm2.bias, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
+
+    def fusable(self, x, rt: Runtime) -> bool:
+        return self.norm_first and RF.tlayer_supported(x, rt, self.self_attn.d, self.self_attn.nhead, self.linear1.weight.shape[0])
+
+    def forward(self, x, rt: Runtime, kpm=None, packed=None):
+        if self.fusable(x, rt):
+            return RF.TLayerFn.apply(x, None, kpm, False, rt.drop_p(self.p), rt, packed, *self._params())   # the whole layer in one launch
         if self.norm_first:
             h, x = RF.layer_norm_skip(x, self.norm1.weight, self.norm1.bias, rt)
             x = self.self_attn.self_attn(h, x, rt, kpm=kpm, p_attn=self.p, p_out=self.p)
@@ -132,8 +142,23 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
         self.norm1, self.norm2, self.norm3 = Affine(d, bias_dim=d), Affine(d, bias_dim=d), Affine(d, bias_dim=d)
         self.p = dropout
 
-    def forward(self, x, mem, rt: Runtime, tgt_kpm=None, stacked=None):
-        """stacked = (kv_all, layer index, plan): this layer's cross-attention K/V were projected with all other layers' (BaseDecoder)"""
+    def _params(self):
+        sa, ca = self.self_attn, self.multihead_attn
+        return (self.norm1.weight, self.norm1.bias, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
+                self.norm2.weight, self.norm2.bias, ca.in_proj_weight, ca.in_proj_bias, ca.out_proj.weight, ca.out_proj.bias,
+                self.norm3.weight, self.norm3.bias, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
+
+    def fusable(self, x, rt: Runtime) -> bool:
+        return RF.tlayer_supported(x, rt, self.self_attn.d, self.self_attn.nhead, self.linear1.weight.shape[0])
+
+    def forward(self, x, mem, rt: Runtime, tgt_kpm=None, stacked=None, packed=None):
+        """stacked = (kv_all, layer index, plan): this layer's cross-attention K/V were projected with all other layers' (BaseDecoder);
+        packed = this layer's weights in fragment order when the caller packed all layers in one launch"""
+        sa, ca = self.self_attn, self.multihead_attn
+        if stacked is None and self.fusable(x, rt):
+            # short target sequences: the memory's K/V projection (the one big product of the layer), then the layer in three launches
+            kv = RF.linear(mem, ca.in_proj_weight, ca.in_proj_bias, rt=rt, rows=(sa.d, 3 * sa.d))
+            return RF.TLayerFn.apply(x, kv, tgt_kpm, True, rt.drop_p(self.p), rt, packed, *self._params())
         h, x = RF.layer_norm_skip(x, self.norm1.weight, self.norm1.bias, rt)
         x = self.self_attn.self_attn(h, x, rt, causal=True, kpm=tgt_kpm, p_attn=self.p, p_out=self.p)
         h, x = RF.layer_norm_skip(x, self.norm2.weight, self.norm2.bias, rt)
@@ -192,6 +217,18 @@ class FuseAttention(nn.Module):
         return RF.linear(o, self.to_out[0].weight, self.to_out[0].bias, rt=rt)
 
 
+def _pack_layers(layers, x, rt: Runtime):
+    """fragment-order weights (ops.tlayer_pack) of all `layers` in ONE launch when they take the fused path on x; else None"""
+    if not layers or not all(l.fusable(x, rt) for l in layers):
+        return None
+    mats = [RF.tlayer_matrices(l._params(), rt) for l in layers]
+    per = len(mats[0])
+    if per * len(layers) > 48:
+        return None
+    flat = ops.tlayer_pack([m for ms in mats for m in ms])
+    return [flat[i * per:(i + 1) * per] for i in range(len(layers))]
+
+
 class BaseDecoder(nn.Module):
     def __init__(self, d_label: int, d_model: int = 256, num_layers: int = 6, nhead: int = 8, dim_feedforward: int = 1024):
         super().__init__()
@@ -215,8 +252,9 @@ class BaseDecoder(nn.Module):
         if plan is not None:   # all layers' cross-attention K/V projections of the memory in one launch
             wb = [t for a in attns for t in (a.in_proj_weight, a.in_proj_bias)]
             kv_all = RF.CrossKVFn.apply(memory, plan, rt, *wb)
+        packs = _pack_layers(layers, h, rt) if plan is None else None   # short sequences: every layer's weights in fragment order, one launch
         for li, layer in enumerate(layers):
-            h = layer(h, memory, rt, kpm, stacked=(kv_all, li, plan) if plan is not None else None)
+            h = layer(h, memory, rt, kpm, stacked=(kv_all, li, plan) if plan is not None else None, packed=packs[li] if packs else None)
         h = RF.layer_norm(h, self.head[0].weight, self.head[0].bias, rt)
         return RF.linear(h, self.head[1].weight, rt=rt, out_f32=True)
 
@@ -300,8 +338,10 @@ class UserConstraintTransformerEncoder(nn.Module):
         h = RF.EmbedFn.apply(src, self.emb.weight, self.pos_emb.pe[0], rt)
         h = RF.drop_add(h, None, rt.drop_p(self.pos_emb.p), rt)
         kpm = _kpm_u8(src_key_padding_mask)
-        for layer in self.encoder.layers:
-            h = layer(h, rt, kpm)
+        layers = list(self.encoder.layers)
+        packs = _pack_layers(layers, h, rt)
+        for li, layer in enumerate(layers):
+            h = layer(h, rt, kpm, packed=packs[li] if packs else None)
         return h
 
 

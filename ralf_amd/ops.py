@@ -528,6 +528,82 @@ def attention_fwd(q, k, v, B, H, Sq, Sk, dh, q_off=0, k_off=0, v_off=0, causal=F
     return o, lse
 
 
+TLAYER_MAX_ROWS = 64
+
+
+def tlayer_pack(mats):
+    """row-major bf16 matrices [N % 32 == 0, K % 16 == 0] -> the fragment order ralf_tlayer_fwd streams its weights in (ralf_tlayer_pack):
+    ONE launch and one buffer for all of them; returns the flat packed views in order."""
+    from ._abi import RalfPackJob
+
+    assert 0 < len(mats) <= 48
+    sizes = [m.shape[0] * m.shape[1] for m in mats]
+    buf = torch.empty(sum(sizes), dtype=torch.bfloat16, device=mats[0].device)
+    outs, off = [], 0
+    jobs = (RalfPackJob * len(mats))()
+    for i, m in enumerate(mats):
+        assert m.dtype == torch.bfloat16 and m.dim() == 2 and m.stride(1) == 1 and m.shape[0] % 32 == 0 and m.shape[1] % 16 == 0
+        outs.append(buf[off:off + sizes[i]])
+        jobs[i].src, jobs[i].dst, jobs[i].ld, jobs[i].N, jobs[i].K = m.data_ptr(), outs[i].data_ptr(), m.stride(0), m.shape[0], m.shape[1]
+        off += sizes[i]
+    _call("ralf_tlayer_pack", jobs, len(mats))
+    return outs
+
+
+def tlayer_fwd(x, W, *, causal, kpm=None, kpm_stride=0, kv=None, p_attn=0.0, p_res=0.0, seed=None, calls=(0, 0, 0, 0, 0, 0), eps=1e-5):
+    """one pre-norm transformer layer forward on SHORT sequences (ralf_tlayer_fwd): x [B, S <= 64, 256] bf16.
+    W: dict of pairs -- LayerNorms "ln1", "ln3" (and "ln2") = (gamma, beta) fp32; linear layers "sa_in" [768, 256], "sa_out" [256, 256],
+    "ffn1" [1024, 256], "ffn2" [256, 1024] (and "q_proj" [256, 256], "out2" [256, 256]) = (weight PACKED by tlayer_pack, fp32 bias).
+    kv None: encoder layer, one launch.  kv [B, M, 512] (the memory's k | v projections): decoder layer = part 1, ralf_attention_fwd, part 2.
+    calls = dropout call ids (self-attention, its out-projection, cross-attention, its out-projection, ffn1, ffn2).
+    Returns the dict of everything the unfused backward reads: h1 mean1 rstd1 qkv o1 lse1 x1 [h2 mean2 rstd2 q o2 lse2 x2] h3 mean3 rstd3 hid out."""
+    from ._abi import RalfTLayerDesc
+
+    B, S, dm = x.shape
+    H, ff = 8, 1024
+    cross = kv is not None
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and dm == 256 and 1 <= S <= TLAYER_MAX_ROWS
+    for name, n in (("sa_in", 3 * dm * dm), ("sa_out", dm * dm), ("ffn1", ff * dm), ("ffn2", ff * dm)) + ((("q_proj", dm * dm), ("out2", dm * dm)) if cross else ()):
+        w, b = W[name]
+        assert w.dtype == torch.bfloat16 and w.is_contiguous() and w.numel() == n and b.dtype == torch.float32 and b.is_contiguous(), name
+    dev = x.device
+
+    def act(width=dm):
+        return torch.empty(B, S, width, dtype=torch.bfloat16, device=dev)
+
+    def stat():
+        return torch.empty(B * S, dtype=torch.float32, device=dev)
+
+    t = {"h1": act(), "mean1": stat(), "rstd1": stat(), "qkv": act(3 * dm), "o1": act(), "lse1": torch.empty(B, H, S, dtype=torch.float32, device=dev), "x1": act(),
+         "h3": act(), "mean3": stat(), "rstd3": stat(), "hid": act(ff), "out": act()}
+    if cross:
+        assert kv.dtype == torch.bfloat16 and kv.is_contiguous() and kv.shape[0] == B and kv.shape[2] == 2 * dm
+        t.update({"h2": act(), "mean2": stat(), "rstd2": stat(), "q": act(), "x2": act()})
+    d = RalfTLayerDesc()
+    d.x = _p(x)
+    d.ln1_g, d.ln1_b, d.w_in, d.b_in, d.w_o, d.b_o = _p(W["ln1"][0]), _p(W["ln1"][1]), _p(W["sa_in"][0]), _p(W["sa_in"][1]), _p(W["sa_out"][0]), _p(W["sa_out"][1])
+    d.ln3_g, d.ln3_b, d.w1, d.b1, d.w2, d.b2 = _p(W["ln3"][0]), _p(W["ln3"][1]), _p(W["ffn1"][0]), _p(W["ffn1"][1]), _p(W["ffn2"][0]), _p(W["ffn2"][1])
+    if cross:
+        d.ln2_g, d.ln2_b, d.w_q, d.b_q, d.w_o2, d.b_o2 = _p(W["ln2"][0]), _p(W["ln2"][1]), _p(W["q_proj"][0]), _p(W["q_proj"][1]), _p(W["out2"][0]), _p(W["out2"][1])
+    d.kpm, d.kpm_bs = _p(kpm), int(kpm_stride) if kpm_stride else (S if kpm is not None else 0)
+    for k, v in t.items():
+        setattr(d, k, _p(v))
+    d.seed = _p(seed) if (p_attn > 0.0 or p_res > 0.0) else None
+    d.call_attn1, d.call_out1, d.call_out2, d.call_ffn1, d.call_ffn2 = int(calls[0]), int(calls[1]), int(calls[3]), int(calls[4]), int(calls[5])
+    d.B, d.S, d.causal = B, S, int(bool(causal))
+    d.scale, d.p_attn, d.p_res, d.eps = (dm // H) ** -0.5, float(p_attn), float(p_res), eps
+    if not cross:
+        d.part = 0
+        _call("ralf_tlayer_fwd", ctypes.byref(d))
+        return t
+    d.part = 1
+    _call("ralf_tlayer_fwd", ctypes.byref(d))
+    t["o2"], t["lse2"] = attention_fwd(t["q"], kv, kv, B, H, S, kv.shape[1], dm // H, 0, 0, dm, p_drop=p_attn, seed=seed, call_id=int(calls[2]))
+    d.o2, d.part = _p(t["o2"]), 2
+    _call("ralf_tlayer_fwd", ctypes.byref(d))
+    return t
+
+
 _DEC_MAXK = None
 
 

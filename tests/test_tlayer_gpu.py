@@ -1,0 +1,199 @@
+"""The one-launch transformer layer (ralf_tlayer_fwd, ralf_amd/csrc/tlayer.hip) against the launches it replaces: same bits for every
+tensor it writes, and -- through the modules -- the same output and the same gradients as the unfused layers
+(nn.TransformerDecoderLayer / nn.TransformerEncoderLayer, norm_first: image2layout/train/models/common/common.py:25-34,84-135,216-226)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+D, H, FF = 256, 8, 1024
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def make_weights(cross, seed=0):
+    w = {}
+    names = ["ln1", "ln3"] + (["ln2"] if cross else [])
+    for i, n in enumerate(names):
+        w[n] = ((1 + 0.1 * rnd(D, seed=seed + i)).cuda(), (0.1 * rnd(D, seed=seed + 10 + i)).cuda())
+    shapes = {"sa_in": (3 * D, D), "sa_out": (D, D), "ffn1": (FF, D), "ffn2": (D, FF)}
+    if cross:
+        shapes.update({"ca_in": (3 * D, D), "ca_out": (D, D)})
+    for i, (n, (no, ni)) in enumerate(sorted(shapes.items())):
+        w[n] = ((rnd(no, ni, seed=seed + 20 + i) * ni ** -0.5).to(torch.bfloat16).cuda(), (0.1 * rnd(no, seed=seed + 40 + i)).cuda())
+    return w
+
+
+def unfused(x, w, kv, kpm, causal, p, seed, calls):
+    """the launches the fused kernel replaces, in their order (functional.LayerNormSkipFn / LinearFn / AttnFn / FFNFn forward)"""
+    from ralf_amd import ops
+
+    B, S, _ = x.shape
+    rows = B * S
+    t = {}
+    sd = seed if p > 0 else None
+    t["h1"], t["mean1"], t["rstd1"] = ops.layernorm_fwd(x, *w["ln1"])
+    t["qkv"] = ops.gemm(t["h1"].view(rows, D), w["sa_in"][0], rows, 3 * D, D, bias=w["sa_in"][1]).view(B, S, 3 * D)
+    t["o1"], t["lse1"] = ops.attention_fwd(t["qkv"], t["qkv"], t["qkv"], B, H, S, S, D // H, 0, D, 2 * D, causal=causal, kpm=kpm, p_drop=p, seed=seed, call_id=calls[0])
+    t["x1"] = ops.gemm(t["o1"].view(rows, D), w["sa_out"][0], rows, D, D, bias=w["sa_out"][1], res=x.view(rows, D), drop_p=p, seed=sd, call_id=calls[1]).view(B, S, D)
+    r = t["x1"]
+    if kv is not None:
+        t["h2"], t["mean2"], t["rstd2"] = ops.layernorm_fwd(r, *w["ln2"])
+        t["q"] = ops.gemm(t["h2"].view(rows, D), w["ca_in"][0][:D], rows, D, D, bias=w["ca_in"][1][:D]).view(B, S, D)
+        t["o2"], t["lse2"] = ops.attention_fwd(t["q"], kv, kv, B, H, S, kv.shape[1], D // H, 0, 0, D, p_drop=p, seed=seed, call_id=calls[2])
+        t["x2"] = ops.gemm(t["o2"].view(rows, D), w["ca_out"][0], rows, D, D, bias=w["ca_out"][1], res=r.view(rows, D), drop_p=p, seed=sd, call_id=calls[3]).view(B, S, D)
+        r = t["x2"]
+    t["h3"], t["mean3"], t["rstd3"] = ops.layernorm_fwd(r, *w["ln3"])
+    t["hid"] = ops.gemm(t["h3"].view(rows, D), w["ffn1"][0], rows, FF, D, bias=w["ffn1"][1], act="relu", drop_p=p, seed=sd, call_id=calls[4]).view(B, S, FF)
+    t["out"] = ops.gemm(t["hid"].view(rows, FF), w["ffn2"][0], rows, D, FF, bias=w["ffn2"][1], res=r.view(rows, D), drop_p=p, seed=sd, call_id=calls[5]).view(B, S, D)
+    return t
+
+
+def same_bits(a, b, name):
+    a, b = a.contiguous().view(-1), b.contiguous().view(-1)
+    ia = a.view(torch.int16 if a.dtype == torch.bfloat16 else torch.int32)
+    ib = b.view(torch.int16 if b.dtype == torch.bfloat16 else torch.int32)
+    bad = (ia != ib).sum().item()
+    if bad:
+        diff = (a.float() - b.float()).abs()
+        raise AssertionError(f"{name}: {bad} of {a.numel()} elements differ (max |diff| {diff.max().item():.3e}, first at {int((ia != ib).nonzero()[0])})")
+
+
+CASES = [
+    # B, S, M (None = encoder layer), causal, key padding, p
+    (3, 50, 532, True, True, 0.1),     # decoder layer of the training step: 5 x 10 tokens, 2 x 14 x 19 memory rows
+    (2, 64, 64, True, False, 0.0),     # full strip, one memory tile
+    (2, 1, 7, True, False, 0.1),       # a single token; a memory shorter than a tile
+    (5, 17, 130, True, True, 0.0),
+    (4, 33, 611, False, True, 0.1),    # not causal + padded keys over three 16-query groups
+    (3, 40, None, False, True, 0.1),   # encoder layer (constraint encoder)
+    (2, 64, None, False, False, 0.0),
+    (1, 16, None, True, True, 0.1),
+]
+
+
+@pytest.mark.parametrize("B,S,M,causal,padded,p", CASES)
+def test_fused_layer_writes_the_bits_of_the_unfused_launches(B, S, M, causal, padded, p):
+    from ralf_amd import ops
+
+    cross = M is not None
+    w = make_weights(cross, seed=S)
+    x = rnd(B, S, D, seed=1).to(torch.bfloat16).cuda()
+    kv = rnd(B, M, 2 * D, seed=2).to(torch.bfloat16).cuda() if cross else None
+    kpm = None
+    if padded:
+        kpm = torch.zeros(B, S, dtype=torch.uint8)
+        for b in range(B):
+            kpm[b, max(1, S - 1 - 3 * b):] = 1 if S > 1 else 0    # a padded tail of varying length, key 0 always visible
+        kpm = kpm.cuda()
+    seed = torch.tensor([1234567], dtype=torch.int64, device="cuda")
+    calls = (3, 4, 5, 6, 7, 8)
+    ref = unfused(x, w, kv, kpm, causal, p, seed, calls)
+    names = ["sa_in", "sa_out"] + (["q_proj", "out2"] if cross else []) + ["ffn1", "ffn2"]
+    rowmajor = {"sa_in": w["sa_in"], "sa_out": w["sa_out"], "ffn1": w["ffn1"], "ffn2": w["ffn2"]}
+    if cross:
+        rowmajor.update({"q_proj": (w["ca_in"][0][:D], w["ca_in"][1][:D].contiguous()), "out2": w["ca_out"]})
+    packed = ops.tlayer_pack([rowmajor[n][0] for n in names])
+    W = {n: (pk, rowmajor[n][1]) for n, pk in zip(names, packed)}
+    W.update({k: w[k] for k in ("ln1", "ln2", "ln3") if k in w})
+    got = ops.tlayer_fwd(x, W, causal=causal, kpm=kpm, kv=kv, p_attn=p, p_res=p, seed=seed, calls=calls)
+    torch.cuda.synchronize()
+    assert set(got) == set(ref)
+    order = ["h1", "mean1", "rstd1", "qkv", "o1", "lse1", "x1", "h2", "mean2", "rstd2", "q", "o2", "lse2", "x2", "h3", "mean3", "rstd3", "hid", "out"]
+    for k in order:
+        if k in ref:
+            same_bits(got[k], ref[k], k)
+
+
+def _layer(cross, seed):
+    from ralf_amd import nn as RN
+
+    torch.manual_seed(seed)
+    layer = RN.TransformerDecoderLayer(D, H, FF, 0.1) if cross else RN.TransformerEncoderLayer(D, H, FF, 0.1, True)
+    for prm in layer.parameters():
+        torch.nn.init.normal_(prm, std=0.05)
+    for n in ("norm1", "norm2", "norm3"):
+        if hasattr(layer, n):
+            getattr(layer, n).weight.data.add_(1.0)
+    return layer.cuda()
+
+
+@pytest.mark.parametrize("cross,training", [(True, True), (True, False), (False, True)])
+def test_fused_layer_module_matches_unfused_module_forward_and_backward(cross, training):
+    """same output and same input / memory gradients bit for bit (with the dropout masks of the training mode); same parameter gradients"""
+    from ralf_amd.functional import Runtime
+
+    B, S, M = 4, 50, 300
+    layer = _layer(cross, 5)
+    x0 = rnd(B, S, D, seed=1).to(torch.bfloat16).cuda()
+    mem0 = rnd(B, M, D, seed=2).to(torch.bfloat16).cuda()
+    kpm = torch.zeros(B, S, dtype=torch.uint8, device="cuda")
+    kpm[1, 40:] = 1
+    go = rnd(B, S, D, seed=3).to(torch.bfloat16).cuda()
+    res = {}
+    for fused in (True, False):
+        rt = Runtime(torch.bfloat16, seed=11)
+        rt.to(torch.device("cuda"))
+        rt.training = training
+        rt.fused_layers = fused
+        rt.begin_step()
+        x, mem = x0.clone().requires_grad_(True), mem0.clone().requires_grad_(True)
+        layer.zero_grad(set_to_none=True)
+        y = layer(x, mem, rt, kpm) if cross else layer(x, rt, kpm)
+        y.backward(go)
+        rt.flush_wgrads()
+        rt.join_side()
+        torch.cuda.synchronize()
+        res[fused] = {"y": y.detach().clone(), "dx": x.grad.clone(), **({"dmem": mem.grad.clone()} if cross else {}),
+                      **{n: prm.grad.clone() for n, prm in layer.named_parameters()}}
+    assert set(res[True]) == set(res[False])
+    for k in res[True]:
+        if k in ("y", "dx", "dmem"):
+            same_bits(res[True][k], res[False][k], k)
+        else:   # parameter gradients: fp32 reductions over the rows with split / atomic partial sums (order not fixed between two runs)
+            torch.testing.assert_close(res[True][k], res[False][k], rtol=1e-5, atol=1e-5 * res[False][k].abs().max().item(), msg=lambda m: f"{k}: {m}")
+
+
+def test_weight_packing_is_the_documented_permutation():
+    from ralf_amd import ops
+
+    for n, k, ld in ((64, 32, 32), (256, 1024, 1024), (256, 256, 768)):
+        src = torch.arange(n * ld, dtype=torch.float32).remainder(4099).to(torch.bfloat16).view(n, ld).cuda()[:, :k]
+        (pk,) = ops.tlayer_pack([src])
+        torch.cuda.synchronize()
+        # dst[((t * K/16 + i) * 64 + lane) * 8 + e] = src[32 t + (lane & 31)][16 i + 8 (lane >> 5) + e]
+        want = src.view(n // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+        assert torch.equal(pk, want)
+
+
+def test_fused_layer_is_what_the_decoder_runs():
+    """a decoder layer on 5N = 50 tokens takes the fused path (and falls back when the runtime is fp32 or the sequence is long)"""
+    from ralf_amd import functional as RF, ops
+
+    seen = []
+    orig = ops.tlayer_fwd
+
+    def spy(*a, **k):
+        seen.append(a[0].shape)
+        return orig(*a, **k)
+
+    ops.tlayer_fwd = spy
+    try:
+        layer = _layer(True, 6)
+        rt = RF.Runtime(torch.bfloat16, seed=1)
+        rt.to(torch.device("cuda"))
+        x = rnd(2, 50, D, seed=1).to(torch.bfloat16).cuda()
+        mem = rnd(2, 100, D, seed=2).to(torch.bfloat16).cuda()
+        layer(x, mem, rt, None)
+        assert seen == [x.shape]
+        long = rnd(2, 65, D, seed=1).to(torch.bfloat16).cuda()
+        layer(long, mem, rt, None)
+        assert len(seen) == 1
+        rt32 = RF.Runtime(torch.float32, seed=1)
+        rt32.to(torch.device("cuda"))
+        layer(x.float(), mem.float(), rt32, None)
+        assert len(seen) == 1
+    finally:
+        ops.tlayer_fwd = orig
