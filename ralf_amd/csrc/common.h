@@ -31,15 +31,23 @@ static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b)
 
 // Element dropout mask (GEMM epilogues, ralf_dropout, ralf_scale_pe_dropout, the LayerNorm backward's masked gradient, tlayer.hip):
 //   keep(e) = 16-bit field (e & 3) of drop_hash4(seed, call, e >> 2) >= p * 2^16
-// ONE 64-bit counter hash (splitmix64 finaliser) decides FOUR consecutive elements of the contiguous tensor.  The kernels hold 4 or 8
-// consecutive elements per lane, so the hash -- three 64-bit multiplies = ~25 quarter-rate 32-bit multiplies, ~120-180 cycles per call
-// measured in the transformer-layer kernel (tools/tlayer_probe.hip: a quarter of its run time with one hash per element) -- runs once per
-// four elements.  p is quantised to 1 / 65536 (0.1 -> 0.099991); the kept elements are scaled by 1 / (1 - p) with the nominal p.
+// ONE hash decides FOUR consecutive elements of the contiguous tensor (the kernels hold 4 or 8 consecutive elements per lane).  The stream
+// (seed, call) goes through one 64-bit mix -- uniform over the launch, so it runs on the scalar unit -- and gives two 32-bit keys; each key and
+// the group index go through the attention kernels' full-rate 24-bit-multiply mixer (attn_rng2x16 below) for two fields each.
+// (A 64-bit splitmix per ELEMENT -- three 64-bit multiplies = ~12 quarter-rate 32-bit multiplies -- took a quarter of the transformer-layer
+//  kernel's time: tools/tlayer_probe.hip.)  p is quantised to 1 / 65536 (0.1 -> 0.099991); kept elements are scaled by 1 / (1 - p), nominal p.
+// Checked in tests/test_ops_gpu.py: keep rate, and correlation between the four fields, neighbouring groups, rows and streams.
+__device__ __forceinline__ uint32_t attn_rng2x16(uint32_t rowkey, uint32_t pair);
 __device__ __forceinline__ uint64_t drop_hash4(uint64_t seed, uint64_t call, uint64_t group) {
-    uint64_t z = seed + call * 0x9E3779B97F4A7C15ull + group * 0xD1B54A32D192ED03ull;
+    uint64_t z = seed + call * 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+    z ^= z >> 31;
+    const uint32_t glo = (uint32_t)group & 0xffffffu;
+    const uint32_t hi = __umul24((uint32_t)(group >> 24), 0x85EBCBu);   // (0 below 2^26 elements)
+    const uint32_t a = attn_rng2x16((uint32_t)z ^ hi, glo);
+    const uint32_t b = attn_rng2x16((uint32_t)(z >> 32) ^ hi, glo);
+    return (uint64_t)a | ((uint64_t)b << 32);
 }
 __device__ __forceinline__ uint32_t drop_thr16(float p) { return (uint32_t)(p * 65536.f); }
 __device__ __forceinline__ bool drop_keep(uint64_t h, int field, uint32_t thr16) { return ((uint32_t)(h >> (16 * field)) & 0xffffu) >= thr16; }

@@ -112,6 +112,39 @@ def test_dropout_is_counter_based():
     assert len(u) == 2 and u[0] == 0.0 and abs(u[1] - 1 / 0.9) < 1e-6
 
 
+def test_dropout_mask_statistics():
+    """the element mask (csrc/common.h drop_hash4: one hash per 4 consecutive elements, 16-bit fields): keep rate at several p, and no
+    correlation between the four fields of a group, neighbouring groups, rows 1024 apart, consecutive streams (call ids) and seeds"""
+    from ralf_amd import ops
+
+    n = 1 << 24
+    x = torch.ones(n + (1 << 26), device="cuda")[-n:]   # (a view: the mask depends on the element INDEX only)
+    seed = torch.tensor([987654321], dtype=torch.int64, device="cuda")
+    for p in (0.1, 0.5, 0.9):
+        k = (ops.dropout(x, p, seed, 3) != 0).float()
+        assert abs(k.mean().item() - (1 - p)) < 6e-4, (p, k.mean().item())
+
+    def corr(a, b):
+        a, b = a - a.mean(), b - b.mean()
+        return ((a * b).mean() / (a.std() * b.std())).item()
+
+    k = (ops.dropout(x, 0.5, seed, 3) != 0).float()
+    g = k.view(-1, 4)
+    for i in range(4):
+        for j in range(i + 1, 4):
+            assert abs(corr(g[:, i], g[:, j])) < 1.5e-3, (i, j)
+    assert abs(corr(k[:-4], k[4:])) < 1.5e-3 and abs(corr(k[:-1024], k[1024:])) < 1.5e-3 and abs(corr(k[:-1], k[1:])) < 1.5e-3
+    k2 = (ops.dropout(x, 0.5, seed, 4) != 0).float()
+    k3 = (ops.dropout(x, 0.5, seed + 1, 3) != 0).float()
+    assert abs(corr(k, k2)) < 1.5e-3 and abs(corr(k, k3)) < 1.5e-3
+    # group sums are binomial(4, 0.5): variance 1 (a mask that repeated a field would show 2 or 4)
+    assert abs(g.sum(1).var().item() - 1.0) < 5e-3
+    # tensors beyond 2^26 elements use the high index bits too
+    big = torch.ones((1 << 26) + (1 << 22), device="cuda")
+    kb = (ops.dropout(big, 0.5, seed, 3) != 0).float()
+    assert abs(corr(kb[: 1 << 22], kb[1 << 26:])) < 3e-3 and abs(kb[1 << 26:].mean().item() - 0.5) < 2e-3
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_pool_upsample_permute(dtype):
     from ralf_amd import ops
