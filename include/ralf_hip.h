@@ -344,7 +344,10 @@ int ralf_decode_attn_max_keys(void);
  * of those launches) and every tensor their backward passes read written on the way -- the backward is the unfused one.
  *   weights: bf16 in FRAGMENT ORDER (ralf_tlayer_pack of the row-major [n_out, n_in] matrix; w_q = the first 256 rows of the cross-attention's
  *   in_proj_weight); biases and LayerNorm parameters fp32; activations bf16 [B*S, width]; statistics fp32 [B*S]; lse fp32 [B, 8, S];
- *   kpm uint8 [B, kpm_bs] or NULL; seed int64[1] on the device (needed when a dropout probability is > 0) */
+ *   kpm uint8 [B, kpm_bs] or NULL; seed int64[1] on the device (needed when a dropout probability is > 0)
+ * Part 2 is also the tail of a KV-cached DECODE step (retrieval_augmented_autoreg.py:274-279: one new token per batch element): the "samples"
+ * are then strips of S <= 32 batch rows (one 32-row MFMA block per workgroup), dropout off, and h3 / mean3 / rstd3 / hid may be NULL (nothing is
+ * kept for a backward pass; x2 is still written -- the kernel reads it back for the last residual add). */
 #define RALF_TLAYER_MAX_ROWS 64
 typedef struct RalfTLayerDesc {
     const void* x;

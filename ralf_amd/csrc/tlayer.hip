@@ -63,8 +63,18 @@ __device__ unsigned long long tlayer_probe_buf[16 * 4096];
 //   LN:      LayerNorm(value) -> dst (LDS, rows >= S zero) + hout (global) + mean / rstd
 // All of a wave's global rows are requested before the first is used (a wave owns 8 rows: one latency, not eight).
 constexpr int STG_LD = TD + 4;   // fp32 staging rows of 1040 bytes
-template <bool STAGE, bool XOUT, bool LN>
-__device__ __forceinline__ void row_pass(const float* stage, const bf16* __restrict__ res, bf16* __restrict__ xout, int S, const float* __restrict__ gamma,
+// a wave's rows (wave, wave + 8, ..) of a global [S][256] tensor, lane l = columns 4l .. 4l+3: requested early, consumed by row_pass
+template <int RB>
+__device__ __forceinline__ void load_rows(bf16x4 (&rr)[32 * RB / NW], const bf16* __restrict__ src, int S, int wave, int lane) {
+#pragma unroll
+    for (int k = 0; k < 32 * RB / NW; ++k) {
+        const int row = wave + k * NW;
+        rr[k] = *reinterpret_cast<const bf16x4*>(src + (int64_t)(row < S ? row : 0) * TD + lane * 4);
+    }
+}
+// rr: in = the residual rows (load_rows, or the previous pass's output); out (STAGE) = the rows this pass produced (x1 / x2 / out)
+template <bool STAGE, bool XOUT, bool LN, int RB = 2>
+__device__ __forceinline__ void row_pass(const float* stage, bf16x4 (&rr)[32 * RB / NW], bf16* __restrict__ xout, int S, const float* __restrict__ gamma,
                                          const float* __restrict__ beta, float eps, bf16* dst, bf16* __restrict__ hout, float* __restrict__ mean,
                                          float* __restrict__ rstd, int wave, int lane) {
     float g[4], bb[4];
@@ -72,14 +82,8 @@ __device__ __forceinline__ void row_pass(const float* stage, const bf16* __restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) { g[i] = gamma[lane * 4 + i]; bb[i] = beta[lane * 4 + i]; }
     }
-    constexpr int NR = TS / NW;   // 8 rows per wave, processed TOGETHER: the two butterfly reductions per row are chains of 6 dependent cross-lane
+    constexpr int NR = 32 * RB / NW;   // 8 (4) rows per wave, processed TOGETHER: the two butterfly reductions per row are chains of 6 dependent cross-lane
                                   // reads each; row after row they cost ~10 k cycles per pass (s_memtime), interleaved over the rows one chain's latency
-    bf16x4 rr[NR];
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-        const int row = wave + k * NW;
-        rr[k] = *reinterpret_cast<const bf16x4*>(res + (int64_t)(row < S ? row : 0) * TD + lane * 4);
-    }
     float v[NR][4];
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
@@ -89,7 +93,8 @@ __device__ __forceinline__ void row_pass(const float* stage, const bf16* __restr
             bf16x4 t;
 #pragma unroll
             for (int i = 0; i < 4; ++i) t[i] = (bf16)(a[i] + (float)rr[k][i]);
-            if (XOUT && row < S) *reinterpret_cast<bf16x4*>(xout + (int64_t)row * TD + lane * 4) = t;
+            if (XOUT && xout && row < S) *reinterpret_cast<bf16x4*>(xout + (int64_t)row * TD + lane * 4) = t;
+            rr[k] = t;
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[k][i] = (float)t[i];
         } else {
@@ -124,7 +129,7 @@ __device__ __forceinline__ void row_pass(const float* stage, const bf16* __restr
         bf16x4 ov;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ov[i] = row < S ? (bf16)__fmaf_rn((v[k][i] - mu) * rs, g[i], bb[i]) : (bf16)0.f;
-        if (row < S) {
+        if (row < S && hout) {   // (inference callers keep neither the normalised rows nor the statistics)
             *reinterpret_cast<bf16x4*>(hout + (int64_t)row * TD + lane * 4) = ov;
             if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
         }
@@ -140,11 +145,12 @@ __device__ __forceinline__ void copy_out(const bf16* src, int ld, bf16* __restri
         *reinterpret_cast<uint4*>(dstg + (int64_t)r * gld + c * 8) = *reinterpret_cast<const uint4*>(src + r * ld + c * 8);
     }
 }
-// global rows [S][256] -> LDS strip [64][LDA] (rows >= S zero)
+// global rows [S][256] -> LDS strip [32 RB][LDA] (rows >= S zero)
+template <int RB = 2>
 __device__ __forceinline__ void copy_in(bf16* dst, const bf16* __restrict__ srcg, int S, int tid) {
     constexpr int VPR = TD / 8;
 #pragma unroll
-    for (int i = 0; i < TS * VPR / NT; ++i) {
+    for (int i = 0; i < 32 * RB * VPR / NT; ++i) {
         const int e = tid + NT * i, r = e / VPR, c = e % VPR;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (r < S) v = *reinterpret_cast<const uint4*>(srcg + (int64_t)r * TD + c * 8);
@@ -170,32 +176,44 @@ __device__ __forceinline__ void load_w_half(WFrag& w, int half, const bf16* __re
     for (int i = 0; i < 8; ++i) w.v[half * 8 + i] = *reinterpret_cast<const bf16x8*>(p + (half * 8 + i) * 512);
 }
 __device__ __forceinline__ void load_w(WFrag& w, const bf16* __restrict__ p) { load_w_half(w, 0, p); load_w_half(w, 1, p); }
-__device__ __forceinline__ void tile_mma(f32x16 (&acc)[2], const bf16* A, int lda, WFrag& w, const bf16* __restrict__ next, int lane) {
+template <int RB>
+__device__ __forceinline__ void tile_mma(f32x16 (&acc)[RB], const bf16* A, int lda, WFrag& w, const bf16* __restrict__ next, int lane) {
     const bf16* a0 = A + (lane & 31) * lda + (lane >> 5) * 8;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
         for (int i = half * 8; i < half * 8 + 8; ++i) {
-            const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(a0 + i * 16);
-            const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(a0 + 32 * lda + i * 16);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v[i], x0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v[i], x1, acc[1], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const bf16x8 x = *reinterpret_cast<const bf16x8*>(a0 + r * 32 * lda + i * 16);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.v[i], x, acc[r], 0, 0, 0);
+            }
         }
         if (next) load_w_half(w, half, next);
     }
 }
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2]) {
+template <int RB>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[RB]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 }
-// epilogue walker: f(row m in 0..63, first column n of 4 consecutive ones, values v[4])
-template <typename F>
-__device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[2], int n0, int lane, F&& f) {
+// The tile's 16 bias values per lane are requested BEFORE its matrix work (load_bias) and added here: a bias load inside the epilogue put one
+// L2 round trip (~1.5 k cycles, s_memtime stamps) on every tile's critical path.
+struct Bias4 { float4 b[4]; };
+__device__ __forceinline__ void load_bias(Bias4& bv, const float* __restrict__ bias, int n0, int lane) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int g = 0; g < 4; ++g) bv.b[g] = *reinterpret_cast<const float4*>(bias + n0 + 8 * g + 4 * (lane >> 5));
+}
+// epilogue walker: f(row m in 0 .. 32 RB - 1, first column n of 4 consecutive ones, values v[4] = accumulator + bias)
+template <int RB, typename F>
+__device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[RB], const Bias4& bv, int n0, int lane, F&& f) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float v[4] = {acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+            float v[4] = {acc[i][4 * g] + bv.b[g].x, acc[i][4 * g + 1] + bv.b[g].y, acc[i][4 * g + 2] + bv.b[g].z, acc[i][4 * g + 3] + bv.b[g].w};
             f(i * 32 + (lane & 31), n0 + 8 * g + 4 * (lane >> 5), v);
         }
 }
@@ -315,8 +333,9 @@ __device__ __forceinline__ void attn_finish(const AttnState& st, int Sq, int h, 
 // PART 2: decoder layer from the cross-attention's output (out-projection 2 + residual, LayerNorm 3, feed-forward block)
 // The cross-attention itself (S x M scores per head over a memory of hundreds of rows) is per-score VALU work that wants the whole chip, not the
 // B workgroups of this kernel: it stays ralf_attention_fwd between parts 1 and 2.
-template <int PART>
+template <int PART, int RB = 2>   // RB: 32-row blocks per strip (1 = strips of <= 32 rows: the decode step's batch rows, part 2 only)
 __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) {
+    static_assert(RB == 2 || PART == 2, "32-row strips: part 2 only");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];   // ONE LDS object
     bf16* bufA = reinterpret_cast<bf16*>(lds);              // the A operand of the running product: h1 | o1 | h2 | o2 | h3
     bf16* bufB = bufA + BUFA_ELEMS;                         // q|k|v strip, fp32 epilogue staging, q, one hidden chunk
@@ -328,15 +347,16 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
     const int64_t row0 = (int64_t)b * S;
     const uint64_t seed = (d.p_attn > 0.f || d.p_res > 0.f) ? (uint64_t)d.seed[0] : 0;
     WFrag w;
+    bf16x4 rr[32 * RB / NW];   // this wave's rows of the residual stream (x -> x1 -> x2), in registers from one row pass to the next
     TL_PROBE(0);
 
-    const bf16* res_g;   // the residual stream the feed-forward block starts from
     if constexpr (PART != 2) {
         // ================= self-attention block: x1 = x + drop(attn(LN1(x)) Wo^T + bo) =================
         const float scale2 = d.scale * 1.4426950408889634f;   // log2 domain
         const bf16* xg = (const bf16*)d.x + row0 * TD;
         load_w(w, w_ptr((const bf16*)d.w_in, 16, wave, 0, lane));
-        row_pass<false, false, true>(nullptr, xg, nullptr, S, d.ln1_g, d.ln1_b, d.eps, bufA, (bf16*)d.h1 + row0 * TD, d.mean1 + row0, d.rstd1 + row0, wave, lane);
+        load_rows<RB>(rr, xg, S, wave, lane);
+        row_pass<false, false, true>(nullptr, rr, nullptr, S, d.ln1_g, d.ln1_b, d.eps, bufA, (bf16*)d.h1 + row0 * TD, d.mean1 + row0, d.rstd1 + row0, wave, lane);
         if (tid < TS) {
             const bool mk = tid >= S || (d.kpm && d.kpm[(int64_t)b * d.kpm_bs + tid]);
             Ms[tid] = mk ? 1 : 0;
@@ -351,10 +371,10 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
             const bf16* next = t + 1 < 3 ? w_ptr((const bf16*)d.w_in, 16, (t + 1) * NW + wave, 0, lane) : w_ptr((const bf16*)d.w_o, 16, wave, 0, lane);
             f32x16 acc[2];
             zero_acc(acc);
+            Bias4 bv;
+            load_bias(bv, d.b_in, n0, lane);
             tile_mma(acc, bufA, LDA, w, next, lane);
-            tile_epilogue(acc, n0, lane, [&](int m, int n, float (&v)[4]) {
-                const float4 bb = *reinterpret_cast<const float4*>(d.b_in + n);
-                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            tile_epilogue(acc, bv, n0, lane, [&](int m, int n, float (&v)[4]) {
                 *reinterpret_cast<bf16x4*>(bufB + m * LDQ + n) = to_bf16x4(v);
             });
         }
@@ -380,10 +400,11 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
         {   // drop(o1 Wo^T + bo) -> fp32 staging (the strip is dead)
             f32x16 acc[2];
             zero_acc(acc);
+            Bias4 bv;
+            load_bias(bv, d.b_o, wave * 32, lane);
+            load_rows<RB>(rr, xg, S, wave, lane);   // the residual rows of the pass behind the next barrier
             tile_mma(acc, bufA, LDA, w, PART == 1 ? w_ptr((const bf16*)d.w_q, 16, wave, 0, lane) : w_ptr((const bf16*)d.w1, 16, wave, 0, lane), lane);
-            tile_epilogue(acc, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
-                const float4 bb = *reinterpret_cast<const float4*>(d.b_o + n);
-                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            tile_epilogue(acc, bv, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
                 drop4(v, d.p_res, seed, d.call_out1, (uint64_t)(row0 + m) * TD + n);
                 *reinterpret_cast<f32x4*>(stage + m * STG_LD + n) = (f32x4){v[0], v[1], v[2], v[3]};
             });
@@ -392,20 +413,19 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
         TL_PROBE(4);
         // x1 = x + staged rows; the next LayerNorm of the residual stream on the way
         if constexpr (PART == 1)
-            row_pass<true, true, true>(stage, xg, (bf16*)d.x1 + row0 * TD, S, d.ln2_g, d.ln2_b, d.eps, bufA, (bf16*)d.h2 + row0 * TD, d.mean2 + row0, d.rstd2 + row0, wave, lane);
+            row_pass<true, true, true>(stage, rr, (bf16*)d.x1 + row0 * TD, S, d.ln2_g, d.ln2_b, d.eps, bufA, (bf16*)d.h2 + row0 * TD, d.mean2 + row0, d.rstd2 + row0, wave, lane);
         else
-            row_pass<true, true, true>(stage, xg, (bf16*)d.x1 + row0 * TD, S, d.ln3_g, d.ln3_b, d.eps, bufA, (bf16*)d.h3 + row0 * TD, d.mean3 + row0, d.rstd3 + row0, wave, lane);
+            row_pass<true, true, true>(stage, rr, (bf16*)d.x1 + row0 * TD, S, d.ln3_g, d.ln3_b, d.eps, bufA, (bf16*)d.h3 + row0 * TD, d.mean3 + row0, d.rstd3 + row0, wave, lane);
         lds_barrier();
         TL_PROBE(5);
-        res_g = (const bf16*)d.x1 + row0 * TD;
     }
     if constexpr (PART == 1) {   // q = h2 Wq^T + bq
         f32x16 acc[2];
         zero_acc(acc);
+        Bias4 bv;
+        load_bias(bv, d.b_q, wave * 32, lane);
         tile_mma(acc, bufA, LDA, w, nullptr, lane);
-        tile_epilogue(acc, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
-            const float4 bb = *reinterpret_cast<const float4*>(d.b_q + n);
-            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        tile_epilogue(acc, bv, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
             *reinterpret_cast<bf16x4*>(bufB + m * LDA + n) = to_bf16x4(v);
         });
         lds_barrier();
@@ -417,63 +437,68 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
         // ================= cross-attention block, second half: x2 = x1 + drop(o2 Wo2^T + bo2) =================
         const bf16* x1g = (const bf16*)d.x1 + row0 * TD;
         load_w(w, w_ptr((const bf16*)d.w_o2, 16, wave, 0, lane));
-        copy_in(bufA, (const bf16*)d.o2 + row0 * TD, S, tid);
+        load_rows<RB>(rr, x1g, S, wave, lane);
+        copy_in<RB>(bufA, (const bf16*)d.o2 + row0 * TD, S, tid);
         lds_barrier();
         TL_PROBE(7);
         {
-            f32x16 acc[2];
+            f32x16 acc[RB];
             zero_acc(acc);
+            Bias4 bv;
+            load_bias(bv, d.b_o2, wave * 32, lane);
             tile_mma(acc, bufA, LDA, w, w_ptr((const bf16*)d.w1, 16, wave, 0, lane), lane);
-            tile_epilogue(acc, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
-                const float4 bb = *reinterpret_cast<const float4*>(d.b_o2 + n);
-                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            tile_epilogue(acc, bv, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
                 drop4(v, d.p_res, seed, d.call_out2, (uint64_t)(row0 + m) * TD + n);
                 *reinterpret_cast<f32x4*>(stage + m * STG_LD + n) = (f32x4){v[0], v[1], v[2], v[3]};
             });
         }
         lds_barrier();
         TL_PROBE(8);
-        row_pass<true, true, true>(stage, x1g, (bf16*)d.x2 + row0 * TD, S, d.ln3_g, d.ln3_b, d.eps, bufA, (bf16*)d.h3 + row0 * TD, d.mean3 + row0, d.rstd3 + row0, wave, lane);
+        // (inference callers pass NULL for h3 / mean3 / rstd3 / hid: nothing is kept for a backward pass; x2 is always written, it is read back below)
+        row_pass<true, true, true, RB>(stage, rr, (bf16*)d.x2 + row0 * TD, S, d.ln3_g, d.ln3_b, d.eps, bufA, d.h3 ? (bf16*)d.h3 + row0 * TD : nullptr,
+                                       d.mean3 + row0, d.rstd3 + row0, wave, lane);
         lds_barrier();
-        res_g = (const bf16*)d.x2 + row0 * TD;
     }
     TL_PROBE(9);
 
     // ================= feed-forward block: out = r + drop(W2 drop(relu(W1 LN3(r) + b1)) + b2) =================
-    f32x16 yacc[2];
+    f32x16 yacc[RB];
     zero_acc(yacc);
+    Bias4 bv2;
+    load_bias(bv2, d.b2, wave * 32, lane);
     bf16* Hc = bufB;   // one 256-wide chunk of the hidden activation, [64][LDA]
 #pragma unroll 1
     for (int c = 0; c < TFF / TD; ++c) {
         {   // hidden columns c*256 + wave*32 ..: tile c*8 + wave of W1; next in the weight stream: W2[wave*32 ..][c*256 ..]
-            f32x16 acc[2];
+            f32x16 acc[RB];
             zero_acc(acc);
+            if (c == 1) TL_PROBE(12);
+            Bias4 bv;
+            load_bias(bv, d.b1, c * TD + wave * 32, lane);
             tile_mma(acc, bufA, LDA, w, w_ptr((const bf16*)d.w2, TFF / 16, wave, c * 16, lane), lane);
-            tile_epilogue(acc, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
+            if (c == 1) TL_PROBE(13);
+            tile_epilogue(acc, bv, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
                 const int col = c * TD + n;
-                const float4 bb = *reinterpret_cast<const float4*>(d.b1 + col);
-                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
                 drop4(v, d.p_res, seed, d.call_ffn1, (uint64_t)(row0 + m) * TFF + col);
                 *reinterpret_cast<bf16x4*>(Hc + m * LDA + n) = to_bf16x4(v);
             });
         }
+        if (c == 1) TL_PROBE(14);
         lds_barrier();
-        copy_out<TD>(Hc, LDA, (bf16*)d.hid + row0 * TFF + c * TD, TFF, S, tid);
+        if (c == 1) TL_PROBE(15);
+        if (d.hid) copy_out<TD>(Hc, LDA, (bf16*)d.hid + row0 * TFF + c * TD, TFF, S, tid);
         tile_mma(yacc, Hc, LDA, w, c + 1 < TFF / TD ? w_ptr((const bf16*)d.w1, 16, (c + 1) * NW + wave, 0, lane) : nullptr, lane);
         lds_barrier();
     }
     TL_PROBE(10);
-    tile_epilogue(yacc, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
-        const float4 bb = *reinterpret_cast<const float4*>(d.b2 + n);
-        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+    tile_epilogue(yacc, bv2, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
         drop4(v, d.p_res, seed, d.call_ffn2, (uint64_t)(row0 + m) * TD + n);
         *reinterpret_cast<f32x4*>(stage + m * STG_LD + n) = (f32x4){v[0], v[1], v[2], v[3]};
     });
     lds_barrier();
-    if constexpr (PART == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // res_g = x1, stored by these same lanes earlier in this launch
-    row_pass<true, true, false>(stage, res_g, (bf16*)d.out + row0 * TD, S, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, wave, lane);
+    row_pass<true, true, false, RB>(stage, rr, (bf16*)d.out + row0 * TD, S, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, wave, lane);
     TL_PROBE(11);
 }
 
@@ -524,11 +549,13 @@ extern "C" int ralf_tlayer_fwd(const RalfTLayerDesc* dp, void* stream) {
     if (d.part == 2) RALF_REQUIRE(d.x1 && d.o2 && d.w_o2 && d.b_o2 && d.x2, "tlayer_fwd: part 2 needs x1, o2, the second out-projection and x2");
     if (d.part != 1) {
         RALF_REQUIRE(d.ln3_g && d.ln3_b && d.w1 && d.b1 && d.w2 && d.b2, "tlayer_fwd: feed-forward block: null weight pointer");
-        RALF_REQUIRE(d.h3 && d.mean3 && d.rstd3 && d.hid && d.out, "tlayer_fwd: feed-forward block: null output pointer");
+        RALF_REQUIRE(d.out && ((d.h3 && d.mean3 && d.rstd3 && d.hid) || (d.part == 2 && !d.h3 && !d.mean3 && !d.rstd3 && !d.hid)),
+                     "tlayer_fwd: feed-forward block: null output pointer (part 2 alone may run without h3 / mean3 / rstd3 / hid: inference)");
     }
     hipStream_t st = (hipStream_t)stream;
     if (d.part == 0) hipLaunchKernelGGL((tlayer_fwd_kernel<0>), dim3(d.B), dim3(NT), 0, st, d);
     else if (d.part == 1) hipLaunchKernelGGL((tlayer_fwd_kernel<1>), dim3(d.B), dim3(NT), 0, st, d);
+    else if (d.S <= 32) hipLaunchKernelGGL((tlayer_fwd_kernel<2, 1>), dim3(d.B), dim3(NT), 0, st, d);   // strips of one 32-row block
     else hipLaunchKernelGGL((tlayer_fwd_kernel<2>), dim3(d.B), dim3(NT), 0, st, d);
     return ralf::check_launch("tlayer_fwd");
 }

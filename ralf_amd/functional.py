@@ -71,6 +71,10 @@ class Runtime:
         # training / full-sequence forward of the SHORT-sequence transformer layers (decoder: 5N <= 64 tokens; constraint encoder): one launch per
         # layer instead of 12 (7) (ops.tlayer_fwd; bf16, d = 256, 8 heads, ff = 1024).  The backward pass is the unfused one.
         self.fused_layers = os.environ.get("RALF_FUSED_LAYERS", "1") != "0"
+        # KV-cached decode step: out-projection + LayerNorm + feed-forward per layer as ONE launch on 32-row strips (ops.tlayer_tail).  OFF: measured
+        # 36.2 vs 34.8 ms per B = 256 decode loop -- a workgroup streams all 1.15 MB of the layer's weights through one CU's L2 port (18.3 us per
+        # launch, 26 k of its 39 k cycles in the feed-forward weight stream), the four launches it replaces spread them over the chip
+        self.fused_decode_tail = os.environ.get("RALF_DECODE_TAIL", "0") == "1"
         self.fused_decode = True  # KV-cached decode step: LayerNorm + projections + attention per block in one launch (bf16, d = 256, 8 heads)
         self.fold_bn = True       # inference: eval-mode BatchNorm folded into the convolution epilogues (conv_bn_infer)
 

@@ -263,8 +263,9 @@ class DecodeCache:
     """per-layer state of the KV-cached decoder: cross-attention K/V of the fixed memory (computed once) and the
     growing self-attention K/V of the generated prefix."""
 
-    def __init__(self, cross_kv, self_kv, max_len):
+    def __init__(self, cross_kv, self_kv, max_len, packed=None):
         self.cross_kv, self.self_kv, self.max_len = cross_kv, self_kv, max_len
+        self.packed = packed   # per layer: (cross out_proj, linear1, linear2) in fragment order (ops.tlayer_pack), or None
 
 
 @torch.no_grad()
@@ -277,7 +278,14 @@ def decoder_init_cache(dec: "BaseDecoder", memory: torch.Tensor, rt: Runtime, ma
         kv = ops.gemm(mem2, rt.lp(a.in_proj_weight)[d:], B * M, 2 * d, d, bias=a.in_proj_bias.detach()[d:])
         cross.append(kv.view(B, M, 2 * d))
         selfkv.append(torch.zeros(B, max_len, 2 * d, dtype=rt.dtype, device=memory.device))
-    return DecodeCache(cross, selfkv, max_len)
+    packed = None
+    layers = list(dec.transformer.layers)
+    if (rt.fused_decode and rt.fused_decode_tail and rt.dtype == torch.bfloat16 and memory.is_cuda and d == 256 and len(layers) * 3 <= 48
+            and all(l.linear1.weight.shape[0] == 1024 for l in layers)):
+        # the step's tail per layer (out-projection + residual, LayerNorm, feed-forward, residual) runs as one launch on weights in fragment order
+        flat = ops.tlayer_pack([m for l in layers for m in (rt.lp(l.multihead_attn.out_proj.weight), rt.lp(l.linear1.weight), rt.lp(l.linear2.weight))])
+        packed = [flat[3 * i:3 * i + 3] for i in range(len(layers))]
+    return DecodeCache(cross, selfkv, max_len, packed)
 
 
 @torch.no_grad()
@@ -307,6 +315,11 @@ def decoder_step(dec: "BaseDecoder", tok: torch.Tensor, pos: int, cache: DecodeC
             x = ops.gemm(o, rt.lp(sa.out_proj.weight), B, d, d, bias=sa.out_proj.bias.detach(), res=x)
             o = ops.decode_attn(x, layer.norm2.weight.detach(), layer.norm2.bias.detach(), rt.lp(ca.in_proj_weight), ca.in_proj_bias.detach(),
                                 ckv, ckv.shape[1], H, False)
+            if cache.packed is not None:   # out-projection + residual + LayerNorm + feed-forward + residual in one launch (ralf_tlayer_fwd part 2)
+                pk = cache.packed[li]
+                x = ops.tlayer_tail(o, x, {"out2": (pk[0], ca.out_proj.bias.detach()), "ln3": (layer.norm3.weight.detach(), layer.norm3.bias.detach()),
+                                           "ffn1": (pk[1], layer.linear1.bias.detach()), "ffn2": (pk[2], layer.linear2.bias.detach())})
+                continue
             x = ops.gemm(o, rt.lp(ca.out_proj.weight), B, d, d, bias=ca.out_proj.bias.detach(), res=x)
         else:
             h, _, _ = ops.layernorm_fwd(x, layer.norm1.weight.detach(), layer.norm1.bias.detach(), save_stats=False)

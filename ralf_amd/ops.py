@@ -604,6 +604,26 @@ def tlayer_fwd(x, W, *, causal, kpm=None, kpm_stride=0, kv=None, p_attn=0.0, p_r
     return t
 
 
+def tlayer_tail(o2, x1, W, rows_per_strip=None, eps=1e-5):
+    """inference tail of a decoder layer on rows [R, 256] bf16 (ralf_tlayer_fwd part 2, nothing kept for a backward pass):
+    r = x1 + o2 Wo2^T + bo2;  out = r + W2 relu(W1 LN3(r) + b1) + b2.  W: "out2", "ffn1", "ffn2" = (weight packed by tlayer_pack, fp32 bias),
+    "ln3" = (gamma, beta).  The R rows are cut into strips of rows_per_strip (default: the largest of 32, 16, .. 1 that divides R)."""
+    from ._abi import RalfTLayerDesc
+
+    R, dm = o2.shape
+    assert dm == 256 and o2.dtype == torch.bfloat16 and x1.dtype == torch.bfloat16 and o2.is_contiguous() and x1.is_contiguous() and x1.shape == o2.shape
+    S = rows_per_strip or next(s for s in (32, 16, 8, 4, 2, 1) if R % s == 0)
+    assert R % S == 0 and 1 <= S <= TLAYER_MAX_ROWS
+    out, x2 = torch.empty_like(x1), torch.empty_like(x1)
+    d = RalfTLayerDesc()
+    d.x1, d.o2, d.x2, d.out = _p(x1), _p(o2), _p(x2), _p(out)
+    d.w_o2, d.b_o2 = _p(W["out2"][0]), _p(W["out2"][1])
+    d.ln3_g, d.ln3_b, d.w1, d.b1, d.w2, d.b2 = _p(W["ln3"][0]), _p(W["ln3"][1]), _p(W["ffn1"][0]), _p(W["ffn1"][1]), _p(W["ffn2"][0]), _p(W["ffn2"][1])
+    d.B, d.S, d.part, d.eps = R // S, S, 2, eps
+    _call("ralf_tlayer_fwd", ctypes.byref(d))
+    return out
+
+
 _DEC_MAXK = None
 
 

@@ -156,6 +156,52 @@ def test_fused_layer_module_matches_unfused_module_forward_and_backward(cross, t
             torch.testing.assert_close(res[True][k], res[False][k], rtol=1e-5, atol=1e-5 * res[False][k].abs().max().item(), msg=lambda m: f"{k}: {m}")
 
 
+@pytest.mark.parametrize("R,strip", [(256, None), (64, None), (48, None), (5, None), (64, 64), (96, 48)])
+def test_decode_tail_equals_the_unfused_chain(R, strip):
+    """part 2 on strips of batch rows, nothing kept (the KV-cached decode step's tail: nn.decoder_step): the bits of
+    out-projection + residual -> LayerNorm -> linear1 + ReLU -> linear2 + residual as four launches"""
+    from ralf_amd import ops
+
+    w = make_weights(True, seed=R)
+    o2 = rnd(R, D, seed=1).to(torch.bfloat16).cuda()
+    x1 = rnd(R, D, seed=2).to(torch.bfloat16).cuda()
+    r = ops.gemm(o2, w["ca_out"][0], R, D, D, bias=w["ca_out"][1], res=x1)
+    h, _, _ = ops.layernorm_fwd(r, *w["ln3"], save_stats=False)
+    f = ops.gemm(h, w["ffn1"][0], R, FF, D, bias=w["ffn1"][1], act="relu")
+    want = ops.gemm(f, w["ffn2"][0], R, D, FF, bias=w["ffn2"][1], res=r)
+    pk = ops.tlayer_pack([w["ca_out"][0], w["ffn1"][0], w["ffn2"][0]])
+    got = ops.tlayer_tail(o2, x1, {"out2": (pk[0], w["ca_out"][1]), "ln3": w["ln3"], "ffn1": (pk[1], w["ffn1"][1]), "ffn2": (pk[2], w["ffn2"][1])}, rows_per_strip=strip)
+    torch.cuda.synchronize()
+    same_bits(got, want, "out")
+
+
+def test_decode_step_with_the_one_launch_tail_equals_the_separate_launches():
+    """nn.decoder_step with Runtime.fused_decode_tail (off by default: slower): same logits, bit for bit, over a few positions"""
+    from ralf_amd import functional as RF, nn as RN
+
+    torch.manual_seed(3)
+    dec = RN.BaseDecoder(137, D, 2, H, FF).cuda()
+    for prm in dec.parameters():
+        torch.nn.init.normal_(prm, std=0.05)
+    mem = rnd(64, 90, D, seed=4).to(torch.bfloat16).cuda()
+    outs = {}
+    for tail in (True, False):
+        rt = RF.Runtime(torch.bfloat16, seed=1)
+        rt.to(torch.device("cuda"))
+        rt.fused_decode_tail = tail
+        cache = RN.decoder_init_cache(dec, mem, rt, 8)
+        assert (cache.packed is not None) == tail
+        kpm = torch.zeros(64, 8, dtype=torch.uint8, device="cuda")
+        tok = torch.arange(64, device="cuda") % 137
+        logits = []
+        for pos in range(4):
+            lg = RN.decoder_step(dec, tok, pos, cache, rt, kpm[:, :pos + 1].contiguous())
+            logits.append(lg)
+            tok = lg.argmax(1)
+        outs[tail] = torch.stack(logits)
+    same_bits(outs[True], outs[False], "logits")
+
+
 def test_weight_packing_is_the_documented_permutation():
     from ralf_amd import ops
 

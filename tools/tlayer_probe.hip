@@ -91,6 +91,11 @@ int main(int argc, char** argv) {
             printf("  %-36s %9.0f cycles\n", names[seq[part][k]], sum);
         }
         printf("  %-36s %9.0f cycles (s_memtime ticks)\n", "workgroup lifetime", tot);
+        if (part != 1) {   // second hidden chunk: matrix work of W1, its epilogue, the wait at the barrier
+            double a = 0, b2 = 0, c2 = 0;
+            for (int b = 0; b < B; ++b) { a += (double)(h[b * 16 + 13] - h[b * 16 + 12]); b2 += (double)(h[b * 16 + 14] - h[b * 16 + 13]); c2 += (double)(h[b * 16 + 15] - h[b * 16 + 14]); }
+            printf("  hidden chunk 1: W1 tile %.0f, epilogue %.0f, barrier %.0f cycles\n", a / B, b2 / B, c2 / B);
+        }
     }
     return 0;
 }
