@@ -237,6 +237,218 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// dQ, dK, dV in ONE pass for short sequences (Sq, Sk <= 256, dh = 32): one workgroup of 8 waves per (batch, head).
+// The two-kernel backward recomputes S, P, the dropout mask and dS twice (once with a lane per query for dQ, once with a lane per key for
+// dK / dV), and that per-score VALU work -- not the matrix cores -- bounds both kernels.  Here wave w owns keys 32w .. 32w+31 as in the
+// per-key kernel (dK, dV accumulate in registers over the query steps), and the SAME dS feeds dQ: the wave writes its dS block
+// [32 keys][32 queries] to a private LDS tile, reads it back through the transpose path as the key-contracted operand
+// (dQ^T[dim][query] = K^T dS^T), and the eight waves' partial dQ of a 32-query step meet in LDS slots that all threads sum IN WAVE ORDER
+// (deterministic; double-buffered slots: one barrier per step).  delta = rowsum(dO o O) is computed in the prologue.
+// ------------------------------------------------------------------------------------------------
+constexpr int FB_S = 256, FB_LD = 40, FB_SLOT_LD = 36;
+__global__ __launch_bounds__(512) void attn_bwd_fused_mfma(const RalfAttnDesc d) {
+    constexpr int DH = 32;
+    __shared__ __attribute__((aligned(16))) bf16 Qs[FB_S * FB_LD];
+    __shared__ __attribute__((aligned(16))) bf16 Gs[FB_S * FB_LD];
+    __shared__ __attribute__((aligned(16))) bf16 Kt[8][32 * FB_LD];      // per wave: its 32 key rows (transpose-read for dQ)
+    __shared__ __attribute__((aligned(16))) bf16 St[8][32 * FB_LD];      // per wave: dS [key][query] of the current step
+    __shared__ __attribute__((aligned(16))) float Slot[2][8][32 * FB_SLOT_LD];   // partial dQ [query][dim] per wave, double-buffered
+    __shared__ __attribute__((aligned(16))) float Ls[FB_S], Ds[FB_S];
+    __shared__ __attribute__((aligned(16))) uint32_t Rk[FB_S];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, Ln = lane & 15;
+    const WgId wg = wg_id(1, d.H);
+    const int b = wg.b, h = wg.h;
+    const bf16* Qp = (const bf16*)d.q + b * d.q_bs + (int64_t)h * DH;
+    const bf16* Kp = (const bf16*)d.k + b * d.k_bs + (int64_t)h * DH;
+    const bf16* Vp = (const bf16*)d.v + b * d.v_bs + (int64_t)h * DH;
+    const bf16* Op = (const bf16*)d.o + b * d.o_bs + (int64_t)h * DH;
+    const bf16* Gp = (const bf16*)d.dout + b * d.do_bs + (int64_t)h * DH;
+    const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * (d.kpm_bs ? d.kpm_bs : (int64_t)d.Sk) : nullptr;
+    const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
+    const uint32_t thr = attn_thr16(d.p_drop);
+    const float inv_keep = 1.f / (1.f - d.p_drop);
+    const float scale2 = d.scale * 1.4426950408889634f;
+    const int64_t stat0 = ((int64_t)b * d.H + h) * d.Sq;
+
+    // ---- prologue: Q and dO rows into LDS, delta, lse (log2 domain), dropout row keys; the wave's key rows ----
+    {   // 2 threads per query row: 16 dims each
+        const int q = tid >> 1, half = tid & 1;
+        uint4 qv[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)}, gv[2] = {qv[0], qv[0]}, ov[2] = {qv[0], qv[0]};
+        if (q < d.Sq) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                qv[i] = *reinterpret_cast<const uint4*>(Qp + (int64_t)q * d.q_rs + half * 16 + i * 8);
+                gv[i] = *reinterpret_cast<const uint4*>(Gp + (int64_t)q * d.do_rs + half * 16 + i * 8);
+                ov[i] = *reinterpret_cast<const uint4*>(Op + (int64_t)q * d.o_rs + half * 16 + i * 8);
+            }
+        }
+        float dl = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<uint4*>(Qs + q * FB_LD + half * 16 + i * 8) = qv[i];
+            *reinterpret_cast<uint4*>(Gs + q * FB_LD + half * 16 + i * 8) = gv[i];
+            const bf16x8 gg = *reinterpret_cast<const bf16x8*>(&gv[i]), oo = *reinterpret_cast<const bf16x8*>(&ov[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += (float)gg[e] * (float)oo[e];
+        }
+        dl += __shfl_xor(dl, 1);
+        if (half == 0) {
+            Ds[q] = dl;
+            Ls[q] = q < d.Sq ? d.lse[stat0 + q] * 1.4426950408889634f : 0.f;
+            Rk[q] = d.p_drop > 0.f ? attn_rowkey(seed, d.call_id, ((uint64_t)b * d.H + h) * d.Sq + q) : 0u;
+            if (d.delta && q < d.Sq) d.delta[stat0 + q] = dl;
+        }
+    }
+    const int kw0 = wave * 32;   // the wave's first key
+    {   // the wave's 32 key rows (4 x 16-byte vectors each): 128 vectors, 2 per lane
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = lane + 64 * i, r = e >> 2, c = e & 3;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (kw0 + r < d.Sk) v = *reinterpret_cast<const uint4*>(Kp + (int64_t)(kw0 + r) * d.k_rs + c * 8);
+            *reinterpret_cast<uint4*>(Kt[wave] + r * FB_LD + c * 8) = v;
+        }
+    }
+    bf16x8 kf[2], vf[2];
+    bool kmasked[2];
+#pragma unroll
+    for (int hk = 0; hk < 2; ++hk) {
+        kf[hk] = frag_global(Kp, d.k_rs, kw0 + hk * 16, d.Sk, 0, lane);
+        vf[hk] = frag_global(Vp, d.v_rs, kw0 + hk * 16, d.Sk, 0, lane);
+        const int kj = kw0 + hk * 16 + Ln;
+        kmasked[hk] = kj >= d.Sk || (kpm && kpm[kj < d.Sk ? kj : 0]);
+    }
+    f32x4 dk[2][2], dv[2][2];
+#pragma unroll
+    for (int hk = 0; hk < 2; ++hk)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) dk[hk][c] = dv[hk][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    const bool wave_active = kw0 < d.Sk;   // (wave-uniform)
+    int step = 0;
+    for (int s0 = 0; s0 < d.Sq; s0 += 32, ++step) {
+        float* slot = Slot[step & 1][wave];
+        if (wave_active) {
+            const f32x4 L4[2] = {*reinterpret_cast<const f32x4*>(Ls + s0 + 4 * g), *reinterpret_cast<const f32x4*>(Ls + s0 + 16 + 4 * g)};
+            const f32x4 D4[2] = {*reinterpret_cast<const f32x4*>(Ds + s0 + 4 * g), *reinterpret_cast<const f32x4*>(Ds + s0 + 16 + 4 * g)};
+            typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+            const u32x4v R4[2] = {*reinterpret_cast<const u32x4v*>(Rk + s0 + 4 * g), *reinterpret_cast<const u32x4v*>(Rk + s0 + 16 + 4 * g)};
+#pragma unroll
+            for (int hk = 0; hk < 2; ++hk) {
+                const int kj = kw0 + hk * 16 + Ln;
+                // S[query][key], dP[query][key]: rows = 16 queries (LDS), columns = 16 of the wave's keys
+                f32x4 s[2], dp[2];
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qs + (s0 + blk * 16 + Ln) * FB_LD + g * 8);
+                    const bf16x8 ga = *reinterpret_cast<const bf16x8*>(Gs + (s0 + blk * 16 + Ln) * FB_LD + g * 8);
+                    s[blk] = mfma16(qa, kf[hk], (f32x4){0.f, 0.f, 0.f, 0.f});
+                    dp[blk] = mfma16(ga, vf[hk], (f32x4){0.f, 0.f, 0.f, 0.f});
+                }
+                float pj[8];
+                if (!d.causal && s0 + 32 <= d.Sq) {
+                    const float kz = kmasked[hk] ? 0.f : 1.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pj[j] = kz * __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -L4[j >> 2][j & 3]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int qi = s0 + (j >> 2) * 16 + 4 * g + (j & 3);
+                        const bool masked = kmasked[hk] || qi >= d.Sq || (d.causal && kj > qi);
+                        pj[j] = masked ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -L4[j >> 2][j & 3]));
+                    }
+                }
+                bf16x8 pf, dsf;
+                if (d.p_drop > 0.f) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const bool keep = attn_keep(R4[j >> 2][j & 3], (uint32_t)kj, thr);
+                        pf[j] = (bf16)(keep ? pj[j] * inv_keep : 0.f);
+                        dsf[j] = (bf16)(pj[j] * ((keep ? dp[j >> 2][j & 3] * inv_keep : 0.f) - D4[j >> 2][j & 3]));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        pf[j] = (bf16)pj[j];
+                        dsf[j] = (bf16)(pj[j] * (dp[j >> 2][j & 3] - D4[j >> 2][j & 3]));
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    // transposed fragments of the query tiles: matrix rows = 16 dims, k-slots = the step's 32 queries (frag_cols_T's slot order
+                    // = the order pf / dsf hold them in)
+                    const bf16* qg = Gs + (s0 + 4 * g + (Ln >> 2)) * FB_LD + c * 16 + (Ln & 3) * 4;
+                    const bf16* qq = Qs + (s0 + 4 * g + (Ln >> 2)) * FB_LD + c * 16 + (Ln & 3) * 4;
+                    const bf16x4 glo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qg)), ghi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qg + 16 * FB_LD));
+                    const bf16x4 qlo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qq)), qhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qq + 16 * FB_LD));
+                    dv[hk][c] = mfma16(__builtin_shufflevector(glo, ghi, 0, 1, 2, 3, 4, 5, 6, 7), pf, dv[hk][c]);
+                    dk[hk][c] = mfma16(__builtin_shufflevector(qlo, qhi, 0, 1, 2, 3, 4, 5, 6, 7), dsf, dk[hk][c]);
+                }
+                // dS block -> the wave's tile [key][query]: the lane's key row, queries 4g .. 4g+3 and 16+4g .. 16+4g+3
+                bf16* sr = St[wave] + (hk * 16 + Ln) * FB_LD;
+                *reinterpret_cast<bf16x4*>(sr + 4 * g) = __builtin_shufflevector(dsf, dsf, 0, 1, 2, 3);
+                *reinterpret_cast<bf16x4*>(sr + 16 + 4 * g) = __builtin_shufflevector(dsf, dsf, 4, 5, 6, 7);
+            }
+            // partial dQ^T[dim][query] = K^T dS^T over the wave's 32 keys (both operands through the transpose read: same k-slot order)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes above (no other wave touches St[wave])
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const bf16* sp = St[wave] + (4 * g + (Ln >> 2)) * FB_LD + qb * 16 + (Ln & 3) * 4;
+                const bf16x4 slo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, sp)), shi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, sp + 16 * FB_LD));
+                const bf16x8 sf = __builtin_shufflevector(slo, shi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16* kp2 = Kt[wave] + (4 * g + (Ln >> 2)) * FB_LD + db * 16 + (Ln & 3) * 4;
+                    const bf16x4 klo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, kp2)), khi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, kp2 + 16 * FB_LD));
+                    const f32x4 part = mfma16(__builtin_shufflevector(klo, khi, 0, 1, 2, 3, 4, 5, 6, 7), sf, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    // lane = query qb*16 + Ln, dims db*16 + 4g .. +3
+                    *reinterpret_cast<f32x4*>(slot + (qb * 16 + Ln) * FB_SLOT_LD + db * 16 + 4 * g) = part;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {   // an idle wave's slot must still read as zero: 32 x 32 floats, 4 x float4 per lane
+                const int e = lane + 64 * i, r = e >> 3, c = e & 7;
+                *reinterpret_cast<f32x4*>(slot + r * FB_SLOT_LD + c * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __syncthreads();
+        {   // dQ rows of this step: the eight partials in wave order, two dims per thread
+            const int q = tid >> 4, dp2 = (tid & 15) * 2;
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const float2 v = *reinterpret_cast<const float2*>(Slot[step & 1][w] + q * FB_SLOT_LD + dp2);
+                a0 += v.x; a1 += v.y;
+            }
+            if (s0 + q < d.Sq) {
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                bf16x2 t;
+                t[0] = (bf16)(a0 * d.scale); t[1] = (bf16)(a1 * d.scale);
+                *reinterpret_cast<bf16x2*>((bf16*)d.dq + b * d.dq_bs + (int64_t)(s0 + q) * d.dq_rs + (int64_t)h * DH + dp2) = t;
+            }
+        }
+    }
+#pragma unroll
+    for (int hk = 0; hk < 2; ++hk) {
+        const int kj = kw0 + hk * 16 + Ln;
+        if (kj < d.Sk) {
+            bf16* dKp = (bf16*)d.dk + b * d.dk_bs + (int64_t)kj * d.dk_rs + (int64_t)h * DH;
+            bf16* dVp = (bf16*)d.dv + b * d.dv_bs + (int64_t)kj * d.dv_rs + (int64_t)h * DH;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                bf16x4 tk, tv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { tk[r] = (bf16)(dk[hk][c][r] * d.scale); tv[r] = (bf16)dv[hk][c][r]; }
+                *reinterpret_cast<bf16x4*>(dKp + c * 16 + 4 * g) = tk;
+                *reinterpret_cast<bf16x4*>(dVp + c * 16 + 4 * g) = tv;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // dQ (+ delta): same geometry as the forward kernel
 // ------------------------------------------------------------------------------------------------
 template <int DH>
@@ -985,6 +1197,17 @@ int ralf_attention_fwd_mfma(const RalfAttnDesc& d, hipStream_t st) {
     return ralf::check_launch("attention_fwd_mfma");
 }
 int ralf_attention_bwd_mfma(const RalfAttnDesc& d, hipStream_t st) {
+    // 128 .. 256 queries x keys per head (the image encoder's 16 x 16 tokens): dQ, dK, dV from one pass over the scores.  Measured inside the
+    // train step (windowed rocprofv3 A/B): 61 us per call against 42 + 29 us for the per-key + per-query kernels at S = 256; on the decoder's
+    // 50-row sequences the one-pass kernel is SLOWER (11.5 us against 4.0 + 4.3: one 8-wave workgroup per head, 158 KB of LDS = one
+    // workgroup per CU, against two kernels whose 4-wave workgroups fill the CUs), so short sequences keep the two kernels.
+    // RALF_ATTN_BWD_FUSED: 0 = never, 2 = wherever it fits (tests).
+    static const int fused = [] { const char* e = getenv("RALF_ATTN_BWD_FUSED"); return e ? atoi(e) : 1; }();
+    if (fused && d.dh == 32 && d.Sq <= FB_S && d.Sk <= FB_S && (fused == 2 || (d.Sq >= 128 && d.Sk >= 128)) && d.q_rs % 8 == 0 && d.k_rs % 8 == 0 && d.v_rs % 8 == 0 && d.o_rs % 8 == 0 && d.do_rs % 8 == 0 &&
+        d.dq_rs % 2 == 0) {
+        hipLaunchKernelGGL(attn_bwd_fused_mfma, dim3(d.H * d.B), dim3(512), 0, st, d);
+        return ralf::check_launch("attention_bwd_fused");
+    }
     const dim3 gq(ceil_div(d.Sq, 64) * d.H * d.B), gk(ceil_div(d.Sk, 64) * d.H * d.B);
     if (d.dh == 32) {
         hipLaunchKernelGGL((attn_bwd_dq_mfma<32>), gq, dim3(256), 0, st, d);

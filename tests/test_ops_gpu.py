@@ -538,3 +538,73 @@ def test_fanout_alias_with_an_extra_consumer_of_the_shared_input():
     want = [x.grad] + [W.grad for W in Ws]
     for u, v in zip(got, want):
         torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-4)
+
+
+_ATTN_BWD_CASES = """
+import sys
+sys.path.insert(0, {root!r})
+import torch
+from ralf_amd import ops
+g = torch.Generator(device="cuda").manual_seed(11)
+out = {{}}
+# (B, H, Sq, Sk, packed self-attention?, causal, padded keys, p)
+for B, H, Sq, Sk, packed, causal, pad, p in [(4, 8, 256, 256, True, False, False, 0.1), (3, 8, 50, 50, True, True, True, 0.1), (2, 8, 50, 200, False, False, False, 0.0),
+                                             (2, 8, 256, 77, False, False, True, 0.1), (5, 8, 1, 33, False, False, False, 0.0), (2, 8, 33, 256, False, True, False, 0.1),
+                                             (2, 8, 40, 300, False, False, False, 0.1)]:
+    dh = 32
+    seed = torch.tensor([99], dtype=torch.int64, device="cuda")
+    if packed:
+        qkv = torch.randn(B, Sq, 3 * H * dh, device="cuda", generator=g).bfloat16()
+        q = k = v = qkv
+        offs = (0, H * dh, 2 * H * dh)
+    else:
+        q = torch.randn(B, Sq, H * dh, device="cuda", generator=g).bfloat16()
+        k = v = torch.randn(B, Sk, 2 * H * dh, device="cuda", generator=g).bfloat16()
+        offs = (0, 0, H * dh)
+    kpm = None
+    if pad:
+        kpm = torch.zeros(B, Sk, dtype=torch.uint8, device="cuda")
+        kpm[:, Sk - 5:] = 1
+        kpm[0, 1] = 1
+    o, lse = ops.attention_fwd(q, k, v, B, H, Sq, Sk, dh, *offs, causal=causal, kpm=kpm, p_drop=p, seed=seed, call_id=5)
+    do = torch.randn(B, Sq, H * dh, device="cuda", generator=g).bfloat16()
+    if packed:
+        da = torch.zeros_like(qkv)
+        ops.attention_bwd(do, q, k, v, o, lse, da, da, da, B, H, Sq, Sk, dh, *offs, *offs, causal=causal, kpm=kpm, p_drop=p, seed=seed, call_id=5)
+        out[(B, Sq, Sk, causal, pad, p, "dqkv")] = da
+    else:
+        dq, dkv = torch.zeros_like(q), torch.zeros_like(k)
+        ops.attention_bwd(do, q, k, v, o, lse, dq, dkv, dkv, B, H, Sq, Sk, dh, *offs, *offs, causal=causal, kpm=kpm, p_drop=p, seed=seed, call_id=5)
+        out[(B, Sq, Sk, causal, pad, p, "dq")] = dq
+        out[(B, Sq, Sk, causal, pad, p, "dkv")] = dkv
+torch.cuda.synchronize()
+torch.save({{k: v.cpu() for k, v in out.items()}}, {path!r})
+"""
+
+
+def test_one_pass_attention_backward_equals_the_two_kernel_backward(tmp_path):
+    """sequences of up to 256 queries / keys (dh = 32) can take dQ, dK, dV from ONE pass over the scores (attn_bwd_fused_mfma: the default
+    from 128 x 128 on, everywhere it fits with RALF_ATTN_BWD_FUSED=2 as here); RALF_ATTN_BWD_FUSED=0 (read once per process) keeps the
+    per-query + per-key kernels.  Same P, dropout mask and dS arithmetic; dQ sums the eight key blocks'
+    partial products in fp32 in a fixed order instead of chaining them through one accumulator, so it may differ in the last bf16 bit.
+    The last case (Sk = 300) runs the two-kernel path in both processes."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for flag in ("2", "0"):
+        path = str(tmp_path / f"attn_bwd{flag}.pt")
+        r = subprocess.run([sys.executable, "-c", _ATTN_BWD_CASES.format(root=root, path=path)], env=dict(os.environ, RALF_ATTN_BWD_FUSED=flag),
+                           capture_output=True, text=True, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        res[flag] = torch.load(path)
+    assert set(res["2"]) == set(res["0"]) and len(res["2"]) == 12
+    for k in res["2"]:
+        a, b = res["2"][k].float(), res["0"][k].float()
+        assert torch.isfinite(a).all(), k
+        tol = 2.0 ** -7 * b.abs().max().item()   # one bf16 ulp at the tensor's scale
+        bad = ((a - b).abs() > tol).float().mean().item()
+        assert (a - b).abs().max().item() <= 4 * tol and bad < 1e-3, (k, (a - b).abs().max().item(), tol, bad)
+        assert b.abs().max().item() > 1e-3, k
