@@ -71,6 +71,8 @@ class Runtime:
         # training / full-sequence forward of the SHORT-sequence transformer layers (decoder: 5N <= 64 tokens; constraint encoder): one launch per
         # layer instead of 12 (7) (ops.tlayer_fwd; bf16, d = 256, 8 heads, ff = 1024).  The backward pass is the unfused one.
         self.fused_layers = os.environ.get("RALF_FUSED_LAYERS", "1") != "0"
+        # ... and the feed-forward half of the LONG-sequence encoder layers (image encoder, 16 384 rows): LayerNorm + both products on 64-row strips
+        self.fused_ffn = os.environ.get("RALF_FUSED_FFN", "1") != "0"
         # KV-cached decode step: out-projection + LayerNorm + feed-forward per layer as ONE launch on 32-row strips (ops.tlayer_tail).  OFF: measured
         # 36.2 vs 34.8 ms per B = 256 decode loop -- a workgroup streams all 1.15 MB of the layer's weights through one CU's L2 port (18.3 us per
         # launch, 26 k of its 39 k cycles in the feed-forward weight stream), the four launches it replaces spread them over the chip
@@ -1046,6 +1048,41 @@ class TLayerFn(Function):
         dh = lin_bwd(dqkv, t["h1"], siw, sib, 2, (0, 3 * d), False, 0)
         dx = ln_bwd(dh, g, x, n1w, n1b, t["mean1"], t["rstd1"], 0, tag_in)
         return (dx, dkv, None, None, None, None, None, *grads)
+
+
+class TFFNFn(Function):
+    """x + drop(W2 drop(relu(W1 LN(x) + b1)) + b2) for ANY number of rows, forward in one launch on 64-row strips (ops.tlayer_ffn): the second
+    half of a pre-norm encoder layer whose attention is too long for TLayerFn (the image encoder: 256 tokens per sample).  Saves what
+    LayerNormSkipFn + FFNFn save; the backward is theirs.  packed = ops.tlayer_pack([linear1, linear2]) or None."""
+
+    @staticmethod
+    def forward(ctx, x, p, rt, packed, n3w, n3b, w1, b1, w2, b2):
+        x = x.contiguous()
+        c1 = rt.next_call() if p > 0.0 else 0
+        c2 = rt.next_call() if p > 0.0 else 0
+        if packed is None:
+            packed = ops.tlayer_pack([rt.lp(w1), rt.lp(w2)])
+        t = ops.tlayer_ffn(x, {"ln3": (n3w.detach(), n3b.detach()), "ffn1": (packed[0], b1.detach()), "ffn2": (packed[1], b2.detach())},
+                           p=p, seed=rt.seed if p > 0.0 else None, calls=(c1, c2))
+        ctx.save_for_backward(x, n3w, n3b, w1, b1, w2, b2, t["h3"], t["mean3"], t["rstd3"], t["hid"])
+        ctx.cfg = (p, c2, rt, rt.dropout_tag(x))
+        rt.tag_dropout(t["out"], p, c2)
+        return t["out"]
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, c2, rt, tag_in = ctx.cfg
+        x, n3w, n3b, w1, b1, w2, b2, h3, mean3, rstd3, hid = ctx.saved_tensors
+        rows = x.numel() // x.shape[-1]
+        c = _Ctx((h3.view(rows, -1), w1, w2, hid.view(rows, -1), None), (True,), b1=b1, b2=b2, rt=rt, act="relu", p=p, has_res=True, xshape=x.shape, c2=c2)
+        dh, dW1, db1, dW2, db2, dres = FFNFn.backward(c, dy)[:6]
+        dx, dg, db = _ln_backward(_Ctx((x, n3w, mean3, rstd3), rt=rt, beta=n3b, tag=tag_in), dh, dres)
+        return dx, None, None, None, dg, db, dW1, db1, dW2, db2
+
+
+def tffn_supported(x, rt, d, dim_ff) -> bool:
+    return (rt.fused_layers and rt.fused_ffn and rt.dtype == torch.bfloat16 and x.is_cuda and d == 256 and dim_ff == 1024 and x.shape[-1] == d
+            and (x.numel() // d) % 64 == 0)
 
 
 def _acc(a, b):

@@ -193,8 +193,10 @@ class _GeneratorBase(nn.Module):
     def _image_memory(self, image):
         rt = self.rt.to(image.device)
         x = self.encoder(image, rt)  # [B, hw, d] with the 2-D sine table already added
-        for layer in self.transformer_encoder.layers:
-            x = layer(x, rt)
+        layers = list(self.transformer_encoder.layers)
+        packs = RN.pack_ffn_layers(layers, x, rt)   # (bf16: the feed-forward halves run as one launch each on weights in fragment order)
+        for li, layer in enumerate(layers):
+            x = layer(x, rt, packed=packs[li] if packs else None)
         return x
 
     def forward(self, inputs: dict) -> dict:

@@ -128,6 +128,9 @@ class TransformerEncoderLayer(nn.Module, _FFNMixin):
         if self.norm_first:
             h, x = RF.layer_norm_skip(x, self.norm1.weight, self.norm1.bias, rt)
             x = self.self_attn.self_attn(h, x, rt, kpm=kpm, p_attn=self.p, p_out=self.p)
+            if RF.tffn_supported(x, rt, self.self_attn.d, self.linear1.weight.shape[0]):   # LayerNorm + feed-forward + residual in one launch
+                return RF.TFFNFn.apply(x, rt.drop_p(self.p), rt, packed, self.norm2.weight, self.norm2.bias, self.linear1.weight, self.linear1.bias,
+                                       self.linear2.weight, self.linear2.bias)
             h, x = RF.layer_norm_skip(x, self.norm2.weight, self.norm2.bias, rt)
             return self._ffn(h, x, rt, self.p)
         x = RF.layer_norm(self.self_attn.self_attn(x, x, rt, kpm=kpm, p_attn=self.p, p_out=self.p), self.norm1.weight, self.norm1.bias, rt)
@@ -215,6 +218,17 @@ class FuseAttention(nn.Module):
         kv = RF.linear(ctx, self.to_kv.weight, rt=rt)
         o = RF.AttnFn.apply(q, kv, self.heads, self.dim_head, False, None, 0.0, rt)
         return RF.linear(o, self.to_out[0].weight, self.to_out[0].bias, rt=rt)
+
+
+def pack_ffn_layers(layers, x, rt: Runtime):
+    """fragment-order linear1 / linear2 weights (ops.tlayer_pack) of all `layers` in ONE launch when their feed-forward halves take the
+    one-launch path on x (functional.TFFNFn) and the layers as a whole do not (long sequences); else None"""
+    if not layers or len(layers) * 2 > 48 or any(l.fusable(x, rt) for l in layers):
+        return None
+    if not all(l.norm_first and RF.tffn_supported(x, rt, l.self_attn.d, l.linear1.weight.shape[0]) for l in layers):
+        return None
+    flat = ops.tlayer_pack([m for l in layers for m in (rt.lp(l.linear1.weight), rt.lp(l.linear2.weight))])
+    return [flat[2 * i:2 * i + 2] for i in range(len(layers))]
 
 
 def _pack_layers(layers, x, rt: Runtime):

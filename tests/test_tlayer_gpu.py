@@ -243,3 +243,52 @@ def test_fused_layer_is_what_the_decoder_runs():
         assert len(seen) == 1
     finally:
         ops.tlayer_fwd = orig
+
+
+@pytest.mark.parametrize("rows,p", [(16384, 0.1), (128, 0.0), (64 * 7, 0.1)])
+def test_feed_forward_block_on_strips_writes_the_bits_of_the_unfused_launches(rows, p):
+    """part 3: LayerNorm -> linear1 + ReLU + dropout -> linear2 + dropout + residual on 64-row strips of any [rows, 256] tensor"""
+    from ralf_amd import ops
+
+    w = make_weights(False, seed=rows % 97)
+    x = rnd(rows, D, seed=1).to(torch.bfloat16).cuda()
+    seed = torch.tensor([4242], dtype=torch.int64, device="cuda")
+    sd = seed if p > 0 else None
+    h, mean, rstd = ops.layernorm_fwd(x, *w["ln3"])
+    hid = ops.gemm(h, w["ffn1"][0], rows, FF, D, bias=w["ffn1"][1], act="relu", drop_p=p, seed=sd, call_id=7)
+    out = ops.gemm(hid, w["ffn2"][0], rows, D, FF, bias=w["ffn2"][1], res=x, drop_p=p, seed=sd, call_id=8)
+    pk = ops.tlayer_pack([w["ffn1"][0], w["ffn2"][0]])
+    t = ops.tlayer_ffn(x, {"ln3": w["ln3"], "ffn1": (pk[0], w["ffn1"][1]), "ffn2": (pk[1], w["ffn2"][1])}, p=p, seed=seed, calls=(7, 8))
+    torch.cuda.synchronize()
+    for name, ref in (("h3", h), ("mean3", mean), ("rstd3", rstd), ("hid", hid), ("out", out)):
+        same_bits(t[name], ref, name)
+
+
+def test_long_sequence_encoder_layer_with_the_one_launch_feed_forward_half():
+    """nn.TransformerEncoderLayer on 256 tokens per sample (the image encoder's layers): attention per operation, the feed-forward half in one
+    launch (functional.TFFNFn): output and input gradient bit for bit equal to the per-operation layer, parameter gradients equal"""
+    from ralf_amd.functional import Runtime
+
+    layer = _layer(False, 9)
+    x0 = rnd(4, 256, D, seed=1).to(torch.bfloat16).cuda()
+    go = rnd(4, 256, D, seed=3).to(torch.bfloat16).cuda()
+    res = {}
+    for fused in (True, False):
+        rt = Runtime(torch.bfloat16, seed=11)
+        rt.to(torch.device("cuda"))
+        rt.training = True
+        rt.fused_ffn = fused
+        rt.begin_step()
+        x = x0.clone().requires_grad_(True)
+        layer.zero_grad(set_to_none=True)
+        y = layer(x, rt)
+        y.backward(go)
+        rt.flush_wgrads()
+        rt.join_side()
+        torch.cuda.synchronize()
+        res[fused] = {"y": y.detach().clone(), "dx": x.grad.clone(), **{n: prm.grad.clone() for n, prm in layer.named_parameters()}}
+    for k in res[True]:
+        if k in ("y", "dx"):
+            same_bits(res[True][k], res[False][k], k)
+        else:
+            torch.testing.assert_close(res[True][k], res[False][k], rtol=1e-5, atol=1e-5 * res[False][k].abs().max().item(), msg=lambda m: f"{k}: {m}")
