@@ -73,6 +73,7 @@ class Runtime:
         self.fused_layers = os.environ.get("RALF_FUSED_LAYERS", "1") != "0"
         # ... and the feed-forward half of the LONG-sequence encoder layers (image encoder, 16 384 rows): LayerNorm + both products on 64-row strips
         self.fused_ffn = os.environ.get("RALF_FUSED_FFN", "1") != "0"
+        self.fused_ffn_out = os.environ.get("RALF_FUSED_FFN_OUT", "1") != "0"   # ... with the attention's out-projection + residual in front
         # KV-cached decode step: out-projection + LayerNorm + feed-forward per layer as ONE launch on 32-row strips (ops.tlayer_tail).  OFF: measured
         # 36.2 vs 34.8 ms per B = 256 decode loop -- a workgroup streams all 1.15 MB of the layer's weights through one CU's L2 port (18.3 us per
         # launch, 26 k of its 39 k cycles in the feed-forward weight stream), the four launches it replaces spread them over the chip
@@ -1051,33 +1052,55 @@ class TLayerFn(Function):
 
 
 class TFFNFn(Function):
-    """x + drop(W2 drop(relu(W1 LN(x) + b1)) + b2) for ANY number of rows, forward in one launch on 64-row strips (ops.tlayer_ffn): the second
-    half of a pre-norm encoder layer whose attention is too long for TLayerFn (the image encoder: 256 tokens per sample).  Saves what
-    LayerNormSkipFn + FFNFn save; the backward is theirs.  packed = ops.tlayer_pack([linear1, linear2]) or None."""
+    """the tail of a pre-norm encoder layer for ANY number of rows, forward in one launch on 64-row strips (ops.tlayer_ffn): with the attention
+    output o, r = x + drop(o Wo^T + bo) first, then r + drop(W2 drop(relu(W1 LN(r) + b1)) + b2) -- the layers whose attention is too long for
+    TLayerFn (the image encoder: 256 tokens per sample).  Saves what LinearFn + LayerNormSkipFn + FFNFn save; the backward is theirs.
+    packed = ops.tlayer_pack([out_proj (when o is given), linear1, linear2]) or None.  params = [out_proj (w, b),] norm (w, b), linear1 (w, b),
+    linear2 (w, b).  Returns the gradients of o (if given) and x."""
 
     @staticmethod
-    def forward(ctx, x, p, rt, packed, n3w, n3b, w1, b1, w2, b2):
+    def forward(ctx, x, o, p, rt, packed, *params):
         x = x.contiguous()
-        c1 = rt.next_call() if p > 0.0 else 0
-        c2 = rt.next_call() if p > 0.0 else 0
+        with_o = o is not None
+        assert len(params) == (8 if with_o else 6)
+        n3w, n3b, w1, b1, w2, b2 = params[-6:]
+        nc = lambda: rt.next_call() if p > 0.0 else 0
+        co = nc() if with_o else 0
+        c1, c2 = nc(), nc()
         if packed is None:
-            packed = ops.tlayer_pack([rt.lp(w1), rt.lp(w2)])
-        t = ops.tlayer_ffn(x, {"ln3": (n3w.detach(), n3b.detach()), "ffn1": (packed[0], b1.detach()), "ffn2": (packed[1], b2.detach())},
-                           p=p, seed=rt.seed if p > 0.0 else None, calls=(c1, c2))
-        ctx.save_for_backward(x, n3w, n3b, w1, b1, w2, b2, t["h3"], t["mean3"], t["rstd3"], t["hid"])
-        ctx.cfg = (p, c2, rt, rt.dropout_tag(x))
+            packed = ops.tlayer_pack(([rt.lp(params[0])] if with_o else []) + [rt.lp(w1), rt.lp(w2)])
+        W = {"ln3": (n3w.detach(), n3b.detach()), "ffn1": (packed[-2], b1.detach()), "ffn2": (packed[-1], b2.detach())}
+        if with_o:
+            o = o.contiguous()
+            W["out"] = (packed[0], params[1].detach())
+        t = ops.tlayer_ffn(x, W, o=o, p=p, seed=rt.seed if p > 0.0 else None, calls=(co, c1, c2))
+        ctx.save_for_backward(x, o, *params, t["h3"], t["mean3"], t["rstd3"], t["hid"], t.get("x2"))
+        ctx.cfg = (with_o, p, co, c2, rt, rt.dropout_tag(x))
         rt.tag_dropout(t["out"], p, c2)
         return t["out"]
 
     @staticmethod
     def backward(ctx, dy):
-        p, c2, rt, tag_in = ctx.cfg
-        x, n3w, n3b, w1, b1, w2, b2, h3, mean3, rstd3, hid = ctx.saved_tensors
+        with_o, p, co, c2, rt, tag_in = ctx.cfg
+        sv = ctx.saved_tensors
+        x, o = sv[:2]
+        npar = 8 if with_o else 6
+        params = sv[2:2 + npar]
+        h3, mean3, rstd3, hid, x2 = sv[2 + npar:]
+        n3w, n3b, w1, b1, w2, b2 = params[-6:]
         rows = x.numel() // x.shape[-1]
+        need = ctx.needs_input_grad[5:]
         c = _Ctx((h3.view(rows, -1), w1, w2, hid.view(rows, -1), None), (True,), b1=b1, b2=b2, rt=rt, act="relu", p=p, has_res=True, xshape=x.shape, c2=c2)
         dh, dW1, db1, dW2, db2, dres = FFNFn.backward(c, dy)[:6]
-        dx, dg, db = _ln_backward(_Ctx((x, n3w, mean3, rstd3), rt=rt, beta=n3b, tag=tag_in), dh, dres)
-        return dx, None, None, None, dg, db, dW1, db1, dW2, db2
+        if not with_o:
+            dx, dg, db = _ln_backward(_Ctx((x, n3w, mean3, rstd3), rt=rt, beta=n3b, tag=tag_in), dh, dres)
+            return dx, None, None, None, None, dg, db, dW1, db1, dW2, db2
+        tag = (p, co) if (p > 0.0 and rt.ln_dropout) else None
+        g, dg, db = _ln_backward(_Ctx((x2, n3w, mean3, rstd3), rt=rt, beta=n3b, tag=tag), dh, dres)   # gradient of r = x + drop(out-projection)
+        c = _Ctx((o.view(rows, -1), params[0]), (True, need[0], need[1]), rt=rt, rows=(0, params[0].shape[0]), p=p, call=co, fan=None, bias=params[1],
+                 has_b=True, has_res=True, xshape=o.shape)
+        do, dWo, dbo = LinearFn.backward(c, g)[:3]
+        return g, do, None, None, None, dWo, dbo, dg, db, dW1, db1, dW2, db2
 
 
 def tffn_supported(x, rt, d, dim_ff) -> bool:

@@ -624,10 +624,13 @@ def tlayer_tail(o2, x1, W, rows_per_strip=None, eps=1e-5):
     return out
 
 
-def tlayer_ffn(x, W, *, p=0.0, seed=None, calls=(0, 0), rows_per_strip=64, eps=1e-5):
-    """the feed-forward block of a pre-norm layer on ANY row count (ralf_tlayer_fwd part 3): out = x + drop(W2 drop(relu(W1 LN(x) + b1)) + b2), in
-    strips of rows_per_strip rows (rows % rows_per_strip == 0).  x [..., 256] bf16; W: "ln3" (gamma, beta), "ffn1" / "ffn2" (weight packed by
-    tlayer_pack, fp32 bias).  Returns what LayerNormSkipFn + FFNFn would have saved plus the output: h3, mean3, rstd3, hid, out."""
+def tlayer_ffn(x, W, *, o=None, p=0.0, seed=None, calls=(0, 0, 0), rows_per_strip=64, eps=1e-5):
+    """the tail of a pre-norm layer on ANY row count, in strips of rows_per_strip rows (rows % rows_per_strip == 0), ralf_tlayer_fwd part 3 / 2:
+        o is None:  out = x + drop(W2 drop(relu(W1 LN(x) + b1)) + b2)                                   (the feed-forward block)
+        o given:    r = x + drop(o Wo^T + bo);  out = r + drop(W2 drop(relu(W1 LN(r) + b1)) + b2)       (+ the attention's out-projection in front)
+    x, o [..., 256] bf16; W: "ln3" (gamma, beta), "ffn1" / "ffn2" (and "out" with o) = (weight packed by tlayer_pack, fp32 bias);
+    calls = dropout call ids (out-projection, ffn1, ffn2).  Returns what the unfused Functions would have saved plus the output:
+    [x2 (= r),] h3, mean3, rstd3, hid, out."""
     from ._abi import RalfTLayerDesc
 
     shape = x.shape
@@ -638,13 +641,18 @@ def tlayer_ffn(x, W, *, p=0.0, seed=None, calls=(0, 0), rows_per_strip=64, eps=1
          "rstd3": torch.empty(rows, dtype=torch.float32, device=dev), "hid": torch.empty(*shape[:-1], ff, dtype=torch.bfloat16, device=dev),
          "out": torch.empty(shape, dtype=torch.bfloat16, device=dev)}
     d = RalfTLayerDesc()
-    d.x = _p(x)
     d.ln3_g, d.ln3_b, d.w1, d.b1, d.w2, d.b2 = _p(W["ln3"][0]), _p(W["ln3"][1]), _p(W["ffn1"][0]), _p(W["ffn1"][1]), _p(W["ffn2"][0]), _p(W["ffn2"][1])
+    if o is None:
+        d.x, d.part = _p(x), 3
+    else:
+        assert o.dtype == torch.bfloat16 and o.is_contiguous() and o.shape == x.shape
+        t["x2"] = torch.empty(shape, dtype=torch.bfloat16, device=dev)
+        d.x1, d.o2, d.w_o2, d.b_o2, d.part = _p(x), _p(o), _p(W["out"][0]), _p(W["out"][1]), 2
     for k, v in t.items():
         setattr(d, k, _p(v))
     d.seed = _p(seed) if p > 0.0 else None
-    d.call_ffn1, d.call_ffn2 = int(calls[0]), int(calls[1])
-    d.B, d.S, d.part = rows // S, S, 3
+    d.call_out2, d.call_ffn1, d.call_ffn2 = int(calls[0]), int(calls[1]), int(calls[2])
+    d.B, d.S = rows // S, S
     d.p_res, d.eps = float(p), eps
     _call("ralf_tlayer_fwd", ctypes.byref(d))
     return t

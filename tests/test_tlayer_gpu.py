@@ -258,15 +258,16 @@ def test_feed_forward_block_on_strips_writes_the_bits_of_the_unfused_launches(ro
     hid = ops.gemm(h, w["ffn1"][0], rows, FF, D, bias=w["ffn1"][1], act="relu", drop_p=p, seed=sd, call_id=7)
     out = ops.gemm(hid, w["ffn2"][0], rows, D, FF, bias=w["ffn2"][1], res=x, drop_p=p, seed=sd, call_id=8)
     pk = ops.tlayer_pack([w["ffn1"][0], w["ffn2"][0]])
-    t = ops.tlayer_ffn(x, {"ln3": w["ln3"], "ffn1": (pk[0], w["ffn1"][1]), "ffn2": (pk[1], w["ffn2"][1])}, p=p, seed=seed, calls=(7, 8))
+    t = ops.tlayer_ffn(x, {"ln3": w["ln3"], "ffn1": (pk[0], w["ffn1"][1]), "ffn2": (pk[1], w["ffn2"][1])}, p=p, seed=seed, calls=(0, 7, 8))
     torch.cuda.synchronize()
     for name, ref in (("h3", h), ("mean3", mean), ("rstd3", rstd), ("hid", hid), ("out", out)):
         same_bits(t[name], ref, name)
 
 
 def test_long_sequence_encoder_layer_with_the_one_launch_feed_forward_half():
-    """nn.TransformerEncoderLayer on 256 tokens per sample (the image encoder's layers): attention per operation, the feed-forward half in one
-    launch (functional.TFFNFn): output and input gradient bit for bit equal to the per-operation layer, parameter gradients equal"""
+    """nn.TransformerEncoderLayer on 256 tokens per sample (the image encoder's layers): attention per operation, then out-projection +
+    residual + LayerNorm + feed-forward + residual in one launch (functional.TFFNFn): output and input gradient bit for bit equal to the
+    per-operation layer, parameter gradients equal"""
     from ralf_amd.functional import Runtime
 
     layer = _layer(False, 9)
