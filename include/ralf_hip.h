@@ -345,6 +345,9 @@ int ralf_decode_attn_max_keys(void);
  *   weights: bf16 in FRAGMENT ORDER (ralf_tlayer_pack of the row-major [n_out, n_in] matrix; w_q = the first 256 rows of the cross-attention's
  *   in_proj_weight); biases and LayerNorm parameters fp32; activations bf16 [B*S, width]; statistics fp32 [B*S]; lse fp32 [B, 8, S];
  *   kpm uint8 [B, kpm_bs] or NULL; seed int64[1] on the device (needed when a dropout probability is > 0)
+ * Parts 2, 3 and 4 also run on 64-row STRIPS of any [rows, 256] tensor (B = rows / S "samples"): the long-sequence encoder layers (256 tokens
+ * per sample: the attention keeps ralf_attention_fwd) are part 4 (h1 = LN1(x), qkv = h1 Win^T + bin), ralf_attention_fwd, part 2 (x1 = the
+ * layer input, o2 = the attention output) -- or part 3 (out = x + drop(W2 drop(relu(W1 LN3(x) + b1)) + b2)) behind a separate out-projection.
  * Part 2 is also the tail of a KV-cached DECODE step (retrieval_augmented_autoreg.py:274-279: one new token per batch element): the "samples"
  * are then strips of S <= 32 batch rows (one 32-row MFMA block per workgroup), dropout off, and h3 / mean3 / rstd3 / hid may be NULL (nothing is
  * kept for a backward pass; x2 is still written -- the kernel reads it back for the last residual add). */

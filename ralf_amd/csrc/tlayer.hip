@@ -331,6 +331,7 @@ __device__ __forceinline__ void attn_finish(const AttnState& st, int Sq, int h, 
 // PART 0: encoder layer (self-attention block + feed-forward block)
 // PART 1: decoder layer up to the cross-attention's queries (self-attention block, LayerNorm 2, q projection)
 // PART 2: decoder layer from the cross-attention's output (out-projection 2 + residual, LayerNorm 3, feed-forward block)
+// PART 4: LayerNorm 1 + the q | k | v projection on 64-row strips of ANY [rows, 256] tensor (the first two launches of a long-sequence layer)
 // PART 3: the feed-forward block alone on 64-row strips of ANY [rows, 256] residual stream (LayerNorm 3 -> FFN -> + residual): the second half of
 //         the image encoder's 16 384-row layers, whose attention spans 256 tokens and stays with the per-operation kernels
 // The cross-attention itself (S x M scores per head over a memory of hundreds of rows) is per-score VALU work that wants the whole chip, not the
@@ -352,14 +353,14 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
     bf16x4 rr[32 * RB / NW];   // this wave's rows of the residual stream (x -> x1 -> x2), in registers from one row pass to the next
     TL_PROBE(0);
 
-    if constexpr (PART == 0 || PART == 1) {
+    if constexpr (PART == 0 || PART == 1 || PART == 4) {
         // ================= self-attention block: x1 = x + drop(attn(LN1(x)) Wo^T + bo) =================
         const float scale2 = d.scale * 1.4426950408889634f;   // log2 domain
         const bf16* xg = (const bf16*)d.x + row0 * TD;
         load_w(w, w_ptr((const bf16*)d.w_in, 16, wave, 0, lane));
         load_rows<RB>(rr, xg, S, wave, lane);
         row_pass<false, false, true>(nullptr, rr, nullptr, S, d.ln1_g, d.ln1_b, d.eps, bufA, (bf16*)d.h1 + row0 * TD, d.mean1 + row0, d.rstd1 + row0, wave, lane);
-        if (tid < TS) {
+        if (PART != 4 && tid < TS) {
             const bool mk = tid >= S || (d.kpm && d.kpm[(int64_t)b * d.kpm_bs + tid]);
             Ms[tid] = mk ? 1 : 0;
             const unsigned long long any = __ballot(mk);
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
 #pragma unroll
         for (int t = 0; t < 3; ++t) {   // qkv = h1 Win^T + bin  -> LDS strip [64][LDQ]: wave h writes exactly head h's q, k and v columns
             const int n0 = (t * NW + wave) * 32;
-            const bf16* next = t + 1 < 3 ? w_ptr((const bf16*)d.w_in, 16, (t + 1) * NW + wave, 0, lane) : w_ptr((const bf16*)d.w_o, 16, wave, 0, lane);
+            const bf16* next = t + 1 < 3 ? w_ptr((const bf16*)d.w_in, 16, (t + 1) * NW + wave, 0, lane) : (PART == 4 ? nullptr : w_ptr((const bf16*)d.w_o, 16, wave, 0, lane));
             f32x16 acc[2];
             zero_acc(acc);
             Bias4 bv;
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
         lds_barrier();
         TL_PROBE(2);
         copy_out<3 * TD>(bufB, LDQ, (bf16*)d.qkv + row0 * (3 * TD), 3 * TD, S, tid);
+        if constexpr (PART == 4) return;
         {   // wave = head: softmax(q k^T / sqrt(32) + masks) v, keys = the sample's own rows
             const int h = wave;
             AttnState st;
@@ -546,9 +548,10 @@ extern "C" int ralf_tlayer_pack(const RalfPackJob* jobs, int njobs, void* stream
 extern "C" int ralf_tlayer_fwd(const RalfTLayerDesc* dp, void* stream) {
     RALF_REQUIRE(dp, "tlayer_fwd: null descriptor");
     const RalfTLayerDesc& d = *dp;
-    RALF_REQUIRE(d.part >= 0 && d.part <= 3, "tlayer_fwd: part 0 (encoder layer), 1 or 2 (decoder layer before / after its cross-attention), 3 (feed-forward block)");
+    RALF_REQUIRE(d.part >= 0 && d.part <= 4, "tlayer_fwd: part 0 (encoder layer), 1 or 2 (decoder layer before / after its cross-attention), 3 (feed-forward block), 4 (LayerNorm + qkv)");
     RALF_REQUIRE(d.B > 0 && d.S > 0 && d.S <= TS, "tlayer_fwd: needs 1 <= S <= %d rows per sample (got %d)", TS, d.S);
     RALF_REQUIRE(d.p_attn >= 0.f && d.p_attn < 1.f && d.p_res >= 0.f && d.p_res < 1.f && ((d.p_attn == 0.f && d.p_res == 0.f) || d.seed), "tlayer_fwd: dropout needs a seed");
+    if (d.part == 4) RALF_REQUIRE(d.x && d.ln1_g && d.ln1_b && d.w_in && d.b_in && d.h1 && d.mean1 && d.rstd1 && d.qkv, "tlayer_fwd: part 4 needs x, LayerNorm 1, in_proj and h1 / mean1 / rstd1 / qkv");
     if (d.part == 0 || d.part == 1) {
         RALF_REQUIRE(d.x && d.ln1_g && d.ln1_b && d.w_in && d.b_in && d.w_o && d.b_o, "tlayer_fwd: self-attention block: null input / weight pointer");
         RALF_REQUIRE(d.h1 && d.mean1 && d.rstd1 && d.qkv && d.o1 && d.lse1 && d.x1, "tlayer_fwd: self-attention block: null output pointer");
@@ -557,7 +560,7 @@ extern "C" int ralf_tlayer_fwd(const RalfTLayerDesc* dp, void* stream) {
     if (d.part == 1) RALF_REQUIRE(d.ln2_g && d.ln2_b && d.w_q && d.b_q && d.h2 && d.mean2 && d.rstd2 && d.q, "tlayer_fwd: part 1 needs LayerNorm 2, the q projection and their outputs");
     if (d.part == 2) RALF_REQUIRE(d.x1 && d.o2 && d.w_o2 && d.b_o2 && d.x2, "tlayer_fwd: part 2 needs x1, o2, the second out-projection and x2");
     if (d.part == 3) RALF_REQUIRE(d.x, "tlayer_fwd: part 3 needs x");
-    if (d.part != 1) {
+    if (d.part != 1 && d.part != 4) {
         RALF_REQUIRE(d.ln3_g && d.ln3_b && d.w1 && d.b1 && d.w2 && d.b2, "tlayer_fwd: feed-forward block: null weight pointer");
         RALF_REQUIRE(d.out && ((d.h3 && d.mean3 && d.rstd3 && d.hid) || (d.part == 2 && !d.h3 && !d.mean3 && !d.rstd3 && !d.hid)),
                      "tlayer_fwd: feed-forward block: null output pointer (part 2 alone may run without h3 / mean3 / rstd3 / hid: inference)");
@@ -566,6 +569,7 @@ extern "C" int ralf_tlayer_fwd(const RalfTLayerDesc* dp, void* stream) {
     if (d.part == 0) hipLaunchKernelGGL((tlayer_fwd_kernel<0>), dim3(d.B), dim3(NT), 0, st, d);
     else if (d.part == 1) hipLaunchKernelGGL((tlayer_fwd_kernel<1>), dim3(d.B), dim3(NT), 0, st, d);
     else if (d.part == 3) hipLaunchKernelGGL((tlayer_fwd_kernel<3>), dim3(d.B), dim3(NT), 0, st, d);
+    else if (d.part == 4) hipLaunchKernelGGL((tlayer_fwd_kernel<4>), dim3(d.B), dim3(NT), 0, st, d);
     else if (d.S <= 32) hipLaunchKernelGGL((tlayer_fwd_kernel<2, 1>), dim3(d.B), dim3(NT), 0, st, d);   // strips of one 32-row block
     else hipLaunchKernelGGL((tlayer_fwd_kernel<2>), dim3(d.B), dim3(NT), 0, st, d);
     return ralf::check_launch("tlayer_fwd");

@@ -74,6 +74,7 @@ class Runtime:
         # ... and the feed-forward half of the LONG-sequence encoder layers (image encoder, 16 384 rows): LayerNorm + both products on 64-row strips
         self.fused_ffn = os.environ.get("RALF_FUSED_FFN", "1") != "0"
         self.fused_ffn_out = os.environ.get("RALF_FUSED_FFN_OUT", "1") != "0"   # ... with the attention's out-projection + residual in front
+        self.fused_lnqkv = os.environ.get("RALF_FUSED_LNQKV", "1") != "0"       # ... and LayerNorm 1 + the q | k | v projection as one launch
         # KV-cached decode step: out-projection + LayerNorm + feed-forward per layer as ONE launch on 32-row strips (ops.tlayer_tail).  OFF: measured
         # 36.2 vs 34.8 ms per B = 256 decode loop -- a workgroup streams all 1.15 MB of the layer's weights through one CU's L2 port (18.3 us per
         # launch, 26 k of its 39 k cycles in the feed-forward weight stream), the four launches it replaces spread them over the chip
@@ -1101,6 +1102,34 @@ class TFFNFn(Function):
                  has_b=True, has_res=True, xshape=o.shape)
         do, dWo, dbo = LinearFn.backward(c, g)[:3]
         return g, do, None, None, None, dWo, dbo, dg, db, dW1, db1, dW2, db2
+
+
+class TLNQKVFn(Function):
+    """(qkv, x) = (LN(x) Win^T + bin, x) for ANY number of rows, forward in one launch on 64-row strips (ops.tlayer_lnqkv): the head of a
+    pre-norm layer whose attention is too long for TLayerFn.  Saves what LayerNormSkipFn + LinearFn save; the backward is theirs.
+    packed_in = ops.tlayer_pack([in_proj_weight])[0] or None."""
+
+    @staticmethod
+    def forward(ctx, x, rt, packed_in, n1w, n1b, siw, sib):
+        x = x.contiguous()
+        if packed_in is None:
+            packed_in = ops.tlayer_pack([rt.lp(siw)])[0]
+        t = ops.tlayer_lnqkv(x, {"ln1": (n1w.detach(), n1b.detach()), "sa_in": (packed_in, sib.detach())})
+        ctx.save_for_backward(x, n1w, n1b, siw, sib, t["h1"], t["mean1"], t["rstd1"])
+        ctx.cfg = (rt, rt.dropout_tag(x))
+        return t["qkv"], x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dqkv, dskip):
+        rt, tag_in = ctx.cfg
+        x, n1w, n1b, siw, sib, h1, mean1, rstd1 = ctx.saved_tensors
+        rows = x.numel() // x.shape[-1]
+        c = _Ctx((h1.view(rows, -1), siw), (True, ctx.needs_input_grad[5], ctx.needs_input_grad[6]), rt=rt, rows=(0, siw.shape[0]), p=0.0, call=0, fan=None,
+                 bias=sib, has_b=True, has_res=False, xshape=x.shape)
+        dh, dW, db = LinearFn.backward(c, dqkv)[:3]
+        skip = dskip.contiguous() if dskip is not None else None
+        dx, dg, dbt = _ln_backward(_Ctx((x, n1w, mean1, rstd1), rt=rt, beta=n1b, tag=tag_in), dh, skip)
+        return dx, None, None, dg, dbt, dW, db
 
 
 def tffn_supported(x, rt, d, dim_ff) -> bool:

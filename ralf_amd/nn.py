@@ -126,18 +126,25 @@ class TransformerEncoderLayer(nn.Module, _FFNMixin):
         if self.fusable(x, rt):
             return RF.TLayerFn.apply(x, None, kpm, False, rt.drop_p(self.p), rt, packed, *self._params())   # the whole layer in one launch
         if self.norm_first:
-            h, x = RF.layer_norm_skip(x, self.norm1.weight, self.norm1.bias, rt)
             a = self.self_attn
+            if rt.fused_lnqkv and rt.fused_ffn_out and RF.tffn_supported(x, rt, a.d, self.linear1.weight.shape[0]):
+                # long sequences, three launches per layer: LayerNorm + q | k | v projection; attention; out-projection + residual + LayerNorm +
+                # feed-forward + residual
+                qkv, x = RF.TLNQKVFn.apply(x, rt, packed[0] if packed else None, self.norm1.weight, self.norm1.bias, a.in_proj_weight, a.in_proj_bias)
+                o = RF.AttnFn.apply(qkv, None, a.nhead, a.d // a.nhead, False, kpm, rt.drop_p(self.p), rt)
+                return RF.TFFNFn.apply(x, o, rt.drop_p(self.p), rt, packed[1:] if packed else None, a.out_proj.weight, a.out_proj.bias, self.norm2.weight,
+                                       self.norm2.bias, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
+            h, x = RF.layer_norm_skip(x, self.norm1.weight, self.norm1.bias, rt)
             if RF.tffn_supported(x, rt, a.d, self.linear1.weight.shape[0]):
                 # long sequences: attention per operation, then out-projection + residual + LayerNorm + feed-forward + residual in one launch
                 if not rt.fused_ffn_out:
                     x = a.self_attn(h, x, rt, kpm=kpm, p_attn=self.p, p_out=self.p)
-                    return RF.TFFNFn.apply(x, None, rt.drop_p(self.p), rt, packed[1:] if packed else None, self.norm2.weight, self.norm2.bias,
+                    return RF.TFFNFn.apply(x, None, rt.drop_p(self.p), rt, packed[2:] if packed else None, self.norm2.weight, self.norm2.bias,
                                            self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
                 qkv = RF.linear(h, a.in_proj_weight, a.in_proj_bias, rt=rt)
                 o = RF.AttnFn.apply(qkv, None, a.nhead, a.d // a.nhead, False, kpm, rt.drop_p(self.p), rt)
-                return RF.TFFNFn.apply(x, o, rt.drop_p(self.p), rt, packed, a.out_proj.weight, a.out_proj.bias, self.norm2.weight, self.norm2.bias,
-                                       self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
+                return RF.TFFNFn.apply(x, o, rt.drop_p(self.p), rt, packed[1:] if packed else None, a.out_proj.weight, a.out_proj.bias, self.norm2.weight,
+                                       self.norm2.bias, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
             x = a.self_attn(h, x, rt, kpm=kpm, p_attn=self.p, p_out=self.p)
             h, x = RF.layer_norm_skip(x, self.norm2.weight, self.norm2.bias, rt)
             return self._ffn(h, x, rt, self.p)
@@ -229,14 +236,15 @@ class FuseAttention(nn.Module):
 
 
 def pack_ffn_layers(layers, x, rt: Runtime):
-    """fragment-order out_proj / linear1 / linear2 weights (ops.tlayer_pack) of all `layers` in ONE launch when their tails take the
-    one-launch path on x (functional.TFFNFn) and the layers as a whole do not (long sequences); else None"""
-    if not layers or len(layers) * 3 > 48 or any(l.fusable(x, rt) for l in layers):
+    """fragment-order in_proj / out_proj / linear1 / linear2 weights (ops.tlayer_pack) of all `layers` in ONE launch when they take the
+    strip-wise path on x (functional.TLNQKVFn / TFFNFn) and not the per-sample one (long sequences); else None"""
+    if not layers or len(layers) * 4 > 48 or any(l.fusable(x, rt) for l in layers):
         return None
     if not all(l.norm_first and RF.tffn_supported(x, rt, l.self_attn.d, l.linear1.weight.shape[0]) for l in layers):
         return None
-    flat = ops.tlayer_pack([m for l in layers for m in (rt.lp(l.self_attn.out_proj.weight), rt.lp(l.linear1.weight), rt.lp(l.linear2.weight))])
-    return [flat[3 * i:3 * i + 3] for i in range(len(layers))]
+    flat = ops.tlayer_pack([m for l in layers for m in (rt.lp(l.self_attn.in_proj_weight), rt.lp(l.self_attn.out_proj.weight), rt.lp(l.linear1.weight),
+                                                         rt.lp(l.linear2.weight))])
+    return [flat[4 * i:4 * i + 4] for i in range(len(layers))]
 
 
 def _pack_layers(layers, x, rt: Runtime):

@@ -658,6 +658,26 @@ def tlayer_ffn(x, W, *, o=None, p=0.0, seed=None, calls=(0, 0, 0), rows_per_stri
     return t
 
 
+def tlayer_lnqkv(x, W, rows_per_strip=64, eps=1e-5):
+    """h1 = LayerNorm(x); qkv = h1 Win^T + bin on strips of rows_per_strip rows of ANY [rows, 256] bf16 tensor (ralf_tlayer_fwd part 4).
+    W: "ln1" (gamma, beta), "sa_in" (in_proj weight packed by tlayer_pack, fp32 bias).  Returns h1, mean1, rstd1, qkv."""
+    from ._abi import RalfTLayerDesc
+
+    shape = x.shape
+    rows, dm, S = x.numel() // shape[-1], shape[-1], int(rows_per_strip)
+    assert dm == 256 and x.dtype == torch.bfloat16 and x.is_contiguous() and rows % S == 0 and 1 <= S <= TLAYER_MAX_ROWS
+    dev = x.device
+    t = {"h1": torch.empty(shape, dtype=torch.bfloat16, device=dev), "mean1": torch.empty(rows, dtype=torch.float32, device=dev),
+         "rstd1": torch.empty(rows, dtype=torch.float32, device=dev), "qkv": torch.empty(*shape[:-1], 3 * dm, dtype=torch.bfloat16, device=dev)}
+    d = RalfTLayerDesc()
+    d.x, d.ln1_g, d.ln1_b, d.w_in, d.b_in = _p(x), _p(W["ln1"][0]), _p(W["ln1"][1]), _p(W["sa_in"][0]), _p(W["sa_in"][1])
+    for k, v in t.items():
+        setattr(d, k, _p(v))
+    d.B, d.S, d.part, d.eps = rows // S, S, 4, eps
+    _call("ralf_tlayer_fwd", ctypes.byref(d))
+    return t
+
+
 _DEC_MAXK = None
 
 

@@ -264,21 +264,59 @@ def test_feed_forward_block_on_strips_writes_the_bits_of_the_unfused_launches(ro
         same_bits(t[name], ref, name)
 
 
+@pytest.mark.parametrize("rows", [16384, 192])
+def test_layernorm_qkv_on_strips_writes_the_bits_of_the_unfused_launches(rows):
+    """part 4: h1 = LayerNorm(x), qkv = h1 Win^T + bin on 64-row strips"""
+    from ralf_amd import ops
+
+    w = make_weights(False, seed=5)
+    x = rnd(rows, D, seed=2).to(torch.bfloat16).cuda()
+    h, mean, rstd = ops.layernorm_fwd(x, *w["ln1"])
+    qkv = ops.gemm(h, w["sa_in"][0], rows, 3 * D, D, bias=w["sa_in"][1])
+    (pk,) = ops.tlayer_pack([w["sa_in"][0]])
+    t = ops.tlayer_lnqkv(x, {"ln1": w["ln1"], "sa_in": (pk, w["sa_in"][1])})
+    torch.cuda.synchronize()
+    for name, ref in (("h1", h), ("mean1", mean), ("rstd1", rstd), ("qkv", qkv)):
+        same_bits(t[name], ref, name)
+
+
+def test_feed_forward_tail_with_the_out_projection_on_strips():
+    """part 2 on 64-row strips of many rows: r = x + drop(o Wo^T + bo); out = r + FFN(LN(r))"""
+    from ralf_amd import ops
+
+    rows, p = 4096, 0.1
+    w = make_weights(True, seed=8)
+    x = rnd(rows, D, seed=1).to(torch.bfloat16).cuda()
+    o = rnd(rows, D, seed=2).to(torch.bfloat16).cuda()
+    seed = torch.tensor([777], dtype=torch.int64, device="cuda")
+    r = ops.gemm(o, w["ca_out"][0], rows, D, D, bias=w["ca_out"][1], res=x, drop_p=p, seed=seed, call_id=3)
+    h, mean, rstd = ops.layernorm_fwd(r, *w["ln3"])
+    hid = ops.gemm(h, w["ffn1"][0], rows, FF, D, bias=w["ffn1"][1], act="relu", drop_p=p, seed=seed, call_id=4)
+    out = ops.gemm(hid, w["ffn2"][0], rows, D, FF, bias=w["ffn2"][1], res=r, drop_p=p, seed=seed, call_id=5)
+    pk = ops.tlayer_pack([w["ca_out"][0], w["ffn1"][0], w["ffn2"][0]])
+    t = ops.tlayer_ffn(x, {"out": (pk[0], w["ca_out"][1]), "ln3": w["ln3"], "ffn1": (pk[1], w["ffn1"][1]), "ffn2": (pk[2], w["ffn2"][1])}, o=o, p=p,
+                       seed=seed, calls=(3, 4, 5))
+    torch.cuda.synchronize()
+    for name, ref in (("x2", r), ("h3", h), ("mean3", mean), ("rstd3", rstd), ("hid", hid), ("out", out)):
+        same_bits(t[name], ref, name)
+
+
 def test_long_sequence_encoder_layer_with_the_one_launch_feed_forward_half():
     """nn.TransformerEncoderLayer on 256 tokens per sample (the image encoder's layers): attention per operation, then out-projection +
     residual + LayerNorm + feed-forward + residual in one launch (functional.TFFNFn): output and input gradient bit for bit equal to the
-    per-operation layer, parameter gradients equal"""
+    per-operation layer, parameter gradients equal; likewise with LayerNorm 1 + the q | k | v projection as one launch (three launches per layer)"""
     from ralf_amd.functional import Runtime
 
     layer = _layer(False, 9)
     x0 = rnd(4, 256, D, seed=1).to(torch.bfloat16).cuda()
     go = rnd(4, 256, D, seed=3).to(torch.bfloat16).cuda()
     res = {}
-    for fused in (True, False):
+    for fused in (True, "tail only", False):
         rt = Runtime(torch.bfloat16, seed=11)
         rt.to(torch.device("cuda"))
         rt.training = True
-        rt.fused_ffn = fused
+        rt.fused_ffn = bool(fused)
+        rt.fused_lnqkv = fused is True
         rt.begin_step()
         x = x0.clone().requires_grad_(True)
         layer.zero_grad(set_to_none=True)
@@ -288,8 +326,9 @@ def test_long_sequence_encoder_layer_with_the_one_launch_feed_forward_half():
         rt.join_side()
         torch.cuda.synchronize()
         res[fused] = {"y": y.detach().clone(), "dx": x.grad.clone(), **{n: prm.grad.clone() for n, prm in layer.named_parameters()}}
-    for k in res[True]:
-        if k in ("y", "dx"):
-            same_bits(res[True][k], res[False][k], k)
-        else:
-            torch.testing.assert_close(res[True][k], res[False][k], rtol=1e-5, atol=1e-5 * res[False][k].abs().max().item(), msg=lambda m: f"{k}: {m}")
+    for variant in (True, "tail only"):
+        for k in res[variant]:
+            if k in ("y", "dx"):
+                same_bits(res[variant][k], res[False][k], k)
+            else:
+                torch.testing.assert_close(res[variant][k], res[False][k], rtol=1e-5, atol=1e-5 * res[False][k].abs().max().item(), msg=lambda m: f"{k}: {m}")
