@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 14
+#define RALF_ABI_VERSION 15
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -366,6 +366,10 @@ typedef struct RalfTLayerDesc {
     int64_t kpm_bs; /* row stride of kpm in bytes */
     int B, S, causal, part;
     float scale, p_attn, p_res, eps;
+    /* part 3 only: act = RALF_ACT_GELU (erf form) instead of ReLU, z = the pre-activation W1 LN(x) + b1 (bf16 [rows, 1024], what the GELU
+     * gradient reads; NULL with ReLU), no_res = 1: out = W2 act(..) + b2 without the residual add -- LN -> Linear -> GELU -> Linear, the
+     * reference's FeedForward (image2layout/train/models/common/attention.py:15-30) */
+    void* z; int act, no_res;
 } RalfTLayerDesc;
 int ralf_tlayer_fwd(const RalfTLayerDesc* d, void* stream);
 /* weights -> the fragment order ralf_tlayer_fwd streams: for the 32-row tile t and the 16-wide k-slice i of src [N][K] (row stride ld

@@ -38,7 +38,8 @@ class RalfTLayerDesc(ctypes.Structure):
                 + [(n, ctypes.c_uint64) for n in ("call_attn1", "call_out1", "call_out2", "call_ffn1", "call_ffn2")]
                 + [("kpm_bs", i64)]
                 + [(n, i32) for n in ("B", "S", "causal", "part")]
-                + [(n, f32) for n in ("scale", "p_attn", "p_res", "eps")])
+                + [(n, f32) for n in ("scale", "p_attn", "p_res", "eps")]
+                + [("z", vp), ("act", i32), ("no_res", i32)])
 
 
 class RalfPackJob(ctypes.Structure):

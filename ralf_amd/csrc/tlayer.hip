@@ -73,7 +73,7 @@ __device__ __forceinline__ void load_rows(bf16x4 (&rr)[32 * RB / NW], const bf16
     }
 }
 // rr: in = the residual rows (load_rows, or the previous pass's output); out (STAGE) = the rows this pass produced (x1 / x2 / out)
-template <bool STAGE, bool XOUT, bool LN, int RB = 2>
+template <bool STAGE, bool XOUT, bool LN, int RB = 2, bool HASRES = true>
 __device__ __forceinline__ void row_pass(const float* stage, bf16x4 (&rr)[32 * RB / NW], bf16* __restrict__ xout, int S, const float* __restrict__ gamma,
                                          const float* __restrict__ beta, float eps, bf16* dst, bf16* __restrict__ hout, float* __restrict__ mean,
                                          float* __restrict__ rstd, int wave, int lane) {
@@ -92,7 +92,7 @@ __device__ __forceinline__ void row_pass(const float* stage, bf16x4 (&rr)[32 * R
             const f32x4 a = *reinterpret_cast<const f32x4*>(stage + row * STG_LD + lane * 4);
             bf16x4 t;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) t[i] = (bf16)(a[i] + (float)rr[k][i]);
+            for (int i = 0; i < 4; ++i) t[i] = (bf16)(HASRES ? a[i] + (float)rr[k][i] : a[i]);
             if (XOUT && xout && row < S) *reinterpret_cast<bf16x4*>(xout + (int64_t)row * TD + lane * 4) = t;
             rr[k] = t;
 #pragma unroll
@@ -223,6 +223,7 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float (&v)[4]) {
     for (int q = 0; q < 4; ++q) t[q] = (bf16)v[q];
     return t;
 }
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }   // (gemm_impl.h's)
 // GEMM-epilogue dropout on 4 consecutive elements of a contiguous [rows][N] output (ralf_dropout's mask: common.h)
 __device__ __forceinline__ void drop4(float (&v)[4], float p, uint64_t seed, uint64_t call, uint64_t e0) {
     if (p > 0.f) drop_apply<4>(v, seed, call, e0, drop_thr16(p), 1.f / (1.f - p));
@@ -478,6 +479,7 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
     Bias4 bv2;
     load_bias(bv2, d.b2, wave * 32, lane);
     bf16* Hc = bufB;   // one 256-wide chunk of the hidden activation, [64][LDA]
+    bf16* Zc = bufB + BUFA_ELEMS;   // ... and of its pre-activation (GELU only)
 #pragma unroll 1
     for (int c = 0; c < TFF / TD; ++c) {
         {   // hidden columns c*256 + wave*32 ..: tile c*8 + wave of W1; next in the weight stream: W2[wave*32 ..][c*256 ..]
@@ -488,10 +490,17 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
             load_bias(bv, d.b1, c * TD + wave * 32, lane);
             tile_mma(acc, bufA, LDA, w, w_ptr((const bf16*)d.w2, TFF / 16, wave, c * 16, lane), lane);
             if (c == 1) TL_PROBE(13);
+            const bool gelu = PART == 3 && d.act == RALF_ACT_GELU;   // (uniform)
             tile_epilogue(acc, bv, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
                 const int col = c * TD + n;
+                if (gelu) {
+                    if (d.z) *reinterpret_cast<bf16x4*>(Zc + m * LDA + n) = to_bf16x4(v);   // the pre-activation, as RalfGemmDesc.C2 keeps it
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                    for (int q = 0; q < 4; ++q) v[q] = gelu_f(v[q]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                }
                 drop4(v, d.p_res, seed, d.call_ffn1, (uint64_t)(row0 + m) * TFF + col);
                 *reinterpret_cast<bf16x4*>(Hc + m * LDA + n) = to_bf16x4(v);
             });
@@ -500,6 +509,7 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
         lds_barrier();
         if (c == 1) TL_PROBE(15);
         if (d.hid) copy_out<TD>(Hc, LDA, (bf16*)d.hid + row0 * TFF + c * TD, TFF, S, tid);
+        if (PART == 3 && d.act == RALF_ACT_GELU && d.z) copy_out<TD>(Zc, LDA, (bf16*)d.z + row0 * TFF + c * TD, TFF, S, tid);
         tile_mma(yacc, Hc, LDA, w, c + 1 < TFF / TD ? w_ptr((const bf16*)d.w1, 16, (c + 1) * NW + wave, 0, lane) : nullptr, lane);
         lds_barrier();
     }
@@ -509,7 +519,8 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
         *reinterpret_cast<f32x4*>(stage + m * STG_LD + n) = (f32x4){v[0], v[1], v[2], v[3]};
     });
     lds_barrier();
-    row_pass<true, true, false, RB>(stage, rr, (bf16*)d.out + row0 * TD, S, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, wave, lane);
+    if (PART == 3 && d.no_res) row_pass<true, true, false, RB, false>(stage, rr, (bf16*)d.out + row0 * TD, S, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, wave, lane);
+    else row_pass<true, true, false, RB>(stage, rr, (bf16*)d.out + row0 * TD, S, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, wave, lane);
     TL_PROBE(11);
 }
 
@@ -559,7 +570,8 @@ extern "C" int ralf_tlayer_fwd(const RalfTLayerDesc* dp, void* stream) {
     }
     if (d.part == 1) RALF_REQUIRE(d.ln2_g && d.ln2_b && d.w_q && d.b_q && d.h2 && d.mean2 && d.rstd2 && d.q, "tlayer_fwd: part 1 needs LayerNorm 2, the q projection and their outputs");
     if (d.part == 2) RALF_REQUIRE(d.x1 && d.o2 && d.w_o2 && d.b_o2 && d.x2, "tlayer_fwd: part 2 needs x1, o2, the second out-projection and x2");
-    if (d.part == 3) RALF_REQUIRE(d.x, "tlayer_fwd: part 3 needs x");
+    if (d.part == 3) RALF_REQUIRE(d.x && (d.act == RALF_ACT_RELU || d.act == RALF_ACT_NONE || d.act == RALF_ACT_GELU), "tlayer_fwd: part 3 needs x; act = ReLU (default) or GELU");
+    RALF_REQUIRE(d.part == 3 || (!d.z && !d.no_res && d.act != RALF_ACT_GELU), "tlayer_fwd: act / z / no_res belong to part 3");
     if (d.part != 1 && d.part != 4) {
         RALF_REQUIRE(d.ln3_g && d.ln3_b && d.w1 && d.b1 && d.w2 && d.b2, "tlayer_fwd: feed-forward block: null weight pointer");
         RALF_REQUIRE(d.out && ((d.h3 && d.mean3 && d.rstd3 && d.hid) || (d.part == 2 && !d.h3 && !d.mean3 && !d.rstd3 && !d.hid)),

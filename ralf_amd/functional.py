@@ -1132,6 +1132,31 @@ class TLNQKVFn(Function):
         return dx, None, None, dg, dbt, dW, db
 
 
+class TFeedForwardFn(Function):
+    """W2 gelu(W1 LN(x) + b1) + b2 (the reference's FeedForward, common/attention.py:15-30) for any number of rows, forward in one launch on
+    64-row strips (ops.tlayer_ffn, act="gelu", no residual).  Saves what LayerNormFn + FFNFn save; the backward is theirs."""
+
+    @staticmethod
+    def forward(ctx, x, rt, packed, lnw, lnb, w1, b1, w2, b2):
+        x = x.contiguous()
+        if packed is None:
+            packed = ops.tlayer_pack([rt.lp(w1), rt.lp(w2)])
+        t = ops.tlayer_ffn(x, {"ln3": (lnw.detach(), lnb.detach()), "ffn1": (packed[0], b1.detach()), "ffn2": (packed[1], b2.detach())}, act="gelu", residual=False)
+        ctx.save_for_backward(x, lnw, lnb, w1, b1, w2, b2, t["h3"], t["mean3"], t["rstd3"], t["hid"], t["z"])
+        ctx.cfg = (rt, rt.dropout_tag(x))
+        return t["out"]
+
+    @staticmethod
+    def backward(ctx, dy):
+        rt, tag_in = ctx.cfg
+        x, lnw, lnb, w1, b1, w2, b2, h3, mean3, rstd3, hid, z = ctx.saved_tensors
+        rows = x.numel() // x.shape[-1]
+        c = _Ctx((h3.view(rows, -1), w1, w2, hid.view(rows, -1), z.view(rows, -1)), (True,), b1=b1, b2=b2, rt=rt, act="gelu", p=0.0, has_res=False, xshape=x.shape, c2=0)
+        dh, dW1, db1, dW2, db2 = FFNFn.backward(c, dy)[:5]
+        dx, dg, db = _ln_backward(_Ctx((x, lnw, mean3, rstd3), rt=rt, beta=lnb, tag=tag_in), dh, None)
+        return dx, None, None, dg, db, dW1, db1, dW2, db2
+
+
 def tffn_supported(x, rt, d, dim_ff) -> bool:
     return (rt.fused_layers and rt.fused_ffn and rt.dtype == torch.bfloat16 and x.is_cuda and d == 256 and dim_ff == 1024 and x.shape[-1] == d
             and (x.numel() // d) % 64 == 0)

@@ -212,6 +212,10 @@ class FeedForward(nn.Module):
                                   Affine(out_dim, hidden, bias_dim=out_dim), nn.Identity()])
 
     def forward(self, x, rt: Runtime):
+        if RF.tffn_supported(x, rt, self.net[1].weight.shape[1], self.net[1].weight.shape[0]) and self.net[4].weight.shape[0] == 256:
+            # LayerNorm + both products in one launch on 64-row strips (the 1024-wide hidden stays in LDS between them)
+            return RF.TFeedForwardFn.apply(x, rt, None, self.net[0].weight, self.net[0].bias, self.net[1].weight, self.net[1].bias, self.net[4].weight,
+                                           self.net[4].bias)
         h = RF.layer_norm(x, self.net[0].weight, self.net[0].bias, rt)
         return RF.FFNFn.apply(h, self.net[1].weight, self.net[1].bias, self.net[4].weight, self.net[4].bias, None, "gelu", 0.0, rt)
 

@@ -624,13 +624,14 @@ def tlayer_tail(o2, x1, W, rows_per_strip=None, eps=1e-5):
     return out
 
 
-def tlayer_ffn(x, W, *, o=None, p=0.0, seed=None, calls=(0, 0, 0), rows_per_strip=64, eps=1e-5):
+def tlayer_ffn(x, W, *, o=None, p=0.0, seed=None, calls=(0, 0, 0), rows_per_strip=64, eps=1e-5, act="relu", residual=True):
     """the tail of a pre-norm layer on ANY row count, in strips of rows_per_strip rows (rows % rows_per_strip == 0), ralf_tlayer_fwd part 3 / 2:
         o is None:  out = x + drop(W2 drop(relu(W1 LN(x) + b1)) + b2)                                   (the feed-forward block)
         o given:    r = x + drop(o Wo^T + bo);  out = r + drop(W2 drop(relu(W1 LN(r) + b1)) + b2)       (+ the attention's out-projection in front)
     x, o [..., 256] bf16; W: "ln3" (gamma, beta), "ffn1" / "ffn2" (and "out" with o) = (weight packed by tlayer_pack, fp32 bias);
-    calls = dropout call ids (out-projection, ffn1, ffn2).  Returns what the unfused Functions would have saved plus the output:
-    [x2 (= r),] h3, mean3, rstd3, hid, out."""
+    calls = dropout call ids (out-projection, ffn1, ffn2).  act="gelu", residual=False (o None only): out = W2 gelu(W1 LN(x) + b1) + b2, the
+    reference's FeedForward, with the pre-activation z kept for the GELU gradient.  Returns what the unfused Functions would have saved plus
+    the output: [x2 (= r),] h3, mean3, rstd3, hid, [z,] out."""
     from ._abi import RalfTLayerDesc
 
     shape = x.shape
@@ -642,6 +643,11 @@ def tlayer_ffn(x, W, *, o=None, p=0.0, seed=None, calls=(0, 0, 0), rows_per_stri
          "out": torch.empty(shape, dtype=torch.bfloat16, device=dev)}
     d = RalfTLayerDesc()
     d.ln3_g, d.ln3_b, d.w1, d.b1, d.w2, d.b2 = _p(W["ln3"][0]), _p(W["ln3"][1]), _p(W["ffn1"][0]), _p(W["ffn1"][1]), _p(W["ffn2"][0]), _p(W["ffn2"][1])
+    assert act in ("relu", "gelu") and (o is None or (act == "relu" and residual))
+    if act == "gelu":
+        t["z"] = torch.empty(*shape[:-1], ff, dtype=torch.bfloat16, device=dev)
+        d.act = 2
+    d.no_res = 0 if residual else 1
     if o is None:
         d.x, d.part = _p(x), 3
     else:

@@ -332,3 +332,46 @@ def test_long_sequence_encoder_layer_with_the_one_launch_feed_forward_half():
                 same_bits(res[variant][k], res[False][k], k)
             else:
                 torch.testing.assert_close(res[variant][k], res[False][k], rtol=1e-5, atol=1e-5 * res[False][k].abs().max().item(), msg=lambda m: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("rows", [33792, 1024])
+def test_gelu_feed_forward_on_strips_and_its_module(rows):
+    """part 3 with GELU, the pre-activation kept, no residual (nn.FeedForward: LN -> Linear -> GELU -> Linear): the bits of the three launches;
+    through the module: same output and input gradient as the per-operation path"""
+    from ralf_amd import nn as RN, ops
+    from ralf_amd.functional import Runtime
+
+    w = make_weights(False, seed=13)
+    x = rnd(rows, D, seed=1).to(torch.bfloat16).cuda()
+    h, mean, rstd = ops.layernorm_fwd(x, *w["ln3"])
+    z = torch.empty(rows, FF, dtype=torch.bfloat16, device="cuda")
+    hid = ops.gemm(h, w["ffn1"][0], rows, FF, D, bias=w["ffn1"][1], act="gelu", out2=z)
+    out = ops.gemm(hid, w["ffn2"][0], rows, D, FF, bias=w["ffn2"][1])
+    pk = ops.tlayer_pack([w["ffn1"][0], w["ffn2"][0]])
+    t = ops.tlayer_ffn(x, {"ln3": w["ln3"], "ffn1": (pk[0], w["ffn1"][1]), "ffn2": (pk[1], w["ffn2"][1])}, act="gelu", residual=False)
+    torch.cuda.synchronize()
+    for name, ref in (("h3", h), ("mean3", mean), ("rstd3", rstd), ("z", z), ("hid", hid), ("out", out)):
+        same_bits(t[name], ref, name)
+    if rows > 2048:
+        return
+    torch.manual_seed(2)
+    ffm = RN.FeedForward(D, FF).cuda()
+    for prm in ffm.parameters():
+        torch.nn.init.normal_(prm, std=0.05)
+    ffm.net[0].weight.data.add_(1.0)
+    go = rnd(rows, D, seed=3).to(torch.bfloat16).cuda()
+    res = {}
+    for fused in (True, False):
+        rt = Runtime(torch.bfloat16, seed=1)
+        rt.to(torch.device("cuda"))
+        rt.fused_ffn = fused
+        xx = x.clone().requires_grad_(True)
+        ffm.zero_grad(set_to_none=True)
+        y = ffm(xx, rt)
+        y.backward(go)
+        rt.flush_wgrads()
+        rt.join_side()
+        torch.cuda.synchronize()
+        res[fused] = (y.detach().clone(), xx.grad.clone())
+    same_bits(res[True][0], res[False][0], "y")
+    same_bits(res[True][1], res[False][1], "dx")
