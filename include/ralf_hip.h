@@ -372,10 +372,31 @@ typedef struct RalfTLayerDesc {
     void* z; int act, no_res;
 } RalfTLayerDesc;
 int ralf_tlayer_fwd(const RalfTLayerDesc* d, void* stream);
+/* Backward of the long-sequence layers' tail (ralf_tlayer_fwd part 2 on 64-row strips), data gradients only -- the launches
+ * ralf_gemm (dz, with the ReLU mask) -> ralf_gemm (dh) -> ralf_layernorm_bwd -> ralf_gemm (d o) of functional.FFNFn / LayerNormSkipFn /
+ * LinearFn.backward in one, with the same arithmetic; the weight / bias gradients are taken afterwards from the tensors it writes
+ * (dz, g_m) by the grouped weight-gradient launches, as before.  B strips of S <= 64 rows:
+ *   dz  = (dy_m W2) o [hid > 0] / (1 - p)        dy_m = the gradient of the layer output masked by the ffn2 dropout (dy itself when p = 0)
+ *   dh  = dz W1                                   (stage 1 stops here and writes dh to g)
+ *   g   = LayerNorm3 backward(dh; x2, mean3, rstd3, gamma) + dy     the gradient of r = x + drop(o Wo^T + bo); dgamma / dbeta += (atomics)
+ *   g_m = g masked by the out-projection dropout (p, call_out);  d_o = g_m Wo
+ * w2t / w1t / wot: ralf_tlayer_pack of the TRANSPOSED weights (RalfPackJob.transpose). */
+typedef struct RalfTLayerBwdDesc {
+    const void* dy_m; const void* dy; const void* hid; const void* x2;
+    const float* mean3; const float* rstd3; const float* ln3_g;
+    const void* w2t; const void* w1t; const void* wot;
+    void* dz; void* g; void* g_m; void* d_o;
+    float* dgamma; float* dbeta;
+    const int64_t* seed; uint64_t call_out;
+    int B, S, stage, pad_;
+    float p, pad2_;
+} RalfTLayerBwdDesc;
+int ralf_tlayer_bwd(const RalfTLayerBwdDesc* d, void* stream);
 /* weights -> the fragment order ralf_tlayer_fwd streams: for the 32-row tile t and the 16-wide k-slice i of src [N][K] (row stride ld
  * elements), the 64 lanes' MFMA operands (lane (r, half) = src[32 t + r][16 i + 8 half .. + 7]) become 1 KiB of consecutive memory at
  * dst + ((t * K/16 + i) * 64 + lane) * 8 elements.  N % 32 == 0, K % 16 == 0; up to 48 matrices per launch (jobs is a HOST array). */
-typedef struct RalfPackJob { const void* src; void* dst; int64_t ld; int N, K; } RalfPackJob;
+typedef struct RalfPackJob { const void* src; void* dst; int64_t ld; int N, K; int transpose, pad_; } RalfPackJob;   /* transpose: the packed
+    matrix is src^T, i.e. element [n][k] = src[k * ld + n] (src [K][N] row-major): the data-gradient products of ralf_tlayer_bwd */
 int ralf_tlayer_pack(const RalfPackJob* jobs, int njobs, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

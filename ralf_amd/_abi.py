@@ -42,8 +42,13 @@ class RalfTLayerDesc(ctypes.Structure):
                 + [("z", vp), ("act", i32), ("no_res", i32)])
 
 
+class RalfTLayerBwdDesc(ctypes.Structure):
+    _fields_ = ([(n, vp) for n in ("dy_m", "dy", "hid", "x2", "mean3", "rstd3", "ln3_g", "w2t", "w1t", "wot", "dz", "g", "g_m", "d_o", "dgamma", "dbeta", "seed")]
+                + [("call_out", ctypes.c_uint64)] + [(n, i32) for n in ("B", "S", "stage", "pad_")] + [("p", f32), ("pad2_", f32)])
+
+
 class RalfPackJob(ctypes.Structure):
-    _fields_ = [("src", vp), ("dst", vp), ("ld", i64), ("N", i32), ("K", i32)]
+    _fields_ = [("src", vp), ("dst", vp), ("ld", i64), ("N", i32), ("K", i32), ("transpose", i32), ("pad_", i32)]
 
 
 class RalfBnFoldJob(ctypes.Structure):
@@ -145,6 +150,7 @@ SIGNATURES.update({
     "ralf_decode_attn_max_keys": (i32, []),
     "ralf_tlayer_fwd": (i32, [ctypes.POINTER(RalfTLayerDesc), vp]),
     "ralf_tlayer_pack": (i32, [ctypes.POINTER(RalfPackJob), i32, vp]),
+    "ralf_tlayer_bwd": (i32, [ctypes.POINTER(RalfTLayerBwdDesc), vp]),
     "ralf_sumsq": (i32, [vp, i64, vp, vp]),
     "ralf_clip_coef": (i32, [vp, f32, vp, vp, vp]),
     "ralf_sumsq_partials": (i32, [vp, i64, vp, vp]),

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const T* __restr
                     ag[c][i] += w * d[r][c][i] * xh[r][c][i];
                     ab[c][i] += w * d[r][c][i];
                     const float dg = d[r][c][i] * g[c][i];
-                    s1[r] += dg; s2[r] += dg * xh[r][c][i];
+                    s1[r] += dg; s2[r] = __fmaf_rn(dg, xh[r][c][i], s2[r]);   // (explicit fma here and below: tlayer.hip's backward writes the same bits)
                 }
         }
 #pragma unroll
@@ -139,8 +139,8 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const T* __restr
                 float o[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    o[i] = rs[r] * (d[r][c][i] * g[c][i] - m1 - xh[r][c][i] * m2);
-                    if (skip) o[i] += sk[r][c][i];   // pre-norm residual: the skip branch's gradient joins here (no separate add kernel)
+                    const float t = __fmaf_rn(-xh[r][c][i], m2, __fmaf_rn(d[r][c][i], g[c][i], -m1));
+                    o[i] = skip ? __fmaf_rn(rs[r], t, sk[r][c][i]) : rs[r] * t;   // pre-norm residual: the skip branch's gradient joins here (no separate add kernel)
                 }
                 V4<T>::store(dx + (int64_t)(row0 + r) * cols + c * 256 + lane * 4, o);
                 if (dx_drop) {

@@ -524,6 +524,162 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
     TL_PROBE(11);
 }
 
+// ---- backward of the strip-wise tail (see RalfTLayerBwdDesc): the forward feed-forward loop with the roles turned -- the strip of dy_m is the
+// LDS operand, W2^T streams where W1 did (dz chunk = 256 hidden columns, masked by the forward hidden), W1^T where W2 did (dh accumulates over
+// the four chunks) -- then the LayerNorm backward as a row pass and the out-projection's data gradient ----
+__global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc d) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    bf16* bufA = reinterpret_cast<bf16*>(lds);          // dy_m strip, later g_m
+    bf16* bufB = bufA + BUFA_ELEMS;
+    bf16* Mc = bufB;                                     // forward hidden chunk (the ReLU / dropout mask source)
+    bf16* Dc = bufB + BUFA_ELEMS;                        // dz chunk
+    float* stage = reinterpret_cast<float*>(bufB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, S = d.S;
+    const int64_t row0 = (int64_t)b * S;
+    const float inv_keep = 1.f / (1.f - d.p);
+    WFrag w;
+    load_w(w, w_ptr((const bf16*)d.w2t, 16, wave, 0, lane));
+    copy_in<2>(bufA, (const bf16*)d.dy_m + row0 * TD, S, tid);
+    // the forward hidden chunk of the next iteration travels in registers (4 x 16 bytes per thread) while the current one is used
+    uint4 hreg[4];
+    auto hid_load = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + NT * i, r = e >> 5, cc = e & 31;
+            hreg[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (r < S) hreg[i] = *reinterpret_cast<const uint4*>((const bf16*)d.hid + (row0 + r) * TFF + c * TD + cc * 8);
+        }
+    };
+    auto hid_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + NT * i, r = e >> 5, cc = e & 31;
+            *reinterpret_cast<uint4*>(Mc + r * LDA + cc * 8) = hreg[i];
+        }
+    };
+    hid_load(0);
+    f32x16 yacc[2];
+    zero_acc(yacc);
+    Bias4 zero4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) zero4.b[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int c = 0; c < TFF / TD; ++c) {
+        hid_store();
+        if (c + 1 < TFF / TD) hid_load(c + 1);
+        lds_barrier();   // dy_m strip (first iteration) and the mask chunk are in place; the previous chunk's readers of Dc are done
+        {   // dz columns c*256 + wave*32 ..: tile c*8 + wave of W2^T [1024][256]; next in the weight stream: W1^T[wave*32 ..][c*256 ..]
+            f32x16 acc[2];
+            zero_acc(acc);
+            tile_mma(acc, bufA, LDA, w, w_ptr((const bf16*)d.w1t, TFF / 16, wave, c * 16, lane), lane);
+            tile_epilogue(acc, zero4, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
+                const bf16x4 hm = *reinterpret_cast<const bf16x4*>(Mc + m * LDA + n);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (float)hm[q] > 0.f ? v[q] * inv_keep : 0.f;   // (RALF_AUX_RELU_MASK with aux_scale = 1 / (1 - p))
+                *reinterpret_cast<bf16x4*>(Dc + m * LDA + n) = to_bf16x4(v);
+            });
+        }
+        lds_barrier();
+        copy_out<TD>(Dc, LDA, (bf16*)d.dz + row0 * TFF + c * TD, TFF, S, tid);
+        tile_mma(yacc, Dc, LDA, w, c + 1 < TFF / TD ? w_ptr((const bf16*)d.w2t, 16, (c + 1) * NW + wave, 0, lane) : (d.stage > 1 ? w_ptr((const bf16*)d.wot, 16, wave, 0, lane) : nullptr), lane);
+    }
+    lds_barrier();   // every wave is done with Mc / Dc: the staging tile takes their place
+    tile_epilogue(yacc, zero4, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
+        *reinterpret_cast<f32x4*>(stage + m * STG_LD + n) = (f32x4){v[0], v[1], v[2], v[3]};
+    });
+    lds_barrier();
+    if (d.stage <= 1) {   // dh rows, as ralf_gemm would have written them
+        bf16x4 none[TS / NW];
+        row_pass<true, true, false, 2, false>(stage, none, (bf16*)d.g + row0 * TD, S, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, wave, lane);
+        return;
+    }
+    // ---- LayerNorm backward (norm.hip ln_bwd_kernel's arithmetic: wave per row, lane l owns columns 4l .. 4l+3), all 8 rows of a wave together ----
+    constexpr int NR = TS / NW;
+    float gm[4], ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gm[i] = d.ln3_g[lane * 4 + i];
+    bf16x4 xr[NR], sk[NR];
+    float mu[NR], rs[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int row = wave + k * NW, rc = row < S ? row : 0;
+        xr[k] = *reinterpret_cast<const bf16x4*>((const bf16*)d.x2 + (row0 + rc) * TD + lane * 4);
+        sk[k] = *reinterpret_cast<const bf16x4*>((const bf16*)d.dy + (row0 + rc) * TD + lane * 4);
+        mu[k] = d.mean3[row0 + rc]; rs[k] = d.rstd3[row0 + rc];
+    }
+    float dv[NR][4], xh[NR][4], s1[NR], s2[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int row = wave + k * NW;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(stage + row * STG_LD + lane * 4);
+        const float wgt = row < S ? 1.f : 0.f;
+        s1[k] = s2[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dv[k][i] = (float)(bf16)a[i];   // dh as the bf16 tensor ralf_gemm would have written
+            xh[k][i] = ((float)xr[k][i] - mu[k]) * rs[k];
+            ag[i] += wgt * dv[k][i] * xh[k][i];
+            ab[i] += wgt * dv[k][i];
+            const float dg = dv[k][i] * gm[i];
+            s1[k] += dg; s2[k] = __fmaf_rn(dg, xh[k][i], s2[k]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < NR; ++k) { s1[k] += __shfl_xor(s1[k], o); s2[k] += __shfl_xor(s2[k], o); }
+    lds_barrier();   // every wave has read its staged rows: bufB is free for the column sums, bufA for g_m
+    const uint64_t seed = d.p > 0.f ? (uint64_t)d.seed[0] : 0;
+    const uint32_t thr = drop_thr16(d.p);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int row = wave + k * NW;
+        const float m1 = s1[k] * (1.f / TD), m2 = s2[k] * (1.f / TD);
+        bf16x4 go, gmk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) go[i] = (bf16)__fmaf_rn(rs[k], __fmaf_rn(-xh[k][i], m2, __fmaf_rn(dv[k][i], gm[i], -m1)), (float)sk[k][i]);
+        gmk = go;
+        if (d.p > 0.f) {
+            const uint64_t hh = drop_hash4(seed, d.call_out, (uint64_t)((row0 + row) * TD + lane * 4) >> 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gmk[i] = (bf16)(drop_keep(hh, i, thr) ? (float)go[i] * inv_keep : 0.f);
+        }
+        if (row >= S) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gmk[i] = (bf16)0.f;
+        } else {
+            *reinterpret_cast<bf16x4*>((bf16*)d.g + (row0 + row) * TD + lane * 4) = go;
+            if (d.p > 0.f) *reinterpret_cast<bf16x4*>((bf16*)d.g_m + (row0 + row) * TD + lane * 4) = gmk;
+        }
+        *reinterpret_cast<bf16x4*>(bufA + row * LDA + lane * 4) = gmk;
+    }
+    if (d.dgamma) {   // column sums of this strip: wave partials -> LDS -> one atomic per column (as ln_bwd_kernel)
+        float* red = stage;   // [2][8][256]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { red[(0 * NW + wave) * TD + lane * 4 + i] = ag[i]; red[(1 * NW + wave) * TD + lane * 4 + i] = ab[i]; }
+    }
+    lds_barrier();
+    if (d.dgamma) {
+        const float* red = stage;
+        const int which = tid >> 8, cc = tid & 255;
+        float t = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) t += red[(which * NW + wv) * TD + cc];
+        atomicAdd((which ? d.dbeta : d.dgamma) + cc, t);
+    }
+    {   // d_o = g_m Wo: the out-projection's data gradient (W = Wo^T in fragment order, requested during the last dh tile)
+        f32x16 acc[2];
+        zero_acc(acc);
+        tile_mma(acc, bufA, LDA, w, nullptr, lane);
+        lds_barrier();   // the column sums have been read: the strip's d_o rows go through the same LDS
+        bf16* Oc = bufB;
+        tile_epilogue(acc, zero4, wave * 32, lane, [&](int m, int n, float (&v)[4]) { *reinterpret_cast<bf16x4*>(Oc + m * LDA + n) = to_bf16x4(v); });
+        lds_barrier();
+        copy_out<TD>(Oc, LDA, (bf16*)d.d_o + row0 * TD, TD, S, tid);
+    }
+}
+
 // ---- weights -> fragment order (see WFrag).  One 16-byte chunk per thread: chunk c of job j = lane (c & 63) of (tile, k-slice) c >> 6 ----
 constexpr int PACK_MAX_JOBS = 48;
 struct PackJobs { RalfPackJob j[PACK_MAX_JOBS]; };
@@ -535,8 +691,15 @@ __global__ __launch_bounds__(256) void tlayer_pack_kernel(const PackJobs jobs) {
         const int lane = (int)(c & 63);
         const int64_t ts = c >> 6;
         const int tile = (int)(ts / kslices), slice = (int)(ts % kslices);
-        const bf16* src = (const bf16*)jb.src + (int64_t)(tile * 32 + (lane & 31)) * jb.ld + slice * 16 + (lane >> 5) * 8;
-        *reinterpret_cast<uint4*>((bf16*)jb.dst + c * 8) = *reinterpret_cast<const uint4*>(src);
+        const int n = tile * 32 + (lane & 31), k0 = slice * 16 + (lane >> 5) * 8;
+        if (!jb.transpose) {
+            *reinterpret_cast<uint4*>((bf16*)jb.dst + c * 8) = *reinterpret_cast<const uint4*>((const bf16*)jb.src + (int64_t)n * jb.ld + k0);
+        } else {   // element [n][k] = src[k][n]
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = ((const bf16*)jb.src)[(int64_t)(k0 + e) * jb.ld + n];
+            *reinterpret_cast<bf16x8*>((bf16*)jb.dst + c * 8) = v;
+        }
     }
 }
 }  // namespace
@@ -548,7 +711,8 @@ extern "C" int ralf_tlayer_pack(const RalfPackJob* jobs, int njobs, void* stream
     int64_t most = 0;
     for (int i = 0; i < njobs; ++i) {
         const RalfPackJob& j = jobs[i];
-        RALF_REQUIRE(j.src && j.dst && j.N > 0 && j.K > 0 && j.N % 32 == 0 && j.K % 16 == 0 && j.ld >= j.K && j.ld % 8 == 0, "tlayer_pack: job %d: [N %% 32 == 0][K %% 16 == 0] bf16, ld %% 8 == 0", i);
+        RALF_REQUIRE(j.src && j.dst && j.N > 0 && j.K > 0 && j.N % 32 == 0 && j.K % 16 == 0 && j.ld >= (j.transpose ? j.N : j.K) && (j.transpose || j.ld % 8 == 0),
+                     "tlayer_pack: job %d: [N %% 32 == 0][K %% 16 == 0] bf16, ld %% 8 == 0", i);
         pj.j[i] = j;
         most = most > (int64_t)j.N * j.K / 8 ? most : (int64_t)j.N * j.K / 8;
     }
@@ -585,4 +749,14 @@ extern "C" int ralf_tlayer_fwd(const RalfTLayerDesc* dp, void* stream) {
     else if (d.S <= 32) hipLaunchKernelGGL((tlayer_fwd_kernel<2, 1>), dim3(d.B), dim3(NT), 0, st, d);   // strips of one 32-row block
     else hipLaunchKernelGGL((tlayer_fwd_kernel<2>), dim3(d.B), dim3(NT), 0, st, d);
     return ralf::check_launch("tlayer_fwd");
+}
+
+extern "C" int ralf_tlayer_bwd(const RalfTLayerBwdDesc* dp, void* stream) {
+    RALF_REQUIRE(dp, "tlayer_bwd: null descriptor");
+    const RalfTLayerBwdDesc& d = *dp;
+    RALF_REQUIRE(d.B > 0 && d.S > 0 && d.S <= TS && d.p >= 0.f && d.p < 1.f, "tlayer_bwd: needs 1 <= S <= %d rows per strip, 0 <= p < 1", TS);
+    RALF_REQUIRE(d.dy_m && d.hid && d.w2t && d.w1t && d.dz && d.g && d.stage >= 1 && d.stage <= 3, "tlayer_bwd: null pointer / stage");
+    RALF_REQUIRE(d.stage == 1 || (d.dy && d.x2 && d.mean3 && d.rstd3 && d.ln3_g && d.wot && d.g_m && d.d_o && (d.p == 0.f || d.seed)), "tlayer_bwd: stage 3 needs the LayerNorm and out-projection operands");
+    hipLaunchKernelGGL(tlayer_bwd_kernel, dim3(d.B), dim3(NT), 0, (hipStream_t)stream, d);
+    return ralf::check_launch("tlayer_bwd");
 }

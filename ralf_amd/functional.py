@@ -75,6 +75,7 @@ class Runtime:
         self.fused_ffn = os.environ.get("RALF_FUSED_FFN", "1") != "0"
         self.fused_ffn_out = os.environ.get("RALF_FUSED_FFN_OUT", "1") != "0"   # ... with the attention's out-projection + residual in front
         self.fused_lnqkv = os.environ.get("RALF_FUSED_LNQKV", "1") != "0"       # ... and LayerNorm 1 + the q | k | v projection as one launch
+        self.fused_ffn_bwd = os.environ.get("RALF_FUSED_FFN_BWD", "1") != "0"   # ... and the tail's four backward data-gradient launches as one
         # KV-cached decode step: out-projection + LayerNorm + feed-forward per layer as ONE launch on 32-row strips (ops.tlayer_tail).  OFF: measured
         # 36.2 vs 34.8 ms per B = 256 decode loop -- a workgroup streams all 1.15 MB of the layer's weights through one CU's L2 port (18.3 us per
         # launch, 26 k of its 39 k cycles in the feed-forward weight stream), the four launches it replaces spread them over the chip
@@ -1070,13 +1071,15 @@ class TFFNFn(Function):
         c1, c2 = nc(), nc()
         if packed is None:
             packed = ops.tlayer_pack(([rt.lp(params[0])] if with_o else []) + [rt.lp(w1), rt.lp(w2)])
-        W = {"ln3": (n3w.detach(), n3b.detach()), "ffn1": (packed[-2], b1.detach()), "ffn2": (packed[-1], b2.detach())}
+        k0 = 1 if with_o else 0   # packed = [out_proj,] linear1, linear2 [, W2^T, W1^T, Wo^T]
+        W = {"ln3": (n3w.detach(), n3b.detach()), "ffn1": (packed[k0], b1.detach()), "ffn2": (packed[k0 + 1], b2.detach())}
         if with_o:
             o = o.contiguous()
             W["out"] = (packed[0], params[1].detach())
         t = ops.tlayer_ffn(x, W, o=o, p=p, seed=rt.seed if p > 0.0 else None, calls=(co, c1, c2))
         ctx.save_for_backward(x, o, *params, t["h3"], t["mean3"], t["rstd3"], t["hid"], t.get("x2"))
         ctx.cfg = (with_o, p, co, c2, rt, rt.dropout_tag(x))
+        ctx.packed_t = tuple(packed[3:6]) if (with_o and len(packed) >= 6) else None   # (W2^T, W1^T, Wo^T in fragment order, when the caller packed them)
         rt.tag_dropout(t["out"], p, c2)
         return t["out"]
 
@@ -1091,6 +1094,29 @@ class TFFNFn(Function):
         n3w, n3b, w1, b1, w2, b2 = params[-6:]
         rows = x.numel() // x.shape[-1]
         need = ctx.needs_input_grad[5:]
+        if with_o and rt.fused_ffn_bwd and rows % 64 == 0:
+            # one launch for the four data-gradient steps (dz, dh, LayerNorm backward + skip, d o); the weight / bias gradients from the tensors
+            # it wrote, through the same (grouped) launches as the per-operation path
+            dy2 = _2d(dy.contiguous())
+            if dy2.dtype != rt.dtype:
+                dy2 = ops.cast(dy2, rt.dtype)
+            dy_m = rt.masked_grad(dy2, p, c2) if p > 0.0 else dy2
+            wo, bo = params[0], params[1]
+            pt = ctx.packed_t or ops.tlayer_pack([rt.lp(w2), rt.lp(w1), rt.lp(wo)], transpose=(0, 1, 2))
+            gg, gb = rt.gview(n3w), rt.gview(n3b)
+            direct = gg is not None and gb is not None
+            if not direct:
+                gg, gb = torch.zeros(n3w.numel(), dtype=torch.float32, device=x.device), torch.zeros(n3b.numel(), dtype=torch.float32, device=x.device)
+            t = ops.tlayer_bwd(dy_m, hid.view(rows, -1), {"w2t": pt[0], "w1t": pt[1], "wot": pt[2]}, p=p, dy=dy2, x2=x2.view(rows, -1), mean3=mean3, rstd3=rstd3,
+                               gamma=n3w.detach(), dgamma=gg, dbeta=gb, seed=rt.seed if p > 0.0 else None, call_out=co)
+            d_model, ff = x.shape[-1], hid.shape[-1]
+            dW2 = wgrad(dy_m, hid.view(rows, -1), d_model, ff, rows, rt.gview(w2), rt)
+            db2 = bgrad(dy_m, rows, d_model, rt.gview(b2), rt)
+            dW1 = wgrad(t["dz"], h3.view(rows, -1), ff, d_model, rows, rt.gview(w1), rt)
+            db1 = bgrad(t["dz"], rows, ff, rt.gview(b1), rt)
+            dWo = wgrad(t["g_m"], o.view(rows, -1), d_model, d_model, rows, rt.gview(wo), rt) if need[0] else None
+            dbo = bgrad(t["g_m"], rows, d_model, rt.gview(bo), rt) if need[1] else None
+            return (t["g"].view(x.shape), t["d_o"].view(o.shape), None, None, None, dWo, dbo, None if direct else gg, None if direct else gb, dW1, db1, dW2, db2)
         c = _Ctx((h3.view(rows, -1), w1, w2, hid.view(rows, -1), None), (True,), b1=b1, b2=b2, rt=rt, act="relu", p=p, has_res=True, xshape=x.shape, c2=c2)
         dh, dW1, db1, dW2, db2, dres = FFNFn.backward(c, dy)[:6]
         if not with_o:

@@ -246,9 +246,16 @@ def pack_ffn_layers(layers, x, rt: Runtime):
         return None
     if not all(l.norm_first and RF.tffn_supported(x, rt, l.self_attn.d, l.linear1.weight.shape[0]) for l in layers):
         return None
-    flat = ops.tlayer_pack([m for l in layers for m in (rt.lp(l.self_attn.in_proj_weight), rt.lp(l.self_attn.out_proj.weight), rt.lp(l.linear1.weight),
-                                                         rt.lp(l.linear2.weight))])
-    return [flat[4 * i:4 * i + 4] for i in range(len(layers))]
+    bwd = rt.fused_ffn_bwd and torch.is_grad_enabled() and len(layers) * 7 <= 48   # + W2^T, W1^T, Wo^T for the one-launch backward of the tail
+    mats, tr = [], []
+    for l in layers:
+        mats += [rt.lp(l.self_attn.in_proj_weight), rt.lp(l.self_attn.out_proj.weight), rt.lp(l.linear1.weight), rt.lp(l.linear2.weight)]
+        if bwd:
+            tr += [len(mats), len(mats) + 1, len(mats) + 2]
+            mats += [rt.lp(l.linear2.weight), rt.lp(l.linear1.weight), rt.lp(l.self_attn.out_proj.weight)]
+    flat = ops.tlayer_pack(mats, transpose=tuple(tr))
+    per = 7 if bwd else 4
+    return [flat[per * i:per * (i + 1)] for i in range(len(layers))]
 
 
 def _pack_layers(layers, x, rt: Runtime):

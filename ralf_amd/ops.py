@@ -531,9 +531,10 @@ def attention_fwd(q, k, v, B, H, Sq, Sk, dh, q_off=0, k_off=0, v_off=0, causal=F
 TLAYER_MAX_ROWS = 64
 
 
-def tlayer_pack(mats):
+def tlayer_pack(mats, transpose=()):
     """row-major bf16 matrices [N % 32 == 0, K % 16 == 0] -> the fragment order ralf_tlayer_fwd streams its weights in (ralf_tlayer_pack):
-    ONE launch and one buffer for all of them; returns the flat packed views in order."""
+    ONE launch and one buffer for all of them; returns the flat packed views in order.  transpose: indices of the matrices to pack as
+    their transpose (the data-gradient products read W^T)."""
     from ._abi import RalfPackJob
 
     assert 0 < len(mats) <= 48
@@ -542,9 +543,11 @@ def tlayer_pack(mats):
     outs, off = [], 0
     jobs = (RalfPackJob * len(mats))()
     for i, m in enumerate(mats):
-        assert m.dtype == torch.bfloat16 and m.dim() == 2 and m.stride(1) == 1 and m.shape[0] % 32 == 0 and m.shape[1] % 16 == 0
+        assert m.dtype == torch.bfloat16 and m.dim() == 2 and m.stride(1) == 1 and m.shape[0] % 32 == 0 and m.shape[1] % 32 == 0
         outs.append(buf[off:off + sizes[i]])
-        jobs[i].src, jobs[i].dst, jobs[i].ld, jobs[i].N, jobs[i].K = m.data_ptr(), outs[i].data_ptr(), m.stride(0), m.shape[0], m.shape[1]
+        tr = i in transpose
+        jobs[i].src, jobs[i].dst, jobs[i].ld = m.data_ptr(), outs[i].data_ptr(), m.stride(0)
+        jobs[i].N, jobs[i].K, jobs[i].transpose = (m.shape[1], m.shape[0], 1) if tr else (m.shape[0], m.shape[1], 0)
         off += sizes[i]
     _call("ralf_tlayer_pack", jobs, len(mats))
     return outs
@@ -681,6 +684,33 @@ def tlayer_lnqkv(x, W, rows_per_strip=64, eps=1e-5):
         setattr(d, k, _p(v))
     d.B, d.S, d.part, d.eps = rows // S, S, 4, eps
     _call("ralf_tlayer_fwd", ctypes.byref(d))
+    return t
+
+
+def tlayer_bwd(dy_m, hid, Wt, *, p=0.0, dy=None, x2=None, mean3=None, rstd3=None, gamma=None, dgamma=None, dbeta=None, seed=None, call_out=0,
+               rows_per_strip=64):
+    """data gradients of the strip-wise layer tail (ralf_tlayer_bwd): dz = (dy_m W2) o [hid > 0] / (1 - p), dh = dz W1 -- and, with the
+    LayerNorm operands (dy, x2, mean3, rstd3, gamma), g = LN-backward(dh) + dy, g_m = g masked by (p, call_out), d_o = g_m Wo.
+    Wt: "w2t", "w1t" (and "wot") = tlayer_pack(.., transpose) of linear2 / linear1 / out_proj weights.  Returns dz and dh (stage 1) or dz, g, g_m, d_o."""
+    from ._abi import RalfTLayerBwdDesc
+
+    shape = dy_m.shape
+    rows, S = dy_m.numel() // shape[-1], int(rows_per_strip)
+    assert shape[-1] == 256 and dy_m.dtype == torch.bfloat16 and dy_m.is_contiguous() and hid.is_contiguous() and rows % S == 0
+    full = x2 is not None
+    dev = dy_m.device
+    t = {"dz": torch.empty(*shape[:-1], 1024, dtype=torch.bfloat16, device=dev), "g": torch.empty(shape, dtype=torch.bfloat16, device=dev)}
+    d = RalfTLayerBwdDesc()
+    d.dy_m, d.hid, d.w2t, d.w1t = _p(dy_m), _p(hid), _p(Wt["w2t"]), _p(Wt["w1t"])
+    if full:
+        t["g_m"] = torch.empty(shape, dtype=torch.bfloat16, device=dev) if p > 0.0 else t["g"]
+        t["d_o"] = torch.empty(shape, dtype=torch.bfloat16, device=dev)
+        d.dy, d.x2, d.mean3, d.rstd3, d.ln3_g, d.wot = _p(dy), _p(x2), _p(mean3), _p(rstd3), _p(gamma), _p(Wt["wot"])
+        d.dgamma, d.dbeta, d.seed, d.call_out = _p(dgamma), _p(dbeta), _p(seed) if p > 0.0 else None, int(call_out)
+    for k, v in t.items():
+        setattr(d, k, _p(v))
+    d.B, d.S, d.stage, d.p = rows // S, S, 3 if full else 1, float(p)
+    _call("ralf_tlayer_bwd", ctypes.byref(d))
     return t
 
 

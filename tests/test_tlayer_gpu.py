@@ -311,12 +311,13 @@ def test_long_sequence_encoder_layer_with_the_one_launch_feed_forward_half():
     x0 = rnd(4, 256, D, seed=1).to(torch.bfloat16).cuda()
     go = rnd(4, 256, D, seed=3).to(torch.bfloat16).cuda()
     res = {}
-    for fused in (True, "tail only", False):
+    for fused in (True, "tail only", "forward only", False):
         rt = Runtime(torch.bfloat16, seed=11)
         rt.to(torch.device("cuda"))
         rt.training = True
         rt.fused_ffn = bool(fused)
-        rt.fused_lnqkv = fused is True
+        rt.fused_lnqkv = fused is True or fused == "forward only"
+        rt.fused_ffn_bwd = fused is True or fused == "tail only"
         rt.begin_step()
         x = x0.clone().requires_grad_(True)
         layer.zero_grad(set_to_none=True)
@@ -326,7 +327,7 @@ def test_long_sequence_encoder_layer_with_the_one_launch_feed_forward_half():
         rt.join_side()
         torch.cuda.synchronize()
         res[fused] = {"y": y.detach().clone(), "dx": x.grad.clone(), **{n: prm.grad.clone() for n, prm in layer.named_parameters()}}
-    for variant in (True, "tail only"):
+    for variant in (True, "tail only", "forward only"):
         for k in res[variant]:
             if k in ("y", "dx"):
                 same_bits(res[variant][k], res[False][k], k)
@@ -375,3 +376,52 @@ def test_gelu_feed_forward_on_strips_and_its_module(rows):
         res[fused] = (y.detach().clone(), xx.grad.clone())
     same_bits(res[True][0], res[False][0], "y")
     same_bits(res[True][1], res[False][1], "dx")
+
+
+@pytest.mark.parametrize("rows,p", [(16384, 0.1), (192, 0.0)])
+def test_tail_backward_stage_1_writes_the_bits_of_the_two_data_gradient_products(rows, p):
+    """ralf_tlayer_bwd stage 1: dz = (dy_m W2) masked by the forward hidden, dh = dz W1 (functional.FFNFn.backward's two products)"""
+    from ralf_amd import ops
+
+    w = make_weights(False, seed=21)
+    dy_m = rnd(rows, D, seed=1).to(torch.bfloat16).cuda()
+    hid = torch.relu(rnd(rows, FF, seed=2)).to(torch.bfloat16).cuda()
+    dz = ops.gemm(dy_m, w["ffn2"][0], rows, FF, D, b_kcontig=False, aux=hid, aux_mode="relu_mask", aux_scale=1.0 / (1.0 - p))
+    dh = ops.gemm(dz, w["ffn1"][0], rows, D, FF, b_kcontig=False)
+    pk = ops.tlayer_pack([w["ffn2"][0], w["ffn1"][0]], transpose=(0, 1))
+    t = ops.tlayer_bwd(dy_m, hid, {"w2t": pk[0], "w1t": pk[1]}, p=p)
+    torch.cuda.synchronize()
+    same_bits(t["dz"], dz, "dz")
+    same_bits(t["g"], dh, "dh")
+
+
+@pytest.mark.parametrize("rows,p", [(16384, 0.1), (192, 0.0), (64, 0.1)])
+def test_tail_backward_writes_the_bits_of_the_four_data_gradient_launches(rows, p):
+    """ralf_tlayer_bwd stage 3 against ralf_gemm (dz) -> ralf_gemm (dh) -> ralf_layernorm_bwd (with the skip gradient and the masked second
+    output) -> ralf_gemm (d o): dz, g, g_m, d_o bit for bit; dgamma / dbeta (fp32 atomics in both) to rounding"""
+    from ralf_amd import ops
+
+    w = make_weights(True, seed=23)
+    dy = rnd(rows, D, seed=1).to(torch.bfloat16).cuda()
+    seed = torch.tensor([31337], dtype=torch.int64, device="cuda")
+    dy_m = ops.dropout(dy, p, seed, 9) if p > 0 else dy
+    hid = torch.relu(rnd(rows, FF, seed=2)).to(torch.bfloat16).cuda()
+    x2 = rnd(rows, D, seed=3).to(torch.bfloat16).cuda()
+    _, mean, rstd = ops.layernorm_fwd(x2, *w["ln3"])
+    dz = ops.gemm(dy_m, w["ffn2"][0], rows, FF, D, b_kcontig=False, aux=hid, aux_mode="relu_mask", aux_scale=1.0 / (1.0 - p))
+    dh = ops.gemm(dz, w["ffn1"][0], rows, D, FF, b_kcontig=False)
+    out = ops.layernorm_bwd(dh, x2, w["ln3"][0], mean, rstd, need_wgrad=True, skip=dy, drop=(p, seed, 4) if p > 0 else None)
+    g, dgam, dbet = out[0], out[1], out[2]
+    g_m = out[3] if p > 0 else g
+    d_o = ops.gemm(g_m, w["ca_out"][0], rows, D, D, b_kcontig=False)
+    pk = ops.tlayer_pack([w["ffn2"][0], w["ffn1"][0], w["ca_out"][0]], transpose=(0, 1, 2))
+    dgam2, dbet2 = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    t = ops.tlayer_bwd(dy_m, hid, {"w2t": pk[0], "w1t": pk[1], "wot": pk[2]}, p=p, dy=dy, x2=x2, mean3=mean, rstd3=rstd, gamma=w["ln3"][0],
+                       dgamma=dgam2, dbeta=dbet2, seed=seed, call_out=4)
+    torch.cuda.synchronize()
+    same_bits(t["dz"], dz, "dz")
+    same_bits(t["g"], g, "g")
+    same_bits(t["g_m"], g_m, "g_m")
+    same_bits(t["d_o"], d_o, "d_o")
+    torch.testing.assert_close(dgam2, dgam, rtol=1e-4, atol=1e-4 * dgam.abs().max().item())
+    torch.testing.assert_close(dbet2, dbet, rtol=1e-4, atol=1e-4 * dbet.abs().max().item())
