@@ -380,7 +380,10 @@ int ralf_tlayer_fwd(const RalfTLayerDesc* d, void* stream);
  *   dh  = dz W1                                   (stage 1 stops here and writes dh to g)
  *   g   = LayerNorm3 backward(dh; x2, mean3, rstd3, gamma) + dy     the gradient of r = x + drop(o Wo^T + bo); dgamma / dbeta += (atomics)
  *   g_m = g masked by the out-projection dropout (p, call_out);  d_o = g_m Wo
- * w2t / w1t / wot: ralf_tlayer_pack of the TRANSPOSED weights (RalfPackJob.transpose). */
+ * w2t / w1t / wot: ralf_tlayer_pack of the TRANSPOSED weights (RalfPackJob.transpose).
+ * stage 4 = the backward of part 4 (LayerNorm 1 + q | k | v projection): dy_m = dqkv [rows, 768], w1t = Win^T, dh = dqkv Win, then the same
+ * LayerNorm backward on (x2, mean3, rstd3, ln3_g) := (x, mean1, rstd1, gamma 1) with dy (may be NULL) as the skip gradient: g = dx,
+ * g_m = dx masked by (p, call_out) -- the dropout of the block that produced x. */
 typedef struct RalfTLayerBwdDesc {
     const void* dy_m; const void* dy; const void* hid; const void* x2;
     const float* mean3; const float* rstd3; const float* ln3_g;

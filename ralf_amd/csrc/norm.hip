@@ -122,7 +122,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const T* __restr
                     ag[c][i] += w * d[r][c][i] * xh[r][c][i];
                     ab[c][i] += w * d[r][c][i];
                     const float dg = d[r][c][i] * g[c][i];
-                    s1[r] += dg; s2[r] = __fmaf_rn(dg, xh[r][c][i], s2[r]);   // (explicit fma here and below: tlayer.hip's backward writes the same bits)
+                    s1[r] = __fmaf_rn(d[r][c][i], g[c][i], s1[r]); s2[r] = __fmaf_rn(dg, xh[r][c][i], s2[r]);   // (explicit fma here and below -- the compiler may or may not contract `s1 += dg` --: tlayer.hip's backward writes the same bits)
                 }
         }
 #pragma unroll

@@ -539,6 +539,29 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
     const int64_t row0 = (int64_t)b * S;
     const float inv_keep = 1.f / (1.f - d.p);
     WFrag w;
+    f32x16 yacc[2];
+    zero_acc(yacc);
+    Bias4 zero4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) zero4.b[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.stage == 4) {
+        // LayerNorm 1 + q | k | v projection backward: dh = dqkv Win (the strip of dqkv [64][768] is the LDS operand, Win^T [256][768] streams in
+        // three 256-wide k chunks), then the LayerNorm backward below; no product behind it
+        load_w(w, w_ptr((const bf16*)d.w1t, 48, wave, 0, lane));
+        {
+            constexpr int VPR = 3 * TD / 8;
+#pragma unroll
+            for (int i = 0; i < TS * VPR / NT; ++i) {
+                const int e = tid + NT * i, r = e / VPR, cc = e % VPR;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (r < S) v = *reinterpret_cast<const uint4*>((const bf16*)d.dy_m + (row0 + r) * (3 * TD) + cc * 8);
+                *reinterpret_cast<uint4*>(bufB + r * LDQ + cc * 8) = v;
+            }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tile_mma(yacc, bufB + c * TD, LDQ, w, c + 1 < 3 ? w_ptr((const bf16*)d.w1t, 48, wave, (c + 1) * 16, lane) : nullptr, lane);
+    } else {
     load_w(w, w_ptr((const bf16*)d.w2t, 16, wave, 0, lane));
     copy_in<2>(bufA, (const bf16*)d.dy_m + row0 * TD, S, tid);
     // the forward hidden chunk of the next iteration travels in registers (4 x 16 bytes per thread) while the current one is used
@@ -559,11 +582,6 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
         }
     };
     hid_load(0);
-    f32x16 yacc[2];
-    zero_acc(yacc);
-    Bias4 zero4;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) zero4.b[g] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
     for (int c = 0; c < TFF / TD; ++c) {
         hid_store();
@@ -584,7 +602,8 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
         copy_out<TD>(Dc, LDA, (bf16*)d.dz + row0 * TFF + c * TD, TFF, S, tid);
         tile_mma(yacc, Dc, LDA, w, c + 1 < TFF / TD ? w_ptr((const bf16*)d.w2t, 16, (c + 1) * NW + wave, 0, lane) : (d.stage > 1 ? w_ptr((const bf16*)d.wot, 16, wave, 0, lane) : nullptr), lane);
     }
-    lds_barrier();   // every wave is done with Mc / Dc: the staging tile takes their place
+    }
+    lds_barrier();   // every wave is done with Mc / Dc (the dqkv strip): the staging tile takes their place
     tile_epilogue(yacc, zero4, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
         *reinterpret_cast<f32x4*>(stage + m * STG_LD + n) = (f32x4){v[0], v[1], v[2], v[3]};
     });
@@ -605,7 +624,7 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
     for (int k = 0; k < NR; ++k) {
         const int row = wave + k * NW, rc = row < S ? row : 0;
         xr[k] = *reinterpret_cast<const bf16x4*>((const bf16*)d.x2 + (row0 + rc) * TD + lane * 4);
-        sk[k] = *reinterpret_cast<const bf16x4*>((const bf16*)d.dy + (row0 + rc) * TD + lane * 4);
+        if (d.dy) sk[k] = *reinterpret_cast<const bf16x4*>((const bf16*)d.dy + (row0 + rc) * TD + lane * 4);
         mu[k] = d.mean3[row0 + rc]; rs[k] = d.rstd3[row0 + rc];
     }
     float dv[NR][4], xh[NR][4], s1[NR], s2[NR];
@@ -622,7 +641,7 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
             ag[i] += wgt * dv[k][i] * xh[k][i];
             ab[i] += wgt * dv[k][i];
             const float dg = dv[k][i] * gm[i];
-            s1[k] += dg; s2[k] = __fmaf_rn(dg, xh[k][i], s2[k]);
+            s1[k] = __fmaf_rn(dv[k][i], gm[i], s1[k]); s2[k] = __fmaf_rn(dg, xh[k][i], s2[k]);
         }
     }
 #pragma unroll
@@ -638,7 +657,10 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
         const float m1 = s1[k] * (1.f / TD), m2 = s2[k] * (1.f / TD);
         bf16x4 go, gmk;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) go[i] = (bf16)__fmaf_rn(rs[k], __fmaf_rn(-xh[k][i], m2, __fmaf_rn(dv[k][i], gm[i], -m1)), (float)sk[k][i]);
+        for (int i = 0; i < 4; ++i) {
+            const float t = __fmaf_rn(-xh[k][i], m2, __fmaf_rn(dv[k][i], gm[i], -m1));
+            go[i] = (bf16)(d.dy ? __fmaf_rn(rs[k], t, (float)sk[k][i]) : rs[k] * t);
+        }
         gmk = go;
         if (d.p > 0.f) {
             const uint64_t hh = drop_hash4(seed, d.call_out, (uint64_t)((row0 + row) * TD + lane * 4) >> 2);
@@ -668,6 +690,7 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
         for (int wv = 0; wv < NW; ++wv) t += red[(which * NW + wv) * TD + cc];
         atomicAdd((which ? d.dbeta : d.dgamma) + cc, t);
     }
+    if (d.stage == 4) return;
     {   // d_o = g_m Wo: the out-projection's data gradient (W = Wo^T in fragment order, requested during the last dh tile)
         f32x16 acc[2];
         zero_acc(acc);
@@ -755,8 +778,10 @@ extern "C" int ralf_tlayer_bwd(const RalfTLayerBwdDesc* dp, void* stream) {
     RALF_REQUIRE(dp, "tlayer_bwd: null descriptor");
     const RalfTLayerBwdDesc& d = *dp;
     RALF_REQUIRE(d.B > 0 && d.S > 0 && d.S <= TS && d.p >= 0.f && d.p < 1.f, "tlayer_bwd: needs 1 <= S <= %d rows per strip, 0 <= p < 1", TS);
-    RALF_REQUIRE(d.dy_m && d.hid && d.w2t && d.w1t && d.dz && d.g && d.stage >= 1 && d.stage <= 3, "tlayer_bwd: null pointer / stage");
-    RALF_REQUIRE(d.stage == 1 || (d.dy && d.x2 && d.mean3 && d.rstd3 && d.ln3_g && d.wot && d.g_m && d.d_o && (d.p == 0.f || d.seed)), "tlayer_bwd: stage 3 needs the LayerNorm and out-projection operands");
+    RALF_REQUIRE(d.stage == 1 || d.stage == 3 || d.stage == 4, "tlayer_bwd: stage 1 (dz, dh), 3 (the whole tail) or 4 (LayerNorm 1 + q | k | v projection)");
+    RALF_REQUIRE(d.dy_m && d.w1t && d.g && (d.stage == 4 || (d.hid && d.w2t && d.dz)), "tlayer_bwd: null pointer");
+    RALF_REQUIRE(d.stage == 1 || (d.x2 && d.mean3 && d.rstd3 && d.ln3_g && d.g_m && (d.p == 0.f || d.seed) && (d.stage == 4 || (d.dy && d.wot && d.d_o))),
+                 "tlayer_bwd: stages 3 / 4 need the LayerNorm operands (3: and the skip gradient and the out-projection)");
     hipLaunchKernelGGL(tlayer_bwd_kernel, dim3(d.B), dim3(NT), 0, (hipStream_t)stream, d);
     return ralf::check_launch("tlayer_bwd");
 }

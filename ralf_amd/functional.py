@@ -1136,13 +1136,14 @@ class TLNQKVFn(Function):
     packed_in = ops.tlayer_pack([in_proj_weight])[0] or None."""
 
     @staticmethod
-    def forward(ctx, x, rt, packed_in, n1w, n1b, siw, sib):
+    def forward(ctx, x, rt, packed_in, n1w, n1b, siw, sib, packed_in_t=None):
         x = x.contiguous()
         if packed_in is None:
             packed_in = ops.tlayer_pack([rt.lp(siw)])[0]
         t = ops.tlayer_lnqkv(x, {"ln1": (n1w.detach(), n1b.detach()), "sa_in": (packed_in, sib.detach())})
         ctx.save_for_backward(x, n1w, n1b, siw, sib, t["h1"], t["mean1"], t["rstd1"])
         ctx.cfg = (rt, rt.dropout_tag(x))
+        ctx.packed_in_t = packed_in_t   # Win^T in fragment order when the caller packed it (the one-launch backward)
         return t["qkv"], x.view_as(x)
 
     @staticmethod
@@ -1150,12 +1151,31 @@ class TLNQKVFn(Function):
         rt, tag_in = ctx.cfg
         x, n1w, n1b, siw, sib, h1, mean1, rstd1 = ctx.saved_tensors
         rows = x.numel() // x.shape[-1]
+        if rt.fused_ffn_bwd and rows % 64 == 0:
+            # in-projection data gradient + LayerNorm backward (+ skip gradient, + the masked copy the producing block's backward asks for)
+            dq2 = _2d(dqkv.contiguous())
+            if dq2.dtype != rt.dtype:
+                dq2 = ops.cast(dq2, rt.dtype)
+            wt = ctx.packed_in_t if ctx.packed_in_t is not None else ops.tlayer_pack([rt.lp(siw)], transpose=(0,))[0]
+            gg, gb = rt.gview(n1w), rt.gview(n1b)
+            direct = gg is not None and gb is not None
+            if not direct:
+                gg, gb = torch.zeros(n1w.numel(), dtype=torch.float32, device=x.device), torch.zeros(n1b.numel(), dtype=torch.float32, device=x.device)
+            p, call = tag_in if tag_in is not None else (0.0, 0)
+            dx, dxm = ops.tlayer_bwd_lnqkv(dq2, wt, x, mean1, rstd1, n1w.detach(), skip=dskip.contiguous() if dskip is not None else None, dgamma=gg, dbeta=gb,
+                                           p=p, seed=rt.seed if p > 0.0 else None, call=call)
+            if dxm is not None:
+                rt.offer_masked(dx, call, dxm)
+            N, K = siw.shape
+            dW = wgrad(dq2, h1.view(rows, -1), N, K, rows, rt.gview(siw), rt) if ctx.needs_input_grad[5] else None
+            db = bgrad(dq2, rows, N, rt.gview(sib), rt) if ctx.needs_input_grad[6] else None
+            return dx, None, None, None if direct else gg, None if direct else gb, dW, db, None
         c = _Ctx((h1.view(rows, -1), siw), (True, ctx.needs_input_grad[5], ctx.needs_input_grad[6]), rt=rt, rows=(0, siw.shape[0]), p=0.0, call=0, fan=None,
                  bias=sib, has_b=True, has_res=False, xshape=x.shape)
         dh, dW, db = LinearFn.backward(c, dqkv)[:3]
         skip = dskip.contiguous() if dskip is not None else None
         dx, dg, dbt = _ln_backward(_Ctx((x, n1w, mean1, rstd1), rt=rt, beta=n1b, tag=tag_in), dh, skip)
-        return dx, None, None, dg, dbt, dW, db
+        return dx, None, None, dg, dbt, dW, db, None
 
 
 class TFeedForwardFn(Function):

@@ -130,9 +130,10 @@ class TransformerEncoderLayer(nn.Module, _FFNMixin):
             if rt.fused_lnqkv and rt.fused_ffn_out and RF.tffn_supported(x, rt, a.d, self.linear1.weight.shape[0]):
                 # long sequences, three launches per layer: LayerNorm + q | k | v projection; attention; out-projection + residual + LayerNorm +
                 # feed-forward + residual
-                qkv, x = RF.TLNQKVFn.apply(x, rt, packed[0] if packed else None, self.norm1.weight, self.norm1.bias, a.in_proj_weight, a.in_proj_bias)
+                qkv, x = RF.TLNQKVFn.apply(x, rt, packed[0] if packed else None, self.norm1.weight, self.norm1.bias, a.in_proj_weight, a.in_proj_bias,
+                                           packed[7] if packed and len(packed) > 7 else None)
                 o = RF.AttnFn.apply(qkv, None, a.nhead, a.d // a.nhead, False, kpm, rt.drop_p(self.p), rt)
-                return RF.TFFNFn.apply(x, o, rt.drop_p(self.p), rt, packed[1:] if packed else None, a.out_proj.weight, a.out_proj.bias, self.norm2.weight,
+                return RF.TFFNFn.apply(x, o, rt.drop_p(self.p), rt, packed[1:7] if packed else None, a.out_proj.weight, a.out_proj.bias, self.norm2.weight,
                                        self.norm2.bias, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
             h, x = RF.layer_norm_skip(x, self.norm1.weight, self.norm1.bias, rt)
             if RF.tffn_supported(x, rt, a.d, self.linear1.weight.shape[0]):
@@ -246,15 +247,15 @@ def pack_ffn_layers(layers, x, rt: Runtime):
         return None
     if not all(l.norm_first and RF.tffn_supported(x, rt, l.self_attn.d, l.linear1.weight.shape[0]) for l in layers):
         return None
-    bwd = rt.fused_ffn_bwd and torch.is_grad_enabled() and len(layers) * 7 <= 48   # + W2^T, W1^T, Wo^T for the one-launch backward of the tail
+    bwd = rt.fused_ffn_bwd and torch.is_grad_enabled() and len(layers) * 8 <= 48   # + W2^T, W1^T, Wo^T, Win^T for the one-launch backward kernels
     mats, tr = [], []
     for l in layers:
         mats += [rt.lp(l.self_attn.in_proj_weight), rt.lp(l.self_attn.out_proj.weight), rt.lp(l.linear1.weight), rt.lp(l.linear2.weight)]
         if bwd:
-            tr += [len(mats), len(mats) + 1, len(mats) + 2]
-            mats += [rt.lp(l.linear2.weight), rt.lp(l.linear1.weight), rt.lp(l.self_attn.out_proj.weight)]
+            tr += [len(mats), len(mats) + 1, len(mats) + 2, len(mats) + 3]
+            mats += [rt.lp(l.linear2.weight), rt.lp(l.linear1.weight), rt.lp(l.self_attn.out_proj.weight), rt.lp(l.self_attn.in_proj_weight)]
     flat = ops.tlayer_pack(mats, transpose=tuple(tr))
-    per = 7 if bwd else 4
+    per = 8 if bwd else 4
     return [flat[per * i:per * (i + 1)] for i in range(len(layers))]
 
 

@@ -714,6 +714,26 @@ def tlayer_bwd(dy_m, hid, Wt, *, p=0.0, dy=None, x2=None, mean3=None, rstd3=None
     return t
 
 
+def tlayer_bwd_lnqkv(dqkv, win_t, x, mean, rstd, gamma, *, skip=None, dgamma=None, dbeta=None, p=0.0, seed=None, call=0, rows_per_strip=64):
+    """backward of tlayer_lnqkv's data path (ralf_tlayer_bwd stage 4): dh = dqkv Win, dx = LN-backward(dh; x, mean, rstd, gamma) + skip, and
+    (p > 0) dx masked by the dropout (p, call) of the block that produced x.  win_t = tlayer_pack([in_proj_weight], transpose=(0,)).
+    Returns (dx, dx_masked or None); dgamma / dbeta are accumulated into."""
+    from ._abi import RalfTLayerBwdDesc
+
+    shape = x.shape
+    rows, S = x.numel() // shape[-1], int(rows_per_strip)
+    assert shape[-1] == 256 and dqkv.dtype == torch.bfloat16 and dqkv.is_contiguous() and dqkv.numel() == rows * 768 and x.is_contiguous() and rows % S == 0
+    dx = torch.empty(shape, dtype=torch.bfloat16, device=x.device)
+    dxm = torch.empty(shape, dtype=torch.bfloat16, device=x.device) if p > 0.0 else None
+    d = RalfTLayerBwdDesc()
+    d.dy_m, d.w1t, d.x2, d.mean3, d.rstd3, d.ln3_g, d.dy = _p(dqkv), _p(win_t), _p(x), _p(mean), _p(rstd), _p(gamma), _p(skip)
+    d.g, d.g_m, d.dgamma, d.dbeta = _p(dx), _p(dxm if dxm is not None else dx), _p(dgamma), _p(dbeta)
+    d.seed, d.call_out = _p(seed) if p > 0.0 else None, int(call)
+    d.B, d.S, d.stage, d.p = rows // S, S, 4, float(p)
+    _call("ralf_tlayer_bwd", ctypes.byref(d))
+    return dx, dxm
+
+
 _DEC_MAXK = None
 
 

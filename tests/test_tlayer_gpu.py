@@ -425,3 +425,27 @@ def test_tail_backward_writes_the_bits_of_the_four_data_gradient_launches(rows, 
     same_bits(t["d_o"], d_o, "d_o")
     torch.testing.assert_close(dgam2, dgam, rtol=1e-4, atol=1e-4 * dgam.abs().max().item())
     torch.testing.assert_close(dbet2, dbet, rtol=1e-4, atol=1e-4 * dbet.abs().max().item())
+
+
+@pytest.mark.parametrize("rows,p,skip", [(16384, 0.1, True), (128, 0.0, False), (64, 0.1, True)])
+def test_layernorm_qkv_backward_writes_the_bits_of_the_two_launches(rows, p, skip):
+    """ralf_tlayer_bwd stage 4 against ralf_gemm (dh = dqkv Win) -> ralf_layernorm_bwd (skip gradient, masked second output)"""
+    from ralf_amd import ops
+
+    w = make_weights(False, seed=29)
+    dqkv = rnd(rows, 3 * D, seed=1).to(torch.bfloat16).cuda()
+    x = rnd(rows, D, seed=2).to(torch.bfloat16).cuda()
+    sk = rnd(rows, D, seed=3).to(torch.bfloat16).cuda() if skip else None
+    seed = torch.tensor([2024], dtype=torch.int64, device="cuda")
+    _, mean, rstd = ops.layernorm_fwd(x, *w["ln1"])
+    dh = ops.gemm(dqkv, w["sa_in"][0], rows, D, 3 * D, b_kcontig=False)
+    out = ops.layernorm_bwd(dh, x, w["ln1"][0], mean, rstd, need_wgrad=True, skip=sk, drop=(p, seed, 6) if p > 0 else None)
+    (wt,) = ops.tlayer_pack([w["sa_in"][0]], transpose=(0,))
+    dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dx, dxm = ops.tlayer_bwd_lnqkv(dqkv, wt, x, mean, rstd, w["ln1"][0], skip=sk, dgamma=dg, dbeta=db, p=p, seed=seed, call=6)
+    torch.cuda.synchronize()
+    same_bits(dx, out[0], "dx")
+    if p > 0:
+        same_bits(dxm, out[3], "dx masked")
+    torch.testing.assert_close(dg, out[1], rtol=1e-4, atol=1e-4 * out[1].abs().max().item())
+    torch.testing.assert_close(db, out[2], rtol=1e-4, atol=1e-4 * out[2].abs().max().item())
