@@ -383,7 +383,9 @@ int ralf_tlayer_fwd(const RalfTLayerDesc* d, void* stream);
  * w2t / w1t / wot: ralf_tlayer_pack of the TRANSPOSED weights (RalfPackJob.transpose).
  * stage 4 = the backward of part 4 (LayerNorm 1 + q | k | v projection): dy_m = dqkv [rows, 768], w1t = Win^T, dh = dqkv Win, then the same
  * LayerNorm backward on (x2, mean3, rstd3, ln3_g) := (x, mean1, rstd1, gamma 1) with dy (may be NULL) as the skip gradient: g = dx,
- * g_m = dx masked by (p, call_out) -- the dropout of the block that produced x. */
+ * g_m = dx masked by (p, call_out) -- the dropout of the block that produced x.
+ * stage 5 = the backward of part 3 with GELU (FeedForward): hid = the pre-activation z, dz = (dy_m W2) o gelu'(z), dh = dz W1, the LayerNorm
+ * backward (dy NULL: no skip gradient), no product behind it. */
 typedef struct RalfTLayerBwdDesc {
     const void* dy_m; const void* dy; const void* hid; const void* x2;
     const float* mean3; const float* rstd3; const float* ln3_g;

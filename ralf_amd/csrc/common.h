@@ -29,6 +29,13 @@ inline int check_launch(const char* what) {
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// exact (erf) GELU and its derivative, shared by the GEMM epilogues and tlayer.hip (the derivative's last step is an EXPLICIT fma: left to the
+// compiler, `a + b * c` is contracted in one kernel and not in another, and the two then differ in the last bit)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    return __fmaf_rn(x * 0.3989422804014327f, __expf(-0.5f * x * x), 0.5f * (1.f + erff(x * 0.70710678118654752f)));
+}
+
 // Element dropout mask (GEMM epilogues, ralf_dropout, ralf_scale_pe_dropout, the LayerNorm backward's masked gradient, tlayer.hip):
 //   keep(e) = 16-bit field (e & 3) of drop_hash4(seed, call, e >> 2) >= p * 2^16
 // ONE hash decides FOUR consecutive elements of the contiguous tensor (the kernels hold 4 or 8 consecutive elements per lane).  The stream

@@ -112,10 +112,7 @@ template <> struct TT<bf16> {
 
 // (the epilogue dropout mask: drop_hash4 / drop_apply, common.h -- shared with ralf_dropout, the LayerNorm backward and tlayer.hip)
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad(float x) {
-    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
-}
+// (gelu_f / gelu_grad: common.h)
 template <typename T> __device__ __forceinline__ float ldf(const void* p, int64_t i);
 template <> __device__ __forceinline__ float ldf<float>(const void* p, int64_t i) { return ((const float*)p)[i]; }
 template <> __device__ __forceinline__ float ldf<bf16>(const void* p, int64_t i) { return (float)((const bf16*)p)[i]; }

@@ -223,7 +223,6 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float (&v)[4]) {
     for (int q = 0; q < 4; ++q) t[q] = (bf16)v[q];
     return t;
 }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }   // (gemm_impl.h's)
 // GEMM-epilogue dropout on 4 consecutive elements of a contiguous [rows][N] output (ralf_dropout's mask: common.h)
 __device__ __forceinline__ void drop4(float (&v)[4], float p, uint64_t seed, uint64_t call, uint64_t e0) {
     if (p > 0.f) drop_apply<4>(v, seed, call, e0, drop_thr16(p), 1.f / (1.f - p));
@@ -591,16 +590,22 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
             f32x16 acc[2];
             zero_acc(acc);
             tile_mma(acc, bufA, LDA, w, w_ptr((const bf16*)d.w1t, TFF / 16, wave, c * 16, lane), lane);
+            const bool gelu = d.stage == 5;   // (uniform) hid = the GELU's pre-activation z
             tile_epilogue(acc, zero4, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
                 const bf16x4 hm = *reinterpret_cast<const bf16x4*>(Mc + m * LDA + n);
+                if (gelu) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = (float)hm[q] > 0.f ? v[q] * inv_keep : 0.f;   // (RALF_AUX_RELU_MASK with aux_scale = 1 / (1 - p))
+                    for (int q = 0; q < 4; ++q) v[q] *= gelu_grad((float)hm[q]);   // (RALF_AUX_GELU_GRAD)
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = (float)hm[q] > 0.f ? v[q] * inv_keep : 0.f;   // (RALF_AUX_RELU_MASK with aux_scale = 1 / (1 - p))
+                }
                 *reinterpret_cast<bf16x4*>(Dc + m * LDA + n) = to_bf16x4(v);
             });
         }
         lds_barrier();
         copy_out<TD>(Dc, LDA, (bf16*)d.dz + row0 * TFF + c * TD, TFF, S, tid);
-        tile_mma(yacc, Dc, LDA, w, c + 1 < TFF / TD ? w_ptr((const bf16*)d.w2t, 16, (c + 1) * NW + wave, 0, lane) : (d.stage > 1 ? w_ptr((const bf16*)d.wot, 16, wave, 0, lane) : nullptr), lane);
+        tile_mma(yacc, Dc, LDA, w, c + 1 < TFF / TD ? w_ptr((const bf16*)d.w2t, 16, (c + 1) * NW + wave, 0, lane) : (d.stage == 3 ? w_ptr((const bf16*)d.wot, 16, wave, 0, lane) : nullptr), lane);
     }
     }
     lds_barrier();   // every wave is done with Mc / Dc (the dqkv strip): the staging tile takes their place
@@ -690,7 +695,7 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
         for (int wv = 0; wv < NW; ++wv) t += red[(which * NW + wv) * TD + cc];
         atomicAdd((which ? d.dbeta : d.dgamma) + cc, t);
     }
-    if (d.stage == 4) return;
+    if (d.stage != 3) return;
     {   // d_o = g_m Wo: the out-projection's data gradient (W = Wo^T in fragment order, requested during the last dh tile)
         f32x16 acc[2];
         zero_acc(acc);
@@ -778,9 +783,9 @@ extern "C" int ralf_tlayer_bwd(const RalfTLayerBwdDesc* dp, void* stream) {
     RALF_REQUIRE(dp, "tlayer_bwd: null descriptor");
     const RalfTLayerBwdDesc& d = *dp;
     RALF_REQUIRE(d.B > 0 && d.S > 0 && d.S <= TS && d.p >= 0.f && d.p < 1.f, "tlayer_bwd: needs 1 <= S <= %d rows per strip, 0 <= p < 1", TS);
-    RALF_REQUIRE(d.stage == 1 || d.stage == 3 || d.stage == 4, "tlayer_bwd: stage 1 (dz, dh), 3 (the whole tail) or 4 (LayerNorm 1 + q | k | v projection)");
+    RALF_REQUIRE(d.stage == 1 || (d.stage >= 3 && d.stage <= 5), "tlayer_bwd: stage 1 (dz, dh), 3 (the whole tail), 4 (LayerNorm 1 + q | k | v projection) or 5 (GELU feed-forward)");
     RALF_REQUIRE(d.dy_m && d.w1t && d.g && (d.stage == 4 || (d.hid && d.w2t && d.dz)), "tlayer_bwd: null pointer");
-    RALF_REQUIRE(d.stage == 1 || (d.x2 && d.mean3 && d.rstd3 && d.ln3_g && d.g_m && (d.p == 0.f || d.seed) && (d.stage == 4 || (d.dy && d.wot && d.d_o))),
+    RALF_REQUIRE(d.stage == 1 || (d.x2 && d.mean3 && d.rstd3 && d.ln3_g && d.g_m && (d.p == 0.f || d.seed) && (d.stage != 3 || (d.dy && d.wot && d.d_o))),
                  "tlayer_bwd: stages 3 / 4 need the LayerNorm operands (3: and the skip gradient and the out-projection)");
     hipLaunchKernelGGL(tlayer_bwd_kernel, dim3(d.B), dim3(NT), 0, (hipStream_t)stream, d);
     return ralf::check_launch("tlayer_bwd");

@@ -1197,6 +1197,26 @@ class TFeedForwardFn(Function):
         rt, tag_in = ctx.cfg
         x, lnw, lnb, w1, b1, w2, b2, h3, mean3, rstd3, hid, z = ctx.saved_tensors
         rows = x.numel() // x.shape[-1]
+        if rt.fused_ffn_bwd and rows % 64 == 0:   # dz, dh and the LayerNorm backward in one launch (ops.tlayer_bwd, gelu)
+            dy2 = _2d(dy.contiguous())
+            if dy2.dtype != rt.dtype:
+                dy2 = ops.cast(dy2, rt.dtype)
+            pt = ops.tlayer_pack([rt.lp(w2), rt.lp(w1)], transpose=(0, 1))
+            gg, gb = rt.gview(lnw), rt.gview(lnb)
+            direct = gg is not None and gb is not None
+            if not direct:
+                gg, gb = torch.zeros(lnw.numel(), dtype=torch.float32, device=x.device), torch.zeros(lnb.numel(), dtype=torch.float32, device=x.device)
+            p, call = tag_in if tag_in is not None else (0.0, 0)
+            t = ops.tlayer_bwd(dy2, z.view(rows, -1), {"w2t": pt[0], "w1t": pt[1]}, p=p, dy=None, x2=x.view(rows, -1), mean3=mean3, rstd3=rstd3, gamma=lnw.detach(),
+                               dgamma=gg, dbeta=gb, seed=rt.seed if p > 0.0 else None, call_out=call, gelu=True)
+            if p > 0.0:
+                rt.offer_masked(t["g"], call, t["g_m"])
+            d_model, ff = x.shape[-1], hid.shape[-1]
+            dW2 = wgrad(dy2, hid.view(rows, -1), w2.shape[0], ff, rows, rt.gview(w2), rt)
+            db2 = bgrad(dy2, rows, w2.shape[0], rt.gview(b2), rt)
+            dW1 = wgrad(t["dz"], h3.view(rows, -1), ff, d_model, rows, rt.gview(w1), rt)
+            db1 = bgrad(t["dz"], rows, ff, rt.gview(b1), rt)
+            return t["g"].view(x.shape), None, None, None if direct else gg, None if direct else gb, dW1, db1, dW2, db2
         c = _Ctx((h3.view(rows, -1), w1, w2, hid.view(rows, -1), z.view(rows, -1)), (True,), b1=b1, b2=b2, rt=rt, act="gelu", p=0.0, has_res=False, xshape=x.shape, c2=0)
         dh, dW1, db1, dW2, db2 = FFNFn.backward(c, dy)[:5]
         dx, dg, db = _ln_backward(_Ctx((x, lnw, mean3, rstd3), rt=rt, beta=lnb, tag=tag_in), dh, None)

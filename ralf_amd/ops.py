@@ -688,9 +688,10 @@ def tlayer_lnqkv(x, W, rows_per_strip=64, eps=1e-5):
 
 
 def tlayer_bwd(dy_m, hid, Wt, *, p=0.0, dy=None, x2=None, mean3=None, rstd3=None, gamma=None, dgamma=None, dbeta=None, seed=None, call_out=0,
-               rows_per_strip=64):
+               rows_per_strip=64, gelu=False):
     """data gradients of the strip-wise layer tail (ralf_tlayer_bwd): dz = (dy_m W2) o [hid > 0] / (1 - p), dh = dz W1 -- and, with the
     LayerNorm operands (dy, x2, mean3, rstd3, gamma), g = LN-backward(dh) + dy, g_m = g masked by (p, call_out), d_o = g_m Wo.
+    gelu=True (FeedForward): hid = the pre-activation z, dz = (dy_m W2) o gelu'(z), no skip gradient needed, no d_o.
     Wt: "w2t", "w1t" (and "wot") = tlayer_pack(.., transpose) of linear2 / linear1 / out_proj weights.  Returns dz and dh (stage 1) or dz, g, g_m, d_o."""
     from ._abi import RalfTLayerBwdDesc
 
@@ -704,12 +705,14 @@ def tlayer_bwd(dy_m, hid, Wt, *, p=0.0, dy=None, x2=None, mean3=None, rstd3=None
     d.dy_m, d.hid, d.w2t, d.w1t = _p(dy_m), _p(hid), _p(Wt["w2t"]), _p(Wt["w1t"])
     if full:
         t["g_m"] = torch.empty(shape, dtype=torch.bfloat16, device=dev) if p > 0.0 else t["g"]
-        t["d_o"] = torch.empty(shape, dtype=torch.bfloat16, device=dev)
-        d.dy, d.x2, d.mean3, d.rstd3, d.ln3_g, d.wot = _p(dy), _p(x2), _p(mean3), _p(rstd3), _p(gamma), _p(Wt["wot"])
+        if not gelu:
+            t["d_o"] = torch.empty(shape, dtype=torch.bfloat16, device=dev)
+        d.dy, d.x2, d.mean3, d.rstd3, d.ln3_g, d.wot = _p(dy), _p(x2), _p(mean3), _p(rstd3), _p(gamma), _p(Wt.get("wot"))
         d.dgamma, d.dbeta, d.seed, d.call_out = _p(dgamma), _p(dbeta), _p(seed) if p > 0.0 else None, int(call_out)
     for k, v in t.items():
         setattr(d, k, _p(v))
-    d.B, d.S, d.stage, d.p = rows // S, S, 3 if full else 1, float(p)
+    assert not gelu or full
+    d.B, d.S, d.stage, d.p = rows // S, S, (5 if gelu else 3) if full else 1, float(p)
     _call("ralf_tlayer_bwd", ctypes.byref(d))
     return t
 
