@@ -383,7 +383,9 @@ int ralf_tlayer_fwd(const RalfTLayerDesc* d, void* stream);
  * w2t / w1t / wot: ralf_tlayer_pack of the TRANSPOSED weights (RalfPackJob.transpose).
  * stage 4 = the backward of part 4 (LayerNorm 1 + q | k | v projection): dy_m = dqkv [rows, 768], w1t = Win^T, dh = dqkv Win, then the same
  * LayerNorm backward on (x2, mean3, rstd3, ln3_g) := (x, mean1, rstd1, gamma 1) with dy (may be NULL) as the skip gradient: g = dx,
- * g_m = dx masked by (p, call_out) -- the dropout of the block that produced x.
+ * g_m = dx masked by (p, call_out) -- the dropout of the block that produced x.  nk = the width of dy_m in 256-column chunks: 3 for dqkv, 1 for
+ * the gradient of a 256 -> 256 projection (the decoder's cross-attention queries); with wot (and d_o) the out-projection's data gradient
+ * d_o = g_m Wo follows as in stage 3 (decoder: q-projection + LayerNorm 2 backward + the self-attention out-projection's data gradient).
  * stage 5 = the backward of part 3 with GELU (FeedForward): hid = the pre-activation z, dz = (dy_m W2) o gelu'(z), dh = dz W1, the LayerNorm
  * backward (dy NULL: no skip gradient), no product behind it. */
 typedef struct RalfTLayerBwdDesc {
@@ -393,13 +395,13 @@ typedef struct RalfTLayerBwdDesc {
     void* dz; void* g; void* g_m; void* d_o;
     float* dgamma; float* dbeta;
     const int64_t* seed; uint64_t call_out;
-    int B, S, stage, pad_;
+    int B, S, stage, nk;
     float p, pad2_;
 } RalfTLayerBwdDesc;
 int ralf_tlayer_bwd(const RalfTLayerBwdDesc* d, void* stream);
 /* weights -> the fragment order ralf_tlayer_fwd streams: for the 32-row tile t and the 16-wide k-slice i of src [N][K] (row stride ld
  * elements), the 64 lanes' MFMA operands (lane (r, half) = src[32 t + r][16 i + 8 half .. + 7]) become 1 KiB of consecutive memory at
- * dst + ((t * K/16 + i) * 64 + lane) * 8 elements.  N % 32 == 0, K % 16 == 0; up to 48 matrices per launch (jobs is a HOST array). */
+ * dst + ((t * K/16 + i) * 64 + lane) * 8 elements.  N % 32 == 0, K % 16 == 0; up to 96 matrices per launch (jobs is a HOST array). */
 typedef struct RalfPackJob { const void* src; void* dst; int64_t ld; int N, K; int transpose, pad_; } RalfPackJob;   /* transpose: the packed
     matrix is src^T, i.e. element [n][k] = src[k * ld + n] (src [K][N] row-major): the data-gradient products of ralf_tlayer_bwd */
 int ralf_tlayer_pack(const RalfPackJob* jobs, int njobs, void* stream);

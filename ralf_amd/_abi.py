@@ -44,7 +44,7 @@ class RalfTLayerDesc(ctypes.Structure):
 
 class RalfTLayerBwdDesc(ctypes.Structure):
     _fields_ = ([(n, vp) for n in ("dy_m", "dy", "hid", "x2", "mean3", "rstd3", "ln3_g", "w2t", "w1t", "wot", "dz", "g", "g_m", "d_o", "dgamma", "dbeta", "seed")]
-                + [("call_out", ctypes.c_uint64)] + [(n, i32) for n in ("B", "S", "stage", "pad_")] + [("p", f32), ("pad2_", f32)])
+                + [("call_out", ctypes.c_uint64)] + [(n, i32) for n in ("B", "S", "stage", "nk")] + [("p", f32), ("pad2_", f32)])
 
 
 class RalfPackJob(ctypes.Structure):

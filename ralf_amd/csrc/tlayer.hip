@@ -546,20 +546,21 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
     if (d.stage == 4) {
         // LayerNorm 1 + q | k | v projection backward: dh = dqkv Win (the strip of dqkv [64][768] is the LDS operand, Win^T [256][768] streams in
         // three 256-wide k chunks), then the LayerNorm backward below; no product behind it
-        load_w(w, w_ptr((const bf16*)d.w1t, 48, wave, 0, lane));
+        const int nk = d.nk;   // 256-wide chunks of the incoming gradient: 3 (dqkv, the packed in-projection) or 1 (a 256 -> 256 projection)
+        load_w(w, w_ptr((const bf16*)d.w1t, nk * 16, wave, 0, lane));
         {
-            constexpr int VPR = 3 * TD / 8;
-#pragma unroll
-            for (int i = 0; i < TS * VPR / NT; ++i) {
-                const int e = tid + NT * i, r = e / VPR, cc = e % VPR;
+            const int vpr = nk * (TD / 8);
+            for (int e = tid; e < TS * vpr; e += NT) {
+                const int r = e / vpr, cc = e - r * vpr;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (r < S) v = *reinterpret_cast<const uint4*>((const bf16*)d.dy_m + (row0 + r) * (3 * TD) + cc * 8);
+                if (r < S) v = *reinterpret_cast<const uint4*>((const bf16*)d.dy_m + (row0 + r) * (int64_t)(nk * TD) + cc * 8);
                 *reinterpret_cast<uint4*>(bufB + r * LDQ + cc * 8) = v;
             }
         }
         lds_barrier();
-#pragma unroll
-        for (int c = 0; c < 3; ++c) tile_mma(yacc, bufB + c * TD, LDQ, w, c + 1 < 3 ? w_ptr((const bf16*)d.w1t, 48, wave, (c + 1) * 16, lane) : nullptr, lane);
+#pragma unroll 1
+        for (int c = 0; c < nk; ++c)
+            tile_mma(yacc, bufB + c * TD, LDQ, w, c + 1 < nk ? w_ptr((const bf16*)d.w1t, nk * 16, wave, (c + 1) * 16, lane) : (d.wot ? w_ptr((const bf16*)d.wot, 16, wave, 0, lane) : nullptr), lane);
     } else {
     load_w(w, w_ptr((const bf16*)d.w2t, 16, wave, 0, lane));
     copy_in<2>(bufA, (const bf16*)d.dy_m + row0 * TD, S, tid);
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
         for (int wv = 0; wv < NW; ++wv) t += red[(which * NW + wv) * TD + cc];
         atomicAdd((which ? d.dbeta : d.dgamma) + cc, t);
     }
-    if (d.stage != 3) return;
+    if (!(d.stage == 3 || (d.stage == 4 && d.wot))) return;
     {   // d_o = g_m Wo: the out-projection's data gradient (W = Wo^T in fragment order, requested during the last dh tile)
         f32x16 acc[2];
         zero_acc(acc);
@@ -709,7 +710,7 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
 }
 
 // ---- weights -> fragment order (see WFrag).  One 16-byte chunk per thread: chunk c of job j = lane (c & 63) of (tile, k-slice) c >> 6 ----
-constexpr int PACK_MAX_JOBS = 48;
+constexpr int PACK_MAX_JOBS = 96;
 struct PackJobs { RalfPackJob j[PACK_MAX_JOBS]; };
 __global__ __launch_bounds__(256) void tlayer_pack_kernel(const PackJobs jobs) {
     const RalfPackJob jb = jobs.j[blockIdx.y];
@@ -784,7 +785,7 @@ extern "C" int ralf_tlayer_bwd(const RalfTLayerBwdDesc* dp, void* stream) {
     const RalfTLayerBwdDesc& d = *dp;
     RALF_REQUIRE(d.B > 0 && d.S > 0 && d.S <= TS && d.p >= 0.f && d.p < 1.f, "tlayer_bwd: needs 1 <= S <= %d rows per strip, 0 <= p < 1", TS);
     RALF_REQUIRE(d.stage == 1 || (d.stage >= 3 && d.stage <= 5), "tlayer_bwd: stage 1 (dz, dh), 3 (the whole tail), 4 (LayerNorm 1 + q | k | v projection) or 5 (GELU feed-forward)");
-    RALF_REQUIRE(d.dy_m && d.w1t && d.g && (d.stage == 4 || (d.hid && d.w2t && d.dz)), "tlayer_bwd: null pointer");
+    RALF_REQUIRE(d.dy_m && d.w1t && d.g && (d.stage == 4 ? (d.nk == 1 || d.nk == 3) && (!d.wot || d.d_o) : (d.hid && d.w2t && d.dz)), "tlayer_bwd: null pointer (stage 4: nk = 1 or 3)");
     RALF_REQUIRE(d.stage == 1 || (d.x2 && d.mean3 && d.rstd3 && d.ln3_g && d.g_m && (d.p == 0.f || d.seed) && (d.stage != 3 || (d.dy && d.wot && d.d_o))),
                  "tlayer_bwd: stages 3 / 4 need the LayerNorm operands (3: and the skip gradient and the out-projection)");
     hipLaunchKernelGGL(tlayer_bwd_kernel, dim3(d.B), dim3(NT), 0, (hipStream_t)stream, d);

@@ -969,6 +969,19 @@ def tlayer_matrices(params, rt):
     return mats + [rt.lp(params[-4]), rt.lp(params[-2])]
 
 
+def tlayer_matrices_t(params, rt):
+    """the matrices whose TRANSPOSES the strip-wise backward streams, in its order: linear2, linear1, the last out-projection (cross, or self
+    for an encoder layer), [cross q-projection rows, self out-projection,] self in-projection"""
+    cross = len(params) == 18
+    d = params[2].shape[1]
+    mats = [rt.lp(params[-2]), rt.lp(params[-4])]
+    if cross:
+        mats += [rt.lp(params[10]), rt.lp(params[8])[:d], rt.lp(params[4])]
+    else:
+        mats += [rt.lp(params[4])]
+    return mats + [rt.lp(params[2])]
+
+
 class TLayerFn(Function):
     """nn.TransformerDecoderLayer (kv = the memory's packed k | v projections [B, M, 2d]) or nn.TransformerEncoderLayer (kv None), norm_first:
     the forward is ONE launch (decoder: two, around the cross-attention's own) that also writes what LayerNormSkipFn / LinearFn / AttnFn / FFNFn would have saved; the backward calls their
@@ -989,8 +1002,10 @@ class TLayerFn(Function):
         calls = (a1, o1, a2, o2, nc(), nc())
         if packed is None:
             packed = ops.tlayer_pack(tlayer_matrices(params, rt))
+        nfw = 6 if cross else 4   # packed = the forward matrices [+ the transposes of tlayer_matrices_t for the strip-wise backward]
+        ctx.packed_t = tuple(packed[nfw:]) if len(packed) > nfw else None
         W = {"ln1": (n1w.detach(), n1b.detach()), "sa_in": (packed[0], sib.detach()), "sa_out": (packed[1], sob.detach()),
-             "ln3": (n3w.detach(), n3b.detach()), "ffn1": (packed[-2], b1.detach()), "ffn2": (packed[-1], b2.detach())}
+             "ln3": (n3w.detach(), n3b.detach()), "ffn1": (packed[nfw - 2], b1.detach()), "ffn2": (packed[nfw - 1], b2.detach())}
         if cross:
             n2w, n2b, ciw, cib, cow, cob = params[6:12]
             W.update({"ln2": (n2w.detach(), n2b.detach()), "q_proj": (packed[2], cib.detach()[:x.shape[2]]), "out2": (packed[3], cob.detach())})
@@ -1018,6 +1033,79 @@ class TLayerFn(Function):
         tag = (lambda call: (p, call)) if (p > 0.0 and rt.ln_dropout) else (lambda call: None)
         two = lambda a: a.view(rows, a.shape[-1])
         grads = [None] * npar
+        if rt.fused_ffn_bwd and rt.ln_dropout and rows % 64 == 0 and dy.is_cuda:
+            # the rows of all samples as 64-row strips (ops.tlayer_bwd / tlayer_bwd_lnqkv): [feed-forward + LayerNorm 3 + out-projection data
+            # gradients] - attention - [q projection + LayerNorm 2 + self out-projection] - attention - [in-projection + LayerNorm 1]: 7 launches
+            # (encoder layer: 4) instead of 13 (8); weight / bias gradients from the tensors they write, through the usual (grouped) launches
+            pt = ctx.packed_t or ops.tlayer_pack(tlayer_matrices_t(params, rt), transpose=tuple(range(6 if cross else 4)))
+
+            def ln_into(wi):
+                gg, gb = rt.gview(params[wi]), rt.gview(params[wi + 1])
+                if gg is not None and gb is not None:
+                    return gg, gb, True
+                return (torch.zeros(params[wi].numel(), dtype=torch.float32, device=x.device), torch.zeros(params[wi + 1].numel(), dtype=torch.float32, device=x.device), False)
+
+            def lin_grads(g2, xin, wi, prows):   # the weight / bias gradient of params[wi][prows] from (dy, x), as LinearFn.backward
+                W, bias = params[wi], params[wi + 1]
+                r0, r1 = prows
+                N, K, full = r1 - r0, W.shape[1], (r1 - r0) == W.shape[0]
+                if need[wi]:
+                    gv = rt.gview(W)
+                    dW = wgrad(g2, two(xin), N, K, rows, gv[r0:r1] if gv is not None else None, rt)
+                    if dW is not None and not full:
+                        gfull = torch.zeros(W.shape, dtype=torch.float32, device=dW.device)
+                        gfull[r0:r1] = dW
+                        dW = gfull
+                    grads[wi] = _acc(grads[wi], dW)
+                if need[wi + 1]:
+                    gv = rt.gview(bias)
+                    db = bgrad(g2, rows, N, gv[r0:r1] if gv is not None else None, rt)
+                    if db is not None and not full:
+                        gfull = torch.zeros(W.shape[0], dtype=torch.float32, device=db.device)
+                        gfull[r0:r1] = db
+                        db = gfull
+                    grads[wi + 1] = _acc(grads[wi + 1], db)
+
+            dy2 = _2d(dy.contiguous())
+            if dy2.dtype != rt.dtype:
+                dy2 = ops.cast(dy2, rt.dtype)
+            dy_m = rt.masked_grad(dy2, p, calls[5]) if p > 0.0 else dy2
+            r = t["x2"] if cross else t["x1"]
+            o_last, wo_i, call_last = (t["o2"], 10, calls[3]) if cross else (t["o1"], 4, calls[1])
+            gg, gb, direct = ln_into(npar - 6)
+            tb = ops.tlayer_bwd(dy_m, two(t["hid"]), {"w2t": pt[0], "w1t": pt[1], "wot": pt[2]}, p=p, dy=dy2, x2=two(r), mean3=t["mean3"], rstd3=t["rstd3"],
+                                gamma=n3w.detach(), dgamma=gg, dbeta=gb, seed=rt.seed if p > 0.0 else None, call_out=call_last)
+            if not direct:
+                grads[npar - 6], grads[npar - 5] = gg, gb
+            lin_grads(dy_m, t["hid"], npar - 2, (0, d))
+            lin_grads(tb["dz"], t["h3"], npar - 4, (0, w1.shape[0]))
+            lin_grads(tb["g_m"], o_last, wo_i, (0, d))
+            g, do = tb["g"], tb["d_o"]
+            dkv = None
+            if cross:
+                n2w, n2b, ciw, cib, cow, cob = params[6:12]
+                c = _Ctx((t["q"], kv, t["o2"], t["lse2"], None), cfg=(B, H, S, kv.shape[1], d // H, (0, 0, d), False, p, calls[2], rt))
+                dq, dkv = AttnFn.backward(c, do.view(x.shape))[:2]
+                gg, gb, direct = ln_into(6)
+                dx1, dx1m, do = ops.tlayer_bwd_lnqkv(two(dq), pt[3], two(t["x1"]), t["mean2"], t["rstd2"], n2w.detach(), skip=g, dgamma=gg, dbeta=gb, p=p,
+                                                    seed=rt.seed if p > 0.0 else None, call=calls[1], wo_t=pt[4])
+                if not direct:
+                    grads[6], grads[7] = gg, gb
+                lin_grads(two(dq), t["h2"], 8, (0, d))
+                lin_grads(dx1m if dx1m is not None else dx1, t["o1"], 4, (0, d))
+                g = dx1
+            c = _Ctx((t["qkv"], None, t["o1"], t["lse1"], kpm), cfg=(B, H, S, S, d // H, (0, d, 2 * d), causal, p, calls[0], rt))
+            dqkv = AttnFn.backward(c, do.view(x.shape))[0]
+            gg, gb, direct = ln_into(0)
+            pin, cin = tag_in if tag_in is not None else (0.0, 0)
+            dx, dxm = ops.tlayer_bwd_lnqkv(two(dqkv), pt[-1], two(x), t["mean1"], t["rstd1"], n1w.detach(), skip=g, dgamma=gg, dbeta=gb, p=pin,
+                                           seed=rt.seed if pin > 0.0 else None, call=cin)
+            if not direct:
+                grads[0], grads[1] = gg, gb
+            if dxm is not None:
+                rt.offer_masked(dx, cin, dxm.view(x.shape))
+            lin_grads(two(dqkv), t["h1"], 2, (0, 3 * d))
+            return (dx.view(x.shape), dkv, None, None, None, None, None, *grads)
 
         def lin_bwd(g, xin, W, b, wi, prows, has_res, call):
             c = _Ctx((two(xin), W), (True, need[wi], need[wi + 1]), rt=rt, rows=prows, p=(p if call else 0.0), call=call, fan=None, bias=b,

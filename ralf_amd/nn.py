@@ -243,11 +243,11 @@ class FuseAttention(nn.Module):
 def pack_ffn_layers(layers, x, rt: Runtime):
     """fragment-order in_proj / out_proj / linear1 / linear2 weights (ops.tlayer_pack) of all `layers` in ONE launch when they take the
     strip-wise path on x (functional.TLNQKVFn / TFFNFn) and not the per-sample one (long sequences); else None"""
-    if not layers or len(layers) * 4 > 48 or any(l.fusable(x, rt) for l in layers):
+    if not layers or len(layers) * 8 > ops.TLAYER_PACK_MAX or any(l.fusable(x, rt) for l in layers):
         return None
     if not all(l.norm_first and RF.tffn_supported(x, rt, l.self_attn.d, l.linear1.weight.shape[0]) for l in layers):
         return None
-    bwd = rt.fused_ffn_bwd and torch.is_grad_enabled() and len(layers) * 8 <= 48   # + W2^T, W1^T, Wo^T, Win^T for the one-launch backward kernels
+    bwd = rt.fused_ffn_bwd and torch.is_grad_enabled()   # + W2^T, W1^T, Wo^T, Win^T for the one-launch backward kernels
     mats, tr = [], []
     for l in layers:
         mats += [rt.lp(l.self_attn.in_proj_weight), rt.lp(l.self_attn.out_proj.weight), rt.lp(l.linear1.weight), rt.lp(l.linear2.weight)]
@@ -263,11 +263,19 @@ def _pack_layers(layers, x, rt: Runtime):
     """fragment-order weights (ops.tlayer_pack) of all `layers` in ONE launch when they take the fused path on x; else None"""
     if not layers or not all(l.fusable(x, rt) for l in layers):
         return None
-    mats = [RF.tlayer_matrices(l._params(), rt) for l in layers]
-    per = len(mats[0])
-    if per * len(layers) > 48:
+    bwd = rt.fused_ffn_bwd and torch.is_grad_enabled()   # + the transposes the strip-wise backward streams
+    mats, tr = [], []
+    for l in layers:
+        prm = l._params()
+        mats += RF.tlayer_matrices(prm, rt)
+        if bwd:
+            mt = RF.tlayer_matrices_t(prm, rt)
+            tr += list(range(len(mats), len(mats) + len(mt)))
+            mats += mt
+    per = len(mats) // len(layers)
+    if len(mats) > ops.TLAYER_PACK_MAX:
         return None
-    flat = ops.tlayer_pack([m for ms in mats for m in ms])
+    flat = ops.tlayer_pack(mats, transpose=tuple(tr))
     return [flat[i * per:(i + 1) * per] for i in range(len(layers))]
 
 
@@ -322,7 +330,7 @@ def decoder_init_cache(dec: "BaseDecoder", memory: torch.Tensor, rt: Runtime, ma
         selfkv.append(torch.zeros(B, max_len, 2 * d, dtype=rt.dtype, device=memory.device))
     packed = None
     layers = list(dec.transformer.layers)
-    if (rt.fused_decode and rt.fused_decode_tail and rt.dtype == torch.bfloat16 and memory.is_cuda and d == 256 and len(layers) * 3 <= 48
+    if (rt.fused_decode and rt.fused_decode_tail and rt.dtype == torch.bfloat16 and memory.is_cuda and d == 256 and len(layers) * 3 <= ops.TLAYER_PACK_MAX
             and all(l.linear1.weight.shape[0] == 1024 for l in layers)):
         # the step's tail per layer (out-projection + residual, LayerNorm, feed-forward, residual) runs as one launch on weights in fragment order
         flat = ops.tlayer_pack([m for l in layers for m in (rt.lp(l.multihead_attn.out_proj.weight), rt.lp(l.linear1.weight), rt.lp(l.linear2.weight))])

@@ -529,6 +529,7 @@ def attention_fwd(q, k, v, B, H, Sq, Sk, dh, q_off=0, k_off=0, v_off=0, causal=F
 
 
 TLAYER_MAX_ROWS = 64
+TLAYER_PACK_MAX = 96   # matrices per ralf_tlayer_pack launch
 
 
 def tlayer_pack(mats, transpose=()):
@@ -537,7 +538,7 @@ def tlayer_pack(mats, transpose=()):
     their transpose (the data-gradient products read W^T)."""
     from ._abi import RalfPackJob
 
-    assert 0 < len(mats) <= 48
+    assert 0 < len(mats) <= TLAYER_PACK_MAX
     sizes = [m.shape[0] * m.shape[1] for m in mats]
     buf = torch.empty(sum(sizes), dtype=torch.bfloat16, device=mats[0].device)
     outs, off = [], 0
@@ -717,24 +718,30 @@ def tlayer_bwd(dy_m, hid, Wt, *, p=0.0, dy=None, x2=None, mean3=None, rstd3=None
     return t
 
 
-def tlayer_bwd_lnqkv(dqkv, win_t, x, mean, rstd, gamma, *, skip=None, dgamma=None, dbeta=None, p=0.0, seed=None, call=0, rows_per_strip=64):
+def tlayer_bwd_lnqkv(dqkv, win_t, x, mean, rstd, gamma, *, skip=None, dgamma=None, dbeta=None, p=0.0, seed=None, call=0, rows_per_strip=64, wo_t=None):
     """backward of tlayer_lnqkv's data path (ralf_tlayer_bwd stage 4): dh = dqkv Win, dx = LN-backward(dh; x, mean, rstd, gamma) + skip, and
     (p > 0) dx masked by the dropout (p, call) of the block that produced x.  win_t = tlayer_pack([in_proj_weight], transpose=(0,)).
-    Returns (dx, dx_masked or None); dgamma / dbeta are accumulated into."""
+    dqkv may also be the [rows, 256] gradient of a 256 -> 256 projection (win_t = that weight's transpose).  wo_t (the packed transpose of the
+    out-projection that produced x's last addend): also d_o = dx_masked Wo.  Returns (dx, dx_masked or None[, d_o]); dgamma / dbeta are accumulated into."""
     from ._abi import RalfTLayerBwdDesc
 
     shape = x.shape
     rows, S = x.numel() // shape[-1], int(rows_per_strip)
-    assert shape[-1] == 256 and dqkv.dtype == torch.bfloat16 and dqkv.is_contiguous() and dqkv.numel() == rows * 768 and x.is_contiguous() and rows % S == 0
+    nk = dqkv.numel() // (rows * 256)
+    assert shape[-1] == 256 and dqkv.dtype == torch.bfloat16 and dqkv.is_contiguous() and dqkv.numel() == rows * 256 * nk and nk in (1, 3) and x.is_contiguous() and rows % S == 0
     dx = torch.empty(shape, dtype=torch.bfloat16, device=x.device)
     dxm = torch.empty(shape, dtype=torch.bfloat16, device=x.device) if p > 0.0 else None
     d = RalfTLayerBwdDesc()
     d.dy_m, d.w1t, d.x2, d.mean3, d.rstd3, d.ln3_g, d.dy = _p(dqkv), _p(win_t), _p(x), _p(mean), _p(rstd), _p(gamma), _p(skip)
     d.g, d.g_m, d.dgamma, d.dbeta = _p(dx), _p(dxm if dxm is not None else dx), _p(dgamma), _p(dbeta)
     d.seed, d.call_out = _p(seed) if p > 0.0 else None, int(call)
-    d.B, d.S, d.stage, d.p = rows // S, S, 4, float(p)
+    d.B, d.S, d.stage, d.p, d.nk = rows // S, S, 4, float(p), nk
+    d_o = None
+    if wo_t is not None:
+        d_o = torch.empty(shape, dtype=torch.bfloat16, device=x.device)
+        d.wot, d.d_o = _p(wo_t), _p(d_o)
     _call("ralf_tlayer_bwd", ctypes.byref(d))
-    return dx, dxm
+    return (dx, dxm) if wo_t is None else (dx, dxm, d_o)
 
 
 _DEC_MAXK = None

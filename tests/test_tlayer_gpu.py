@@ -120,12 +120,13 @@ def _layer(cross, seed):
     return layer.cuda()
 
 
-@pytest.mark.parametrize("cross,training", [(True, True), (True, False), (False, True)])
-def test_fused_layer_module_matches_unfused_module_forward_and_backward(cross, training):
-    """same output and same input / memory gradients bit for bit (with the dropout masks of the training mode); same parameter gradients"""
+@pytest.mark.parametrize("cross,training,B", [(True, True, 4), (True, False, 4), (False, True, 4), (True, True, 32), (False, True, 32), (True, False, 32)])
+def test_fused_layer_module_matches_unfused_module_forward_and_backward(cross, training, B):
+    """same output and same input / memory gradients bit for bit (with the dropout masks of the training mode); same parameter gradients.
+    B = 32 (B S = 1600 rows = 25 strips of 64): the backward also takes the strip-wise launches (ops.tlayer_bwd / tlayer_bwd_lnqkv)"""
     from ralf_amd.functional import Runtime
 
-    B, S, M = 4, 50, 300
+    S, M = 50, 300
     layer = _layer(cross, 5)
     x0 = rnd(B, S, D, seed=1).to(torch.bfloat16).cuda()
     mem0 = rnd(B, M, D, seed=2).to(torch.bfloat16).cuda()
@@ -138,6 +139,7 @@ def test_fused_layer_module_matches_unfused_module_forward_and_backward(cross, t
         rt.to(torch.device("cuda"))
         rt.training = training
         rt.fused_layers = fused
+        rt.fused_ffn_bwd = fused
         rt.begin_step()
         x, mem = x0.clone().requires_grad_(True), mem0.clone().requires_grad_(True)
         layer.zero_grad(set_to_none=True)
