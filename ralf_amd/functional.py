@@ -1033,7 +1033,7 @@ class TLayerFn(Function):
         tag = (lambda call: (p, call)) if (p > 0.0 and rt.ln_dropout) else (lambda call: None)
         two = lambda a: a.view(rows, a.shape[-1])
         grads = [None] * npar
-        if rt.fused_ffn_bwd and rt.ln_dropout and rows % 64 == 0 and dy.is_cuda:
+        if rt.fused_ffn_bwd and rt.ln_dropout and rows % 64 == 0 and rows >= 1024 and dy.is_cuda:   # (a handful of strips would leave the chip empty: 28 us per launch at 4 workgroups)
             # the rows of all samples as 64-row strips (ops.tlayer_bwd / tlayer_bwd_lnqkv): [feed-forward + LayerNorm 3 + out-projection data
             # gradients] - attention - [q projection + LayerNorm 2 + self out-projection] - attention - [in-projection + LayerNorm 1]: 7 launches
             # (encoder layer: 4) instead of 13 (8); weight / bias gradients from the tensors they write, through the usual (grouped) launches

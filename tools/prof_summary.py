@@ -32,9 +32,9 @@ def main(db, out, header, steps, gap_ms=None):
         f.write(f"{'kernel':100s} {'calls':>7s} {'total_ms':>9s} {'avg_us':>9s} {'min_us':>8s} {'max_us':>9s} {'pct':>6s}\n")
         for r in rows:
             f.write(f"{short(r[0]):100s} {r[1]:7d} {r[2] / 1e6:9.2f} {r[3] / 1e3:9.1f} {r[4] / 1e3:8.1f} {r[5] / 1e3:9.1f} {r[2] / tot * 100:6.2f}\n")
-        f.write("\n# GEMM dispatches by launch geometry (threads_x, splits, batch)\n")
-        gw = (where + " and " if where else " where ") + "name like '%gemm%kernel%'"
-        for r in c.execute(f"select name, grid_x, grid_y, grid_z, count(*), sum(end-start), avg(end-start) from kernels{gw} group by name, grid_x, grid_y, grid_z order by 6 desc limit 40"):
+        f.write("\n# GEMM and transformer-layer dispatches by launch geometry (threads_x, splits, batch)\n")
+        gw = (where + " and " if where else " where ") + "(name like '%gemm%kernel%' or name like '%tlayer%' or name like '%attn_bwd_fused%')"
+        for r in c.execute(f"select name, grid_x, grid_y, grid_z, count(*), sum(end-start), avg(end-start) from kernels{gw} group by name, grid_x, grid_y, grid_z order by 6 desc limit 60"):
             f.write(f"{short(r[0])[:70]:70s} grid=({r[1]},{r[2]},{r[3]}) calls {r[4]:5d} total_ms {r[5] / 1e6:8.2f} avg_us {r[6] / 1e3:8.1f}\n")
 
 
