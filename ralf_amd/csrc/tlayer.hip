@@ -223,9 +223,10 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float (&v)[4]) {
     for (int q = 0; q < 4; ++q) t[q] = (bf16)v[q];
     return t;
 }
-// GEMM-epilogue dropout on 4 consecutive elements of a contiguous [rows][N] output (ralf_dropout's mask: common.h)
-__device__ __forceinline__ void drop4(float (&v)[4], float p, uint64_t seed, uint64_t call, uint64_t e0) {
-    if (p > 0.f) drop_apply<4>(v, seed, call, e0, drop_thr16(p), 1.f / (1.f - p));
+// GEMM-epilogue dropout on 4 consecutive elements of a contiguous [rows][N] output (ralf_dropout's mask: common.h); the stream keys of the
+// launch's call ids are computed once per kernel
+__device__ __forceinline__ void drop4(float (&v)[4], float p, const DropKeys k, uint64_t e0) {
+    if (p > 0.f) drop_apply_k<4>(v, k, e0, drop_thr16(p), 1.f / (1.f - p));
 }
 
 // ---- attention of ONE head by ONE wave over keys / values staged in LDS (attn_fwd_mfma's arithmetic) ----
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
     const int b = blockIdx.x, S = d.S;
     const int64_t row0 = (int64_t)b * S;
     const uint64_t seed = (d.p_attn > 0.f || d.p_res > 0.f) ? (uint64_t)d.seed[0] : 0;
+    const DropKeys k_out1 = drop_keys(seed, d.call_out1), k_out2 = drop_keys(seed, d.call_out2), k_ffn1 = drop_keys(seed, d.call_ffn1), k_ffn2 = drop_keys(seed, d.call_ffn2);
     WFrag w;
     bf16x4 rr[32 * RB / NW];   // this wave's rows of the residual stream (x -> x1 -> x2), in registers from one row pass to the next
     TL_PROBE(0);
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
             load_rows<RB>(rr, xg, S, wave, lane);   // the residual rows of the pass behind the next barrier
             tile_mma(acc, bufA, LDA, w, PART == 1 ? w_ptr((const bf16*)d.w_q, 16, wave, 0, lane) : w_ptr((const bf16*)d.w1, 16, wave, 0, lane), lane);
             tile_epilogue(acc, bv, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
-                drop4(v, d.p_res, seed, d.call_out1, (uint64_t)(row0 + m) * TD + n);
+                drop4(v, d.p_res, k_out1, (uint64_t)(row0 + m) * TD + n);
                 *reinterpret_cast<f32x4*>(stage + m * STG_LD + n) = (f32x4){v[0], v[1], v[2], v[3]};
             });
         }
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
             load_bias(bv, d.b_o2, wave * 32, lane);
             tile_mma(acc, bufA, LDA, w, w_ptr((const bf16*)d.w1, 16, wave, 0, lane), lane);
             tile_epilogue(acc, bv, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
-                drop4(v, d.p_res, seed, d.call_out2, (uint64_t)(row0 + m) * TD + n);
+                drop4(v, d.p_res, k_out2, (uint64_t)(row0 + m) * TD + n);
                 *reinterpret_cast<f32x4*>(stage + m * STG_LD + n) = (f32x4){v[0], v[1], v[2], v[3]};
             });
         }
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
                 }
-                drop4(v, d.p_res, seed, d.call_ffn1, (uint64_t)(row0 + m) * TFF + col);
+                drop4(v, d.p_res, k_ffn1, (uint64_t)(row0 + m) * TFF + col);
                 *reinterpret_cast<bf16x4*>(Hc + m * LDA + n) = to_bf16x4(v);
             });
         }
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
     }
     TL_PROBE(10);
     tile_epilogue(yacc, bv2, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
-        drop4(v, d.p_res, seed, d.call_ffn2, (uint64_t)(row0 + m) * TD + n);
+        drop4(v, d.p_res, k_ffn2, (uint64_t)(row0 + m) * TD + n);
         *reinterpret_cast<f32x4*>(stage + m * STG_LD + n) = (f32x4){v[0], v[1], v[2], v[3]};
     });
     lds_barrier();
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
 #pragma unroll
         for (int k = 0; k < NR; ++k) { s1[k] += __shfl_xor(s1[k], o); s2[k] += __shfl_xor(s2[k], o); }
     lds_barrier();   // every wave has read its staged rows: bufB is free for the column sums, bufA for g_m
-    const uint64_t seed = d.p > 0.f ? (uint64_t)d.seed[0] : 0;
+    const DropKeys k_out = drop_keys(d.p > 0.f ? (uint64_t)d.seed[0] : 0, d.call_out);
     const uint32_t thr = drop_thr16(d.p);
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
         }
         gmk = go;
         if (d.p > 0.f) {
-            const uint64_t hh = drop_hash4(seed, d.call_out, (uint64_t)((row0 + row) * TD + lane * 4) >> 2);
+            const uint64_t hh = drop_hash4k(k_out, (uint64_t)((row0 + row) * TD + lane * 4) >> 2);
 #pragma unroll
             for (int i = 0; i < 4; ++i) gmk[i] = (bf16)(drop_keep(hh, i, thr) ? (float)go[i] * inv_keep : 0.f);
         }
