@@ -66,3 +66,13 @@ def _dist_cleanup():
             dist.destroy_process_group()
     except Exception:
         pass
+
+
+def free_port() -> int:
+    """a TCP port nobody listens on right now (rendezvous of the multi-process tests): asked from the kernel, not derived from the pid --
+    a fixed scheme met a lingering listener once in a few hundred runs (EADDRINUSE)"""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

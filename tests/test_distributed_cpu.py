@@ -6,6 +6,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from conftest import free_port
+
 
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -26,7 +28,7 @@ def _worker(rank, world, port, q):
 def test_flat_gradient_average_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -90,7 +92,7 @@ def _worker_ranges(rank, world, port, q):
 def test_ranged_exchange_equals_whole_buffer_exchange_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
+    port = free_port()
     procs = [ctx.Process(target=_worker_ranges, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -146,7 +148,7 @@ def test_grad_exchange_fp32_and_bf16_wire_world2():
     all-gather; the (opt-in) bf16 wire halves the bytes"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 35500 + os.getpid() % 2000
+    port = free_port()
     procs = [ctx.Process(target=_worker_exchange, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -205,7 +207,7 @@ def test_sharded_knn_world2():
     assert [query_block(11, r, 4) for r in range(4)] == [slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 11)]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + os.getpid() % 2000
+    port = free_port()
     procs = [ctx.Process(target=_worker_knn, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

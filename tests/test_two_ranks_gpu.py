@@ -5,6 +5,7 @@ import os
 import sys
 
 import pytest
+from conftest import free_port
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -82,7 +83,7 @@ def test_two_ranks_on_one_gpu_keep_identical_weights(tmp_path, wire, mode):
     pairs as all_reduce on two ranks (same weights and clip norm); the bf16 wire moves the clip norm by rounding only"""
     import torch.multiprocessing as mp
 
-    port = 29600 + os.getpid() % 300 + {"allreduce": 0, "rs_ag": 1}[mode] + (2 if wire == "bf16" else 0)
+    port = free_port()
     mp.spawn(_rank, args=(2, port, str(tmp_path), wire, mode), nprocs=2, join=True)
     r = [torch.load(os.path.join(str(tmp_path), f"r{i}.pt")) for i in range(2)]
     if "skip" in r[0]:
@@ -114,7 +115,7 @@ def test_bench_two_ranks_on_one_gpu_prints_one_json_line(tmp_path):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RALF_BENCH_ONE_DEVICE="1", OMP_NUM_THREADS="4")
-    port = 29900 + os.getpid() % 90
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -164,7 +165,7 @@ def test_sharded_knn_two_ranks_on_the_hip_scan(tmp_path):
     included"""
     import torch.multiprocessing as mp
 
-    port = 29800 + os.getpid() % 90
+    port = free_port()
     mp.spawn(_rank_knn, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         ok = torch.load(os.path.join(str(tmp_path), f"k{r}.pt"))
