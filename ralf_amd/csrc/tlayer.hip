@@ -528,7 +528,9 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
 // ---- backward of the strip-wise tail (see RalfTLayerBwdDesc): the forward feed-forward loop with the roles turned -- the strip of dy_m is the
 // LDS operand, W2^T streams where W1 did (dz chunk = 256 hidden columns, masked by the forward hidden), W1^T where W2 did (dh accumulates over
 // the four chunks) -- then the LayerNorm backward as a row pass and the out-projection's data gradient ----
+template <int RB>   // 32-row blocks per strip (1: strips of <= 32 rows, for row counts that would leave most CUs empty at 64)
 __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc d) {
+    constexpr int RS = 32 * RB;   // rows of the strip's MFMA tiles
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     bf16* bufA = reinterpret_cast<bf16*>(lds);          // dy_m strip, later g_m
     bf16* bufB = bufA + BUFA_ELEMS;
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
     const int64_t row0 = (int64_t)b * S;
     const float inv_keep = 1.f / (1.f - d.p);
     WFrag w;
-    f32x16 yacc[2];
+    f32x16 yacc[RB];
     zero_acc(yacc);
     Bias4 zero4;
 #pragma unroll
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
         load_w(w, w_ptr((const bf16*)d.w1t, nk * 16, wave, 0, lane));
         {
             const int vpr = nk * (TD / 8);
-            for (int e = tid; e < TS * vpr; e += NT) {
+            for (int e = tid; e < RS * vpr; e += NT) {
                 const int r = e / vpr, cc = e - r * vpr;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
                 if (r < S) v = *reinterpret_cast<const uint4*>((const bf16*)d.dy_m + (row0 + r) * (int64_t)(nk * TD) + cc * 8);
@@ -565,12 +567,12 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
             tile_mma(yacc, bufB + c * TD, LDQ, w, c + 1 < nk ? w_ptr((const bf16*)d.w1t, nk * 16, wave, (c + 1) * 16, lane) : (d.wot ? w_ptr((const bf16*)d.wot, 16, wave, 0, lane) : nullptr), lane);
     } else {
     load_w(w, w_ptr((const bf16*)d.w2t, 16, wave, 0, lane));
-    copy_in<2>(bufA, (const bf16*)d.dy_m + row0 * TD, S, tid);
+    copy_in<RB>(bufA, (const bf16*)d.dy_m + row0 * TD, S, tid);
     // the forward hidden chunk of the next iteration travels in registers (4 x 16 bytes per thread) while the current one is used
-    uint4 hreg[4];
+    uint4 hreg[2 * RB];
     auto hid_load = [&](int c) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2 * RB; ++i) {
             const int e = tid + NT * i, r = e >> 5, cc = e & 31;
             hreg[i] = make_uint4(0u, 0u, 0u, 0u);
             if (r < S) hreg[i] = *reinterpret_cast<const uint4*>((const bf16*)d.hid + (row0 + r) * TFF + c * TD + cc * 8);
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
     };
     auto hid_store = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2 * RB; ++i) {
             const int e = tid + NT * i, r = e >> 5, cc = e & 31;
             *reinterpret_cast<uint4*>(Mc + r * LDA + cc * 8) = hreg[i];
         }
@@ -590,7 +592,7 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
         if (c + 1 < TFF / TD) hid_load(c + 1);
         lds_barrier();   // dy_m strip (first iteration) and the mask chunk are in place; the previous chunk's readers of Dc are done
         {   // dz columns c*256 + wave*32 ..: tile c*8 + wave of W2^T [1024][256]; next in the weight stream: W1^T[wave*32 ..][c*256 ..]
-            f32x16 acc[2];
+            f32x16 acc[RB];
             zero_acc(acc);
             tile_mma(acc, bufA, LDA, w, w_ptr((const bf16*)d.w1t, TFF / 16, wave, c * 16, lane), lane);
             const bool gelu = d.stage == 5;   // (uniform) hid = the GELU's pre-activation z
@@ -617,12 +619,12 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
     });
     lds_barrier();
     if (d.stage <= 1) {   // dh rows, as ralf_gemm would have written them
-        bf16x4 none[TS / NW];
-        row_pass<true, true, false, 2, false>(stage, none, (bf16*)d.g + row0 * TD, S, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, wave, lane);
+        bf16x4 none[RS / NW];
+        row_pass<true, true, false, RB, false>(stage, none, (bf16*)d.g + row0 * TD, S, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, wave, lane);
         return;
     }
     // ---- LayerNorm backward (norm.hip ln_bwd_kernel's arithmetic: wave per row, lane l owns columns 4l .. 4l+3), all 8 rows of a wave together ----
-    constexpr int NR = TS / NW;
+    constexpr int NR = RS / NW;
     float gm[4], ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) gm[i] = d.ln3_g[lane * 4 + i];
@@ -700,7 +702,7 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
     }
     if (!(d.stage == 3 || (d.stage == 4 && d.wot))) return;
     {   // d_o = g_m Wo: the out-projection's data gradient (W = Wo^T in fragment order, requested during the last dh tile)
-        f32x16 acc[2];
+        f32x16 acc[RB];
         zero_acc(acc);
         tile_mma(acc, bufA, LDA, w, nullptr, lane);
         lds_barrier();   // the column sums have been read: the strip's d_o rows go through the same LDS
@@ -790,6 +792,7 @@ extern "C" int ralf_tlayer_bwd(const RalfTLayerBwdDesc* dp, void* stream) {
     RALF_REQUIRE(d.dy_m && d.w1t && d.g && (d.stage == 4 ? (d.nk == 1 || d.nk == 3) && (!d.wot || d.d_o) : (d.hid && d.w2t && d.dz)), "tlayer_bwd: null pointer (stage 4: nk = 1 or 3)");
     RALF_REQUIRE(d.stage == 1 || (d.x2 && d.mean3 && d.rstd3 && d.ln3_g && d.g_m && (d.p == 0.f || d.seed) && (d.stage != 3 || (d.dy && d.wot && d.d_o))),
                  "tlayer_bwd: stages 3 / 4 need the LayerNorm operands (3: and the skip gradient and the out-projection)");
-    hipLaunchKernelGGL(tlayer_bwd_kernel, dim3(d.B), dim3(NT), 0, (hipStream_t)stream, d);
+    if (d.S <= 32) hipLaunchKernelGGL(tlayer_bwd_kernel<1>, dim3(d.B), dim3(NT), 0, (hipStream_t)stream, d);
+    else hipLaunchKernelGGL(tlayer_bwd_kernel<2>, dim3(d.B), dim3(NT), 0, (hipStream_t)stream, d);
     return ralf::check_launch("tlayer_bwd");
 }

@@ -4,6 +4,7 @@ torch's current stream.  Autograd wiring lives in ralf_amd/functional.py."""
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -532,6 +533,14 @@ TLAYER_MAX_ROWS = 64
 TLAYER_PACK_MAX = 96   # matrices per ralf_tlayer_pack launch
 
 
+def tlayer_strip(rows: int) -> int:
+    """rows per strip of the strip-wise layer kernels: 64, or 32 where 64 would leave most of the 256 CUs without a workgroup"""
+    return 32 if (rows < 8192 and rows % 32 == 0 and not _STRIP64) else 64
+
+
+_STRIP64 = os.environ.get("RALF_TLAYER_STRIP64", "0") == "1"   # A/B runs: 64-row strips (per-sample part 2) everywhere
+
+
 def tlayer_pack(mats, transpose=()):
     """row-major bf16 matrices [N % 32 == 0, K % 16 == 0] -> the fragment order ralf_tlayer_fwd streams its weights in (ralf_tlayer_pack):
     ONE launch and one buffer for all of them; returns the flat packed views in order.  transpose: indices of the matrices to pack as
@@ -604,6 +613,8 @@ def tlayer_fwd(x, W, *, causal, kpm=None, kpm_stride=0, kv=None, p_attn=0.0, p_r
     _call("ralf_tlayer_fwd", ctypes.byref(d))
     t["o2"], t["lse2"] = attention_fwd(t["q"], kv, kv, B, H, S, kv.shape[1], dm // H, 0, 0, dm, p_drop=p_attn, seed=seed, call_id=int(calls[2]))
     d.o2, d.part = _p(t["o2"]), 2
+    if (B * S) % 32 == 0 and B * S < 8192 and not _STRIP64:   # part 2 is row-wise: 32-row strips of all samples' rows put twice as many (lighter) workgroups on the chip
+        d.B, d.S = B * S // 32, 32
     _call("ralf_tlayer_fwd", ctypes.byref(d))
     return t
 
@@ -689,7 +700,7 @@ def tlayer_lnqkv(x, W, rows_per_strip=64, eps=1e-5):
 
 
 def tlayer_bwd(dy_m, hid, Wt, *, p=0.0, dy=None, x2=None, mean3=None, rstd3=None, gamma=None, dgamma=None, dbeta=None, seed=None, call_out=0,
-               rows_per_strip=64, gelu=False):
+               rows_per_strip=None, gelu=False):
     """data gradients of the strip-wise layer tail (ralf_tlayer_bwd): dz = (dy_m W2) o [hid > 0] / (1 - p), dh = dz W1 -- and, with the
     LayerNorm operands (dy, x2, mean3, rstd3, gamma), g = LN-backward(dh) + dy, g_m = g masked by (p, call_out), d_o = g_m Wo.
     gelu=True (FeedForward): hid = the pre-activation z, dz = (dy_m W2) o gelu'(z), no skip gradient needed, no d_o.
@@ -697,7 +708,8 @@ def tlayer_bwd(dy_m, hid, Wt, *, p=0.0, dy=None, x2=None, mean3=None, rstd3=None
     from ._abi import RalfTLayerBwdDesc
 
     shape = dy_m.shape
-    rows, S = dy_m.numel() // shape[-1], int(rows_per_strip)
+    rows = dy_m.numel() // shape[-1]
+    S = int(rows_per_strip) if rows_per_strip else tlayer_strip(rows)
     assert shape[-1] == 256 and dy_m.dtype == torch.bfloat16 and dy_m.is_contiguous() and hid.is_contiguous() and rows % S == 0
     full = x2 is not None
     dev = dy_m.device
@@ -718,7 +730,7 @@ def tlayer_bwd(dy_m, hid, Wt, *, p=0.0, dy=None, x2=None, mean3=None, rstd3=None
     return t
 
 
-def tlayer_bwd_lnqkv(dqkv, win_t, x, mean, rstd, gamma, *, skip=None, dgamma=None, dbeta=None, p=0.0, seed=None, call=0, rows_per_strip=64, wo_t=None):
+def tlayer_bwd_lnqkv(dqkv, win_t, x, mean, rstd, gamma, *, skip=None, dgamma=None, dbeta=None, p=0.0, seed=None, call=0, rows_per_strip=None, wo_t=None):
     """backward of tlayer_lnqkv's data path (ralf_tlayer_bwd stage 4): dh = dqkv Win, dx = LN-backward(dh; x, mean, rstd, gamma) + skip, and
     (p > 0) dx masked by the dropout (p, call) of the block that produced x.  win_t = tlayer_pack([in_proj_weight], transpose=(0,)).
     dqkv may also be the [rows, 256] gradient of a 256 -> 256 projection (win_t = that weight's transpose).  wo_t (the packed transpose of the
@@ -726,7 +738,8 @@ def tlayer_bwd_lnqkv(dqkv, win_t, x, mean, rstd, gamma, *, skip=None, dgamma=Non
     from ._abi import RalfTLayerBwdDesc
 
     shape = x.shape
-    rows, S = x.numel() // shape[-1], int(rows_per_strip)
+    rows = x.numel() // shape[-1]
+    S = int(rows_per_strip) if rows_per_strip else tlayer_strip(rows)
     nk = dqkv.numel() // (rows * 256)
     assert shape[-1] == 256 and dqkv.dtype == torch.bfloat16 and dqkv.is_contiguous() and dqkv.numel() == rows * 256 * nk and nk in (1, 3) and x.is_contiguous() and rows % S == 0
     dx = torch.empty(shape, dtype=torch.bfloat16, device=x.device)

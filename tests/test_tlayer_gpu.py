@@ -397,7 +397,7 @@ def test_tail_backward_stage_1_writes_the_bits_of_the_two_data_gradient_products
     same_bits(t["g"], dh, "dh")
 
 
-@pytest.mark.parametrize("rows,p", [(16384, 0.1), (192, 0.0), (64, 0.1)])
+@pytest.mark.parametrize("rows,p", [(16384, 0.1), (192, 0.0), (64, 0.1), (3200, 0.1)])
 def test_tail_backward_writes_the_bits_of_the_four_data_gradient_launches(rows, p):
     """ralf_tlayer_bwd stage 3 against ralf_gemm (dz) -> ralf_gemm (dh) -> ralf_layernorm_bwd (with the skip gradient and the masked second
     output) -> ralf_gemm (d o): dz, g, g_m, d_o bit for bit; dgamma / dbeta (fp32 atomics in both) to rounding"""
@@ -429,7 +429,7 @@ def test_tail_backward_writes_the_bits_of_the_four_data_gradient_launches(rows, 
     torch.testing.assert_close(dbet2, dbet, rtol=1e-4, atol=1e-4 * dbet.abs().max().item())
 
 
-@pytest.mark.parametrize("rows,p,skip", [(16384, 0.1, True), (128, 0.0, False), (64, 0.1, True)])
+@pytest.mark.parametrize("rows,p,skip", [(16384, 0.1, True), (128, 0.0, False), (64, 0.1, True), (3200, 0.1, True)])
 def test_layernorm_qkv_backward_writes_the_bits_of_the_two_launches(rows, p, skip):
     """ralf_tlayer_bwd stage 4 against ralf_gemm (dh = dqkv Win) -> ralf_layernorm_bwd (skip gradient, masked second output)"""
     from ralf_amd import ops
