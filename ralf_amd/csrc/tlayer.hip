@@ -339,7 +339,7 @@ __device__ __forceinline__ void attn_finish(const AttnState& st, int Sq, int h, 
 // B workgroups of this kernel: it stays ralf_attention_fwd between parts 1 and 2.
 template <int PART, int RB = 2>   // RB: 32-row blocks per strip (1 = strips of <= 32 rows: the decode step's batch rows, part 2 only)
 __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) {
-    static_assert(RB == 2 || PART == 2, "32-row strips: part 2 only");
+    static_assert(RB == 2 || PART == 2 || PART == 3, "32-row strips: parts 2 and 3 only");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];   // ONE LDS object
     bf16* bufA = reinterpret_cast<bf16*>(lds);              // the A operand of the running product: h1 | o1 | h2 | o2 | h3
     bf16* bufB = bufA + BUFA_ELEMS;                         // q|k|v strip, fp32 epilogue staging, q, one hidden chunk
@@ -777,6 +777,7 @@ extern "C" int ralf_tlayer_fwd(const RalfTLayerDesc* dp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (d.part == 0) hipLaunchKernelGGL((tlayer_fwd_kernel<0>), dim3(d.B), dim3(NT), 0, st, d);
     else if (d.part == 1) hipLaunchKernelGGL((tlayer_fwd_kernel<1>), dim3(d.B), dim3(NT), 0, st, d);
+    else if (d.part == 3 && d.S <= 32) hipLaunchKernelGGL((tlayer_fwd_kernel<3, 1>), dim3(d.B), dim3(NT), 0, st, d);
     else if (d.part == 3) hipLaunchKernelGGL((tlayer_fwd_kernel<3>), dim3(d.B), dim3(NT), 0, st, d);
     else if (d.part == 4) hipLaunchKernelGGL((tlayer_fwd_kernel<4>), dim3(d.B), dim3(NT), 0, st, d);
     else if (d.S <= 32) hipLaunchKernelGGL((tlayer_fwd_kernel<2, 1>), dim3(d.B), dim3(NT), 0, st, d);   // strips of one 32-row block

@@ -639,7 +639,7 @@ def tlayer_tail(o2, x1, W, rows_per_strip=None, eps=1e-5):
     return out
 
 
-def tlayer_ffn(x, W, *, o=None, p=0.0, seed=None, calls=(0, 0, 0), rows_per_strip=64, eps=1e-5, act="relu", residual=True):
+def tlayer_ffn(x, W, *, o=None, p=0.0, seed=None, calls=(0, 0, 0), rows_per_strip=None, eps=1e-5, act="relu", residual=True):
     """the tail of a pre-norm layer on ANY row count, in strips of rows_per_strip rows (rows % rows_per_strip == 0), ralf_tlayer_fwd part 3 / 2:
         o is None:  out = x + drop(W2 drop(relu(W1 LN(x) + b1)) + b2)                                   (the feed-forward block)
         o given:    r = x + drop(o Wo^T + bo);  out = r + drop(W2 drop(relu(W1 LN(r) + b1)) + b2)       (+ the attention's out-projection in front)
@@ -650,7 +650,8 @@ def tlayer_ffn(x, W, *, o=None, p=0.0, seed=None, calls=(0, 0, 0), rows_per_stri
     from ._abi import RalfTLayerDesc
 
     shape = x.shape
-    rows, dm, ff, S = x.numel() // shape[-1], shape[-1], 1024, int(rows_per_strip)
+    rows, dm, ff = x.numel() // shape[-1], shape[-1], 1024
+    S = int(rows_per_strip) if rows_per_strip else tlayer_strip(rows)
     assert dm == 256 and x.dtype == torch.bfloat16 and x.is_contiguous() and rows % S == 0 and 1 <= S <= TLAYER_MAX_ROWS
     dev = x.device
     t = {"h3": torch.empty(shape, dtype=torch.bfloat16, device=dev), "mean3": torch.empty(rows, dtype=torch.float32, device=dev),
