@@ -64,6 +64,12 @@ __device__ __forceinline__ uint64_t drop_hash4k(const DropKeys k, uint64_t group
     const uint32_t b = attn_rng2x16(k.k1 ^ hi, glo);
     return (uint64_t)a | ((uint64_t)b << 32);
 }
+__device__ __forceinline__ uint64_t drop_hash4k32(const DropKeys k, uint32_t group) {   // the same value for group < 2^32 with 32-bit index arithmetic
+    const uint32_t hi = __umul24(group >> 24, 0x85EBCBu);
+    const uint32_t a = attn_rng2x16(k.k0 ^ hi, group & 0xffffffu);
+    const uint32_t b = attn_rng2x16(k.k1 ^ hi, group & 0xffffffu);
+    return (uint64_t)a | ((uint64_t)b << 32);
+}
 __device__ __forceinline__ uint64_t drop_hash4(uint64_t seed, uint64_t call, uint64_t group) { return drop_hash4k(drop_keys(seed, call), group); }
 __device__ __forceinline__ uint32_t drop_thr16(float p) { return (uint32_t)(p * 65536.f); }
 __device__ __forceinline__ bool drop_keep(uint64_t h, int field, uint32_t thr16) { return ((uint32_t)(h >> (16 * field)) & 0xffffu) >= thr16; }

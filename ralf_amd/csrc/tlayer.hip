@@ -225,8 +225,14 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float (&v)[4]) {
 }
 // GEMM-epilogue dropout on 4 consecutive elements of a contiguous [rows][N] output (ralf_dropout's mask: common.h); the stream keys of the
 // launch's call ids are computed once per kernel
-__device__ __forceinline__ void drop4(float (&v)[4], float p, const DropKeys k, uint64_t e0) {
-    if (p > 0.f) drop_apply_k<4>(v, k, e0, drop_thr16(p), 1.f / (1.f - p));
+__device__ __forceinline__ void drop4(float (&v)[4], float p, const DropKeys k, uint32_t group) {   // group = (element index) / 4, below 2^32 (checked at launch)
+    if (p > 0.f) {
+        const uint32_t thr = drop_thr16(p);
+        const float inv = 1.f / (1.f - p);
+        const uint64_t h = drop_hash4k32(k, group);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = drop_keep(h, q, thr) ? v[q] * inv : 0.f;
+    }
 }
 
 // ---- attention of ONE head by ONE wave over keys / values staged in LDS (attn_fwd_mfma's arithmetic) ----
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
             load_rows<RB>(rr, xg, S, wave, lane);   // the residual rows of the pass behind the next barrier
             tile_mma(acc, bufA, LDA, w, PART == 1 ? w_ptr((const bf16*)d.w_q, 16, wave, 0, lane) : w_ptr((const bf16*)d.w1, 16, wave, 0, lane), lane);
             tile_epilogue(acc, bv, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
-                drop4(v, d.p_res, k_out1, (uint64_t)(row0 + m) * TD + n);
+                drop4(v, d.p_res, k_out1, ((uint32_t)(row0 + m) * TD + n) >> 2);
                 *reinterpret_cast<f32x4*>(stage + m * STG_LD + n) = (f32x4){v[0], v[1], v[2], v[3]};
             });
         }
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
             load_bias(bv, d.b_o2, wave * 32, lane);
             tile_mma(acc, bufA, LDA, w, w_ptr((const bf16*)d.w1, 16, wave, 0, lane), lane);
             tile_epilogue(acc, bv, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
-                drop4(v, d.p_res, k_out2, (uint64_t)(row0 + m) * TD + n);
+                drop4(v, d.p_res, k_out2, ((uint32_t)(row0 + m) * TD + n) >> 2);
                 *reinterpret_cast<f32x4*>(stage + m * STG_LD + n) = (f32x4){v[0], v[1], v[2], v[3]};
             });
         }
@@ -502,7 +508,7 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
                 }
-                drop4(v, d.p_res, k_ffn1, (uint64_t)(row0 + m) * TFF + col);
+                drop4(v, d.p_res, k_ffn1, (uint32_t)(row0 + m) * (TFF / 4) + (col >> 2));
                 *reinterpret_cast<bf16x4*>(Hc + m * LDA + n) = to_bf16x4(v);
             });
         }
@@ -516,7 +522,7 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
     }
     TL_PROBE(10);
     tile_epilogue(yacc, bv2, wave * 32, lane, [&](int m, int n, float (&v)[4]) {
-        drop4(v, d.p_res, k_ffn2, (uint64_t)(row0 + m) * TD + n);
+        drop4(v, d.p_res, k_ffn2, ((uint32_t)(row0 + m) * TD + n) >> 2);
         *reinterpret_cast<f32x4*>(stage + m * STG_LD + n) = (f32x4){v[0], v[1], v[2], v[3]};
     });
     lds_barrier();
@@ -758,6 +764,7 @@ extern "C" int ralf_tlayer_fwd(const RalfTLayerDesc* dp, void* stream) {
     const RalfTLayerDesc& d = *dp;
     RALF_REQUIRE(d.part >= 0 && d.part <= 4, "tlayer_fwd: part 0 (encoder layer), 1 or 2 (decoder layer before / after its cross-attention), 3 (feed-forward block), 4 (LayerNorm + qkv)");
     RALF_REQUIRE(d.B > 0 && d.S > 0 && d.S <= TS, "tlayer_fwd: needs 1 <= S <= %d rows per sample (got %d)", TS, d.S);
+    RALF_REQUIRE((int64_t)d.B * d.S < (1 << 22), "tlayer_fwd: at most 2^22 rows per launch (32-bit dropout element indices)");
     RALF_REQUIRE(d.p_attn >= 0.f && d.p_attn < 1.f && d.p_res >= 0.f && d.p_res < 1.f && ((d.p_attn == 0.f && d.p_res == 0.f) || d.seed), "tlayer_fwd: dropout needs a seed");
     if (d.part == 4) RALF_REQUIRE(d.x && d.ln1_g && d.ln1_b && d.w_in && d.b_in && d.h1 && d.mean1 && d.rstd1 && d.qkv, "tlayer_fwd: part 4 needs x, LayerNorm 1, in_proj and h1 / mean1 / rstd1 / qkv");
     if (d.part == 0 || d.part == 1) {
