@@ -953,9 +953,29 @@ class _Ctx:
         self.__dict__.update(kw)
 
 
-def tlayer_supported(x, rt, d, nhead, dim_ff) -> bool:
-    return (rt.fused_layers and rt.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 3 and x.shape[1] <= ops.TLAYER_MAX_ROWS
-            and d == 256 and nhead == 8 and dim_ff == 1024 and x.shape[2] == d)
+def tlayer_supported(x, rt, d, nhead, dim_ff, allow_long=False) -> bool:
+    """allow_long (decoder layers): sequences of more than 64 tokens take the strip-wise kernels for their row-wise parts when the rows of all
+    samples split into 64-row strips (TLayerFn forward: _tlayer_fwd_long)"""
+    if not (rt.fused_layers and rt.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 3 and d == 256 and nhead == 8 and dim_ff == 1024 and x.shape[2] == d):
+        return False
+    return x.shape[1] <= ops.TLAYER_MAX_ROWS or (allow_long and rt.fused_ffn and (x.shape[0] * x.shape[1]) % 64 == 0)
+
+
+def _tlayer_fwd_long(x, W, rowmajor, kv, kpm, causal, p, seed, calls):
+    """a decoder layer on MORE than 64 tokens per sample: the same tensors as ops.tlayer_fwd writes, from [LayerNorm 1 + q|k|v] on strips,
+    attention, the self out-projection / LayerNorm 2 / q projection per operation, cross-attention, [out-projection 2 + LayerNorm 3 + FFN] on
+    strips.  rowmajor = (self out_proj weight, cross q-projection weight) as bf16 row-major matrices (these two stay ralf_gemm)."""
+    B, S, d = x.shape
+    rows, H = B * S, 8
+    sd = seed if p > 0.0 else None
+    t = ops.tlayer_lnqkv(x, {"ln1": W["ln1"], "sa_in": W["sa_in"]})
+    t["o1"], t["lse1"] = ops.attention_fwd(t["qkv"], t["qkv"], t["qkv"], B, H, S, S, d // H, 0, d, 2 * d, causal=causal, kpm=kpm, p_drop=p, seed=seed, call_id=calls[0])
+    t["x1"] = ops.gemm(t["o1"].view(rows, d), rowmajor[0], rows, d, d, bias=W["sa_out"][1], res=x.view(rows, d), drop_p=p, seed=sd, call_id=calls[1]).view(B, S, d)
+    t["h2"], t["mean2"], t["rstd2"] = ops.layernorm_fwd(t["x1"], *W["ln2"])
+    t["q"] = ops.gemm(t["h2"].view(rows, d), rowmajor[1], rows, d, d, bias=W["q_proj"][1]).view(B, S, d)
+    t["o2"], t["lse2"] = ops.attention_fwd(t["q"], kv, kv, B, H, S, kv.shape[1], d // H, 0, 0, d, p_drop=p, seed=seed, call_id=calls[2])
+    t.update(ops.tlayer_ffn(t["x1"], {"out": W["out2"], "ln3": W["ln3"], "ffn1": W["ffn1"], "ffn2": W["ffn2"]}, o=t["o2"], p=p, seed=seed, calls=(calls[3], calls[4], calls[5])))
+    return t
 
 
 def tlayer_matrices(params, rt):
@@ -1010,7 +1030,11 @@ class TLayerFn(Function):
             n2w, n2b, ciw, cib, cow, cob = params[6:12]
             W.update({"ln2": (n2w.detach(), n2b.detach()), "q_proj": (packed[2], cib.detach()[:x.shape[2]]), "out2": (packed[3], cob.detach())})
             kv = kv.contiguous()
-        t = ops.tlayer_fwd(x, W, causal=causal, kpm=kpm, kv=kv, p_attn=p, p_res=p, seed=rt.seed if p > 0.0 else None, calls=calls)
+        if x.shape[1] <= ops.TLAYER_MAX_ROWS:
+            t = ops.tlayer_fwd(x, W, causal=causal, kpm=kpm, kv=kv, p_attn=p, p_res=p, seed=rt.seed if p > 0.0 else None, calls=calls)
+        else:
+            assert cross, "long encoder layers take TLNQKVFn / TFFNFn"
+            t = _tlayer_fwd_long(x, W, (rt.lp(sow), rt.lp(params[8])[:x.shape[2]]), kv, kpm, causal, p, rt.seed if p > 0.0 else None, calls)
         ctx.keys = tuple(k for k in t if k != "out")
         ctx.save_for_backward(x, kv, kpm, *params, *[t[k] for k in ctx.keys])
         ctx.cfg = (cross, causal, p, calls, rt, rt.dropout_tag(x))

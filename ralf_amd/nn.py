@@ -168,7 +168,7 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
                 self.norm3.weight, self.norm3.bias, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
 
     def fusable(self, x, rt: Runtime) -> bool:
-        return RF.tlayer_supported(x, rt, self.self_attn.d, self.self_attn.nhead, self.linear1.weight.shape[0])
+        return RF.tlayer_supported(x, rt, self.self_attn.d, self.self_attn.nhead, self.linear1.weight.shape[0], allow_long=True)
 
     def forward(self, x, mem, rt: Runtime, tgt_kpm=None, stacked=None, packed=None):
         """stacked = (kv_all, layer index, plan): this layer's cross-attention K/V were projected with all other layers' (BaseDecoder);

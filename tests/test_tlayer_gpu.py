@@ -451,3 +451,40 @@ def test_layernorm_qkv_backward_writes_the_bits_of_the_two_launches(rows, p, ski
         same_bits(dxm, out[3], "dx masked")
     torch.testing.assert_close(dg, out[1], rtol=1e-4, atol=1e-4 * out[1].abs().max().item())
     torch.testing.assert_close(db, out[2], rtol=1e-4, atol=1e-4 * out[2].abs().max().item())
+
+
+@pytest.mark.parametrize("B", [4, 8])
+def test_long_sequence_decoder_layer_takes_the_strip_kernels(B):
+    """S = 160 tokens per sample (N = 32 elements): [LayerNorm 1 + q|k|v] and [out-projection 2 + LayerNorm 3 + FFN] on strips of all samples' rows,
+    the rest per operation (functional._tlayer_fwd_long); B = 8 (1 280 rows): the backward on strips too.  Same bits as the per-operation layer."""
+    from ralf_amd.functional import Runtime
+
+    S, M = 160, 300
+    layer = _layer(True, 15)
+    x0 = rnd(B, S, D, seed=1).to(torch.bfloat16).cuda()
+    mem0 = rnd(B, M, D, seed=2).to(torch.bfloat16).cuda()
+    kpm = torch.zeros(B, S, dtype=torch.uint8, device="cuda")
+    kpm[1, 120:] = 1
+    go = rnd(B, S, D, seed=3).to(torch.bfloat16).cuda()
+    res = {}
+    for fused in (True, False):
+        rt = Runtime(torch.bfloat16, seed=11)
+        rt.to(torch.device("cuda"))
+        rt.training = True
+        rt.fused_layers = fused
+        rt.fused_ffn_bwd = fused
+        rt.begin_step()
+        x, mem = x0.clone().requires_grad_(True), mem0.clone().requires_grad_(True)
+        layer.zero_grad(set_to_none=True)
+        assert layer.fusable(x, rt) == fused
+        y = layer(x, mem, rt, kpm)
+        y.backward(go)
+        rt.flush_wgrads()
+        rt.join_side()
+        torch.cuda.synchronize()
+        res[fused] = {"y": y.detach().clone(), "dx": x.grad.clone(), "dmem": mem.grad.clone(), **{n: prm.grad.clone() for n, prm in layer.named_parameters()}}
+    for k in res[True]:
+        if k in ("y", "dx", "dmem"):
+            same_bits(res[True][k], res[False][k], k)
+        else:
+            torch.testing.assert_close(res[True][k], res[False][k], rtol=1e-5, atol=1e-5 * res[False][k].abs().max().item(), msg=lambda m: f"{k}: {m}")
