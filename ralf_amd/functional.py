@@ -958,7 +958,10 @@ def tlayer_supported(x, rt, d, nhead, dim_ff, allow_long=False) -> bool:
     samples split into 64-row strips (TLayerFn forward: _tlayer_fwd_long)"""
     if not (rt.fused_layers and rt.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 3 and d == 256 and nhead == 8 and dim_ff == 1024 and x.shape[2] == d):
         return False
-    return x.shape[1] <= ops.TLAYER_MAX_ROWS or (allow_long and rt.fused_ffn and (x.shape[0] * x.shape[1]) % 64 == 0)
+    return x.shape[1] <= ops.TLAYER_MAX_ROWS or (allow_long and rt.fused_ffn and _FUSED_LONG and (x.shape[0] * x.shape[1]) % 64 == 0)
+
+
+_FUSED_LONG = os.environ.get("RALF_FUSED_LONG", "1") != "0"   # A/B runs: long decoder layers per operation
 
 
 def _tlayer_fwd_long(x, W, rowmajor, kv, kpm, causal, p, seed, calls):
