@@ -70,7 +70,8 @@ def build_model(device, N=10, dtype="bfloat16", task="uncond"):
     tok = LayoutSequenceTokenizer(labels, N)
     torch.manual_seed(0)
     model = RALF(features={"label": LabelFeature(labels)}, tokenizer=tok, dataset_name="pku", max_seq_length=N, db_dataset=None, top_k=16,
-                 retrieval_backbone="dreamsim", random_retrieval=False, saliency_k="None", auxilary_task=task, compute_dtype=dtype)
+                 retrieval_backbone="dreamsim", random_retrieval=False, saliency_k="None", auxilary_task=task, compute_dtype=dtype,
+                 pretrained=False)   # no weight files on the bench box: random-init weights of the architecture (`data: synthetic`)
     return model.to(device).train()
 
 
@@ -219,6 +220,51 @@ def bench_step_variant(device, N, B, dtype, steps, H=256, W=256):
     return t
 
 
+def bench_reference_loop(device, N, B, dtype, steps):
+    """the reference's UNCHANGED loop body (image2layout/train/train.py:432-454) around this library's model, a fresh host batch per
+    step: preprocess -> .to(device) -> zero_grad -> train_loss -> backward -> clip_grad_norm_ -> optimizer.step() -> loss.cpu().item().
+    (a) with torch.optim.AdamW(model.optim_groups(...)) as configs/optimizer/adamw.yaml builds it: the eager autograd path of the HIP ops;
+    (b) with the one extra override optimizer._target_=ralf_amd.engine.GraphedAdamW: the same lines reach the graph-replayed step."""
+    from ralf_amd.engine import GraphedAdamW
+    from ralf_amd.synthetic import make_batch
+
+    batches = [make_batch(B, N, seed=21 + i) for i in range(3)]   # what a DataLoader's collate hands over (host tensors)
+    lr, max_norm = 1e-4, 0.1
+
+    def loop_body(model, optimizer, batch):   # train/train.py:432-454, line for line (no discriminator)
+        inputs, targets = model.preprocess(batch)
+        inputs = {k: v.to(device) if torch.is_tensor(v) else v for (k, v) in inputs.items()}
+        targets = {k: v.to(device) if torch.is_tensor(v) else v for (k, v) in targets.items()}
+        model.zero_grad()
+        outputs_gen, losses = model.train_loss(inputs, targets)
+        loss = sum(losses.values())
+        loss.backward()
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+        optimizer.step()
+        return loss.cpu().item()
+
+    out = {}
+    for name, make_opt in (("eager_torch_adamw", lambda groups: torch.optim.AdamW(params=groups, weight_decay=0.01)),
+                           ("graphed_adamw", lambda groups: GraphedAdamW(params=groups, weight_decay=0.01, max_norm=max_norm))):
+        model = build_model(device, N, dtype)
+        opt = make_opt(model.optim_groups(base_lr=lr, weight_decay=0.01, custom_lr={"encoder.extractor.body": lr * 0.1}))
+        for i in range(3):
+            last = loop_body(model, opt, batches[i % 3])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            last = loop_body(model, opt, batches[i % 3])
+        torch.cuda.synchronize()
+        out[name + "_ms"] = (time.perf_counter() - t0) / steps * 1e3
+        out[name + "_loss"] = last
+        del opt, model
+    out["note"] = ("train/train.py:432-454 verbatim, wall clock per iteration incl. model.preprocess on the host, the pageable H2D of the "
+                   "4-channel image batch and the loss.cpu().item() sync; eager_torch_adamw = torch.optim.AdamW + clip_grad_norm_ on the eager autograd "
+                   "path of the HIP ops; graphed_adamw = the same lines with optimizer._target_=ralf_amd.engine.GraphedAdamW (hipGraph replay inside train_loss)")
+    return out
+
+
 def bench_relation(device, N=10, B=256, dtype="bfloat16"):
     """BASELINE configs[4], relationship task at batch 256: sample(cond_type="relation") with back-tracking
     (retrieval_augmented_autoreg.py:336-507: a per-sample loop by construction -- a violated constraint rewinds THAT sample's
@@ -240,7 +286,7 @@ def bench_relation(device, N=10, B=256, dtype="bfloat16"):
     torch.manual_seed(0)
     model = RALF(features={"label": LabelFeature(labels)}, tokenizer=tok, dataset_name="pku", max_seq_length=N, db_dataset=None, top_k=16,
                  retrieval_backbone="dreamsim", random_retrieval=False, saliency_k="None", auxilary_task="relation", compute_dtype=dtype,
-                 relation_table=table).to(device).eval()
+                 relation_table=table, pretrained=False).to(device).eval()
     cond, _ = get_condition(batch, "relation", tok)
     cond.retrieved = {k: v for k, v in cond.retrieved.items() if k != "image"}
     cfg = {"name": "deterministic", "temperature": 1.0}
@@ -574,6 +620,7 @@ def main():
             out["real_canvas_350x240"] = {"workload": f"350x240 canvases (hw = 22x15 = 330, M = 680), N={N}, batch {B}", "ms_per_step": trc * 1e3, "tokens_per_s": tokens / trc,
                                           "TFLOP": frc / 1e12, "achieved": frc / trc / 1e12, "frac": frc / trc / 1e12 / PEAK_BF16_TFLOPS, "unit": "TFLOP/s"}
             out["relation"] = bench_relation(device, N)
+            out["reference_loop_ms"] = bench_reference_loop(device, N, B, a.dtype, min(a.steps, 10))
         if world == 1 and not a.skip_cpu:
             out["cpu_baseline"] = cpu_baseline_train(N, B=a.cpu_batch)
             out["cpu_baseline_knn"] = cpu_baseline_knn()

@@ -348,9 +348,14 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_mfma(const RalfAttnDesc d)
                 }
                 float pj[8];
                 if (!d.causal && s0 + 32 <= d.Sq) {
-                    const float kz = kmasked[hk] ? 0.f : 1.f;
+                    // (a select, not a product with 0 / 1: a padded key whose score exceeds the row's log-sum-exp by > 128 in the log2 domain
+                    //  gives exp2 = +inf, and 0 * inf = NaN would poison dQ / dK / dV of the whole (batch, head))
+                    const bool km = kmasked[hk];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) pj[j] = kz * __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -L4[j >> 2][j & 3]));
+                    for (int j = 0; j < 8; ++j) {
+                        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -L4[j >> 2][j & 3]));
+                        pj[j] = km ? 0.f : e;
+                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {

@@ -752,6 +752,7 @@ extern "C" int ralf_tlayer_pack(const RalfPackJob* jobs, int njobs, void* stream
         const RalfPackJob& j = jobs[i];
         RALF_REQUIRE(j.src && j.dst && j.N > 0 && j.K > 0 && j.N % 32 == 0 && j.K % 16 == 0 && j.ld >= (j.transpose ? j.N : j.K) && (j.transpose || j.ld % 8 == 0),
                      "tlayer_pack: job %d: [N %% 32 == 0][K %% 16 == 0] bf16, ld %% 8 == 0", i);
+        RALF_REQUIRE((((uintptr_t)j.src | (uintptr_t)j.dst) & 15) == 0, "tlayer_pack: job %d: src / dst must be 16-byte aligned (16-byte vector accesses)", i);
         pj.j[i] = j;
         most = most > (int64_t)j.N * j.K / 8 ? most : (int64_t)j.N * j.K / 8;
     }
@@ -781,6 +782,12 @@ extern "C" int ralf_tlayer_fwd(const RalfTLayerDesc* dp, void* stream) {
         RALF_REQUIRE(d.out && ((d.h3 && d.mean3 && d.rstd3 && d.hid) || (d.part == 2 && !d.h3 && !d.mean3 && !d.rstd3 && !d.hid)),
                      "tlayer_fwd: feed-forward block: null output pointer (part 2 alone may run without h3 / mean3 / rstd3 / hid: inference)");
     }
+    {   // every activation / packed-weight pointer is read or written in 16-byte vectors (bf16x8 / uint4)
+        const void* al[] = {d.x, d.x1, d.x2, d.o1, d.o2, d.q, d.qkv, d.h1, d.h2, d.h3, d.hid, d.z, d.out, d.w_in, d.w_o, d.w_q, d.w_o2, d.w1, d.w2};
+        uintptr_t bits = 0;
+        for (const void* p : al) bits |= (uintptr_t)p;
+        RALF_REQUIRE((bits & 15) == 0, "tlayer_fwd: activation and packed-weight pointers must be 16-byte aligned");
+    }
     hipStream_t st = (hipStream_t)stream;
     if (d.part == 0) hipLaunchKernelGGL((tlayer_fwd_kernel<0>), dim3(d.B), dim3(NT), 0, st, d);
     else if (d.part == 1) hipLaunchKernelGGL((tlayer_fwd_kernel<1>), dim3(d.B), dim3(NT), 0, st, d);
@@ -800,6 +807,13 @@ extern "C" int ralf_tlayer_bwd(const RalfTLayerBwdDesc* dp, void* stream) {
     RALF_REQUIRE(d.dy_m && d.w1t && d.g && (d.stage == 4 ? (d.nk == 1 || d.nk == 3) && (!d.wot || d.d_o) : (d.hid && d.w2t && d.dz)), "tlayer_bwd: null pointer (stage 4: nk = 1 or 3)");
     RALF_REQUIRE(d.stage == 1 || (d.x2 && d.mean3 && d.rstd3 && d.ln3_g && d.g_m && (d.p == 0.f || d.seed) && (d.stage != 3 || (d.dy && d.wot && d.d_o))),
                  "tlayer_bwd: stages 3 / 4 need the LayerNorm operands (3: and the skip gradient and the out-projection)");
+    RALF_REQUIRE((int64_t)d.B * d.S < (1 << 22), "tlayer_bwd: at most 2^22 rows per launch (32-bit dropout element indices, like the forward)");
+    {
+        const void* al[] = {d.dy_m, d.dy, d.hid, d.dz, d.g, d.g_m, d.x2, d.d_o, d.w1t, d.w2t, d.wot};
+        uintptr_t bits = 0;
+        for (const void* p : al) bits |= (uintptr_t)p;
+        RALF_REQUIRE((bits & 15) == 0, "tlayer_bwd: activation and packed-weight pointers must be 16-byte aligned");
+    }
     if (d.S <= 32) hipLaunchKernelGGL(tlayer_bwd_kernel<1>, dim3(d.B), dim3(NT), 0, (hipStream_t)stream, d);
     else hipLaunchKernelGGL(tlayer_bwd_kernel<2>, dim3(d.B), dim3(NT), 0, (hipStream_t)stream, d);
     return ralf::check_launch("tlayer_bwd");

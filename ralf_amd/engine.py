@@ -13,6 +13,7 @@ The reference's DDP wiring never all-reduces (SURVEY.md section 5 "DDP quirk"); 
 from __future__ import annotations
 
 import os
+import weakref
 from typing import Optional
 
 import torch
@@ -36,7 +37,7 @@ class FlatAdamW:
         params = [p for g in groups for p in g["params"]]
         dev = params[0].device
         sizes = [_align(p.numel()) for p in params]
-        total = sum(sizes)
+        total = _align(sum(sizes), 1024)   # (tail padding, never updated: every range of the staged exchange can end on a multiple of world * 64)
         self.P = torch.zeros(total, dtype=torch.float32, device=dev)
         self.G = torch.zeros(total, dtype=torch.float32, device=dev)
         self.M = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -51,6 +52,8 @@ class FlatAdamW:
                 self.P[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.P[off:off + n].view(p.shape)
                 p.grad = self.G[off:off + n].view(p.shape)
+                if runtime is not None:
+                    runtime.register_grad_view(p, p.grad)
                 if self.P16 is not None and runtime is not None:
                     runtime.register_shadow(p, self.P16[off:off + n].view(p.shape))
                 off += _align(n)
@@ -156,6 +159,7 @@ class GradExchange:
         self._pack = pack or ops.cast_into
         self._unpack = unpack or ops.cast_into
         self.rank = torch.distributed.get_rank(group) if self.active and torch.distributed.is_initialized() else 0
+        self.ran: dict = {}
 
     @property
     def active(self) -> bool:
@@ -178,7 +182,9 @@ class GradExchange:
         for a, b in ranges:
             if self.wire == "bf16":
                 self._pack(self.flat[a:b], self.stage[a:b])
-            if self.mode == "rs_ag" and (b - a) % self.world == 0 and b > a:
+            rs = self.mode == "rs_ag" and (b - a) % self.world == 0 and b > a
+            self.ran[(a, b)] = "rs_ag" if rs else "allreduce"   # (diagnostics: bench.py reports which collective carried each range)
+            if rs:
                 works.append((dist.reduce_scatter_tensor(self._shard(buf, a, b), buf[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), a, b))
             else:
                 works.append((dist.all_reduce(buf[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), None, None))
@@ -220,6 +226,18 @@ def flat_ranges(params, flat: torch.Tensor, align: int = 1):
     return [(a, b) for a, b in out]
 
 
+def _round_ranges(ranges, q: int, total: int):
+    """grow every [a, b) to multiples of q (clipped to the buffer, overlaps merged)"""
+    out = []
+    for a, b in sorted(ranges):
+        a, b = a // q * q, min(total, (b + q - 1) // q * q)
+        if out and a <= out[-1][1]:
+            out[-1][1] = max(out[-1][1], b)
+        else:
+            out.append([a, b])
+    return [(a, b) for a, b in out]
+
+
 def complement_ranges(ranges, total: int):
     out, pos = [], 0
     for a, b in sorted(ranges):
@@ -253,10 +271,13 @@ class TrainStep:
     """One optimisation step of `model` (a ralf_amd generator) = forward + backward + (all-reduce) + clip + AdamW."""
 
     def __init__(self, model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, backbone_lr_scale=0.1, betas=(0.9, 0.999), eps=1e-8,
-                 use_graph=True, process_group=None, overlap_wgrad=True, overlap_allreduce=None, grad_wire=None, grad_exchange=None):
+                 use_graph=True, process_group=None, overlap_wgrad=True, overlap_allreduce=None, grad_wire=None, grad_exchange=None, groups=None):
+        """groups: ready-made AdamW groups (what `model.optim_groups(...)` returned to the caller, train/train.py:217-223) instead of
+        lr / weight_decay / backbone_lr_scale"""
         self.model = model
         rt = model.rt.to(model.device)
-        groups = model.optim_groups(base_lr=lr, weight_decay=weight_decay, custom_lr={"encoder.extractor.body": lr * backbone_lr_scale})
+        if groups is None:
+            groups = model.optim_groups(base_lr=lr, weight_decay=weight_decay, custom_lr={"encoder.extractor.body": lr * backbone_lr_scale})
         self.opt = FlatAdamW(groups, betas, eps, max_norm, shadow_dtype=rt.dtype if rt.dtype == torch.bfloat16 else None, runtime=rt)
         rt.direct_grads = True   # kernels accumulate parameter gradients straight into the flat buffer
         rt.overlap = overlap_wgrad  # ... on a side stream: a parallel branch of the captured graph
@@ -276,6 +297,7 @@ class TrainStep:
         self._graphs = None
         self._seed_grad = None
         self.loss = None
+        self.outputs = None
         self.steps_done = 0
         # Data parallel: the backward runs in two stages around rt.grad_cut() (after layer2 of the ResNet).  Stage 1
         # (decoder, encoders, FPN, layer4, layer3) completes 94 % of the gradient bytes; their all-reduce runs on RCCL's
@@ -286,7 +308,9 @@ class TrainStep:
         if self.staged:
             before = self._params_before_cut()
             if before:
-                self._late = flat_ranges(before, self.opt.G, align=64)            # exchanged after stage 2
+                # boundaries on multiples of world * 64 elements (parameters start on multiples of 64; the few elements a range grows by
+                # are whole neighbours or zero padding, exchanged twice at worst): every range keeps the reduce-scatter + all-gather form
+                self._late = _round_ranges(flat_ranges(before, self.opt.G, align=64), 64 * max(self.world, 1), self.opt.G.numel())   # exchanged after stage 2
                 self._early = complement_ranges(self._late, self.opt.G.numel())     # exchanged during stage 2
             else:
                 self.staged = False
@@ -305,10 +329,11 @@ class TrainStep:
         self.opt.zero_grad()
         rt.cut_enabled, rt._cuts = self.staged, []
         try:
-            _, losses = self.model.train_loss(inputs, targets)
+            out, losses = self.model._train_loss(inputs, targets)
         finally:
             rt.cut_enabled = False
         loss = losses["nll_loss"]
+        self.outputs = {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}   # (inside a capture: the graph's static output tensors)
         if self._seed_grad is None or self._seed_grad.device != loss.device:   # d(loss) = 1 / world, a constant made once (no fill kernel per step)
             self._seed_grad = torch.full_like(loss, 1.0 / self.world)
         loss.backward(self._seed_grad)
@@ -444,6 +469,70 @@ class TrainStep:
         # (capturing ran the host side of the step once more without executing kernels: put the host counters back too)
         self.opt.step_count = snap["step_count"]
         self.model.rt._wtoken += 1
+
+
+# models that handed out optimizer groups, by the token their groups carry ("ralf_model"): lets an optimizer built from nothing but
+# `model.optim_groups(...)` (train/train.py:217-223) find the model it trains
+_MODELS: "weakref.WeakValueDictionary[int, torch.nn.Module]" = weakref.WeakValueDictionary()
+
+
+def register_model(model) -> int:
+    _MODELS[id(model)] = model
+    return id(model)
+
+
+class GraphedAdamW(torch.optim.Optimizer):
+    """`torch.optim.AdamW`-shaped front of `TrainStep`, so that the reference's UNCHANGED loop body (train/train.py:432-454) runs the
+    graph-replayed step.  Selected by one more Hydra override next to the generator's:
+
+        optimizer._target_=ralf_amd.engine.GraphedAdamW  +optimizer.max_norm=${training.clip_max_norm}
+
+    The loop calls, in order: `model.zero_grad()` -> `model.train_loss(inputs, targets)` -> `loss.backward()` -> `clip_grad_norm_(
+    model.parameters(), max_norm)` -> `optimizer.step()`.  With this optimizer attached, `train_loss` (training mode, grad enabled) copies the
+    batch into the step's static buffers and replays the captured forward + backward + (RCCL exchange) + global-norm clip + AdamW; the
+    loss it returns is a leaf, so `loss.backward()` is a no-op on the model; parameters carry no `.grad` (the flat gradient buffer is
+    private), so `clip_grad_norm_` has nothing to scale -- the clip already ran inside the graph with `max_norm`, which is why it is a
+    constructor keyword here; `step()` only follows the learning-rate schedule.  `evaluate()` (eval mode, no_grad) takes the ordinary
+    forward.  lr / weight_decay per group come from `model.optim_groups`, exactly as with torch's AdamW."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, max_norm: float = 0.0, **step_kw):
+        groups = [dict(g) for g in params]
+        tokens = {g.get("ralf_model") for g in groups}
+        assert len(tokens) == 1 and None not in tokens, "GraphedAdamW takes the groups returned by a ralf_amd generator's optim_groups()"
+        model = _MODELS.get(tokens.pop())
+        assert model is not None, "the model these optimizer groups came from no longer exists"
+        super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        for g in self.param_groups:
+            assert g["lr"] is not None, "optim_groups(base_lr=...) sets every group's learning rate"
+        self._base_lrs = [g["lr"] for g in self.param_groups]
+        self._factor = 1.0
+        self.engine = TrainStep(model, max_norm=max_norm, betas=betas, eps=eps, use_graph=True,
+                                groups=[{"params": g["params"], "lr": g["lr"], "weight_decay": g["weight_decay"]} for g in self.param_groups], **step_kw)
+        self._detached = False
+        model._engine = self
+
+    def train_step(self, inputs, targets):
+        loss = self.engine(inputs, targets)
+        if not self._detached:   # the replays do not involve autograd: from here on the flat gradient buffer is the engine's own
+            for g in self.param_groups:
+                for p in g["params"]:
+                    p.grad = None
+            self._detached = True
+        return self.engine.outputs, {"nll_loss": loss.clone().requires_grad_()}
+
+    def zero_grad(self, set_to_none: bool = True):   # the captured step zeroes its gradient buffer itself
+        pass
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        """the update itself ran inside train_loss(); here: a scheduler that rewrote param_groups[i]["lr"] (MultiStepLR and the
+        like scale every group by one factor) is followed through the device-resident factor the captured AdamW reads"""
+        fs = [g["lr"] / b for g, b in zip(self.param_groups, self._base_lrs) if b]
+        if fs and abs(fs[0] - self._factor) > 1e-12 * max(1.0, abs(self._factor)):
+            assert all(abs(f - fs[0]) <= 1e-9 * max(1.0, abs(fs[0])) for f in fs), "per-group learning-rate schedules need a re-capture (not supported)"
+            self._factor = fs[0]
+            self.engine.opt.lr_scale.fill_(self._factor)
+        return None
 
 
 class GraphedDecode:

@@ -28,6 +28,8 @@ class Runtime:
         self._lp: dict = {}
         self._shadow: dict = {}   # id(param) -> persistent low-precision view kept current by the fused optimizer
         self.direct_grads = False  # engine mode: parameter gradients are accumulated by the kernels straight into p.grad
+        self._packs: dict = {}    # fragment-order weight copies by weight identity (packed())
+        self._gviews: dict = {}   # id(param) -> (weakref, flat-buffer gradient view): survives `p.grad = None` (engine.GraphedAdamW)
         self._wtoken = 0          # bumped when weights are rewritten behind torch's version counters
         self._conv_table = None   # batched re-layout job table of the convolution weights (refresh_conv_shadows)
         self.overlap = False      # engine mode: weight / bias gradient kernels run on a side stream, off the data-gradient chain
@@ -300,7 +302,14 @@ class Runtime:
         and the autograd function returns None), else None (gradients are returned to autograd as tensors)."""
         if self.direct_grads and p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous():
             return p.grad
+        if self.direct_grads and p.grad is None:
+            hit = self._gviews.get(id(p))
+            if hit is not None and hit[0]() is p:
+                return hit[1]
         return None
+
+    def register_grad_view(self, p: torch.Tensor, view: torch.Tensor):
+        self._gviews[id(p)] = (weakref.ref(p), view)
 
     def refresh_conv_shadows(self, weights):
         """re-layout shadows ([Co][kh][kw][Ci] and [Ci][kh][kw][Co]) of all k>1 convolution weights in ONE launch when the
@@ -331,6 +340,21 @@ class Runtime:
             self._lp[(id(w), "ohwi", self.dtype)] = (stamp[0], stamp[1], o1, weakref.ref(w))
             self._lp[(id(w), "ikwo", self.dtype)] = (stamp[0], stamp[1], o2, weakref.ref(w))
         st["sig"], st["token"] = sig, self._wtoken
+
+    def packed(self, weights, with_transposes: bool):
+        """fragment-order copies (ops.tlayer_pack) of the row-major bf16 shadows of `weights`, followed -- with_transposes -- by the packed
+        transposes in REVERSE order (what the strip-wise backward streams): one launch for all of them, repeated only when a master changed
+        (every optimizer step in training, never for frozen / inference weights)"""
+        key = tuple(id(w) for w in weights) + (bool(with_transposes),)
+        stamp = tuple((w.data_ptr(), w._version) for w in weights) + (self._wtoken, self.dtype)
+        hit = self._packs.get(key)
+        if hit is not None and hit[0] == stamp and all(r() is w for r, w in zip(hit[2], weights)):
+            return hit[1]
+        mats = [self.lp(w) for w in weights]
+        n = len(mats)
+        out = ops.tlayer_pack(mats + (mats[::-1] if with_transposes else []), transpose=tuple(range(n, 2 * n)) if with_transposes else ())
+        self._packs[key] = (stamp, out, [weakref.ref(w) for w in weights])
+        return out
 
     # low-precision / re-laid-out shadows of fp32 master weights, refreshed when the master changes
     def lp(self, w: torch.Tensor, kind: str = "cast") -> torch.Tensor:
@@ -1300,8 +1324,14 @@ class TFeedForwardFn(Function):
     @staticmethod
     def forward(ctx, x, rt, packed, lnw, lnb, w1, b1, w2, b2):
         x = x.contiguous()
+        ctx.pt = None
         if packed is None:
-            packed = ops.tlayer_pack([rt.lp(w1), rt.lp(w2)])
+            # W1, W2 and (when a backward will follow) W2^T, W1^T in ONE launch per step and module, none while the weights stand still
+            rows = x.numel() // x.shape[-1]
+            with_t = rt.fused_ffn_bwd and rows % 64 == 0 and any(ctx.needs_input_grad)
+            packed = rt.packed((w1, w2), with_t)
+            if with_t:
+                ctx.pt = (packed[2], packed[3])
         t = ops.tlayer_ffn(x, {"ln3": (lnw.detach(), lnb.detach()), "ffn1": (packed[0], b1.detach()), "ffn2": (packed[1], b2.detach())}, act="gelu", residual=False)
         ctx.save_for_backward(x, lnw, lnb, w1, b1, w2, b2, t["h3"], t["mean3"], t["rstd3"], t["hid"], t["z"])
         ctx.cfg = (rt, rt.dropout_tag(x))
@@ -1316,7 +1346,7 @@ class TFeedForwardFn(Function):
             dy2 = _2d(dy.contiguous())
             if dy2.dtype != rt.dtype:
                 dy2 = ops.cast(dy2, rt.dtype)
-            pt = ops.tlayer_pack([rt.lp(w2), rt.lp(w1)], transpose=(0, 1))
+            pt = ctx.pt if ctx.pt is not None else ops.tlayer_pack([rt.lp(w2), rt.lp(w1)], transpose=(0, 1))
             gg, gb = rt.gview(lnw), rt.gview(lnb)
             direct = gg is not None and gb is not None
             if not direct:

@@ -91,18 +91,26 @@ class _GeneratorBase(nn.Module):
                 no_decay.add(n)
             else:
                 decay.add(n)
+        from ..engine import register_model
+        token = register_model(self)   # extra group option (torch optimizers keep unknown keys): lets engine.GraphedAdamW find this model
         groups, taken = [], set()
         for prefix, lr in (custom_lr or {}).items():
             for names, wd in ((decay, weight_decay), (no_decay, 0.0)):
                 sel = sorted(n for n in names if n.startswith(prefix))
                 if sel:
-                    groups.append({"params": [named[n] for n in sel], "weight_decay": wd, "lr": lr})
+                    groups.append({"params": [named[n] for n in sel], "weight_decay": wd, "lr": lr, "ralf_model": token})
                     taken.update(sel)
         for names, wd in ((decay, weight_decay), (no_decay, 0.0)):
             sel = sorted(n for n in names if n not in taken)
             if sel:
-                groups.append({"params": [named[n] for n in sel], "weight_decay": wd, "lr": base_lr})
+                groups.append({"params": [named[n] for n in sel], "weight_decay": wd, "lr": base_lr, "ralf_model": token})
         return groups
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        """train/train.py:440.  With an engine.GraphedAdamW attached the captured step zeroes its own flat gradient buffer and the
+        parameters' .grad views must survive until the capture: nothing to do here."""
+        if getattr(self, "_engine", None) is None:
+            super().zero_grad(set_to_none)
 
     def postprocess(self, outputs: dict) -> dict:
         if "seq" in outputs:
@@ -114,7 +122,7 @@ class _GeneratorBase(nn.Module):
         return self.tokenizer.decode(seq)
 
     # ---- shared model pieces --------------------------------------------------------------------
-    def _build_common(self, tokenizer, d_model, auxilary_task, use_flag_embedding, use_multitask, global_task_embedding, decoder_d_model=256):
+    def _build_common(self, tokenizer, d_model, auxilary_task, use_flag_embedding, use_multitask, global_task_embedding, decoder_d_model=256, pretrained=True):
         assert auxilary_task in COND_TYPES, f"{auxilary_task=} must be one of {COND_TYPES}"
         assert d_model == 256 and decoder_d_model == 256, "the reference configs use d_model = 256"
         self.tokenizer = tokenizer
@@ -124,7 +132,8 @@ class _GeneratorBase(nn.Module):
         self.auxilary_task, self.use_multitask, self.global_task_embedding = auxilary_task, use_multitask, global_task_embedding
         assert not global_task_embedding, "global_task_embedding=True is not used by any shipped config"
         self.preprocessor = self._make_preprocessor(auxilary_task)
-        self.encoder = RN.ResnetFeatureExtractor(d_model)
+        self.pretrained = bool(pretrained)
+        self.encoder = RN.ResnetFeatureExtractor(d_model, pretrained)   # pretrained: timm checkpoint loaded here, like common/image.py:38-48
         self.transformer_encoder = RN.LayerStack([RN.TransformerEncoderLayer(d_model, self.nhead, self.dim_feedforward, self.dropout, True)
                                                   for _ in range(self.num_layers)])
         self.decoder = RN.BaseDecoder(tokenizer.N_total, decoder_d_model, self.num_layers, self.nhead, self.dim_feedforward)
@@ -156,7 +165,12 @@ class _GeneratorBase(nn.Module):
         """reference initialisation (retrieval_augmented_autoreg.py:171-175, common/common.py:69-82,228-236)
         on top of torch-default-like fills for the rest."""
         g = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
+        # what the constructor loaded from the authors' weight files stays as loaded (the reference's init_weights only touches the decoder
+        # and the image transformer encoder); the frozen layout encoder is loaded AFTER this (see the RALF constructor)
+        loaded = ("encoder.extractor.body.",) if getattr(self, "pretrained", False) else ()
         for name, p in self.named_parameters():
+            if name.startswith(loaded):
+                continue
             with torch.no_grad():
                 if name.endswith("bias"):
                     p.zero_()
@@ -206,6 +220,12 @@ class _GeneratorBase(nn.Module):
         return {"logits": logits}
 
     def train_loss(self, inputs: dict, targets: dict, test: bool = False):
+        eng = getattr(self, "_engine", None)
+        if eng is not None and self.training and torch.is_grad_enabled() and not test:
+            return eng.train_step(inputs, targets)   # whole optimisation step = one hipGraph replay (engine.GraphedAdamW)
+        return self._train_loss(inputs, targets)
+
+    def _train_loss(self, inputs: dict, targets: dict):
         outputs = self(inputs)
         loss = RF.XentFn.apply(outputs["logits"], targets["seq"], self.tokenizer.name_to_id("pad"), 0.1, self.rt)
         return outputs, {"nll_loss": loss}
@@ -328,6 +348,12 @@ class _GeneratorBase(nn.Module):
             else:
                 for dst, src in zip(self.cache.cross_kv, cache.cross_kv):
                     dst.copy_(src)
+                # the fragment-order weight copies of the fused tail (Runtime.fused_decode_tail) are baked into the captured graphs as well:
+                # a load_state_dict / training step between two calls must reach them (the row-major shadows are refreshed in place)
+                if self.cache.packed is not None and cache.packed is not None:
+                    for dl, sl in zip(self.cache.packed, cache.packed):
+                        for dst, src in zip(dl, sl):
+                            dst.copy_(src)
 
         def __call__(self, token, pos, kpm_prefix):
             m = self.model
@@ -384,9 +410,10 @@ class _GeneratorBase(nn.Module):
             key = (int(memory.shape[1]), str(dev))
             if key not in pool:
                 while len(pool) >= 4:
-                    pool.pop(next(iter(pool)))
+                    pool.pop(next(iter(pool)))    # least recently USED (a hit re-inserts its key below)
                 pool[key] = self._StepGraphs(self, T, dev)
-            stepper = pool[key]
+            stepper = pool.pop(key)
+            pool[key] = stepper
         # the sequence, the masks and the draw live on the HOST (518 logits per step come back in one copy): the reference's
         # control flow is host logic anyway, and a dozen tiny device ops + three syncs per step cost more than the decoder step
         for b in range(B):
@@ -501,7 +528,12 @@ class ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg(_GeneratorBas
                  layout_backbone: str = "feature_extractor", use_reference_image: bool = False, freeze_layout_encoder: bool = True,
                  retrieval_backbone: str = "saliency", random_retrieval: bool = False, saliency_k=8, decoder_d_model: int = 256,
                  auxilary_task: Optional[str] = None, use_flag_embedding: bool = True, use_multitask: bool = False, RELATION_SIZE: int = 10,
-                 shared_embedding: bool = False, global_task_embedding: bool = False, compute_dtype="float32", relation_table=None, **_ignored):
+                 shared_embedding: bool = False, global_task_embedding: bool = False, compute_dtype="float32", relation_table=None,
+                 pretrained: bool = True, **_ignored):
+        """pretrained (extension, default = the reference's behaviour): load `resnet50_a1_0-14fe96d1.pth` into the ResNet-50 body
+        (common/image.py:38-48,70-77) and `fidnet/<dataset>/model_best.pth.tar` into the frozen layout encoder (fid/model.py:131-175,
+        retrieval_augmented_autoreg.py:144-155) from the reference's locations; missing files fail like the reference's.  pretrained=False
+        (tests, smoke, bench: no weight files on the box) keeps the random initialisation."""
         super().__init__()
         self.relation_table = relation_table   # extension: in-memory relationship table (default: the reference's cache file)
         assert encoder_pos_emb == "sine" and decoder_pos_emb == "layout" and not use_reference_image and not shared_embedding
@@ -511,13 +543,15 @@ class ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg(_GeneratorBas
         self.dataset_name, self.max_seq_length, self.top_k = dataset_name, max_seq_length, top_k
         self.retrieval_backbone, self.random_retrieval, self.saliency_k = retrieval_backbone, random_retrieval, saliency_k
         self.use_reference_image, self.layout_backbone, self.weight_init = use_reference_image, layout_backbone, weight_init
-        self._build_common(tokenizer, d_model, auxilary_task, use_flag_embedding, use_multitask, global_task_embedding, decoder_d_model)
+        self._build_common(tokenizer, d_model, auxilary_task, use_flag_embedding, use_multitask, global_task_embedding, decoder_d_model, pretrained)
         self.layout_encoer = RN.LayoutEncoder(_num_classes(features))  # [sic] checkpoint key of the reference
         self.pos_emb_1d = RN.PosEnc1d(d_model, 5000)
         self.layout_adapter = RN.FeedForward(256, 4 * d_model, d_model)
         self.head = RN.FeedForward(d_model, 4 * d_model)
         self.attn = RN.FuseAttention(d_model, d_model, heads=8, dim_head=64)
         self.init_weights()
+        if pretrained:   # after init_weights(): the trained FIDNetV3 encoder is what gets frozen, not a re-drawn one
+            self.layout_encoer.load_fidnet(dataset_name)
         for p in self.layout_encoer.parameters():
             p.requires_grad = False
 
@@ -567,13 +601,15 @@ class ConcateAuxilaryTaskAutoreg(_GeneratorBase):
     def __init__(self, features, tokenizer, d_model: int = 256, encoder_pos_emb: str = "sine", decoder_pos_emb: str = "layout",
                  weight_init: bool = False, shared_embedding: bool = False, decoder_num_layers: int = 6, decoder_d_model: int = 256,
                  auxilary_task: Optional[str] = None, use_flag_embedding: bool = True, use_multitask: bool = False, RELATION_SIZE: int = 10,
-                 global_task_embedding: bool = False, compute_dtype="float32", relation_table=None, **_ignored):
+                 global_task_embedding: bool = False, compute_dtype="float32", relation_table=None, pretrained: bool = True, **_ignored):
+        """pretrained (extension, default = the reference's behaviour, autoreg.py:29-118 -> common/image.py:38-48): the ResNet-50 body is
+        loaded from `resnet50_a1_0-14fe96d1.pth`; pretrained=False keeps the random initialisation (tests, bench)."""
         super().__init__()
         self.relation_table = relation_table
         assert encoder_pos_emb == "sine" and decoder_pos_emb == "layout" and not shared_embedding and decoder_num_layers == 6
         self._init_runtime(compute_dtype)
         self.features = features
-        self._build_common(tokenizer, d_model, auxilary_task, use_flag_embedding, use_multitask, global_task_embedding, decoder_d_model)
+        self._build_common(tokenizer, d_model, auxilary_task, use_flag_embedding, use_multitask, global_task_embedding, decoder_d_model, pretrained)
         self.init_weights()
 
     def preprocess(self, inputs: dict):

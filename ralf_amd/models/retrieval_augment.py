@@ -23,7 +23,9 @@ LAYOUT_KEYS = ("label", "mask", "center_x", "center_y", "width", "height")
 
 class RetrievalAugmentation(nn.Module):
     def __init__(self, *, d_model: int, dataset_name: str, top_k: int, num_classes: int, max_seq_length: int, use_reference_image: bool,
-                 compute_dtype="float32"):
+                 compute_dtype="float32", pretrained: bool = True):
+        """pretrained (extension; default = the reference): the frozen layout encoder is the trained FIDNetV3 of `dataset_name`, loaded from the
+        reference's locations (fid/model.py:131-175); pretrained=False keeps random weights (tests)"""
         super().__init__()
         if use_reference_image:
             raise NotImplementedError("use_reference_image=True (exemplar IMAGES through the backbone) is not on the accelerated path")
@@ -31,6 +33,8 @@ class RetrievalAugmentation(nn.Module):
         self.dataset_name, self.max_seq_length = dataset_name, max_seq_length
         self.rt = Runtime(_DTYPES[compute_dtype] if isinstance(compute_dtype, str) else compute_dtype)
         self.layout_encoder = RN.LayoutEncoder(num_classes)       # load_fidnet_feature_extractor: frozen, decoder side deleted
+        if pretrained:
+            self.layout_encoder.load_fidnet(dataset_name)
         for p in self.layout_encoder.parameters():
             p.requires_grad = False
         self.pos_emb_1d = RN.PosEnc1d(d_model, 5000)

@@ -431,6 +431,15 @@ class LayoutEncoder(nn.Module):
         self.dec_fc_in = Affine(d_model, 2 * d_model, bias_dim=d_model)
         self.d = d_model
 
+    @torch.no_grad()
+    def load_fidnet(self, dataset_name: str, ckpt_dir: str = "tmp/fidnet") -> "LayoutEncoder":
+        """load_fidnet_feature_extractor (fid/model.py:131-175): the trained FIDNetV3 of `dataset_name` (pku -> pku10) from
+        `<ckpt_dir>/<dataset>/model_best.pth.tar`, else from ./cache/PRECOMPUTED_WEIGHT_DIR/fidnet/...; the decoder-side keys the reference
+        deletes after its strict load are dropped, anything else that does not match fails"""
+        from .pretrained import fidnet_encoder_state, load_fidnet_state
+        self.load_state_dict(fidnet_encoder_state(load_fidnet_state(dataset_name, ckpt_dir), self.state_dict().keys()), strict=True)
+        return self.eval()
+
     def _frozen_operands(self, rt: Runtime, dev):
         """the zero-padded fc_bbox weight [d, 8] and the learned token in the compute dtype: the encoder is frozen
         (retrieval_augmented_autoreg.py:150-155), so they are rebuilt only when the masters change"""
@@ -561,7 +570,10 @@ class ResnetBackbone(nn.Module):
     """common/image.py:27-120 with head='transformer'; returns the projected map ALREADY as the
     [B, h*w, d] sequence with the 2-D sine table added (PositionEmbeddingSine fused into proj)."""
 
-    def __init__(self, d_model: int = 256):
+    def __init__(self, d_model: int = 256, pretrained: bool = False):
+        """pretrained=True is the reference constructor's behaviour (common/image.py:38-48,70-77): the timm ResNet-50 checkpoint is looked
+        up in the working directory, then under ./cache/PRECOMPUTED_WEIGHT_DIR (AssertionError when absent) and loaded into the body; the
+        generators pass it (models/ralf.py), the building-block default is off"""
         super().__init__()
         self.body = ResNetBody()
         self.fpn_conv11_4, self.fpn_conv11_5 = Conv(1024, 256, 1, bias=True), Conv(2048, 256, 1, bias=True)
@@ -570,6 +582,10 @@ class ResnetBackbone(nn.Module):
         self._pos_cache: dict = {}
         self._conv_weights = None
         self._fold_state = None
+        self.pretrained = bool(pretrained)
+        if pretrained:
+            from .pretrained import load_resnet50_state
+            self.load_pretrained_body(load_resnet50_state())
 
     def parameters_before_cut(self):
         """parameters whose gradients are produced AFTER the rt.grad_cut() point in the backward (stem, layer1, layer2)"""
@@ -645,7 +661,10 @@ class ResnetBackbone(nn.Module):
         """timm ResNet-50 checkpoint (3-channel stem, e.g. resnet50_a1_0-14fe96d1.pth) -> this body, the way the reference's
         constructor does it (common/image.py:39-48, 70-77): `fc.*` is not part of the extracted body and the 4th stem channel
         (saliency) is the mean of the RGB filters."""
-        sd = {k: v for k, v in state_dict.items() if not k.startswith("fc.")}
+        fc = {k for k in state_dict if k.startswith("fc.")}
+        # the reference loads the checkpoint STRICTLY into timm's resnet50 (fc.weight / fc.bias included) before it extracts the body
+        assert fc == {"fc.weight", "fc.bias"}, f"not a timm resnet50 checkpoint: classifier keys {sorted(fc)}"
+        sd = {k: v for k, v in state_dict.items() if k not in fc}
         w3 = sd["conv1.weight"]
         assert w3.shape[1] == 3, "expected the pretrained 3-channel stem"
         sd["conv1.weight"] = torch.cat([w3, w3.mean(dim=1, keepdim=True)], dim=1)
@@ -653,9 +672,9 @@ class ResnetBackbone(nn.Module):
 
 
 class ResnetFeatureExtractor(nn.Module):
-    def __init__(self, d_model: int = 256):
+    def __init__(self, d_model: int = 256, pretrained: bool = False):
         super().__init__()
-        self.extractor = ResnetBackbone(d_model)
+        self.extractor = ResnetBackbone(d_model, pretrained)
 
     def forward(self, img, rt):
         return self.extractor(img, rt)

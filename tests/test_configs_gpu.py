@@ -33,7 +33,7 @@ def cgl_model(dtype, task="uncond"):
     tok = LayoutSequenceTokenizer(CGL_LABELS, 10)
     torch.manual_seed(0)
     m = RALF(features={"label": LabelFeature(CGL_LABELS)}, tokenizer=tok, dataset_name="cgl", max_seq_length=10, db_dataset=None, top_k=16,
-             retrieval_backbone="dreamsim", random_retrieval=False, saliency_k="None", auxilary_task=task, compute_dtype=dtype)
+             retrieval_backbone="dreamsim", random_retrieval=False, saliency_k="None", auxilary_task=task, compute_dtype=dtype, pretrained=False)
     return m.to(DEV).train()
 
 

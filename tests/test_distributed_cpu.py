@@ -215,3 +215,20 @@ def test_sharded_knn_world2():
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
+
+
+def test_staged_ranges_are_rounded_so_that_every_range_keeps_reduce_scatter_form():
+    """the staged exchange's ranges end where a parameter ends; rounded outwards to world * 64 elements (and the complement
+    taken afterwards) every range is divisible by the world size, late parameters stay inside late ranges, nothing is exchanged twice"""
+    from ralf_amd.engine import _round_ranges, complement_ranges
+
+    total = 1024 * 9
+    late = [(64, 1000), (1100, 1160), (5000, 5003)]
+    for world in (2, 4, 8):
+        q = 64 * world
+        r = _round_ranges(late, q, total)
+        early = complement_ranges(r, total)
+        assert all(a % q == 0 and b % q == 0 for a, b in r + early)
+        assert all(any(ra <= a and b <= rb for ra, rb in r) for a, b in late)
+        cover = sorted(r + early)
+        assert cover[0][0] == 0 and cover[-1][1] == total and all(x[1] == y[0] for x, y in zip(cover, cover[1:]))

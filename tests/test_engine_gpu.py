@@ -265,3 +265,47 @@ def test_grouped_wgrads_and_branches_equal_plain_step(golden):
         p1, p2 = dict(m1.named_parameters())[k], dict(m2.named_parameters())[k]
         r = ((p1.grad - p2.grad).norm() / p2.grad.norm().clamp_min(1e-12)).item()
         assert r < 2e-3, (k, r)
+
+
+def test_unchanged_reference_loop_reaches_the_graph_through_graphed_adamw(golden):
+    """image2layout/train/train.py:432-454 verbatim (zero_grad -> train_loss -> backward -> clip_grad_norm_ -> optimizer.step) with
+    optimizer._target_=ralf_amd.engine.GraphedAdamW trains exactly like TrainStep: the adapter replays the captured step inside train_loss"""
+    from ralf_amd.engine import GraphedAdamW, TrainStep
+
+    m1, inputs, tgt = make(golden, "bfloat16")
+    m2, _, _ = make(golden, "bfloat16")
+    for m in (m1, m2):
+        m.train()
+        m.rt.drop_p = lambda p: 0.0   # training mode (the adapter's hook), dropout off (comparable runs)
+    groups = m1.optim_groups(base_lr=1e-4, weight_decay=1e-4, custom_lr={"encoder.extractor.body": 1e-5})   # train/train.py:217-223
+    opt = GraphedAdamW(params=groups, weight_decay=0.01, max_norm=0.1)   # instantiate(cfg.optimizer)(params=...) with the override
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[1], gamma=0.1)
+    step = TrainStep(m2, lr=1e-4, weight_decay=1e-4, max_norm=0.1, use_graph=True)
+    la, lb = [], []
+    for it in range(4):
+        m1.zero_grad()
+        out, losses = m1.train_loss(inputs, tgt)
+        loss = sum(losses.values())
+        loss.backward()
+        total = torch.nn.utils.clip_grad_norm_(m1.parameters(), 0.1)
+        opt.step()
+        la.append(loss.cpu().item())
+        lb.append(step(inputs, tgt).item())
+        assert out["logits"].shape[0] == inputs["seq"].shape[0] and float(total) == 0.0   # nothing left for the host-side clip to scale
+        assert all(p.grad is None for p in m1.parameters())
+    assert la[0] > la[-1]
+    for a, b in zip(la, lb):
+        assert abs(a - b) < 2e-3, (la, lb)
+    torch.cuda.synchronize()
+    assert (opt.engine.opt.P - step.opt.P).abs().max().item() <= 8e-4
+    # evaluate() (train/train.py:492-520: eval mode, no_grad) takes the ordinary forward and does not step
+    before = opt.engine.steps_done
+    m1.eval()
+    with torch.no_grad():
+        _, l = m1.train_loss(inputs, tgt, test=True)
+    assert opt.engine.steps_done == before and torch.isfinite(l["nll_loss"])
+    m1.train()
+    # the epoch-wise scheduler rewrites param_groups[i]["lr"]: the captured AdamW follows through its device-resident factor
+    sched.step()
+    opt.step()
+    assert abs(float(opt.engine.opt.lr_scale) - 0.1) < 1e-7

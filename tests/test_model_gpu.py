@@ -471,7 +471,7 @@ def test_retrieval_augmentation_block_matches_reference(golden):
 
     g = golden("retrieval_augment.npz")
     shapes = dict(ref_shapes("retrieval_augment_state_shapes.json"))
-    m = RetrievalAugmentation(d_model=256, dataset_name="pku", top_k=16, num_classes=3, max_seq_length=10, use_reference_image=False)
+    m = RetrievalAugmentation(d_model=256, dataset_name="pku", top_k=16, num_classes=3, max_seq_length=10, use_reference_image=False, pretrained=False)
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == shapes     # state_dict layout of the reference module
     m.load_state_dict(det_state_dict(shapes), strict=True)
     m = m.cuda().eval()

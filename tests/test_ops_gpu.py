@@ -262,6 +262,33 @@ def test_attention(dtype, B, H, Sq, Sk, dh, causal, pad):
     close(dq, q.grad, dtype, **tol); close(dk, k.grad, dtype, **tol); close(dv, v.grad, dtype, **tol)
 
 
+def test_attention_backward_padded_key_with_a_huge_score():
+    """one-pass backward (S = 256: the image encoder's shape): a PADDED key whose score exceeds the row's log-sum-exp by more than 128 in
+    the log2 domain makes exp2 overflow; its probability must be an exact zero (0 * inf would be NaN in dQ / dK / dV of the whole head)"""
+    from ralf_amd import ops
+
+    B, H, S, dh = 2, 8, 256, 32
+    d = H * dh
+    q, k, v = (rnd(B, S, d, seed=s, dtype=torch.bfloat16).float() for s in (60, 61, 62))
+    k[0, 7] = q[0].mean(0) * 0 + 60.0 * torch.sign(q[0, 3])     # key 7 of sample 0: score ~ 60 * |q|_1 * dh^-0.5 >> every other score
+    q, k, v = (t.requires_grad_(True) for t in (q, k, v))
+    kpm = torch.zeros(B, S, dtype=torch.bool); kpm[0, 7] = True; kpm[1, 200:] = True
+    o = ref_attention(q, k, v, H, False, kpm, dh ** -0.5)
+    go = rnd(B, S, d, seed=63, dtype=torch.bfloat16).float()
+    o.backward(go)
+    dev = lambda t: t.detach().to(torch.bfloat16).cuda()
+    qd, kd, vd = dev(q), dev(k), dev(v)
+    kp = kpm.to(torch.uint8).cuda()
+    od, lse = ops.attention_fwd(qd, kd, vd, B, H, S, S, dh, kpm=kp)
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    ops.attention_bwd(dev(go), qd, kd, vd, od, lse, dq, dk, dv, B, H, S, S, dh, kpm=kp)
+    for t in (od, dq, dk, dv):
+        assert torch.isfinite(t.float()).all()
+    tol = dict(atol=5e-2, rtol=5e-2)
+    close(od, o.detach(), torch.bfloat16)
+    close(dq, q.grad, torch.bfloat16, **tol); close(dk, k.grad, torch.bfloat16, **tol); close(dv, v.grad, torch.bfloat16, **tol)
+
+
 def test_attention_packed_qkv_and_dropout():
     """self-attention on a packed [B,S,3d] buffer; dropout backward consistent with forward (finite differences)."""
     from ralf_amd import ops
