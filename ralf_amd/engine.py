@@ -249,11 +249,13 @@ def complement_ranges(ranges, total: int):
     return out
 
 
-def _clone_tree(x):
+def _clone_tree(x, device=None):
+    """private copies of all tensors of a tree; with `device`: ON that device (the unchanged reference loop leaves the nested
+    `retrieved` dict on the host, train/train.py:434-439 -- a captured graph cannot hold a host-to-device copy)"""
     if torch.is_tensor(x):
-        return x.clone()
+        return x.clone() if (device is None or x.device == device) else x.to(device)
     if isinstance(x, dict):
-        return {k: _clone_tree(v) for k, v in x.items()}
+        return {k: _clone_tree(v, device) for k, v in x.items()}
     return x
 
 
@@ -433,7 +435,7 @@ class TrainStep:
         rt.weights_changed()
 
     def _capture(self, inputs, targets):
-        self._static = _clone_tree({"inputs": inputs, "targets": targets})
+        self._static = _clone_tree({"inputs": inputs, "targets": targets}, self.model.device)
         si, st = self._static["inputs"], self._static["targets"]
         # the warm-up steps (allocator, lazy inits, LDS attributes) must not train: the state they touch is put back, so the
         # first graphed call is exactly ONE optimisation step, like use_graph=False and like the reference's loop

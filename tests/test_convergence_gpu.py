@@ -1,0 +1,112 @@
+"""GPU: parity of TRAINING, not of one step (train/train.py:409-489 with config/experiment/ralf.yaml:11-18: lr 1e-4, clip 0.1,
+weight decay 1e-4, backbone lr x 0.1).
+
+(1) bf16 throughput mode against fp32 parity mode over a few hundred optimisation steps on a fixed learnable synthetic set, plain
+    initialisation, dropout on, same seeds: both loss curves fall and stay inside a stated band of each other.
+(2) the fp32 HIP step against the CPU oracle (functional restatement + torch autograd + torch AdamW) for the first 20 steps at a tiny
+    size, dropout off, batch-statistics BatchNorm: the curves coincide.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+import bench
+from conftest import GOLDEN
+from oracle import ralf_oracle as O
+from oracle.detweights import det_state_dict, resnet50_fpn_shapes
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+STEPS, SET, B, N, HW = 320, 512, 64, 10, 128   # 40 epochs over 8 batches; 128x128 canvases bound the fp32 run (the whole test ~ 60 s)
+BAND = 0.04        # |smoothed bf16 loss / smoothed fp32 loss - 1| at every step of the run
+FALL = 0.80        # both runs end below FALL x their first loss
+
+
+def _curve(dtype, batches, steps=STEPS):
+    from ralf_amd.engine import TrainStep
+    from ralf_amd.synthetic import to_device
+
+    model = bench.build_model(torch.device(DEV), N, dtype)   # torch.manual_seed(0) inside: the same plain initialisation in both modes
+    dev_batches = []
+    for b in batches:
+        inputs, targets = model.preprocess(b)
+        inputs, targets = to_device(inputs, DEV), to_device(targets, DEV)
+        inputs["retrieved"] = {k: v for k, v in inputs["retrieved"].items() if k != "image"}
+        dev_batches.append((inputs, targets))
+    step = TrainStep(model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, use_graph=True)
+    losses = []
+    for i in range(steps):
+        inputs, targets = dev_batches[i % len(dev_batches)]
+        losses.append(step(inputs, targets).clone())
+    torch.cuda.synchronize()
+    out = torch.stack(losses).float().cpu()
+    del step, model
+    return out
+
+
+def _smooth(x, w=16):
+    c = torch.cumsum(torch.cat([torch.zeros(1), x]), 0)
+    return (c[w:] - c[:-w]) / w
+
+
+def test_bf16_training_tracks_fp32_training_for_320_steps():
+    from ralf_amd.synthetic import make_learnable_set
+
+    batches = make_learnable_set(SET, B, N, H=HW, W=HW)
+    l32 = _curve("float32", batches)
+    l16 = _curve("bfloat16", batches)
+    assert torch.isfinite(l32).all() and torch.isfinite(l16).all()
+    s32, s16 = _smooth(l32), _smooth(l16)
+    rel = (s16 / s32 - 1).abs()
+    report = {"first": (l32[0].item(), l16[0].item()), "last16_mean": (s32[-1].item(), s16[-1].item()), "max_rel_gap": rel.max().item(),
+              "at_step": int(rel.argmax())}
+    print("convergence:", json.dumps(report))
+    assert abs(l16[0].item() - l32[0].item()) < 2e-2, report                      # same weights, same batch, same dropout masks
+    assert s32[-1] < FALL * l32[0] and s16[-1] < FALL * l16[0], report            # both train
+    assert rel.max().item() < BAND, report                                          # and stay together all the way
+
+
+def test_fp32_training_equals_the_cpu_oracle_for_20_steps():
+    from ralf_amd.engine import TrainStep
+    from ralf_amd.helpers.layout_tokenizer import LabelFeature, LayoutSequenceTokenizer
+    from ralf_amd.models.generator import ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg as RALF
+    from ralf_amd.synthetic import make_learnable_set, to_device
+
+    labels = ["text", "logo", "underlay"]
+    tok = LayoutSequenceTokenizer(labels, N)
+    model = RALF(features={"label": LabelFeature(labels)}, tokenizer=tok, dataset_name="pku", max_seq_length=N, top_k=16, retrieval_backbone="dreamsim",
+                 saliency_k="None", auxilary_task="uncond", compute_dtype="float32", pretrained=False)
+    with open(os.path.join(GOLDEN, "ralf_state_shapes.json")) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f)["shapes"].items()}
+    shapes.update(resnet50_fpn_shapes())
+    sd = det_state_dict(shapes)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()
+    model.rt.drop_p = lambda p: 0.0                        # dropout off on both sides; BatchNorm on batch statistics
+    batches = make_learnable_set(4, 2, N, H=64, W=96, seed=3)
+    host = [model.preprocess(b) for b in batches]
+    # oracle side: the functional restatement under torch autograd, the reference's optimizer set-up (train/train.py:217-223, 449-454)
+    names = {id(p): n for n, p in model.named_parameters()}
+    groups_o, params_o = [], []
+    for g in model.optim_groups(base_lr=1e-4, weight_decay=1e-4, custom_lr={"encoder.extractor.body": 1e-5}):
+        ps = [sd[names[id(p)]].requires_grad_(True) for p in g["params"]]
+        params_o += ps
+        groups_o.append({"params": ps, "lr": g["lr"], "weight_decay": g["weight_decay"]})
+    opt = torch.optim.AdamW(groups_o)
+    step = TrainStep(model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, use_graph=False)
+    lo, lh = [], []
+    for i in range(20):
+        inputs, targets = host[i % len(host)]
+        opt.zero_grad(set_to_none=True)
+        loss = O.xent_label_smoothing(O.ralf_forward(sd, inputs, training_bn=True, p_drop=0.0), targets["seq"], tok.name_to_id("pad"))
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params_o, 0.1)
+        opt.step()
+        lo.append(loss.item())
+        di, dt = to_device(inputs, DEV), to_device(targets, DEV)
+        lh.append(step(di, dt).item())
+    gap = max(abs(a - b) for a, b in zip(lo, lh))
+    assert lo[-1] < lo[0] - 0.05 and gap < 2e-3, (lo, lh)

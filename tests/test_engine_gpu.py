@@ -281,10 +281,12 @@ def test_unchanged_reference_loop_reaches_the_graph_through_graphed_adamw(golden
     opt = GraphedAdamW(params=groups, weight_decay=0.01, max_norm=0.1)   # instantiate(cfg.optimizer)(params=...) with the override
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[1], gamma=0.1)
     step = TrainStep(m2, lr=1e-4, weight_decay=1e-4, max_norm=0.1, use_graph=True)
+    # train/train.py:434-439 moves only top-level tensors to the device: the nested `retrieved` dict arrives on the HOST
+    loop_inputs = dict(inputs, retrieved={k: v.cpu() for k, v in inputs["retrieved"].items()})
     la, lb = [], []
     for it in range(4):
         m1.zero_grad()
-        out, losses = m1.train_loss(inputs, tgt)
+        out, losses = m1.train_loss(loop_inputs, tgt)
         loss = sum(losses.values())
         loss.backward()
         total = torch.nn.utils.clip_grad_norm_(m1.parameters(), 0.1)
