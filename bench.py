@@ -246,7 +246,8 @@ def bench_reference_loop(device, N, B, dtype, steps):
 
     out = {}
     for name, make_opt in (("eager_torch_adamw", lambda groups: torch.optim.AdamW(params=groups, weight_decay=0.01)),
-                           ("graphed_adamw", lambda groups: GraphedAdamW(params=groups, weight_decay=0.01, max_norm=max_norm))):
+                           ("graphed_adamw", lambda groups: GraphedAdamW(params=groups, weight_decay=0.01, max_norm=max_norm)),
+                           ("graphed_adamw_loss_lag1", lambda groups: GraphedAdamW(params=groups, weight_decay=0.01, max_norm=max_norm, loss_lag=1))):
         model = build_model(device, N, dtype)
         opt = make_opt(model.optim_groups(base_lr=lr, weight_decay=0.01, custom_lr={"encoder.extractor.body": lr * 0.1}))
         for i in range(3):

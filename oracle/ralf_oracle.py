@@ -217,6 +217,15 @@ RESNET50_STAGES = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))  # (planes
 def resnet50_fpn(img: Tensor, sd: SD, p: str = "encoder.extractor", training: bool = False) -> Tensor:
     """ResnetBackbone.forward (common/image.py:90-120): 4-channel stem, ResNet-v1.5 bottlenecks
     (stride on the 3x3), taps at layer3/layer4, FPN fuse, 1x1 proj. img [B,4,H,W] -> [B,256,H/16,W/16]."""
+    feats = resnet50_body(img, sd, p, training)
+    return fpn_fuse(feats[3], feats[4], sd, p)
+
+
+def resnet50_body(img: Tensor, sd: SD, p: str = "encoder.extractor", training: bool = False) -> Dict[int, Tensor]:
+    """the body alone (what create_feature_extractor(timm resnet50, {layer3, layer4}) returns, common/image.py:39-67): stage outputs
+    {1..4}.  timm / torchvision are absent here; CROSS-CHECKED against an independent implementation of the same published architecture,
+    transformers.ResNetModel(layer_type="bottleneck", downsample_in_bottleneck=False) = ResNet-v1.5 (tests/golden/resnet_body_hf.npz,
+    tests/golden/make_golden.py: golden_resnet_body_hf) -- not a pin to timm itself, but no reading of the architecture shared with this file."""
     b = p + ".body"
     x = F.conv2d(img, sd[b + ".conv1.weight"], None, 2, 3)
     x = torch.relu(_bn(x, sd, b + ".bn1", training))
@@ -234,7 +243,7 @@ def resnet50_fpn(img: Tensor, sd: SD, p: str = "encoder.extractor", training: bo
                 idn = _bn(F.conv2d(x, sd[q + ".downsample.0.weight"], None, s), sd, q + ".downsample.1", training)
             x = torch.relu(y + idn)
         feats[li] = x
-    return fpn_fuse(feats[3], feats[4], sd, p)
+    return feats
 
 
 def stem_weight_4ch(w3: Tensor) -> Tensor:

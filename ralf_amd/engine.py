@@ -497,7 +497,8 @@ class GraphedAdamW(torch.optim.Optimizer):
     constructor keyword here; `step()` only follows the learning-rate schedule.  `evaluate()` (eval mode, no_grad) takes the ordinary
     forward.  lr / weight_decay per group come from `model.optim_groups`, exactly as with torch's AdamW."""
 
-    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, max_norm: float = 0.0, **step_kw):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, max_norm: float = 0.0,
+                 loss_lag: int = 0, **step_kw):
         groups = [dict(g) for g in params]
         tokens = {g.get("ralf_model") for g in groups}
         assert len(tokens) == 1 and None not in tokens, "GraphedAdamW takes the groups returned by a ralf_amd generator's optim_groups()"
@@ -511,6 +512,12 @@ class GraphedAdamW(torch.optim.Optimizer):
         self.engine = TrainStep(model, max_norm=max_norm, betas=betas, eps=eps, use_graph=True,
                                 groups=[{"params": g["params"], "lr": g["lr"], "weight_decay": g["weight_decay"]} for g in self.param_groups], **step_kw)
         self._detached = False
+        # loss_lag = 1 (opt-in): train_loss hands back the PREVIOUS step's loss as a host scalar, so the loop's `loss.cpu().item()`
+        # (train/train.py:456) does not wait for the replay it has just enqueued and the host prepares batch i + 1 while the GPU runs step i.
+        # The logged curve is shifted by one iteration; the training itself is unchanged.  0 (default): the loop's exact behaviour.
+        self.loss_lag = int(loss_lag)
+        assert self.loss_lag in (0, 1)
+        self._prev = None
         model._engine = self
 
     def train_step(self, inputs, targets):
@@ -520,6 +527,16 @@ class GraphedAdamW(torch.optim.Optimizer):
                 for p in g["params"]:
                     p.grad = None
             self._detached = True
+        if self.loss_lag:
+            host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+            host.copy_(loss.reshape(1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            prev, self._prev = self._prev, (host, ev)
+            if prev is None:
+                prev = (host, ev)          # first call: nothing older to report
+            prev[1].synchronize()          # (the replay BEFORE the one just enqueued: long finished)
+            return self.engine.outputs, {"nll_loss": prev[0].reshape(()).clone().requires_grad_()}
         return self.engine.outputs, {"nll_loss": loss.clone().requires_grad_()}
 
     def zero_grad(self, set_to_none: bool = True):   # the captured step zeroes its gradient buffer itself

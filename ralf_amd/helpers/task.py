@@ -160,6 +160,28 @@ def _sample_ids(batch):
         return ids
 
 
+_PINNED: dict = {}
+
+
+def cat_image(image: torch.Tensor, saliency: torch.Tensor) -> torch.Tensor:
+    """torch.cat([image, saliency], dim=1) (helpers/task.py:78-80 of the reference).  On a GPU box the 4-channel batch (67 MB at B = 64,
+    256 x 256) is assembled in a page-locked staging buffer by two multi-threaded slice copies: the loop's `.to(rank)` (train/train.py:434)
+    is then one DMA at PCIe rate instead of a pageable copy, and the single-threaded cat (10-13 ms of a 15 ms step) is gone.  Three
+    buffers rotate, so a batch stays valid while the next two are being built."""
+    if not (image.device.type == "cpu" and saliency.device.type == "cpu" and image.numel() >= (1 << 20) and torch.cuda.is_available()):
+        return torch.cat([image, saliency], dim=1)
+    B, C, H, W = image.shape
+    key = (B, C + saliency.size(1), H, W, image.dtype)
+    ring = _PINNED.setdefault(key, {"bufs": [], "i": 0})
+    if len(ring["bufs"]) < 3:
+        ring["bufs"].append(torch.empty(key[:4], dtype=image.dtype, pin_memory=True))
+    buf = ring["bufs"][ring["i"] % len(ring["bufs"])]
+    ring["i"] += 1
+    buf[:, :C].copy_(image)
+    buf[:, C:].copy_(saliency)
+    return buf
+
+
 def get_condition(batch: dict, cond_type: Optional[str] = None, tokenizer=None):
     """(condition container, batch) for `cond_type` -- same contract as image2layout/train/helpers/task.py:45-183: `seq` holds
     the known tokens with the blank id (-1 / [MASK]) where the model must generate, `mask` is True on known and special
@@ -167,7 +189,7 @@ def get_condition(batch: dict, cond_type: Optional[str] = None, tokenizer=None):
     assert cond_type in COND_TYPES
     if tokenizer is None:
         return batch, batch
-    image = batch["image"] if batch["image"].size(1) == 4 else torch.cat([batch["image"], batch["saliency"]], dim=1)
+    image = batch["image"] if batch["image"].size(1) == 4 else cat_image(batch["image"], batch["saliency"])
     fields = _CONDITION_BUILDERS[cond_type](tokenizer.encode(batch), batch, tokenizer)
     fields = dict(fields, id=_sample_ids(batch))
     container = ConditionalInputsForDiscreteLayout

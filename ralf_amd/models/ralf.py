@@ -23,7 +23,7 @@ from .. import nn as RN
 from .. import ops
 from ..functional import Runtime
 from ..helpers.sampling import DECODE_SPACE_RESTRICTION, _get, forced_tokens_all, sample as sample_tokens
-from ..helpers.task import COND_TYPES, get_condition
+from ..helpers.task import COND_TYPES, cat_image, get_condition
 from ..helpers.task_preprocessor import PREPROCESSOR
 
 logger = logging.getLogger(__name__)
@@ -562,7 +562,7 @@ class ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg(_GeneratorBas
         cond, inputs = get_condition(inputs, self.auxilary_task, self.tokenizer)
         seqc = self.preprocessor(cond)
         data = self.tokenizer.encode(inputs)
-        image = cond.image if torch.is_tensor(getattr(cond, "image", None)) and cond.image.size(1) == 4 else torch.cat([inputs["image"], inputs["saliency"]], dim=1)   # (get_condition already built the 4-channel image: 67 MB per batch)
+        image = cond.image if torch.is_tensor(getattr(cond, "image", None)) and cond.image.size(1) == 4 else cat_image(inputs["image"], inputs["saliency"])   # (get_condition already built the 4-channel image: 67 MB per batch)
         assert inputs["retrieved"]["image"].size(2) == 4
         _inputs = {"seq": data["seq"][:, :-1], "tgt_key_padding_mask": ~data["mask"][:, :-1], "image": image,
                    "retrieved": inputs["retrieved"], "seq_layout_const": seqc["seq"], "seq_layout_const_pad_mask": seqc["pad_mask"]}
@@ -618,7 +618,7 @@ class ConcateAuxilaryTaskAutoreg(_GeneratorBase):
         cond, inputs = get_condition(inputs, self.auxilary_task, self.tokenizer)
         seqc = self.preprocessor(cond)
         data = self.tokenizer.encode(inputs)
-        image = cond.image if torch.is_tensor(getattr(cond, "image", None)) and cond.image.size(1) == 4 else torch.cat([inputs["image"], inputs["saliency"]], dim=1)   # (get_condition already built the 4-channel image: 67 MB per batch)
+        image = cond.image if torch.is_tensor(getattr(cond, "image", None)) and cond.image.size(1) == 4 else cat_image(inputs["image"], inputs["saliency"])   # (get_condition already built the 4-channel image: 67 MB per batch)
         _inputs = {"seq": data["seq"][:, :-1], "tgt_key_padding_mask": ~data["mask"][:, :-1], "image": image,
                    "seq_layout_const": seqc["seq"], "seq_layout_const_pad_mask": seqc["pad_mask"]}
         return _inputs, {"seq": data["seq"][:, 1:]}

@@ -612,6 +612,11 @@ class ResnetBackbone(nn.Module):
         ops.bn_fold_batched(self._fold_state[1], self._fold_state[3])
 
     def forward(self, img: torch.Tensor, rt: Runtime) -> torch.Tensor:
+        lat3, layer4 = self.body_features(img, rt)
+        return self.fpn(lat3, layer4, rt)
+
+    def body_features(self, img: torch.Tensor, rt: Runtime):
+        """the body's two taps (common/image.py:66-67,96-97: layer3, layer4) as NHWC maps; the layer3 map is the alias the FPN lateral reads"""
         B, C, H, W = img.shape
         assert C == 4
         # NCHW fp32 [B,4,H,W] -> NHWC compute dtype, channels zero-padded to 8 (16-byte pixel vectors)
@@ -642,7 +647,7 @@ class ResnetBackbone(nn.Module):
             if li == 2:   # data parallel: stem + layer1-2 hold 6 % of the parameters and most of the backbone's backward time
                 x = rt.grad_cut(x)
             feats[li] = x
-        return self.fpn(lat3 if lat3 is not None else feats[3], feats[4], rt)
+        return (lat3 if lat3 is not None else feats[3]), feats[4]
 
     def fpn(self, layer3: torch.Tensor, layer4: torch.Tensor, rt: Runtime) -> torch.Tensor:
         """FPN fuse + projection (common/image.py:99-111) on NHWC maps -> [B, h*w, d] with the 2-D sine table added."""

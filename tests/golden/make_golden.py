@@ -656,6 +656,63 @@ def golden_backbone_wrapper():
     save("backbone_wrapper.npz", out)
 
 
+def golden_resnet_body_hf():
+    """independent check of the ResNet-50 BODY (timm ^0.9.5 / torchvision are absent, so the body cannot be run from the reference):
+    transformers' ResNetModel with layer_type="bottleneck", depths [3, 4, 6, 3], downsample_in_bottleneck=False is the same published
+    architecture (ResNet-v1.5: stride on the 3x3) written by other people.  The deterministic body weights of oracle/detweights.py are
+    mapped into it key by key; recorded: the layer3 / layer4 maps (the two taps of common/image.py:66-67) and gradients, with running
+    statistics (eval) and with batch statistics (train), on a 96 x 128 canvas."""
+    from oracle.detweights import resnet50_fpn_shapes
+
+    # (the stub modules that stand in for the reference's absent imports have no __spec__, which transformers' availability probe trips over)
+    stubs = {k: sys.modules.pop(k) for k in list(sys.modules) if k.split(".")[0] in ("torchvision", "timm")}
+    try:
+        from transformers import ResNetConfig, ResNetModel
+        ResNetModel(ResNetConfig(depths=[1, 1, 1, 1]))   # resolve the lazy imports now
+    finally:
+        sys.modules.update(stubs)
+    cfg = ResNetConfig(num_channels=4, embedding_size=64, hidden_sizes=[256, 512, 1024, 2048], depths=[3, 4, 6, 3], layer_type="bottleneck",
+                       hidden_act="relu", downsample_in_bottleneck=False)
+    hf = ResNetModel(cfg)
+    pre = "encoder.extractor.body."
+    det = det_state_dict({k: v for k, v in resnet50_fpn_shapes().items() if k.startswith(pre)})
+
+    def hf_key(k):   # torchvision / timm naming -> transformers naming
+        parts = k[len(pre):].split(".")
+        if parts[0] in ("conv1", "bn1"):
+            return "embedder.embedder." + ("convolution." if parts[0] == "conv1" else "normalization.") + parts[-1]
+        stage, blk, mod = int(parts[0][5:]) - 1, int(parts[1]), parts[2]
+        base = f"encoder.stages.{stage}.layers.{blk}."
+        if mod == "downsample":
+            return base + "shortcut." + ("convolution." if parts[3] == "0" else "normalization.") + parts[-1]
+        return base + f"layer.{int(mod[-1]) - 1}." + ("convolution." if mod.startswith("conv") else "normalization.") + parts[-1]
+
+    mapped = {hf_key(k): v.clone() for k, v in det.items()}
+    assert set(mapped) == set(hf.state_dict()), sorted(set(mapped) ^ set(hf.state_dict()))[:6]
+    hf.load_state_dict(mapped, strict=True)
+    assert sum(p.numel() for p in hf.parameters()) - 64 * 7 * 7 == 23508032, "ResNet-50 body: 23 508 032 parameters with the 3-channel stem"
+    g = torch.Generator().manual_seed(41)
+    img = torch.rand(2, 4, 96, 128, generator=g)
+    go3, go4 = torch.randn(2, 1024, 6, 8, generator=g) * 0.1, torch.randn(2, 2048, 3, 4, generator=g) * 0.1
+    keys = ["conv1.weight", "bn1.weight", "layer1.0.conv1.weight", "layer1.0.downsample.0.weight", "layer1.2.bn3.bias", "layer2.0.conv2.weight",
+            "layer2.3.conv3.weight", "layer3.0.downsample.1.weight", "layer3.5.conv2.weight", "layer4.0.conv1.weight", "layer4.2.conv3.weight", "layer4.2.bn3.weight"]
+    named = dict(hf.named_parameters())
+    # (img / go3 / go4 are regenerated from the seed by the tests, like the injected maps of golden_backbone_wrapper; the maps are stored thinned)
+    out = {"seed": torch.tensor(41)}
+    for mode in ("eval", "train"):
+        hf.train(mode == "train")
+        hf.zero_grad()
+        x = img.clone().requires_grad_(True)
+        hs = hf(x, output_hidden_states=True).hidden_states
+        l3, l4 = hs[3], hs[4]
+        ((l3 * go3).sum() + (l4 * go4).sum()).backward()
+        out[mode] = {"layer3": l3.flatten()[::5], "layer4": l4.flatten()[::3], "g_img": x.grad.clone(), "grads": {k: named[hf_key(pre + k)].grad.clone() for k in keys}}
+        if mode == "train":   # the running statistics after ONE training forward (momentum 0.1, unbiased variance)
+            sd1 = hf.state_dict()
+            out[mode]["running"] = {k: sd1[hf_key(pre + k)].clone() for k in ("bn1.running_mean", "layer2.0.bn2.running_var", "layer4.2.bn3.running_mean")}
+    save("resnet_body_hf.npz", out)
+
+
 def golden_e2e_cgl():
     """BASELINE config 3's model: the CGL label set (4 labels -> V = 519, Vc = 549, 4-row layout-encoder label table;
     helpers/layout_tokenizer.py:253-274).  train_loss + gradients (task c) and deterministic sample() tokens (task cwh)."""
@@ -715,9 +772,9 @@ def golden_e2e_cgl():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tokenizer", "host", "modules", "e2e", "sample", "reranker", "relation", "retrieval_augment", "backbone_wrapper", "e2e_cgl"]
+    which = sys.argv[1:] or ["tokenizer", "host", "modules", "e2e", "sample", "reranker", "relation", "retrieval_augment", "backbone_wrapper", "e2e_cgl", "resnet_body_hf"]
     fns = {"tokenizer": golden_tokenizer, "host": golden_host_path, "modules": golden_modules, "e2e": golden_e2e, "sample": golden_sample,
            "reranker": golden_reranker, "relation": golden_relation, "retrieval_augment": golden_retrieval_augment,
-           "backbone_wrapper": golden_backbone_wrapper, "e2e_cgl": golden_e2e_cgl}
+           "backbone_wrapper": golden_backbone_wrapper, "e2e_cgl": golden_e2e_cgl, "resnet_body_hf": golden_resnet_body_hf}
     for w in which:
         fns[w]()

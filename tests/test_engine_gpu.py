@@ -311,3 +311,29 @@ def test_unchanged_reference_loop_reaches_the_graph_through_graphed_adamw(golden
     sched.step()
     opt.step()
     assert abs(float(opt.engine.opt.lr_scale) - 0.1) < 1e-7
+
+
+def test_graphed_adamw_loss_lag_reports_the_previous_step(golden):
+    """optimizer.loss_lag=1: train_loss returns the previous replay's loss as a host scalar (no wait for the replay just enqueued); the training
+    itself is the lag-0 training"""
+    from ralf_amd.engine import GraphedAdamW
+
+    curves = []
+    for lag in (0, 1):
+        m, inputs, tgt = make(golden, "bfloat16")
+        m.train()
+        m.rt.drop_p = lambda p: 0.0
+        opt = GraphedAdamW(params=m.optim_groups(base_lr=1e-4, weight_decay=1e-4), max_norm=0.1, loss_lag=lag)
+        ls = []
+        for _ in range(5):
+            m.zero_grad()
+            _, losses = m.train_loss(inputs, tgt)
+            loss = sum(losses.values())
+            loss.backward()
+            opt.step()
+            ls.append(loss.cpu().item())
+        torch.cuda.synchronize()
+        curves.append((ls, opt.engine.opt.P.clone()))
+    (l0, p0), (l1, p1) = curves
+    assert abs(l1[0] - l0[0]) < 2e-3 and all(abs(a - b) < 2e-3 for a, b in zip(l1[1:], l0[:-1])), (l0, l1)
+    assert (p0 - p1).abs().max().item() <= 8e-4

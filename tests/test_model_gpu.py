@@ -485,3 +485,39 @@ def test_retrieval_augmentation_block_matches_reference(golden):
     for k, want in g.sub("grads").items():
         torch.testing.assert_close(thin(named[k].grad).cpu(), want, atol=5e-4, rtol=3e-3, msg=lambda m, k=k: f"{k}: {m}")
     assert all(p.grad is None for p in m.layout_encoder.parameters())           # frozen
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_resnet_body_hip_against_an_independent_implementation(golden, mode):
+    """a1 body on the HIP path (fp32 parity mode) against vectors recorded from transformers.ResNetModel (ResNet-50 v1.5) carrying the same
+    deterministic weights: layer3 / layer4 taps, image and weight gradients, running statistics after one training forward"""
+    from test_oracle_golden import hf_body_inputs, thin
+
+    z = golden("resnet_body_hf.npz")
+    r = z.sub(mode)
+    img, go3, go4 = hf_body_inputs(int(z["seed"]))
+    sd = det_state_dict(resnet50_fpn_shapes())
+    bb = RN.ResnetBackbone(256)
+    bb.load_state_dict({k[len("encoder.extractor."):]: v.clone() for k, v in sd.items()}, strict=True)
+    bb = bb.cuda()
+    rt = RN.Runtime(torch.float32).to(torch.device("cuda"))
+    rt.training = mode == "train"
+    x = img.cuda().requires_grad_(True)
+    l3, l4 = bb.body_features(x, rt)                       # NHWC
+    l3c, l4c = l3.permute(0, 3, 1, 2), l4.permute(0, 3, 1, 2)
+    tol = dict(atol=2e-3, rtol=2e-3) if mode == "train" else dict(atol=2e-4, rtol=2e-4)   # (batch statistics over 24-96 samples amplify summation-order noise)
+    torch.testing.assert_close(l3c.detach().cpu().flatten()[::5], r["layer3"], **tol)
+    torch.testing.assert_close(l4c.detach().cpu().flatten()[::3], r["layer4"], **tol)
+    ((l3c * go3.cuda()).sum() + (l4c * go4.cuda()).sum()).backward()
+    named = dict(bb.body.named_parameters())
+    got = {"g_img": x.grad, **{k: named[k].grad for k in r["grads"]}}
+    want = {"g_img": r["g_img"], **r["grads"]}
+    for k, w in want.items():
+        gk = thin(got[k].detach().cpu())
+        cos = torch.nn.functional.cosine_similarity(gk.flatten(), w.flatten(), dim=0).item()
+        ratio = (gk.norm() / w.norm()).item()
+        assert cos > (0.98 if mode == "train" else 0.9999) and abs(ratio - 1) < (0.05 if mode == "train" else 2e-3), (k, cos, ratio)
+    if mode == "train":
+        bufs = dict(bb.body.named_buffers())
+        for k, w in r["running"].items():
+            torch.testing.assert_close(bufs[k].cpu(), w, atol=1e-5, rtol=1e-3)

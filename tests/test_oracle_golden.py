@@ -192,3 +192,33 @@ def test_ralf_cgl_e2e(golden):
     close(gs[0], r["gfeat"], atol=1e-6)
     for k, g in zip(ks, gs[1:]):
         close(thin(g), r["grads"][k], atol=2e-6, rtol=2e-3)
+
+
+def hf_body_inputs(seed):
+    """img / output gradients of tests/golden/make_golden.py: golden_resnet_body_hf, regenerated from the seed"""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(2, 4, 96, 128, generator=g)
+    return img, torch.randn(2, 1024, 6, 8, generator=g) * 0.1, torch.randn(2, 2048, 3, 4, generator=g) * 0.1
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_resnet_body_against_an_independent_implementation(golden, mode):
+    """a1 body: the oracle's restatement of ResNet-50 v1.5 against transformers.ResNetModel (bottleneck, downsample_in_bottleneck=False)
+    carrying the same deterministic weights -- layer3 / layer4 maps and gradients, on running and on batch statistics.  Not a pin to timm
+    (absent), but a second reading of the published architecture that shares nothing with oracle/ralf_oracle.py."""
+    z = golden("resnet_body_hf.npz")
+    r = z.sub(mode)
+    img, go3, go4 = hf_body_inputs(int(z["seed"]))
+    sd = det_state_dict({k: v for k, v in resnet50_fpn_shapes().items() if ".body." in k})
+    for k, v in sd.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+    x = img.clone().requires_grad_(True)
+    f = O.resnet50_body(x, sd, training=(mode == "train"))
+    close(f[3].flatten()[::5], r["layer3"], atol=2e-5, rtol=2e-4)
+    close(f[4].flatten()[::3], r["layer4"], atol=2e-5, rtol=2e-4)
+    ks = list(r["grads"].keys())
+    gs = torch.autograd.grad((f[3] * go3).sum() + (f[4] * go4).sum(), [x] + [sd["encoder.extractor.body." + k] for k in ks])
+    close(thin(gs[0]), r["g_img"], atol=1e-5, rtol=2e-3)
+    for k, g in zip(ks, gs[1:]):
+        close(thin(g), r["grads"][k], atol=5e-5, rtol=5e-3)
