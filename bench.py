@@ -258,6 +258,7 @@ def bench_reference_loop(device, N, B, dtype, steps):
             last = loop_body(model, opt, batches[i % 3])
         torch.cuda.synchronize()
         out[name + "_ms"] = (time.perf_counter() - t0) / steps * 1e3
+        out[name + "_tokens_per_s"] = B * (5 * N + 1) / (out[name + "_ms"] * 1e-3)
         out[name + "_loss"] = last
         del opt, model
     out["note"] = ("train/train.py:432-454 verbatim, wall clock per iteration incl. model.preprocess on the host, the pageable H2D of the "
@@ -622,6 +623,9 @@ def main():
                                           "TFLOP": frc / 1e12, "achieved": frc / trc / 1e12, "frac": frc / trc / 1e12 / PEAK_BF16_TFLOPS, "unit": "TFLOP/s"}
             out["relation"] = bench_relation(device, N)
             out["reference_loop_ms"] = bench_reference_loop(device, N, B, a.dtype, min(a.steps, 10))
+            # end-to-end: a fresh host batch per step through model.preprocess and the loop's own .to(device), overlapped with the previous replay
+            out["e2e_tokens_per_s"] = out["reference_loop_ms"]["graphed_adamw_loss_lag1_tokens_per_s"]
+            out["e2e_over_resident"] = out["e2e_tokens_per_s"] / out["value"]
         if world == 1 and not a.skip_cpu:
             out["cpu_baseline"] = cpu_baseline_train(N, B=a.cpu_batch)
             out["cpu_baseline_knn"] = cpu_baseline_knn()

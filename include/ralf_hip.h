@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 15
+#define RALF_ABI_VERSION 16
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -137,6 +137,22 @@ typedef struct RalfGemmDesc {
      * bnb_x: the BatchNorm INPUT x, contiguous [M][N] in the GEMM's dtype.  Needs splitk 1, one batch, N % 64 == 0, a contiguous
      * 16-byte aligned [M][N] output in the GEMM's dtype, epilogue limited to alpha / bias / res / accumulate. */
     const void* bnb_x; const unsigned char* bnb_mask; const float* bnb_mean; float* bnb_part;
+    /* A-operand transform with write-through (at_mode 0 = off): the matrix cores see a'(m, k) = f(A(m, k), ...) instead of A, i.e. the
+     * element-wise kernel that would have produced this GEMM's input runs in its operand loader -- no pass of its own over the tensor:
+     *   at_mode 1  a' = relu?( A * at_c1[k] + at_c2[k] (+ at_a2) )      BatchNorm apply (+ residual, + ReLU) of the consumer's INPUT:
+     *              A = the producing convolution's raw output, c1 / c2 = scale / shift (ralf_bn_stats_from_partials), at_a2 = the
+     *              residual branch or NULL (replaces ralf_bn_apply in front of a 1x1 convolution; torch: F.batch_norm + relu, + add)
+     *   at_mode 2  a' = A * at_c1[k] + (at_a2 * at_c2[k] + at_c3[k])     BatchNorm backward apply on the consumer's OUTPUT GRADIENT:
+     *              A = the masked gradient dz, at_a2 = the BatchNorm input x, c1..c3 from ralf_bn_bwd_stats_from_partials
+     *              (replaces ralf_bn_bwd_apply in front of a 1x1 convolution's data gradient; torch: native_batch_norm_backward)
+     * a' is rounded to bf16 (what the separate kernel would have stored).  The workgroups of the first column tile also store a' to
+     * at_out (layout of A; may be NULL) and, in mode 1 with at_relu, the bits a' > 0 to at_mask (bit (m*K + k) & 7 of byte
+     * (m*K + k) >> 3; may be NULL), so every later reader (weight gradient, residual, BatchNorm backward) finds the tensor and the
+     * mask exactly as the separate kernel leaves them.  Needs bf16, a plain k-contiguous A (no gather) with lda == K on the aligned
+     * interior path, K % 64 == 0, K <= 512, one batch, no split-K; at_a2 / at_out share A's layout and 16-byte alignment. */
+    int at_mode, at_relu;
+    const void* at_a2; const float* at_c1; const float* at_c2; const float* at_c3;
+    void* at_out; unsigned char* at_mask;
 } RalfGemmDesc;
 size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d);
 int ralf_gemm(const RalfGemmDesc* d, void* workspace, size_t workspace_bytes, void* stream);
@@ -214,7 +230,12 @@ int ralf_bn_bwd_reduce(int dtype, const void* x, const void* dy, const void* y, 
 /* the reductions from the partial rows a data-gradient GEMM wrote (RalfGemmDesc.bnb_part, nrows = ceil(M/64)):
  * s1[c] += sum dz, s2[c] += rstd[c] * sum dz*(x - mean) = sum dz*xhat; workspace: 128*2*C floats.  Then ralf_bn_bwd_apply with relu = 0
  * (dz is already masked; the gradient of the residual branch is dz itself). */
-int ralf_bn_bwd_stats_from_partials(const float* partials, int nrows, const float* rstd, float* s1, float* s2, int C, float* workspace, void* stream);
+int ralf_bn_bwd_stats_from_partials(const float* partials, int nrows, const float* rstd, float* s1, float* s2, int C, float* workspace,
+                                    const float* gamma, const float* mean, int64_t M, float* coef, void* stream);
+/* coef (fp32 [3][C], may be NULL; needs gamma, mean, M and s1 / s2 zero on entry): dx = coef[0][c] * dz + coef[1][c] * x + coef[2][c], the whole
+ * backward apply as one per-channel affine map -- applied by ralf_bn_bwd_apply_affine or inside the operand loader of the data-gradient GEMM
+ * that consumes dx (RalfGemmDesc.at_mode 2) */
+int ralf_bn_bwd_apply_affine(int dtype, const void* dz, const void* x, const float* c1, const float* c2, const float* c3, void* dx, int64_t M, int C, void* stream);
 int ralf_bn_bwd_apply(int dtype, const void* x, const void* dy, const void* y, const uint8_t* relu_mask, const float* mean, const float* rstd,
                       const float* gamma, const float* s1, const float* s2, void* dx, void* dres, int64_t M, int C, int relu, void* stream);
 

@@ -74,6 +74,7 @@ class RalfGemmDesc(ctypes.Structure):
         + [("seed", vp), ("call_id", ctypes.c_uint64), ("drop_p", f32), ("atomic_out", i32), ("colstats", vp)]
         + [("sBias0", i64), ("sBk", i64), ("kseg", i32), ("colscale", vp)]
         + [("bnb_x", vp), ("bnb_mask", vp), ("bnb_mean", vp), ("bnb_part", vp)]
+        + [("at_mode", i32), ("at_relu", i32), ("at_a2", vp), ("at_c1", vp), ("at_c2", vp), ("at_c3", vp), ("at_out", vp), ("at_mask", vp)]
     )
 
 
@@ -122,7 +123,8 @@ SIGNATURES.update({
     "ralf_bn_fold_batched": (i32, [vp, i32, f32, vp]),
     "ralf_bn_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "ralf_bn_bwd_reduce": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]),
-    "ralf_bn_bwd_stats_from_partials": (i32, [vp, i32, vp, vp, vp, i32, vp, vp]),
+    "ralf_bn_bwd_stats_from_partials": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, vp, i64, vp, vp]),
+    "ralf_bn_bwd_apply_affine": (i32, [i32, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
     "ralf_bn_bwd_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "ralf_embed_fwd": (i32, [i32, vp, vp, vp, vp, i64, i32, i32, f32, vp]),
     "ralf_embed_bwd": (i32, [i32, vp, vp, vp, i64, i32, f32, vp]),

@@ -142,6 +142,16 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
         P.partial = (float*)workspace;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (d.at_mode) {
+        RALF_REQUIRE(d.at_mode == 1 || d.at_mode == 2, "gemm: at_mode %d", d.at_mode);
+        RALF_REQUIRE(d.dtype == RALF_BF16 && !d.gather && d.a_kcontig && P.fast && d.lda == d.K && d.K <= 512 && nbatch == 1 && d.splitk == 1 && !d.kseg &&
+                     (int64_t)d.M * d.K < (1ll << 31),
+                     "gemm: the operand transform needs bf16, a plain k-contiguous A with lda == K on the aligned path, K %% 64 == 0, K <= 512, one batch, no split-K");
+        RALF_REQUIRE(d.at_c1 && d.at_c2 && (d.at_mode == 1 || (d.at_c3 && d.at_a2)), "gemm: at_mode %d: missing coefficients / second operand", d.at_mode);
+        RALF_REQUIRE((((uintptr_t)d.at_a2 | (uintptr_t)d.at_out) & 15) == 0, "gemm: at_a2 / at_out must be 16-byte aligned");
+        RALF_REQUIRE(!d.C2 && !d.aux && !d.act && d.drop_p == 0.f && !d.atomic_out && !d.colscale, "gemm: the operand transform goes with a plain, column-statistics or bnb_* epilogue");
+        return ralf_gemm_dispatch_at(&P, nbatch, st);
+    }
     int rc = d.dtype == RALF_F32 ? ralf_gemm_dispatch_f32(&P, nbatch, st) : ralf_gemm_dispatch_bf16(&P, nbatch, st);
     if (rc || d.splitk <= 1 || d.atomic_out) return rc;
     const int64_t total = (int64_t)d.M * d.N * nbatch;

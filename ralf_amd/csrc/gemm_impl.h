@@ -414,6 +414,13 @@ __device__ __forceinline__ void lds_stage(T* l, const u32x4 (&regs)[NV], int tid
 // FM, FN: 32x32 fragments per wave along m / n  ->  workgroup tile (64*FM) x (64*FN).
 // NW: waves per workgroup, 4 (2 x 2 waves, FM x FN fragments each) or 8 (2 x 4 waves, FM x FN/2 fragments each; FN = 2 only)
 // LDS bytes of one workgroup: two buffers of operand tiles, re-used as the fp32 C staging tile [64][BN + 4] of the epilogue
+// GATHER 7 / 9 / 8 = the interior fast path (3) with an A-OPERAND TRANSFORM (RalfGemmDesc.at_*): 7 = mode 1 with a second operand (BatchNorm apply +
+// residual), 9 = mode 1 without, 8 = mode 2 (BatchNorm backward apply).  Register-staged only: the transform happens between the global load
+// and the LDS write; its per-channel coefficients sit in LDS behind the operand buffers (read with ds_read: the vector-memory queue keeps
+// nothing but the prefetched tiles, so the prefetch distance survives).
+constexpr int gemm_at_mode(int GATHER) { return (GATHER == 7 || GATHER == 9) ? 1 : GATHER == 8 ? 2 : 0; }
+constexpr int AT_KMAX = 512;                       // channels of the transformed operand (K of the product)
+constexpr int AT_LDS_BYTES = 3 * AT_KMAX * 4;      // c1 | c2 | c3
 template <int GATHER, int FM>
 constexpr int gemm_nbuf() { return GATHER == 6 ? 3 : ((GATHER == 1 || GATHER == 4) && FM == 1) ? 1 : 2; }   // the prefetch-distance-1 kernels keep one buffer
 // GLDS (GATHER 5 / 6): operand tiles go global -> LDS directly (global_load_lds_dwordx4), unpadded images whose 16-byte slots are
@@ -486,6 +493,10 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     const bool b_al = (d.ldb % VEC == 0) && (((uintptr_t)Bp & 15) == 0);
 
     u32x4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];   // two staging register sets: prefetch distance 2 k-tiles
+    u32x4 rc0[NVA], rc1[NVA];                       // (operand transform: the second operand of A's vectors)
+    int at_oo[NVA];                                 // (operand transform: element offset of each staged vector in A / at_a2 / at_out at k = 0)
+    uint32_t at_rowok = 0;                          // bit i: vector i's row lies inside M (write-through)
+    int64_t at_a2d = 0;                             // at_a2 - A in elements
     RowInfo ia[NVA], ib[NVB];
     // PMC (SQ_ACTIVE_INST_ANY ~ 84 % of the kernel, MFMA busy 10 %) showed this kernel is instruction-issue bound:
     // the interior fast path keeps one pointer per staging vector and advances it by a constant per k-tile.
@@ -499,7 +510,10 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     constexpr int SA = BM * 2, SB = BN * 2;
     constexpr int RPCA = 1024 / SA, RPCB = 1024 / SB, LPRA = SA / 16, LPRB = SB / 16;
     auto xkey = [](int S, int k) { return S == 256 ? (k & 3) : ((k >> 1) & 1); };
-    constexpr bool fast = GATHER == 3;   // compile-time: the general loaders (and their RowInfo registers) are not even compiled in
+    constexpr int AT = gemm_at_mode(GATHER);
+    constexpr bool AT2 = GATHER == 7 || GATHER == 8;   // a second operand is staged beside A
+    static_assert(!AT || (AK && sizeof(T) == 2 && !RALF_GEMM_PERSISTENT), "operand transform: bf16, k-contiguous A, one tile per workgroup");
+    constexpr bool fast = GATHER == 3 || AT != 0;   // compile-time: the general loaders (and their RowInfo registers) are not even compiled in
     const T* pa[NVA];
     const T* pb[NVB];
     // LEAN GATHERS.  ISA of the first version (one RowInfo per vector, 64-bit offsets, a division per tap): 90-300 VALU instructions per
@@ -602,6 +616,15 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                 if (d.kseg) pb[i] += (int64_t)(kbeg / d.kseg) * d.sBk;   // segmented K range of B (kbeg is a multiple of the k-tile)
             }
         }
+        if constexpr (AT != 0) {
+            at_a2d = AT2 ? ((const T*)d.at_a2 - (const T*)d.A) : 0;
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                const int v = tid + NT * i, row = m0 + v / KV;
+                at_oo[i] = min(row, d.M - 1) * (int)d.lda + (v % KV) * VEC;   // (M * lda < 2^31: checked at launch)
+                at_rowok |= (uint32_t)(row < d.M) << i;
+            }
+        }
         constexpr bool generic = GATHER == 0 || GATHER == 4;   // (GLDS: neither)
         if (AK && generic) {
 #pragma unroll
@@ -613,11 +636,16 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
         }
     };
     uint32_t okm0 = ~0u, okm1 = ~0u;   // validity bits of the staged vectors of set 0 / 1 (A: bits 0.., B: bits 16..): zeroed at stage time
-    auto gload = [&](u32x4 (&ra)[NVA], u32x4 (&rb)[NVB], int k0, uint32_t& okm) {
+    auto gload = [&](u32x4 (&ra)[NVA], u32x4 (&rb)[NVB], u32x4 (&rc)[NVA], int k0, uint32_t& okm) {
+        (void)rc;
         if constexpr (GLDS) {
             (void)ra; (void)rb; (void)k0; (void)okm;   // (the direct-to-LDS loop below issues its own loads)
         } else if constexpr (fast) {
             (void)okm;
+            if constexpr (AT2) {
+#pragma unroll
+                for (int i = 0; i < NVA; ++i) rc[i] = *reinterpret_cast<const u32x4*>(pa[i] + at_a2d);
+            }
 #pragma unroll
             for (int i = 0; i < NVA; ++i) { ra[i] = *reinterpret_cast<const u32x4*>(pa[i]); pa[i] += stepA; }
 #pragma unroll
@@ -822,7 +850,48 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     // 256-tile launches -- one workgroup per CU, nothing to interleave with -- at 1.2 us per 128x128x64 step, 6x the MFMA time.)
     // Steady state is branch-free (an `if` around a prefetch made the compiler shuttle every accumulator
     // AGPR -> VGPR -> AGPR per iteration); the last 1-4 tiles are peeled.
-    auto stage = [&](T* la, T* lb, u32x4 (&ra)[NVA], u32x4 (&rb)[NVB], uint32_t okm) {
+    auto stage = [&](T* la, T* lb, u32x4 (&ra)[NVA], u32x4 (&rb)[NVB], u32x4 (&rc)[NVA], int k0, uint32_t okm) {
+        (void)rc; (void)k0;
+        if constexpr (AT != 0) {
+            // this thread's 8 channels of the tile (the same for all of its vectors: NT % KV == 0); coefficients from the LDS table
+            constexpr int OPS = gemm_lds_bytes<T, AK, BKC, FM, FN, gemm_nbuf<GATHER, FM>(), false>();
+            const float* lc = reinterpret_cast<const float*>(lds_raw + OPS) + k0 + (tid % KV) * VEC;
+            float c1[8], c2[8], c3[8];
+            { const float4 a = *reinterpret_cast<const float4*>(lc), b = *reinterpret_cast<const float4*>(lc + 4);
+              c1[0] = a.x; c1[1] = a.y; c1[2] = a.z; c1[3] = a.w; c1[4] = b.x; c1[5] = b.y; c1[6] = b.z; c1[7] = b.w; }
+            { const float4 a = *reinterpret_cast<const float4*>(lc + AT_KMAX), b = *reinterpret_cast<const float4*>(lc + AT_KMAX + 4);
+              c2[0] = a.x; c2[1] = a.y; c2[2] = a.z; c2[3] = a.w; c2[4] = b.x; c2[5] = b.y; c2[6] = b.z; c2[7] = b.w; }
+            if constexpr (AT == 2) {
+                const float4 a = *reinterpret_cast<const float4*>(lc + 2 * AT_KMAX), b = *reinterpret_cast<const float4*>(lc + 2 * AT_KMAX + 4);
+                c3[0] = a.x; c3[1] = a.y; c3[2] = a.z; c3[3] = a.w; c3[4] = b.x; c3[5] = b.y; c3[6] = b.z; c3[7] = b.w;
+            }
+            const bool wr = n0 == 0 && d.at_out != nullptr;   // the first column tile leaves the transformed operand (and its ReLU bits) in memory
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                const bf16x8 xv = *reinterpret_cast<const bf16x8*>(&ra[i]);
+                bf16x8 o;
+                uint32_t bits = 0;
+                if constexpr (AT == 1) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        float v = __builtin_fmaf((float)xv[q], c1[q], c2[q]);
+                        if constexpr (AT2) v += (float)(*reinterpret_cast<const bf16x8*>(&rc[i]))[q];
+                        if (d.at_relu) { bits |= (v > 0.f ? 1u : 0u) << q; v = fmaxf(v, 0.f); }
+                        o[q] = (bf16)v;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        o[q] = (bf16)__builtin_fmaf((float)xv[q], c1[q], __builtin_fmaf((float)(*reinterpret_cast<const bf16x8*>(&rc[i]))[q], c2[q], c3[q]));
+                }
+                ra[i] = *reinterpret_cast<const u32x4*>(&o);
+                if (wr && ((at_rowok >> i) & 1u)) {
+                    const int e = at_oo[i] + k0;
+                    *reinterpret_cast<u32x4*>((T*)d.at_out + e) = ra[i];
+                    if (AT == 1 && d.at_relu && d.at_mask) d.at_mask[e >> 3] = (unsigned char)bits;
+                }
+            }
+        }
         if constexpr (!fast) {
 #pragma unroll
             for (int i = 0; i < NVA; ++i) ra[i] = sel_vec((okm >> i) & 1u, ra[i]);
@@ -837,8 +906,18 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     constexpr int PF = ((GATHER == 1 || GATHER == 4) && FM == 1) ? 1 : 2;
     RALF_PROBE(1);
     setup(bid0);
-    gload(ra0, rb0, kbeg, okm0);
-    if (PF == 2 && nt > 1) gload(ra1, rb1, kbeg + BK, okm1);
+    gload(ra0, rb0, rc0, kbeg, okm0);
+    if (PF == 2 && nt > 1) gload(ra1, rb1, rc1, kbeg + BK, okm1);
+    if constexpr (AT != 0) {   // per-channel coefficients -> LDS (behind the first tiles' loads: no latency of their own)
+        constexpr int OPS = gemm_lds_bytes<T, AK, BKC, FM, FN, gemm_nbuf<GATHER, FM>(), false>();
+        float* lc = reinterpret_cast<float*>(lds_raw + OPS);
+        for (int k = tid; k < d.K; k += NT) {
+            lc[k] = d.at_c1[k];
+            lc[AT_KMAX + k] = d.at_c2[k];
+            if constexpr (AT == 2) lc[2 * AT_KMAX + k] = d.at_c3[k];
+        }
+        __syncthreads();
+    }
     for (int bid = bid0;;) {
     const int c_m0 = m0, c_n0 = n0, c_split = split, c_kbeg = kbeg, c_nt = nt;   // the tile being COMPUTED
 #pragma unroll
@@ -893,45 +972,45 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
         }
         compute(la0 + st * STAGE, la0 + st * STAGE + BM * BK);
     } else if constexpr (PF == 1) {   // one LDS buffer (a second one measured 46.6 -> 54.3 us on the layer1 3x3 convolutions)
-        stage(la0, lb0, ra0, rb0, okm0);
+        stage(la0, lb0, ra0, rb0, rc0, c_kbeg, okm0);
         __syncthreads();
         for (int t = 0; t + 1 < c_nt; ++t) {
-            gload(ra0, rb0, c_kbeg + (t + 1) * BK, okm0);
+            gload(ra0, rb0, rc0, c_kbeg + (t + 1) * BK, okm0);
             compute(la0, lb0);
             __syncthreads();
-            stage(la0, lb0, ra0, rb0, okm0);
+            stage(la0, lb0, ra0, rb0, rc0, c_kbeg + (t + 1) * BK, okm0);
             __syncthreads();
         }
         compute(la0, lb0);
     } else {
-        stage(la0, lb0, ra0, rb0, okm0);
-        if (c_nt > 2) gload(ra0, rb0, c_kbeg + 2 * BK, okm0);
+        stage(la0, lb0, ra0, rb0, rc0, c_kbeg, okm0);
+        if (c_nt > 2) gload(ra0, rb0, rc0, c_kbeg + 2 * BK, okm0);
         __syncthreads();
         RALF_PROBE(2);
         // top of an even step t: buffer 0 = tile t, set 1 = tile t+1 and set 0 = tile t+2 (both on their way)
         int t = 0;
         for (; t + 4 < c_nt; t += 2) {
-            stage(la1, lb1, ra1, rb1, okm1);
-            gload(ra1, rb1, c_kbeg + (t + 3) * BK, okm1);
+            stage(la1, lb1, ra1, rb1, rc1, c_kbeg + (t + 1) * BK, okm1);
+            gload(ra1, rb1, rc1, c_kbeg + (t + 3) * BK, okm1);
             compute(la0, lb0);
             __syncthreads();
-            stage(la0, lb0, ra0, rb0, okm0);
-            gload(ra0, rb0, c_kbeg + (t + 4) * BK, okm0);
+            stage(la0, lb0, ra0, rb0, rc0, c_kbeg + (t + 2) * BK, okm0);
+            gload(ra0, rb0, rc0, c_kbeg + (t + 4) * BK, okm0);
             compute(la1, lb1);
             __syncthreads();
         }
         const int rem = c_nt - t;             // 1..4 tiles left; tile t+3 (rem == 4) has not been requested yet
-        if (rem >= 2) stage(la1, lb1, ra1, rb1, okm1);
-        if (rem == 4) gload(ra1, rb1, c_kbeg + (t + 3) * BK, okm1);
+        if (rem >= 2) stage(la1, lb1, ra1, rb1, rc1, c_kbeg + (t + 1) * BK, okm1);
+        if (rem == 4) gload(ra1, rb1, rc1, c_kbeg + (t + 3) * BK, okm1);
         compute(la0, lb0);
         if (rem >= 2) {
             __syncthreads();
-            if (rem >= 3) stage(la0, lb0, ra0, rb0, okm0);
+            if (rem >= 3) stage(la0, lb0, ra0, rb0, rc0, c_kbeg + (t + 2) * BK, okm0);
             compute(la1, lb1);
         }
         if (rem >= 3) {
             __syncthreads();
-            if (rem == 4) stage(la1, lb1, ra1, rb1, okm1);
+            if (rem == 4) stage(la1, lb1, ra1, rb1, rc1, c_kbeg + (t + 3) * BK, okm1);
             compute(la0, lb0);
         }
         if (rem == 4) {
@@ -944,8 +1023,8 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     const bool more = RALF_GEMM_PERSISTENT && nbid < total;
     if (more) {
         setup(nbid);
-        gload(ra0, rb0, kbeg, okm0);
-        if (PF == 2 && nt > 1) gload(ra1, rb1, kbeg + BK, okm1);
+        gload(ra0, rb0, rc0, kbeg, okm0);
+        if (PF == 2 && nt > 1) gload(ra1, rb1, rc1, kbeg + BK, okm1);
     }
 
     RALF_PROBE(3);
@@ -1071,8 +1150,9 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
 }
 
 template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? ((GATHER == 6 || FM == 4) ? 2 : 4) : 1) void gemm_kernel(const KParams P) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[gemm_lds_bytes<T, AK, BKC, FM, FN, gemm_nbuf<GATHER, FM>(), (GATHER == 5 || GATHER == 6)>()];   // ONE LDS object
+__global__ __launch_bounds__(64 * NW, NW == 8 ? ((GATHER == 6 || FM == 4 || gemm_at_mode(GATHER)) ? 2 : 4) : 1) void gemm_kernel(const KParams P) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[gemm_lds_bytes<T, AK, BKC, FM, FN, gemm_nbuf<GATHER, FM>(), (GATHER == 5 || GATHER == 6)>() +
+                                                                  (gemm_at_mode(GATHER) ? AT_LDS_BYTES : 0)];   // ONE LDS object (+ the operand transform's coefficient table)
     gemm_body<T, AK, BKC, GATHER, FM, FN, EPI, NW>(P, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z, (int)gridDim.z, lds_raw);
 }
 
@@ -1283,7 +1363,7 @@ template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int NW>
 int launch_epi(KParams& P, int nbatch, hipStream_t st) {
     const RalfGemmDesc& d = P.d;
     if (d.bnb_part) {   // BatchNorm-backward statistics: data-gradient products only (A k-contiguous: 1x1 on the interior path, k x k through the tap gather)
-        if constexpr (AK && (GATHER == 0 || GATHER == 1 || GATHER == 3 || GATHER == 5 || GATHER == 6)) return launch<T, AK, BKC, GATHER, FM, FN, 3, NW>(P, nbatch, st);
+        if constexpr (AK && (GATHER == 0 || GATHER == 1 || GATHER == 3 || GATHER == 5 || GATHER == 6 || GATHER == 8)) return launch<T, AK, BKC, GATHER, FM, FN, 3, NW>(P, nbatch, st);
         else { ralf::set_error("gemm: bnb_* needs a k-contiguous A (no general per-vector gather, no weight-gradient layout)"); return RALF_ERR_INVALID; }
     }
     const bool lvl2 = d.C2 || d.act == RALF_ACT_GELU || d.aux_mode == RALF_AUX_GELU_GRAD || d.atomic_out;
@@ -1327,6 +1407,24 @@ int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
     }
     if (use128) return launch_epi<T, AK, BKC, GATHER, 2, 2, 8>(P, nbatch, st);
     return launch_epi<T, AK, BKC, GATHER, 1, 1, 4>(P, nbatch, st);
+}
+
+// products with an A-operand transform (RalfGemmDesc.at_*): the tile rule of launch_cfg, register-staged loaders only, and the two epilogues
+// their callers use (plain / column statistics for the forward, the BatchNorm-backward reductions for the data gradient)
+template <typename T, bool BKC, int G>
+int launch_at(KParams& P, int nbatch, hipStream_t st) {
+    const RalfGemmDesc& d = P.d;
+    const bool ok22 = (!d.colstats && !d.bnb_part) || d.N % 128 == 0;
+    const int64_t big = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128);
+    const bool use128 = ok22 && d.M >= 128 && (d.N % 128 == 0 || d.N >= 512) && big >= 192;
+    if (d.bnb_part) {
+        if constexpr (G == 8) {
+            if (use128) return launch<T, true, BKC, G, 2, 2, 3, 8>(P, nbatch, st);
+            return launch<T, true, BKC, G, 1, 1, 3, 4>(P, nbatch, st);
+        } else { ralf::set_error("gemm: at_mode 1 with bnb_*: not built"); return RALF_ERR_INVALID; }
+    }
+    if (use128) return launch<T, true, BKC, G, 2, 2, 0, 8>(P, nbatch, st);
+    return launch<T, true, BKC, G, 1, 1, 0, 4>(P, nbatch, st);
 }
 
 template <typename T>
@@ -1375,3 +1473,4 @@ int ralf_gemm_dispatch_bf16(void* kparams, int nbatch, hipStream_t st);
 int ralf_gemm_reduce_f32(void* kparams, int nbatch, int blocks, hipStream_t st);
 int ralf_gemm_reduce_bf16(void* kparams, int nbatch, int blocks, hipStream_t st);
 int ralf_gemm_grouped_bf16(const void* jobs, int njobs, void* workspace, size_t workspace_bytes, hipStream_t st);
+int ralf_gemm_dispatch_at(void* kparams, int nbatch, hipStream_t st);   // gemm_at.hip: the operand-transform kernels (their own translation unit)

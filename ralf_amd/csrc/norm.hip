@@ -423,9 +423,13 @@ __global__ __launch_bounds__(64 * WAVES) void bn_partial_finalize_kernel(const f
 
 // backward statistics from the partial rows a data-gradient GEMM wrote (RalfGemmDesc.bnb_part: [nblk][2][C], sums of dz and of dz * (x - mean)):
 // s1[c] += sum_b part[b][0][c],  s2[c] += rstd[c] * sum_b part[b][1][c]   (= sum dz * xhat); deterministic order
+// coef (optional, fp32 [3][C]): the affine form of the backward apply, dx = c1 * dz + c2 * x + c3 with c1 = gamma rstd,
+// c2 = -c1 rstd (sum dz xhat) / M, c3 = -c1 (sum dz) / M - c2 mean (ralf_bn_bwd_apply_affine, RalfGemmDesc.at_mode 2); needs s1 / s2 to
+// hold nothing but this layer's sums (they are the zero-initialised dbeta / dgamma views)
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void bn_bwd_partial_sum_kernel(const float* __restrict__ part, int nblk, int C, const float* __restrict__ rstd,
-                                                                  float* __restrict__ s1, float* __restrict__ s2) {
+                                                                  float* __restrict__ s1, float* __restrict__ s2, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ mean, float invM, float* __restrict__ coef) {
     __shared__ float red[2][WAVES][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
@@ -442,6 +446,10 @@ __global__ __launch_bounds__(64 * WAVES) void bn_bwd_partial_sum_kernel(const fl
         for (int w = 0; w < WAVES; ++w) { t1 += red[0][w][tx]; t2 += red[1][w][tx]; }
         s1[c] += t1;
         s2[c] += rstd[c] * t2;
+        if (coef) {
+            const float rs = rstd[c], c1 = gamma[c] * rs, c2 = -c1 * rs * (rs * t2) * invM;
+            coef[c] = c1; coef[C + c] = c2; coef[2 * C + c] = -c1 * t1 * invM - c2 * mean[c];
+        }
     }
 }
 
@@ -490,7 +498,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
             float xv[NV], o[NV];
             VW<T>::load(x + e * 8 + h * NV, xv);
 #pragma unroll
-            for (int i = 0; i < NV; ++i) o[i] = xv[i] * sc[h * NV + i] + sh[h * NV + i];
+            for (int i = 0; i < NV; ++i) o[i] = __builtin_fmaf(xv[i], sc[h * NV + i], sh[h * NV + i]);   // (the same fma as the operand-transform loader, gemm_impl.h)
             if (res) {
                 float rv[NV];
                 VW<T>::load(res + e * 8 + h * NV, rv);
@@ -552,6 +560,39 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             }
             VW<T>::store(dx + off, o);
             if (dres) VW<T>::store(dres + off, g);
+        }
+    }
+}
+
+// dx = c1 * dz + (c2 * x + c3): the backward apply with the per-channel work folded into three coefficients (bn_bwd_partial_sum_kernel);
+// the stand-alone form of RalfGemmDesc.at_mode 2, same arithmetic
+template <typename T, bool HOIST>
+__global__ __launch_bounds__(256) void bn_bwd_apply_affine_kernel(const T* __restrict__ dz, const T* __restrict__ x, const float* __restrict__ c1p,
+                                                                   const float* __restrict__ c2p, const float* __restrict__ c3p, T* __restrict__ dx,
+                                                                   int64_t total8, int C) {
+    constexpr int NV = VW<T>::N, H = 8 / NV;
+    float c1[8], c2[8], c3[8];
+    auto coef = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            VW<float>::load(c1p + c0 + 4 * q, *reinterpret_cast<float (*)[4]>(&c1[4 * q]));
+            VW<float>::load(c2p + c0 + 4 * q, *reinterpret_cast<float (*)[4]>(&c2[4 * q]));
+            VW<float>::load(c3p + c0 + 4 * q, *reinterpret_cast<float (*)[4]>(&c3[4 * q]));
+        }
+    };
+    const int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (HOIST && e0 < total8) coef((int)((e0 * 8) % C));
+    for (int64_t e = e0; e < total8; e += (int64_t)gridDim.x * 256) {
+        if (!HOIST) coef((int)((e * 8) % C));
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const int64_t off = e * 8 + h * NV;
+            float xv[NV], g[NV], o[NV];
+            VW<T>::load(x + off, xv);
+            VW<T>::load(dz + off, g);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) o[i] = __builtin_fmaf(g[i], c1[h * NV + i], __builtin_fmaf(xv[i], c2[h * NV + i], c3[h * NV + i]));
+            VW<T>::store(dx + off, o);
         }
     }
 }
@@ -799,8 +840,11 @@ extern "C" int ralf_bn_stats_from_partials(const float* partials, int nrows, con
     return ralf::check_launch("bn_stats_from_partials");
 }
 
-extern "C" int ralf_bn_bwd_stats_from_partials(const float* partials, int nrows, const float* rstd, float* s1, float* s2, int C, float* workspace, void* stream) {
+extern "C" int ralf_bn_bwd_stats_from_partials(const float* partials, int nrows, const float* rstd, float* s1, float* s2, int C, float* workspace,
+                                               const float* gamma, const float* mean, int64_t M, float* coef, void* stream) {
     RALF_REQUIRE(partials && nrows > 0 && rstd && s1 && s2 && workspace && C > 0, "bn_bwd_stats_from_partials: bad arguments");
+    RALF_REQUIRE(!coef || (gamma && mean && M > 0), "bn_bwd_stats_from_partials: the coefficient output needs gamma, mean and M");
+    const float invM = coef ? 1.f / (float)M : 0.f;
     hipStream_t st = (hipStream_t)stream;
     const float* src = partials;
     int n = nrows;
@@ -809,9 +853,19 @@ extern "C" int ralf_bn_bwd_stats_from_partials(const float* partials, int nrows,
         hipLaunchKernelGGL(bn_partial_fold_kernel, dim3(ceil_div(C, 64), G), dim3(256), 0, st, partials, nrows, C, G, workspace);
         src = workspace; n = G;
     }
-    if (n > 64) hipLaunchKernelGGL(bn_bwd_partial_sum_kernel<16>, dim3(ceil_div(C, 64)), dim3(1024), 0, st, src, n, C, rstd, s1, s2);
-    else hipLaunchKernelGGL(bn_bwd_partial_sum_kernel<4>, dim3(ceil_div(C, 64)), dim3(256), 0, st, src, n, C, rstd, s1, s2);
+    if (n > 64) hipLaunchKernelGGL(bn_bwd_partial_sum_kernel<16>, dim3(ceil_div(C, 64)), dim3(1024), 0, st, src, n, C, rstd, s1, s2, gamma, mean, invM, coef);
+    else hipLaunchKernelGGL(bn_bwd_partial_sum_kernel<4>, dim3(ceil_div(C, 64)), dim3(256), 0, st, src, n, C, rstd, s1, s2, gamma, mean, invM, coef);
     return ralf::check_launch("bn_bwd_stats_from_partials");
+}
+
+extern "C" int ralf_bn_bwd_apply_affine(int dtype, const void* dz, const void* x, const float* c1, const float* c2, const float* c3, void* dx, int64_t M, int C, void* stream) {
+    RALF_REQUIRE(dz && x && c1 && c2 && c3 && dx && C % 8 == 0, "bn_bwd_apply_affine: bad arguments (C %% 8 == 0)");
+    const int64_t total8 = M * C / 8;
+    bool hoist;
+    const int grid = flat_grid(total8, C, &hoist);
+    if (hoist) DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_affine_kernel<T, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)dz, (const T*)x, c1, c2, c3, (T*)dx, total8, C));
+    else DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_affine_kernel<T, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)dz, (const T*)x, c1, c2, c3, (T*)dx, total8, C));
+    return ralf::check_launch("bn_bwd_apply_affine");
 }
 
 extern "C" int ralf_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, uint8_t* relu_mask,

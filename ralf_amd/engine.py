@@ -259,25 +259,74 @@ def _clone_tree(x, device=None):
     return x
 
 
-def _copy_tree(dst, src):
+def _record_tree(x, stream):
+    if torch.is_tensor(x):
+        if x.is_cuda:
+            x.record_stream(stream)
+    elif isinstance(x, dict):
+        for v in x.values():
+            _record_tree(v, stream)
+
+
+class _HostStager:
+    """host-resident leaves of a batch tree (the nested `retrieved` dict the reference's loop leaves on the CPU) reach the static device buffers
+    through page-locked mirrors: a pageable source makes every copy_ a synchronous staging copy that waits for the stream to drain, i.e. for
+    the previous step's replay (11 ms of host time per iteration measured).  Three mirror sets rotate; a set is reused only after the
+    event that follows its copies."""
+
+    def __init__(self, depth: int = 3):
+        self.sets = [dict() for _ in range(depth)]
+        self.events = [None] * depth
+        self.i = 0
+        self.cur = None
+
+    def begin(self):
+        j = self.i % len(self.sets)
+        self.i += 1
+        if self.events[j] is not None:
+            self.events[j].synchronize()
+        self.cur = j
+
+    def mirror(self, dst, src):
+        m = self.sets[self.cur].get(id(dst))
+        if m is None or m.shape != src.shape or m.dtype != src.dtype:
+            m = self.sets[self.cur][id(dst)] = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+        m.copy_(src)
+        return m
+
+    def end(self):
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[self.cur] = ev
+
+
+def _copy_tree(dst, src, stager=None):
     if torch.is_tensor(dst):
         if dst is not src:   # a caller that filled the step's own buffers in place (static_batch()) pays no copy
+            if stager is not None and dst.is_cuda and not src.is_cuda and not src.is_pinned():
+                src = stager.mirror(dst, src)
             dst.copy_(src, non_blocking=True)
     elif isinstance(dst, dict):
         for k in dst:
             if dst[k] is not None:
-                _copy_tree(dst[k], src[k])
+                _copy_tree(dst[k], src[k], stager)
 
 
 class TrainStep:
     """One optimisation step of `model` (a ralf_amd generator) = forward + backward + (all-reduce) + clip + AdamW."""
 
     def __init__(self, model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, backbone_lr_scale=0.1, betas=(0.9, 0.999), eps=1e-8,
-                 use_graph=True, process_group=None, overlap_wgrad=True, overlap_allreduce=None, grad_wire=None, grad_exchange=None, groups=None):
+                 use_graph=True, process_group=None, overlap_wgrad=True, overlap_allreduce=None, grad_wire=None, grad_exchange=None, groups=None,
+                 own_stream=False):
         """groups: ready-made AdamW groups (what `model.optim_groups(...)` returned to the caller, train/train.py:217-223) instead of
         lr / weight_decay / backbone_lr_scale"""
         self.model = model
         rt = model.rt.to(model.device)
+        # own_stream: the step (batch copy into the static buffers, replays, collectives) runs on a library-owned stream, ordered after the
+        # caller's stream at the call but NOT the other way round: the caller's next host-to-device copy does not queue up behind the replay
+        # (measured in the reference's loop: `.to(rank)` of the next batch waited 22 ms for the previous step).  Results are ordered for the
+        # caller by sync_caller().
+        self._run = ops.own_stream("run", model.device) if own_stream else None
         if groups is None:
             groups = model.optim_groups(base_lr=lr, weight_decay=weight_decay, custom_lr={"encoder.extractor.body": lr * backbone_lr_scale})
         self.opt = FlatAdamW(groups, betas, eps, max_norm, shadow_dtype=rt.dtype if rt.dtype == torch.bfloat16 else None, runtime=rt)
@@ -296,6 +345,7 @@ class TrainStep:
         if self.world > 1:
             self._sync_replicas(rt)
         self._static = None
+        self._stager = None
         self._graphs = None
         self._seed_grad = None
         self.loss = None
@@ -390,13 +440,30 @@ class TrainStep:
         return loss
 
     def __call__(self, inputs, targets):
+        if self._run is None:
+            return self._step(inputs, targets)
+        self._run.wait_stream(torch.cuda.current_stream())
+        _record_tree({"inputs": inputs, "targets": targets}, self._run)   # (allocated on the caller's stream, read on this one)
+        with torch.cuda.stream(self._run):
+            return self._step(inputs, targets)
+
+    def sync_caller(self):
+        """order the caller's current stream after everything issued by the step so far (own_stream mode)"""
+        if self._run is not None:
+            torch.cuda.current_stream().wait_stream(self._run)
+
+    def _step(self, inputs, targets):
         if not self.use_graph:
             self.loss = self._eager(inputs, targets)
         else:
             if self._graphs is None:
                 self._capture(inputs, targets)
             else:
-                _copy_tree(self._static, {"inputs": inputs, "targets": targets})
+                if self._stager is None:
+                    self._stager = _HostStager()
+                self._stager.begin()
+                _copy_tree(self._static, {"inputs": inputs, "targets": targets}, self._stager)
+                self._stager.end()
             ga, gm, gb = self._graphs
             ga.replay()
             if gm is not None:
@@ -509,6 +576,7 @@ class GraphedAdamW(torch.optim.Optimizer):
             assert g["lr"] is not None, "optim_groups(base_lr=...) sets every group's learning rate"
         self._base_lrs = [g["lr"] for g in self.param_groups]
         self._factor = 1.0
+        step_kw.setdefault("own_stream", True)
         self.engine = TrainStep(model, max_norm=max_norm, betas=betas, eps=eps, use_graph=True,
                                 groups=[{"params": g["params"], "lr": g["lr"], "weight_decay": g["weight_decay"]} for g in self.param_groups], **step_kw)
         self._detached = False
@@ -528,15 +596,18 @@ class GraphedAdamW(torch.optim.Optimizer):
                     p.grad = None
             self._detached = True
         if self.loss_lag:
-            host = torch.empty(1, dtype=torch.float32, pin_memory=True)
-            host.copy_(loss.reshape(1), non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
+            run = self.engine._run or torch.cuda.current_stream()
+            with torch.cuda.stream(run):
+                host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+                host.copy_(loss.reshape(1), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(run)
             prev, self._prev = self._prev, (host, ev)
             if prev is None:
                 prev = (host, ev)          # first call: nothing older to report
             prev[1].synchronize()          # (the replay BEFORE the one just enqueued: long finished)
             return self.engine.outputs, {"nll_loss": prev[0].reshape(()).clone().requires_grad_()}
+        self.engine.sync_caller()   # the loop reads the loss (and may read the logits) on its own stream
         return self.engine.outputs, {"nll_loss": loss.clone().requires_grad_()}
 
     def zero_grad(self, set_to_none: bool = True):   # the captured step zeroes its gradient buffer itself

@@ -73,8 +73,9 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
          bias=None, act=None, res=None, ldr=None, aux=None, aux_mode=None, aux_scale=1.0, out2=None,
          alpha=1.0, accumulate=False, splitk=1, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=None,
          conv: Optional[dict] = None, gather=0, drop_p=0.0, seed=None, call_id=0, atomic=False, colstats=None,
-         sBias0=0, kseg=0, sBk=0, colscale=None, bnb=None) -> torch.Tensor:
-    """C = epi(alpha * A @ B) through ralf_gemm (see include/ralf_hip.h: RalfGemmDesc)."""
+         sBias0=0, kseg=0, sBk=0, colscale=None, bnb=None, at=None) -> torch.Tensor:
+    """C = epi(alpha * A @ B) through ralf_gemm (see include/ralf_hip.h: RalfGemmDesc).
+    at = dict(mode=1|2, c1, c2, c3=None, a2=None, out=None, mask=None, relu=False): the A-operand transform with write-through (at_*)."""
     assert A.is_cuda and B.is_cuda and A.dtype == B.dtype
     d = RalfGemmDesc()
     d.dtype = dtype_code(A)
@@ -111,6 +112,14 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
         bx, bm, bmean, bpart = bnb
         assert bx.dtype == A.dtype and bx.is_contiguous() and bx.numel() == M * N and bpart.dtype == torch.float32 and bpart.numel() >= ((M + 63) // 64) * 2 * N
         d.bnb_x, d.bnb_mask, d.bnb_mean, d.bnb_part = _p(bx), _p(bm), _p(bmean), _p(bpart)
+    if at is not None:
+        a2, ao, am = at.get("a2"), at.get("out"), at.get("mask")
+        assert A.dtype == torch.bfloat16 and a_kcontig and A.is_contiguous() and A.numel() == M * K
+        assert (a2 is None or (a2.dtype == A.dtype and a2.is_contiguous() and a2.numel() == M * K)) and (ao is None or (ao.dtype == A.dtype and ao.is_contiguous() and ao.numel() == M * K))
+        assert all(c is None or (c.dtype == torch.float32 and c.numel() >= K and c.is_contiguous()) for c in (at["c1"], at["c2"], at.get("c3")))
+        assert am is None or (am.dtype == torch.uint8 and am.numel() >= M * K // 8)
+        d.at_mode, d.at_relu = at["mode"], int(bool(at.get("relu", False)))
+        d.at_a2, d.at_c1, d.at_c2, d.at_c3, d.at_out, d.at_mask = _p(a2), _p(at["c1"]), _p(at["c2"]), _p(at.get("c3")), _p(ao), _p(am)
     if colstats is not None:   # fp32 [ceil(M/64), 2, N]: per-64-row column sums / sums of squares of the stored output
         assert colstats.dtype == torch.float32 and colstats.numel() >= ((M + 63) // 64) * 2 * N
         d.colstats = _p(colstats)
@@ -485,7 +494,8 @@ def bn_backward(x2d, dy, y, gamma, mean, rstd, relu, want_dres, training=True, i
         st = torch.zeros(2, C, dtype=torch.float32, device=x2d.device)
         s = (st[0], st[1])
     if partials is not None:
-        _call("ralf_bn_bwd_stats_from_partials", _p(partials), partials.shape[0], _p(rstd), _p(s[0]), _p(s[1]), C, _p(workspace(128 * 2 * C * 4, x2d.device)))
+        _call("ralf_bn_bwd_stats_from_partials", _p(partials), partials.shape[0], _p(rstd), _p(s[0]), _p(s[1]), C, _p(workspace(128 * 2 * C * 4, x2d.device)),
+              None, None, 0, None)
         dx = torch.empty_like(x2d)
         _call("ralf_bn_bwd_apply", dt, _p(x2d), _p(dy), None, None, _p(mean), _p(rstd), _p(gamma), _p(s[0]), _p(s[1]), _p(dx), None, M, C, 0)
         return dx, s[1], s[0], (dy if want_dres else None)

@@ -165,7 +165,7 @@ def test_batchnorm_backward_statistics_epilogue(dtype, M, N, K, relu):
     torch.testing.assert_close(part[:, 0], z64(d).sum(1), atol=1e-3, rtol=1e-4)
     torch.testing.assert_close(part[:, 1], z64(d * (x.float() - mean)).sum(1), atol=2e-3, rtol=1e-4)
     s = torch.ones(2, N, device="cuda")
-    ops._call("ralf_bn_bwd_stats_from_partials", ops._p(part), part.shape[0], ops._p(rstd), ops._p(s[0]), ops._p(s[1]), N, ops._p(torch.empty(128 * 2 * N, device="cuda")))
+    ops._call("ralf_bn_bwd_stats_from_partials", ops._p(part), part.shape[0], ops._p(rstd), ops._p(s[0]), ops._p(s[1]), N, ops._p(torch.empty(128 * 2 * N, device="cuda")), None, None, 0, None)
     torch.testing.assert_close(s[0] - 1, d.sum(0), atol=2e-3, rtol=1e-4)
     torch.testing.assert_close(s[1] - 1, (d * (x.float() - mean) * rstd).sum(0), atol=5e-3, rtol=2e-4)
 
