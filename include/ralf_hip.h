@@ -449,6 +449,10 @@ int ralf_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, 
  * collective's completion poll fail (hipErrorCapturedEvent) and takes the process down.  Non-blocking w.r.t. the null stream.
  * ------------------------------------------------------------------------------------------- */
 int ralf_stream_create(void** out_stream);
+/* the same with the device's highest (high != 0) or lowest stream priority: a prioritised stream gets a hardware queue of its own, so a
+ * host-to-device copy of the NEXT batch issued on it is not parked behind the kernels of the running step (a plain stream shares one of
+ * the 4 hardware queues with the step's graph branches: the loop's `.to(rank)`, train/train.py:434, waited 17-22 ms per iteration) */
+int ralf_stream_create_priority(void** out_stream, int high);
 int ralf_stream_destroy(void* stream);
 
 #ifdef __cplusplus

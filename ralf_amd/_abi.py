@@ -159,5 +159,6 @@ SIGNATURES.update({
     "ralf_clip_coef_partials": (i32, [vp, f32, vp, vp, vp]),
     "ralf_adamw": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, vp, vp, vp]),
     "ralf_stream_create": (i32, [ctypes.POINTER(vp)]),
+    "ralf_stream_create_priority": (i32, [ctypes.POINTER(vp), i32]),
     "ralf_stream_destroy": (i32, [vp]),
 })

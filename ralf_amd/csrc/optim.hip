@@ -142,6 +142,17 @@ extern "C" int ralf_stream_create(void** out_stream) {
     return RALF_OK;
 }
 
+extern "C" int ralf_stream_create_priority(void** out_stream, int high) {
+    if (!out_stream) { ralf::set_error("stream_create_priority: null output"); return RALF_ERR_INVALID; }
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    hipStream_t s = nullptr;
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high ? greatest : least);
+    if (e != hipSuccess) { ralf::set_error("stream_create_priority: %s", hipGetErrorString(e)); return RALF_ERR_LAUNCH; }
+    *out_stream = (void*)s;
+    return RALF_OK;
+}
+
 extern "C" int ralf_stream_destroy(void* stream) {
     if (!stream) return RALF_OK;
     hipError_t e = hipStreamDestroy((hipStream_t)stream);

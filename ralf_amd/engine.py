@@ -565,7 +565,7 @@ class GraphedAdamW(torch.optim.Optimizer):
     forward.  lr / weight_decay per group come from `model.optim_groups`, exactly as with torch's AdamW."""
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, max_norm: float = 0.0,
-                 loss_lag: int = 0, **step_kw):
+                 loss_lag: int = 0, host_threads: Optional[int] = 16, **step_kw):
         groups = [dict(g) for g in params]
         tokens = {g.get("ralf_model") for g in groups}
         assert len(tokens) == 1 and None not in tokens, "GraphedAdamW takes the groups returned by a ralf_amd generator's optim_groups()"
@@ -576,6 +576,11 @@ class GraphedAdamW(torch.optim.Optimizer):
             assert g["lr"] is not None, "optim_groups(base_lr=...) sets every group's learning rate"
         self._base_lrs = [g["lr"] for g in self.param_groups]
         self._factor = 1.0
+        # intra-op CPU threads of THIS process (the data loader's workers are processes of their own): torch defaults to one per core, and a
+        # 128-thread OpenMP team on a busy 256-core host stalled the loop body for 50-80 ms every few iterations -- one descheduled thread
+        # holds the team's barrier in the batch assembly copies (tools/loop_phases.py: 34-60 ms per iteration, 17.4 with 8 threads)
+        if host_threads and torch.get_num_threads() > host_threads:
+            torch.set_num_threads(int(host_threads))
         step_kw.setdefault("own_stream", True)
         self.engine = TrainStep(model, max_norm=max_norm, betas=betas, eps=eps, use_graph=True,
                                 groups=[{"params": g["params"], "lr": g["lr"], "weight_decay": g["weight_decay"]} for g in self.param_groups], **step_kw)
@@ -590,6 +595,9 @@ class GraphedAdamW(torch.optim.Optimizer):
 
     def train_step(self, inputs, targets):
         loss = self.engine(inputs, targets)
+        done = torch.cuda.Event()
+        done.record(self.engine._run or torch.cuda.current_stream())
+        self.engine.model._uploaded_batch_consumed(done)   # (the device buffer preprocess filled may be rewritten after this point)
         if not self._detached:   # the replays do not involve autograd: from here on the flat gradient buffer is the engine's own
             for g in self.param_groups:
                 for p in g["params"]:

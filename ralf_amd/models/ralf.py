@@ -12,6 +12,7 @@ update_per_epoch / compute_stats / aggregate_sampling_config), attributes and st
 from __future__ import annotations
 
 import logging
+import os
 import random
 from typing import Iterable, Optional
 
@@ -105,6 +106,60 @@ class _GeneratorBase(nn.Module):
             if sel:
                 groups.append({"params": [named[n] for n in sel], "weight_decay": wd, "lr": base_lr, "ralf_model": token})
         return groups
+
+    def _upload_batch(self, inputs: dict, targets: dict):
+        """with an engine.GraphedAdamW attached: the batch starts its way to the device HERE -- page-locked staging (the 4-channel image is
+        assembled in a page-locked buffer already, helpers/task.py: cat_image), then asynchronous copies on a library-owned copy stream -- and preprocess returns DEVICE tensors, so the loop's `.to(rank)` calls (train/train.py:434-439) are no-ops.  Why: a pageable
+        source makes `.to(rank)` a host-blocking staged copy on the loop's stream, which waited for the previous replay (17-35 ms per
+        iteration measured).  Three sets of device buffers rotate; a set is rewritten only after the step that read it
+        (_uploaded_batch_consumed)."""
+        eng = getattr(self, "_engine", None)
+        if eng is None or self.device.type != "cuda":
+            return inputs, targets
+        st = self.__dict__.setdefault("_h2d", {"sets": [dict(), dict(), dict()], "done": [None] * 3, "i": 0})
+        j = st["i"] % 3
+        st["i"] += 1
+        bufs = st["sets"][j]
+        # a plain library-owned copy stream beside the step's stream: the 67 MB (1.3 ms at the 54 GB/s of this host link) overlap the replay in
+        # flight.  Measured (tools/loop_phases.py, loss_lag 1): this 16.2 ms per iteration against 15.9 for the resident batch; the copies on
+        # the step's own stream 17.4 (serial); on a PRIORITISED stream 20.6 (a prioritised stream re-maps the hardware queues of the graph's
+        # branches: the replay itself slows to 20 ms).  RALF_UPLOAD_STREAM = run / prio select those for A/B runs.
+        which = os.environ.get("RALF_UPLOAD_STREAM", "own")
+        if which == "run":
+            cs = getattr(eng.engine, "_run", None) or torch.cuda.current_stream()
+        else:
+            cs = ops.own_stream("h2d", self.device, priority="high" if which == "prio" else None)
+        if st["done"][j] is not None:
+            st["done"][j].synchronize()        # (the step that read this set: three iterations back, long finished)
+        dev = self.device
+
+        def up(key, t):
+            if not torch.is_tensor(t) or t.is_cuda:
+                return t
+            slot = bufs.get(key)
+            if slot is None or slot[1].shape != t.shape or slot[1].dtype != t.dtype:
+                slot = bufs[key] = (None if t.is_pinned() else torch.empty(t.shape, dtype=t.dtype, pin_memory=True), torch.empty(t.shape, dtype=t.dtype, device=dev))
+            src = t
+            if not t.is_pinned():
+                slot[0].copy_(t)
+                src = slot[0]
+            with torch.cuda.stream(cs):
+                slot[1].copy_(src, non_blocking=True)
+            return slot[1]
+
+        def walk(prefix, tree):
+            return {k: (walk(prefix + k + "/", v) if isinstance(v, dict) else up(prefix + k, v)) for k, v in tree.items()}
+        out_i, out_t = walk("i/", inputs), walk("t/", targets)
+        ev = torch.cuda.Event()
+        ev.record(cs)
+        torch.cuda.current_stream().wait_event(ev)   # (asynchronous: readers on the loop's stream are ordered after the copies)
+        st["last"] = j
+        return out_i, out_t
+
+    def _uploaded_batch_consumed(self, event) -> None:
+        st = self.__dict__.get("_h2d")
+        if st is not None and "last" in st:
+            st["done"][st["last"]] = event
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         """train/train.py:440.  With an engine.GraphedAdamW attached the captured step zeroes its own flat gradient buffer and the
@@ -566,7 +621,7 @@ class ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg(_GeneratorBas
         assert inputs["retrieved"]["image"].size(2) == 4
         _inputs = {"seq": data["seq"][:, :-1], "tgt_key_padding_mask": ~data["mask"][:, :-1], "image": image,
                    "retrieved": inputs["retrieved"], "seq_layout_const": seqc["seq"], "seq_layout_const_pad_mask": seqc["pad_mask"]}
-        return _inputs, {"seq": data["seq"][:, 1:]}
+        return self._upload_batch(_inputs, {"seq": data["seq"][:, 1:]})
 
     def _retrieved_features(self, retrieved: dict, device) -> torch.Tensor:
         """extract_retrieved_features (retrieval_augmented_autoreg.py:526-584): frozen layout encoder over
@@ -621,7 +676,7 @@ class ConcateAuxilaryTaskAutoreg(_GeneratorBase):
         image = cond.image if torch.is_tensor(getattr(cond, "image", None)) and cond.image.size(1) == 4 else cat_image(inputs["image"], inputs["saliency"])   # (get_condition already built the 4-channel image: 67 MB per batch)
         _inputs = {"seq": data["seq"][:, :-1], "tgt_key_padding_mask": ~data["mask"][:, :-1], "image": image,
                    "seq_layout_const": seqc["seq"], "seq_layout_const_pad_mask": seqc["pad_mask"]}
-        return _inputs, {"seq": data["seq"][:, 1:]}
+        return self._upload_batch(_inputs, {"seq": data["seq"][:, 1:]})
 
     def _encode_into_memory(self, inputs: dict) -> dict:
         self.rt.to(inputs["image"].device)

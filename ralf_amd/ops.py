@@ -50,7 +50,7 @@ def _p(t):
 _own_streams: dict = {}
 
 
-def own_stream(slot, device=None) -> "torch.cuda.Stream":
+def own_stream(slot, device=None, priority=None) -> "torch.cuda.Stream":
     """the library-owned HIP stream `slot` (any hashable name) of `device`, created on first use and kept for the life of the
     process (ralf_stream_create, include/ralf_hip.h).  Every side stream, graph branch and capture stream of the runtime is
     one of these -- NOT torch.cuda.Stream(), which deals out the 32 streams of a shared pool round-robin: RCCL's stream comes
@@ -63,7 +63,10 @@ def own_stream(slot, device=None) -> "torch.cuda.Stream":
     if st is None:
         with torch.cuda.device(idx):
             raw = ctypes.c_void_p()
-            _lib.check(_lib.lib().ralf_stream_create(ctypes.byref(raw)), "ralf_stream_create")
+            if priority is None:
+                _lib.check(_lib.lib().ralf_stream_create(ctypes.byref(raw)), "ralf_stream_create")
+            else:   # "high" / "low": a hardware queue of its own (ralf_stream_create_priority)
+                _lib.check(_lib.lib().ralf_stream_create_priority(ctypes.byref(raw), 1 if priority == "high" else 0), "ralf_stream_create_priority")
             st = _own_streams[key] = torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", idx))
     return st
 
