@@ -177,11 +177,13 @@ def bench_decode(device, N=10, B=256, dtype="bfloat16", reps=3):
            "note": "sample() incl. H2D of the image batch and host-side token decoding; graph_ms = the captured device loop alone; hbm_frac = the "
                    "loop's unavoidable stream (the cross-attention K/V cache of 6 layers, read once per generated token) / graph_ms / 8 TB/s: the "
                    "whole-loop lower bound on the memory side (the cross-attention kernel itself runs at 0.62 of peak, profiles/*_decode_kernel_stats.txt)"}
+    out["mode"] = ("bf16 throughput mode: labels identical to the fp32 mode, >= 90 % of the geometry tokens (tests/test_configs_gpu.py); the north star's "
+                   "bit-exact tokens hold in the fp32 parity mode, timed in `fp32_parity_mode` below") if dtype.startswith("b") else "fp32 parity mode: tokens bit-exact against the reference's (tests/test_model_gpu.py, tests/test_fullsize_gpu.py)"
     for task in ("c", "cwh"):
         model = build_model(device, N, dtype, task).eval()
         cond, _ = get_condition(make_batch(B, N, seed=9), task, model.tokenizer)
         cond.retrieved = {k: v for k, v in cond.retrieved.items() if k != "image"}
-        for name, cfg in (("deterministic", {"name": "deterministic"}), ("top_k5", {"name": "top_k", "top_k": 5, "temperature": 1.0})):
+        for name, cfg in (("deterministic", {"name": "deterministic"}), ("top_k5", {"name": "top_k", "top_k": 5, "temperature": 1.0}))[:2 if dtype.startswith("b") else 1]:
             dec = GraphedDecode(model, task, cfg, True)
             for _ in range(2):
                 res = model.sample(cond=cond, sampling_cfg=cfg, cond_type=task, decoder=dec)
@@ -423,10 +425,7 @@ def self_launch(n, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's intra-node transport on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
-    # ROCclr's default, pinned: the graph branches of the step alias onto this many hardware queues, and which branch shares a queue with
-    # which decides whether a graph edge is an in-queue order or a cross-queue signal (8 queues ran the three-graph data-parallel
-    # step at 35.6 ms instead of 16.2) -- a box with another default must not change the measurement
-    env.setdefault("GPU_MAX_HW_QUEUES", "4")
+    # (GPU_MAX_HW_QUEUES is pinned by the library itself when the ranks import it: ralf_amd/__init__.py)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     return subprocess.call(cmd, env=env)
@@ -452,7 +451,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=4, help="batch of the CPU baseline's RALF leg (64 = the GPU batch: minutes)")
     a = ap.parse_args()
 
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")   # (see self_launch; read by the HIP runtime when the device is first touched)
+    import ralf_amd   # noqa: F401  (pins GPU_MAX_HW_QUEUES before the device is first touched: ralf_amd/__init__.py)
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if a.gpus > 1 and "RANK" not in os.environ:
         # not under a launcher: spawn one rank per GPU ourselves, like the reference does (image2layout/train/train.py:52-61,
@@ -611,6 +610,7 @@ def main():
                                            + (ke["file"] if ke else "no committed profile")}
         if world == 1 and not a.skip_decode:
             out["decode"] = bench_decode(device, N)
+            out["decode"]["fp32_parity_mode"] = bench_decode(device, N, dtype="float32", reps=2)   # the bit-exact mode (deterministic draw only)
         if world == 1 and not a.skip_variants and B == 64 and N == 10:
             # the other sizes SURVEY 8d names: the north star's 32-element layouts and the real 350x240 canvases, same step, same B
             t32 = bench_step_variant(device, 32, B, a.dtype, min(a.steps, 10))

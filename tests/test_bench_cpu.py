@@ -44,3 +44,17 @@ def test_committed_rocprof_average_reader():
     assert f and f.startswith("profiles/") and f.endswith("_knn_kernel_stats.txt")
     assert 60.0 < mn <= avg < 120.0          # 441 MB at 3.7 ... 7.3 TB/s
     assert bench.committed_kernel_avg_us(r"no_such_kernel") == (None, None, None)
+
+
+def test_the_package_pins_the_hardware_queue_count_before_the_device_is_touched():
+    """GPU_MAX_HW_QUEUES is owned by the runtime (ralf_amd/__init__.py): pinned to 4 at import unless RALF_KEEP_HW_QUEUES=1"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, warnings; warnings.simplefilter('ignore'); import ralf_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'), ralf_amd.HW_QUEUES['pinned'])"
+    for extra, want in (({}, "4 True"), ({"GPU_MAX_HW_QUEUES": "8"}, "4 True"), ({"GPU_MAX_HW_QUEUES": "8", "RALF_KEEP_HW_QUEUES": "1"}, "8 False")):
+        env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "RALF_KEEP_HW_QUEUES")}
+        env.update(extra, PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and out.stdout.strip() == want, (extra, out.stdout, out.stderr[-500:])

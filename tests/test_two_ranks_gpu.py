@@ -170,3 +170,23 @@ def test_sharded_knn_two_ranks_on_the_hip_scan(tmp_path):
     for r in range(2):
         ok = torch.load(os.path.join(str(tmp_path), f"k{r}.pt"))
         assert ok == {"query_sharded": True, "index_sharded": True}, (r, ok)
+
+
+def test_dp_selftest_is_as_fast_with_the_users_queue_setting_as_with_the_default():
+    """the staged data-parallel step (three graphs around RCCL) depended on how its graph branches alias onto the hardware queues: 8 queues
+    ran it at 35.6 ms against 16.2 with ROCclr's default of 4.  The library now pins GPU_MAX_HW_QUEUES itself when it is
+    imported (ralf_amd/__init__.py): `bench.py --dp-selftest` (1-rank RCCL group, staged backward, overlapped exchange) started with
+    GPU_MAX_HW_QUEUES=8 in the environment must run like the one started without it"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ms = {}
+    for name, extra in (("default", {}), ("user_sets_8", {"GPU_MAX_HW_QUEUES": "8"})):
+        env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "RALF_KEEP_HW_QUEUES")}
+        env.update(extra, MASTER_PORT=str(free_port()), PYTHONWARNINGS="ignore")
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--dp-selftest", "--steps", "10", "--warmup", "3", "--skip-cpu", "--skip-knn", "--skip-split",
+               "--skip-decode", "--skip-variants"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+        assert d["config"]["data_parallel"]["staged_backward"] and d["config"]["data_parallel"]["rccl_ranks"] == 1
+        ms[name] = d["ms_per_step"]
+    assert ms["user_sets_8"] < 1.15 * ms["default"] and ms["default"] < 20.0, ms
