@@ -62,6 +62,11 @@ int ralf_knn_select_cand(const float* exact, const int64_t* cand, int nq, int po
 /* per row of X fp32 [R, D] and its bf16 copy Xb: norms[r] = {|x|, |xb|, |x - xb|} (fp32 [R, 3], may be NULL); maxes fp32 [3]
  * (may be NULL, zero on entry) = column maxima over the rows.  Values are rounded UP (they feed an upper bound). */
 int ralf_knn_rownorms(const float* X, const void* Xb_bf16, int64_t R, int D, float* norms, float* maxes, void* stream);
+/* the candidate lists a filtered coarse pass wrote (RalfGemmDesc.flt_*: list int32 [nq][cap][2] = {row, score bits}, count int32 [nq]) as the
+ * dense pair the selection kernels take: rows int64 [nq][cap] (0 beyond the count), scores fp32 [nq][cap] (-inf beyond the count), and
+ * over int32 [nq] (may be NULL) = 1 where count > cap (the list lost candidates).  ralf_knn_gather_rows: out[q][j] = rows[q][pos[q][j]]. */
+int ralf_knn_list_unpack(const int* list, const int* count, int nq, int cap, int64_t* rows, float* scores, int* over, void* stream);
+int ralf_knn_gather_rows(const int64_t* rows, int cap, const int64_t* pos, int nq, int m, int64_t* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * element types of activation / weight buffers (accumulation is always fp32)
@@ -153,6 +158,14 @@ typedef struct RalfGemmDesc {
     int at_mode, at_relu;
     const void* at_a2; const float* at_c1; const float* at_c2; const float* at_c3;
     void* at_out; unsigned char* at_mask;
+    /* Threshold filter instead of an output matrix (flt_list NULL = off): element (m, n) of the product is APPENDED to row m's candidate
+     * list when value >= flt_thresh[m] -- flt_count[m] (int32, zeroed by the caller) counts the hits, hit number p < flt_cap is stored as
+     * flt_list[(m * flt_cap + p)] = {n as int32, value as fp32} (8 bytes); nothing else is written (C is ignored).  The coarse bf16 pass
+     * of the two-stage top-k search (ralf_amd/retrieval/knn.py; replaces writing and re-reading the [nq, N] score matrix, 252 MB at BASELINE
+     * config 4): with a per-query lower bound of its (pool+1)-th best score as threshold the lists hold a superset of the pool.  Hits arrive
+     * in no fixed order (atomics); rows with flt_count > flt_cap lost hits and must be redone by the caller.  bf16, A and B k-contiguous,
+     * aligned interior path, one batch, no split-K, plain epilogue (alpha only). */
+    const float* flt_thresh; int* flt_count; void* flt_list; int flt_cap, flt_pad_;
 } RalfGemmDesc;
 size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d);
 int ralf_gemm(const RalfGemmDesc* d, void* workspace, size_t workspace_bytes, void* stream);

@@ -141,6 +141,12 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
         }
         P.partial = (float*)workspace;
     }
+    if (d.flt_list) {
+        RALF_REQUIRE(d.flt_thresh && d.flt_count && d.flt_cap > 0 && d.dtype == RALF_BF16 && d.a_kcontig && d.b_kcontig && P.fast && nbatch == 1 && d.splitk == 1 &&
+                     !d.bias && !d.act && !d.res && !d.aux && !d.C2 && !d.colstats && !d.bnb_part && !d.colscale && !d.accumulate && !d.atomic_out && d.drop_p == 0.f && !d.kseg &&
+                     ((uintptr_t)d.flt_list % 8) == 0,
+                     "gemm: flt_* needs thresholds, counters and a capacity, bf16 NT operands on the aligned path, one batch, no split-K and a plain epilogue");
+    }
     hipStream_t st = (hipStream_t)stream;
     if (d.at_mode) {
         RALF_REQUIRE(d.at_mode == 1 || d.at_mode == 2, "gemm: at_mode %d", d.at_mode);

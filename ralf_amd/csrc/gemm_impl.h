@@ -291,6 +291,25 @@ __device__ __forceinline__ void epilogue_storev_bnb(const RalfGemmDesc& d, int m
     }
     VIO<T, 8>::st(d.C, e, v);
 }
+// EPI 4 (RalfGemmDesc.flt_*): no output matrix -- the W values of row m that reach the row's threshold are appended to its candidate list
+template <int W>
+__device__ __forceinline__ void epilogue_filter(const RalfGemmDesc& d, int m, int n, const float (&v)[W], int ncols) {
+    const float th = d.flt_thresh[m];
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < W; ++q) any = any || (v[q] * d.alpha >= th && n + q < ncols);
+    if (any) {   // (rare: the threshold passes ~1-2 % of the scores)
+        int2* list = reinterpret_cast<int2*>(d.flt_list) + (int64_t)m * d.flt_cap;
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            const float s = v[q] * d.alpha;
+            if (s >= th && n + q < ncols) {
+                const int pos = atomicAdd(d.flt_count + m, 1);
+                if (pos < d.flt_cap) list[pos] = make_int2(n + q, __float_as_int(s));
+            }
+        }
+    }
+}
 template <typename T, int EPI>
 __device__ __forceinline__ void epilogue_store4(const RalfGemmDesc& d, int z0, int z1, int m, int n, float (&v)[4]) {
     epilogue_storev<T, EPI, 4>(d, z0, z1, m, n, v);
@@ -1031,7 +1050,7 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     // ---- epilogue: lane holds 4 consecutive columns n per register group g = r>>2 ----
     // (no `continue`/`break` in these loops: they must unroll completely or the accumulators spill to scratch)
     const bool slab = d.splitk > 1 && !d.atomic_out;
-    if (P.vec_epi >= 2 && c_n0 + BN <= d.N) {
+    if ((P.vec_epi >= 2 || EPI == 4) && c_n0 + BN <= d.N) {
         // tile interior in n: the accumulators go through LDS so every lane stores 8 consecutive columns of one row
         // (8 lanes = one 128-byte line of bf16) instead of 32 rows x 8 bytes per store instruction; residual / mask /
         // accumulate reads get the same shape.  64 tile rows per round.
@@ -1089,8 +1108,9 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                     const float4 lo = *reinterpret_cast<const float4*>(cs + lr * CP + c), hi = *reinterpret_cast<const float4*>(cs + lr * CP + c + 4);
                     float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                     if constexpr (EPI == 3) epilogue_storev_bnb<T>(d, m, c_n0 + c, v, bmu, bs1, bs2);
+                    else if constexpr (EPI == 4) epilogue_filter<8>(d, m, c_n0 + c, v, d.N);
                     else if (slab) VIO<float, 8>::st(pbase, (int64_t)m * d.N + c_n0 + c, v);
-                    else epilogue_storev<T, EPI, 8>(d, z0, z1, m, c_n0 + c, v);
+                    else epilogue_storev<T, (EPI >= 3 ? 0 : EPI), 8>(d, z0, z1, m, c_n0 + c, v);
                 }
             }
             if constexpr (EPI == 3) {
@@ -1122,6 +1142,9 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                 const int n = c_n0 + wn * 32 * WFN + j * 32 + 8 * g + 4 * lh;
                 float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 if (m < d.M && n < d.N) {
+                    if constexpr (EPI == 4) {
+                        epilogue_filter<4>(d, m, n, v, d.N);
+                    } else
                     if (slab) {
                         float* pp = P.partial + (((int64_t)c_split * nbatch + z) * d.M + m) * d.N + n;
                         if (P.vec_epi && n + 3 < d.N) *reinterpret_cast<float4*>(pp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -1131,11 +1154,11 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                                 if (n + q < d.N) pp[q] = v[q];
                         }
                     } else if (P.vec_epi && n + 3 < d.N) {
-                        epilogue_store4<T, (EPI == 3 ? 0 : EPI)>(d, z0, z1, m, n, v);
+                        epilogue_store4<T, (EPI >= 3 ? 0 : EPI)>(d, z0, z1, m, n, v);
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (n + q < d.N) epilogue_store<T, (EPI == 3 ? 0 : EPI)>(d, z0, z1, m, n + q, v[q]);
+                            if (n + q < d.N) epilogue_store<T, (EPI >= 3 ? 0 : EPI)>(d, z0, z1, m, n + q, v[q]);
                     }
                 }
             }
@@ -1365,6 +1388,10 @@ int launch_epi(KParams& P, int nbatch, hipStream_t st) {
     if (d.bnb_part) {   // BatchNorm-backward statistics: data-gradient products only (A k-contiguous: 1x1 on the interior path, k x k through the tap gather)
         if constexpr (AK && (GATHER == 0 || GATHER == 1 || GATHER == 3 || GATHER == 5 || GATHER == 6 || GATHER == 8)) return launch<T, AK, BKC, GATHER, FM, FN, 3, NW>(P, nbatch, st);
         else { ralf::set_error("gemm: bnb_* needs a k-contiguous A (no general per-vector gather, no weight-gradient layout)"); return RALF_ERR_INVALID; }
+    }
+    if (d.flt_list) {   // threshold filter: the coarse pass of the two-stage top-k search (bf16 NT products on the aligned path only)
+        if constexpr (AK && BKC && sizeof(T) == 2 && (GATHER == 3 || GATHER == 5 || GATHER == 6)) return launch<T, AK, BKC, GATHER, FM, FN, 4, NW>(P, nbatch, st);
+        else { ralf::set_error("gemm: flt_* needs bf16 operands, both k-contiguous, on the aligned interior path"); return RALF_ERR_INVALID; }
     }
     const bool lvl2 = d.C2 || d.act == RALF_ACT_GELU || d.aux_mode == RALF_AUX_GELU_GRAD || d.atomic_out;
     const bool lvl1 = d.drop_p > 0.f || d.aux;

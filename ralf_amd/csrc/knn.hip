@@ -511,6 +511,41 @@ static int scores_impl(const float* X, int64_t N, int D, const float* Q, int nq,
     return launch_scores<32, 4, 2>(X, N, D, Q, nq, S, st, zero_me, nzero);
 }
 
+// ---- candidate lists of the filtered coarse pass (RalfGemmDesc.flt_*) -> the dense form the selection kernels take ----
+namespace {
+__global__ __launch_bounds__(256) void knn_list_unpack_kernel(const int2* __restrict__ list, const int* __restrict__ count, int nq, int cap,
+                                                               int64_t* __restrict__ rows, float* __restrict__ scores, int* __restrict__ over) {
+    const int q = blockIdx.y;
+    const int n = min(count[q], cap);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cap; i += gridDim.x * 256) {
+        const bool ok = i < n;
+        const int2 e = list[(int64_t)q * cap + (ok ? i : 0)];
+        rows[(int64_t)q * cap + i] = ok ? (int64_t)e.x : 0;                       // (an unused slot must still name a valid row)
+        scores[(int64_t)q * cap + i] = ok ? __int_as_float(e.y) : -INFINITY;
+    }
+    if (over && blockIdx.x == 0 && threadIdx.x == 0) over[q] = count[q] > cap ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void knn_gather_rows_kernel(const int64_t* __restrict__ rows, int cap, const int64_t* __restrict__ pos, int nq, int m,
+                                                               int64_t* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)nq * m) return;
+    const int q = (int)(e / m);
+    const int64_t p = pos[e];
+    out[e] = rows[(int64_t)q * cap + (p >= 0 && p < cap ? p : 0)];
+}
+}  // namespace
+
+extern "C" int ralf_knn_list_unpack(const int* list, const int* count, int nq, int cap, int64_t* rows, float* scores, int* over, void* stream) {
+    RALF_REQUIRE(list && count && rows && scores && nq > 0 && cap > 0, "knn_list_unpack: bad arguments");
+    hipLaunchKernelGGL(knn_list_unpack_kernel, dim3((cap + 255) / 256, nq), dim3(256), 0, (hipStream_t)stream, (const int2*)list, count, nq, cap, rows, scores, over);
+    return ralf::check_launch("knn_list_unpack");
+}
+extern "C" int ralf_knn_gather_rows(const int64_t* rows, int cap, const int64_t* pos, int nq, int m, int64_t* out, void* stream) {
+    RALF_REQUIRE(rows && pos && out && nq > 0 && m > 0 && cap > 0, "knn_gather_rows: bad arguments");
+    hipLaunchKernelGGL(knn_gather_rows_kernel, dim3((unsigned)(((int64_t)nq * m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, cap, pos, nq, m, out);
+    return ralf::check_launch("knn_gather_rows");
+}
+
 extern "C" int ralf_knn_scores(const float* X, int64_t N, int D, const float* Q, int nq, float* S, void* stream) {
     RALF_REQUIRE(X && Q && S, "knn_scores: null pointer");
     RALF_REQUIRE(N > 0 && nq > 0 && D > 0, "knn_scores: empty problem (n_db=%lld nq=%d dim=%d)", (long long)N, nq, D);

@@ -76,13 +76,15 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
          bias=None, act=None, res=None, ldr=None, aux=None, aux_mode=None, aux_scale=1.0, out2=None,
          alpha=1.0, accumulate=False, splitk=1, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=None,
          conv: Optional[dict] = None, gather=0, drop_p=0.0, seed=None, call_id=0, atomic=False, colstats=None,
-         sBias0=0, kseg=0, sBk=0, colscale=None, bnb=None, at=None) -> torch.Tensor:
+         sBias0=0, kseg=0, sBk=0, colscale=None, bnb=None, at=None, flt=None) -> torch.Tensor:
     """C = epi(alpha * A @ B) through ralf_gemm (see include/ralf_hip.h: RalfGemmDesc).
     at = dict(mode=1|2, c1, c2, c3=None, a2=None, out=None, mask=None, relu=False): the A-operand transform with write-through (at_*)."""
     assert A.is_cuda and B.is_cuda and A.dtype == B.dtype
     d = RalfGemmDesc()
     d.dtype = dtype_code(A)
     nb0, nb1 = batch
+    if out is None and flt is not None:
+        out = torch.empty(8, dtype=A.dtype, device=A.device)   # (never written: the filter replaces the output matrix)
     if out is None:
         odt = out_dtype or A.dtype
         out = torch.empty((nb1, nb0, M, N) if nb0 * nb1 > 1 else (M, N), dtype=odt, device=A.device)
@@ -115,6 +117,10 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
         bx, bm, bmean, bpart = bnb
         assert bx.dtype == A.dtype and bx.is_contiguous() and bx.numel() == M * N and bpart.dtype == torch.float32 and bpart.numel() >= ((M + 63) // 64) * 2 * N
         d.bnb_x, d.bnb_mask, d.bnb_mean, d.bnb_part = _p(bx), _p(bm), _p(bmean), _p(bpart)
+    if flt is not None:   # (thresholds fp32 [M], counters int32 [M] (zeroed), list int32 [M, cap, 2]): threshold filter instead of an output (flt_*)
+        th, cnt, lst = flt
+        assert th.dtype == torch.float32 and th.numel() >= M and cnt.dtype == torch.int32 and cnt.numel() >= M and lst.dtype == torch.int32 and lst.dim() == 3 and lst.shape[0] >= M and lst.shape[2] == 2
+        d.flt_thresh, d.flt_count, d.flt_list, d.flt_cap = _p(th), _p(cnt), _p(lst), lst.shape[1]
     if at is not None:
         a2, ao, am = at.get("a2"), at.get("out"), at.get("mask")
         assert A.dtype == torch.bfloat16 and a_kcontig and A.is_contiguous() and A.numel() == M * K

@@ -85,7 +85,12 @@ def knn_select_cand(exact: torch.Tensor, cand: torch.Tensor, k: int, bound=None,
     return val, idx, bad
 
 
-def knn_topk_ip_two_stage(index: torch.Tensor, index_bf16: torch.Tensor, queries: torch.Tensor, k: int, pool: int = 0, index_norms: torch.Tensor | None = None):
+FILTER_SAMPLE_ROWS = 4096   # rows of the index the threshold pass ranks (expected list length: (pool + 1) * N / this)
+FILTER_LIST_CAP = 4096      # candidate slots per query (a multiple of 4: the selection kernel's row alignment)
+
+
+def knn_topk_ip_two_stage(index: torch.Tensor, index_bf16: torch.Tensor, queries: torch.Tensor, k: int, pool: int = 0, index_norms: torch.Tensor | None = None,
+                          filtered: bool | None = None):
     """Exact top-k for LARGE query batches (nq >> 32, where the fp32 scan is bound by the 157 TFLOP/s fp32 matrix rate,
     SURVEY section 7): a bf16-MFMA coarse pass ranks every row, the best `pool` candidates per query are re-scored exactly
     in fp32 (same ascending-d accumulation chain as the exhaustive scan, so the scores are bit-identical), and the result is
@@ -108,11 +113,35 @@ def knn_topk_ip_two_stage(index: torch.Tensor, index_bf16: torch.Tensor, queries
     if index_norms is None:
         _, index_norms = knn_rownorms(index, index_bf16, want_rows=False, want_max=True)
     qn, _ = knn_rownorms(q, qb)
-    coarse = ops.gemm(qb, index_bf16, nq, N, D, out_dtype=torch.float32)             # [nq, N] = Qb Xb^T (bf16 MFMA, fp32 accumulate)
-    cval, cidx = knn_select(coarse, pool + 1)                                         # sorted by coarse score
+    cval = cidx = over = None
+    if filtered is None:
+        filtered = nq >= 256 and N >= 16 * FILTER_SAMPLE_ROWS // 4
+    if filtered:
+        # the coarse scores never reach memory: a first pass over a slice of the index gives every query a LOWER bound of its (pool+1)-th
+        # best coarse score (the (pool+1)-th best of a subset cannot exceed that of the whole), the pass over the whole index then keeps only
+        # the scores at or above that bound (RalfGemmDesc.flt_*: ~pool * N / slice candidates per query instead of N scores: 8 MB instead of
+        # the 252 MB score matrix written and re-read at BASELINE config 4)
+        ns = min(FILTER_SAMPLE_ROWS, N)
+        sval, _ = knn_select(ops.gemm(qb, index_bf16[:ns], nq, ns, D, out_dtype=torch.float32), pool + 1)
+        thresh = sval[:, pool].contiguous()
+        cnt = torch.zeros(nq, dtype=torch.int32, device=q.device)
+        lst = torch.empty(nq, FILTER_LIST_CAP, 2, dtype=torch.int32, device=q.device)
+        ops.gemm(qb, index_bf16, nq, N, D, flt=(thresh, cnt, lst))
+        rows = torch.empty(nq, FILTER_LIST_CAP, dtype=torch.int64, device=q.device)   # row ids / scores of the lists, -inf beyond the count
+        scores = torch.empty(nq, FILTER_LIST_CAP, dtype=torch.float32, device=q.device)
+        over = torch.empty(nq, dtype=torch.int32, device=q.device)                    # lists that lost candidates: redone exhaustively below
+        _lib.check(_lib.lib().ralf_knn_list_unpack(_lib.ptr(lst), _lib.ptr(cnt), nq, FILTER_LIST_CAP, _lib.ptr(rows), _lib.ptr(scores), _lib.ptr(over), _lib.stream_ptr()), "ralf_knn_list_unpack")
+        cval, pos = knn_select(scores, pool + 1)
+        cidx = torch.empty(nq, pool + 1, dtype=torch.int64, device=q.device)
+        _lib.check(_lib.lib().ralf_knn_gather_rows(_lib.ptr(rows), FILTER_LIST_CAP, _lib.ptr(pos), nq, pool + 1, _lib.ptr(cidx), _lib.stream_ptr()), "ralf_knn_gather_rows")
+    else:
+        coarse = ops.gemm(qb, index_bf16, nq, N, D, out_dtype=torch.float32)         # [nq, N] = Qb Xb^T (bf16 MFMA, fp32 accumulate)
+        cval, cidx = knn_select(coarse, pool + 1)                                     # sorted by coarse score
     # candidates = the pool+1 best coarse rows; every row outside them has a coarse score <= cval[:, pool]
     exact = knn_rescore(index, q, cidx)                                              # same fp32 MFMA chain as the exhaustive scan
     val, idx, bad = knn_select_cand(exact, cidx, k, bound=cval[:, pool], qnorms=qn, xnorms=index_norms, D=D)
+    if over is not None:
+        bad = bad | over
     bad = torch.nonzero(bad).flatten()                                               # (index plumbing; syncs with the host)
     if bad.numel():   # not certified (tiny gaps / mass ties): exhaustive fp32 scan for those queries only
         v2, i2 = knn_topk_ip(index, q[bad].contiguous(), k)

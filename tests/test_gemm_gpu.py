@@ -354,3 +354,75 @@ def test_direct_to_lds_kernels_are_bit_identical_to_register_staged(tmp_path):
         assert torch.equal(res["1"][k], res["0"][k]), k
     x = res["1"][(16384, 1024, 256, "plain")]
     assert torch.isfinite(x.float()).all() and x.float().abs().max() > 0.1
+
+
+# ---- operand transform with write-through (RalfGemmDesc.at_*): BatchNorm apply / backward apply inside the loader of a 1x1 convolution ----
+@pytest.mark.parametrize("M,K,N,res", [(4096 + 40, 256, 64, True), (4096, 512, 128, True), (8192 + 8, 64, 256, False), (2048, 128, 512, False), (2048, 256, 1024, False)])
+def test_operand_transform_forward_equals_bn_apply_then_product(M, K, N, res):
+    """at_mode 1: relu(A * scale + shift (+ res)) in the A loader, written through with its ReLU bits by the first column tile, product with
+    column statistics -- everything bit-identical to ralf_bn_apply followed by the plain product (64x64 and 128x128 tiles, ragged M,
+    one and several column tiles)"""
+    from ralf_amd import ops
+
+    y, W = rnd(M, K, seed=1).to(torch.bfloat16).cuda(), (rnd(N, K, seed=2) * K ** -0.5).to(torch.bfloat16).cuda()
+    r = rnd(M, K, seed=3).to(torch.bfloat16).cuda() if res else None
+    sc, sh = (0.5 + torch.rand(K, generator=torch.Generator().manual_seed(4))).cuda(), (0.3 * rnd(K, seed=5)).cuda()
+    z, mask = torch.empty_like(y), torch.empty(M * K // 8, dtype=torch.uint8, device="cuda")
+    stats = N % 64 == 0
+    cst = ops.colstats_buffer(M, N, y.device) if stats else None
+    ops._call("ralf_bn_apply", ops.dtype_code(y), ops._p(y), ops._p(sc), ops._p(sh), ops._p(r), ops._p(z), ops._p(mask), M, K, 1)
+    want = ops.gemm(z, W, M, N, K, colstats=cst)
+    z2, mask2 = torch.full_like(y, 7.0), torch.zeros_like(mask)
+    cst2 = ops.colstats_buffer(M, N, y.device) if stats else None
+    got = ops.gemm(y, W, M, N, K, colstats=cst2, at=dict(mode=1, c1=sc, c2=sh, a2=r, out=z2, mask=mask2, relu=True))
+    assert torch.equal(got, want) and torch.equal(z2, z) and torch.equal(mask2, mask)
+    if stats:
+        assert torch.equal(cst2, cst)
+    torch.testing.assert_close(z.float().cpu(), torch.relu(y.float().cpu() * sc.cpu() + sh.cpu() + (r.float().cpu() if res else 0)), atol=2e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("M,K,N,bnb", [(4096 + 40, 256, 64, True), (4096, 512, 128, True), (4096, 64, 256, True), (2048, 128, 512, False)])
+def test_operand_transform_backward_equals_bn_bwd_apply_then_data_gradient(M, K, N, bnb):
+    """at_mode 2: dy = c1 dz + c2 x + c3 in the A loader of the data-gradient product (NN), written through; with the BatchNorm-backward
+    reductions of the NEXT layer in the epilogue (bnb_*): bit-identical to ralf_bn_bwd_apply_affine followed by the product.  The
+    coefficients come from ralf_bn_bwd_stats_from_partials and reproduce torch's batch-norm backward."""
+    from ralf_amd import ops
+
+    dev = "cuda"
+    dz, x, W = rnd(M, K, seed=1).to(torch.bfloat16).cuda(), rnd(M, K, seed=2).to(torch.bfloat16).cuda(), (rnd(K, N, seed=3) * K ** -0.5).to(torch.bfloat16).cuda()
+    gamma, mean = (0.5 + torch.rand(K, generator=torch.Generator().manual_seed(4))).cuda(), x.float().mean(0)
+    rstd = (x.float().var(0, unbiased=False) + 1e-5).rsqrt()
+    # the partial rows a data-gradient epilogue would have written: per 64-row block, sum dz and sum dz (x - mean)
+    nb = (M + 63) // 64
+    pad = nb * 64 - M
+    dzp, xp = torch.nn.functional.pad(dz.float(), (0, 0, 0, pad)), torch.nn.functional.pad(x.float() - mean, (0, 0, 0, pad))
+    part = torch.stack([dzp.view(nb, 64, K).sum(1), (dzp * xp).view(nb, 64, K).sum(1)], dim=1).contiguous()
+    s1, s2, coef = torch.zeros(K, device=dev), torch.zeros(K, device=dev), torch.empty(3, K, device=dev)
+    ops._call("ralf_bn_bwd_stats_from_partials", ops._p(part), nb, ops._p(rstd), ops._p(s1), ops._p(s2), K, ops._p(torch.empty(128 * 2 * K, device=dev)),
+              ops._p(gamma), ops._p(mean), M, ops._p(coef))
+    dy = torch.empty_like(dz)
+    ops._call("ralf_bn_bwd_apply_affine", ops.dtype_code(dz), ops._p(dz), ops._p(x), ops._p(coef[0]), ops._p(coef[1]), ops._p(coef[2]), ops._p(dy), M, K)
+    xh = (x.float() - mean) * rstd
+    ref = gamma * rstd * (dz.float() - dz.float().mean(0) - xh * (dz.float() * xh).mean(0))          # torch's native_batch_norm_backward (training)
+    torch.testing.assert_close(dy.float(), ref, atol=3e-2, rtol=2e-2)
+    extra, extra2 = {}, {}
+    if bnb:
+        bx, bm = rnd(M, N, seed=6).to(torch.bfloat16).cuda(), torch.randint(0, 256, (M * N // 8,), dtype=torch.uint8, generator=torch.Generator().manual_seed(7)).cuda()
+        bmean, res = rnd(N, seed=8).cuda(), rnd(M, N, seed=9).to(torch.bfloat16).cuda()
+        p1, p2 = torch.empty(nb, 2, N, device=dev), torch.empty(nb, 2, N, device=dev)
+        extra, extra2 = dict(res=res, bnb=(bx, bm, bmean, p1)), dict(res=res, bnb=(bx, bm, bmean, p2))
+    want = ops.gemm(dy, W, M, N, K, b_kcontig=False, **extra)
+    dy2 = torch.full_like(dz, 7.0)
+    got = ops.gemm(dz, W, M, N, K, b_kcontig=False, at=dict(mode=2, c1=coef[0], c2=coef[1], c3=coef[2], a2=x, out=dy2), **extra2)
+    assert torch.equal(got, want) and torch.equal(dy2, dy)
+    if bnb:
+        assert torch.equal(p1, p2)
+
+
+def test_operand_transform_refuses_what_it_does_not_cover():
+    from ralf_amd import _lib, ops
+
+    y, W = rnd(256, 1024, seed=1).to(torch.bfloat16).cuda(), rnd(64, 1024, seed=2).to(torch.bfloat16).cuda()
+    c = torch.ones(1024, device="cuda")
+    with pytest.raises(_lib.RalfHipError, match="K <= 512"):
+        ops.gemm(y, W, 256, 64, 1024, at=dict(mode=1, c1=c, c2=c))

@@ -173,6 +173,40 @@ def test_two_stage_search_equals_exhaustive(N, D, nq, k):
     assert torch.equal(i2, i_ref) and torch.equal(v2, v_ref)
 
 
+@pytest.mark.parametrize("filtered", [True, False])
+def test_two_stage_filtered_coarse_pass_equals_the_dense_one(filtered):
+    """the coarse pass that keeps only the scores above a per-query bound (RalfGemmDesc.flt_*: no [nq, N] score matrix) returns what the dense
+    coarse pass returns = the exhaustive scan; an index whose leading slice holds nothing similar to the queries floods the lists
+    (more hits than slots), which must be noticed and redone exhaustively"""
+    from ralf_amd import ops
+    from ralf_amd.retrieval import knn as K
+
+    N, D, nq, k = 20000, 256, 300, 16
+    g = torch.Generator(device="cuda").manual_seed(11)
+    X = torch.randn(N, D, device="cuda", generator=g)
+    X /= X.norm(dim=1, keepdim=True)
+    X[9000] = X[40]                                     # exact duplicates inside the candidate range
+    Q = torch.randn(nq, D, device="cuda", generator=g)
+    Q /= Q.norm(dim=1, keepdim=True)
+    Q[5] = X[40]
+    v_ref, i_ref = K.knn_topk_ip(X, Q, k)
+    v, i, nfb = K.knn_topk_ip_two_stage(X, ops.cast(X, torch.bfloat16), Q, k, filtered=filtered)
+    assert torch.equal(i, i_ref) and torch.equal(v, v_ref) and nfb < nq // 4
+    if not filtered:
+        return
+    # flooded lists: the threshold slice is orthogonal to every query, the rest of the index is not
+    u = torch.zeros(D, device="cuda"); u[0] = 1.0
+    X2 = X.clone()
+    X2[:K.FILTER_SAMPLE_ROWS] = -u                      # scores <= 0 against queries with a positive first coordinate
+    Q2 = Q.clone(); Q2[:, 0] = Q2[:, 0].abs() + 0.5; Q2 /= Q2.norm(dim=1, keepdim=True)
+    X2[K.FILTER_SAMPLE_ROWS:, 0] = X2[K.FILTER_SAMPLE_ROWS:, 0].abs() + 0.5
+    X2[K.FILTER_SAMPLE_ROWS:] /= X2[K.FILTER_SAMPLE_ROWS:].norm(dim=1, keepdim=True)
+    v_ref, i_ref = K.knn_topk_ip(X2, Q2, k)
+    v, i, nfb = K.knn_topk_ip_two_stage(X2, ops.cast(X2, torch.bfloat16), Q2, k, filtered=True)
+    assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
+    assert nfb == nq                                    # every list overflowed (N - 4096 hits > 4096 slots): all redone exhaustively
+
+
 def test_sharded_search_forms_on_the_hip_scan():
     """SURVEY 8e on the real scan (1-rank RCCL group; the 2-rank exchange is covered on CPU with gloo): query-sharded replicas and
     an index shard with a row offset return the table of the plain search"""

@@ -177,6 +177,9 @@ def test_dp_selftest_is_as_fast_with_the_users_queue_setting_as_with_the_default
     ran it at 35.6 ms against 16.2 with ROCclr's default of 4.  The library now pins GPU_MAX_HW_QUEUES itself when it is
     imported (ralf_amd/__init__.py): `bench.py --dp-selftest` (1-rank RCCL group, staged backward, overlapped exchange) started with
     GPU_MAX_HW_QUEUES=8 in the environment must run like the one started without it"""
+    import json
+    import subprocess
+
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ms = {}
     for name, extra in (("default", {}), ("user_sets_8", {"GPU_MAX_HW_QUEUES": "8"})):

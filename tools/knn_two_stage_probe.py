@@ -27,6 +27,26 @@ t["coarse GEMM bf16 -> fp32 scores [1024 x 61548]"] = _time_gpu(lambda: ops.gemm
 t["select top-65 of the coarse scores"] = _time_gpu(lambda: knn_select(coarse, pool + 1), 10, 2)
 t["exact re-score of 65 candidates per query"] = _time_gpu(lambda: knn_rescore(X, Q, cidx), 10, 2)
 t["candidate select + certificate"] = _time_gpu(lambda: knn_select_cand(exact, cidx, k, bound=cval[:, pool], qnorms=qn, xnorms=xn, D=D), 10, 2)
-t["whole call"] = _time_gpu(lambda: knn_topk_ip_two_stage(X, Xb, Q, k, index_norms=xn), 10, 2)
+t["whole call, dense coarse pass"] = _time_gpu(lambda: knn_topk_ip_two_stage(X, Xb, Q, k, index_norms=xn, filtered=False), 10, 2)
+from ralf_amd.retrieval import knn as K  # noqa: E402
+ns = K.FILTER_SAMPLE_ROWS
+t["threshold pass: GEMM on 4096 rows + select"] = _time_gpu(lambda: knn_select(ops.gemm(qb, Xb[:ns], nq, ns, D, out_dtype=torch.float32), pool + 1), 10, 2)
+sval, _ = knn_select(ops.gemm(qb, Xb[:ns], nq, ns, D, out_dtype=torch.float32), pool + 1)
+th = sval[:, pool].contiguous()
+cnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
+lst = torch.empty(nq, K.FILTER_LIST_CAP, 2, dtype=torch.int32, device="cuda")
+
+
+def filt():
+    cnt.zero_()
+    ops.gemm(qb, Xb, nq, N, D, flt=(th, cnt, lst))
+
+
+t["filtered coarse GEMM (no score matrix) incl. counter reset"] = _time_gpu(filt, 10, 2)
+print("list lengths: mean %.0f max %d (capacity %d)" % (cnt.float().mean().item(), int(cnt.max()), K.FILTER_LIST_CAP))
+t["whole call, filtered coarse pass"] = _time_gpu(lambda: knn_topk_ip_two_stage(X, Xb, Q, k, index_norms=xn, filtered=True), 10, 2)
+v0, i0, _ = knn_topk_ip_two_stage(X, Xb, Q, k, index_norms=xn, filtered=False)
+v1, i1, nfb = knn_topk_ip_two_stage(X, Xb, Q, k, index_norms=xn, filtered=True)
+print("filtered == dense:", bool(torch.equal(i0, i1) and torch.equal(v0, v1)), "fallback queries:", nfb)
 for name, v in t.items():
     print(f"{name:52s} {v * 1e6:8.1f} us")
