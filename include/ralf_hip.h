@@ -62,10 +62,11 @@ int ralf_knn_select_cand(const float* exact, const int64_t* cand, int nq, int po
 /* per row of X fp32 [R, D] and its bf16 copy Xb: norms[r] = {|x|, |xb|, |x - xb|} (fp32 [R, 3], may be NULL); maxes fp32 [3]
  * (may be NULL, zero on entry) = column maxima over the rows.  Values are rounded UP (they feed an upper bound). */
 int ralf_knn_rownorms(const float* X, const void* Xb_bf16, int64_t R, int D, float* norms, float* maxes, void* stream);
-/* the candidate lists a filtered coarse pass wrote (RalfGemmDesc.flt_*: list int32 [nq][cap][2] = {row, score bits}, count int32 [nq]) as the
- * dense pair the selection kernels take: rows int64 [nq][cap] (0 beyond the count), scores fp32 [nq][cap] (-inf beyond the count), and
- * over int32 [nq] (may be NULL) = 1 where count > cap (the list lost candidates).  ralf_knn_gather_rows: out[q][j] = rows[q][pos[q][j]]. */
-int ralf_knn_list_unpack(const int* list, const int* count, int nq, int cap, int64_t* rows, float* scores, int* over, void* stream);
+/* the candidate slots a filtered coarse pass wrote (RalfGemmDesc.flt_*: list int32 [nq][T][cap][2] = {row, score bits}, count int32 [nq][T]) as
+ * the dense pair the selection kernels take: rows int64 [nq][T * cap] (0 in unused slots), scores fp32 [nq][T * cap] (-inf in unused slots);
+ * over int32 [nq] (may be NULL, ZEROED by the caller) is set to 1 where a tile's count exceeds cap (the list lost candidates).
+ * ralf_knn_gather_rows: out[q][j] = rows[q][pos[q][j]] (rows with a row length of cap). */
+int ralf_knn_list_unpack(const int* list, const int* count, int nq, int T, int cap, int64_t* rows, float* scores, int* over, void* stream);
 int ralf_knn_gather_rows(const int64_t* rows, int cap, const int64_t* pos, int nq, int m, int64_t* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -158,17 +159,19 @@ typedef struct RalfGemmDesc {
     int at_mode, at_relu;
     const void* at_a2; const float* at_c1; const float* at_c2; const float* at_c3;
     void* at_out; unsigned char* at_mask;
-    /* Threshold filter instead of an output matrix (flt_list NULL = off): element (m, n) of the product is APPENDED to row m's candidate
-     * list when value >= flt_thresh[m] -- flt_count[m] (int32, zeroed by the caller) counts the hits, hit number p < flt_cap is stored as
-     * flt_list[(m * flt_cap + p)] = {n as int32, value as fp32} (8 bytes); nothing else is written (C is ignored).  The coarse bf16 pass
-     * of the two-stage top-k search (ralf_amd/retrieval/knn.py; replaces writing and re-reading the [nq, N] score matrix, 252 MB at BASELINE
-     * config 4): with a per-query lower bound of its (pool+1)-th best score as threshold the lists hold a superset of the pool.  Hits arrive
-     * in no fixed order (atomics); rows with flt_count > flt_cap lost hits and must be redone by the caller.  bf16, A and B k-contiguous,
-     * aligned interior path, one batch, no split-K, plain epilogue (alpha only). */
+    /* Threshold filter instead of an output matrix (flt_list NULL = off): element (m, n) of the product is kept when value >= flt_thresh[m].
+     * Every column tile t of the launch (tiles of flt_tile columns, as ralf_gemm_filter_tile() reports for the shape) owns flt_cap slots
+     * of row m's candidate list: hit number p < flt_cap of the tile is stored as flt_list[(m * T + t) * flt_cap + p] = {n as int32, value as
+     * fp32} (8 bytes), and flt_count[m * T + t] = the tile's number of hits (T = ceil(N / flt_tile); every entry is written exactly once:
+     * no zero-fill; a count above flt_cap means the tile lost hits and the caller must redo that row).  Nothing else is written (C is
+     * ignored).  The coarse bf16 pass of the two-stage top-k search (ralf_amd/retrieval/knn.py; replaces writing and re-reading the [nq, N]
+     * score matrix, 252 MB at BASELINE config 4): with a per-query lower bound of its (pool+1)-th best score as threshold the lists hold a
+     * superset of the pool.  bf16, A and B k-contiguous, aligned interior path, one batch, no split-K, plain epilogue (alpha only). */
     const float* flt_thresh; int* flt_count; void* flt_list; int flt_cap, flt_pad_;
 } RalfGemmDesc;
 size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d);
 int ralf_gemm(const RalfGemmDesc* d, void* workspace, size_t workspace_bytes, void* stream);
+int ralf_gemm_filter_tile(const RalfGemmDesc* d);   /* column-tile width (64 or 128) ralf_gemm will use for this flt_* product; <= 0 on error */
 
 /* Weight gradients of MANY linear layers in one launch (the `dW += dy^T x` products autograd issues one by one for nn.Linear /
  * nn.MultiheadAttention in_proj / out_proj, e.g. 24 per encoder stack): job j adds dy_j^T x_j into the fp32 matrix dw_j.

@@ -15,7 +15,7 @@ SIGNATURES = {
     "ralf_knn_rescore": (i32, [vp, i64, i32, vp, i32, vp, i32, vp, vp]),
     "ralf_knn_select_cand": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, i64, vp, vp, i32, vp, vp]),
     "ralf_knn_rownorms": (i32, [vp, vp, i64, i32, vp, vp, vp]),
-    "ralf_knn_list_unpack": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
+    "ralf_knn_list_unpack": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "ralf_knn_gather_rows": (i32, [vp, i32, vp, i32, i32, vp, vp]),
 }
 
@@ -98,6 +98,7 @@ SIGNATURES.update({
     "ralf_conv_relayout_batched": (i32, [vp, i32, i32, vp]),
     "ralf_gemm_workspace_bytes": (sz, [ctypes.POINTER(RalfGemmDesc)]),
     "ralf_gemm": (i32, [ctypes.POINTER(RalfGemmDesc), vp, sz, vp]),
+    "ralf_gemm_filter_tile": (i32, [ctypes.POINTER(RalfGemmDesc)]),
 })
 
 u64, u8p = ctypes.c_uint64, vp

@@ -35,6 +35,13 @@ extern "C" size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d) {
     return (size_t)d->splitk * nb * d->M * d->N * sizeof(float);
 }
 
+extern "C" int ralf_gemm_filter_tile(const RalfGemmDesc* dp) {
+    if (!dp || dp->M <= 0 || dp->N <= 0 || dp->K <= 0) { ralf::set_error("gemm_filter_tile: bad descriptor"); return RALF_ERR_INVALID; }
+    RalfGemmDesc d = *dp;
+    d.splitk = 1;
+    return gemm_use128(d, 1) ? 128 : 64;
+}
+
 extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspace_bytes, void* stream) {
     RALF_REQUIRE(dp, "gemm: null descriptor");
     KParams P;

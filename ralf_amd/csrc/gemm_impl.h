@@ -82,6 +82,7 @@ struct KParams {
     FastDiv fd_hw, fd_rw, fd_sc, fd_kw, fd_st;   // RH*RW, RW, SC, KW, stride of d.g
     FastDiv fd_tap;                              // stride in mode 1 (data gradient), 1 in mode 0: the divisor of tap_offset
     int tiles_m, tiles_n, nwg;
+    int mfast;        // tile order: 0 = column tiles fastest (consecutive workgroups of an XCD share an A tile: B small / L2-resident), 1 = row tiles fastest
     int kchunk;       // K range handled by one split (multiple of BK)
     float* partial;   // [split][batch][M][N] fp32 (splitk > 1)
     int vec_epi;      // leading dims / bases allow 4-wide epilogue accesses
@@ -291,22 +292,18 @@ __device__ __forceinline__ void epilogue_storev_bnb(const RalfGemmDesc& d, int m
     }
     VIO<T, 8>::st(d.C, e, v);
 }
-// EPI 4 (RalfGemmDesc.flt_*): no output matrix -- the W values of row m that reach the row's threshold are appended to its candidate list
+// EPI 4 (RalfGemmDesc.flt_*): no output matrix -- the values of row m that reach the row's threshold go to the slots this COLUMN TILE owns in the
+// row's candidate list: flt_list[(m * tiles_n + tn) * flt_cap + p], p counted by an LDS counter per tile row (no global atomics: device-scope
+// returning atomics on ~1000 addresses ran the product at 850 us instead of 390), flt_count[m * tiles_n + tn] = hits of the tile (every
+// (row, tile) pair is written exactly once: no zero-fill)
 template <int W>
-__device__ __forceinline__ void epilogue_filter(const RalfGemmDesc& d, int m, int n, const float (&v)[W], int ncols) {
-    const float th = d.flt_thresh[m];
-    bool any = false;
+__device__ __forceinline__ void epilogue_filter(const RalfGemmDesc& d, int m, int n, const float (&v)[W], int ncols, float th, unsigned* lcnt, int2* slots) {
 #pragma unroll
-    for (int q = 0; q < W; ++q) any = any || (v[q] * d.alpha >= th && n + q < ncols);
-    if (any) {   // (rare: the threshold passes ~1-2 % of the scores)
-        int2* list = reinterpret_cast<int2*>(d.flt_list) + (int64_t)m * d.flt_cap;
-#pragma unroll
-        for (int q = 0; q < W; ++q) {
-            const float s = v[q] * d.alpha;
-            if (s >= th && n + q < ncols) {
-                const int pos = atomicAdd(d.flt_count + m, 1);
-                if (pos < d.flt_cap) list[pos] = make_int2(n + q, __float_as_int(s));
-            }
+    for (int q = 0; q < W; ++q) {
+        const float s = v[q] * d.alpha;
+        if (s >= th && n + q < ncols) {   // (rare: the threshold passes ~1-2 % of the scores)
+            const unsigned pos = atomicAdd(lcnt, 1u);
+            if (pos < (unsigned)d.flt_cap) slots[pos] = make_int2(n + q, __float_as_int(s));
         }
     }
 }
@@ -550,7 +547,9 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
         const int vid = xcd_remap(bid, total);
         split = vid / P.nwg;
         const int tile = vid - split * P.nwg;
-        const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
+        int tm, tn;
+        if (P.mfast) { tn = tile / P.tiles_m; tm = tile - tn * P.tiles_m; }
+        else         { tm = tile / P.tiles_n; tn = tile - tm * P.tiles_n; }
         m0 = tm * BM; n0 = tn * BN;
         kbeg = split * P.kchunk;
         kend = min(d.K, kbeg + P.kchunk);
@@ -1050,7 +1049,7 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     // ---- epilogue: lane holds 4 consecutive columns n per register group g = r>>2 ----
     // (no `continue`/`break` in these loops: they must unroll completely or the accumulators spill to scratch)
     const bool slab = d.splitk > 1 && !d.atomic_out;
-    if ((P.vec_epi >= 2 || EPI == 4) && c_n0 + BN <= d.N) {
+    if (EPI == 4 || (P.vec_epi >= 2 && c_n0 + BN <= d.N)) {   // (the filter checks the column range itself: partial tiles take the staged form too)
         // tile interior in n: the accumulators go through LDS so every lane stores 8 consecutive columns of one row
         // (8 lanes = one 128-byte line of bf16) instead of 32 rows x 8 bytes per store instruction; residual / mask /
         // accumulate reads get the same shape.  64 tile rows per round.
@@ -1094,6 +1093,12 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                     pr[0] = s1; pr[d.N] = s2;
                 }
             }
+            unsigned* fcnt = reinterpret_cast<unsigned*>(cs + 64 * CP);   // EPI 4: hit counters of the round's 64 rows (behind the C staging tile)
+            if constexpr (EPI == 4) {
+                static_assert(64 * CP * 4 + 64 * 4 <= gemm_lds_bytes<T, AK, BKC, FM, FN, gemm_nbuf<GATHER, FM>(), (GATHER == 5 || GATHER == 6)>(), "filter counters behind the staging tile");
+                if (tid < 64) fcnt[tid] = 0u;
+                __syncthreads();
+            }
             float bs1[8], bs2[8], bmu[8];   // EPI 3: this thread's column sums over its rows of the block, the columns' BatchNorm means
             if constexpr (EPI == 3) {
                 VIO<float, 8>::ld(d.bnb_mean, c_n0 + (tid % CG) * 8, bmu);
@@ -1108,10 +1113,17 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                     const float4 lo = *reinterpret_cast<const float4*>(cs + lr * CP + c), hi = *reinterpret_cast<const float4*>(cs + lr * CP + c + 4);
                     float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                     if constexpr (EPI == 3) epilogue_storev_bnb<T>(d, m, c_n0 + c, v, bmu, bs1, bs2);
-                    else if constexpr (EPI == 4) epilogue_filter<8>(d, m, c_n0 + c, v, d.N);
+                    else if constexpr (EPI == 4)
+                        epilogue_filter<8>(d, m, c_n0 + c, v, d.N, d.flt_thresh[m], fcnt + lr,
+                                           reinterpret_cast<int2*>(d.flt_list) + ((int64_t)m * P.tiles_n + c_n0 / BN) * d.flt_cap);
                     else if (slab) VIO<float, 8>::st(pbase, (int64_t)m * d.N + c_n0 + c, v);
                     else epilogue_storev<T, (EPI >= 3 ? 0 : EPI), 8>(d, z0, z1, m, c_n0 + c, v);
                 }
+            }
+            if constexpr (EPI == 4) {
+                __syncthreads();
+                const int m = c_m0 + h * 64 + tid;
+                if (tid < 64 && m < d.M) d.flt_count[(int64_t)m * P.tiles_n + c_n0 / BN] = (int)fcnt[tid];
             }
             if constexpr (EPI == 3) {
                 // the RPP threads that share a column group hand their sums over through the (now idle) staging tile, fixed order
@@ -1142,9 +1154,6 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                 const int n = c_n0 + wn * 32 * WFN + j * 32 + 8 * g + 4 * lh;
                 float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 if (m < d.M && n < d.N) {
-                    if constexpr (EPI == 4) {
-                        epilogue_filter<4>(d, m, n, v, d.N);
-                    } else
                     if (slab) {
                         float* pp = P.partial + (((int64_t)c_split * nbatch + z) * d.M + m) * d.N + n;
                         if (P.vec_epi && n + 3 < d.N) *reinterpret_cast<float4*>(pp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -1211,7 +1220,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_grouped_kernel(
     d.alpha = 1.f; d.aux_scale = 1.f; d.seed = nullptr; d.call_id = 0; d.drop_p = 0.f; d.atomic_out = 0; d.colstats = nullptr;
     d.sBias0 = 0; d.sBk = 0; d.kseg = 0; d.colscale = nullptr;
     d.bnb_x = nullptr; d.bnb_mask = nullptr; d.bnb_mean = nullptr; d.bnb_part = nullptr;
-    P.tiles_n = J.tiles_n; P.tiles_m = J.nwg / J.tiles_n; P.nwg = J.nwg; P.kchunk = J.kchunk; P.partial = J.partial;
+    P.tiles_n = J.tiles_n; P.tiles_m = J.nwg / J.tiles_n; P.nwg = J.nwg; P.kchunk = J.kchunk; P.partial = J.partial; P.mfast = 0;
     P.vec_epi = 2; P.fast = 1; P.tapuni = 0;
     gemm_body<T, false, false, GATHER, FM, FN, 0, NW>(P, b - J.first, 1, 0, 1, lds_raw);
 }
@@ -1367,6 +1376,12 @@ int resident_workgroups(K kernel, int threads) {
 template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW = 4>
 int launch(KParams& P, int nbatch, hipStream_t st) {
     P.tiles_m = ceil_div(P.d.M, 64 * FM);
+    // which operand an XCD keeps in its L2 while the other streams past: workgroups get consecutive tile ids per XCD (xcd_remap), so the
+    // tile index that runs fastest is the one whose operand is re-read.  Activations x weights: the weights (B) are the small operand ->
+    // column tiles fastest.  A few hundred queries x a 220 MB index (the two-stage k-NN's coarse pass): with column tiles fastest every XCD
+    // owned one row tile and streamed the WHOLE index (8 x 220 MB per call: 390 us); row tiles fastest keeps the 3.7 MB of queries resident
+    // and streams every index row once.
+    P.mfast = (AK && BKC && GATHER != 1 && GATHER != 4 && nbatch == 1 && P.d.splitk == 1 && !P.d.kseg && (int64_t)P.d.M * 4 <= (int64_t)P.d.N) ? 1 : 0;
     P.tiles_n = ceil_div(P.d.N, 64 * FN);
     P.nwg = P.tiles_m * P.tiles_n;
     constexpr bool persist = RALF_GEMM_PERSISTENT != 0;   // off: measured -4...+6 % (the prefetch across the epilogue costs a wave of occupancy)
@@ -1406,18 +1421,29 @@ int launch_epi(KParams& P, int nbatch, hipStream_t st) {
 //   128x128, 8 waves (2 x 4, 64x32 per wave, 2 workgroups = 16 waves per CU): a third fewer LDS cycles per flop and as
 //     many waves in flight -> 10-15 % faster wherever >= ~200 such tiles exist.  (128x128 with 4 waves of 64x64 has the
 //     fewest LDS cycles but only 8 waves per CU: latency-bound, no faster than 64x64 below K ~ 4096; 128x64 / 64x128: +-5 %.)
-template <typename T, bool AK, bool BKC, int GATHER>
-int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
-    const RalfGemmDesc& d = P.d;
+// 128 x 128 tiles (8 waves) or 64 x 64 (4 waves) for this product -- ONE rule for launch_cfg and for callers that must know the tile width
+// (ralf_gemm_filter_tile: the slot layout of the threshold filter)
+inline bool gemm_use128(const RalfGemmDesc& d, int nbatch) {
     static const int forced = [] { const char* e = getenv("RALF_GEMM_TILE"); return e ? atoi(e) : 0; }();  // tuning / test aid: 22 / 11
     const bool ok22 = (!d.colstats && !d.bnb_part) || d.N % 128 == 0;   // column statistics come from the staged epilogue: every tile interior in n
-    if (forced == 22 && ok22) return launch_epi<T, AK, BKC, GATHER, 2, 2, 8>(P, nbatch, st);
-    if (forced == 11) return launch_epi<T, AK, BKC, GATHER, 1, 1, 4>(P, nbatch, st);
+    if (forced == 22 && ok22) return true;
+    if (forced == 11) return false;
     const int64_t big = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) * d.splitk * nbatch;
     const int kspan = ceil_div(d.K, d.splitk);
     const bool shape_ok = ok22 && d.M >= 128 && (d.N % 128 == 0 || d.N >= 512);
     static const int big1 = [] { const char* e = getenv("RALF_GEMM_BIG"); return e ? atoi(e) : 192; }();   // tuning aid (tools/knob_sweep.sh)
-    const bool use128 = shape_ok && ((d.splitk == 1 && big >= big1) || (kspan >= 1024 && big >= 512));
+    return shape_ok && ((d.splitk == 1 && big >= big1) || (kspan >= 1024 && big >= 512));
+}
+
+template <typename T, bool AK, bool BKC, int GATHER>
+int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
+    const RalfGemmDesc& d = P.d;
+    static const int forced = [] { const char* e = getenv("RALF_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    const bool use128 = gemm_use128(d, nbatch);
+    const int64_t big = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) * d.splitk * nbatch;
+    const int kspan = ceil_div(d.K, d.splitk);
+    if (forced == 22 && use128) return launch_epi<T, AK, BKC, GATHER, 2, 2, 8>(P, nbatch, st);
+    if (forced == 11) return launch_epi<T, AK, BKC, GATHER, 1, 1, 4>(P, nbatch, st);
     if constexpr (GATHER == 3 && AK && BKC && sizeof(T) == 2) {
         // DIRECT-TO-LDS main loop for the aligned NT products on 128x128 tiles (forward linear layers / 1x1 convolutions): bit-identical to
         // the register-staged kernel.  Measured on MI355X -- tools/gemm_lab.hip (back-to-back launches of one shape, interleaved A/B):
@@ -1469,7 +1495,7 @@ int dispatch(KParams& P, int nbatch, hipStream_t st) {
     }
     if constexpr (sizeof(T) == 2) {   // bf16: the interior fast path is its own (leaner) set of kernels; fp32 is the parity mode
         static const int skinny_rows = [] { const char* e = getenv("RALF_GEMM_SKINNY_ROWS"); return e ? atoi(e) : 512; }();   // 0 = off (A/B runs)
-        if (P.fast && key == 6 && d.M <= skinny_rows && nbatch == 1 && d.splitk == 1 && !d.colstats && !d.bnb_part && !d.kseg && !d.atomic_out) {
+        if (P.fast && key == 6 && d.M <= skinny_rows && nbatch == 1 && d.splitk == 1 && !d.colstats && !d.bnb_part && !d.kseg && !d.atomic_out && !d.flt_list) {
             const bool lvl2 = d.C2 || d.act == RALF_ACT_GELU || d.aux_mode == RALF_AUX_GELU_GRAD;
             const bool lvl1 = d.drop_p > 0.f || d.aux;
             return lvl2 ? launch_skinny<T, 2>(P, st) : lvl1 ? launch_skinny<T, 1>(P, st) : launch_skinny<T, 0>(P, st);

@@ -513,17 +513,22 @@ static int scores_impl(const float* X, int64_t N, int D, const float* Q, int nq,
 
 // ---- candidate lists of the filtered coarse pass (RalfGemmDesc.flt_*) -> the dense form the selection kernels take ----
 namespace {
-__global__ __launch_bounds__(256) void knn_list_unpack_kernel(const int2* __restrict__ list, const int* __restrict__ count, int nq, int cap,
+// slots [nq][T][cap] {row, score bits} with count [nq][T] hits per column tile -> dense rows / scores [nq][T * cap] (unused slots: row 0, -inf)
+__global__ __launch_bounds__(256) void knn_list_unpack_kernel(const int2* __restrict__ list, const int* __restrict__ count, int nq, int T, int cap,
                                                                int64_t* __restrict__ rows, float* __restrict__ scores, int* __restrict__ over) {
     const int q = blockIdx.y;
-    const int n = min(count[q], cap);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < cap; i += gridDim.x * 256) {
-        const bool ok = i < n;
-        const int2 e = list[(int64_t)q * cap + (ok ? i : 0)];
-        rows[(int64_t)q * cap + i] = ok ? (int64_t)e.x : 0;                       // (an unused slot must still name a valid row)
-        scores[(int64_t)q * cap + i] = ok ? __int_as_float(e.y) : -INFINITY;
+    const int64_t W = (int64_t)T * cap;
+    int lost = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < W; i += (int64_t)gridDim.x * 256) {
+        const int t = (int)(i / cap), p = (int)(i % cap);
+        const int c = count[(int64_t)q * T + t];
+        const bool ok = p < c;
+        lost |= (p == 0 && c > cap) ? 1 : 0;
+        const int2 e = list[(int64_t)q * W + (ok ? i : (int64_t)t * cap)];
+        rows[(int64_t)q * W + i] = ok ? (int64_t)e.x : 0;                         // (an unused slot must still name a valid row)
+        scores[(int64_t)q * W + i] = ok ? __int_as_float(e.y) : -INFINITY;
     }
-    if (over && blockIdx.x == 0 && threadIdx.x == 0) over[q] = count[q] > cap ? 1 : 0;
+    if (over && lost) atomicOr(over + q, 1);
 }
 __global__ __launch_bounds__(256) void knn_gather_rows_kernel(const int64_t* __restrict__ rows, int cap, const int64_t* __restrict__ pos, int nq, int m,
                                                                int64_t* __restrict__ out) {
@@ -535,9 +540,10 @@ __global__ __launch_bounds__(256) void knn_gather_rows_kernel(const int64_t* __r
 }
 }  // namespace
 
-extern "C" int ralf_knn_list_unpack(const int* list, const int* count, int nq, int cap, int64_t* rows, float* scores, int* over, void* stream) {
-    RALF_REQUIRE(list && count && rows && scores && nq > 0 && cap > 0, "knn_list_unpack: bad arguments");
-    hipLaunchKernelGGL(knn_list_unpack_kernel, dim3((cap + 255) / 256, nq), dim3(256), 0, (hipStream_t)stream, (const int2*)list, count, nq, cap, rows, scores, over);
+extern "C" int ralf_knn_list_unpack(const int* list, const int* count, int nq, int T, int cap, int64_t* rows, float* scores, int* over, void* stream) {
+    RALF_REQUIRE(list && count && rows && scores && nq > 0 && T > 0 && cap > 0, "knn_list_unpack: bad arguments");
+    const int64_t W = (int64_t)T * cap;
+    hipLaunchKernelGGL(knn_list_unpack_kernel, dim3((unsigned)std::min<int64_t>((W + 255) / 256, 64), nq), dim3(256), 0, (hipStream_t)stream, (const int2*)list, count, nq, T, cap, rows, scores, over);
     return ralf::check_launch("knn_list_unpack");
 }
 extern "C" int ralf_knn_gather_rows(const int64_t* rows, int cap, const int64_t* pos, int nq, int m, int64_t* out, void* stream) {

@@ -71,6 +71,15 @@ def own_stream(slot, device=None, priority=None) -> "torch.cuda.Stream":
     return st
 
 
+def gemm_filter_tile(M: int, N: int, K: int) -> int:
+    """column-tile width ralf_gemm uses for a threshold-filter product of this shape (the slot layout of RalfGemmDesc.flt_*)"""
+    d = RalfGemmDesc()
+    d.M, d.N, d.K, d.dtype, d.splitk = M, N, K, 1, 1
+    w = _lib.lib().ralf_gemm_filter_tile(ctypes.byref(d))
+    assert w > 0
+    return w
+
+
 def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=True, b_kcontig=True,
          lda=None, ldb=None, out: Optional[torch.Tensor] = None, ldc=None, out_dtype=None,
          bias=None, act=None, res=None, ldr=None, aux=None, aux_mode=None, aux_scale=1.0, out2=None,
@@ -117,10 +126,12 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
         bx, bm, bmean, bpart = bnb
         assert bx.dtype == A.dtype and bx.is_contiguous() and bx.numel() == M * N and bpart.dtype == torch.float32 and bpart.numel() >= ((M + 63) // 64) * 2 * N
         d.bnb_x, d.bnb_mask, d.bnb_mean, d.bnb_part = _p(bx), _p(bm), _p(bmean), _p(bpart)
-    if flt is not None:   # (thresholds fp32 [M], counters int32 [M] (zeroed), list int32 [M, cap, 2]): threshold filter instead of an output (flt_*)
+    if flt is not None:   # (thresholds fp32 [M], hit counts int32 [M, T], slots int32 [M, T, cap, 2]; T = ceil(N / gemm_filter_tile)): threshold filter (flt_*)
         th, cnt, lst = flt
-        assert th.dtype == torch.float32 and th.numel() >= M and cnt.dtype == torch.int32 and cnt.numel() >= M and lst.dtype == torch.int32 and lst.dim() == 3 and lst.shape[0] >= M and lst.shape[2] == 2
-        d.flt_thresh, d.flt_count, d.flt_list, d.flt_cap = _p(th), _p(cnt), _p(lst), lst.shape[1]
+        T = lst.shape[1]
+        assert th.dtype == torch.float32 and th.numel() >= M and cnt.dtype == torch.int32 and tuple(cnt.shape) == (M, T) and lst.dtype == torch.int32 and lst.dim() == 4 and lst.shape[0] == M and lst.shape[3] == 2
+        assert T == (N + gemm_filter_tile(M, N, K) - 1) // gemm_filter_tile(M, N, K), "slot layout does not match the tile width of this product"
+        d.flt_thresh, d.flt_count, d.flt_list, d.flt_cap = _p(th), _p(cnt), _p(lst), lst.shape[2]
     if at is not None:
         a2, ao, am = at.get("a2"), at.get("out"), at.get("mask")
         assert A.dtype == torch.bfloat16 and a_kcontig and A.is_contiguous() and A.numel() == M * K

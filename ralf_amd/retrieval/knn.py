@@ -86,7 +86,7 @@ def knn_select_cand(exact: torch.Tensor, cand: torch.Tensor, k: int, bound=None,
 
 
 FILTER_SAMPLE_ROWS = 4096   # rows of the index the threshold pass ranks (expected list length: (pool + 1) * N / this)
-FILTER_LIST_CAP = 4096      # candidate slots per query (a multiple of 4: the selection kernel's row alignment)
+FILTER_TILE_SLOTS = 16      # candidate slots per (query, 128-column tile of the index): ~2 hits expected per tile, P(> 16) ~ 1e-10 for unordered data
 
 
 def knn_topk_ip_two_stage(index: torch.Tensor, index_bf16: torch.Tensor, queries: torch.Tensor, k: int, pool: int = 0, index_norms: torch.Tensor | None = None,
@@ -115,7 +115,10 @@ def knn_topk_ip_two_stage(index: torch.Tensor, index_bf16: torch.Tensor, queries
     qn, _ = knn_rownorms(q, qb)
     cval = cidx = over = None
     if filtered is None:
-        filtered = nq >= 256 and N >= 16 * FILTER_SAMPLE_ROWS // 4
+        # measured at BASELINE config 4 (tools/knn_two_stage_probe.py, profiles/r04_knn_two_stage_stages.txt): the filtered product itself is
+        # faster (305 vs 352 us: no 252 MB score matrix), but the threshold pass (44 us) and the slot unpack + selection cost what it saves --
+        # 664 us against 652 for the dense form.  Kept for indexes whose score matrix would not fit; off by default.
+        filtered = False
     if filtered:
         # the coarse scores never reach memory: a first pass over a slice of the index gives every query a LOWER bound of its (pool+1)-th
         # best coarse score (the (pool+1)-th best of a subset cannot exceed that of the whole), the pass over the whole index then keeps only
@@ -124,16 +127,19 @@ def knn_topk_ip_two_stage(index: torch.Tensor, index_bf16: torch.Tensor, queries
         ns = min(FILTER_SAMPLE_ROWS, N)
         sval, _ = knn_select(ops.gemm(qb, index_bf16[:ns], nq, ns, D, out_dtype=torch.float32), pool + 1)
         thresh = sval[:, pool].contiguous()
-        cnt = torch.zeros(nq, dtype=torch.int32, device=q.device)
-        lst = torch.empty(nq, FILTER_LIST_CAP, 2, dtype=torch.int32, device=q.device)
+        tile = ops.gemm_filter_tile(nq, N, D)
+        T = (N + tile - 1) // tile
+        cnt = torch.empty(nq, T, dtype=torch.int32, device=q.device)                  # hits per (query, column tile): every entry is written
+        lst = torch.empty(nq, T, FILTER_TILE_SLOTS, 2, dtype=torch.int32, device=q.device)
         ops.gemm(qb, index_bf16, nq, N, D, flt=(thresh, cnt, lst))
-        rows = torch.empty(nq, FILTER_LIST_CAP, dtype=torch.int64, device=q.device)   # row ids / scores of the lists, -inf beyond the count
-        scores = torch.empty(nq, FILTER_LIST_CAP, dtype=torch.float32, device=q.device)
-        over = torch.empty(nq, dtype=torch.int32, device=q.device)                    # lists that lost candidates: redone exhaustively below
-        _lib.check(_lib.lib().ralf_knn_list_unpack(_lib.ptr(lst), _lib.ptr(cnt), nq, FILTER_LIST_CAP, _lib.ptr(rows), _lib.ptr(scores), _lib.ptr(over), _lib.stream_ptr()), "ralf_knn_list_unpack")
+        W = T * FILTER_TILE_SLOTS
+        rows = torch.empty(nq, W, dtype=torch.int64, device=q.device)                 # row ids / scores of the slots, -inf where unused
+        scores = torch.empty(nq, W, dtype=torch.float32, device=q.device)
+        over = torch.zeros(nq, dtype=torch.int32, device=q.device)                    # queries with a flooded tile: redone exhaustively below
+        _lib.check(_lib.lib().ralf_knn_list_unpack(_lib.ptr(lst), _lib.ptr(cnt), nq, T, FILTER_TILE_SLOTS, _lib.ptr(rows), _lib.ptr(scores), _lib.ptr(over), _lib.stream_ptr()), "ralf_knn_list_unpack")
         cval, pos = knn_select(scores, pool + 1)
         cidx = torch.empty(nq, pool + 1, dtype=torch.int64, device=q.device)
-        _lib.check(_lib.lib().ralf_knn_gather_rows(_lib.ptr(rows), FILTER_LIST_CAP, _lib.ptr(pos), nq, pool + 1, _lib.ptr(cidx), _lib.stream_ptr()), "ralf_knn_gather_rows")
+        _lib.check(_lib.lib().ralf_knn_gather_rows(_lib.ptr(rows), W, _lib.ptr(pos), nq, pool + 1, _lib.ptr(cidx), _lib.stream_ptr()), "ralf_knn_gather_rows")
     else:
         coarse = ops.gemm(qb, index_bf16, nq, N, D, out_dtype=torch.float32)         # [nq, N] = Qb Xb^T (bf16 MFMA, fp32 accumulate)
         cval, cidx = knn_select(coarse, pool + 1)                                     # sorted by coarse score

@@ -204,7 +204,7 @@ def test_two_stage_filtered_coarse_pass_equals_the_dense_one(filtered):
     v_ref, i_ref = K.knn_topk_ip(X2, Q2, k)
     v, i, nfb = K.knn_topk_ip_two_stage(X2, ops.cast(X2, torch.bfloat16), Q2, k, filtered=True)
     assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
-    assert nfb == nq                                    # every list overflowed (N - 4096 hits > 4096 slots): all redone exhaustively
+    assert nfb == nq                                    # every query has flooded tiles (all 128 columns of a tile pass, 16 slots): all redone exhaustively
 
 
 def test_sharded_search_forms_on_the_hip_scan():

@@ -33,17 +33,12 @@ ns = K.FILTER_SAMPLE_ROWS
 t["threshold pass: GEMM on 4096 rows + select"] = _time_gpu(lambda: knn_select(ops.gemm(qb, Xb[:ns], nq, ns, D, out_dtype=torch.float32), pool + 1), 10, 2)
 sval, _ = knn_select(ops.gemm(qb, Xb[:ns], nq, ns, D, out_dtype=torch.float32), pool + 1)
 th = sval[:, pool].contiguous()
-cnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
-lst = torch.empty(nq, K.FILTER_LIST_CAP, 2, dtype=torch.int32, device="cuda")
-
-
-def filt():
-    cnt.zero_()
-    ops.gemm(qb, Xb, nq, N, D, flt=(th, cnt, lst))
-
-
-t["filtered coarse GEMM (no score matrix) incl. counter reset"] = _time_gpu(filt, 10, 2)
-print("list lengths: mean %.0f max %d (capacity %d)" % (cnt.float().mean().item(), int(cnt.max()), K.FILTER_LIST_CAP))
+tile = ops.gemm_filter_tile(nq, N, D)
+T = (N + tile - 1) // tile
+cnt = torch.empty(nq, T, dtype=torch.int32, device="cuda")
+lst = torch.empty(nq, T, K.FILTER_TILE_SLOTS, 2, dtype=torch.int32, device="cuda")
+t["filtered coarse GEMM (no score matrix)"] = _time_gpu(lambda: ops.gemm(qb, Xb, nq, N, D, flt=(th, cnt, lst)), 10, 2)
+print("hits per query: mean %.0f max %d; per (query, tile): max %d of %d slots" % (cnt.sum(1).float().mean().item(), int(cnt.sum(1).max()), int(cnt.max()), K.FILTER_TILE_SLOTS))
 t["whole call, filtered coarse pass"] = _time_gpu(lambda: knn_topk_ip_two_stage(X, Xb, Q, k, index_norms=xn, filtered=True), 10, 2)
 v0, i0, _ = knn_topk_ip_two_stage(X, Xb, Q, k, index_norms=xn, filtered=False)
 v1, i1, nfb = knn_topk_ip_two_stage(X, Xb, Q, k, index_norms=xn, filtered=True)
