@@ -313,6 +313,18 @@ typedef struct RalfConvRelayoutJob {
 } RalfConvRelayoutJob;
 int ralf_conv_relayout_batched(const RalfConvRelayoutJob* jobs_device, int njobs, int total_blocks, void* stream);
 /* ResNet stem max-pool 3x3/s2/p1 (NHWC) with saved arg-max; FPN nearest up-sampling fused with the lateral add */
+/* The stem's BatchNorm (batch statistics) + ReLU + 3x3 / stride 2 / pad 1 max-pool in one pass over the convolution output y (NHWC), and its
+ * backward in two (timm resnet50 conv1 -> bn1 -> act1 -> maxpool, common/image.py:39-48,66-67; torch: F.batch_norm, relu, F.max_pool2d and their
+ * autograd backward).  scale / shift from ralf_bn_stats_from_partials.  fwd: out [B,OH,OW,C], arg int8 = position 0..8 of the maximum;
+ * pooled values and arg equal ralf_bn_apply -> ralf_maxpool3x3s2_fwd bit for bit, the normalised tensor is never stored.
+ * bwd_reduce: part[nblk][2][C] = per-workgroup column sums of dz and dz * (y - mean), dz = the gradient reaching relu(BN(y)) through the
+ * pooling (rounded to dtype, zero where the ReLU was inactive) -> ralf_bn_bwd_stats_from_partials(part, nblk, ..., coef);
+ * bwd_apply: dy = c1 * dz + c2 * y + c3 with dz recomputed. */
+int ralf_bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out, int8_t* arg, int B, int H, int W, int C, void* stream);
+int ralf_bn_relu_maxpool_bwd_reduce(int dtype, const void* dpool, const int8_t* arg, const void* y, const float* scale, const float* shift, const float* mean,
+                                    float* part, int nblk, int B, int H, int W, int C, void* stream);
+int ralf_bn_relu_maxpool_bwd_apply(int dtype, const void* dpool, const int8_t* arg, const void* y, const float* scale, const float* shift, const float* c1,
+                                   const float* c2, const float* c3, void* dy, int B, int H, int W, int C, void* stream);
 int ralf_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int8_t* arg, int B, int H, int W, int C, void* stream);
 int ralf_maxpool3x3s2_bwd(int dtype, const void* dy, const int8_t* arg, void* dx, int B, int H, int W, int C, void* stream);
 int ralf_upsample_nearest_add(int dtype, const void* src, const void* lateral, void* up, int64_t ld_up, void* sum, int B, int IH, int IW, int OH, int OW, int C, void* stream);

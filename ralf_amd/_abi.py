@@ -144,6 +144,9 @@ SIGNATURES.update({
     "ralf_zero": (i32, [vp, i64, vp]),
     "ralf_copy2d": (i32, [i32, i32, vp, vp, i64, i32, i64, i64, i32, vp]),
     "ralf_permute4": (i32, [i32, i32, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, i32, vp]),
+    "ralf_bn_relu_maxpool_fwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "ralf_bn_relu_maxpool_bwd_reduce": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ralf_bn_relu_maxpool_bwd_apply": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ralf_maxpool3x3s2_fwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ralf_maxpool3x3s2_bwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ralf_upsample_nearest_add": (i32, [i32, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp]),

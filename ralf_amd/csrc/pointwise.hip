@@ -771,6 +771,183 @@ extern "C" int ralf_conv_relayout_batched(const RalfConvRelayoutJob* jobs_device
     hipLaunchKernelGGL(conv_relayout_batched_kernel, dim3(total_blocks), dim3(256), 0, ST, jobs_device, njobs);
     return ralf::check_launch("conv_relayout_batched");
 }
+// ---- the stem's BatchNorm + ReLU + 3x3/2 max-pool as ONE pass over the convolution output (timm resnet50: conv1 -> bn1 -> act1 -> maxpool,
+// image2layout/train/models/common/image.py:39-48,66-67).  z = relu(y * scale + shift) is never stored: 134 MB written and read again at
+// B = 64, 256 x 256.  Every tap is normalised, rounded to T (what ralf_bn_apply would have stored) and compared, so pooled values and argmax
+// equal the ralf_bn_apply -> ralf_maxpool3x3s2_fwd chain bit for bit.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                   T* __restrict__ y, int8_t* __restrict__ arg, int B, int H, int W, int C, int OH, int OW) {
+    constexpr int N = PV<T>::N;
+    const int cv = C / N;
+    const int64_t total = (int64_t)B * OH * OW * cv;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % cv) * N;
+        const int pix = (int)(e / cv);
+        const int ow = pix % OW, t = pix / OW, oh = t % OH, b = t / OH;
+        float sc[N], sh[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; }
+        float best[N];
+        __attribute__((aligned(8))) int8_t bi[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { best[i] = -__builtin_inff(); bi[i] = -1; }
+        float v[9][N];   // (unconditional loads of clamped taps, see maxpool_fwd_kernel)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = min(max(oh * 2 - 1 + kh, 0), H - 1);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = min(max(ow * 2 - 1 + kw, 0), W - 1);
+                PV<T>::load(x + (((int64_t)b * H + ih) * W + iw) * C + c, v[kh * 3 + kw]);
+            }
+        }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * 2 - 1 + kh;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * 2 - 1 + kw;
+                const bool inside = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const float z = (float)(T)fmaxf(__builtin_fmaf(v[kh * 3 + kw][i], sc[i], sh[i]), 0.f);
+                    if (inside && (bi[i] < 0 || z > best[i])) { best[i] = z; bi[i] = (int8_t)(kh * 3 + kw); }
+                }
+            }
+        }
+        const int64_t o = (int64_t)pix * C + c;
+        PV<T>::store(y + o, best);
+        if constexpr (N == 8) *reinterpret_cast<uint2*>(arg + o) = *reinterpret_cast<const uint2*>(bi);
+        else *reinterpret_cast<uint32_t*>(arg + o) = *reinterpret_cast<const uint32_t*>(bi);
+    }
+}
+
+// the gradient that reaches z = relu(BN(y)) at input pixel (b, ih, iw) through the pooling: the sum over the <= 4 windows whose argmax it is,
+// rounded to T (what ralf_maxpool3x3s2_bwd stores), zero where the ReLU was inactive (y * scale + shift <= 0)
+template <typename T, int N>
+__device__ __forceinline__ void pooled_dz(const T* __restrict__ dpool, const int8_t* __restrict__ arg, const float (&yv)[N], const float (&sc)[N], const float (&sh)[N],
+                                          int b, int ih, int iw, int c, int C, int OH, int OW, float (&g)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) g[i] = 0.f;
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh) {
+        const int oh = (ih + dh) / 2;
+        if (dh == 1 && oh == ih / 2) continue;
+        const int kh = ih - (oh * 2 - 1);
+        if (oh >= OH || kh < 0 || kh > 2) continue;
+#pragma unroll
+        for (int dw = 0; dw < 2; ++dw) {
+            const int ow = (iw + dw) / 2;
+            if (dw == 1 && ow == iw / 2) continue;
+            const int kw = iw - (ow * 2 - 1);
+            if (ow >= OW || kw < 0 || kw > 2) continue;
+            const int64_t o = (((int64_t)b * OH + oh) * OW + ow) * C + c;
+            float v[N];
+            PV<T>::load(dpool + o, v);
+            int8_t a[N];
+            if constexpr (N == 8) *reinterpret_cast<uint2*>(a) = *reinterpret_cast<const uint2*>(arg + o);
+            else *reinterpret_cast<uint32_t*>(a) = *reinterpret_cast<const uint32_t*>(arg + o);
+            const int8_t want = (int8_t)(kh * 3 + kw);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                if (a[i] == want) g[i] += v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) g[i] = __builtin_fmaf(yv[i], sc[i], sh[i]) > 0.f ? (float)(T)g[i] : 0.f;
+}
+
+// backward, pass 1: per workgroup the column sums of dz and of dz * (y - mean) -> part[blockIdx.x][2][C] (the layout of RalfGemmDesc.bnb_part:
+// ralf_bn_bwd_stats_from_partials finishes them).  A thread owns one channel vector and walks pixels.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_reduce_kernel(const T* __restrict__ dpool, const int8_t* __restrict__ arg, const T* __restrict__ y,
+                                                                          const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                          float* __restrict__ part, int B, int H, int W, int C, int OH, int OW) {
+    constexpr int N = PV<T>::N;
+    __shared__ float red[2][256][N];
+    const int cv = C / N;                 // channel vectors per pixel (<= 256, a power of two: C = 64)
+    const int ppi = 256 / cv;             // pixels per iteration of the workgroup
+    const int tx = threadIdx.x % cv, ty = threadIdx.x / cv;
+    const int c = tx * N;
+    float sc[N], sh[N], mu[N], a1[N], a2[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; mu[i] = mean[c + i]; a1[i] = a2[i] = 0.f; }
+    const int64_t npix = (int64_t)B * H * W;
+    for (int64_t p = (int64_t)blockIdx.x * ppi + ty; p < npix; p += (int64_t)gridDim.x * ppi) {
+        const int iw = (int)(p % W);
+        const int64_t t = p / W;
+        const int ih = (int)(t % H), b = (int)(t / H);
+        float yv[N], g[N];
+        PV<T>::load(y + p * C + c, yv);
+        pooled_dz<T, N>(dpool, arg, yv, sc, sh, b, ih, iw, c, C, OH, OW, g);
+#pragma unroll
+        for (int i = 0; i < N; ++i) { a1[i] += g[i]; a2[i] += g[i] * (yv[i] - mu[i]); }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { red[0][threadIdx.x][i] = a1[i]; red[1][threadIdx.x][i] = a2[i]; }
+    __syncthreads();
+    if (ty == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int j = 0; j < ppi; ++j) { t1 += red[0][j * cv + tx][i]; t2 += red[1][j * cv + tx][i]; }
+            part[((int64_t)blockIdx.x * 2 + 0) * C + c + i] = t1;
+            part[((int64_t)blockIdx.x * 2 + 1) * C + c + i] = t2;
+        }
+    }
+}
+
+// backward, pass 2: dy = c1 * dz + c2 * y + c3 (the affine form of the BatchNorm backward apply), dz recomputed as in pass 1
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_apply_kernel(const T* __restrict__ dpool, const int8_t* __restrict__ arg, const T* __restrict__ y,
+                                                                         const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ c1p,
+                                                                         const float* __restrict__ c2p, const float* __restrict__ c3p, T* __restrict__ dy,
+                                                                         int B, int H, int W, int C, int OH, int OW) {
+    constexpr int N = PV<T>::N;
+    const int cv = C / N;
+    const int64_t total = (int64_t)B * H * W * cv;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % cv) * N;
+        const int64_t p = e / cv;
+        const int iw = (int)(p % W);
+        const int64_t t = p / W;
+        const int ih = (int)(t % H), b = (int)(t / H);
+        float sc[N], sh[N], yv[N], g[N], o[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; }
+        PV<T>::load(y + p * C + c, yv);
+        pooled_dz<T, N>(dpool, arg, yv, sc, sh, b, ih, iw, c, C, OH, OW, g);
+#pragma unroll
+        for (int i = 0; i < N; ++i) o[i] = __builtin_fmaf(g[i], c1p[c + i], __builtin_fmaf(yv[i], c2p[c + i], c3p[c + i]));
+        PV<T>::store(dy + p * C + c, o);
+    }
+}
+}  // namespace
+
+extern "C" int ralf_bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out, int8_t* arg, int B, int H, int W, int C, void* stream) {
+    RALF_REQUIRE(y && scale && shift && out && arg && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "bn_relu_maxpool_fwd: bad arguments (C %% 8 == 0)");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_maxpool_fwd_kernel<T>), dim3(grid_for((int64_t)B * OH * OW * C / 4, 256, 1 << 20)), dim3(256), 0, ST, (const T*)y, scale, shift, (T*)out, arg, B, H, W, C, OH, OW));
+    return ralf::check_launch("bn_relu_maxpool_fwd");
+}
+extern "C" int ralf_bn_relu_maxpool_bwd_reduce(int dtype, const void* dpool, const int8_t* arg, const void* y, const float* scale, const float* shift, const float* mean,
+                                               float* part, int nblk, int B, int H, int W, int C, void* stream) {
+    RALF_REQUIRE(dpool && arg && y && scale && shift && mean && part && nblk > 0 && B > 0 && H > 0 && W > 0, "bn_relu_maxpool_bwd_reduce: bad arguments");
+    RALF_REQUIRE(C % 8 == 0 && C <= 1024 && (256 % (C / (dtype == RALF_F32 ? 4 : 8))) == 0, "bn_relu_maxpool_bwd_reduce: C / vector width must divide 256");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_maxpool_bwd_reduce_kernel<T>), dim3(nblk), dim3(256), 0, ST, (const T*)dpool, arg, (const T*)y, scale, shift, mean, part, B, H, W, C, OH, OW));
+    return ralf::check_launch("bn_relu_maxpool_bwd_reduce");
+}
+extern "C" int ralf_bn_relu_maxpool_bwd_apply(int dtype, const void* dpool, const int8_t* arg, const void* y, const float* scale, const float* shift, const float* c1,
+                                              const float* c2, const float* c3, void* dy, int B, int H, int W, int C, void* stream) {
+    RALF_REQUIRE(dpool && arg && y && scale && shift && c1 && c2 && c3 && dy && B > 0 && H > 0 && W > 0 && C % 8 == 0, "bn_relu_maxpool_bwd_apply: bad arguments");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_maxpool_bwd_apply_kernel<T>), dim3(grid_for((int64_t)B * H * W * C / 4, 256, 1 << 20)), dim3(256), 0, ST, (const T*)dpool, arg, (const T*)y, scale, shift, c1, c2, c3, (T*)dy, B, H, W, C, OH, OW));
+    return ralf::check_launch("bn_relu_maxpool_bwd_apply");
+}
+
 extern "C" int ralf_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int8_t* arg, int B, int H, int W, int C, void* stream) {
     RALF_REQUIRE(x && y && arg && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "maxpool_fwd: bad arguments (C %% 8 == 0)");
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;

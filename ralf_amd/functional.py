@@ -84,6 +84,7 @@ class Runtime:
         self.fused_decode_tail = os.environ.get("RALF_DECODE_TAIL", "0") == "1"
         self.fused_decode = True  # KV-cached decode step: LayerNorm + projections + attention per block in one launch (bf16, d = 256, 8 heads)
         self.fold_bn = True       # inference: eval-mode BatchNorm folded into the convolution epilogues (conv_bn_infer)
+        self.fused_stem = os.environ.get("RALF_FUSED_STEM", "1") != "0"   # training: the stem's BatchNorm + ReLU + max-pool as one pass (StemBNReluPoolFn)
 
     def to(self, device):
         if self.seed is None or self.seed.device != device:
@@ -1535,6 +1536,33 @@ class BatchNormFn(Function):
         if into is not None:
             dg = db = None
         return dx.view(shp), dg, db, None, None, (dres.view(shp) if has_res else None), None, None, None, None, None
+
+
+class StemBNReluPoolFn(Function):
+    """maxpool3x3s2(relu(BN(y))) with batch statistics, forward in ONE pass over the stem convolution's output and backward in two
+    (ops.bn_relu_maxpool_*): the normalised 64-channel map (134 MB at B = 64, 256 x 256) is neither written nor read back.  Same values as
+    BatchNormFn -> MaxPoolFn (pooled output and argmax bit for bit; the backward uses the affine form of the BatchNorm backward apply)."""
+
+    @staticmethod
+    def forward(ctx, y, g, b, rm, rv, counter, partials, rt):
+        y = y.contiguous()
+        if partials is not None and partials.numel() == 0:
+            partials = None
+        stats = ops.bn_train_stats(y.view(-1, y.shape[-1]), g.detach(), b.detach(), rm, rv, counter, partials)
+        out, arg = ops.bn_relu_maxpool_fwd(y, stats[2], stats[3])
+        ctx.save_for_backward(y, arg, stats, g)
+        ctx.beta, ctx.rt = b, rt
+        return out
+
+    @staticmethod
+    def backward(ctx, dpool):
+        y, arg, stats, g = ctx.saved_tensors
+        gg, gb = ctx.rt.gview(g), ctx.rt.gview(ctx.beta)
+        into = (gg, gb) if (gg is not None and gb is not None) else None
+        dy, dg, db = ops.bn_relu_maxpool_bwd(dpool.contiguous(), arg, y, stats, g.detach(), into)
+        if into is not None:
+            dg = db = None
+        return dy, dg, db, None, None, None, None, None
 
 
 class MaxPoolFn(Function):

@@ -131,6 +131,9 @@ class _GeneratorBase(nn.Module):
             cs = ops.own_stream("h2d", self.device, priority="high" if which == "prio" else None)
         if st["done"][j] is not None:
             st["done"][j].synchronize()        # (the step that read this set: three iterations back, long finished)
+        # readers of this set that ran on the loop's own stream (evaluate(): the ordinary forward) are ordered before the rewrite as well; in
+        # training the loop's stream is all but empty (the step runs on the engine's stream), so this costs nothing
+        cs.wait_stream(torch.cuda.current_stream())
         dev = self.device
 
         def up(key, t):

@@ -629,10 +629,15 @@ class ResnetBackbone(nn.Module):
         if infer:
             self._refresh_fold(img.device)
             x = RF.conv_bn_infer(x, b.conv1.weight, b.bn1.fold[0], b.bn1.fold[1], b.conv1.stride, b.conv1.pad, True, None, rt)
+            x = RF.MaxPoolFn.apply(x)
+        elif rt.training and rt.fused_stem:
+            # training: BatchNorm (batch statistics) + ReLU + max-pool in one pass over the convolution output (RF.StemBNReluPoolFn)
+            x, st = b.conv1(x, rt, stats=True)
+            x = RF.StemBNReluPoolFn.apply(x, b.bn1.weight, b.bn1.bias, b.bn1.running_mean, b.bn1.running_var, b.bn1.num_batches_tracked, st, rt)
         else:
             x, st = b.conv1(x, rt, stats=True)
             x = b.bn1(x, rt, True, stats=st)
-        x = RF.MaxPoolFn.apply(x)
+            x = RF.MaxPoolFn.apply(x)
         feats, lat3 = {}, None
         for li in (1, 2, 3, 4):
             for bi, blk in enumerate(getattr(b, f"layer{li}")):

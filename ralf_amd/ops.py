@@ -439,6 +439,50 @@ def permute4_batched(table, njobs, total_blocks):
     _call("ralf_permute4_batched", _p(table), njobs, total_blocks)
 
 
+def bn_train_stats(x2d, gamma, beta, running_mean, running_var, counter, partials, eps=1e-5, momentum=0.1):
+    """batch statistics of a BatchNorm input (from the producing convolution's epilogue partials when given) -> fp32 [4, C] = mean, rstd,
+    scale, shift; updates the running statistics and num_batches_tracked like bn_forward(training=True)"""
+    M, C = x2d.shape
+    out = torch.empty(4, C, dtype=torch.float32, device=x2d.device)
+    if partials is not None:
+        _call("ralf_bn_stats_from_partials", _p(partials), partials.shape[0], _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(counter),
+              _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), M, C, eps, momentum, _p(workspace(1024 * 2 * C * 4, x2d.device)))
+    else:
+        _call("ralf_bn_batch_stats", dtype_code(x2d), _p(x2d), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(counter),
+              _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), M, C, eps, momentum, _p(workspace(1024 * 2 * C * 4, x2d.device)))
+    return out
+
+
+def bn_relu_maxpool_fwd(y, scale, shift):
+    """relu(y * scale + shift) -> 3x3 / 2 max-pool in one pass (ralf_bn_relu_maxpool_fwd); y NHWC"""
+    B, H, W, C = y.shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty(B, OH, OW, C, dtype=y.dtype, device=y.device)
+    arg = torch.empty(B, OH, OW, C, dtype=torch.int8, device=y.device)
+    _call("ralf_bn_relu_maxpool_fwd", dtype_code(y), _p(y), _p(scale), _p(shift), _p(out), _p(arg), B, H, W, C)
+    return out, arg
+
+
+def bn_relu_maxpool_bwd(dpool, arg, y, stats, gamma, into):
+    """backward of bn_relu_maxpool_fwd (batch statistics): -> (dy, dgamma, dbeta); into = (dgamma, dbeta) zeroed flat-gradient views or None"""
+    B, H, W, C = y.shape
+    dev = y.device
+    nblk = 1024
+    part = torch.empty(nblk, 2, C, dtype=torch.float32, device=dev)
+    _call("ralf_bn_relu_maxpool_bwd_reduce", dtype_code(y), _p(dpool), _p(arg), _p(y), _p(stats[2]), _p(stats[3]), _p(stats[0]), _p(part), nblk, B, H, W, C)
+    if into is not None:
+        dg, db = into
+    else:
+        st = torch.zeros(2, C, dtype=torch.float32, device=dev)
+        dg, db = st[0], st[1]
+    coef = torch.empty(3, C, dtype=torch.float32, device=dev)
+    _call("ralf_bn_bwd_stats_from_partials", _p(part), nblk, _p(stats[1]), _p(db), _p(dg), C, _p(workspace(128 * 2 * C * 4, dev)),
+          _p(gamma), _p(stats[0]), B * H * W, _p(coef))
+    dy = torch.empty_like(y)
+    _call("ralf_bn_relu_maxpool_bwd_apply", dtype_code(y), _p(dpool), _p(arg), _p(y), _p(stats[2]), _p(stats[3]), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(dy), B, H, W, C)
+    return dy, dg, db
+
+
 def maxpool_fwd(x):
     B, H, W, C = x.shape
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1

@@ -635,3 +635,44 @@ def test_one_pass_attention_backward_equals_the_two_kernel_backward(tmp_path):
         bad = ((a - b).abs() > tol).float().mean().item()
         assert (a - b).abs().max().item() <= 4 * tol and bad < 1e-3, (k, (a - b).abs().max().item(), tol, bad)
         assert b.abs().max().item() > 1e-3, k
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_stem_bn_relu_maxpool_in_one_pass_equals_the_three_kernels(dtype):
+    """ralf_bn_relu_maxpool_fwd / _bwd_reduce / _bwd_apply (the stem: conv1 -> bn1 -> relu -> maxpool, common/image.py:39-48) against
+    ralf_bn_apply -> ralf_maxpool3x3s2 and their backward: pooled values and argmax bit for bit (odd sizes, negative gammas, dead channels),
+    gradients to rounding, and against torch's own batch_norm / relu / max_pool2d"""
+    from ralf_amd import ops
+
+    B, H, W, C = 3, 37, 50, 64
+    y = rnd(B, H, W, C, seed=70, dtype=dtype).cuda()
+    gamma = (0.5 + torch.rand(C, generator=torch.Generator().manual_seed(71)))
+    gamma[::7] *= -1.0                       # negative scales: relu(BN(.)) is not monotone in y, every tap must be normalised before the comparison
+    beta = 0.3 * rnd(C, seed=72)
+    beta[5] = -50.0                          # a channel the ReLU kills everywhere
+    gamma, beta = gamma.cuda(), beta.cuda()
+    rm, rv, cnt = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.zeros((), dtype=torch.long, device="cuda")
+    stats = ops.bn_train_stats(y.view(-1, C), gamma, beta, rm, rv, cnt, None)
+    pooled, arg = ops.bn_relu_maxpool_fwd(y, stats[2], stats[3])
+    # the three-kernel chain with the same statistics
+    z, mask = torch.empty_like(y), torch.empty(B * H * W * C // 8, dtype=torch.uint8, device="cuda")
+    ops._call("ralf_bn_apply", ops.dtype_code(y), ops._p(y), ops._p(stats[2]), ops._p(stats[3]), None, ops._p(z), ops._p(mask), B * H * W, C, 1)
+    pooled2, arg2 = ops.maxpool_fwd(z)
+    assert torch.equal(pooled, pooled2) and torch.equal(arg, arg2)
+    dpool = rnd(*pooled.shape, seed=73, dtype=dtype).cuda()
+    dy, dg, db = ops.bn_relu_maxpool_bwd(dpool, arg, y, stats, gamma, None)
+    dz = ops.maxpool_bwd(dpool, arg2, tuple(y.shape))
+    dx2, dg2, db2, _ = ops.bn_backward(y.view(-1, C), dz.view(-1, C), None, gamma, stats[0], stats[1], True, False, True, mask=mask)
+    tol = dict(atol=2e-2, rtol=2e-2) if dtype == torch.bfloat16 else dict(atol=2e-5, rtol=1e-4)
+    torch.testing.assert_close(dy.view(-1, C).float(), dx2.float(), **tol)
+    torch.testing.assert_close(dg, dg2, atol=2e-3 * float(dg2.abs().max()), rtol=1e-3)
+    torch.testing.assert_close(db, db2, atol=2e-3 * float(db2.abs().max()), rtol=1e-3)
+    if dtype == torch.float32:   # torch's own chain on the CPU
+        yc = y.cpu().permute(0, 3, 1, 2).clone().requires_grad_(True)
+        g, bta = gamma.cpu().clone().requires_grad_(True), beta.cpu().clone().requires_grad_(True)
+        ref = F.max_pool2d(torch.relu(F.batch_norm(yc, None, None, g, bta, True, 0.1, 1e-5)), 3, 2, 1)
+        torch.testing.assert_close(pooled.cpu().permute(0, 3, 1, 2), ref.detach(), atol=2e-5, rtol=1e-5)
+        ref.backward(dpool.cpu().permute(0, 3, 1, 2))
+        torch.testing.assert_close(dy.cpu().permute(0, 3, 1, 2), yc.grad, atol=3e-5, rtol=1e-3)
+        torch.testing.assert_close(dg.cpu(), g.grad, atol=1e-3, rtol=1e-3)
+        torch.testing.assert_close(db.cpu(), bta.grad, atol=1e-3, rtol=1e-3)
