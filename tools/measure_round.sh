@@ -1,6 +1,6 @@
 #!/bin/bash
 # final measurements of the round: bench line, rocprofv3 kernel statistics, PMC HBM traffic, kNN / decode profiles
-R=${1:-r03a}
+R=${1:-r04a}
 O=gpurun_out/$R; mkdir -p $O
 ROOT=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
@@ -55,3 +55,9 @@ timeout 300 python3 tools/knn_graph_bench.py 1 16 32 64 128 1024 > $O/knn_microb
 timeout 2400 python3 bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
 timeout 600 python3 bench.py --dp-selftest --skip-cpu --skip-knn --skip-split --skip-decode > $O/bench_dp_selftest.json 2> $O/bench_dp.err; python3 -c "
 import json; d=json.load(open('$O/bench_dp_selftest.json')); print('dp-selftest ms', d['ms_per_step'])"
+
+# round 4: the unchanged reference loop (phases), the BatchNorm-fusion microbenchmark, the two-stage kNN stages, the host link
+timeout 200 python3 tools/loop_phases.py 1 > $O/loop_phases_lag1.txt 2>&1; timeout 200 python3 tools/loop_phases.py 0 > $O/loop_phases_lag0.txt 2>&1
+timeout 300 python3 tools/at_bench.py > $O/at_bench.txt 2>&1
+timeout 300 python3 tools/knn_two_stage_probe.py > $O/knn_two_stage_stages.txt 2>&1
+timeout 100 python3 tools/h2d_probe.py > $O/h2d_probe.txt 2>&1
