@@ -269,6 +269,35 @@ def bench_reference_loop(device, N, B, dtype, steps):
     return out
 
 
+def bench_convergence(device, N=10, B=64, steps=160, hw=128):
+    """training parity, not step parity (tests/test_convergence_gpu.py runs the 320-step version): the same learnable synthetic set, the same
+    plain initialisation, dropout on, the reference's hyper-parameters (config/experiment/ralf.yaml:11-18) -- bf16 throughput mode against the
+    fp32 parity mode on the graph-replayed HIP step; reported: first loss, mean of the last 16, largest relative gap of the 16-step means"""
+    from ralf_amd.engine import TrainStep
+    from ralf_amd.synthetic import make_learnable_set, to_device
+
+    batches = make_learnable_set(512, B, N, H=hw, W=hw)
+    curves = {}
+    for dtype in ("float32", "bfloat16"):
+        model = build_model(device, N, dtype)
+        dev_batches = []
+        for b in batches:
+            i, t = model.preprocess(b)
+            i, t = to_device(i, device), to_device(t, device)
+            i["retrieved"] = {k: v for k, v in i["retrieved"].items() if k != "image"}
+            dev_batches.append((i, t))
+        step = TrainStep(model, lr=1e-4, weight_decay=1e-4, max_norm=0.1, use_graph=True)
+        ls = [step(*dev_batches[k % len(dev_batches)]).clone() for k in range(steps)]
+        torch.cuda.synchronize()
+        curves[dtype] = torch.stack(ls).float().cpu()
+        del step, model
+    sm = {k: torch.nn.functional.avg_pool1d(v[None, None], 16, 1)[0, 0] for k, v in curves.items()}
+    gap = float((sm["bfloat16"] / sm["float32"] - 1).abs().max())
+    return {"steps": steps, "set": f"512 learnable synthetic samples, B={B}, {hw}x{hw}, lr 1e-4, clip 0.1, dropout 0.1, plain init",
+            "first_loss": {k: float(v[0]) for k, v in curves.items()}, "last16_mean": {k: float(v[-16:].mean()) for k, v in curves.items()},
+            "max_rel_gap_of_16_step_means": gap}
+
+
 def bench_relation(device, N=10, B=256, dtype="bfloat16"):
     """BASELINE configs[4], relationship task at batch 256: sample(cond_type="relation") with back-tracking
     (retrieval_augmented_autoreg.py:336-507: a per-sample loop by construction -- a violated constraint rewinds THAT sample's
@@ -624,6 +653,7 @@ def main():
             out["relation"] = bench_relation(device, N)
             out["reference_loop_ms"] = bench_reference_loop(device, N, B, a.dtype, min(a.steps, 10))
             # end-to-end: a fresh host batch per step through model.preprocess and the loop's own .to(device), overlapped with the previous replay
+            out["convergence"] = bench_convergence(device, N, B)
             out["e2e_tokens_per_s"] = out["reference_loop_ms"]["graphed_adamw_loss_lag1_tokens_per_s"]
             out["e2e_over_resident"] = out["e2e_tokens_per_s"] / out["value"]
         if world == 1 and not a.skip_cpu:
