@@ -562,7 +562,14 @@ class GraphedAdamW(torch.optim.Optimizer):
     loss it returns is a leaf, so `loss.backward()` is a no-op on the model; parameters carry no `.grad` (the flat gradient buffer is
     private), so `clip_grad_norm_` has nothing to scale -- the clip already ran inside the graph with `max_norm`, which is why it is a
     constructor keyword here; `step()` only follows the learning-rate schedule.  `evaluate()` (eval mode, no_grad) takes the ordinary
-    forward.  lr / weight_decay per group come from `model.optim_groups`, exactly as with torch's AdamW."""
+    forward.  lr / weight_decay per group come from `model.optim_groups`, exactly as with torch's AdamW.
+
+    The step runs on a library-owned stream and `model.preprocess` uploads the batch on a library-owned copy stream (the loop's `.to(rank)`
+    then finds device tensors); with loss_lag = 0 the loop's stream is ordered after the step before train_loss returns, so the loss and the
+    returned `outputs` can be read as usual.  With loss_lag = 1 the returned loss is a HOST scalar of the previous step and the loop's stream
+    is not ordered after the step just enqueued: a caller that reads `outputs["logits"]` must `torch.cuda.synchronize()` first (the
+    reference's loop does not read them).  Wrapping the model in the reference's DDPWrapper is fine: its own `zero_grad()` only drops `.grad`
+    views the engine keeps a registry of, and its reducer never fires (the engine exchanges the flat gradient buffer itself)."""
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, max_norm: float = 0.0,
                  loss_lag: int = 0, host_threads: Optional[int] = 16, **step_kw):
