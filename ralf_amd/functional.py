@@ -371,11 +371,17 @@ class Runtime:
                 return sh[0]
         key = (id(w), kind, self.dtype)
         hit = self._lp.get(key)
-        if hit is not None and hit[3]() is w and hit[0] == (w._version, self._wtoken) and hit[1] == w.data_ptr():
+        # _wtoken covers rewrites through raw pointers (the fused optimizer), i.e. tensors the optimizer manages; a plain cast of anything else
+        # (the FROZEN layout encoder's 18 matrices) follows torch's own version counter only -- they were re-cast after every optimizer step
+        tok = self._wtoken if (kind != "cast" or id(w) in self._gviews) else 0
+        if hit is not None and hit[3]() is w and hit[0] == (w._version, tok) and hit[1] == w.data_ptr():
             return hit[2]
         wd = w.detach()
         if kind == "cast":
-            t = ops.cast(wd, self.dtype)
+            if hit is not None and hit[3]() is w and hit[2].shape == wd.shape and hit[2].dtype == self.dtype:
+                t = ops.cast_into(wd.contiguous(), hit[2])   # refreshed IN PLACE: a captured graph that read the old copy sees the new values
+            else:
+                t = ops.cast(wd, self.dtype)
         else:
             Co, Ci, kh, kw = wd.shape
             if kind == "ohwi":      # [Co][kh][kw][Ci padded to 8]   (forward / weight-gradient layout)
@@ -385,7 +391,7 @@ class Runtime:
                 t = ops.permute4(wd, (Ci, kh, kw, Co), (kh * kw, kw, 1, Ci * kh * kw), Co, self.dtype)
             else:
                 raise ValueError(kind)
-        self._lp[key] = ((w._version, self._wtoken), w.data_ptr(), t, weakref.ref(w))  # id() can be recycled: keep a weakref
+        self._lp[key] = ((w._version, tok), w.data_ptr(), t, weakref.ref(w))  # id() can be recycled: keep a weakref
         return t
 
 

@@ -285,6 +285,8 @@ def test_unchanged_reference_loop_reaches_the_graph_through_graphed_adamw(golden
     loop_inputs = dict(inputs, retrieved={k: v.cpu() for k, v in inputs["retrieved"].items()})
     la, lb = [], []
     for it in range(4):
+        if it == 0:
+            torch.nn.Module.zero_grad(m1)   # what a wrapper's own zero_grad() does (the reference's DDPWrapper): .grad = None BEFORE the capture
         m1.zero_grad()
         out, losses = m1.train_loss(loop_inputs, tgt)
         loss = sum(losses.values())
