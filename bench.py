@@ -404,7 +404,7 @@ def cpu_baseline_train(N=10, B=4, steps=5, warm=2):
     ta = run("autoreg_state_shapes.json", O.autoreg_forward, steps)
     return {"value": B * (5 * N + 1) / t, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle/ralf_oracle.py RALF train step (fp32, dropout 0.1, batch-stat BN, clip 0.1, AdamW, anomaly detection off), "
-                      f"BOUND: B={B} = 1/16 of the GPU batch (a B=64 step on these cores takes ~16x as long: bench.py --cpu-batch 64 times it), 256x256, N={N}, "
+                      (f"BOUND: B={B} = 1/{64 // B} of the GPU batch (the full B=64 step: 11.95 s on 32 threads = 273 tokens/s, profiles/r04a_cpu_baseline_b64.json; bench.py --cpu-batch 64 times it), " if B < 64 else f"the GPU batch B={B}, ") + f"256x256, N={N}, "
                       f"median of {steps} steps after {warm} warm-ups; {t:.2f} s/step",
             "autoreg_baseline": {"value": B * (5 * N + 1) / ta, "unit": "tokens/s",
                                  "sample": f"BASELINE configs[0]: Autoreg baseline (no retrieval), uncond, B={B} (its own batch), same oracle, median of {steps} steps after {warm} warm-ups; {ta:.2f} s/step"}}

@@ -1467,9 +1467,7 @@ int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
 template <typename T, bool BKC, int G>
 int launch_at(KParams& P, int nbatch, hipStream_t st) {
     const RalfGemmDesc& d = P.d;
-    const bool ok22 = (!d.colstats && !d.bnb_part) || d.N % 128 == 0;
-    const int64_t big = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128);
-    const bool use128 = ok22 && d.M >= 128 && (d.N % 128 == 0 || d.N >= 512) && big >= 192;
+    const bool use128 = gemm_use128(d, nbatch);   // (the tile rule of launch_cfg)
     if (d.bnb_part) {
         if constexpr (G == 8) {
             if (use128) return launch<T, true, BKC, G, 2, 2, 3, 8>(P, nbatch, st);
