@@ -360,7 +360,7 @@ def committed_kernel_avg_us(pattern, suffix="_knn_kernel_stats.txt"):
     return None, None, None
 
 
-def cpu_baseline_train(N=10, B=4, steps=5, warm=2):
+def cpu_baseline_train(N=10, B=4, steps=5, warm=2, hw=256):
     """oracle (CPU restatement, fp32) train steps on the host cores, bounded samples of B = 4 at 256x256: the RALF model (the
     `value` workload at 1/16 of its batch) and the Autoreg baseline without retrieval (BASELINE configs[0], its own batch)."""
     from oracle import ralf_oracle as O
@@ -373,7 +373,7 @@ def cpu_baseline_train(N=10, B=4, steps=5, warm=2):
     # B = 4 at 256x256 does not scale past a few dozen threads (128 threads: 5.3 s/step, 8 threads: 1.5 s/step on the same code)
     torch.set_num_threads(min(32, os.cpu_count() or 8))
     tok = LayoutSequenceTokenizer(["text", "logo", "underlay"], N)
-    batch = make_batch(B, N, seed=3)
+    batch = make_batch(B, N, H=hw, W=hw, seed=3)
     cond, b2 = get_condition(batch, "uncond", tok)
     seqc = PREPROCESSOR["uncond"](tokenizer=tok)(cond)
     data = tok.encode(b2)
@@ -403,7 +403,7 @@ def cpu_baseline_train(N=10, B=4, steps=5, warm=2):
     t = run("ralf_state_shapes.json", O.ralf_forward, steps)
     ta = run("autoreg_state_shapes.json", O.autoreg_forward, steps)
     return {"value": B * (5 * N + 1) / t, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/ralf_oracle.py RALF train step (fp32, dropout 0.1, batch-stat BN, clip 0.1, AdamW, anomaly detection off), "
+            "sample": "oracle/ralf_oracle.py RALF train step (fp32, dropout 0.1, batch-stat BN, clip 0.1, AdamW, anomaly detection off), " +
                       (f"BOUND: B={B} = 1/{64 // B} of the GPU batch (the full B=64 step: 11.95 s on 32 threads = 273 tokens/s, profiles/r04a_cpu_baseline_b64.json; bench.py --cpu-batch 64 times it), " if B < 64 else f"the GPU batch B={B}, ") + f"256x256, N={N}, "
                       f"median of {steps} steps after {warm} warm-ups; {t:.2f} s/step",
             "autoreg_baseline": {"value": B * (5 * N + 1) / ta, "unit": "tokens/s",

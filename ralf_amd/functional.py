@@ -84,6 +84,7 @@ class Runtime:
         self.fused_decode_tail = os.environ.get("RALF_DECODE_TAIL", "0") == "1"
         self.fused_decode = True  # KV-cached decode step: LayerNorm + projections + attention per block in one launch (bf16, d = 256, 8 heads)
         self.fold_bn = True       # inference: eval-mode BatchNorm folded into the convolution epilogues (conv_bn_infer)
+        self.conv_wgrad_direct = os.environ.get("RALF_CONV_WGRAD_DIRECT", "1") != "0"   # 3x3 / stride-1 weight gradients in the direct form (ops.conv3x3_wgrad)
         self.fused_stem = os.environ.get("RALF_FUSED_STEM", "1") != "0"   # training: the stem's BatchNorm + ReLU + max-pool as one pass (StemBNReluPoolFn)
 
     def to(self, device):
@@ -1472,7 +1473,10 @@ class ConvFn(Function):
                 dW = dW.view(Co, Ci, 1, 1) if dW is not None else None
             else:
                 geom = dict(RH=OH, RW=OW, SH=H, SW=Wd, SC=C, KH=kh, KW=kw, stride=stride, pad=pad, mode=0)
+                direct = rt.conv_wgrad_direct and kw == kh and ops.conv3x3_wgrad_supported(dy, x, stride, pad, kh, kw)
                 def run(out=None):
+                    if direct:   # 3x3 / stride 1: the direct form (dy tile and halo patch staged once for all nine taps), straight into OIHW
+                        return ops.conv3x3_wgrad(dy, x, out=out)
                     g = ops.gemm(dy2, x, Co, kh * kw * C, M, a_kcontig=False, b_kcontig=False, conv=geom, gather=2,
                                  out_dtype=torch.float32, splitk=_splitk_for(Co, kh * kw * C, M))
                     # fp32 [Co][kh][kw][Cpad] -> OIHW master layout (drops the stem's channel padding)

@@ -58,3 +58,21 @@ def test_the_package_pins_the_hardware_queue_count_before_the_device_is_touched(
         env.update(extra, PYTHONPATH=root)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
         assert out.returncode == 0 and out.stdout.strip() == want, (extra, out.stdout, out.stderr[-500:])
+
+
+def test_bench_compiles_without_warnings_and_its_cpu_baseline_leg_runs():
+    """bench.py is only exercised end to end on the GPU box: catch on the CPU what can be caught -- the file compiles with warnings as errors
+    (an implicit string concatenation next to a parenthesis once turned a JSON field into a call), and the cpu_baseline leg (oracle train
+    steps, the one part of the bench that needs no GPU) runs at a tiny size"""
+    import warnings
+
+    with open(os.path.join(ROOT, "bench.py")) as f:
+        src = f.read()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        compile(src, "bench.py", "exec")
+    sys.path.insert(0, ROOT)
+    import bench
+
+    r = bench.cpu_baseline_train(N=10, B=2, steps=1, warm=0, hw=64)
+    assert r["value"] > 0 and r["kind"] == "port" and "BOUND" in r["sample"] and r["autoreg_baseline"]["value"] > 0

@@ -426,3 +426,27 @@ def test_operand_transform_refuses_what_it_does_not_cover():
     c = torch.ones(1024, device="cuda")
     with pytest.raises(_lib.RalfHipError, match="K <= 512"):
         ops.gemm(y, W, 256, 64, 1024, at=dict(mode=1, c1=c, c2=c))
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 64, 64, 64, 64), (3, 32, 32, 128, 128), (4, 16, 16, 256, 256), (5, 8, 8, 512, 512), (2, 16, 32, 64, 128)])
+def test_conv3x3_weight_gradient_direct_form(B, H, W, Ci, Co):
+    """ralf_conv3x3_wgrad (dy tile and halo patch staged once for all nine taps; OIHW fp32 output) against torch's conv2d weight gradient on
+    the same bf16 operands and against the implicit-GEMM form (ralf_gemm gather = 2) it replaces -- the four bottleneck geometries (one, two,
+    four and eight image rows per 64-pixel tile), image borders, accumulate"""
+    from ralf_amd import ops
+
+    x = rnd(B, H, W, Ci, seed=1).to(torch.bfloat16).cuda()
+    dy = rnd(B, H, W, Co, seed=2).to(torch.bfloat16).cuda()
+    got = ops.conv3x3_wgrad(dy, x)
+    ref = torch.nn.grad.conv2d_weight(x.float().cpu().permute(0, 3, 1, 2), (Co, Ci, 3, 3), dy.float().cpu().permute(0, 3, 1, 2), stride=1, padding=1)
+    scale = (B * H * W) ** 0.5
+    torch.testing.assert_close(got.cpu() / scale, ref / scale, atol=2e-3, rtol=2e-3)
+    M = B * H * W
+    geom = dict(RH=H, RW=W, SH=H, SW=W, SC=Ci, KH=3, KW=3, stride=1, pad=1, mode=0)
+    g = ops.gemm(dy.view(M, Co), x, Co, 9 * Ci, M, a_kcontig=False, b_kcontig=False, conv=geom, gather=2, out_dtype=torch.float32, splitk=4)
+    old = g.view(Co, 3, 3, Ci).permute(0, 3, 1, 2)
+    torch.testing.assert_close(got / scale, old / scale, atol=1e-4, rtol=1e-4)       # same products, fp32 sums in another order
+    acc = torch.ones(Co, Ci, 3, 3, device="cuda")
+    ops.conv3x3_wgrad(dy, x, out=acc, accumulate=True)
+    torch.testing.assert_close(acc, got + 1.0, atol=1e-5, rtol=1e-6)
+    assert torch.equal(ops.conv3x3_wgrad(dy, x), got)                                   # deterministic
