@@ -313,15 +313,15 @@ typedef struct RalfConvRelayoutJob {
 } RalfConvRelayoutJob;
 int ralf_conv_relayout_batched(const RalfConvRelayoutJob* jobs_device, int njobs, int total_blocks, void* stream);
 /* ResNet stem max-pool 3x3/s2/p1 (NHWC) with saved arg-max; FPN nearest up-sampling fused with the lateral add */
-/* Weight gradient of a 3x3 / stride 1 / pad 1 convolution, DIRECT form (ralf_amd/csrc/conv_wgrad.hip): dW[co][ci][kh][kw] (fp32, OIHW; = or +=)
- * = sum over pixels of dy[b,oy,ox,co] * x[b,oy+kh-1,ox+kw-1,ci]; dy [B,H,W,Co] and x [B,H,W,Ci] NHWC bf16.  A workgroup keeps a 64 x 64 x 9
+/* Weight gradient of a 3x3 / pad 1 convolution of stride s = 1 or 2, DIRECT form (ralf_amd/csrc/conv_wgrad.hip): dW[co][ci][kh][kw] (fp32, OIHW;
+ * = or +=) = sum over pixels of dy[b,oy,ox,co] * x[b,s oy+kh-1,s ox+kw-1,ci]; dy [B,H,W,Co] and x [B,IH,IW,Ci] NHWC bf16 (H, W: the OUTPUT grid).  A workgroup keeps a 64 x 64 x 9
  * block of dW in registers and stages each 64-pixel tile of dy and the halo patch of x once for all nine taps (the implicit-GEMM form,
- * ralf_gemm gather = 2, moves every input pixel nine times).  W in {8, 16, 32, 64}, H % (64 / W) == 0, Ci % 64 == 0, Co % 64 == 0.  Replaces
+ * ralf_gemm gather = 2, moves every input pixel nine times).  W in {8, 16, 32, 64} (stride 2: <= 32), H % (64 / W) == 0, Ci % 64 == 0, Co % 64 == 0.  Replaces
  * the weight half of torch's conv2d backward for the bottlenecks' 3x3 convolutions (common/image.py:39-48).  Deterministic (splits summed
  * in order). */
 size_t ralf_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co);
-int ralf_conv3x3_wgrad(const void* dy, const void* x, float* dW, int B, int H, int W, int Ci, int Co, int accumulate, void* workspace, size_t workspace_bytes,
-                       void* stream);
+int ralf_conv3x3_wgrad(const void* dy, const void* x, float* dW, int B, int H, int W, int IH, int IW, int stride, int Ci, int Co, int accumulate,
+                       void* workspace, size_t workspace_bytes, void* stream);
 /* The stem's BatchNorm (batch statistics) + ReLU + 3x3 / stride 2 / pad 1 max-pool in one pass over the convolution output y (NHWC), and its
  * backward in two (timm resnet50 conv1 -> bn1 -> act1 -> maxpool, common/image.py:39-48,66-67; torch: F.batch_norm, relu, F.max_pool2d and their
  * autograd backward).  scale / shift from ralf_bn_stats_from_partials.  fwd: out [B,OH,OW,C], arg int8 = position 0..8 of the maximum;

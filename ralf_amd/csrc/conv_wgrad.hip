@@ -1,6 +1,6 @@
-// Weight gradient of a 3x3 / stride 1 / pad 1 convolution on NHWC bf16 activations, DIRECT form (gfx950):
+// Weight gradient of a 3x3 / pad 1 convolution (stride 1 or 2) on NHWC bf16 activations, DIRECT form (gfx950):
 //
-//   dW[co][kh][kw][ci] = sum over (b, oy, ox) of  dy[b, oy, ox, co] * x[b, oy + kh - 1, ox + kw - 1, ci]
+//   dW[co][kh][kw][ci] = sum over (b, oy, ox) of  dy[b, oy, ox, co] * x[b, s oy + kh - 1, s ox + kw - 1, ci]
 //
 // Replaces the weight-gradient half of torch's conv2d backward for the 3x3 convolutions of the ResNet bottlenecks
 // (image2layout/train/models/common/image.py:39-48: timm Bottleneck.conv2).  The implicit-GEMM form (gemm_impl.h, gather = 2) builds the
@@ -27,20 +27,26 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
 constexpr int LD = 72;            // LDS row stride in elements: 64 channels + 8 pad (conflict-light transpose reads, as gemm_impl.h RPAD)
-constexpr int PPMAX = 3 * 66;     // largest halo patch: one row of 64 pixels (layer1) -> 3 x 66
-constexpr int PSLOTS = 4;         // 16-byte vectors of the patch per thread (512 threads x 4 >= 198 x 8)
+// largest halo patch of a 64-output-pixel tile and its 16-byte vectors per thread: stride 1: one row of 64 pixels -> 3 x 66 (512 x 4 >= 198 x 8);
+// stride 2: two rows of 32 -> 5 x 65 input pixels (512 x 6 >= 325 x 8)
+template <int S> struct PatchCfg;
+template <> struct PatchCfg<1> { static constexpr int PPMAX = 3 * 66, PSLOTS = 4; };
+template <> struct PatchCfg<2> { static constexpr int PPMAX = 5 * 65, PSLOTS = 6; };
 
 struct WParams {
     const bf16* dy; const bf16* x; float* partial;
-    int B, H, W, Co, Ci, R, nsplit, ntiles, tiles_per_img;   // R = 64 / W rows per pixel tile; ntiles = B * H / R
+    int B, H, W, Co, Ci, R, nsplit, ntiles, tiles_per_img;   // H, W: the OUTPUT (dy) grid; R = 64 / W rows per pixel tile; ntiles = B * H / R
+    int IH, IW;                                              // the input (x) grid: H, W at stride 1; 2 H, 2 W (or one less) at stride 2
 };
 
+template <int S>
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_kernel(const WParams P) {
+    constexpr int PPMAX = PatchCfg<S>::PPMAX, PSLOTS = PatchCfg<S>::PSLOTS;
     __shared__ __attribute__((aligned(16))) bf16 dyt[2][64 * LD];
     __shared__ __attribute__((aligned(16))) bf16 xpt[2][PPMAX * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = (wave >> 1) & 1, tg = wave >> 2;          // co half, ci half, tap group
-    const int W = P.W, R = P.R, WP = W + 2, PP = (R + 2) * WP;
+    const int W = P.W, R = P.R, WP = (W - 1) * S + 3, PP = ((R - 1) * S + 3) * WP;   // patch: input columns s ox + kw - 1, rows s oy + kh - 1
     // block -> (split, ci tile, co tile)
     const int tiles_ci = P.Ci / 64, tiles_co = P.Co / 64;
     int bid = blockIdx.x;
@@ -61,35 +67,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_kernel(const WParams P) 
         const int v = tid + 512 * i, px = v >> 3, vec = v & 7;
         const bool used = px < PP;
         const int pr = used ? px / WP : 0, pc = used ? px - pr * WP : 0;
-        p_rel[i] = ((pr - 1) * W + (pc - 1)) * P.Ci + ci0 + vec * 8;
+        p_rel[i] = ((pr - 1) * P.IW + (pc - 1)) * P.Ci + ci0 + vec * 8;        // relative to input pixel (s oy0, 0)
         p_lds[i] = (used ? px : 0) * LD + vec * 8;
         p_used |= (uint32_t)used << i;
-        p_colok |= (uint32_t)(pc >= 1 && pc <= W) << i;
+        p_colok |= (uint32_t)(pc >= 1 && pc <= P.IW) << i;
         p_top |= (uint32_t)(pr == 0) << i;
-        p_bot |= (uint32_t)(pr == R + 1) << i;
+        p_bot |= (uint32_t)(pr == (R - 1) * S + 2) << i;
     }
-    u32x4 rdy, rxp[PSLOTS];
-    uint32_t rok = 0;
-    auto gload = [&](int t) {   // pixel tile t: image b, first output row oy0
+    // two staging register sets: a tile's global loads get TWO compute phases to land (with one set, and one workgroup of 8 waves per CU,
+    // the loop ran at the load latency: 2.8 us per 64-pixel tile against 0.3 us of matrix work)
+    struct Regs { u32x4 dy; u32x4 xp[PSLOTS]; uint32_t ok; };
+    Regs r0, r1;
+    auto gload = [&](Regs& r, int t) {   // pixel tile t: image b, first output row oy0
         const int b = t / P.tiles_per_img, oy0 = (t - b * P.tiles_per_img) * R;
         const int64_t pix0 = ((int64_t)b * P.H + oy0) * W;
-        rdy = *reinterpret_cast<const u32x4*>(P.dy + pix0 * P.Co + dy_rel);
+        r.dy = *reinterpret_cast<const u32x4*>(P.dy + pix0 * P.Co + dy_rel);
         uint32_t ok = p_used & p_colok;
         if (oy0 == 0) ok &= ~p_top;
-        if (oy0 + R == P.H) ok &= ~p_bot;
-        const bf16* xb = P.x + pix0 * P.Ci;
+        if ((oy0 + R - 1) * S + 1 >= P.IH) ok &= ~p_bot;   // the patch's last row lies below the image (stride 1: the tile is the image's last rows)
+        const bf16* xb = P.x + (((int64_t)b * P.IH + (int64_t)oy0 * S) * P.IW) * P.Ci;
 #pragma unroll
         for (int i = 0; i < PSLOTS; ++i)   // unconditional loads from a clamped address, zero selected when the registers are staged
-            rxp[i] = *reinterpret_cast<const u32x4*>(xb + (((ok >> i) & 1u) ? p_rel[i] : ci0));
-        rok = ok;
+            r.xp[i] = *reinterpret_cast<const u32x4*>(xb + (((ok >> i) & 1u) ? p_rel[i] : ci0));
+        r.ok = ok;
     };
-    auto stage = [&](int buf) {
-        *reinterpret_cast<u32x4*>(&dyt[buf][dpx * LD + dvec * 8]) = rdy;
+    auto stage = [&](const Regs& r, int buf) {
+        *reinterpret_cast<u32x4*>(&dyt[buf][dpx * LD + dvec * 8]) = r.dy;
 #pragma unroll
         for (int i = 0; i < PSLOTS; ++i) {
             if ((p_used >> i) & 1u) {
-                const bool ok = (rok >> i) & 1u;
-                u32x4 v = rxp[i];
+                const bool ok = (r.ok >> i) & 1u;
+                u32x4 v = r.xp[i];
                 v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
                 *reinterpret_cast<u32x4*>(&xpt[buf][p_lds[i]]) = v;
             }
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_kernel(const WParams P) 
         for (int h = 0; h < 2; ++h) {
             const int kr = ks * 16 + tr_k + 4 * h;
             a_off[ks][h] = kr * LD + wm * 32 + tr_rowblk + tr_c;
-            b_off[ks][h] = ((kr / W) * WP + kr % W) * LD + wn * 32 + tr_rowblk + tr_c;
+            b_off[ks][h] = ((kr / W) * S * WP + (kr % W) * S) * LD + wn * 32 + tr_rowblk + tr_c;
         }
     const int tap0 = tg ? 5 : 0, ntap = tg ? 4 : 5;
     f32x16 acc[5];
@@ -135,22 +143,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_kernel(const WParams P) 
         }
     };
 
-    // ---- pixel tiles split, split + nsplit, ...: register-staged double buffering ----
-    int t = split, buf = 0;
-    if (t < P.ntiles) {
-        gload(t);
-        stage(0);
+    // ---- pixel tiles split, split + nsplit, ...: two LDS buffers, two register sets (prefetch distance 2), branch-free steady state ----
+    const int n = split < P.ntiles ? (P.ntiles - split + P.nsplit - 1) / P.nsplit : 0;   // tiles of this split
+    auto tile_of = [&](int i) { return split + (i < n ? i : n - 1) * P.nsplit; };         // (beyond the end: the last tile again, loaded and dropped)
+    if (n > 0) {
+        gload(r0, tile_of(0));
+        gload(r1, tile_of(1));
+        stage(r0, 0);
         __syncthreads();
-        for (;;) {
-            const int tn = t + P.nsplit;
-            const bool more = tn < P.ntiles;
-            if (more) gload(tn);
-            compute(buf);
-            if (!more) break;
-            stage(buf ^ 1);
+        int i = 0;
+        for (; i + 2 < n; i += 2) {   // buffer 0 = tile i; set 1 = tile i + 1 (on its way)
+            gload(r0, tile_of(i + 2));
+            compute(0);
+            stage(r1, 1);
             __syncthreads();
-            buf ^= 1;
-            t = tn;
+            gload(r1, tile_of(i + 3));
+            compute(1);
+            stage(r0, 0);
+            __syncthreads();
+        }
+        compute(0);
+        if (n - i == 2) {
+            stage(r1, 1);
+            __syncthreads();
+            compute(1);
         }
     }
     // ---- this split's block -> partial[split][co][tap][ci] (a lane holds 4 consecutive ci per register group) ----
@@ -200,23 +216,28 @@ extern "C" size_t ralf_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Ci
     return (size_t)nsplit * Co * 9 * Ci * sizeof(float);
 }
 
-extern "C" int ralf_conv3x3_wgrad(const void* dy, const void* x, float* dW, int B, int H, int W, int Ci, int Co, int accumulate, void* workspace, size_t workspace_bytes,
-                                  void* stream) {
+/* H, W: the OUTPUT grid (dy [B,H,W,Co]); x is [B,IH,IW,Ci] with IH = H, IW = W at stride 1 and (IH + 1) / 2 == H, (IW + 1) / 2 == W at stride 2 */
+extern "C" int ralf_conv3x3_wgrad(const void* dy, const void* x, float* dW, int B, int H, int W, int IH, int IW, int stride, int Ci, int Co, int accumulate,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
     RALF_REQUIRE(dy && x && dW && B > 0 && H > 0, "conv3x3_wgrad: bad arguments");
-    RALF_REQUIRE(W >= 8 && W <= 64 && (64 % W) == 0 && H % (64 / W) == 0, "conv3x3_wgrad: W must be 8, 16, 32 or 64 and H a multiple of 64 / W (whole image rows per 64-pixel tile)");
+    RALF_REQUIRE(stride == 1 || stride == 2, "conv3x3_wgrad: stride 1 or 2");
+    RALF_REQUIRE(W >= 8 && W <= 64 && (64 % W) == 0 && H % (64 / W) == 0, "conv3x3_wgrad: output width must be 8, 16, 32 or 64 and the output height a multiple of 64 / W");
+    RALF_REQUIRE(stride == 1 ? (IH == H && IW == W) : ((IH + 1) / 2 == H && (IW + 1) / 2 == W && W <= 32), "conv3x3_wgrad: input grid does not match (pad 1; stride 2: output width <= 32)");
     RALF_REQUIRE(Ci % 64 == 0 && Co % 64 == 0, "conv3x3_wgrad: channel counts must be multiples of 64 (Ci=%d Co=%d)", Ci, Co);
     RALF_REQUIRE((((uintptr_t)dy | (uintptr_t)x) & 15) == 0 && ((uintptr_t)dW & 3) == 0, "conv3x3_wgrad: operands must be 16-byte aligned");
-    RALF_REQUIRE((int64_t)B * H * W * (int64_t)(Ci > Co ? Ci : Co) < (1ll << 31), "conv3x3_wgrad: tensor too large for 32-bit offsets");
+    RALF_REQUIRE((int64_t)B * IH * IW * (int64_t)Ci < (1ll << 31) && (int64_t)B * H * W * (int64_t)Co < (1ll << 31), "conv3x3_wgrad: tensor too large for 32-bit offsets");
     const size_t need = ralf_conv3x3_wgrad_workspace_bytes(B, H, W, Ci, Co);
     if (!workspace || workspace_bytes < need) { ralf::set_error("conv3x3_wgrad: workspace %zu < required %zu bytes", workspace_bytes, need); return RALF_ERR_WORKSPACE; }
     WParams P;
     P.dy = (const bf16*)dy; P.x = (const bf16*)x; P.partial = (float*)workspace;
-    P.B = B; P.H = H; P.W = W; P.Co = Co; P.Ci = Ci; P.R = 64 / W;
+    P.B = B; P.H = H; P.W = W; P.Co = Co; P.Ci = Ci; P.R = 64 / W; P.IH = IH; P.IW = IW;
     P.tiles_per_img = H / P.R; P.ntiles = B * P.tiles_per_img;
     const int blocks = (Co / 64) * (Ci / 64);
     P.nsplit = (int)(need / ((size_t)Co * 9 * Ci * sizeof(float)));
+    RALF_REQUIRE(((P.R - 1) * stride + 3) * ((W - 1) * stride + 3) <= (stride == 1 ? PatchCfg<1>::PPMAX : PatchCfg<2>::PPMAX), "conv3x3_wgrad: halo patch too large");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(blocks * P.nsplit), dim3(512), 0, st, P);
+    if (stride == 1) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, dim3(blocks * P.nsplit), dim3(512), 0, st, P);
+    else hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, dim3(blocks * P.nsplit), dim3(512), 0, st, P);
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)(((int64_t)Co * 9 * Ci + 255) / 256)), dim3(256), 0, st, (const float*)workspace, P.nsplit, Co, Ci, dW, accumulate);
     return ralf::check_launch("conv3x3_wgrad");
 }

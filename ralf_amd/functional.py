@@ -1476,7 +1476,7 @@ class ConvFn(Function):
                 direct = rt.conv_wgrad_direct and kw == kh and ops.conv3x3_wgrad_supported(dy, x, stride, pad, kh, kw)
                 def run(out=None):
                     if direct:   # 3x3 / stride 1: the direct form (dy tile and halo patch staged once for all nine taps), straight into OIHW
-                        return ops.conv3x3_wgrad(dy, x, out=out)
+                        return ops.conv3x3_wgrad(dy, x, out=out, stride=stride)
                     g = ops.gemm(dy2, x, Co, kh * kw * C, M, a_kcontig=False, b_kcontig=False, conv=geom, gather=2,
                                  out_dtype=torch.float32, splitk=_splitk_for(Co, kh * kw * C, M))
                     # fp32 [Co][kh][kw][Cpad] -> OIHW master layout (drops the stem's channel padding)

@@ -439,12 +439,12 @@ def permute4_batched(table, njobs, total_blocks):
     _call("ralf_permute4_batched", _p(table), njobs, total_blocks)
 
 
-def conv3x3_wgrad(dy, x, out=None, accumulate=False):
-    """weight gradient of a 3x3 / stride 1 / pad 1 convolution in the direct form (ralf_conv3x3_wgrad): dy [B,H,W,Co], x [B,H,W,Ci] NHWC bf16 ->
+def conv3x3_wgrad(dy, x, out=None, accumulate=False, stride=1):
+    """weight gradient of a 3x3 / pad 1 convolution (stride 1 or 2) in the direct form (ralf_conv3x3_wgrad): dy [B,H,W,Co], x [B,IH,IW,Ci] NHWC bf16 ->
     fp32 OIHW [Co, Ci, 3, 3] (written into `out` when given)"""
     B, H, W, Co = dy.shape
-    Ci = x.shape[3]
-    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous() and tuple(x.shape[:3]) == (B, H, W)
+    _, IH, IW, Ci = x.shape
+    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous() and x.shape[0] == B
     if out is None:
         out = torch.empty(Co, Ci, 3, 3, dtype=torch.float32, device=dy.device)
         accumulate = False
@@ -453,14 +453,16 @@ def conv3x3_wgrad(dy, x, out=None, accumulate=False):
     need = L.ralf_conv3x3_wgrad_workspace_bytes(B, H, W, Ci, Co)
     assert need > 0, "conv3x3_wgrad: shape not covered"
     ws = workspace(need, dy.device)
-    _call("ralf_conv3x3_wgrad", _p(dy), _p(x), _p(out), B, H, W, Ci, Co, int(accumulate), _p(ws), need)
+    _call("ralf_conv3x3_wgrad", _p(dy), _p(x), _p(out), B, H, W, IH, IW, stride, Ci, Co, int(accumulate), _p(ws), need)
     return out
 
 
 def conv3x3_wgrad_supported(dy, x, stride, pad, kh, kw) -> bool:
     B, H, W, Co = dy.shape
-    return (kh == 3 and kw == 3 and stride == 1 and pad == 1 and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and W in (8, 16, 32, 64)
-            and H % (64 // W) == 0 and Co % 64 == 0 and x.shape[3] % 64 == 0 and tuple(x.shape[:3]) == (B, H, W))
+    IH, IW = x.shape[1], x.shape[2]
+    grid_ok = (IH == H and IW == W) if stride == 1 else ((IH + 1) // 2 == H and (IW + 1) // 2 == W and W <= 32)
+    return (kh == 3 and kw == 3 and stride in (1, 2) and pad == 1 and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and W in (8, 16, 32, 64)
+            and H % (64 // W) == 0 and Co % 64 == 0 and x.shape[3] % 64 == 0 and x.shape[0] == B and grid_ok)
 
 
 def bn_train_stats(x2d, gamma, beta, running_mean, running_var, counter, partials, eps=1e-5, momentum=0.1):

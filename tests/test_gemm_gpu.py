@@ -446,6 +446,13 @@ def test_conv3x3_weight_gradient_direct_form(B, H, W, Ci, Co):
     g = ops.gemm(dy.view(M, Co), x, Co, 9 * Ci, M, a_kcontig=False, b_kcontig=False, conv=geom, gather=2, out_dtype=torch.float32, splitk=4)
     old = g.view(Co, 3, 3, Ci).permute(0, 3, 1, 2)
     torch.testing.assert_close(got / scale, old / scale, atol=1e-4, rtol=1e-4)       # same products, fp32 sums in another order
+    # stride 2 (the first block of layer2-4): output grid [H/2, W/2] over the same input
+    if W >= 16:
+        dy2 = rnd(B, H // 2, W // 2, Co, seed=3).to(torch.bfloat16).cuda()
+        got2 = ops.conv3x3_wgrad(dy2, x, stride=2)
+        ref2 = torch.nn.grad.conv2d_weight(x.float().cpu().permute(0, 3, 1, 2), (Co, Ci, 3, 3), dy2.float().cpu().permute(0, 3, 1, 2), stride=2, padding=1)
+        s2 = (B * H * W / 4) ** 0.5
+        torch.testing.assert_close(got2.cpu() / s2, ref2 / s2, atol=2e-3, rtol=2e-3)
     acc = torch.ones(Co, Ci, 3, 3, device="cuda")
     ops.conv3x3_wgrad(dy, x, out=acc, accumulate=True)
     torch.testing.assert_close(acc, got + 1.0, atol=1e-5, rtol=1e-6)
