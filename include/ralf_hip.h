@@ -313,6 +313,11 @@ typedef struct RalfConvRelayoutJob {
 } RalfConvRelayoutJob;
 int ralf_conv_relayout_batched(const RalfConvRelayoutJob* jobs_device, int njobs, int total_blocks, void* stream);
 /* ResNet stem max-pool 3x3/s2/p1 (NHWC) with saved arg-max; FPN nearest up-sampling fused with the lateral add */
+/* The ResNet stem convolution (7x7, stride 2, pad 3, 4 input channels stored as 8, 64 output channels) in direct form (ralf_amd/csrc/stem.hip;
+ * timm resnet50 conv1 with the saliency channel, common/image.py:39-48,70-77; torch: F.conv2d): x [B,IH,IW,8] bf16 NHWC (channels 4..7 zero),
+ * w [64][7][7][8] bf16 -> y [B,OH,OW,64] bf16 with OH = (IH-1)/2+1, OW = (IW-1)/2+1.  part (may be NULL): fp32 [B*OH*ceil(OW/128)][2][64], per
+ * output-row tile the channel sums and sums of squares of y as stored: BatchNorm partial statistics for ralf_bn_stats_from_partials. */
+int ralf_stem7x7_fwd(const void* x, const void* w, void* y, float* part, int B, int IH, int IW, void* stream);
 /* Weight gradient of a 3x3 / pad 1 convolution of stride s = 1 or 2, DIRECT form (ralf_amd/csrc/conv_wgrad.hip): dW[co][ci][kh][kw] (fp32, OIHW;
  * = or +=) = sum over pixels of dy[b,oy,ox,co] * x[b,s oy+kh-1,s ox+kw-1,ci]; dy [B,H,W,Co] and x [B,IH,IW,Ci] NHWC bf16 (H, W: the OUTPUT grid).  A workgroup keeps a 64 x 64 x 9
  * block of dW in registers and stages each 64-pixel tile of dy and the halo patch of x once for all nine taps (the implicit-GEMM form,

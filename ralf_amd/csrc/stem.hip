@@ -1,0 +1,174 @@
+// The ResNet stem convolution -- 7x7, stride 2, pad 3, 4 input channels stored as 8 (16-byte pixels), 64 output channels -- in DIRECT form for
+// gfx950 (timm resnet50 conv1 with the 4th saliency channel, image2layout/train/models/common/image.py:39-48,70-77).
+//
+// The implicit-GEMM form (gemm_impl.h, the general per-vector gather) spends 147 us on it at B = 64, 256 x 256: a 16-byte vector per tap and pixel,
+// each with its own address arithmetic, for a product whose real contraction is 196 deep.  Here:
+//   * a workgroup (8 waves) owns ONE OUTPUT ROW segment of <= 128 pixels x 64 channels per tile and walks tiles blockIdx.x, + gridDim.x, ...;
+//   * the 7 x (2 * 128 + 5) input pixels the tile needs are staged once in LDS (30 KB); for a fixed kernel row kh the contraction runs over
+//     (kw, c) = the 7 x 8 values that lie CONTIGUOUSLY behind input pixel 2 ox - 3 of row 2 oy - 3 + kh, so the pixel-side MFMA operand of k-step
+//     (kh, kw pair) is one 16-byte LDS read per lane (conflict-free: the 64 lanes cover a dense 1 KiB), 28 k-steps of v_mfma_f32_32x32x16_bf16;
+//   * the 64 x 448 weights (kw padded to 8, zero tap) live in REGISTERS for the whole kernel (28 fragments per lane, loaded once per workgroup);
+//   * the tile leaves through LDS in 16-byte row-contiguous stores, with its per-channel sum / sum of squares (of the stored bf16 values) as one
+//     row of BatchNorm partial statistics (the layout ralf_bn_stats_from_partials takes).
+#include "common.h"
+
+namespace {
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TPX = 128;                 // output pixels per tile (one output row segment)
+constexpr int PW = 2 * TPX + 6;          // patch columns: input pixels 2 ox - 3 ... 2 ox + 4 for ox in [0, 128) (column 2 ox + 4 = the zero tap kw = 7) -> 262
+constexpr int PROWS = 7;
+constexpr int PVEC = PROWS * PW;         // 16-byte pixels per patch
+constexpr int PSLOTS = (PVEC + 511) / 512;
+constexpr int OLD = 64 + 8;              // output staging row stride (elements)
+
+struct SParams {
+    const bf16* x; const bf16* w; bf16* y; float* part;
+    int B, IH, IW, OH, OW, segs, ntiles;   // segs = ceil(OW / 128) row segments; ntiles = B * OH * segs
+};
+
+__global__ __launch_bounds__(512, 2) void stem7x7_fwd_kernel(const SParams P) {
+    __shared__ __attribute__((aligned(16))) bf16 patch[PVEC * 8];
+    __shared__ __attribute__((aligned(16))) bf16 ost[TPX * OLD];
+    __shared__ float red[2][8][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pxf = wave & 3, cof = wave >> 2, l31 = lane & 31, lh = lane >> 5;
+
+    // ---- weights -> registers: fragment (kh, j): row co = 32 cof + l31, the 8 channels of tap (kh, kw = 2 j + lh); kw = 7 is the zero tap ----
+    bf16x8 wf[PROWS][4];
+    {
+        const bf16* wr = P.w + (int64_t)(cof * 32 + l31) * (7 * 7 * 8);
+#pragma unroll
+        for (int kh = 0; kh < PROWS; ++kh)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kw = 2 * j + lh;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(wr + (kh * 7 + (kw < 7 ? kw : 6)) * 8);
+                if (kw >= 7) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = (bf16)0.f;
+                }
+                wf[kh][j] = v;
+            }
+    }
+    // ---- this thread's patch slots: vector v = tid + 512 i -> (row kh, column pc); input pixel (2 oy - 3 + kh, 2 ox0 - 3 + pc) ----
+    int s_kh[PSLOTS], s_pc[PSLOTS];
+    uint32_t s_used = 0;
+#pragma unroll
+    for (int i = 0; i < PSLOTS; ++i) {
+        const int v = tid + 512 * i;
+        const bool used = v < PVEC;
+        s_kh[i] = used ? v / PW : 0;
+        s_pc[i] = used ? v - s_kh[i] * PW : 0;
+        s_used |= (uint32_t)used << i;
+    }
+    u32x4 rp[PSLOTS];
+    uint32_t rok = 0;
+    auto gload = [&](int t) {
+        const int seg = t % P.segs, row = t / P.segs, oy = row % P.OH, b = row / P.OH;
+        const int iy0 = 2 * oy - 3, ix0 = 2 * seg * TPX - 3;
+        uint32_t ok = 0;
+#pragma unroll
+        for (int i = 0; i < PSLOTS; ++i) {
+            const int iy = iy0 + s_kh[i], ix = ix0 + s_pc[i];
+            const bool in = ((s_used >> i) & 1u) && (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW;
+            const int64_t off = (((int64_t)b * P.IH + (in ? iy : 0)) * P.IW + (in ? ix : 0)) * 8;   // (clamped address, zero selected at stage time)
+            rp[i] = *reinterpret_cast<const u32x4*>(P.x + off);
+            ok |= (uint32_t)in << i;
+        }
+        rok = ok;
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < PSLOTS; ++i) {
+            if ((s_used >> i) & 1u) {
+                const bool ok = (rok >> i) & 1u;
+                u32x4 v = rp[i];
+                v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+                *reinterpret_cast<u32x4*>(&patch[(s_kh[i] * PW + s_pc[i]) * 8]) = v;
+            }
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t < P.ntiles) gload(t);
+    for (; t < P.ntiles; t += gridDim.x) {
+        __syncthreads();            // the previous tile's reads of patch / ost are done
+        stage();
+        __syncthreads();
+        const int tn = t + gridDim.x;
+        if (tn < P.ntiles) gload(tn);
+        // ---- 28 k-steps: pixel operand = 16 bytes behind patch pixel (kh, 2 px + 2 j + lh) ----
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const bf16* ap = patch + (2 * (pxf * 32 + l31) + lh) * 8;
+#pragma unroll
+        for (int kh = 0; kh < PROWS; ++kh)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + (kh * PW + 2 * j) * 8);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kh][j], a, acc, 0, 0, 0);
+            }
+        // ---- tile -> LDS [128 px][64 co] (a lane holds pixel 32 pxf + l31, channels 32 cof + 8 g + 4 lh + 0..3) ----
+        {
+            bf16* o = ost + (pxf * 32 + l31) * OLD + cof * 32 + 4 * lh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                bf16x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (bf16)acc[4 * g + q];
+                *reinterpret_cast<bf16x4*>(o + 8 * g) = v;
+            }
+        }
+        __syncthreads();
+        const int seg = t % P.segs, row = t / P.segs;
+        const int npx = min(TPX, P.OW - seg * TPX);
+        // 16-byte row-contiguous stores: thread -> (pixel tid / 8 [+ 64], vector tid % 8)
+        bf16* yrow = P.y + ((int64_t)row * P.OW + (int64_t)seg * TPX) * 64;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int px = (tid >> 3) + 64 * h, vec = tid & 7;
+            if (px < npx) *reinterpret_cast<u32x4*>(yrow + (int64_t)px * 64 + vec * 8) = *reinterpret_cast<const u32x4*>(ost + px * OLD + vec * 8);
+        }
+        if (P.part) {   // BatchNorm partial statistics of the values as stored: channel tid % 64, pixels tid / 64 + 8 k
+            const int c = tid & 63, pg = tid >> 6;
+            float s1 = 0.f, s2 = 0.f;
+            for (int px = pg; px < npx; px += 8) {
+                const float v = (float)ost[px * OLD + c];
+                s1 += v; s2 += v * v;
+            }
+            red[0][pg][c] = s1; red[1][pg][c] = s2;
+            __syncthreads();
+            if (tid < 128) {
+                const int which = tid >> 6, cc = tid & 63;
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += red[which][k][cc];
+                P.part[((int64_t)t * 2 + which) * 64 + cc] = s;
+            }
+        }
+    }
+}
+}  // namespace
+
+/* x [B, IH, IW, 8] bf16 (channels 4..7 zero), w [64][7][7][8] bf16 -> y [B, OH, OW, 64] bf16, OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
+ * part (may be NULL): fp32 [B * OH * ceil(OW / 128)][2][64] per-tile channel sums / sums of squares of y */
+extern "C" int ralf_stem7x7_fwd(const void* x, const void* w, void* y, float* part, int B, int IH, int IW, void* stream) {
+    RALF_REQUIRE(x && w && y && B > 0 && IH >= 7 && IW >= 7, "stem7x7_fwd: bad arguments");
+    RALF_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0, "stem7x7_fwd: operands must be 16-byte aligned");
+    SParams P;
+    P.x = (const bf16*)x; P.w = (const bf16*)w; P.y = (bf16*)y; P.part = part;
+    P.B = B; P.IH = IH; P.IW = IW; P.OH = (IH - 1) / 2 + 1; P.OW = (IW - 1) / 2 + 1;
+    P.segs = (P.OW + TPX - 1) / TPX;
+    const int64_t nt = (int64_t)B * P.OH * P.segs;
+    RALF_REQUIRE(nt < (1ll << 30) && (int64_t)B * IH * IW * 8 < (1ll << 40), "stem7x7_fwd: problem too large");
+    P.ntiles = (int)nt;
+    const int grid = (int)(nt < 256 ? nt : 256);   // one persistent workgroup per CU (the weights sit in its registers)
+    hipLaunchKernelGGL(stem7x7_fwd_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, P);
+    return ralf::check_launch("stem7x7_fwd");
+}

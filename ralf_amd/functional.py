@@ -85,6 +85,7 @@ class Runtime:
         self.fused_decode = True  # KV-cached decode step: LayerNorm + projections + attention per block in one launch (bf16, d = 256, 8 heads)
         self.fold_bn = True       # inference: eval-mode BatchNorm folded into the convolution epilogues (conv_bn_infer)
         self.conv_wgrad_direct = os.environ.get("RALF_CONV_WGRAD_DIRECT", "1") != "0"   # 3x3 / stride-1 weight gradients in the direct form (ops.conv3x3_wgrad)
+        self.stem_direct = os.environ.get("RALF_STEM_DIRECT", "1") != "0"               # the 7x7 stem convolution in direct form (ops.stem7x7_fwd)
         self.fused_stem = os.environ.get("RALF_FUSED_STEM", "1") != "0"   # training: the stem's BatchNorm + ReLU + max-pool as one pass (StemBNReluPoolFn)
 
     def to(self, device):
@@ -1419,6 +1420,10 @@ class ConvFn(Function):
                              sA=(hw * Ci, 0), sC=(hw * Co, 0), sR=(0, 0), out=torch.empty(M, Co, dtype=x.dtype, device=x.device))
             else:
                 y = ops.gemm(x.view(-1, C), rt.lp(W).view(Co, Ci), M, Co, Ci, bias=bias, colstats=cst)
+        elif (rt.stem_direct and kh == 7 and kw == 7 and stride == 2 and pad == 3 and C == 8 and Co == 64 and b is None and pos is None
+              and x.dtype == torch.bfloat16):
+            # the stem: direct form (one output row per tile, the input patch staged once, weights in registers), statistics from its own epilogue
+            y, cst = ops.stem7x7_fwd(x, rt.lp(W, "ohwi"), want_stats=stats)
         else:
             assert pos is None
             geom = dict(RH=OH, RW=OW, SH=H, SW=Wd, SC=C, KH=kh, KW=kw, stride=stride, pad=pad, mode=0)

@@ -439,6 +439,18 @@ def permute4_batched(table, njobs, total_blocks):
     _call("ralf_permute4_batched", _p(table), njobs, total_blocks)
 
 
+def stem7x7_fwd(x8, w_ohwi, want_stats=True):
+    """the stem convolution in direct form (ralf_stem7x7_fwd): x8 [B,IH,IW,8] bf16, w_ohwi [64,7,7,8] bf16 -> (y [B,OH,OW,64] bf16, partial statistics
+    [tiles,2,64] fp32 or None)"""
+    B, IH, IW, C = x8.shape
+    assert C == 8 and x8.dtype == torch.bfloat16 and x8.is_contiguous() and w_ohwi.dtype == torch.bfloat16 and w_ohwi.numel() == 64 * 7 * 7 * 8 and w_ohwi.is_contiguous()
+    OH, OW = (IH - 1) // 2 + 1, (IW - 1) // 2 + 1
+    y = torch.empty(B, OH, OW, 64, dtype=torch.bfloat16, device=x8.device)
+    part = torch.empty(B * OH * ((OW + 127) // 128), 2, 64, dtype=torch.float32, device=x8.device) if want_stats else None
+    _call("ralf_stem7x7_fwd", _p(x8), _p(w_ohwi), _p(y), _p(part), B, IH, IW)
+    return y, part
+
+
 def conv3x3_wgrad(dy, x, out=None, accumulate=False, stride=1):
     """weight gradient of a 3x3 / pad 1 convolution (stride 1 or 2) in the direct form (ralf_conv3x3_wgrad): dy [B,H,W,Co], x [B,IH,IW,Ci] NHWC bf16 ->
     fp32 OIHW [Co, Ci, 3, 3] (written into `out` when given)"""

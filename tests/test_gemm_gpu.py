@@ -457,3 +457,30 @@ def test_conv3x3_weight_gradient_direct_form(B, H, W, Ci, Co):
     ops.conv3x3_wgrad(dy, x, out=acc, accumulate=True)
     torch.testing.assert_close(acc, got + 1.0, atol=1e-5, rtol=1e-6)
     assert torch.equal(ops.conv3x3_wgrad(dy, x), got)                                   # deterministic
+
+
+@pytest.mark.parametrize("B,IH,IW", [(2, 64, 64), (1, 350, 240), (3, 32, 96), (1, 30, 300)])
+def test_stem_convolution_direct_form(B, IH, IW):
+    """ralf_stem7x7_fwd (7x7 / 2 / pad 3 on 8-channel pixels, one output row per tile, statistics from its epilogue) against torch's conv2d on the
+    same bf16 operands and against the implicit-GEMM form it replaces; odd sizes, rows wider than one tile (OW > 128), image borders"""
+    from ralf_amd import ops
+
+    x = torch.zeros(B, IH, IW, 8)
+    x[..., :4] = rnd(B, IH, IW, 4, seed=1)
+    x = x.to(torch.bfloat16).cuda()
+    w = torch.zeros(64, 7, 7, 8)
+    w[..., :4] = rnd(64, 7, 7, 4, seed=2) * 0.1
+    w = w.to(torch.bfloat16).cuda()
+    y, part = ops.stem7x7_fwd(x, w)
+    OH, OW = (IH - 1) // 2 + 1, (IW - 1) // 2 + 1
+    ref = F.conv2d(x[..., :4].float().cpu().permute(0, 3, 1, 2), w[..., :4].float().cpu().permute(0, 3, 1, 2), None, 2, 3).permute(0, 2, 3, 1)
+    assert tuple(y.shape) == (B, OH, OW, 64)
+    torch.testing.assert_close(y.float().cpu(), ref, atol=2e-2, rtol=2e-2)
+    M = B * OH * OW
+    geom = dict(RH=OH, RW=OW, SH=IH, SW=IW, SC=8, KH=7, KW=7, stride=2, pad=3, mode=0)
+    old = ops.gemm(x, w, M, 64, 7 * 7 * 8, conv=geom, gather=1).view(B, OH, OW, 64)
+    assert (y.float() - old.float()).abs().max().item() <= 2.0 ** -7 * old.float().abs().max().item()   # same products, another fp32 summation order: <= 1 bf16 ulp
+    s = part.sum(0)
+    yf = y.float().view(-1, 64)
+    torch.testing.assert_close(s[0], yf.sum(0), atol=1e-2, rtol=1e-4)
+    torch.testing.assert_close(s[1], (yf * yf).sum(0), atol=1e-2, rtol=1e-4)
