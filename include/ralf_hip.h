@@ -318,6 +318,11 @@ int ralf_conv_relayout_batched(const RalfConvRelayoutJob* jobs_device, int njobs
  * w [64][7][7][8] bf16 -> y [B,OH,OW,64] bf16 with OH = (IH-1)/2+1, OW = (IW-1)/2+1.  part (may be NULL): fp32 [B*OH*ceil(OW/128)][2][64], per
  * output-row tile the channel sums and sums of squares of y as stored: BatchNorm partial statistics for ralf_bn_stats_from_partials. */
 int ralf_stem7x7_fwd(const void* x, const void* w, void* y, float* part, int B, int IH, int IW, void* stream);
+/* its weight gradient in the same form (the weight half of torch's conv2d backward): dW [64][4][7][7] fp32 OIHW (= or +=) from x [B,IH,IW,8] and
+ * dy [B,OH,OW,64] bf16; one persistent workgroup per CU keeps the 64 x 7 x 64 block in registers over its output-row tiles, a second kernel sums the
+ * workgroups' blocks in order (deterministic) */
+size_t ralf_stem7x7_wgrad_workspace_bytes(int B, int IH, int IW);
+int ralf_stem7x7_wgrad(const void* x, const void* dy, float* dW, int B, int IH, int IW, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 /* Weight gradient of a 3x3 / pad 1 convolution of stride s = 1 or 2, DIRECT form (ralf_amd/csrc/conv_wgrad.hip): dW[co][ci][kh][kw] (fp32, OIHW;
  * = or +=) = sum over pixels of dy[b,oy,ox,co] * x[b,s oy+kh-1,s ox+kw-1,ci]; dy [B,H,W,Co] and x [B,IH,IW,Ci] NHWC bf16 (H, W: the OUTPUT grid).  A workgroup keeps a 64 x 64 x 9
  * block of dW in registers and stages each 64-pixel tile of dy and the halo patch of x once for all nine taps (the implicit-GEMM form,

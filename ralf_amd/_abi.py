@@ -145,6 +145,8 @@ SIGNATURES.update({
     "ralf_copy2d": (i32, [i32, i32, vp, vp, i64, i32, i64, i64, i32, vp]),
     "ralf_permute4": (i32, [i32, i32, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, i32, vp]),
     "ralf_stem7x7_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "ralf_stem7x7_wgrad_workspace_bytes": (sz, [i32, i32, i32]),
+    "ralf_stem7x7_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
     "ralf_conv3x3_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "ralf_conv3x3_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "ralf_bn_relu_maxpool_fwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

@@ -154,7 +154,183 @@ __global__ __launch_bounds__(512, 2) void stem7x7_fwd_kernel(const SParams P) {
         }
     }
 }
+
+// ---- weight gradient of the stem:  dW[co][kh][kw][c] = sum over (b, oy, ox) of dy[b, oy, ox, co] * x[b, 2 oy - 3 + kh, 2 ox - 3 + kw, c] ----
+// Same tiles and the same patch: per output-row tile the 128 x 64 slice of dy and the 7-row input patch are staged once; for a fixed kernel row kh
+// the (kw, c) axis of the weight block is the 64 contiguous values behind patch pixel (kh, 2 ox), so the x operand of the contraction over pixels is
+// a [k = pixel][n = 64] tile whose k-rows lie 32 bytes apart in the patch -- read through ds_read_b64_tr_b16 like the dy tile.  A workgroup (8 waves:
+// co half x kernel-row group {0,1} {2,3} {4,5} {6}) keeps the whole 64 x 7 x 64 block in registers over its tiles and writes it once; a second
+// kernel sums the workgroups' blocks in order into the OIHW fp32 gradient (4 real channels, 7 real taps).
+constexpr int DLD = 64 + 8;      // dy tile row stride (elements)
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+struct SWParams {
+    const bf16* x; const bf16* dy; float* partial;
+    int B, IH, IW, OH, OW, segs, ntiles;
+};
+
+__global__ __launch_bounds__(512, 2) void stem7x7_wgrad_kernel(const SWParams P) {   // (two workgroups per CU at 128 registers spilled and ran 199 us instead of 137)
+    __shared__ __attribute__((aligned(16))) bf16 patch[PVEC * 8 + 64];   // (+ slack: the zero-tap columns of the last pixels read just past the last row)
+    __shared__ __attribute__((aligned(16))) bf16 dyt[TPX * DLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cof = wave & 1, khg = wave >> 1;                 // co half; kernel rows 2 khg, 2 khg + 1 (khg = 3: row 6 only)
+    const int nkh = khg == 3 ? 1 : 2;
+    int s_kh[PSLOTS], s_pc[PSLOTS];
+    uint32_t s_used = 0;
+#pragma unroll
+    for (int i = 0; i < PSLOTS; ++i) {
+        const int v = tid + 512 * i;
+        const bool used = v < PVEC;
+        s_kh[i] = used ? v / PW : 0;
+        s_pc[i] = used ? v - s_kh[i] * PW : 0;
+        s_used |= (uint32_t)used << i;
+    }
+    u32x4 rp[PSLOTS], rd[2];
+    uint32_t rok = 0, dok = 0;
+    auto gload = [&](int t) {
+        const int seg = t % P.segs, row = t / P.segs, oy = row % P.OH, b = row / P.OH;
+        const int iy0 = 2 * oy - 3, ix0 = 2 * seg * TPX - 3;
+        uint32_t ok = 0;
+#pragma unroll
+        for (int i = 0; i < PSLOTS; ++i) {
+            const int iy = iy0 + s_kh[i], ix = ix0 + s_pc[i];
+            const bool in = ((s_used >> i) & 1u) && (unsigned)iy < (unsigned)P.IH && (unsigned)ix < (unsigned)P.IW;
+            rp[i] = *reinterpret_cast<const u32x4*>(P.x + (((int64_t)b * P.IH + (in ? iy : 0)) * P.IW + (in ? ix : 0)) * 8);
+            ok |= (uint32_t)in << i;
+        }
+        rok = ok;
+        // dy tile: pixel tid / 8 (+ 64), vector tid % 8; pixels beyond the row's end are zero (they contribute nothing)
+        const int npx = min(TPX, P.OW - seg * TPX);
+        const bf16* drow = P.dy + ((int64_t)row * P.OW + (int64_t)seg * TPX) * 64;
+        uint32_t dk = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int px = (tid >> 3) + 64 * h;
+            const bool in = px < npx;
+            rd[h] = *reinterpret_cast<const u32x4*>(drow + (int64_t)(in ? px : 0) * 64 + (tid & 7) * 8);
+            dk |= (uint32_t)in << h;
+        }
+        dok = dk;
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < PSLOTS; ++i) {
+            if ((s_used >> i) & 1u) {
+                const bool ok = (rok >> i) & 1u;
+                u32x4 v = rp[i];
+                v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+                *reinterpret_cast<u32x4*>(&patch[(s_kh[i] * PW + s_pc[i]) * 8]) = v;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool ok = (dok >> h) & 1u;
+            u32x4 v = rd[h];
+            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+            *reinterpret_cast<u32x4*>(&dyt[((tid >> 3) + 64 * h) * DLD + (tid & 7) * 8]) = v;
+        }
+    };
+    if (tid < 64) patch[PVEC * 8 + tid] = (bf16)0.f;   // the slack behind the patch
+
+    // transpose-read geometry (gemm_impl.h): a 16-lane group reads [4 k-rows][16 rows]
+    const int lh = lane >> 5, trL = lane & 15, tr_rowblk = ((lane >> 4) & 1) * 16, tr_k = lh * 8 + (trL >> 2), tr_c = (trL & 3) * 4;
+    f32x16 acc[2][2];   // [kernel row of the group][n fragment: (kw, c) 0..31 / 32..63]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][n][r] = 0.f;
+
+    int t = blockIdx.x;
+    if (t < P.ntiles) gload(t);
+    for (; t < P.ntiles; t += gridDim.x) {
+        __syncthreads();
+        stage();
+        __syncthreads();
+        const int tn = t + gridDim.x;
+        if (tn < P.ntiles) gload(tn);
+#pragma unroll
+        for (int ks = 0; ks < TPX / 16; ++ks) {   // 16 pixels per k-step
+            const int kr = ks * 16 + tr_k;         // this lane's pixel (low half; high half + 4)
+            const bf16* qa = dyt + kr * DLD + cof * 32 + tr_rowblk + tr_c;
+            const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qa));
+            const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qa + 4 * DLD));
+            const bf16x8 a = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if (kk < nkh) {   // (wave-uniform)
+                    const int kh = 2 * khg + kk;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const bf16* qb = patch + (kh * PW + 2 * kr) * 8 + n * 32 + tr_rowblk + tr_c;   // k-row stride = 2 pixels = 16 elements
+                        const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qb));
+                        const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qb + 4 * 16));
+                        const bf16x8 b = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[kk][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc[kk][n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- this workgroup's block -> partial[blockIdx.x][co][kh][(kw, c) 0..63] ----
+    const int co = cof * 32 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        if (kk < nkh) {
+            float* o = P.partial + (((int64_t)blockIdx.x * 64 + co) * 7 + (2 * khg + kk)) * 64 + 4 * lh;
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(o + n * 32 + 8 * g) = make_float4(acc[kk][n][4 * g], acc[kk][n][4 * g + 1], acc[kk][n][4 * g + 2], acc[kk][n][4 * g + 3]);
+        }
+    }
+}
+
+// dW[co][c][kh][kw] (OIHW fp32, c < 4, kw < 7) = sum over the workgroups' blocks, in order
+__global__ __launch_bounds__(256) void stem7x7_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dW, int accumulate) {
+    const int e = blockIdx.x * 256 + threadIdx.x;   // index into [co][kh][kw 0..7][c 0..7]
+    if (e >= 64 * 7 * 64) return;
+    const int c = e & 7, kw = (e >> 3) & 7, kh = (e >> 6) % 7, co = (e >> 6) / 7;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * (64 * 7 * 64) + e];
+    if (c < 4 && kw < 7) {
+        float* o = dW + ((co * 4 + c) * 7 + kh) * 7 + kw;
+        *o = accumulate ? *o + s : s;
+    }
+}
 }  // namespace
+
+constexpr int SW_GRID = 256;   // one persistent workgroup per CU
+
+extern "C" size_t ralf_stem7x7_wgrad_workspace_bytes(int B, int IH, int IW) {
+    if (B <= 0 || IH < 7 || IW < 7) return 0;
+    const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
+    const int64_t nt = (int64_t)B * OH * ((OW + TPX - 1) / TPX);
+    return (size_t)(nt < SW_GRID ? nt : SW_GRID) * 64 * 7 * 64 * sizeof(float);
+}
+
+/* x [B, IH, IW, 8] bf16, dy [B, OH, OW, 64] bf16 -> dW [64][4][7][7] fp32 (OIHW; = or +=) */
+extern "C" int ralf_stem7x7_wgrad(const void* x, const void* dy, float* dW, int B, int IH, int IW, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    RALF_REQUIRE(x && dy && dW && B > 0 && IH >= 7 && IW >= 7, "stem7x7_wgrad: bad arguments");
+    RALF_REQUIRE((((uintptr_t)x | (uintptr_t)dy) & 15) == 0, "stem7x7_wgrad: operands must be 16-byte aligned");
+    const size_t need = ralf_stem7x7_wgrad_workspace_bytes(B, IH, IW);
+    if (!workspace || workspace_bytes < need) { ralf::set_error("stem7x7_wgrad: workspace %zu < required %zu bytes", workspace_bytes, need); return RALF_ERR_WORKSPACE; }
+    SWParams P;
+    P.x = (const bf16*)x; P.dy = (const bf16*)dy; P.partial = (float*)workspace;
+    P.B = B; P.IH = IH; P.IW = IW; P.OH = (IH - 1) / 2 + 1; P.OW = (IW - 1) / 2 + 1;
+    P.segs = (P.OW + TPX - 1) / TPX;
+    const int64_t nt = (int64_t)B * P.OH * P.segs;
+    RALF_REQUIRE(nt < (1ll << 30), "stem7x7_wgrad: problem too large");
+    P.ntiles = (int)nt;
+    const int grid = (int)(nt < SW_GRID ? nt : SW_GRID);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(stem7x7_wgrad_kernel, dim3(grid), dim3(512), 0, st, P);
+    hipLaunchKernelGGL(stem7x7_wgrad_reduce_kernel, dim3((64 * 7 * 64 + 255) / 256), dim3(256), 0, st, (const float*)workspace, grid, dW, accumulate);
+    return ralf::check_launch("stem7x7_wgrad");
+}
 
 /* x [B, IH, IW, 8] bf16 (channels 4..7 zero), w [64][7][7][8] bf16 -> y [B, OH, OW, 64] bf16, OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
  * part (may be NULL): fp32 [B * OH * ceil(OW / 128)][2][64] per-tile channel sums / sums of squares of y */

@@ -1479,7 +1479,11 @@ class ConvFn(Function):
             else:
                 geom = dict(RH=OH, RW=OW, SH=H, SW=Wd, SC=C, KH=kh, KW=kw, stride=stride, pad=pad, mode=0)
                 direct = rt.conv_wgrad_direct and kw == kh and ops.conv3x3_wgrad_supported(dy, x, stride, pad, kh, kw)
+                stem = (rt.stem_direct and kh == 7 and kw == 7 and stride == 2 and pad == 3 and C == 8 and Co == 64 and Ci == 4 and x.dtype == torch.bfloat16
+                        and dy.dtype == torch.bfloat16)
                 def run(out=None):
+                    if stem:     # the stem: direct form (ops.stem7x7_wgrad), straight into OIHW
+                        return ops.stem7x7_wgrad(x, dy, out=out)
                     if direct:   # 3x3 / stride 1: the direct form (dy tile and halo patch staged once for all nine taps), straight into OIHW
                         return ops.conv3x3_wgrad(dy, x, out=out, stride=stride)
                     g = ops.gemm(dy2, x, Co, kh * kw * C, M, a_kcontig=False, b_kcontig=False, conv=geom, gather=2,

@@ -451,6 +451,21 @@ def stem7x7_fwd(x8, w_ohwi, want_stats=True):
     return y, part
 
 
+def stem7x7_wgrad(x8, dy, out=None, accumulate=False):
+    """weight gradient of the stem convolution in direct form (ralf_stem7x7_wgrad): x8 [B,IH,IW,8], dy [B,OH,OW,64] bf16 -> fp32 OIHW [64, 4, 7, 7]"""
+    B, IH, IW, C = x8.shape
+    assert C == 8 and x8.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x8.is_contiguous() and dy.is_contiguous()
+    assert tuple(dy.shape) == (B, (IH - 1) // 2 + 1, (IW - 1) // 2 + 1, 64)
+    if out is None:
+        out = torch.empty(64, 4, 7, 7, dtype=torch.float32, device=x8.device)
+        accumulate = False
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == 64 * 4 * 49
+    need = _lib.lib().ralf_stem7x7_wgrad_workspace_bytes(B, IH, IW)
+    ws = workspace(need, x8.device)
+    _call("ralf_stem7x7_wgrad", _p(x8), _p(dy), _p(out), B, IH, IW, int(accumulate), _p(ws), need)
+    return out
+
+
 def conv3x3_wgrad(dy, x, out=None, accumulate=False, stride=1):
     """weight gradient of a 3x3 / pad 1 convolution (stride 1 or 2) in the direct form (ralf_conv3x3_wgrad): dy [B,H,W,Co], x [B,IH,IW,Ci] NHWC bf16 ->
     fp32 OIHW [Co, Ci, 3, 3] (written into `out` when given)"""

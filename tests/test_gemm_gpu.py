@@ -480,6 +480,16 @@ def test_stem_convolution_direct_form(B, IH, IW):
     geom = dict(RH=OH, RW=OW, SH=IH, SW=IW, SC=8, KH=7, KW=7, stride=2, pad=3, mode=0)
     old = ops.gemm(x, w, M, 64, 7 * 7 * 8, conv=geom, gather=1).view(B, OH, OW, 64)
     assert (y.float() - old.float()).abs().max().item() <= 2.0 ** -7 * old.float().abs().max().item()   # same products, another fp32 summation order: <= 1 bf16 ulp
+    # ... and its weight gradient against torch's (fp32 accumulation of bf16 products)
+    dyt = rnd(B, OH, OW, 64, seed=3).to(torch.bfloat16).cuda()
+    dW = ops.stem7x7_wgrad(x, dyt)
+    refw = torch.nn.grad.conv2d_weight(x[..., :4].float().cpu().permute(0, 3, 1, 2), (64, 4, 7, 7), dyt.float().cpu().permute(0, 3, 1, 2), stride=2, padding=3)
+    sc = (B * OH * OW) ** 0.5
+    torch.testing.assert_close(dW.cpu() / sc, refw / sc, atol=2e-3, rtol=2e-3)
+    acc = torch.ones(64, 4, 7, 7, device="cuda")
+    ops.stem7x7_wgrad(x, dyt, out=acc, accumulate=True)
+    torch.testing.assert_close(acc, dW + 1.0, atol=1e-4, rtol=1e-6)
+    assert torch.equal(ops.stem7x7_wgrad(x, dyt), dW)
     s = part.sum(0)
     yf = y.float().view(-1, 64)
     torch.testing.assert_close(s[0], yf.sum(0), atol=1e-2, rtol=1e-4)

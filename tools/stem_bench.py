@@ -18,3 +18,19 @@ cst = ops.colstats_buffer(M, 64, x.device)
 to = _time_gpu(lambda: ops.gemm(x, w, M, 64, 392, conv=geom, gather=1, colstats=cst), 20, 3)
 tn = _time_gpu(lambda: ops.stem7x7_fwd(x, w), 20, 3)
 print(f"stem forward: implicit-GEMM {to * 1e6:.1f} us, direct {tn * 1e6:.1f} us ({(67.1 + 134.2) / tn / 1e6:.2f} TB/s of 201 MB)")
+
+dy = torch.randn(B, 128, 128, 64, device="cuda", generator=g).to(torch.bfloat16)
+from ralf_amd.functional import _splitk_for  # noqa: E402
+out = torch.empty(64, 4, 7, 7, device="cuda")
+
+
+def old_w():
+    gg = ops.gemm(dy.view(M, 64), x, 64, 392, M, a_kcontig=False, b_kcontig=False, conv=geom, gather=2, out_dtype=torch.float32, splitk=_splitk_for(64, 392, M))
+    return ops.permute4(gg, (64, 4, 7, 7), (392, 1, 56, 8), 7, torch.float32, out=out)
+
+
+a = old_w().clone()
+b = ops.stem7x7_wgrad(x, dy).clone()
+print("wgrad max rel diff", ((a - b).abs().max() / a.abs().max()).item())
+to, tn = _time_gpu(old_w, 20, 3), _time_gpu(lambda: ops.stem7x7_wgrad(x, dy, out=out), 20, 3)
+print(f"stem weight gradient: implicit-GEMM {to * 1e6:.1f} us, direct {tn * 1e6:.1f} us")
