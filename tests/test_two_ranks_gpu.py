@@ -97,8 +97,12 @@ def test_two_ranks_on_one_gpu_keep_identical_weights(tmp_path, wire, mode):
         _FP32_RUN.update(r[0])
     elif _FP32_RUN:
         base = _FP32_RUN
-        if wire == "fp32":   # (two runs of the step agree to the order of the fp32 atomics in the embedding gradients)
-            assert abs(r[0]["gnorm"] - base["gnorm"]) < 1e-5 * base["gnorm"] and abs(r[0]["pnorm"] - base["pnorm"]) < 1e-6 * base["pnorm"]
+        if wire == "fp32":
+            # two runs of the same step agree to the order of the fp32 atomics in the column sums (bias / LayerNorm / embedding gradients:
+            # one ulp, tools/determinism_probe.py -- every matrix and filter gradient is bit-identical): the FIRST step's clip norm to 1e-6;
+            # by the third step AdamW's normalised update has amplified those ulps on this 2-sample batch (measured 2.4e-5)
+            assert abs(r[0]["gnorm1"] - base["gnorm1"]) < 1e-6 * base["gnorm1"], (r[0]["gnorm1"], base["gnorm1"])
+            assert abs(r[0]["gnorm"] - base["gnorm"]) < 2e-4 * base["gnorm"] and abs(r[0]["pnorm"] - base["pnorm"]) < 1e-6 * base["pnorm"]
         else:
             # bf16 on the wire: every gradient element rounded to 8 bits once per rank -> the FIRST step's norm moves by << 2^-8 relative
             # (measured 4e-5).  Later steps are not comparable: AdamW's normalised update turns the rounding of a near-zero gradient
