@@ -427,6 +427,35 @@ def test_attention_decode_step(B, Sk, pad):
             assert torch.equal(o3, o if not need_lse else o2)
 
 
+@pytest.mark.parametrize("B,H,Sk,pad", [(3, 8, 1, False), (5, 8, 51, True), (4, 8, 532, False), (2, 4, 700, True), (3, 8, 3000, True)])
+def test_attention_decode_step_fp32(B, H, Sk, pad):
+    """Sq = 1 in the fp32 parity mode (attn_decode_f32_kernel: a workgroup per batch element, lanes across the 256-wide row): against
+    torch at 1e-5, and against the general one-lane-per-query kernel (need_lse=True keeps that one)."""
+    from ralf_amd import ops
+
+    dh = 256 // H
+    d = H * dh
+    L = Sk + 7
+    q = rnd(B, 1, d, seed=52)
+    kv = rnd(B, L, 2 * d, seed=53)
+    kv[:, Sk:] = float("nan")
+    kpm = None
+    if pad:
+        kpm = torch.zeros(B, Sk, dtype=torch.bool); kpm[0, Sk // 2:] = True; kpm[-1, 0] = True
+    ref = ref_attention(q, kv[:, :Sk, :d], kv[:, :Sk, d:], H, False, kpm, dh ** -0.5)
+    kp = kpm.to(torch.uint8).cuda() if pad else None
+    o, lse = ops.attention_fwd(q.cuda(), kv.cuda(), kv.cuda(), B, H, 1, Sk, dh, 0, 0, d, causal=False, kpm=kp, need_lse=False, kv_rows=L)
+    assert lse is None and bool(torch.isfinite(o).all())
+    assert float((o.cpu() - ref).abs().max()) < 2e-5
+    o2, _ = ops.attention_fwd(q.cuda(), kv.cuda(), kv.cuda(), B, H, 1, Sk, dh, 0, 0, d, causal=False, kpm=kp, need_lse=True, kv_rows=L)
+    assert float((o - o2).abs().max()) < 2e-5
+    if pad:
+        wide = torch.ones(B, Sk + 5, dtype=torch.uint8)
+        wide[:, :Sk] = kpm.to(torch.uint8)
+        o3, _ = ops.attention_fwd(q.cuda(), kv.cuda(), kv.cuda(), B, H, 1, Sk, dh, 0, 0, d, causal=False, kpm=wide.cuda(), need_lse=False, kv_rows=L, kpm_stride=Sk + 5)
+        assert torch.equal(o3, o)
+
+
 @pytest.mark.parametrize("B,pos,pad", [(3, 0, False), (5, 1, False), (6, 37, True), (9, 70, True), (4, 159, False)])
 def test_decode_attn_self_block(B, pos, pad):
     """ralf_decode_attn, self-attention form: LayerNorm + q/k/v projections + cache append + attention over pos+1 keys in one launch,

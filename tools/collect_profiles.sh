@@ -11,6 +11,7 @@ cp $O/train_step_mfma_pmc.txt profiles/${R}_train_step_mfma_pmc.txt
 cp $O/encoder_decoder_only_mfma_pmc.txt profiles/${R}_encoder_decoder_only_mfma_pmc.txt
 cp $O/${R}_mfma_busy.json profiles/${R}_mfma_busy.json
 cp $O/decode_kernel_stats.txt profiles/${R}_decode_kernel_stats.txt
+[ -f $O/decode_fp32_kernel_stats.txt ] && cp $O/decode_fp32_kernel_stats.txt profiles/${R}_decode_fp32_kernel_stats.txt
 cp $O/knn_kernel_stats.txt profiles/${R}_knn_kernel_stats.txt
 cp $O/knn_microbench.txt profiles/${R}_knn_microbench.txt
 cp $O/${R}_hbm_traffic.json profiles/${R}_hbm_traffic.json

@@ -1,4 +1,4 @@
-"""B = 256 constrained decode (task c, argmax) a few times -- for rocprofv3 timelines: python3 tools/decode_once.py [reps]"""
+"""B = 256 constrained decode (task c, argmax) a few times -- for rocprofv3 timelines: python3 tools/decode_once.py [reps] [bfloat16|float32]"""
 import os
 import sys
 
@@ -13,7 +13,8 @@ from ralf_amd.synthetic import make_batch  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 dev = torch.device("cuda", 0)
-model = bench.build_model(dev, 10, "bfloat16", "c").eval()
+dtype = sys.argv[2] if len(sys.argv) > 2 else "bfloat16"
+model = bench.build_model(dev, 10, dtype, "c").eval()
 cond, _ = get_condition(make_batch(256, 10, seed=9), "c", model.tokenizer)
 cond.retrieved = {k: v for k, v in cond.retrieved.items() if k != "image"}
 cfg = {"name": "deterministic"}

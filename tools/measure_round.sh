@@ -20,6 +20,7 @@ prof encoder_decoder_only 11 "# rocprofv3 --kernel-trace --stats -- python3 tool
 # single stream, graph replays only (the window after the idle second): kernel time per step re-derives the HIP-event figure of bench.py
 GAP=300 prof encoder_decoder_only_single_stream 8 "# rocprofv3 --kernel-trace --stats -- python3 tools/encdec_once.py 8 single (MI355X, $R; backbone replaced by a fixed feature sequence; ONE stream: no parallel graph branches, kernel durations not inflated by overlap)" python3 $ROOT/tools/encdec_once.py 8 single
 prof decode 5 "# rocprofv3 --kernel-trace --stats -- python3 tools/decode_once.py 3 (MI355X, $R; B = 256, task c, argmax; 4 replays of the captured loop + 2 eager warm-up passes in the trace)" python3 $ROOT/tools/decode_once.py 3
+prof decode_fp32 5 "# rocprofv3 --kernel-trace --stats -- python3 tools/decode_once.py 3 float32 (MI355X, $R; B = 256, task c, argmax, the fp32 parity mode; 4 replays of the captured loop + 2 eager warm-up passes in the trace)" python3 $ROOT/tools/decode_once.py 3 float32
 prof knn 1 "# rocprofv3 --kernel-trace --stats -- python3 tools/knn_once.py (MI355X, $R; 61548 x 1792 fp32, nq = 16: 20 scans + 10 whole calls, nq = 1024: 3 scans + 1 whole call)" python3 $ROOT/tools/knn_once.py
 # PMC passes (one counter per run; --kernel-trace only)
 PB="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-graph --skip-cpu --skip-knn --skip-split --skip-decode --skip-variants"
