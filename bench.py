@@ -298,7 +298,7 @@ def bench_convergence(device, N=10, B=64, steps=160, hw=128):
             "max_rel_gap_of_16_step_means": gap}
 
 
-def bench_relation(device, N=10, B=256, dtype="bfloat16"):
+def bench_relation(device, N=10, B=256, dtype="bfloat16", sharpen=None, lockstep=None):
     """BASELINE configs[4], relationship task at batch 256: sample(cond_type="relation") with back-tracking
     (retrieval_augmented_autoreg.py:336-507: a per-sample loop by construction -- a violated constraint rewinds THAT sample's
     prefix, and the draws come from one global `random` stream in sample order), the decoder step KV-cached on the device and
@@ -320,9 +320,19 @@ def bench_relation(device, N=10, B=256, dtype="bfloat16"):
     model = RALF(features={"label": LabelFeature(labels)}, tokenizer=tok, dataset_name="pku", max_seq_length=N, db_dataset=None, top_k=16,
                  retrieval_backbone="dreamsim", random_retrieval=False, saliency_k="None", auxilary_task="relation", compute_dtype=dtype,
                  relation_table=table, pretrained=False).to(device).eval()
+    if sharpen:
+        # a stand-in for a TRAINED model's confident logits (random-init logits sit around 0, so the reference's gate `logits < 0.3` fires at
+        # almost every step and every sample asks for a random back-track position right away): the head's LayerNorm outputs the ones vector
+        # and the vocabulary matrix is |w| * sharpen, i.e. every admissible token scores well above the gate and back-tracking is left to the
+        # relation constraints themselves
+        with torch.no_grad():
+            model.decoder.head[0].weight.zero_()
+            model.decoder.head[0].bias.fill_(1.0)
+            model.decoder.head[1].weight.abs_().mul_(sharpen)
     cond, _ = get_condition(batch, "relation", tok)
     cond.retrieved = {k: v for k, v in cond.retrieved.items() if k != "image"}
     cfg = {"name": "deterministic", "temperature": 1.0}
+    kw = {} if lockstep is None else {"lockstep": lockstep}
 
     def sub(c, n):
         import copy
@@ -333,10 +343,10 @@ def bench_relation(device, N=10, B=256, dtype="bfloat16"):
         if hasattr(c, "id"):
             c2.id = c.id[:n]
         return c2
-    model.sample(cond=sub(cond, 4), sampling_cfg=cfg, cond_type="relation", return_violation=True, use_backtrack=True)   # warm-up (graphs per position)
+    model.sample(cond=sub(cond, 4), sampling_cfg=cfg, cond_type="relation", return_violation=True, use_backtrack=True, **kw)   # warm-up (graphs per position)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res, vio = model.sample(cond=cond, sampling_cfg=cfg, cond_type="relation", return_violation=True, use_backtrack=True)
+    res, vio = model.sample(cond=cond, sampling_cfg=cfg, cond_type="relation", return_violation=True, use_backtrack=True, **kw)
     torch.cuda.synchronize()
     t = time.perf_counter() - t0
     assert res["label"].shape == (B, N)

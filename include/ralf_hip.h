@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 16
+#define RALF_ABI_VERSION 17
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -394,6 +394,9 @@ typedef struct RalfDecodeAttnDesc {
     int64_t x_rs, kv_bs, kv_rs, kpm_bs, o_rs;
     int B, H, d, Sk, self_;
     float scale, eps;
+    const int32_t* pos;   /* self_ only, may be NULL: int32 [B] on the device, the number of cached rows PER ELEMENT (then Sk = their upper bound):
+                           * the samples of a lock-step decode that rewind their prefixes independently (sample_relation's back-tracking,
+                           * retrieval_augmented_autoreg.py:432-460) */
 } RalfDecodeAttnDesc;
 int ralf_decode_attn(const RalfDecodeAttnDesc* d, void* stream);
 /* most keys (cached rows, + the new one when self_) ralf_decode_attn accepts: its scores live in LDS.  Callers with longer memories

@@ -1004,6 +1004,9 @@ __global__ __launch_bounds__(256) void attn_decode_self4_kernel(const RalfDecode
     const int chunk = lane & 7, slot = lane >> 3, head = chunk >> 2, sub = slot;
     const int b = b0 + wave;                 // this wave's batch element
     const bool live = b < d.B;
+    // keys already cached for THIS element: one count for the batch, or per element (d.pos: samples of a lock-step loop that rewind their
+    // prefixes independently -- the relation task's back-tracking) -- wave-uniform either way
+    const int Sk = d.pos ? d.pos[live ? b : d.B - 1] : d.Sk;
     // ---- weight rows of this wave: rows {wave*8 + sub, 32 + wave*8 + sub} of each of q, k, v ----
     bf16x8 w[3][2][4];
     float bias_r[3][2];
@@ -1024,7 +1027,7 @@ __global__ __launch_bounds__(256) void attn_decode_self4_kernel(const RalfDecode
     {
         const int bb = live ? b : d.B - 1;
         const bf16* KVr = (const bf16*)d.kv + (int64_t)bb * d.kv_bs + hp * 64 + chunk * 8;
-        const int last = d.Sk > 0 ? d.Sk - 1 : 0;
+        const int last = Sk > 0 ? Sk - 1 : 0;
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) {
             const int key = min(u * 8 + slot, last);
@@ -1081,8 +1084,8 @@ __global__ __launch_bounds__(256) void attn_decode_self4_kernel(const RalfDecode
     if (!live) return;
     // ---- from here on: one wave = one batch element, wave-local ----
     bf16* KV = (bf16*)d.kv + (int64_t)b * d.kv_bs + hp * 64;
-    KV[(int64_t)d.Sk * d.kv_rs + lane] = (bf16)qkv[wave][1][lane];            // the new token's k / v: row Sk of the cache
-    KV[(int64_t)d.Sk * d.kv_rs + D + lane] = (bf16)qkv[wave][2][lane];
+    KV[(int64_t)Sk * d.kv_rs + lane] = (bf16)qkv[wave][1][lane];            // the new token's k / v: row Sk of the cache
+    KV[(int64_t)Sk * d.kv_rs + D + lane] = (bf16)qkv[wave][2][lane];
     const bf16* Kp = KV + chunk * 8;
     const bf16* Vp = KV + D + chunk * 8;
     const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * d.kpm_bs : nullptr;
@@ -1099,13 +1102,13 @@ __global__ __launch_bounds__(256) void attn_decode_self4_kernel(const RalfDecode
         for (int i = 0; i < 8; ++i) s += qv[i] * (float)kpre[u][i];
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
-        if ((chunk & 3) == 0 && key < d.Sk) scw[key][head] = (kpm && kpm[key]) ? -__builtin_inff() : s;
+        if ((chunk & 3) == 0 && key < Sk) scw[key][head] = (kpm && kpm[key]) ? -__builtin_inff() : s;
     }
-    for (int key0 = NPRE * 8; key0 < d.Sk; key0 += 32) {
+    for (int key0 = NPRE * 8; key0 < Sk; key0 += 32) {
         bf16x8 kv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int key = min(key0 + u * 8 + slot, d.Sk - 1);
+            const int key = min(key0 + u * 8 + slot, Sk - 1);
             kv[u] = *reinterpret_cast<const bf16x8*>(Kp + (int64_t)key * d.kv_rs);
         }
 #pragma unroll
@@ -1116,7 +1119,7 @@ __global__ __launch_bounds__(256) void attn_decode_self4_kernel(const RalfDecode
             for (int i = 0; i < 8; ++i) s += qv[i] * (float)kv[u][i];
             s += __shfl_xor(s, 1);
             s += __shfl_xor(s, 2);
-            if ((chunk & 3) == 0 && key < d.Sk) scw[key][head] = (kpm && kpm[key]) ? -__builtin_inff() : s;
+            if ((chunk & 3) == 0 && key < Sk) scw[key][head] = (kpm && kpm[key]) ? -__builtin_inff() : s;
         }
     }
     if (lane < 8) {   // the new key (slot 0)
@@ -1125,10 +1128,10 @@ __global__ __launch_bounds__(256) void attn_decode_self4_kernel(const RalfDecode
         for (int i = 0; i < 8; ++i) s += qv[i] * qkv[wave][1][chunk * 8 + i];
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
-        if ((chunk & 3) == 0) scw[d.Sk][head] = (kpm && kpm[d.Sk]) ? -__builtin_inff() : s;
+        if ((chunk & 3) == 0) scw[Sk][head] = (kpm && kpm[Sk]) ? -__builtin_inff() : s;
     }
     __builtin_amdgcn_wave_barrier();   // (scores written by other lanes of this wave: LDS accesses of a wave complete in order)
-    const int nk = d.Sk + 1;
+    const int nk = Sk + 1;
     // softmax per head: lane parity = head, 32 lanes per head
     const int h2 = lane & 1;
     float m = -__builtin_inff();
@@ -1152,19 +1155,19 @@ __global__ __launch_bounds__(256) void attn_decode_self4_kernel(const RalfDecode
 #pragma unroll
     for (int u = 0; u < NPRE; ++u) {
         const int key = u * 8 + slot;
-        const bool in = key < d.Sk;          // (rows beyond the prefix may hold anything: select, never multiply by zero)
+        const bool in = key < Sk;          // (rows beyond the prefix may hold anything: select, never multiply by zero)
         const float p = in ? scw[key][head] : 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] += in ? p * (float)vpre[u][i] : 0.f;
     }
-    for (int key0 = NPRE * 8; key0 < d.Sk; key0 += 32) {
+    for (int key0 = NPRE * 8; key0 < Sk; key0 += 32) {
         bf16x8 vv[4];
         float p[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int key = key0 + u * 8 + slot, kc = min(key, d.Sk - 1);
+            const int key = key0 + u * 8 + slot, kc = min(key, Sk - 1);
             vv[u] = *reinterpret_cast<const bf16x8*>(Vp + (int64_t)kc * d.kv_rs);
-            p[u] = key < d.Sk ? scw[kc][head] : 0.f;
+            p[u] = key < Sk ? scw[kc][head] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -1180,7 +1183,7 @@ __global__ __launch_bounds__(256) void attn_decode_self4_kernel(const RalfDecode
     // lanes 0..7 (slot 0) hold the 64 sums: chunk c -> columns 8c .. 8c+7 (head = c >> 2)
     const float l0 = __shfl(l, 0), l1 = __shfl(l, 1);
     if (slot == 0) {
-        const float lsum = head ? l1 : l0, pn = scw[d.Sk][head];
+        const float lsum = head ? l1 : l0, pn = scw[Sk][head];
         bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (bf16)((acc[i] + pn * qkv[wave][2][chunk * 8 + i]) / lsum);
@@ -1234,6 +1237,7 @@ extern "C" int ralf_decode_attn(const RalfDecodeAttnDesc* dp, void* stream) {
                  "decode_attn: needs d = 256, H = 8 and at most %d keys (got d=%d H=%d Sk=%d)", DEC_MAXK, d.d, d.H, d.Sk);
     RALF_REQUIRE(d.kv_rs % 8 == 0 && d.kv_bs % 8 == 0 && ((uintptr_t)d.kv % 16) == 0 && ((uintptr_t)d.W % 16) == 0 && (!d.kpm || d.kpm_bs > 0),
                  "decode_attn: cache rows and weights must be 16-byte aligned; kpm needs its row stride");
+    RALF_REQUIRE(!d.pos || d.self_, "decode_attn: per-element positions belong to the self-attention block");
     hipStream_t st = (hipStream_t)stream;
     // self-attention (a few dozen keys): 4 batch elements share a workgroup's weight rows; cross-attention streams its K/V cache
     // from HBM and wants every workgroup it can get

@@ -431,15 +431,167 @@ class _GeneratorBase(nn.Module):
             self.graphs[pos].replay()
             return self.out[pos]
 
+    class _LockstepStep:
+        """ONE captured hipGraph for the decoder step of a whole batch whose elements sit at positions of their own (decoder_step's pos_vec):
+        token / position / key-padding buffers are static and filled from pinned host mirrors, the logits come back in one copy."""
+
+        def __init__(self, model, T, dev, B):
+            self.model, self.T, self.B = model, T, B
+            self.tok = torch.zeros(B, dtype=torch.long, device=dev)
+            self.pos = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.kpm = torch.ones(B, T, dtype=torch.uint8, device=dev)
+            self.tok_h, self.pos_h, self.kpm_h = (torch.empty_like(t, device="cpu").pin_memory() for t in (self.tok, self.pos, self.kpm))
+            self.tok_h.zero_(); self.pos_h.zero_(); self.kpm_h.fill_(1)
+            self.cache, self.graph, self.out, self.out_h = None, None, None, None
+
+        def bind(self, cache):
+            if self.cache is None:
+                self.cache = cache
+                return
+            for dst, src in zip(self.cache.cross_kv, cache.cross_kv):
+                dst.copy_(src)
+            for t in self.cache.self_kv:
+                t.zero_()
+            if self.cache.packed is not None and cache.packed is not None:   # (see _StepGraphs.bind)
+                for dl, sl in zip(self.cache.packed, cache.packed):
+                    for dst, src in zip(dl, sl):
+                        dst.copy_(src)
+
+        def __call__(self):
+            m = self.model
+            self.tok.copy_(self.tok_h, non_blocking=True)
+            self.pos.copy_(self.pos_h, non_blocking=True)
+            self.kpm.copy_(self.kpm_h, non_blocking=True)
+            if self.graph is None:
+                run = lambda: RN.decoder_step(m.decoder, self.tok, self.T - 1, self.cache, m.rt, self.kpm, kpm_stride=self.T, pos_vec=self.pos)  # noqa: E731
+                side = ops.own_stream("capture")
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    run()
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=ops.own_stream("capture"), capture_error_mode="thread_local"):
+                    self.out = run()
+                self.graph = g
+                self.out_h = torch.empty_like(self.out, device="cpu").pin_memory()
+            self.graph.replay()
+            self.out_h.copy_(self.out, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            return self.out_h
+
+    class _RelationState:
+        """one sample of sample_relation between two decoder steps (retrieval_augmented_autoreg.py:372-383: input_, REL_COUNT, reset_num, idx)"""
+        __slots__ = ("seq", "flagged", "back_flag", "n_back", "resets", "idx", "rel", "con", "cond_seq", "done")
+
+        def __init__(self, bos, rel, con, cond_seq):
+            self.seq = torch.full((1, 1), bos, dtype=torch.long)
+            self.flagged, self.back_flag, self.n_back, self.resets, self.idx = [], False, 0, 0, 0
+            self.rel, self.con, self.cond_seq, self.done = rel, con, cond_seq, False
+
+    def _relation_advance(self, st, logits, may_draw, env) -> bool:
+        """the body of the reference's `while` loop after the decoder call (retrieval_augmented_autoreg.py:394-460) for ONE sample: `logits`
+        fp32 [1, V] of the sample's current prefix (modified in place).  Returns False -- with the state untouched -- when the step needs a
+        draw from Python's `random` and may_draw is False (lock-step decoding: an earlier sample has not finished drawing yet); True otherwise."""
+        ids, T, token_mask_h, restrict, prob_gate, sampling_cfg = env
+        seq = st.seq
+        n_dec = seq.size(1) - 1
+        logits[:, ~token_mask_h[n_dec]] = NEG_INF
+        logits = restrict(n_dec + 1, st.cond_seq, logits, pad_id=ids["pad"], eos_id=ids["eos"], max_length=T)
+        raw = logits.clone()
+        mask, back_idx = st.con(seq, st.rel)
+        logits[:, mask] = NEG_INF
+        pruned_max = torch.where(logits < prob_gate, torch.full_like(logits, NEG_INF), logits).max()
+        if st.resets > 3:
+            logits, st.back_flag = raw, False
+        elif (not st.back_flag and bool(pruned_max == NEG_INF)) or bool(logits.max() == NEG_INF):
+            # (the reference appends idx to its flag list first and then asks whether it is there fewer than 3 times)
+            draw = not (back_idx is not None and st.flagged.count(st.idx) + 1 < 3)
+            if draw and not may_draw:
+                return False
+            st.flagged.append(st.idx)
+            st.back_flag = True
+            st.idx = random.randint(2, max(2, st.idx - 1)) if draw else back_idx
+            st.seq = seq[:, :st.idx]
+            st.n_back += 1
+            if st.n_back > 30:
+                st.flagged, st.back_flag, st.n_back = [], False, 0
+                st.resets += 1
+                st.seq = torch.full((1, 1), ids["bos"], dtype=torch.long)
+                st.idx = 0
+            return True
+        temperature = None
+        if st.back_flag:
+            st.back_flag, temperature = False, 1.5
+        nxt = sample_tokens(logits, sampling_cfg, temperature=temperature)
+        st.seq = torch.cat([seq, nxt], dim=1)
+        if int(nxt) == ids["eos"] or st.seq.size(1) == T + 1:
+            st.done = True
+        else:
+            st.idx += 1
+        return True
+
+    def _relation_lockstep(self, states, memory, env, dev, min_active):
+        """All samples step TOGETHER while enough of them can: one decoder launch chain per step for the whole batch (every element at its own
+        position), the masks and the control flow per sample on the host.  The reference's only cross-sample coupling is the global `random`
+        stream, consumed in sample order: a sample whose step needs a draw waits ("parks", its state untouched) until every earlier sample has
+        finished -- so the stream is consumed exactly as in the sequential loop and the tokens are the same.  Returns the batch cache (the
+        unfinished samples' prefixes live in it)."""
+        ids, T = env[0], env[1]
+        B = len(states)
+        pool = self.__dict__.setdefault("_relation_lockstep_steps", {})
+        key = (B, int(memory.shape[1]), str(dev))
+        if key not in pool:
+            while len(pool) >= 2:
+                pool.pop(next(iter(pool)))
+            pool[key] = self._LockstepStep(self, T, dev, B)
+        step = pool.pop(key)
+        pool[key] = step
+        step.bind(RN.decoder_init_cache(self.decoder, memory, self.rt, T))
+        step.kpm_h.fill_(1)
+        active = list(range(B))
+        first_open = 0                                   # lowest sample that has not finished: the only one allowed to draw
+        while len(active) >= min_active:
+            for b in active:
+                seq = states[b].seq
+                L = seq.size(1)
+                step.tok_h[b] = seq[0, L - 1]
+                step.pos_h[b] = L - 1
+                row = step.kpm_h[b]
+                row[:L] = (seq[0] == ids["pad"]).to(torch.uint8)
+                row[L:] = 1
+            logits = step()
+            still = []
+            for b in active:
+                while first_open < B and states[first_open].done:
+                    first_open += 1
+                st = states[b]
+                if not self._relation_advance(st, logits[b:b + 1].clone(), b == first_open, env):
+                    continue                             # parked: resumes in the sequential phase, after every earlier sample
+                if not st.done:
+                    still.append(b)
+            while first_open < B and states[first_open].done:
+                first_open += 1
+            if first_open < B and (not still or still[0] != first_open):
+                still.insert(0, first_open)              # a parked sample whose turn to draw has come steps with the others again
+            active = still
+        return step.cache
+
     @torch.no_grad()
     def sample_relation(self, cond, batch_size: Optional[int] = None, sampling_cfg=None, return_violation: bool = False,
-                        prob_gate: float = 0.3, RELATION_SIZE: int = 10, use_graph: bool = True, **kwargs):
+                        prob_gate: float = 0.3, RELATION_SIZE: int = 10, use_graph: bool = True, lockstep: Optional[bool] = None, **kwargs):
         """Relation-constrained decoding with back-tracking (retrieval_augmented_autoreg.py:336-507): per sample, every step
         masks the vocabulary by (token mask, forced label, relation constraints); when nothing admissible is left (or only
         logits below `prob_gate`), the prefix is cut back to the element the violated constraint refers to (random position
         after three failures at one step), the next draw uses temperature 1.5; > 30 back-tracks restart the sample and after
         the 4th restart the relation mask is dropped.  Same control flow and `random` consumption as the reference; the
-        decoder runs KV-cached on the device (a cut prefix just rewinds the cache position)."""
+        decoder runs KV-cached on the device (a cut prefix just rewinds the cache position).
+        lockstep (opt-in; RALF_RELATION_LOCKSTEP=1 makes it the default for argmax decoding of >= 8 samples): the samples step together,
+        one batched decoder step per token, until they need `random` (_relation_lockstep); what is left runs sample by sample as the
+        reference does.  Tokens are identical either way (tests/test_configs_gpu.py).  Off by default because it does not pay on any input
+        available here: the constraint sequence lists the labels in SHUFFLED order while the forced label of a step follows the layout's own
+        order (both as in the reference), so the first step of most samples admits no token at all, and with no element to go back to the
+        reference draws the position from `random` -- 220 of 260 synthetic samples ask for a draw at their first step
+        (tools/relation_probe.py) and the loop is sequential from there: 126.3 against 126.7 ms per sample."""
         from ..helpers.relation_restriction import RelationConstraint
 
         self.preprocessor.set_relation_size(RELATION_SIZE)
@@ -455,13 +607,19 @@ class _GeneratorBase(nn.Module):
                    for k, v in enc_in.items()}
         self.rt.to(dev).begin_step()
         memory = self._encode_into_memory(enc_dev)["memory"]
-        constraint = RelationConstraint(self.preprocessor)
-        restrict = DECODE_SPACE_RESTRICTION["relation"]
         cond_seq = cond.seq.cpu()
-        token_mask_h = self.tokenizer.token_mask.cpu()
-        rows, prepared = [], []
+        env = (ids, T, self.tokenizer.token_mask.cpu(), DECODE_SPACE_RESTRICTION["relation"], prob_gate, sampling_cfg)
+        if lockstep is None:
+            # a stochastic draw consumes torch's generator at every step, in sample order: only argmax decoding leaves `random` as the one
+            # shared stream, which the lock-step loop consumes in the reference's order
+            lockstep = (os.environ.get("RALF_RELATION_LOCKSTEP", "0") == "1" and B >= 8 and dev.type == "cuda" and _get(sampling_cfg, "name") == "deterministic")
+        states = []
+        for b in range(B):   # (a constraint object keeps the decode history of ITS sample)
+            con = RelationConstraint(self.preprocessor)
+            states.append(self._RelationState(ids["bos"], con.prepare(seqc["seq"][b].cpu()), con, cond_seq[b:b + 1]))
+        batch_cache = self._relation_lockstep(states, memory, env, dev, max(2, B // 32)) if lockstep else None
         stepper = None
-        if use_graph:
+        if use_graph and not all(st.done for st in states):
             # the captured steps hold the cross-attention cache of ONE memory length (2 h w + K + Lc, and Lc is padded per batch):
             # one set of graphs per length, the few most recent kept
             pool = self.__dict__.setdefault("_relation_steppers", {})
@@ -474,53 +632,28 @@ class _GeneratorBase(nn.Module):
             pool[key] = stepper
         # the sequence, the masks and the draw live on the HOST (518 logits per step come back in one copy): the reference's
         # control flow is host logic anyway, and a dozen tiny device ops + three syncs per step cost more than the decoder step
-        for b in range(B):
-            cache = RN.decoder_init_cache(self.decoder, memory[b:b + 1].contiguous(), self.rt, T)
-            if stepper is not None:
-                stepper.bind(cache)
-            rel = constraint.prepare(seqc["seq"][b].cpu())
-            seq = torch.full((1, 1), ids["bos"], dtype=torch.long)
-            flagged, back_flag, n_back, resets, idx = [], False, 0, 0, 0
-            while True:
+        rows = []
+        for b, st in enumerate(states):
+            if not st.done:
+                cache = RN.decoder_init_cache(self.decoder, memory[b:b + 1].contiguous(), self.rt, T)
+                if stepper is not None:
+                    stepper.bind(cache)
+                    cache = stepper.cache
+                if batch_cache is not None:       # the prefix decoded in lock-step: its keys / values are rows of the batch cache
+                    for dst, src in zip(cache.self_kv, batch_cache.self_kv):
+                        dst.copy_(src[b:b + 1])
+            while not st.done:
+                seq = st.seq
                 L = seq.size(1)
                 kpm = (seq == ids["pad"]).to(torch.uint8)
                 if stepper is not None:
                     logits = stepper(seq[:, L - 1].to(dev), L - 1, kpm.to(dev)).float().cpu()
                 else:
                     logits = RN.decoder_step(self.decoder, seq[:, L - 1].to(dev).contiguous(), L - 1, cache, self.rt, kpm.to(dev).contiguous()).float().cpu()
-                n_dec = L - 1
-                logits[:, ~token_mask_h[n_dec]] = NEG_INF
-                logits = restrict(n_dec + 1, cond_seq[b:b + 1], logits, pad_id=ids["pad"], eos_id=ids["eos"], max_length=T)
-                raw = logits.clone()
-                mask, back_idx = constraint(seq, rel)
-                logits[:, mask] = NEG_INF
-                pruned_max = torch.where(logits < prob_gate, torch.full_like(logits, NEG_INF), logits).max()
-                if resets > 3:
-                    logits, back_flag = raw, False
-                elif (not back_flag and bool(pruned_max == NEG_INF)) or bool(logits.max() == NEG_INF):
-                    flagged.append(idx)
-                    back_flag = True
-                    idx = back_idx if (back_idx is not None and flagged.count(idx) < 3) else random.randint(2, max(2, idx - 1))
-                    seq = seq[:, :idx]
-                    n_back += 1
-                    if n_back > 30:
-                        flagged, back_flag, n_back = [], False, 0
-                        resets += 1
-                        seq = torch.full((1, 1), ids["bos"], dtype=torch.long)
-                        idx = 0
-                    continue
-                temperature = None
-                if back_flag:
-                    back_flag, temperature = False, 1.5
-                nxt = sample_tokens(logits, sampling_cfg, temperature=temperature)
-                seq = torch.cat([seq, nxt], dim=1)
-                if int(nxt) == ids["eos"] or seq.size(1) == T + 1:
-                    break
-                idx += 1
+                self._relation_advance(st, logits, True, env)
             # (sic) finished sequences are padded with the literal True (= token 1), retrieval_augmented_autoreg.py:475-483
-            seq = torch.cat([seq, torch.full((1, T + 2 - seq.size(1)), 1, dtype=torch.long)], dim=1)
-            rows.append(seq)
-            prepared.append(rel)
+            rows.append(torch.cat([st.seq, torch.full((1, T + 2 - st.seq.size(1)), 1, dtype=torch.long)], dim=1))
+        prepared = [st.rel for st in states]
         tokens = torch.cat(rows, dim=0)[:, 1:-1]
         result = self.postprocess({"seq": tokens})
         if not return_violation:

@@ -340,28 +340,42 @@ def decoder_init_cache(dec: "BaseDecoder", memory: torch.Tensor, rt: Runtime, ma
 
 @torch.no_grad()
 def decoder_step(dec: "BaseDecoder", tok: torch.Tensor, pos: int, cache: DecodeCache, rt: Runtime, kpm_prefix: torch.Tensor,
-                 kpm_stride: Optional[int] = None) -> torch.Tensor:
+                 kpm_stride: Optional[int] = None, pos_vec: Optional[torch.Tensor] = None) -> torch.Tensor:
     """one KV-cached decode step: token ids [B] at position `pos` -> fp32 logits [B, V].  kpm_prefix uint8
     [B, pos+1] marks padded prefix tokens (tgt_key_padding_mask of the reference's full-prefix call,
     retrieval_augmented_autoreg.py:274-279); with `kpm_stride` it is the [B, kpm_stride] mask buffer of the whole loop, of
-    which the first pos+1 columns are read.  Same arithmetic as BaseDecoder.forward restricted to the last row."""
+    which the first pos+1 columns are read.  Same arithmetic as BaseDecoder.forward restricted to the last row.
+    pos_vec (int32 [B] on the device; fused bf16 path only): every element sits at ITS OWN position pos_vec[b] <= pos -- the samples of
+    sample_relation rewind their prefixes independently (retrieval_augmented_autoreg.py:432-460) and still step together."""
     B = tok.shape[0]
     d, H = dec.d_model, dec.transformer.layers[0].self_attn.nhead
     dh = d // H
-    x = ops.embed_fwd(tok.view(B, 1).contiguous(), dec.emb.weight.detach(), dec.pos_emb.pe[0, pos:pos + 1].contiguous(), 1, math.sqrt(d), rt.dtype).view(B, d)
+    if pos_vec is None:
+        x = ops.embed_fwd(tok.view(B, 1).contiguous(), dec.emb.weight.detach(), dec.pos_emb.pe[0, pos:pos + 1].contiguous(), 1, math.sqrt(d), rt.dtype).view(B, d)
+    else:   # the batch as ONE sequence whose positional rows are gathered per element: the same kernel, the same arithmetic
+        pe = dec.pos_emb.pe[0].index_select(0, pos_vec.long())
+        x = ops.embed_fwd(tok.view(1, B).contiguous(), dec.emb.weight.detach(), pe, B, math.sqrt(d), rt.dtype).view(B, d)
     L = cache.max_len
     # bf16, d = 256, 8 heads: LayerNorm + q / k / v projections + attention of each block in ONE launch (ralf_decode_attn)
     # (the fused kernel keeps the scores of at most ops.decode_attn_max_keys() keys in LDS; longer memories, e.g. 512x512 canvases, take
     #  the per-kernel path below)
     fused = (rt.fused_decode and rt.dtype == torch.bfloat16 and d == 256 and H == 8 and x.stride(1) == 1
              and cache.cross_kv[0].shape[1] <= ops.decode_attn_max_keys() and pos + 1 <= ops.decode_attn_max_keys())
+    # per-element positions on the per-kernel path (the fp32 parity mode): the new k / v rows are scattered to row pos_vec[b] of each element's
+    # cache and the attention runs over ALL L cache rows with the keys beyond an element's prefix masked by `kpm_prefix` (the caller's
+    # [B, kpm_stride] buffer: row b = the padding flags of its prefix, 1 from pos_vec[b] + 1 on) -- masked keys contribute exact zeros, so the
+    # result equals the Sk = pos + 1 call bit for bit (tests/test_model_gpu.py)
+    rowidx = None
+    if pos_vec is not None and not fused:
+        assert kpm_stride is not None and kpm_stride >= L, "per-element positions: the key-padding buffer must cover every cache row"
+        rowidx = torch.arange(B, device=tok.device) * L + pos_vec.long()
     for li, layer in enumerate(dec.transformer.layers):
         sa, ca = layer.self_attn, layer.multihead_attn
         skv, ckv = cache.self_kv[li], cache.cross_kv[li]
         if fused:
             kst = kpm_stride if kpm_stride else kpm_prefix.shape[1]
             o = ops.decode_attn(x, layer.norm1.weight.detach(), layer.norm1.bias.detach(), rt.lp(sa.in_proj_weight), sa.in_proj_bias.detach(),
-                                skv, pos, H, True, kpm=kpm_prefix, kpm_stride=kst)
+                                skv, pos, H, True, kpm=kpm_prefix, kpm_stride=kst, pos=pos_vec)
             x = ops.gemm(o, rt.lp(sa.out_proj.weight), B, d, d, bias=sa.out_proj.bias.detach(), res=x)
             o = ops.decode_attn(x, layer.norm2.weight.detach(), layer.norm2.bias.detach(), rt.lp(ca.in_proj_weight), ca.in_proj_bias.detach(),
                                 ckv, ckv.shape[1], H, False)
@@ -375,9 +389,13 @@ def decoder_step(dec: "BaseDecoder", tok: torch.Tensor, pos: int, cache: DecodeC
             h, _, _ = ops.layernorm_fwd(x, layer.norm1.weight.detach(), layer.norm1.bias.detach(), save_stats=False)
             W, bvec = rt.lp(sa.in_proj_weight), sa.in_proj_bias.detach()
             q = ops.gemm(h, W[:d], B, d, d, bias=bvec[:d])
-            # k,v of the new token go straight into row `pos` of the cache (row stride = L*2d)
-            ops.gemm(h, W[d:], B, 2 * d, d, bias=bvec[d:], out=skv.view(B, L * 2 * d)[:, pos * 2 * d:], ldc=L * 2 * d)
-            o, _ = ops.attention_fwd(q.view(B, 1, d), skv, skv, B, H, 1, pos + 1, dh, 0, 0, d, causal=False, kpm=kpm_prefix, need_lse=False, kv_rows=L, kpm_stride=kpm_stride)
+            if rowidx is None:
+                # k,v of the new token go straight into row `pos` of the cache (row stride = L*2d)
+                ops.gemm(h, W[d:], B, 2 * d, d, bias=bvec[d:], out=skv.view(B, L * 2 * d)[:, pos * 2 * d:], ldc=L * 2 * d)
+                o, _ = ops.attention_fwd(q.view(B, 1, d), skv, skv, B, H, 1, pos + 1, dh, 0, 0, d, causal=False, kpm=kpm_prefix, need_lse=False, kv_rows=L, kpm_stride=kpm_stride)
+            else:
+                skv.view(B * L, 2 * d).index_copy_(0, rowidx, ops.gemm(h, W[d:], B, 2 * d, d, bias=bvec[d:]))
+                o, _ = ops.attention_fwd(q.view(B, 1, d), skv, skv, B, H, 1, L, dh, 0, 0, d, causal=False, kpm=kpm_prefix, need_lse=False, kv_rows=L, kpm_stride=kpm_stride)
             x = ops.gemm(o.view(B, d), rt.lp(sa.out_proj.weight), B, d, d, bias=sa.out_proj.bias.detach(), res=x)
             h, _, _ = ops.layernorm_fwd(x, layer.norm2.weight.detach(), layer.norm2.bias.detach(), save_stats=False)
             q = ops.gemm(h, rt.lp(ca.in_proj_weight)[:d], B, d, d, bias=ca.in_proj_bias.detach()[:d])

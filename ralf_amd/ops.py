@@ -896,9 +896,10 @@ def decode_attn_max_keys() -> int:
     return _DEC_MAXK
 
 
-def decode_attn(x, ln_g, ln_b, W, bias, kv, Sk, H, self_attn, kpm=None, kpm_stride=0, eps=1e-5):
+def decode_attn(x, ln_g, ln_b, W, bias, kv, Sk, H, self_attn, kpm=None, kpm_stride=0, eps=1e-5, pos=None):
     """one attention block of a KV-cached decode step with LayerNorm and the q (k, v) projections inside (ralf_decode_attn):
-    x [B, d] bf16, W bf16 [3d, d] (in_proj_weight), bias fp32 [3d], kv bf16 cache [B, rows, 2d] -> o [B, d]."""
+    x [B, d] bf16, W bf16 [3d, d] (in_proj_weight), bias fp32 [3d], kv bf16 cache [B, rows, 2d] -> o [B, d].
+    pos (self-attention only): int32 [B] on the device, the cached rows PER ELEMENT (Sk is then their upper bound)."""
     from ._abi import RalfDecodeAttnDesc
 
     B, d_model = x.shape
@@ -909,6 +910,9 @@ def decode_attn(x, ln_g, ln_b, W, bias, kv, Sk, H, self_attn, kpm=None, kpm_stri
     d.x_rs, d.kv_bs, d.kv_rs, d.kpm_bs, d.o_rs = x.stride(0), kv.stride(0), kv.stride(1), int(kpm_stride), d_model
     d.B, d.H, d.d, d.Sk, d.self_ = B, H, d_model, int(Sk), int(bool(self_attn))
     d.scale, d.eps = (d_model // H) ** -0.5, eps
+    if pos is not None:
+        assert self_attn and pos.dtype == torch.int32 and pos.is_contiguous() and pos.numel() == B and pos.device == x.device
+    d.pos = _p(pos)
     _call("ralf_decode_attn", ctypes.byref(d))
     return o
 

@@ -153,6 +153,13 @@ def test_relation_b256_rows_equal_reference_rows(golden):
     finally:
         random.randint = real_randint
     print(f"relation decode with back-tracking, B = {B}: {dt * 1e3 / B:.2f} ms per sample, {draws[0]} random back-track draws")
+    # the lock-step form (one batched decoder step for all samples, every element at its own position; a sample that needs `random` waits for
+    # the samples before it): the same stream consumption, so ALL 256 rows equal the sequential loop's
+    random.setstate(state)
+    out_l = model.sample(cond=cond, sampling_cfg={"name": "deterministic", "temperature": 1.0}, cond_type="relation", return_violation=False,
+                         use_backtrack=True, RELATION_SIZE=30, lockstep=True)
+    for k in ("label", "mask", "center_x", "center_y", "width", "height"):
+        assert torch.equal(out_l[k], out[k]), ("lockstep", k)
     rows = B if draws[0] == 0 else n0
     for k in ("label", "mask", "center_x", "center_y", "width", "height"):
         assert out[k].shape[0] == B

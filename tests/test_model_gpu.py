@@ -421,6 +421,49 @@ def test_fused_decode_attention_equals_separate_kernels_bf16(golden, task):
     assert agree >= 0.97 * B * T, (agree, B * T)
 
 
+@pytest.mark.parametrize("dtype", ["bfloat16", "float32"])
+def test_decode_step_with_per_element_positions(golden, dtype):
+    """RalfDecodeAttnDesc.pos / decoder_step(pos_vec=...): after a teacher-forced decode of the whole sequence, every element re-steps a
+    position of ITS OWN (its prefix rows are still in the cache, row pos is rewritten with the same values): the logits are bit-identical
+    to the ones the all-at-one-position step produced there -- the lock-step form of sample_relation's per-sample rewinds.  bf16: the fused
+    block kernel with per-element key counts; fp32 (parity mode): scattered k / v rows + the keys beyond each prefix masked."""
+    r = golden("sample.npz").sub("c")
+    model = load_det(build(task="c", compute_dtype=dtype), "ralf_state_shapes.json").eval()
+    model.encoder = FeatStandIn(r["feat"].cuda())
+    rt, dec = model.rt, model.decoder
+    dev = torch.device("cuda")
+    enc_in = {"image": torch.zeros(r["feat"].shape[0], 4, 8, 8, device=dev), "retrieved": to_dev(dict(r["retrieved"])),
+              "seq_layout_const": r["seq_layout_const"].cuda(), "seq_layout_const_pad_mask": r["seq_layout_const_pad_mask"].cuda()}
+    with torch.no_grad():
+        rt.to(dev).begin_step()
+        memory = model._encode_into_memory(enc_in)["memory"]
+        B, T = memory.shape[0], model.tokenizer.max_token_length
+        ids = model.special_token_ids
+        cache = RN.decoder_init_cache(dec, memory, rt, T)
+        seq = torch.full((B, 1), ids["bos"], dtype=torch.long, device=dev)
+        model._token_mask_dev(dev)
+        kbuf = torch.zeros(B, T, dtype=torch.uint8, device=dev)
+        kbuf[0, 3] = 1                                  # a masked key inside the prefixes that reach it
+        logits = []
+        for i in range(T):
+            out = RN.decoder_step(dec, seq[:, i].contiguous(), i, cache, rt, kbuf, kpm_stride=T).float()
+            logits.append(out)
+            nxt = RN.ops.mask_sample(out, model._token_mask_u8[i], None, 0, 1, 1.0, rt.seed, 1000 + i)
+            seq = torch.cat([seq, nxt.view(B, 1)], dim=1)
+        g = torch.Generator().manual_seed(3)
+        for trial in range(3):
+            pos = torch.randint(0, T, (B,), generator=g)
+            if trial == 0:
+                pos[0], pos[-1] = 0, T - 1
+            tok = seq[torch.arange(B), pos.to(dev)].contiguous()
+            kb = kbuf.clone()
+            for b in range(B):
+                kb[b, int(pos[b]) + 1:] = 1              # keys beyond an element's prefix (stale rows of the longer decode)
+            out = RN.decoder_step(dec, tok, int(pos.max()), cache, rt, kb, kpm_stride=T, pos_vec=pos.to(torch.int32).to(dev)).float()
+            want = torch.stack([logits[int(pos[b])][b] for b in range(B)])
+            assert torch.equal(out, want), trial
+
+
 def test_train_mode_dropout_step_is_finite_and_seeded(golden):
     r = golden("e2e.npz").sub("ralf_uncond")
     model = load_det(build(task="uncond", compute_dtype="bfloat16"), "ralf_state_shapes.json").train()

@@ -1,6 +1,6 @@
 """Where the relation decode's time goes (bench_relation's workload at a smaller batch): decoder steps per sample, device step
 (graph replay + the logits' way back) against the host-side masks, and how early a sample needs its first `random` draw.
-    python tools/relation_probe.py [B]"""
+    python tools/relation_probe.py [B] [head scale] [lockstep 0|1]"""
 import os
 import random
 import sys
@@ -17,6 +17,8 @@ from ralf_amd.models import ralf as M  # noqa: E402
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    sharpen = float(sys.argv[2]) if len(sys.argv) > 2 else None
+    lockstep = {"1": True, "0": False}.get(sys.argv[3]) if len(sys.argv) > 3 else None
     dev = torch.device("cuda:0")
     acc = {"step_s": 0.0, "steps": 0, "con_s": 0.0, "draws": 0, "first_draw_step": []}
     SG = M._GeneratorBase._StepGraphs
@@ -54,10 +56,10 @@ def main():
         return ri0(a, b)
     random.randint = ri
     t0 = time.perf_counter()
-    out = bench.bench_relation(dev, 10, B)
+    out = bench.bench_relation(dev, 10, B, sharpen=sharpen, lockstep=lockstep)
     wall = time.perf_counter() - t0
     n = max(acc["steps"], 1)
-    print(f"B={B}: {out['ms_per_sample']:.1f} ms per sample; {acc['steps']} decoder steps incl. warm-up ({acc['steps'] / (B + 4):.0f} per sample)")
+    print(f"B={B} sharpen={sharpen} lockstep={lockstep}: {out['ms_per_sample']:.2f} ms per sample, violated {out['relations_violated']} of {out['relations_checked']}; {acc['steps']} decoder steps incl. warm-up ({acc['steps'] / (B + 4):.0f} per sample)")
     print(f"device step + logits to the host: {acc['step_s'] / n * 1e6:.0f} us per step ({acc['step_s']:.2f} s); relation masks: {acc['con_s'] / n * 1e6:.0f} us per step "
           f"({acc['con_s']:.2f} s); wall {wall:.2f} s incl. model build")
     fd = sorted(acc["first_draw_step"])
