@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 17
+#define RALF_ABI_VERSION 18
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -394,6 +394,10 @@ typedef struct RalfDecodeAttnDesc {
     int64_t x_rs, kv_bs, kv_rs, kpm_bs, o_rs;
     int B, H, d, Sk, self_;
     float scale, eps;
+    int64_t kv_hs, kv_vo; /* cross-attention only; 0, 0 = the [B, rows, 2d] cache above.  Head-pair-major cache (e.g. [B, 2, H/2, rows, 64], written by
+                           * a batched ralf_gemm over the 8 column slices of the k | v projection): the keys of head pair hp of element b start at
+                           * kv + b*kv_bs + hp*kv_hs, rows kv_rs (= 64) apart, its values kv_vo elements behind them -- a workgroup streams two
+                           * contiguous blocks instead of 128-byte pieces 1 KB apart */
     const int32_t* pos;   /* self_ only, may be NULL: int32 [B] on the device, the number of cached rows PER ELEMENT (then Sk = their upper bound):
                            * the samples of a lock-step decode that rewind their prefixes independently (sample_relation's back-tracking,
                            * retrieval_augmented_autoreg.py:432-460) */

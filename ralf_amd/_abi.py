@@ -27,7 +27,7 @@ class RalfConvGeom(ctypes.Structure):
 class RalfDecodeAttnDesc(ctypes.Structure):
     _fields_ = ([(n, vp) for n in ("x", "ln_g", "ln_b", "W", "bias", "kv", "kpm", "o")]
                 + [(n, i64) for n in ("x_rs", "kv_bs", "kv_rs", "kpm_bs", "o_rs")]
-                + [(n, i32) for n in ("B", "H", "d", "Sk", "self_")] + [("scale", f32), ("eps", f32), ("pos", vp)])
+                + [(n, i32) for n in ("B", "H", "d", "Sk", "self_")] + [("scale", f32), ("eps", f32), ("kv_hs", i64), ("kv_vo", i64), ("pos", vp)])
 
 
 class RalfTLayerDesc(ctypes.Structure):

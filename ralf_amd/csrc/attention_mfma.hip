@@ -827,6 +827,15 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const RalfDecode
     //      8 rows per wave-load.  (NS batch elements share them: with one element per workgroup the 1024 workgroups pulled
     //      100 MB of the same 384 KB through the L2 per call and the self-attention block took 21 us.)
     const int sub = lane >> 3;
+    // cross-attention (one element per workgroup): the first 128 cached keys start their way BEFORE the weights, the LayerNorm and the
+    // projection (all 1024 workgroups of a launch run that prologue at the same time, with nothing in flight from the K / V stream)
+    constexpr bool PRE = !SELF && NS == 1;
+    bf16x8 kpre[4];
+    if (PRE) {
+        const bf16* Kp0 = (const bf16*)d.kv + (int64_t)min(b0, d.B - 1) * d.kv_bs + (int64_t)hp * (d.kv_hs ? d.kv_hs : 64) + chunk * 8;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kpre[u] = *reinterpret_cast<const bf16x8*>(Kp0 + (int64_t)min(wave * 8 + u * 32 + slot, d.Sk - 1) * d.kv_rs);
+    }
     bf16x8 w[NP][2][4];
     float bias_r[NP][2];
 #pragma unroll
@@ -885,13 +894,14 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const RalfDecode
             }
     }
     __syncthreads();
-    bf16* KV = (bf16*)d.kv + (int64_t)b * d.kv_bs + hp * 64;
+    bf16* KV = (bf16*)d.kv + (int64_t)b * d.kv_bs + (int64_t)hp * (d.kv_hs ? d.kv_hs : 64);
+    const int64_t v_off = d.kv_hs ? d.kv_vo : D;   // head-pair-major cache: this pair's values follow its keys
     if (SELF && tid < 128) {   // the new token's k / v: row Sk of the cache (k at column 0, v at column d)
         const int which = tid >> 6, c = tid & 63;
         KV[(int64_t)d.Sk * d.kv_rs + which * D + c] = (bf16)qkv[1 + which][c];
     }
     const bf16* Kp = KV + chunk * 8;
-    const bf16* Vp = KV + D + chunk * 8;
+    const bf16* Vp = KV + v_off + chunk * 8;
     const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * d.kpm_bs : nullptr;
     float qv[8];
 #pragma unroll
@@ -901,10 +911,15 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const RalfDecode
     if (d.Sk > 0) {
         for (int key0 = wave * 8; key0 < d.Sk; key0 += 32 * 4) {
             bf16x8 kv[4];
+            if (PRE && key0 == wave * 8) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int key = min(key0 + u * 32 + slot, d.Sk - 1);
-                kv[u] = *reinterpret_cast<const bf16x8*>(Kp + (int64_t)key * d.kv_rs);
+                for (int u = 0; u < 4; ++u) kv[u] = kpre[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int key = min(key0 + u * 32 + slot, d.Sk - 1);
+                    kv[u] = *reinterpret_cast<const bf16x8*>(Kp + (int64_t)key * d.kv_rs);
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -925,6 +940,12 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const RalfDecode
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         if ((chunk & 3) == 0) sc[d.Sk][head] = (kpm && kpm[d.Sk]) ? -__builtin_inff() : s;
+    }
+    // (cross-attention) the first 128 values start their way before the softmax: they do not depend on it
+    bf16x8 vpre[4];
+    if (PRE) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vpre[u] = *reinterpret_cast<const bf16x8*>(Vp + (int64_t)min(wave * 8 + u * 32 + slot, d.Sk - 1) * d.kv_rs);
     }
     __syncthreads();
     // ---- softmax over the keys, per head (thread parity = head) ----
@@ -958,7 +979,8 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const RalfDecode
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int key = key0 + u * 32 + slot, kc = min(key, d.Sk - 1);
-                vv[u] = *reinterpret_cast<const bf16x8*>(Vp + (int64_t)kc * d.kv_rs);
+                if (PRE && key0 == wave * 8) vv[u] = vpre[u];
+                else vv[u] = *reinterpret_cast<const bf16x8*>(Vp + (int64_t)kc * d.kv_rs);
                 p[u] = key < d.Sk ? sc[kc][head] : 0.f;
             }
 #pragma unroll
@@ -1238,6 +1260,7 @@ extern "C" int ralf_decode_attn(const RalfDecodeAttnDesc* dp, void* stream) {
     RALF_REQUIRE(d.kv_rs % 8 == 0 && d.kv_bs % 8 == 0 && ((uintptr_t)d.kv % 16) == 0 && ((uintptr_t)d.W % 16) == 0 && (!d.kpm || d.kpm_bs > 0),
                  "decode_attn: cache rows and weights must be 16-byte aligned; kpm needs its row stride");
     RALF_REQUIRE(!d.pos || d.self_, "decode_attn: per-element positions belong to the self-attention block");
+    RALF_REQUIRE(!d.kv_hs || (!d.self_ && d.kv_hs % 8 == 0 && d.kv_vo % 8 == 0), "decode_attn: the head-pair-major cache layout belongs to the cross-attention block (16-byte aligned strides)");
     hipStream_t st = (hipStream_t)stream;
     // self-attention (a few dozen keys): 4 batch elements share a workgroup's weight rows; cross-attention streams its K/V cache
     // from HBM and wants every workgroup it can get

@@ -11,6 +11,7 @@ shapes as the torch modules the reference instantiates (checkpoints load with st
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -309,13 +310,21 @@ class BaseDecoder(nn.Module):
         return RF.linear(h, self.head[1].weight, rt=rt, out_f32=True)
 
 
+_DECODE_KV_PACKED = os.environ.get("RALF_DECODE_KV_PACKED", "1") != "0"   # A/B runs: 0 keeps the row-major cross-attention cache
+
+
 class DecodeCache:
     """per-layer state of the KV-cached decoder: cross-attention K/V of the fixed memory (computed once) and the
     growing self-attention K/V of the generated prefix."""
 
-    def __init__(self, cross_kv, self_kv, max_len, packed=None):
+    def __init__(self, cross_kv, self_kv, max_len, packed=None, cross_rows=None, cross_packed=False):
         self.cross_kv, self.self_kv, self.max_len = cross_kv, self_kv, max_len
         self.packed = packed   # per layer: (cross out_proj, linear1, linear2) in fragment order (ops.tlayer_pack), or None
+        # cross_packed: cross_kv[l] is [B, 2 (k | v), H / 2 head pairs, rows, 64] instead of [B, rows, 2 d]: the fused decode block's workgroup
+        # (element, head pair) then streams two CONTIGUOUS 68 KB blocks instead of 128-byte pieces 1 KB apart (26.6 against 29.6 us per call
+        # at B = 256 over 532 rows: 5.24 against 4.70 TB/s, tools/decode_attn_bench.py)
+        self.cross_rows = cross_rows if cross_rows is not None else cross_kv[0].shape[1]
+        self.cross_packed = cross_packed
 
 
 @torch.no_grad()
@@ -323,10 +332,20 @@ def decoder_init_cache(dec: "BaseDecoder", memory: torch.Tensor, rt: Runtime, ma
     B, M, d = memory.shape
     cross, selfkv = [], []
     mem2 = memory.reshape(B * M, d).contiguous()
+    H = dec.transformer.layers[0].self_attn.nhead
+    # the fused decode block's conditions (decoder_step): then the projection writes the head-pair-major layout itself -- 8 column slices
+    # (k | v x head pair) x B elements as ONE batched product, slice j = 4 kv + hp of element b at [b, j, :, :]
+    pack = (_DECODE_KV_PACKED and rt.fused_decode and rt.dtype == torch.bfloat16 and memory.is_cuda and d == 256 and H == 8 and M <= ops.decode_attn_max_keys())
     for layer in dec.transformer.layers:
         a = layer.multihead_attn
-        kv = ops.gemm(mem2, rt.lp(a.in_proj_weight)[d:], B * M, 2 * d, d, bias=a.in_proj_bias.detach()[d:])
-        cross.append(kv.view(B, M, 2 * d))
+        if pack:
+            kv = torch.empty(B, 8, M, 64, dtype=rt.dtype, device=memory.device)
+            ops.gemm(mem2, rt.lp(a.in_proj_weight)[d:], M, 64, d, bias=a.in_proj_bias.detach()[d:], batch=(8, B), sA=(0, M * d), sB=(64 * d, 0),
+                     sC=(M * 64, 8 * M * 64), sBias0=64, out=kv)
+            cross.append(kv)
+        else:
+            kv = ops.gemm(mem2, rt.lp(a.in_proj_weight)[d:], B * M, 2 * d, d, bias=a.in_proj_bias.detach()[d:])
+            cross.append(kv.view(B, M, 2 * d))
         selfkv.append(torch.zeros(B, max_len, 2 * d, dtype=rt.dtype, device=memory.device))
     packed = None
     layers = list(dec.transformer.layers)
@@ -335,7 +354,7 @@ def decoder_init_cache(dec: "BaseDecoder", memory: torch.Tensor, rt: Runtime, ma
         # the step's tail per layer (out-projection + residual, LayerNorm, feed-forward, residual) runs as one launch on weights in fragment order
         flat = ops.tlayer_pack([m for l in layers for m in (rt.lp(l.multihead_attn.out_proj.weight), rt.lp(l.linear1.weight), rt.lp(l.linear2.weight))])
         packed = [flat[3 * i:3 * i + 3] for i in range(len(layers))]
-    return DecodeCache(cross, selfkv, max_len, packed)
+    return DecodeCache(cross, selfkv, max_len, packed, cross_rows=M, cross_packed=pack)
 
 
 @torch.no_grad()
@@ -360,7 +379,10 @@ def decoder_step(dec: "BaseDecoder", tok: torch.Tensor, pos: int, cache: DecodeC
     # (the fused kernel keeps the scores of at most ops.decode_attn_max_keys() keys in LDS; longer memories, e.g. 512x512 canvases, take
     #  the per-kernel path below)
     fused = (rt.fused_decode and rt.dtype == torch.bfloat16 and d == 256 and H == 8 and x.stride(1) == 1
-             and cache.cross_kv[0].shape[1] <= ops.decode_attn_max_keys() and pos + 1 <= ops.decode_attn_max_keys())
+             and cache.cross_rows <= ops.decode_attn_max_keys() and pos + 1 <= ops.decode_attn_max_keys())
+    if cache.cross_packed and not fused:
+        raise RuntimeError("decoder_step: this cache holds the fused block's head-pair-major K/V layout (decoder_init_cache under rt.fused_decode); "
+                           "build the cache with the runtime flags the steps run under")
     # per-element positions on the per-kernel path (the fp32 parity mode): the new k / v rows are scattered to row pos_vec[b] of each element's
     # cache and the attention runs over ALL L cache rows with the keys beyond an element's prefix masked by `kpm_prefix` (the caller's
     # [B, kpm_stride] buffer: row b = the padding flags of its prefix, 1 from pos_vec[b] + 1 on) -- masked keys contribute exact zeros, so the
@@ -378,7 +400,7 @@ def decoder_step(dec: "BaseDecoder", tok: torch.Tensor, pos: int, cache: DecodeC
                                 skv, pos, H, True, kpm=kpm_prefix, kpm_stride=kst, pos=pos_vec)
             x = ops.gemm(o, rt.lp(sa.out_proj.weight), B, d, d, bias=sa.out_proj.bias.detach(), res=x)
             o = ops.decode_attn(x, layer.norm2.weight.detach(), layer.norm2.bias.detach(), rt.lp(ca.in_proj_weight), ca.in_proj_bias.detach(),
-                                ckv, ckv.shape[1], H, False)
+                                ckv, cache.cross_rows, H, False, packed_rows=cache.cross_rows if cache.cross_packed else 0)
             if cache.packed is not None:   # out-projection + residual + LayerNorm + feed-forward + residual in one launch (ralf_tlayer_fwd part 2)
                 pk = cache.packed[li]
                 x = ops.tlayer_tail(o, x, {"out2": (pk[0], ca.out_proj.bias.detach()), "ln3": (layer.norm3.weight.detach(), layer.norm3.bias.detach()),

@@ -896,18 +896,25 @@ def decode_attn_max_keys() -> int:
     return _DEC_MAXK
 
 
-def decode_attn(x, ln_g, ln_b, W, bias, kv, Sk, H, self_attn, kpm=None, kpm_stride=0, eps=1e-5, pos=None):
+def decode_attn(x, ln_g, ln_b, W, bias, kv, Sk, H, self_attn, kpm=None, kpm_stride=0, eps=1e-5, pos=None, packed_rows=0):
     """one attention block of a KV-cached decode step with LayerNorm and the q (k, v) projections inside (ralf_decode_attn):
     x [B, d] bf16, W bf16 [3d, d] (in_proj_weight), bias fp32 [3d], kv bf16 cache [B, rows, 2d] -> o [B, d].
     pos (self-attention only): int32 [B] on the device, the cached rows PER ELEMENT (Sk is then their upper bound)."""
     from ._abi import RalfDecodeAttnDesc
 
     B, d_model = x.shape
-    assert x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and kv.dtype == torch.bfloat16 and kv.shape[2] == 2 * d_model
+    assert x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and kv.dtype == torch.bfloat16
     o = torch.empty(B, d_model, dtype=x.dtype, device=x.device)
     d = RalfDecodeAttnDesc()
     d.x, d.ln_g, d.ln_b, d.W, d.bias, d.kv, d.kpm, d.o = _p(x), _p(ln_g), _p(ln_b), _p(W), _p(bias), _p(kv), _p(kpm), _p(o)
-    d.x_rs, d.kv_bs, d.kv_rs, d.kpm_bs, d.o_rs = x.stride(0), kv.stride(0), kv.stride(1), int(kpm_stride), d_model
+    if packed_rows:   # head-pair-major cross-attention cache [B, 2 (k | v), H/2, rows, 64] (nn.decoder_init_cache)
+        R = int(packed_rows)
+        assert not self_attn and kv.is_contiguous() and kv.numel() == B * 2 * (H // 2) * R * 64
+        d.x_rs, d.kv_bs, d.kv_rs, d.kpm_bs, d.o_rs = x.stride(0), 2 * (H // 2) * R * 64, 64, int(kpm_stride), d_model
+        d.kv_hs, d.kv_vo = R * 64, (H // 2) * R * 64
+    else:
+        assert kv.shape[2] == 2 * d_model
+        d.x_rs, d.kv_bs, d.kv_rs, d.kpm_bs, d.o_rs = x.stride(0), kv.stride(0), kv.stride(1), int(kpm_stride), d_model
     d.B, d.H, d.d, d.Sk, d.self_ = B, H, d_model, int(Sk), int(bool(self_attn))
     d.scale, d.eps = (d_model // H) ** -0.5, eps
     if pos is not None:

@@ -397,7 +397,16 @@ def test_fused_decode_attention_equals_separate_kernels_bf16(golden, task):
         memory = model._encode_into_memory(enc_in)["memory"]
         B, T = memory.shape[0], model.tokenizer.max_token_length
         ids = model.special_token_ids
-        caches = {f: RN.decoder_init_cache(dec, memory, rt, T) for f in (True, False)}
+        caches = {}
+        for f in (True, False):   # (the fused block's cache keeps its keys / values head-pair-major: a cache belongs to the flags it was built under)
+            rt.fused_decode = f
+            caches[f] = RN.decoder_init_cache(dec, memory, rt, T)
+        assert caches[True].cross_packed and not caches[False].cross_packed
+        M = memory.shape[1]
+        for pk, rm in zip(caches[True].cross_kv, caches[False].cross_kv):   # same products, the 8 column slices written block by block
+            want = rm.view(B, M, 2, 4, 64).permute(0, 2, 3, 1, 4).reshape(pk.shape)
+            bad = torch.nonzero(pk != want)
+            assert bad.numel() == 0, (bad.shape[0], bad[:6].tolist(), pk.shape)
         seq = torch.full((B, 1), ids["bos"], dtype=torch.long, device=dev)
         model._token_mask_dev(dev)
         worst, agree = 0.0, 0
