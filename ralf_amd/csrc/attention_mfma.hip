@@ -810,6 +810,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const RalfAttnDesc d) 
 // Rounding points are those of the separate kernels (LayerNorm output, q / k / v and o in bf16; fp32 accumulation).
 // d = 256, H = 8 (head dim 32).
 // ------------------------------------------------------------------------------------------------
+// a K / V row of the cross-attention cache: read once per decode step and 139 MB per layer -- a streaming (non-temporal) load, so that the
+// stream does not push the step's 10 MB of weights out of the L2 / infinity cache on its way through
+template <bool STREAM>
+__device__ __forceinline__ bf16x8 kv_load(const bf16* p) {
+    if constexpr (STREAM) return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
+    else return *reinterpret_cast<const bf16x8*>(p);
+}
+
 template <bool SELF, int NS>
 __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const RalfDecodeAttnDesc d) {
     __shared__ float sc[DEC_MAXK + 1][2];
@@ -834,7 +842,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const RalfDecode
     if (PRE) {
         const bf16* Kp0 = (const bf16*)d.kv + (int64_t)min(b0, d.B - 1) * d.kv_bs + (int64_t)hp * (d.kv_hs ? d.kv_hs : 64) + chunk * 8;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) kpre[u] = *reinterpret_cast<const bf16x8*>(Kp0 + (int64_t)min(wave * 8 + u * 32 + slot, d.Sk - 1) * d.kv_rs);
+        for (int u = 0; u < 4; ++u) kpre[u] = kv_load<PRE>(Kp0 + (int64_t)min(wave * 8 + u * 32 + slot, d.Sk - 1) * d.kv_rs);
     }
     bf16x8 w[NP][2][4];
     float bias_r[NP][2];
@@ -918,7 +926,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const RalfDecode
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int key = min(key0 + u * 32 + slot, d.Sk - 1);
-                    kv[u] = *reinterpret_cast<const bf16x8*>(Kp + (int64_t)key * d.kv_rs);
+                    kv[u] = kv_load<PRE>(Kp + (int64_t)key * d.kv_rs);
                 }
             }
 #pragma unroll
@@ -945,7 +953,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const RalfDecode
     bf16x8 vpre[4];
     if (PRE) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) vpre[u] = *reinterpret_cast<const bf16x8*>(Vp + (int64_t)min(wave * 8 + u * 32 + slot, d.Sk - 1) * d.kv_rs);
+        for (int u = 0; u < 4; ++u) vpre[u] = kv_load<PRE>(Vp + (int64_t)min(wave * 8 + u * 32 + slot, d.Sk - 1) * d.kv_rs);
     }
     __syncthreads();
     // ---- softmax over the keys, per head (thread parity = head) ----
@@ -980,7 +988,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const RalfDecode
             for (int u = 0; u < 4; ++u) {
                 const int key = key0 + u * 32 + slot, kc = min(key, d.Sk - 1);
                 if (PRE && key0 == wave * 8) vv[u] = vpre[u];
-                else vv[u] = *reinterpret_cast<const bf16x8*>(Vp + (int64_t)kc * d.kv_rs);
+                else vv[u] = kv_load<PRE>(Vp + (int64_t)kc * d.kv_rs);
                 p[u] = key < d.Sk ? sc[kc][head] : 0.f;
             }
 #pragma unroll

@@ -1254,15 +1254,19 @@ __global__ __launch_bounds__(256) void gemm_grouped_reduce_kernel(const GRedPara
 // chain in the same order as the tiled kernel (bit-identical results).  A decode-step linear layer (256 x 256..1024 x 256..1024) is
 // pure latency: the tiled kernel's index set-up, two staging hops and barriers cost 7.2 us per launch (1 266 launches per batch);
 // here a tile is one load round trip + K/16 MFMAs.
-template <typename T, int EPI, int CH>
-__global__ __launch_bounds__(64) void gemm_skinny_kernel(const KParams P) {
+// KW = 4 (long reductions, K % 512 == 0: the feed-forward block's second product, 256 x 256 x 1024): four waves per tile, each runs a
+// quarter of the k range, the partial tiles are summed through LDS in wave order (deterministic; NOT the tiled kernel's single chain any
+// more -- bf16 throughput mode only) -- a 64-MFMA chain behind 128 KB of loads per wave took 16 us, half of all few-row time in a decode step.
+template <typename T, int EPI, int CH, int KW>
+__global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(const KParams P) {
     static_assert(sizeof(T) == 2, "bf16 only");
     const RalfGemmDesc& d = P.d;
-    const int lane = threadIdx.x, l31 = lane & 31, lh = lane >> 5;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5, kw = KW > 1 ? (int)(threadIdx.x >> 6) : 0;
     const int tm = (int)blockIdx.x / P.tiles_n, tn = (int)blockIdx.x - tm * P.tiles_n;
     const int m0 = tm * 32, n0 = tn * 32;
-    const bf16* a = (const bf16*)d.A + (int64_t)min(m0 + l31, d.M - 1) * d.lda + lh * 8;   // (rows beyond M / N are clamped: never stored)
-    const bf16* b = (const bf16*)d.B + (int64_t)min(n0 + l31, d.N - 1) * d.ldb + lh * 8;
+    const int kspan = d.K / KW;                                                              // this wave's k range: [kw * kspan, (kw + 1) * kspan)
+    const bf16* a = (const bf16*)d.A + (int64_t)min(m0 + l31, d.M - 1) * d.lda + lh * 8 + kw * kspan;   // (rows beyond M / N are clamped: never stored)
+    const bf16* b = (const bf16*)d.B + (int64_t)min(n0 + l31, d.N - 1) * d.ldb + lh * 8 + kw * kspan;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -1279,7 +1283,7 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(const KParams P) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(br[i], ar[i], acc, 0, 0, 0);
     };
-    const int nch = d.K / (16 * CH);
+    const int nch = kspan / (16 * CH);
     load(a0, b0, 0);
     int c = 0;
     for (; c + 2 < nch; c += 2) {
@@ -1294,6 +1298,19 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(const KParams P) {
         comp(a1, b1);
     } else {
         comp(a0, b0);
+    }
+    if constexpr (KW > 1) {
+        __shared__ float red[KW - 1][16][64];
+        if (kw > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[kw - 1][r][lane] = acc[r];
+        }
+        __syncthreads();
+        if (kw > 0) return;
+#pragma unroll
+        for (int w = 0; w < KW - 1; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += red[w][r][lane];
     }
     const int m = m0 + l31;
     // (written out per register group: a loop the compiler leaves rolled indexes the accumulator dynamically = scratch memory)
@@ -1320,8 +1337,10 @@ template <typename T, int EPI>
 int launch_skinny(KParams& P, hipStream_t st) {
     P.tiles_m = ceil_div(P.d.M, 32);
     P.tiles_n = ceil_div(P.d.N, 32);
-    if (P.d.K % 128 == 0) hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 8>), dim3(P.tiles_m * P.tiles_n), dim3(64), 0, st, P);
-    else hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 4>), dim3(P.tiles_m * P.tiles_n), dim3(64), 0, st, P);
+    static const int split = [] { const char* e = getenv("RALF_GEMM_SKINNY_SPLIT"); return e ? atoi(e) : 1; }();   // 0 = off (A/B runs)
+    if (split && P.d.K % 512 == 0) hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 8, 4>), dim3(P.tiles_m * P.tiles_n), dim3(256), 0, st, P);
+    else if (P.d.K % 128 == 0) hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 8, 1>), dim3(P.tiles_m * P.tiles_n), dim3(64), 0, st, P);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 4, 1>), dim3(P.tiles_m * P.tiles_n), dim3(64), 0, st, P);
     return ralf::check_launch("gemm (few rows)");
 }
 

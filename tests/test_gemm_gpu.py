@@ -244,13 +244,20 @@ def test_few_row_kernel_is_bit_identical_to_the_tiled_kernel(tmp_path):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for rows in ("512", "0"):
-        f = str(tmp_path / f"o{rows}.pt")
-        env = dict(os.environ, RALF_GEMM_SKINNY_ROWS=rows)
+    for rows, split in (("512", "0"), ("0", "0"), ("512", "1")):
+        f = str(tmp_path / f"o{rows}_{split}.pt")
+        env = dict(os.environ, RALF_GEMM_SKINNY_ROWS=rows, RALF_GEMM_SKINNY_SPLIT=split)
         subprocess.run([sys.executable, "-c", _FEW_ROW_SNIPPET, root, f], check=True, env=env, timeout=600)
         outs.append(torch.load(f))
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
+        # reductions of K % 512 == 0 (the feed-forward block's second product) run as four quarter chains summed in wave order: the same
+        # product to bf16 rounding, no longer the same bits
+        K = int(k.split("x")[2])
+        if K % 512:
+            assert torch.equal(outs[2][k], outs[1][k]), k
+        else:
+            torch.testing.assert_close(outs[2][k].float(), outs[1][k].float(), rtol=1.6e-2, atol=1e-2)
 
 
 _GLDS_CASES = """
