@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 18
+#define RALF_ABI_VERSION 19
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -168,6 +168,11 @@ typedef struct RalfGemmDesc {
      * score matrix, 252 MB at BASELINE config 4): with a per-query lower bound of its (pool+1)-th best score as threshold the lists hold a
      * superset of the pool.  bf16, A and B k-contiguous, aligned interior path, one batch, no split-K, plain epilogue (alpha only). */
     const float* flt_thresh; int* flt_count; void* flt_list; int flt_cap, flt_pad_;
+    /* LayerNorm in front of a FEW-ROW product (ln_g NULL = off): A = LayerNorm(A rows; ln_g, ln_b, ln_eps) rounded to bf16, applied by every tile's
+     * wave to the 32 rows it has just loaded -- replaces ralf_layernorm_fwd + ralf_gemm for the LayerNorm -> linear pairs of a KV-cached decode
+     * step (norm3 -> linear1, head LayerNorm -> vocabulary matrix: common/common.py:25-34,52-56), one launch instead of two at batch 256.
+     * bf16, K == 256 (the whole row in the wave's registers), M <= 512, A and B k-contiguous, one batch, no split-K: refused otherwise. */
+    const float* ln_g; const float* ln_b; float ln_eps; int ln_pad_;
 } RalfGemmDesc;
 size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d);
 int ralf_gemm(const RalfGemmDesc* d, void* workspace, size_t workspace_bytes, void* stream);

@@ -154,6 +154,11 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
                      ((uintptr_t)d.flt_list % 8) == 0,
                      "gemm: flt_* needs thresholds, counters and a capacity, bf16 NT operands on the aligned path, one batch, no split-K and a plain epilogue");
     }
+    if (d.ln_g) {
+        RALF_REQUIRE(d.ln_b && d.dtype == RALF_BF16 && !d.gather && d.a_kcontig && d.b_kcontig && P.fast && d.K == 256 && d.M <= 512 && nbatch == 1 && d.splitk == 1 &&
+                     !d.colstats && !d.bnb_part && !d.kseg && !d.atomic_out && !d.flt_list && !d.at_mode && ((uintptr_t)d.ln_g % 16) == 0 && ((uintptr_t)d.ln_b % 16) == 0,
+                     "gemm: ln_* (LayerNorm in front of a few-row product) needs bf16 NT operands on the aligned path, K == 256, M <= 512, one batch, no split-K");
+    }
     hipStream_t st = (hipStream_t)stream;
     if (d.at_mode) {
         RALF_REQUIRE(d.at_mode == 1 || d.at_mode == 2, "gemm: at_mode %d", d.at_mode);

@@ -1257,7 +1257,9 @@ __global__ __launch_bounds__(256) void gemm_grouped_reduce_kernel(const GRedPara
 // KW = 4 (long reductions, K % 512 == 0: the feed-forward block's second product, 256 x 256 x 1024): four waves per tile, each runs a
 // quarter of the k range, the partial tiles are summed through LDS in wave order (deterministic; NOT the tiled kernel's single chain any
 // more -- bf16 throughput mode only) -- a 64-MFMA chain behind 128 KB of loads per wave took 16 us, half of all few-row time in a decode step.
-template <typename T, int EPI, int CH, int KW>
+// LN (K == 256, CH = 8, KW = 1: both register sets together hold the lane's half of its row): LayerNorm of the 32 A rows in registers before
+// the MFMAs -- the two lanes of a row (l31, lh = 0 / 1) own the k-octets of their parity, one shuffle joins their sums; formulas of ln_fwd_kernel.
+template <typename T, int EPI, int CH, int KW, bool LN = false>
 __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(const KParams P) {
     static_assert(sizeof(T) == 2, "bf16 only");
     const RalfGemmDesc& d = P.d;
@@ -1285,6 +1287,45 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(const KParams P) {
     };
     const int nch = kspan / (16 * CH);
     load(a0, b0, 0);
+    if constexpr (LN) {
+        static_assert(CH == 8 && KW == 1, "the LayerNorm prologue keeps a 256-wide row in the two register sets");
+        load(a1, b1, 1);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += (float)a0[i][e] + (float)a1[i][e];
+        sum += __shfl_xor(sum, 32);
+        const float mu = sum * (1.f / 256.f);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d0 = (float)a0[i][e] - mu, d1 = (float)a1[i][e] - mu;
+                q = __fmaf_rn(d0, d0, q);
+                q = __fmaf_rn(d1, d1, q);
+            }
+        q += __shfl_xor(q, 32);
+        const float rs = rsqrtf(__fmaf_rn(q, 1.f / 256.f, d.ln_eps));
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {   // element e of chunk i sits at column 16 i + 8 lh + e (set 0) / 128 + that (set 1)
+            const int k0 = 16 * i + 8 * lh;
+            const float4 g0 = *reinterpret_cast<const float4*>(d.ln_g + k0), g1 = *reinterpret_cast<const float4*>(d.ln_g + k0 + 4);
+            const float4 h0 = *reinterpret_cast<const float4*>(d.ln_b + k0), h1 = *reinterpret_cast<const float4*>(d.ln_b + k0 + 4);
+            const float4 g2 = *reinterpret_cast<const float4*>(d.ln_g + 128 + k0), g3 = *reinterpret_cast<const float4*>(d.ln_g + 128 + k0 + 4);
+            const float4 h2 = *reinterpret_cast<const float4*>(d.ln_b + 128 + k0), h3 = *reinterpret_cast<const float4*>(d.ln_b + 128 + k0 + 4);
+            const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, ba[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+            const float gb[8] = {g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w}, bb[8] = {h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                a0[i][e] = (bf16)__fmaf_rn(((float)a0[i][e] - mu) * rs, ga[e], ba[e]);
+                a1[i][e] = (bf16)__fmaf_rn(((float)a1[i][e] - mu) * rs, gb[e], bb[e]);
+            }
+        }
+        comp(a0, b0);
+        comp(a1, b1);
+    } else {
     int c = 0;
     for (; c + 2 < nch; c += 2) {
         load(a1, b1, c + 1);
@@ -1298,6 +1339,7 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(const KParams P) {
         comp(a1, b1);
     } else {
         comp(a0, b0);
+    }
     }
     if constexpr (KW > 1) {
         __shared__ float red[KW - 1][16][64];
@@ -1338,7 +1380,8 @@ int launch_skinny(KParams& P, hipStream_t st) {
     P.tiles_m = ceil_div(P.d.M, 32);
     P.tiles_n = ceil_div(P.d.N, 32);
     static const int split = [] { const char* e = getenv("RALF_GEMM_SKINNY_SPLIT"); return e ? atoi(e) : 1; }();   // 0 = off (A/B runs)
-    if (split && P.d.K % 512 == 0) hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 8, 4>), dim3(P.tiles_m * P.tiles_n), dim3(256), 0, st, P);
+    if (P.d.ln_g) hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 8, 1, true>), dim3(P.tiles_m * P.tiles_n), dim3(64), 0, st, P);   // (K == 256: checked at entry)
+    else if (split && P.d.K % 512 == 0) hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 8, 4>), dim3(P.tiles_m * P.tiles_n), dim3(256), 0, st, P);
     else if (P.d.K % 128 == 0) hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 8, 1>), dim3(P.tiles_m * P.tiles_n), dim3(64), 0, st, P);
     else hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 4, 1>), dim3(P.tiles_m * P.tiles_n), dim3(64), 0, st, P);
     return ralf::check_launch("gemm (few rows)");
@@ -1517,6 +1560,7 @@ int dispatch(KParams& P, int nbatch, hipStream_t st) {
             const bool lvl1 = d.drop_p > 0.f || d.aux;
             return lvl2 ? launch_skinny<T, 2>(P, st) : lvl1 ? launch_skinny<T, 1>(P, st) : launch_skinny<T, 0>(P, st);
         }
+        if (d.ln_g) { ralf::set_error("gemm: ln_* is part of the few-row kernel, which RALF_GEMM_SKINNY_ROWS has switched off for this size"); return RALF_ERR_INVALID; }
         if (P.fast) {
             switch (key) {
                 case 6: return launch_cfg<T, true, true, 3>(P, nbatch, st);

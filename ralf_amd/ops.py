@@ -85,8 +85,9 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
          bias=None, act=None, res=None, ldr=None, aux=None, aux_mode=None, aux_scale=1.0, out2=None,
          alpha=1.0, accumulate=False, splitk=1, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=None,
          conv: Optional[dict] = None, gather=0, drop_p=0.0, seed=None, call_id=0, atomic=False, colstats=None,
-         sBias0=0, kseg=0, sBk=0, colscale=None, bnb=None, at=None, flt=None) -> torch.Tensor:
+         sBias0=0, kseg=0, sBk=0, colscale=None, bnb=None, at=None, flt=None, ln=None) -> torch.Tensor:
     """C = epi(alpha * A @ B) through ralf_gemm (see include/ralf_hip.h: RalfGemmDesc).
+    ln = (gamma, beta, eps): LayerNorm of the A rows in front of a few-row product (gemm_ln_ok says where it exists).
     at = dict(mode=1|2, c1, c2, c3=None, a2=None, out=None, mask=None, relu=False): the A-operand transform with write-through (at_*)."""
     assert A.is_cuda and B.is_cuda and A.dtype == B.dtype
     d = RalfGemmDesc()
@@ -126,6 +127,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
         bx, bm, bmean, bpart = bnb
         assert bx.dtype == A.dtype and bx.is_contiguous() and bx.numel() == M * N and bpart.dtype == torch.float32 and bpart.numel() >= ((M + 63) // 64) * 2 * N
         d.bnb_x, d.bnb_mask, d.bnb_mean, d.bnb_part = _p(bx), _p(bm), _p(bmean), _p(bpart)
+    if ln is not None:
+        d.ln_g, d.ln_b, d.ln_eps = _p(ln[0]), _p(ln[1]), float(ln[2])
     if flt is not None:   # (thresholds fp32 [M], hit counts int32 [M, T], slots int32 [M, T, cap, 2]; T = ceil(N / gemm_filter_tile)): threshold filter (flt_*)
         th, cnt, lst = flt
         T = lst.shape[1]
@@ -567,6 +570,17 @@ def upsample_bwd(g_up, g_sum, src_shape):
     d = torch.empty(src_shape, dtype=g_sum.dtype, device=g_sum.device)
     _call("ralf_upsample_nearest_bwd", dtype_code(g_sum), _p(g_up), C, _p(g_sum), _p(d), B, IH, IW, OH, OW, C)
     return d
+
+
+_SKINNY_ROWS = int(os.environ.get("RALF_GEMM_SKINNY_ROWS", "512"))
+
+
+def gemm_ln_ok(A: torch.Tensor, M: int, K: int) -> bool:
+    """RalfGemmDesc.ln_*: the LayerNorm -> linear pairs of a decode step as ONE launch (bf16 rows of 256, at most 512 of them)"""
+    return (_LN_GEMM and A.dtype == torch.bfloat16 and K == 256 and M <= min(512, _SKINNY_ROWS) and A.stride(-1) == 1 and A.data_ptr() % 16 == 0)
+
+
+_LN_GEMM = os.environ.get("RALF_LN_GEMM", "1") != "0"   # A/B runs
 
 
 def colstats_buffer(M, N, device):

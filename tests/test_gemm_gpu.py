@@ -235,6 +235,31 @@ torch.save(out, sys.argv[2])
 """
 
 
+@pytest.mark.parametrize("M,N,act,f32out", [(256, 1024, "relu", False), (256, 518, None, True), (33, 256, None, False), (512, 64, "gelu", False)])
+def test_layernorm_prologue_of_the_few_row_product(M, N, act, f32out):
+    """RalfGemmDesc.ln_*: LayerNorm of the A rows inside the few-row kernel against ralf_layernorm_fwd + the plain product (same formulas;
+    the row sums are taken in another order, so a normalised element may round to the neighbouring bf16 value now and then)."""
+    from ralf_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = (torch.randn(M, 256, device="cuda", generator=g) * 2 + 0.3).bfloat16()
+    W = (torch.randn(N, 256, device="cuda", generator=g) * 0.05).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g)
+    lg, lb = torch.rand(256, device="cuda", generator=g) + 0.5, torch.randn(256, device="cuda", generator=g) * 0.1
+    assert ops.gemm_ln_ok(x, M, 256)
+    odt = torch.float32 if f32out else None
+    got = ops.gemm(x, W, M, N, 256, bias=b, act=act, ln=(lg, lb, 1e-5), out_dtype=odt)
+    h, _, _ = ops.layernorm_fwd(x, lg, lb, save_stats=False)
+    want = ops.gemm(h, W, M, N, 256, bias=b, act=act, out_dtype=odt)
+    assert float((got.float() - want.float()).abs().max()) <= 0.02 * float(want.float().abs().max())
+    assert float((got.float() != want.float()).float().mean()) < 0.2     # mostly the same bits
+    ref = torch.nn.functional.layer_norm(x.float(), (256,), lg, lb).bfloat16().float() @ W.float().t() + b
+    ref = torch.relu(ref) if act == "relu" else (torch.nn.functional.gelu(ref) if act == "gelu" else ref)
+    assert float((got.float() - ref).abs().max()) <= 0.03 * float(ref.abs().max())
+    with pytest.raises(RuntimeError):   # rows wider than the kernel keeps in registers
+        ops.gemm(torch.zeros(M, 512, device="cuda", dtype=torch.bfloat16), torch.zeros(N, 512, device="cuda", dtype=torch.bfloat16), M, N, 512, ln=(lg, lb, 1e-5))
+
+
 def test_few_row_kernel_is_bit_identical_to_the_tiled_kernel(tmp_path):
     """gemm_skinny_kernel (bf16 NT products with M <= 512: the decode step's linear layers) runs the tiled kernel's MFMA chain in the same
     order: the two builds of the same product agree bit for bit (RALF_GEMM_SKINNY_ROWS=0 switches the few-row path off in a child process)."""
