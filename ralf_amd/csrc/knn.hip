@@ -22,7 +22,9 @@
 //    top-k of the [queries x 128..256 rows] tile in LDS, no score matrix: a wave-level exact top-16 of 128 is thousands of
 //    dependent scalar/vector round trips per query, the scan got 14-23 us slower at nq = 16-32 and 39 % slower at nq = 1024;
 //    (b) one 1024-thread workgroup per query over the whole score row: a single CU pulls ~25 GB/s, 17-19 us per launch vs
-//    16 us for the two launches it replaced.
+//    16 us for the two launches it replaced;
+//    (d, round 4) two k-tiles requested back to back (256 contiguous bytes of every row within a few hundred ns, the second tile waiting in a
+//    second register set) and streaming (non-temporal) index loads: scan 76.9 vs 76.8 us at nq = 1, 107 vs 101 us at nq = 32; 73.4 vs 69.4 us.
 #include "common.h"
 
 namespace {
@@ -69,7 +71,7 @@ __device__ __forceinline__ bool better(uint32_t ka, int pa, uint32_t kb, int pb)
 // GATHER (exact re-scoring of per-query candidate lists, two-stage search): workgroup <-> (query q, chunk of its `pool`
 // candidates); the index rows come from cand[q][*], the query tile holds the single query q, S is [nq][pool].  The
 // accumulation code is the one of the exhaustive scan, so a re-scored pair is bit-identical to its exhaustive score.
-template <int MF, int TQ, int TR, bool GATHER = false, bool PAIR = false>
+template <int MF, int TQ, int TR, bool GATHER = false>
 __global__ __launch_bounds__(256) void knn_scores_kernel(const float* __restrict__ X, int64_t N, int D,
                                                           const float* __restrict__ Q, int nq, float* __restrict__ S,
                                                           int n_qtiles, int nwg, const int64_t* __restrict__ cand = nullptr, int pool = 0,
@@ -93,24 +95,7 @@ __global__ __launch_bounds__(256) void knn_scores_kernel(const float* __restrict
     const int64_t nrows = GATHER ? pool : N;               // rows addressable by this workgroup's list
     const int nq_hi = GATHER ? q0 + 1 : nq;                // GATHER: only row 0 of the query tile is real
 
-    // PAIR: two k-tiles are requested back to back (256 contiguous bytes of every row within a few hundred ns instead of two 128-byte pieces
-    // a whole tile's compute apart: the second finds its DRAM page still open); the second tile waits in `xr2 / qr2`
-    float4 xr[XV], qr[QV], xr2[PAIR ? XV : 1], qr2[PAIR ? QV : 1];
-    auto gload2 = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < XV; ++i) {
-            const int f = tid + 256 * i, r = f >> 3, kq = f & 7;
-            const int64_t n = row0 + r;
-            const int k = k0 + kq * 4;
-            xr2[PAIR ? i : 0] = (n < nrows && k < D) ? *reinterpret_cast<const float4*>(X + n * D + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < QV; ++i) {
-            const int f = tid + 256 * i, r = f >> 3, kq = f & 7;
-            const int qi = q0 + r, k = k0 + kq * 4;
-            qr2[PAIR ? i : 0] = (f < QW * 8 && qi < nq_hi && k < D) ? *reinterpret_cast<const float4*>(Q + (int64_t)qi * D + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
+    float4 xr[XV], qr[QV];
     auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
@@ -166,7 +151,11 @@ __global__ __launch_bounds__(256) void knn_scores_kernel(const float* __restrict
     for (int b = 0; b < TR; ++b) { const int r = (wave * TR + b) * MF + lr; xoff[b] = r * BK; xrot[b] = ROT * r + lk; }
 
     const int nkt = (D + BK - 1) / BK;
-    auto compute = [&]() {
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) gload((kt + 1) * BK);  // next tile's HBM loads fly under this tile's MFMAs
 #pragma unroll
         for (int s = 0; s < BK / KS; ++s) {
             float a[TQ], b[TR];
@@ -179,45 +168,11 @@ __global__ __launch_bounds__(256) void knn_scores_kernel(const float* __restrict
 #pragma unroll
                 for (int j = 0; j < TR; ++j) acc[i][j] = F::mfma(a[i], b[j], acc[i][j]);
         }
-    };
-    if constexpr (PAIR) {
-        // tiles (kt, kt + 1) are loaded together; tile kt is in LDS, tile kt + 1 in the second register set
-        gload(0);
-        gload2(BK);
-        lstore();
-        __syncthreads();
-        for (int kt = 0; kt < nkt; kt += 2) {
-            compute();                               // tile kt
-            __syncthreads();
-            if (kt + 1 < nkt) {
-#pragma unroll
-                for (int i = 0; i < XV; ++i) xr[i] = xr2[i];
-#pragma unroll
-                for (int i = 0; i < QV; ++i) qr[i] = qr2[i];
-                lstore();                            // tile kt + 1
-                __syncthreads();
-                if (kt + 2 < nkt) { gload((kt + 2) * BK); gload2((kt + 3) * BK); }   // the next pair flies under tile kt + 1's MFMAs
-                compute();
-                __syncthreads();
-                if (kt + 2 < nkt) {
-                    lstore();
-                    __syncthreads();
-                }
-            }
-        }
-    } else {
-    gload(0);
-    lstore();
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) gload((kt + 1) * BK);  // next tile's HBM loads fly under this tile's MFMAs
-        compute();
         __syncthreads();
         if (kt + 1 < nkt) {
             lstore();
             __syncthreads();
         }
-    }
     }
 
 #pragma unroll
@@ -517,9 +472,7 @@ int launch_scores(const float* X, int64_t N, int D, const float* Q, int nq, floa
     constexpr int RW = 4 * TR * MF, QW = TQ * MF;
     const int nrc = ceil_div(N, RW), nqt = ceil_div(nq, QW);
     const int nwg = nrc * nqt;
-    static const int pair = [] { const char* e = getenv("RALF_KNN_PAIR"); return e ? atoi(e) : 0; }();
-    if (pair) hipLaunchKernelGGL((knn_scores_kernel<MF, TQ, TR, false, true>), dim3(nwg), dim3(256), 0, st, X, N, D, Q, nq, S, nqt, nwg, nullptr, 0, zero_me, nzero);
-    else hipLaunchKernelGGL((knn_scores_kernel<MF, TQ, TR>), dim3(nwg), dim3(256), 0, st, X, N, D, Q, nq, S, nqt, nwg, nullptr, 0, zero_me, nzero);
+    hipLaunchKernelGGL((knn_scores_kernel<MF, TQ, TR>), dim3(nwg), dim3(256), 0, st, X, N, D, Q, nq, S, nqt, nwg, nullptr, 0, zero_me, nzero);
     return ralf::check_launch("knn_scores");
 }
 
