@@ -172,7 +172,11 @@ typedef struct RalfGemmDesc {
      * wave to the 32 rows it has just loaded -- replaces ralf_layernorm_fwd + ralf_gemm for the LayerNorm -> linear pairs of a KV-cached decode
      * step (norm3 -> linear1, head LayerNorm -> vocabulary matrix: common/common.py:25-34,52-56), one launch instead of two at batch 256.
      * bf16, K == 256 (the whole row in the wave's registers), M <= 512, A and B k-contiguous, one batch, no split-K: refused otherwise. */
-    const float* ln_g; const float* ln_b; float ln_eps; int ln_pad_;
+    const float* ln_g; const float* ln_b; float ln_eps;
+    /* few_row_split = 1: a few-row product (M <= 512, bf16 NT) with K % 512 == 0 may run FOUR waves per tile, a quarter of the k range each,
+     * partial tiles summed in wave order -- deterministic, but not the single MFMA chain every other path of this product writes (the fused
+     * layer kernels reproduce that chain bit for bit), so the caller asks for it: the decode step's 256 x 256 x 1024 product does. */
+    int few_row_split;
 } RalfGemmDesc;
 size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d);
 int ralf_gemm(const RalfGemmDesc* d, void* workspace, size_t workspace_bytes, void* stream);

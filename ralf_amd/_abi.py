@@ -78,7 +78,7 @@ class RalfGemmDesc(ctypes.Structure):
         + [("bnb_x", vp), ("bnb_mask", vp), ("bnb_mean", vp), ("bnb_part", vp)]
         + [("at_mode", i32), ("at_relu", i32), ("at_a2", vp), ("at_c1", vp), ("at_c2", vp), ("at_c3", vp), ("at_out", vp), ("at_mask", vp)]
         + [("flt_thresh", vp), ("flt_count", vp), ("flt_list", vp), ("flt_cap", i32), ("flt_pad_", i32)]
-        + [("ln_g", vp), ("ln_b", vp), ("ln_eps", f32), ("ln_pad_", i32)]
+        + [("ln_g", vp), ("ln_b", vp), ("ln_eps", f32), ("few_row_split", i32)]
     )
 
 

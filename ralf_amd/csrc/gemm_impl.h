@@ -1381,7 +1381,7 @@ int launch_skinny(KParams& P, hipStream_t st) {
     P.tiles_n = ceil_div(P.d.N, 32);
     static const int split = [] { const char* e = getenv("RALF_GEMM_SKINNY_SPLIT"); return e ? atoi(e) : 1; }();   // 0 = off (A/B runs)
     if (P.d.ln_g) hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 8, 1, true>), dim3(P.tiles_m * P.tiles_n), dim3(64), 0, st, P);   // (K == 256: checked at entry)
-    else if (split && P.d.K % 512 == 0) hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 8, 4>), dim3(P.tiles_m * P.tiles_n), dim3(256), 0, st, P);
+    else if (split && P.d.few_row_split && P.d.K % 512 == 0) hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 8, 4>), dim3(P.tiles_m * P.tiles_n), dim3(256), 0, st, P);
     else if (P.d.K % 128 == 0) hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 8, 1>), dim3(P.tiles_m * P.tiles_n), dim3(64), 0, st, P);
     else hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 4, 1>), dim3(P.tiles_m * P.tiles_n), dim3(64), 0, st, P);
     return ralf::check_launch("gemm (few rows)");

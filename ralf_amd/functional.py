@@ -84,6 +84,10 @@ class Runtime:
         self.fused_decode_tail = os.environ.get("RALF_DECODE_TAIL", "0") == "1"
         self.fused_decode = True  # KV-cached decode step: LayerNorm + projections + attention per block in one launch (bf16, d = 256, 8 heads)
         self.fold_bn = True       # inference: eval-mode BatchNorm folded into the convolution epilogues (conv_bn_infer)
+        # decode step: LayerNorm inside the few-row product that follows it (RalfGemmDesc.ln_*) and the four-wave split of the 256 x 256 x 1024
+        # product (few_row_split) -- same arithmetic, other summation orders than the separate launches (off: their bits)
+        self.decode_ln_gemm = True
+        self.decode_few_row_split = True
         self.conv_wgrad_direct = os.environ.get("RALF_CONV_WGRAD_DIRECT", "1") != "0"   # 3x3 / stride-1 weight gradients in the direct form (ops.conv3x3_wgrad)
         self.stem_direct = os.environ.get("RALF_STEM_DIRECT", "1") != "0"               # the 7x7 stem convolution in direct form (ops.stem7x7_fwd)
         self.fused_stem = os.environ.get("RALF_FUSED_STEM", "1") != "0"   # training: the stem's BatchNorm + ReLU + max-pool as one pass (StemBNReluPoolFn)

@@ -423,14 +423,14 @@ def decoder_step(dec: "BaseDecoder", tok: torch.Tensor, pos: int, cache: DecodeC
             q = ops.gemm(h, rt.lp(ca.in_proj_weight)[:d], B, d, d, bias=ca.in_proj_bias.detach()[:d])
             o, _ = ops.attention_fwd(q.view(B, 1, d), ckv, ckv, B, H, 1, ckv.shape[1], dh, 0, 0, d, need_lse=False)
             x = ops.gemm(o.view(B, d), rt.lp(ca.out_proj.weight), B, d, d, bias=ca.out_proj.bias.detach(), res=x)
-        if ops.gemm_ln_ok(x, B, d):   # LayerNorm inside the few-row product (every tile's wave normalises the 32 rows it has just loaded)
+        if rt.decode_ln_gemm and ops.gemm_ln_ok(x, B, d):   # LayerNorm inside the few-row product (every tile's wave normalises the 32 rows it has just loaded)
             f = ops.gemm(x, rt.lp(layer.linear1.weight), B, layer.linear1.weight.shape[0], d, bias=layer.linear1.bias.detach(), act="relu",
                          ln=(layer.norm3.weight.detach(), layer.norm3.bias.detach(), 1e-5))
         else:
             h, _, _ = ops.layernorm_fwd(x, layer.norm3.weight.detach(), layer.norm3.bias.detach(), save_stats=False)
             f = ops.gemm(h, rt.lp(layer.linear1.weight), B, layer.linear1.weight.shape[0], d, bias=layer.linear1.bias.detach(), act="relu")
-        x = ops.gemm(f, rt.lp(layer.linear2.weight), B, d, f.shape[1], bias=layer.linear2.bias.detach(), res=x)
-    if ops.gemm_ln_ok(x, B, d):
+        x = ops.gemm(f, rt.lp(layer.linear2.weight), B, d, f.shape[1], bias=layer.linear2.bias.detach(), res=x, few_row_split=rt.decode_few_row_split)
+    if rt.decode_ln_gemm and ops.gemm_ln_ok(x, B, d):
         return ops.gemm(x, rt.lp(dec.head[1].weight), B, dec.head[1].weight.shape[0], d, out_dtype=torch.float32,
                         ln=(dec.head[0].weight.detach(), dec.head[0].bias.detach(), 1e-5))
     h, _, _ = ops.layernorm_fwd(x, dec.head[0].weight.detach(), dec.head[0].bias.detach(), save_stats=False)

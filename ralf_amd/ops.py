@@ -85,7 +85,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
          bias=None, act=None, res=None, ldr=None, aux=None, aux_mode=None, aux_scale=1.0, out2=None,
          alpha=1.0, accumulate=False, splitk=1, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=None,
          conv: Optional[dict] = None, gather=0, drop_p=0.0, seed=None, call_id=0, atomic=False, colstats=None,
-         sBias0=0, kseg=0, sBk=0, colscale=None, bnb=None, at=None, flt=None, ln=None) -> torch.Tensor:
+         sBias0=0, kseg=0, sBk=0, colscale=None, bnb=None, at=None, flt=None, ln=None, few_row_split=False) -> torch.Tensor:
     """C = epi(alpha * A @ B) through ralf_gemm (see include/ralf_hip.h: RalfGemmDesc).
     ln = (gamma, beta, eps): LayerNorm of the A rows in front of a few-row product (gemm_ln_ok says where it exists).
     at = dict(mode=1|2, c1, c2, c3=None, a2=None, out=None, mask=None, relu=False): the A-operand transform with write-through (at_*)."""
@@ -129,6 +129,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=
         d.bnb_x, d.bnb_mask, d.bnb_mean, d.bnb_part = _p(bx), _p(bm), _p(bmean), _p(bpart)
     if ln is not None:
         d.ln_g, d.ln_b, d.ln_eps = _p(ln[0]), _p(ln[1]), float(ln[2])
+    d.few_row_split = int(bool(few_row_split))
     if flt is not None:   # (thresholds fp32 [M], hit counts int32 [M, T], slots int32 [M, T, cap, 2]; T = ceil(N / gemm_filter_tile)): threshold filter (flt_*)
         th, cnt, lst = flt
         T = lst.shape[1]
