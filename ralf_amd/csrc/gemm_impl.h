@@ -1375,16 +1375,105 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(const KParams P) {
 #undef RALF_SKINNY_STORE
 }
 
+// fp32 (the parity mode) few-row products: one wave per 16x16 output tile on v_mfma_f32_16x16x4_f32 -- a chain of K / 4 matrix instructions on
+// one accumulator is the ascending-k fma chain of the tiled kernel's v_mfma_f32_32x32x2_f32 (same bits: tests/test_gemm_gpu.py), but 256 waves
+// instead of 16 workgroups share a 256 x 256 product and a wave's chain is 64 x 32 cycles instead of 128 x 64.  Operands travel global ->
+// registers (a whole 256-wide k chunk of both operands requested at once, two chunks in flight) -> LDS (rotated rows as in knn.hip:
+// conflict-free 4-byte fragment reads) one 32-wide k-tile at a time; a single wave needs no barrier beyond the compiler's ordering.
+// The tiled kernel took 15.3 us per launch on the decode step's 256 x 256..1024 x 256 products (16-64 workgroups on 256 CUs).
+template <int EPI>
+__global__ __launch_bounds__(64) void gemm_skinny_f32_kernel(const KParams P) {
+    const RalfGemmDesc& d = P.d;
+    __shared__ float la[16 * 32], lb[16 * 32];
+    const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
+    const int tm = (int)blockIdx.x / P.tiles_n, tn = (int)blockIdx.x - tm * P.tiles_n;
+    const int m0 = tm * 16, n0 = tn * 16;
+    // loader: float4 #i of a 16 x 32 k-tile = row (lane + 64 i) >> 3, k-quad (lane + 64 i) & 7
+    const int r0 = lane >> 3, kq = lane & 7;
+    const float* a0p = (const float*)d.A + (int64_t)min(m0 + r0, d.M - 1) * d.lda + kq * 4;
+    const float* a1p = (const float*)d.A + (int64_t)min(m0 + r0 + 8, d.M - 1) * d.lda + kq * 4;
+    const float* b0p = (const float*)d.B + (int64_t)min(n0 + r0, d.N - 1) * d.ldb + kq * 4;
+    const float* b1p = (const float*)d.B + (int64_t)min(n0 + r0 + 8, d.N - 1) * d.ldb + kq * 4;
+    constexpr int CT = 8;                                   // k-tiles per chunk (256 k)
+    struct Chunk { float4 a[CT][2], b[CT][2]; };
+    Chunk c0, c1;
+    auto load = [&](Chunk& c, int chunk) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int k = (chunk * CT + t) * 32;
+            c.a[t][0] = *reinterpret_cast<const float4*>(a0p + k); c.a[t][1] = *reinterpret_cast<const float4*>(a1p + k);
+            c.b[t][0] = *reinterpret_cast<const float4*>(b0p + k); c.b[t][1] = *reinterpret_cast<const float4*>(b1p + k);
+        }
+    };
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // element (row, k) of a tile lives at row * 32 + ((k + 2 row) & 31)
+    const int w0 = r0 * 32, w1 = (r0 + 8) * 32, rot0 = kq * 4 + 2 * r0, rot1 = kq * 4 + 2 * (r0 + 8);
+    const int foff = lr * 32, frot = 2 * lr + lk;
+    auto comp = [&](const Chunk& c, int ntile) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            if (t < ntile) {
+                la[w0 + ((rot0 + 0) & 31)] = c.a[t][0].x; la[w0 + ((rot0 + 1) & 31)] = c.a[t][0].y; la[w0 + ((rot0 + 2) & 31)] = c.a[t][0].z; la[w0 + ((rot0 + 3) & 31)] = c.a[t][0].w;
+                la[w1 + ((rot1 + 0) & 31)] = c.a[t][1].x; la[w1 + ((rot1 + 1) & 31)] = c.a[t][1].y; la[w1 + ((rot1 + 2) & 31)] = c.a[t][1].z; la[w1 + ((rot1 + 3) & 31)] = c.a[t][1].w;
+                lb[w0 + ((rot0 + 0) & 31)] = c.b[t][0].x; lb[w0 + ((rot0 + 1) & 31)] = c.b[t][0].y; lb[w0 + ((rot0 + 2) & 31)] = c.b[t][0].z; lb[w0 + ((rot0 + 3) & 31)] = c.b[t][0].w;
+                lb[w1 + ((rot1 + 0) & 31)] = c.b[t][1].x; lb[w1 + ((rot1 + 1) & 31)] = c.b[t][1].y; lb[w1 + ((rot1 + 2) & 31)] = c.b[t][1].z; lb[w1 + ((rot1 + 3) & 31)] = c.b[t][1].w;
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const float av = la[foff + ((frot + 4 * s) & 31)], bv = lb[foff + ((frot + 4 * s) & 31)];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc, 0, 0, 0);   // rows = n (4 consecutive per lane), columns = m
+                }
+                __syncthreads();
+            }
+        }
+    };
+    const int ntiles = d.K / 32, nch = (ntiles + CT - 1) / CT;
+    load(c0, 0);                                            // (a chunk may reach past K: K % 256 == 0 is the dispatch rule)
+    int c = 0;
+    for (; c + 2 < nch; c += 2) {
+        load(c1, c + 1);
+        comp(c0, CT);
+        load(c0, c + 2);
+        comp(c1, CT);
+    }
+    if (c + 1 < nch) {
+        load(c1, c + 1);
+        comp(c0, CT);
+        comp(c1, CT);
+    } else {
+        comp(c0, CT);
+    }
+    const int m = m0 + lr, n = n0 + 4 * lk;
+    if (m < d.M && n < d.N) {
+        float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+        if (P.vec_epi && n + 3 < d.N) {
+            epilogue_store4<float, EPI>(d, 0, 0, m, n, v);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (n + q < d.N) epilogue_store<float, EPI>(d, 0, 0, m, n + q, v[q]);
+        }
+    }
+}
+
 template <typename T, int EPI>
 int launch_skinny(KParams& P, hipStream_t st) {
     P.tiles_m = ceil_div(P.d.M, 32);
     P.tiles_n = ceil_div(P.d.N, 32);
+    if constexpr (sizeof(T) == 4) {
+        P.tiles_m = ceil_div(P.d.M, 16);
+        P.tiles_n = ceil_div(P.d.N, 16);
+        hipLaunchKernelGGL((gemm_skinny_f32_kernel<EPI>), dim3(P.tiles_m * P.tiles_n), dim3(64), 0, st, P);
+        return ralf::check_launch("gemm (few rows, fp32)");
+    } else {
     static const int split = [] { const char* e = getenv("RALF_GEMM_SKINNY_SPLIT"); return e ? atoi(e) : 1; }();   // 0 = off (A/B runs)
     if (P.d.ln_g) hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 8, 1, true>), dim3(P.tiles_m * P.tiles_n), dim3(64), 0, st, P);   // (K == 256: checked at entry)
     else if (split && P.d.few_row_split && P.d.K % 512 == 0) hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 8, 4>), dim3(P.tiles_m * P.tiles_n), dim3(256), 0, st, P);
     else if (P.d.K % 128 == 0) hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 8, 1>), dim3(P.tiles_m * P.tiles_n), dim3(64), 0, st, P);
     else hipLaunchKernelGGL((gemm_skinny_kernel<T, EPI, 4, 1>), dim3(P.tiles_m * P.tiles_n), dim3(64), 0, st, P);
     return ralf::check_launch("gemm (few rows)");
+    }
 }
 
 template <typename T>
@@ -1552,6 +1641,14 @@ int dispatch(KParams& P, int nbatch, hipStream_t st) {
     if (d.gather == 2) {
         if (key != 0) { ralf::set_error("gemm: gather=2 needs A and B row-contiguous"); return RALF_ERR_INVALID; }
         return launch_cfg<T, false, false, 2>(P, nbatch, st);
+    }
+    if constexpr (sizeof(T) == 4) {   // fp32 parity mode: few rows x K % 256 == 0 (a decode step's linear layers)
+        static const int skinny_rows32 = [] { const char* e = getenv("RALF_GEMM_SKINNY_ROWS"); return e ? atoi(e) : 512; }();
+        if (P.fast && key == 6 && d.M <= skinny_rows32 && d.K % 256 == 0 && nbatch == 1 && d.splitk == 1 && !d.colstats && !d.bnb_part && !d.kseg && !d.atomic_out && !d.flt_list && !d.ln_g) {
+            const bool lvl2 = d.C2 || d.act == RALF_ACT_GELU || d.aux_mode == RALF_AUX_GELU_GRAD;
+            const bool lvl1 = d.drop_p > 0.f || d.aux;
+            return lvl2 ? launch_skinny<T, 2>(P, st) : lvl1 ? launch_skinny<T, 1>(P, st) : launch_skinny<T, 0>(P, st);
+        }
     }
     if constexpr (sizeof(T) == 2) {   // bf16: the interior fast path is its own (leaner) set of kernels; fp32 is the parity mode
         static const int skinny_rows = [] { const char* e = getenv("RALF_GEMM_SKINNY_ROWS"); return e ? atoi(e) : 512; }();   // 0 = off (A/B runs)

@@ -232,6 +232,8 @@ for (M, N, K, act, res) in [(256, 256, 256, None, True), (256, 1024, 256, "gelu"
     r = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda() if res else None
     out[f"{M}x{N}x{K}"] = ops.gemm(A, W, M, N, K, bias=b, act=act, res=r, few_row_split=True).cpu()
     assert torch.equal(ops.gemm(A, W, M, N, K, bias=b, act=act, res=r).cpu(), out[f"{M}x{N}x{K}"]) or (K % 512 == 0)   # without the flag: the single chain
+    # the fp32 parity mode's few-row kernel (gemm_skinny_f32_kernel, K % 256 == 0): 16x16 tiles, the tiled kernel's bits; fp32 and bf16-to-fp32 outputs
+    out[f"{M}x{N}x{K}xfp32"] = ops.gemm(A.float(), W.float(), M, N, K, bias=b, act=act, res=r.float() if res else None).cpu()
 torch.save(out, sys.argv[2])
 """
 
@@ -280,7 +282,7 @@ def test_few_row_kernel_is_bit_identical_to_the_tiled_kernel(tmp_path):
         # reductions of K % 512 == 0 (the feed-forward block's second product) run as four quarter chains summed in wave order: the same
         # product to bf16 rounding, no longer the same bits
         K = int(k.split("x")[2])
-        if K % 512:
+        if K % 512 or k.endswith("fp32"):
             assert torch.equal(outs[2][k], outs[1][k]), k
         else:
             torch.testing.assert_close(outs[2][k].float(), outs[1][k].float(), rtol=1.6e-2, atol=1e-2)
