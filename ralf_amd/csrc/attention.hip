@@ -361,6 +361,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const RalfAttnDesc d)
 // lanes' head over all keys; pass 2: o += p * V, the 8 partial rows merged through LDS.  The general kernel above gives a query row to ONE
 // lane: with Sq = 1 it ran 1 lane in 64 and took 345-980 us per call on the decoder's 532-row memory at B = 256 (70 % of the fp32 decode).
 constexpr int DQ_WAVES = 8;
+// STREAM (long memories: the decoder's cross-attention, 279 MB of K / V per call at B = 256): the rows are read once per step -- streaming
+// (non-temporal) loads, so that they do not push the step's weights out of the L2 / infinity cache on their way through (as in the bf16 block)
+template <bool STREAM>
+__device__ __forceinline__ float4 dq_load(const float* p) {
+    if constexpr (STREAM) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return *reinterpret_cast<const float4*>(p);
+    }
+}
+template <bool STREAM>
 __global__ __launch_bounds__(512) void attn_decode_f32_kernel(const RalfAttnDesc d) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sc = smem;                              // [Sk][H]
@@ -376,7 +389,7 @@ __global__ __launch_bounds__(512) void attn_decode_f32_kernel(const RalfAttnDesc
     for (int key0 = wave * 8; key0 < Sk; key0 += DQ_WAVES * 8) {
         float4 kv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) kv[u] = *reinterpret_cast<const float4*>(Kp + (int64_t)min(key0 + u, last) * d.k_rs);
+        for (int u = 0; u < 8; ++u) kv[u] = dq_load<STREAM>(Kp + (int64_t)min(key0 + u, last) * d.k_rs);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             float s = q.x * kv[u].x + q.y * kv[u].y + q.z * kv[u].z + q.w * kv[u].w;
@@ -406,7 +419,7 @@ __global__ __launch_bounds__(512) void attn_decode_f32_kernel(const RalfAttnDesc
     for (int key0 = wave * 8; key0 < Sk; key0 += DQ_WAVES * 8) {
         float4 vv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) vv[u] = *reinterpret_cast<const float4*>(Vp + (int64_t)min(key0 + u, last) * d.v_rs);
+        for (int u = 0; u < 8; ++u) vv[u] = dq_load<STREAM>(Vp + (int64_t)min(key0 + u, last) * d.v_rs);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int key = key0 + u;
@@ -455,8 +468,14 @@ bool decode_f32_fits(const RalfAttnDesc& d) {
 int run_decode_f32(const RalfAttnDesc& d, hipStream_t st) {
     const size_t lds = sizeof(float) * ((size_t)d.Sk * d.H + DQ_WAVES * 256);
     static bool allowed = false;
-    if (!allowed) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ((size_t)DQ_MAX_KEYS * 8 + DQ_WAVES * 256))); allowed = true; }
-    hipLaunchKernelGGL(attn_decode_f32_kernel, dim3(d.B), dim3(512), lds, st, d);
+    if (!allowed) {
+        const int most = (int)(sizeof(float) * ((size_t)DQ_MAX_KEYS * 8 + DQ_WAVES * 256));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_f32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_f32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+        allowed = true;
+    }
+    if (d.Sk > 128) hipLaunchKernelGGL(attn_decode_f32_kernel<true>, dim3(d.B), dim3(512), lds, st, d);
+    else hipLaunchKernelGGL(attn_decode_f32_kernel<false>, dim3(d.B), dim3(512), lds, st, d);
     return ralf::check_launch("attention_decode_f32");
 }
 template <typename T, int DH>
