@@ -176,7 +176,7 @@ def bench_decode(device, N=10, B=256, dtype="bfloat16", reps=3):
     out = {"batch": B, "tokens_per_sample": 5 * N,
            "note": "sample() incl. H2D of the image batch and host-side token decoding; graph_ms = the captured device loop alone; hbm_frac = the "
                    "loop's unavoidable stream (the cross-attention K/V cache of 6 layers, read once per generated token) / graph_ms / 8 TB/s: the "
-                   "whole-loop lower bound on the memory side (the cross-attention kernel itself runs at 0.62 of peak, profiles/*_decode_kernel_stats.txt)"}
+                   "whole-loop lower bound on the memory side (the cross-attention kernel itself runs at 0.70 of peak: tools/decode_attn_bench.py, profiles/*_decode_kernel_stats.txt)"}
     out["mode"] = ("bf16 throughput mode: labels identical to the fp32 mode, >= 90 % of the geometry tokens (tests/test_configs_gpu.py); the north star's "
                    "bit-exact tokens hold in the fp32 parity mode, timed in `fp32_parity_mode` below") if dtype.startswith("b") else "fp32 parity mode: tokens bit-exact against the reference's (tests/test_model_gpu.py, tests/test_fullsize_gpu.py)"
     for task in ("c", "cwh"):
