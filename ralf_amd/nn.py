@@ -335,7 +335,7 @@ def decoder_init_cache(dec: "BaseDecoder", memory: torch.Tensor, rt: Runtime, ma
     H = dec.transformer.layers[0].self_attn.nhead
     # the fused decode block's conditions (decoder_step): then the projection writes the head-pair-major layout itself -- 8 column slices
     # (k | v x head pair) x B elements as ONE batched product, slice j = 4 kv + hp of element b at [b, j, :, :]
-    pack = (_DECODE_KV_PACKED and rt.fused_decode and rt.dtype == torch.bfloat16 and memory.is_cuda and d == 256 and H == 8 and M <= ops.decode_attn_max_keys())
+    pack = (_DECODE_KV_PACKED and rt.fused_decode and rt.dtype == torch.bfloat16 and memory.is_cuda and d == 256 and H == 8 and max(M, max_len) <= ops.decode_attn_max_keys())
     for layer in dec.transformer.layers:
         a = layer.multihead_attn
         if pack:
