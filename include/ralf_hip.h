@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 19
+#define RALF_ABI_VERSION 20
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -332,6 +332,16 @@ int ralf_stem7x7_fwd(const void* x, const void* w, void* y, float* part, int B, 
  * workgroups' blocks in order (deterministic) */
 size_t ralf_stem7x7_wgrad_workspace_bytes(int B, int IH, int IW);
 int ralf_stem7x7_wgrad(const void* x, const void* dy, float* dW, int B, int IH, int IW, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* 1x1 convolution with FEW (K = 64 or 128) input channels on NHWC bf16 rows (ralf_amd/csrc/conv1x1_k64.hip): y [M, N] = x [M, K] w [N, K]^T, M % 64 == 0,
+ * N = 64 * 2^k <= 2048.  Replaces torch's conv2d for timm Bottleneck.conv3 / downsample.0 / the first conv1 of ResNet-50's layer1
+ * (image2layout/train/models/common/image.py:39-48) -- one k-tile of matrix work per output tile in front of a store four times the operand's
+ * size, where ralf_gemm's tiled kernel spends the tile on its latency chain.  Same output bits as ralf_gemm.
+ *   colstats (may be NULL): fp32 [M / 64, 2, N], per 64-row block the column sums / sums of squares of y as stored (= RalfGemmDesc.colstats)
+ *   scale, shift (NULL together = off; not with colstats): y = act(acc * scale[n] + shift[n]) (+ res [M, N]); relu 0 / 1 / 2 (2 = after the
+ *   residual: RALF_ACT_RELU_POST) -- the eval-mode BatchNorm of the inference backbone (RalfGemmDesc.colscale / bias / res). */
+int ralf_conv1x1_k64(const void* x, const void* w, void* y, float* colstats, const float* scale, const float* shift, const void* res,
+                     int relu, int64_t M, int N, int K, void* stream);
+
 /* Weight gradient of a 3x3 / pad 1 convolution of stride s = 1 or 2, DIRECT form (ralf_amd/csrc/conv_wgrad.hip): dW[co][ci][kh][kw] (fp32, OIHW;
  * = or +=) = sum over pixels of dy[b,oy,ox,co] * x[b,s oy+kh-1,s ox+kw-1,ci]; dy [B,H,W,Co] and x [B,IH,IW,Ci] NHWC bf16 (H, W: the OUTPUT grid).  A workgroup keeps a 64 x 64 x 9
  * block of dW in registers and stages each 64-pixel tile of dy and the halo patch of x once for all nine taps (the implicit-GEMM form,

@@ -9,6 +9,7 @@ SIGNATURES = {
     "ralf_abi_version": (i32, []),
     # exact inner-product top-k
     "ralf_knn_topk_ip_workspace_bytes": (sz, [i64, i32, i32, i32]),
+    "ralf_conv1x1_k64": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp]),
     "ralf_knn_topk_ip": (i32, [vp, i64, i32, vp, i32, i32, vp, vp, vp, sz, vp]),
     "ralf_knn_scores": (i32, [vp, i64, i32, vp, i32, vp, vp]),
     "ralf_knn_select": (i32, [vp, i64, i32, i32, vp, vp, vp, sz, vp]),

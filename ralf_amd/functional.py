@@ -1422,6 +1422,10 @@ class ConvFn(Function):
                 hw = OH * OW
                 y = ops.gemm(x.view(-1, C), rt.lp(W).view(Co, Ci), hw, Co, Ci, bias=bias, res=pos, batch=(B, 1),
                              sA=(hw * Ci, 0), sC=(hw * Co, 0), sR=(0, 0), out=torch.empty(M, Co, dtype=x.dtype, device=x.device))
+            elif bias is None and ops.conv1x1_k64_ok(x.view(-1, C), Co) and (cst is not None or not stats):
+                # 64 input channels (layer1's conv3 / downsample / first conv1): one k-tile per output tile in front of a store four times its
+                # size -- a wave per 64 x 64 tile with the weights in registers (ops.conv1x1_k64), the same bits as the tiled product
+                y = ops.conv1x1_k64(x.view(-1, C), rt.lp(W).view(Co, Ci), colstats=cst)
             else:
                 y = ops.gemm(x.view(-1, C), rt.lp(W).view(Co, Ci), M, Co, Ci, bias=bias, colstats=cst)
         elif (rt.stem_direct and kh == 7 and kw == 7 and stride == 2 and pad == 3 and C == 8 and Co == 64 and b is None and pos is None
@@ -1520,7 +1524,9 @@ def conv_bn_infer(x, W, scale, shift, stride, pad, relu, res, rt):
     x = x.contiguous()
     act = "relu_post" if (relu and res is not None) else ("relu" if relu else None)
     r2 = res.contiguous().view(M, Co) if res is not None else None
-    if kh == 1 and stride == 1:
+    if kh == 1 and stride == 1 and ops.conv1x1_k64_ok(x.view(-1, C), Co):
+        y = ops.conv1x1_k64(x.view(-1, C), rt.lp(W).view(Co, Ci), scale=scale, shift=shift, res=r2, relu=2 if act == "relu_post" else (1 if act == "relu" else 0))
+    elif kh == 1 and stride == 1:
         y = ops.gemm(x.view(-1, C), rt.lp(W).view(Co, Ci), M, Co, Ci, bias=shift, colscale=scale, act=act, res=r2)
     else:
         geom = dict(RH=OH, RW=OW, SH=H, SW=Wd, SC=C, KH=kh, KW=kw, stride=stride, pad=pad, mode=0)

@@ -584,6 +584,29 @@ def gemm_ln_ok(A: torch.Tensor, M: int, K: int) -> bool:
 _LN_GEMM = os.environ.get("RALF_LN_GEMM", "1") != "0"   # A/B runs
 
 
+def conv1x1_k64_ok(x2d: torch.Tensor, N: int, any_k: bool = False) -> bool:
+    """ralf_conv1x1_k64: 64 input channels (the entry also takes 128 -- any_k -- where it is level with the tiled product: 28 against 32 us
+    with statistics, 26 against 26 without, so the model does not route those), bf16 rows, M % 64 == 0, N = 64 * 2^k <= 2048"""
+    M, K = x2d.shape
+    n64 = N // 64
+    return (_CONV1X1_K64 and x2d.is_cuda and x2d.dtype == torch.bfloat16 and (K == 64 or (any_k and K == 128)) and x2d.is_contiguous() and M % 64 == 0 and N % 64 == 0 and N <= 2048
+            and (n64 & (n64 - 1)) == 0 and x2d.data_ptr() % 16 == 0)
+
+
+_CONV1X1_K64 = os.environ.get("RALF_CONV1X1_K64", "1") != "0"   # A/B runs
+
+
+def conv1x1_k64(x2d, W, colstats=None, scale=None, shift=None, res=None, relu=0, out=None):
+    """y [M, N] = x [M, 64] W [N, 64]^T (ralf_conv1x1_k64: one wave per 64 x 64 tile, weights in registers, no LDS for the operands).
+    colstats: the [M/64, 2, N] statistics partials of the following BatchNorm; scale / shift (+ res, relu 0 / 1 / 2 = after the residual): the
+    inference epilogue."""
+    M, K, N = x2d.shape[0], x2d.shape[1], W.shape[0]
+    assert W.dtype == torch.bfloat16 and W.is_contiguous() and W.numel() == N * K
+    y = out if out is not None else torch.empty(M, N, dtype=x2d.dtype, device=x2d.device)
+    _call("ralf_conv1x1_k64", _p(x2d), _p(W), _p(y), _p(colstats), _p(scale), _p(shift), _p(res), int(relu), M, N, K)
+    return y
+
+
 def colstats_buffer(M, N, device):
     return torch.empty((M + 63) // 64, 2, N, dtype=torch.float32, device=device)
 

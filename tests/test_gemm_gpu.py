@@ -238,6 +238,36 @@ torch.save(out, sys.argv[2])
 """
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (4096, 256, 64), (16384, 64, 64), (1088 * 64, 256, 64), (128, 2048, 64), (8192, 512, 128), (192, 128, 128)])
+def test_conv1x1_with_64_input_channels(M, N, K):
+    """ralf_conv1x1_k64 (a wave per 64 x 64 tile, weights in registers) against ralf_gemm: the same output bits; the statistics partials of the
+    same stored values (sums in another order); the inference epilogue (scale / shift / residual / ReLU before or after it) like the tiled one."""
+    from ralf_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.1).bfloat16()
+    assert ops.conv1x1_k64_ok(x, N, any_k=True) and ops.conv1x1_k64_ok(x, N) == (K == 64)
+    want = ops.gemm(x, w, M, N, K)
+    assert torch.equal(ops.conv1x1_k64(x, w), want)
+    cst, cst0 = ops.colstats_buffer(M, N, x.device), ops.colstats_buffer(M, N, x.device)
+    want2 = ops.gemm(x, w, M, N, K, colstats=cst0)
+    got2 = ops.conv1x1_k64(x, w, colstats=cst)
+    assert torch.equal(got2, want2)
+    ref = want.float().view(M // 64, 64, N)
+    assert torch.allclose(cst[:, 0], ref.sum(1), rtol=1e-5, atol=1e-4) and torch.allclose(cst[:, 1], (ref * ref).sum(1), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(cst, cst0, rtol=1e-5, atol=1e-4)
+    sc, sh = torch.rand(N, device="cuda", generator=g) + 0.5, torch.randn(N, device="cuda", generator=g)
+    r = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    for relu, act, res in ((1, "relu", None), (2, "relu_post", r), (0, None, r), (0, None, None)):
+        a = ops.conv1x1_k64(x, w, scale=sc, shift=sh, res=res, relu=relu)
+        b = ops.gemm(x, w, M, N, K, bias=sh, colscale=sc, act=act, res=res)
+        assert float((a.float() - b.float()).abs().max()) <= 2.0 ** -7 * float(b.float().abs().max()), (relu, act)
+        assert float((a != b).float().mean()) < 0.01, (relu, act)      # (the same bits but for where the compiler contracts scale * x + shift)
+    with pytest.raises(RuntimeError):
+        ops.conv1x1_k64(x[:32], w)
+
+
 @pytest.mark.parametrize("M,N,act,f32out", [(256, 1024, "relu", False), (256, 518, None, True), (33, 256, None, False), (512, 64, "gelu", False)])
 def test_layernorm_prologue_of_the_few_row_product(M, N, act, f32out):
     """RalfGemmDesc.ln_*: LayerNorm of the A rows inside the few-row kernel against ralf_layernorm_fwd + the plain product (same formulas;
