@@ -225,7 +225,8 @@ sys.path.insert(0, sys.argv[1])
 from ralf_amd import ops
 g = torch.Generator().manual_seed(7)
 out = {}
-for (M, N, K, act, res) in [(256, 256, 256, None, True), (256, 1024, 256, "gelu", False), (256, 256, 1024, None, True), (33, 518, 256, None, False), (500, 192, 64, "relu", False)]:
+for (M, N, K, act, res) in [(256, 256, 256, None, True), (256, 1024, 256, "gelu", False), (256, 256, 1024, None, True), (33, 518, 256, None, False), (500, 192, 64, "relu", False),
+                            (33, 72, 512, "relu", True), (1, 256, 1024, None, False)]:
     A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
     W = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16).cuda()
     b = torch.randn(N, generator=g).cuda()
