@@ -18,4 +18,7 @@ for (name, hw, K, N, res) in [("layer1 conv1 (first)", 64, 64, 64, False), ("lay
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     t = timeit(lambda: ops.gemm(x, w, M, N, K, bias=sh, colscale=sc, act="relu_post" if res else "relu", res=r, out=out), iters=10)
     byts = 2 * (M * K + M * N * (2 if res else 1) + N * K)
+    if ops.conv1x1_k64_ok(x, N):
+        t2 = timeit(lambda: ops.conv1x1_k64(x, w, scale=sc, shift=sh, res=r, relu=2 if res else 1, out=out), iters=10)
+        print(f"{'  ralf_conv1x1_k64':22s} {'':34s} {t2 * 1e6:7.1f} us  {byts / t2 / 1e12:5.2f} TB/s")
     print(f"{name:22s} M={M:8d} K={K:5d} N={N:5d}: {t * 1e6:7.1f} us  {byts / t / 1e12:5.2f} TB/s  {2 * M * N * K / t / 1e12:6.1f} TFLOP/s")
