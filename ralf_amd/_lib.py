@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libralf_hip.so")
+# RALF_HIP_LIB: another build of the same ABI, for same-box A/B timing of kernel changes (tools/ab_encdec.sh); never a fallback
+LIB_PATH = os.environ.get("RALF_HIP_LIB") or os.path.join(_HERE, "libralf_hip.so")
 _lib = None
 
 c_i64, c_int, c_size, c_void, c_float = ctypes.c_int64, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_float

@@ -108,8 +108,8 @@ __device__ __forceinline__ bf16x8 frag_cols_T(const bf16* tile, int r0, int c0, 
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ float xor_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
-__device__ __forceinline__ float xor_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+__device__ __forceinline__ float xor_max(float v) { return wave::max_x16_x32(v); }   // (v_permlane16/32_swap instead of ds_bpermute: wave_ops.h)
+__device__ __forceinline__ float xor_sum(float v) { return wave::sum_x16_x32(v); }
 
 // ------------------------------------------------------------------------------------------------
 // forward: grid (ceil(Sq/64), H, B), 4 waves x 16 queries

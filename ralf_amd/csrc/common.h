@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include "../../include/ralf_hip.h"
+#include "wave_ops.h"
 
 namespace ralf {
 void set_error(const char* fmt, ...);

@@ -33,9 +33,7 @@ template <> struct VL<bf16> {
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    return wave::sum64_desc(v);   // the descending butterfly, bit for bit, without the LDS crossbar (wave_ops.h)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -126,10 +124,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const T* __restr
                 }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            s1[0] += __shfl_xor(s1[0], o); s2[0] += __shfl_xor(s2[0], o);
-            s1[1] += __shfl_xor(s1[1], o); s2[1] += __shfl_xor(s2[1], o);
-        }
+        for (int r = 0; r < 2; ++r) { s1[r] = wave::sum64_desc(s1[r]); s2[r] = wave::sum64_desc(s2[r]); }   // (four independent chains)
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             if (r >= nr) break;

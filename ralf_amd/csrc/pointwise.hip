@@ -18,14 +18,10 @@ template <typename T> __device__ __forceinline__ float ld(const T* p, int64_t i)
 template <typename T> __device__ __forceinline__ void st(T* p, int64_t i, float v) { p[i] = (T)v; }
 
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    return wave::sum64_desc(v);   // the descending butterfly, bit for bit, without the LDS crossbar (wave_ops.h)
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    return wave::max64(v);
 }
 
 // stateless counter-based RNG: 24 uniform bits from (seed, stream id, element index)

@@ -38,13 +38,11 @@ constexpr int LDS_BYTES = (BUFA_ELEMS + BUFB_ELEMS) * 2 + 64 + 16;
 // reads global memory another thread of it wrote.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    return wave::sum64_desc(v);   // the descending butterfly, bit for bit, without the LDS crossbar (wave_ops.h)
 }
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ float xor_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
-__device__ __forceinline__ float xor_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+__device__ __forceinline__ float xor_max(float v) { return wave::max_x16_x32(v); }
+__device__ __forceinline__ float xor_sum(float v) { return wave::sum_x16_x32(v); }
 
 // tools/tlayer_probe.hip builds this file with -DRALF_TLAYER_PROBE: s_memtime stamps per workgroup at the phase boundaries
 #ifdef RALF_TLAYER_PROBE
@@ -107,9 +105,7 @@ __device__ __forceinline__ void row_pass(const float* stage, bf16x4 (&rr)[32 * R
 #pragma unroll
     for (int k = 0; k < NR; ++k) s1[k] = v[k][0] + v[k][1] + v[k][2] + v[k][3];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int k = 0; k < NR; ++k) s1[k] += __shfl_xor(s1[k], o);
+    for (int k = 0; k < NR; ++k) s1[k] = wave::sum64_desc(s1[k]);   // (NR independent chains of DPP / permlane-swap adds: wave_ops.h)
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
         s1[k] *= (1.f / TD);   // mean
@@ -119,9 +115,7 @@ __device__ __forceinline__ void row_pass(const float* stage, bf16x4 (&rr)[32 * R
         s2[k] = q;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int k = 0; k < NR; ++k) s2[k] += __shfl_xor(s2[k], o);
+    for (int k = 0; k < NR; ++k) s2[k] = wave::sum64_desc(s2[k]);
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
         const int row = wave + k * NW;
@@ -661,9 +655,7 @@ __global__ __launch_bounds__(NT) void tlayer_bwd_kernel(const RalfTLayerBwdDesc 
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int k = 0; k < NR; ++k) { s1[k] += __shfl_xor(s1[k], o); s2[k] += __shfl_xor(s2[k], o); }
+    for (int k = 0; k < NR; ++k) { s1[k] = wave::sum64_desc(s1[k]); s2[k] = wave::sum64_desc(s2[k]); }
     lds_barrier();   // every wave has read its staged rows: bufB is free for the column sums, bufA for g_m
     const DropKeys k_out = drop_keys(d.p > 0.f ? (uint64_t)d.seed[0] : 0, d.call_out);
     const uint32_t thr = drop_thr16(d.p);

@@ -525,10 +525,18 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         self._restore(snap)
         torch.cuda.synchronize()
-        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        dot = os.environ.get("RALF_GRAPH_DOT")   # diagnostics: the captured forward + backward graph as a DOT file (tools/graph_dot.py)
+        ga, gb = torch.cuda.CUDAGraph(keep_graph=True) if dot else torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         gm = torch.cuda.CUDAGraph() if self.staged else None
         with torch.cuda.graph(ga, stream=cap, capture_error_mode=_CAPTURE_MODE):
             self.loss = self._fwd_bwd(si, st)
+        if dot:
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipGraphDebugDotPrint.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint]
+            rc = hip.hipGraphDebugDotPrint(ctypes.c_void_p(ga.raw_cuda_graph()), dot.encode(), int(os.environ.get("RALF_GRAPH_DOT_FLAGS", "1")))
+            assert rc == 0, f"hipGraphDebugDotPrint: {rc}"
+            ga.instantiate()
         if gm is not None:
             with torch.cuda.graph(gm, pool=ga.pool(), stream=cap, capture_error_mode=_CAPTURE_MODE):
                 self._bwd_rest()

@@ -30,6 +30,7 @@ from ..helpers.task_preprocessor import PREPROCESSOR
 logger = logging.getLogger(__name__)
 _DTYPES = {"float32": torch.float32, "fp32": torch.float32, "bfloat16": torch.bfloat16, "bf16": torch.bfloat16}
 NEG_INF = -float("inf")
+_CONSTRAINT_FIRST = os.environ.get("RALF_CONSTRAINT_FIRST", "0") == "1"
 
 
 def _num_classes(features) -> int:
@@ -775,6 +776,8 @@ class ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg(_GeneratorBas
         assert inputs["image"].size(1) == 4
         # three independent sub-networks; the two small ones run on their own graph branches (Runtime.branch: issued late,
         # started with the step)
+        # RALF_CONSTRAINT_FIRST (A/B): the constraint branch recorded FIRST, so that autograd reaches its backward LAST
+        cf = self._constraint_features(inputs) if _CONSTRAINT_FIRST else None
         mem = self._image_memory(inputs["image"])
         with rt.branch("retrieved"):
             ref = self._retrieved_features(inputs["retrieved"], inputs["image"].device)
@@ -783,7 +786,7 @@ class ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg(_GeneratorBas
         ref_a, ref_b = RF.fork2(ref)
         ca = self.attn(mem_a, ref_a, rt)
         fused = self.head(RF.concat_rows([mem_b, ca, ref_b], rt), rt)
-        return {"memory": self._constraint_memory(fused, inputs)}
+        return {"memory": self._constraint_memory(fused, inputs, cf)}
 
 
 class ConcateAuxilaryTaskAutoreg(_GeneratorBase):
