@@ -14,6 +14,7 @@
 // (per-key kernel, lane = one key).  P is recomputed from (Q, K, lse); dropout masks come from the same
 // counter-based generator as the VALU kernels, so forward/backward of either implementation agree.
 #include "common.h"
+#include "attn_core.h"
 
 namespace {
 typedef __bf16 bf16;
@@ -140,10 +141,10 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
     f32x4 o[DH / 16];
 #pragma unroll
     for (int c = 0; c < DH / 16; ++c) o[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // the per-score work bounds this kernel (VALU, not the matrix cores): scores live in the log2 domain (one multiply, one
-    // v_exp_f32 per score), masks come from LDS, the dropout hash uses full-rate integer ops (common.h)
-    float m = -__builtin_inff(), l = 0.f;   // running max / sum of 2^(score * scale * log2 e)
+    // the per-score work bounds this kernel (VALU, not the matrix cores): attn::fwd_step (attn_core.h)
+    float m = -__builtin_inff(), l = 0.f;   // running max of the RAW scores / this lane's share of the sum of 2^((score - m) * scale * log2 e)
     const float scale2 = d.scale * 1.4426950408889634f;
+    const bool drop = d.p_drop > 0.f;
 
     TileRegs<DH> kreg, vreg;
     tile_load<DH>(kreg, Kp, d.k_rs, 0, d.Sk);
@@ -175,55 +176,19 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
 #pragma unroll
                     for (int c = 0; c < DH / 32; ++c) s[blk] = mfma16(frag_rows<DH>(Ks, s0 + blk * 16, c * 32, lane), qf[c], s[blk]);
                 }
-                float p[8];
-                float mt = -__builtin_inff();
-                if (tile_masked || d.causal) {   // wave-uniform: most tiles of the model (no padded key, not causal) skip the mask work
-                    const uint32_t mw[2] = {*reinterpret_cast<const uint32_t*>(Ms + s0 + 4 * g), *reinterpret_cast<const uint32_t*>(Ms + s0 + 16 + 4 * g)};
+                const bool msk = tile_masked || d.causal;   // wave-uniform: most tiles of the model (no padded key, not causal) skip the mask work
+                uint32_t mw0 = 0u, mw1 = 0u;
+                if (msk) { mw0 = *reinterpret_cast<const uint32_t*>(Ms + s0 + 4 * g); mw1 = *reinterpret_cast<const uint32_t*>(Ms + s0 + 16 + 4 * g); }
+                const bf16x8 pf = attn::fwd_step<DH / 16>(s, m, l, o, scale2, msk, mw0, mw1, d.causal != 0, t0 + s0 + 4 * g, qi, drop, rowkey, thr);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int key = t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3);
-                        const bool masked = ((mw[j >> 2] >> (8 * (j & 3))) & 0xffu) || (d.causal && key > qi);
-                        p[j] = masked ? -__builtin_inff() : s[j >> 2][j & 3] * scale2;
-                        mt = fmaxf(mt, p[j]);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { p[j] = s[j >> 2][j & 3] * scale2; mt = fmaxf(mt, p[j]); }
-                }
-                mt = xor_max(mt);
-                const float mn = fmaxf(m, mt);
-                // branch-free online softmax (matrix-core ops must not sit under divergent control flow): while a
-                // query has seen only masked keys mn = -inf -> use 0 as the reference so every exp() is exp(-inf) = 0
-                const float mref = mn > -__builtin_inff() ? mn : 0.f;
-                const float corr = __builtin_amdgcn_exp2f(m - mref);
-                float ls = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { p[j] = __builtin_amdgcn_exp2f(p[j] - mref); ls += p[j]; }
-                l = __fmaf_rn(l, corr, xor_sum(ls));   // (explicit: tlayer.hip must write the same bits)
-                m = mn;
-                bf16x8 pf;
-                if (d.p_drop > 0.f) {
-#pragma unroll
-                    for (int j = 0; j < 8; j += 2) {   // keys j, j+1 of this lane are an (even, odd) pair: one hash for both
-                        const uint32_t h = attn_rng2x16(rowkey, (uint32_t)(t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3)) >> 1);
-                        pf[j] = (bf16)((h & 0xffffu) >= thr ? p[j] * inv_keep : 0.f);
-                        pf[j + 1] = (bf16)((h >> 16) >= thr ? p[j + 1] * inv_keep : 0.f);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pf[j] = (bf16)p[j];
-                }
-#pragma unroll
-                for (int c = 0; c < DH / 16; ++c) {
-                    o[c] *= corr;
-                    o[c] = mfma16(frag_cols_T<DH>(Vs, s0, c * 16, lane), pf, o[c]);
-                }
+                for (int c = 0; c < DH / 16; ++c) o[c] = mfma16(frag_cols_T<DH>(Vs, s0, c * 16, lane), pf, o[c]);
             }
         }
         __syncthreads();
     }
+    l = xor_sum(l);   // the four lane groups' shares (every wave, whether it writes or not: cross-lane operations want all lanes)
     if (active && qi < d.Sq) {
-        const float inv = 1.f / l;
+        const float inv = (drop ? inv_keep : 1.f) / l;   // (the kept probabilities went into P V unscaled)
         bf16* Op = (bf16*)d.o + b * d.o_bs + (int64_t)qi * d.o_rs + (int64_t)h * DH;
 #pragma unroll
         for (int c = 0; c < DH / 16; ++c) {
@@ -232,7 +197,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
             for (int r = 0; r < 4; ++r) t[r] = (bf16)(o[c][r] * inv);
             *reinterpret_cast<bf16x4*>(Op + c * 16 + 4 * g) = t;
         }
-        if (d.lse && g == 0) d.lse[((int64_t)b * d.H + h) * d.Sq + qi] = __fmaf_rn(m, 0.6931471805599453f, __logf(l));   // (explicit fma: tlayer.hip must write the same bits)
+        if (d.lse && g == 0) d.lse[((int64_t)b * d.H + h) * d.Sq + qi] = __fmaf_rn(m, d.scale, __logf(l));   // (explicit fma: tlayer.hip must write the same bits)
     }
 }
 
@@ -326,14 +291,15 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_mfma(const RalfAttnDesc d)
     __syncthreads();
 
     const bool wave_active = kw0 < d.Sk;   // (wave-uniform)
+    const bool drop = d.p_drop > 0.f;
+    const bool any_kmasked = __builtin_amdgcn_ballot_w64(kmasked[0] || kmasked[1]) != 0ull;   // (wave-uniform)
     int step = 0;
     for (int s0 = 0; s0 < d.Sq; s0 += 32, ++step) {
         float* slot = Slot[step & 1][wave];
         if (wave_active) {
             const f32x4 L4[2] = {*reinterpret_cast<const f32x4*>(Ls + s0 + 4 * g), *reinterpret_cast<const f32x4*>(Ls + s0 + 16 + 4 * g)};
             const f32x4 D4[2] = {*reinterpret_cast<const f32x4*>(Ds + s0 + 4 * g), *reinterpret_cast<const f32x4*>(Ds + s0 + 16 + 4 * g)};
-            typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
-            const u32x4v R4[2] = {*reinterpret_cast<const u32x4v*>(Rk + s0 + 4 * g), *reinterpret_cast<const u32x4v*>(Rk + s0 + 16 + 4 * g)};
+            const attn::u32x4 R4[2] = {*reinterpret_cast<const attn::u32x4*>(Rk + s0 + 4 * g), *reinterpret_cast<const attn::u32x4*>(Rk + s0 + 16 + 4 * g)};
 #pragma unroll
             for (int hk = 0; hk < 2; ++hk) {
                 const int kj = kw0 + hk * 16 + Ln;
@@ -346,39 +312,13 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_mfma(const RalfAttnDesc d)
                     s[blk] = mfma16(qa, kf[hk], (f32x4){0.f, 0.f, 0.f, 0.f});
                     dp[blk] = mfma16(ga, vf[hk], (f32x4){0.f, 0.f, 0.f, 0.f});
                 }
-                float pj[8];
-                if (!d.causal && s0 + 32 <= d.Sq) {
-                    // (a select, not a product with 0 / 1: a padded key whose score exceeds the row's log-sum-exp by > 128 in the log2 domain
-                    //  gives exp2 = +inf, and 0 * inf = NaN would poison dQ / dK / dV of the whole (batch, head))
-                    const bool km = kmasked[hk];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -L4[j >> 2][j & 3]));
-                        pj[j] = km ? 0.f : e;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int qi = s0 + (j >> 2) * 16 + 4 * g + (j & 3);
-                        const bool masked = kmasked[hk] || qi >= d.Sq || (d.causal && kj > qi);
-                        pj[j] = masked ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -L4[j >> 2][j & 3]));
-                    }
-                }
                 bf16x8 pf, dsf;
-                if (d.p_drop > 0.f) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const bool keep = attn_keep(R4[j >> 2][j & 3], (uint32_t)kj, thr);
-                        pf[j] = (bf16)(keep ? pj[j] * inv_keep : 0.f);
-                        dsf[j] = (bf16)(pj[j] * ((keep ? dp[j >> 2][j & 3] * inv_keep : 0.f) - D4[j >> 2][j & 3]));
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        pf[j] = (bf16)pj[j];
-                        dsf[j] = (bf16)(pj[j] * (dp[j >> 2][j & 3] - D4[j >> 2][j & 3]));
-                    }
-                }
+                // (masked probabilities are SELECTED zeros: a padded key whose score exceeds the row's log-sum-exp by > 128 in the log2 domain gives
+                //  exp2 = +inf, and 0 * inf = NaN would poison dQ / dK / dV of the whole (batch, head))
+                if (d.causal || s0 + 32 > d.Sq || any_kmasked)
+                    attn::bwd_step_keys<true>(s, dp, L4, D4, R4, scale2, kmasked[hk], d.causal != 0, kj, s0 + 4 * g, d.Sq, drop, thr, inv_keep, pf, dsf);
+                else
+                    attn::bwd_step_keys<false>(s, dp, L4, D4, R4, scale2, false, false, kj, s0 + 4 * g, d.Sq, drop, thr, inv_keep, pf, dsf);
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     // transposed fragments of the query tiles: matrix rows = 16 dims, k-slots = the step's 32 queries (frag_cols_T's slot order
@@ -435,6 +375,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_mfma(const RalfAttnDesc d)
             }
         }
     }
+    const float vscale = drop ? inv_keep : 1.f;   // (P went into the dV product unscaled)
 #pragma unroll
     for (int hk = 0; hk < 2; ++hk) {
         const int kj = kw0 + hk * 16 + Ln;
@@ -445,10 +386,216 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_mfma(const RalfAttnDesc d)
             for (int c = 0; c < 2; ++c) {
                 bf16x4 tk, tv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { tk[r] = (bf16)(dk[hk][c][r] * d.scale); tv[r] = (bf16)dv[hk][c][r]; }
+                for (int r = 0; r < 4; ++r) { tk[r] = (bf16)(dk[hk][c][r] * d.scale); tv[r] = (bf16)(dv[hk][c][r] * vscale); }
                 *reinterpret_cast<bf16x4*>(dKp + c * 16 + 4 * g) = tk;
                 *reinterpret_cast<bf16x4*>(dVp + c * 16 + 4 * g) = tv;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dQ, dK, dV in ONE pass for the decoder's CROSS-attention (a few dozen queries over hundreds of memory rows; dh = 32, not causal): one
+// workgroup of 8 waves per (batch, head), two of them per CU.  The per-query + per-key pair spends 24 + 33 us per layer on it (Sq = 51,
+// Sk = 532, B = 64): the per-key kernel is 4 608 workgroups that each stage the 51 query rows again for two steps of matrix work, the
+// per-query kernel walks nine key tiles behind two barriers each.  Here the <= 64 query rows (Q, dO, delta, lse, dropout row keys) are staged
+// ONCE; wave w owns the 32-key blocks w, w + 8, w + 16, ..: per block it forms S, P, dP, dS exactly as attn_bwd_fused_mfma does (lane = one
+// key), accumulates dK / dV of the block in registers over the two query steps and stores them, and adds the block's contribution to ITS
+// partial dQ (registers, all query steps) through the transpose-read of its private dS / K tiles -- no barrier inside the key loop.  The
+// eight partial dQ meet once at the end in LDS (the K / dS tiles' space) and are summed in wave order (deterministic).
+// dK / dV carry the bits of attn_bwd_dkv_mfma (same arithmetic, same query order); dQ sums the keys in another association than
+// attn_bwd_dq_mfma (per-wave partials) -- both are fp32 sums of the same bf16-rounded dS K products.
+// ------------------------------------------------------------------------------------------------
+constexpr int XB_Q = 64, XB_LD = 40, XB_SLD = XB_Q + 8, XB_SLOT_LD = 36;
+constexpr int XB_TILE = 32 * XB_LD + 32 * XB_SLD;   // per wave (elements): 32 key rows [32][40] | dS [32 keys][64 queries + pad]
+template <int WPS>   // waves per SIMD the register allocation aims at: 4 = two workgroups per CU (128 registers), 2 = one
+__global__ __launch_bounds__(512, WPS) void attn_bwd_cross_mfma(const RalfAttnDesc d) {
+    constexpr int DH = 32;
+    __shared__ __attribute__((aligned(16))) bf16 Qs[XB_Q * XB_LD];
+    __shared__ __attribute__((aligned(16))) bf16 Gs[XB_Q * XB_LD];
+    __shared__ __attribute__((aligned(16))) bf16 Tile[8 * XB_TILE];   // at the end: the partial dQ [32 queries][dim] per wave (fp32)
+    static_assert(sizeof(Tile) >= 8 * 32 * XB_SLOT_LD * 4, "the dQ slots reuse the tiles' space");
+    __shared__ __attribute__((aligned(16))) float Ls[XB_Q], Ds[XB_Q];
+    __shared__ __attribute__((aligned(16))) uint32_t Rk[XB_Q];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, Ln = lane & 15;
+    bf16* Kt = Tile + wave * XB_TILE;
+    bf16* St = Kt + 32 * XB_LD;
+    const WgId wg = wg_id(1, d.H);
+    const int b = wg.b, h = wg.h;
+    const bf16* Qp = (const bf16*)d.q + b * d.q_bs + (int64_t)h * DH;
+    const bf16* Kp = (const bf16*)d.k + b * d.k_bs + (int64_t)h * DH;
+    const bf16* Vp = (const bf16*)d.v + b * d.v_bs + (int64_t)h * DH;
+    const bf16* Op = (const bf16*)d.o + b * d.o_bs + (int64_t)h * DH;
+    const bf16* Gp = (const bf16*)d.dout + b * d.do_bs + (int64_t)h * DH;
+    const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * (d.kpm_bs ? d.kpm_bs : (int64_t)d.Sk) : nullptr;
+    const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
+    const uint32_t thr = attn_thr16(d.p_drop);
+    const float inv_keep = 1.f / (1.f - d.p_drop);
+    const float scale2 = d.scale * 1.4426950408889634f;
+    const int64_t stat0 = ((int64_t)b * d.H + h) * d.Sq;
+
+    // the fragments of the wave's first 16 keys: requested before the query rows are staged (one round trip for both)
+    bf16x8 kf_n = frag_global(Kp, d.k_rs, wave * 32, d.Sk, 0, lane), vf_n = frag_global(Vp, d.v_rs, wave * 32, d.Sk, 0, lane);
+
+    // ---- prologue: Q and dO rows into LDS, delta, lse (log2 domain), dropout row keys: 2 threads per query row, 16 dims each ----
+    if (tid < 2 * XB_Q) {
+        const int q = tid >> 1, half = tid & 1;
+        uint4 qv[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)}, gv[2] = {qv[0], qv[0]}, ov[2] = {qv[0], qv[0]};
+        if (q < d.Sq) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                qv[i] = *reinterpret_cast<const uint4*>(Qp + (int64_t)q * d.q_rs + half * 16 + i * 8);
+                gv[i] = *reinterpret_cast<const uint4*>(Gp + (int64_t)q * d.do_rs + half * 16 + i * 8);
+                ov[i] = *reinterpret_cast<const uint4*>(Op + (int64_t)q * d.o_rs + half * 16 + i * 8);
+            }
+        }
+        float dl = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<uint4*>(Qs + q * XB_LD + half * 16 + i * 8) = qv[i];
+            *reinterpret_cast<uint4*>(Gs + q * XB_LD + half * 16 + i * 8) = gv[i];
+            const bf16x8 gg = *reinterpret_cast<const bf16x8*>(&gv[i]), oo = *reinterpret_cast<const bf16x8*>(&ov[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += (float)gg[e] * (float)oo[e];
+        }
+        dl += wave::dpp<wave::QUAD_XOR1>(dl);
+        if (half == 0) {
+            Ds[q] = dl;
+            Ls[q] = q < d.Sq ? d.lse[stat0 + q] * 1.4426950408889634f : 0.f;
+            Rk[q] = d.p_drop > 0.f ? attn_rowkey(seed, d.call_id, ((uint64_t)b * d.H + h) * d.Sq + q) : 0u;
+            if (d.delta && q < d.Sq) d.delta[stat0 + q] = dl;
+        }
+    }
+    f32x4 dqa[2][2][2];   // [query step][16-query block][16-dim block]: this wave's partial dQ^T
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dqa[i >> 2][(i >> 1) & 1][i & 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const int nst = d.Sq > 32 ? 2 : 1;
+    const bool drop = d.p_drop > 0.f;
+    const float vscale = drop ? inv_keep : 1.f;   // (P goes into the dV product unscaled)
+
+    for (int kw0 = wave * 32; kw0 < d.Sk; kw0 += 8 * 32) {
+        // the block's key rows (for the transposed operand of dQ): requested now, stored into the wave's tile after the two key halves
+        uint4 krows[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = lane + 64 * i, r = e >> 2, c = e & 3;
+            krows[i] = *reinterpret_cast<const uint4*>(Kp + (int64_t)min(kw0 + r, d.Sk - 1) * d.k_rs + c * 8);   // (rows beyond Sk: their dS is zero)
+        }
+#pragma unroll
+        for (int hk = 0; hk < 2; ++hk) {
+            const int kj = kw0 + hk * 16 + Ln;
+            const bf16x8 kf = kf_n, vf = vf_n;
+            {   // the next 16 keys' fragments fly under this half's work: the block's second half, or the first half of the wave's next block
+                const int nk = hk == 0 ? kw0 + 16 : kw0 + 8 * 32;
+                kf_n = frag_global(Kp, d.k_rs, nk, d.Sk, 0, lane);
+                vf_n = frag_global(Vp, d.v_rs, nk, d.Sk, 0, lane);
+            }
+            const bool kmasked = kj >= d.Sk || (kpm && kpm[kj < d.Sk ? kj : 0]);
+            f32x4 dk[2], dv[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) dk[c] = dv[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            bf16* sr = St + (hk * 16 + Ln) * XB_SLD;   // the lane's key row of the dS tile
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int s0 = st * 32;
+                if (st >= nst) break;
+                const f32x4 L4[2] = {*reinterpret_cast<const f32x4*>(Ls + s0 + 4 * g), *reinterpret_cast<const f32x4*>(Ls + s0 + 16 + 4 * g)};
+                const f32x4 D4[2] = {*reinterpret_cast<const f32x4*>(Ds + s0 + 4 * g), *reinterpret_cast<const f32x4*>(Ds + s0 + 16 + 4 * g)};
+                // S[query][key], dP[query][key]: rows = 16 queries (LDS), columns = the 16 keys
+                f32x4 s[2], dp[2];
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qs + (s0 + blk * 16 + Ln) * XB_LD + g * 8);
+                    const bf16x8 ga = *reinterpret_cast<const bf16x8*>(Gs + (s0 + blk * 16 + Ln) * XB_LD + g * 8);
+                    s[blk] = mfma16(qa, kf, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    dp[blk] = mfma16(ga, vf, (f32x4){0.f, 0.f, 0.f, 0.f});
+                }
+                const attn::u32x4 R4[2] = {*reinterpret_cast<const attn::u32x4*>(Rk + s0 + 4 * g), *reinterpret_cast<const attn::u32x4*>(Rk + s0 + 16 + 4 * g)};
+                bf16x8 pf, dsf;
+                if (s0 + 32 > d.Sq || __builtin_amdgcn_ballot_w64(kmasked) != 0ull)   // (wave-uniform; masked probabilities are selected zeros)
+                    attn::bwd_step_keys<true>(s, dp, L4, D4, R4, scale2, kmasked, false, kj, s0 + 4 * g, d.Sq, drop, thr, inv_keep, pf, dsf);
+                else
+                    attn::bwd_step_keys<false>(s, dp, L4, D4, R4, scale2, false, false, kj, s0 + 4 * g, d.Sq, drop, thr, inv_keep, pf, dsf);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    // transposed fragments of the query tiles: matrix rows = 16 dims, k-slots = the step's 32 queries (the order pf / dsf hold them in)
+                    const bf16* qg = Gs + (s0 + 4 * g + (Ln >> 2)) * XB_LD + c * 16 + (Ln & 3) * 4;
+                    const bf16* qq = Qs + (s0 + 4 * g + (Ln >> 2)) * XB_LD + c * 16 + (Ln & 3) * 4;
+                    const bf16x4 glo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qg)), ghi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qg + 16 * XB_LD));
+                    const bf16x4 qlo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qq)), qhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qq + 16 * XB_LD));
+                    dv[c] = mfma16(__builtin_shufflevector(glo, ghi, 0, 1, 2, 3, 4, 5, 6, 7), pf, dv[c]);
+                    dk[c] = mfma16(__builtin_shufflevector(qlo, qhi, 0, 1, 2, 3, 4, 5, 6, 7), dsf, dk[c]);
+                }
+                // dS -> the wave's tile [key][query]: the lane's key row, queries s0 + 4g .. +3 and s0 + 16 + 4g .. +3
+                *reinterpret_cast<bf16x4*>(sr + s0 + 4 * g) = __builtin_shufflevector(dsf, dsf, 0, 1, 2, 3);
+                *reinterpret_cast<bf16x4*>(sr + s0 + 16 + 4 * g) = __builtin_shufflevector(dsf, dsf, 4, 5, 6, 7);
+            }
+            if (kj < d.Sk) {
+                bf16* dKp = (bf16*)d.dk + b * d.dk_bs + (int64_t)kj * d.dk_rs + (int64_t)h * DH;
+                bf16* dVp = (bf16*)d.dv + b * d.dv_bs + (int64_t)kj * d.dv_rs + (int64_t)h * DH;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    bf16x4 tk, tv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { tk[r] = (bf16)(dk[c][r] * d.scale); tv[r] = (bf16)(dv[c][r] * vscale); }
+                    *reinterpret_cast<bf16x4*>(dKp + c * 16 + 4 * g) = tk;
+                    *reinterpret_cast<bf16x4*>(dVp + c * 16 + 4 * g) = tv;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = lane + 64 * i;
+            *reinterpret_cast<uint4*>(Kt + (e >> 2) * XB_LD + (e & 3) * 8) = krows[i];
+        }
+        // partial dQ^T[dim][query] += K^T dS^T over the block's 32 keys (both operands through the transpose read: same k-slot order)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes above (no other wave touches its tiles)
+        bf16x8 ktf[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const bf16* kp2 = Kt + (4 * g + (Ln >> 2)) * XB_LD + db * 16 + (Ln & 3) * 4;
+            const bf16x4 klo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, kp2)), khi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, kp2 + 16 * XB_LD));
+            ktf[db] = __builtin_shufflevector(klo, khi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            if (st >= nst) break;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const bf16* sp = St + (4 * g + (Ln >> 2)) * XB_SLD + st * 32 + qb * 16 + (Ln & 3) * 4;
+                const bf16x4 slo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, sp)), shi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, sp + 16 * XB_SLD));
+                const bf16x8 sf = __builtin_shufflevector(slo, shi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) dqa[st][qb][db] = mfma16(ktf[db], sf, dqa[st][qb][db]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the next block rewrites the tiles)
+    }
+    // ---- the eight partial dQ: 32 queries per round through the tiles' space, summed in wave order ----
+    float* Slot = reinterpret_cast<float*>(Tile);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        if (st >= nst) break;
+        __syncthreads();   // every wave is done with its tiles (round 0) / with reading the previous round's slots
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int db = 0; db < 2; ++db)   // lane = query qb*16 + Ln, dims db*16 + 4g .. +3
+                *reinterpret_cast<f32x4*>(Slot + wave * 32 * XB_SLOT_LD + (qb * 16 + Ln) * XB_SLOT_LD + db * 16 + 4 * g) = dqa[st][qb][db];
+        __syncthreads();
+        const int q = tid >> 4, dp2 = (tid & 15) * 2;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const float2 v = *reinterpret_cast<const float2*>(Slot + w * 32 * XB_SLOT_LD + q * XB_SLOT_LD + dp2);
+            a0 += v.x; a1 += v.y;
+        }
+        if (st * 32 + q < d.Sq) {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            bf16x2 t;
+            t[0] = (bf16)(a0 * d.scale); t[1] = (bf16)(a1 * d.scale);
+            *reinterpret_cast<bf16x2*>((bf16*)d.dq + b * d.dq_bs + (int64_t)(st * 32 + q) * d.dq_rs + (int64_t)h * DH + dp2) = t;
         }
     }
 }
@@ -530,31 +677,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const RalfAttnDesc d) {
                     }
                 }
                 bf16x8 dsf;
-                float pj[8];
-                if (tile_masked || d.causal || !qok) {
-                    const uint32_t mw[2] = {*reinterpret_cast<const uint32_t*>(Ms + s0 + 4 * g), *reinterpret_cast<const uint32_t*>(Ms + s0 + 16 + 4 * g)};
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int key = t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3);
-                        const bool masked = ((mw[j >> 2] >> (8 * (j & 3))) & 0xffu) || (d.causal && key > qi) || !qok;
-                        pj[j] = masked ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -lse2));
-                    }
+                if (tile_masked || d.causal || !qok) {   // (wave-uniform ballot not needed: !qok only makes the slow path run for a whole wave's step)
+                    const uint32_t mw0 = *reinterpret_cast<const uint32_t*>(Ms + s0 + 4 * g), mw1 = *reinterpret_cast<const uint32_t*>(Ms + s0 + 16 + 4 * g);
+                    dsf = attn::bwd_step_queries<true>(s, dp, lse2, delta, scale2, mw0, mw1, d.causal != 0, t0 + s0 + 4 * g, qi, qok, d.p_drop > 0.f, rowkey, thr, inv_keep);
                 } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pj[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -lse2));
-                }
-                if (d.p_drop > 0.f) {
-#pragma unroll
-                    for (int j = 0; j < 8; j += 2) {
-                        const uint32_t h = attn_rng2x16(rowkey, (uint32_t)(t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3)) >> 1);
-                        const float d0 = (h & 0xffffu) >= thr ? dp[j >> 2][j & 3] * inv_keep : 0.f;
-                        const float d1 = (h >> 16) >= thr ? dp[(j + 1) >> 2][(j + 1) & 3] * inv_keep : 0.f;
-                        dsf[j] = (bf16)(pj[j] * (d0 - delta));
-                        dsf[j + 1] = (bf16)(pj[j + 1] * (d1 - delta));
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) dsf[j] = (bf16)(pj[j] * (dp[j >> 2][j & 3] - delta));
+                    dsf = attn::bwd_step_queries<false>(s, dp, lse2, delta, scale2, 0u, 0u, false, t0 + s0 + 4 * g, qi, true, d.p_drop > 0.f, rowkey, thr, inv_keep);
                 }
 #pragma unroll
                 for (int c = 0; c < DH / 16; ++c) dq[c] = mfma16(frag_cols_T<DH>(Ks, s0, c * 16, lane), dsf, dq[c]);
@@ -609,6 +736,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
     f32x4 dk[DH / 16], dv[DH / 16];
 #pragma unroll
     for (int c = 0; c < DH / 16; ++c) dk[c] = dv[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool drop = d.p_drop > 0.f;
+    const bool any_kmasked = __builtin_amdgcn_ballot_w64(kmasked) != 0ull;   // (wave-uniform)
+    const float vscale = drop ? inv_keep : 1.f;                               // (P goes into the dV product unscaled)
 
     TileRegs<DH> qreg, greg;
     tile_load<DH>(qreg, Qp, d.q_rs, 0, d.Sq);
@@ -647,35 +777,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
                 // the lane's 8 queries are two runs of 4: their statistics / row keys come as 16-byte LDS reads
                 const f32x4 L4[2] = {*reinterpret_cast<const f32x4*>(Ls + s0 + 4 * g), *reinterpret_cast<const f32x4*>(Ls + s0 + 16 + 4 * g)};
                 const f32x4 D4[2] = {*reinterpret_cast<const f32x4*>(Ds + s0 + 4 * g), *reinterpret_cast<const f32x4*>(Ds + s0 + 16 + 4 * g)};
-                float pj[8];
-                if (!d.causal && t0 + KT <= d.Sq) {   // wave-uniform: whole query tile valid, only this lane's key can be masked
-                    const float kz = kmasked ? 0.f : 1.f;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pj[j] = kz * __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -L4[j >> 2][j & 3]));
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int qi = t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3);
-                        const bool masked = kmasked || qi >= d.Sq || (d.causal && kj > qi);
-                        pj[j] = masked ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(s[j >> 2][j & 3], scale2, -L4[j >> 2][j & 3]));
-                    }
-                }
-                if (d.p_drop > 0.f) {
-                    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
-                    const u32x4v R4[2] = {*reinterpret_cast<const u32x4v*>(Rk + s0 + 4 * g), *reinterpret_cast<const u32x4v*>(Rk + s0 + 16 + 4 * g)};
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const bool keep = attn_keep(R4[j >> 2][j & 3], (uint32_t)kj, thr);
-                        pf[j] = (bf16)(keep ? pj[j] * inv_keep : 0.f);
-                        dsf[j] = (bf16)(pj[j] * ((keep ? dp[j >> 2][j & 3] * inv_keep : 0.f) - D4[j >> 2][j & 3]));
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        pf[j] = (bf16)pj[j];
-                        dsf[j] = (bf16)(pj[j] * (dp[j >> 2][j & 3] - D4[j >> 2][j & 3]));
-                    }
-                }
+                attn::u32x4 R4[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+                if (drop) { R4[0] = *reinterpret_cast<const attn::u32x4*>(Rk + s0 + 4 * g); R4[1] = *reinterpret_cast<const attn::u32x4*>(Rk + s0 + 16 + 4 * g); }
+                if (d.causal || t0 + KT > d.Sq || any_kmasked)   // (wave-uniform; masked probabilities are selected zeros)
+                    attn::bwd_step_keys<true>(s, dp, L4, D4, R4, scale2, kmasked, d.causal != 0, kj, t0 + s0 + 4 * g, d.Sq, drop, thr, inv_keep, pf, dsf);
+                else
+                    attn::bwd_step_keys<false>(s, dp, L4, D4, R4, scale2, false, false, kj, t0 + s0 + 4 * g, d.Sq, drop, thr, inv_keep, pf, dsf);
 #pragma unroll
                 for (int c = 0; c < DH / 16; ++c) {
                     dv[c] = mfma16(frag_cols_T<DH>(Gs, s0, c * 16, lane), pf, dv[c]);
@@ -692,7 +799,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const RalfAttnDesc d) {
         for (int c = 0; c < DH / 16; ++c) {
             bf16x4 tk, tv;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { tk[r] = (bf16)(dk[c][r] * d.scale); tv[r] = (bf16)dv[c][r]; }
+            for (int r = 0; r < 4; ++r) { tk[r] = (bf16)(dk[c][r] * d.scale); tv[r] = (bf16)(dv[c][r] * vscale); }
             *reinterpret_cast<bf16x4*>(dKp + c * 16 + 4 * g) = tk;
             *reinterpret_cast<bf16x4*>(dVp + c * 16 + 4 * g) = tv;
         }
@@ -1245,6 +1352,15 @@ int ralf_attention_bwd_mfma(const RalfAttnDesc& d, hipStream_t st) {
         d.dq_rs % 2 == 0) {
         hipLaunchKernelGGL(attn_bwd_fused_mfma, dim3(d.H * d.B), dim3(512), 0, st, d);
         return ralf::check_launch("attention_bwd_fused");
+    }
+    // a few dozen queries over a long memory (the decoder's cross-attention): one pass, one workgroup per (batch, head).  RALF_ATTN_BWD_CROSS=0: the pair below
+    static const int cross = [] { const char* e = getenv("RALF_ATTN_BWD_CROSS"); return e ? atoi(e) : 1; }();
+    if (cross && d.dh == 32 && !d.causal && d.Sq <= XB_Q && (cross == 2 || d.Sk >= 128) && d.q_rs % 8 == 0 && d.k_rs % 8 == 0 && d.v_rs % 8 == 0 && d.o_rs % 8 == 0 &&
+        d.do_rs % 8 == 0 && d.dq_rs % 2 == 0 && d.dk_rs % 4 == 0 && d.dv_rs % 4 == 0) {
+        static const int occ = [] { const char* e = getenv("RALF_ATTN_CROSS_OCC"); return e ? atoi(e) : 2; }();   // (4: 128 registers, 41 of them spilled: 53 us against 40)
+        if (occ == 4) hipLaunchKernelGGL(attn_bwd_cross_mfma<4>, dim3(d.H * d.B), dim3(512), 0, st, d);
+        else hipLaunchKernelGGL(attn_bwd_cross_mfma<2>, dim3(d.H * d.B), dim3(512), 0, st, d);
+        return ralf::check_launch("attention_bwd_cross");
     }
     const dim3 gq(ceil_div(d.Sq, 64) * d.H * d.B), gk(ceil_div(d.Sk, 64) * d.H * d.B);
     if (d.dh == 32) {

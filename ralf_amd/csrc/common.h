@@ -114,6 +114,8 @@ __device__ __forceinline__ uint32_t attn_rowkey(uint64_t seed, uint64_t call, ui
 // Full-rate integer instructions only (24-bit multiplies, shifts, xors): the attention kernels are VALU-bound on their per-score
 // work, and a 32-bit v_mul_lo_u32 costs four issue slots.  Checked on 4 M (row, key) pairs (also with sequential row keys):
 // keep rate 0.8998-0.9000 at p = 0.1; correlation within a pair, between pairs and between rows < 1.1e-3.
+// (A two-round form -- without the last multiply -- was tried: three instructions fewer per hash, keep rate and correlations ALONG a row as good,
+//  but masks of different streams / rows correlate at 0.5-2.5 % at p = 0.5, tools/dropout_hash_stats.py; the attention kernels gain ~5 % from it.  Not taken.)
 __device__ __forceinline__ uint32_t attn_rng2x16(uint32_t rowkey, uint32_t pair) {
     uint32_t x = rowkey ^ __umul24(pair, 0x9E3779u);
     x ^= x >> 16; x = __umul24(x, 0xEB352Du);

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "attn_core.h"
 
 namespace {
 typedef __bf16 bf16;
@@ -245,7 +246,6 @@ __device__ __forceinline__ void attn_tile(AttnState& st, const bf16* qt, int ldq
                                           int t0, int Sk, int Sq, float scale2, float p_drop, const uint32_t (&rowkey)[4], int lane) {
     const int g = lane >> 4, Ls = lane & 15;
     const uint32_t thr = attn_thr16(p_drop);
-    const float inv_keep = 1.f / (1.f - p_drop);
 #pragma unroll
     for (int qg = 0; qg < 4; ++qg) {
         if (qg * 16 >= Sq) break;                        // (wave-uniform)
@@ -262,62 +262,32 @@ __device__ __forceinline__ void attn_tile(AttnState& st, const bf16* qt, int ldq
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + (s0 + blk * 16 + Ls) * ldk + g * 8);
                 s[blk] = mfma16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f});
             }
-            float p[8];
-            float mt = -__builtin_inff();
-            if (tile_masked || CAUSAL) {
-                const uint32_t mw[2] = {*reinterpret_cast<const uint32_t*>(Ms + s0 + 4 * g), *reinterpret_cast<const uint32_t*>(Ms + s0 + 16 + 4 * g)};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int key = t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3);
-                    const bool masked = ((mw[j >> 2] >> (8 * (j & 3))) & 0xffu) || (CAUSAL && key > qi);
-                    p[j] = masked ? -__builtin_inff() : s[j >> 2][j & 3] * scale2;
-                    mt = fmaxf(mt, p[j]);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { p[j] = s[j >> 2][j & 3] * scale2; mt = fmaxf(mt, p[j]); }
-            }
-            mt = xor_max(mt);
-            const float mn = fmaxf(m, mt);
-            const float mref = mn > -__builtin_inff() ? mn : 0.f;
-            const float corr = __builtin_amdgcn_exp2f(m - mref);
-            float ls = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { p[j] = __builtin_amdgcn_exp2f(p[j] - mref); ls += p[j]; }
-            l = __fmaf_rn(l, corr, xor_sum(ls));
-            m = mn;
-            bf16x8 pf;
-            if (p_drop > 0.f) {
-#pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    const uint32_t hh = attn_rng2x16(rowkey[qg], (uint32_t)(t0 + s0 + (j >> 2) * 16 + 4 * g + (j & 3)) >> 1);
-                    pf[j] = (bf16)((hh & 0xffffu) >= thr ? p[j] * inv_keep : 0.f);
-                    pf[j + 1] = (bf16)((hh >> 16) >= thr ? p[j + 1] * inv_keep : 0.f);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (bf16)p[j];
-            }
+            const bool msk = tile_masked || CAUSAL;
+            uint32_t mw0 = 0u, mw1 = 0u;
+            if (msk) { mw0 = *reinterpret_cast<const uint32_t*>(Ms + s0 + 4 * g); mw1 = *reinterpret_cast<const uint32_t*>(Ms + s0 + 16 + 4 * g); }
+            const bf16x8 pf = attn::fwd_step<2>(s, m, l, st.o[qg], scale2, msk, mw0, mw1, CAUSAL, t0 + s0 + 4 * g, qi, p_drop > 0.f, rowkey[qg], thr);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 // V^T fragment: matrix rows = 16 columns (dims) of the value tile, k-slots = keys {s0+4g+j, s0+16+4g+(j-4)}
                 const bf16* q = vt + (s0 + 4 * g + (Ls >> 2)) * ldk + c * 16 + (Ls & 3) * 4;
                 const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q));
                 const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 16 * ldk));
-                st.o[qg][c] *= corr;
                 st.o[qg][c] = mfma16(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), pf, st.o[qg][c]);
             }
         }
         st.m[qg] = m; st.l[qg] = l;
     }
 }
-// normalise a head's output into the O strip (LDS, [64][LDA]; rows >= Sq zero) + lse
-__device__ __forceinline__ void attn_finish(const AttnState& st, int Sq, int h, bf16* Os, float* __restrict__ lse, int lane) {
+// normalise a head's output into the O strip (LDS, [64][LDA]; rows >= Sq zero) + lse.  st.m = maxima of the RAW scores, st.l = the lanes' shares of
+// the sums (attn::fwd_step); kept probabilities went into P V unscaled: the 1 / (1 - p) of the dropout is part of the normalisation here
+__device__ __forceinline__ void attn_finish(const AttnState& st, int Sq, int h, bf16* Os, float* __restrict__ lse, int lane, float scale, float p_drop) {
     const int g = lane >> 4, Ls = lane & 15;
+    const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
 #pragma unroll
     for (int qg = 0; qg < 4; ++qg) {
         const int qi = qg * 16 + Ls;
-        const float inv = 1.f / st.l[qg];
+        const float lsum = xor_sum(st.l[qg]);
+        const float inv = keep_scale / lsum;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             bf16x4 t;
@@ -325,7 +295,7 @@ __device__ __forceinline__ void attn_finish(const AttnState& st, int Sq, int h, 
             for (int r = 0; r < 4; ++r) t[r] = qi < Sq ? (bf16)(st.o[qg][c][r] * inv) : (bf16)0.f;
             *reinterpret_cast<bf16x4*>(Os + qi * LDA + h * TDH + c * 16 + 4 * g) = t;
         }
-        if (qi < Sq && g == 0) lse[qi] = __fmaf_rn(st.m[qg], 0.6931471805599453f, __logf(st.l[qg]));   // (as attn_fwd_mfma)
+        if (qi < Sq && g == 0) lse[qi] = __fmaf_rn(st.m[qg], scale, __logf(lsum));   // (as attn_fwd_mfma)
     }
 }
 
@@ -398,7 +368,7 @@ __global__ __launch_bounds__(NT) void tlayer_fwd_kernel(const RalfTLayerDesc d) 
             const bool tm = flags[0] != 0;
             if (d.causal) attn_tile<true>(st, bufB + h * TDH, LDQ, bufB + TD + h * TDH, bufB + 2 * TD + h * TDH, LDQ, Ms, tm, 0, S, S, scale2, d.p_attn, rowkey, lane);
             else attn_tile<false>(st, bufB + h * TDH, LDQ, bufB + TD + h * TDH, bufB + 2 * TD + h * TDH, LDQ, Ms, tm, 0, S, S, scale2, d.p_attn, rowkey, lane);
-            attn_finish(st, S, h, bufA, d.lse1 + ((int64_t)b * TH + h) * S, lane);
+            attn_finish(st, S, h, bufA, d.lse1 + ((int64_t)b * TH + h) * S, lane, d.scale, d.p_attn);
         }
         lds_barrier();
         TL_PROBE(3);

@@ -44,6 +44,7 @@ class Runtime:
         # streams = parallel branches of the captured graph; autograd replays every backward node on its forward stream, so
         # the branches' backward chains of tiny launch-latency-bound kernels overlap the big kernels of the image branch too
         self.branches = False
+        self.kv_ahead = os.environ.get("RALF_KV_AHEAD", "1") != "0"   # decoder: the memory's K/V projections ahead of the layers (Runtime.ahead)
         self._branch_streams: dict = {}
         self._branch_keep: list = []
         # engine mode (bf16): weight / bias gradients of the linear layers are COLLECTED during the backward and issued as grouped
@@ -171,7 +172,7 @@ class Runtime:
         if not (torch.is_grad_enabled() and x.requires_grad):
             return x
         a = _AliasFn.apply(x)
-        a._ralf_fan = [None]
+        a._ralf_fan = [None, 0]   # [the shared d(x) buffer, backwards still to come]
         return a
 
     def tag_dropout(self, y: torch.Tensor, p: float, call: int):
@@ -296,6 +297,27 @@ class Runtime:
         torch.cuda.current_stream().wait_stream(st)
         # tensors that cross streams stay allocated until the end of the step: the caching allocator only orders reuse per stream
         self._branch_keep.extend(o for o in outputs if torch.is_tensor(o))
+
+    def ahead(self, fns, name: str):
+        """results of the independent products `fns` (all inputs ready on the current stream), issued NOW on the stream `name`: each result r carries
+        r._ralf_ready, the event its consumer on the current stream has to wait for (ops.tlayer_fwd does, just before the launch that reads r).
+        None unless the engine runs sub-networks on graph branches (then the caller computes them in line)."""
+        if not (self.branches and self.kv_ahead and self._main_stream is not None and torch.is_grad_enabled()):
+            return None
+        st = self._branch_streams.get(name)
+        if st is None:
+            st = self._branch_streams[name] = ops.own_stream(("branch", name))
+        st.wait_stream(torch.cuda.current_stream())
+        outs = []
+        with torch.cuda.stream(st):
+            for fn in fns:
+                r = fn()
+                ev = torch.cuda.Event()
+                ev.record(st)
+                r._ralf_ready = ev
+                outs.append(r)
+        self._branch_keep.extend(outs)   # allocated on `st`, read on the current stream: alive until the streams meet again (join_all_branches)
+        return outs
 
     def join_all_branches(self):
         """end of the backward: the branches' parameter-gradient kernels wrote into the flat buffer on their own streams"""
@@ -503,6 +525,8 @@ class LinearFn(Function):
         ctx.bias, ctx.p, ctx.call = b, p, call
         ctx.rt, ctx.has_b, ctx.has_res, ctx.xshape, ctx.rows = rt, b is not None, res is not None, x.shape, (r0, r1)
         ctx.fan = getattr(x, "_ralf_fan", None)   # (Runtime.fanout_alias)
+        if ctx.fan is not None:
+            ctx.fan[1] += 1
         rt.tag_dropout(y, p, call)
         return y.view(*x.shape[:-1], N)
 
@@ -530,6 +554,12 @@ class LinearFn(Function):
                 dx = ops.gemm(dy2, rt.lp(W)[r0:r1], nrow, K, N, b_kcontig=False)
                 if acc is not None:
                     acc[0] = dx
+            if acc is not None:
+                # The buffer goes to autograd from the LAST of the fan's backwards to run: the consumer of d(x) may sit on another stream than
+                # these products (Runtime.ahead), and autograd orders it behind the node that RETURNS the gradient only.
+                acc[1] -= 1
+                dx = acc[0] if acc[1] == 0 else None
+            if dx is not None:
                 dx = dx.view(ctx.xshape)
         if ctx.needs_input_grad[1]:
             gv = rt.gview(W)
@@ -1069,9 +1099,11 @@ class TLayerFn(Function):
         if cross:
             n2w, n2b, ciw, cib, cow, cob = params[6:12]
             W.update({"ln2": (n2w.detach(), n2b.detach()), "q_proj": (packed[2], cib.detach()[:x.shape[2]]), "out2": (packed[3], cob.detach())})
+            ready = getattr(kv, "_ralf_ready", None)   # (Runtime.ahead: kv was projected on another stream)
             kv = kv.contiguous()
         if x.shape[1] <= ops.TLAYER_MAX_ROWS:
-            t = ops.tlayer_fwd(x, W, causal=causal, kpm=kpm, kv=kv, p_attn=p, p_res=p, seed=rt.seed if p > 0.0 else None, calls=calls)
+            t = ops.tlayer_fwd(x, W, causal=causal, kpm=kpm, kv=kv, p_attn=p, p_res=p, seed=rt.seed if p > 0.0 else None, calls=calls,
+                               kv_ready=ready if cross else None)
         else:
             assert cross, "long encoder layers take TLNQKVFn / TFFNFn"
             t = _tlayer_fwd_long(x, W, (rt.lp(sow), rt.lp(params[8])[:x.shape[2]]), kv, kpm, causal, p, rt.seed if p > 0.0 else None, calls)

@@ -30,7 +30,7 @@ from ..helpers.task_preprocessor import PREPROCESSOR
 logger = logging.getLogger(__name__)
 _DTYPES = {"float32": torch.float32, "fp32": torch.float32, "bfloat16": torch.bfloat16, "bf16": torch.bfloat16}
 NEG_INF = -float("inf")
-_CONSTRAINT_FIRST = os.environ.get("RALF_CONSTRAINT_FIRST", "0") == "1"
+_CONSTRAINT_FIRST = os.environ.get("RALF_CONSTRAINT_FIRST", "1") != "0"
 
 
 def _num_classes(features) -> int:
@@ -776,7 +776,11 @@ class ConcateAuxilaryTaskConcateCrossAttnRetrievalAugmentedAutoreg(_GeneratorBas
         assert inputs["image"].size(1) == 4
         # three independent sub-networks; the two small ones run on their own graph branches (Runtime.branch: issued late,
         # started with the step)
-        # RALF_CONSTRAINT_FIRST (A/B): the constraint branch recorded FIRST, so that autograd reaches its backward LAST
+        # The constraint branch is recorded FIRST: its six launch-latency-bound layers then sit at the head of the captured graph and start with the
+        # step (recorded after the image encoder, the graph executor started them ~0.8 ms into the replay: they, not the fusion head, gated the
+        # decoder), and autograd reaches the branch's backward LAST, after it has issued the image encoder's -- recorded last, its ~50 tiny kernels
+        # per layer were enqueued in front of the fusion head's and the image encoder's backward and held those back by ~0.3 ms
+        # (profiles/r05_graph_timeline_*: -0.11 ms per step).  RALF_CONSTRAINT_FIRST=0: the round-4 order.
         cf = self._constraint_features(inputs) if _CONSTRAINT_FIRST else None
         mem = self._image_memory(inputs["image"])
         with rt.branch("retrieved"):

@@ -171,13 +171,20 @@ class TransformerDecoderLayer(nn.Module, _FFNMixin):
     def fusable(self, x, rt: Runtime) -> bool:
         return RF.tlayer_supported(x, rt, self.self_attn.d, self.self_attn.nhead, self.linear1.weight.shape[0], allow_long=True)
 
-    def forward(self, x, mem, rt: Runtime, tgt_kpm=None, stacked=None, packed=None):
+    def project_memory(self, mem, rt: Runtime):
+        """the memory's packed k | v projection [B, M, 2d] of this layer's cross-attention"""
+        sa, ca = self.self_attn, self.multihead_attn
+        return RF.linear(mem, ca.in_proj_weight, ca.in_proj_bias, rt=rt, rows=(sa.d, 3 * sa.d))
+
+    def forward(self, x, mem, rt: Runtime, tgt_kpm=None, stacked=None, packed=None, kv=None):
         """stacked = (kv_all, layer index, plan): this layer's cross-attention K/V were projected with all other layers' (BaseDecoder);
-        packed = this layer's weights in fragment order when the caller packed all layers in one launch"""
+        packed = this layer's weights in fragment order when the caller packed all layers in one launch; kv = project_memory(mem) when the
+        caller issued it ahead of the layer (BaseDecoder: on the projection stream)"""
         sa, ca = self.self_attn, self.multihead_attn
         if stacked is None and self.fusable(x, rt):
             # short target sequences: the memory's K/V projection (the one big product of the layer), then the layer in three launches
-            kv = RF.linear(mem, ca.in_proj_weight, ca.in_proj_bias, rt=rt, rows=(sa.d, 3 * sa.d))
+            if kv is None:
+                kv = self.project_memory(mem, rt)
             return RF.TLayerFn.apply(x, kv, tgt_kpm, True, rt.drop_p(self.p), rt, packed, *self._params())
         h, x = RF.layer_norm_skip(x, self.norm1.weight, self.norm1.bias, rt)
         x = self.self_attn.self_attn(h, x, rt, causal=True, kpm=tgt_kpm, p_attn=self.p, p_out=self.p)
@@ -304,8 +311,14 @@ class BaseDecoder(nn.Module):
             wb = [t for a in attns for t in (a.in_proj_weight, a.in_proj_bias)]
             kv_all = RF.CrossKVFn.apply(memory, plan, rt, *wb)
         packs = _pack_layers(layers, h, rt) if plan is None else None   # short sequences: every layer's weights in fragment order, one launch
+        # The six K/V projections of the memory depend on nothing a decoder layer computes: in engine mode they are issued AHEAD of the layers on a
+        # stream of their own (a parallel branch of the captured graph), beside the layers' 64 .. 100-workgroup launches that leave most of the chip
+        # idle; layer l waits for projection l just before its cross-attention (ops.tlayer_fwd).  Autograd replays their backward (the d(memory)
+        # products) on that stream too, so those leave the layers' backward chain as well.
+        kvs = rt.ahead([(lambda l=l: l.project_memory(memory, rt)) for l in layers], "kv") if packs is not None else None
         for li, layer in enumerate(layers):
-            h = layer(h, memory, rt, kpm, stacked=(kv_all, li, plan) if plan is not None else None, packed=packs[li] if packs else None)
+            h = layer(h, memory, rt, kpm, stacked=(kv_all, li, plan) if plan is not None else None, packed=packs[li] if packs else None,
+                      kv=kvs[li] if kvs else None)
         h = RF.layer_norm(h, self.head[0].weight, self.head[0].bias, rt)
         return RF.linear(h, self.head[1].weight, rt=rt, out_f32=True)
 

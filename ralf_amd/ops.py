@@ -728,7 +728,7 @@ def tlayer_pack(mats, transpose=()):
     return outs
 
 
-def tlayer_fwd(x, W, *, causal, kpm=None, kpm_stride=0, kv=None, p_attn=0.0, p_res=0.0, seed=None, calls=(0, 0, 0, 0, 0, 0), eps=1e-5):
+def tlayer_fwd(x, W, *, causal, kpm=None, kpm_stride=0, kv=None, p_attn=0.0, p_res=0.0, seed=None, calls=(0, 0, 0, 0, 0, 0), eps=1e-5, kv_ready=None):
     """one pre-norm transformer layer forward on SHORT sequences (ralf_tlayer_fwd): x [B, S <= 64, 256] bf16.
     W: dict of pairs -- LayerNorms "ln1", "ln3" (and "ln2") = (gamma, beta) fp32; linear layers "sa_in" [768, 256], "sa_out" [256, 256],
     "ffn1" [1024, 256], "ffn2" [256, 1024] (and "q_proj" [256, 256], "out2" [256, 256]) = (weight PACKED by tlayer_pack, fp32 bias).
@@ -776,6 +776,8 @@ def tlayer_fwd(x, W, *, causal, kpm=None, kpm_stride=0, kv=None, p_attn=0.0, p_r
         return t
     d.part = 1
     _call("ralf_tlayer_fwd", ctypes.byref(d))
+    if kv_ready is not None:   # kv comes from another stream (functional.Runtime.ahead): part 1 did not need it
+        torch.cuda.current_stream().wait_event(kv_ready)
     t["o2"], t["lse2"] = attention_fwd(t["q"], kv, kv, B, H, S, kv.shape[1], dm // H, 0, 0, dm, p_drop=p_attn, seed=seed, call_id=int(calls[2]))
     d.o2, d.part = _p(t["o2"]), 2
     if (B * S) % 32 == 0 and B * S < 8192 and not _STRIP64:   # part 2 is row-wise: 32-row strips of all samples' rows put twice as many (lighter) workgroups on the chip

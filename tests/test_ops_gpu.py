@@ -238,7 +238,8 @@ def ref_attention(q, k, v, H, causal, kpm, scale):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("B,H,Sq,Sk,dh,causal,pad", [(2, 8, 50, 50, 32, True, True), (2, 8, 70, 300, 32, False, False), (3, 4, 11, 11, 64, False, True),
-                                                      (2, 8, 256, 16, 64, False, False), (1, 8, 130, 130, 32, True, False)])
+                                                      (2, 8, 256, 16, 64, False, False), (1, 8, 130, 130, 32, True, False),
+                                                      (2, 8, 51, 532, 32, False, False), (3, 8, 64, 300, 32, False, True), (2, 8, 17, 129, 32, False, False)])
 def test_attention(dtype, B, H, Sq, Sk, dh, causal, pad):
     from ralf_amd import ops
 
@@ -652,7 +653,7 @@ def test_one_pass_attention_backward_equals_the_two_kernel_backward(tmp_path):
     res = {}
     for flag in ("2", "0"):
         path = str(tmp_path / f"attn_bwd{flag}.pt")
-        r = subprocess.run([sys.executable, "-c", _ATTN_BWD_CASES.format(root=root, path=path)], env=dict(os.environ, RALF_ATTN_BWD_FUSED=flag),
+        r = subprocess.run([sys.executable, "-c", _ATTN_BWD_CASES.format(root=root, path=path)], env=dict(os.environ, RALF_ATTN_BWD_FUSED=flag, RALF_ATTN_BWD_CROSS="0"),
                            capture_output=True, text=True, cwd=root)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         res[flag] = torch.load(path)
@@ -664,6 +665,41 @@ def test_one_pass_attention_backward_equals_the_two_kernel_backward(tmp_path):
         bad = ((a - b).abs() > tol).float().mean().item()
         assert (a - b).abs().max().item() <= 4 * tol and bad < 1e-3, (k, (a - b).abs().max().item(), tol, bad)
         assert b.abs().max().item() > 1e-3, k
+
+
+_ATTN_CROSS_CASES = _ATTN_BWD_CASES.replace("""for B, H, Sq, Sk, packed, causal, pad, p in [(4, 8, 256, 256, True, False, False, 0.1), (3, 8, 50, 50, True, True, True, 0.1), (2, 8, 50, 200, False, False, False, 0.0),
+                                             (2, 8, 256, 77, False, False, True, 0.1), (5, 8, 1, 33, False, False, False, 0.0), (2, 8, 33, 256, False, True, False, 0.1),
+                                             (2, 8, 40, 300, False, False, False, 0.1)]:""", """for B, H, Sq, Sk, packed, causal, pad, p in [(64, 8, 51, 532, False, False, False, 0.1), (3, 8, 64, 300, False, False, True, 0.1), (2, 8, 20, 129, False, False, False, 0.0),
+                                             (2, 8, 33, 40, False, False, True, 0.1), (1, 8, 64, 1000, False, False, False, 0.1), (2, 8, 5, 31, False, False, False, 0.0),
+                                             (2, 8, 50, 50, True, False, True, 0.1)]:""")
+assert _ATTN_CROSS_CASES != _ATTN_BWD_CASES
+
+
+def test_cross_attention_backward_in_one_pass_equals_the_two_kernel_backward(tmp_path):
+    """the decoder's cross-attention (<= 64 queries over a long memory, dh = 32, not causal) takes dQ, dK, dV from ONE pass (attn_bwd_cross_mfma:
+    one workgroup per (batch, head), each wave owns 32-key blocks; the default from 128 keys on, everywhere it fits with RALF_ATTN_BWD_CROSS=2 as
+    here); RALF_ATTN_BWD_CROSS=0 keeps the per-query + per-key kernels.  Same P, dropout mask and dS arithmetic; dQ sums per-wave partial
+    products in a fixed order instead of one accumulator chain: last-bit differences at most."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for flag in ("2", "0"):
+        path = str(tmp_path / f"attn_cross{flag}.pt")
+        r = subprocess.run([sys.executable, "-c", _ATTN_CROSS_CASES.format(root=root, path=path)],
+                           env=dict(os.environ, RALF_ATTN_BWD_CROSS=flag, RALF_ATTN_BWD_FUSED="0"), capture_output=True, text=True, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        res[flag] = torch.load(path)
+    assert set(res["2"]) == set(res["0"]) and len(res["2"]) == 13
+    for k in res["2"]:
+        a, b = res["2"][k].float(), res["0"][k].float()
+        assert torch.isfinite(a).all(), k
+        assert b.abs().max().item() > 1e-3, k
+        tol = 2.0 ** -7 * b.abs().max().item()   # one bf16 ulp at the tensor's scale
+        bad = ((a - b).abs() > tol).float().mean().item()
+        assert (a - b).abs().max().item() <= 4 * tol and bad < 1e-3, (k, (a - b).abs().max().item(), tol, bad)
 
 
 @pytest.mark.parametrize("dtype", DT)
