@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 20
+#define RALF_ABI_VERSION 21
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -192,6 +192,8 @@ typedef struct RalfWgradJob {
     const void* dy; const void* x; float* dw;
     int64_t rows, ld_dy, ld_x, ld_dw;
     int n_out, n_in, splitk, pad;
+    float* db;   /* may be NULL: fp32 [n_out] += column sums of dy (the bias gradient of the same layer: LinearFn.backward of
+                    train/models/common/common.py's nn.Linear / in_proj), taken from the dy tiles the product reads anyway; n_out % 256 == 0 */
 } RalfWgradJob;
 size_t ralf_wgrad_grouped_workspace_bytes(const RalfWgradJob* jobs, int njobs);
 int ralf_wgrad_grouped(const RalfWgradJob* jobs, int njobs, int dtype, void* workspace, size_t workspace_bytes, void* stream);

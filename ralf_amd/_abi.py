@@ -85,7 +85,7 @@ class RalfGemmDesc(ctypes.Structure):
 
 class RalfWgradJob(ctypes.Structure):
     _fields_ = [("dy", vp), ("x", vp), ("dw", vp), ("rows", i64), ("ld_dy", i64), ("ld_x", i64), ("ld_dw", i64),
-                ("n_out", i32), ("n_in", i32), ("splitk", i32), ("pad", i32)]
+                ("n_out", i32), ("n_in", i32), ("splitk", i32), ("pad", i32), ("db", vp)]
 
 
 class RalfColsumJob(ctypes.Structure):

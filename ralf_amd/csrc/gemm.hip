@@ -180,7 +180,7 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
 extern "C" size_t ralf_wgrad_grouped_workspace_bytes(const RalfWgradJob* jobs, int njobs) {
     size_t n = 0;
     for (int i = 0; jobs && i < njobs; ++i)
-        if (jobs[i].splitk > 1) n += (size_t)jobs[i].splitk * jobs[i].n_out * jobs[i].n_in * sizeof(float);
+        if (jobs[i].splitk > 1) n += (size_t)jobs[i].splitk * ((size_t)jobs[i].n_out * jobs[i].n_in + (jobs[i].db ? jobs[i].n_out : 0)) * sizeof(float);
     return n;
 }
 
@@ -193,6 +193,7 @@ extern "C" int ralf_wgrad_grouped(const RalfWgradJob* jobs, int njobs, int dtype
         RALF_REQUIRE(w.n_out >= 8 && w.n_in >= 8 && w.n_out % 8 == 0 && w.n_in % 8 == 0 && w.ld_dy % 8 == 0 && w.ld_x % 8 == 0 && w.ld_dw % 8 == 0,
                      "wgrad_grouped: job %d: dimensions and leading dimensions must be multiples of 8", i);
         RALF_REQUIRE(((uintptr_t)w.dy % 16) == 0 && ((uintptr_t)w.x % 16) == 0 && ((uintptr_t)w.dw % 16) == 0, "wgrad_grouped: job %d: operands must be 16-byte aligned", i);
+        RALF_REQUIRE(!w.db || (w.n_out % 256 == 0 && ((uintptr_t)w.db % 16) == 0), "wgrad_grouped: job %d: a bias gradient needs n_out %% 256 == 0 and a 16-byte aligned buffer", i);
     }
     return ralf_gemm_grouped_bf16(jobs, njobs, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -1,4 +1,6 @@
 // bf16 instantiations of the GEMM kernel (see gemm_impl.h); split from gemm.hip so the two element types build in parallel
+#include <vector>
+
 #include "gemm_impl.h"
 
 int ralf_gemm_dispatch_bf16(void* kparams, int nbatch, hipStream_t st) { return dispatch<bf16>(*(KParams*)kparams, nbatch, st); }
@@ -12,6 +14,8 @@ int ralf_gemm_reduce_bf16(void* kparams, int nbatch, int blocks, hipStream_t st)
 // some job splits its reduction, one gemm_grouped_reduce_kernel per chunk.
 int ralf_gemm_grouped_bf16(const void* jobs_v, int njobs, void* workspace, size_t workspace_bytes, hipStream_t st) {
     const RalfWgradJob* jobs = (const RalfWgradJob*)jobs_v;
+    // direct-to-LDS ring (gemm_impl.h GATHER 5, both operands row-contiguous): bit-identical, 81.9 -> 71.0 us per launch inside the step
+    static const int glds = [] { const char* e = getenv("RALF_GEMM_GLDS_GROUPED"); return e ? atoi(e) : 1; }();   // 0: off (A/B runs, tests)
     float* ws = (float*)workspace;
     size_t ws_used = 0;
     for (int j0 = 0; j0 < njobs; j0 += GROUP_MAX) {
@@ -25,6 +29,7 @@ int ralf_gemm_grouped_bf16(const void* jobs_v, int njobs, void* workspace, size_
             const RalfWgradJob& w = jobs[j0 + i];
             GJob& J = G.j[i];
             J.A = w.dy; J.B = w.x; J.C = w.dw; J.partial = nullptr;
+            J.db = glds ? w.db : nullptr; J.db_partial = nullptr;   // (the register-staged form has no column sums: ralf_colsum_grouped below)
             J.M = w.n_out; J.N = w.n_in; J.K = (int)w.rows; J.lda = (int)w.ld_dy; J.ldb = (int)w.ld_x; J.ldc = (int)w.ld_dw;
             const int ktiles = J.K / 64;
             int sk = w.splitk < 1 ? 1 : (w.splitk > ktiles ? ktiles : w.splitk);
@@ -46,13 +51,29 @@ int ralf_gemm_grouped_bf16(const void* jobs_v, int njobs, void* workspace, size_
                 GRed& r = R.j[R.njobs++];
                 r.partial = J.partial; r.C = J.C; r.per = (int64_t)J.M * J.N; r.ldc = J.ldc; r.N = J.N; r.splitk = sk; r.first = rfirst;
                 rfirst += ceil_div(r.per, 2048);
+                if (J.db) {   // the bias slabs [sk][M]: one more record of the same reduce kernel (a [1, M] matrix)
+                    if ((ws_used + (size_t)sk * J.M) * sizeof(float) > workspace_bytes) {
+                        ralf::set_error("wgrad_grouped: split-K workspace too small (%zu bytes)", workspace_bytes);
+                        return RALF_ERR_WORKSPACE;
+                    }
+                    J.db_partial = ws + ws_used;
+                    ws_used += (size_t)sk * J.M;
+                    GRed& rb = R.j[R.njobs++];
+                    rb.partial = J.db_partial; rb.C = J.db; rb.per = J.M; rb.ldc = J.M; rb.N = J.M; rb.splitk = sk; rb.first = rfirst;
+                    rfirst += ceil_div(rb.per, 2048);
+                }
             }
         }
-        // direct-to-LDS ring (gemm_impl.h GATHER 5, both operands row-contiguous): bit-identical, 81.9 -> 71.0 us per launch inside the step
-        static const int glds = [] { const char* e = getenv("RALF_GEMM_GLDS_GROUPED"); return e ? atoi(e) : 1; }();   // 0: off (A/B runs, tests)
         if (glds) hipLaunchKernelGGL((gemm_grouped_kernel<bf16, 2, 2, 8, 5>), dim3(first), dim3(512), 0, st, G);
         else hipLaunchKernelGGL((gemm_grouped_kernel<bf16, 2, 2, 8>), dim3(first), dim3(512), 0, st, G);
         if (R.njobs) hipLaunchKernelGGL(gemm_grouped_reduce_kernel, dim3(rfirst), dim3(256), 0, st, R);
+    }
+    if (!glds) {   // bias gradients of the register-staged form: the separate column-sum launch
+        std::vector<RalfColsumJob> cj;
+        for (int i = 0; i < njobs; ++i)
+            if (jobs[i].db) cj.push_back(RalfColsumJob{jobs[i].dy, jobs[i].db, jobs[i].ld_dy, (int)jobs[i].rows, jobs[i].n_out});
+        for (size_t i = 0; i < cj.size(); ++i)   // (its own constraint: cols % 256 == 0 -- checked there)
+            if (int rc = ralf_colsum_grouped(&cj[i], 1, RALF_BF16, st)) return rc;
     }
     return ralf::check_launch("wgrad_grouped");
 }

@@ -85,6 +85,8 @@ struct KParams {
     int mfast;        // tile order: 0 = column tiles fastest (consecutive workgroups of an XCD share an A tile: B small / L2-resident), 1 = row tiles fastest
     int kchunk;       // K range handled by one split (multiple of BK)
     float* partial;   // [split][batch][M][N] fp32 (splitk > 1)
+    float* colsum;    // grouped weight gradients (gemm_body<.., CS = true>): fp32 [M], += the column sums of the k-major A operand (the bias gradient
+    float* colsum_partial;   // that goes with dW = dy^T x), or NULL; splitk > 1: slabs [split][M] instead, summed by the grouped reduce kernel
     int vec_epi;      // leading dims / bases allow 4-wide epilogue accesses
     int fast;         // interior fast path: aligned operands, K range a multiple of BK (no per-tile bounds math)
     int tapuni;       // gather = 1 and channels % BK == 0: every k-tile lies inside one (kh, kw) tap
@@ -462,9 +464,10 @@ __device__ __forceinline__ void lds_barrier() {
 
 // the body of one workgroup: output tiles bid0, bid0 + grid_x, ... of batch entry z (grid_x matters only for persistent
 // launches).  Called by gemm_kernel (one problem per launch) and gemm_grouped_kernel (many problems per launch).
-template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW>
+template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW, bool CS = false>
 __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, const int grid_x, const int z, const int nbatch, unsigned char* lds_raw) {
     using X = TT<T>;
+    static_assert(!CS || (!AK && (GATHER == 5) && sizeof(T) == 2), "column sums of A: k-major bf16 A through the direct-to-LDS ring (the grouped weight gradients)");
     constexpr int VEC = X::VEC, BK = X::BK;
     constexpr int BM = 64 * FM, BN = 64 * FN;
     constexpr int LDRA = BM + X::RPAD, LDRB = BN + X::RPAD;
@@ -770,6 +773,11 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
 #pragma unroll
     for (int j = 0; j < WFN; ++j) gl_trb[j] = (unsigned)(tr_k * SB) + (((unsigned)(wn * WFN + j) * 64u) ^ ((unsigned)xkey(SB, tr_k) << 6)) + (unsigned)(tr_rowblk + tr_c) * 2u;
     // one k-tile of MFMAs from the staged LDS tile
+    // CS: the waves that own the tile's first column block (wn == 0, first column tile, when P.colsum is set) also sum the A fragments they read
+    // over k: sum_k A[k][m] = the bias gradient that goes with dW = dy^T x.  4 v_dot2_f32_bf16 per fragment (against a vector of ones) beside
+    // its 32-cycle MFMA; the separate column-sum launch re-read every dy from memory (0.19 ms per encoder-decoder step).
+    bool cs_on = false;
+    float csacc[FM];
     auto compute = [&](const T* la, const T* lb) {
         // the matrix core computes the TRANSPOSED tile: row operand = n-fragment (weights), column operand =
         // m-fragment, so accumulator register r of a lane holds (n = (r&3) + 8*(r>>2) + 4*(lane>>5), m = lane&31)
@@ -811,6 +819,19 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q));
                         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 4 * SA));
                         a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
+                if constexpr (CS) {
+                    if (cs_on) {   // (wave-uniform)
+                        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                        const bf16x2 ones = {(__bf16)1.f, (__bf16)1.f};
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) {
+                            csacc[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a[i], a[i], 0, 1), ones, csacc[i], false);
+                            csacc[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a[i], a[i], 2, 3), ones, csacc[i], false);
+                            csacc[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a[i], a[i], 4, 5), ones, csacc[i], false);
+                            csacc[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a[i], a[i], 6, 7), ones, csacc[i], false);
+                        }
                     }
                 }
 #pragma unroll
@@ -938,6 +959,11 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     }
     for (int bid = bid0;;) {
     const int c_m0 = m0, c_n0 = n0, c_split = split, c_kbeg = kbeg, c_nt = nt;   // the tile being COMPUTED
+    if constexpr (CS) {
+        cs_on = P.colsum != nullptr && c_n0 == 0 && wn == 0;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) csacc[i] = 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -1045,6 +1071,21 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
         if (PF == 2 && nt > 1) gload(ra1, rb1, rc1, kbeg + BK, okm1);
     }
 
+    if constexpr (CS) {
+        if (cs_on) {   // lane (l31, lh) holds the sum over its k-slices of fragment row l31: the two k-halves meet, the lower half stores
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                float a = csacc[i], b = csacc[i];
+                wave::swap32(a, b);
+                const float v = a + b;
+                const int m = c_m0 + wm * 32 * WFM + i * 32 + (lane & 31);
+                if (lane < 32 && m < d.M) {
+                    if (d.splitk > 1) P.colsum_partial[(int64_t)c_split * d.M + m] = v;
+                    else P.colsum[m] += v;
+                }
+            }
+        }
+    }
     RALF_PROBE(3);
     // ---- epilogue: lane holds 4 consecutive columns n per register group g = r>>2 ----
     // (no `continue`/`break` in these loops: they must unroll completely or the accumulators spill to scratch)
@@ -1196,10 +1237,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((GATHER == 6 || FM == 4 || gemm
 // transformer-sized problems.  Job records travel by value in the kernel arguments (graph-capture friendly).
 struct GJob {
     const void* A; const void* B; float* C; float* partial;
+    float* db; float* db_partial;   // bias gradient [M] += column sums of A (NULL: none), its split-K slabs [splitk][M]
     int M, N, K, lda, ldb, ldc, splitk, kchunk, tiles_n, nwg, first;   // first = first workgroup of the job
     int pad;
 };
-constexpr int GROUP_MAX = 48;
+constexpr int GROUP_MAX = 40;   // (the records travel in the kernel arguments: 4 KiB)
 struct GParams { int njobs; int pad[3]; GJob j[GROUP_MAX]; };
 
 template <typename T, int FM, int FN, int NW, int GATHER = 3>   // GATHER 3: register-staged, 5: direct-to-LDS ring
@@ -1222,12 +1264,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_grouped_kernel(
     d.bnb_x = nullptr; d.bnb_mask = nullptr; d.bnb_mean = nullptr; d.bnb_part = nullptr;
     P.tiles_n = J.tiles_n; P.tiles_m = J.nwg / J.tiles_n; P.nwg = J.nwg; P.kchunk = J.kchunk; P.partial = J.partial; P.mfast = 0;
     P.vec_epi = 2; P.fast = 1; P.tapuni = 0;
-    gemm_body<T, false, false, GATHER, FM, FN, 0, NW>(P, b - J.first, 1, 0, 1, lds_raw);
+    P.colsum = J.db; P.colsum_partial = J.db_partial;
+    gemm_body<T, false, false, GATHER, FM, FN, 0, NW, GATHER == 5>(P, b - J.first, 1, 0, 1, lds_raw);
 }
 
 // C_j += sum over the k-splits of job j's slabs (jobs with splitk > 1 only); first = first workgroup, 2048 outputs per workgroup
 struct GRed { const float* partial; float* C; int64_t per; int ldc, N, splitk, first; };
-struct GRedParams { int njobs; int pad[3]; GRed j[GROUP_MAX]; };
+struct GRedParams { int njobs; int pad[3]; GRed j[2 * GROUP_MAX]; };   // (a job's weight slabs and its bias slabs)
 __global__ __launch_bounds__(256) void gemm_grouped_reduce_kernel(const GRedParams G) {
     const int b = (int)blockIdx.x;
     int ji = 0;

@@ -53,6 +53,7 @@ class Runtime:
         self.group_wgrads = False
         self.group_tiles = int(os.environ.get("RALF_WGRAD_GROUP_TILES", "100"))
         self.group_target_wgs = int(os.environ.get("RALF_WGRAD_GROUP_WGS", "2048"))
+        self.fold_bgrads = os.environ.get("RALF_FOLD_BGRADS", "1") != "0"   # bias gradients from the grouped weight-gradient product's dy tiles
         self._wjobs: list = []
         self._bjobs: list = []
         self._wtiles = 0
@@ -254,7 +255,26 @@ class Runtime:
         # reduction splits: one workgroup sustains ~1 TFLOP/s on a 128x128 tile (measured), so a launch wants ~1000 workgroups;
         # every split walks at least 4096 rows (slab traffic; 2048: +0.05 ms per step), tiny reductions stay whole
         want = max(1, self.group_target_wgs // max(self._wtiles, 1))
-        wj = [(dy, x, dw, max(1, min(want, dy.shape[0] // _GROUP_MIN_ROWS))) for dy, x, dw, _ in wj]
+        # a bias gradient whose dy is also the operand of a queued weight gradient rides on that product (ralf_wgrad_grouped: the column sums
+        # of the dy tiles it reads anyway); the others keep the column-sum launch
+        by_dy = {}
+        if self.fold_bgrads:
+            for i, (dy, into) in enumerate(bj):
+                by_dy.setdefault((dy.data_ptr(), dy.shape[0], dy.shape[1], dy.stride(0)), []).append(i)
+        taken = set()
+
+        def bias_of(dy):
+            hit = by_dy.get((dy.data_ptr(), dy.shape[0], dy.shape[1], dy.stride(0)))
+            if not hit or dy.shape[1] % 256 != 0:
+                return None
+            i = hit.pop(0)
+            if bj[i][1].data_ptr() % 16 != 0 or not bj[i][1].is_contiguous():
+                hit.insert(0, i)
+                return None
+            taken.add(i)
+            return bj[i][1]
+        wj = [(dy, x, dw, max(1, min(want, dy.shape[0] // _GROUP_MIN_ROWS)), bias_of(dy)) for dy, x, dw, _ in wj]
+        bj = [b for i, b in enumerate(bj) if i not in taken]
         self._wjobs, self._bjobs, self._wtiles = [], [], 0
 
         def run():

@@ -338,13 +338,18 @@ def copy2d_acc(src, dst, rows, cols, lds, ldd):
 
 
 def wgrad_grouped(jobs):
-    """jobs: list of (dy2d bf16 [rows, n_out], x2d bf16 [rows, n_in], dw fp32 view [n_out, n_in], splitk): dw += dy^T x for all jobs
-    in one launch (ralf_wgrad_grouped)."""
+    """jobs: list of (dy2d bf16 [rows, n_out], x2d bf16 [rows, n_in], dw fp32 view [n_out, n_in], splitk[, db fp32 [n_out] or None]):
+    dw += dy^T x (and db += column sums of dy, from the tiles the product reads anyway) for all jobs in one launch (ralf_wgrad_grouped)."""
     from ._abi import RalfWgradJob
 
     arr = (RalfWgradJob * len(jobs))()
-    for r, (dy, x, dw, sk) in zip(arr, jobs):
+    for r, job in zip(arr, jobs):
+        dy, x, dw, sk = job[:4]
+        db = job[4] if len(job) > 4 else None
         rows, n_out = dy.shape
+        if db is not None:
+            assert db.dtype == torch.float32 and db.is_contiguous() and db.numel() == n_out and n_out % 256 == 0
+            r.db = db.data_ptr()
         n_in = x.shape[1]
         assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32 and x.shape[0] == rows
         assert dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(1) == 1 and tuple(dw.shape) == (n_out, n_in)

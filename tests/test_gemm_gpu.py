@@ -217,6 +217,25 @@ def test_grouped_weight_gradients_match_per_layer_products():
     assert torch.equal(flat[off:], before[off:])                       # nothing written past the last job
     for (_, db), ref in zip(bjobs, brefs):
         assert ((db - ref).abs().max() / ref.abs().max()).item() < 2e-5
+    # the bias gradients riding on the weight-gradient products (RalfWgradJob.db: column sums of the dy tiles the product reads anyway), accumulated
+    # into a buffer that already holds something; whole reductions and the slab form
+    flat2 = before.clone()
+    jobs2, pre, off = [], [], 0
+    for (dy, x, _, sk), (rows, n_out, n_in, _) in zip(jobs, shapes):
+        db = torch.randn(n_out, device="cuda", generator=g) if n_out % 256 == 0 else None
+        pre.append(db.clone() if db is not None else None)
+        jobs2.append((dy, x, flat2[off:off + n_out * n_in].view(n_out, n_in), sk, db))
+        off += n_out * n_in
+    ops.wgrad_grouped(jobs2)
+    torch.cuda.synchronize()
+    assert torch.equal(flat2, flat)                                    # the weight gradients do not notice
+    nb = 0
+    for (dy, _, _, _, db), p0 in zip(jobs2, pre):
+        if db is not None:
+            ref = dy.float().sum(0)
+            assert (((db - p0) - ref).abs().max() / ref.abs().max()).item() < 2e-5
+            nb += 1
+    assert nb == len(bjobs)
 
 
 _FEW_ROW_SNIPPET = r"""
