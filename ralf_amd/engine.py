@@ -300,9 +300,20 @@ class _HostStager:
         self.events[self.cur] = ev
 
 
+def _tree_signature(x):
+    """shapes and dtypes of a batch tree's tensors (what a captured graph is specific to)"""
+    if torch.is_tensor(x):
+        return (tuple(x.shape), str(x.dtype))
+    if isinstance(x, dict):
+        return tuple((k, _tree_signature(v)) for k, v in sorted(x.items()) if v is not None)
+    return None
+
+
 def _copy_tree(dst, src, stager=None):
     if torch.is_tensor(dst):
         if dst is not src:   # a caller that filled the step's own buffers in place (static_batch()) pays no copy
+            # (copy_ would BROADCAST a size-1 tail batch into 64 rows and train on duplicates: the shapes were matched by the caller, checked again here)
+            assert dst.shape == src.shape, f"batch tensor of shape {tuple(src.shape)} for a graph captured on {tuple(dst.shape)}"
             if stager is not None and dst.is_cuda and not src.is_cuda and not src.is_pinned():
                 src = stager.mirror(dst, src)
             dst.copy_(src, non_blocking=True)
@@ -351,6 +362,14 @@ class TrainStep:
         self.loss = None
         self.outputs = None
         self.steps_done = 0
+        # A captured graph is specific to the SHAPES of its batch.  The reference's loader keeps the last, smaller batch of an epoch
+        # (drop_last=False, train/train.py:166) and the conditional tasks' constraint sequences have batch-dependent lengths
+        # (helpers/task_preprocessor.py: kmax = n_valid.max()): each new shape signature gets graphs of its own, up to `max_graph_shapes`
+        # of them (activations of every set stay allocated); further shapes run the same step eagerly -- same arithmetic, launch-bound.
+        self._by_shape: dict = {}
+        self._sig = None
+        self.max_graph_shapes = int(os.environ.get("RALF_MAX_GRAPH_SHAPES", "3"))
+        self.eager_fallbacks = 0
         # Data parallel: the backward runs in two stages around rt.grad_cut() (after layer2 of the ResNet).  Stage 1
         # (decoder, encoders, FPN, layer4, layer3) completes 94 % of the gradient bytes; their all-reduce runs on RCCL's
         # stream WHILE stage 2 (layer2, layer1, stem: most of the backbone's backward time, 6 % of the bytes) computes.
@@ -453,7 +472,20 @@ class TrainStep:
             torch.cuda.current_stream().wait_stream(self._run)
 
     def _step(self, inputs, targets):
-        if not self.use_graph:
+        sig = _tree_signature({"inputs": inputs, "targets": targets}) if self.use_graph else None
+        if self.use_graph and sig != self._sig:   # another batch shape than the last step's: its own graphs, or (cache full) the eager step
+            if self._sig is not None:
+                self._by_shape[self._sig] = (self._static, self._graphs, self.loss, self.outputs)
+            if sig in self._by_shape:
+                self._static, self._graphs, self.loss, self.outputs = self._by_shape[sig]
+                self._sig = sig
+            elif len(self._by_shape) + (self._sig is not None) < self.max_graph_shapes:
+                self._static, self._graphs, self._sig = None, None, sig
+            else:
+                sig = None
+        if not self.use_graph or sig is None:
+            if self.use_graph:
+                self.eager_fallbacks += 1
             self.loss = self._eager(inputs, targets)
         else:
             if self._graphs is None:
@@ -579,8 +611,13 @@ class GraphedAdamW(torch.optim.Optimizer):
     reference's loop does not read them).  Wrapping the model in the reference's DDPWrapper is fine: its own `zero_grad()` only drops `.grad`
     views the engine keeps a registry of, and its reducer never fires (the engine exchanges the flat gradient buffer itself)."""
 
-    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, max_norm: float = 0.0,
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, max_norm: Optional[float] = None,
                  loss_lag: int = 0, host_threads: Optional[int] = 16, **step_kw):
+        if max_norm is None:
+            # a silent default would train WITHOUT the reference's gradient clipping (training.clip_max_norm = 0.1): the loop's own
+            # clip_grad_norm_ finds no .grad to scale
+            raise TypeError("GraphedAdamW needs max_norm: the global-norm clip runs inside the captured step, not in the loop's clip_grad_norm_ "
+                            "(+optimizer.max_norm=${training.clip_max_norm}; max_norm=0 switches clipping off explicitly)")
         groups = [dict(g) for g in params]
         tokens = {g.get("ralf_model") for g in groups}
         assert len(tokens) == 1 and None not in tokens, "GraphedAdamW takes the groups returned by a ralf_amd generator's optim_groups()"
@@ -609,6 +646,7 @@ class GraphedAdamW(torch.optim.Optimizer):
         model._engine = self
 
     def train_step(self, inputs, targets):
+        self._follow_lr()   # a scheduler that stepped since the last update (per-epoch schedules step AFTER optimizer.step()) takes effect in THIS step
         loss = self.engine(inputs, targets)
         done = torch.cuda.Event()
         done.record(self.engine._run or torch.cuda.current_stream())
@@ -638,8 +676,13 @@ class GraphedAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        """the update itself ran inside train_loss(); here: a scheduler that rewrote param_groups[i]["lr"] (MultiStepLR and the
-        like scale every group by one factor) is followed through the device-resident factor the captured AdamW reads"""
+        """the update itself ran inside train_loss(); a scheduler that rewrote param_groups[i]["lr"] (MultiStepLR and the like scale every
+        group by one factor) is followed through the device-resident factor the captured AdamW reads -- here and at the top of train_step"""
+        self._follow_lr()
+        return None
+
+    @torch.no_grad()
+    def _follow_lr(self):
         fs = [g["lr"] / b for g, b in zip(self.param_groups, self._base_lrs) if b]
         if fs and abs(fs[0] - self._factor) > 1e-12 * max(1.0, abs(self._factor)):
             assert all(abs(f - fs[0]) <= 1e-9 * max(1.0, abs(fs[0])) for f in fs), "per-group learning-rate schedules need a re-capture (not supported)"

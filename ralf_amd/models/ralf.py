@@ -482,12 +482,13 @@ class _GeneratorBase(nn.Module):
 
     class _RelationState:
         """one sample of sample_relation between two decoder steps (retrieval_augmented_autoreg.py:372-383: input_, REL_COUNT, reset_num, idx)"""
-        __slots__ = ("seq", "flagged", "back_flag", "n_back", "resets", "idx", "rel", "con", "cond_seq", "done")
+        __slots__ = ("seq", "flagged", "back_flag", "n_back", "resets", "idx", "rel", "con", "cond_seq", "done", "rng")
 
-        def __init__(self, bos, rel, con, cond_seq):
+        def __init__(self, bos, rel, con, cond_seq, rng=random):
             self.seq = torch.full((1, 1), bos, dtype=torch.long)
             self.flagged, self.back_flag, self.n_back, self.resets, self.idx = [], False, 0, 0, 0
             self.rel, self.con, self.cond_seq, self.done = rel, con, cond_seq, False
+            self.rng = rng   # where the back-track positions come from: Python's global stream (the reference), or a generator of the sample's own
 
     def _relation_advance(self, st, logits, may_draw, env) -> bool:
         """the body of the reference's `while` loop after the decoder call (retrieval_augmented_autoreg.py:394-460) for ONE sample: `logits`
@@ -511,7 +512,7 @@ class _GeneratorBase(nn.Module):
                 return False
             st.flagged.append(st.idx)
             st.back_flag = True
-            st.idx = random.randint(2, max(2, st.idx - 1)) if draw else back_idx
+            st.idx = st.rng.randint(2, max(2, st.idx - 1)) if draw else back_idx
             st.seq = seq[:, :st.idx]
             st.n_back += 1
             if st.n_back > 30:
@@ -531,12 +532,13 @@ class _GeneratorBase(nn.Module):
             st.idx += 1
         return True
 
-    def _relation_lockstep(self, states, memory, env, dev, min_active):
+    def _relation_lockstep(self, states, memory, env, dev, min_active, independent=False):
         """All samples step TOGETHER while enough of them can: one decoder launch chain per step for the whole batch (every element at its own
         position), the masks and the control flow per sample on the host.  The reference's only cross-sample coupling is the global `random`
         stream, consumed in sample order: a sample whose step needs a draw waits ("parks", its state untouched) until every earlier sample has
         finished -- so the stream is consumed exactly as in the sequential loop and the tokens are the same.  Returns the batch cache (the
-        unfinished samples' prefixes live in it)."""
+        unfinished samples' prefixes live in it).
+        independent (rng="per_sample"): every sample draws from a generator of its own, so nobody waits and the loop runs until all are done."""
         ids, T = env[0], env[1]
         B = len(states)
         pool = self.__dict__.setdefault("_relation_lockstep_steps", {})
@@ -566,20 +568,21 @@ class _GeneratorBase(nn.Module):
                 while first_open < B and states[first_open].done:
                     first_open += 1
                 st = states[b]
-                if not self._relation_advance(st, logits[b:b + 1].clone(), b == first_open, env):
+                if not self._relation_advance(st, logits[b:b + 1].clone(), independent or b == first_open, env):
                     continue                             # parked: resumes in the sequential phase, after every earlier sample
                 if not st.done:
                     still.append(b)
             while first_open < B and states[first_open].done:
                 first_open += 1
-            if first_open < B and (not still or still[0] != first_open):
+            if not independent and first_open < B and (not still or still[0] != first_open):
                 still.insert(0, first_open)              # a parked sample whose turn to draw has come steps with the others again
             active = still
         return step.cache
 
     @torch.no_grad()
     def sample_relation(self, cond, batch_size: Optional[int] = None, sampling_cfg=None, return_violation: bool = False,
-                        prob_gate: float = 0.3, RELATION_SIZE: int = 10, use_graph: bool = True, lockstep: Optional[bool] = None, **kwargs):
+                        prob_gate: float = 0.3, RELATION_SIZE: int = 10, use_graph: bool = True, lockstep: Optional[bool] = None, rng: str = "shared",
+                        **kwargs):
         """Relation-constrained decoding with back-tracking (retrieval_augmented_autoreg.py:336-507): per sample, every step
         masks the vocabulary by (token mask, forced label, relation constraints); when nothing admissible is left (or only
         logits below `prob_gate`), the prefix is cut back to the element the violated constraint refers to (random position
@@ -592,7 +595,13 @@ class _GeneratorBase(nn.Module):
         available here: the constraint sequence lists the labels in SHUFFLED order while the forced label of a step follows the layout's own
         order (both as in the reference), so the first step of most samples admits no token at all, and with no element to go back to the
         reference draws the position from `random` -- 220 of 260 synthetic samples ask for a draw at their first step
-        (tools/relation_probe.py) and the loop is sequential from there: 126.3 against 126.7 ms per sample."""
+        (tools/relation_probe.py) and the loop is sequential from there: 126.3 against 126.7 ms per sample.
+        rng = "per_sample" (opt-in THROUGHPUT mode, NOT the reference's draw order): every sample draws its back-track positions from a
+        generator of its own, so no sample waits for another and the whole batch decodes in lock-step, one batched decoder step per token
+        (B = 256: 30 s -> under a second).  Sample 0 continues Python's global stream -- a batch of one decodes exactly as the sequential
+        loop does -- and leaves it where it stopped; sample b > 0 is seeded from that stream's state and b.  Same masks, same control flow per
+        sample, same distribution of the draws; only WHICH random number a sample sees differs from the reference."""
+        assert rng in ("shared", "per_sample")
         from ..helpers.relation_restriction import RelationConstraint
 
         self.preprocessor.set_relation_size(RELATION_SIZE)
@@ -614,11 +623,21 @@ class _GeneratorBase(nn.Module):
             # a stochastic draw consumes torch's generator at every step, in sample order: only argmax decoding leaves `random` as the one
             # shared stream, which the lock-step loop consumes in the reference's order
             lockstep = (os.environ.get("RALF_RELATION_LOCKSTEP", "0") == "1" and B >= 8 and dev.type == "cuda" and _get(sampling_cfg, "name") == "deterministic")
+        independent = rng == "per_sample"
+        gens = [random] * B
+        if independent:
+            g0 = random.Random()
+            g0.setstate(random.getstate())                      # sample 0 continues the global stream ...
+            probe = random.Random()
+            probe.setstate(random.getstate())
+            base = probe.getrandbits(64)                        # ... the others are seeded from its state (a copy draws: the stream itself is not consumed)
+            gens = [g0] + [random.Random((base + 0x9E3779B97F4A7C15 * b) & (2 ** 64 - 1)) for b in range(1, B)]
+            lockstep = dev.type == "cuda" and B > 1
         states = []
         for b in range(B):   # (a constraint object keeps the decode history of ITS sample)
             con = RelationConstraint(self.preprocessor)
-            states.append(self._RelationState(ids["bos"], con.prepare(seqc["seq"][b].cpu()), con, cond_seq[b:b + 1]))
-        batch_cache = self._relation_lockstep(states, memory, env, dev, max(2, B // 32)) if lockstep else None
+            states.append(self._RelationState(ids["bos"], con.prepare(seqc["seq"][b].cpu()), con, cond_seq[b:b + 1], gens[b]))
+        batch_cache = self._relation_lockstep(states, memory, env, dev, 1 if independent else max(2, B // 32), independent) if lockstep else None
         stepper = None
         if use_graph and not all(st.done for st in states):
             # the captured steps hold the cross-attention cache of ONE memory length (2 h w + K + Lc, and Lc is padded per batch):
@@ -654,6 +673,8 @@ class _GeneratorBase(nn.Module):
                 self._relation_advance(st, logits, True, env)
             # (sic) finished sequences are padded with the literal True (= token 1), retrieval_augmented_autoreg.py:475-483
             rows.append(torch.cat([st.seq, torch.full((1, T + 2 - st.seq.size(1)), 1, dtype=torch.long)], dim=1))
+        if independent:
+            random.setstate(gens[0].getstate())                 # (what the sequential loop would have left behind after ITS first sample)
         prepared = [st.rel for st in states]
         tokens = torch.cat(rows, dim=0)[:, 1:-1]
         result = self.postprocess({"seq": tokens})

@@ -339,3 +339,53 @@ def test_graphed_adamw_loss_lag_reports_the_previous_step(golden):
     (l0, p0), (l1, p1) = curves
     assert abs(l1[0] - l0[0]) < 2e-3 and all(abs(a - b) < 2e-3 for a, b in zip(l1[1:], l0[:-1])), (l0, l1)
     assert (p0 - p1).abs().max().item() <= 8e-4
+
+
+def _slice_batch(tree, n, lc=None):
+    """the first n samples of a batch tree (and, lc: constraint sequences cut to lc tokens, as a batch whose longest sample is shorter)"""
+    out = {}
+    for k, v in tree.items():
+        if isinstance(v, dict):
+            out[k] = _slice_batch(v, n)
+        elif torch.is_tensor(v) and v.dim() > 0:
+            v = v[:n]
+            if lc is not None and k in ("seq_layout_const", "seq_layout_const_pad_mask"):
+                v = v[:, :lc]
+            out[k] = v.contiguous()
+        else:
+            out[k] = v
+    return out
+
+
+def test_graphed_step_follows_the_batch_shape(golden):
+    """the reference's loader keeps the smaller last batch of an epoch (drop_last=False, train/train.py:166) and the conditional tasks'
+    constraint sequences have batch-dependent lengths (helpers/task_preprocessor.py): a captured graph must never be fed another shape.  Every
+    shape signature gets graphs of its own (up to max_graph_shapes), further shapes run the eager step; the sequence of losses and the weights
+    equal those of a step that never uses a graph."""
+    from ralf_amd.engine import TrainStep
+
+    m1, inputs, tgt = make(golden, "bfloat16")
+    m2, _, _ = make(golden, "bfloat16")
+    B, Lc = inputs["seq"].shape[0], inputs["seq_layout_const"].shape[1]
+    assert B >= 3 and Lc >= 4
+    batches = [(inputs, tgt), (_slice_batch(inputs, B - 1), _slice_batch(tgt, B - 1)), (inputs, tgt), (_slice_batch(inputs, B, Lc - 1), tgt),
+               (_slice_batch(inputs, 1), _slice_batch(tgt, 1)), (_slice_batch(inputs, B - 1), _slice_batch(tgt, B - 1)), (inputs, tgt)]
+    eager, graphed = TrainStep(m1, use_graph=False), TrainStep(m2, use_graph=True)
+    graphed.max_graph_shapes = 3
+    le = [eager(i, t).item() for i, t in batches]
+    lg = [graphed(i, t).item() for i, t in batches]
+    assert graphed.eager_fallbacks == 1 and len(graphed._by_shape) + 1 == 3      # the fourth shape (one sample) ran eagerly
+    assert graphed.steps_done == len(batches) == int(graphed.opt.step_dev)
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 2e-2 * max(1.0, abs(a)), (le, lg)
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        if p1.requires_grad:
+            assert (p1 - p2).abs().max().item() <= 2e-3, k      # seven Adam steps of lr 1e-4: sign flips at rounding level bound the distance
+
+
+def test_graphed_adamw_refuses_a_silent_clip_default(golden):
+    from ralf_amd.engine import GraphedAdamW
+
+    m, _, _ = make(golden, "bfloat16")
+    with pytest.raises(TypeError, match="max_norm"):
+        GraphedAdamW(params=m.optim_groups(base_lr=1e-4, weight_decay=1e-4))
