@@ -345,14 +345,28 @@ def bench_relation(device, N=10, B=256, dtype="bfloat16", sharpen=None, lockstep
         return c2
     model.sample(cond=sub(cond, 4), sampling_cfg=cfg, cond_type="relation", return_violation=True, use_backtrack=True, **kw)   # warm-up (graphs per position)
     torch.cuda.synchronize()
+    state = random.getstate()
     t0 = time.perf_counter()
     res, vio = model.sample(cond=cond, sampling_cfg=cfg, cond_type="relation", return_violation=True, use_backtrack=True, **kw)
     torch.cuda.synchronize()
     t = time.perf_counter() - t0
     assert res["label"].shape == (B, N)
-    return {"batch": B, "ms_per_batch": t * 1e3, "ms_per_sample": t * 1e3 / B, "relations_checked": int(vio["total"]), "relations_violated": int(vio["viorated"]),
-            "note": "sample_relation with back-tracking, deterministic draw, RELATION_SIZE 10; one decoder step per generated / re-generated token and sample "
-                    "(device, graph replay) + the constraint masks of layoutformerpp/relation_restriction.py on the host"}
+    out = {"batch": B, "ms_per_batch": t * 1e3, "ms_per_sample": t * 1e3 / B, "relations_checked": int(vio["total"]), "relations_violated": int(vio["viorated"]),
+           "note": "sample_relation with back-tracking, deterministic draw, RELATION_SIZE 10; one decoder step per generated / re-generated token and sample "
+                   "(device, graph replay) + the constraint masks of layoutformerpp/relation_restriction.py on the host.  The reference's order of draws "
+                   "from Python's global `random` (sample after sample) is kept: this is the exact mode"}
+    # opt-in throughput mode: a generator per sample, the whole batch in lock-step (models/ralf.py sample_relation rng="per_sample")
+    model.sample(cond=sub(cond, 4), sampling_cfg=cfg, cond_type="relation", return_violation=True, use_backtrack=True, rng="per_sample")   # warm-up
+    torch.cuda.synchronize()
+    random.setstate(state)
+    t0 = time.perf_counter()
+    res_p, vio_p = model.sample(cond=cond, sampling_cfg=cfg, cond_type="relation", return_violation=True, use_backtrack=True, rng="per_sample")
+    torch.cuda.synchronize()
+    tp = time.perf_counter() - t0
+    out["rng_per_sample"] = {"ms_per_batch": tp * 1e3, "ms_per_sample": tp * 1e3 / B, "relations_checked": int(vio_p["total"]), "relations_violated": int(vio_p["viorated"]),
+                             "note": "NOT the reference's draw order: every sample draws its back-track positions from a generator of its own (sample 0 continues the "
+                                     "global stream: a batch of one is the sequential loop), so the batch decodes in lock-step, one batched decoder step per token"}
+    return out
 
 
 def committed_kernel_avg_us(pattern, suffix="_knn_kernel_stats.txt"):

@@ -475,11 +475,11 @@ class TrainStep:
         sig = _tree_signature({"inputs": inputs, "targets": targets}) if self.use_graph else None
         if self.use_graph and sig != self._sig:   # another batch shape than the last step's: its own graphs, or (cache full) the eager step
             if self._sig is not None:
-                self._by_shape[self._sig] = (self._static, self._graphs, self.loss, self.outputs)
+                self._by_shape[self._sig] = (self._static, self._graphs, self.loss, self.outputs)   # (every captured set, the current one included)
             if sig in self._by_shape:
                 self._static, self._graphs, self.loss, self.outputs = self._by_shape[sig]
                 self._sig = sig
-            elif len(self._by_shape) + (self._sig is not None) < self.max_graph_shapes:
+            elif len(self._by_shape) < self.max_graph_shapes:
                 self._static, self._graphs, self._sig = None, None, sig
             else:
                 sig = None

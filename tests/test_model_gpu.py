@@ -40,7 +40,7 @@ class FeatStandIn(torch.nn.Module):
         self.pos = RN.pos2d_sine(h, w, C).to(feat.device)
 
     def forward(self, img, rt):
-        seq = self.feat.flatten(2).transpose(1, 2) + self.pos
+        seq = self.feat[: img.shape[0]].flatten(2).transpose(1, 2) + self.pos   # (a smaller batch: its first samples)
         return seq.to(rt.dtype).contiguous()
 
 
