@@ -371,16 +371,18 @@ int ralf_upsample_nearest_add(int dtype, const void* src, const void* lateral, v
 int ralf_upsample_nearest_bwd(int dtype, const void* g_up, int64_t ld_up, const void* g_sum, void* dsrc, int B, int IH, int IW, int OH, int OW, int C, void* stream);
 
 /* decode step tail (retrieval_augmented_autoreg.py:282-296; helpers/sampling.py:18-71): vocabulary mask of the
- * position (tokenizer.token_mask[i]), forced token from DECODE_SPACE_RESTRICTION (-1 = free), then argmax
- * (mode 0) or top-k multinomial with temperature (mode 1, counter-based RNG).  logits fp32 [B,V], V <= 1024. */
+ * position (tokenizer.token_mask[i]), forced token from DECODE_SPACE_RESTRICTION (-1 = free), then the choice of sampling.py:18-71:
+ * mode 0 argmax (`deterministic`), 1 `top_k`, 2 `top_p` (nucleus: candidates whose inclusive cumulative probability in descending order
+ * exceeds top_p are dropped, the first stays), 3 `random` (softmax(x / T)), 4 `gumbel`; one multinomial draw with a counter-based
+ * generator for modes 1-4.  logits fp32 [B,V], V <= 1024. */
 int ralf_mask_sample(const float* logits, const uint8_t* allowed, const int64_t* forced, int mode, int top_k, float temperature,
-                     const int64_t* seed, uint64_t call_id, int64_t* out, int B, int V, void* stream);
+                     const int64_t* seed, uint64_t call_id, int64_t* out, int B, int V, float top_p, void* stream);
 /* the same, and the chosen token also lands where the NEXT decode step reads it (no slice / compare / concatenate kernels between
  * steps): seq_out[b * seq_ld] = token (column of the [B, max_len+1] sequence buffer, may be NULL), pad_flag_out[b * flag_ld] =
  * (token == pad_id) (column of the uint8 key-padding mask of the self-attention, may be NULL) */
 int ralf_mask_sample_step(const float* logits, const uint8_t* allowed, const int64_t* forced, int mode, int top_k, float temperature,
                           const int64_t* seed, uint64_t call_id, int64_t* out, int64_t* seq_out, int64_t seq_ld, uint8_t* pad_flag_out,
-                          int64_t flag_ld, int64_t pad_id, int B, int V, void* stream);
+                          int64_t flag_ld, int64_t pad_id, int B, int V, float top_p, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused attention (ralf_amd/csrc/attention.hip): O = dropout(softmax(scale*Q K^T + mask)) V.

@@ -546,9 +546,15 @@ __global__ void upsample_bwd_kernel(const T* __restrict__ g1, int64_t ld1, const
 // per-row decode-space mask + token choice (one wave per row of fp32 logits [B,V]):
 //   allowed[c] == 0 -> -inf (tokenizer.token_mask row);  forced[b] >= 0 -> that token is the only candidate
 //   mode 0: argmax (first maximum);  mode 1: keep logits >= k-th largest, softmax(x/T), one multinomial draw
-//   with the counter-based generator (inverse CDF in lane-major order).
+//   with the counter-based generator (inverse CDF in lane-major order);
+//   mode 2 (top_p, helpers/sampling.py:35-58): with the candidates sorted by descending logit, those whose INCLUSIVE cumulative probability exceeds
+//           top_p are removed, the first always stays -- without a sort: the kept set is {x >= t} for the smallest t whose tail mass
+//           S(t) = sum of p over {x >= t} is <= top_p (the reference's cumulative sum at an element is S(its logit)), found by bisection over the
+//           ORDERED BIT PATTERNS of fp32 (32 steps of a masked wave sum), united with the arg-max; equal logits are kept or dropped together;
+//   mode 3 (random): softmax(x/T) over all candidates;  mode 4 (gumbel): x/T - log(-log(u + 1e-30) + 1e-30) with a counter-based u per candidate,
+//           then the same softmax + draw (as the reference does).
 __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ allowed,
-                                                           const int64_t* __restrict__ forced, int mode, int top_k, float temperature,
+                                                           const int64_t* __restrict__ forced, int mode, int top_k, float temperature, float top_p,
                                                            const int64_t* __restrict__ seed, uint64_t call, int64_t* __restrict__ out, int B, int V,
                                                            int64_t* __restrict__ seq_out, int64_t seq_ld, uint8_t* __restrict__ flag_out, int64_t flag_ld, int64_t pad_id) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -581,10 +587,24 @@ __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restric
         const int oi = __shfl_xor(bi, o);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
-    if (mode == 0 || top_k <= 1) { if (lane == 0) emit(bi); return; }
+    if (mode == 0 || (mode == 1 && top_k <= 1)) { if (lane == 0) emit(bi); return; }
+    const float invT = 1.f / temperature;
+    if (mode == 4) {   // Gumbel noise on the temperature-scaled logits; the maximum moves
+        best = NEG;
+#pragma unroll
+        for (int i = 0; i < MAXPER; ++i) {
+            const int c = lane + 64 * i;
+            if (v[i] > NEG) {
+                const float u = (rng24((uint64_t)seed[0], call, (1ull << 40) + (uint64_t)row * 1024 + c) + 0.5f) * (1.f / 16777216.f);
+                v[i] = v[i] * invT - __logf(-__logf(u + 1e-30f) + 1e-30f);
+            }
+            best = fmaxf(best, v[i]);
+        }
+        best = wave_max(best);
+    }
     // k-th largest value: peel the maximum k-1 times (ties are removed one at a time)
-    float kth = best;
-    {
+    float kth = mode == 1 ? best : NEG;
+    if (mode == 1) {
         float w[MAXPER];
 #pragma unroll
         for (int i = 0; i < MAXPER; ++i) w[i] = v[i];
@@ -605,10 +625,33 @@ __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restric
             kth = b2; wi = i2;
         }
     }
-    const float invT = 1.f / temperature;
+    const float pscale = mode == 4 ? 1.f : invT;   // (the Gumbel branch scaled its logits already)
     float p[MAXPER], ls = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXPER; ++i) { p[i] = v[i] >= kth && v[i] > NEG ? __expf((v[i] - best) * invT) : 0.f; ls += p[i]; }
+    for (int i = 0; i < MAXPER; ++i) { p[i] = v[i] >= kth && v[i] > NEG ? __expf((v[i] - best) * pscale) : 0.f; ls += p[i]; }
+    if (mode == 2) {
+        const float mass = wave_sum(ls) * top_p;   // un-normalised p: compare against top_p x total
+        // order-preserving map float -> uint (negative floats reversed); bisection for the smallest key t with S(t) <= mass
+        auto key_of = [](float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); };
+        uint32_t kv[MAXPER];
+#pragma unroll
+        for (int i = 0; i < MAXPER; ++i) kv[i] = key_of(v[i]);
+        uint32_t lo = 0u, hi = key_of(best);   // S(hi) may exceed the mass (then only the arg-max stays: it is united below); S(lo) = total
+        // invariant: S(hi_candidate) checked on the fly; find the smallest t in [lo, hi] with S(t) <= mass, or hi + 1 if none
+        uint32_t ans = 0xffffffffu;
+        for (int it = 0; it < 33 && lo <= hi; ++it) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXPER; ++i) sm += kv[i] >= mid ? p[i] : 0.f;
+            sm = wave_sum(sm);
+            if (sm <= mass) { ans = mid; if (mid == 0u) break; hi = mid - 1u; }
+            else { if (mid == 0xffffffffu) break; lo = mid + 1u; }
+        }
+        ls = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXPER; ++i) { if (!(kv[i] >= ans || lane + 64 * i == bi)) p[i] = 0.f; ls += p[i]; }
+    }
     // exclusive scan of the lane sums (lane-major CDF)
     float inc = ls;
 #pragma unroll
@@ -972,15 +1015,18 @@ extern "C" int ralf_upsample_nearest_bwd(int dtype, const void* g_up, int64_t ld
  * mode 0 deterministic (argmax), 1 top-k multinomial with temperature; out int64 [B] */
 extern "C" int ralf_mask_sample_step(const float* logits, const uint8_t* allowed, const int64_t* forced, int mode, int top_k, float temperature,
                                      const int64_t* seed, uint64_t call_id, int64_t* out, int64_t* seq_out, int64_t seq_ld, uint8_t* pad_flag_out,
-                                     int64_t flag_ld, int64_t pad_id, int B, int V, void* stream) {
+                                     int64_t flag_ld, int64_t pad_id, int B, int V, float top_p, void* stream) {
     RALF_REQUIRE(logits && out && B > 0 && V > 0 && V <= 1024, "mask_sample: bad arguments (V <= 1024)");
-    RALF_REQUIRE(mode == 0 || (mode == 1 && seed && top_k >= 1 && temperature > 0.f), "mask_sample: top-k sampling needs a seed, k >= 1, T > 0");
+    RALF_REQUIRE(mode >= 0 && mode <= 4, "mask_sample: mode 0 (argmax), 1 (top_k), 2 (top_p), 3 (random), 4 (gumbel)");
+    RALF_REQUIRE(mode == 0 || (seed && temperature > 0.f), "mask_sample: sampling needs a seed and T > 0");
+    RALF_REQUIRE(mode != 1 || top_k >= 1, "mask_sample: top-k sampling needs k >= 1");
+    RALF_REQUIRE(mode != 2 || (top_p > 0.f && top_p <= 1.f), "mask_sample: top-p sampling needs 0 < top_p <= 1");
     RALF_REQUIRE((!seq_out || seq_ld > 0) && (!pad_flag_out || flag_ld > 0), "mask_sample: output strides must be positive");
-    hipLaunchKernelGGL(mask_sample_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, logits, allowed, forced, mode, top_k, temperature, seed, call_id, out, B, V,
+    hipLaunchKernelGGL(mask_sample_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, logits, allowed, forced, mode, top_k, temperature, top_p, seed, call_id, out, B, V,
                        seq_out, seq_ld, pad_flag_out, flag_ld, pad_id);
     return ralf::check_launch("mask_sample");
 }
 extern "C" int ralf_mask_sample(const float* logits, const uint8_t* allowed, const int64_t* forced, int mode, int top_k, float temperature,
-                                const int64_t* seed, uint64_t call_id, int64_t* out, int B, int V, void* stream) {
-    return ralf_mask_sample_step(logits, allowed, forced, mode, top_k, temperature, seed, call_id, out, nullptr, 0, nullptr, 0, -1, B, V, stream);
+                                const int64_t* seed, uint64_t call_id, int64_t* out, int B, int V, float top_p, void* stream) {
+    return ralf_mask_sample_step(logits, allowed, forced, mode, top_k, temperature, seed, call_id, out, nullptr, 0, nullptr, 0, -1, B, V, top_p, stream);
 }

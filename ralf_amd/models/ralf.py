@@ -310,7 +310,7 @@ class _GeneratorBase(nn.Module):
         T = self.tokenizer.max_token_length
         name = _get(sampling_cfg, "name")
         cache = None
-        fused = name in ("deterministic", "top_k")   # vocabulary mask + restriction + choice in one kernel
+        fused = name in RN.ops.SAMPLING_MODES         # vocabulary mask + restriction + choice in one kernel (every sampling.py mode)
         forced_all = forced_tokens_all(cond_seq, cond_type, ids["pad"], ids["eos"], T) if fused else None
         if use_kv_cache and fused:
             # static buffers for the whole loop: the sampling kernel writes each token into its column of `seqbuf`, its
@@ -323,12 +323,12 @@ class _GeneratorBase(nn.Module):
             for j in range(start):   # prefix given by the condition (partial): fill the cache
                 RN.decoder_step(self.decoder, seqbuf[:, j].contiguous(), j, cache, self.rt, padbuf, kpm_stride=T + 1)
             tok = seqbuf[:, start].contiguous()
-            mode, k = (0 if name == "deterministic" else 1), int(_get(sampling_cfg, "top_k", 1) or 1)
-            temp = float(_get(sampling_cfg, "temperature", 1.0) or 1.0)
+            mode, k = RN.ops.SAMPLING_MODES[name], int(_get(sampling_cfg, "top_k", 1) or 1)
+            temp, top_p = float(_get(sampling_cfg, "temperature", 1.0) or 1.0), float(_get(sampling_cfg, "top_p", 1.0) or 1.0)
             for i in range(start, T):
                 logits = RN.decoder_step(self.decoder, tok, i, cache, self.rt, padbuf, kpm_stride=T + 1)
                 tok = RN.ops.mask_sample(logits, token_mask_u8[i], forced_all[i] if forced_all is not None else None, mode, k, temp,
-                                         self.rt.seed, 1000 + i, seq_col=seqbuf[:, i + 1], pad_flag_col=padbuf[:, i + 1], pad_id=ids["pad"])
+                                         self.rt.seed, 1000 + i, seq_col=seqbuf[:, i + 1], pad_flag_col=padbuf[:, i + 1], pad_id=ids["pad"], top_p=top_p)
             self.rt.advance_seed()   # on-device: the next call (or graph replay) draws different samples
             return seqbuf[:, 1:]
         if use_kv_cache:  # O(S) decoder work per sample instead of the reference's O(S^2) prefix recompute
@@ -342,9 +342,9 @@ class _GeneratorBase(nn.Module):
                 logits = self.decoder(seq, memory, self.rt, seq == ids["pad"])[:, i].clone()
             if fused:
                 forced = forced_all[i] if forced_all is not None else None
-                nxt = RN.ops.mask_sample(logits.float(), token_mask_u8[i], forced, 0 if name == "deterministic" else 1,
+                nxt = RN.ops.mask_sample(logits.float(), token_mask_u8[i], forced, RN.ops.SAMPLING_MODES[name],
                                          int(_get(sampling_cfg, "top_k", 1) or 1), float(_get(sampling_cfg, "temperature", 1.0) or 1.0),
-                                         self.rt.seed, 1000 + i)
+                                         self.rt.seed, 1000 + i, top_p=float(_get(sampling_cfg, "top_p", 1.0) or 1.0))
                 seq = torch.cat([seq, nxt.view(B, 1)], dim=1)
                 continue
             logits[:, ~token_mask[i]] = NEG_INF

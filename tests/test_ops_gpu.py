@@ -398,6 +398,55 @@ def test_mask_sample():
     assert torch.equal(draws, d3)
 
 
+def test_mask_sample_top_p_random_gumbel():
+    """ralf_mask_sample modes 2-4 against image2layout/train/helpers/sampling.py:18-71 (ralf_amd.helpers.sampling.sample restates it with torch
+    ops): the nucleus is the reference's kept SET (sort + inclusive cumulative sum; here a bisection, no sort), the draws follow the
+    renormalised softmax; `random` and `gumbel` follow softmax(x / T) (a Gumbel-perturbed softmax is checked through its argmax-free mean)"""
+    import torch.nn.functional as F
+
+    from ralf_amd import ops
+
+    g = torch.Generator().manual_seed(61)
+    V, n = 518, 40000
+    allowed = torch.rand(V, generator=g) > 0.3
+    seed = torch.tensor([11], dtype=torch.int64, device="cuda")
+    al = allowed.to(torch.uint8).cuda()
+    for T, top_p, spread in ((1.0, 0.9, 1.0), (0.7, 0.5, 2.0), (1.3, 0.999, 0.5), (1.0, 0.05, 3.0)):
+        row = torch.randn(V, generator=g) * spread
+        masked = row.masked_fill(~allowed, float("-inf"))
+        scaled = masked / T
+        srt, order = torch.sort(scaled, descending=True)
+        cum = torch.cumsum(F.softmax(srt, 0), 0)
+        keep_sorted = ~((cum > top_p) & (torch.arange(V) > 0))
+        kept = set(order[keep_sorted & (srt > float("-inf"))].tolist())
+        x = row.repeat(n, 1).cuda()
+        draws = ops.mask_sample(x, al, None, mode=ops.SAMPLING_MODES["top_p"], temperature=T, top_p=top_p, seed=seed, call_id=5).cpu()
+        got = set(draws.tolist())
+        pk = F.softmax(scaled, 0)
+        # the kept set: nothing outside it is ever drawn; everything in it that is likely enough to show up in n draws does
+        boundary = {int(order[i]) for i in range(V) if abs(float(cum[i]) - top_p) < 1e-5}       # (an element ON the threshold may round either way)
+        assert got <= kept | boundary, (T, top_p, sorted(got - kept))
+        likely = {i for i in kept if float(pk[i]) * n / sum(float(pk[j]) for j in kept) > 30}
+        assert likely <= got | boundary, (T, top_p)
+        want = torch.zeros(V); idx = torch.tensor(sorted(kept)); want[idx] = pk[idx] / pk[idx].sum()
+        freq = torch.bincount(draws, minlength=V).float() / n
+        assert (freq - want).abs().max() < 0.012, (T, top_p, (freq - want).abs().max())
+    row = torch.randn(V, generator=g) * 2
+    masked = row.masked_fill(~allowed, float("-inf"))
+    x = row.repeat(n, 1).cuda()
+    draws = ops.mask_sample(x, al, None, mode=ops.SAMPLING_MODES["random"], temperature=0.8, seed=seed, call_id=6).cpu()
+    freq = torch.bincount(draws, minlength=V).float() / n
+    assert (freq - F.softmax(masked / 0.8, 0)).abs().max() < 0.012 and not bool(freq[~allowed].any())
+    # gumbel: softmax(x / T + G) drawn once per row = a draw from a RANDOM distribution; its mean over rows is compared with a torch simulation
+    draws = ops.mask_sample(x, al, None, mode=ops.SAMPLING_MODES["gumbel"], temperature=0.8, seed=seed, call_id=7).cpu()
+    freq = torch.bincount(draws, minlength=V).float() / n
+    u = torch.rand(4000, V, generator=g)
+    sim = F.softmax(masked / 0.8 - torch.log(-torch.log(u + 1e-30) + 1e-30), 1).mean(0)
+    assert (freq - sim).abs().max() < 0.02 and not bool(freq[~allowed].any())
+    d2 = ops.mask_sample(x, al, None, mode=ops.SAMPLING_MODES["gumbel"], temperature=0.8, seed=seed, call_id=7).cpu()
+    assert torch.equal(draws, d2)
+
+
 @pytest.mark.parametrize("B,Sk,pad", [(3, 1, False), (5, 51, True), (4, 532, False), (2, 700, True)])
 def test_attention_decode_step(B, Sk, pad):
     """Sq = 1 streaming kernel (bf16, need_lse=False) on the KV-cache layout of nn.decoder_step: packed [K|V] rows,

@@ -148,9 +148,11 @@ def test_preprocess_drivers_end_to_end_on_a_saved_dataset(tmp_path):
             for k in ("center_x", "center_y", "width", "height"):
                 rows[k].append(rng.random(m).astype(np.float32).tolist())
         return ds.Dataset.from_dict(rows, features=feats)
-    dd = ds.DatasetDict({"train": split(150, 1000), "val": split(20, 5000), "test": split(20, 7000)})
+    dd = ds.DatasetDict({"train": split(150, 1000), "val": split(20, 5000), "test": split(20, 7000), "with_no_annotation": split(30, 9000)})
     root = tmp_path / "data" / "pku10"
     dd.save_to_disk(str(root))
+    dd_cgl = ds.DatasetDict({"train": split(120, 20000), "with_no_annotation": split(25, 30000)})
+    dd_cgl.save_to_disk(str(tmp_path / "data" / "cgl"))
     cache = tmp_path / "cache"
     build_retrieval_indexes.main(["--dataset_name", "pku", "--dataset_path", str(tmp_path / "data"), "--retrieval_backbone", "saliency",
                                   "--top_k", "32", "--save_scores", "--cache_dir", str(cache)])
@@ -164,6 +166,19 @@ def test_preprocess_drivers_end_to_end_on_a_saved_dataset(tmp_path):
             assert tables[sp][int(e["id"])] == (ref[i, 1:] if sp == "train" else ref[i, :32]).tolist(), (sp, i)
         assert (cache / f"pku_{sp}_saliency_wo_head_table_between_dataset_indexes_top_k32.pt").exists()
         assert (cache / f"pku_{sp}_saliency_wo_head_table_between_dataset_scores_top_k32.pt").exists()
+    # the cross-dataset driver (image2layout/preprocess/build_retrieval_indexes_cross_dataset.py:40-105): the unannotated split of each dataset
+    # against the other one's train-split index, all top_k + 1 hits kept
+    from ralf_amd.preprocess import build_retrieval_indexes_cross_dataset
+    build_retrieval_indexes_cross_dataset.main(["--dataset_path", str(tmp_path / "data"), "--retrieval_backbone", "saliency", "--top_k", "16", "--save_scores",
+                                                "--cache_dir", str(cache)])
+    emb = lambda d: np.stack([coarse_saliency(torch.as_tensor(np.asarray(e["saliency"]))) for e in d])   # noqa: E731
+    for src, ref_name, dsrc, dref in (("pku", "cgl", dd, dd_cgl), ("cgl", "pku", dd_cgl, dd)):
+        t = load_cache_table(str(cache / f"source_{src}_reference_{ref_name}_with_no_annotation_saliency_cross_dataset_indexes_top_k16.pt"), 17)
+        want, _ = knn_oracle.topk_ip(emb(dref["train"]), emb(dsrc["with_no_annotation"]), 17)
+        assert len(t) == len(dsrc["with_no_annotation"])
+        for i, e in enumerate(dsrc["with_no_annotation"]):
+            assert t[int(e["id"]) if src == "pku" else e["id"]] == want[i].tolist(), (src, i)
+        assert (cache / f"source_{src}_reference_{ref_name}_with_no_annotation_saliency_cross_dataset_scores_top_k16.pt").exists()
     # FIDNetV3 checkpoint as a DDP run would have written it: keys prefixed with "module." (the loader strips it and refuses a
     # checkpoint that leaves encoder keys unfilled)
     enc = LayoutEncoder(num_label=3)
