@@ -592,7 +592,14 @@ def main():
         torch.cuda.synchronize()
         group_ranks = torch.distributed.get_world_size()
         assert group_ranks == a.gpus and (one_device or torch.distributed.get_backend() == "nccl"), "the exchange must run on an RCCL group of --gpus ranks"
+        # replicas after the timed steps: the master weights of all ranks must be the SAME BITS (fixed-order norm reduction, identical averaged gradients)
+        chk = step.opt.P.view(torch.int32).to(torch.int64)
+        sig = torch.stack([chk.sum(), (chk * (1 + torch.arange(chk.numel(), device=chk.device) % 8191)).sum()])
+        lo, hi = sig.clone(), sig.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
         dp_info = {"rccl_ranks": group_ranks, "backend": torch.distributed.get_backend(), "wire": step.exchange.wire, "exchange": step.exchange.mode,
+                   "replicas_bit_identical": bool(torch.equal(lo, hi)),
                    "bytes_on_wire_per_step": step.exchange.bytes_on_wire([(0, nG)]),
                    "allreduce_ms_standalone": x0.elapsed_time(x1) / 5, "staged_backward": bool(step.staged),
                    "bytes_exchanged_during_stage2": step.exchange.bytes_on_wire(step._early) if step.staged else 0}

@@ -192,3 +192,30 @@ def test_b64_grouped_wgrads_and_branches_equal_plain_step():
         worst = max(worst, r)
         assert r < 5e-3, (k, r)       # identical bf16 products; fp32 sums in a different order
     assert worst > 0.0                 # (the two paths really ran different kernels)
+
+
+def test_b64_gradients_bf16_against_fp32_on_trained_weights_without_damping():
+    """the comparison of test_b64_train_step_bf16_against_fp32_whole_model WITHOUT damping the residual branches: the weights after 400 optimisation
+    steps of the benchmark's own recipe (bf16, learnable synthetic set) go into an fp32 and a bf16 model; gradients on a fresh batch.
+    What the data supports (tools/grad_agreement_trained.py, 1000 steps: profiles/r05_grad_agreement_trained.json): everything behind the backbone
+    agrees to cosine 0.98-0.9997 with norms within 10 %; the ResNet body does NOT -- cosine 0.75 (layer4) ... 0.2-0.4 (layer1-3, stem), before and
+    after training alike.  Its weight gradients are means of large, nearly cancelling per-position terms, so the 2^-9 rounding of every stored
+    activation moves them by their own size; loss, logits and the training curves (tests/test_convergence_gpu.py) agree.  The thresholds below state
+    exactly that and no more."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("grad_agreement_trained", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "grad_agreement_trained.py"))
+    ga = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ga)
+    dev = torch.device(DEV)
+    sd, batch, curve = ga.trained_state(400, dev)
+    assert curve[-1] < curve[0] - 1.5, curve                       # it trained (6.27 -> ~4)
+    res = ga.gradient_table(sd, batch, dev)
+    print("trained weights, no damping: bf16 vs fp32", res)
+    assert abs(res["loss_f32"] - res["loss_bf16"]) < 1e-2 * abs(res["loss_f32"]) and res["logits_cosine"] > 0.9995
+    for k, (c, r) in res["grad_cos_normratio"].items():
+        if ".body." in k:
+            assert c > 0.1 and 0.6 < r < 1.5, (k, c, r)                # positively correlated, comparable size: see the docstring
+        else:
+            assert c > 0.96 and abs(r - 1) < 0.15, (k, c, r)

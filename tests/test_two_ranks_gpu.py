@@ -130,10 +130,36 @@ def test_bench_two_ranks_on_one_gpu_prints_one_json_line(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["warmup"] == 1
     dp = d["config"]["data_parallel"]
     assert dp["rccl_ranks"] == 2 and dp["staged_backward"] and dp["bytes_on_wire_per_step"] > 0 and dp["allreduce_ms_standalone"] > 0
+    assert dp["replicas_bit_identical"]
     assert d["config"]["parallelism"] == "dp2" and d["value"] > 0
     # whole-job throughput: both ranks' tokens over the slowest rank's time
     assert abs(d["value"] - 2 * d["config"]["tokens_per_step_per_gpu"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "knn" not in d and "cpu_baseline" not in d        # single-GPU legs only run at N = 1
+
+
+def test_bench_two_ranks_on_real_rccl_when_two_gpus_are_visible():
+    """BASELINE config 3's transport itself: `bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per GPU,
+    backend nccl = RCCL over xGMI) -- runs only where a second GPU is visible, so that the first multi-GPU node does not meet untested code
+    (image2layout/train/helpers/distrubuted.py:10-31, train/train.py:52-61).  The gradient exchange must run on an RCCL group of two ranks and
+    leave both replicas with the same bits."""
+    import json
+    import subprocess
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the two-rank RCCL run needs two")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "RALF_BENCH_ONE_DEVICE"}
+    env.update(OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    dp = d["config"]["data_parallel"]
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert dp["rccl_ranks"] == 2 and dp["backend"] == "nccl" and dp["replicas_bit_identical"] and dp["bytes_on_wire_per_step"] > 0
 
 
 def _rank_knn(rank, world, port, out_dir):
