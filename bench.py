@@ -29,10 +29,13 @@ PEAK_HBM_GBS = 8000.0
 
 
 def measured_traffic(key):
-    """HBM bytes per launch from the NEWEST committed PMC summary profiles/r*_hbm_traffic.json (written by tools/pmc_total.py from
-    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this very workload: FETCH_SIZE x 2 (gfx950 correction for
-    wide coalesced reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE).  bench.py cannot run the profiler on itself inside the timed
-    region; None when no profile of the workload has been committed.  -> (bytes, entry dict) or (None, None)"""
+    """Bytes per launch that crossed the L2 <-> fabric boundary, from the NEWEST committed PMC summary profiles/r*_hbm_traffic.json (written by
+    tools/pmc_total.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this very workload: FETCH_SIZE x 2 + WRITE_SIZE).
+    Calibrated in profiles/r05_pmc_fetch_write_calibration.txt: a 4 GiB streaming copy reports FETCH_SIZE = exactly half its read bytes (the gfx950
+    correction of MI355X_MICROARCH.md "HBM") and WRITE_SIZE = its written bytes; a 64 MiB ping-pong that lives in the 256 MB infinity cache reports
+    THE SAME per-copy values -- the counters sit on the L2's memory side and count infinity-cache hits like HBM accesses.  So this is an UPPER
+    bound on HBM bytes (what missed the 4 MiB L2s), not HBM traffic itself.  bench.py cannot run the profiler on itself inside the timed region;
+    None when no profile of the workload has been committed.  -> (bytes, entry dict) or (None, None)"""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
         try:
@@ -636,11 +639,15 @@ def main():
         tb, te = measured_traffic("train_step_B64_N10_bf16") if (B == 64 and N == 10 and a.dtype.startswith("b")) else (None, None)
         if tb:   # the same step seen from the memory side (measured PMC bytes / measured time)
             out["roofline"]["traffic"] = tb
-            out["roofline"]["note"] += (f"; traffic = PMC HBM bytes per step from {te['file']} ({2 * te['fetch_size_bytes'] / 1e9:.1f} GB fetched + "
-                                        f"{te['write_size_bytes'] / 1e9:.1f} GB written = {tb / (gpu_ms * 1e-3) / 1e12:.2f} TB/s): the step is as much HBM- as MFMA-shaped")
+            out["roofline"]["note"] += (f"; traffic = PMC bytes per step across the L2 <-> fabric boundary from {te['file']} ({2 * te['fetch_size_bytes'] / 1e9:.1f} GB fetched + "
+                                        f"{te['write_size_bytes'] / 1e9:.1f} GB written = {tb / (gpu_ms * 1e-3) / 1e12:.2f} TB/s).  FETCH_SIZE / WRITE_SIZE count infinity-cache "
+                                        "hits like HBM accesses (profiles/r05_pmc_fetch_write_calibration.txt): an UPPER bound on HBM bytes -- producer -> consumer round trips "
+                                        "of tensors below 256 MB are largely served by the infinity cache")
             gbs = tb / (gpu_ms * 1e-3) / 1e9
             out["roofline_hbm_view"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": tb,
-                                        "note": f"whole train step: measured HBM-side bytes per step ({te['file']}, not algorithmic bytes) / step time; BatchNorm passes and the 1x1 convolutions of layer1/2 dominate"}
+                                        "note": f"whole train step: measured L2-miss bytes per step ({te['file']}; infinity-cache hits included, not algorithmic bytes, NOT HBM bytes: "
+                                                "profiles/r05_pmc_fetch_write_calibration.txt) / step time against the HBM peak: an upper bound on the step's HBM-side load, "
+                                                "i.e. `frac` overstates how HBM-bound the step is; BatchNorm passes and the 1x1 convolutions of layer1/2 dominate the bytes"}
         if world == 1 and not a.skip_split:
             t_ed = bench_encdec(device, N, B, a.dtype, a.steps, not a.no_graph)
             f_ed = ENCDEC_GFLOP_PER_SAMPLE.get(N, 15.98) * 1e9 * B
