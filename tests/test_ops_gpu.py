@@ -263,26 +263,29 @@ def test_attention(dtype, B, H, Sq, Sk, dh, causal, pad):
     close(dq, q.grad, dtype, **tol); close(dk, k.grad, dtype, **tol); close(dv, v.grad, dtype, **tol)
 
 
-def test_attention_backward_padded_key_with_a_huge_score():
-    """one-pass backward (S = 256: the image encoder's shape): a PADDED key whose score exceeds the row's log-sum-exp by more than 128 in
-    the log2 domain makes exp2 overflow; its probability must be an exact zero (0 * inf would be NaN in dQ / dK / dV of the whole head)"""
+@pytest.mark.parametrize("Sq,Sk", [(256, 256), (130, 300), (51, 532)])
+def test_attention_backward_padded_key_with_a_huge_score(Sq, Sk):
+    """a PADDED key whose score exceeds the row's log-sum-exp by more than 128 in the log2 domain makes exp2 overflow; its probability must be an
+    exact zero in every backward kernel (0 * inf would be NaN in dQ / dK / dV of the whole head): the one-pass kernel (S = 256: the image
+    encoder's shape), the per-query + per-key pair (130 x 300) and the one-pass cross-attention kernel (51 x 532) -- all through the select in
+    attn::bwd_step_keys / bwd_step_queries (csrc/attn_core.h)"""
     from ralf_amd import ops
 
-    B, H, S, dh = 2, 8, 256, 32
+    B, H, dh = 2, 8, 32
     d = H * dh
-    q, k, v = (rnd(B, S, d, seed=s, dtype=torch.bfloat16).float() for s in (60, 61, 62))
+    q, k, v = (rnd(B, S, d, seed=s, dtype=torch.bfloat16).float() for S, s in ((Sq, 60), (Sk, 61), (Sk, 62)))
     k[0, 7] = q[0].mean(0) * 0 + 60.0 * torch.sign(q[0, 3])     # key 7 of sample 0: score ~ 60 * |q|_1 * dh^-0.5 >> every other score
     q, k, v = (t.requires_grad_(True) for t in (q, k, v))
-    kpm = torch.zeros(B, S, dtype=torch.bool); kpm[0, 7] = True; kpm[1, 200:] = True
+    kpm = torch.zeros(B, Sk, dtype=torch.bool); kpm[0, 7] = True; kpm[1, Sk - 56:] = True
     o = ref_attention(q, k, v, H, False, kpm, dh ** -0.5)
-    go = rnd(B, S, d, seed=63, dtype=torch.bfloat16).float()
+    go = rnd(B, Sq, d, seed=63, dtype=torch.bfloat16).float()
     o.backward(go)
     dev = lambda t: t.detach().to(torch.bfloat16).cuda()
     qd, kd, vd = dev(q), dev(k), dev(v)
     kp = kpm.to(torch.uint8).cuda()
-    od, lse = ops.attention_fwd(qd, kd, vd, B, H, S, S, dh, kpm=kp)
+    od, lse = ops.attention_fwd(qd, kd, vd, B, H, Sq, Sk, dh, kpm=kp)
     dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
-    ops.attention_bwd(dev(go), qd, kd, vd, od, lse, dq, dk, dv, B, H, S, S, dh, kpm=kp)
+    ops.attention_bwd(dev(go), qd, kd, vd, od, lse, dq, dk, dv, B, H, Sq, Sk, dh, kpm=kp)
     for t in (od, dq, dk, dv):
         assert torch.isfinite(t.float()).all()
     tol = dict(atol=5e-2, rtol=5e-2)
