@@ -161,22 +161,52 @@ def _sample_ids(batch):
 
 
 _PINNED: dict = {}
+_PINNED_MAX = 6
+
+
+def _storage_unshared(t: torch.Tensor) -> bool:
+    """no tensor but `t` refers to t's storage (torch's own reference count of the storage: `t` and the temporary handle made here)"""
+    try:
+        return torch._C._storage_Use_Count(t.untyped_storage()._cdata) <= 2
+    except AttributeError:   # a torch without that hook: never reuse (every call gets a buffer of its own, up to the cap, then torch.cat)
+        return False
+
+
+def pinned_copy_issued(src: torch.Tensor, event) -> None:
+    """an asynchronous host-to-device copy that READS a cat_image staging buffer has been issued (models/ralf.py: _upload_batch): the buffer
+    is not rewritten before `event`"""
+    for ring in _PINNED.values():
+        for slot in ring["bufs"]:
+            if slot[0].data_ptr() == src.data_ptr():
+                slot[1] = event
 
 
 def cat_image(image: torch.Tensor, saliency: torch.Tensor) -> torch.Tensor:
     """torch.cat([image, saliency], dim=1) (helpers/task.py:78-80 of the reference).  On a GPU box the 4-channel batch (67 MB at B = 64,
     256 x 256) is assembled in a page-locked staging buffer by two multi-threaded slice copies: the loop's `.to(rank)` (train/train.py:434)
-    is then one DMA at PCIe rate instead of a pageable copy, and the single-threaded cat (10-13 ms of a 15 ms step) is gone.  Three
-    buffers rotate, so a batch stays valid while the next two are being built."""
+    is then one DMA at PCIe rate instead of a pageable copy, and the single-threaded cat (10-13 ms of a 15 ms step) is gone.
+    The buffers rotate, but a buffer is only ever REUSED when nothing refers to it any more: a caller that keeps the returned tensor (or a
+    view of it: a collected condition, a prefetched batch) keeps its buffer, and an asynchronous copy that reads it is waited for
+    (pinned_copy_issued).  With all buffers (at most six per shape) in use the plain torch.cat semantics apply."""
     if not (image.device.type == "cpu" and saliency.device.type == "cpu" and image.numel() >= (1 << 20) and torch.cuda.is_available()):
         return torch.cat([image, saliency], dim=1)
     B, C, H, W = image.shape
     key = (B, C + saliency.size(1), H, W, image.dtype)
-    ring = _PINNED.setdefault(key, {"bufs": [], "i": 0})
-    if len(ring["bufs"]) < 3:
-        ring["bufs"].append(torch.empty(key[:4], dtype=image.dtype, pin_memory=True))
-    buf = ring["bufs"][ring["i"] % len(ring["bufs"])]
-    ring["i"] += 1
+    ring = _PINNED.setdefault(key, {"bufs": []})
+    slot = None
+    for cand in ring["bufs"]:   # [pinned storage owner, event of the last asynchronous reader]
+        if _storage_unshared(cand[0]):   # only the ring itself refers to the storage: the tensor handed out last time (and every view of it) is gone
+            slot = cand
+            break
+    if slot is None:
+        if len(ring["bufs"]) >= _PINNED_MAX:
+            return torch.cat([image, saliency], dim=1)
+        slot = [torch.empty(key[:4], dtype=image.dtype, pin_memory=True), None]
+        ring["bufs"].append(slot)
+    if slot[1] is not None:
+        slot[1].synchronize()
+        slot[1] = None
+    buf = slot[0].view(key[:4])   # (a VIEW is handed out: its lifetime is what the use count above observes)
     buf[:, :C].copy_(image)
     buf[:, C:].copy_(saliency)
     return buf

@@ -24,7 +24,7 @@ from .. import nn as RN
 from .. import ops
 from ..functional import Runtime
 from ..helpers.sampling import DECODE_SPACE_RESTRICTION, _get, forced_tokens_all, sample as sample_tokens
-from ..helpers.task import COND_TYPES, cat_image, get_condition
+from ..helpers.task import COND_TYPES, cat_image, get_condition, pinned_copy_issued
 from ..helpers.task_preprocessor import PREPROCESSOR
 
 logger = logging.getLogger(__name__)
@@ -149,13 +149,18 @@ class _GeneratorBase(nn.Module):
                 src = slot[0]
             with torch.cuda.stream(cs):
                 slot[1].copy_(src, non_blocking=True)
+            if src is t and t.is_pinned():
+                pinned.append(t)           # (possibly a cat_image staging buffer: it must not be rewritten before this copy has read it)
             return slot[1]
 
         def walk(prefix, tree):
             return {k: (walk(prefix + k + "/", v) if isinstance(v, dict) else up(prefix + k, v)) for k, v in tree.items()}
+        pinned: list = []
         out_i, out_t = walk("i/", inputs), walk("t/", targets)
         ev = torch.cuda.Event()
         ev.record(cs)
+        for t in pinned:
+            pinned_copy_issued(t, ev)
         torch.cuda.current_stream().wait_event(ev)   # (asynchronous: readers on the loop's stream are ordered after the copies)
         st["last"] = j
         return out_i, out_t

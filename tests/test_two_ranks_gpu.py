@@ -204,16 +204,17 @@ def test_sharded_knn_two_ranks_on_the_hip_scan(tmp_path):
 
 def test_dp_selftest_is_as_fast_with_the_users_queue_setting_as_with_the_default():
     """the staged data-parallel step (three graphs around RCCL) depended on how its graph branches alias onto the hardware queues: 8 queues
-    ran it at 35.6 ms against 16.2 with ROCclr's default of 4.  The library now pins GPU_MAX_HW_QUEUES itself when it is
-    imported (ralf_amd/__init__.py): `bench.py --dp-selftest` (1-rank RCCL group, staged backward, overlapped exchange) started with
-    GPU_MAX_HW_QUEUES=8 in the environment must run like the one started without it"""
+    ran it at 35.6 ms against 16.2 with ROCclr's default of 4 (HISTORY.md section 5).  The package sets GPU_MAX_HW_QUEUES=4 when it is unset and
+    respects an exported value; bench.py -- a launcher of its own -- forces 4 for itself (RALF_FORCE_HW_QUEUES): `bench.py --dp-selftest`
+    (1-rank RCCL group, staged backward, overlapped exchange) started with GPU_MAX_HW_QUEUES=8 in the environment must run like the one
+    started without it"""
     import json
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ms = {}
     for name, extra in (("default", {}), ("user_sets_8", {"GPU_MAX_HW_QUEUES": "8"})):
-        env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "RALF_KEEP_HW_QUEUES")}
+        env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "RALF_FORCE_HW_QUEUES")}
         env.update(extra, MASTER_PORT=str(free_port()), PYTHONWARNINGS="ignore")
         cmd = [sys.executable, os.path.join(root, "bench.py"), "--dp-selftest", "--steps", "10", "--warmup", "3", "--skip-cpu", "--skip-knn", "--skip-split",
                "--skip-decode", "--skip-variants"]
