@@ -145,6 +145,8 @@ class _GeneratorBase(nn.Module):
                 slot = bufs[key] = (None if t.is_pinned() else torch.empty(t.shape, dtype=t.dtype, pin_memory=True), torch.empty(t.shape, dtype=t.dtype, device=dev))
             src = t
             if not t.is_pinned():
+                if slot[0] is None:   # (the key's first tensor was page-locked already, this one is not: cat_image ran out of staging buffers)
+                    slot = bufs[key] = (torch.empty(t.shape, dtype=t.dtype, pin_memory=True), slot[1])
                 slot[0].copy_(t)
                 src = slot[0]
             with torch.cuda.stream(cs):
@@ -161,6 +163,7 @@ class _GeneratorBase(nn.Module):
         ev.record(cs)
         for t in pinned:
             pinned_copy_issued(t, ev)
+        pinned.clear()   # (`walk` refers to itself: the closures form a reference cycle that only the cyclic collector frees -- it must not hold the staging buffers)
         torch.cuda.current_stream().wait_event(ev)   # (asynchronous: readers on the loop's stream are ordered after the copies)
         st["last"] = j
         return out_i, out_t
