@@ -382,7 +382,8 @@ int ralf_mask_sample(const float* logits, const uint8_t* allowed, const int64_t*
  * (token == pad_id) (column of the uint8 key-padding mask of the self-attention, may be NULL) */
 int ralf_mask_sample_step(const float* logits, const uint8_t* allowed, const int64_t* forced, int mode, int top_k, float temperature,
                           const int64_t* seed, uint64_t call_id, int64_t* out, int64_t* seq_out, int64_t seq_ld, uint8_t* pad_flag_out,
-                          int64_t flag_ld, int64_t pad_id, int B, int V, float top_p, void* stream);
+                          int64_t flag_ld, int64_t pad_id, int B, int V, float top_p, int row0, void* stream);
+/* row0: number of the first row in the WHOLE batch when a batch is decoded in slices (the counter-based draws are indexed by it) */
 
 /* ---------------------------------------------------------------------------------------------
  * Fused attention (ralf_amd/csrc/attention.hip): O = dropout(softmax(scale*Q K^T + mask)) V.

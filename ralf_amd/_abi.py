@@ -159,7 +159,7 @@ SIGNATURES.update({
     "ralf_upsample_nearest_add": (i32, [i32, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ralf_upsample_nearest_bwd": (i32, [i32, vp, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ralf_mask_sample": (i32, [vp, vp, vp, i32, i32, f32, vp, u64, vp, i32, i32, f32, vp]),
-    "ralf_mask_sample_step": (i32, [vp, vp, vp, i32, i32, f32, vp, u64, vp, vp, i64, vp, i64, i64, i32, i32, f32, vp]),
+    "ralf_mask_sample_step": (i32, [vp, vp, vp, i32, i32, f32, vp, u64, vp, vp, i64, vp, i64, i64, i32, i32, f32, i32, vp]),
     "ralf_attention_fwd": (i32, [ctypes.POINTER(RalfAttnDesc), vp]),
     "ralf_attention_bwd": (i32, [ctypes.POINTER(RalfAttnDesc), vp]),
     "ralf_decode_attn": (i32, [ctypes.POINTER(RalfDecodeAttnDesc), vp]),

@@ -64,7 +64,9 @@ int ralf_gemm_grouped_bf16(const void* jobs_v, int njobs, void* workspace, size_
                 }
             }
         }
-        if (glds) hipLaunchKernelGGL((gemm_grouped_kernel<bf16, 2, 2, 8, 5>), dim3(first), dim3(512), 0, st, G);
+        static const int nw4 = [] { const char* e = getenv("RALF_WGRAD_NW4"); return e ? atoi(e) : 0; }();   // A/B: 4 waves of 64 x 64 per 128 x 128 tile
+        if (glds && nw4) hipLaunchKernelGGL((gemm_grouped_kernel<bf16, 2, 2, 4, 5>), dim3(first), dim3(256), 0, st, G);
+        else if (glds) hipLaunchKernelGGL((gemm_grouped_kernel<bf16, 2, 2, 8, 5>), dim3(first), dim3(512), 0, st, G);
         else hipLaunchKernelGGL((gemm_grouped_kernel<bf16, 2, 2, 8>), dim3(first), dim3(512), 0, st, G);
         if (R.njobs) hipLaunchKernelGGL(gemm_grouped_reduce_kernel, dim3(rfirst), dim3(256), 0, st, R);
     }

@@ -556,9 +556,11 @@ __global__ void upsample_bwd_kernel(const T* __restrict__ g1, int64_t ld1, const
 __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ allowed,
                                                            const int64_t* __restrict__ forced, int mode, int top_k, float temperature, float top_p,
                                                            const int64_t* __restrict__ seed, uint64_t call, int64_t* __restrict__ out, int B, int V,
-                                                           int64_t* __restrict__ seq_out, int64_t seq_ld, uint8_t* __restrict__ flag_out, int64_t flag_ld, int64_t pad_id) {
+                                                           int64_t* __restrict__ seq_out, int64_t seq_ld, uint8_t* __restrict__ flag_out, int64_t flag_ld, int64_t pad_id,
+                                                           int row0) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
+    const uint64_t rrow = (uint64_t)row + (uint64_t)row0;   // the row's number in the WHOLE batch: a batch decoded in slices draws what the unsplit call draws
     auto emit = [&](int64_t tok) {   // lane 0: the token, its column of the sequence buffer, its key-padding flag
         out[row] = tok;
         if (seq_out) seq_out[(int64_t)row * seq_ld] = tok;
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restric
         for (int i = 0; i < MAXPER; ++i) {
             const int c = lane + 64 * i;
             if (v[i] > NEG) {
-                const float u = (rng24((uint64_t)seed[0], call, (1ull << 40) + (uint64_t)row * 1024 + c) + 0.5f) * (1.f / 16777216.f);
+                const float u = (rng24((uint64_t)seed[0], call, (1ull << 40) + rrow * 1024 + c) + 0.5f) * (1.f / 16777216.f);
                 v[i] = v[i] * invT - __logf(-__logf(u + 1e-30f) + 1e-30f);
             }
             best = fmaxf(best, v[i]);
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restric
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(inc, o); if (lane >= o) inc += t; }
     const float total = __shfl(inc, 63);
-    const float u = (rng24((uint64_t)seed[0], call, (uint64_t)row) + 0.5f) * (1.f / 16777216.f) * total;
+    const float u = (rng24((uint64_t)seed[0], call, rrow) + 0.5f) * (1.f / 16777216.f) * total;
     float acc = inc - ls;
     int pick = -1;
 #pragma unroll
@@ -1015,18 +1017,18 @@ extern "C" int ralf_upsample_nearest_bwd(int dtype, const void* g_up, int64_t ld
  * mode 0 deterministic (argmax), 1 top-k multinomial with temperature; out int64 [B] */
 extern "C" int ralf_mask_sample_step(const float* logits, const uint8_t* allowed, const int64_t* forced, int mode, int top_k, float temperature,
                                      const int64_t* seed, uint64_t call_id, int64_t* out, int64_t* seq_out, int64_t seq_ld, uint8_t* pad_flag_out,
-                                     int64_t flag_ld, int64_t pad_id, int B, int V, float top_p, void* stream) {
-    RALF_REQUIRE(logits && out && B > 0 && V > 0 && V <= 1024, "mask_sample: bad arguments (V <= 1024)");
+                                     int64_t flag_ld, int64_t pad_id, int B, int V, float top_p, int row0, void* stream) {
+    RALF_REQUIRE(logits && out && B > 0 && V > 0 && V <= 1024 && row0 >= 0, "mask_sample: bad arguments (V <= 1024)");
     RALF_REQUIRE(mode >= 0 && mode <= 4, "mask_sample: mode 0 (argmax), 1 (top_k), 2 (top_p), 3 (random), 4 (gumbel)");
     RALF_REQUIRE(mode == 0 || (seed && temperature > 0.f), "mask_sample: sampling needs a seed and T > 0");
     RALF_REQUIRE(mode != 1 || top_k >= 1, "mask_sample: top-k sampling needs k >= 1");
     RALF_REQUIRE(mode != 2 || (top_p > 0.f && top_p <= 1.f), "mask_sample: top-p sampling needs 0 < top_p <= 1");
     RALF_REQUIRE((!seq_out || seq_ld > 0) && (!pad_flag_out || flag_ld > 0), "mask_sample: output strides must be positive");
     hipLaunchKernelGGL(mask_sample_kernel, dim3((B + 3) / 4), dim3(256), 0, ST, logits, allowed, forced, mode, top_k, temperature, top_p, seed, call_id, out, B, V,
-                       seq_out, seq_ld, pad_flag_out, flag_ld, pad_id);
+                       seq_out, seq_ld, pad_flag_out, flag_ld, pad_id, row0);
     return ralf::check_launch("mask_sample");
 }
 extern "C" int ralf_mask_sample(const float* logits, const uint8_t* allowed, const int64_t* forced, int mode, int top_k, float temperature,
                                 const int64_t* seed, uint64_t call_id, int64_t* out, int B, int V, float top_p, void* stream) {
-    return ralf_mask_sample_step(logits, allowed, forced, mode, top_k, temperature, seed, call_id, out, nullptr, 0, nullptr, 0, -1, B, V, top_p, stream);
+    return ralf_mask_sample_step(logits, allowed, forced, mode, top_k, temperature, seed, call_id, out, nullptr, 0, nullptr, 0, -1, B, V, top_p, 0, stream);
 }

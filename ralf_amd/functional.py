@@ -88,6 +88,10 @@ class Runtime:
         self.fold_bn = True       # inference: eval-mode BatchNorm folded into the convolution epilogues (conv_bn_infer)
         # decode step: LayerNorm inside the few-row product that follows it (RalfGemmDesc.ln_*) and the four-wave split of the 256 x 256 x 1024
         # product (few_row_split) -- same arithmetic, other summation orders than the separate launches (off: their bits)
+        # KV-cached loop of large batches as independent row slices on streams of their own (models/ralf.py: decode_tokens).  OFF: measured at B = 256
+        # (tools/decode_once.py, same tokens): 31.6 ms for one chain, 35.7 for two slices, 40.5 for three, 46.6 for four -- the captured branches do
+        # not overlap their launch-latency-bound kernels, they add cross-queue hand-offs
+        self.decode_slices = int(os.environ.get("RALF_DECODE_SLICES", "1"))
         self.decode_ln_gemm = True
         self.decode_few_row_split = True
         self.conv_wgrad_direct = os.environ.get("RALF_CONV_WGRAD_DIRECT", "1") != "0"   # 3x3 / stride-1 weight gradients in the direct form (ops.conv3x3_wgrad)

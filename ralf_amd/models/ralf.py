@@ -330,13 +330,35 @@ class _GeneratorBase(nn.Module):
             padbuf = (seqbuf == ids["pad"]).to(torch.uint8)
             for j in range(start):   # prefix given by the condition (partial): fill the cache
                 RN.decoder_step(self.decoder, seqbuf[:, j].contiguous(), j, cache, self.rt, padbuf, kpm_stride=T + 1)
-            tok = seqbuf[:, start].contiguous()
             mode, k = RN.ops.SAMPLING_MODES[name], int(_get(sampling_cfg, "top_k", 1) or 1)
             temp, top_p = float(_get(sampling_cfg, "temperature", 1.0) or 1.0), float(_get(sampling_cfg, "top_p", 1.0) or 1.0)
-            for i in range(start, T):
-                logits = RN.decoder_step(self.decoder, tok, i, cache, self.rt, padbuf, kpm_stride=T + 1)
-                tok = RN.ops.mask_sample(logits, token_mask_u8[i], forced_all[i] if forced_all is not None else None, mode, k, temp,
-                                         self.rt.seed, 1000 + i, seq_col=seqbuf[:, i + 1], pad_flag_col=padbuf[:, i + 1], pad_id=ids["pad"], top_p=top_p)
+
+            def loop(b0, b1, c):   # rows b0 .. b1 - 1 of the batch through all steps (views of the loop's static buffers)
+                tok = seqbuf[b0:b1, start].contiguous()
+                pb = padbuf[b0:b1]
+                for i in range(start, T):
+                    logits = RN.decoder_step(self.decoder, tok, i, c, self.rt, pb, kpm_stride=T + 1)
+                    tok = RN.ops.mask_sample(logits, token_mask_u8[i], forced_all[i][b0:b1] if forced_all is not None else None, mode, k, temp,
+                                             self.rt.seed, 1000 + i, seq_col=seqbuf[b0:b1, i + 1], pad_flag_col=pb[:, i + 1], pad_id=ids["pad"], top_p=top_p, row0=b0)
+            # A decode step is a chain of ~45 launches that each occupy a fraction of the chip for 5-25 us (few-row products, the per-element
+            # attention blocks); elements never interact.  `Runtime.decode_slices` > 1 decodes a large batch as that many independent chains on
+            # streams of their own (parallel branches of the captured loop; same kernels, same per-row arithmetic, the same draws through
+            # mask_sample's row0).  Measured SLOWER than one chain (Runtime.decode_slices): off by default.
+            nsl = self.rt.decode_slices if (dev.type == "cuda" and B >= 64 * self.rt.decode_slices) else 1
+            if nsl <= 1:
+                loop(0, B, cache)
+            else:
+                cur = torch.cuda.current_stream()
+                bounds = [B * s // nsl for s in range(nsl + 1)]
+                streams = [ops.own_stream(("decode", s)) for s in range(nsl)]
+                for s, st in enumerate(streams):
+                    b0, b1 = bounds[s], bounds[s + 1]
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        loop(b0, b1, RN.DecodeCache([t[b0:b1] for t in cache.cross_kv], [t[b0:b1] for t in cache.self_kv], cache.max_len, cache.packed,
+                                                    cross_rows=cache.cross_rows, cross_packed=cache.cross_packed))
+                for st in streams:
+                    cur.wait_stream(st)
             self.rt.advance_seed()   # on-device: the next call (or graph replay) draws different samples
             return seqbuf[:, 1:]
         if use_kv_cache:  # O(S) decoder work per sample instead of the reference's O(S^2) prefix recompute

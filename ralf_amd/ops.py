@@ -1014,12 +1014,12 @@ SAMPLING_MODES = {"deterministic": 0, "top_k": 1, "top_p": 2, "random": 3, "gumb
 
 
 def mask_sample(logits, allowed=None, forced=None, mode=0, top_k=1, temperature=1.0, seed=None, call_id=0,
-                seq_col=None, pad_flag_col=None, pad_id=-1, top_p=1.0):
+                seq_col=None, pad_flag_col=None, pad_id=-1, top_p=1.0, row0=0):
     """decode-space mask + token choice on the device -> int64 [B].  seq_col / pad_flag_col: COLUMN views of the [B, L] int64
     sequence buffer / uint8 key-padding mask that also receive the token / (token == pad_id)."""
     B, V = logits.shape
     out = torch.empty(B, dtype=torch.int64, device=logits.device)
-    if seq_col is None and pad_flag_col is None:
+    if seq_col is None and pad_flag_col is None and row0 == 0:
         _call("ralf_mask_sample", _p(logits.contiguous()), _p(allowed), _p(forced), mode, top_k, temperature, _p(seed), call_id, _p(out), B, V, float(top_p))
         return out
 
@@ -1032,5 +1032,5 @@ def mask_sample(logits, allowed=None, forced=None, mode=0, top_k=1, temperature=
     sp, sl = col(seq_col, torch.int64)
     fp, fl = col(pad_flag_col, torch.uint8)
     _call("ralf_mask_sample_step", _p(logits.contiguous()), _p(allowed), _p(forced), mode, top_k, temperature, _p(seed), call_id, _p(out),
-          sp, sl, fp, fl, int(pad_id), B, V, float(top_p))
+          sp, sl, fp, fl, int(pad_id), B, V, float(top_p), int(row0))
     return out

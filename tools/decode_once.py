@@ -28,3 +28,4 @@ dec._graph.replay()
 e1.record()
 torch.cuda.synchronize()
 print("graph replay ms", e0.elapsed_time(e1))
+print("token checksum", int(sum((res[k].long() * (1 + i)).sum() for i, k in enumerate(("label", "mask"))).item()), float(res["center_x"].double().sum() + res["width"].double().sum()))
