@@ -12,7 +12,6 @@ interval [lo, hi) of admissible bins; intervals of all constraints on the curren
 """
 from __future__ import annotations
 
-import copy
 from math import ceil, floor
 from typing import List, Optional, Tuple
 
@@ -37,6 +36,14 @@ class _State:
     @property
     def finished(self) -> bool:
         return self.curr_element == self.num_elements and self.num_bbox >= 4
+
+    def copy(self) -> "_State":
+        """what copy.deepcopy gives for this record (ints and lists of ints), without its generic walk: 20 us per decode step and sample otherwise"""
+        c = _State.__new__(_State)
+        c.num_elements, c.curr_element, c.num_bbox = self.num_elements, self.curr_element, self.num_bbox
+        c.pred_labels = list(self.pred_labels)
+        c.pred_bbox = [list(b) for b in self.pred_bbox]
+        return c
 
 
 def _nth_occurrence(types: torch.Tensor, label: torch.Tensor, ordinal: int) -> int:
@@ -184,7 +191,7 @@ class RelationConstraint:
         """token_ids [1, L] (bos + L-1 decoded tokens) -> (mask [V] True = forbidden, back-track position or None)"""
         n_decoded = token_ids.size(1) - 1
         self.history = self.history[: n_decoded + 1]
-        st = copy.deepcopy(self.history[-1])
+        st = self.history[-1].copy()
         slot = n_decoded % 5
         if n_decoded > 0:
             last = int(token_ids[0, -1])

@@ -512,13 +512,14 @@ class _GeneratorBase(nn.Module):
 
     class _RelationState:
         """one sample of sample_relation between two decoder steps (retrieval_augmented_autoreg.py:372-383: input_, REL_COUNT, reset_num, idx)"""
-        __slots__ = ("seq", "flagged", "back_flag", "n_back", "resets", "idx", "rel", "con", "cond_seq", "done", "rng")
+        __slots__ = ("seq", "flagged", "back_flag", "n_back", "resets", "idx", "rel", "con", "cond_seq", "done", "rng", "forced")
 
-        def __init__(self, bos, rel, con, cond_seq, rng=random):
+        def __init__(self, bos, rel, con, cond_seq, rng=random, forced=None):
             self.seq = torch.full((1, 1), bos, dtype=torch.long)
             self.flagged, self.back_flag, self.n_back, self.resets, self.idx = [], False, 0, 0, 0
             self.rel, self.con, self.cond_seq, self.done = rel, con, cond_seq, False
             self.rng = rng   # where the back-track positions come from: Python's global stream (the reference), or a generator of the sample's own
+            self.forced = forced   # per step: the token DECODE_SPACE_RESTRICTION["relation"] forces (-1: free), tabulated once (helpers/sampling.forced_tokens_all)
 
     def _relation_advance(self, st, logits, may_draw, env) -> bool:
         """the body of the reference's `while` loop after the decoder call (retrieval_augmented_autoreg.py:394-460) for ONE sample: `logits`
@@ -528,7 +529,14 @@ class _GeneratorBase(nn.Module):
         seq = st.seq
         n_dec = seq.size(1) - 1
         logits[:, ~token_mask_h[n_dec]] = NEG_INF
-        logits = restrict(n_dec + 1, st.cond_seq, logits, pad_id=ids["pad"], eos_id=ids["eos"], max_length=T)
+        if st.forced is not None:   # the same restriction from the per-sample table: one kept logit instead of the generic [1, V] mask arithmetic
+            f = st.forced[n_dec]
+            if f >= 0:
+                keep = float(logits[0, f])
+                logits.fill_(NEG_INF)
+                logits[0, f] = keep
+        else:
+            logits = restrict(n_dec + 1, st.cond_seq, logits, pad_id=ids["pad"], eos_id=ids["eos"], max_length=T)
         raw = logits.clone()
         mask, back_idx = st.con(seq, st.rel)
         logits[:, mask] = NEG_INF
@@ -664,9 +672,11 @@ class _GeneratorBase(nn.Module):
             gens = [g0] + [random.Random((base + 0x9E3779B97F4A7C15 * b) & (2 ** 64 - 1)) for b in range(1, B)]
             lockstep = dev.type == "cuda" and B > 1
         states = []
+        forced_tab = forced_tokens_all(cond_seq, "relation", ids["pad"], ids["eos"], T)   # [T, B]: step i + 1 of sample b
+        forced_tab = forced_tab.t().tolist() if forced_tab is not None else [None] * B
         for b in range(B):   # (a constraint object keeps the decode history of ITS sample)
             con = RelationConstraint(self.preprocessor)
-            states.append(self._RelationState(ids["bos"], con.prepare(seqc["seq"][b].cpu()), con, cond_seq[b:b + 1], gens[b]))
+            states.append(self._RelationState(ids["bos"], con.prepare(seqc["seq"][b].cpu()), con, cond_seq[b:b + 1], gens[b], forced_tab[b]))
         batch_cache = self._relation_lockstep(states, memory, env, dev, 1 if independent else max(2, B // 32), independent) if lockstep else None
         stepper = None
         if use_graph and not all(st.done for st in states):
