@@ -32,3 +32,11 @@ def test_workspace_query_is_pure_host():
     assert L.ralf_knn_topk_ip_workspace_bytes(0, 64, 1, 16) == 0
     w = L.ralf_knn_topk_ip_workspace_bytes(61548, 1792, 1024, 17)
     assert w >= 61548 * 1024 * 4
+
+
+def test_graft_entry_build_agrees_with_the_header():
+    """__graft_entry__.build() is the driver's "does it build" check: it must accept the library the tree builds (its ABI assertion once
+    lagged one version behind the header)"""
+    import __graft_entry__ as g
+
+    g.build()
