@@ -395,6 +395,182 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_mfma(const RalfAttnDesc d)
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same one-pass backward with SIXTEEN waves of 16 keys each (1 024 threads: four waves per SIMD, <= 128 registers).  The 8-wave form
+// above holds 32 keys per wave in 147 registers and 157 KB of LDS (the double-buffered fp32 partial-dQ slots are 73 KB of it): two waves per
+// SIMD, and the per-score chain of one wave (LDS -> MFMA -> ~200 VALU instructions -> MFMA -> LDS) has nobody to hide behind (rocprofv3:
+// ~40 % VALU issue).  Here
+//   * a wave's S / dP / dV / dK work is the same code on HALF the keys (the registers of one 16-key block); with four waves per SIMD the
+//     score arithmetic runs at the VALU issue rate (cycle stamps: 3 750 cycles per 32-query step = 4 waves x ~215 instructions x 4 cycles
+//     + the quarter-rate exponentials);
+//   * dS of all 256 keys of a 64-query batch goes to ONE shared tile St[key][query] (bf16, double-buffered over the batches); behind the
+//     batch's barrier waves 0 .. 7 -- two per SIMD -- each form one 16 x 16 tile of dQ^T = K^T dS^T over ALL keys in a single accumulator
+//     chain (ascending key blocks: deterministic) and store it, while the other eight are already in the next batch's score arithmetic:
+//     no fp32 partials, no reduction pass, one barrier per 64 queries.  137 KB of LDS.
+// What is left outside the VALU rate (cycle stamps of one workgroup, 256 x 256, p = 0.1: 50 000 cycles per head): the prologue's loads
+// (10 000 cycles: every workgroup of the chip loads its head at the same moment, HBM rate; a persistent form that prefetched the next
+// head's rows -- into registers or, by one dword per line, into L2 -- moved the wait but did not shorten the kernel: 32 heads per XCD are
+// 6 MB of lines against 4 MB of L2) and the dK / dV stores.
+// ------------------------------------------------------------------------------------------------
+constexpr int F16_LD = 40, F16_SLD = 72, F16_BATCH = 64;
+__global__ __launch_bounds__(1024) void attn_bwd_fused16_mfma(const RalfAttnDesc d) {
+    constexpr int DH = 32;
+    __shared__ __attribute__((aligned(16))) bf16 Qs[FB_S * F16_LD];
+    __shared__ __attribute__((aligned(16))) bf16 Gs[FB_S * F16_LD];
+    __shared__ __attribute__((aligned(16))) bf16 Kt[FB_S * F16_LD];         // all key rows (transpose-read for dQ)
+    __shared__ __attribute__((aligned(16))) bf16 St[2][FB_S * F16_SLD];     // dS [key][query of the batch], double-buffered over the batches
+    __shared__ __attribute__((aligned(16))) float Ls[FB_S], Ds[FB_S];
+    __shared__ __attribute__((aligned(16))) uint32_t Rk[FB_S];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, Ln = lane & 15;
+    const WgId wg = wg_id(1, d.H);
+    const int b = wg.b, h = wg.h;
+    const bf16* Qp = (const bf16*)d.q + b * d.q_bs + (int64_t)h * DH;
+    const bf16* Kp = (const bf16*)d.k + b * d.k_bs + (int64_t)h * DH;
+    const bf16* Vp = (const bf16*)d.v + b * d.v_bs + (int64_t)h * DH;
+    const bf16* Op = (const bf16*)d.o + b * d.o_bs + (int64_t)h * DH;
+    const bf16* Gp = (const bf16*)d.dout + b * d.do_bs + (int64_t)h * DH;
+    const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * (d.kpm_bs ? d.kpm_bs : (int64_t)d.Sk) : nullptr;
+    const uint64_t seed = d.p_drop > 0.f ? (uint64_t)d.seed[0] : 0;
+    const uint32_t thr = attn_thr16(d.p_drop);
+    const float inv_keep = 1.f / (1.f - d.p_drop);
+    const float scale2 = d.scale * 1.4426950408889634f;
+    const int64_t stat0 = ((int64_t)b * d.H + h) * d.Sq;
+
+    // ---- prologue: Q and dO rows into LDS, delta, lse (log2 domain), dropout row keys; the key rows; zeroed dS rows of idle waves ----
+    const int kw0 = wave * 16;   // the wave's first key
+    const int kj = kw0 + Ln;
+    const bf16x8 kf = frag_global(Kp, d.k_rs, kw0, d.Sk, 0, lane), vf = frag_global(Vp, d.v_rs, kw0, d.Sk, 0, lane);
+    const bool kmasked = kj >= d.Sk || (kpm && kpm[kj < d.Sk ? kj : 0]);
+    {   // 4 threads per query row: 8 dims each
+        const int q = tid >> 2, part = tid & 3;
+        uint4 qv = make_uint4(0, 0, 0, 0), gv = qv, ov = qv;
+        float lse_q = 0.f;
+        if (q < d.Sq) {
+            qv = *reinterpret_cast<const uint4*>(Qp + (int64_t)q * d.q_rs + part * 8);
+            gv = *reinterpret_cast<const uint4*>(Gp + (int64_t)q * d.do_rs + part * 8);
+            ov = *reinterpret_cast<const uint4*>(Op + (int64_t)q * d.o_rs + part * 8);
+            lse_q = d.lse[stat0 + q];
+        }
+        // key row q, vector `part` (256 rows x 4 vectors = one per thread)
+        uint4 kv = make_uint4(0, 0, 0, 0);
+        if (q < d.Sk) kv = *reinterpret_cast<const uint4*>(Kp + (int64_t)q * d.k_rs + part * 8);
+        *reinterpret_cast<uint4*>(Qs + q * F16_LD + part * 8) = qv;
+        *reinterpret_cast<uint4*>(Gs + q * F16_LD + part * 8) = gv;
+        *reinterpret_cast<uint4*>(Kt + q * F16_LD + part * 8) = kv;
+        const bf16x8 gg = *reinterpret_cast<const bf16x8*>(&gv), oo = *reinterpret_cast<const bf16x8*>(&ov);
+        float dl = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)gg[e] * (float)oo[e];
+        dl += wave::dpp<wave::QUAD_XOR1>(dl);
+        dl += wave::dpp<wave::QUAD_XOR2>(dl);
+        if (part == 0) {
+            Ds[q] = dl;
+            Ls[q] = lse_q * 1.4426950408889634f;
+            Rk[q] = d.p_drop > 0.f ? attn_rowkey(seed, d.call_id, ((uint64_t)b * d.H + h) * d.Sq + q) : 0u;
+            if (d.delta && q < d.Sq) d.delta[stat0 + q] = dl;
+        }
+        // a wave beyond Sk never writes its dS rows: they must read as zero in both buffers (16 of the row's 64 queries per thread)
+        if (q >= (d.Sk & ~15)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(St[i >> 1] + q * F16_SLD + part * 16 + (i & 1) * 8) = make_uint4(0, 0, 0, 0);
+        }
+    }
+    f32x4 dk[2], dv[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) dk[c] = dv[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    const bool wave_active = kw0 < d.Sk;   // (wave-uniform)
+    const bool drop = d.p_drop > 0.f;
+    const bool any_kmasked = __builtin_amdgcn_ballot_w64(kmasked) != 0ull;   // (wave-uniform)
+    const int nkb = (d.Sk + 31) >> 5;      // 32-key blocks the dQ chain walks
+    int nb = 0;
+    for (int b0 = 0; b0 < d.Sq; b0 += F16_BATCH, ++nb) {
+        bf16* stw = St[nb & 1];
+        if (wave_active) {
+            for (int s0 = b0; s0 < d.Sq && s0 < b0 + F16_BATCH; s0 += 32) {
+                const f32x4 L4[2] = {*reinterpret_cast<const f32x4*>(Ls + s0 + 4 * g), *reinterpret_cast<const f32x4*>(Ls + s0 + 16 + 4 * g)};
+                const f32x4 D4[2] = {*reinterpret_cast<const f32x4*>(Ds + s0 + 4 * g), *reinterpret_cast<const f32x4*>(Ds + s0 + 16 + 4 * g)};
+                const attn::u32x4 R4[2] = {*reinterpret_cast<const attn::u32x4*>(Rk + s0 + 4 * g), *reinterpret_cast<const attn::u32x4*>(Rk + s0 + 16 + 4 * g)};
+                f32x4 s[2], dp[2];
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qs + (s0 + blk * 16 + Ln) * F16_LD + g * 8);
+                    const bf16x8 ga = *reinterpret_cast<const bf16x8*>(Gs + (s0 + blk * 16 + Ln) * F16_LD + g * 8);
+                    s[blk] = mfma16(qa, kf, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    dp[blk] = mfma16(ga, vf, (f32x4){0.f, 0.f, 0.f, 0.f});
+                }
+                bf16x8 pf, dsf;
+                // (masked probabilities are SELECTED zeros, see attn_bwd_fused_mfma)
+                if (d.causal || s0 + 32 > d.Sq || any_kmasked)
+                    attn::bwd_step_keys<true>(s, dp, L4, D4, R4, scale2, kmasked, d.causal != 0, kj, s0 + 4 * g, d.Sq, drop, thr, inv_keep, pf, dsf);
+                else
+                    attn::bwd_step_keys<false>(s, dp, L4, D4, R4, scale2, false, false, kj, s0 + 4 * g, d.Sq, drop, thr, inv_keep, pf, dsf);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    // transposed fragments of the query tiles: matrix rows = 16 dims, k-slots = the step's 32 queries (the order pf / dsf hold them in)
+                    const bf16* qg = Gs + (s0 + 4 * g + (Ln >> 2)) * F16_LD + c * 16 + (Ln & 3) * 4;
+                    const bf16* qq = Qs + (s0 + 4 * g + (Ln >> 2)) * F16_LD + c * 16 + (Ln & 3) * 4;
+                    const bf16x4 glo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qg)), ghi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qg + 16 * F16_LD));
+                    const bf16x4 qlo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qq)), qhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qq + 16 * F16_LD));
+                    dv[c] = mfma16(__builtin_shufflevector(glo, ghi, 0, 1, 2, 3, 4, 5, 6, 7), pf, dv[c]);
+                    dk[c] = mfma16(__builtin_shufflevector(qlo, qhi, 0, 1, 2, 3, 4, 5, 6, 7), dsf, dk[c]);
+                }
+                bf16* sr = stw + kj * F16_SLD + (s0 - b0);   // the lane's key row: queries 4g .. 4g+3 and 16+4g .. 16+4g+3 of the step
+                *reinterpret_cast<bf16x4*>(sr + 4 * g) = __builtin_shufflevector(dsf, dsf, 0, 1, 2, 3);
+                *reinterpret_cast<bf16x4*>(sr + 16 + 4 * g) = __builtin_shufflevector(dsf, dsf, 4, 5, 6, 7);
+            }
+        }
+        __syncthreads();
+        // (the NEXT batch writes the other buffer; this one is rewritten two batches on, behind the next barrier, which the dQ waves reach only
+        //  after their reads below)
+        const int qb = wave >> 1, db = wave & 1;   // dQ^T tile of wave w < 8: dims db*16 .. +15 x queries b0 + qb*16 .. +15, over all keys
+        if (wave < 8 && b0 + qb * 16 < d.Sq) {     // (wave-uniform; the columns of a skipped step hold an earlier batch's values)
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const bf16* sp = stw + (4 * g + (Ln >> 2)) * F16_SLD + qb * 16 + (Ln & 3) * 4;
+            const bf16* kp2 = Kt + (4 * g + (Ln >> 2)) * F16_LD + db * 16 + (Ln & 3) * 4;
+            // four key blocks' operands in flight at a time; blocks beyond Sk are zero rows of both tiles
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (half * 4 < nkb) {
+                    bf16x4 sl[4], sh[4], kl[4], kh[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int kb = half * 4 + i;
+                        sl[i] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, sp + kb * 32 * F16_SLD));
+                        sh[i] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, sp + (kb * 32 + 16) * F16_SLD));
+                        kl[i] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, kp2 + kb * 32 * F16_LD));
+                        kh[i] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, kp2 + (kb * 32 + 16) * F16_LD));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc = mfma16(__builtin_shufflevector(kl[i], kh[i], 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(sl[i], sh[i], 0, 1, 2, 3, 4, 5, 6, 7), acc);
+                }
+            }
+            const int q = b0 + qb * 16 + Ln;   // lane = query, dims db*16 + 4g .. +3
+            if (q < d.Sq) {
+                bf16x4 t;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] = (bf16)(acc[r] * d.scale);
+                *reinterpret_cast<bf16x4*>((bf16*)d.dq + b * d.dq_bs + (int64_t)q * d.dq_rs + (int64_t)h * DH + db * 16 + 4 * g) = t;
+            }
+        }
+    }
+    const float vscale = drop ? inv_keep : 1.f;   // (P went into the dV product unscaled)
+    if (kj < d.Sk) {
+        bf16* dKp = (bf16*)d.dk + b * d.dk_bs + (int64_t)kj * d.dk_rs + (int64_t)h * DH;
+        bf16* dVp = (bf16*)d.dv + b * d.dv_bs + (int64_t)kj * d.dv_rs + (int64_t)h * DH;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            bf16x4 tk, tv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { tk[r] = (bf16)(dk[c][r] * d.scale); tv[r] = (bf16)(dv[c][r] * vscale); }
+            *reinterpret_cast<bf16x4*>(dKp + c * 16 + 4 * g) = tk;
+            *reinterpret_cast<bf16x4*>(dVp + c * 16 + 4 * g) = tv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // dQ, dK, dV in ONE pass for the decoder's CROSS-attention (a few dozen queries over hundreds of memory rows; dh = 32, not causal): one
 // workgroup of 8 waves per (batch, head), two of them per CU.  The per-query + per-key pair spends 24 + 33 us per layer on it (Sq = 51,
 // Sk = 532, B = 64): the per-key kernel is 4 608 workgroups that each stage the 51 query rows again for two steps of matrix work, the
@@ -1350,7 +1526,10 @@ int ralf_attention_bwd_mfma(const RalfAttnDesc& d, hipStream_t st) {
     static const int fused = [] { const char* e = getenv("RALF_ATTN_BWD_FUSED"); return e ? atoi(e) : 1; }();
     if (fused && d.dh == 32 && d.Sq <= FB_S && d.Sk <= FB_S && (fused == 2 || (d.Sq >= 128 && d.Sk >= 128)) && d.q_rs % 8 == 0 && d.k_rs % 8 == 0 && d.v_rs % 8 == 0 && d.o_rs % 8 == 0 && d.do_rs % 8 == 0 &&
         d.dq_rs % 2 == 0) {
-        hipLaunchKernelGGL(attn_bwd_fused_mfma, dim3(d.H * d.B), dim3(512), 0, st, d);
+        // RALF_ATTN_BWD_FUSED16=0: the 8-wave form (32 keys per wave, fp32 partial-dQ slots)
+        static const int w16 = [] { const char* e = getenv("RALF_ATTN_BWD_FUSED16"); return e ? atoi(e) : 1; }();
+        if (w16 && d.dq_rs % 4 == 0) hipLaunchKernelGGL(attn_bwd_fused16_mfma, dim3(d.H * d.B), dim3(1024), 0, st, d);
+        else hipLaunchKernelGGL(attn_bwd_fused_mfma, dim3(d.H * d.B), dim3(512), 0, st, d);
         return ralf::check_launch("attention_bwd_fused");
     }
     // a few dozen queries over a long memory (the decoder's cross-attention): one pass, one workgroup per (batch, head).  RALF_ATTN_BWD_CROSS=0: the pair below

@@ -692,10 +692,10 @@ torch.save({{k: v.cpu() for k, v in out.items()}}, {path!r})
 
 
 def test_one_pass_attention_backward_equals_the_two_kernel_backward(tmp_path):
-    """sequences of up to 256 queries / keys (dh = 32) can take dQ, dK, dV from ONE pass over the scores (attn_bwd_fused_mfma: the default
-    from 128 x 128 on, everywhere it fits with RALF_ATTN_BWD_FUSED=2 as here); RALF_ATTN_BWD_FUSED=0 (read once per process) keeps the
-    per-query + per-key kernels.  Same P, dropout mask and dS arithmetic; dQ sums the eight key blocks'
-    partial products in fp32 in a fixed order instead of chaining them through one accumulator, so it may differ in the last bf16 bit.
+    """sequences of up to 256 queries / keys (dh = 32) can take dQ, dK, dV from ONE pass over the scores (attn_bwd_fused16_mfma, or the 8-wave
+    attn_bwd_fused_mfma with RALF_ATTN_BWD_FUSED16=0: the default from 128 x 128 on, everywhere it fits with RALF_ATTN_BWD_FUSED=2 as
+    here); RALF_ATTN_BWD_FUSED=0 (read once per process) keeps the per-query + per-key kernels.  Same P, dropout mask and dS arithmetic;
+    delta is summed in another order and the 8-wave form adds eight fp32 partial dQ, so results may differ in the last bf16 bit.
     The last case (Sk = 300) runs the two-kernel path in both processes."""
     import os
     import subprocess
@@ -703,15 +703,15 @@ def test_one_pass_attention_backward_equals_the_two_kernel_backward(tmp_path):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for flag in ("2", "0"):
-        path = str(tmp_path / f"attn_bwd{flag}.pt")
-        r = subprocess.run([sys.executable, "-c", _ATTN_BWD_CASES.format(root=root, path=path)], env=dict(os.environ, RALF_ATTN_BWD_FUSED=flag, RALF_ATTN_BWD_CROSS="0"),
-                           capture_output=True, text=True, cwd=root)
+    for flag, w16 in (("2", "1"), ("2", "0"), ("0", "1")):
+        path = str(tmp_path / f"attn_bwd{flag}{w16}.pt")
+        r = subprocess.run([sys.executable, "-c", _ATTN_BWD_CASES.format(root=root, path=path)],
+                           env=dict(os.environ, RALF_ATTN_BWD_FUSED=flag, RALF_ATTN_BWD_FUSED16=w16, RALF_ATTN_BWD_CROSS="0"), capture_output=True, text=True, cwd=root)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-        res[flag] = torch.load(path)
-    assert set(res["2"]) == set(res["0"]) and len(res["2"]) == 12
-    for k in res["2"]:
-        a, b = res["2"][k].float(), res["0"][k].float()
+        res[flag + w16] = torch.load(path)
+    assert set(res["21"]) == set(res["01"]) == set(res["20"]) and len(res["21"]) == 12
+    for k, form in [(k, form) for k in res["21"] for form in ("21", "20")]:
+        a, b = res[form][k].float(), res["01"][k].float()
         assert torch.isfinite(a).all(), k
         tol = 2.0 ** -7 * b.abs().max().item()   # one bf16 ulp at the tensor's scale
         bad = ((a - b).abs() > tol).float().mean().item()
