@@ -66,6 +66,8 @@ class RelationConstraint:
             assert hi - lo == self.nbin
             self.start[slot] = lo
         self.ordinal = {e: i for i, e in enumerate(RelElement)}
+        self._eos = int(tok.name_to_id("eos"))
+        self._all_bins = frozenset(range(self.nbin))   # (never modified: _meet builds new sets)
         self.history: List[_State] = []
         self.types: Optional[torch.Tensor] = None
 
@@ -189,12 +191,26 @@ class RelationConstraint:
     # ------------------------------------------------------------------------------------------
     def __call__(self, token_ids: torch.Tensor, rel_constraints: list):
         """token_ids [1, L] (bos + L-1 decoded tokens) -> (mask [V] True = forbidden, back-track position or None)"""
-        n_decoded = token_ids.size(1) - 1
+        what, back = self.step(token_ids.size(1) - 1, int(token_ids[0, -1]), rel_constraints)
+        if what[0] == "only":
+            mask = torch.ones(self.V, dtype=torch.bool)
+            mask[what[1]] = False
+        elif what[0] == "bins":
+            mask = self._mask_from(what[2], what[1])
+        else:
+            mask = ~self._token_mask[what[1]].clone()
+        return mask, back
+
+    def step(self, n_decoded: int, last: int, rel_constraints: list):
+        """the same step without tensors (the batched decode loop builds the masks of all samples at once): n_decoded tokens are decoded, `last`
+        is the latest of them -> (what is admissible, back-track position or None):
+          ("only", token)        that one token
+          ("bins", slot, set)    the bin tokens start[slot] + b, b in the set (an EMPTY set admits nothing)
+          ("slot", n_decoded)    whatever the tokenizer admits at this position"""
         self.history = self.history[: n_decoded + 1]
         st = self.history[-1].copy()
         slot = n_decoded % 5
         if n_decoded > 0:
-            last = int(token_ids[0, -1])
             if last in self.label_tokens:
                 st.pred_labels.append(last)
                 st.pred_bbox.append([])
@@ -202,27 +218,24 @@ class RelationConstraint:
                 st.pred_bbox[-1].append(int(last - self.start[{HEIGHT: WIDTH, CX: HEIGHT, CY: CX, TYPE: CY}[slot]]))
         back = None
         if st.finished:
-            mask = torch.ones(self.V, dtype=torch.bool)
-            mask[self.pre.tokenizer.name_to_id("eos")] = False
-            return mask, back            # (a finished state is not recorded)
+            return ("only", self._eos), back            # (a finished state is not recorded)
         if slot == TYPE:
             st.curr_element += 1
             st.num_bbox = 0
-            mask = torch.ones(self.V, dtype=torch.bool)
-            mask[self.types[n_decoded // 5]] = False
+            what = ("only", int(self.types[n_decoded // 5]))
         else:
             cons = rel_constraints[st.curr_element - 1]
             cur = st.pred_bbox[-1]
             if st.curr_element == 1:     # first element: only canvas constraints, and only on cy
-                allowed = set(range(self.nbin))
+                allowed = self._all_bins
                 for kind, arg in cons:
                     if slot == CY and kind == CANVAS:
                         allowed = self._meet(allowed, self._canvas_cy(arg, cur[1]))
-                mask = self._mask_from(allowed, slot)
+                what = ("bins", slot, allowed)
             elif len(cons) == 0:
-                mask = ~self._token_mask[n_decoded].clone()
+                what = ("slot", n_decoded)
             else:
-                allowed = set(range(self.nbin))
+                allowed = self._all_bins
                 for kind, arg in cons:
                     if kind == CANVAS:
                         back = None      # (the reference overwrites the back-track target with every constraint it visits)
@@ -232,7 +245,7 @@ class RelationConstraint:
                         continue
                     back = arg * 5 + st.num_bbox + 1
                     allowed = self._meet(allowed, self._interval(slot, kind, st.pred_bbox[arg], cur))
-                mask = self._mask_from(allowed, slot)
+                what = ("bins", slot, allowed)
             st.num_bbox += 1
         self.history.append(st)
-        return mask, back
+        return what, back

@@ -617,6 +617,99 @@ class _GeneratorBase(nn.Module):
             active = still
         return step.cache
 
+    def _relation_lockstep_batched(self, states, memory, env, dev):
+        """rng="per_sample" with argmax decoding: the lock-step loop with the per-sample tensor arithmetic of _relation_advance done for ALL samples
+        at once -- the [B, V] logits are masked (tokenizer slot, forced label, relation restriction), gated and arg-maxed as one numpy array; per
+        sample only the restriction's interval logic (RelationConstraint.step, no tensors) and the back-track bookkeeping on plain ints stay in
+        Python.  Same masks, same comparisons, same draws per sample as _relation_advance (tests/test_configs_gpu.py decodes both ways); the
+        per-sample form spends ~130 us of tiny CPU tensor operations per sample and step, 33 ms per step at B = 256 against 0.5 ms on the device."""
+        import numpy as np
+
+        ids, T, token_mask_h, _restrict, prob_gate, _cfg = env
+        B = len(states)
+        pool = self.__dict__.setdefault("_relation_lockstep_steps", {})
+        key = (B, int(memory.shape[1]), str(dev))
+        if key not in pool:
+            while len(pool) >= 2:
+                pool.pop(next(iter(pool)))
+            pool[key] = self._LockstepStep(self, T, dev, B)
+        step = pool.pop(key)
+        pool[key] = step
+        step.bind(RN.decoder_init_cache(self.decoder, memory, self.rt, T))
+        tok_h, pos_h, kpm_h = step.tok_h.numpy(), step.pos_h.numpy(), step.kpm_h.numpy()   # (views of the pinned mirrors)
+        pad, eos, bos = int(ids["pad"]), int(ids["eos"]), int(ids["bos"])
+        kpm_h[:] = 1
+        kpm_h[:, 0] = int(bos == pad)
+        tmask = token_mask_h.numpy()                                     # [positions, V]: what the tokenizer admits at a position
+        forced = np.asarray([st.forced for st in states], dtype=np.int64)   # [B, T]: the forced label of a step, -1 = free
+        start = states[0].con.start
+        seqs = [[bos] for _ in range(B)]
+        active = list(range(B))
+        while active:
+            n_dec = np.fromiter((len(seqs[b]) - 1 for b in active), np.int64, len(active))
+            tok_h[active] = [seqs[b][-1] for b in active]
+            pos_h[active] = n_dec
+            lg = step().numpy()[active]                                  # (a copy: fancy indexing)
+            lg[~tmask[n_dec]] = NEG_INF
+            f = forced[active, n_dec]
+            r = np.nonzero(f >= 0)[0]
+            if r.size:                                                   # one kept logit, as _relation_advance
+                keep = lg[r, f[r]]
+                lg[r] = NEG_INF
+                lg[r, f[r]] = keep
+            raw = lg.copy() if any(states[b].resets > 3 for b in active) else None
+            allow = np.zeros(lg.shape, dtype=bool)
+            backs = []
+            for i, b in enumerate(active):
+                st, sq = states[b], seqs[b]
+                what, back = st.con.step(len(sq) - 1, sq[-1], st.rel)
+                backs.append(back)
+                if what[0] == "only":
+                    allow[i, what[1]] = True
+                elif what[0] == "bins":
+                    if what[2]:
+                        allow[i, np.fromiter(what[2], np.int64, len(what[2])) + start[what[1]]] = True
+                else:
+                    allow[i] = tmask[what[1]]
+            lg[~allow] = NEG_INF
+            rowmax, arg = lg.max(axis=1), lg.argmax(axis=1)
+            still = []
+            for i, b in enumerate(active):
+                st, sq = states[b], seqs[b]
+                if st.resets > 3:
+                    st.back_flag = False
+                    nxt = int(raw[i].argmax())
+                elif (not st.back_flag and not rowmax[i] >= prob_gate) or rowmax[i] == NEG_INF:
+                    back_idx = backs[i]
+                    draw = not (back_idx is not None and st.flagged.count(st.idx) + 1 < 3)
+                    st.flagged.append(st.idx)
+                    st.back_flag = True
+                    st.idx = st.rng.randint(2, max(2, st.idx - 1)) if draw else back_idx
+                    del sq[st.idx:]
+                    st.n_back += 1
+                    if st.n_back > 30:
+                        st.flagged, st.back_flag, st.n_back = [], False, 0
+                        st.resets += 1
+                        sq[:] = [bos]
+                        st.idx = 0
+                    kpm_h[b, len(sq):] = 1
+                    still.append(b)
+                    continue
+                else:
+                    st.back_flag = False                                 # (its temperature does not move an argmax)
+                    nxt = int(arg[i])
+                sq.append(nxt)
+                if nxt == eos or len(sq) == T + 1:
+                    st.done = True
+                else:
+                    kpm_h[b, len(sq) - 1] = int(nxt == pad)
+                    st.idx += 1
+                    still.append(b)
+            active = still
+        for st, sq in zip(states, seqs):
+            st.seq = torch.tensor([sq], dtype=torch.long)
+        return step.cache
+
     @torch.no_grad()
     def sample_relation(self, cond, batch_size: Optional[int] = None, sampling_cfg=None, return_violation: bool = False,
                         prob_gate: float = 0.3, RELATION_SIZE: int = 10, use_graph: bool = True, lockstep: Optional[bool] = None, rng: str = "shared",
@@ -677,7 +770,11 @@ class _GeneratorBase(nn.Module):
         for b in range(B):   # (a constraint object keeps the decode history of ITS sample)
             con = RelationConstraint(self.preprocessor)
             states.append(self._RelationState(ids["bos"], con.prepare(seqc["seq"][b].cpu()), con, cond_seq[b:b + 1], gens[b], forced_tab[b]))
-        batch_cache = self._relation_lockstep(states, memory, env, dev, 1 if independent else max(2, B // 32), independent) if lockstep else None
+        batch_cache = None
+        if lockstep and independent and _get(sampling_cfg, "name") == "deterministic" and forced_tab[0] is not None and os.environ.get("RALF_RELATION_BATCHED", "1") != "0":
+            batch_cache = self._relation_lockstep_batched(states, memory, env, dev)
+        elif lockstep:
+            batch_cache = self._relation_lockstep(states, memory, env, dev, 1 if independent else max(2, B // 32), independent)
         stepper = None
         if use_graph and not all(st.done for st in states):
             # the captured steps hold the cross-attention cache of ONE memory length (2 h w + K + Lc, and Lc is padded per batch):

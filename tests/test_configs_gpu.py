@@ -1,6 +1,7 @@
 """GPU: the BASELINE.json configurations the earlier suites did not reach at their sizes -- CGL (4 labels) in bf16 at B = 64 / 256,
 relation decoding at B = 256 -- and the bf16 throughput mode against the fp32 parity mode BLOCK BY BLOCK on the unmodified
 initialisation, with error budgets derived from the bf16 unit round-off and the number of rounding points of a block."""
+import os
 import random
 
 import pytest
@@ -177,6 +178,20 @@ def test_relation_b256_rows_equal_reference_rows(golden):
     assert vio_p["total"] == vio["total"] and out_p["label"].shape == out["label"].shape
     assert abs(vio_p["viorated"] - vio["viorated"]) <= max(8, 0.05 * vio["total"]), (vio_p, vio)
     assert dt_p < 0.5 * dt
+    # ... decoded with the masks, gates and arg-maxes of all samples taken on ONE [B, V] array (the default for argmax decoding) or sample by
+    # sample with _relation_advance's tensor arithmetic: the same tokens
+    random.setstate(state)
+    os.environ["RALF_RELATION_BATCHED"] = "0"
+    try:
+        t0 = time.perf_counter()
+        out_q, vio_q = model.sample(cond=cond, sampling_cfg={"name": "deterministic", "temperature": 1.0}, cond_type="relation", return_violation=True,
+                                    use_backtrack=True, RELATION_SIZE=30, rng="per_sample")
+        print(f"relation decode, rng=per_sample, per-sample host arithmetic: {time.perf_counter() - t0:.2f} s per batch")
+    finally:
+        del os.environ["RALF_RELATION_BATCHED"]
+    for k in ("label", "mask", "center_x", "center_y", "width", "height"):
+        assert torch.equal(out_p[k], out_q[k]), k
+    assert vio_p == vio_q
     # ... and a batch of ONE is the sequential loop itself: sample 0 continues the global stream and leaves it where the loop would have
     def first(x):
         if torch.is_tensor(x):
