@@ -628,6 +628,9 @@ def main():
         }
         if dp_info is not None:
             out["config"]["data_parallel"] = dp_info
+        if getattr(step, "side_graph_ms", None):   # where the weight gradients run: measured at capture (engine.TrainStep._capture), the faster form kept
+            out["config"]["weight_gradients"] = {"form": "side graph behind event nodes" if step.side_graph else "branches of the main graph",
+                                                 "fwd_bwd_ms_at_capture": {"branches": round(step.side_graph_ms[False], 3), "side_graph": round(step.side_graph_ms[True], 3)}}
         mb, mf = measured_mfma_busy("train_step_B64_N10_bf16") if (B == 64 and N == 10 and a.dtype.startswith("b")) else (None, None)
         if mb is not None:
             out["roofline"]["mfma_busy"] = mb

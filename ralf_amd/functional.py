@@ -18,6 +18,57 @@ from torch.autograd import Function
 from . import ops
 
 
+class ExternalEvent:
+    """a HIP event whose record and wait are EVENT NODES of the graphs under capture, so that a wait in one graph orders behind a record in
+    ANOTHER graph (the side graph of engine.TrainStep).  torch.cuda.Event(external=True) is refused on ROCm builds of torch and the runtime
+    rejects hipEventRecordWithFlags(.., hipEventRecordExternal) under capture, so the nodes are added by hand: the capture's graph and the
+    stream's current dependency set (hipStreamGetCaptureInfo_v2), hipGraphAddEventRecordNode / hipGraphAddEventWaitNode behind them, and the
+    new node as the stream's dependency set (hipStreamUpdateCaptureDependencies).  A wait binds to the record most recently ENQUEUED:
+    replay the recording graph first (tools/lab/ext_event_probe.py: the waiting graph then runs beside the rest of the recording one)."""
+    _hip = None
+
+    def __init__(self):
+        import ctypes
+        vp = ctypes.c_void_p
+        if ExternalEvent._hip is None:
+            hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(vp), ctypes.c_uint]
+            hip.hipEventDestroy.argtypes = [vp]
+            hip.hipStreamGetCaptureInfo_v2.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(vp),
+                                                       ctypes.POINTER(ctypes.POINTER(vp)), ctypes.POINTER(ctypes.c_size_t)]
+            hip.hipGraphAddEventRecordNode.argtypes = [ctypes.POINTER(vp), vp, ctypes.POINTER(vp), ctypes.c_size_t, vp]
+            hip.hipGraphAddEventWaitNode.argtypes = [ctypes.POINTER(vp), vp, ctypes.POINTER(vp), ctypes.c_size_t, vp]
+            hip.hipStreamUpdateCaptureDependencies.argtypes = [vp, ctypes.POINTER(vp), ctypes.c_size_t, ctypes.c_uint]
+            ExternalEvent._hip = hip
+        self._ev = vp()
+        rc = ExternalEvent._hip.hipEventCreateWithFlags(ctypes.byref(self._ev), 2)   # hipEventDisableTiming
+        assert rc == 0, f"hipEventCreateWithFlags: {rc}"
+
+    def _node(self, stream, record: bool):
+        import ctypes
+        vp, hip = ctypes.c_void_p, ExternalEvent._hip
+        status, cid, graph, deps, nd = ctypes.c_int(), ctypes.c_ulonglong(), vp(), ctypes.POINTER(vp)(), ctypes.c_size_t()
+        rc = hip.hipStreamGetCaptureInfo_v2(stream.cuda_stream, ctypes.byref(status), ctypes.byref(cid), ctypes.byref(graph), ctypes.byref(deps), ctypes.byref(nd))
+        assert rc == 0 and status.value == 1, f"ExternalEvent: the stream is not capturing (rc {rc}, status {status.value})"
+        node = vp()
+        rc = (hip.hipGraphAddEventRecordNode if record else hip.hipGraphAddEventWaitNode)(ctypes.byref(node), graph, deps, nd.value, self._ev)
+        assert rc == 0, f"hipGraphAddEvent{'Record' if record else 'Wait'}Node: {rc}"
+        rc = hip.hipStreamUpdateCaptureDependencies(stream.cuda_stream, (vp * 1)(node), 1, 1)   # hipStreamSetCaptureDependencies
+        assert rc == 0, f"hipStreamUpdateCaptureDependencies: {rc}"
+
+    def record(self, stream) -> "ExternalEvent":
+        self._node(stream, True)
+        return self
+
+    def wait(self, stream):
+        self._node(stream, False)
+
+    def __del__(self):
+        hip = getattr(ExternalEvent, "_hip", None) if ExternalEvent is not None else None   # (module globals may be gone at interpreter exit)
+        if hip is not None and self._ev:
+            hip.hipEventDestroy(self._ev)
+
+
 class Runtime:
     def __init__(self, dtype=torch.float32, seed: int = 0):
         self.dtype = dtype
@@ -38,6 +89,12 @@ class Runtime:
         self.side_policy = os.environ.get("RALF_SIDE_POLICY", "rr")
         self._side_rr = 0
         self._keep: list = []     # operands of side-stream work in flight (kept alive until join_side)
+        # defer_side (set by the engine while it captures the forward + backward graph): the side-stream work is not issued but QUEUED, each
+        # item behind EXTERNAL events recorded at its producers; the engine captures the queue as a graph of its own and replays it on the
+        # side stream next to the main graph -- concurrency by stream order instead of by the hipGraph executor's branch placement
+        self.defer_side = False
+        self._deferred: list = []   # (events to wait for, closure, operands kept alive)
+        self._wdep_streams: dict = {}
         self.cut_enabled = False  # engine mode (data parallel): split the backward at grad_cut() points
         self._cuts: list = []     # (tensor of the early graph, detached leaf the late graph continued from)
         # engine mode: independent sub-networks (constraint encoder, retrieved-layout branch) are issued on their own HIP
@@ -156,7 +213,10 @@ class Runtime:
         if not (self.overlap and self.direct_grads):
             return fn()
         if not self._side:
-            self._side = [ops.own_stream(("side", i)) for i in range(self.n_side)]
+            self._side = self._make_side()
+        if self.defer_side:
+            self._deferred.append(([ExternalEvent().record(torch.cuda.current_stream())], fn, operands))
+            return
         if self.side_policy == "rr" and len(self._side) == 1:   # call order: the same assignment in every run
             st = self._side[0]
         else:
@@ -167,6 +227,10 @@ class Runtime:
         with torch.cuda.stream(st):
             fn()
         self._keep.append(operands)
+
+    def _make_side(self):
+        prio = os.environ.get("RALF_SIDE_PRIORITY")   # "low" / "high": the side stream on a hardware queue of that priority (A/B runs)
+        return [ops.own_stream(("side", i, prio), priority=prio) for i in range(self.n_side)]
 
     def fanout_alias(self, x: torch.Tensor) -> torch.Tensor:
         """an alias of x to hand to SEVERAL linear layers: their backward products are summed in the GEMM epilogue
@@ -247,6 +311,9 @@ class Runtime:
         big layers behind the chain of tiny kernels of an unrelated branch"""
         if self.overlap and self.direct_grads:
             st = torch.cuda.current_stream()
+            if self.defer_side:   # one external record per stream at FLUSH time (a record node per queued operand would be hundreds per step)
+                self._wdep_streams[st.cuda_stream] = st
+                return
             ev = torch.cuda.Event()
             ev.record(st)
             self._wdeps[st.cuda_stream] = ev   # a later event on the same stream covers the earlier ones
@@ -286,9 +353,15 @@ class Runtime:
                 ops.wgrad_grouped(wj)
             if bj:
                 ops.colsum_grouped(bj)
-        if self.overlap and self.direct_grads:
+        if self.overlap and self.direct_grads and self.defer_side:
+            evs = []
+            for st in self._wdep_streams.values():
+                evs.append(ExternalEvent().record(st))
+            self._wdep_streams = {}
+            self._deferred.append((evs, run, (wj, bj)))
+        elif self.overlap and self.direct_grads:
             if not self._side:
-                self._side = [ops.own_stream(("side", i)) for i in range(self.n_side)]
+                self._side = self._make_side()
             st = self._side[0]
             for ev in self._wdeps.values():
                 st.wait_event(ev)

@@ -267,6 +267,37 @@ def test_grouped_wgrads_and_branches_equal_plain_step(golden):
         assert r < 2e-3, (k, r)
 
 
+def test_side_graph_mode_equals_the_branch_mode(golden, monkeypatch):
+    """RALF_SIDE_GRAPH=1 (opt-in, read when the step is captured): the weight / bias gradient launches are a SECOND graph replayed on the side
+    stream, each item behind event nodes of the main graph (functional.ExternalEvent), instead of parallel branches inside the main graph.
+    Same kernels, same order per gradient region: losses and parameters agree as two runs of one mode do (the step has fp32 atomics: loss
+    and LayerNorm-parameter sums are not bit-reproducible run to run)."""
+    from ralf_amd.engine import TrainStep
+
+    m1, inputs, tgt = make(golden, "bfloat16")
+    m2, _, _ = make(golden, "bfloat16")
+    m3, _, _ = make(golden, "bfloat16")
+    monkeypatch.setenv("RALF_SIDE_GRAPH", "0")
+    a = TrainStep(m1, use_graph=True)
+    la = [a(inputs, tgt).item() for _ in range(4)]
+    monkeypatch.setenv("RALF_SIDE_GRAPH", "1")
+    b = TrainStep(m2, use_graph=True)
+    lb = [b(inputs, tgt).item() for _ in range(4)]
+    torch.cuda.synchronize()
+    assert a._graphs[3] is None and a.side_graph is False and b._graphs[3] is not None and len(b._graphs[4]) > 0 and b.side_graph is True
+    # the default: both captured, three replays of each timed on this model and batch, the faster kept -- and exactly ONE optimisation step done
+    monkeypatch.setenv("RALF_SIDE_GRAPH", "auto")
+    c = TrainStep(m3, use_graph=True)
+    lc = [c(inputs, tgt).item() for _ in range(4)]
+    assert set(c.side_graph_ms) == {False, True} and c.side_graph == min(c.side_graph_ms, key=c.side_graph_ms.get) and (c._graphs[3] is not None) == c.side_graph
+    assert c.steps_done == 4 and int(c.opt.step_dev) == 4 and max(abs(x - y) for x, y in zip(la, lc)) < 2e-3, (la, lc)
+    assert (a.opt.P - c.opt.P).abs().max().item() <= 4 * 2 * 1e-4 + 1e-6
+    assert max(abs(x - y) for x, y in zip(la, lb)) < 2e-3 and la[0] > la[-1], (la, lb)
+    assert ((a.opt.G - b.opt.G).norm() / a.opt.G.norm()).item() < 2e-2
+    # Adam's first steps move every weight by ~lr * sign(g): a sign flip at rounding level moves an element by 2 lr per step
+    assert (a.opt.P - b.opt.P).abs().max().item() <= 4 * 2 * 1e-4 + 1e-6 and ((a.opt.P - b.opt.P).abs() > 1e-5).float().mean().item() < 0.02
+
+
 def test_unchanged_reference_loop_reaches_the_graph_through_graphed_adamw(golden):
     """image2layout/train/train.py:432-454 verbatim (zero_grad -> train_loss -> backward -> clip_grad_norm_ -> optimizer.step) with
     optimizer._target_=ralf_amd.engine.GraphedAdamW trains exactly like TrainStep: the adapter replays the captured step inside train_loss"""
