@@ -496,15 +496,10 @@ class TrainStep:
                 self._stager.begin()
                 _copy_tree(self._static, {"inputs": inputs, "targets": targets}, self._stager)
                 self._stager.end()
-            ga, gm, gb, gs, _side_work = self._graphs
-            ga.replay()
-            if gs is not None:   # the parameter-gradient work, a graph of its own on the side stream: its wait nodes refer to the records ga just enqueued
-                side = self.model.rt._side[0]
-                with torch.cuda.stream(side):
-                    gs.replay()
-                torch.cuda.current_stream().wait_stream(side)
+            ga, gm, gb, gs, _work, gs2, _work2 = self._graphs
+            self._replay_with_side(ga, gs)   # (the parameter-gradient work: branches of ga, or a graph of its own on the side stream)
             if gm is not None:
-                self._exchange_around(gm.replay)
+                self._exchange_around(lambda: self._replay_with_side(gm, gs2))
             else:
                 self._allreduce()
             gb.replay()
@@ -538,16 +533,21 @@ class TrainStep:
         self.steps_done = snap["steps_done"]
         rt.weights_changed()
 
-    def _time_fwd_bwd(self, ga, gs, stream, reps: int = 3) -> float:
-        """milliseconds per replay of the forward + backward graph (with its side graph, joined): one untimed replay, then `reps` timed ones"""
-        side = self.model.rt._side[0] if gs is not None else None
+    def _replay_with_side(self, g, gs):
+        """a backward graph and, on the side stream, its side graph (whose wait nodes refer to the records `g` just enqueued); joined"""
+        g.replay()
+        if gs is not None:
+            side = self.model.rt._side[0]
+            with torch.cuda.stream(side):
+                gs.replay()
+            torch.cuda.current_stream().wait_stream(side)
 
+    def _time_fwd_bwd(self, pairs, stream, reps: int = 3) -> float:
+        """milliseconds per replay of the forward + backward graphs (each with its side graph, joined): one untimed pass, then `reps` timed ones"""
         def once():
-            ga.replay()
-            if gs is not None:
-                with torch.cuda.stream(side):
-                    gs.replay()
-                torch.cuda.current_stream().wait_stream(side)
+            for g, gs in pairs:
+                if g is not None:
+                    self._replay_with_side(g, gs)
         with torch.cuda.stream(stream):
             once()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -584,7 +584,6 @@ class TrainStep:
         torch.cuda.synchronize()
         dot = os.environ.get("RALF_GRAPH_DOT")   # diagnostics: the captured forward + backward graph as a DOT file (tools/graph_dot.py)
         gb = torch.cuda.CUDAGraph()
-        gm = torch.cuda.CUDAGraph() if self.staged else None
         rt = self.model.rt
         # Where the side-stream work (weight / bias gradients) runs: as parallel BRANCHES of the forward + backward graph (the hipGraph executor
         # places them: in practice behind the data-gradient chain), or as a SECOND graph replayed on the side stream, every item behind an event
@@ -592,34 +591,43 @@ class TrainStep:
         # made of (whole step, B = 64: 14.6 -> 13.9 ms with the side graph, the HBM-bound backbone kernels leave the matrix pipes to the
         # weight gradients; encoder-decoder alone: 4.66 -> 4.81 ms, its chain of sub-256-workgroup kernels loses more to the sharing than the
         # tail gains).  RALF_SIDE_GRAPH=auto (default): capture both, time three replays of each on THIS model, batch shape and box, keep the
-        # faster, free the other.  0 / 1 force a mode.
+        # faster, free the other.  0 / 1 force a mode.  The staged (data-parallel) backward has a side graph per stage.
         want = os.environ.get("RALF_SIDE_GRAPH", "auto")
-        can_defer = not self.staged and rt.overlap and rt.direct_grads and rt.n_side == 1
+        can_defer = rt.overlap and rt.direct_grads and rt.n_side == 1
         modes = [False] if (want == "0" or not can_defer or dot) else [True] if want == "1" else [False, True]
         cands, self.side_graph_ms = {}, {}
-        for mode in modes:
-            ga = torch.cuda.CUDAGraph(keep_graph=True) if dot else torch.cuda.CUDAGraph()
-            rt.weights_changed()   # every capture derives its own weight images (casts, packed layouts): a hit in a cache the OTHER capture filled would leave them out of this graph
+
+        def capture(graph, pool, body, mode):
+            """one piece of the backward under capture (+ its side graph in side-graph mode) -> (side graph, its work list, body's result)"""
             rt.defer_side, rt._deferred = mode, []
             try:
-                with torch.cuda.graph(ga, stream=cap, capture_error_mode=_CAPTURE_MODE):
-                    loss = self._fwd_bwd(si, st)
+                with torch.cuda.graph(graph, pool=pool, stream=cap, capture_error_mode=_CAPTURE_MODE):
+                    res = body()
             finally:
                 rt.defer_side = False
-            gs, side_work = None, None
+            gs, work = None, None
             if mode and rt._deferred:
-                side_work, rt._deferred = rt._deferred, []   # (kept with the graphs: the closures hold operands in graph memory that must not be handed out again)
+                work, rt._deferred = rt._deferred, []   # (kept with the graphs: the closures hold operands in graph memory that must not be handed out again)
                 gs = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gs, pool=ga.pool(), stream=rt._side[0], capture_error_mode=_CAPTURE_MODE):
-                    for evs, fn, _keep in side_work:
+                with torch.cuda.graph(gs, pool=graph.pool(), stream=rt._side[0], capture_error_mode=_CAPTURE_MODE):
+                    for evs, fn, _keep in work:
                         for ev in evs:
                             ev.wait(torch.cuda.current_stream())
                         fn()
-            cands[mode] = (ga, gs, side_work, loss, self.outputs)
+            return gs, work, res
+        for mode in modes:
+            ga = torch.cuda.CUDAGraph(keep_graph=True) if dot else torch.cuda.CUDAGraph()
+            rt.weights_changed()   # every capture derives its own weight images (casts, packed layouts): a hit in a cache the OTHER capture filled would leave them out of this graph
+            gs, side_work, loss = capture(ga, None, lambda: self._fwd_bwd(si, st), mode)
+            gm = gs2 = work2 = None
+            if self.staged:
+                gm = torch.cuda.CUDAGraph()
+                gs2, work2, _ = capture(gm, ga.pool(), self._bwd_rest, mode)
+            cands[mode] = (ga, gm, gs, side_work, gs2, work2, loss, self.outputs)
             if len(modes) > 1:
-                self.side_graph_ms[mode] = self._time_fwd_bwd(ga, gs, cap)
+                self.side_graph_ms[mode] = self._time_fwd_bwd([(ga, gs), (gm, gs2)], cap)
         self.side_graph = min(self.side_graph_ms, key=self.side_graph_ms.get) if len(modes) > 1 else modes[0]
-        ga, gs, side_work, self.loss, self.outputs = cands.pop(self.side_graph)
+        ga, gm, gs, side_work, gs2, work2, self.loss, self.outputs = cands.pop(self.side_graph)
         if cands:   # the slower variant: its graph memory goes back to the allocator
             del cands, loss
             self._restore(snap)   # (the timed replays moved BatchNorm's running statistics)
@@ -632,12 +640,9 @@ class TrainStep:
             rc = hip.hipGraphDebugDotPrint(ctypes.c_void_p(ga.raw_cuda_graph()), dot.encode(), int(os.environ.get("RALF_GRAPH_DOT_FLAGS", "1")))
             assert rc == 0, f"hipGraphDebugDotPrint: {rc}"
             ga.instantiate()
-        if gm is not None:
-            with torch.cuda.graph(gm, pool=ga.pool(), stream=cap, capture_error_mode=_CAPTURE_MODE):
-                self._bwd_rest()
         with torch.cuda.graph(gb, pool=ga.pool(), stream=cap, capture_error_mode=_CAPTURE_MODE):
             self._update()
-        self._graphs = (ga, gm, gb, gs, side_work)
+        self._graphs = (ga, gm, gb, gs, side_work, gs2, work2)
         # (capturing ran the host side of the step once more without executing kernels: put the host counters back too)
         self.opt.step_count = snap["step_count"]
         self.model.rt._wtoken += 1
