@@ -14,7 +14,7 @@ prof() { # name, steps-in-trace, header, command...
 }
 BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --skip-cpu --skip-knn --skip-split --skip-decode --skip-variants --profile-pause 1"
 # (the window after the idle second = the 5 timed graph replays only: no model set-up, eager warm-up, snapshot copies or capture)
-GAP=300 prof train_step 5 "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --skip-cpu --skip-knn --skip-split --skip-decode --skip-variants --profile-pause 1 (MI355X, $R; graph replay, parameter-gradient kernels on parallel graph branches: per-kernel times include overlap)" $BENCH
+GAP=300 prof train_step 5 "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --skip-cpu --skip-knn --skip-split --skip-decode --skip-variants --profile-pause 1 (MI355X, $R; graph replay; the parameter-gradient kernels are a second graph on the side stream: per-kernel times include overlap, and the profiler's per-launch host cost lets that graph start late, so the wall time per step in THIS trace is 3-4 ms above the unprofiled step of bench.json)" $BENCH
 GAP=300 prof train_step_single_stream 5 "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 ... --profile-pause 1 --no-overlap (MI355X, $R; one stream: per-kernel times are not inflated by overlap)" $BENCH --no-overlap
 prof encoder_decoder_only 11 "# rocprofv3 --kernel-trace --stats -- python3 tools/encdec_once.py 8 (MI355X, $R; backbone replaced by a fixed feature sequence; whole trace incl. eager warm-up + capture)" python3 $ROOT/tools/encdec_once.py 8
 # single stream, graph replays only (the window after the idle second): kernel time per step re-derives the HIP-event figure of bench.py
