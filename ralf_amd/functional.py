@@ -148,6 +148,8 @@ class Runtime:
         # KV-cached loop of large batches as independent row slices on streams of their own (models/ralf.py: decode_tokens).  OFF: measured at B = 256
         # (tools/decode_once.py, same tokens): 31.6 ms for one chain, 35.7 for two slices, 40.5 for three, 46.6 for four -- the captured branches do
         # not overlap their launch-latency-bound kernels, they add cross-queue hand-offs
+        # (round 5: every slice as a graph of ITS OWN replayed on its stream -- real concurrency, as the train step's side graph has -- is no better:
+        #  34.6 ms for two slices, 53 for three or four: two chains of chip-wide 5-25 us kernels take turns, they do not overlap)
         self.decode_slices = int(os.environ.get("RALF_DECODE_SLICES", "1"))
         self.decode_ln_gemm = True
         self.decode_few_row_split = True
