@@ -231,8 +231,10 @@ class Runtime:
         self._keep.append(operands)
 
     def _make_side(self):
-        prio = os.environ.get("RALF_SIDE_PRIORITY")   # "low" / "high": the side stream on a hardware queue of that priority (A/B runs)
-        return [ops.own_stream(("side", i, prio), priority=prio) for i in range(self.n_side)]
+        # (measured and not kept: the side stream on a priority queue -- whole step 22-25 ms -- or restricted to 32 / 64 / 128 CUs by
+        #  hipExtStreamCreateWithCUMask -- 27-28 ms: either one is a FIFTH hardware queue, and the graph-replayed step leaves its 13.9 ms
+        #  regime as soon as the process owns more than four)
+        return [ops.own_stream(("side", i)) for i in range(self.n_side)]
 
     def fanout_alias(self, x: torch.Tensor) -> torch.Tensor:
         """an alias of x to hand to SEVERAL linear layers: their backward products are summed in the GEMM epilogue
