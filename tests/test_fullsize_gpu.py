@@ -214,8 +214,13 @@ def test_b64_gradients_bf16_against_fp32_on_trained_weights_without_damping():
     res = ga.gradient_table(sd, batch, dev)
     print("trained weights, no damping: bf16 vs fp32", res)
     assert abs(res["loss_f32"] - res["loss_bf16"]) < 1e-2 * abs(res["loss_f32"]) and res["logits_cosine"] > 0.9995
+    body = []
     for k, (c, r) in res["grad_cos_normratio"].items():
         if ".body." in k:
-            assert c > 0.1 and 0.6 < r < 1.5, (k, c, r)                # positively correlated, comparable size: see the docstring
+            # positively correlated, comparable size: see the docstring.  A single small tensor's cosine moves by +-0.1 from run to run (the 400
+            # steps are not bit-reproducible: fp32 atomics), so the per-tensor floor is 0 and the body as a whole is held to its median
+            assert c > 0.0 and 0.6 < r < 1.5, (k, c, r)
+            body.append(c)
         else:
             assert c > 0.96 and abs(r - 1) < 0.15, (k, c, r)
+    assert sorted(body)[len(body) // 2] > 0.2, sorted(body)
