@@ -497,11 +497,14 @@ class TrainStep:
                 _copy_tree(self._static, {"inputs": inputs, "targets": targets}, self._stager)
                 self._stager.end()
             ga, gm, gb, gs, _work, gs2, _work2 = self._graphs
-            self._replay_with_side(ga, gs)   # (the parameter-gradient work: branches of ga, or a graph of its own on the side stream)
-            if gm is not None:
-                self._exchange_around(lambda: self._replay_with_side(gm, gs2))
-            else:
+            if gm is None:
+                self._replay_with_side(ga, gs)   # (the parameter-gradient work: branches of ga, or a graph of its own on the side stream)
                 self._allreduce()
+            elif gs is None and gs2 is None:
+                ga.replay()
+                self._exchange_around(gm.replay)
+            else:
+                self._staged_with_side(ga, gs, gm, gs2, True)
             gb.replay()
         self.steps_done += 1
         return self.loss
@@ -542,12 +545,40 @@ class TrainStep:
                 gs.replay()
             torch.cuda.current_stream().wait_stream(side)
 
+    def _staged_with_side(self, ga, gs, gm, gs2, exchange: bool):
+        """the staged backward with side graphs: the main stream goes straight from stage 1 to stage 2; the side stream runs stage 1's weight
+        gradients, then -- behind all of stage 1 -- ISSUES the exchange of the stage-1 ranges (the collective's stream waits for the stream it is
+        issued from), then stage 2's weight gradients; one join at the end.  Nothing of the side work sits between the two stages of the chain."""
+        rt, main = self.model.rt, torch.cuda.current_stream()
+        side = rt._side[0]
+        ga.replay()
+        token = None
+        with torch.cuda.stream(side):
+            if gs is not None:
+                gs.replay()
+            side.wait_stream(main)      # (all of stage 1: the directly written gradients of the chain as well)
+            if exchange:
+                token = self.exchange.start(self._early, True)
+        gm.replay()
+        if gs2 is not None:
+            with torch.cuda.stream(side):
+                gs2.replay()
+        main.wait_stream(side)
+        if exchange:
+            self.exchange.finish(token)
+            self.exchange.run(self._late)
+
     def _time_fwd_bwd(self, pairs, stream, reps: int = 3) -> float:
         """milliseconds per replay of the forward + backward graphs (each with its side graph, joined): one untimed pass, then `reps` timed ones"""
         def once():
-            for g, gs in pairs:
-                if g is not None:
-                    self._replay_with_side(g, gs)
+            (ga, gs), (gm, gs2) = pairs
+            if gm is None:
+                self._replay_with_side(ga, gs)
+            elif gs is None and gs2 is None:
+                ga.replay()
+                gm.replay()
+            else:
+                self._staged_with_side(ga, gs, gm, gs2, False)
         with torch.cuda.stream(stream):
             once()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -625,7 +656,8 @@ class TrainStep:
                 gs2, work2, _ = capture(gm, ga.pool(), self._bwd_rest, mode)
             cands[mode] = (ga, gm, gs, side_work, gs2, work2, loss, self.outputs)
             if len(modes) > 1:
-                self.side_graph_ms[mode] = self._time_fwd_bwd([(ga, gs), (gm, gs2)], cap)
+                # (timed on the stream the replays will be launched from: which hardware queue it shares with the side stream is part of the answer)
+                self.side_graph_ms[mode] = self._time_fwd_bwd([(ga, gs), (gm, gs2)], torch.cuda.current_stream())
         self.side_graph = min(self.side_graph_ms, key=self.side_graph_ms.get) if len(modes) > 1 else modes[0]
         ga, gm, gs, side_work, gs2, work2, self.loss, self.outputs = cands.pop(self.side_graph)
         if cands:   # the slower variant: its graph memory goes back to the allocator
