@@ -67,7 +67,7 @@ class RelationConstraint:
             self.start[slot] = lo
         self.ordinal = {e: i for i, e in enumerate(RelElement)}
         self._eos = int(tok.name_to_id("eos"))
-        self._all_bins = frozenset(range(self.nbin))   # (never modified: _meet builds new sets)
+        self._all_bins = (0, self.nbin)   # admissible bins are always ONE run [lo, hi): the full range met with intervals
         self.history: List[_State] = []
         self.types: Optional[torch.Tensor] = None
 
@@ -173,19 +173,23 @@ class RelationConstraint:
         return None
 
     @staticmethod
-    def _meet(allowed: set, interval) -> set:
-        """intersection with [lo, hi); an EMPTY interval leaves the set unchanged (the reference's `_intersect`)"""
+    def _meet(allowed, interval):
+        """intersection of the admissible run [a, b) with [lo, hi); an EMPTY interval leaves it unchanged (the reference's `_intersect`).
+        (The reference filters a set of bins; every set it can reach is a run, the empty one included.)"""
         if interval is None:
             return allowed
         lo, hi = interval
         if hi <= lo:
             return allowed
-        return {b for b in allowed if lo <= b < hi}
+        a, b = allowed
+        a, b = (a if a > lo else lo), (b if b < hi else hi)
+        return (a, b) if b > a else (0, 0)
 
-    def _mask_from(self, allowed: set, slot: int) -> torch.Tensor:
+    def _mask_from(self, allowed, slot: int) -> torch.Tensor:
         mask = torch.ones(self.V, dtype=torch.bool)
-        if allowed:
-            mask[torch.tensor(sorted(allowed), dtype=torch.long) + self.start[slot]] = False
+        a, b = allowed
+        if b > a:
+            mask[self.start[slot] + int(a):self.start[slot] + int(b)] = False
         return mask
 
     # ------------------------------------------------------------------------------------------
@@ -205,7 +209,7 @@ class RelationConstraint:
         """the same step without tensors (the batched decode loop builds the masks of all samples at once): n_decoded tokens are decoded, `last`
         is the latest of them -> (what is admissible, back-track position or None):
           ("only", token)        that one token
-          ("bins", slot, set)    the bin tokens start[slot] + b, b in the set (an EMPTY set admits nothing)
+          ("bins", slot, (a, b)) the bin tokens start[slot] + a .. start[slot] + b - 1 (an EMPTY run admits nothing)
           ("slot", n_decoded)    whatever the tokenizer admits at this position"""
         self.history = self.history[: n_decoded + 1]
         st = self.history[-1].copy()

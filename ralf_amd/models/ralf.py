@@ -667,8 +667,9 @@ class _GeneratorBase(nn.Module):
                 if what[0] == "only":
                     allow[i, what[1]] = True
                 elif what[0] == "bins":
-                    if what[2]:
-                        allow[i, np.fromiter(what[2], np.int64, len(what[2])) + start[what[1]]] = True
+                    lo, hi = what[2]
+                    if hi > lo:
+                        allow[i, start[what[1]] + int(lo):start[what[1]] + int(hi)] = True
                 else:
                     allow[i] = tmask[what[1]]
             lg[~allow] = NEG_INF
