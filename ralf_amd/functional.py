@@ -93,6 +93,7 @@ class Runtime:
         # item behind EXTERNAL events recorded at its producers; the engine captures the queue as a graph of its own and replays it on the
         # side stream next to the main graph -- concurrency by stream order instead of by the hipGraph executor's branch placement
         self.defer_side = False
+        self.cut_branches = os.environ.get("RALF_BRANCH_CUT", "1") != "0"   # side-graph capture: the constraint encoder's backward is side work too (branch_cut)
         self._deferred: list = []   # (events to wait for, closure, operands kept alive)
         self._wdep_streams: dict = {}
         self.cut_enabled = False  # engine mode (data parallel): split the backward at grad_cut() points
@@ -196,6 +197,30 @@ class Runtime:
             return x
         leaf = x.detach().requires_grad_()
         self._cuts.append((x, leaf))
+        return leaf
+
+    def branch_cut(self, x: torch.Tensor) -> torch.Tensor:
+        """identity, unless the engine is capturing with the side work deferred (defer_side): then the autograd graph is cut at this output of a
+        sub-network branch whose backward feeds nothing but parameter gradients (the constraint encoder), and that backward is QUEUED like a
+        weight gradient -- behind an event recorded where the gradient of x is complete -- and captured into the side graph: it runs beside the
+        data-gradient chain instead of where the hipGraph executor places the branch (after the chain: a tail of ~70 tiny kernels)."""
+        if not (self.defer_side and self.cut_branches and torch.is_grad_enabled() and x.requires_grad):
+            return x
+        leaf = x.detach().requires_grad_()
+
+        def hook(g):
+            ev = ExternalEvent().record(torch.cuda.current_stream())
+
+            def run():   # (under capture of the side graph, current stream = the side stream: autograd forks to the branch's stream and joins back)
+                ov, self.overlap = self.overlap, False   # the branch's own weight gradients run in line, on its stream
+                try:
+                    torch.autograd.backward([x], [g])
+                    self.flush_wgrads()
+                finally:
+                    self.overlap = ov
+            self._deferred.append(([ev], run, (x, g)))
+            return g
+        leaf.register_hook(hook)
         return leaf
 
     def register_shadow(self, w: torch.Tensor, view: torch.Tensor):

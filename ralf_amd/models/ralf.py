@@ -267,6 +267,7 @@ class _GeneratorBase(nn.Module):
         if cf is None:
             cf = self._constraint_features(inputs)
         rt.join_branch("constraint", cf)
+        cf = rt.branch_cut(cf)   # (side-graph capture: the constraint encoder's backward becomes side work)
         if self.use_flag_embedding:   # cat([img_mem + task_emb[0], cf + task_emb[1]]) in one launch (retrieval_augmented_autoreg.py:1022-1028)
             return RF.concat_rows([img_mem, cf], rt, self.task_emb.weight, [0, 1])
         return RF.concat_rows([img_mem, cf], rt)
