@@ -731,7 +731,7 @@ class _GeneratorBase(nn.Module):
         (tools/relation_probe.py) and the loop is sequential from there: 126.3 against 126.7 ms per sample.
         rng = "per_sample" (opt-in THROUGHPUT mode, NOT the reference's draw order): every sample draws its back-track positions from a
         generator of its own, so no sample waits for another and the whole batch decodes in lock-step, one batched decoder step per token
-        (B = 256: 28 s -> 1.1 s per batch; argmax decoding takes the masks of all samples on one array, _relation_lockstep_batched).  Sample 0 continues Python's global stream -- a batch of one decodes exactly as the sequential
+        (B = 256: 28 s -> 0.97 s per batch; argmax decoding takes the masks of all samples on one array, _relation_lockstep_batched).  Sample 0 continues Python's global stream -- a batch of one decodes exactly as the sequential
         loop does -- and leaves it where it stopped; sample b > 0 is seeded from that stream's state and b.  Same masks, same control flow per
         sample, same distribution of the draws; only WHICH random number a sample sees differs from the reference."""
         assert rng in ("shared", "per_sample")
