@@ -215,6 +215,15 @@ class Runtime:
                 ov, self.overlap = self.overlap, False   # the branch's own weight gradients run in line, on its stream
                 try:
                     torch.autograd.backward([x], [g])
+                    # autograd joins the streams it accumulated LEAF gradients on; the parameter gradients here are written straight into the flat
+                    # buffer, so a stream it forked to may be left open: close every one that is part of this capture
+                    here = torch.cuda.current_stream()
+                    for st in list(self._branch_streams.values()) + [self._main_stream]:
+                        if st is not None and st.cuda_stream != here.cuda_stream:
+                            with torch.cuda.stream(st):
+                                forked = torch.cuda.is_current_stream_capturing()
+                            if forked:
+                                here.wait_stream(st)
                     self.flush_wgrads()
                 finally:
                     self.overlap = ov
