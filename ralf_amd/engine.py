@@ -19,6 +19,7 @@ from typing import Optional
 import torch
 
 from . import ops
+from .functional import ExternalEvent
 
 
 # other threads (RCCL's watchdog polls events) may touch the HIP runtime while this thread captures
@@ -624,7 +625,7 @@ class TrainStep:
         # tail gains).  RALF_SIDE_GRAPH=auto (default): capture both, time three replays of each on THIS model, batch shape and box, keep the
         # faster, free the other.  0 / 1 force a mode.  The staged (data-parallel) backward has a side graph per stage.
         want = os.environ.get("RALF_SIDE_GRAPH", "auto")
-        can_defer = rt.overlap and rt.direct_grads and rt.n_side == 1
+        can_defer = rt.overlap and rt.direct_grads and rt.n_side == 1 and want != "0" and not dot and ExternalEvent.supported()
         modes = [False] if (want == "0" or not can_defer or dot) else [True] if want == "1" else [False, True]
         cands, self.side_graph_ms = {}, {}
 

@@ -56,6 +56,34 @@ class ExternalEvent:
         rc = hip.hipStreamUpdateCaptureDependencies(stream.cuda_stream, (vp * 1)(node), 1, 1)   # hipStreamSetCaptureDependencies
         assert rc == 0, f"hipStreamUpdateCaptureDependencies: {rc}"
 
+    _ok = None
+
+    @classmethod
+    def supported(cls) -> bool:
+        """one probe per process: a record node and a wait node in two tiny captures (a runtime without the calls, or one that rejects the nodes,
+        keeps the engine on graph branches)"""
+        if cls._ok is None:
+            try:
+                s1, s2 = ops.own_stream("event-probe-a"), ops.own_stream("event-probe-b")
+                x = torch.zeros(64, device="cuda")
+                torch.cuda.synchronize()
+                ev, g1, g2 = cls(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1, stream=s1, capture_error_mode="thread_local"):
+                    x.add_(1.0)
+                    ev.record(torch.cuda.current_stream())
+                with torch.cuda.graph(g2, pool=g1.pool(), stream=s2, capture_error_mode="thread_local"):
+                    ev.wait(torch.cuda.current_stream())
+                    x.mul_(2.0)
+                with torch.cuda.stream(s1):
+                    g1.replay()
+                with torch.cuda.stream(s2):
+                    g2.replay()
+                torch.cuda.synchronize()
+                cls._ok = float(x[0]) == 2.0
+            except Exception:   # noqa: BLE001 -- whatever the runtime objects to: no side graph
+                cls._ok = False
+        return cls._ok
+
     def record(self, stream) -> "ExternalEvent":
         self._node(stream, True)
         return self
