@@ -591,6 +591,21 @@ class TrainStep:
         return e0.elapsed_time(e1) / reps
 
     def _capture(self, inputs, targets):
+        # No collector pass while graphs are being captured: a pass that runs inside a capture frees whatever cyclic garbage it finds there and
+        # then (graph executables, events of an earlier TrainStep), and a destructor's HIP call on the capturing thread aborts the process
+        # (seen as "Fatal Python error: Aborted ... Garbage-collecting" in the middle of a captured forward once a capture had become several
+        # captures and timed replays).  Everything collectable goes before the first capture begins.
+        import gc
+        gc.collect()
+        was = gc.isenabled()
+        gc.disable()
+        try:
+            self._capture_impl(inputs, targets)
+        finally:
+            if was:
+                gc.enable()
+
+    def _capture_impl(self, inputs, targets):
         self._static = _clone_tree({"inputs": inputs, "targets": targets}, self.model.device)
         si, st = self._static["inputs"], self._static["targets"]
         # the warm-up steps (allocator, lazy inits, LDS attributes) must not train: the state they touch is put back, so the

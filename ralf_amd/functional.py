@@ -91,10 +91,9 @@ class ExternalEvent:
     def wait(self, stream):
         self._node(stream, False)
 
-    def __del__(self):
-        hip = getattr(ExternalEvent, "_hip", None) if ExternalEvent is not None else None   # (module globals may be gone at interpreter exit)
-        if hip is not None and self._ev:
-            hip.hipEventDestroy(self._ev)
+    # (no __del__: the event is referenced by nodes of captured graphs whose executables may be destroyed AFTER this object -- the garbage
+    #  collector frees a TrainStep's members in no particular order, and hipGraphExecDestroy on a graph whose event is gone aborts the
+    #  process.  A capture creates a few dozen of these; they live as long as the process.)
 
 
 class Runtime:
