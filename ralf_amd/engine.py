@@ -828,8 +828,16 @@ class GraphedDecode:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph, stream=ops.own_stream("capture"), capture_error_mode=_CAPTURE_MODE):
-                self._out = self.model.decode_tokens(s["enc"], s["seq"], self.cond_type, self.cfg, self.kv)
+            import gc
+            gc.collect()
+            was = gc.isenabled()
+            gc.disable()   # (no collector pass inside a capture: TrainStep._capture)
+            try:
+                with torch.cuda.graph(self._graph, stream=ops.own_stream("capture"), capture_error_mode=_CAPTURE_MODE):
+                    self._out = self.model.decode_tokens(s["enc"], s["seq"], self.cond_type, self.cfg, self.kv)
+            finally:
+                if was:
+                    gc.enable()
         else:
             _copy_tree(self._static, {"enc": enc_in, "seq": cond_seq})
         self._graph.replay()
