@@ -188,7 +188,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
     }
     l = xor_sum(l);   // the four lane groups' shares (every wave, whether it writes or not: cross-lane operations want all lanes)
     if (active && qi < d.Sq) {
-        const float inv = (drop ? inv_keep : 1.f) / l;   // (the kept probabilities went into P V unscaled)
+        // (a query row whose keys are ALL masked has l == 0: its output is defined as 0 and its lse as -inf -- this translation unit is compiled
+        //  with -fno-honor-nans, under which a 0 * inf here would be poison, not a NaN the training loop's checks could see)
+        const float inv = l > 0.f ? (drop ? inv_keep : 1.f) / l : 0.f;   // (the kept probabilities went into P V unscaled)
         bf16* Op = (bf16*)d.o + b * d.o_bs + (int64_t)qi * d.o_rs + (int64_t)h * DH;
 #pragma unroll
         for (int c = 0; c < DH / 16; ++c) {
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const RalfAttnDesc d) {
             for (int r = 0; r < 4; ++r) t[r] = (bf16)(o[c][r] * inv);
             *reinterpret_cast<bf16x4*>(Op + c * 16 + 4 * g) = t;
         }
-        if (d.lse && g == 0) d.lse[((int64_t)b * d.H + h) * d.Sq + qi] = __fmaf_rn(m, d.scale, __logf(l));   // (explicit fma: tlayer.hip must write the same bits)
+        if (d.lse && g == 0) d.lse[((int64_t)b * d.H + h) * d.Sq + qi] = l > 0.f ? __fmaf_rn(m, d.scale, __logf(l)) : -INFINITY;   // (explicit fma: tlayer.hip must write the same bits)
     }
 }
 

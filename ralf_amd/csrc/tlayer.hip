@@ -287,7 +287,7 @@ __device__ __forceinline__ void attn_finish(const AttnState& st, int Sq, int h, 
     for (int qg = 0; qg < 4; ++qg) {
         const int qi = qg * 16 + Ls;
         const float lsum = xor_sum(st.l[qg]);
-        const float inv = keep_scale / lsum;
+        const float inv = lsum > 0.f ? keep_scale / lsum : 0.f;   // (all keys masked: output 0, lse -inf -- as attn_fwd_mfma)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             bf16x4 t;
@@ -295,7 +295,7 @@ __device__ __forceinline__ void attn_finish(const AttnState& st, int Sq, int h, 
             for (int r = 0; r < 4; ++r) t[r] = qi < Sq ? (bf16)(st.o[qg][c][r] * inv) : (bf16)0.f;
             *reinterpret_cast<bf16x4*>(Os + qi * LDA + h * TDH + c * 16 + 4 * g) = t;
         }
-        if (qi < Sq && g == 0) lse[qi] = __fmaf_rn(st.m[qg], scale, __logf(lsum));   // (as attn_fwd_mfma)
+        if (qi < Sq && g == 0) lse[qi] = lsum > 0.f ? __fmaf_rn(st.m[qg], scale, __logf(lsum)) : -INFINITY;   // (as attn_fwd_mfma)
     }
 }
 

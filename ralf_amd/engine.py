@@ -161,6 +161,7 @@ class GradExchange:
         self._unpack = unpack or ops.cast_into
         self.rank = torch.distributed.get_rank(group) if self.active and torch.distributed.is_initialized() else 0
         self.ran: dict = {}
+        self.rounds = 0          # collective launches so far (diagnostics: ranks of one job must agree, tests/test_two_ranks_gpu.py)
 
     @property
     def active(self) -> bool:
@@ -181,6 +182,7 @@ class GradExchange:
         buf = self.flat if self.wire == "fp32" else self.stage
         works = []
         for a, b in ranges:
+            self.rounds += 1
             if self.wire == "bf16":
                 self._pack(self.flat[a:b], self.stage[a:b])
             rs = self.mode == "rs_ag" and (b - a) % self.world == 0 and b > a
@@ -371,6 +373,7 @@ class TrainStep:
         self._sig = None
         self.max_graph_shapes = int(os.environ.get("RALF_MAX_GRAPH_SHAPES", "3"))
         self.eager_fallbacks = 0
+        self.captures = 0
         # Data parallel: the backward runs in two stages around rt.grad_cut() (after layer2 of the ResNet).  Stage 1
         # (decoder, encoders, FPN, layer4, layer3) completes 94 % of the gradient bytes; their all-reduce runs on RCCL's
         # stream WHILE stage 2 (layer2, layer1, stem: most of the backbone's backward time, 6 % of the bytes) computes.
@@ -400,6 +403,7 @@ class TrainStep:
         rt = self.model.rt
         self.opt.zero_grad()
         rt.cut_enabled, rt._cuts = self.staged, []
+        rt._fans = []
         try:
             out, losses = self.model._train_loss(inputs, targets)
         finally:
@@ -411,6 +415,8 @@ class TrainStep:
         loss.backward(self._seed_grad)
         rt.join_side()
         rt.join_all_branches()
+        if not rt._cuts:
+            rt.check_fans()
         return loss.detach()
 
     def _bwd_rest(self):
@@ -421,6 +427,7 @@ class TrainStep:
             torch.autograd.backward([o for o, _ in cuts], [leaf.grad for _, leaf in cuts])
             rt.join_side()
             rt.join_all_branches()
+            rt.check_fans()
 
     def _sync_replicas(self, rt):
         """what the reference's DDP constructor does (train/train.py:208): every rank starts from rank 0's parameters and
@@ -486,7 +493,11 @@ class TrainStep:
                 sig = None
         if not self.use_graph or sig is None:
             if self.use_graph:
+                # shape cache full: the same arithmetic, eagerly.  The graphs of the previous shape keep THEIR static loss / output tensors
+                # (saved in _by_shape above); forgetting the current signature makes the next graphed step restore its own set from the
+                # cache instead of replaying into handles this eager step has just replaced (a stale loss after a fallback).
                 self.eager_fallbacks += 1
+                self._static = self._graphs = self._sig = None
             self.loss = self._eager(inputs, targets)
         else:
             if self._graphs is None:
@@ -615,10 +626,16 @@ class TrainStep:
         # stream, so its per-stream workspaces reach their size before the capture and outside its pool.  No collective may ever
         # run on the capture stream: RCCL issues a synchronous collective on the CURRENT stream, and its completion event --
         # polled by the watchdog thread -- must not sit on a stream that starts capturing (hipErrorCapturedEvent -> abort).
+        # Data parallel: only the FIRST capture's warm-up runs the gradient exchange (every rank captures at its first step, so the rounds
+        # match and RCCL / the wire's staging buffers are warm afterwards).  A later capture is triggered by THIS rank's batch shape (ragged
+        # last batch, kmax = n_valid.max() of its own data) while other ranks replay a cached shape: a warm-up exchange here would pair this
+        # rank's throw-away gradients with their real ones and shift every later round by one.
         side, cap = ops.own_stream("warmup"), ops.own_stream("capture")
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            self._eager(si, st)
+        if self.world == 1 or self.captures == 0:
+            with torch.cuda.stream(side):
+                self._eager(si, st)
+        self.captures += 1
         cap.wait_stream(side)
         with torch.cuda.stream(cap):
             self._fwd_bwd(si, st)

@@ -132,6 +132,7 @@ class Runtime:
         self.kv_ahead = os.environ.get("RALF_KV_AHEAD", "1") != "0"   # decoder: the memory's K/V projections ahead of the layers (Runtime.ahead)
         self._branch_streams: dict = {}
         self._branch_keep: list = []
+        self._fans: list = []            # fan-out aliases of the current forward (check_fans)
         # engine mode (bf16): weight / bias gradients of the linear layers are COLLECTED during the backward and issued as grouped
         # launches (ops.wgrad_grouped: every output tile walks its whole reduction, no split-K slabs, no reduce kernels; one
         # column-sum launch for all bias gradients) whenever `group_tiles` output tiles are pending
@@ -307,7 +308,20 @@ class Runtime:
             return x
         a = _AliasFn.apply(x)
         a._ralf_fan = [None, 0]   # [the shared d(x) buffer, backwards still to come]
+        self._fans.append(a._ralf_fan)
+        if len(self._fans) > 64:   # (forward-only callers never reach check_fans)
+            del self._fans[:-64]
         return a
+
+    def check_fans(self):
+        """end of a COMPLETE backward (engine.TrainStep): every fan-out alias handed its summed d(x) to autograd.  The buffer is returned by the
+        LAST of the fan's backwards (LinearFn.backward); a consumer whose backward never ran -- an output that does not reach the loss -- would
+        leave the counter above zero and the gradient of the shared tensor silently dropped."""
+        fans, self._fans = self._fans, []
+        for f in fans:
+            if f[1] != 0:
+                raise RuntimeError(f"fanout_alias: {f[1]} of the linear layers that consumed the alias never ran their backward; d(x) of the shared "
+                                   "tensor was not handed to autograd (a consumer's output does not reach the loss)")
 
     def tag_dropout(self, y: torch.Tensor, p: float, call: int):
         if p > 0.0 and self.ln_dropout:   # (called inside Function.forward, where grad mode is off: no grad-mode test here)

@@ -207,7 +207,11 @@ class RetrievalDatasetWrapper(torch.utils.data.Dataset):
                  with_images: bool = False, **_):
         self.dataset_name, self.dataset, self.db_dataset = dataset_name, dataset, db_dataset
         self.top_k, self.max_seq_length, self.with_images = top_k, max_seq_length, with_images
-        self.table_idx = load_cache_table(table_path(dataset_name, split, retrieval_backbone, num_cache_indexes_per_sample, cache_dir), top_k)
+        # random_retrieval=True: the reference's train.py:136-137 picks RandomRetrievalDatasetWrapper (no table file is read, K uniform draws
+        # per item).  Constructed through THIS class with the flag set, the behaviour is the same -- never a silent table lookup.
+        self.random_retrieval = bool(random_retrieval) or isinstance(self, RandomRetrievalDatasetWrapper)
+        self.table_idx = None if self.random_retrieval else load_cache_table(
+            table_path(dataset_name, split, retrieval_backbone, num_cache_indexes_per_sample, cache_dir), top_k)
         self._layouts = self._layout_table(db_dataset, max_seq_length)
 
     @staticmethod
@@ -233,8 +237,13 @@ class RetrievalDatasetWrapper(torch.utils.data.Dataset):
 
     def __getitem__(self, index: int) -> dict:
         data = dict(self.dataset[index])
-        data_id = int(data["id"]) if "pku" in self.dataset_name else data["id"]
-        hits = self.table_idx[data_id]
+        if self.random_retrieval:
+            # helpers/random_retrieval_dataset_wrapper.py:75-77: K draws from torch's GLOBAL generator, upper bound = len(self) (the split's
+            # own length, not the database's), used as database rows -- the same call, so a seeded run draws the same exemplars
+            hits = torch.randint(low=0, high=len(self), size=[self.top_k]).tolist()
+        else:
+            data_id = int(data["id"]) if "pku" in self.dataset_name else data["id"]
+            hits = self.table_idx[data_id]
         assert len(hits) == self.top_k, f"{len(hits)=} != {self.top_k=}"
         sel = np.asarray(hits, np.int64)
         retrieved = {"index": hits}
@@ -248,3 +257,10 @@ class RetrievalDatasetWrapper(torch.utils.data.Dataset):
             retrieved["image"] = torch.zeros(self.top_k, 4, 1, 1)
         data["retrieved"] = [retrieved]
         return data
+
+
+class RandomRetrievalDatasetWrapper(RetrievalDatasetWrapper):
+    """`helpers/random_retrieval_dataset_wrapper.py:12-112` (the `generator.random_retrieval=true` ablation, train/train.py:136-137): the K
+    exemplars of an item are K uniform draws `torch.randint(0, len(self), [K])` from torch's global generator instead of a table lookup; no
+    retrieval cache file is needed.  Same constructor keywords; `random_retrieval` is forced on as in the reference (its line 38)."""
+

@@ -76,5 +76,5 @@ def test_bench_compiles_without_warnings_and_its_cpu_baseline_leg_runs():
     sys.path.insert(0, ROOT)
     import bench
 
-    r = bench.cpu_baseline_train(N=10, B=2, steps=1, warm=0, hw=64)
+    r = bench.cpu_baseline_train(N=10, B=2, steps=1, warm=0, hw=64, B_autoreg=2, steps_autoreg=1, warm_autoreg=0)
     assert r["value"] > 0 and r["kind"] == "port" and "BOUND" in r["sample"] and r["autoreg_baseline"]["value"] > 0

@@ -399,19 +399,28 @@ def test_graphed_step_follows_the_batch_shape(golden):
     m2, _, _ = make(golden, "bfloat16")
     B, Lc = inputs["seq"].shape[0], inputs["seq_layout_const"].shape[1]
     assert B >= 3 and Lc >= 4
+    # A, B, A, C, D (cache full: eager), C AGAIN (the shape that was current when the fallback happened: ADVICE r5, its replay must report its
+    # own static loss, not the eager step's tensor), B, A
     batches = [(inputs, tgt), (_slice_batch(inputs, B - 1), _slice_batch(tgt, B - 1)), (inputs, tgt), (_slice_batch(inputs, B, Lc - 1), tgt),
-               (_slice_batch(inputs, 1), _slice_batch(tgt, 1)), (_slice_batch(inputs, B - 1), _slice_batch(tgt, B - 1)), (inputs, tgt)]
+               (_slice_batch(inputs, 1), _slice_batch(tgt, 1)), (_slice_batch(inputs, B, Lc - 1), tgt),
+               (_slice_batch(inputs, B - 1), _slice_batch(tgt, B - 1)), (inputs, tgt)]
     eager, graphed = TrainStep(m1, use_graph=False), TrainStep(m2, use_graph=True)
     graphed.max_graph_shapes = 3
     le = [eager(i, t).item() for i, t in batches]
-    lg = [graphed(i, t).item() for i, t in batches]
+    lg, handles = [], []
+    for i, t in batches:
+        loss = graphed(i, t)
+        lg.append(loss.item())
+        handles.append((loss.data_ptr(), graphed.outputs["logits"].data_ptr()))
     assert graphed.eager_fallbacks == 1 and len(graphed._by_shape) == 3          # the fourth shape (one sample) ran eagerly
+    assert handles[5] == handles[3] and handles[5] != handles[4], "the step after a fallback reports the eager step's tensors"
+    assert handles[7] == handles[2] == handles[0] and handles[6] == handles[1]
     assert graphed.steps_done == len(batches) == int(graphed.opt.step_dev)
     for a, b in zip(le, lg):
         assert abs(a - b) <= 2e-2 * max(1.0, abs(a)), (le, lg)
     for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         if p1.requires_grad:
-            assert (p1 - p2).abs().max().item() <= 2e-3, k      # seven Adam steps of lr 1e-4: sign flips at rounding level bound the distance
+            assert (p1 - p2).abs().max().item() <= 2.5e-3, k      # eight Adam steps of lr 1e-4: sign flips at rounding level bound the distance
 
 
 def test_graphed_adamw_refuses_a_silent_clip_default(golden):

@@ -293,6 +293,30 @@ def test_attention_backward_padded_key_with_a_huge_score(Sq, Sk):
     close(dq, q.grad, torch.bfloat16, **tol); close(dk, k.grad, torch.bfloat16, **tol); close(dv, v.grad, torch.bfloat16, **tol)
 
 
+@pytest.mark.parametrize("Sq,Sk", [(256, 256), (50, 300)])
+def test_attention_with_every_key_of_a_sample_masked_is_defined(Sq, Sk):
+    """a sample whose keys are ALL padded (an empty constraint sequence): l == 0 in the forward's epilogue.  attention_mfma.hip / tlayer.hip are
+    built with -fno-honor-nans, so the kernel defines the case instead of leaving 0 * inf to the flag: output 0, lse -inf, zero gradients for
+    that sample; the other sample is untouched"""
+    from ralf_amd import ops
+
+    B, H, dh = 2, 8, 32
+    d = H * dh
+    q, k, v = (rnd(B, S, d, seed=s, dtype=torch.bfloat16).float() for S, s in ((Sq, 70), (Sk, 71), (Sk, 72)))
+    kpm = torch.zeros(B, Sk, dtype=torch.bool); kpm[0, :] = True
+    dev = lambda t: t.detach().to(torch.bfloat16).cuda()
+    qd, kd, vd = dev(q), dev(k), dev(v)
+    od, lse = ops.attention_fwd(qd, kd, vd, B, H, Sq, Sk, dh, kpm=kpm.to(torch.uint8).cuda())
+    assert torch.equal(od[0].float(), torch.zeros_like(od[0].float())) and bool(torch.isinf(lse.view(B, -1)[0]).all()) and bool((lse.view(B, -1)[0] < 0).all())
+    want = ref_attention(q[1:], k[1:], v[1:], H, False, None, dh ** -0.5)
+    close(od[1:], want, torch.bfloat16)
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    go = dev(rnd(B, Sq, d, seed=73, dtype=torch.bfloat16))
+    ops.attention_bwd(go, qd, kd, vd, od, lse, dq, dk, dv, B, H, Sq, Sk, dh, kpm=kpm.to(torch.uint8).cuda())
+    for t in (dq, dk, dv):
+        assert torch.isfinite(t.float()).all() and float(t[0].float().abs().max()) == 0.0
+
+
 def test_attention_packed_qkv_and_dropout():
     """self-attention on a packed [B,S,3d] buffer; dropout backward consistent with forward (finite differences)."""
     from ralf_amd import ops

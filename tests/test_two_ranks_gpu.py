@@ -111,6 +111,69 @@ def test_two_ranks_on_one_gpu_keep_identical_weights(tmp_path, wire, mode):
             assert abs(r[0]["gnorm1"] - base["gnorm1"]) < 2.0 ** -8 * base["gnorm1"], (r[0]["gnorm1"], base["gnorm1"])
 
 
+def _rank_shapes(rank, world, port, out_dir):
+    """rank 0 meets a NEW batch shape (the ragged last batch) at a step where rank 1 replays a cached one, and vice versa"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import datetime
+
+    import torch.distributed as dist
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from ralf_amd.engine import TrainStep
+    from ralf_amd.synthetic import make_batch, to_device
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=240))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    try:
+        t = torch.ones(4, device=dev) * (rank + 1)
+        dist.all_reduce(t)
+    except Exception as e:
+        torch.save({"skip": repr(e)}, os.path.join(out_dir, f"s{rank}.pt"))
+        return
+    torch.manual_seed(3)
+    model = bench.build_model(dev, 10, "bfloat16")
+
+    def batch(n, seed):
+        i, t = model.preprocess(make_batch(n, 10, seed=seed))
+        i, t = to_device(i, dev), to_device(t, dev)
+        i["retrieved"] = {k: v for k, v in i["retrieved"].items() if k != "image"}
+        return i, t
+    full, ragged = batch(3, 11 + rank), batch(2, 21 + rank)
+    # step:      0     1       2       3     4
+    seq = [[full, ragged, full, full, ragged], [full, full, full, ragged, ragged]][rank]
+    step = TrainStep(model, use_graph=True)
+    rounds0 = step.exchange.rounds
+    losses = [float(step(*b)) for b in seq]
+    torch.cuda.synchronize()
+    P = step.opt.P.detach().clone()
+    gathered = [torch.empty_like(P) for _ in range(world)]
+    dist.all_gather(gathered, P)
+    torch.save({"losses": losses, "same": bool(torch.equal(gathered[0], gathered[1])), "captures": step.captures,
+                "rounds": step.exchange.rounds - rounds0}, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_with_different_batch_shape_sequences_stay_in_step(tmp_path):
+    """ADVICE r5 (engine.py capture): a capture triggered by ONE rank's batch shape must not issue an extra round of the gradient exchange --
+    the other rank replays a cached shape and issues one.  Both ranks run five steps with two shapes met at different steps: the same number
+    of exchange rounds on both (the first capture's warm-up + one per step), identical weights at the end, no hang."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_rank_shapes, args=(2, free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), f"s{i}.pt")) for i in range(2)]
+    if "skip" in r[0]:
+        pytest.skip("gloo cannot reduce device tensors in this build: " + r[0]["skip"])
+    assert r[0]["captures"] == 2 and r[1]["captures"] == 2
+    assert r[0]["rounds"] == r[1]["rounds"], (r[0]["rounds"], r[1]["rounds"])
+    assert r[0]["same"] and r[1]["same"], "ranks diverged"
+    assert all(x == x for x in r[0]["losses"] + r[1]["losses"])
+
+
 def test_bench_two_ranks_on_one_gpu_prints_one_json_line(tmp_path):
     """the N > 1 flow of bench.py itself (launcher environment, replica sync, barriers, max-over-ranks timing, rank 0's line, the
     data_parallel block) with two ranks on this one GPU (RALF_BENCH_ONE_DEVICE: gloo instead of RCCL, both ranks on device 0)"""
