@@ -439,8 +439,12 @@ __device__ __forceinline__ void lds_stage(T* l, const u32x4 (&regs)[NV], int tid
 constexpr int gemm_at_mode(int GATHER) { return (GATHER == 7 || GATHER == 9) ? 1 : GATHER == 8 ? 2 : 0; }
 constexpr int AT_KMAX = 512;                       // channels of the transformed operand (K of the product)
 constexpr int AT_LDS_BYTES = 3 * AT_KMAX * 4;      // c1 | c2 | c3
+// GATHER 10 / 12 / 13 (round 6): the PIPELINED direct-to-LDS ring -- 3 / 4 / 2 stages, operand fragments double-buffered in registers, the k-tile's
+// one barrier in front of its LAST k-slice (gemm_body: "pipelined ring"); 11 = 10 with the tap-uniform im2col gather of A through the ring
+constexpr bool gemm_is_mt(int GATHER) { return GATHER >= 10 && GATHER <= 13; }
 template <int GATHER, int FM>
-constexpr int gemm_nbuf() { return GATHER == 6 ? 3 : ((GATHER == 1 || GATHER == 4) && FM == 1) ? 1 : 2; }   // the prefetch-distance-1 kernels keep one buffer
+constexpr int gemm_nbuf() { return (GATHER == 6 || GATHER == 10 || GATHER == 11) ? 3 : GATHER == 12 ? 4 : ((GATHER == 1 || GATHER == 4) && FM == 1) ? 1 : 2; }   // the prefetch-distance-1 kernels keep one buffer
+constexpr bool gemm_is_glds(int GATHER) { return GATHER == 5 || GATHER == 6 || gemm_is_mt(GATHER); }
 // GLDS (GATHER 5 / 6): operand tiles go global -> LDS directly (global_load_lds_dwordx4), unpadded images whose 16-byte slots are
 // XOR-swizzled through the SOURCE address; a ring of 2 / 3 stages
 template <typename T, bool AK, bool BKC, int FM, int FN, int NBUF = 2, bool GLDS = false>
@@ -464,7 +468,8 @@ __device__ __forceinline__ void lds_barrier() {
 
 // the body of one workgroup: output tiles bid0, bid0 + grid_x, ... of batch entry z (grid_x matters only for persistent
 // launches).  Called by gemm_kernel (one problem per launch) and gemm_grouped_kernel (many problems per launch).
-template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW, bool CS = false>
+// WGM: waves along m (2 everywhere except the round-6 256-row tiles: 4 x 2 waves of 64 x 64)
+template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW, bool CS = false, int WGM = 2>
 __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, const int grid_x, const int z, const int nbatch, unsigned char* lds_raw) {
     using X = TT<T>;
     static_assert(!CS || (!AK && (GATHER == 5) && sizeof(T) == 2), "column sums of A: k-major bf16 A through the direct-to-LDS ring (the grouped weight gradients)");
@@ -474,9 +479,11 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     constexpr int A_ELEMS = AK ? BM * X::LDK : BK * LDRA;
     constexpr int KV = BK / VEC;                                   // vectors along k (k-contiguous tile)
     constexpr int RVA = BM / VEC, RVB = BN / VEC;                  // vectors along rows (row-contiguous tile)
-    constexpr int NT = 64 * NW, WGN = NW / 2;                       // threads; waves along n (2 along m)
-    constexpr int WFM = FM, WFN = FN * 2 / WGN;                    // 32x32 fragments per wave
-    static_assert(NW == 4 || (NW == 8 && FN == 2), "8 waves: 2 x 4 over a 128-wide tile");
+    constexpr int NT = 64 * NW, WGN = NW / WGM;                     // threads; waves along n (WGM along m)
+    constexpr int WFM = FM * 2 / WGM, WFN = FN * 2 / WGN;          // 32x32 fragments per wave
+    static_assert(NW == 4 || (NW == 8 && FN == 2), "8 waves: 2 x 4 over a 128-wide tile (or 4 x 2 over 256 x 128)");
+    static_assert(WFM >= 1 && WFN >= 1 && WFM * WGM == 2 * FM && WFN * WGN == 2 * FN, "the wave grid tiles the workgroup tile");
+    static_assert(WGM == 2 || (WFM == 2 && EPI != 3 && EPI != 4), "wave grids other than 2 x n: 64-row wave tiles, plain epilogues");
     constexpr int NVA = BM * BK / VEC / NT, NVB = BN * BK / VEC / NT;  // 16-byte vectors per thread per k-tile
     constexpr int CP = BN + 4;                                     // fp32 C staging tile [64][CP] (epilogue)
     constexpr int B_ELEMS = BKC ? BN * X::LDK : BK * LDRB;
@@ -520,7 +527,9 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     // PMC (SQ_ACTIVE_INST_ANY ~ 84 % of the kernel, MFMA busy 10 %) showed this kernel is instruction-issue bound:
     // the interior fast path keeps one pointer per staging vector and advances it by a constant per k-tile.
     // Rows beyond M/N are clamped to the last valid row (their results are never stored).
-    constexpr bool GLDS = GATHER == 5 || GATHER == 6;   // direct-to-LDS ring (bf16, interior fast path, any of the four operand layouts)
+    constexpr bool MT = gemm_is_mt(GATHER);             // ... its pipelined form (both operands k-contiguous)
+    constexpr bool GLDS = gemm_is_glds(GATHER);         // direct-to-LDS ring (bf16, interior fast path, any of the four operand layouts)
+    static_assert(!MT || (AK && BKC && !CS), "pipelined ring: NT products");
     static_assert(!GLDS || sizeof(T) == 2, "direct-to-LDS: bf16 operands");
     // row-contiguous image of an operand with R = BM / BN rows: [BK k-rows][R] bf16, S = 2 R bytes per k-row (128 or 256), no padding.
     // A 1-KiB LDS-DMA covers 1024 / S k-rows with S / 16 lanes each.  The transpose read of a 32-lane half touches 4 consecutive k-rows

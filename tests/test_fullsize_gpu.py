@@ -194,34 +194,42 @@ def test_b64_grouped_wgrads_and_branches_equal_plain_step():
     assert worst > 0.0                 # (the two paths really ran different kernels)
 
 
-def test_b64_gradients_bf16_against_fp32_on_trained_weights_without_damping():
-    """the comparison of test_b64_train_step_bf16_against_fp32_whole_model WITHOUT damping the residual branches: the weights after 400 optimisation
-    steps of the benchmark's own recipe (bf16, learnable synthetic set) go into an fp32 and a bf16 model; gradients on a fresh batch.
-    What the data supports (tools/grad_agreement_trained.py, 1000 steps: profiles/r05_grad_agreement_trained.json): everything behind the backbone
-    agrees to cosine 0.98-0.9997 with norms within 10 %; the ResNet body does NOT -- cosine 0.75 (layer4) ... 0.2-0.4 (layer1-3, stem), before and
-    after training alike.  Its weight gradients are means of large, nearly cancelling per-position terms, so the 2^-9 rounding of every stored
-    activation moves them by their own size; loss, logits and the training curves (tests/test_convergence_gpu.py) agree.  The thresholds below state
-    exactly that and no more."""
+def test_b64_gradients_bf16_against_fp32_on_trained_weights_with_the_autocast_yardstick():
+    """bf16 throughput mode against fp32 parity mode, gradients of the whole model at B = 64 on TRAINED weights (400 steps of the benchmark's recipe,
+    no damping of the residual branches) -- with a YARDSTICK (tools/grad_yardstick.py): the oracle model (stock torch ops, checker
+    use) on the GPU in fp32 and under torch.autocast(bfloat16), same weights, batch and tensors.
+    What the data shows (profiles/r06_grad_agreement_yardstick.json): everything behind the backbone agrees bf16 vs fp32 to cosine >= 0.9995 in
+    BOTH implementations; the ResNet body does not in EITHER -- layer4 0.88 / 0.88, layer3 0.29 / 0.24, layer2 0.25 / 0.25, layer1 0.19 / 0.19,
+    stem 0.16 / 0.08 (HIP / stock autocast; at initialisation 0.82 / 0.82 ... -0.25 / -0.11) -- while the two fp32 implementations agree to
+    0.9994-1.0 on every tensor.  The low cosines are the precision's property (weight gradients that are means of large, nearly cancelling
+    per-position terms), not a rounding point of the HIP path: it is held to the yardstick, tensor by tensor."""
     import importlib.util
     import os
+    import sys
 
-    spec = importlib.util.spec_from_file_location("grad_agreement_trained", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "grad_agreement_trained.py"))
-    ga = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(ga)
-    dev = torch.device(DEV)
-    sd, batch, curve = ga.trained_state(400, dev)
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    sys.path.insert(0, tools)
+    spec = importlib.util.spec_from_file_location("grad_yardstick", os.path.join(tools, "grad_yardstick.py"))
+    gy = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gy)
+    res = gy.yardstick(400, torch.device(DEV))
+    print("trained weights, no damping:", res)
+    curve, loss = res["loss_curve"], res["loss"]
     assert curve[-1] < curve[0] - 1.5, curve                       # it trained (6.27 -> ~4)
-    res = ga.gradient_table(sd, batch, dev)
-    print("trained weights, no damping: bf16 vs fp32", res)
-    assert abs(res["loss_f32"] - res["loss_bf16"]) < 1e-2 * abs(res["loss_f32"]) and res["logits_cosine"] > 0.9995
-    body = []
-    for k, (c, r) in res["grad_cos_normratio"].items():
+    assert abs(loss["hip_fp32"] - loss["torch_fp32"]) < 1e-4 * abs(loss["torch_fp32"])          # the fp32 mode IS the oracle's loss at full size
+    assert abs(loss["hip_bf16"] - loss["hip_fp32"]) < 2e-3 * abs(loss["hip_fp32"])
+    assert abs(loss["hip_bf16"] - loss["hip_fp32"]) < 3 * abs(loss["torch_autocast_bf16"] - loss["torch_fp32"]) + 1e-3
+    hip, yard, f32 = res["hip_bf16_vs_hip_fp32"], res["autocast_vs_torch_fp32"], res["hip_fp32_vs_torch_fp32"]
+    body_h, body_y = [], []
+    for k in hip:
+        (ch, rh), (cy, ry), (c32, r32) = hip[k], yard[k], f32[k]
+        assert c32 > 0.999 and abs(r32 - 1) < 0.02, (k, c32, r32)          # fp32 parity mode against the oracle's fp32 gradients, every tensor
         if ".body." in k:
-            # comparable size, and positively correlated AS A WHOLE: see the docstring.  A single tensor's cosine moves by +-0.2 from run to run
-            # (the 400 steps are not bit-reproducible: fp32 atomics; the stem's has been seen at -0.21 and +0.3), so the body is held to its
-            # median and to a handful of negative tensors at most
-            assert 0.6 < r < 1.5, (k, c, r)
-            body.append(c)
+            # a single tensor's cosine moves by +-0.2 between runs (the 400 steps are not bit-reproducible: fp32 atomics): tensor by tensor the
+            # HIP path may fall short of the yardstick by that much and no more; norms within what the yardstick itself shows (+-10 %)
+            assert ch > cy - 0.25 and 0.85 < rh < 1.15, (k, ch, cy, rh)
+            body_h.append(ch); body_y.append(cy)
         else:
-            assert c > 0.96 and abs(r - 1) < 0.15, (k, c, r)
-    assert sorted(body)[len(body) // 2] > 0.2 and sum(c < 0.0 for c in body) <= max(2, len(body) // 10), sorted(body)
+            assert ch > 0.999 and ch > cy - 2e-4 and abs(rh - 1) < 0.06, (k, ch, cy, rh)
+    med = lambda v: sorted(v)[len(v) // 2]
+    assert med(body_h) > med(body_y) - 0.08 and med(body_h) > 0.15, (sorted(body_h), sorted(body_y))
