@@ -979,7 +979,98 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
         for (int j = 0; j < WFN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if constexpr (GLDS) {
+    if constexpr (MT) {
+        // PIPELINED RING (round 6).  The direct-to-LDS ring below with three changes that take the LDS round trip and the
+        // barrier out of the matrix pipe's way:
+        //   * wave tiles of 64 x 64 (WFM = WFN = 2): 4 fragment reads per 4 MFMAs instead of 3 per 2 (the LDS carried ~190 of its 256 B/clk
+        //     for fragment reads alone at the 64 x 32 tiles' full MFMA rate);
+        //   * fragments double-buffered in registers: k-slice s + 1 is read while slice s multiplies (an in-order wave otherwise waits
+        //     ~64-128 cycles of ds_read latency per slice with the matrix pipe idle);
+        //   * the tile's one barrier sits in front of its LAST k-slice: the wave that arrives has 4 MFMAs (128 cycles of its SIMD's pipe)
+        //     still to issue behind it, the first fragments of the next tile are requested right behind the barrier, and the stage that was
+        //     just read is re-filled while those MFMAs run.
+        // Ring of NST stages, NST - 2 tiles in flight across every barrier (counted vmcnt, raw s_barrier).  Same MFMA chain in the same
+        // order as every other bf16 path: bit-identical results.
+        static_assert(!RALF_GEMM_PERSISTENT, "the direct-to-LDS loop is one tile per workgroup");
+        static_assert(BK == 64, "four 16-wide k-slices per tile");
+        constexpr int NST = gemm_nbuf<GATHER, FM>();
+        constexpr int STAGE = (BM + BN) * BK, NLD = NVA + NVB;
+        const unsigned char* const ring = reinterpret_cast<const unsigned char*>(la0);
+        auto issue = [&](int st) {
+            T* sa = la0 + st * STAGE + wave * (NVA * 512);
+            T* sb = la0 + st * STAGE + BM * BK + wave * (NVB * 512);
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[i], LDS_PTR(void, sa + i * 512), 16, 0, 0);
+                pa[i] += stepA;
+            }
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb[i], LDS_PTR(void, sb + i * 512), 16, 0, 0);
+                pb[i] += stepB;
+            }
+        };
+        bf16x8 fa0[WFM], fb0[WFN], fa1[WFM], fb1[WFN];
+        auto rd = [&](bf16x8 (&fa)[WFM], bf16x8 (&fb)[WFN], int st, int ks) {   // the fragments of k-slice ks of stage st
+            const unsigned char* base = ring + (size_t)st * STAGE * 2;
+            const unsigned oa = gl_offa ^ (unsigned)(ks << 5), ob = (unsigned)(BM * BK * 2) + (gl_offb ^ (unsigned)(ks << 5));
+#pragma unroll
+            for (int i = 0; i < WFM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(base + oa + i * 32 * 128);
+#pragma unroll
+            for (int j = 0; j < WFN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(base + ob + j * 32 * 128);
+        };
+        auto mm = [&](const bf16x8 (&fa)[WFM], const bf16x8 (&fb)[WFN]) {
+#pragma unroll
+            for (int i = 0; i < WFM; ++i)
+#pragma unroll
+                for (int j = 0; j < WFN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        };
+        // prologue: tiles 0 .. NST-1 on their way, tile 0 landed, its first fragments in registers
+#pragma unroll
+        for (int q = 0; q < NST; ++q)
+            if (q < c_nt) issue(q);
+        {
+            const int ahead = min(c_nt, NST) - 1;   // tiles that may stay in flight (wave-uniform)
+            if (ahead >= 3) vm_wait<NLD * 3>(); else if (ahead == 2) vm_wait<NLD * 2>(); else if (ahead == 1) vm_wait<NLD>(); else vm_wait<0>();
+        }
+        lds_barrier();
+        rd(fa0, fb0, 0, 0);
+        int st = 0, t = 0;
+        // one k-tile: slices 0..2 with the next slice's reads in front of each, then [wait for tile t+1 | barrier | first reads of tile t+1 |
+        // slice 3 | re-fill of this tile's stage]
+#define RALF_MT_TILE(WAIT, REFILL)                                                                      \
+        {                                                                                               \
+            const int sn = (st + 1 == NST) ? 0 : st + 1;                                                \
+            rd(fa1, fb1, st, 1);                                                                        \
+            mm(fa0, fb0);                                                                               \
+            rd(fa0, fb0, st, 2);                                                                        \
+            mm(fa1, fb1);                                                                               \
+            rd(fa1, fb1, st, 3);                                                                        \
+            mm(fa0, fb0);                                                                               \
+            WAIT;                                                                                       \
+            lds_barrier();                                                                              \
+            rd(fa0, fb0, sn, 0);                                                                        \
+            mm(fa1, fb1);                                                                               \
+            REFILL;                                                                                     \
+            st = sn;                                                                                    \
+        }
+        for (; t + NST < c_nt; ++t) RALF_MT_TILE(vm_wait<NLD * (NST - 2)>(), issue(st))   // steady state: tile t+NST follows tile t into its stage
+        for (; t + 1 < c_nt; ++t) {                                                      // drain: nothing left to issue
+            const int ahead = c_nt - t - 2;   // tiles behind t+1 that may stay in flight
+            if (NST >= 4 && ahead >= 2) RALF_MT_TILE(vm_wait<NLD * 2>(), (void)0)
+            else if (NST >= 3 && ahead >= 1) RALF_MT_TILE(vm_wait<NLD>(), (void)0)
+            else RALF_MT_TILE(vm_wait<0>(), (void)0)
+        }
+#undef RALF_MT_TILE
+        // last tile: its slice-0 fragments are in set 0
+        rd(fa1, fb1, st, 1);
+        mm(fa0, fb0);
+        rd(fa0, fb0, st, 2);
+        mm(fa1, fb1);
+        rd(fa1, fb1, st, 3);
+        mm(fa0, fb0);
+        mm(fa1, fb1);
+    } else if constexpr (GLDS) {
         // DIRECT-TO-LDS RING.  No staging registers and no ds_write: every wave issues NVA + NVB global_load_lds_dwordx4 per k-tile (1 KiB
         // each) into a ring of NST stages.  Waits are COUNTED (s_waitcnt vmcnt(N) leaves the younger tiles in flight) and the barrier is
         // the raw s_barrier: __syncthreads() would drain the queue (an LDS-DMA is a pending LDS write on the VM counter).  A tile is
@@ -1145,7 +1236,7 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
             }
             unsigned* fcnt = reinterpret_cast<unsigned*>(cs + 64 * CP);   // EPI 4: hit counters of the round's 64 rows (behind the C staging tile)
             if constexpr (EPI == 4) {
-                static_assert(64 * CP * 4 + 64 * 4 <= gemm_lds_bytes<T, AK, BKC, FM, FN, gemm_nbuf<GATHER, FM>(), (GATHER == 5 || GATHER == 6)>(), "filter counters behind the staging tile");
+                static_assert(64 * CP * 4 + 64 * 4 <= gemm_lds_bytes<T, AK, BKC, FM, FN, gemm_nbuf<GATHER, FM>(), gemm_is_glds(GATHER)>(), "filter counters behind the staging tile");
                 if (tid < 64) fcnt[tid] = 0u;
                 __syncthreads();
             }
@@ -1231,11 +1322,11 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     }
 }
 
-template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? ((GATHER == 6 || FM == 4 || gemm_at_mode(GATHER)) ? 2 : 4) : 1) void gemm_kernel(const KParams P) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[gemm_lds_bytes<T, AK, BKC, FM, FN, gemm_nbuf<GATHER, FM>(), (GATHER == 5 || GATHER == 6)>() +
+template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW = 4, int WGM = 2>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? ((GATHER == 6 || FM == 4 || gemm_at_mode(GATHER) || gemm_is_mt(GATHER)) ? 2 : 4) : 1) void gemm_kernel(const KParams P) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[gemm_lds_bytes<T, AK, BKC, FM, FN, gemm_nbuf<GATHER, FM>(), gemm_is_glds(GATHER)>() +
                                                                   (gemm_at_mode(GATHER) ? AT_LDS_BYTES : 0)];   // ONE LDS object (+ the operand transform's coefficient table)
-    gemm_body<T, AK, BKC, GATHER, FM, FN, EPI, NW>(P, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z, (int)gridDim.z, lds_raw);
+    gemm_body<T, AK, BKC, GATHER, FM, FN, EPI, NW, false, WGM>(P, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z, (int)gridDim.z, lds_raw);
 }
 
 // ---- grouped weight gradients ---------------------------------------------------------------------------------------
@@ -1576,7 +1667,7 @@ int resident_workgroups(K kernel, int threads) {
     return (cus / 8 * 8) * per_cu;
 }
 
-template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW = 4>
+template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW = 4, int WGM = 2>
 int launch(KParams& P, int nbatch, hipStream_t st) {
     P.tiles_m = ceil_div(P.d.M, 64 * FM);
     // which operand an XCD keeps in its L2 while the other streams past: workgroups get consecutive tile ids per XCD (xcd_remap), so the
@@ -1588,7 +1679,7 @@ int launch(KParams& P, int nbatch, hipStream_t st) {
     P.tiles_n = ceil_div(P.d.N, 64 * FN);
     P.nwg = P.tiles_m * P.tiles_n;
     constexpr bool persist = RALF_GEMM_PERSISTENT != 0;   // off: measured -4...+6 % (the prefetch across the epilogue costs a wave of occupancy)
-    static const int cap = persist ? resident_workgroups(gemm_kernel<T, AK, BKC, GATHER, FM, FN, EPI, NW>, 64 * NW) : 0;
+    static const int cap = persist ? resident_workgroups(gemm_kernel<T, AK, BKC, GATHER, FM, FN, EPI, NW, WGM>, 64 * NW) : 0;
     const int total = P.nwg * P.d.splitk;
     int grid = total;
     const int room = std::max(8, cap / nbatch / 8 * 8);
@@ -1596,7 +1687,7 @@ int launch(KParams& P, int nbatch, hipStream_t st) {
         const int rounds = ceil_div(total, room);
         grid = std::min(room, ceil_div(ceil_div(total, rounds), 8) * 8);
     }
-    hipLaunchKernelGGL((gemm_kernel<T, AK, BKC, GATHER, FM, FN, EPI, NW>), dim3(grid, 1, nbatch), dim3(64 * NW), 0, st, P);
+    hipLaunchKernelGGL((gemm_kernel<T, AK, BKC, GATHER, FM, FN, EPI, NW, WGM>), dim3(grid, 1, nbatch), dim3(64 * NW), 0, st, P);
     return ralf::check_launch("gemm");
 }
 
