@@ -303,11 +303,9 @@ def bench_convergence(device, N=10, B=64, steps=160, hw=128):
             "max_rel_gap_of_16_step_means": gap}
 
 
-def bench_relation(device, N=10, B=256, dtype="bfloat16", sharpen=None, lockstep=None):
-    """BASELINE configs[4], relationship task at batch 256: sample(cond_type="relation") with back-tracking
-    (retrieval_augmented_autoreg.py:336-507: a per-sample loop by construction -- a violated constraint rewinds THAT sample's
-    prefix, and the draws come from one global `random` stream in sample order), the decoder step KV-cached on the device and
-    replayed from per-position hipGraphs.  Synthetic relation table built with the reference's own rules from the batch."""
+def relation_workload(device, N=10, B=256, dtype="bfloat16", sharpen=None):
+    """model + condition of the relationship-task decode (BASELINE configs[4]): synthetic relation table built with the reference's own rules from
+    the batch.  -> (model, cond, sub) with sub(cond, n) = the first n samples"""
     import random
 
     from ralf_amd.helpers.layout_tokenizer import LabelFeature, LayoutSequenceTokenizer
@@ -336,8 +334,6 @@ def bench_relation(device, N=10, B=256, dtype="bfloat16", sharpen=None, lockstep
             model.decoder.head[1].weight.abs_().mul_(sharpen)
     cond, _ = get_condition(batch, "relation", tok)
     cond.retrieved = {k: v for k, v in cond.retrieved.items() if k != "image"}
-    cfg = {"name": "deterministic", "temperature": 1.0}
-    kw = {} if lockstep is None else {"lockstep": lockstep}
 
     def sub(c, n):
         import copy
@@ -348,6 +344,20 @@ def bench_relation(device, N=10, B=256, dtype="bfloat16", sharpen=None, lockstep
         if hasattr(c, "id"):
             c2.id = c.id[:n]
         return c2
+    return model, cond, sub
+
+
+def bench_relation(device, N=10, B=256, dtype="bfloat16", sharpen=None, lockstep=None):
+    """BASELINE configs[4], relationship task at batch 256: sample(cond_type="relation") with back-tracking
+    (retrieval_augmented_autoreg.py:336-507: a per-sample loop by construction -- a violated constraint rewinds THAT sample's
+    prefix, and the draws come from one global `random` stream in sample order), the decoder step KV-cached on the device.  Exact mode
+    (the reference's draw order): the batch decodes in lock-step, range-one draws deferred (models/ralf.py _relation_lockstep_batched)."""
+    import random
+
+    model, cond, sub = relation_workload(device, N, B, dtype, sharpen)
+    cfg = {"name": "deterministic", "temperature": 1.0}
+    kw = {} if lockstep is None else {"lockstep": lockstep}
+
     model.sample(cond=sub(cond, 4), sampling_cfg=cfg, cond_type="relation", return_violation=True, use_backtrack=True, **kw)   # warm-up (graphs per position)
     torch.cuda.synchronize()
     state = random.getstate()
@@ -359,7 +369,13 @@ def bench_relation(device, N=10, B=256, dtype="bfloat16", sharpen=None, lockstep
     out = {"batch": B, "ms_per_batch": t * 1e3, "ms_per_sample": t * 1e3 / B, "relations_checked": int(vio["total"]), "relations_violated": int(vio["viorated"]),
            "note": "sample_relation with back-tracking, deterministic draw, RELATION_SIZE 10; one decoder step per generated / re-generated token and sample "
                    "(device, graph replay) + the constraint masks of layoutformerpp/relation_restriction.py on the host.  The reference's order of draws "
-                   "from Python's global `random` (sample after sample) is kept: this is the exact mode"}
+                   "from Python's global `random` (sample after sample) is kept: this is the exact mode, decoded in lock-step (range-one draws take their "
+                   "value at once and are consumed from the stream in sample order; other draws wait for the lower-indexed samples)"}
+    random.setstate(state)
+    t0 = time.perf_counter()
+    model.sample(cond=sub(cond, min(B, 32)), sampling_cfg=cfg, cond_type="relation", return_violation=True, use_backtrack=True, lockstep=False)
+    torch.cuda.synchronize()
+    out["sequential_ms_per_sample"] = (time.perf_counter() - t0) * 1e3 / min(B, 32)   # the sample-after-sample loop (round 5's exact mode), first 32 samples
     # opt-in throughput mode: a generator per sample, the whole batch in lock-step (models/ralf.py sample_relation rng="per_sample")
     model.sample(cond=sub(cond, 4), sampling_cfg=cfg, cond_type="relation", return_violation=True, use_backtrack=True, rng="per_sample")   # warm-up
     torch.cuda.synchronize()

@@ -618,12 +618,30 @@ class _GeneratorBase(nn.Module):
             active = still
         return step.cache
 
-    def _relation_lockstep_batched(self, states, memory, env, dev):
-        """rng="per_sample" with argmax decoding: the lock-step loop with the per-sample tensor arithmetic of _relation_advance done for ALL samples
-        at once -- the [B, V] logits are masked (tokenizer slot, forced label, relation restriction), gated and arg-maxed as one numpy array; per
-        sample only the restriction's interval logic (RelationConstraint.step, no tensors) and the back-track bookkeeping on plain ints stay in
-        Python.  Same masks, same comparisons, same draws per sample as _relation_advance (tests/test_configs_gpu.py decodes both ways); the
-        per-sample form spends ~130 us of tiny CPU tensor operations per sample and step, 33 ms per step at B = 256 against 0.5 ms on the device."""
+    def _relation_lockstep_batched(self, states, memory, env, dev, shared: bool = False, serial: bool = False):
+        """The relation decode of a whole batch in LOCK-STEP for argmax decoding: one batched decoder step per iteration (every sample at a
+        position of its own), the masks (tokenizer slot, forced label, relation restriction), the gate and the arg-max of ALL samples taken on
+        one [B, V] numpy array; per sample only the restriction's interval logic (RelationConstraint.step, no tensors) and the back-track
+        bookkeeping on plain ints stay in Python.  Same masks, same comparisons, same draws per sample as _relation_advance.
+
+        MEMO (round 6).  Argmax decoding is deterministic: the logits of a sample depend on its prefix alone, and back-tracking re-decodes the
+        same few prefixes again and again (a sample of the benchmark's workload takes 150-500 steps over a few dozen distinct prefixes).  Every
+        logits row that came back from the device is kept per (sample, prefix); a step whose prefix is known costs no device work, and an
+        iteration in which every stepping sample hits its memo replays nothing at all.  `devtok[b]` records which tokens' keys / values the
+        device cache of sample b holds; when a NEW prefix must be decoded and the cache was last written by another branch, the positions
+        from the first difference on are re-fed first (their rows go to the memo as well).
+
+        shared = True: the EXACT mode, the reference's draw order.  All samples draw from Python's global `random`, consumed sample after
+        sample as in the sequential loop (retrieval_augmented_autoreg.py:437-443), and still nobody waits for a sample that never draws a VALUE:
+          * `random.randint(2, max(2, idx - 1))` with idx <= 3 has ONE possible result, so the sample takes 2 at once and only the CONSUMPTION
+            of the stream (randint(2, 2) loops over 1-bit draws: a stream-dependent number of words) is deferred: `pending[b]` counts those
+            draws and catch_up() replays them on the global stream in sample order, as soon as every lower-indexed sample has finished;
+          * a draw with more than one possible result parks its sample (state untouched: the step is repeated later from the memo) until it is
+            the lowest unfinished sample -- then every draw before it in the reference's order has been consumed and it draws directly.
+        Tokens and the final state of `random` are those of the sequential loop by construction (tests/test_relation_cpu.py on a fake decoder,
+        tests/test_relation_gpu.py).  serial = True (test aid): only the lowest unfinished sample steps -- the sequential ORDER on the batched
+        step's arithmetic.
+        shared = False (rng="per_sample"): every sample draws from its own generator; nobody parks."""
         import numpy as np
 
         ids, T, token_mask_h, _restrict, prob_gate, _cfg = env
@@ -639,54 +657,136 @@ class _GeneratorBase(nn.Module):
         step.bind(RN.decoder_init_cache(self.decoder, memory, self.rt, T))
         tok_h, pos_h, kpm_h = step.tok_h.numpy(), step.pos_h.numpy(), step.kpm_h.numpy()   # (views of the pinned mirrors)
         pad, eos, bos = int(ids["pad"]), int(ids["eos"]), int(ids["bos"])
+        tok_h[:] = bos
+        pos_h[:] = 0
         kpm_h[:] = 1
         kpm_h[:, 0] = int(bos == pad)
         tmask = token_mask_h.numpy()                                     # [positions, V]: what the tokenizer admits at a position
         forced = np.asarray([st.forced for st in states], dtype=np.int64)   # [B, T]: the forced label of a step, -1 = free
         start = states[0].con.start
         seqs = [[bos] for _ in range(B)]
-        active = list(range(B))
-        while active:
-            n_dec = np.fromiter((len(seqs[b]) - 1 for b in active), np.int64, len(active))
-            tok_h[active] = [seqs[b][-1] for b in active]
-            pos_h[active] = n_dec
-            lg = step().numpy()[active]                                  # (a copy: fancy indexing)
-            lg[~tmask[n_dec]] = NEG_INF
-            f = forced[active, n_dec]
-            r = np.nonzero(f >= 0)[0]
-            if r.size:                                                   # one kept logit, as _relation_advance
-                keep = lg[r, f[r]]
-                lg[r] = NEG_INF
-                lg[r, f[r]] = keep
-            raw = lg.copy() if any(states[b].resets > 3 for b in active) else None
-            allow = np.zeros(lg.shape, dtype=bool)
-            backs = []
-            for i, b in enumerate(active):
-                st, sq = states[b], seqs[b]
-                what, back = st.con.step(len(sq) - 1, sq[-1], st.rel)
-                backs.append(back)
-                if what[0] == "only":
-                    allow[i, what[1]] = True
-                elif what[0] == "bins":
-                    lo, hi = what[2]
-                    if hi > lo:
-                        allow[i, start[what[1]] + int(lo):start[what[1]] + int(hi)] = True
-                else:
-                    allow[i] = tmask[what[1]]
-            lg[~allow] = NEG_INF
-            rowmax, arg = lg.max(axis=1), lg.argmax(axis=1)
+        # per sample: prefix (tuple of tokens) -> the DECISION of the step at that prefix, everything the control flow needs of the logits:
+        # (max admissible logit, its token, the arg-max without the relation mask, back-track target, the constraint's state after the step)
+        memo = [dict() for _ in range(B)]
+        devtok = [[] for _ in range(B)]              # per sample: the tokens whose keys / values sit in the device cache, by position
+        active = [0] if (shared and serial) else list(range(B))
+        pending, first_open = [0] * B, 0
+        parked = set(range(1, B)) if (shared and serial) else set()
+        memo_drop = int(os.environ.get("RALF_RELATION_MEMO_DROP", "0"))
+        self.relation_stats = stats = {"iterations": 0, "device_steps": 0, "rows_from_device": 0, "rows_from_memo": 0, "refed_positions": 0}
+
+        def catch_up():
+            """consume, in sample order, the range-one draws of every sample below (and of) the lowest unfinished one"""
+            nonlocal first_open
+            while first_open < B:
+                for _ in range(pending[first_open]):
+                    random.randint(2, 2)
+                pending[first_open] = 0
+                if not states[first_open].done:
+                    break
+                first_open += 1
+        while active or parked:
+            if shared:
+                catch_up()
+                if first_open in parked:             # its turn: every earlier draw of the reference's order has been consumed
+                    parked.discard(first_open)
+                    active = sorted(active + [first_open])
+                assert active, "relation lock-step: parked samples but nobody to step"
+            stats["iterations"] += 1
+            if memo_drop and stats["iterations"] % memo_drop == 0:       # (test aid: forget every decision -- the caches now hold other branches' tokens)
+                for m_ in memo:
+                    m_.clear()
+            # ---- device work: only for prefixes this sample has not decoded before
+            need = []
+            for b in active:
+                sq = seqs[b]
+                if tuple(sq) in memo[b]:
+                    continue
+                dt, L = devtok[b], len(sq)
+                q = 0
+                while q < L - 1 and q < len(dt) and dt[q] == sq[q]:
+                    q += 1
+                # q == L - 1: the cache holds the keys / values of sq[:-1] -> feed the last token; else re-feed position q first
+                stats["refed_positions"] += int(q < L - 1)
+                need.append((b, q))
+                tok_h[b], pos_h[b] = sq[q], q
+                kpm_h[b, :q + 1] = [int(t == pad) for t in sq[:q + 1]]
+                kpm_h[b, q + 1:] = 1
+            if need:
+                stats["device_steps"] += 1
+                stats["rows_from_device"] += len(need)
+                out = step().numpy()
+                for b, q in need:
+                    devtok[b] = seqs[b][:q + 1]
+                fresh = [b for b, q in need if q == len(seqs[b]) - 1]    # rows of the samples' CURRENT prefixes (the others re-fed an older position)
+                if fresh:
+                    n_dec = np.fromiter((len(seqs[b]) - 1 for b in fresh), np.int64, len(fresh))
+                    lg = out[fresh]                                          # (a copy: fancy indexing)
+                    lg[~tmask[n_dec]] = NEG_INF
+                    f = forced[fresh, n_dec]
+                    r = np.nonzero(f >= 0)[0]
+                    if r.size:                                               # one kept logit, as _relation_advance
+                        keep = lg[r, f[r]]
+                        lg[r] = NEG_INF
+                        lg[r, f[r]] = keep
+                    rawarg = lg.argmax(axis=1)                               # (what `resets > 3` decodes: the relation mask dropped)
+                    allow = np.zeros(lg.shape, dtype=bool)
+                    aux = []
+                    for i, b in enumerate(fresh):
+                        st, sq = states[b], seqs[b]
+                        n = len(sq) - 1
+                        what, back = st.con.step(n, sq[-1], st.rel)
+                        h = st.con.history
+                        aux.append((back, h[n + 1] if len(h) > n + 1 else None))
+                        if what[0] == "only":
+                            allow[i, what[1]] = True
+                        elif what[0] == "bins":
+                            lo, hi = what[2]
+                            if hi > lo:
+                                allow[i, start[what[1]] + int(lo):start[what[1]] + int(hi)] = True
+                        else:
+                            allow[i] = tmask[what[1]]
+                    lg[~allow] = NEG_INF
+                    rowmax, arg = lg.max(axis=1), lg.argmax(axis=1)
+                    for i, b in enumerate(fresh):
+                        memo[b][tuple(seqs[b])] = (float(rowmax[i]), int(arg[i]), int(rawarg[i]), aux[i][0], aux[i][1])
+            # ---- control flow on plain numbers
             still = []
-            for i, b in enumerate(active):
+            for b in active:
                 st, sq = states[b], seqs[b]
+                d = memo[b].get(tuple(sq))
+                if d is None:                        # still re-feeding an older branch's positions
+                    still.append(b)
+                    continue
+                rowmax_b, arg_b, rawarg_b, back_idx, cstate = d
+                n = len(sq) - 1
+                h = st.con.history                   # the constraint's history follows the prefix (RelationConstraint.step appends one state per token)
+                del h[n + 1:]
+                if cstate is not None:
+                    h.append(cstate)
+                stats["rows_from_memo"] += 1
                 if st.resets > 3:
                     st.back_flag = False
-                    nxt = int(raw[i].argmax())
-                elif (not st.back_flag and not rowmax[i] >= prob_gate) or rowmax[i] == NEG_INF:
-                    back_idx = backs[i]
+                    nxt = rawarg_b
+                elif (not st.back_flag and not rowmax_b >= prob_gate) or rowmax_b == NEG_INF:
                     draw = not (back_idx is not None and st.flagged.count(st.idx) + 1 < 3)
+                    pos = back_idx
+                    if draw and not shared:
+                        pos = st.rng.randint(2, max(2, st.idx - 1))
+                    elif draw:
+                        hi = max(2, st.idx - 1)
+                        catch_up()
+                        if b == first_open:          # (pending[b] is 0 now: its deferred draws went first)
+                            pos = random.randint(2, hi)
+                        elif hi == 2 and not serial:
+                            pending[b] += 1
+                            pos = 2
+                        else:
+                            parked.add(b)            # state untouched: this step is taken again when b is the lowest unfinished sample
+                            continue
                     st.flagged.append(st.idx)
                     st.back_flag = True
-                    st.idx = st.rng.randint(2, max(2, st.idx - 1)) if draw else back_idx
+                    st.idx = pos
                     del sq[st.idx:]
                     st.n_back += 1
                     if st.n_back > 30:
@@ -694,20 +794,24 @@ class _GeneratorBase(nn.Module):
                         st.resets += 1
                         sq[:] = [bos]
                         st.idx = 0
-                    kpm_h[b, len(sq):] = 1
                     still.append(b)
                     continue
                 else:
                     st.back_flag = False                                 # (its temperature does not move an argmax)
-                    nxt = int(arg[i])
+                    nxt = arg_b
                 sq.append(nxt)
                 if nxt == eos or len(sq) == T + 1:
                     st.done = True
                 else:
-                    kpm_h[b, len(sq) - 1] = int(nxt == pad)
                     st.idx += 1
                     still.append(b)
             active = still
+            if shared and serial:                    # (only the lowest unfinished sample ever steps)
+                parked.update(b for b in active if b != first_open and not states[b].done)
+                active = [b for b in active if b not in parked]
+        if shared:
+            catch_up()
+            assert first_open == B and not any(pending)
         for st, sq in zip(states, seqs):
             st.seq = torch.tensor([sq], dtype=torch.long)
         return step.cache
@@ -722,13 +826,11 @@ class _GeneratorBase(nn.Module):
         after three failures at one step), the next draw uses temperature 1.5; > 30 back-tracks restart the sample and after
         the 4th restart the relation mask is dropped.  Same control flow and `random` consumption as the reference; the
         decoder runs KV-cached on the device (a cut prefix just rewinds the cache position).
-        lockstep (opt-in; RALF_RELATION_LOCKSTEP=1 makes it the default for argmax decoding of >= 8 samples): the samples step together,
-        one batched decoder step per token, until they need `random` (_relation_lockstep); what is left runs sample by sample as the
-        reference does.  Tokens are identical either way (tests/test_configs_gpu.py).  Off by default because it does not pay on any input
-        available here: the constraint sequence lists the labels in SHUFFLED order while the forced label of a step follows the layout's own
-        order (both as in the reference), so the first step of most samples admits no token at all, and with no element to go back to the
-        reference draws the position from `random` -- 220 of 260 synthetic samples ask for a draw at their first step
-        (tools/relation_probe.py) and the loop is sequential from there: 126.3 against 126.7 ms per sample.
+        lockstep (default for argmax decoding of >= 2 samples on the GPU; RALF_RELATION_LOCKSTEP=0 / lockstep=False keep the sample-after-sample
+        loop): the samples step together, one batched decoder step per iteration, and `random` is still consumed in the reference's order
+        (_relation_lockstep_batched: range-one draws deferred, other draws wait for the lower-indexed samples, every (sample, prefix) decoded
+        once).  Tokens and the final state of `random` are identical either way (tests/test_relation_cpu.py, test_relation_gpu.py,
+        test_configs_gpu.py); B = 256 on the benchmark's workload: 27.9 s -> 1.6 s per batch.
         rng = "per_sample" (opt-in THROUGHPUT mode, NOT the reference's draw order): every sample draws its back-track positions from a
         generator of its own, so no sample waits for another and the whole batch decodes in lock-step, one batched decoder step per token
         (B = 256: 28 s -> 0.97 s per batch; argmax decoding takes the masks of all samples on one array, _relation_lockstep_batched).  Sample 0 continues Python's global stream -- a batch of one decodes exactly as the sequential
@@ -754,8 +856,9 @@ class _GeneratorBase(nn.Module):
         env = (ids, T, self.tokenizer.token_mask.cpu(), DECODE_SPACE_RESTRICTION["relation"], prob_gate, sampling_cfg)
         if lockstep is None:
             # a stochastic draw consumes torch's generator at every step, in sample order: only argmax decoding leaves `random` as the one
-            # shared stream, which the lock-step loop consumes in the reference's order
-            lockstep = (os.environ.get("RALF_RELATION_LOCKSTEP", "0") == "1" and B >= 8 and dev.type == "cuda" and _get(sampling_cfg, "name") == "deterministic")
+            # shared stream, which the lock-step loop consumes in the reference's order (round 6: on by default -- range-one draws no longer
+            # serialise the batch, _relation_lockstep_batched; RALF_RELATION_LOCKSTEP=0 keeps the sample-after-sample loop)
+            lockstep = (os.environ.get("RALF_RELATION_LOCKSTEP", "1") != "0" and B >= 2 and dev.type == "cuda" and _get(sampling_cfg, "name") == "deterministic")
         independent = rng == "per_sample"
         gens = [random] * B
         if independent:
@@ -773,8 +876,9 @@ class _GeneratorBase(nn.Module):
             con = RelationConstraint(self.preprocessor)
             states.append(self._RelationState(ids["bos"], con.prepare(seqc["seq"][b].cpu()), con, cond_seq[b:b + 1], gens[b], forced_tab[b]))
         batch_cache = None
-        if lockstep and independent and _get(sampling_cfg, "name") == "deterministic" and forced_tab[0] is not None and os.environ.get("RALF_RELATION_BATCHED", "1") != "0":
-            batch_cache = self._relation_lockstep_batched(states, memory, env, dev)
+        if lockstep and _get(sampling_cfg, "name") == "deterministic" and forced_tab[0] is not None and os.environ.get("RALF_RELATION_BATCHED", "1") != "0":
+            batch_cache = self._relation_lockstep_batched(states, memory, env, dev, shared=not independent,
+                                                          serial=os.environ.get("RALF_RELATION_SERIAL", "0") == "1")
         elif lockstep:
             batch_cache = self._relation_lockstep(states, memory, env, dev, 1 if independent else max(2, B // 32), independent)
         stepper = None

@@ -149,16 +149,19 @@ def test_relation_b256_rows_equal_reference_rows(golden):
         import time
         t0 = time.perf_counter()
         out, vio = model.sample(cond=cond, sampling_cfg={"name": "deterministic", "temperature": 1.0}, cond_type="relation", return_violation=True,
-                                use_backtrack=True, RELATION_SIZE=30)
+                                use_backtrack=True, RELATION_SIZE=30, lockstep=False)      # sample after sample: the reference's loop
         dt = time.perf_counter() - t0
     finally:
         random.randint = real_randint
+    after_seq = random.getstate()
     print(f"relation decode with back-tracking, B = {B}: {dt * 1e3 / B:.2f} ms per sample, {draws[0]} random back-track draws")
-    # the lock-step form (one batched decoder step for all samples, every element at its own position; a sample that needs `random` waits for
-    # the samples before it): the same stream consumption, so ALL 256 rows equal the sequential loop's
+    # the lock-step form, the DEFAULT since round 6 (one batched decoder step for all samples, every element at its own position; range-one draws
+    # take their value at once and are consumed from the stream in sample order, other draws wait for the samples before them): the same stream
+    # consumption, so ALL 256 rows equal the sequential loop's and `random` is left in the same state
     random.setstate(state)
     out_l = model.sample(cond=cond, sampling_cfg={"name": "deterministic", "temperature": 1.0}, cond_type="relation", return_violation=False,
-                         use_backtrack=True, RELATION_SIZE=30, lockstep=True)
+                         use_backtrack=True, RELATION_SIZE=30)
+    assert random.getstate() == after_seq
     for k in ("label", "mask", "center_x", "center_y", "width", "height"):
         assert torch.equal(out_l[k], out[k]), ("lockstep", k)
     rows = B if draws[0] == 0 else n0

@@ -153,3 +153,104 @@ def test_long_layouts_keep_every_other_task():
     assert pre.name_to_id(RelLoc.UNKNOWN) == tok.N_total + 10 + 32
     with pytest.raises(ValueError):
         PREPROCESSOR["relation"](tokenizer=tok, table={})
+
+
+def _fake_logits(b, prefix, V, scale):
+    """a deterministic stand-in for the decoder: logits of sample b after the tokens `prefix` -- a function of what the KEY / VALUE CACHE holds at
+    the positions below the current one, so a cache written by another branch gives other logits (as on the device)"""
+    h = int(b) * 1000003
+    for t in prefix:
+        h = (h * 1000003 + int(t) + 7) & 0x7FFFFFFF
+    g = np.random.default_rng(h)
+    return torch.from_numpy((g.standard_normal(V) * scale).astype(np.float32))
+
+
+@pytest.mark.parametrize("scale", [0.25, 1.0, 3.0])
+def test_lockstep_exact_mode_consumes_random_like_the_sequential_loop(golden, monkeypatch, scale):
+    """the ORDER logic of the exact-mode lock-step decode (models/ralf.py _relation_lockstep_batched, shared=True) on a fake decoder, no GPU:
+    range-one draws deferred and replayed in sample order, wide draws parked until their sample is the lowest unfinished one -- the randint
+    calls (arguments and results, in order), the tokens and the final state of `random` are those of the sample-after-sample loop.  The scale of
+    the fake logits moves the mix: below the gate almost every step back-tracks (range-one draws), above it back-tracks come from the relation
+    constraints (wide draws after three failures at one step)."""
+    import ralf_amd.models.ralf as R
+    import ralf_amd.nn as RN
+    from test_model_cpu import build
+
+    g = golden("relation.npz")
+    table, _ = load_table()
+    random.seed(6)
+    model = build(task="relation", relation_table=table).eval()
+    tok = LayoutSequenceTokenizer(LABELS, 10)
+    batch = make_batch(g.sub("compute_relation"))
+    n0 = batch["label"].size(0)
+    rep = 6
+    batch = {k: (v.repeat((rep,) + (1,) * (v.dim() - 1)) if torch.is_tensor(v) else v * rep) for k, v in batch.items()}
+    B = n0 * rep
+    batch["id"] = [str(1000 + i % n0) for i in range(B)]
+    r = g.sub("sample")
+    batch["retrieved"] = [{k: v.repeat((rep,) + (1,) * (v.dim() - 1)) for k, v in dict(r["retrieved"], image=torch.zeros(n0, 16, 4, 1, 1)).items()}]
+    random.seed(8)
+    torch.manual_seed(8)
+    cond, _ = get_condition(batch, "relation", tok)
+    V = model.tokenizer.N_total
+
+    class FakeCache:
+        def __init__(self, ids):
+            self.ids, self.self_kv, self.cross_kv, self.packed = ids, [], [], None
+            self.toks = [[0] * 64 for _ in ids]       # the token whose key / value sits at each position, per row
+
+    class FakeStep:
+        def __init__(self, m, T, dev, nb):
+            self.tok_h, self.pos_h, self.kpm_h = torch.zeros(nb, dtype=torch.long), torch.zeros(nb, dtype=torch.int32), torch.ones(nb, T, dtype=torch.uint8)
+            self.cache = None
+
+        def bind(self, cache):
+            self.cache = cache
+
+        def __call__(self):   # EVERY row steps, wanted or not (the captured graph has a fixed batch): a row the loop does not feed repeats its last step
+            rows = []
+            for b in range(self.tok_h.numel()):
+                p = int(self.pos_h[b])
+                self.cache.toks[b][p] = int(self.tok_h[b])
+                rows.append(_fake_logits(b, self.cache.toks[b][:p + 1], V, scale))
+            return torch.stack(rows)
+
+    def fake_decoder_step(dec, tok_, pos, cache, rt, kpm):
+        cache.toks[0][pos] = int(tok_[0])
+        return _fake_logits(cache.ids[0], cache.toks[0][:pos + 1], V, scale)[None]
+    monkeypatch.setattr(type(model), "_LockstepStep", FakeStep)
+    monkeypatch.setattr(model, "_encode_into_memory", lambda enc: {"memory": torch.arange(B, dtype=torch.float32).view(B, 1, 1).expand(B, 3, 4).contiguous()})
+    monkeypatch.setattr(RN, "decoder_init_cache", lambda dec, mem, rt, T: FakeCache(mem[:, 0, 0].long().tolist()))
+    monkeypatch.setattr(RN, "decoder_step", fake_decoder_step)
+    monkeypatch.setattr(type(model.rt), "to", lambda self, dev: self)
+    monkeypatch.setattr(type(model.rt), "begin_step", lambda self: None)
+    cfg = {"name": "deterministic", "temperature": 1.0}
+    real = random.randint
+    runs = {}
+    for mode in ("sequential", "lockstep", "serial", "lockstep_forgetful"):
+        calls = []
+        monkeypatch.setattr(random, "randint", lambda a, b, _c=calls: (_c.append((a, b, real(a, b))), _c[-1][2])[1])
+        random.seed(21)
+        torch.manual_seed(21)
+        model.__dict__.pop("_relation_lockstep_steps", None)
+        monkeypatch.setenv("RALF_RELATION_SERIAL", "1" if mode == "serial" else "0")
+        monkeypatch.setenv("RALF_RELATION_MEMO_DROP", "37" if mode == "lockstep_forgetful" else "0")
+        out = model.sample_relation(cond, sampling_cfg=cfg, return_violation=False, RELATION_SIZE=30, use_graph=False, lockstep=(mode != "sequential"))
+        runs[mode] = (out, list(calls), random.getstate())
+        if mode != "sequential":
+            print(mode, model.relation_stats)
+        monkeypatch.setattr(random, "randint", real)
+    (o1, c1, s1), (o2, c2, s2) = runs["sequential"], runs["lockstep"]
+    wide = sum(1 for a, b, _ in c1 if b > a)
+    print(f"scale {scale}: {len(c1)} draws over {B} samples, {wide} wide")
+    assert len(c1) > 0
+    first = next((i for i, (x, y) in enumerate(zip(c1, c2)) if x != y), None)
+    assert first is None and len(c1) == len(c2), (first, c1[max(0, (first or 0) - 3):(first or 0) + 3], c2[max(0, (first or 0) - 3):(first or 0) + 3], len(c1), len(c2))
+    assert s1 == s2
+    for k in ("label", "mask", "center_x", "center_y", "width", "height"):
+        assert torch.equal(o1[k], o2[k]), k
+    o3, c3, s3 = runs["serial"]           # the sequential ORDER on the lock-step machinery (the GPU test's yardstick: same arithmetic per row)
+    assert c3 == c1 and s3 == s1 and all(torch.equal(o1[k], o3[k]) for k in o1 if torch.is_tensor(o1[k]))
+    o4, c4, s4 = runs["lockstep_forgetful"]   # the memo dropped every 37 iterations: prefixes are decoded again on caches other branches have written
+    assert c4 == c1 and s4 == s1 and all(torch.equal(o1[k], o4[k]) for k in o1 if torch.is_tensor(o1[k]))
+    assert model.relation_stats["refed_positions"] > 0
