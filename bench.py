@@ -164,9 +164,25 @@ def bench_knn(device):
     v0, i0 = knn_topk_ip(X, Q, k)
     v1, i1, nfb = knn_topk_ip_two_stage(X, Xb, Q, k, index_norms=xn)
     assert torch.equal(i0, i1) and torch.equal(v0, v1), "two-stage search must equal the exhaustive scan"
-    t2 = _time_gpu(lambda: knn_topk_ip_two_stage(X, Xb, Q, k, index_norms=xn), iters=10)
-    out["nq1024_two_stage"] = {"qps": nq / t2, "us_per_call": t2 * 1e6, "fallback_queries": nfb, "bf16_coarse_TFLOPs": 2.0 * nq * N * D / t2 / 1e12,
-                               "note": "identical results to nq1024 (checked in this run); coarse pass on the bf16 matrix cores"}
+    from ralf_amd.retrieval.knn import FlatIPIndex, knn_topk_ip_two_stage_fused
+    v2, i2, nfb2, ws2 = knn_topk_ip_two_stage_fused(X, Xb, Q, k, xn)
+    assert torch.equal(i0, i2) and torch.equal(v0, v2), "two-stage search (one library call) must equal the exhaustive scan"
+    t2 = _time_gpu(lambda: knn_topk_ip_two_stage_fused(X, Xb, Q, k, xn, workspace=ws2), iters=10)
+    out["nq1024_two_stage"] = {"qps": nq / t2, "us_per_call": t2 * 1e6, "fallback_queries": nfb2, "bf16_coarse_TFLOPs": 2.0 * nq * N * D / t2 / 1e12,
+                               "note": "identical results to nq1024 (checked in this run); coarse pass on the bf16 matrix cores (256 x 256 tiles), every launch of the "
+                                       "search from ONE library call (ralf_knn_topk_ip_two_stage) + one read of the certificate flags"}
+    # the front end (retrieval.FlatIPIndex.search = faiss.IndexFlat.search's place) at the batch sizes between the two regimes: two-stage from 40 queries
+    index = FlatIPIndex(X, device=str(device))
+    for nq in (64, 128, 256):
+        Q = torch.randn(nq, D, device=device, generator=g)
+        Q /= Q.norm(dim=1, keepdim=True)
+        v0, i0 = knn_topk_ip(X, Q, k)
+        v1, i1 = index.search(Q, k)
+        assert torch.equal(i0, i1) and torch.equal(v0, v1), "FlatIPIndex.search must equal the exhaustive scan"
+        t = _time_gpu(lambda: index.search(Q, k), iters=20)
+        te = _time_gpu(lambda: knn_topk_ip(X, Q, k), iters=10)
+        out[f"nq{nq}"] = {"qps": nq / t, "us_per_call": t * 1e6, "exhaustive_us_per_call": te * 1e6, "fallback_queries": index.last_fallbacks,
+                          "path": "FlatIPIndex.search -> two-stage (identical results, checked in this run)"}
     return {"index": f"{N}x{D} fp32", "k": k, **out}
 
 

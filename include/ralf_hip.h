@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 21
+#define RALF_ABI_VERSION 22
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -62,6 +62,14 @@ int ralf_knn_select_cand(const float* exact, const int64_t* cand, int nq, int po
 /* per row of X fp32 [R, D] and its bf16 copy Xb: norms[r] = {|x|, |xb|, |x - xb|} (fp32 [R, 3], may be NULL); maxes fp32 [3]
  * (may be NULL, zero on entry) = column maxima over the rows.  Values are rounded UP (they feed an upper bound). */
 int ralf_knn_rownorms(const float* X, const void* Xb_bf16, int64_t R, int D, float* norms, float* maxes, void* stream);
+/* The whole two-stage search as ONE call (what `index.search(x, k)` costs for a batch of queries: retriever.py:200-202 loops faiss over single
+ * queries; cross_retriever.py:133-207): queries -> bf16 + norms, coarse scores on the bf16 matrix cores, the pool + 1 best coarse rows, their exact
+ * fp32 scores, the k best with the per-query certificate.  bad[q] = 1: not certified -- the caller sends those queries through ralf_knn_topk_ip
+ * (the results of certified queries ARE ralf_knn_topk_ip's, bit for bit).  Xb: the bf16 copy of the index (ralf_copy2d), xnorms fp32 [3] = the
+ * column maxima of ralf_knn_rownorms(X, Xb).  dim % 64 == 0, 1 <= k <= pool, pool + 1 <= 1024, pool < n_db; workspace 256-byte aligned. */
+size_t ralf_knn_two_stage_workspace_bytes(int64_t n_db, int dim, int nq, int pool);
+int ralf_knn_topk_ip_two_stage(const float* X, const void* Xb_bf16, int64_t n_db, int dim, const float* Q, int nq, int k, int pool, const float* xnorms,
+                               int64_t* out_idx, float* out_score, int32_t* bad, void* workspace, size_t workspace_bytes, void* stream);
 /* the candidate slots a filtered coarse pass wrote (RalfGemmDesc.flt_*: list int32 [nq][T][cap][2] = {row, score bits}, count int32 [nq][T]) as
  * the dense pair the selection kernels take: rows int64 [nq][T * cap] (0 in unused slots), scores fp32 [nq][T * cap] (-inf in unused slots);
  * over int32 [nq] (may be NULL, ZEROED by the caller) is set to 1 where a tile's count exceeds cap (the list lost candidates).

@@ -16,6 +16,8 @@ SIGNATURES = {
     "ralf_knn_rescore": (i32, [vp, i64, i32, vp, i32, vp, i32, vp, vp]),
     "ralf_knn_select_cand": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, i64, vp, vp, i32, vp, vp]),
     "ralf_knn_rownorms": (i32, [vp, vp, i64, i32, vp, vp, vp]),
+    "ralf_knn_two_stage_workspace_bytes": (sz, [i64, i32, i32, i32]),
+    "ralf_knn_topk_ip_two_stage": (i32, [vp, vp, i64, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "ralf_knn_list_unpack": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "ralf_knn_gather_rows": (i32, [vp, i32, vp, i32, i32, vp, vp]),
 }

@@ -481,7 +481,7 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     constexpr int RVA = BM / VEC, RVB = BN / VEC;                  // vectors along rows (row-contiguous tile)
     constexpr int NT = 64 * NW, WGN = NW / WGM;                     // threads; waves along n (WGM along m)
     constexpr int WFM = FM * 2 / WGM, WFN = FN * 2 / WGN;          // 32x32 fragments per wave
-    static_assert(NW == 4 || (NW == 8 && FN == 2), "8 waves: 2 x 4 over a 128-wide tile (or 4 x 2 over 256 x 128)");
+    static_assert(NW == 4 || (NW == 8 && (FN == 2 || FN == 4)), "8 waves: 2 x 4 over a 128- or 256-wide tile (or 4 x 2 over 256 x 128)");
     static_assert(WFM >= 1 && WFN >= 1 && WFM * WGM == 2 * FM && WFN * WGN == 2 * FN, "the wave grid tiles the workgroup tile");
     static_assert(WGM == 2 || (WFM == 2 && EPI != 3 && EPI != 4), "wave grids other than 2 x n: 64-row wave tiles, plain epilogues");
     constexpr int NVA = BM * BK / VEC / NT, NVB = BN * BK / VEC / NT;  // 16-byte vectors per thread per k-tile
@@ -991,6 +991,10 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
         //     just read is re-filled while those MFMAs run.
         // Ring of NST stages, NST - 2 tiles in flight across every barrier (counted vmcnt, raw s_barrier).  Same MFMA chain in the same
         // order as every other bf16 path: bit-identical results.
+        // MEASURED (tools/gemm_lab.hip, profiles/r06_gemm_lab_*.txt): NOT faster than the plain ring on any shape of the model -- 128 x 128 on 4 waves
+        // 722 vs 802 TFLOP/s (16384 x 256 x 2304), 256 x 256 on 8 waves 1182 vs 1167 (8192^3).  PMC: the LDS is 21 % busy, bank conflicts 0, MFMA pipes 27 %
+        // busy, waves parked on vmcnt / the barrier half of their life: the loop waits for OPERANDS (a CU takes in ~20-23 B/clk with every tile
+        // shape and ring depth), not for fragment reads.  Kept as lab variants (GATHER 10-13 are not dispatched by launch_cfg).
         static_assert(!RALF_GEMM_PERSISTENT, "the direct-to-LDS loop is one tile per workgroup");
         static_assert(BK == 64, "four 16-wide k-slices per tile");
         constexpr int NST = gemm_nbuf<GATHER, FM>();
@@ -1748,6 +1752,14 @@ int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
         // Three stages (one workgroup per CU) where a launch has at most one workgroup per CU anyway and a long reduction to pipeline.
         static const int glds = [] { const char* e = getenv("RALF_GEMM_GLDS"); return e ? atoi(e) : 1; }();   // 0: off (A/B runs, tests)
         if (glds && use128 && !d.kseg && !d.bnb_part && !forced) {
+            // 256 x 256 tiles (8 waves of 128 x 64, two 64-KiB stages) where at least ~1.5 of them exist per CU and the reduction is long: the operand
+            // feed of a CU tops out at ~20-23 B/clk whatever the loop looks like (profiles/r06_gemm_feed_limit.txt), i.e. a tile's flops per loaded
+            // byte set the rate -- 8192^3: 929 -> 1167 TFLOP/s, the two-stage k-NN's coarse pass (1024 x 61548 x 1792): 266 -> 230 us.  Plain
+            // epilogues only (the model's own products have too few such tiles: they lose on 256-row tiles, tools/gemm_lab.hip).
+            static const int t256 = [] { const char* e = getenv("RALF_GEMM_TILE256"); return e ? atoi(e) : 400; }();   // tiles needed; 0 = off
+            const int64_t n256 = (int64_t)ceil_div(d.M, 256) * ceil_div(d.N, 256) * nbatch;
+            const bool plain = !d.colstats && !d.flt_list && !d.C2 && d.act != RALF_ACT_GELU && d.aux_mode != RALF_AUX_GELU_GRAD && !d.atomic_out && d.drop_p == 0.f && !d.aux;
+            if (t256 && plain && d.splitk == 1 && d.M >= 256 && d.K >= 512 && n256 >= t256) return launch<T, AK, BKC, 5, 4, 4, 0, 8>(P, nbatch, st);
             if (big <= 256 && kspan >= 1024) return launch_epi<T, AK, BKC, 6, 2, 2, 8>(P, nbatch, st);
             return launch_epi<T, AK, BKC, 5, 2, 2, 8>(P, nbatch, st);
         }
@@ -1795,12 +1807,14 @@ int dispatch(KParams& P, int nbatch, hipStream_t st) {
     }
     if constexpr (sizeof(T) == 2) {   // bf16: the interior fast path is its own (leaner) set of kernels; fp32 is the parity mode
         static const int skinny_rows = [] { const char* e = getenv("RALF_GEMM_SKINNY_ROWS"); return e ? atoi(e) : 512; }();   // 0 = off (A/B runs)
-        if (P.fast && key == 6 && d.M <= skinny_rows && nbatch == 1 && d.splitk == 1 && !d.colstats && !d.bnb_part && !d.kseg && !d.atomic_out && !d.flt_list) {
+        // (few rows AND a weight-sized second operand: one wave per 32 x 32 tile re-reads both operands per tile -- a 64..512-row product against the
+        //  61548-row k-NN index ran 3-4x slower here than on the tiled kernel, profiles/r06_knn_route_sweep_before.txt)
+        if (P.fast && key == 6 && d.M <= skinny_rows && d.N <= 8192 && nbatch == 1 && d.splitk == 1 && !d.colstats && !d.bnb_part && !d.kseg && !d.atomic_out && !d.flt_list) {
             const bool lvl2 = d.C2 || d.act == RALF_ACT_GELU || d.aux_mode == RALF_AUX_GELU_GRAD;
             const bool lvl1 = d.drop_p > 0.f || d.aux;
             return lvl2 ? launch_skinny<T, 2>(P, st) : lvl1 ? launch_skinny<T, 1>(P, st) : launch_skinny<T, 0>(P, st);
         }
-        if (d.ln_g) { ralf::set_error("gemm: ln_* is part of the few-row kernel, which RALF_GEMM_SKINNY_ROWS has switched off for this size"); return RALF_ERR_INVALID; }
+        if (d.ln_g) { ralf::set_error("gemm: ln_* is part of the few-row kernel (M <= RALF_GEMM_SKINNY_ROWS, N <= 8192), which does not take this product"); return RALF_ERR_INVALID; }
         if (P.fast) {
             switch (key) {
                 case 6: return launch_cfg<T, true, true, 3>(P, nbatch, st);

@@ -25,6 +25,8 @@
 //    16 us for the two launches it replaced;
 //    (d, round 4) two k-tiles requested back to back (256 contiguous bytes of every row within a few hundred ns, the second tile waiting in a
 //    second register set) and streaming (non-temporal) index loads: scan 76.9 vs 76.8 us at nq = 1, 107 vs 101 us at nq = 32; 73.4 vs 69.4 us.
+#include <cstring>
+
 #include "common.h"
 
 namespace {
@@ -424,7 +426,8 @@ __global__ __launch_bounds__(64) void knn_select_cand_kernel(const float* __rest
         const uint32_t kj = key[j];
         const int64_t rj = row[j];
         int rank = 0;
-        for (int i = 0; i < pool; ++i) rank += (key[i] > kj) || (key[i] == kj && row[i] < rj);
+#pragma unroll 16
+        for (int i = 0; i < pool; ++i) rank += (key[i] > kj) || (key[i] == kj && row[i] < rj);   // (unrolled: the LDS reads of 16 iterations go out together)
         if (rank < k) {
             os[(int64_t)q * k + rank] = key2f(kj);
             oi[(int64_t)q * k + rank] = rj;
@@ -467,6 +470,33 @@ __global__ __launch_bounds__(256) void knn_rownorms_kernel(const float* __restri
 }
 
 
+// the queries of the two-stage search in one pass: Qb = bf16(Q) (round to nearest even, as ralf_copy2d) and norms[q] = {|q|, |qb|, |q - qb|} rounded up.
+// One wave per query, 16 bytes per lane and step.  D % 4 == 0.
+__global__ __launch_bounds__(256) void knn_query_prep_kernel(const float* __restrict__ Q, __bf16* __restrict__ Qb, int nq, int D, float* __restrict__ norms) {
+    const int lane = threadIdx.x & 63;
+    const int r = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (r >= nq) return;
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int d = 4 * lane; d < D; d += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(Q + (int64_t)r * D + d);
+        const float xs[4] = {x.x, x.y, x.z, x.w};
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = (__bf16)xs[e];
+            const float xb = (float)o[e], err = xs[e] - xb;
+            a += xs[e] * xs[e]; b += xb * xb; c += err * err;
+        }
+        *reinterpret_cast<bf16x4*>(Qb + (int64_t)r * D + d) = o;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+    if (lane == 0) {
+        norms[r * 3] = sqrtf(a) * 1.000001f; norms[r * 3 + 1] = sqrtf(b) * 1.000001f; norms[r * 3 + 2] = sqrtf(c) * 1.000001f;   // rounded up: these feed an upper bound
+    }
+}
+
 template <int MF, int TQ, int TR>
 int launch_scores(const float* X, int64_t N, int D, const float* Q, int nq, float* S, hipStream_t st, unsigned int* zero_me = nullptr, int nzero = 0) {
     constexpr int RW = 4 * TR * MF, QW = TQ * MF;
@@ -476,7 +506,80 @@ int launch_scores(const float* X, int64_t N, int D, const float* Q, int nq, floa
     return ralf::check_launch("knn_scores");
 }
 
+// Exact re-scoring, one WAVE per (query, 16 candidates) (round 6).  The gathered form of the scan kernel above walks D in 32-wide k-tiles with two
+// barriers and one (random-row, HBM-latency) load round trip per tile: 50 us at any batch size, 126 us at nq = 1024.  Here a single-wave
+// workgroup streams its 16 candidate rows through a ring of three 128-column chunks in LDS (global_load_lds_dwordx4, 8 per chunk, counted
+// vmcnt, no barrier: one wave) and runs the D / 4 v_mfma_f32_16x16x4_f32 of the block behind them: A[m][k] = candidate m's element d + k,
+// B[k][n] = the query's element d + k in every column n, so column 0 of the accumulator is <q, x_m> summed by the ascending-d fma chain of
+// the scan (v_mfma_f32_16x16x4_f32 on one accumulator == the scan's chain, bit for bit: tests/test_knn_gpu.py).  ~30 KiB of LDS per wave:
+// five such waves per CU, each bound by its own 40-cycle MFMA chain.  D % 128 == 0 (a whole number of chunks = of the scan's k-tiles).
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+constexpr int RS_CH = 128, RS_NB = 3, RS_PAIR = 2 * RS_CH + 4;   // chunk columns, ring depth, floats per row PAIR (rows 2p, 2p+1 adjacent: one 1-KiB DMA; +4: pairs start in different banks)
+__global__ __launch_bounds__(64) void knn_rescore_wave_kernel(const float* __restrict__ X, int D, const float* __restrict__ Q, const int64_t* __restrict__ cand,
+                                                              int pool, float* __restrict__ S) {
+    extern __shared__ __attribute__((aligned(16))) float rl[];   // [RS_NB][8 pairs][RS_PAIR] | [D] the query
+    const int lane = threadIdx.x, q = blockIdx.y, g = blockIdx.x;
+    float* lq = rl + RS_NB * 8 * RS_PAIR;
+    const int nc = D / RS_CH;
+    // DMA j of a chunk: rows 2j, 2j+1; lane l moves 16 bytes: row 2j + (l >> 5), columns 4 (l & 31) ..
+    const float* rp[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = 2 * j + (lane >> 5);
+        rp[j] = X + cand[(int64_t)q * pool + min(g * 16 + r, pool - 1)] * D + 4 * (lane & 31);
+    }
+    auto issue = [&](int c) {
+        float* dst = rl + (c % RS_NB) * 8 * RS_PAIR;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rp[j] + c * RS_CH), LDS_PTR(void, dst + j * RS_PAIR), 16, 0, 0);
+    };
+    const int nqd = D / 256;                                       // 1-KiB pieces of the query (D % 256 may leave a 512-byte tail: moved by plain loads)
+    for (int v = 0; v < nqd; ++v)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Q + (int64_t)q * D + 256 * v + 4 * lane), LDS_PTR(void, lq + 256 * v), 16, 0, 0);
+    if (D % 256) { if (lane < 32) *reinterpret_cast<float4*>(lq + 256 * nqd + 4 * lane) = *reinterpret_cast<const float4*>(Q + (int64_t)q * D + 256 * nqd + 4 * lane); }
+    issue(0);
+    if (nc > 1) issue(1);
+    if (nc > 2) issue(2);
+    const int i = lane & 15, kq = lane >> 4;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int xoff = (i >> 1) * RS_PAIR + (i & 1) * RS_CH + kq;    // row i of a chunk image, column kq
+    for (int c = 0; c < nc; ++c) {
+        // chunk c has landed when at most the DMAs of the chunks behind it are outstanding (c + 1, c + 2: 8 each; fewer at the end)
+        const int behind = min(nc - 1 - c, 2);
+        if (behind == 2) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        else if (behind == 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const float* xp = rl + (c % RS_NB) * 8 * RS_PAIR + xoff;
+        const float* qp = lq + c * RS_CH + kq;
+#pragma unroll
+        for (int h = 0; h < RS_CH / 32; ++h) {
+            float xa[8], qa[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { xa[u] = xp[32 * h + 4 * u]; qa[u] = qp[32 * h + 4 * u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u], qa[u], acc, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this chunk's reads are done before its ring slot is filled again
+        if (c + RS_NB < nc) issue(c + RS_NB);
+    }
+    if (i == 0) {                                                // column 0: lane (0, kq) holds candidates 4 kq .. 4 kq + 3
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cc = g * 16 + 4 * kq + r;
+            if (cc < pool) S[(int64_t)q * pool + cc] = acc[r];
+        }
+    }
+}
+
 int launch_rescore(const float* X, int64_t N, int D, const float* Q, int nq, const int64_t* cand, int pool, float* S, hipStream_t st) {
+    static const int wave_form = [] { const char* e = getenv("RALF_KNN_RESCORE_WAVE"); return e ? atoi(e) : 1; }();   // 0 = the k-tiled form (A/B runs, tests)
+    const size_t lds = ((size_t)RS_NB * 8 * RS_PAIR + (size_t)D) * sizeof(float);
+    if (wave_form && D % RS_CH == 0 && lds <= 64 * 1024 && nq <= 65535) {
+        hipLaunchKernelGGL(knn_rescore_wave_kernel, dim3(ceil_div(pool, 16), nq), dim3(64), lds, st, X, D, Q, cand, pool, S);
+        return ralf::check_launch("knn_rescore (one wave per 16 candidates)");
+    }
     constexpr int MF = 16, RW = 4 * MF;                    // 64 candidates per workgroup, one query per 16-row query tile
     const int nrc = ceil_div(pool, RW);
     const int nwg = nrc * nq;
@@ -594,7 +697,7 @@ extern "C" size_t ralf_knn_topk_ip_workspace_bytes(int64_t N, int D, int nq, int
 
 // workspace for select alone = 2 candidate buffers (+ 256 bytes of ticket counters per 64 queries at its end)
 static int select_impl(const float* S, int64_t N, int nq, int k, int64_t* out_idx, float* out_score, void* ws, size_t ws_bytes,
-                       hipStream_t st, bool tickets_zeroed) {
+                       hipStream_t st, bool tickets_zeroed, bool one_launch_ok = true) {
     SelectPlan p = plan_select(N, nq, k);
     if (p.nseg == 1) {
         hipLaunchKernelGGL((knn_select_kernel<true>), dim3(1, nq), dim3(256), 0, st, S, nullptr, nullptr, N, N, (int64_t)SEG, k, out_score, out_idx,
@@ -613,7 +716,9 @@ static int select_impl(const float* S, int64_t N, int nq, int k, int64_t* out_id
         ci[i] = (int64_t*)(w + i * align256(p.cand_bytes));
         cs[i] = (float*)(ci[i] + (size_t)nq * p.nseg * k);
     }
-    if (k <= 64 && p.nseg <= 64) {   // one launch: the last workgroup of every query merges that query's segment lists
+    // (one_launch_ok = false: the two-stage search's top-64 of every row -- the merge of 64-entry lists by each query's last workgroup took 25.5 us
+    //  at nq = 64 against 11 + 9 for two launches, and 2x the two-launch time at nq = 1024: profiles/r06_knn_*)
+    if (one_launch_ok && k <= 64 && p.nseg <= 64) {   // one launch: the last workgroup of every query merges that query's segment lists
         unsigned int* tickets = (unsigned int*)(w + 2 * align256(p.cand_bytes));
         if (!tickets_zeroed && hipMemsetAsync(tickets, 0, (size_t)nq * sizeof(unsigned int), st) != hipSuccess) return ralf::check_launch("knn_select memset");
         hipLaunchKernelGGL((knn_select_kernel<true, true>), dim3((unsigned)p.nseg, nq), dim3(256), 0, st, S, nullptr, nullptr, N, N, (int64_t)SEG, k, cs[0], ci[0],
@@ -635,6 +740,67 @@ static int select_impl(const float* S, int64_t N, int nq, int k, int64_t* out_id
         cur ^= 1;
     }
     return ralf::check_launch("knn_select");
+}
+
+// ---- the whole two-stage search behind ONE entry point (round 6) ----
+// Host-side, the search used to be eight calls through the Python wrapper (cast, norms, product, selection, re-score, candidate selection, each with
+// its own output allocations): ~80 us of host time on top of ~200 us of kernels at nq = 64.  Here the launches go out back to back from C into one
+// caller-provided workspace; the caller reads `bad` (one flag per query) and sends the uncertified queries through ralf_knn_topk_ip.
+namespace {
+struct TwoStagePlan { size_t qb, qn, coarse, cval, cidx, exact, sel, total; };
+TwoStagePlan plan_two_stage(int64_t N, int D, int nq, int pool) {
+    TwoStagePlan p;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += align256(bytes); return at; };
+    p.qb = take((size_t)nq * D * 2);
+    p.qn = take((size_t)nq * 3 * sizeof(float));
+    p.coarse = take((size_t)nq * N * sizeof(float));
+    p.cval = take((size_t)nq * (pool + 1) * sizeof(float));
+    p.cidx = take((size_t)nq * (pool + 1) * sizeof(int64_t));
+    p.exact = take((size_t)nq * (pool + 1) * sizeof(float));
+    SelectPlan sp = plan_select(N, nq, pool + 1);
+    p.sel = take(2 * align256(sp.cand_bytes) + align256((size_t)nq * sizeof(unsigned int)) + 256);
+    p.total = o;
+    return p;
+}
+}  // namespace
+
+extern "C" size_t ralf_knn_two_stage_workspace_bytes(int64_t N, int D, int nq, int pool) {
+    if (N <= 0 || D <= 0 || nq <= 0 || pool <= 0) return 0;
+    return plan_two_stage(N, D, nq, pool).total;
+}
+
+extern "C" int ralf_knn_topk_ip_two_stage(const float* X, const void* Xb, int64_t N, int D, const float* Q, int nq, int k, int pool, const float* xnorms,
+                                          int64_t* out_idx, float* out_score, int32_t* bad, void* workspace, size_t workspace_bytes, void* stream) {
+    RALF_REQUIRE(X && Xb && Q && xnorms && out_idx && out_score && bad && workspace, "knn two-stage: null pointer");
+    RALF_REQUIRE(N > 0 && nq > 0 && D > 0 && D % 64 == 0, "knn two-stage: dim %d must be a multiple of 64 (bf16 coarse product on the aligned path)", D);
+    RALF_REQUIRE(k >= 1 && k <= pool && pool + 1 <= KMAX && pool < N, "knn two-stage: k=%d pool=%d outside 1 <= k <= pool < min(%d, n_db)", k, pool, KMAX);
+    RALF_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)Q & 15) == 0 && ((uintptr_t)Xb & 15) == 0 && ((uintptr_t)workspace & 255) == 0, "knn two-stage: alignment");
+    const TwoStagePlan p = plan_two_stage(N, D, nq, pool);
+    if (workspace_bytes < p.total) {
+        ralf::set_error("knn two-stage: workspace %zu < required %zu bytes", workspace_bytes, p.total);
+        return RALF_ERR_WORKSPACE;
+    }
+    char* w = (char*)workspace;
+    void* qb = w + p.qb;
+    float *qn = (float*)(w + p.qn), *coarse = (float*)(w + p.coarse), *cval = (float*)(w + p.cval), *exact = (float*)(w + p.exact);
+    int64_t* cidx = (int64_t*)(w + p.cidx);
+    hipStream_t st = (hipStream_t)stream;
+    // queries -> bf16, their norms {|q|, |qb|, |q - qb|}
+    hipLaunchKernelGGL(knn_query_prep_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, Q, (__bf16*)qb, nq, D, qn);
+    // coarse scores [nq, N] = Qb Xb^T on the bf16 matrix cores, fp32 out
+    RalfGemmDesc d;
+    memset(&d, 0, sizeof(d));
+    d.A = qb; d.B = Xb; d.C = coarse;
+    d.M = nq; d.N = (int)N; d.K = D; d.lda = D; d.ldb = D; d.ldc = N; d.nb0 = d.nb1 = 1; d.splitk = 1; d.alpha = 1.f; d.aux_scale = 1.f;
+    d.dtype = RALF_BF16; d.a_kcontig = 1; d.b_kcontig = 1; d.out_f32 = 1;
+    if (int rc = ralf_gemm(&d, nullptr, 0, stream)) return rc;
+    // the pool + 1 best coarse rows per query, sorted by coarse score
+    if (int rc = select_impl(coarse, N, nq, pool + 1, cidx, cval, w + p.sel, p.total - p.sel, st, false, false)) return rc;
+    // exact scores of the candidates (the scan's accumulation chain), the k best of them, the certificate against the (pool + 1)-th coarse score
+    if (int rc = launch_rescore(X, N, D, Q, nq, cidx, pool + 1, exact, st)) return rc;
+    hipLaunchKernelGGL(knn_select_cand_kernel, dim3(nq), dim3(64), 0, st, exact, cidx, pool + 1, k, out_score, out_idx, cval + pool, (int64_t)(pool + 1), qn, xnorms, D, bad);
+    return ralf::check_launch("knn two-stage");
 }
 
 extern "C" int ralf_knn_select(const float* S, int64_t N, int nq, int k, int64_t* out_idx, float* out_score, void* ws,

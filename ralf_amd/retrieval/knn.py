@@ -155,13 +155,52 @@ def knn_topk_ip_two_stage(index: torch.Tensor, index_bf16: torch.Tensor, queries
     return val, idx, int(bad.numel())
 
 
+_BAD_HOST: dict = {}   # page-locked mirrors of the certificate flags, by batch size
+
+
+def knn_topk_ip_two_stage_fused(index: torch.Tensor, index_bf16: torch.Tensor, queries: torch.Tensor, k: int, index_norms: torch.Tensor, pool: int = 0,
+                                workspace: torch.Tensor | None = None):
+    """knn_topk_ip_two_stage through ONE call of the library (ralf_knn_topk_ip_two_stage: every launch of the search back to back from C into one
+    workspace) + one read of the certificate flags; queries that are not certified go through the exhaustive scan.  Same results as
+    knn_topk_ip, bit for bit.  Returns (scores, idx, n_fallback, workspace)."""
+    N, D = index.shape
+    nq = queries.shape[0]
+    # pool + 1 candidates per query: a multiple of 16 (whole blocks of the re-score kernel: 64 candidates are four waves, 65 were five)
+    pool = pool or min(max(4 * k, 64) - 1, N - 1, 1023)
+    L = _lib.lib()
+    need = L.ralf_knn_two_stage_workspace_bytes(N, D, nq, pool)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=index.device)
+    q = queries.contiguous()
+    idx = torch.empty(nq, k, dtype=torch.int64, device=index.device)
+    val = torch.empty(nq, k, dtype=torch.float32, device=index.device)
+    bad = torch.empty(nq, dtype=torch.int32, device=index.device)
+    rc = L.ralf_knn_topk_ip_two_stage(_lib.ptr(index), _lib.ptr(index_bf16), N, D, _lib.ptr(q), nq, k, pool, _lib.ptr(index_norms), _lib.ptr(idx), _lib.ptr(val),
+                                      _lib.ptr(bad), _lib.ptr(workspace), workspace.numel(), _lib.stream_ptr())
+    _lib.check(rc, "ralf_knn_topk_ip_two_stage")
+    nbad = 0
+    # the one host read of the search (the flags themselves, one small copy into page-locked memory: an `any` kernel + its read cost two more hops)
+    host = _BAD_HOST.get(nq)
+    if host is None:
+        host = _BAD_HOST[nq] = torch.empty(nq, dtype=torch.int32, pin_memory=True)
+    host.copy_(bad, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    if bool(host.any()):   # (almost never)
+        rows = torch.nonzero(bad).flatten()
+        nbad = int(rows.numel())
+        v2, i2 = knn_topk_ip(index, q[rows].contiguous(), k)
+        val[rows], idx[rows] = v2, i2
+    return val, idx, nbad, workspace
+
+
 class FlatIPIndex:
     """Flat inner-product index kept in HBM; `search` mirrors faiss.IndexFlat.search(x, k) -> (D, I)."""
 
-    def __init__(self, vectors: torch.Tensor, device: str = "cuda", two_stage_min_queries: int = 256):
+    def __init__(self, vectors: torch.Tensor, device: str = "cuda", two_stage_min_queries: int = 40):
         self.vectors = torch.as_tensor(vectors, dtype=torch.float32).to(device).contiguous()
         self._ws = None
-        self._bf16 = None                 # bf16 shadow of the index for the coarse pass of large query batches (built on first use)
+        self._ws2 = None
+        self._bf16 = None                 # bf16 shadow of the index for the coarse pass of query batches (built on first use)
         self._norms = None                # {max|x|, max|xb|, max|x - xb|} of the index rows: the certificate's constants
         self.two_stage_min_queries = two_stage_min_queries
         self.last_fallbacks = 0
@@ -178,12 +217,15 @@ class FlatIPIndex:
         q = torch.as_tensor(queries, dtype=torch.float32).to(self.vectors.device)
         if q.dim() == 1:
             q = q[None]
-        if self.two_stage_min_queries and q.shape[0] >= self.two_stage_min_queries and k < self.ntotal // 8 and self.d % 8 == 0:
+        # Batches of >= two_stage_min_queries queries take the two-stage search (identical results).  The exhaustive fp32 scan streams the index
+        # once at ~0.7 of the HBM rate up to 16 queries per pass (92 us at BASELINE config 4's index) and is bound by the fp32 matrix rate
+        # beyond: 108 / 179 / 304 us at nq = 32 / 64 / 128 against ~100-120 for the two-stage search (profiles/r06_knn_route_sweep.txt).
+        if self.two_stage_min_queries and q.shape[0] >= self.two_stage_min_queries and 4 * k < self.ntotal // 8 and self.d % 64 == 0:
             from .. import ops
             if self._bf16 is None:
                 self._bf16 = ops.cast(self.vectors, torch.bfloat16)
                 _, self._norms = knn_rownorms(self.vectors, self._bf16, want_rows=False, want_max=True)
-            val, idx, self.last_fallbacks = knn_topk_ip_two_stage(self.vectors, self._bf16, q, k, index_norms=self._norms)
+            val, idx, self.last_fallbacks, self._ws2 = knn_topk_ip_two_stage_fused(self.vectors, self._bf16, q.contiguous(), k, self._norms, workspace=self._ws2)
             return val, idx
         need = _lib.lib().ralf_knn_topk_ip_workspace_bytes(self.ntotal, self.d, q.shape[0], k)
         if self._ws is None or self._ws.numel() < need:

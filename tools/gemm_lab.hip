@@ -24,7 +24,8 @@ static const Shape SHAPES[] = {
     {34048, 512, 256, "cross-attn K/V"},         {33792, 1024, 256, "head FFN1"},         {262144, 256, 64, "layer1 conv3"},
     {65536, 512, 128, "layer2 conv3"},           {4096, 2048, 512, "layer4 conv3"},       {4096, 512, 2048, "layer4 conv1"},
     {65536, 128, 512, "layer2 conv1"},           {3200, 1024, 256, "decoder FFN1"},       {8192, 8192, 8192, "8192^3"},
-    {4096, 4096, 4096, "4096^3"},
+    {4096, 4096, 4096, "4096^3"},            {1024, 61548, 1792, "kNN coarse nq=1024"}, {512, 61548, 1792, "kNN coarse nq=512"},
+    {256, 61548, 1792, "kNN coarse nq=256"},   {128, 61548, 1792, "kNN coarse nq=128"},
 };
 
 typedef int (*LaunchFn)(KParams&, int, hipStream_t);
@@ -38,6 +39,7 @@ int main(int argc, char** argv) {
         {"mt3 128x128/4w", launch<bf16, true, true, 10, 2, 2, 0, 4>}, {"mt4 128x128/4w", launch<bf16, true, true, 12, 2, 2, 0, 4>},
         {"mt2 128x128/4w", launch<bf16, true, true, 13, 2, 2, 0, 4>}, {"mt3 128x128/8w", launch<bf16, true, true, 10, 2, 2, 0, 8>},
         {"mt3 256x128/8w4x2", launch<bf16, true, true, 10, 4, 2, 0, 8, 4>}, {"mt3 256x64/4w4x1", launch<bf16, true, true, 10, 4, 1, 0, 4, 4>},
+        {"glds2 256x256/8w", launch<bf16, true, true, 5, 4, 4, 0, 8>}, {"mt2 256x256/8w", launch<bf16, true, true, 13, 4, 4, 0, 8>},
     };
     const int NVALL = sizeof(V) / sizeof(V[0]);
     // LAB_SHAPES / LAB_VARIANTS: comma-separated indices (profiling runs: one shape, a few variants); LAB_ITERS: launches per timed round
@@ -49,7 +51,7 @@ int main(int argc, char** argv) {
         return v;
     };
     const std::vector<int> vsel = pick("LAB_VARIANTS", NVALL), ssel = pick("LAB_SHAPES", (int)(sizeof(SHAPES) / sizeof(SHAPES[0])));
-    Variant VS[16];
+    Variant VS[24];
     int NV = 0;
     for (int i : vsel) VS[NV++] = V[i];
     const int iters_env = getenv("LAB_ITERS") ? atoi(getenv("LAB_ITERS")) : 0;
@@ -89,7 +91,7 @@ int main(int argc, char** argv) {
         std::vector<unsigned short> ref((size_t)sh.M * sh.N), got((size_t)sh.M * sh.N);
         CK(hipMemcpy(ref.data(), Cref, ref.size() * 2, hipMemcpyDeviceToHost));
         d.C = C;
-        bool mismatch[16] = {false};
+        bool mismatch[24] = {false};
         for (int v = 0; v < NV; ++v) {
             CK(hipMemset(C, 0xff, (size_t)sh.M * sh.N * 2));
             VS[v].fn(P, 1, 0);
