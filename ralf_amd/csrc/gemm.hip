@@ -86,6 +86,18 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
             P.inc_b = (int)((BK / hw) * img); P.inc_y = (int)((BK % hw) / g.RW); P.inc_x = (int)((BK % hw) % g.RW);
         }
     }
+    // data gradient of a stride-2 convolution: the parity-class form (gemm_impl.h GATHER 14) -- even output grid, whole 128-row tiles per class, <= 9 taps
+    P.par = 0;
+    P.fd_q.set(1); P.fd_hw2.set(1); P.fd_rw2.set(1);
+    {
+        static const int par_on = [] { const char* e = getenv("RALF_GEMM_PARITY"); return e ? atoi(e) : 1; }();   // 0 = off (A/B runs, tests)
+        const RalfConvGeom& g = d.g;
+        if (par_on && d.gather == 1 && lean_ok && g.mode == 1 && g.stride == 2 && d.dtype == RALF_BF16 && d.splitk == 1 && nbatch == 1 && g.RH % 2 == 0 && g.RW % 2 == 0 &&
+            g.KH * g.KW <= 9 && d.M % 4 == 0 && (d.M / 4) % 128 == 0 && (int64_t)d.M % ((int64_t)g.RH * g.RW) == 0) {
+            P.par = 1;
+            P.fd_q.set((uint32_t)(d.M / 4)); P.fd_hw2.set((uint32_t)((g.RH / 2) * (g.RW / 2))); P.fd_rw2.set((uint32_t)(g.RW / 2));
+        }
+    }
     const int ktiles = ceil_div(d.K, BK);
     if (d.splitk > ktiles) d.splitk = ktiles;
     P.kchunk = ceil_div(ktiles, d.splitk) * BK;

@@ -94,7 +94,25 @@ struct KParams {
     int ln_sgn, ln_sh, ln_pm;       // gather 1: tap sign (+1 forward, -1 data gradient), log2 / mask of the tap stride (data gradient: the conv stride)
     int img, swsc;                  // elements of one source image, of one source row
     int inc_b, inc_y, inc_x;        // gather 2: BK rows of the pixel grid = inc_b ELEMENTS of whole images + inc_y rows + inc_x pixels
+    // data gradient of a STRIDE-2 convolution by parity classes (GATHER 14): rows are ordered (class, image, y / 2, x / 2), class = (y & 1, x & 1)
+    FastDiv fd_q, fd_hw2, fd_rw2;   // rows per class (M / 4), (RH / 2) * (RW / 2), RW / 2
+    int par;                        // 1: take the parity form (set by ralf_gemm)
 };
+
+// virtual row (class-major order) -> class, image, pixel of the output grid
+__device__ __forceinline__ void par_decompose(const KParams& P, uint32_t row, int& cls, int& b, int& ry, int& rx) {
+    int rem, rem2, y2, x2;
+    P.fd_q.divmod(row, cls, rem);
+    P.fd_hw2.divmod((uint32_t)rem, b, rem2);
+    P.fd_rw2.divmod((uint32_t)rem2, y2, x2);
+    ry = 2 * y2 + (cls >> 1);
+    rx = 2 * x2 + (cls & 1);
+}
+__device__ __forceinline__ int par_real_row(const KParams& P, int row) {
+    int cls, b, ry, rx;
+    par_decompose(P, (uint32_t)row, cls, b, ry, rx);
+    return (b * P.d.g.RH + ry) * P.d.g.RW + rx;
+}
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -443,7 +461,7 @@ constexpr int AT_LDS_BYTES = 3 * AT_KMAX * 4;      // c1 | c2 | c3
 // one barrier in front of its LAST k-slice (gemm_body: "pipelined ring"); 11 = 10 with the tap-uniform im2col gather of A through the ring
 constexpr bool gemm_is_mt(int GATHER) { return GATHER >= 10 && GATHER <= 13; }
 template <int GATHER, int FM>
-constexpr int gemm_nbuf() { return (GATHER == 6 || GATHER == 10 || GATHER == 11) ? 3 : GATHER == 12 ? 4 : ((GATHER == 1 || GATHER == 4) && FM == 1) ? 1 : 2; }   // the prefetch-distance-1 kernels keep one buffer
+constexpr int gemm_nbuf() { return (GATHER == 6 || GATHER == 10 || GATHER == 11) ? 3 : GATHER == 12 ? 4 : ((GATHER == 1 || GATHER == 4) && FM == 1) ? 1 : 2; }   // the prefetch-distance-1 kernels keep one buffer (GATHER 14: 128 x 128 only)
 constexpr bool gemm_is_glds(int GATHER) { return GATHER == 5 || GATHER == 6 || gemm_is_mt(GATHER); }
 // GLDS (GATHER 5 / 6): operand tiles go global -> LDS directly (global_load_lds_dwordx4), unpadded images whose 16-byte slots are
 // XOR-swizzled through the SOURCE address; a ring of 2 / 3 stages
@@ -527,6 +545,17 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     // PMC (SQ_ACTIVE_INST_ANY ~ 84 % of the kernel, MFMA busy 10 %) showed this kernel is instruction-issue bound:
     // the interior fast path keeps one pointer per staging vector and advances it by a constant per k-tile.
     // Rows beyond M/N are clamped to the last valid row (their results are never stored).
+    // GATHER 14 = GATHER 1 (tap-uniform im2col gather of A) for the DATA GRADIENT OF A STRIDE-2 CONVOLUTION, by parity classes (round 6).  Output
+    // pixel (y, x) of the input grid receives tap (kh, kw) only when y + pad - kh and x + pad - kw are even: a quarter of the taps on average
+    // (3 x 3: 1, 2, 2 or 4 of 9; 1 x 1: the even-even pixels only).  The plain gather multiplied every tap for every pixel and zeroed three
+    // quarters of the operand vectors.  Here the rows are visited class by class -- virtual row = (class, image, y / 2, x / 2), a tile never
+    // straddles classes -- and a tile walks ONLY the k-tiles of its class's taps (none at all: the zero rows of a 1 x 1 stride-2 gradient,
+    // epilogue only).  Valid taps in the same order, the skipped products were exact zeros: same results.  Epilogues address memory by the
+    // REAL row (par_real_row).
+    constexpr bool PAR = GATHER == 14;
+    constexpr bool G1 = GATHER == 1 || PAR;
+    static_assert(!PAR || (AK && BKC && FM == 2 && FN == 2 && NW == 8 && (EPI == 0 || EPI == 3)), "parity form: 128 x 128 tiles, plain / BatchNorm-backward epilogues");
+    uint32_t par_taps = 0;                              // the class's taps (kh * KW + kw), four bits each, in ascending order
     constexpr bool MT = gemm_is_mt(GATHER);             // ... its pipelined form (both operands k-contiguous)
     constexpr bool GLDS = gemm_is_glds(GATHER);         // direct-to-LDS ring (bf16, interior fast path, any of the four operand layouts)
     static_assert(!MT || (AK && BKC && !CS), "pipelined ring: NT products");
@@ -562,16 +591,41 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
         int tm, tn;
         if (P.mfast) { tn = tile / P.tiles_m; tm = tile - tn * P.tiles_m; }
         else         { tm = tile / P.tiles_n; tn = tile - tm * P.tiles_n; }
+        if constexpr (GATHER == 14) {
+            // consecutive row tiles take turns through the four parity classes (their reductions differ: 1 / 2 / 2 / 4 taps of a 3 x 3, 1 / 0 / 0 / 0
+            // of a 1 x 1): in class-major order an XCD's share of the tile ids was ONE class, i.e. two of the eight XCDs did all of a 1 x 1's work
+            const int q4 = P.tiles_m >> 2;
+            tm = (tm & 3) * q4 + (tm >> 2);
+        }
         m0 = tm * BM; n0 = tn * BN;
         kbeg = split * P.kchunk;
         kend = min(d.K, kbeg + P.kchunk);
         nt = (kend - kbeg + BK - 1) / BK;
-        if constexpr (GATHER == 1) {
+        if constexpr (PAR) {   // the tile's class and its taps; the reduction is taps x channels
+            const RalfConvGeom& g = d.g;
+            const int cls = (int)P.fd_q.div((uint32_t)m0), py = cls >> 1, px = cls & 1;
+            int n = 0;
+            par_taps = 0;
+            for (int kh = 0; kh < g.KH; ++kh)
+                for (int kw = 0; kw < g.KW; ++kw)
+                    if ((((py + g.pad - kh) | (px + g.pad - kw)) & 1) == 0) { par_taps |= (uint32_t)(kh * g.KW + kw) << (4 * n); ++n; }
+            kbeg = 0; kend = n * g.SC;
+            nt = kend / BK;
+        }
+        if constexpr (G1) {
             const RalfConvGeom& g = d.g;
 #pragma unroll
             for (int i = 0; i < NVA; ++i) {
                 const int v = tid + NT * i;
-                const RowInfo r = row_info<true>(P, m0 + v / KV, d.M, d.lda);
+                RowInfo r;
+                if constexpr (PAR) {
+                    int cls, b, ry, rx;
+                    const int row = m0 + v / KV;
+                    par_decompose(P, (uint32_t)row, cls, b, ry, rx);
+                    r.ok = row < d.M; r.base = (int64_t)b * g.SH * g.SW * g.SC; r.y0 = ry + g.pad; r.x0 = rx + g.pad;
+                } else {
+                    r = row_info<true>(P, m0 + v / KV, d.M, d.lda);
+                }
                 g_bc[i] = (int)r.base + (v % KV) * VEC;
                 g_p0[i] = (r.y0 * g.SW + r.x0) * g.SC;
                 g_y0[i] = r.ok ? r.y0 : -(1 << 30);     // a row beyond M fails every bounds test
@@ -684,11 +738,12 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
 #pragma unroll
                 for (int i = 0; i < NVB; ++i) pb[i] += d.sBk;
             }
-        } else if constexpr (GATHER == 1) {
+        } else if constexpr (G1) {
             // every k-tile lies inside ONE tap (channels % BK == 0): its (kh, kw, c0) come from the scalar unit
             const RalfConvGeom& g = d.g;
             int t, c0, kh, kw;
             P.fd_sc.divmod((uint32_t)k0, t, c0);
+            if constexpr (PAR) t = (int)((par_taps >> (4 * t)) & 15u);   // k0 counts the class's taps: the t-th of them
             P.fd_kw.divmod((uint32_t)t, kh, kw);
             const int skh = P.ln_sgn * kh, skw = P.ln_sgn * kw;
             const int delta = (skh * g.SW + skw) * g.SC;
@@ -703,8 +758,14 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                 ra[i] = *reinterpret_cast<const u32x4*>(Ap + (ok ? off : 0));
                 m |= (uint32_t)ok << i;
             }
+            if constexpr (PAR) {
+                const int kreal = t * g.SC + c0;                         // the weights' k range of this tile (uniform)
 #pragma unroll
-            for (int i = 0; i < NVB; ++i) { rb[i] = *reinterpret_cast<const u32x4*>(pb[i]); pb[i] += BK; }
+                for (int i = 0; i < NVB; ++i) rb[i] = *reinterpret_cast<const u32x4*>(pb[i] + kreal);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NVB; ++i) { rb[i] = *reinterpret_cast<const u32x4*>(pb[i]); pb[i] += BK; }
+            }
             okm = m;
         } else if constexpr (GATHER == 2) {
             const RalfConvGeom& g = d.g;
@@ -1130,6 +1191,8 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
             __syncthreads();
         }
         compute(la0, lb0);
+    } else if (PAR && c_nt == 0) {
+        // (a parity class without taps -- the odd pixels of a 1 x 1 stride-2 data gradient: the product is zero, the epilogue still runs)
     } else {
         stage(la0, lb0, ra0, rb0, rc0, c_kbeg, okm0);
         if (c_nt > 2) gload(ra0, rb0, rc0, c_kbeg + 2 * BK, okm0);
@@ -1253,8 +1316,9 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
 #pragma unroll
             for (int p = 0; p < 64 / RPP; ++p) {
                 const int lr = p * RPP + tid / CG, c = (tid % CG) * 8;
-                const int m = c_m0 + h * 64 + lr;
-                if (m < d.M) {
+                const int mv = c_m0 + h * 64 + lr;                         // (PAR: the virtual row; memory is addressed by the real one)
+                if (mv < d.M) {
+                    const int m = PAR ? par_real_row(P, mv) : mv;
                     const float4 lo = *reinterpret_cast<const float4*>(cs + lr * CP + c), hi = *reinterpret_cast<const float4*>(cs + lr * CP + c + 4);
                     float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                     if constexpr (EPI == 3) epilogue_storev_bnb<T>(d, m, c_n0 + c, v, bmu, bs1, bs2);
@@ -1291,14 +1355,15 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     } else {
 #pragma clang loop unroll(full)
     for (int i = 0; i < FM; ++i) {
-        const int m = c_m0 + wm * 32 * WFM + i * 32 + l31;
+        const int mv = c_m0 + wm * 32 * WFM + i * 32 + l31;
+        const int m = (PAR && mv < d.M) ? par_real_row(P, mv) : mv;
 #pragma clang loop unroll(full)
         for (int j = 0; j < WFN; ++j) {
 #pragma clang loop unroll(full)
             for (int g = 0; g < 4; ++g) {
                 const int n = c_n0 + wn * 32 * WFN + j * 32 + 8 * g + 4 * lh;
                 float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                if (m < d.M && n < d.N) {
+                if (mv < d.M && n < d.N) {
                     if (slab) {
                         float* pp = P.partial + (((int64_t)c_split * nbatch + z) * d.M + m) * d.N + n;
                         if (P.vec_epi && n + 3 < d.N) *reinterpret_cast<float4*>(pp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -1679,7 +1744,7 @@ int launch(KParams& P, int nbatch, hipStream_t st) {
     // column tiles fastest.  A few hundred queries x a 220 MB index (the two-stage k-NN's coarse pass): with column tiles fastest every XCD
     // owned one row tile and streamed the WHOLE index (8 x 220 MB per call: 390 us); row tiles fastest keeps the 3.7 MB of queries resident
     // and streams every index row once.
-    P.mfast = (AK && BKC && GATHER != 1 && GATHER != 4 && nbatch == 1 && P.d.splitk == 1 && !P.d.kseg && (int64_t)P.d.M * 4 <= (int64_t)P.d.N) ? 1 : 0;
+    P.mfast = (AK && BKC && GATHER != 1 && GATHER != 4 && GATHER != 14 && nbatch == 1 && P.d.splitk == 1 && !P.d.kseg && (int64_t)P.d.M * 4 <= (int64_t)P.d.N) ? 1 : 0;
     P.tiles_n = ceil_div(P.d.N, 64 * FN);
     P.nwg = P.tiles_m * P.tiles_n;
     constexpr bool persist = RALF_GEMM_PERSISTENT != 0;   // off: measured -4...+6 % (the prefetch across the epilogue costs a wave of occupancy)
@@ -1790,6 +1855,14 @@ int dispatch(KParams& P, int nbatch, hipStream_t st) {
     const int key = (d.a_kcontig ? 4 : 0) | (d.b_kcontig ? 2 : 0);
     if (d.gather == 1) {
         if (key != 6) { ralf::set_error("gemm: gather=1 needs A and B k-contiguous"); return RALF_ERR_INVALID; }
+        if constexpr (sizeof(T) == 2) {
+            // data gradient of a stride-2 convolution: parity classes (gemm_body GATHER 14) where the tile rule picks 128 x 128 tiles anyway
+            const bool plain = !d.colstats && !d.flt_list && !d.C2 && d.act != RALF_ACT_GELU && d.aux_mode != RALF_AUX_GELU_GRAD && !d.atomic_out && d.drop_p == 0.f && !d.aux;
+            if (P.tapuni && P.par && plain && gemm_use128(d, nbatch)) {
+                if (d.bnb_part) return launch<T, true, true, 14, 2, 2, 3, 8>(P, nbatch, st);
+                return launch<T, true, true, 14, 2, 2, 0, 8>(P, nbatch, st);
+            }
+        }
         if (P.tapuni) return launch_cfg<T, true, true, 1>(P, nbatch, st);
         return launch_cfg<T, true, true, 4>(P, nbatch, st);
     }

@@ -110,6 +110,47 @@ def test_conv_gather(dtype, cfg):
     torch.testing.assert_close(gw.cpu().view(Co, k, k, Ci).permute(0, 3, 1, 2), w.grad, **tol)
 
 
+@pytest.mark.parametrize("cfg", [(8, 64, 64, 128, 128, 3, 1), (8, 64, 64, 128, 256, 1, 0), (16, 32, 32, 256, 128, 3, 1)])
+@pytest.mark.parametrize("bnb", [False, True])
+def test_stride2_data_gradient_by_parity_classes(cfg, bnb):
+    """the data gradient of a STRIDE-2 convolution at sizes where ralf_gemm takes the parity-class form (gemm_impl.h GATHER 14: rows visited class by
+    class, only the class's taps multiplied, none at all for the odd pixels of a 1 x 1 convolution) against torch's conv2d autograd -- plain with
+    a skip gradient, and with the BatchNorm-backward epilogue (ReLU mask, dz stored, per-64-row partial sums: any row order gives the same column
+    sums).  layer2.0 / layer3.0 / layer4.0 of the backbone: conv2 (3 x 3) and downsample (1 x 1), common/image.py:39-48."""
+    from ralf_amd import ops
+
+    dtype = torch.bfloat16
+    Bn, H, W, Ci, Co, k, p = cfg
+    x = rnd(Bn, Ci, H, W, seed=11, dtype=dtype).float().requires_grad_(True)
+    w = (rnd(Co, Ci, k, k, seed=12, dtype=dtype) * 0.05).float().requires_grad_(True)
+    y = F.conv2d(x, w, None, 2, p)
+    OH, OW = y.shape[2:]
+    gy = rnd(*y.shape, seed=13, dtype=dtype).float()
+    y.backward(gy)
+    w_dgrad = w.detach().permute(1, 2, 3, 0).contiguous().to(dtype).cuda()       # [Ci][kh][kw][co]
+    gyn = gy.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    Mi = Bn * H * W
+    assert (Mi // 4) % 128 == 0 and (Mi // 128) * ((Ci + 127) // 128) >= 192       # the parity form's conditions (whole tiles per class, the 128 x 128 tile rule)
+    geom_d = dict(RH=H, RW=W, SH=OH, SW=OW, SC=Co, KH=k, KW=k, stride=2, pad=p, mode=1)
+    skip = rnd(Mi, Ci, seed=14, dtype=dtype).cuda()
+    want = x.grad.permute(0, 2, 3, 1).reshape(Mi, Ci) + skip.float().cpu()
+    if not bnb:
+        gx = ops.gemm(gyn, w_dgrad, Mi, Ci, k * k * Co, conv=geom_d, gather=1, res=skip)
+        torch.testing.assert_close(gx.float().cpu(), want, **TOL[dtype])
+        return
+    xa = rnd(Mi, Ci, seed=15, dtype=dtype).cuda()
+    mean = rnd(Ci, seed=16).cuda() * 0.3
+    keep = torch.rand(Mi, Ci, generator=torch.Generator().manual_seed(17)) > 0.4
+    bits = (keep.view(-1, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(1).to(torch.uint8).cuda()
+    part = torch.full(((Mi + 63) // 64, 2, Ci), float("nan"), device="cuda")
+    dz = ops.gemm(gyn, w_dgrad, Mi, Ci, k * k * Co, conv=geom_d, gather=1, res=skip, bnb=(xa, bits, mean, part))
+    torch.testing.assert_close(dz.float().cpu(), (want * keep).to(dtype).float(), **TOL[dtype])
+    assert bool((dz[~keep.cuda()] == 0).all())
+    d = dz.float()
+    torch.testing.assert_close(part[:, 0].sum(0), d.sum(0), atol=2e-2, rtol=1e-3)                       # (block order differs from the row order: the TOTALS are what the statistics use)
+    torch.testing.assert_close(part[:, 1].sum(0), (d * (xa.float() - mean)).sum(0), atol=5e-2, rtol=1e-3)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(64, 64, 64), (1000, 64, 128), (4101, 128, 2048), (70000, 256, 64), (130, 192, 64)])
 def test_column_statistics_epilogue(dtype, M, N, K):
