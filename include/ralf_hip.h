@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 22
+#define RALF_ABI_VERSION 23
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -438,6 +438,35 @@ int ralf_decode_attn(const RalfDecodeAttnDesc* d, void* stream);
 /* most keys (cached rows, + the new one when self_) ralf_decode_attn accepts: its scores live in LDS.  Callers with longer memories
  * (2*h*w + K + Lc rows: e.g. 512x512 canvases) use ralf_layernorm_fwd + ralf_gemm + ralf_attention_fwd instead. */
 int ralf_decode_attn_max_keys(void);
+
+/* One KV-cached decode step of the WHOLE decoder stack in ONE launch, a workgroup per sample (ralf_amd/csrc/decode_token.hip): token ids [B] at
+ * positions pos (or pos_vec[b]) -> fp32 logits [B, V].  Replaces the per-token decoder call of the reference's sampling loop
+ * (retrieval_augmented_autoreg.py:274-279; common/common.py:84-135: embedding, nlayers x nn.TransformerDecoderLayer(norm_first), head) and the
+ * ~45 launches per token it took through ralf_embed_fwd / ralf_decode_attn / ralf_gemm.  bf16 weights row-major [n_out, n_in] (the
+ * nn.Linear / in_proj layouts), fp32 biases and LayerNorm parameters, d = 256, 8 heads, feed-forward 1024.
+ *   self_kv  bf16 [B, L, 2d] per layer: rows < pos are read, row pos is written (k at column 0, v at column d)
+ *   cross_kv bf16 [B, 8, M, 64] per layer: slice 4 * kv + hp = keys (kv = 0) / values (1) of head pair hp (nn.decoder_init_cache)
+ *   kpm uint8 [B, kpm_bs] or NULL: padded PREFIX tokens of the self-attention (tgt_key_padding_mask), columns 0 .. pos
+ *   emb fp32 [vocab, d], pe fp32 [positions, d], emb_scale = sqrt(d); lnh_*, w_head [V, d]: the head (LayerNorm + Linear without bias) */
+#define RALF_DECODE_TOKEN_MAX_LAYERS 8
+typedef struct RalfDecodeTokenLayer {
+    const void* w_qkv; const float* b_qkv; const float* ln1_g; const float* ln1_b;
+    const void* w_o1; const float* b_o1;
+    const float* ln2_g; const float* ln2_b; const void* w_q2; const float* b_q2;
+    const void* w_o2; const float* b_o2;
+    const float* ln3_g; const float* ln3_b; const void* w_f1; const float* b_f1; const void* w_f2; const float* b_f2;
+    void* self_kv; const void* cross_kv;
+} RalfDecodeTokenLayer;
+typedef struct RalfDecodeTokenDesc {
+    const int64_t* tok; const int32_t* pos_vec; const uint8_t* kpm;
+    const float* emb; const float* pe; const float* lnh_g; const float* lnh_b; const void* w_head; float* logits;
+    int64_t kpm_bs;
+    int B, L, M, V, nlayers, pos;
+    float emb_scale, eps;
+    RalfDecodeTokenLayer layer[RALF_DECODE_TOKEN_MAX_LAYERS];
+} RalfDecodeTokenDesc;
+int ralf_decode_token(const RalfDecodeTokenDesc* d, void* stream);
+int ralf_decode_token_limits(int* max_self_rows, int* max_memory_rows);   /* most cached positions (L) and memory rows (M) ralf_decode_token takes */
 
 /* Pre-norm transformer layers (forward, training) of SHORT sequences (ralf_amd/csrc/tlayer.hip): a workgroup per sample keeps its
  * S <= RALF_TLAYER_MAX_ROWS rows in LDS from a LayerNorm to the end of the block chain.  bf16, d = 256, 8 heads, ff = 1024:

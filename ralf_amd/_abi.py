@@ -16,6 +16,8 @@ SIGNATURES = {
     "ralf_knn_rescore": (i32, [vp, i64, i32, vp, i32, vp, i32, vp, vp]),
     "ralf_knn_select_cand": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, i64, vp, vp, i32, vp, vp]),
     "ralf_knn_rownorms": (i32, [vp, vp, i64, i32, vp, vp, vp]),
+    "ralf_decode_token": (i32, [vp, vp]),
+    "ralf_decode_token_limits": (i32, [vp, vp]),
     "ralf_knn_two_stage_workspace_bytes": (sz, [i64, i32, i32, i32]),
     "ralf_knn_topk_ip_two_stage": (i32, [vp, vp, i64, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "ralf_knn_list_unpack": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
@@ -31,6 +33,16 @@ class RalfDecodeAttnDesc(ctypes.Structure):
     _fields_ = ([(n, vp) for n in ("x", "ln_g", "ln_b", "W", "bias", "kv", "kpm", "o")]
                 + [(n, i64) for n in ("x_rs", "kv_bs", "kv_rs", "kpm_bs", "o_rs")]
                 + [(n, i32) for n in ("B", "H", "d", "Sk", "self_")] + [("scale", f32), ("eps", f32), ("kv_hs", i64), ("kv_vo", i64), ("pos", vp)])
+
+
+class RalfDecodeTokenLayer(ctypes.Structure):
+    _fields_ = [(n, vp) for n in ("w_qkv", "b_qkv", "ln1_g", "ln1_b", "w_o1", "b_o1", "ln2_g", "ln2_b", "w_q2", "b_q2", "w_o2", "b_o2",
+                                  "ln3_g", "ln3_b", "w_f1", "b_f1", "w_f2", "b_f2", "self_kv", "cross_kv")]
+
+
+class RalfDecodeTokenDesc(ctypes.Structure):
+    _fields_ = ([(n, vp) for n in ("tok", "pos_vec", "kpm", "emb", "pe", "lnh_g", "lnh_b", "w_head", "logits")] + [("kpm_bs", i64)]
+                + [(n, i32) for n in ("B", "L", "M", "V", "nlayers", "pos")] + [("emb_scale", f32), ("eps", f32)] + [("layer", RalfDecodeTokenLayer * 8)])
 
 
 class RalfTLayerDesc(ctypes.Structure):

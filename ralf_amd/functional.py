@@ -171,6 +171,8 @@ class Runtime:
         # launch, 26 k of its 39 k cycles in the feed-forward weight stream), the four launches it replaces spread them over the chip
         self.fused_decode_tail = os.environ.get("RALF_DECODE_TAIL", "0") == "1"
         self.fused_decode = True  # KV-cached decode step: LayerNorm + projections + attention per block in one launch (bf16, d = 256, 8 heads)
+        # ... the WHOLE step (embedding, every layer, head) as one launch with a workgroup per sample (ops.decode_token, csrc/decode_token.hip)
+        self.fused_decode_token = os.environ.get("RALF_DECODE_TOKEN", "1") != "0"
         self.fold_bn = True       # inference: eval-mode BatchNorm folded into the convolution epilogues (conv_bn_infer)
         # decode step: LayerNorm inside the few-row product that follows it (RalfGemmDesc.ln_*) and the four-wave split of the 256 x 256 x 1024
         # product (few_row_split) -- same arithmetic, other summation orders than the separate launches (off: their bits)

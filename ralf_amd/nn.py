@@ -370,6 +370,31 @@ def decoder_init_cache(dec: "BaseDecoder", memory: torch.Tensor, rt: Runtime, ma
     return DecodeCache(cross, selfkv, max_len, packed, cross_rows=M, cross_packed=pack)
 
 
+def _decode_token_ok(dec, cache, rt, tok) -> bool:
+    """ralf_decode_token's conditions: bf16, d = 256, 8 heads, feed-forward 1024, the head-pair-major cross-attention cache, sizes within its LDS"""
+    if not (rt.fused_decode and rt.fused_decode_token and rt.dtype == torch.bfloat16 and tok.is_cuda and cache.cross_packed and cache.packed is None):
+        return False
+    layers = dec.transformer.layers
+    maxl, maxm = ops.decode_token_limits()
+    return (dec.d_model == 256 and layers[0].self_attn.nhead == 8 and len(layers) <= 8 and all(l.linear1.weight.shape[0] == 1024 for l in layers)
+            and cache.max_len <= maxl and cache.cross_rows <= maxm and getattr(dec.head[1], "bias", None) is None and tok.dtype == torch.long
+            and dec.pos_emb.pe.dtype == torch.float32 and dec.emb.weight.dtype == torch.float32)
+
+
+def _decode_token_weights(dec, rt):
+    """device tensors ralf_decode_token reads, per layer (the bf16 shadows are refreshed in place when the masters change: Runtime.lp)"""
+    d = dec.d_model
+    layers = []
+    for l in dec.transformer.layers:
+        sa, ca = l.self_attn, l.multihead_attn
+        layers.append({"w_qkv": rt.lp(sa.in_proj_weight), "b_qkv": sa.in_proj_bias.detach(), "ln1_g": l.norm1.weight.detach(), "ln1_b": l.norm1.bias.detach(),
+                       "w_o1": rt.lp(sa.out_proj.weight), "b_o1": sa.out_proj.bias.detach(), "ln2_g": l.norm2.weight.detach(), "ln2_b": l.norm2.bias.detach(),
+                       "w_q2": rt.lp(ca.in_proj_weight)[:d], "b_q2": ca.in_proj_bias.detach()[:d], "w_o2": rt.lp(ca.out_proj.weight), "b_o2": ca.out_proj.bias.detach(),
+                       "ln3_g": l.norm3.weight.detach(), "ln3_b": l.norm3.bias.detach(), "w_f1": rt.lp(l.linear1.weight), "b_f1": l.linear1.bias.detach(),
+                       "w_f2": rt.lp(l.linear2.weight), "b_f2": l.linear2.bias.detach()})
+    return {"layers": layers, "head": (dec.head[0].weight.detach(), dec.head[0].bias.detach(), rt.lp(dec.head[1].weight))}
+
+
 @torch.no_grad()
 def decoder_step(dec: "BaseDecoder", tok: torch.Tensor, pos: int, cache: DecodeCache, rt: Runtime, kpm_prefix: torch.Tensor,
                  kpm_stride: Optional[int] = None, pos_vec: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -382,6 +407,12 @@ def decoder_step(dec: "BaseDecoder", tok: torch.Tensor, pos: int, cache: DecodeC
     B = tok.shape[0]
     d, H = dec.d_model, dec.transformer.layers[0].self_attn.nhead
     dh = d // H
+    if _decode_token_ok(dec, cache, rt, tok):
+        # the whole step as ONE launch, a workgroup per sample (bf16 throughput mode; same rounding points as the launches below)
+        lw = _decode_token_weights(dec, rt)
+        kst = kpm_stride if kpm_stride else kpm_prefix.shape[1]
+        return ops.decode_token(lw["layers"], lw["head"], dec.emb.weight.detach(), dec.pos_emb.pe[0], math.sqrt(d), tok, pos, cache.self_kv, cache.cross_kv,
+                                cache.max_len, cache.cross_rows, dec.head[1].weight.shape[0], kpm=kpm_prefix, kpm_stride=kst, pos_vec=pos_vec)
     if pos_vec is None:
         x = ops.embed_fwd(tok.view(B, 1).contiguous(), dec.emb.weight.detach(), dec.pos_emb.pe[0, pos:pos + 1].contiguous(), 1, math.sqrt(d), rt.dtype).view(B, d)
     else:   # the batch as ONE sequence whose positional rows are gathered per element: the same kernel, the same arithmetic

@@ -969,6 +969,41 @@ def decode_attn(x, ln_g, ln_b, W, bias, kv, Sk, H, self_attn, kpm=None, kpm_stri
     return o
 
 
+_DEC_TOKEN_LIMITS = None
+
+
+def decode_token_limits():
+    """(most cached positions, most memory rows) ralf_decode_token takes"""
+    global _DEC_TOKEN_LIMITS
+    if _DEC_TOKEN_LIMITS is None:
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.lib().ralf_decode_token_limits(ctypes.byref(a), ctypes.byref(b))
+        _DEC_TOKEN_LIMITS = (a.value, b.value)
+    return _DEC_TOKEN_LIMITS
+
+
+def decode_token(layers, head, emb, pe, emb_scale, tok, pos, self_kv, cross_kv, L, M, V, kpm=None, kpm_stride=0, pos_vec=None, eps=1e-5, keep=None):
+    """one KV-cached decode step of the whole decoder stack in ONE launch, a workgroup per sample (ralf_decode_token): token ids [B] -> fp32
+    logits [B, V].  layers: per layer a dict of device tensors (bf16 weights row-major [n_out, n_in], fp32 biases / LayerNorm parameters):
+    w_qkv b_qkv ln1_g ln1_b w_o1 b_o1 ln2_g ln2_b w_q2 b_q2 w_o2 b_o2 ln3_g ln3_b w_f1 b_f1 w_f2 b_f2; head = (ln_g, ln_b, w_head)."""
+    from ._abi import RalfDecodeTokenDesc
+
+    B = tok.numel()
+    logits = torch.empty(B, V, dtype=torch.float32, device=tok.device)
+    d = RalfDecodeTokenDesc()
+    d.tok, d.pos_vec, d.kpm, d.emb, d.pe = _p(tok), _p(pos_vec), _p(kpm), _p(emb), _p(pe)
+    d.lnh_g, d.lnh_b, d.w_head, d.logits = _p(head[0]), _p(head[1]), _p(head[2]), _p(logits)
+    d.kpm_bs, d.B, d.L, d.M, d.V, d.nlayers, d.pos = int(kpm_stride), B, int(L), int(M), int(V), len(layers), int(pos)
+    d.emb_scale, d.eps = float(emb_scale), float(eps)
+    for i, w in enumerate(layers):
+        lw = d.layer[i]
+        for n in ("w_qkv", "b_qkv", "ln1_g", "ln1_b", "w_o1", "b_o1", "ln2_g", "ln2_b", "w_q2", "b_q2", "w_o2", "b_o2", "ln3_g", "ln3_b", "w_f1", "b_f1", "w_f2", "b_f2"):
+            setattr(lw, n, _p(w[n]))
+        lw.self_kv, lw.cross_kv = _p(self_kv[i]), _p(cross_kv[i])
+    _call("ralf_decode_token", ctypes.byref(d))
+    return logits
+
+
 def attention_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, dh, q_off=0, k_off=0, v_off=0, dq_off=0, dk_off=0, dv_off=0,
                   causal=False, kpm=None, scale=None, p_drop=0.0, seed=None, call_id=0):
     d = _attn_desc(q, k, v, o, B, H, Sq, Sk, dh, q_off, k_off, v_off, causal, kpm, scale if scale is not None else dh ** -0.5, p_drop, seed, call_id)
