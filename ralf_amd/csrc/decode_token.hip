@@ -22,7 +22,7 @@ typedef __bf16 bf16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int D = 256, NH = 8, DH = 32, FF = 1024, NT = 512, DT_MAXM = 1024, DT_MAXL = 64;
+constexpr int D = 256, NH = 8, DH = 32, FF = 1024, NT = 512, DT_MAXM = 1024, DT_MAXL = 64, KVS_LD = 2 * D + 8;
 
 struct Lds {
     float x[D];                 // the residual stream (values representable in bf16)
@@ -32,6 +32,7 @@ struct Lds {
     float red[32];              // LayerNorm / softmax hand-offs
     __attribute__((aligned(16))) bf16 hb[D];    // input of the current 256-wide matrix-vector product (LayerNorm / attention output)
     __attribute__((aligned(16))) bf16 hb2[FF];  // the feed-forward hidden layer
+    __attribute__((aligned(16))) bf16 kvs[DT_MAXL][KVS_LD];   // self-attention: the sample's cached k | v rows (row stride 1040 bytes: 16 rows of a 16-byte read hit 64 banks)
 };
 
 __device__ __forceinline__ float bfr(float v) { return (float)(bf16)v; }
@@ -158,8 +159,9 @@ __device__ __forceinline__ void gemv(const bf16* __restrict__ W, const float* __
     __syncthreads();
 }
 
-// hb[0..255] = bf16(LayerNorm(x) * g + b) (the formulas of ln_fwd_kernel: mean, then the centred sum of squares).  Ends with a barrier.
-__device__ __forceinline__ void layer_norm(const float* __restrict__ gam, const float* __restrict__ bet, float eps, Lds& L, int tid) {
+// hb[0..255] = bf16(LayerNorm(x) * g + b) (the formulas of ln_fwd_kernel: mean, then the centred sum of squares); g / b = this thread's element of
+// the parameters, requested long before (a load behind the statistics cost ~1 k cycles per LayerNorm).  Ends with a barrier.
+__device__ __forceinline__ void layer_norm(float gam, float bet, float eps, Lds& L, int tid) {
     const int lane = tid & 63, wv = tid >> 6;
     const float xv = tid < D ? L.x[tid] : 0.f;
     const float s = wave::sum64(xv);
@@ -171,7 +173,7 @@ __device__ __forceinline__ void layer_norm(const float* __restrict__ gam, const 
     if (lane == 0) L.red[8 + wv] = q;
     __syncthreads();
     const float rs = rsqrtf((L.red[8] + L.red[9] + L.red[10] + L.red[11]) * (1.f / D) + eps);
-    if (tid < D) L.hb[tid] = (bf16)(dv * rs * gam[tid] + bet[tid]);
+    if (tid < D) L.hb[tid] = (bf16)(dv * rs * gam + bet);
     __syncthreads();
 }
 
@@ -193,25 +195,45 @@ __global__ __launch_bounds__(NT) void decode_token_kernel(const RalfDecodeTokenD
     if (tid < D) L.x[tid] = bfr(d.emb[(int64_t)d.tok[b] * D + tid] * d.emb_scale + d.pe[(int64_t)pos * D + tid]);
     __syncthreads();
     DT_STAMP(0);
+    const int pt = tid & (D - 1);                                 // (threads 256 .. 511 request the same elements: no divergent loads)
+    const float gh = d.lnh_g[pt], bh = d.lnh_b[pt];
+    float g1 = d.layer[0].ln1_g[pt], b1 = d.layer[0].ln1_b[pt];   // LayerNorm 1 of the first layer; the later ones are requested a phase ahead
     for (int li = 0; li < d.nlayers; ++li) {
         const RalfDecodeTokenLayer& W = d.layer[li];
         const int sb = 1 + li * 12; (void)sb;
+        const float g2 = W.ln2_g[pt], b2 = W.ln2_b[pt], g3 = W.ln3_g[pt], b3 = W.ln3_b[pt];
+        // the sample's cached k | v rows (<= 63 KB from L2) start their way now and land in LDS behind the q | k | v product: one round trip
+        // instead of one per key (the self-attention block took 6.4 k cycles with per-key loads)
+        constexpr int KVU = DT_MAXL * 2 * D / 8 / NT;             // 16-byte pieces per thread: 8
+        bf16x8 kvr[KVU];
+        {
+            const bf16* KV = (const bf16*)W.self_kv + (int64_t)b * d.L * 2 * D;
+#pragma unroll
+            for (int u = 0; u < KVU; ++u) {
+                const int piece = tid + NT * u, row = piece >> 6;  // 64 pieces per 1-KiB row
+                kvr[u] = *reinterpret_cast<const bf16x8*>(KV + (int64_t)min(row, max(pos - 1, 0)) * 2 * D + (piece & 63) * 8);
+            }
+        }
         // ================= self-attention block: x += Wo1 attn(LN1(x)) + bo1 =================
-        layer_norm(W.ln1_g, W.ln1_b, d.eps, L, tid);
+        layer_norm(g1, b1, d.eps, L, tid);
         DT_STAMP(sb + 0);
         gemv<256, EPI_QKV>((const bf16*)W.w_qkv, W.b_qkv, 3 * D, L, tid, (bf16*)W.self_kv + ((int64_t)b * d.L + pos) * 2 * D);   // (q | k | v in bf16; k / v of the new token -> cache row `pos`)
         DT_STAMP(sb + 1);
+#pragma unroll
+        for (int u = 0; u < KVU; ++u) {
+            const int piece = tid + NT * u, row = piece >> 6;
+            if (row < pos) *reinterpret_cast<bf16x8*>(&L.kvs[row][(piece & 63) * 8]) = kvr[u];
+        }
+        __syncthreads();
         {   // one wave per head; lane = key (cached rows 0 .. pos - 1, the new one = pos)
             const int h = wv;
-            const bf16* KV = (const bf16*)W.self_kv + (int64_t)b * d.L * 2 * D;
             float s = -__builtin_inff();
             if (lane <= pos) {
                 float a = 0.f;
                 if (lane < pos) {
-                    const bf16* kr = KV + (int64_t)lane * 2 * D + h * DH;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const bf16x8 kk = *reinterpret_cast<const bf16x8*>(kr + 8 * c);
+                        const bf16x8 kk = *reinterpret_cast<const bf16x8*>(&L.kvs[lane][h * DH + 8 * c]);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) a += L.y[h * DH + 8 * c + e] * scale * (float)kk[e];
                     }
@@ -231,7 +253,7 @@ __global__ __launch_bounds__(NT) void decode_token_kernel(const RalfDecodeTokenD
             if (lane < DH) {
                 float o = 0.f;
 #pragma unroll 8
-                for (int j = 0; j < pos; ++j) o += L.sc[h][j] * (float)KV[(int64_t)j * 2 * D + D + h * DH + lane];
+                for (int j = 0; j < pos; ++j) o += L.sc[h][j] * (float)L.kvs[j][D + h * DH + lane];
                 o += L.sc[h][pos] * L.y[2 * D + h * DH + lane];
                 L.hb[h * DH + lane] = (bf16)(l > 0.f ? o / l : 0.f);
             }
@@ -241,7 +263,7 @@ __global__ __launch_bounds__(NT) void decode_token_kernel(const RalfDecodeTokenD
         gemv<256, EPI_RES>((const bf16*)W.w_o1, W.b_o1, D, L, tid);
         // ================= cross-attention block: x += Wo2 attn(LN2(x) Wq^T + bq; memory K, V) + bo2 =================
         DT_STAMP(sb + 3);
-        layer_norm(W.ln2_g, W.ln2_b, d.eps, L, tid);
+        layer_norm(g2, b2, d.eps, L, tid);
         gemv<256, EPI_Q>((const bf16*)W.w_q2, W.b_q2, D, L, tid);
         {
             DT_STAMP(sb + 4);
@@ -317,7 +339,8 @@ __global__ __launch_bounds__(NT) void decode_token_kernel(const RalfDecodeTokenD
         DT_STAMP(sb + 7);
         gemv<256, EPI_RES>((const bf16*)W.w_o2, W.b_o2, D, L, tid);
         // ================= feed-forward block: x += W2 relu(W1 LN3(x) + b1) + b2 =================
-        layer_norm(W.ln3_g, W.ln3_b, d.eps, L, tid);
+        if (li + 1 < d.nlayers) { g1 = d.layer[li + 1].ln1_g[pt]; b1 = d.layer[li + 1].ln1_b[pt]; }   // (the next layer's first LayerNorm)
+        layer_norm(g3, b3, d.eps, L, tid);
         DT_STAMP(sb + 8);
         gemv<256, EPI_RELU>((const bf16*)W.w_f1, W.b_f1, FF, L, tid);
         DT_STAMP(sb + 9);
@@ -327,7 +350,7 @@ __global__ __launch_bounds__(NT) void decode_token_kernel(const RalfDecodeTokenD
     }
     DT_STAMP(1 + 12 * RALF_DECODE_TOKEN_MAX_LAYERS);
     // ---- head: logits = Wh LN(x) (fp32, no bias) ----
-    layer_norm(d.lnh_g, d.lnh_b, d.eps, L, tid);
+    layer_norm(gh, bh, d.eps, L, tid);
     gemv<256, EPI_LOGITS>((const bf16*)d.w_head, nullptr, d.V, L, tid, nullptr, d.logits + (int64_t)b * d.V);
 }
 }  // namespace
