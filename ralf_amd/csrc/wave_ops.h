@@ -16,6 +16,7 @@ constexpr int QUAD_XOR1 = 0xB1, QUAD_XOR2 = 0x4E, ROW_HALF_MIRROR = 0x141, ROW_M
 // (a, b) := copies of v; after the swap a holds the even rows' (lower half's) values in both partner positions, b the odd rows' (upper half's):
 // lane l reads v[l] and v[l ^ 16] (v[l ^ 32]) from the pair.  Inline assembly: the builtins' second result is mis-allocated by this compiler
 // (ROCm 7.2 emits `v_add v1, v1, v1` after the swap).  The s_nop covers the VALU-write -> permlane-read hazard the assembler does not see.
+// NOT enough behind a v_dot2_f32_bf16 chain that produced the operands (stale reads seen: decode_token.hip uses five wait states there).
 __device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 
