@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 23
+#define RALF_ABI_VERSION 24
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -189,6 +189,10 @@ typedef struct RalfGemmDesc {
 size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d);
 int ralf_gemm(const RalfGemmDesc* d, void* workspace, size_t workspace_bytes, void* stream);
 int ralf_gemm_filter_tile(const RalfGemmDesc* d);   /* column-tile width (64 or 128) ralf_gemm will use for this flt_* product; <= 0 on error */
+/* Which form ralf_gemm takes for a gather = 1 product that is a 3 x 3 / stride-1 / pad-1 convolution (timm Bottleneck.conv2, common/image.py:39-48; forward
+ * or data gradient): 0 = the tap gather, 1 / 2 / 3 = the tile's input patch resident in LDS on 128 x 128 / 256 x 128 / 256 x 64 tiles (same results bit for
+ * bit; tests and tools ask).  Only shape, dtype, layout and geometry fields of the descriptor are read.  < 0 on error. */
+int ralf_gemm_patch_variant(const RalfGemmDesc* d);
 
 /* Weight gradients of MANY linear layers in one launch (the `dW += dy^T x` products autograd issues one by one for nn.Linear /
  * nn.MultiheadAttention in_proj / out_proj, e.g. 24 per encoder stack): job j adds dy_j^T x_j into the fp32 matrix dw_j.

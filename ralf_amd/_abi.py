@@ -115,6 +115,7 @@ SIGNATURES.update({
     "ralf_gemm_workspace_bytes": (sz, [ctypes.POINTER(RalfGemmDesc)]),
     "ralf_gemm": (i32, [ctypes.POINTER(RalfGemmDesc), vp, sz, vp]),
     "ralf_gemm_filter_tile": (i32, [ctypes.POINTER(RalfGemmDesc)]),
+    "ralf_gemm_patch_variant": (i32, [ctypes.POINTER(RalfGemmDesc)]),
 })
 
 u64, u8p = ctypes.c_uint64, vp

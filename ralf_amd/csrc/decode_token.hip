@@ -185,9 +185,16 @@ __device__ unsigned long long ralf_dt_probe[256];
 #define DT_STAMP(i)
 #endif
 
-__global__ __launch_bounds__(NT) void decode_token_kernel(const RalfDecodeTokenDesc d) {
+__global__ __launch_bounds__(NT) void decode_token_kernel(const RalfDecodeTokenDesc d, const int stagger) {
     __shared__ Lds L;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
+    // Every workgroup walks the same phases at the same pace, so all of them ask HBM for the memory keys / values at once (that phase runs AT the
+    // HBM rate) and the L2 for the weights at once.  Every second workgroup of an XCD therefore starts `stagger` clock ticks late: its
+    // HBM phases fall into the others' weight phases.
+    if (stagger > 0 && ((b >> 3) & 1)) {
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)stagger) __builtin_amdgcn_s_sleep(32);
+    }
     const int pos = d.pos_vec ? d.pos_vec[b] : d.pos;             // this element's position = its number of cached rows
     const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * d.kpm_bs : nullptr;
     const float scale = 0.17677669529663687f;                     // 32^-0.5
@@ -263,33 +270,46 @@ __global__ __launch_bounds__(NT) void decode_token_kernel(const RalfDecodeTokenD
         gemv<256, EPI_RES>((const bf16*)W.w_o1, W.b_o1, D, L, tid);
         // ================= cross-attention block: x += Wo2 attn(LN2(x) Wq^T + bq; memory K, V) + bo2 =================
         DT_STAMP(sb + 3);
+        // wave = (head pair, key half); lane = (key slot of eight, 16-byte piece of the pair's 128-byte row).  The FIRST batch of keys (128 per wave: eight
+        // 16-byte loads per lane) starts its way before LayerNorm 2 and the query projection -- it needs neither --, every later batch while
+        // the one before it is multiplied, and the first batch of values before the softmax.
+        const int hp = wv & 3, half = wv >> 2, chunk = lane & 7, slot = lane >> 3, head = chunk >> 2;
+        const int M = d.M, kstart = half * 8 + slot;
+        const bf16* Kb = (const bf16*)W.cross_kv + ((int64_t)b * 8 + hp) * M * 64 + chunk * 8;
+        const bf16* Vb = Kb + (int64_t)4 * M * 64;
+        auto ldkv = [&](bf16x8 (&r)[8], const bf16* base, int k0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + (int64_t)min(k0 + 16 * u, M - 1) * 64));
+        };
+        bf16x8 ka[8], kb[8];
+        ldkv(ka, Kb, kstart);
         layer_norm(g2, b2, d.eps, L, tid);
         gemv<256, EPI_Q>((const bf16*)W.w_q2, W.b_q2, D, L, tid);
         {
             DT_STAMP(sb + 4);
-            const int hp = wv & 3, half = wv >> 2, chunk = lane & 7, slot = lane >> 3, head = chunk >> 2;
-            const int M = d.M;
-            const bf16* Kb = (const bf16*)W.cross_kv + ((int64_t)b * 8 + hp) * M * 64 + chunk * 8;
-            const bf16* Vb = Kb + (int64_t)4 * M * 64;
             float qv[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) qv[e] = L.y[hp * 64 + chunk * 8 + e];
-            // pass 1: scores.  Keys of this wave: half * 8 + slot + 16 t; eight loads per lane in flight (128 keys of the wave's head pair)
-            for (int k0 = half * 8 + slot; k0 < M; k0 += 128) {
-                bf16x8 kk[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) kk[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(Kb + (int64_t)min(k0 + 16 * u, M - 1) * 64));
+            auto score = [&](const bf16x8 (&r)[8], int k0) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    float s = 0.f;
+                    float sv = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) s += qv[e] * (float)kk[u][e];
-                    s += wave::dpp<wave::QUAD_XOR1>(s);
-                    s += wave::dpp<wave::QUAD_XOR2>(s);
+                    for (int e = 0; e < 8; ++e) sv += qv[e] * (float)r[u][e];
+                    sv += wave::dpp<wave::QUAD_XOR1>(sv);
+                    sv += wave::dpp<wave::QUAD_XOR2>(sv);
                     const int key = k0 + 16 * u;
-                    if ((chunk & 3) == 0 && key < M) L.sc[hp * 2 + head][key] = s;
+                    if ((chunk & 3) == 0 && key < M) L.sc[hp * 2 + head][key] = sv;
                 }
+            };
+            // pass 1: scores
+            for (int k0 = kstart; k0 < M; k0 += 256) {
+                if (k0 + 128 < M) ldkv(kb, Kb, k0 + 128);
+                score(ka, k0);
+                if (k0 + 256 < M) ldkv(ka, Kb, k0 + 256);
+                if (k0 + 128 < M) score(kb, k0 + 128);
             }
+            ldkv(ka, Vb, kstart);   // (the first values: on their way through the softmax)
             __syncthreads();
             DT_STAMP(sb + 5);
             {   // softmax per head: wave = head
@@ -311,17 +331,20 @@ __global__ __launch_bounds__(NT) void decode_token_kernel(const RalfDecodeTokenD
             float acc[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-            for (int k0 = half * 8 + slot; k0 < M; k0 += 128) {
-                bf16x8 vv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) vv[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(Vb + (int64_t)min(k0 + 16 * u, M - 1) * 64));
+            auto pv = [&](const bf16x8 (&r)[8], int k0) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int key = k0 + 16 * u;
                     const float p = key < M ? L.sc[hp * 2 + head][key] : 0.f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] += p * (float)vv[u][e];
+                    for (int e = 0; e < 8; ++e) acc[e] += p * (float)r[u][e];
                 }
+            };
+            for (int k0 = kstart; k0 < M; k0 += 256) {
+                if (k0 + 128 < M) ldkv(kb, Vb, k0 + 128);
+                pv(ka, k0);
+                if (k0 + 256 < M) ldkv(ka, Vb, k0 + 256);
+                if (k0 + 128 < M) pv(kb, k0 + 128);
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {   // the eight key slots of the wave (lane bits 3, 4, 5)
@@ -370,7 +393,9 @@ extern "C" int ralf_decode_token(const RalfDecodeTokenDesc* dp, void* stream) {
         RALF_REQUIRE((((uintptr_t)w.w_qkv | (uintptr_t)w.w_o1 | (uintptr_t)w.w_q2 | (uintptr_t)w.w_o2 | (uintptr_t)w.w_f1 | (uintptr_t)w.w_f2 | (uintptr_t)w.self_kv | (uintptr_t)w.cross_kv) & 15) == 0,
                      "decode_token: layer %d: weights and caches must be 16-byte aligned", i);
     }
-    hipLaunchKernelGGL(decode_token_kernel, dim3(d.B), dim3(NT), 0, (hipStream_t)stream, d);
+    static const int stagger_env = [] { const char* e = getenv("RALF_DECODE_STAGGER"); return e ? atoi(e) : 0; }();
+    const int stagger = d.B > 128 ? stagger_env : 0;
+    hipLaunchKernelGGL(decode_token_kernel, dim3(d.B), dim3(NT), 0, (hipStream_t)stream, d, stagger);
     return ralf::check_launch("decode_token");
 }
 

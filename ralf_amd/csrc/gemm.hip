@@ -42,6 +42,40 @@ extern "C" int ralf_gemm_filter_tile(const RalfGemmDesc* dp) {
     return gemm_use128(d, 1) ? 128 : 64;
 }
 
+// the gathered tensor can be addressed with 32-bit element offsets (and 24-bit row multiplies): the lean loaders of gemm_body
+static bool gather_lean_ok(const RalfGemmDesc& d) {
+    const RalfConvGeom& g = d.g;
+    if (!d.gather || g.RH <= 0 || g.RW <= 0 || g.SH <= 0 || g.SW <= 0) return false;
+    const int64_t rows = d.gather == 1 ? d.M : d.K, hw = (int64_t)g.RH * g.RW;
+    const int64_t img = (int64_t)g.SH * g.SW * g.SC, src = ceil_div(rows, hw) * img + img;
+    const int tap = g.mode ? g.stride : 1;
+    bool ok = src < (1ll << 30) && (int64_t)g.SW * g.SC < (1 << 22) && g.SH < (1 << 20) && g.RH < (1 << 20) && g.KH < 1024 && g.KW < 1024 && g.stride < 1024;
+    if (d.gather == 1 && (tap & (tap - 1)) != 0) ok = false;
+    return ok;
+}
+
+// 3 x 3 / stride-1 / pad-1 convolution (forward or data gradient) on whole image rows: the patch form (gemm_impl.h GATHER 15).  The tile it takes:
+// 0 = none (the tap gather), 1 = 128 x 128, 2 = 256 x 128, 3 = 256 x 64 -- the taller tile where its halo patch fits the variant's LDS and enough tiles
+// exist to fill the chip (fewer: the 64 x 64 tap gather spreads wider).
+static int patch_variant(const RalfGemmDesc& d, int nbatch) {
+    static const int patch_on = [] { const char* e = getenv("RALF_GEMM_PATCH"); return e ? atoi(e) : 1; }();             // 0 = off (A/B runs, tests)
+    static const int min_tiles = [] { const char* e = getenv("RALF_GEMM_PATCH_TILES"); return e ? atoi(e) : 192; }();
+    const RalfConvGeom& g = d.g;
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    if (!(patch_on && d.gather == 1 && gather_lean_ok(d) && g.stride == 1 && g.KH == 3 && g.KW == 3 && g.pad == 1 && g.RH == g.SH && g.RW == g.SW && d.dtype == RALF_BF16 &&
+          d.a_kcontig && d.b_kcontig && d.splitk <= 1 && nbatch == 1 && pow2(g.SW) && g.SW <= 128 && pow2(g.SC) && g.SC >= 64 && d.K == 9 * g.SC && !d.kseg)) return 0;
+    auto fits = [&](int bm, int fn) {   // whole image rows per tile, tiles inside one image, the halo patch inside the variant's LDS
+        return bm % g.SW == 0 && (g.SH * g.SW) % bm == 0 && d.M % bm == 0 && d.N % (64 * fn) == 0 &&
+               (int64_t)(bm / g.SW + 2) * (g.SW + 2) * (2 * g.SC + 16) <= gemm_patch_bytes(fn) && (int64_t)(d.M / bm) * (d.N / (64 * fn)) >= min_tiles;
+    };
+    return fits(256, 2) ? 2 : fits(128, 2) ? 1 : fits(256, 1) ? 3 : 0;
+}
+
+extern "C" int ralf_gemm_patch_variant(const RalfGemmDesc* dp) {
+    if (!dp || dp->M <= 0 || dp->N <= 0 || dp->K <= 0) { ralf::set_error("gemm_patch_variant: bad descriptor"); return RALF_ERR_INVALID; }
+    return patch_variant(*dp, (dp->nb0 > 0 ? dp->nb0 : 1) * (dp->nb1 > 0 ? dp->nb1 : 1));
+}
+
 extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspace_bytes, void* stream) {
     RALF_REQUIRE(dp, "gemm: null descriptor");
     KParams P;
@@ -97,6 +131,16 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
             P.par = 1;
             P.fd_q.set((uint32_t)(d.M / 4)); P.fd_hw2.set((uint32_t)((g.RH / 2) * (g.RW / 2))); P.fd_rw2.set((uint32_t)(g.RW / 2));
         }
+    }
+    P.patch = lean_ok ? patch_variant(d, nbatch) : 0;   // (3 x 3 / stride 1: the tile's input patch resident in LDS, gemm_impl.h GATHER 15)
+    P.p_rows = P.p_pw = P.p_str = P.p_swsh = P.p_c8sh = 0;
+    P.fd_pw.set(1);
+    if (P.patch) {
+        const RalfConvGeom& g = d.g;
+        P.p_rows = (P.patch == 1 ? 128 : 256) / g.SW; P.p_pw = g.SW + 2; P.p_str = 2 * g.SC + 16;
+        while ((1 << P.p_swsh) < g.SW) ++P.p_swsh;
+        while ((8 << P.p_c8sh) < g.SC) ++P.p_c8sh;
+        P.fd_pw.set((uint32_t)P.p_pw);
     }
     const int ktiles = ceil_div(d.K, BK);
     if (d.splitk > ktiles) d.splitk = ktiles;

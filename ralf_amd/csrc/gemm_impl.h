@@ -97,6 +97,11 @@ struct KParams {
     // data gradient of a STRIDE-2 convolution by parity classes (GATHER 14): rows are ordered (class, image, y / 2, x / 2), class = (y & 1, x & 1)
     FastDiv fd_q, fd_hw2, fd_rw2;   // rows per class (M / 4), (RH / 2) * (RW / 2), RW / 2
     int par;                        // 1: take the parity form (set by ralf_gemm)
+    // 3 x 3 / stride-1 convolutions with the tile's input PATCH resident in LDS (GATHER 15): a 128-row tile = p_rows whole image rows
+    int patch;                      // take the patch form (set by ralf_gemm): 1 = 128 x 128 tiles, 2 = 256 x 128, 3 = 256 x 64
+    int p_rows, p_pw, p_str;        // image rows per tile (tile rows / SW), patch width in pixels (SW + 2), bytes per patch pixel (2 SC + 16)
+    int p_swsh, p_c8sh;             // log2(SW), log2(SC / 8)
+    FastDiv fd_pw;                  // p_pw
 };
 
 // virtual row (class-major order) -> class, image, pixel of the output grid
@@ -460,6 +465,12 @@ constexpr int AT_LDS_BYTES = 3 * AT_KMAX * 4;      // c1 | c2 | c3
 // GATHER 10 / 12 / 13 (round 6): the PIPELINED direct-to-LDS ring -- 3 / 4 / 2 stages, operand fragments double-buffered in registers, the k-tile's
 // one barrier in front of its LAST k-slice (gemm_body: "pipelined ring"); 11 = 10 with the tap-uniform im2col gather of A through the ring
 constexpr bool gemm_is_mt(int GATHER) { return GATHER >= 10 && GATHER <= 13; }
+// GATHER 15 (round 6): 3 x 3 / stride-1 convolution, forward or data gradient, with the tile's INPUT PATCH resident in LDS -- see gemm_body
+// LDS of a variant: the weights' ring (NST stages of [64 FN][64] k-tiles) in front of the patch.  64-column tiles (layer1: 64 channels) keep two
+// stages and a 6 x 66-pixel patch so that TWO workgroups fit a CU (a tile's reduction is nine k-tiles: prologue and epilogue want company).
+constexpr int gemm_patch_nst(int FN) { return FN == 1 ? 2 : 3; }
+constexpr int gemm_patch_ring(int FN) { return gemm_patch_nst(FN) * 64 * FN * 64 * 2; }
+constexpr int gemm_patch_bytes(int FN) { return FN == 1 ? 6 * 66 * 144 : 96 * 1024; }   // (FN >= 2: 10 x 18 pixels x 256 channels + 16 bytes per pixel = 95 040)
 template <int GATHER, int FM>
 constexpr int gemm_nbuf() { return (GATHER == 6 || GATHER == 10 || GATHER == 11) ? 3 : GATHER == 12 ? 4 : ((GATHER == 1 || GATHER == 4) && FM == 1) ? 1 : 2; }   // the prefetch-distance-1 kernels keep one buffer (GATHER 14: 128 x 128 only)
 constexpr bool gemm_is_glds(int GATHER) { return GATHER == 5 || GATHER == 6 || gemm_is_mt(GATHER); }
@@ -499,9 +510,9 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     constexpr int RVA = BM / VEC, RVB = BN / VEC;                  // vectors along rows (row-contiguous tile)
     constexpr int NT = 64 * NW, WGN = NW / WGM;                     // threads; waves along n (WGM along m)
     constexpr int WFM = FM * 2 / WGM, WFN = FN * 2 / WGN;          // 32x32 fragments per wave
-    static_assert(NW == 4 || (NW == 8 && (FN == 2 || FN == 4)), "8 waves: 2 x 4 over a 128- or 256-wide tile (or 4 x 2 over 256 x 128)");
+    static_assert(NW == 4 || (NW == 8 && (FN == 2 || FN == 4 || GATHER == 15)), "8 waves: 2 x 4 over a 128- or 256-wide tile (or 4 x 2 over 256 x 128)");
     static_assert(WFM >= 1 && WFN >= 1 && WFM * WGM == 2 * FM && WFN * WGN == 2 * FN, "the wave grid tiles the workgroup tile");
-    static_assert(WGM == 2 || (WFM == 2 && EPI != 3 && EPI != 4), "wave grids other than 2 x n: 64-row wave tiles, plain epilogues");
+    static_assert(WGM == 2 || (WFM == 2 && ((EPI != 3 && EPI != 4) || GATHER == 15)), "wave grids other than 2 x n: 64-row wave tiles, plain epilogues");
     constexpr int NVA = BM * BK / VEC / NT, NVB = BN * BK / VEC / NT;  // 16-byte vectors per thread per k-tile
     constexpr int CP = BN + 4;                                     // fp32 C staging tile [64][CP] (epilogue)
     constexpr int B_ELEMS = BKC ? BN * X::LDK : BK * LDRB;
@@ -555,6 +566,15 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     constexpr bool PAR = GATHER == 14;
     constexpr bool G1 = GATHER == 1 || PAR;
     static_assert(!PAR || (AK && BKC && FM == 2 && FN == 2 && NW == 8 && (EPI == 0 || EPI == 3)), "parity form: 128 x 128 tiles, plain / BatchNorm-backward epilogues");
+    // GATHER 15 = the tap gather of a 3 x 3 / stride-1 / pad-1 convolution (forward or data gradient) with the tile's INPUT PATCH RESIDENT IN LDS (round 6).
+    // The tile GEMM is bound by the bytes a CU takes in per flop, and the tap gather loads a 128-row tile's A operand nine
+    // times -- once per tap, shifted by a pixel.  Here a tile is 128 / SW whole image rows; their (rows + 2) x (SW + 2) halo patch, all channels,
+    // is loaded ONCE ([pixel][SC + 8] bf16: the odd 16-byte stride keeps the 32 pixels of a fragment read on distinct banks; pixels outside the
+    // image are zeros), and the A fragment of k-tile (tap, channel chunk) is read at a per-tap BYTE OFFSET from the same image.  Only the weights
+    // stream (direct-to-LDS ring, three stages): 92 + 590 KB per 128 x 128 tile of layer3 instead of 590 + 590.  Same k-tiles in the same
+    // order, same MFMA chain: bit-identical to GATHER 1.
+    constexpr bool PATCH = GATHER == 15;
+    static_assert(!PATCH || (AK && BKC && sizeof(T) == 2 && (EPI == 0 || EPI == 3) && !RALF_GEMM_PERSISTENT), "patch form: bf16, plain / BatchNorm-backward epilogues");
     uint32_t par_taps = 0;                              // the class's taps (kh * KW + kw), four bits each, in ascending order
     constexpr bool MT = gemm_is_mt(GATHER);             // ... its pipelined form (both operands k-contiguous)
     constexpr bool GLDS = gemm_is_glds(GATHER);         // direct-to-LDS ring (bf16, interior fast path, any of the four operand layouts)
@@ -635,6 +655,14 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
             for (int i = 0; i < NVB; ++i) {   // weights [N][K], K a multiple of the k-tile: a pointer per vector, rows clamped (never stored)
                 const int v = tid + NT * i;
                 pb[i] = Bp + (int64_t)min(n0 + v / KV, d.N - 1) * d.ldb + kbeg + (v % KV) * VEC;
+            }
+        }
+        if constexpr (PATCH) {   // the weights' k-tiles through the direct-to-LDS ring (the swizzled [rows][64] image of the GLDS loop)
+            static_assert(!PATCH || BN / 8 / NW == NVB, "chunk = one 16-byte vector per lane");
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                const int row = (wave * NVB + i) * 8 + (lane >> 3);
+                pb[i] = Bp + (int64_t)min(n0 + row, d.N - 1) * d.ldb + kbeg + (((lane & 7) ^ ((row >> 1) & 7)) * VEC);
             }
         }
         if constexpr (GATHER == 2) {
@@ -722,8 +750,8 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     uint32_t okm0 = ~0u, okm1 = ~0u;   // validity bits of the staged vectors of set 0 / 1 (A: bits 0.., B: bits 16..): zeroed at stage time
     auto gload = [&](u32x4 (&ra)[NVA], u32x4 (&rb)[NVB], u32x4 (&rc)[NVA], int k0, uint32_t& okm) {
         (void)rc;
-        if constexpr (GLDS) {
-            (void)ra; (void)rb; (void)k0; (void)okm;   // (the direct-to-LDS loop below issues its own loads)
+        if constexpr (GLDS || PATCH) {
+            (void)ra; (void)rb; (void)k0; (void)okm;   // (the direct-to-LDS loops below issue their own loads)
         } else if constexpr (fast) {
             (void)okm;
             if constexpr (AT2) {
@@ -1135,6 +1163,196 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
         rd(fa1, fb1, st, 3);
         mm(fa0, fb0);
         mm(fa1, fb1);
+    } else if constexpr (PATCH) {
+        const RalfConvGeom& g = d.g;
+        constexpr int NST = gemm_patch_nst(FN), STAGE = BN * BK;   // (elements)
+        unsigned char* const patch = lds_raw + gemm_patch_ring(FN);
+        auto issue = [&](int st) {
+            T* sb = la0 + st * STAGE + wave * (NVB * 512);
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb[i], LDS_PTR(void, sb + i * 512), 16, 0, 0);
+                pb[i] += BK;
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < NST; ++q) issue(q);     // (9 SC / 64 >= 9 k-tiles)
+        {   // the patch: pieces of 16 bytes, piece v = (pixel, channel octet); image rows y0t - 1 .. y0t + BM / SW, columns -1 .. SW
+            int bimg, rem;
+            P.fd_hw.divmod((uint32_t)c_m0, bimg, rem);
+            const int y0t = rem >> P.p_swsh;
+            const int c8m = (1 << P.p_c8sh) - 1, npieces = (((BM >> P.p_swsh) + 2) * P.p_pw) << P.p_c8sh;
+            const T* img = Ap + (int64_t)bimg * P.img;
+            constexpr int PU = 8;
+            for (int v0 = tid; v0 < npieces; v0 += PU * NT) {
+                u32x4 r[PU];
+                unsigned off[PU];
+                uint32_t okv = 0;
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    const int v = v0 + u * NT;
+                    const int pix = v >> P.p_c8sh, piece = v & c8m;
+                    int py, px;
+                    P.fd_pw.divmod((uint32_t)pix, py, px);
+                    const int sy = y0t + py - 1, sx = px - 1;
+                    const bool in = (v < npieces) & ((uint32_t)sy < (uint32_t)g.SH) & ((uint32_t)sx < (uint32_t)g.SW);
+                    r[u] = *reinterpret_cast<const u32x4*>(img + (in ? (sy * g.SW + sx) * g.SC + piece * 8 : 0));
+                    okv |= (uint32_t)in << u;
+                    off[u] = (unsigned)(pix * P.p_str + piece * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < PU; ++u)
+                    if (v0 + u * NT < npieces) *reinterpret_cast<u32x4*>(patch + off[u]) = sel_vec((okv >> u) & 1u, r[u]);
+            }
+        }
+        // this lane's pixel of each fragment (byte offset in the patch at tap (0, 0), channel 0) and the k-half it reads
+        unsigned pa_off[WFM];
+#pragma unroll
+        for (int i = 0; i < WFM; ++i) {
+            const int r = wm * 32 * WFM + i * 32 + l31;
+            pa_off[i] = (unsigned)(((r >> P.p_swsh) * P.p_pw + (r & (g.SW - 1))) * P.p_str + lh * 16);
+        }
+        const unsigned char* const ring8 = reinterpret_cast<const unsigned char*>(la0);
+        auto tapbase = [&](int t) -> const unsigned char* {   // the patch at k-tile t's (tap, channel chunk): a scalar byte offset
+            int tap, c0, kh, kw;
+            P.fd_sc.divmod((uint32_t)(t * BK), tap, c0);
+            P.fd_kw.divmod((uint32_t)tap, kh, kw);
+            if (g.mode) { kh = 2 - kh; kw = 2 - kw; }   // data gradient: source pixel (y + 1 - kh, x + 1 - kw)
+            return patch + (kh * P.p_pw + kw) * P.p_str + c0 * 2;
+        };
+#ifndef RALF_PATCH_ABL
+#define RALF_PATCH_ABL 0   // (lab: ablation bits -- 1 no MFMA, 2 no A reads, 4 no B reads, 8 no waits / barriers / refills; results are wrong then)
+#endif
+        auto rd = [&](bf16x8 (&fa)[WFM], bf16x8 (&fb)[WFN], const unsigned char* pa8, int st, int ks) {
+            const unsigned char* pb8 = ring8 + st * (STAGE * 2);
+            const unsigned ob = gl_offb ^ (unsigned)(ks << 5);
+            // (in the order the MFMAs want them: the first product needs fa[0] and fb[0])
+            if constexpr (!(RALF_PATCH_ABL & 2)) fa[0] = *reinterpret_cast<const bf16x8*>(pa8 + pa_off[0] + ks * 32);
+            if constexpr (!(RALF_PATCH_ABL & 4)) {
+#pragma unroll
+                for (int j = 0; j < WFN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(pb8 + ob + j * 32 * 128);
+            }
+            if constexpr (!(RALF_PATCH_ABL & 2)) {
+#pragma unroll
+                for (int i = 1; i < WFM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(pa8 + pa_off[i] + ks * 32);
+            }
+        };
+        auto mm = [&](const bf16x8 (&fa)[WFM], const bf16x8 (&fb)[WFN]) {
+            if constexpr (RALF_PATCH_ABL & 1) {
+#pragma unroll
+                for (int i = 0; i < WFM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WFN; ++j) asm volatile("" :: "v"(fa[i]), "v"(fb[j]));
+            } else {
+#pragma unroll
+            for (int i = 0; i < WFM; ++i)
+#pragma unroll
+                for (int j = 0; j < WFN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+        };
+        __syncthreads();                            // (drains the ring's first three stages and the patch writes)
+        RALF_PROBE(2);
+        if constexpr (WFM * WFN >= 4) {
+            // 64 x 64 wave tiles (four fragment reads per four MFMAs): fragments double-buffered in registers, the k-tile's one barrier in front of
+            // its LAST k-slice (the pipelined ring of GATHER 10-13, which did not pay while the loop waited for operands; here it does not)
+            bf16x8 fa0[WFM] = {}, fb0[WFN] = {}, fa1[WFM] = {}, fb1[WFN] = {};
+            const unsigned char* pa_c = tapbase(0);
+            rd(fa0, fb0, pa_c, 0, 0);
+            int st = 0, t = 0;
+            // (the scheduler is fenced at every phase boundary: left alone it pulls each fragment read down to the MFMA that consumes it -- an
+            //  `s_waitcnt lgkmcnt(0)` in front of nearly every MFMA, nothing overlapped: 40.5 k cycles per 36 k-tiles against 19.4 k of bare MFMAs)
+#define RALF_PT_FENCE __builtin_amdgcn_sched_barrier(0)
+            // one phase = the NEXT k-slice's WFM + WFN fragment reads woven into this slice's MFMAs: [MFMA, read] pairs, the rest of the MFMAs behind
+#define RALF_PT_WEAVE                                                                                   \
+            _Pragma("unroll") for (int q = 0; q < WFM + WFN; ++q) {                                    \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                      \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                      \
+            }                                                                                           \
+            __builtin_amdgcn_sched_group_barrier(0x008, WFM * WFN - (WFM + WFN) > 0 ? WFM * WFN - (WFM + WFN) : 0, 0);
+#define RALF_PT_TILE(WAIT, REFILL)                                                                      \
+            {                                                                                           \
+                const int sn = (st + 1 == NST) ? 0 : st + 1;                                            \
+                const unsigned char* pa_n = tapbase(t + 1);                                             \
+                RALF_PT_FENCE;                                                                          \
+                rd(fa1, fb1, pa_c, st, 1);                                                              \
+                mm(fa0, fb0);                                                                           \
+                RALF_PT_WEAVE                                                                           \
+                RALF_PT_FENCE;                                                                          \
+                rd(fa0, fb0, pa_c, st, 2);                                                              \
+                mm(fa1, fb1);                                                                           \
+                RALF_PT_WEAVE                                                                           \
+                RALF_PT_FENCE;                                                                          \
+                rd(fa1, fb1, pa_c, st, 3);                                                              \
+                mm(fa0, fb0);                                                                           \
+                RALF_PT_WEAVE                                                                           \
+                RALF_PT_FENCE;                                                                          \
+                WAIT;                                                                                   \
+                if constexpr (!(RALF_PATCH_ABL & 8)) lds_barrier();                                     \
+                RALF_PT_FENCE;                                                                          \
+                rd(fa0, fb0, pa_n, sn, 0);                                                              \
+                mm(fa1, fb1);                                                                           \
+                REFILL;                                                                                 \
+                _Pragma("unroll") for (int q = 0; q < WFM + WFN; ++q) {                                 \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  \
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                  \
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                  \
+                }                                                                                       \
+                RALF_PT_FENCE;                                                                          \
+                st = sn; pa_c = pa_n;                                                                   \
+            }
+            if constexpr (RALF_PATCH_ABL & 8) { for (; t + 1 < c_nt; ++t) RALF_PT_TILE((void)0, (void)0) }
+            for (; t + NST < c_nt; ++t) RALF_PT_TILE(vm_wait<NVB * (NST - 2)>(), issue(st))
+            for (; t + 1 < c_nt; ++t) {
+                const int ahead = c_nt - t - 2;   // tiles behind t + 1 that may stay in flight
+                if (NST >= 5 && ahead >= 3) RALF_PT_TILE(vm_wait<NVB * 3>(), (void)0)
+                else if (NST >= 4 && ahead >= 2) RALF_PT_TILE(vm_wait<NVB * 2>(), (void)0)
+                else if (ahead >= 1) RALF_PT_TILE(vm_wait<NVB>(), (void)0)
+                else RALF_PT_TILE(vm_wait<0>(), (void)0)
+            }
+#undef RALF_PT_TILE
+            RALF_PT_FENCE;
+            rd(fa1, fb1, pa_c, st, 1);
+            mm(fa0, fb0);
+            RALF_PT_WEAVE
+            RALF_PT_FENCE;
+            rd(fa0, fb0, pa_c, st, 2);
+            mm(fa1, fb1);
+            RALF_PT_WEAVE
+            RALF_PT_FENCE;
+            rd(fa1, fb1, pa_c, st, 3);
+            mm(fa0, fb0);
+            RALF_PT_WEAVE
+            RALF_PT_FENCE;
+            mm(fa1, fb1);
+#undef RALF_PT_FENCE
+#undef RALF_PT_WEAVE
+        } else {
+            auto compute_patch = [&](int t, int st) {
+                const unsigned char* pa8 = tapbase(t);
+#pragma unroll
+                for (int ks = 0; ks < BK / 16; ++ks) {
+                    bf16x8 a[WFM], b[WFN];
+                    rd(a, b, pa8, st, ks);
+                    mm(a, b);
+                }
+            };
+            int st = 0, t = 0;
+            for (; t + NST < c_nt; ++t) {               // steady state: tiles t+1, t+2 landed or in flight
+                compute_patch(t, st);
+                vm_wait<NVB * (NST - 2)>();
+                lds_barrier();
+                issue(st);
+                st = (st + 1 == NST) ? 0 : st + 1;
+            }
+            for (; t + 1 < c_nt; ++t) {
+                compute_patch(t, st);
+                const int ahead = c_nt - t - 2;
+                if (NST >= 5 && ahead >= 3) vm_wait<NVB * 3>(); else if (NST >= 4 && ahead >= 2) vm_wait<NVB * 2>(); else if (ahead >= 1) vm_wait<NVB>(); else vm_wait<0>();
+                lds_barrier();
+                st = (st + 1 == NST) ? 0 : st + 1;
+            }
+            compute_patch(t, st);
+        }
     } else if constexpr (GLDS) {
         // DIRECT-TO-LDS RING.  No staging registers and no ds_write: every wave issues NVA + NVB global_load_lds_dwordx4 per k-tile (1 KiB
         // each) into a ring of NST stages.  Waits are COUNTED (s_waitcnt vmcnt(N) leaves the younger tiles in flight) and the barrier is
@@ -1263,7 +1481,10 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
         // accumulate reads get the same shape.  64 tile rows per round.
         float* cs = reinterpret_cast<float*>(lds_raw);
         float* pbase = slab ? P.partial + ((int64_t)c_split * nbatch + z) * d.M * d.N : nullptr;
-        constexpr int CG = BN / 8, RPP = NT / CG;
+        // (BatchNorm-backward sums: at most 32 thread rows -- 64-column tiles on 8 waves leave half their threads out of this epilogue -- so that every
+        //  thread sums rows lr, lr + 32 and the block sum runs over 32 partials in one order whatever the tile shape)
+        constexpr int CG = BN / 8, RPP = (EPI == 3 && NT / CG > 32) ? 32 : NT / CG;
+        const bool epi_on = tid < RPP * CG;
 #pragma clang loop unroll(full)
         for (int h = 0; h < FM; ++h) {
             __syncthreads();
@@ -1285,9 +1506,11 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
             }
             __syncthreads();
             if (d.colstats) {   // BatchNorm batch statistics of this 64-row block, on the values as stored (rounded to T)
-                constexpr int CPW = BN / NW, RG = 64 / CPW;           // columns per wave, row groups per column
+                // (16 columns per wave at least -- 64-column tiles on 8 waves leave four of them idle here -- so that a column's rows are summed in the
+                //  order of the 64 x 64 / 128 x 128 tiles: the statistics do not depend on the tile shape)
+                constexpr int CPW = BN / NW < 16 ? 16 : BN / NW, RG = 64 / CPW;   // columns per wave, row groups per column
                 const int col = wave * CPW + (lane % CPW), rg = lane / CPW;
-                const int nvalid = min(64, d.M - (c_m0 + h * 64));   // <= 0: this 64-row block lies beyond M (no partial row exists)
+                const int nvalid = wave * CPW < BN ? min(64, d.M - (c_m0 + h * 64)) : 0;   // <= 0: this 64-row block lies beyond M (no partial row exists)
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll 8
                 for (int r = rg; r < nvalid; r += RG) {
@@ -1317,7 +1540,7 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
             for (int p = 0; p < 64 / RPP; ++p) {
                 const int lr = p * RPP + tid / CG, c = (tid % CG) * 8;
                 const int mv = c_m0 + h * 64 + lr;                         // (PAR: the virtual row; memory is addressed by the real one)
-                if (mv < d.M) {
+                if (mv < d.M && epi_on) {
                     const int m = PAR ? par_real_row(P, mv) : mv;
                     const float4 lo = *reinterpret_cast<const float4*>(cs + lr * CP + c), hi = *reinterpret_cast<const float4*>(cs + lr * CP + c + 4);
                     float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -1339,10 +1562,12 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                 static_assert(RPP * 2 * BN <= 64 * CP, "the partial sums reuse the C staging tile");
                 __syncthreads();
                 float* ps = cs + (tid / CG) * 2 * BN + (tid % CG) * 8;
-                *reinterpret_cast<float4*>(ps) = make_float4(bs1[0], bs1[1], bs1[2], bs1[3]);
-                *reinterpret_cast<float4*>(ps + 4) = make_float4(bs1[4], bs1[5], bs1[6], bs1[7]);
-                *reinterpret_cast<float4*>(ps + BN) = make_float4(bs2[0], bs2[1], bs2[2], bs2[3]);
-                *reinterpret_cast<float4*>(ps + BN + 4) = make_float4(bs2[4], bs2[5], bs2[6], bs2[7]);
+                if (epi_on) {
+                    *reinterpret_cast<float4*>(ps) = make_float4(bs1[0], bs1[1], bs1[2], bs1[3]);
+                    *reinterpret_cast<float4*>(ps + 4) = make_float4(bs1[4], bs1[5], bs1[6], bs1[7]);
+                    *reinterpret_cast<float4*>(ps + BN) = make_float4(bs2[0], bs2[1], bs2[2], bs2[3]);
+                    *reinterpret_cast<float4*>(ps + BN + 4) = make_float4(bs2[4], bs2[5], bs2[6], bs2[7]);
+                }
                 __syncthreads();
                 if (tid < 2 * BN && c_m0 + h * 64 < d.M) {
                     float t = 0.f;
@@ -1392,8 +1617,9 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
 }
 
 template <typename T, bool AK, bool BKC, int GATHER, int FM, int FN, int EPI, int NW = 4, int WGM = 2>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? ((GATHER == 6 || FM == 4 || gemm_at_mode(GATHER) || gemm_is_mt(GATHER)) ? 2 : 4) : 1) void gemm_kernel(const KParams P) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[gemm_lds_bytes<T, AK, BKC, FM, FN, gemm_nbuf<GATHER, FM>(), gemm_is_glds(GATHER)>() +
+__global__ __launch_bounds__(64 * NW, (GATHER == 15 && FN == 1) ? 2 : NW == 8 ? (GATHER == 15 ? 1 : (GATHER == 6 || FM == 4 || gemm_at_mode(GATHER) || gemm_is_mt(GATHER)) ? 2 : 4) : 1) void gemm_kernel(const KParams P) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[GATHER == 15 ? gemm_patch_ring(FN) + gemm_patch_bytes(FN) :
+                                                                  gemm_lds_bytes<T, AK, BKC, FM, FN, gemm_nbuf<GATHER, FM>(), gemm_is_glds(GATHER)>() +
                                                                   (gemm_at_mode(GATHER) ? AT_LDS_BYTES : 0)];   // ONE LDS object (+ the operand transform's coefficient table)
     gemm_body<T, AK, BKC, GATHER, FM, FN, EPI, NW, false, WGM>(P, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z, (int)gridDim.z, lds_raw);
 }
@@ -1744,7 +1970,7 @@ int launch(KParams& P, int nbatch, hipStream_t st) {
     // column tiles fastest.  A few hundred queries x a 220 MB index (the two-stage k-NN's coarse pass): with column tiles fastest every XCD
     // owned one row tile and streamed the WHOLE index (8 x 220 MB per call: 390 us); row tiles fastest keeps the 3.7 MB of queries resident
     // and streams every index row once.
-    P.mfast = (AK && BKC && GATHER != 1 && GATHER != 4 && GATHER != 14 && nbatch == 1 && P.d.splitk == 1 && !P.d.kseg && (int64_t)P.d.M * 4 <= (int64_t)P.d.N) ? 1 : 0;
+    P.mfast = (AK && BKC && GATHER != 1 && GATHER != 4 && GATHER != 14 && GATHER != 15 && nbatch == 1 && P.d.splitk == 1 && !P.d.kseg && (int64_t)P.d.M * 4 <= (int64_t)P.d.N) ? 1 : 0;
     P.tiles_n = ceil_div(P.d.N, 64 * FN);
     P.nwg = P.tiles_m * P.tiles_n;
     constexpr bool persist = RALF_GEMM_PERSISTENT != 0;   // off: measured -4...+6 % (the prefetch across the epilogue costs a wave of occupancy)
@@ -1861,6 +2087,15 @@ int dispatch(KParams& P, int nbatch, hipStream_t st) {
             if (P.tapuni && P.par && plain && gemm_use128(d, nbatch)) {
                 if (d.bnb_part) return launch<T, true, true, 14, 2, 2, 3, 8>(P, nbatch, st);
                 return launch<T, true, true, 14, 2, 2, 0, 8>(P, nbatch, st);
+            }
+        }
+        if constexpr (sizeof(T) == 2) {   // 3 x 3 / stride 1: the tile's input patch resident in LDS (gemm_body GATHER 15; ralf_gemm picked the tile)
+            const bool plain = !d.flt_list && !d.C2 && d.act != RALF_ACT_GELU && d.aux_mode != RALF_AUX_GELU_GRAD && !d.atomic_out && d.drop_p == 0.f && !d.aux;
+            if (P.tapuni && P.patch && plain && P.vec_epi >= 2) {
+                const bool bnb = d.bnb_part != nullptr;
+                if (P.patch == 1) return bnb ? launch<T, true, true, 15, 2, 2, 3, 8>(P, nbatch, st) : launch<T, true, true, 15, 2, 2, 0, 8>(P, nbatch, st);
+                if (P.patch == 2) return bnb ? launch<T, true, true, 15, 4, 2, 3, 8, 4>(P, nbatch, st) : launch<T, true, true, 15, 4, 2, 0, 8, 4>(P, nbatch, st);
+                return bnb ? launch<T, true, true, 15, 4, 1, 3, 8, 4>(P, nbatch, st) : launch<T, true, true, 15, 4, 1, 0, 8, 4>(P, nbatch, st);
             }
         }
         if (P.tapuni) return launch_cfg<T, true, true, 1>(P, nbatch, st);

@@ -80,6 +80,20 @@ def gemm_filter_tile(M: int, N: int, K: int) -> int:
     return w
 
 
+def gemm_patch_variant(M: int, N: int, K: int, conv: dict, dtype=torch.bfloat16) -> int:
+    """the form ralf_gemm takes for this gather = 1 convolution product: 0 = tap gather, 1 / 2 / 3 = input patch resident in LDS on 128 x 128 / 256 x 128 /
+    256 x 64 tiles (ralf_gemm_patch_variant)"""
+    d = RalfGemmDesc()
+    d.M, d.N, d.K, d.dtype, d.splitk, d.nb0, d.nb1 = M, N, K, _TORCH2CODE[dtype], 1, 1, 1
+    d.a_kcontig = d.b_kcontig = 1
+    d.lda = d.ldb = K
+    d.gather = 1
+    d.g = RalfConvGeom(**conv)
+    v = _lib.lib().ralf_gemm_patch_variant(ctypes.byref(d))
+    _lib.check(min(v, 0), "ralf_gemm_patch_variant")
+    return v
+
+
 def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kcontig=True, b_kcontig=True,
          lda=None, ldb=None, out: Optional[torch.Tensor] = None, ldc=None, out_dtype=None,
          bias=None, act=None, res=None, ldr=None, aux=None, aux_mode=None, aux_scale=1.0, out2=None,

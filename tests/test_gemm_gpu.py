@@ -482,6 +482,78 @@ def test_direct_to_lds_kernels_are_bit_identical_to_register_staged(tmp_path):
     assert torch.isfinite(x.float()).all() and x.float().abs().max() > 0.1
 
 
+_PATCH_CASES = """
+import sys, torch
+sys.path.insert(0, {root!r})
+from ralf_amd import ops
+dt = torch.bfloat16
+out = {{}}
+for (B, H, C) in [(16, 64, 64), (64, 32, 128), (32, 32, 128), (64, 16, 256), (2, 16, 256)]:
+    M = B * H * H
+    g = torch.Generator(device="cuda").manual_seed(H + B)
+    x = torch.randn(M, C, device="cuda", generator=g).to(dt)
+    w = (torch.randn(C, 3, 3, C, device="cuda", generator=g) * 0.05).to(dt)
+    bias = torch.randn(C, device="cuda", generator=g)
+    skip = torch.randn(M, C, device="cuda", generator=g).to(dt)
+    xa = torch.randn(M, C, device="cuda", generator=g).to(dt)
+    mean = torch.randn(C, device="cuda", generator=g)
+    bits = torch.randint(0, 256, (M * C // 8,), device="cuda", dtype=torch.uint8, generator=g)
+    gf = dict(RH=H, RW=H, SH=H, SW=H, SC=C, KH=3, KW=3, stride=1, pad=1, mode=0)
+    gd = dict(gf, mode=1)
+    st = torch.full(((M + 63) // 64, 2, C), float("nan"), device="cuda")
+    part = torch.full(((M + 63) // 64, 2, C), float("nan"), device="cuda")
+    k = (B, H, C)
+    out[k + ("variant",)] = torch.tensor([ops.gemm_patch_variant(M, C, 9 * C, conv=gf), ops.gemm_patch_variant(M, C, 9 * C, conv=gd)])
+    out[k + ("fwd",)] = ops.gemm(x, w, M, C, 9 * C, conv=gf, gather=1, colstats=st)
+    out[k + ("fwd_stats",)] = st
+    out[k + ("fwd_eval",)] = ops.gemm(x, w, M, C, 9 * C, conv=gf, gather=1, bias=bias, act="relu")
+    out[k + ("dgrad",)] = ops.gemm(x, w, M, C, 9 * C, conv=gd, gather=1, res=skip)
+    out[k + ("dgrad_bnb",)] = ops.gemm(x, w, M, C, 9 * C, conv=gd, gather=1, res=skip, bnb=(xa, bits, mean, part))
+    out[k + ("dgrad_bnb_part",)] = part
+torch.cuda.synchronize()
+torch.save({{k: v.cpu() for k, v in out.items()}}, {path!r})
+"""
+
+
+def test_conv3x3_with_the_input_patch_in_lds_is_bit_identical_to_the_tap_gather(tmp_path):
+    """3 x 3 / stride-1 convolutions (timm Bottleneck.conv2 of layer1..3, common/image.py:39-48) take the patch form (gemm_impl.h GATHER 15: the tile's
+    halo patch resident in LDS, only the weights stream) where whole image rows make a tile and enough tiles exist: 256 x 64 tiles (layer1), 256 x 128
+    (layer2 at B = 64), 128 x 128 (layer2 at B = 32, layer3); RALF_GEMM_PATCH=0 (read once per process) keeps the tap gather.  Same k-tiles in the same
+    order on the same MFMA chain: forward with column statistics, the eval form (bias + ReLU), data gradient with a skip gradient, data gradient with
+    the BatchNorm-backward epilogue -- the same bits.  The smallest case (B = 2) has too few tiles and stays on the tap gather in both runs."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for flag in ("1", "0"):
+        path = str(tmp_path / f"patch{flag}.pt")
+        r = subprocess.run([sys.executable, "-c", _PATCH_CASES.format(root=root, path=path)], env=dict(os.environ, RALF_GEMM_PATCH=flag),
+                           capture_output=True, text=True, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        res[flag] = torch.load(path)
+    want = {(16, 64, 64): 3, (64, 32, 128): 2, (32, 32, 128): 1, (64, 16, 256): 1, (2, 16, 256): 0}
+    for k, v in want.items():
+        assert res["1"][k + ("variant",)].tolist() == [v, v] and res["0"][k + ("variant",)].tolist() == [0, 0], k
+    for k in res["1"]:
+        if k[-1] != "variant":
+            assert torch.equal(res["1"][k], res["0"][k]), k
+    # ... and the convolution itself against torch (one case per variant, forward and data gradient)
+    for (B, H, C) in [(16, 64, 64), (64, 32, 128), (64, 16, 256)]:
+        M = B * H * H
+        g = torch.Generator(device="cuda").manual_seed(H + B)   # (the subprocess's operands: x, w, bias, skip in its order)
+        x = torch.randn(M, C, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(C, 3, 3, C, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+        torch.randn(C, device="cuda", generator=g)
+        skip = torch.randn(M, C, device="cuda", generator=g).to(torch.bfloat16)
+        xi = x.float().view(B, H, H, C).permute(0, 3, 1, 2)
+        y = F.conv2d(xi, w.float().permute(0, 3, 1, 2), None, 1, 1).permute(0, 2, 3, 1).reshape(M, C)               # weights [co][kh][kw][ci]
+        torch.testing.assert_close(res["1"][(B, H, C, "fwd")].float(), y.cpu(), atol=6e-2, rtol=2e-2)
+        dx = F.conv_transpose2d(xi, w.float().permute(3, 0, 1, 2), None, 1, 1).permute(0, 2, 3, 1).reshape(M, C)   # weights [ci][kh][kw][co]
+        torch.testing.assert_close(res["1"][(B, H, C, "dgrad")].float(), (dx + skip.float()).cpu(), atol=6e-2, rtol=2e-2)
+
+
 # ---- operand transform with write-through (RalfGemmDesc.at_*): BatchNorm apply / backward apply inside the loader of a 1x1 convolution ----
 @pytest.mark.parametrize("M,K,N,res", [(4096 + 40, 256, 64, True), (4096, 512, 128, True), (8192 + 8, 64, 256, False), (2048, 128, 512, False), (2048, 256, 1024, False)])
 def test_operand_transform_forward_equals_bn_apply_then_product(M, K, N, res):
