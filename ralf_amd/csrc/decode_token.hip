@@ -185,16 +185,13 @@ __device__ unsigned long long ralf_dt_probe[256];
 #define DT_STAMP(i)
 #endif
 
-__global__ __launch_bounds__(NT) void decode_token_kernel(const RalfDecodeTokenDesc d, const int stagger) {
+__global__ __launch_bounds__(NT) void decode_token_kernel(const RalfDecodeTokenDesc d) {
     __shared__ Lds L;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
-    // Every workgroup walks the same phases at the same pace, so all of them ask HBM for the memory keys / values at once (that phase runs AT the
-    // HBM rate) and the L2 for the weights at once.  Every second workgroup of an XCD therefore starts `stagger` clock ticks late: its
-    // HBM phases fall into the others' weight phases.
-    if (stagger > 0 && ((b >> 3) & 1)) {
-        const uint64_t t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)stagger) __builtin_amdgcn_s_sleep(32);
-    }
+    // (every workgroup walks the same phases at the same pace, so all of them ask HBM for the memory keys / values at once and the L2 for the weights at
+    //  once.  Starting every second workgroup of an XCD late -- its HBM phases inside the others' weight phases -- was measured: 297.6 us per token
+    //  without, 286.5 / 292.5 / 290.7 / 305 with 20 / 35 / 50 / 65 k cycles of delay (profiles/r06_decode_stagger.txt): the delay costs what the
+    //  interleaving gains, not kept.)
     const int pos = d.pos_vec ? d.pos_vec[b] : d.pos;             // this element's position = its number of cached rows
     const uint8_t* kpm = d.kpm ? d.kpm + (int64_t)b * d.kpm_bs : nullptr;
     const float scale = 0.17677669529663687f;                     // 32^-0.5
@@ -393,9 +390,7 @@ extern "C" int ralf_decode_token(const RalfDecodeTokenDesc* dp, void* stream) {
         RALF_REQUIRE((((uintptr_t)w.w_qkv | (uintptr_t)w.w_o1 | (uintptr_t)w.w_q2 | (uintptr_t)w.w_o2 | (uintptr_t)w.w_f1 | (uintptr_t)w.w_f2 | (uintptr_t)w.self_kv | (uintptr_t)w.cross_kv) & 15) == 0,
                      "decode_token: layer %d: weights and caches must be 16-byte aligned", i);
     }
-    static const int stagger_env = [] { const char* e = getenv("RALF_DECODE_STAGGER"); return e ? atoi(e) : 0; }();
-    const int stagger = d.B > 128 ? stagger_env : 0;
-    hipLaunchKernelGGL(decode_token_kernel, dim3(d.B), dim3(NT), 0, (hipStream_t)stream, d, stagger);
+    hipLaunchKernelGGL(decode_token_kernel, dim3(d.B), dim3(NT), 0, (hipStream_t)stream, d);
     return ralf::check_launch("decode_token");
 }
 

@@ -567,12 +567,20 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
     constexpr bool G1 = GATHER == 1 || PAR;
     static_assert(!PAR || (AK && BKC && FM == 2 && FN == 2 && NW == 8 && (EPI == 0 || EPI == 3)), "parity form: 128 x 128 tiles, plain / BatchNorm-backward epilogues");
     // GATHER 15 = the tap gather of a 3 x 3 / stride-1 / pad-1 convolution (forward or data gradient) with the tile's INPUT PATCH RESIDENT IN LDS (round 6).
-    // The tile GEMM is bound by the bytes a CU takes in per flop, and the tap gather loads a 128-row tile's A operand nine
-    // times -- once per tap, shifted by a pixel.  Here a tile is 128 / SW whole image rows; their (rows + 2) x (SW + 2) halo patch, all channels,
-    // is loaded ONCE ([pixel][SC + 8] bf16: the odd 16-byte stride keeps the 32 pixels of a fragment read on distinct banks; pixels outside the
-    // image are zeros), and the A fragment of k-tile (tap, channel chunk) is read at a per-tap BYTE OFFSET from the same image.  Only the weights
-    // stream (direct-to-LDS ring, three stages): 92 + 590 KB per 128 x 128 tile of layer3 instead of 590 + 590.  Same k-tiles in the same
-    // order, same MFMA chain: bit-identical to GATHER 1.
+    // The tile GEMM is bound by the bytes a CU takes in per flop, and the tap gather loads a tile's A operand nine times -- once
+    // per tap, shifted by a pixel.  Here a tile is BM / SW whole image rows; their (rows + 2) x (SW + 2) halo patch, all channels, is loaded ONCE
+    // ([pixel][SC + 8] bf16: the odd 16-byte stride keeps the pixels of a fragment read on distinct banks; pixels outside the image are zeros), and
+    // the A fragment of k-tile (tap, channel chunk) is read at a per-tap BYTE OFFSET from the same image.  Only the weights stream (direct-to-LDS
+    // ring): 92 + 590 KB per 128 x 128 tile of layer3 instead of 590 + 590.  Same k-tiles in the same order, same MFMA chain: bit-identical to
+    // GATHER 1.  Tiles (ralf_gemm picks, P.patch): 128 x 128 on 8 waves of 64 x 32 (layer3; layer2 at small batch), 256 x 128 on 4 x 2 waves of
+    // 64 x 64 with the fragments double-buffered in registers (layer2), 256 x 64 on 4 x 2 waves of 64 x 32 with TWO workgroups per CU (layer1: nine
+    // k-tiles per tile -- prologue and epilogue want company).
+    // MEASURED (tools/lab/patch_lab.hip, profiles/r06_patch_lab.txt; B = 64): layer1 42.7 -> 31.5 us, layer2 30.4 -> 25.8, layer3 33.0 -> 28.5.  What
+    // bounds it now (cycle stamps of layer3, 56 k cycles per tile): the patch prologue -- 95 KB per CU, every CU at once, ~10 k cycles (the chip's
+    // ~11 B/clk/CU prologue burst) --, 36 k-tiles at ~1 100 cycles each against 540 of bare MFMAs, the epilogue 4-6 k.  The k-tile's cost is additive:
+    // + 240 cycles for the 16 fragment reads (the LDS array's own 4 cycles per ds_read_b128 and wave), + 240 for the wait / barrier / four LDS-DMA
+    // issues, whether the loop is the plain one, fenced phase by phase or woven [MFMA, read] by sched_group_barrier (all within 3 %); a deeper
+    // ring (4 stages) changes nothing (not load latency), 128 x 128 on 4 waves of 64 x 64 is no faster than 8 waves of 64 x 32.
     constexpr bool PATCH = GATHER == 15;
     static_assert(!PATCH || (AK && BKC && sizeof(T) == 2 && (EPI == 0 || EPI == 3) && !RALF_GEMM_PERSISTENT), "patch form: bf16, plain / BatchNorm-backward epilogues");
     uint32_t par_taps = 0;                              // the class's taps (kh * KW + kw), four bits each, in ascending order
