@@ -1,6 +1,7 @@
 """B = 256 constrained decode (task c, argmax) a few times -- for rocprofv3 timelines: python3 tools/decode_once.py [reps] [bfloat16|float32]"""
 import os
 import sys
+import time
 
 import torch
 
@@ -22,6 +23,7 @@ dec = GraphedDecode(model, "c", cfg, True)
 for _ in range(reps):
     res = model.sample(cond=cond, sampling_cfg=cfg, cond_type="c", decoder=dec)
 torch.cuda.synchronize()
+time.sleep(0.25)   # (an idle gap in front of the last replay: tools/prof_sequence.py lists the dispatches behind it)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 dec._graph.replay()
