@@ -227,7 +227,7 @@ def test_b64_gradients_bf16_against_fp32_on_trained_weights_with_the_autocast_ya
         if ".body." in k:
             # a single tensor's cosine moves by +-0.2 between runs (the 400 steps are not bit-reproducible: fp32 atomics): tensor by tensor the
             # HIP path may fall short of the yardstick by that much and no more.  The norm ratio of the two shallowest tensors is a noisy number
-            # too: seven runs of one build gave 0.84 ... 1.36 for the stem and 0.92 ... 1.23 for layer1.0.conv1 (gpurun_out/yard_ab.txt, round 6; the
+            # too: seven runs of one build gave 0.84 ... 1.36 for the stem and 0.92 ... 1.23 for layer1.0.conv1 (profiles/r06_yardstick_run_to_run.txt; the
             # kernels in between are bit-identical, tools/lab/patch_step_check.py), +-5 % for the deeper ones
             shallow = k.endswith("body.conv1.weight") or ".layer1." in k
             assert ch > cy - 0.25 and (0.7 < rh < 1.5 if shallow else 0.85 < rh < 1.15), (k, ch, cy, rh)
