@@ -185,6 +185,13 @@ __device__ unsigned long long ralf_dt_probe[256];
 #define DT_STAMP(i)
 #endif
 
+#ifndef DT_KV_LOAD
+// the memory keys / values are read once per token: streaming loads.  Plain loads let the 848 MB per token sweep the weights out of the L2 (350.9 us per
+// token against 297.8); with all six layers pointed at ONE cache (141 MB: infinity-cache resident) the K / V passes take the same cycles as from HBM
+// (tools/lab/decode_token_lab.hip LAB_SHARE_KV, profiles/r06_decode_kv_source.txt) -- the phase is bound by the rate at which a CU takes the rows
+// in, wherever they come from; only fewer bytes would shorten it.
+#define DT_KV_LOAD(p) __builtin_nontemporal_load(p)
+#endif
 __global__ __launch_bounds__(NT) void decode_token_kernel(const RalfDecodeTokenDesc d) {
     __shared__ Lds L;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(NT) void decode_token_kernel(const RalfDecodeTokenD
         const bf16* Vb = Kb + (int64_t)4 * M * 64;
         auto ldkv = [&](bf16x8 (&r)[8], const bf16* base, int k0) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) r[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + (int64_t)min(k0 + 16 * u, M - 1) * 64));
+            for (int u = 0; u < 8; ++u) r[u] = DT_KV_LOAD(reinterpret_cast<const bf16x8*>(base + (int64_t)min(k0 + 16 * u, M - 1) * 64));
         };
         bf16x8 ka[8], kb[8];
         ldkv(ka, Kb, kstart);

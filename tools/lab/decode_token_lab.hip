@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
         w.w_q2 = dalloc(256 * 256 * 2, 1); w.b_q2 = (const float*)dalloc(1024, 0); w.w_o2 = dalloc(256 * 256 * 2, 1); w.b_o2 = (const float*)dalloc(1024, 0);
         w.ln3_g = (const float*)dalloc(1024, 2); w.ln3_b = (const float*)dalloc(1024, 0); w.w_f1 = dalloc(1024 * 256 * 2, 1); w.b_f1 = (const float*)dalloc(4096, 0);
         w.w_f2 = dalloc(256 * 1024 * 2, 1); w.b_f2 = (const float*)dalloc(1024, 0);
-        w.self_kv = dalloc((size_t)B * L * 512 * 2, 1); w.cross_kv = dalloc((size_t)B * 8 * M * 64 * 2, 1);
+        w.self_kv = dalloc((size_t)B * L * 512 * 2, 1); w.cross_kv = (getenv("LAB_SHARE_KV") && i > 0) ? d.layer[0].cross_kv : dalloc((size_t)B * 8 * M * 64 * 2, 1);   // LAB_SHARE_KV=1: one K / V cache for all layers (infinity-cache resident)
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int r = 0; r < 3; ++r) if (ralf_decode_token(&d, nullptr)) { printf("launch failed\n"); return 1; }
