@@ -236,3 +236,24 @@ def test_b64_gradients_bf16_against_fp32_on_trained_weights_with_the_autocast_ya
             assert ch > 0.999 and ch > cy - 2e-4 and abs(rh - 1) < 0.06, (k, ch, cy, rh)
     med = lambda v: sorted(v)[len(v) // 2]
     assert med(body_h) > med(body_y) - 0.08 and med(body_h) > 0.15, (sorted(body_h), sorted(body_y))
+
+
+def test_patch_form_convolutions_leave_the_captured_step_bit_identical(tmp_path):
+    """BASELINE's batch (B = 64, 256 x 256, N = 10, bf16) through four captured steps with lr = 0 (hipGraph, weight gradients on the side stream, dropout
+    on): the gradients of every weight matrix of the ResNet body are the SAME BITS with the 3 x 3 convolutions on the patch form (default) and on the
+    tap gather (RALF_GEMM_PATCH=0, read once per process) -- the kernel-level identity of tests/test_gemm_gpu.py holds inside the model, under capture
+    and concurrency.  (Bias / LayerNorm-parameter gradients and the loss are summed with fp32 atomics and differ from run to run of ONE setting;
+    tools/lab/patch_step_check.py prints the comparison.)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / "grads.pt")
+    outs = []
+    for flag in ("0", "1"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "lab", "patch_step_check.py"), path, "4"], env=dict(os.environ, RALF_GEMM_PATCH=flag),
+                           capture_output=True, text=True, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs.append(r.stdout)
+    assert "saved" in outs[0] and "differing backbone-body tensors: 0" in outs[1], outs
