@@ -2052,7 +2052,7 @@ int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
         static const int glds = [] { const char* e = getenv("RALF_GEMM_GLDS"); return e ? atoi(e) : 1; }();   // 0: off (A/B runs, tests)
         if (glds && use128 && !d.kseg && !d.bnb_part && !forced) {
             // 256 x 256 tiles (8 waves of 128 x 64, two 64-KiB stages) where at least ~1.5 of them exist per CU and the reduction is long: the operand
-            // feed of a CU tops out at ~20-23 B/clk whatever the loop looks like (profiles/r06_gemm_feed_limit.txt), i.e. a tile's flops per loaded
+            // feed of a CU tops out at ~20-23 B/clk whatever the loop looks like (profiles/r06_gemm_lab_2.txt, r06_l2_feed_bench.txt), i.e. a tile's flops per loaded
             // byte set the rate -- 8192^3: 929 -> 1167 TFLOP/s, the two-stage k-NN's coarse pass (1024 x 61548 x 1792): 266 -> 230 us.  Plain
             // epilogues only (the model's own products have too few such tiles: they lose on 256-row tiles, tools/gemm_lab.hip).
             static const int t256 = [] { const char* e = getenv("RALF_GEMM_TILE256"); return e ? atoi(e) : 400; }();   // tiles needed; 0 = off
