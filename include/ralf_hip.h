@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 24
+#define RALF_ABI_VERSION 25
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -468,6 +468,15 @@ typedef struct RalfDecodeTokenDesc {
     int B, L, M, V, nlayers, pos;
     float emb_scale, eps;
     RalfDecodeTokenLayer layer[RALF_DECODE_TOKEN_MAX_LAYERS];
+    /* optional (ABI 25; s_out != NULL): the token choice of ralf_mask_sample_step on this step's logits in the SAME launch -- one wave per sample runs the
+     * same function on the same values (helpers/sampling.py: deterministic / top_k / top_p / random / gumbel; retrieval_augmented_autoreg.py:280-300).
+     * Arguments as ralf_mask_sample_step's: allowed uint8 [V], forced int64 [B] or NULL, seed, call id, out int64 [B] (may be `tok`: a workgroup
+     * reads its element at the start and writes it at the end), the sequence / pad-flag columns with their strides, pad id, row0.  V <= 1024. */
+    const uint8_t* s_allowed; const int64_t* s_forced; const int64_t* s_seed; int64_t* s_out; int64_t* s_seq_out; uint8_t* s_flag_out;
+    int64_t s_seq_ld, s_flag_ld, s_pad_id;
+    uint64_t s_call;
+    int s_mode, s_top_k, s_row0;
+    float s_temperature, s_top_p;
 } RalfDecodeTokenDesc;
 int ralf_decode_token(const RalfDecodeTokenDesc* d, void* stream);
 int ralf_decode_token_limits(int* max_self_rows, int* max_memory_rows);   /* most cached positions (L) and memory rows (M) ralf_decode_token takes */

@@ -42,7 +42,9 @@ class RalfDecodeTokenLayer(ctypes.Structure):
 
 class RalfDecodeTokenDesc(ctypes.Structure):
     _fields_ = ([(n, vp) for n in ("tok", "pos_vec", "kpm", "emb", "pe", "lnh_g", "lnh_b", "w_head", "logits")] + [("kpm_bs", i64)]
-                + [(n, i32) for n in ("B", "L", "M", "V", "nlayers", "pos")] + [("emb_scale", f32), ("eps", f32)] + [("layer", RalfDecodeTokenLayer * 8)])
+                + [(n, i32) for n in ("B", "L", "M", "V", "nlayers", "pos")] + [("emb_scale", f32), ("eps", f32)] + [("layer", RalfDecodeTokenLayer * 8)]
+                + [(n, vp) for n in ("s_allowed", "s_forced", "s_seed", "s_out", "s_seq_out", "s_flag_out")] + [(n, i64) for n in ("s_seq_ld", "s_flag_ld", "s_pad_id")]
+                + [("s_call", ctypes.c_uint64)] + [(n, i32) for n in ("s_mode", "s_top_k", "s_row0")] + [("s_temperature", f32), ("s_top_p", f32)])
 
 
 class RalfTLayerDesc(ctypes.Structure):

@@ -16,6 +16,7 @@
 // layer in bf16; accumulation, softmax and logits in fp32), summation orders differ: bf16 throughput mode only (the fp32 parity mode keeps the
 // per-kernel path).  d = 256, 8 heads, feed-forward 1024, <= 8 layers, <= 64 self-attention keys, <= DT_MAXM memory rows.
 #include "common.h"
+#include "sample_core.h"
 
 namespace {
 typedef __bf16 bf16;
@@ -74,6 +75,7 @@ __device__ __forceinline__ void gemv_epi(int r, float a, float bias, Lds& L, bf1
         L.hb2[r] = (bf16)fmaxf(a + bias, 0.f);
     } else {
         logits[r] = a;
+        L.y[r] = a;                            // (the in-kernel token choice reads the row from LDS: V <= 1024)
     }
 }
 // the 32-lane sums of EIGHT values per lane in 14 cross-lane steps instead of 8 x 5: each level halves the values a lane keeps (its partner
@@ -379,6 +381,16 @@ __global__ __launch_bounds__(NT) void decode_token_kernel(const RalfDecodeTokenD
     // ---- head: logits = Wh LN(x) (fp32, no bias) ----
     layer_norm(gh, bh, d.eps, L, tid);
     gemv<256, EPI_LOGITS>((const bf16*)d.w_head, nullptr, d.V, L, tid, nullptr, d.logits + (int64_t)b * d.V);
+    // ---- optional: the token choice of ralf_mask_sample_step on this row, by one wave, from the logits in LDS (the same function on the same values) ----
+    if (d.s_out && wv == 0) {
+        auto emit = [&](int64_t tok) {
+            d.s_out[b] = tok;
+            if (d.s_seq_out) d.s_seq_out[(int64_t)b * d.s_seq_ld] = tok;
+            if (d.s_flag_out) d.s_flag_out[(int64_t)b * d.s_flag_ld] = tok == d.s_pad_id ? 1 : 0;
+        };
+        sample_core::mask_sample_row(L.y, d.s_allowed, d.s_forced ? d.s_forced[b] : -1, d.s_mode, d.s_top_k, d.s_temperature, d.s_top_p, d.s_seed, d.s_call,
+                                     (uint64_t)b + (uint64_t)d.s_row0, d.V, lane, emit);
+    }
 }
 }  // namespace
 
@@ -396,6 +408,12 @@ extern "C" int ralf_decode_token(const RalfDecodeTokenDesc* dp, void* stream) {
                      w.w_f1 && w.b_f1 && w.w_f2 && w.b_f2 && w.self_kv && w.cross_kv, "decode_token: layer %d: null pointer", i);
         RALF_REQUIRE((((uintptr_t)w.w_qkv | (uintptr_t)w.w_o1 | (uintptr_t)w.w_q2 | (uintptr_t)w.w_o2 | (uintptr_t)w.w_f1 | (uintptr_t)w.w_f2 | (uintptr_t)w.self_kv | (uintptr_t)w.cross_kv) & 15) == 0,
                      "decode_token: layer %d: weights and caches must be 16-byte aligned", i);
+    }
+    if (d.s_out) {
+        RALF_REQUIRE(d.V <= DT_MAXM, "decode_token: the in-kernel token choice keeps the row's logits in LDS (V = %d <= %d)", d.V, DT_MAXM);
+        RALF_REQUIRE(d.s_mode >= 0 && d.s_mode <= 4 && (d.s_mode == 0 || (d.s_seed && d.s_temperature > 0.f)) && (d.s_mode != 1 || d.s_top_k >= 1) &&
+                     (d.s_mode != 2 || (d.s_top_p > 0.f && d.s_top_p <= 1.f)) && (!d.s_seq_out || d.s_seq_ld > 0) && (!d.s_flag_out || d.s_flag_ld > 0),
+                     "decode_token: token choice arguments (ralf_mask_sample_step's rules)");
     }
     hipLaunchKernelGGL(decode_token_kernel, dim3(d.B), dim3(NT), 0, (hipStream_t)stream, d);
     return ralf::check_launch("decode_token");

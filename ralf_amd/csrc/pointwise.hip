@@ -10,6 +10,7 @@
 //   task_emb flag add                                            retrieval_augmented_autoreg.py:1022-1028
 //   ResnetBackbone max-pool / F.interpolate(nearest)            common/image.py:66-67,103-105
 #include "common.h"
+#include "sample_core.h"
 
 namespace {
 typedef __bf16 bf16;
@@ -17,21 +18,9 @@ typedef __bf16 bf16;
 template <typename T> __device__ __forceinline__ float ld(const T* p, int64_t i) { return (float)p[i]; }
 template <typename T> __device__ __forceinline__ void st(T* p, int64_t i, float v) { p[i] = (T)v; }
 
-__device__ __forceinline__ float wave_sum(float v) {
-    return wave::sum64_desc(v);   // the descending butterfly, bit for bit, without the LDS crossbar (wave_ops.h)
-}
-__device__ __forceinline__ float wave_max(float v) {
-    return wave::max64(v);
-}
-
-// stateless counter-based RNG: 24 uniform bits from (seed, stream id, element index)
-__device__ __forceinline__ uint32_t rng24(uint64_t seed, uint64_t call, uint64_t idx) {
-    uint64_t z = seed + call * 0x9E3779B97F4A7C15ull + idx * 0xD1B54A32D192ED03ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (uint32_t)(z >> 40);
-}
+using sample_core::rng24;
+using sample_core::wave_max;
+using sample_core::wave_sum;
 
 inline int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
     int64_t b = (n + per_block - 1) / per_block;
@@ -543,16 +532,7 @@ __global__ void upsample_bwd_kernel(const T* __restrict__ g1, int64_t ld1, const
     }
 }
 
-// per-row decode-space mask + token choice (one wave per row of fp32 logits [B,V]):
-//   allowed[c] == 0 -> -inf (tokenizer.token_mask row);  forced[b] >= 0 -> that token is the only candidate
-//   mode 0: argmax (first maximum);  mode 1: keep logits >= k-th largest, softmax(x/T), one multinomial draw
-//   with the counter-based generator (inverse CDF in lane-major order);
-//   mode 2 (top_p, helpers/sampling.py:35-58): with the candidates sorted by descending logit, those whose INCLUSIVE cumulative probability exceeds
-//           top_p are removed, the first always stays -- without a sort: the kept set is {x >= t} for the smallest t whose tail mass
-//           S(t) = sum of p over {x >= t} is <= top_p (the reference's cumulative sum at an element is S(its logit)), found by bisection over the
-//           ORDERED BIT PATTERNS of fp32 (32 steps of a masked wave sum), united with the arg-max; equal logits are kept or dropped together;
-//   mode 3 (random): softmax(x/T) over all candidates;  mode 4 (gumbel): x/T - log(-log(u + 1e-30) + 1e-30) with a counter-based u per candidate,
-//           then the same softmax + draw (as the reference does).
+// per-row decode-space mask + token choice (one wave per row of fp32 logits [B,V]): sample_core.h mask_sample_row
 __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ allowed,
                                                            const int64_t* __restrict__ forced, int mode, int top_k, float temperature, float top_p,
                                                            const int64_t* __restrict__ seed, uint64_t call, int64_t* __restrict__ out, int B, int V,
@@ -560,116 +540,13 @@ __global__ __launch_bounds__(256) void mask_sample_kernel(const float* __restric
                                                            int row0) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
-    const uint64_t rrow = (uint64_t)row + (uint64_t)row0;   // the row's number in the WHOLE batch: a batch decoded in slices draws what the unsplit call draws
     auto emit = [&](int64_t tok) {   // lane 0: the token, its column of the sequence buffer, its key-padding flag
         out[row] = tok;
         if (seq_out) seq_out[(int64_t)row * seq_ld] = tok;
         if (flag_out) flag_out[(int64_t)row * flag_ld] = tok == pad_id ? 1 : 0;
     };
-    const float NEG = -__builtin_inff();
-    const int64_t f = forced ? forced[row] : -1;
-    if (f >= 0) { if (lane == 0) emit(f); return; }
-    const float* x = logits + (int64_t)row * V;
-    constexpr int MAXPER = 16;  // V <= 1024
-    float v[MAXPER];
-    float best = NEG;
-    int bi = 0x7fffffff;
-#pragma unroll
-    for (int i = 0; i < MAXPER; ++i) {
-        const int c = lane + 64 * i, cc = min(c, V - 1);   // unconditional loads of a clamped column (conditional ones are serialised)
-        const float xv = x[cc];
-        const uint8_t al = allowed ? allowed[cc] : (uint8_t)1;
-        v[i] = (c < V && al) ? xv : NEG;
-        if (v[i] > best) { best = v[i]; bi = c; }
-    }
-    // wave arg-max with lowest-index tie break
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o);
-        const int oi = __shfl_xor(bi, o);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
-    if (mode == 0 || (mode == 1 && top_k <= 1)) { if (lane == 0) emit(bi); return; }
-    const float invT = 1.f / temperature;
-    if (mode == 4) {   // Gumbel noise on the temperature-scaled logits; the maximum moves
-        best = NEG;
-#pragma unroll
-        for (int i = 0; i < MAXPER; ++i) {
-            const int c = lane + 64 * i;
-            if (v[i] > NEG) {
-                const float u = (rng24((uint64_t)seed[0], call, (1ull << 40) + rrow * 1024 + c) + 0.5f) * (1.f / 16777216.f);
-                v[i] = v[i] * invT - __logf(-__logf(u + 1e-30f) + 1e-30f);
-            }
-            best = fmaxf(best, v[i]);
-        }
-        best = wave_max(best);
-    }
-    // k-th largest value: peel the maximum k-1 times (ties are removed one at a time)
-    float kth = mode == 1 ? best : NEG;
-    if (mode == 1) {
-        float w[MAXPER];
-#pragma unroll
-        for (int i = 0; i < MAXPER; ++i) w[i] = v[i];
-        int wi = bi;
-        for (int r = 1; r < top_k; ++r) {
-#pragma unroll
-            for (int i = 0; i < MAXPER; ++i) if (lane + 64 * i == wi) w[i] = NEG;
-            float b2 = NEG; int i2 = 0x7fffffff;
-#pragma unroll
-            for (int i = 0; i < MAXPER; ++i) if (w[i] > b2) { b2 = w[i]; i2 = lane + 64 * i; }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ob = __shfl_xor(b2, o);
-                const int oi = __shfl_xor(i2, o);
-                if (ob > b2 || (ob == b2 && oi < i2)) { b2 = ob; i2 = oi; }
-            }
-            if (b2 == NEG) break;
-            kth = b2; wi = i2;
-        }
-    }
-    const float pscale = mode == 4 ? 1.f : invT;   // (the Gumbel branch scaled its logits already)
-    float p[MAXPER], ls = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXPER; ++i) { p[i] = v[i] >= kth && v[i] > NEG ? __expf((v[i] - best) * pscale) : 0.f; ls += p[i]; }
-    if (mode == 2) {
-        const float mass = wave_sum(ls) * top_p;   // un-normalised p: compare against top_p x total
-        // order-preserving map float -> uint (negative floats reversed); bisection for the smallest key t with S(t) <= mass
-        auto key_of = [](float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); };
-        uint32_t kv[MAXPER];
-#pragma unroll
-        for (int i = 0; i < MAXPER; ++i) kv[i] = key_of(v[i]);
-        uint32_t lo = 0u, hi = key_of(best);   // S(hi) may exceed the mass (then only the arg-max stays: it is united below); S(lo) = total
-        // invariant: S(hi_candidate) checked on the fly; find the smallest t in [lo, hi] with S(t) <= mass, or hi + 1 if none
-        uint32_t ans = 0xffffffffu;
-        for (int it = 0; it < 33 && lo <= hi; ++it) {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            float sm = 0.f;
-#pragma unroll
-            for (int i = 0; i < MAXPER; ++i) sm += kv[i] >= mid ? p[i] : 0.f;
-            sm = wave_sum(sm);
-            if (sm <= mass) { ans = mid; if (mid == 0u) break; hi = mid - 1u; }
-            else { if (mid == 0xffffffffu) break; lo = mid + 1u; }
-        }
-        ls = 0.f;
-#pragma unroll
-        for (int i = 0; i < MAXPER; ++i) { if (!(kv[i] >= ans || lane + 64 * i == bi)) p[i] = 0.f; ls += p[i]; }
-    }
-    // exclusive scan of the lane sums (lane-major CDF)
-    float inc = ls;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-    const float total = __shfl(inc, 63);
-    const float u = (rng24((uint64_t)seed[0], call, rrow) + 0.5f) * (1.f / 16777216.f) * total;
-    float acc = inc - ls;
-    int pick = -1;
-#pragma unroll
-    for (int i = 0; i < MAXPER; ++i) { if (pick < 0 && p[i] > 0.f && acc + p[i] >= u) pick = lane + 64 * i; acc += p[i]; }
-    // the first lane whose range contains u owns the draw
-    const bool mine = (u > inc - ls) && (u <= inc) && pick >= 0;
-    const unsigned long long ball = __ballot(mine);
-    const int owner = ball ? __ffsll((long long)ball) - 1 : -1;
-    const int res = owner >= 0 ? __shfl(pick, owner) : bi;
-    if (lane == 0) emit(res);
+    sample_core::mask_sample_row(logits + (int64_t)row * V, allowed, forced ? forced[row] : -1, mode, top_k, temperature, top_p, seed, call,
+                                 (uint64_t)row + (uint64_t)row0, V, lane, emit);
 }
 
 }  // namespace

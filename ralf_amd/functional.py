@@ -173,6 +173,8 @@ class Runtime:
         self.fused_decode = True  # KV-cached decode step: LayerNorm + projections + attention per block in one launch (bf16, d = 256, 8 heads)
         # ... the WHOLE step (embedding, every layer, head) as one launch with a workgroup per sample (ops.decode_token, csrc/decode_token.hip)
         self.fused_decode_token = os.environ.get("RALF_DECODE_TOKEN", "1") != "0"
+        # ... and the decode-space mask + token choice inside that launch (ralf_decode_token's s_* arguments; 0: a launch of its own, the same tokens)
+        self.fused_decode_sample = os.environ.get("RALF_DECODE_SAMPLE", "1") != "0"
         self.fold_bn = True       # inference: eval-mode BatchNorm folded into the convolution epilogues (conv_bn_infer)
         # decode step: LayerNorm inside the few-row product that follows it (RalfGemmDesc.ln_*) and the four-wave split of the 256 x 256 x 1024
         # product (few_row_split) -- same arithmetic, other summation orders than the separate launches (off: their bits)

@@ -338,9 +338,11 @@ class _GeneratorBase(nn.Module):
                 tok = seqbuf[b0:b1, start].contiguous()
                 pb = padbuf[b0:b1]
                 for i in range(start, T):
-                    logits = RN.decoder_step(self.decoder, tok, i, c, self.rt, pb, kpm_stride=T + 1)
-                    tok = RN.ops.mask_sample(logits, token_mask_u8[i], forced_all[i][b0:b1] if forced_all is not None else None, mode, k, temp,
-                                             self.rt.seed, 1000 + i, seq_col=seqbuf[b0:b1, i + 1], pad_flag_col=pb[:, i + 1], pad_id=ids["pad"], top_p=top_p, row0=b0)
+                    # (decoder step + decode-space mask + token choice: ONE launch on the bf16 path, ralf_decode_token with its s_* arguments)
+                    tok = RN.decoder_step(self.decoder, tok, i, c, self.rt, pb, kpm_stride=T + 1,
+                                          sample=dict(allowed=token_mask_u8[i], forced=forced_all[i][b0:b1] if forced_all is not None else None, mode=mode, top_k=k,
+                                                      temperature=temp, seed=self.rt.seed, call_id=1000 + i, seq_col=seqbuf[b0:b1, i + 1], pad_flag_col=pb[:, i + 1],
+                                                      pad_id=ids["pad"], top_p=top_p, row0=b0))
             # A decode step is a chain of ~45 launches that each occupy a fraction of the chip for 5-25 us (few-row products, the per-element
             # attention blocks); elements never interact.  `Runtime.decode_slices` > 1 decodes a large batch as that many independent chains on
             # streams of their own (parallel branches of the captured loop; same kernels, same per-row arithmetic, the same draws through

@@ -397,13 +397,15 @@ def _decode_token_weights(dec, rt):
 
 @torch.no_grad()
 def decoder_step(dec: "BaseDecoder", tok: torch.Tensor, pos: int, cache: DecodeCache, rt: Runtime, kpm_prefix: torch.Tensor,
-                 kpm_stride: Optional[int] = None, pos_vec: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 kpm_stride: Optional[int] = None, pos_vec: Optional[torch.Tensor] = None, sample: Optional[dict] = None):
     """one KV-cached decode step: token ids [B] at position `pos` -> fp32 logits [B, V].  kpm_prefix uint8
     [B, pos+1] marks padded prefix tokens (tgt_key_padding_mask of the reference's full-prefix call,
     retrieval_augmented_autoreg.py:274-279); with `kpm_stride` it is the [B, kpm_stride] mask buffer of the whole loop, of
     which the first pos+1 columns are read.  Same arithmetic as BaseDecoder.forward restricted to the last row.
     pos_vec (int32 [B] on the device; fused bf16 path only): every element sits at ITS OWN position pos_vec[b] <= pos -- the samples of
-    sample_relation rewind their prefixes independently (retrieval_augmented_autoreg.py:432-460) and still step together."""
+    sample_relation rewind their prefixes independently (retrieval_augmented_autoreg.py:432-460) and still step together.
+    sample (optional): the keyword arguments of ops.mask_sample -- the call then returns the chosen TOKENS int64 [B] instead of the logits (the same
+    function on the same logits: inside the one-launch step where that path runs, as a launch of its own behind the others)."""
     B = tok.shape[0]
     d, H = dec.d_model, dec.transformer.layers[0].self_attn.nhead
     dh = d // H
@@ -411,8 +413,13 @@ def decoder_step(dec: "BaseDecoder", tok: torch.Tensor, pos: int, cache: DecodeC
         # the whole step as ONE launch, a workgroup per sample (bf16 throughput mode; same rounding points as the launches below)
         lw = _decode_token_weights(dec, rt)
         kst = kpm_stride if kpm_stride else kpm_prefix.shape[1]
-        return ops.decode_token(lw["layers"], lw["head"], dec.emb.weight.detach(), dec.pos_emb.pe[0], math.sqrt(d), tok, pos, cache.self_kv, cache.cross_kv,
-                                cache.max_len, cache.cross_rows, dec.head[1].weight.shape[0], kpm=kpm_prefix, kpm_stride=kst, pos_vec=pos_vec)
+        fuse_choice = sample is not None and rt.fused_decode_sample and dec.head[1].weight.shape[0] <= 1024
+        r = ops.decode_token(lw["layers"], lw["head"], dec.emb.weight.detach(), dec.pos_emb.pe[0], math.sqrt(d), tok, pos, cache.self_kv, cache.cross_kv,
+                             cache.max_len, cache.cross_rows, dec.head[1].weight.shape[0], kpm=kpm_prefix, kpm_stride=kst, pos_vec=pos_vec,
+                             sample=sample if fuse_choice else None)
+        if sample is None:
+            return r
+        return r[1] if fuse_choice else ops.mask_sample(r, **sample)
     if pos_vec is None:
         x = ops.embed_fwd(tok.view(B, 1).contiguous(), dec.emb.weight.detach(), dec.pos_emb.pe[0, pos:pos + 1].contiguous(), 1, math.sqrt(d), rt.dtype).view(B, d)
     else:   # the batch as ONE sequence whose positional rows are gathered per element: the same kernel, the same arithmetic
@@ -475,10 +482,12 @@ def decoder_step(dec: "BaseDecoder", tok: torch.Tensor, pos: int, cache: DecodeC
             f = ops.gemm(h, rt.lp(layer.linear1.weight), B, layer.linear1.weight.shape[0], d, bias=layer.linear1.bias.detach(), act="relu")
         x = ops.gemm(f, rt.lp(layer.linear2.weight), B, d, f.shape[1], bias=layer.linear2.bias.detach(), res=x, few_row_split=rt.decode_few_row_split)
     if rt.decode_ln_gemm and ops.gemm_ln_ok(x, B, d):
-        return ops.gemm(x, rt.lp(dec.head[1].weight), B, dec.head[1].weight.shape[0], d, out_dtype=torch.float32,
-                        ln=(dec.head[0].weight.detach(), dec.head[0].bias.detach(), 1e-5))
-    h, _, _ = ops.layernorm_fwd(x, dec.head[0].weight.detach(), dec.head[0].bias.detach(), save_stats=False)
-    return ops.gemm(h, rt.lp(dec.head[1].weight), B, dec.head[1].weight.shape[0], d, out_dtype=torch.float32)
+        logits = ops.gemm(x, rt.lp(dec.head[1].weight), B, dec.head[1].weight.shape[0], d, out_dtype=torch.float32,
+                          ln=(dec.head[0].weight.detach(), dec.head[0].bias.detach(), 1e-5))
+    else:
+        h, _, _ = ops.layernorm_fwd(x, dec.head[0].weight.detach(), dec.head[0].bias.detach(), save_stats=False)
+        logits = ops.gemm(h, rt.lp(dec.head[1].weight), B, dec.head[1].weight.shape[0], d, out_dtype=torch.float32)
+    return logits if sample is None else ops.mask_sample(logits, **sample)
 
 
 class UserConstraintTransformerEncoder(nn.Module):

@@ -996,10 +996,12 @@ def decode_token_limits():
     return _DEC_TOKEN_LIMITS
 
 
-def decode_token(layers, head, emb, pe, emb_scale, tok, pos, self_kv, cross_kv, L, M, V, kpm=None, kpm_stride=0, pos_vec=None, eps=1e-5, keep=None):
+def decode_token(layers, head, emb, pe, emb_scale, tok, pos, self_kv, cross_kv, L, M, V, kpm=None, kpm_stride=0, pos_vec=None, eps=1e-5, keep=None, sample=None):
     """one KV-cached decode step of the whole decoder stack in ONE launch, a workgroup per sample (ralf_decode_token): token ids [B] -> fp32
     logits [B, V].  layers: per layer a dict of device tensors (bf16 weights row-major [n_out, n_in], fp32 biases / LayerNorm parameters):
-    w_qkv b_qkv ln1_g ln1_b w_o1 b_o1 ln2_g ln2_b w_q2 b_q2 w_o2 b_o2 ln3_g ln3_b w_f1 b_f1 w_f2 b_f2; head = (ln_g, ln_b, w_head)."""
+    w_qkv b_qkv ln1_g ln1_b w_o1 b_o1 ln2_g ln2_b w_q2 b_q2 w_o2 b_o2 ln3_g ln3_b w_f1 b_f1 w_f2 b_f2; head = (ln_g, ln_b, w_head).
+    sample (optional): the keyword arguments of mask_sample (allowed, forced, mode, top_k, temperature, seed, call_id, seq_col, pad_flag_col, pad_id, top_p,
+    row0) -- the token choice runs in the same launch and the call returns (logits, tokens int64 [B])."""
     from ._abi import RalfDecodeTokenDesc
 
     B = tok.numel()
@@ -1014,8 +1016,25 @@ def decode_token(layers, head, emb, pe, emb_scale, tok, pos, self_kv, cross_kv, 
         for n in ("w_qkv", "b_qkv", "ln1_g", "ln1_b", "w_o1", "b_o1", "ln2_g", "ln2_b", "w_q2", "b_q2", "w_o2", "b_o2", "ln3_g", "ln3_b", "w_f1", "b_f1", "w_f2", "b_f2"):
             setattr(lw, n, _p(w[n]))
         lw.self_kv, lw.cross_kv = _p(self_kv[i]), _p(cross_kv[i])
+    out = None
+    if sample is not None:
+        out = torch.empty(B, dtype=torch.int64, device=tok.device)
+
+        def col(t, dtype):
+            if t is None:
+                return None, 0
+            assert t.dtype == dtype and t.dim() == 1 and t.shape[0] == B and t.stride(0) > 0
+            return ctypes.c_void_p(t.data_ptr()), t.stride(0)
+
+        sp, sl = col(sample.get("seq_col"), torch.int64)
+        fp, fl = col(sample.get("pad_flag_col"), torch.uint8)
+        d.s_allowed, d.s_forced, d.s_seed, d.s_out = _p(sample.get("allowed")), _p(sample.get("forced")), _p(sample.get("seed")), _p(out)
+        d.s_seq_out, d.s_seq_ld, d.s_flag_out, d.s_flag_ld = sp, sl, fp, fl
+        d.s_pad_id, d.s_call, d.s_row0 = int(sample.get("pad_id", -1)), int(sample.get("call_id", 0)), int(sample.get("row0", 0))
+        d.s_mode, d.s_top_k = int(sample.get("mode", 0)), int(sample.get("top_k", 1))
+        d.s_temperature, d.s_top_p = float(sample.get("temperature", 1.0)), float(sample.get("top_p", 1.0))
     _call("ralf_decode_token", ctypes.byref(d))
-    return logits
+    return logits if sample is None else (logits, out)
 
 
 def attention_bwd(dout, q, k, v, o, lse, dq, dk, dv, B, H, Sq, Sk, dh, q_off=0, k_off=0, v_off=0, dq_off=0, dk_off=0, dv_off=0,

@@ -257,6 +257,52 @@ def test_one_launch_decode_token_equals_the_per_kernel_step(layers, M):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("mode,top_k,top_p", [(0, 1, 1.0), (1, 5, 1.0), (2, 1, 0.9), (3, 1, 1.0), (4, 1, 1.0)])
+def test_token_choice_inside_the_one_launch_step_equals_the_sampling_kernel(mode, top_k, top_p):
+    """ralf_decode_token with its s_* arguments (the decode-space mask + token choice of helpers/sampling.py in the SAME launch as the decoder step: one
+    wave per sample runs sample_core.h's row function on the logits it finds in LDS) against ralf_mask_sample_step on the logits the same launch wrote:
+    the same tokens, sequence column and pad flags for every mode (deterministic, top_k, top_p, random, gumbel), with an allowed-token mask, forced
+    tokens and a row offset."""
+    from ralf_amd import functional as RF, nn as RN, ops
+
+    torch.manual_seed(11)
+    B, T, V, M = 160, 8, 518, 70
+    dec = RN.BaseDecoder(V, D, 2, H, FF).cuda()
+    for prm in dec.parameters():
+        torch.nn.init.normal_(prm, std=0.08)
+    mem = rnd(B, M, D, seed=12).to(torch.bfloat16).cuda()
+    rt = RF.Runtime(torch.bfloat16, seed=3)
+    rt.to(torch.device("cuda"))
+    g = torch.Generator().manual_seed(13)
+    allowed = (torch.rand(V, generator=g) > 0.3).to(torch.uint8).cuda()
+    allowed[:4] = 1
+    forced = torch.full((B,), -1, dtype=torch.int64)
+    forced[5], forced[17] = 3, 0
+    forced = forced.cuda()
+    kpm = torch.zeros(B, T + 1, dtype=torch.uint8, device="cuda")
+    res = {}
+    for fused in (True, False):
+        rt.fused_decode_sample = fused
+        cache = RN.decoder_init_cache(dec, mem, rt, T)
+        assert RN._decode_token_ok(dec, cache, rt, forced)
+        seqbuf = torch.full((B, T + 1), 7, dtype=torch.int64, device="cuda")
+        pad = kpm.clone()
+        tok = torch.randint(0, V, (B,), generator=torch.Generator().manual_seed(14)).cuda()
+        toks = []
+        for pos in range(4):
+            tok = RN.decoder_step(dec, tok, pos, cache, rt, pad, kpm_stride=T + 1,
+                                  sample=dict(allowed=allowed, forced=forced if pos == 1 else None, mode=mode, top_k=top_k, temperature=0.8, seed=rt.seed, call_id=1000 + pos,
+                                              seq_col=seqbuf[:, pos + 1], pad_flag_col=pad[:, pos + 1], pad_id=3, top_p=top_p, row0=32))
+            toks.append(tok.clone())
+        res[fused] = (torch.stack(toks), seqbuf.clone(), pad.clone())
+    torch.cuda.synchronize()
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    t = res[True][0]
+    assert bool(allowed[t[0]].all()) and int(t[1][5]) == 3 and int(t[1][17]) == 0 and bool(res[True][2][5, 2] == 1)
+    assert mode == 0 or len(torch.unique(t)) > 8
+
+
 def test_weight_packing_is_the_documented_permutation():
     from ralf_amd import ops
 
