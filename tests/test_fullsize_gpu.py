@@ -228,7 +228,7 @@ def test_b64_gradients_bf16_against_fp32_on_trained_weights_with_the_autocast_ya
             # a single tensor's cosine moves by +-0.2 between runs (the 400 steps are not bit-reproducible: fp32 atomics): tensor by tensor the
             # HIP path may fall short of the yardstick by that much and no more.  The norm ratio of the two shallowest tensors is a noisy number
             # too: seven runs of one build gave 0.84 ... 1.36 for the stem and 0.92 ... 1.23 for layer1.0.conv1 (profiles/r06_yardstick_run_to_run.txt; the
-            # kernels in between are bit-identical, tools/lab/patch_step_check.py), +-5 % for the deeper ones
+            # kernels in between are bit-identical, tools/patch_step_check.py), +-5 % for the deeper ones
             shallow = k.endswith("body.conv1.weight") or ".layer1." in k
             assert ch > cy - 0.25 and (0.7 < rh < 1.5 if shallow else 0.85 < rh < 1.15), (k, ch, cy, rh)
             body_h.append(ch); body_y.append(cy)
@@ -243,7 +243,7 @@ def test_patch_form_convolutions_leave_the_captured_step_bit_identical(tmp_path)
     on): the gradients of every weight matrix of the ResNet body are the SAME BITS with the 3 x 3 convolutions on the patch form (default) and on the
     tap gather (RALF_GEMM_PATCH=0, read once per process) -- the kernel-level identity of tests/test_gemm_gpu.py holds inside the model, under capture
     and concurrency.  (Bias / LayerNorm-parameter gradients and the loss are summed with fp32 atomics and differ from run to run of ONE setting;
-    tools/lab/patch_step_check.py prints the comparison.)"""
+    tools/patch_step_check.py prints the comparison.)"""
     import os
     import subprocess
     import sys
@@ -252,7 +252,7 @@ def test_patch_form_convolutions_leave_the_captured_step_bit_identical(tmp_path)
     path = str(tmp_path / "grads.pt")
     outs = []
     for flag in ("0", "1"):
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "lab", "patch_step_check.py"), path, "4"], env=dict(os.environ, RALF_GEMM_PATCH=flag),
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "patch_step_check.py"), path, "4"], env=dict(os.environ, RALF_GEMM_PATCH=flag),
                            capture_output=True, text=True, cwd=root)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         outs.append(r.stdout)
