@@ -3,6 +3,9 @@ reference builds in image2layout/train/models/retrieval/retriever.py:79-84 and s
 query at a time at :200-202)."""
 from __future__ import annotations
 
+import ctypes
+import os
+
 import torch
 
 from .. import _lib
@@ -156,6 +159,7 @@ def knn_topk_ip_two_stage(index: torch.Tensor, index_bf16: torch.Tensor, queries
 
 
 _BAD_HOST: dict = {}   # page-locked mirrors of the certificate flags, by batch size
+_HOST_FLAGS = os.environ.get("RALF_KNN_HOST_FLAGS", "1") != "0"   # the search's last kernel writes the flags straight into them
 
 
 def knn_topk_ip_two_stage_fused(index: torch.Tensor, index_bf16: torch.Tensor, queries: torch.Tensor, k: int, index_norms: torch.Tensor, pool: int = 0,
@@ -174,19 +178,21 @@ def knn_topk_ip_two_stage_fused(index: torch.Tensor, index_bf16: torch.Tensor, q
     q = queries.contiguous()
     idx = torch.empty(nq, k, dtype=torch.int64, device=index.device)
     val = torch.empty(nq, k, dtype=torch.float32, device=index.device)
-    bad = torch.empty(nq, dtype=torch.int32, device=index.device)
-    rc = L.ralf_knn_topk_ip_two_stage(_lib.ptr(index), _lib.ptr(index_bf16), N, D, _lib.ptr(q), nq, k, pool, _lib.ptr(index_norms), _lib.ptr(idx), _lib.ptr(val),
-                                      _lib.ptr(bad), _lib.ptr(workspace), workspace.numel(), _lib.stream_ptr())
-    _lib.check(rc, "ralf_knn_topk_ip_two_stage")
-    nbad = 0
-    # the one host read of the search (the flags themselves, one small copy into page-locked memory: an `any` kernel + its read cost two more hops)
+    # the certificate flags, the one host read of the search: the last kernel writes them STRAIGHT into page-locked host memory (device-visible, coherent) -- a
+    # device buffer + copy was one more launch on the call's dependent chain (an `any` kernel + its read: two more); RALF_KNN_HOST_FLAGS=0: the copy
     host = _BAD_HOST.get(nq)
     if host is None:
         host = _BAD_HOST[nq] = torch.empty(nq, dtype=torch.int32, pin_memory=True)
-    host.copy_(bad, non_blocking=True)
+    bad = host if _HOST_FLAGS else torch.empty(nq, dtype=torch.int32, device=index.device)
+    rc = L.ralf_knn_topk_ip_two_stage(_lib.ptr(index), _lib.ptr(index_bf16), N, D, _lib.ptr(q), nq, k, pool, _lib.ptr(index_norms), _lib.ptr(idx), _lib.ptr(val),
+                                      ctypes.c_void_p(bad.data_ptr()), _lib.ptr(workspace), workspace.numel(), _lib.stream_ptr())
+    _lib.check(rc, "ralf_knn_topk_ip_two_stage")
+    nbad = 0
+    if not _HOST_FLAGS:
+        host.copy_(bad, non_blocking=True)
     torch.cuda.current_stream().synchronize()
     if bool(host.any()):   # (almost never)
-        rows = torch.nonzero(bad).flatten()
+        rows = torch.nonzero(host).flatten().to(index.device)
         nbad = int(rows.numel())
         v2, i2 = knn_topk_ip(index, q[rows].contiguous(), k)
         val[rows], idx[rows] = v2, i2
