@@ -133,11 +133,11 @@ extern "C" int ralf_gemm(const RalfGemmDesc* dp, void* workspace, size_t workspa
         }
     }
     P.patch = lean_ok ? patch_variant(d, nbatch) : 0;   // (3 x 3 / stride 1: the tile's input patch resident in LDS, gemm_impl.h GATHER 15)
-    P.p_rows = P.p_pw = P.p_str = P.p_swsh = P.p_c8sh = 0;
+    P.p_pw = P.p_str = P.p_swsh = P.p_c8sh = 0;
     P.fd_pw.set(1);
     if (P.patch) {
         const RalfConvGeom& g = d.g;
-        P.p_rows = (P.patch == 1 ? 128 : 256) / g.SW; P.p_pw = g.SW + 2; P.p_str = 2 * g.SC + 16;
+        P.p_pw = g.SW + 2; P.p_str = 2 * g.SC + 16;
         while ((1 << P.p_swsh) < g.SW) ++P.p_swsh;
         while ((8 << P.p_c8sh) < g.SC) ++P.p_c8sh;
         P.fd_pw.set((uint32_t)P.p_pw);

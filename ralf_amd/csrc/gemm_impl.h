@@ -97,9 +97,9 @@ struct KParams {
     // data gradient of a STRIDE-2 convolution by parity classes (GATHER 14): rows are ordered (class, image, y / 2, x / 2), class = (y & 1, x & 1)
     FastDiv fd_q, fd_hw2, fd_rw2;   // rows per class (M / 4), (RH / 2) * (RW / 2), RW / 2
     int par;                        // 1: take the parity form (set by ralf_gemm)
-    // 3 x 3 / stride-1 convolutions with the tile's input PATCH resident in LDS (GATHER 15): a 128-row tile = p_rows whole image rows
+    // 3 x 3 / stride-1 convolutions with the tile's input PATCH resident in LDS (GATHER 15): a tile = (tile rows / SW) whole image rows
     int patch;                      // take the patch form (set by ralf_gemm): 1 = 128 x 128 tiles, 2 = 256 x 128, 3 = 256 x 64
-    int p_rows, p_pw, p_str;        // image rows per tile (tile rows / SW), patch width in pixels (SW + 2), bytes per patch pixel (2 SC + 16)
+    int p_pw, p_str;                // patch width in pixels (SW + 2), bytes per patch pixel (2 SC + 16)
     int p_swsh, p_c8sh;             // log2(SW), log2(SC / 8)
     FastDiv fd_pw;                  // p_pw
 };

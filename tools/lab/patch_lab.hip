@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
     P.ln_sgn = mode ? -1 : 1; P.ln_sh = 0; P.ln_pm = 0; P.img = H * H * C; P.swsc = H * C;
     P.fd_q.set(1); P.fd_hw2.set(1); P.fd_rw2.set(1);
     P.kchunk = K; P.fast = 0; P.tapuni = 1; P.vec_epi = 2;
-    P.patch = 1; P.p_pw = H + 2; P.p_str = 2 * C + 16; P.p_rows = 128 / H;
+    P.patch = 1; P.p_pw = H + 2; P.p_str = 2 * C + 16;
     while ((1 << P.p_swsh) < H) ++P.p_swsh;
     while ((8 << P.p_c8sh) < C) ++P.p_c8sh;
     P.fd_pw.set(H + 2);
