@@ -83,15 +83,19 @@ __global__ __launch_bounds__(NT) void xattn_raw_kernel(const bf16* __restrict__ 
         else if (inflight == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned char* tl = L.tile[wv][buf];
-        // ---- scores: keys x heads ----
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        // ---- scores: keys x heads (two accumulators: a 4-deep instead of an 8-deep dependent chain) ----
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc) {
-            const int piece = kc * 4 + g;
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(tl + n * 512 + ((piece ^ n) << 4));
-            const bf16x8 bb = *reinterpret_cast<const bf16x8*>(L.u + n * 512 + ((piece ^ n) << 4));
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, s, 0, 0, 0);
+        for (int kc = 0; kc < 8; kc += 2) {
+            const int p0 = kc * 4 + g, p1 = p0 + 4;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(tl + n * 512 + ((p0 ^ n) << 4));
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(L.u + n * 512 + ((p0 ^ n) << 4));
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(tl + n * 512 + ((p1 ^ n) << 4));
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(L.u + n * 512 + ((p1 ^ n) << 4));
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, s, 0, 0, 0);
+            s2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, s2, 0, 0, 0);
         }
+        s += s2;
         // lane (head n, key group g): keys 4 g + i of the tile
         float tmax = -__builtin_inff();
 #pragma unroll
@@ -109,20 +113,25 @@ __global__ __launch_bounds__(NT) void xattn_raw_kernel(const bf16* __restrict__ 
         ps += __shfl_xor(ps, 16);
         ps += __shfl_xor(ps, 32);
         l_run = l_run * alpha + ps;
+        const bool moved = __any(m_new != m_run);   // (wave-uniform: after the first tiles the running maxima seldom move -- no rescale then)
         m_run = m_new;
         const bf16x4 pa = {(bf16)p[0], (bf16)p[1], (bf16)p[2], (bf16)p[3]};
-        // the accumulators' rows are heads 4 g + i: their rescale factors live in the lanes of those heads
-        float al[4];
+        if (moved) {
+            // the accumulators' rows are heads 4 g + i: their rescale factors live in the lanes of those heads
+            float al[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) al[i] = __shfl(alpha, 4 * g + i);
+            for (int i = 0; i < 4; ++i) al[i] = __shfl(alpha, 4 * g + i);
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[c][i] *= al[i];
+        }
         // ---- weighted sum: heads x columns, 16 column tiles ----
         const int trow = 4 * g + (n >> 2);   // the key row this lane points the transposing read at
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const int piece = c * 2 + ((n & 3) >> 1), half = n & 1;
             const bf16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, tl + trow * 512 + ((piece ^ trow) << 4) + half * 8));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) r[c][i] *= al[i];
             r[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, vb, r[c], 0, 0, 0);
         }
     }
