@@ -488,8 +488,9 @@ sys.path.insert(0, {root!r})
 from ralf_amd import ops
 dt = torch.bfloat16
 out = {{}}
-for (B, H, C) in [(16, 64, 64), (64, 32, 128), (32, 32, 128), (64, 16, 256), (2, 16, 256)]:
-    M = B * H * H
+for (B, H, C) in [(16, 64, 64), (64, 32, 128), (32, 32, 128), (64, 16, 256), (2, 16, 256), (16, (32, 64), 128)]:
+    H, W = H if isinstance(H, tuple) else (H, H)
+    M = B * H * W
     g = torch.Generator(device="cuda").manual_seed(H + B)
     x = torch.randn(M, C, device="cuda", generator=g).to(dt)
     w = (torch.randn(C, 3, 3, C, device="cuda", generator=g) * 0.05).to(dt)
@@ -498,11 +499,11 @@ for (B, H, C) in [(16, 64, 64), (64, 32, 128), (32, 32, 128), (64, 16, 256), (2,
     xa = torch.randn(M, C, device="cuda", generator=g).to(dt)
     mean = torch.randn(C, device="cuda", generator=g)
     bits = torch.randint(0, 256, (M * C // 8,), device="cuda", dtype=torch.uint8, generator=g)
-    gf = dict(RH=H, RW=H, SH=H, SW=H, SC=C, KH=3, KW=3, stride=1, pad=1, mode=0)
+    gf = dict(RH=H, RW=W, SH=H, SW=W, SC=C, KH=3, KW=3, stride=1, pad=1, mode=0)
     gd = dict(gf, mode=1)
     st = torch.full(((M + 63) // 64, 2, C), float("nan"), device="cuda")
     part = torch.full(((M + 63) // 64, 2, C), float("nan"), device="cuda")
-    k = (B, H, C)
+    k = (B, H if H == W else (H, W), C)
     out[k + ("variant",)] = torch.tensor([ops.gemm_patch_variant(M, C, 9 * C, conv=gf), ops.gemm_patch_variant(M, C, 9 * C, conv=gd)])
     out[k + ("fwd",)] = ops.gemm(x, w, M, C, 9 * C, conv=gf, gather=1, colstats=st)
     out[k + ("fwd_stats",)] = st
@@ -533,25 +534,27 @@ def test_conv3x3_with_the_input_patch_in_lds_is_bit_identical_to_the_tap_gather(
                            capture_output=True, text=True, cwd=root)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         res[flag] = torch.load(path)
-    want = {(16, 64, 64): 3, (64, 32, 128): 2, (32, 32, 128): 1, (64, 16, 256): 1, (2, 16, 256): 0}
+    want = {(16, 64, 64): 3, (64, 32, 128): 2, (32, 32, 128): 1, (64, 16, 256): 1, (2, 16, 256): 0, (16, (32, 64), 128): 1}   # (the last: 32 x 64-pixel maps)
     for k, v in want.items():
         assert res["1"][k + ("variant",)].tolist() == [v, v] and res["0"][k + ("variant",)].tolist() == [0, 0], k
     for k in res["1"]:
         if k[-1] != "variant":
             assert torch.equal(res["1"][k], res["0"][k]), k
     # ... and the convolution itself against torch (one case per variant, forward and data gradient)
-    for (B, H, C) in [(16, 64, 64), (64, 32, 128), (64, 16, 256)]:
-        M = B * H * H
+    for (B, H, C) in [(16, 64, 64), (64, 32, 128), (64, 16, 256), (16, (32, 64), 128)]:
+        key = (B, H, C)
+        H, W = H if isinstance(H, tuple) else (H, H)
+        M = B * H * W
         g = torch.Generator(device="cuda").manual_seed(H + B)   # (the subprocess's operands: x, w, bias, skip in its order)
         x = torch.randn(M, C, device="cuda", generator=g).to(torch.bfloat16)
         w = (torch.randn(C, 3, 3, C, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
         torch.randn(C, device="cuda", generator=g)
         skip = torch.randn(M, C, device="cuda", generator=g).to(torch.bfloat16)
-        xi = x.float().view(B, H, H, C).permute(0, 3, 1, 2)
+        xi = x.float().view(B, H, W, C).permute(0, 3, 1, 2)
         y = F.conv2d(xi, w.float().permute(0, 3, 1, 2), None, 1, 1).permute(0, 2, 3, 1).reshape(M, C)               # weights [co][kh][kw][ci]
-        torch.testing.assert_close(res["1"][(B, H, C, "fwd")].float(), y.cpu(), atol=6e-2, rtol=2e-2)
+        torch.testing.assert_close(res["1"][key + ("fwd",)].float(), y.cpu(), atol=6e-2, rtol=2e-2)
         dx = F.conv_transpose2d(xi, w.float().permute(3, 0, 1, 2), None, 1, 1).permute(0, 2, 3, 1).reshape(M, C)   # weights [ci][kh][kw][co]
-        torch.testing.assert_close(res["1"][(B, H, C, "dgrad")].float(), (dx + skip.float()).cpu(), atol=6e-2, rtol=2e-2)
+        torch.testing.assert_close(res["1"][key + ("dgrad",)].float(), (dx + skip.float()).cpu(), atol=6e-2, rtol=2e-2)
 
 
 # ---- operand transform with write-through (RalfGemmDesc.at_*): BatchNorm apply / backward apply inside the loader of a 1x1 convolution ----
