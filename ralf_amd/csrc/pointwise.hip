@@ -22,6 +22,25 @@ using sample_core::rng24;
 using sample_core::wave_max;
 using sample_core::wave_sum;
 
+// division by a launch-time constant as multiply-high + shift (n < 2^31; the FastDiv of gemm_impl.h): the index arithmetic of the per-pixel kernels below
+// ran on 64-bit hardware-less divisions -- 6 per 16-byte element in the stem's fused BatchNorm / ReLU / max-pool backward, which streamed at 1.1-2.2 TB/s
+struct FDiv {
+    uint32_t mul, shr, den;
+    __device__ __forceinline__ uint32_t div(uint32_t n) const { const uint32_t t = __umulhi(n, mul) >> shr; return den == 1 ? n : t; }
+    __device__ __forceinline__ void divmod(uint32_t n, int& q, int& r) const { const uint32_t t = div(n); q = (int)t; r = (int)(n - t * den); }
+};
+inline FDiv make_fdiv(uint32_t d) {
+    FDiv f;
+    f.den = d ? d : 1;
+    if (f.den == 1) { f.mul = 0; f.shr = 0; return f; }
+    uint32_t lg = 0;
+    while ((1u << lg) < f.den) ++lg;
+    const uint32_t p = 31 + lg;
+    f.mul = (uint32_t)((((uint64_t)1 << p) + f.den - 1) / f.den);
+    f.shr = p - 32;
+    return f;
+}
+
 inline int grid_for(int64_t n, int per_block = 256, int cap = 4096) {
     int64_t b = (n + per_block - 1) / per_block;
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -742,66 +761,94 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __res
     }
 }
 
-// the gradient that reaches z = relu(BN(y)) at input pixel (b, ih, iw) through the pooling: the sum over the <= 4 windows whose argmax it is,
-// rounded to T (what ralf_maxpool3x3s2_bwd stores), zero where the ReLU was inactive (y * scale + shift <= 0)
+// the gradient that reaches z = relu(BN(y)) at an input pixel through the pooling: the sum over the <= 4 windows whose argmax it is, rounded to T (what
+// ralf_maxpool3x3s2_bwd stores), zero where the ReLU was inactive (y * scale + shift <= 0).
+// dz of the 2 x 2 pixel block (rows 2 k, 2 k + 1; columns 2 l, 2 l + 1) of image b: its four pixels draw on the four pooling windows (k .. k + 1) x (l .. l + 1)
+// and on no other, so each window's gradient and arg-max vector is loaded ONCE for the block (a pixel at a time they were loaded 9 times per block, behind
+// parity-dependent branches: the two kernels below were bound by their ~240 instructions per 16-byte element, 1.1-2.2 TB/s).  Pixel (dy, dx) sits in window
+// (wy, wx) at tap (dy - 2 wy + 1, dx - 2 wx + 1) where that is inside 0 .. 2; windows are added in the order (0,0), (0,1), (1,0), (1,1) -- pooled_dz's order.
 template <typename T, int N>
-__device__ __forceinline__ void pooled_dz(const T* __restrict__ dpool, const int8_t* __restrict__ arg, const float (&yv)[N], const float (&sc)[N], const float (&sh)[N],
-                                          int b, int ih, int iw, int c, int C, int OH, int OW, float (&g)[N]) {
+__device__ __forceinline__ void pooled_dz_2x2(const T* __restrict__ dpool, const int8_t* __restrict__ arg, const float (&yv)[4][N], const float (&sc)[N], const float (&sh)[N],
+                                              int b, int k, int l, int c, int C, int OH, int OW, float (&g)[4][N]) {
+    float wv[4][N];
+    __attribute__((aligned(8))) int8_t wa[4][N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) g[i] = 0.f;
-#pragma unroll
-    for (int dh = 0; dh < 2; ++dh) {
-        const int oh = (ih + dh) / 2;
-        if (dh == 1 && oh == ih / 2) continue;
-        const int kh = ih - (oh * 2 - 1);
-        if (oh >= OH || kh < 0 || kh > 2) continue;
-#pragma unroll
-        for (int dw = 0; dw < 2; ++dw) {
-            const int ow = (iw + dw) / 2;
-            if (dw == 1 && ow == iw / 2) continue;
-            const int kw = iw - (ow * 2 - 1);
-            if (ow >= OW || kw < 0 || kw > 2) continue;
-            const int64_t o = (((int64_t)b * OH + oh) * OW + ow) * C + c;
-            float v[N];
-            PV<T>::load(dpool + o, v);
-            int8_t a[N];
-            if constexpr (N == 8) *reinterpret_cast<uint2*>(a) = *reinterpret_cast<const uint2*>(arg + o);
-            else *reinterpret_cast<uint32_t*>(a) = *reinterpret_cast<const uint32_t*>(arg + o);
-            const int8_t want = (int8_t)(kh * 3 + kw);
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-                if (a[i] == want) g[i] += v[i];
-        }
+    for (int w = 0; w < 4; ++w) {
+        const int oh = min(k + (w >> 1), OH - 1), ow = min(l + (w & 1), OW - 1);   // (clamped: a window beyond the edge is loaded from a valid place and not used)
+        const int64_t o = (((int64_t)b * OH + oh) * OW + ow) * C + c;
+        PV<T>::load(dpool + o, wv[w]);
+        if constexpr (N == 8) *reinterpret_cast<uint2*>(wa[w]) = *reinterpret_cast<const uint2*>(arg + o);
+        else *reinterpret_cast<uint32_t*>(wa[w]) = *reinterpret_cast<const uint32_t*>(arg + o);
     }
+    const bool wok[4] = {true, l + 1 < OW, k + 1 < OH, (k + 1 < OH) && (l + 1 < OW)};
 #pragma unroll
-    for (int i = 0; i < N; ++i) g[i] = __builtin_fmaf(yv[i], sc[i], sh[i]) > 0.f ? (float)(T)g[i] : 0.f;
+    for (int q = 0; q < 4; ++q) {
+        const int dy = q >> 1, dx = q & 1;
+#pragma unroll
+        for (int i = 0; i < N; ++i) g[q][i] = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int kh = dy - 2 * (w >> 1) + 1, kw = dx - 2 * (w & 1) + 1;   // (compile-time)
+            if (kh < 0 || kh > 2 || kw < 0 || kw > 2) continue;
+            const int8_t want = (int8_t)(kh * 3 + kw);
+            if (wok[w]) {
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    if (wa[w][i] == want) g[q][i] += wv[w][i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) g[q][i] = __builtin_fmaf(yv[q][i], sc[i], sh[i]) > 0.f ? (float)(T)g[q][i] : 0.f;
+    }
 }
 
 // backward, pass 1: per workgroup the column sums of dz and of dz * (y - mean) -> part[blockIdx.x][2][C] (the layout of RalfGemmDesc.bnb_part:
-// ralf_bn_bwd_stats_from_partials finishes them).  A thread owns one channel vector and walks pixels.
+// ralf_bn_bwd_stats_from_partials finishes them).  A thread owns one channel vector and walks 2 x 2 pixel blocks (block coordinates advanced with carries).
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_reduce_kernel(const T* __restrict__ dpool, const int8_t* __restrict__ arg, const T* __restrict__ y,
                                                                           const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-                                                                          float* __restrict__ part, int B, int H, int W, int C, int OH, int OW) {
+                                                                          float* __restrict__ part, int B, int H, int W, int C, int OH, int OW, FDiv fkw, FDiv fkh) {
     constexpr int N = PV<T>::N;
     __shared__ float red[2][256][N];
     const int cv = C / N;                 // channel vectors per pixel (<= 256, a power of two: C = 64)
-    const int ppi = 256 / cv;             // pixels per iteration of the workgroup
+    const int ppi = 256 / cv;             // blocks per iteration of the workgroup
     const int tx = threadIdx.x % cv, ty = threadIdx.x / cv;
     const int c = tx * N;
     float sc[N], sh[N], mu[N], a1[N], a2[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; mu[i] = mean[c + i]; a1[i] = a2[i] = 0.f; }
-    const int64_t npix = (int64_t)B * H * W;
-    for (int64_t p = (int64_t)blockIdx.x * ppi + ty; p < npix; p += (int64_t)gridDim.x * ppi) {
-        const int iw = (int)(p % W);
-        const int64_t t = p / W;
-        const int ih = (int)(t % H), b = (int)(t / H);
-        float yv[N], g[N];
-        PV<T>::load(y + p * C + c, yv);
-        pooled_dz<T, N>(dpool, arg, yv, sc, sh, b, ih, iw, c, C, OH, OW, g);
+    const int KH = (int)fkh.den, KW = (int)fkw.den, nblocks = B * KH * KW;
+    const int stride = (int)gridDim.x * ppi;
+    int sl, sk, sb, t0;
+    fkw.divmod((uint32_t)stride, t0, sl);
+    fkh.divmod((uint32_t)t0, sb, sk);
+    int q = (int)blockIdx.x * ppi + ty, l, k, b;
+    fkw.divmod((uint32_t)min(q, nblocks - 1), t0, l);
+    fkh.divmod((uint32_t)t0, b, k);
+    for (; q < nblocks; q += stride) {
+        float yv[4][N], g[4][N];
+        const bool rok = 2 * k + 1 < H, cok = 2 * l + 1 < W;
 #pragma unroll
-        for (int i = 0; i < N; ++i) { a1[i] += g[i]; a2[i] += g[i] * (yv[i] - mu[i]); }
+        for (int p = 0; p < 4; ++p) {
+            const int ih = min(2 * k + (p >> 1), H - 1), iw = min(2 * l + (p & 1), W - 1);
+            PV<T>::load(y + (((int64_t)b * H + ih) * W + iw) * C + c, yv[p]);
+        }
+        pooled_dz_2x2<T, N>(dpool, arg, yv, sc, sh, b, k, l, c, C, OH, OW, g);
+        const bool pok[4] = {true, cok, rok, rok && cok};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (pok[p]) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) { a1[i] += g[p][i]; a2[i] += g[p][i] * (yv[p][i] - mu[i]); }
+            }
+        }
+        l += sl;
+        const int cl = l >= KW;
+        l -= cl ? KW : 0;
+        k += sk + cl;
+        const int ck = k >= KH;
+        k -= ck ? KH : 0;
+        b += sb + ck;
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) { red[0][threadIdx.x][i] = a1[i]; red[1][threadIdx.x][i] = a2[i]; }
@@ -817,29 +864,40 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_reduce_kernel(const T
     }
 }
 
-// backward, pass 2: dy = c1 * dz + c2 * y + c3 (the affine form of the BatchNorm backward apply), dz recomputed as in pass 1
+// backward, pass 2: dy = c1 * dz + c2 * y + c3 (the affine form of the BatchNorm backward apply), dz recomputed as in pass 1; a thread per (2 x 2 block, channel vector)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_apply_kernel(const T* __restrict__ dpool, const int8_t* __restrict__ arg, const T* __restrict__ y,
                                                                          const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ c1p,
                                                                          const float* __restrict__ c2p, const float* __restrict__ c3p, T* __restrict__ dy,
-                                                                         int B, int H, int W, int C, int OH, int OW) {
+                                                                         int B, int H, int W, int C, int OH, int OW, FDiv fcv, FDiv fkw, FDiv fkh) {
     constexpr int N = PV<T>::N;
-    const int cv = C / N;
-    const int64_t total = (int64_t)B * H * W * cv;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int c = (int)(e % cv) * N;
-        const int64_t p = e / cv;
-        const int iw = (int)(p % W);
-        const int64_t t = p / W;
-        const int ih = (int)(t % H), b = (int)(t / H);
-        float sc[N], sh[N], yv[N], g[N], o[N];
+    const uint32_t total = (uint32_t)B * fkh.den * fkw.den * fcv.den;   // (< 2^31: checked at launch)
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+        int q, cq, t, l, k, b;
+        fcv.divmod(e, q, cq);
+        fkw.divmod((uint32_t)q, t, l);
+        fkh.divmod((uint32_t)t, b, k);
+        const int c = cq * N;
+        float sc[N], sh[N], k1[N], k2[N], k3[N], yv[4][N], g[4][N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; }
-        PV<T>::load(y + p * C + c, yv);
-        pooled_dz<T, N>(dpool, arg, yv, sc, sh, b, ih, iw, c, C, OH, OW, g);
+        for (int i = 0; i < N; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; k1[i] = c1p[c + i]; k2[i] = c2p[c + i]; k3[i] = c3p[c + i]; }
+        const bool rok = 2 * k + 1 < H, cok = 2 * l + 1 < W;
 #pragma unroll
-        for (int i = 0; i < N; ++i) o[i] = __builtin_fmaf(g[i], c1p[c + i], __builtin_fmaf(yv[i], c2p[c + i], c3p[c + i]));
-        PV<T>::store(dy + p * C + c, o);
+        for (int p = 0; p < 4; ++p) {
+            const int ih = min(2 * k + (p >> 1), H - 1), iw = min(2 * l + (p & 1), W - 1);
+            PV<T>::load(y + (((int64_t)b * H + ih) * W + iw) * C + c, yv[p]);
+        }
+        pooled_dz_2x2<T, N>(dpool, arg, yv, sc, sh, b, k, l, c, C, OH, OW, g);
+        const bool pok[4] = {true, cok, rok, rok && cok};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (pok[p]) {
+                float o[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) o[i] = __builtin_fmaf(g[p][i], k1[i], __builtin_fmaf(yv[p][i], k2[i], k3[i]));
+                PV<T>::store(dy + (((int64_t)b * H + 2 * k + (p >> 1)) * W + 2 * l + (p & 1)) * C + c, o);
+            }
+        }
     }
 }
 }  // namespace
@@ -855,14 +913,19 @@ extern "C" int ralf_bn_relu_maxpool_bwd_reduce(int dtype, const void* dpool, con
     RALF_REQUIRE(dpool && arg && y && scale && shift && mean && part && nblk > 0 && B > 0 && H > 0 && W > 0, "bn_relu_maxpool_bwd_reduce: bad arguments");
     RALF_REQUIRE(C % 8 == 0 && C <= 1024 && (256 % (C / (dtype == RALF_F32 ? 4 : 8))) == 0, "bn_relu_maxpool_bwd_reduce: C / vector width must divide 256");
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_maxpool_bwd_reduce_kernel<T>), dim3(nblk), dim3(256), 0, ST, (const T*)dpool, arg, (const T*)y, scale, shift, mean, part, B, H, W, C, OH, OW));
+    RALF_REQUIRE((int64_t)B * H * W * C < (1ll << 31), "bn_relu_maxpool_bwd_reduce: 32-bit element index");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_maxpool_bwd_reduce_kernel<T>), dim3(nblk), dim3(256), 0, ST, (const T*)dpool, arg, (const T*)y, scale, shift, mean, part, B, H, W, C, OH, OW,
+                                         make_fdiv((uint32_t)((W + 1) / 2)), make_fdiv((uint32_t)((H + 1) / 2))));
     return ralf::check_launch("bn_relu_maxpool_bwd_reduce");
 }
 extern "C" int ralf_bn_relu_maxpool_bwd_apply(int dtype, const void* dpool, const int8_t* arg, const void* y, const float* scale, const float* shift, const float* c1,
                                               const float* c2, const float* c3, void* dy, int B, int H, int W, int C, void* stream) {
     RALF_REQUIRE(dpool && arg && y && scale && shift && c1 && c2 && c3 && dy && B > 0 && H > 0 && W > 0 && C % 8 == 0, "bn_relu_maxpool_bwd_apply: bad arguments");
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_maxpool_bwd_apply_kernel<T>), dim3(grid_for((int64_t)B * H * W * C / 4, 256, 1 << 20)), dim3(256), 0, ST, (const T*)dpool, arg, (const T*)y, scale, shift, c1, c2, c3, (T*)dy, B, H, W, C, OH, OW));
+    RALF_REQUIRE((int64_t)B * H * W * C < (1ll << 31), "bn_relu_maxpool_bwd_apply: 32-bit element index");
+    const int nvec = dtype == RALF_F32 ? 4 : 8, KH = (H + 1) / 2, KW = (W + 1) / 2;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_maxpool_bwd_apply_kernel<T>), dim3(grid_for((int64_t)B * KH * KW * (C / nvec), 256, 1 << 20)), dim3(256), 0, ST, (const T*)dpool, arg, (const T*)y, scale, shift, c1, c2, c3, (T*)dy, B, H, W, C, OH, OW,
+                                         make_fdiv((uint32_t)(C / nvec)), make_fdiv((uint32_t)KW), make_fdiv((uint32_t)KH)));
     return ralf::check_launch("bn_relu_maxpool_bwd_apply");
 }
 
