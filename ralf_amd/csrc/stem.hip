@@ -289,16 +289,25 @@ __global__ __launch_bounds__(512, 2) void stem7x7_wgrad_kernel(const SWParams P)
     }
 }
 
-// dW[co][c][kh][kw] (OIHW fp32, c < 4, kw < 7) = sum over the workgroups' blocks, in order
+// dW[co][c][kh][kw] (OIHW fp32, c < 4, kw < 7) = sum over the workgroups' blocks in a FIXED order: 64 elements per workgroup, four slices of the blocks
+// (b = slice, slice + 4, ...) summed by four waves and combined as (s0 + s1) + (s2 + s3).  (One thread per element over all 256 blocks was a chain of 256
+// dependent 114-KB-strided loads on 112 workgroups: 65 us at the very end of the backward, in front of the optimizer.)
 __global__ __launch_bounds__(256) void stem7x7_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dW, int accumulate) {
-    const int e = blockIdx.x * 256 + threadIdx.x;   // index into [co][kh][kw 0..7][c 0..7]
-    if (e >= 64 * 7 * 64) return;
-    const int c = e & 7, kw = (e >> 3) & 7, kh = (e >> 6) % 7, co = (e >> 6) / 7;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;   // index into [co][kh][kw 0..7][c 0..7]  (64 * 7 * 64 elements: a multiple of 64)
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * (64 * 7 * 64) + e];
-    if (c < 4 && kw < 7) {
-        float* o = dW + ((co * 4 + c) * 7 + kh) * 7 + kw;
-        *o = accumulate ? *o + s : s;
+#pragma unroll 8
+    for (int b = slice; b < nblk; b += 4) s += partial[(int64_t)b * (64 * 7 * 64) + e];
+    red[slice][lane] = s;
+    __syncthreads();
+    if (slice == 0) {
+        s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        const int c = e & 7, kw = (e >> 3) & 7, kh = (e >> 6) % 7, co = (e >> 6) / 7;
+        if (c < 4 && kw < 7) {
+            float* o = dW + ((co * 4 + c) * 7 + kh) * 7 + kw;
+            *o = accumulate ? *o + s : s;
+        }
     }
 }
 }  // namespace
@@ -328,7 +337,7 @@ extern "C" int ralf_stem7x7_wgrad(const void* x, const void* dy, float* dW, int 
     const int grid = (int)(nt < SW_GRID ? nt : SW_GRID);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(stem7x7_wgrad_kernel, dim3(grid), dim3(512), 0, st, P);
-    hipLaunchKernelGGL(stem7x7_wgrad_reduce_kernel, dim3((64 * 7 * 64 + 255) / 256), dim3(256), 0, st, (const float*)workspace, grid, dW, accumulate);
+    hipLaunchKernelGGL(stem7x7_wgrad_reduce_kernel, dim3(64 * 7 * 64 / 64), dim3(256), 0, st, (const float*)workspace, grid, dW, accumulate);
     return ralf::check_launch("stem7x7_wgrad");
 }
 
