@@ -373,8 +373,12 @@ __device__ __forceinline__ void relayout_tile(const RalfConvRelayoutJob& J, int 
     const int ni = min(TI, J.Ci - i0), no = min(RL_O, J.Co - o0);
     const float* in = (const float*)J.w;
     const int run = ni * KK;                       // contiguous floats per output channel
+    // e / d for e < 8 * 576 and d <= 576 through the float reciprocal: (e + 0.5) / d stays >= 0.5 / 576 away from an integer, the product's error is
+    // ~1e-6 -- exact.  (Integer divisions by run-time values were most of this kernel: six per two-byte element.)
+    auto qdiv = [](int e, float inv) { return (int)(((float)e + 0.5f) * inv); };
+    const float inv_run = 1.f / (float)run;
     for (int e = threadIdx.x; e < RL_O * run; e += 256) {
-        const int o = e / run, r = e - o * run;
+        const int o = qdiv(e, inv_run), r = e - o * run;
         lds[o * RL_LS + r] = o < no ? in[((int64_t)(o0 + o) * J.Ci + i0) * KK + r] : 0.f;
     }
     __syncthreads();
@@ -382,14 +386,16 @@ __device__ __forceinline__ void relayout_tile(const RalfConvRelayoutJob& J, int 
     TD* o2 = (TD*)J.ikwo;
     // ohwi: [o][t][i0 + i]; channels beyond Ci (up to Cip) are zero
     const int nip = (i0 + TI >= J.Ci) ? (J.Cip - i0) : TI;     // the last i-tile also writes the padding
+    const float inv_nip = 1.f / (float)nip, inv_kk = 1.f / (float)KK;
     for (int e = threadIdx.x; e < no * KK * nip; e += 256) {
-        const int i = e % nip, t = (e / nip) % KK, o = e / (nip * KK);
+        const int q = qdiv(e, inv_nip), i = e - q * nip, o = qdiv(q, inv_kk), t = q - o * KK;
         const float v = i < ni ? lds[o * RL_LS + i * KK + t] : 0.f;
         o1[((int64_t)(o0 + o) * KK + t) * J.Cip + i0 + i] = (TD)v;
     }
     // ikwo: [i0 + i][t][o0 + o]
+    const float inv_no = 1.f / (float)no;
     for (int e = threadIdx.x; e < ni * KK * no; e += 256) {
-        const int o = e % no, t = (e / no) % KK, i = e / (no * KK);
+        const int q = qdiv(e, inv_no), o = e - q * no, i = qdiv(q, inv_kk), t = q - i * KK;
         o2[((int64_t)(i0 + i) * KK + t) * J.Co + o0 + o] = (TD)lds[o * RL_LS + i * KK + t];
     }
     __syncthreads();
