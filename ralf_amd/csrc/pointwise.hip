@@ -330,32 +330,6 @@ __global__ __launch_bounds__(256) void permute4_pack8_kernel(const TS* __restric
         }
     }
 }
-// ... FOUR consecutive pixels of a row per thread (d2 % 4 == 0, planes 16-byte aligned): a 16-byte load per channel plane and four 16-byte stores, one
-// decomposition of the pixel index per four pixels (fast divisions) -- the one-pixel form reads 4 bytes per lane and instruction (3.2 TB/s of its 134 MB at
-// the head of every train step)
-__global__ __launch_bounds__(256) void permute4_pack8x4_kernel(const float* __restrict__ in, bf16* __restrict__ out, int d0, int d1, int d2, int64_t s0, int64_t s1, int64_t s3,
-                                                                int valid3, FDiv fq, FDiv f1) {
-    typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
-    const uint32_t total = (uint32_t)d0 * d1 * fq.den;   // groups of four pixels (< 2^31: checked at launch)
-    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
-        int t, q, i0, i1;
-        fq.divmod(e, t, q);
-        f1.divmod((uint32_t)t, i0, i1);
-        const int64_t base = i0 * s0 + i1 * s1 + 4 * q;
-        float4 v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const float4*>(in + base + (c < valid3 ? c : valid3 - 1) * s3);
-        const float* f = reinterpret_cast<const float*>(v);
-        bf16* o = out + ((int64_t)(i0 * d1 + i1) * d2 + 4 * q) * 8;
-#pragma unroll
-        for (int px = 0; px < 4; ++px) {
-            bf16x8v w;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) w[c] = (__bf16)((c < valid3 && c < 4) ? f[c * 4 + px] : 0.f);
-            *reinterpret_cast<bf16x8v*>(o + px * 8) = w;
-        }
-    }
-}
 
 // many permute4 jobs in ONE launch (the per-step re-layout of every 3x3 convolution weight: ~40 launches of a few
 // microseconds each otherwise); jobs[] lives in device memory, job j owns workgroups [first_block[j], first_block[j+1])
@@ -390,7 +364,8 @@ __global__ __launch_bounds__(256) void permute4_batched_kernel(const RalfPermute
 // A workgroup owns a tile of 8 output channels x 64 input channels (all taps): the reads are runs of 64*KK contiguous floats per
 // output channel, the writes 128-byte runs of i (ohwi) and 16-byte vectors of o (ikwo).  (The generic element-wise permute read
 // with a stride and divided three times per element: 109 us per step for the 17 weights of the ResNet-50 + FPN, 45 MB.)
-constexpr int RL_O = 8, RL_LS = 577;   // 8 output channels x (i-tile * KK <= 576) floats (+1: bank spread)
+constexpr int RL_O = 8, RL_LS = 577;   // 8 output channels x (i-tile * KK <= 576) floats (+1: bank spread).  (32 channels per tile -- 64-byte instead of 16-byte runs in the
+                                       // [i][tap][o] image, 74 KB of LDS -- ran at 127 us against 58.)
 __host__ __device__ __forceinline__ int rl_itile(int KK) { return KK <= 9 ? 64 : (576 / KK > 0 ? 576 / KK : 1); }
 template <typename TD>
 __device__ __forceinline__ void relayout_tile(const RalfConvRelayoutJob& J, int tile, float* lds) {
@@ -399,8 +374,8 @@ __device__ __forceinline__ void relayout_tile(const RalfConvRelayoutJob& J, int 
     const int ni = min(TI, J.Ci - i0), no = min(RL_O, J.Co - o0);
     const float* in = (const float*)J.w;
     const int run = ni * KK;                       // contiguous floats per output channel
-    // e / d for e < 8 * 576 and d <= 576 through the float reciprocal: (e + 0.5) / d stays >= 0.5 / 576 away from an integer, the product's error is
-    // ~1e-6 -- exact.  (Integer divisions by run-time values were most of this kernel: six per two-byte element.)
+    // e / d for e < 32 * 576 and d <= 576 through the float reciprocal: (e + 0.5) / d stays >= 0.5 / 576 away from an integer, the product's error is
+    // ~4e-6 -- exact.  (Integer divisions by run-time values were most of this kernel: six per two-byte element.)
     auto qdiv = [](int e, float inv) { return (int)(((float)e + 0.5f) * inv); };
     const float inv_run = 1.f / (float)run;
     for (int e = threadIdx.x; e < RL_O * run; e += 256) {
@@ -717,12 +692,6 @@ extern "C" int ralf_copy2d(int src_dtype, int dst_dtype, const void* src, void* 
 extern "C" int ralf_permute4(int src_dtype, int dst_dtype, const void* in, void* out, int d0, int d1, int d2, int d3, int64_t s0, int64_t s1, int64_t s2, int64_t s3,
                              int valid3, void* stream) {
     RALF_REQUIRE(in && out && d0 > 0 && d1 > 0 && d2 > 0 && d3 > 0, "permute4: bad arguments");
-    if (d3 == 8 && src_dtype == RALF_F32 && dst_dtype == RALF_BF16 && s2 == 1 && valid3 <= 4 && d2 % 4 == 0 && (((uintptr_t)out) & 15) == 0 && (((uintptr_t)in) & 15) == 0 &&
-        s0 % 4 == 0 && s1 % 4 == 0 && s3 % 4 == 0 && (int64_t)d0 * d1 * d2 < (1ll << 31)) {   // the image batch (NCHW fp32, <= 4 channels -> NHWC bf16 x 8): four pixels per thread
-        hipLaunchKernelGGL(permute4_pack8x4_kernel, dim3(grid_for((int64_t)d0 * d1 * (d2 / 4), 256, 1 << 20)), dim3(256), 0, ST, (const float*)in, (bf16*)out, d0, d1, d2, s0, s1, s3, valid3,
-                           make_fdiv((uint32_t)(d2 / 4)), make_fdiv((uint32_t)d1));
-        return ralf::check_launch("permute4");
-    }
     if (d3 == 8 && src_dtype == RALF_F32 && s2 == 1 && (((uintptr_t)out) & 31) == 0) {   // pixel packing (see permute4_pack8_kernel)
         const dim3 gp(grid_for((int64_t)d0 * d1 * d2));
         if (dst_dtype == RALF_F32) hipLaunchKernelGGL((permute4_pack8_kernel<float, float>), gp, dim3(256), 0, ST, (const float*)in, (float*)out, d0, d1, d2, s0, s1, s2, s3, valid3);
