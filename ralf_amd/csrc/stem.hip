@@ -31,27 +31,29 @@ struct SParams {
 };
 
 __global__ __launch_bounds__(512, 2) void stem7x7_fwd_kernel(const SParams P) {
-    __shared__ __attribute__((aligned(16))) bf16 patch[PVEC * 8];
+    // the patch keeps the FOUR real channels of a pixel (8 bytes; the image is stored with 8, the upper four zero): a 16-byte operand then spans two pixels, a
+    // k-step of the matrix core four taps x four channels, and a kernel row takes 2 k-steps (taps 0 .. 7, the eighth a zero tap) instead of 4 -- 14 MFMAs per
+    // 32 x 32 output tile instead of 28, half of which multiplied zeros
+    __shared__ __attribute__((aligned(16))) bf16 patch[PVEC * 4 + 16];   // (+ slack: the zero tap of the last pixel reads one pixel past the row)
     __shared__ __attribute__((aligned(16))) bf16 ost[TPX * OLD];
     __shared__ float red[2][8][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pxf = wave & 3, cof = wave >> 2, l31 = lane & 31, lh = lane >> 5;
 
-    // ---- weights -> registers: fragment (kh, j): row co = 32 cof + l31, the 8 channels of tap (kh, kw = 2 j + lh); kw = 7 is the zero tap ----
-    bf16x8 wf[PROWS][4];
+    // ---- weights -> registers: fragment (kh, j): row co = 32 cof + l31, taps kw = 4 j + 2 lh, + 1 with their 4 real channels; kw = 7 is the zero tap ----
+    bf16x8 wf[PROWS][2];
     {
         const bf16* wr = P.w + (int64_t)(cof * 32 + l31) * (7 * 7 * 8);
+        typedef __bf16 bf16x4w __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int kh = 0; kh < PROWS; ++kh)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kw = 2 * j + lh;
-                bf16x8 v = *reinterpret_cast<const bf16x8*>(wr + (kh * 7 + (kw < 7 ? kw : 6)) * 8);
-                if (kw >= 7) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = (bf16)0.f;
-                }
-                wf[kh][j] = v;
+            for (int j = 0; j < 2; ++j) {
+                const int kw = 4 * j + 2 * lh;
+                const bf16x4w lo = *reinterpret_cast<const bf16x4w*>(wr + (kh * 7 + kw) * 8);
+                bf16x4w hi = *reinterpret_cast<const bf16x4w*>(wr + (kh * 7 + (kw + 1 < 7 ? kw + 1 : 6)) * 8);
+                if (kw + 1 >= 7) hi = bf16x4w{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+                wf[kh][j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
     }
     // ---- this thread's patch slots: vector v = tid + 512 i -> (row kh, column pc); input pixel (2 oy - 3 + kh, 2 ox0 - 3 + pc) ----
@@ -86,31 +88,33 @@ __global__ __launch_bounds__(512, 2) void stem7x7_fwd_kernel(const SParams P) {
         for (int i = 0; i < PSLOTS; ++i) {
             if ((s_used >> i) & 1u) {
                 const bool ok = (rok >> i) & 1u;
-                u32x4 v = rp[i];
-                v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-                *reinterpret_cast<u32x4*>(&patch[(s_kh[i] * PW + s_pc[i]) * 8]) = v;
+                const u32x4 v = rp[i];
+                uint2 lo;
+                lo.x = ok ? v.x : 0u; lo.y = ok ? v.y : 0u;
+                *reinterpret_cast<uint2*>(&patch[(s_kh[i] * PW + s_pc[i]) * 4]) = lo;
             }
         }
     };
 
     int t = blockIdx.x;
     if (t < P.ntiles) gload(t);
+    if (tid < 4) *reinterpret_cast<uint2*>(&patch[PVEC * 4 + tid * 4]) = uint2{0u, 0u};   // (the slack behind the last row)
     for (; t < P.ntiles; t += gridDim.x) {
         __syncthreads();            // the previous tile's reads of patch / ost are done
         stage();
         __syncthreads();
         const int tn = t + gridDim.x;
         if (tn < P.ntiles) gload(tn);
-        // ---- 28 k-steps: pixel operand = 16 bytes behind patch pixel (kh, 2 px + 2 j + lh) ----
+        // ---- 14 k-steps: pixel operand = the 16 bytes (two pixels x four channels) behind patch pixel (kh, 2 px + 4 j + 2 lh) ----
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const bf16* ap = patch + (2 * (pxf * 32 + l31) + lh) * 8;
+        const bf16* ap = patch + (2 * (pxf * 32 + l31) + 2 * lh) * 4;
 #pragma unroll
         for (int kh = 0; kh < PROWS; ++kh)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + (kh * PW + 2 * j) * 8);
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + (kh * PW + 4 * j) * 4);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kh][j], a, acc, 0, 0, 0);
             }
         // ---- tile -> LDS [128 px][64 co] (a lane holds pixel 32 pxf + l31, channels 32 cof + 8 g + 4 lh + 0..3) ----
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void stem7x7_fwd_kernel(const SParams P) {
 // Same tiles and the same patch: per output-row tile the 128 x 64 slice of dy and the 7-row input patch are staged once; for a fixed kernel row kh
 // the (kw, c) axis of the weight block is the 64 contiguous values behind patch pixel (kh, 2 ox), so the x operand of the contraction over pixels is
 // a [k = pixel][n = 64] tile whose k-rows lie 32 bytes apart in the patch -- read through ds_read_b64_tr_b16 like the dy tile.  A workgroup (8 waves:
-// co half x kernel-row group {0,1} {2,3} {4,5} {6}) keeps the whole 64 x 7 x 64 block in registers over its tiles and writes it once; a second
+// co half x kernel-row group {0,1} {2,3} {4,5} {6}) keeps the whole 64 x 7 x 32 block in registers over its tiles and writes it once; a second
 // kernel sums the workgroups' blocks in order into the OIHW fp32 gradient (4 real channels, 7 real taps).
 constexpr int DLD = 64 + 8;      // dy tile row stride (elements)
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -171,7 +175,9 @@ struct SWParams {
 };
 
 __global__ __launch_bounds__(512, 2) void stem7x7_wgrad_kernel(const SWParams P) {   // (two workgroups per CU at 128 registers spilled and ran 199 us instead of 137)
-    __shared__ __attribute__((aligned(16))) bf16 patch[PVEC * 8 + 64];   // (+ slack: the zero-tap columns of the last pixels read just past the last row)
+    // (the patch keeps the FOUR real channels of a pixel, as in the forward: the (kw, c) axis of a kernel row is 8 taps x 4 channels = 32 values, ONE 32-wide
+    //  fragment per kernel row instead of two, half of which were the zero channels)
+    __shared__ __attribute__((aligned(16))) bf16 patch[PVEC * 4 + 64];   // (+ slack: the zero-tap columns of the last pixels read just past the last row)
     __shared__ __attribute__((aligned(16))) bf16 dyt[TPX * DLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cof = wave & 1, khg = wave >> 1;                 // co half; kernel rows 2 khg, 2 khg + 1 (khg = 3: row 6 only)
@@ -218,9 +224,10 @@ __global__ __launch_bounds__(512, 2) void stem7x7_wgrad_kernel(const SWParams P)
         for (int i = 0; i < PSLOTS; ++i) {
             if ((s_used >> i) & 1u) {
                 const bool ok = (rok >> i) & 1u;
-                u32x4 v = rp[i];
-                v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-                *reinterpret_cast<u32x4*>(&patch[(s_kh[i] * PW + s_pc[i]) * 8]) = v;
+                const u32x4 v = rp[i];
+                uint2 lo;
+                lo.x = ok ? v.x : 0u; lo.y = ok ? v.y : 0u;
+                *reinterpret_cast<uint2*>(&patch[(s_kh[i] * PW + s_pc[i]) * 4]) = lo;
             }
         }
 #pragma unroll
@@ -231,17 +238,15 @@ __global__ __launch_bounds__(512, 2) void stem7x7_wgrad_kernel(const SWParams P)
             *reinterpret_cast<u32x4*>(&dyt[((tid >> 3) + 64 * h) * DLD + (tid & 7) * 8]) = v;
         }
     };
-    if (tid < 64) patch[PVEC * 8 + tid] = (bf16)0.f;   // the slack behind the patch
+    if (tid < 64) patch[PVEC * 4 + tid] = (bf16)0.f;   // the slack behind the patch
 
     // transpose-read geometry (gemm_impl.h): a 16-lane group reads [4 k-rows][16 rows]
     const int lh = lane >> 5, trL = lane & 15, tr_rowblk = ((lane >> 4) & 1) * 16, tr_k = lh * 8 + (trL >> 2), tr_c = (trL & 3) * 4;
-    f32x16 acc[2][2];   // [kernel row of the group][n fragment: (kw, c) 0..31 / 32..63]
+    f32x16 acc[2];   // [kernel row of the group]: co x the 32 (kw, c) values of the row
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][n][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
     int t = blockIdx.x;
     if (t < P.ntiles) gload(t);
@@ -262,29 +267,24 @@ __global__ __launch_bounds__(512, 2) void stem7x7_wgrad_kernel(const SWParams P)
             for (int kk = 0; kk < 2; ++kk) {
                 if (kk < nkh) {   // (wave-uniform)
                     const int kh = 2 * khg + kk;
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        const bf16* qb = patch + (kh * PW + 2 * kr) * 8 + n * 32 + tr_rowblk + tr_c;   // k-row stride = 2 pixels = 16 elements
-                        const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qb));
-                        const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qb + 4 * 16));
-                        const bf16x8 b = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
-                        acc[kk][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc[kk][n], 0, 0, 0);
-                    }
+                    const bf16* qb = patch + (kh * PW + 2 * kr) * 4 + tr_rowblk + tr_c;   // k-row stride = 2 pixels = 8 elements
+                    const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qb));
+                    const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, qb + 4 * 8));
+                    const bf16x8 b = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[kk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc[kk], 0, 0, 0);
                 }
             }
         }
     }
-    // ---- this workgroup's block -> partial[blockIdx.x][co][kh][(kw, c) 0..63] ----
+    // ---- this workgroup's block -> partial[blockIdx.x][co][kh][(kw, c) 0..31] ----
     const int co = cof * 32 + (lane & 31);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         if (kk < nkh) {
-            float* o = P.partial + (((int64_t)blockIdx.x * 64 + co) * 7 + (2 * khg + kk)) * 64 + 4 * lh;
+            float* o = P.partial + (((int64_t)blockIdx.x * 64 + co) * 7 + (2 * khg + kk)) * 32 + 4 * lh;
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(o + n * 32 + 8 * g) = make_float4(acc[kk][n][4 * g], acc[kk][n][4 * g + 1], acc[kk][n][4 * g + 2], acc[kk][n][4 * g + 3]);
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(o + 8 * g) = make_float4(acc[kk][4 * g], acc[kk][4 * g + 1], acc[kk][4 * g + 2], acc[kk][4 * g + 3]);
         }
     }
 }
@@ -295,16 +295,16 @@ __global__ __launch_bounds__(512, 2) void stem7x7_wgrad_kernel(const SWParams P)
 __global__ __launch_bounds__(256) void stem7x7_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dW, int accumulate) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + lane;   // index into [co][kh][kw 0..7][c 0..7]  (64 * 7 * 64 elements: a multiple of 64)
+    const int e = blockIdx.x * 64 + lane;   // index into [co][kh][kw 0..7][c 0..3]  (64 * 7 * 32 elements: a multiple of 64)
     float s = 0.f;
 #pragma unroll 8
-    for (int b = slice; b < nblk; b += 4) s += partial[(int64_t)b * (64 * 7 * 64) + e];
+    for (int b = slice; b < nblk; b += 4) s += partial[(int64_t)b * (64 * 7 * 32) + e];
     red[slice][lane] = s;
     __syncthreads();
     if (slice == 0) {
         s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-        const int c = e & 7, kw = (e >> 3) & 7, kh = (e >> 6) % 7, co = (e >> 6) / 7;
-        if (c < 4 && kw < 7) {
+        const int c = e & 3, kw = (e >> 2) & 7, kh = (e >> 5) % 7, co = (e >> 5) / 7;
+        if (kw < 7) {
             float* o = dW + ((co * 4 + c) * 7 + kh) * 7 + kw;
             *o = accumulate ? *o + s : s;
         }
@@ -318,7 +318,7 @@ extern "C" size_t ralf_stem7x7_wgrad_workspace_bytes(int B, int IH, int IW) {
     if (B <= 0 || IH < 7 || IW < 7) return 0;
     const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
     const int64_t nt = (int64_t)B * OH * ((OW + TPX - 1) / TPX);
-    return (size_t)(nt < SW_GRID ? nt : SW_GRID) * 64 * 7 * 64 * sizeof(float);
+    return (size_t)(nt < SW_GRID ? nt : SW_GRID) * 64 * 7 * 32 * sizeof(float);
 }
 
 /* x [B, IH, IW, 8] bf16, dy [B, OH, OW, 64] bf16 -> dW [64][4][7][7] fp32 (OIHW; = or +=) */
@@ -337,7 +337,7 @@ extern "C" int ralf_stem7x7_wgrad(const void* x, const void* dy, float* dW, int 
     const int grid = (int)(nt < SW_GRID ? nt : SW_GRID);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(stem7x7_wgrad_kernel, dim3(grid), dim3(512), 0, st, P);
-    hipLaunchKernelGGL(stem7x7_wgrad_reduce_kernel, dim3(64 * 7 * 64 / 64), dim3(256), 0, st, (const float*)workspace, grid, dW, accumulate);
+    hipLaunchKernelGGL(stem7x7_wgrad_reduce_kernel, dim3(64 * 7 * 32 / 64), dim3(256), 0, st, (const float*)workspace, grid, dW, accumulate);
     return ralf::check_launch("stem7x7_wgrad");
 }
 
