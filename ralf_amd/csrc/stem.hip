@@ -174,7 +174,7 @@ struct SWParams {
     int B, IH, IW, OH, OW, segs, ntiles;
 };
 
-__global__ __launch_bounds__(512, 2) void stem7x7_wgrad_kernel(const SWParams P) {   // (two workgroups per CU at 128 registers spilled and ran 199 us instead of 137)
+__global__ __launch_bounds__(512, 4) void stem7x7_wgrad_kernel(const SWParams P) {   // (two workgroups per CU: with the 8-channel patch's 64 accumulators that spilled and ran 199 us instead of 137)
     // (the patch keeps the FOUR real channels of a pixel, as in the forward: the (kw, c) axis of a kernel row is 8 taps x 4 channels = 32 values, ONE 32-wide
     //  fragment per kernel row instead of two, half of which were the zero channels)
     __shared__ __attribute__((aligned(16))) bf16 patch[PVEC * 4 + 64];   // (+ slack: the zero-tap columns of the last pixels read just past the last row)
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void stem7x7_wgrad_reduce_kernel(const float* 
 }
 }  // namespace
 
-constexpr int SW_GRID = 256;   // one persistent workgroup per CU
+constexpr int SW_GRID = 512;   // persistent workgroups, two per CU (92 registers since the accumulators halved: 81 -> 68 us with the reduction)
 
 extern "C" size_t ralf_stem7x7_wgrad_workspace_bytes(int B, int IH, int IW) {
     if (B <= 0 || IH < 7 || IW < 7) return 0;
@@ -353,7 +353,8 @@ extern "C" int ralf_stem7x7_fwd(const void* x, const void* w, void* y, float* pa
     const int64_t nt = (int64_t)B * P.OH * P.segs;
     RALF_REQUIRE(nt < (1ll << 30) && (int64_t)B * IH * IW * 8 < (1ll << 40), "stem7x7_fwd: problem too large");
     P.ntiles = (int)nt;
-    const int grid = (int)(nt < 256 ? nt : 256);   // one persistent workgroup per CU (the weights sit in its registers)
+    static const int fwd_grid = [] { const char* e = getenv("RALF_STEM_GRID"); return e ? atoi(e) : 512; }();   // two per CU: one's staging / statistics phases under the other's products (90 -> 80 us; three or four: 85-87)
+    const int grid = (int)(nt < fwd_grid ? nt : fwd_grid);   // persistent workgroups (the weights sit in their registers)
     hipLaunchKernelGGL(stem7x7_fwd_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, P);
     return ralf::check_launch("stem7x7_fwd");
 }
