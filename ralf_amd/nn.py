@@ -728,8 +728,14 @@ class ResnetBackbone(nn.Module):
         infer = rt.fold_bn and not rt.training and not torch.is_grad_enabled()
         if infer:
             self._refresh_fold(img.device)
-            x = RF.conv_bn_infer(x, b.conv1.weight, b.bn1.fold[0], b.bn1.fold[1], b.conv1.stride, b.conv1.pad, True, None, rt)
-            x = RF.MaxPoolFn.apply(x)
+            if rt.stem_direct and rt.fused_stem and x.dtype == torch.bfloat16 and tuple(b.conv1.weight.shape) == (64, 4, 7, 7):
+                # the stem in direct form (ops.stem7x7_fwd) and ONE pass for the folded BatchNorm + ReLU + max-pool (the training forward's two kernels with the
+                # eval-mode scale / shift): at B = 256 the general 8-channel gather + a separate max-pool took 633 + 174 us
+                y, _ = ops.stem7x7_fwd(x, rt.lp(b.conv1.weight, "ohwi"), want_stats=False)
+                x, _ = ops.bn_relu_maxpool_fwd(y, b.bn1.fold[0], b.bn1.fold[1])
+            else:
+                x = RF.conv_bn_infer(x, b.conv1.weight, b.bn1.fold[0], b.bn1.fold[1], b.conv1.stride, b.conv1.pad, True, None, rt)
+                x = RF.MaxPoolFn.apply(x)
         elif rt.training and rt.fused_stem:
             # training: BatchNorm (batch statistics) + ReLU + max-pool in one pass over the convolution output (RF.StemBNReluPoolFn)
             x, st = b.conv1(x, rt, stats=True)
