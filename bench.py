@@ -167,10 +167,16 @@ def bench_knn(device):
     from ralf_amd.retrieval.knn import FlatIPIndex, knn_topk_ip_two_stage_fused
     v2, i2, nfb2, ws2 = knn_topk_ip_two_stage_fused(X, Xb, Q, k, xn)
     assert torch.equal(i0, i2) and torch.equal(v0, v2), "two-stage search (one library call) must equal the exhaustive scan"
-    t2 = _time_gpu(lambda: knn_topk_ip_two_stage_fused(X, Xb, Q, k, xn, workspace=ws2), iters=10)
-    out["nq1024_two_stage"] = {"qps": nq / t2, "us_per_call": t2 * 1e6, "fallback_queries": nfb2, "bf16_coarse_TFLOPs": 2.0 * nq * N * D / t2 / 1e12,
-                               "note": "identical results to nq1024 (checked in this run); coarse pass on the bf16 matrix cores (256 x 256 tiles), every launch of the "
-                                       "search from ONE library call (ralf_knn_topk_ip_two_stage) + one read of the certificate flags"}
+    v3, i3, nfb3, ws2 = knn_topk_ip_two_stage_fused(X, Xb, Q, k, xn, workspace=ws2, filtered=True)
+    assert torch.equal(i0, i3) and torch.equal(v0, v3), "two-stage search (filtered coarse pass) must equal the exhaustive scan"
+    t2d = _time_gpu(lambda: knn_topk_ip_two_stage_fused(X, Xb, Q, k, xn, workspace=ws2), iters=10)
+    t2 = _time_gpu(lambda: knn_topk_ip_two_stage_fused(X, Xb, Q, k, xn, workspace=ws2, filtered=True), iters=10)
+    out["nq1024_two_stage"] = {"qps": nq / t2, "us_per_call": t2 * 1e6, "fallback_queries": nfb3, "bf16_coarse_TFLOPs": 2.0 * nq * N * D / t2 / 1e12,
+                               "dense_coarse_pass_us_per_call": t2d * 1e6, "dense_fallback_queries": nfb2,
+                               "note": "identical results to nq1024 (checked in this run); coarse pass on the bf16 matrix cores (256 x 256 tiles) with the threshold "
+                                       "filter in its epilogue (no [nq, N] score matrix: ralf_knn_topk_ip_two_stage_filtered, what FlatIPIndex.search takes from 640 "
+                                       "queries; dense_coarse_pass_us_per_call = ralf_knn_topk_ip_two_stage, the form with the score matrix), every launch of the "
+                                       "search from ONE library call + one read of the certificate flags"}
     # the front end (retrieval.FlatIPIndex.search = faiss.IndexFlat.search's place) at the batch sizes between the two regimes: two-stage from 40 queries
     index = FlatIPIndex(X, device=str(device))
     for nq in (64, 128, 256):

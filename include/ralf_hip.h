@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RALF_ABI_VERSION 25
+#define RALF_ABI_VERSION 26
 #define RALF_OK 0
 #define RALF_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define RALF_ERR_WORKSPACE (-2) /* workspace too small */
@@ -70,6 +70,13 @@ int ralf_knn_rownorms(const float* X, const void* Xb_bf16, int64_t R, int D, flo
 size_t ralf_knn_two_stage_workspace_bytes(int64_t n_db, int dim, int nq, int pool);
 int ralf_knn_topk_ip_two_stage(const float* X, const void* Xb_bf16, int64_t n_db, int dim, const float* Q, int nq, int k, int pool, const float* xnorms,
                                int64_t* out_idx, float* out_score, int32_t* bad, void* workspace, size_t workspace_bytes, void* stream);
+/* The same search without the [nq, n_db] coarse score matrix (written and re-read by the selection: 252 MB at BASELINE config 4's 1024 queries): a first
+ * product against the first min(n_db, 4096) rows gives every query a lower bound of its (pool+1)-th best coarse score, the product over the whole index keeps
+ * the scores at or above it in slot lists (RalfGemmDesc.flt_*, 16 slots per query and column tile), the selection reads the slots.  Same arguments, workspace
+ * size and results; bad[q] is ALSO set when a column tile of the query had more hits than slots or fewer than pool + 1 rows reached the bound (an index whose
+ * rows are ordered by similarity floods tiles: the caller should route such an index through ralf_knn_topk_ip_two_stage). */
+int ralf_knn_topk_ip_two_stage_filtered(const float* X, const void* Xb_bf16, int64_t n_db, int dim, const float* Q, int nq, int k, int pool, const float* xnorms,
+                                        int64_t* out_idx, float* out_score, int32_t* bad, void* workspace, size_t workspace_bytes, void* stream);
 /* the candidate slots a filtered coarse pass wrote (RalfGemmDesc.flt_*: list int32 [nq][T][cap][2] = {row, score bits}, count int32 [nq][T]) as
  * the dense pair the selection kernels take: rows int64 [nq][T * cap] (0 in unused slots), scores fp32 [nq][T * cap] (-inf in unused slots);
  * over int32 [nq] (may be NULL, ZEROED by the caller) is set to 1 where a tile's count exceeds cap (the list lost candidates).
@@ -175,7 +182,7 @@ typedef struct RalfGemmDesc {
      * ignored).  The coarse bf16 pass of the two-stage top-k search (ralf_amd/retrieval/knn.py; replaces writing and re-reading the [nq, N]
      * score matrix, 252 MB at BASELINE config 4): with a per-query lower bound of its (pool+1)-th best score as threshold the lists hold a
      * superset of the pool.  bf16, A and B k-contiguous, aligned interior path, one batch, no split-K, plain epilogue (alpha only). */
-    const float* flt_thresh; int* flt_count; void* flt_list; int flt_cap, flt_pad_;
+    const float* flt_thresh; int* flt_count; void* flt_list; int flt_cap, flt_thresh_ld;   /* row m's threshold = flt_thresh[m * flt_thresh_ld] (0 = 1) */
     /* LayerNorm in front of a FEW-ROW product (ln_g NULL = off): A = LayerNorm(A rows; ln_g, ln_b, ln_eps) rounded to bf16, applied by every tile's
      * wave to the 32 rows it has just loaded -- replaces ralf_layernorm_fwd + ralf_gemm for the LayerNorm -> linear pairs of a KV-cached decode
      * step (norm3 -> linear1, head LayerNorm -> vocabulary matrix: common/common.py:25-34,52-56), one launch instead of two at batch 256.
@@ -188,7 +195,7 @@ typedef struct RalfGemmDesc {
 } RalfGemmDesc;
 size_t ralf_gemm_workspace_bytes(const RalfGemmDesc* d);
 int ralf_gemm(const RalfGemmDesc* d, void* workspace, size_t workspace_bytes, void* stream);
-int ralf_gemm_filter_tile(const RalfGemmDesc* d);   /* column-tile width (64 or 128) ralf_gemm will use for this flt_* product; <= 0 on error */
+int ralf_gemm_filter_tile(const RalfGemmDesc* d);   /* column-tile width (64, 128 or 256) ralf_gemm will use for this flt_* product; <= 0 on error */
 /* Which form ralf_gemm takes for a gather = 1 product that is a 3 x 3 / stride-1 / pad-1 convolution (timm Bottleneck.conv2, common/image.py:39-48; forward
  * or data gradient): 0 = the tap gather, 1 / 2 / 3 = the tile's input patch resident in LDS on 128 x 128 / 256 x 128 / 256 x 64 tiles (same results bit for
  * bit; tests and tools ask).  Only shape, dtype, layout and geometry fields of the descriptor are read.  < 0 on error. */

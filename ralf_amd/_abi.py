@@ -20,6 +20,7 @@ SIGNATURES = {
     "ralf_decode_token_limits": (i32, [vp, vp]),
     "ralf_knn_two_stage_workspace_bytes": (sz, [i64, i32, i32, i32]),
     "ralf_knn_topk_ip_two_stage": (i32, [vp, vp, i64, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "ralf_knn_topk_ip_two_stage_filtered": (i32, [vp, vp, i64, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "ralf_knn_list_unpack": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "ralf_knn_gather_rows": (i32, [vp, i32, vp, i32, i32, vp, vp]),
 }
@@ -94,7 +95,7 @@ class RalfGemmDesc(ctypes.Structure):
         + [("sBias0", i64), ("sBk", i64), ("kseg", i32), ("colscale", vp)]
         + [("bnb_x", vp), ("bnb_mask", vp), ("bnb_mean", vp), ("bnb_part", vp)]
         + [("at_mode", i32), ("at_relu", i32), ("at_a2", vp), ("at_c1", vp), ("at_c2", vp), ("at_c3", vp), ("at_out", vp), ("at_mask", vp)]
-        + [("flt_thresh", vp), ("flt_count", vp), ("flt_list", vp), ("flt_cap", i32), ("flt_pad_", i32)]
+        + [("flt_thresh", vp), ("flt_count", vp), ("flt_list", vp), ("flt_cap", i32), ("flt_thresh_ld", i32)]
         + [("ln_g", vp), ("ln_b", vp), ("ln_eps", f32), ("few_row_split", i32)]
     )
 

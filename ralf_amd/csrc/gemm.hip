@@ -39,7 +39,8 @@ extern "C" int ralf_gemm_filter_tile(const RalfGemmDesc* dp) {
     if (!dp || dp->M <= 0 || dp->N <= 0 || dp->K <= 0) { ralf::set_error("gemm_filter_tile: bad descriptor"); return RALF_ERR_INVALID; }
     RalfGemmDesc d = *dp;
     d.splitk = 1;
-    return gemm_use128(d, 1) ? 128 : 64;
+    if (!gemm_use128(d, 1)) return 64;
+    return gemm_env_glds() && !gemm_env_tile() && gemm_tile256_shape(d, 1) ? 256 : 128;   // (launch_cfg's rule for a bf16 NT product on the aligned path)
 }
 
 // the gathered tensor can be addressed with 32-bit element offsets (and 24-bit row multiplies): the lean loaders of gemm_body

@@ -1554,7 +1554,7 @@ __device__ __forceinline__ void gemm_body(const KParams& P, const int bid0, cons
                     float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                     if constexpr (EPI == 3) epilogue_storev_bnb<T>(d, m, c_n0 + c, v, bmu, bs1, bs2);
                     else if constexpr (EPI == 4)
-                        epilogue_filter<8>(d, m, c_n0 + c, v, d.N, d.flt_thresh[m], fcnt + lr,
+                        epilogue_filter<8>(d, m, c_n0 + c, v, d.N, d.flt_thresh[(int64_t)m * (d.flt_thresh_ld > 0 ? d.flt_thresh_ld : 1)], fcnt + lr,
                                            reinterpret_cast<int2*>(d.flt_list) + ((int64_t)m * P.tiles_n + c_n0 / BN) * d.flt_cap);
                     else if (slab) VIO<float, 8>::st(pbase, (int64_t)m * d.N + c_n0 + c, v);
                     else epilogue_storev<T, (EPI >= 3 ? 0 : EPI), 8>(d, z0, z1, m, c_n0 + c, v);
@@ -2032,10 +2032,19 @@ inline bool gemm_use128(const RalfGemmDesc& d, int nbatch) {
     return shape_ok && ((d.splitk == 1 && big >= big1) || (kspan >= 1024 && big >= 512));
 }
 
+inline int gemm_env_tile() { static const int v = [] { const char* e = getenv("RALF_GEMM_TILE"); return e ? atoi(e) : 0; }(); return v; }   // tuning / test aid: 22 / 11
+inline int gemm_env_glds() { static const int v = [] { const char* e = getenv("RALF_GEMM_GLDS"); return e ? atoi(e) : 1; }(); return v; }   // 0: off (A/B runs, tests)
+// the shape side of the 256 x 256-tile rule of launch_cfg (shared with ralf_gemm_filter_tile: a filtered product's slot lists are per column tile)
+inline bool gemm_tile256_shape(const RalfGemmDesc& d, int nbatch) {
+    static const int t256 = [] { const char* e = getenv("RALF_GEMM_TILE256"); return e ? atoi(e) : 400; }();   // tiles needed; 0 = off
+    const int64_t n256 = (int64_t)ceil_div(d.M, 256) * ceil_div(d.N, 256) * nbatch;
+    return t256 && d.splitk == 1 && d.M >= 256 && d.K >= 512 && n256 >= t256;
+}
+
 template <typename T, bool AK, bool BKC, int GATHER>
 int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
     const RalfGemmDesc& d = P.d;
-    static const int forced = [] { const char* e = getenv("RALF_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    const int forced = gemm_env_tile();
     const bool use128 = gemm_use128(d, nbatch);
     const int64_t big = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) * d.splitk * nbatch;
     const int kspan = ceil_div(d.K, d.splitk);
@@ -2049,16 +2058,18 @@ int launch_cfg(KParams& P, int nbatch, hipStream_t st) {
         // neutral or slower (the padded register-staged images read with fewer conflicts than the XOR-swizzled transpose reads), the
         // grouped weight gradients (TN, 128x128) -13 %.  So: 128x128 NT here, the grouped kernel in gemm_bf16.hip, nothing else.
         // Three stages (one workgroup per CU) where a launch has at most one workgroup per CU anyway and a long reduction to pipeline.
-        static const int glds = [] { const char* e = getenv("RALF_GEMM_GLDS"); return e ? atoi(e) : 1; }();   // 0: off (A/B runs, tests)
+        const int glds = gemm_env_glds();
         if (glds && use128 && !d.kseg && !d.bnb_part && !forced) {
             // 256 x 256 tiles (8 waves of 128 x 64, two 64-KiB stages) where at least ~1.5 of them exist per CU and the reduction is long: the operand
             // feed of a CU tops out at ~20-23 B/clk whatever the loop looks like (profiles/r06_gemm_lab_2.txt, r06_l2_feed_bench.txt), i.e. a tile's flops per loaded
             // byte set the rate -- 8192^3: 929 -> 1167 TFLOP/s, the two-stage k-NN's coarse pass (1024 x 61548 x 1792): 266 -> 230 us.  Plain
-            // epilogues only (the model's own products have too few such tiles: they lose on 256-row tiles, tools/gemm_lab.hip).
-            static const int t256 = [] { const char* e = getenv("RALF_GEMM_TILE256"); return e ? atoi(e) : 400; }();   // tiles needed; 0 = off
-            const int64_t n256 = (int64_t)ceil_div(d.M, 256) * ceil_div(d.N, 256) * nbatch;
+            // epilogues only (the model's own products have too few such tiles: they lose on 256-row tiles, tools/gemm_lab.hip) and the threshold filter
+            // of the k-NN's coarse pass (no output at all: 260 -> ... us; its slot lists are per 256-column tile then, ralf_gemm_filter_tile()).
             const bool plain = !d.colstats && !d.flt_list && !d.C2 && d.act != RALF_ACT_GELU && d.aux_mode != RALF_AUX_GELU_GRAD && !d.atomic_out && d.drop_p == 0.f && !d.aux;
-            if (t256 && plain && d.splitk == 1 && d.M >= 256 && d.K >= 512 && n256 >= t256) return launch<T, AK, BKC, 5, 4, 4, 0, 8>(P, nbatch, st);
+            if (gemm_tile256_shape(d, nbatch)) {
+                if (plain) return launch<T, AK, BKC, 5, 4, 4, 0, 8>(P, nbatch, st);
+                if (d.flt_list) return launch<T, AK, BKC, 5, 4, 4, 4, 8>(P, nbatch, st);
+            }
             if (big <= 256 && kspan >= 1024) return launch_epi<T, AK, BKC, 6, 2, 2, 8>(P, nbatch, st);
             return launch_epi<T, AK, BKC, 5, 2, 2, 8>(P, nbatch, st);
         }

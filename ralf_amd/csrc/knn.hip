@@ -408,11 +408,11 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict
 // (score desc, row index asc) -- the order of the exhaustive scan -- plus the per-query certificate of the two-stage search:
 //   bad[q] = !(k-th exact score >= bound[q] + eps[q]),  eps = |q - qb| xmax + |qb| dxmax + 2 D 2^-24 |q| xmax + 1e-6
 // (qn = per-query norms {|q|, |qb|, |q - qb|}, xn = index constants {max|x|, max|xb|, max|x - xb|}; see retrieval/knn.py).
-// One wave per query; pool <= 1024.
+// One wave per query; pool <= 1024.  (`over`: see knn_select_lists_kernel.)
 __global__ __launch_bounds__(64) void knn_select_cand_kernel(const float* __restrict__ exact, const int64_t* __restrict__ cand, int pool, int k,
                                                              float* __restrict__ os, int64_t* __restrict__ oi, const float* __restrict__ bound,
                                                              int64_t bound_ld, const float* __restrict__ qn, const float* __restrict__ xn, int D,
-                                                             int32_t* __restrict__ bad) {
+                                                             int32_t* __restrict__ bad, const int32_t* __restrict__ over = nullptr) {
     __shared__ uint32_t key[KMAX];
     __shared__ int64_t row[KMAX];
     const int q = blockIdx.x, lane = threadIdx.x;
@@ -439,7 +439,9 @@ __global__ __launch_bounds__(64) void knn_select_cand_kernel(const float* __rest
         for (int o = 32; o > 0; o >>= 1) kth = fmaxf(kth, __shfl_xor(kth, o));
         if (lane == 0) {
             const float eps = qn[q * 3 + 2] * xn[0] + qn[q * 3 + 1] * xn[2] + 2.f * (float)D * 5.9604645e-8f * qn[q * 3] * xn[0] + 1e-6f;
-            bad[q] = !(kth >= bound[(int64_t)q * bound_ld] + eps * 1.001f);
+            // (a -inf bound = the candidate list was padded: fewer than `pool` rows reached a filtered coarse pass's threshold; over = a tile of that pass lost hits)
+            const float b = bound[(int64_t)q * bound_ld];
+            bad[q] = !(kth >= b + eps * 1.001f) || b == -__builtin_inff() || (over && over[q]);
         }
     }
 }
@@ -472,7 +474,8 @@ __global__ __launch_bounds__(256) void knn_rownorms_kernel(const float* __restri
 
 // the queries of the two-stage search in one pass: Qb = bf16(Q) (round to nearest even, as ralf_copy2d) and norms[q] = {|q|, |qb|, |q - qb|} rounded up.
 // One wave per query, 16 bytes per lane and step.  D % 4 == 0.
-__global__ __launch_bounds__(256) void knn_query_prep_kernel(const float* __restrict__ Q, __bf16* __restrict__ Qb, int nq, int D, float* __restrict__ norms) {
+__global__ __launch_bounds__(256) void knn_query_prep_kernel(const float* __restrict__ Q, __bf16* __restrict__ Qb, int nq, int D, float* __restrict__ norms,
+                                                             int32_t* __restrict__ zero = nullptr) {
     const int lane = threadIdx.x & 63;
     const int r = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (r >= nq) return;
@@ -494,7 +497,60 @@ __global__ __launch_bounds__(256) void knn_query_prep_kernel(const float* __rest
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
     if (lane == 0) {
         norms[r * 3] = sqrtf(a) * 1.000001f; norms[r * 3 + 1] = sqrtf(b) * 1.000001f; norms[r * 3 + 2] = sqrtf(c) * 1.000001f;   // rounded up: these feed an upper bound
+        if (zero) zero[r] = 0;   // (the filtered search's per-query "a tile lost hits" flag, set by knn_select_lists_kernel further down the stream)
     }
+}
+
+// Selection among the candidate slots a FILTERED coarse pass wrote (RalfGemmDesc.flt_*; round 6: the unpack -> dense selection -> row gather chain of the
+// Python path in one kernel).  Slot p of query q = list[q * W + p] = {row, score bits}, W = T << capsh, in use when (p & (cap - 1)) < count[q * T + (p >> capsh)].
+// One workgroup per (segment of SEG slots = blockIdx.x, query = blockIdx.y): the segment's k best by (score desc, then a fixed order of the slots) -> os / oi[q][segment][k], padded
+// with (-inf, row 0): a padded entry must name a row the re-score can read, and knn_select_cand_kernel refuses to certify against a -inf bound.  (The order of
+// equal coarse scores is the tile's arrival order, not the row order of the dense selection: the candidate SET may differ among ties at the pool's edge, the
+// certificate -- every row outside the candidates scores <= the (pool+1)-th coarse score -- holds for either.)  over[q] |= a tile of the query lost hits.
+__global__ __launch_bounds__(256) void knn_select_lists_kernel(const int2* __restrict__ list, const int* __restrict__ count, int T, int capsh, int k,
+                                                               float* __restrict__ os, int64_t* __restrict__ oi, int32_t* __restrict__ over) {
+    __shared__ SelLds L_;
+    const int tid = threadIdx.x, q = blockIdx.y, seg = blockIdx.x, nseg = gridDim.x;
+    const int cap = 1 << capsh, W = T << capsh, base = seg * SEG;
+    const int2* src = list + (int64_t)q * W;
+    const int* cq = count + (int64_t)q * T;
+    float* so = os + ((int64_t)q * nseg + seg) * k;
+    int64_t* io = oi + ((int64_t)q * nseg + seg) * k;
+    // Entry i of thread t is slot 256 i + ((t + i) & 255): the slots of a tile fill from position 0 and hold ~2 hits, so with entry i = slot 256 i + t the
+    // threads with (t & 15) >= 3 would hold no key at all -- fewer non-empty threads than k, select_winners' bound drops to 0 and all ~1000 hits of the query
+    // are ranked against each other (84 us at 1024 queries; 14 with the rotation).  slot_of() maps select_winners' position t + 256 i back.
+    auto slot_of = [](int pos) { return (pos & ~255) | ((pos + (pos >> 8)) & 255); };
+    uint32_t key[EPT];
+    int sc[EPT], c[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {   // (unconditional loads on clamped positions, as knn_select_kernel)
+        const int p = base + 256 * i + ((tid + i) & 255), pc = p < W ? p : W - 1;
+        sc[i] = src[pc].y;
+        c[i] = cq[pc >> capsh];
+    }
+    int lost = 0;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int p = base + 256 * i + ((tid + i) & 255);
+        key[i] = (p < W && (p & (cap - 1)) < c[i]) ? f2key(__int_as_float(sc[i])) : 0u;
+        lost |= (p < W && c[i] > cap) ? 1 : 0;
+    }
+    const int nw = select_winners(key, k, L_);
+    for (int i = tid; i < nw; i += 256) {
+        const uint32_t ki = L_.wkey[i];
+        const int pi = L_.wpos[i];
+        int rank = 0;
+        for (int j = 0; j < nw; ++j) rank += better(L_.wkey[j], L_.wpos[j], ki, pi);
+        if (rank < k) {
+            so[rank] = key2f(ki);
+            io[rank] = (int64_t)src[base + slot_of(pi)].x;
+        }
+    }
+    for (int i = (nw < k ? nw : k) + tid; i < k; i += 256) {
+        so[i] = -__builtin_inff();
+        io[i] = 0;
+    }
+    if (lost) atomicOr(over + q, 1);
 }
 
 template <int MF, int TQ, int TR>
@@ -678,7 +734,7 @@ extern "C" int ralf_knn_select_cand(const float* exact, const int64_t* cand, int
     RALF_REQUIRE(pool >= 1 && pool <= KMAX && k >= 1 && k <= pool, "knn_select_cand: pool=%d k=%d outside [1,%d]", pool, k, KMAX);
     RALF_REQUIRE(!bad || (bound && qnorms && xnorms), "knn_select_cand: the certificate needs bound, qnorms and xnorms");
     hipLaunchKernelGGL(knn_select_cand_kernel, dim3(nq), dim3(64), 0, (hipStream_t)stream, exact, cand, pool, k, out_score, out_idx, bound, bound_ld,
-                       qnorms, xnorms, D, bad);
+                       qnorms, xnorms, D, bad, (const int32_t*)nullptr);
     return ralf::check_launch("knn_select_cand");
 }
 
@@ -693,6 +749,22 @@ extern "C" size_t ralf_knn_topk_ip_workspace_bytes(int64_t N, int D, int nq, int
     if (N <= 0 || nq <= 0 || k <= 0) return 0;
     SelectPlan p = plan_select(N, nq, k);
     return align256((size_t)nq * N * sizeof(float)) + 2 * align256(p.cand_bytes) + align256((size_t)nq * sizeof(unsigned int)) + 256;
+}
+
+// the nl sorted k-entry lists per query in cs[0] / ci[0] -> one (SEG / k lists per workgroup and level, ping-pong between the two buffers)
+static int merge_lists(float** cs, int64_t** ci, int64_t nl, int nq, int k, int64_t* out_idx, float* out_score, hipStream_t st) {
+    int cur = 0;
+    const int64_t group = SEG / k;  // lists merged per workgroup (>= 8 since k <= 1024)
+    while (nl > 1) {
+        const int64_t nout = (nl + group - 1) / group;
+        float* so = nout == 1 ? out_score : cs[cur ^ 1];
+        int64_t* io = nout == 1 ? out_idx : ci[cur ^ 1];
+        hipLaunchKernelGGL((knn_select_kernel<false>), dim3((unsigned)nout, nq), dim3(256), 0, st, nullptr, cs[cur], ci[cur], nl * k, nl * k, group * k, k, so, io,
+                           (unsigned int*)nullptr, (float*)nullptr, (int64_t*)nullptr);
+        nl = nout;
+        cur ^= 1;
+    }
+    return ralf::check_launch("knn_select");
 }
 
 // workspace for select alone = 2 candidate buffers (+ 256 bytes of ticket counters per 64 queries at its end)
@@ -727,19 +799,7 @@ static int select_impl(const float* S, int64_t N, int nq, int k, int64_t* out_id
     }
     hipLaunchKernelGGL((knn_select_kernel<true>), dim3((unsigned)p.nseg, nq), dim3(256), 0, st, S, nullptr, nullptr, N, N, (int64_t)SEG, k, cs[0], ci[0],
                        (unsigned int*)nullptr, (float*)nullptr, (int64_t*)nullptr);
-    int cur = 0;
-    int64_t nl = p.nseg;
-    const int64_t group = SEG / k;  // lists merged per workgroup (>= 8 since k <= 1024)
-    while (nl > 1) {
-        const int64_t nout = (nl + group - 1) / group;
-        float* so = nout == 1 ? out_score : cs[cur ^ 1];
-        int64_t* io = nout == 1 ? out_idx : ci[cur ^ 1];
-        hipLaunchKernelGGL((knn_select_kernel<false>), dim3((unsigned)nout, nq), dim3(256), 0, st, nullptr, cs[cur], ci[cur], nl * k, nl * k, group * k, k, so, io,
-                           (unsigned int*)nullptr, (float*)nullptr, (int64_t*)nullptr);
-        nl = nout;
-        cur ^= 1;
-    }
-    return ralf::check_launch("knn_select");
+    return merge_lists(cs, ci, p.nseg, nq, k, out_idx, out_score, st);
 }
 
 // ---- the whole two-stage search behind ONE entry point (round 6) ----
@@ -747,31 +807,50 @@ static int select_impl(const float* S, int64_t N, int nq, int k, int64_t* out_id
 // its own output allocations): ~80 us of host time on top of ~200 us of kernels at nq = 64.  Here the launches go out back to back from C into one
 // caller-provided workspace; the caller reads `bad` (one flag per query) and sends the uncertified queries through ralf_knn_topk_ip.
 namespace {
-struct TwoStagePlan { size_t qb, qn, coarse, cval, cidx, exact, sel, total; };
+constexpr int FLT_SAMPLE_ROWS = 4096;   // rows of the index the threshold pass ranks (expected list length: (pool + 1) * N / this)
+// candidate slots per (query, column tile of the index) = tile / 8 (16 per 128 columns): ~2 hits expected per 128 columns, P(> slots) ~ 1e-10 on unordered data
+inline int flt_capsh(int tile) { return tile >= 256 ? 5 : tile >= 128 ? 4 : 3; }
+struct TwoStagePlan { size_t qb, qn, coarse, cval, cidx, exact, sel, over, total;
+                      size_t f_sample, f_tval, f_tidx, f_cnt, f_lst; int64_t f_ns, f_T; int f_tile, f_capsh; };   // f_*: inside the `coarse` region
+int filter_tile(int64_t N, int D, int nq) {
+    RalfGemmDesc d;
+    memset(&d, 0, sizeof(d));
+    d.M = nq; d.N = (int)N; d.K = D; d.lda = D; d.ldb = D; d.ldc = N; d.nb0 = d.nb1 = 1; d.splitk = 1; d.dtype = RALF_BF16; d.a_kcontig = 1; d.b_kcontig = 1;
+    return ralf_gemm_filter_tile(&d);
+}
 TwoStagePlan plan_two_stage(int64_t N, int D, int nq, int pool) {
     TwoStagePlan p;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += align256(bytes); return at; };
     p.qb = take((size_t)nq * D * 2);
     p.qn = take((size_t)nq * 3 * sizeof(float));
-    p.coarse = take((size_t)nq * N * sizeof(float));
+    // the score matrix of the dense coarse pass, or (filtered pass) the sample's scores, its selection, the tile counters and the candidate slots
+    p.f_ns = N < FLT_SAMPLE_ROWS ? N : FLT_SAMPLE_ROWS;
+    p.f_tile = filter_tile(N, D, nq);
+    p.f_T = p.f_tile > 0 ? (N + p.f_tile - 1) / p.f_tile : 0;
+    p.f_capsh = flt_capsh(p.f_tile);
+    size_t f = 0;
+    auto ftake = [&](size_t bytes) { const size_t at = f; f += align256(bytes); return at; };
+    p.f_sample = ftake((size_t)nq * p.f_ns * sizeof(float));
+    p.f_tval = ftake((size_t)nq * (pool + 1) * sizeof(float));
+    p.f_tidx = ftake((size_t)nq * (pool + 1) * sizeof(int64_t));
+    p.f_cnt = ftake((size_t)nq * p.f_T * sizeof(int));
+    p.f_lst = ftake(((size_t)nq * p.f_T << p.f_capsh) * 8);
+    const size_t dense = (size_t)nq * N * sizeof(float);
+    p.coarse = take(dense > f ? dense : f);
     p.cval = take((size_t)nq * (pool + 1) * sizeof(float));
     p.cidx = take((size_t)nq * (pool + 1) * sizeof(int64_t));
     p.exact = take((size_t)nq * (pool + 1) * sizeof(float));
-    SelectPlan sp = plan_select(N, nq, pool + 1);
+    p.over = take((size_t)nq * sizeof(int32_t));
+    const int64_t W = p.f_T << p.f_capsh;
+    SelectPlan sp = plan_select(N > W ? N : W, nq, pool + 1);
     p.sel = take(2 * align256(sp.cand_bytes) + align256((size_t)nq * sizeof(unsigned int)) + 256);
     p.total = o;
     return p;
 }
-}  // namespace
 
-extern "C" size_t ralf_knn_two_stage_workspace_bytes(int64_t N, int D, int nq, int pool) {
-    if (N <= 0 || D <= 0 || nq <= 0 || pool <= 0) return 0;
-    return plan_two_stage(N, D, nq, pool).total;
-}
-
-extern "C" int ralf_knn_topk_ip_two_stage(const float* X, const void* Xb, int64_t N, int D, const float* Q, int nq, int k, int pool, const float* xnorms,
-                                          int64_t* out_idx, float* out_score, int32_t* bad, void* workspace, size_t workspace_bytes, void* stream) {
+int two_stage_impl(const float* X, const void* Xb, int64_t N, int D, const float* Q, int nq, int k, int pool, const float* xnorms,
+                   int64_t* out_idx, float* out_score, int32_t* bad, void* workspace, size_t workspace_bytes, void* stream, bool filtered) {
     RALF_REQUIRE(X && Xb && Q && xnorms && out_idx && out_score && bad && workspace, "knn two-stage: null pointer");
     RALF_REQUIRE(N > 0 && nq > 0 && D > 0 && D % 64 == 0, "knn two-stage: dim %d must be a multiple of 64 (bf16 coarse product on the aligned path)", D);
     RALF_REQUIRE(k >= 1 && k <= pool && pool + 1 <= KMAX && pool < N, "knn two-stage: k=%d pool=%d outside 1 <= k <= pool < min(%d, n_db)", k, pool, KMAX);
@@ -785,22 +864,76 @@ extern "C" int ralf_knn_topk_ip_two_stage(const float* X, const void* Xb, int64_
     void* qb = w + p.qb;
     float *qn = (float*)(w + p.qn), *coarse = (float*)(w + p.coarse), *cval = (float*)(w + p.cval), *exact = (float*)(w + p.exact);
     int64_t* cidx = (int64_t*)(w + p.cidx);
+    int32_t* over = (int32_t*)(w + p.over);
     hipStream_t st = (hipStream_t)stream;
     // queries -> bf16, their norms {|q|, |qb|, |q - qb|}
-    hipLaunchKernelGGL(knn_query_prep_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, Q, (__bf16*)qb, nq, D, qn);
-    // coarse scores [nq, N] = Qb Xb^T on the bf16 matrix cores, fp32 out
+    hipLaunchKernelGGL(knn_query_prep_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, Q, (__bf16*)qb, nq, D, qn, filtered ? over : (int32_t*)nullptr);
     RalfGemmDesc d;
     memset(&d, 0, sizeof(d));
     d.A = qb; d.B = Xb; d.C = coarse;
     d.M = nq; d.N = (int)N; d.K = D; d.lda = D; d.ldb = D; d.ldc = N; d.nb0 = d.nb1 = 1; d.splitk = 1; d.alpha = 1.f; d.aux_scale = 1.f;
     d.dtype = RALF_BF16; d.a_kcontig = 1; d.b_kcontig = 1; d.out_f32 = 1;
-    if (int rc = ralf_gemm(&d, nullptr, 0, stream)) return rc;
-    // the pool + 1 best coarse rows per query, sorted by coarse score
-    if (int rc = select_impl(coarse, N, nq, pool + 1, cidx, cval, w + p.sel, p.total - p.sel, st, false, false)) return rc;
+    if (!filtered) {
+        // coarse scores [nq, N] = Qb Xb^T on the bf16 matrix cores, fp32 out; the pool + 1 best coarse rows per query, sorted by coarse score
+        if (int rc = ralf_gemm(&d, nullptr, 0, stream)) return rc;
+        if (int rc = select_impl(coarse, N, nq, pool + 1, cidx, cval, w + p.sel, p.total - p.sel, st, false, false)) return rc;
+    } else {
+        // The coarse scores never reach memory (252 MB written and re-read by the selection at BASELINE config 4).  A first product against the first f_ns rows
+        // of the index gives every query a LOWER bound of its (pool+1)-th best coarse score (the (pool+1)-th best of a subset cannot exceed that of the whole);
+        // the product over the whole index keeps only the scores at or above it, in per-(query, column tile) slot lists (RalfGemmDesc.flt_*: ~(pool+1) N / f_ns
+        // candidates per query); the selection reads the slots.  A tile with more hits than slots flags its query (over -> bad): ordered indexes flood tiles, and
+        // the caller is expected to fall back to the dense pass for an index that does (retrieval/knn.py: FlatIPIndex).
+        RALF_REQUIRE(p.f_tile > 0 && (p.f_T << p.f_capsh) < ((int64_t)1 << 31) / 2, "knn two-stage (filtered): index of %lld rows too large for 32-bit slot positions", (long long)N);
+        char* f = (char*)coarse;
+        float *sample = (float*)(f + p.f_sample), *tval = (float*)(f + p.f_tval);
+        int64_t* tidx = (int64_t*)(f + p.f_tidx);
+        int* cnt = (int*)(f + p.f_cnt);
+        void* lst = f + p.f_lst;
+        RalfGemmDesc ds = d;
+        ds.C = sample; ds.N = (int)p.f_ns; ds.ldc = p.f_ns;
+        if (int rc = ralf_gemm(&ds, nullptr, 0, stream)) return rc;
+        if (int rc = select_impl(sample, p.f_ns, nq, pool + 1, tidx, tval, w + p.sel, p.total - p.sel, st, false, false)) return rc;
+        d.C = lst; d.out_f32 = 0;   // (C is not written by a filtered product; the entry refuses a null one)
+        d.flt_thresh = tval + pool; d.flt_thresh_ld = pool + 1; d.flt_count = cnt; d.flt_list = lst; d.flt_cap = 1 << p.f_capsh;
+        if (int rc = ralf_gemm(&d, nullptr, 0, stream)) return rc;
+        const int64_t W = p.f_T << p.f_capsh, nseg = (W + SEG - 1) / SEG;
+        if (nseg == 1) {
+            hipLaunchKernelGGL(knn_select_lists_kernel, dim3(1, nq), dim3(256), 0, st, (const int2*)lst, cnt, (int)p.f_T, p.f_capsh, pool + 1, cval, cidx, over);
+        } else {
+            char* sw = w + p.sel;
+            const size_t cb = align256((size_t)nq * nseg * (pool + 1) * (sizeof(float) + sizeof(int64_t)));
+            float* cs[2];
+            int64_t* ci[2];
+            for (int i = 0; i < 2; ++i) {
+                ci[i] = (int64_t*)(sw + i * cb);
+                cs[i] = (float*)(ci[i] + (size_t)nq * nseg * (pool + 1));
+            }
+            hipLaunchKernelGGL(knn_select_lists_kernel, dim3((unsigned)nseg, nq), dim3(256), 0, st, (const int2*)lst, cnt, (int)p.f_T, p.f_capsh, pool + 1, cs[0], ci[0], over);
+            if (int rc = merge_lists(cs, ci, nseg, nq, pool + 1, cidx, cval, st)) return rc;
+        }
+        if (int rc = ralf::check_launch("knn_select_lists")) return rc;
+    }
     // exact scores of the candidates (the scan's accumulation chain), the k best of them, the certificate against the (pool + 1)-th coarse score
     if (int rc = launch_rescore(X, N, D, Q, nq, cidx, pool + 1, exact, st)) return rc;
-    hipLaunchKernelGGL(knn_select_cand_kernel, dim3(nq), dim3(64), 0, st, exact, cidx, pool + 1, k, out_score, out_idx, cval + pool, (int64_t)(pool + 1), qn, xnorms, D, bad);
+    hipLaunchKernelGGL(knn_select_cand_kernel, dim3(nq), dim3(64), 0, st, exact, cidx, pool + 1, k, out_score, out_idx, cval + pool, (int64_t)(pool + 1), qn, xnorms, D, bad,
+                       filtered ? (const int32_t*)over : (const int32_t*)nullptr);
     return ralf::check_launch("knn two-stage");
+}
+}  // namespace
+
+extern "C" size_t ralf_knn_two_stage_workspace_bytes(int64_t N, int D, int nq, int pool) {
+    if (N <= 0 || D <= 0 || nq <= 0 || pool <= 0) return 0;
+    return plan_two_stage(N, D, nq, pool).total;
+}
+
+extern "C" int ralf_knn_topk_ip_two_stage(const float* X, const void* Xb, int64_t N, int D, const float* Q, int nq, int k, int pool, const float* xnorms,
+                                          int64_t* out_idx, float* out_score, int32_t* bad, void* workspace, size_t workspace_bytes, void* stream) {
+    return two_stage_impl(X, Xb, N, D, Q, nq, k, pool, xnorms, out_idx, out_score, bad, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int ralf_knn_topk_ip_two_stage_filtered(const float* X, const void* Xb, int64_t N, int D, const float* Q, int nq, int k, int pool, const float* xnorms,
+                                                   int64_t* out_idx, float* out_score, int32_t* bad, void* workspace, size_t workspace_bytes, void* stream) {
+    return two_stage_impl(X, Xb, N, D, Q, nq, k, pool, xnorms, out_idx, out_score, bad, workspace, workspace_bytes, stream, true);
 }
 
 extern "C" int ralf_knn_select(const float* S, int64_t N, int nq, int k, int64_t* out_idx, float* out_score, void* ws,

@@ -89,7 +89,7 @@ def knn_select_cand(exact: torch.Tensor, cand: torch.Tensor, k: int, bound=None,
 
 
 FILTER_SAMPLE_ROWS = 4096   # rows of the index the threshold pass ranks (expected list length: (pool + 1) * N / this)
-FILTER_TILE_SLOTS = 16      # candidate slots per (query, 128-column tile of the index): ~2 hits expected per tile, P(> 16) ~ 1e-10 for unordered data
+FILTER_TILE_SLOTS = 16      # candidate slots per (query, 128 columns of a tile of the index): ~2 hits expected, P(> 16) ~ 1e-10 for unordered data
 
 
 def knn_topk_ip_two_stage(index: torch.Tensor, index_bf16: torch.Tensor, queries: torch.Tensor, k: int, pool: int = 0, index_norms: torch.Tensor | None = None,
@@ -133,13 +133,14 @@ def knn_topk_ip_two_stage(index: torch.Tensor, index_bf16: torch.Tensor, queries
         tile = ops.gemm_filter_tile(nq, N, D)
         T = (N + tile - 1) // tile
         cnt = torch.empty(nq, T, dtype=torch.int32, device=q.device)                  # hits per (query, column tile): every entry is written
-        lst = torch.empty(nq, T, FILTER_TILE_SLOTS, 2, dtype=torch.int32, device=q.device)
+        slots = FILTER_TILE_SLOTS * max(tile // 128, 1)
+        lst = torch.empty(nq, T, slots, 2, dtype=torch.int32, device=q.device)
         ops.gemm(qb, index_bf16, nq, N, D, flt=(thresh, cnt, lst))
-        W = T * FILTER_TILE_SLOTS
+        W = T * slots
         rows = torch.empty(nq, W, dtype=torch.int64, device=q.device)                 # row ids / scores of the slots, -inf where unused
         scores = torch.empty(nq, W, dtype=torch.float32, device=q.device)
         over = torch.zeros(nq, dtype=torch.int32, device=q.device)                    # queries with a flooded tile: redone exhaustively below
-        _lib.check(_lib.lib().ralf_knn_list_unpack(_lib.ptr(lst), _lib.ptr(cnt), nq, T, FILTER_TILE_SLOTS, _lib.ptr(rows), _lib.ptr(scores), _lib.ptr(over), _lib.stream_ptr()), "ralf_knn_list_unpack")
+        _lib.check(_lib.lib().ralf_knn_list_unpack(_lib.ptr(lst), _lib.ptr(cnt), nq, T, slots, _lib.ptr(rows), _lib.ptr(scores), _lib.ptr(over), _lib.stream_ptr()), "ralf_knn_list_unpack")
         cval, pos = knn_select(scores, pool + 1)
         cidx = torch.empty(nq, pool + 1, dtype=torch.int64, device=q.device)
         _lib.check(_lib.lib().ralf_knn_gather_rows(_lib.ptr(rows), W, _lib.ptr(pos), nq, pool + 1, _lib.ptr(cidx), _lib.stream_ptr()), "ralf_knn_gather_rows")
@@ -163,10 +164,12 @@ _HOST_FLAGS = os.environ.get("RALF_KNN_HOST_FLAGS", "1") != "0"   # the search's
 
 
 def knn_topk_ip_two_stage_fused(index: torch.Tensor, index_bf16: torch.Tensor, queries: torch.Tensor, k: int, index_norms: torch.Tensor, pool: int = 0,
-                                workspace: torch.Tensor | None = None):
+                                workspace: torch.Tensor | None = None, filtered: bool = False):
     """knn_topk_ip_two_stage through ONE call of the library (ralf_knn_topk_ip_two_stage: every launch of the search back to back from C into one
     workspace) + one read of the certificate flags; queries that are not certified go through the exhaustive scan.  Same results as
-    knn_topk_ip, bit for bit.  Returns (scores, idx, n_fallback, workspace)."""
+    knn_topk_ip, bit for bit.  filtered: ralf_knn_topk_ip_two_stage_filtered -- the coarse scores are thresholded in the product's epilogue instead
+    of written as an [nq, N] matrix (pays from ~640 queries at BASELINE config 4: profiles/r06_knn_filtered_ab.txt; a query with a flooded column tile counts as not certified).
+    Returns (scores, idx, n_fallback, workspace)."""
     N, D = index.shape
     nq = queries.shape[0]
     # pool + 1 candidates per query: a multiple of 16 (whole blocks of the re-score kernel: 64 candidates are four waves, 65 were five)
@@ -184,9 +187,10 @@ def knn_topk_ip_two_stage_fused(index: torch.Tensor, index_bf16: torch.Tensor, q
     if host is None:
         host = _BAD_HOST[nq] = torch.empty(nq, dtype=torch.int32, pin_memory=True)
     bad = host if _HOST_FLAGS else torch.empty(nq, dtype=torch.int32, device=index.device)
-    rc = L.ralf_knn_topk_ip_two_stage(_lib.ptr(index), _lib.ptr(index_bf16), N, D, _lib.ptr(q), nq, k, pool, _lib.ptr(index_norms), _lib.ptr(idx), _lib.ptr(val),
-                                      ctypes.c_void_p(bad.data_ptr()), _lib.ptr(workspace), workspace.numel(), _lib.stream_ptr())
-    _lib.check(rc, "ralf_knn_topk_ip_two_stage")
+    entry = L.ralf_knn_topk_ip_two_stage_filtered if filtered else L.ralf_knn_topk_ip_two_stage
+    rc = entry(_lib.ptr(index), _lib.ptr(index_bf16), N, D, _lib.ptr(q), nq, k, pool, _lib.ptr(index_norms), _lib.ptr(idx), _lib.ptr(val),
+               ctypes.c_void_p(bad.data_ptr()), _lib.ptr(workspace), workspace.numel(), _lib.stream_ptr())
+    _lib.check(rc, "ralf_knn_topk_ip_two_stage_filtered" if filtered else "ralf_knn_topk_ip_two_stage")
     nbad = 0
     if not _HOST_FLAGS:
         host.copy_(bad, non_blocking=True)
@@ -202,13 +206,16 @@ def knn_topk_ip_two_stage_fused(index: torch.Tensor, index_bf16: torch.Tensor, q
 class FlatIPIndex:
     """Flat inner-product index kept in HBM; `search` mirrors faiss.IndexFlat.search(x, k) -> (D, I)."""
 
-    def __init__(self, vectors: torch.Tensor, device: str = "cuda", two_stage_min_queries: int = 40):
+    def __init__(self, vectors: torch.Tensor, device: str = "cuda", two_stage_min_queries: int = 40, filtered_min_queries: int = 640):
         self.vectors = torch.as_tensor(vectors, dtype=torch.float32).to(device).contiguous()
         self._ws = None
         self._ws2 = None
         self._bf16 = None                 # bf16 shadow of the index for the coarse pass of query batches (built on first use)
         self._norms = None                # {max|x|, max|xb|, max|x - xb|} of the index rows: the certificate's constants
         self.two_stage_min_queries = two_stage_min_queries
+        # from this many queries the coarse pass thresholds its scores instead of writing them (0 = never).  Switched off for good by the first batch
+        # that floods tiles (more than 1 in 16 queries not certified: an index ordered by similarity), so such an index pays the fallback once.
+        self.filtered_min_queries = int(os.environ.get("RALF_KNN_FILTERED_MIN", filtered_min_queries))
         self.last_fallbacks = 0
 
     @property
@@ -231,7 +238,10 @@ class FlatIPIndex:
             if self._bf16 is None:
                 self._bf16 = ops.cast(self.vectors, torch.bfloat16)
                 _, self._norms = knn_rownorms(self.vectors, self._bf16, want_rows=False, want_max=True)
-            val, idx, self.last_fallbacks, self._ws2 = knn_topk_ip_two_stage_fused(self.vectors, self._bf16, q.contiguous(), k, self._norms, workspace=self._ws2)
+            flt = bool(self.filtered_min_queries) and q.shape[0] >= self.filtered_min_queries
+            val, idx, self.last_fallbacks, self._ws2 = knn_topk_ip_two_stage_fused(self.vectors, self._bf16, q.contiguous(), k, self._norms, workspace=self._ws2, filtered=flt)
+            if flt and self.last_fallbacks * 16 > q.shape[0]:
+                self.filtered_min_queries = 0
             return val, idx
         need = _lib.lib().ralf_knn_topk_ip_workspace_bytes(self.ntotal, self.d, q.shape[0], k)
         if self._ws is None or self._ws.numel() < need:

@@ -21,7 +21,7 @@ def test_header_matches_abi_table_and_library():
     L = _lib.lib()
     for s in syms:
         assert hasattr(L, s), f"libralf_hip.so does not export {s}"
-    assert L.ralf_abi_version() == 25
+    assert L.ralf_abi_version() == 26
     assert isinstance(L.ralf_last_error(), bytes)
 
 

@@ -207,6 +207,51 @@ def test_two_stage_filtered_coarse_pass_equals_the_dense_one(filtered):
     assert nfb == nq                                    # every query has flooded tiles (all 128 columns of a tile pass, 16 slots): all redone exhaustively
 
 
+@pytest.mark.parametrize("N,D,nq,k", [(20000, 256, 600, 16), (61548, 1792, 1024, 16), (70000, 64, 520, 5), (3000, 128, 513, 16)])
+def test_one_call_filtered_search_equals_exhaustive(N, D, nq, k):
+    """ralf_knn_topk_ip_two_stage_filtered (threshold product on the index's first rows, filtered product, selection straight from the slot lists,
+    re-score, certificate -- one library call) == the exhaustive scan, bit for bit, on ordinary data (a handful of fallbacks at most: an exact
+    duplicate pair and a query on it), with more slots than one selection segment (N = 70000: 547 tiles x 16 slots), and on an index whose leading
+    rows hold nothing similar to the queries: every tile floods, every query is flagged and redone, and the index front end stops using the form"""
+    from ralf_amd import ops
+    from ralf_amd.retrieval import knn as K
+
+    g = torch.Generator(device="cuda").manual_seed(N + nq)
+    X = torch.randn(N, D, device="cuda", generator=g)
+    X /= X.norm(dim=1, keepdim=True)
+    X[N // 2] = X[40]
+    Q = torch.randn(nq, D, device="cuda", generator=g)
+    Q /= Q.norm(dim=1, keepdim=True)
+    Q[5] = X[40]
+    Xb = ops.cast(X, torch.bfloat16)
+    _, xn = K.knn_rownorms(X, Xb, want_rows=False, want_max=True)
+    v_ref, i_ref = K.knn_topk_ip(X, Q, k)
+    v, i, nfb, ws = K.knn_topk_ip_two_stage_fused(X, Xb, Q, k, xn, filtered=True)
+    assert torch.equal(i, i_ref) and torch.equal(v, v_ref) and nfb < nq // 8
+    v, i, nfb2, ws = K.knn_topk_ip_two_stage_fused(X, Xb, Q, k, xn, workspace=ws, filtered=False)   # the same workspace serves the dense form
+    assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
+    index = K.FlatIPIndex(X)
+    assert nq >= index.filtered_min_queries
+    v, i = index.search(Q, k)
+    assert torch.equal(i, i_ref) and torch.equal(v, v_ref) and index.filtered_min_queries > 0
+    if N < 8192:
+        return
+    ns = 4096
+    u = torch.zeros(D, device="cuda"); u[0] = 1.0
+    X2 = X.clone()
+    X2[:ns] = -u
+    Q2 = Q.clone(); Q2[:, 0] = Q2[:, 0].abs() + 0.5; Q2 /= Q2.norm(dim=1, keepdim=True)
+    X2[ns:, 0] = X2[ns:, 0].abs() + 0.5
+    X2[ns:] /= X2[ns:].norm(dim=1, keepdim=True)
+    v_ref, i_ref = K.knn_topk_ip(X2, Q2, k)
+    index = K.FlatIPIndex(X2)
+    v, i = index.search(Q2, k)
+    assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
+    assert index.last_fallbacks == nq and index.filtered_min_queries == 0
+    v, i = index.search(Q2, k)                       # ... and the next batch takes the dense coarse pass
+    assert torch.equal(i, i_ref) and torch.equal(v, v_ref) and index.last_fallbacks < nq // 8
+
+
 def test_sharded_search_forms_on_the_hip_scan():
     """SURVEY 8e on the real scan (1-rank RCCL group; the 2-rank exchange is covered on CPU with gloo): query-sharded replicas and
     an index shard with a row offset return the table of the plain search"""

@@ -36,9 +36,10 @@ th = sval[:, pool].contiguous()
 tile = ops.gemm_filter_tile(nq, N, D)
 T = (N + tile - 1) // tile
 cnt = torch.empty(nq, T, dtype=torch.int32, device="cuda")
-lst = torch.empty(nq, T, K.FILTER_TILE_SLOTS, 2, dtype=torch.int32, device="cuda")
+slots = K.FILTER_TILE_SLOTS * max(tile // 128, 1)
+lst = torch.empty(nq, T, slots, 2, dtype=torch.int32, device="cuda")
 t["filtered coarse GEMM (no score matrix)"] = _time_gpu(lambda: ops.gemm(qb, Xb, nq, N, D, flt=(th, cnt, lst)), 10, 2)
-print("hits per query: mean %.0f max %d; per (query, tile): max %d of %d slots" % (cnt.sum(1).float().mean().item(), int(cnt.sum(1).max()), int(cnt.max()), K.FILTER_TILE_SLOTS))
+print("hits per query: mean %.0f max %d; per (query, tile): max %d of %d slots" % (cnt.sum(1).float().mean().item(), int(cnt.sum(1).max()), int(cnt.max()), slots))
 t["whole call, filtered coarse pass"] = _time_gpu(lambda: knn_topk_ip_two_stage(X, Xb, Q, k, index_norms=xn, filtered=True), 10, 2)
 v0, i0, _ = knn_topk_ip_two_stage(X, Xb, Q, k, index_norms=xn, filtered=False)
 v1, i1, nfb = knn_topk_ip_two_stage(X, Xb, Q, k, index_norms=xn, filtered=True)
