@@ -61,4 +61,5 @@ import json; d=json.load(open('$O/bench_dp_selftest.json')); print('dp-selftest 
 timeout 200 python3 tools/loop_phases.py 1 > $O/loop_phases_lag1.txt 2>&1; timeout 200 python3 tools/loop_phases.py 0 > $O/loop_phases_lag0.txt 2>&1
 timeout 300 python3 tools/at_bench.py > $O/at_bench.txt 2>&1
 timeout 300 python3 tools/knn_two_stage_probe.py > $O/knn_two_stage_stages.txt 2>&1
+timeout 300 python3 tools/knn_filtered_ab.py 512 640 1024 2048 2>&1 | grep 'nq =' > $O/knn_filtered_ab.txt
 timeout 100 python3 tools/h2d_probe.py > $O/h2d_probe.txt 2>&1
