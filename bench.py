@@ -721,7 +721,7 @@ def main():
                                    "note": "dominant kernel knn_scores_kernel<16,1,2> at nq=16 (HBM-bound regime): 441.2 MB algorithmic bytes per launch (index 61548x1792 fp32 streamed once) / "
                                            f"{k16['scan_us']:.1f} us (HIP events); whole call incl. select+merge {k16['us_per_call']:.1f} us = {k16['hbm_frac']:.3f} of peak; "
                                            "nq=1024 is fp32-FLOP-bound when scanned exhaustively (knn.nq1024: 2.9x the algorithmic traffic, 0.6 of the fp32-matrix peak); "
-                                           "the index front end (retrieval.FlatIPIndex.search) therefore routes batches of >= 256 queries to the two-stage search "
+                                           "the index front end (retrieval.FlatIPIndex.search) therefore routes batches of >= 40 queries to the two-stage search "
                                            "(knn.nq1024_two_stage: identical results, checked in this run); traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
                                            + (ke["file"] if ke else "no committed profile")}
         if world == 1 and not a.skip_decode:
