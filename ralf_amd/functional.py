@@ -175,6 +175,8 @@ class Runtime:
         self.fused_decode_token = os.environ.get("RALF_DECODE_TOKEN", "1") != "0"
         # ... and the decode-space mask + token choice inside that launch (ralf_decode_token's s_* arguments; 0: a launch of its own, the same tokens)
         self.fused_decode_sample = os.environ.get("RALF_DECODE_SAMPLE", "1") != "0"
+        # inference batches above this many images go through the backbone in slices (nn.ResnetBackbone.body_features); 0 = whole batch
+        self.infer_chunk = int(os.environ.get("RALF_INFER_CHUNK", "0"))
         self.fold_bn = True       # inference: eval-mode BatchNorm folded into the convolution epilogues (conv_bn_infer)
         # decode step: LayerNorm inside the few-row product that follows it (RalfGemmDesc.ln_*) and the four-wave split of the 256 x 256 x 1024
         # product (few_row_split) -- same arithmetic, other summation orders than the separate launches (off: their bits)

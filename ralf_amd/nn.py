@@ -728,15 +728,15 @@ class ResnetBackbone(nn.Module):
         infer = rt.fold_bn and not rt.training and not torch.is_grad_enabled()
         if infer:
             self._refresh_fold(img.device)
-            if rt.stem_direct and rt.fused_stem and x.dtype == torch.bfloat16 and tuple(b.conv1.weight.shape) == (64, 4, 7, 7):
-                # the stem in direct form (ops.stem7x7_fwd) and ONE pass for the folded BatchNorm + ReLU + max-pool (the training forward's two kernels with the
-                # eval-mode scale / shift): at B = 256 the general 8-channel gather + a separate max-pool took 633 + 174 us
-                y, _ = ops.stem7x7_fwd(x, rt.lp(b.conv1.weight, "ohwi"), want_stats=False)
-                x, _ = ops.bn_relu_maxpool_fwd(y, b.bn1.fold[0], b.bn1.fold[1])
-            else:
-                x = RF.conv_bn_infer(x, b.conv1.weight, b.bn1.fold[0], b.bn1.fold[1], b.conv1.stride, b.conv1.pad, True, None, rt)
-                x = RF.MaxPoolFn.apply(x)
-        elif rt.training and rt.fused_stem:
+            if rt.infer_chunk and B > rt.infer_chunk:
+                # a large inference batch in slices of infer_chunk images (RALF_INFER_CHUNK, off by default): samples do not interact in eval mode, and
+                # at 64 images layer1's maps (134 MB) would stay in the 256 MB infinity cache between the kernel that writes them and the one that reads
+                # them (at B = 256: 537 MB each).  Measured at B = 256, same box, same tokens: decode loop 26.1 ms whole / 26.3 in slices of 128 / 26.6 of 64
+                # -- the shorter launches lose more than the cache gives (profiles/r06_infer_chunk.txt)
+                outs = [self._body_infer(x[i:i + rt.infer_chunk], rt) for i in range(0, B, rt.infer_chunk)]
+                return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+            return self._body_infer(x, rt)
+        if rt.training and rt.fused_stem:
             # training: BatchNorm (batch statistics) + ReLU + max-pool in one pass over the convolution output (RF.StemBNReluPoolFn)
             x, st = b.conv1(x, rt, stats=True)
             x = RF.StemBNReluPoolFn.apply(x, b.bn1.weight, b.bn1.bias, b.bn1.running_mean, b.bn1.running_var, b.bn1.num_batches_tracked, st, rt)
@@ -747,9 +747,7 @@ class ResnetBackbone(nn.Module):
         feats, lat3 = {}, None
         for li in (1, 2, 3, 4):
             for bi, blk in enumerate(getattr(b, f"layer{li}")):
-                if infer:
-                    x = blk.forward_infer(x, rt)
-                elif li == 4 and bi == 0 and torch.is_grad_enabled():
+                if li == 4 and bi == 0 and torch.is_grad_enabled():
                     # layer3's output has two consumers (layer4 and the FPN lateral): the lateral reads an alias handed out by layer4's first
                     # block, so both gradients meet inside that block's data-gradient epilogues instead of in an autograd add kernel
                     x, lat3 = blk(x, rt, want_alias=True)
@@ -759,6 +757,24 @@ class ResnetBackbone(nn.Module):
                 x = rt.grad_cut(x)
             feats[li] = x
         return (lat3 if lat3 is not None else feats[3]), feats[4]
+
+    def _body_infer(self, x: torch.Tensor, rt: Runtime):
+        """the folded-BatchNorm forward of the body on NHWC pixels [b, H, W, 8] -> (layer3, layer4) maps"""
+        b = self.body
+        # the stem in direct form (ops.stem7x7_fwd) and ONE pass for the folded BatchNorm + ReLU + max-pool (the training forward's two kernels with the
+        # eval-mode scale / shift): at B = 256 the general 8-channel gather + a separate max-pool took 633 + 174 us
+        if rt.stem_direct and rt.fused_stem and x.dtype == torch.bfloat16 and tuple(b.conv1.weight.shape) == (64, 4, 7, 7):
+            y, _ = ops.stem7x7_fwd(x, rt.lp(b.conv1.weight, "ohwi"), want_stats=False)
+            x, _ = ops.bn_relu_maxpool_fwd(y, b.bn1.fold[0], b.bn1.fold[1])
+        else:
+            x = RF.conv_bn_infer(x, b.conv1.weight, b.bn1.fold[0], b.bn1.fold[1], b.conv1.stride, b.conv1.pad, True, None, rt)
+            x = RF.MaxPoolFn.apply(x)
+        feats = {}
+        for li in (1, 2, 3, 4):
+            for blk in getattr(b, f"layer{li}"):
+                x = blk.forward_infer(x, rt)
+            feats[li] = x
+        return feats[3], feats[4]
 
     def fpn(self, layer3: torch.Tensor, layer4: torch.Tensor, rt: Runtime) -> torch.Tensor:
         """FPN fuse + projection (common/image.py:99-111) on NHWC maps -> [B, h*w, d] with the 2-D sine table added."""
