@@ -230,7 +230,7 @@ def test_one_call_filtered_search_equals_exhaustive(N, D, nq, k):
     assert torch.equal(i, i_ref) and torch.equal(v, v_ref) and nfb < nq // 8
     v, i, nfb2, ws = K.knn_topk_ip_two_stage_fused(X, Xb, Q, k, xn, workspace=ws, filtered=False)   # the same workspace serves the dense form
     assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
-    index = K.FlatIPIndex(X)
+    index = K.FlatIPIndex(X, filtered_min_queries=512)   # (default 640: BASELINE config 4's crossover)
     assert nq >= index.filtered_min_queries
     v, i = index.search(Q, k)
     assert torch.equal(i, i_ref) and torch.equal(v, v_ref) and index.filtered_min_queries > 0
@@ -244,7 +244,7 @@ def test_one_call_filtered_search_equals_exhaustive(N, D, nq, k):
     X2[ns:, 0] = X2[ns:, 0].abs() + 0.5
     X2[ns:] /= X2[ns:].norm(dim=1, keepdim=True)
     v_ref, i_ref = K.knn_topk_ip(X2, Q2, k)
-    index = K.FlatIPIndex(X2)
+    index = K.FlatIPIndex(X2, filtered_min_queries=512)
     v, i = index.search(Q2, k)
     assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
     assert index.last_fallbacks == nq and index.filtered_min_queries == 0

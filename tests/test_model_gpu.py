@@ -267,6 +267,9 @@ def test_inference_backbone_with_folded_batchnorm_equals_separate_batchnorm(dtyp
     with torch.no_grad():
         rt.fold_bn = True
         a = bb(img.cuda(), rt).float()
+        rt.infer_chunk = 2                      # (RALF_INFER_CHUNK: the batch of 3 in slices of 2 + 1 images -- the same bits)
+        assert torch.equal(bb(img.cuda(), rt).float(), a)
+        rt.infer_chunk = 0
         rt.fold_bn = False
         b = bb(img.cuda(), rt).float()
     if dtype == "float32":
