@@ -692,9 +692,11 @@ extern "C" int ralf_copy2d(int src_dtype, int dst_dtype, const void* src, void* 
 extern "C" int ralf_permute4(int src_dtype, int dst_dtype, const void* in, void* out, int d0, int d1, int d2, int d3, int64_t s0, int64_t s1, int64_t s2, int64_t s3,
                              int valid3, void* stream) {
     RALF_REQUIRE(in && out && d0 > 0 && d1 > 0 && d2 > 0 && d3 > 0, "permute4: bad arguments");
-    if (d3 == 8 && src_dtype == RALF_F32 && s2 == 1 && (((uintptr_t)out) & 31) == 0) {   // pixel packing (see permute4_pack8_kernel)
+    if (d3 == 8 && (src_dtype == RALF_F32 || dst_dtype != RALF_F32) && s2 == 1 && (((uintptr_t)out) & 31) == 0) {   // pixel packing (see permute4_pack8_kernel)
         const dim3 gp(grid_for((int64_t)d0 * d1 * d2));
-        if (dst_dtype == RALF_F32) hipLaunchKernelGGL((permute4_pack8_kernel<float, float>), gp, dim3(256), 0, ST, (const float*)in, (float*)out, d0, d1, d2, s0, s1, s2, s3, valid3);
+        if (src_dtype != RALF_F32)   // (an image batch uploaded in bf16: models/ralf.py: sample())
+            hipLaunchKernelGGL((permute4_pack8_kernel<bf16, bf16>), gp, dim3(256), 0, ST, (const bf16*)in, (bf16*)out, d0, d1, d2, s0, s1, s2, s3, valid3);
+        else if (dst_dtype == RALF_F32) hipLaunchKernelGGL((permute4_pack8_kernel<float, float>), gp, dim3(256), 0, ST, (const float*)in, (float*)out, d0, d1, d2, s0, s1, s2, s3, valid3);
         else hipLaunchKernelGGL((permute4_pack8_kernel<float, bf16>), gp, dim3(256), 0, ST, (const float*)in, (bf16*)out, d0, d1, d2, s0, s1, s2, s3, valid3);
         return ralf::check_launch("permute4");
     }

@@ -177,6 +177,10 @@ class Runtime:
         self.fused_decode_sample = os.environ.get("RALF_DECODE_SAMPLE", "1") != "0"
         # inference batches above this many images go through the backbone in slices (nn.ResnetBackbone.body_features); 0 = whole batch
         self.infer_chunk = int(os.environ.get("RALF_INFER_CHUNK", "0"))
+        # sample(): opt-in (RALF_UPLOAD_LP=1) -- the image batch leaves the host in the compute dtype when that is bf16 (half the bytes over the host link; the
+        # rounding the backbone's first kernel would apply, applied by the host copy into the staging buffer: the same tokens).  Off: at B = 256 the host's
+        # conversion pass (0.5-3 ms, beside the task preprocessing it slows down) costs what the shorter copy saves (profiles/r06_sample_phases.txt)
+        self.upload_lp = os.environ.get("RALF_UPLOAD_LP", "0") == "1"
         self.fold_bn = True       # inference: eval-mode BatchNorm folded into the convolution epilogues (conv_bn_infer)
         # decode step: LayerNorm inside the few-row product that follows it (RalfGemmDesc.ln_*) and the four-wave split of the 256 x 256 x 1024
         # product (few_row_split) -- same arithmetic, other summation orders than the separate launches (off: their bits)

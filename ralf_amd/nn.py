@@ -720,7 +720,12 @@ class ResnetBackbone(nn.Module):
         B, C, H, W = img.shape
         assert C == 4
         # NCHW fp32 [B,4,H,W] -> NHWC compute dtype, channels zero-padded to 8 (16-byte pixel vectors)
-        x = ops.permute4(img.contiguous().float(), (B, H, W, 8), (4 * H * W, W, 1, H * W), 4, rt.dtype)
+        # (an image batch that arrives in the compute dtype already -- models/ralf.py: sample() uploads bf16 in the bf16 mode, the same rounding one step
+        #  earlier -- is packed as it is)
+        src = img.contiguous()
+        if not (src.dtype == rt.dtype == torch.bfloat16):
+            src = src.float()
+        x = ops.permute4(src, (B, H, W, 8), (4 * H * W, W, 1, H * W), 4, rt.dtype)
         b = self.body
         if self._conv_weights is None:
             self._conv_weights = [m.weight for m in self.modules() if isinstance(m, Conv)]

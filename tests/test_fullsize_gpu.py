@@ -235,7 +235,9 @@ def test_b64_gradients_bf16_against_fp32_on_trained_weights_with_the_autocast_ya
         else:
             assert ch > 0.999 and ch > cy - 2e-4 and abs(rh - 1) < 0.06, (k, ch, cy, rh)
     med = lambda v: sorted(v)[len(v) // 2]
-    assert med(body_h) > med(body_y) - 0.08 and med(body_h) > 0.15, (sorted(body_h), sorted(body_y))
+    # (the medians of five noisy cosines are noisy themselves: 0.21 ... 0.28 for the HIP path over six runs of one build (profiles/r06_yardstick_run_to_run.txt),
+    #  0.21 ... 0.33 for the yardstick; one run in ~ten put them 0.09 apart -- 0.2399 against 0.3323 -- with bit-identical kernels)
+    assert med(body_h) > med(body_y) - 0.18 and med(body_h) > 0.15, (sorted(body_h), sorted(body_y))
 
 
 def test_patch_form_convolutions_leave_the_captured_step_bit_identical(tmp_path):
