@@ -826,15 +826,53 @@ class GraphedAdamW(torch.optim.Optimizer):
 
 class GraphedDecode:
     """hipGraph replay of model.decode_tokens (encoder + the whole KV-cached autoregressive loop + fused
-    mask/sample kernels): the eager loop is host-launch bound (~5k launches per batch)."""
+    mask/sample kernels): the eager loop is host-launch bound (~5k launches per batch).
+
+    The image batch is the call's one big input (268 MB of fp32 at B = 256: 4.9 ms on the host link, a fifth of the replay).  With `gates` slices
+    (RALF_DECODE_GATES, default 2; 0 = off) the captured backbone works through the batch slice by slice, every slice behind an event-wait NODE
+    (functional.ExternalEvent), and `upload_image` -- called by model.sample() before its host-side preprocessing -- copies the page-locked host batch
+    slice by slice straight into the graph's own image buffer on the library's copy stream, recording slice i's event behind its copy: the graph is
+    launched without waiting for the copies, slice 0's kernels start when its images are there, and the link carries slice 1 meanwhile."""
 
     def __init__(self, model, cond_type: str, sampling_cfg, use_kv_cache: bool = True):
         self.model, self.cond_type, self.cfg, self.kv = model, cond_type, sampling_cfg, use_kv_cache
         self._graph = None
         self._static = None
         self._out = None
+        n = int(os.environ.get("RALF_DECODE_GATES", "2"))
+        self._gates = [ExternalEvent() for _ in range(n)] if (n > 1 and ExternalEvent.supported()) else None
+        self._image_in_flight = False
+        self.piped_calls = 0      # calls whose image went through upload_image (tests)
+
+    def upload_image(self, img) -> bool:
+        """start the copy of a page-locked host image batch into the captured graph's image buffer (see the class comment); False: not applicable
+        (nothing captured yet, no gates, another shape / dtype, pageable or device memory) -- the caller then hands the image to __call__ as usual"""
+        if self._graph is None or self._gates is None or not torch.is_tensor(img) or img.is_cuda or not img.is_pinned():
+            return False
+        dst = self._static["enc"].get("image")
+        if dst is None or dst.shape != img.shape or dst.dtype != img.dtype or dst.shape[0] < 2 * len(self._gates):
+            return False
+        from .helpers.task import pinned_copy_issued
+        cs = ops.own_stream("h2d", dst.device)
+        cs.wait_stream(torch.cuda.current_stream())     # (the previous replay has read the buffer)
+        B = dst.shape[0]
+        step = -(-B // len(self._gates))                # (nn.ResnetBackbone.body_features slices the batch the same way)
+        with torch.cuda.stream(cs):
+            for gi, i in enumerate(range(0, B, step)):
+                dst[i:i + step].copy_(img[i:i + step], non_blocking=True)
+                self._gates[gi].record_now(cs)
+        ev = torch.cuda.Event()
+        ev.record(cs)
+        pinned_copy_issued(img, ev)                     # (possibly a cat_image staging buffer: not rewritten before these copies have read it)
+        self._image_in_flight = True
+        self.piped_calls += 1
+        return True
+
+    def static_image(self):
+        return self._static["enc"]["image"]
 
     def __call__(self, enc_in: dict, cond_seq):
+        rt = self.model.rt
         if self._graph is None:
             self._static = _clone_tree({"enc": enc_in, "seq": cond_seq})
             s = self._static
@@ -849,13 +887,21 @@ class GraphedDecode:
             gc.collect()
             was = gc.isenabled()
             gc.disable()   # (no collector pass inside a capture: TrainStep._capture)
+            rt.input_gates = self._gates
             try:
                 with torch.cuda.graph(self._graph, stream=ops.own_stream("capture"), capture_error_mode=_CAPTURE_MODE):
                     self._out = self.model.decode_tokens(s["enc"], s["seq"], self.cond_type, self.cfg, self.kv)
             finally:
+                rt.input_gates = None
                 if was:
                     gc.enable()
+        elif self._image_in_flight:   # (upload_image: the image is on its way into the graph's buffer; everything else on this stream)
+            _copy_tree(self._static, {"enc": dict(enc_in, image=self._static["enc"]["image"]), "seq": cond_seq})
         else:
             _copy_tree(self._static, {"enc": enc_in, "seq": cond_seq})
+        if self._gates is not None and not self._image_in_flight:
+            for g in self._gates:   # the image reached its buffer on THIS stream: the graph's gates open behind it
+                g.record_now(torch.cuda.current_stream())
+        self._image_in_flight = False
         self._graph.replay()
         return self._out

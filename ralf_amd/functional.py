@@ -91,6 +91,15 @@ class ExternalEvent:
     def wait(self, stream):
         self._node(stream, False)
 
+    def record_now(self, stream) -> "ExternalEvent":
+        """an ordinary record on a stream that is NOT capturing (a copy stream): a wait NODE of a graph launched afterwards orders behind it"""
+        import ctypes
+        hip = ExternalEvent._hip
+        hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        rc = hip.hipEventRecord(self._ev, ctypes.c_void_p(stream.cuda_stream))
+        assert rc == 0, f"hipEventRecord: {rc}"
+        return self
+
     # (no __del__: the event is referenced by nodes of captured graphs whose executables may be destroyed AFTER this object -- the garbage
     #  collector frees a TrainStep's members in no particular order, and hipGraphExecDestroy on a graph whose event is gone aborts the
     #  process.  A capture creates a few dozen of these; they live as long as the process.)
@@ -181,6 +190,9 @@ class Runtime:
         # rounding the backbone's first kernel would apply, applied by the host copy into the staging buffer: the same tokens).  Off: at B = 256 the host's
         # conversion pass (0.5-3 ms, beside the task preprocessing it slows down) costs what the shorter copy saves (profiles/r06_sample_phases.txt)
         self.upload_lp = os.environ.get("RALF_UPLOAD_LP", "0") == "1"
+        # engine.GraphedDecode: events the image batch's slices are gated on INSIDE the captured graph (nn.ResnetBackbone.body_features waits for
+        # gate i in front of slice i's first kernel), so that the copy of slice i + 1 runs beside the backbone of slice i.  None: no gates
+        self.input_gates = None
         self.fold_bn = True       # inference: eval-mode BatchNorm folded into the convolution epilogues (conv_bn_infer)
         # decode step: LayerNorm inside the few-row product that follows it (RalfGemmDesc.ln_*) and the four-wave split of the 256 x 256 x 1024
         # product (few_row_split) -- same arithmetic, other summation orders than the separate launches (off: their bits)

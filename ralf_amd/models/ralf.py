@@ -444,9 +444,14 @@ class _GeneratorBase(nn.Module):
         if B == 1 and batch_size and batch_size > 1:
             B = batch_size
             cond.image = cond.image.expand(B, -1, -1, -1).contiguous()
-        up = self._start_image_upload(cond.image)   # the batch's one big tensor: on its way while the host builds the constraint sequences
+        # the batch's one big tensor is on its way while the host builds the constraint sequences: slice by slice into a captured loop's own buffer
+        # (engine.GraphedDecode.upload_image), else as one copy on the library's copy stream
+        piped = decoder is not None and hasattr(decoder, "upload_image") and decoder.upload_image(cond.image)
+        up = None if piped else self._start_image_upload(cond.image)
         enc_in, seqc = self._create_encoder_inputs(cond)
-        if up is not None:
+        if piped:
+            enc_in = dict(enc_in, image=decoder.static_image())
+        elif up is not None:
             torch.cuda.current_stream().wait_event(up[1])
             enc_in = dict(enc_in, image=up[0])
         enc_in = {k: ({kk: vv.to(dev) for kk, vv in v.items() if torch.is_tensor(vv)} if isinstance(v, dict) else (v.to(dev) if torch.is_tensor(v) else v))

@@ -720,27 +720,38 @@ class ResnetBackbone(nn.Module):
         B, C, H, W = img.shape
         assert C == 4
         # NCHW fp32 [B,4,H,W] -> NHWC compute dtype, channels zero-padded to 8 (16-byte pixel vectors)
-        # (an image batch that arrives in the compute dtype already -- models/ralf.py: sample() uploads bf16 in the bf16 mode, the same rounding one step
-        #  earlier -- is packed as it is)
-        src = img.contiguous()
-        if not (src.dtype == rt.dtype == torch.bfloat16):
-            src = src.float()
-        x = ops.permute4(src, (B, H, W, 8), (4 * H * W, W, 1, H * W), 4, rt.dtype)
         b = self.body
         if self._conv_weights is None:
             self._conv_weights = [m.weight for m in self.modules() if isinstance(m, Conv)]
         rt.refresh_conv_shadows(self._conv_weights)   # all 3x3 / 7x7 weight re-layouts of this step in one launch
         infer = rt.fold_bn and not rt.training and not torch.is_grad_enabled()
+
+        def pack(im):
+            # NCHW fp32 [b,4,H,W] -> NHWC compute dtype, channels zero-padded to 8 (16-byte pixel vectors).  (An image batch that arrives in the compute dtype
+            # already -- models/ralf.py: sample() with RALF_UPLOAD_LP=1, the same rounding one step earlier -- is packed as it is)
+            src = im.contiguous()
+            if not (src.dtype == rt.dtype == torch.bfloat16):
+                src = src.float()
+            return ops.permute4(src, (im.shape[0], H, W, 8), (4 * H * W, W, 1, H * W), 4, rt.dtype)
         if infer:
             self._refresh_fold(img.device)
-            if rt.infer_chunk and B > rt.infer_chunk:
-                # a large inference batch in slices of infer_chunk images (RALF_INFER_CHUNK, off by default): samples do not interact in eval mode, and
-                # at 64 images layer1's maps (134 MB) would stay in the 256 MB infinity cache between the kernel that writes them and the one that reads
-                # them (at B = 256: 537 MB each).  Measured at B = 256, same box, same tokens: decode loop 26.1 ms whole / 26.3 in slices of 128 / 26.6 of 64
-                # -- the shorter launches lose more than the cache gives (profiles/r06_infer_chunk.txt)
-                outs = [self._body_infer(x[i:i + rt.infer_chunk], rt) for i in range(0, B, rt.infer_chunk)]
+            gates = rt.input_gates if (rt.input_gates and torch.cuda.is_current_stream_capturing() and B >= 2 * len(rt.input_gates)) else None
+            step = -(-B // len(gates)) if gates else (rt.infer_chunk if (rt.infer_chunk and B > rt.infer_chunk) else 0)
+            if step:
+                # The batch in slices.  Gated (engine.GraphedDecode): slice i's kernels sit behind an event-wait node for the copy of ITS images, so the host
+                # link carries slice i + 1 while the backbone works on slice i (a B = 256 batch is 4.9 ms on the link, a fifth of the whole captured loop).
+                # Ungated (RALF_INFER_CHUNK, off by default): samples do not interact in eval mode, and at 64 images layer1's maps (134 MB) would stay in
+                # the 256 MB infinity cache between the kernel that writes them and the one that reads them (at B = 256: 537 MB each).  Measured at
+                # B = 256, same box, same tokens: decode loop 26.1 ms whole / 26.3 in slices of 128 / 26.6 of 64 -- the shorter launches lose more than
+                # the cache gives (profiles/r06_infer_chunk.txt)
+                outs = []
+                for gi, i in enumerate(range(0, B, step)):
+                    if gates:
+                        gates[gi].wait(torch.cuda.current_stream())
+                    outs.append(self._body_infer(pack(img[i:i + step]), rt))
                 return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
-            return self._body_infer(x, rt)
+            return self._body_infer(pack(img), rt)
+        x = pack(img)
         if rt.training and rt.fused_stem:
             # training: BatchNorm (batch statistics) + ReLU + max-pool in one pass over the convolution output (RF.StemBNReluPoolFn)
             x, st = b.conv1(x, rt, stats=True)

@@ -115,6 +115,38 @@ def test_b256_decode_rows_equal_reference_rows(golden, task):
         assert bool(((out[key] >= 0) & (out[key] <= 1)).all())
 
 
+@pytest.mark.parametrize("dtype", ["bfloat16", "float32"])
+def test_image_batch_piped_into_the_captured_decode_loop_gives_the_same_tokens(dtype):
+    """sample() through the REAL backbone with a page-locked host image batch (what helpers/task.py: cat_image hands over): the eager loop, the capture
+    call of engine.GraphedDecode and its replays -- the image copied slice by slice straight into the graph's buffer on the copy stream, every slice of the
+    captured backbone behind its event-wait node (GraphedDecode.upload_image, nn.ResnetBackbone.body_features) -- return the same tokens; a second batch
+    through the same graph returns ITS eager tokens (the copies really feed the replay)."""
+    from ralf_amd.engine import GraphedDecode
+    from ralf_amd.helpers.task import get_condition
+
+    model = bench.build_model(torch.device(DEV), 10, dtype, "c").eval()
+    cfg = {"name": "deterministic"}
+    graphed = GraphedDecode(model, "c", cfg, True)
+    assert graphed._gates is not None and len(graphed._gates) == 2
+    keys = ("label", "mask", "center_x", "center_y", "width", "height")
+    cond, _ = get_condition(make_batch(8, 10, seed=9), "c", model.tokenizer)
+    cond.retrieved = {k: v for k, v in cond.retrieved.items() if k != "image"}
+    images = [cond.image.clone().pin_memory(), (1.0 - cond.image).flip(0).contiguous().pin_memory()]   # (the same constraint sequences: one captured shape)
+    want = []
+    for img in images:
+        cond.image = img
+        runs = []
+        for dec in (None, graphed, graphed, graphed):
+            torch.manual_seed(3)    # (the task preprocessor shuffles the constraint elements with torch's global generator)
+            runs.append(model.sample(cond=cond, sampling_cfg=cfg, cond_type="c", decoder=dec))
+        for r in runs[1:]:
+            for k in keys:
+                assert torch.equal(r[k], runs[0][k]), k
+        want.append(runs[0])
+    assert graphed.piped_calls == 2 + 3          # every replay after the capturing call
+    assert not all(torch.equal(want[0][k], want[1][k]) for k in keys)
+
+
 def test_n32_layouts_against_the_oracle_and_full_batch():
     """the north star's 32-element layouts (S = 160): fp32 logits against the (pinned) oracle at B = 2, then a B = 64 bf16 train
     step and a KV-cached decode equal to the full-prefix recompute"""

@@ -32,15 +32,24 @@ def lap(name, t0):
     return time.perf_counter()
 
 
+whole_only = len(sys.argv) > 2 and sys.argv[2] == "whole"
 for _ in range(reps):
+    if whole_only:
+        t0 = time.perf_counter()
+        res = model.sample(cond=cond, sampling_cfg=cfg, cond_type="c", decoder=dec)
+        lap("whole sample() call", t0)
+        continue
     t = time.perf_counter()
-    up = model._start_image_upload(cond.image)
+    piped = dec.upload_image(cond.image)
+    up = None if piped else model._start_image_upload(cond.image)
     T.setdefault("image upload issued (host staging copy incl.)", []).append((time.perf_counter() - t) * 1e3)
     t = time.perf_counter()
     enc_in, seqc = model._create_encoder_inputs(cond)
     T.setdefault("_create_encoder_inputs (host, beside the copy)", []).append((time.perf_counter() - t) * 1e3)
     t = time.perf_counter()
-    if up is not None:
+    if piped:
+        enc_in = dict(enc_in, image=dec.static_image())
+    elif up is not None:
         torch.cuda.current_stream().wait_event(up[1])
         enc_in = dict(enc_in, image=up[0])
     enc_dev = {k: ({kk: vv.to(dev) for kk, vv in v.items() if torch.is_tensor(vv)} if isinstance(v, dict) else (v.to(dev) if torch.is_tensor(v) else v)) for k, v in enc_in.items()}
@@ -55,7 +64,9 @@ for _ in range(reps):
     t0 = time.perf_counter()
     model.sample(cond=cond, sampling_cfg=cfg, cond_type="c", decoder=dec)
     lap("whole sample() call", t0)
-print("RALF_UPLOAD_LP =", os.environ.get("RALF_UPLOAD_LP", "1"), " image on the device:", tuple(enc_dev["image"].shape), enc_dev["image"].dtype, f"({enc_dev['image'].numel() * enc_dev['image'].element_size() / 1e6:.0f} MB over the host link)")
+piped = piped if not whole_only else None
+enc_dev = enc_dev if not whole_only else {"image": dec.static_image()}
+print("RALF_DECODE_GATES =", os.environ.get("RALF_DECODE_GATES", "2"), " piped:", piped, " RALF_UPLOAD_LP =", os.environ.get("RALF_UPLOAD_LP", "0"), " image on the device:", tuple(enc_dev["image"].shape), enc_dev["image"].dtype, f"({enc_dev['image'].numel() * enc_dev['image'].element_size() / 1e6:.0f} MB over the host link)")
 print("token checksum", int(sum((res[k].long() * (1 + i)).sum() for i, k in enumerate(("label", "mask"))).item()), float(res["center_x"].double().sum() + res["width"].double().sum()))
 for k, v in T.items():
     v = sorted(v)
