@@ -67,6 +67,7 @@ for _ in range(reps):
 piped = piped if not whole_only else None
 enc_dev = enc_dev if not whole_only else {"image": dec.static_image()}
 print("RALF_DECODE_GATES =", os.environ.get("RALF_DECODE_GATES", "2"), " piped:", piped, " RALF_UPLOAD_LP =", os.environ.get("RALF_UPLOAD_LP", "0"), " image on the device:", tuple(enc_dev["image"].shape), enc_dev["image"].dtype, f"({enc_dev['image'].numel() * enc_dev['image'].element_size() / 1e6:.0f} MB over the host link)")
+print("copy stream picked:", dec._cs_pick, {k: [round(x, 2) for x in v] for k, v in dec._cs_ms.items()})
 print("token checksum", int(sum((res[k].long() * (1 + i)).sum() for i, k in enumerate(("label", "mask"))).item()), float(res["center_x"].double().sum() + res["width"].double().sum()))
 for k, v in T.items():
     v = sorted(v)
