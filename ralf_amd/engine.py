@@ -860,7 +860,7 @@ class GraphedDecode:
         if self._cs_probe is not None:                  # the previous piped call was a timed one (it has long finished: sample() reads the tokens back)
             i, e0, e1 = self._cs_probe
             self._cs_probe = None
-            if e1.query():
+            if e1 is not None and e1.query():
                 self._cs_ms.setdefault(i, []).append(e0.elapsed_time(e1))
         which = self._cs_pick
         if which is None:
