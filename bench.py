@@ -192,7 +192,7 @@ def bench_knn(device):
     return {"index": f"{N}x{D} fp32", "k": k, **out}
 
 
-def bench_decode(device, N=10, B=256, dtype="bfloat16", reps=3):
+def bench_decode(device, N=10, B=256, dtype="bfloat16", reps=5):
     """constrained inference (BASELINE configs[4]): B = 256 autoregressive decode, tasks c -> s+p and cwh -> p, deterministic
     (argmax) and top-k 5 sampling; ms per sample as image2layout/train/inference.py:494-495 reports it (whole sample() call from
     host tensors: encoder + 5N KV-cached decoder steps captured in one hipGraph + token decode on the host)."""
@@ -212,7 +212,7 @@ def bench_decode(device, N=10, B=256, dtype="bfloat16", reps=3):
         cond.retrieved = {k: v for k, v in cond.retrieved.items() if k != "image"}
         for name, cfg in (("deterministic", {"name": "deterministic"}), ("top_k5", {"name": "top_k", "top_k": 5, "temperature": 1.0}))[:2 if dtype.startswith("b") else 1]:
             dec = GraphedDecode(model, task, cfg, True)
-            for _ in range(2):
+            for _ in range(6):   # the capturing call + the decoder's four timed calls on its two candidate copy streams (engine.GraphedDecode.upload_image)
                 res = model.sample(cond=cond, sampling_cfg=cfg, cond_type=task, decoder=dec)
             torch.cuda.synchronize()
             t0 = time.perf_counter()

@@ -17,5 +17,5 @@ cp $O/knn_microbench.txt profiles/${R}_knn_microbench.txt
 cp $O/${R}_hbm_traffic.json profiles/${R}_hbm_traffic.json
 cp $O/train_step_hbm_traffic_pmc.txt profiles/${R}_train_step_hbm_traffic_pmc.txt
 cp $O/knn_pmc.txt profiles/${R}_knn_pmc.txt
-for f in loop_phases_lag1 loop_phases_lag0 at_bench knn_two_stage_stages knn_filtered_ab h2d_probe; do [ -f $O/$f.txt ] && grep -v "amdgpu.ids" $O/$f.txt > profiles/${R}_$f.txt; done
+for f in loop_phases_lag1 loop_phases_lag0 at_bench knn_two_stage_stages knn_filtered_ab h2d_probe sample_whole; do [ -f $O/$f.txt ] && grep -v "amdgpu.ids" $O/$f.txt > profiles/${R}_$f.txt; done
 ls -la profiles | grep $R

@@ -63,3 +63,4 @@ timeout 300 python3 tools/at_bench.py > $O/at_bench.txt 2>&1
 timeout 300 python3 tools/knn_two_stage_probe.py > $O/knn_two_stage_stages.txt 2>&1
 timeout 300 python3 tools/knn_filtered_ab.py 512 640 1024 2048 2>&1 | grep 'nq =' > $O/knn_filtered_ab.txt
 timeout 100 python3 tools/h2d_probe.py > $O/h2d_probe.txt 2>&1
+timeout 300 python3 tools/sample_phases.py 15 whole 2>&1 | grep -E 'GATES|picked|whole' > $O/sample_whole.txt; RALF_DECODE_GATES=0 timeout 300 python3 tools/sample_phases.py 15 whole 2>&1 | grep -E 'GATES|whole' >> $O/sample_whole.txt
