@@ -807,7 +807,9 @@ static int select_impl(const float* S, int64_t N, int nq, int k, int64_t* out_id
 // its own output allocations): ~80 us of host time on top of ~200 us of kernels at nq = 64.  Here the launches go out back to back from C into one
 // caller-provided workspace; the caller reads `bad` (one flag per query) and sends the uncertified queries through ralf_knn_topk_ip.
 namespace {
-constexpr int FLT_SAMPLE_ROWS = 4096;   // rows of the index the threshold pass ranks (expected list length: (pool + 1) * N / this)
+// rows of the index the threshold pass ranks (expected list length: (pool + 1) * N / this).  RALF_KNN_FLT_SAMPLE: tuning aid -- at BASELINE config 4, 1024 queries:
+// 2048 / 3072 / 4096 / 8192 rows = 431 / 431 / 435 / 446 us whole call (fewer rows: cheaper threshold pass, longer lists)
+inline int64_t flt_sample_rows() { static const int64_t v = [] { const char* e = getenv("RALF_KNN_FLT_SAMPLE"); return e ? (int64_t)atoi(e) : (int64_t)4096; }(); return v > 0 ? v : 4096; }
 // candidate slots per (query, column tile of the index) = tile / 8 (16 per 128 columns): ~2 hits expected per 128 columns, P(> slots) ~ 1e-10 on unordered data
 inline int flt_capsh(int tile) { return tile >= 256 ? 5 : tile >= 128 ? 4 : 3; }
 struct TwoStagePlan { size_t qb, qn, coarse, cval, cidx, exact, sel, over, total;
@@ -825,7 +827,7 @@ TwoStagePlan plan_two_stage(int64_t N, int D, int nq, int pool) {
     p.qb = take((size_t)nq * D * 2);
     p.qn = take((size_t)nq * 3 * sizeof(float));
     // the score matrix of the dense coarse pass, or (filtered pass) the sample's scores, its selection, the tile counters and the candidate slots
-    p.f_ns = N < FLT_SAMPLE_ROWS ? N : FLT_SAMPLE_ROWS;
+    p.f_ns = N < flt_sample_rows() ? N : flt_sample_rows();
     p.f_tile = filter_tile(N, D, nq);
     p.f_T = p.f_tile > 0 ? (N + p.f_tile - 1) / p.f_tile : 0;
     p.f_capsh = flt_capsh(p.f_tile);
