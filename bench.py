@@ -201,7 +201,8 @@ def bench_decode(device, N=10, B=256, dtype="bfloat16", reps=5):
     from ralf_amd.synthetic import make_batch
 
     out = {"batch": B, "tokens_per_sample": 5 * N,
-           "note": "sample() incl. H2D of the image batch and host-side token decoding; graph_ms = the captured device loop alone; hbm_frac = the "
+           "note": "sample() incl. H2D of the image batch (page-locked, piped slice by slice into the captured loop: engine.GraphedDecode.upload_image) and host-side "
+                   "token decoding; graph_ms = the captured device loop alone; hbm_frac = the "
                    "loop's unavoidable stream (the cross-attention K/V cache of 6 layers, read once per generated token) / graph_ms / 8 TB/s: the "
                    "whole-loop lower bound on the memory side (the cross-attention kernel itself runs at 0.70 of peak: tools/decode_attn_bench.py, profiles/*_decode_kernel_stats.txt)"}
     out["mode"] = ("bf16 throughput mode: labels identical to the fp32 mode, >= 90 % of the geometry tokens (tests/test_configs_gpu.py); the north star's "
