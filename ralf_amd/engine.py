@@ -876,11 +876,10 @@ class GraphedDecode:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record(cs)
             self._cs_probe = [which, e0, None]
-        B = dst.shape[0]
-        step = -(-B // len(self._gates))                # (nn.ResnetBackbone.body_features slices the batch the same way)
+        bounds = self.model.rt.input_bounds(dst.shape[0], len(self._gates))   # (nn.ResnetBackbone.body_features slices the batch the same way)
         with torch.cuda.stream(cs):
-            for gi, i in enumerate(range(0, B, step)):
-                dst[i:i + step].copy_(img[i:i + step], non_blocking=True)
+            for gi in range(len(bounds) - 1):
+                dst[bounds[gi]:bounds[gi + 1]].copy_(img[bounds[gi]:bounds[gi + 1]], non_blocking=True)
                 self._gates[gi].record_now(cs)
         ev = torch.cuda.Event()
         ev.record(cs)

@@ -736,8 +736,9 @@ class ResnetBackbone(nn.Module):
         if infer:
             self._refresh_fold(img.device)
             gates = rt.input_gates if (rt.input_gates and torch.cuda.is_current_stream_capturing() and B >= 2 * len(rt.input_gates)) else None
-            step = -(-B // len(gates)) if gates else (rt.infer_chunk if (rt.infer_chunk and B > rt.infer_chunk) else 0)
-            if step:
+            step = rt.infer_chunk if (rt.infer_chunk and B > rt.infer_chunk) else 0
+            bounds = rt.input_bounds(B, len(gates)) if gates else (list(range(0, B, step)) + [B] if step else None)
+            if bounds:
                 # The batch in slices.  Gated (engine.GraphedDecode): slice i's kernels sit behind an event-wait node for the copy of ITS images, so the host
                 # link carries slice i + 1 while the backbone works on slice i (a B = 256 batch is 4.9 ms on the link, a fifth of the whole captured loop).
                 # Ungated (RALF_INFER_CHUNK, off by default): samples do not interact in eval mode, and at 64 images layer1's maps (134 MB) would stay in
@@ -745,10 +746,10 @@ class ResnetBackbone(nn.Module):
                 # B = 256, same box, same tokens: decode loop 26.1 ms whole / 26.3 in slices of 128 / 26.6 of 64 -- the shorter launches lose more than
                 # the cache gives (profiles/r06_infer_chunk.txt)
                 outs = []
-                for gi, i in enumerate(range(0, B, step)):
+                for gi in range(len(bounds) - 1):
                     if gates:
                         gates[gi].wait(torch.cuda.current_stream())
-                    outs.append(self._body_infer(pack(img[i:i + step]), rt))
+                    outs.append(self._body_infer(pack(img[bounds[gi]:bounds[gi + 1]]), rt))
                 return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
             return self._body_infer(pack(img), rt)
         x = pack(img)
