@@ -216,6 +216,7 @@ class FlatIPIndex:
         # from this many queries the coarse pass thresholds its scores instead of writing them (0 = never).  Switched off for good by the first batch
         # that floods tiles (more than 1 in 16 queries not certified: an index ordered by similarity), so such an index pays the fallback once.
         self.filtered_min_queries = int(os.environ.get("RALF_KNN_FILTERED_MIN", filtered_min_queries))
+        self.max_queries_per_call = 16384
         self.last_fallbacks = 0
 
     @property
@@ -230,6 +231,16 @@ class FlatIPIndex:
         q = torch.as_tensor(queries, dtype=torch.float32).to(self.vectors.device)
         if q.dim() == 1:
             q = q[None]
+        if q.shape[0] > self.max_queries_per_call:
+            # a whole split as one query set (retriever.py: table building hands over every sample of the split): in blocks -- the search's workspace grows
+            # with the batch (score matrix or slot lists: 4 GB per 16 384 queries at BASELINE config 4's index) and its launches take the query count as a
+            # grid dimension (<= 65 535); per-query results do not depend on the batch they travel in
+            outs, fallbacks = [], 0
+            for i in range(0, q.shape[0], self.max_queries_per_call):
+                outs.append(self.search(q[i:i + self.max_queries_per_call], k))
+                fallbacks += self.last_fallbacks
+            self.last_fallbacks = fallbacks
+            return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
         # Batches of >= two_stage_min_queries queries take the two-stage search (identical results).  The exhaustive fp32 scan streams the index
         # once at ~0.7 of the HBM rate up to 16 queries per pass (92 us at BASELINE config 4's index) and is bound by the fp32 matrix rate
         # beyond: 108 / 179 / 304 us at nq = 32 / 64 / 128 against ~100-120 for the two-stage search (profiles/r06_knn_route_sweep.txt).
@@ -243,6 +254,7 @@ class FlatIPIndex:
             if flt and self.last_fallbacks * 16 > q.shape[0]:
                 self.filtered_min_queries = 0
             return val, idx
+        self.last_fallbacks = 0
         need = _lib.lib().ralf_knn_topk_ip_workspace_bytes(self.ntotal, self.d, q.shape[0], k)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.vectors.device)

@@ -171,6 +171,9 @@ def test_two_stage_search_equals_exhaustive(N, D, nq, k):
     index = FlatIPIndex(X)                      # the index front end picks the two-stage path for large batches
     v2, i2 = index.search(Q, k)
     assert torch.equal(i2, i_ref) and torch.equal(v2, v_ref)
+    index.max_queries_per_call = 96             # ... and a query set larger than one call takes travels in blocks (the last one ragged): the same table
+    v3, i3 = index.search(Q, k)
+    assert torch.equal(i3, i_ref) and torch.equal(v3, v_ref)
 
 
 @pytest.mark.parametrize("filtered", [True, False])
